@@ -1,0 +1,275 @@
+/*
+ * grafimo_oracle.c -- CPU restatement of GRAFIMO's k-mer scoring hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under grafimo_amd/ may include, link,
+ * import or execute this file; it is the checker for tests/, for
+ * __graft_entry__.smoke() and for bench.py's `cpu_baseline` leg.
+ *
+ * Parity status: PINNED.  Checked (tests/test_oracle.py) against
+ *   - the reference's own golden vectors (tests/golden/ref_data/: the 4x19
+ *     integer score matrices and the 704-row scoring_results.tsv), and
+ *   - vectors captured by importing the reference in the build container
+ *     (tests/golden/ *.json, pmf.npz; generator: tests/golden/make_golden.py).
+ *
+ * Every function cites the reference lines it follows
+ * (paths relative to /root/reference/src/grafimo/).
+ *
+ * Plain C99, no dependencies beyond libm.  Scalar and single-threaded on
+ * purpose: it mirrors the reference's per-k-mer arithmetic, including the
+ * two O(1000*W) sums per k-mer (score_sequences.py:390-391).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_RANGE 1000            /* utils.py:26 */
+#define ORC_LOG_FACTOR 1.44269504 /* utils.py:25 (truncated 1/ln 2, used verbatim) */
+
+/* ---- compute_log_odds : motif_processing.pyx:444-507 + utils.lg2 (utils.py:479-493)
+ * probs, out: row-major [4][W] rows A,C,G,T.  returns 0, or -1 if an assert of
+ * the reference would fire (bg<=0, p<=0, sums off by >= 1e-3). */
+int orc_compute_log_odds(const double *probs, int W, const double *bg, double *out)
+{
+    double totBG = 0.0, totFG = 0.0;
+    for (int n = 0; n < 4; ++n) {
+        if (!(bg[n] > 0)) return -1;
+        totBG += bg[n];
+        for (int j = 0; j < W; ++j) {
+            double p = probs[n * W + j];
+            if (!(p > 0)) return -1;
+            totFG += p;
+            double odds = p / bg[n];
+            out[n * W + j] = log(odds) * ORC_LOG_FACTOR;
+        }
+    }
+    if (!(totBG - 1.0 < 0.001)) return -1;
+    if (!(totFG - (double)W < 0.001)) return -1;
+    return 0;
+}
+
+/* ---- scale_pwm : motif_ops.py:1090-1111
+ * np.round is round-half-to-even == rint() in the default rounding mode. */
+int orc_scale_pwm(const double *lo, int W, int64_t *sm, int *min_val, int *max_val,
+                  int *scale, double *offset)
+{
+    double lower = lo[0], upper = lo[0];
+    for (int i = 1; i < 4 * W; ++i) {
+        if (lo[i] < lower) lower = lo[i];
+        if (lo[i] > upper) upper = lo[i];
+    }
+    if (lower == upper) lower = upper - 1.0;
+    lower = floor(lower);
+    double off = rint(floor(lower));
+    double scale_factor = floor((double)ORC_RANGE / (upper - lower));
+    int64_t mn = 0, mx = 0;
+    for (int i = 0; i < 4 * W; ++i) {
+        double v = rint((lo[i] - off) * scale_factor);
+        sm[i] = (int64_t)v;
+        if (i == 0 || sm[i] < mn) mn = sm[i];
+        if (i == 0 || sm[i] > mx) mx = sm[i];
+    }
+    *min_val = (int)mn;
+    *max_val = (int)mx;
+    *scale = (int)scale_factor;
+    *offset = off;
+    return 0;
+}
+
+/* ---- comp_pval_mat : motif_processing.pyx:552-603 (Staden 1994 DP)
+ * Same loop nest as the reference: pos, then nucleotide in alphabet order
+ * (A,C,G,T), then ascending source index over the support (prev > 0);
+ * scatter `cur[sm + idx] += prev[idx] * bg` with the product rounded before
+ * the add (no FMA: compile with -ffp-contract=off).  out: pmf[1000*W+1]
+ * (last DP row, un-normalised). */
+int orc_comp_pval_mat(const int64_t *sm, int W, const double *bg, double *out)
+{
+    const int L = ORC_RANGE * W + 1;
+    double *mat = (double *)calloc((size_t)W * L, sizeof(double));
+    if (!mat) return -2;
+    for (int pos = 0; pos < W; ++pos) {
+        double *cur = mat + (size_t)pos * L;
+        const double *prev = pos ? mat + (size_t)(pos - 1) * L : NULL;
+        for (int n = 0; n < 4; ++n) {
+            if (!(bg[n] > 0)) { free(mat); return -1; }
+            int64_t s = sm[n * W + pos];
+            if (pos == 0) {
+                if (s < 0 || s >= L) { free(mat); return -3; }
+                cur[s] += 1.0 * bg[n];
+            } else {
+                for (int idx = 0; idx < L; ++idx) {
+                    if (prev[idx] > 0) {
+                        int64_t t = s + idx;
+                        if (t < 0 || t >= L) { free(mat); return -3; }
+                        volatile double prod = prev[idx] * bg[n];
+                        cur[t] += prod;
+                    }
+                }
+            }
+        }
+    }
+    memcpy(out, mat + (size_t)(W - 1) * L, (size_t)L * sizeof(double));
+    free(mat);
+    return 0;
+}
+
+/* ---- numpy's pairwise summation of a contiguous f64 vector (what
+ * `pval_mat.sum()` / `pval_mat[score:].sum()` evaluate to when the reference
+ * runs un-jitted; numpy/_core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum).
+ * Restated from the published algorithm: <8 sequential; <=128 eight
+ * accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a tail;
+ * else split at n/2 rounded down to a multiple of 8. */
+static double pairwise_sum(const double *a, long n)
+{
+    if (n < 8) {
+        double res = -0.0;
+        for (long i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        long i;
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        long n2 = n / 2;
+        n2 -= n2 % 8;
+        return pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2);
+    }
+}
+
+/* np.add.reduce walks a contiguous vector in blocks of the ufunc buffer size
+ * (8192 elements) and adds each block's pairwise sum to the running total
+ * (verified against numpy 2.2 in tests/test_oracle.py). */
+double orc_np_sum(const double *a, long n)
+{
+    double tot = 0.0;
+    for (long i = 0; i < n; i += 8192) {
+        long m = n - i < 8192 ? n - i : 8192;
+        tot += pairwise_sum(a + i, m);
+    }
+    return tot;
+}
+
+/* sequential left-to-right sum: what numba's nopython `arr.sum()` lowers to */
+double orc_seq_sum(const double *a, long n)
+{
+    double c = 0.0;
+    for (long i = 0; i < n; ++i) c += a[i];
+    return c;
+}
+
+/* ---- compute_score_seq : score_sequences.py:331-396
+ * seq: W ASCII bytes.  sum_mode 0 = numpy pairwise sums (un-jitted reference),
+ * 1 = sequential sums (numba).  Returns the integer scaled score; writes the
+ * log-odds score and the p-value.  Bytes other than ACGTacgtN are undefined
+ * behaviour in the reference (unassigned `nucidx`); the oracle flags them by
+ * returning INT32_MIN. */
+int32_t orc_compute_score_seq(const uint8_t *seq, const int64_t *sm, const double *pmf,
+                              int min_score, int scale, int W, double offset,
+                              int sum_mode, double *logodds, double *pvalue)
+{
+    const long L = (long)ORC_RANGE * W + 1;
+    int64_t score = 0;
+    for (int i = 0; i < W; ++i) {
+        uint8_t c = seq[i];
+        int nuc;
+        if (c == 'N') { score = min_score; break; }
+        switch (c) {
+            case 'A': case 'a': nuc = 0; break;
+            case 'C': case 'c': nuc = 1; break;
+            case 'G': case 'g': nuc = 2; break;
+            case 'T': case 't': nuc = 3; break;
+            default: return INT32_MIN;
+        }
+        score += sm[nuc * W + i];
+    }
+    double tot, tail;
+    if (sum_mode == 0) {
+        tot = orc_np_sum(pmf, L);
+        tail = orc_np_sum(pmf + score, L - score);
+    } else {
+        tot = orc_seq_sum(pmf, L);
+        tail = orc_seq_sum(pmf + score, L - score);
+    }
+    *pvalue = tail / tot;
+    *logodds = ((double)score / (double)scale) + ((double)W * offset);
+    return (int32_t)score;
+}
+
+/* batch form over a dense uint8 [N][W] k-mer matrix (the layout the HIP path
+ * consumes); this is also the loop bench.py times as the CPU baseline
+ * ("reference-faithful": two O(L) sums per k-mer). */
+int orc_score_kmers(const uint8_t *kmers, long N, const int64_t *sm, const double *pmf,
+                    int min_score, int scale, int W, double offset, int sum_mode,
+                    int32_t *scores, double *logodds, double *pvalues)
+{
+    for (long r = 0; r < N; ++r) {
+        double lo, pv;
+        int32_t s = orc_compute_score_seq(kmers + r * W, sm, pmf, min_score, scale, W,
+                                          offset, sum_mode, &lo, &pv);
+        if (s == INT32_MIN) return -1;
+        scores[r] = s;
+        if (logodds) logodds[r] = lo;
+        if (pvalues) pvalues[r] = pv;
+    }
+    return 0;
+}
+
+/* "table" variant: same integer scores, p-value by one lookup in a
+ * precomputed p_table (variant 2). */
+int orc_score_kmers_table(const uint8_t *kmers, long N, const int64_t *sm,
+                          const double *p_table, int min_score, int W,
+                          int32_t *scores, double *pvalues)
+{
+    for (long r = 0; r < N; ++r) {
+        const uint8_t *seq = kmers + r * W;
+        int64_t score = 0;
+        for (int i = 0; i < W; ++i) {
+            uint8_t c = seq[i];
+            int nuc;
+            if (c == 'N') { score = min_score; break; }
+            switch (c) {
+                case 'A': case 'a': nuc = 0; break;
+                case 'C': case 'c': nuc = 1; break;
+                case 'G': case 'g': nuc = 2; break;
+                case 'T': case 't': nuc = 3; break;
+                default: return -1;
+            }
+            score += sm[nuc * W + i];
+        }
+        scores[r] = (int32_t)score;
+        if (pvalues) pvalues[r] = p_table[score];
+    }
+    return 0;
+}
+
+/* ---- compute_qvalues : score_sequences.py:401-428 ->
+ * statsmodels.stats.multitest.multipletests(method="fdr_bh") (statsmodels >= 0.11,
+ * not vendored in the reference).  Published algorithm (fdrcorrection):
+ * sort ascending; raw_i = p_(i) / (i/n); q_(i) = min_{j>=i} raw_j; clip to 1. */
+typedef struct { double p; long i; } orc_pi;
+static int cmp_pi(const void *a, const void *b)
+{
+    double x = ((const orc_pi *)a)->p, y = ((const orc_pi *)b)->p;
+    return (x > y) - (x < y);
+}
+int orc_fdr_bh(const double *p, long n, double *q)
+{
+    orc_pi *v = (orc_pi *)malloc((size_t)n * sizeof(orc_pi));
+    if (!v) return -2;
+    for (long i = 0; i < n; ++i) { v[i].p = p[i]; v[i].i = i; }
+    qsort(v, (size_t)n, sizeof(orc_pi), cmp_pi);
+    double run = INFINITY;
+    for (long k = n - 1; k >= 0; --k) {
+        double ecdf = (double)(k + 1) / (double)n;
+        double raw = v[k].p / ecdf;
+        if (raw < run) run = raw;
+        q[v[k].i] = run > 1.0 ? 1.0 : run;
+    }
+    free(v);
+    return 0;
+}
