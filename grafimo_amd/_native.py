@@ -1,0 +1,119 @@
+"""ctypes binding of libgrafimo_hip.so (the C ABI declared in include/grafimo_hip.h).
+
+Loading the library does NOT initialise HIP (the reference forks worker processes,
+extract_regions.py:128 -- a parent that touched the GPU could not).  There is no CPU
+fallback: if the shared object is missing, or a call needs a GPU and none is present,
+the call fails loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgrafimo_hip.so")
+
+GFM_OK = 0
+GFM_ERR_INVALID = -1
+GFM_ERR_ASSERT = -2
+GFM_ERR_HIP = -3
+GFM_ERR_NOMEM = -4
+GFM_ERR_NODEVICE = -5
+GFM_ERR_IO = -6
+GFM_ERR_OVERFLOW = -7
+GFM_NO_SELECT = 2**31 - 1
+GFM_MAX_WIDTH = 64
+RANGE = 1000
+
+c_int = ctypes.c_int
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_u64 = ctypes.c_uint64
+c_double = ctypes.c_double
+c_void_p = ctypes.c_void_p
+P = ctypes.POINTER
+
+# every exported symbol of include/grafimo_hip.h: name -> (restype, argtypes)
+PROTOTYPES = {
+    "gfm_abi_version": (c_int, []),
+    "gfm_last_error": (ctypes.c_char_p, []),
+    "gfm_device_count": (c_int, [P(c_int)]),
+    "gfm_set_device": (c_int, [c_int]),
+    "gfm_compute_log_odds": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "gfm_scale_pwm": (c_int, [c_void_p, c_int, c_void_p, P(c_int), P(c_int), P(c_int), P(c_double)]),
+    "gfm_comp_pval_mat": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "gfm_motif_create": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_double, c_void_p, P(c_void_p)]),
+    "gfm_motif_destroy": (None, [c_void_p]),
+    "gfm_motif_width": (c_int, [c_void_p]),
+    "gfm_motif_table_len": (c_int, [c_void_p]),
+    "gfm_motif_score_range": (c_int, [c_void_p, P(c_i32), P(c_i32)]),
+    "gfm_motif_tables": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "gfm_motif_pvalue_cutoff": (c_int, [c_void_p, c_double, P(c_i32)]),
+    "gfm_motif_annotate": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "gfm_score_kmers": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_i64,
+                                c_void_p, c_i64, c_void_p, c_void_p]),
+    "gfm_qvalue_table": (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
+    "gfm_select_hits": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
+    "gfm_scan_host": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_int, c_i64, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_void_p, P(c_i64)]),
+    "gfm_tsv_open": (c_int, [P(ctypes.c_char_p), c_int, c_int, c_int, c_int, P(c_void_p), P(c_i64)]),
+    "gfm_tsv_read": (c_int, [c_void_p] * 9),
+    "gfm_tsv_name_count": (c_int, [c_void_p]),
+    "gfm_tsv_names_bytes": (c_i64, [c_void_p]),
+    "gfm_tsv_names": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "gfm_tsv_close": (None, [c_void_p]),
+}
+
+
+class NativeError(RuntimeError):
+    """A libgrafimo_hip call failed; .code holds the GFM_ERR_* value."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libgrafimo_hip error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it was not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with grafimo_amd/csrc/build.sh "
+                "(or python -c 'import __graft_entry__ as g; g.build()'). "
+                "grafimo_amd has no CPU fallback."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        if L.gfm_abi_version() != 1:
+            raise ImportError("libgrafimo_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != GFM_OK:
+        raise NativeError(rc, lib().gfm_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    """Address of a numpy array / int address / None."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return int(a)
+
+
+def device_count():
+    n = c_int(0)
+    check(lib().gfm_device_count(ctypes.byref(n)))
+    return n.value

@@ -1,0 +1,986 @@
+// grafimo_hip.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI for GRAFIMO's k-mer scoring path.
+//
+// Written for gfx950 only: 64-lane wavefronts, 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+// The hot op is an HBM-bound gather (W table lookups + W integer adds per k-mer,
+// < 1 op per byte): no MFMA.  See DESIGN.md for the roofline and the data layout.
+//
+// Reference lines cited as file:line are relative to /root/reference/src/grafimo/.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "grafimo_hip.h"
+
+#define GFM_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+constexpr int kRange = 1000;             // utils.py:26
+constexpr double kLogFactor = 1.44269504;  // utils.py:25 (truncated 1/ln2, verbatim)
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(GFM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// score kernel geometry
+constexpr int kWave = 64;
+constexpr int kThreads = 512;                  // 8 waves per workgroup
+constexpr int kWavesPerWG = kThreads / kWave;
+constexpr int kChunk = 128;                    // k-mers per wave per iteration (multiple of 64)
+constexpr unsigned kPoison = 0xFFFFu;          // table entry of a byte that is not A,C,G,T (> 1000*64)
+constexpr int kMaxLdsBytes = 160 * 1024;
+constexpr int kWGsPerCU = 3;                   // target residency of the score kernel
+
+__host__ __device__ inline int stage_stride_bytes(int W) { return ((kChunk * W + 15) & ~15) + 16; }
+
+// ---------------------------------------------------------------------------------------
+// score_hist_kernel<NDW, SELECT>
+//
+// One wave owns a stream of 128-k-mer chunks.  A chunk is W*128 contiguous bytes of the
+// row-major uint8 [n][W] matrix (16-byte aligned because 128*W % 16 == 0), fetched with
+// fully coalesced 16 B/lane loads into registers one chunk ahead, parked in a wave-private
+// LDS strip, and re-read row-wise: lane r takes k-mer r as NDW+1 aligned dwords that
+// v_alignbit turns into NDW dwords of consecutive bases.  Each base indexes a (4*NDW) x 8
+// uint16 log-odds table in LDS by bits 1..3 of its ASCII code ((c>>1)&7: A/a 0, C/c 1,
+// T/t 2, G/g 3, N/n 7): 4 hot entries per position sit in 2 banks and broadcast, so the
+// lookup is conflict free.  Entries 4..7 hold kPoison: a k-mer that touched one scores
+// min_val (score_sequences.py:376-378).  Positions >= W have zero entries, so the tail of
+// the last dword needs no masking.  Scores go out as coalesced int32; the score histogram
+// is built with LDS atomics in a per-workgroup window [lo, lo+nb) (+1 bin for N rows)
+// and flushed once per workgroup as a plain-store slab (no global atomics).
+template <int NDW, bool SELECT>
+__global__ void __launch_bounds__(kThreads)
+score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
+                  const uint16_t *__restrict__ g_tab, int lo, int nb, int min_val,
+                  int use_hist, int *__restrict__ scores, unsigned *__restrict__ partials,
+                  int cutoff, long long row_base, long long *__restrict__ hit_rows,
+                  long long hit_cap, unsigned long long *__restrict__ hit_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kTabBytes = 4 * NDW * 8 * 2;
+    constexpr int kLoads = (kChunk * 4 * NDW + 1023) / 1024;  // 16 B loads per lane per chunk
+
+    unsigned char *tab = smem;
+    unsigned char *stage_base = smem + kTabBytes;
+    const int sstride = stage_stride_bytes(W);
+    unsigned *hist = reinterpret_cast<unsigned *>(stage_base + kWavesPerWG * sstride);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+
+    for (int i = tid; i < kTabBytes / 2; i += kThreads)
+        reinterpret_cast<uint16_t *>(tab)[i] = g_tab[i];
+    if (use_hist)
+        for (int i = tid; i <= nb; i += kThreads) hist[i] = 0u;
+    __syncthreads();
+
+    unsigned char *stage = stage_base + wave * sstride;
+    const long long total_bytes = n * (long long)W;
+    const long long nchunks = (n + kChunk - 1) / kChunk;
+    const int chunk_bytes = kChunk * W;
+    const long long cstride = (long long)gridDim.x * kWavesPerWG;
+
+    uint4 pre[kLoads];
+    auto fetch = [&](long long c) {
+        const long long cbase = c * (long long)chunk_bytes;
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int off = i * 1024 + lane * 16;
+            const long long g = cbase + off;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (off < chunk_bytes) {
+                if (g + 16 <= total_bytes) {
+                    v = *reinterpret_cast<const uint4 *>(kmers + g);
+                } else if (g < total_bytes) {  // ragged end of the matrix: byte loads
+                    unsigned t[4] = {0u, 0u, 0u, 0u};
+                    for (int b = 0; b < 16 && g + b < total_bytes; ++b)
+                        t[b >> 2] |= (unsigned)kmers[g + b] << (8 * (b & 3));
+                    v = make_uint4(t[0], t[1], t[2], t[3]);
+                }
+            }
+            pre[i] = v;
+        }
+    };
+
+    long long c = (long long)blockIdx.x * kWavesPerWG + wave;
+    if (c < nchunks) fetch(c);
+    for (; c < nchunks; c += cstride) {
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            const int off = i * 1024 + lane * 16;
+            if (off < chunk_bytes) *reinterpret_cast<uint4 *>(stage + off) = pre[i];
+        }
+        if (c + cstride < nchunks) fetch(c + cstride);
+        // LDS ops of one wave execute in program order; the fence only pins the compiler.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+        for (int p = 0; p < kChunk / kWave; ++p) {
+            const int k = p * kWave + lane;
+            const long long row = c * kChunk + k;
+            const int boff = k * W;
+            const unsigned sh = (unsigned)(boff & 3) * 8u;
+            const unsigned *src = reinterpret_cast<const unsigned *>(stage + (boff & ~3));
+            unsigned w[NDW + 1];
+#pragma unroll
+            for (int d = 0; d <= NDW; ++d) w[d] = src[d];
+            int acc = 0;
+#pragma unroll
+            for (int d = 0; d < NDW; ++d) {
+                const unsigned x = __builtin_amdgcn_alignbit(w[d + 1], w[d], sh);
+                const unsigned xm = x & 0x0E0E0E0Eu;  // 2 * ((c >> 1) & 7) per byte
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const unsigned e = (xm >> (8 * b)) & 0xFFu;
+                    acc += *reinterpret_cast<const uint16_t *>(tab + (4 * d + b) * 16 + e);
+                }
+            }
+            const bool is_n = (unsigned)acc >= kPoison;
+            const int score = is_n ? min_val : acc;
+            const bool live = row < n;
+            if (live) {
+                scores[row] = score;
+                if (use_hist) atomicAdd(&hist[is_n ? nb : score - lo], 1u);
+            }
+            if (SELECT) {
+                const bool hit = live && score >= cutoff;
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(hit_count, (unsigned long long)__popcll(mask));
+                    base = __shfl(base, 0);
+                    if (hit) {
+                        const unsigned long long slot =
+                            base + __popcll(mask & ((1ull << lane) - 1ull));
+                        if ((long long)slot < hit_cap) hit_rows[slot] = row_base + row;
+                    }
+                }
+            }
+        }
+        // the strip is rewritten next iteration: keep this iteration's reads ahead of it
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (use_hist) {
+        __syncthreads();
+        unsigned *slab = partials + (size_t)blockIdx.x * (size_t)(nb + 1);
+        for (int i = tid; i <= nb; i += kThreads) slab[i] = hist[i];
+    }
+}
+
+// Sums the per-workgroup slabs into the caller's uint64 histogram (bin lo+b; the extra
+// slab bin counts N rows, which score min_val).
+__global__ void __launch_bounds__(256)
+hist_reduce_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo,
+                   int min_val, unsigned long long *__restrict__ hist64)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    unsigned long long s = 0;
+    const size_t stride = (size_t)(nb + 1);
+    for (int g = 0; g < nslabs; ++g) s += partials[g * stride + b];
+    if (s) atomicAdd(&hist64[b == nb ? min_val : lo + b], s);
+}
+
+// Rows with score >= *cutoff -> hit list (separate pass; used when the cutoff depends on
+// the global histogram, i.e. --qvalueT).
+__global__ void __launch_bounds__(256)
+select_hits_kernel(const int *__restrict__ scores, long long n, const int *__restrict__ cutoff_ptr,
+                   long long row_base, long long *__restrict__ hit_rows, long long hit_cap,
+                   unsigned long long *__restrict__ hit_count)
+{
+    const int cutoff = *cutoff_ptr;
+    const int lane = threadIdx.x & 63;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    const long long n4 = n >> 2;
+    const long long iters = (n4 + nthreads - 1) / nthreads;  // wave-uniform trip count
+    const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long it = 0; it < iters; ++it) {
+        const long long i = t0 + it * nthreads;
+        int4 v = make_int4(INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN);
+        if (i < n4) v = reinterpret_cast<const int4 *>(scores)[i];
+        const int s[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool hit = s[j] >= cutoff;
+            const unsigned long long mask = __ballot(hit);
+            if (mask) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(hit_count, (unsigned long long)__popcll(mask));
+                base = __shfl(base, 0);
+                if (hit) {
+                    const unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+                    if ((long long)slot < hit_cap) hit_rows[slot] = row_base + i * 4 + j;
+                }
+            }
+        }
+    }
+    // ragged tail (n % 4 rows), one thread
+    if (t0 == 0) {
+        for (long long r = n4 * 4; r < n; ++r)
+            if (scores[r] >= cutoff) {
+                const unsigned long long slot = atomicAdd(hit_count, 1ull);
+                if ((long long)slot < hit_cap) hit_rows[slot] = row_base + r;
+            }
+    }
+}
+
+__global__ void gather_scores_kernel(const int *__restrict__ scores,
+                                     const long long *__restrict__ rows, long long row_base,
+                                     long long cnt, int *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) out[i] = scores[rows[i] - row_base];
+}
+
+// ---------------------------------------------------------------------------------------
+// pvalue_dp_kernel: score-distribution DP of comp_pval_mat (motif_processing.pyx:552-603),
+// one 1024-thread workgroup per motif, gather form:
+//   cur[t] = sum over n in A,C,G,T of prev[t - sm[n][pos]] * bg[n]
+// accumulated per target in A->C->G->T order with the product rounded before the add
+// (__dmul_rn/__dadd_rn: no FMA contraction) and the reference's `> 0` support test.  The
+// reference scatters, but each (n, idx) pair hits a distinct target once per n and n runs
+// outermost, so per target the additions arrive in exactly this order: bit-identical.
+// Rows ping-pong in global memory (they live in L2: 2*L*8 B <= 1 MB); only the reachable
+// window [cum_lo[pos], cum_hi[pos]] of a row is computed or read.
+constexpr int kDpThreads = 1024;
+
+__global__ void __launch_bounds__(kDpThreads)
+pvalue_dp_kernel(const int *__restrict__ sm, const double *__restrict__ bg, int W, int L,
+                 const int *__restrict__ cum_lo, const int *__restrict__ cum_hi,
+                 double *__restrict__ buf, double *__restrict__ pmf_out)
+{
+    double *cur = buf;
+    double *prev = buf + L;
+    const int tid = threadIdx.x;
+    {   // position 0 (motif_processing.pyx:593-594)
+        const int l0 = cum_lo[0], h0 = cum_hi[0];
+        for (int t = l0 + tid; t <= h0; t += kDpThreads) cur[t] = 0.0;
+        __syncthreads();
+        if (tid == 0)
+            for (int nuc = 0; nuc < 4; ++nuc) {
+                const int s = sm[nuc * W];
+                cur[s] = __dadd_rn(cur[s], __dmul_rn(1.0, bg[nuc]));
+            }
+        __syncthreads();
+    }
+    for (int pos = 1; pos < W; ++pos) {
+        double *tmp = cur; cur = prev; prev = tmp;
+        const int lp = cum_lo[pos - 1], hp = cum_hi[pos - 1];
+        const int lc = cum_lo[pos], hc = cum_hi[pos];
+        const int s0 = sm[0 * W + pos], s1 = sm[1 * W + pos], s2 = sm[2 * W + pos],
+                  s3 = sm[3 * W + pos];
+        const double b0 = bg[0], b1 = bg[1], b2 = bg[2], b3 = bg[3];
+        for (int t = lc + tid; t <= hc; t += kDpThreads) {
+            double acc = 0.0;
+            int idx = t - s0;
+            if (idx >= lp && idx <= hp) { const double v = prev[idx]; if (v > 0) acc = __dadd_rn(acc, __dmul_rn(v, b0)); }
+            idx = t - s1;
+            if (idx >= lp && idx <= hp) { const double v = prev[idx]; if (v > 0) acc = __dadd_rn(acc, __dmul_rn(v, b1)); }
+            idx = t - s2;
+            if (idx >= lp && idx <= hp) { const double v = prev[idx]; if (v > 0) acc = __dadd_rn(acc, __dmul_rn(v, b2)); }
+            idx = t - s3;
+            if (idx >= lp && idx <= hp) { const double v = prev[idx]; if (v > 0) acc = __dadd_rn(acc, __dmul_rn(v, b3)); }
+            cur[t] = acc;
+        }
+        __syncthreads();
+    }
+    const int lf = cum_lo[W - 1], hf = cum_hi[W - 1];
+    for (int t = tid; t < L; t += kDpThreads) pmf_out[t] = (t >= lf && t <= hf) ? cur[t] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------
+// block-wide scans over a table of L entries split into 1024 contiguous segments
+constexpr int kScanThreads = 1024;
+
+// p_table[s] = (sum_{t>=s} pmf[t]) / (sum_t pmf[t])   -- O(1) form of
+// `pval_mat[score:].sum() / pval_mat.sum()` (score_sequences.py:390-391).
+// The suffix sums are ONE sequential top-down chain over the reachable window (one lane,
+// <= 64k dependent f64 adds, once per motif): that makes the table exactly monotone and
+// p_table[s] == 1.0 exactly for every s at or below the lowest reachable score, which a
+// blocked scan's mixed association orders would not guarantee.  The division runs in parallel.
+__global__ void __launch_bounds__(kScanThreads)
+ptable_kernel(const double *__restrict__ pmf, int L, int lo, int hi, double *__restrict__ ptable)
+{
+    __shared__ double tot_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        double run = 0.0;
+        for (int j = hi; j >= lo; --j) {
+            run += pmf[j];
+            ptable[j] = run;
+        }
+        tot_s = run;
+    }
+    __syncthreads();
+    const double tot = tot_s;
+    for (int j = tid; j < L; j += kScanThreads) {
+        const double suffix = j < lo ? tot : (j > hi ? 0.0 : ptable[j]);
+        ptable[j] = suffix / tot;
+    }
+}
+
+// q-value of every score from the histogram (Benjamini-Hochberg as statsmodels'
+// fdrcorrection evaluates it: raw = p / (rank/n), reverse cumulative minimum, clip 1),
+// plus the selection cutoff.  Ranks: all rows sharing a score share a p-value; the
+// largest rank in the tie group is C(s) = #rows with score >= s, and the cumulative
+// minimum makes the whole group take p(s) / (C(s)/n).
+__global__ void __launch_bounds__(kScanThreads)
+qvalue_kernel(const unsigned long long *__restrict__ hist, const double *__restrict__ ptable,
+              int L, double threshold, int on_qvalue, double *__restrict__ qtable,
+              int *__restrict__ cutoff_out, unsigned long long *__restrict__ nrows_out)
+{
+    __shared__ unsigned long long cseg[kScanThreads];
+    __shared__ double mseg[kScanThreads];
+    __shared__ int cut_s;
+    const int tid = threadIdx.x;
+    const int per = (L + kScanThreads - 1) / kScanThreads;
+    const int a = min(tid * per, L), b = min(a + per, L);
+    if (tid == 0) cut_s = L;
+
+    unsigned long long c = 0;
+    for (int j = a; j < b; ++j) c += hist[j];
+    cseg[tid] = c;
+    __syncthreads();
+    for (int d = 1; d < kScanThreads; d <<= 1) {  // inclusive suffix scan of counts
+        const unsigned long long v = (tid + d < kScanThreads) ? cseg[tid + d] : 0ull;
+        __syncthreads();
+        cseg[tid] += v;
+        __syncthreads();
+    }
+    const unsigned long long n = cseg[0];
+    const double nd = (double)n;
+    unsigned long long above = (tid + 1 < kScanThreads) ? cseg[tid + 1] : 0ull;
+
+    // raw BH value per occupied bin, segment minimum
+    double m = INFINITY;
+    {
+        unsigned long long run = above;
+        for (int j = b - 1; j >= a; --j) {
+            const unsigned long long h = hist[j];
+            run += h;
+            if (h) {
+                const double ecdf = (double)run / nd;
+                const double raw = ptable[j] / ecdf;
+                m = fmin(m, raw);
+            }
+        }
+    }
+    mseg[tid] = m;
+    __syncthreads();
+    for (int d = 1; d < kScanThreads; d <<= 1) {  // inclusive prefix-min scan
+        const double v = (tid >= d) ? mseg[tid - d] : INFINITY;
+        __syncthreads();
+        mseg[tid] = fmin(mseg[tid], v);
+        __syncthreads();
+    }
+    double runmin = (tid > 0) ? mseg[tid - 1] : INFINITY;
+    // walk the segment upward: counts above bin j shrink as j grows
+    unsigned long long cge = above;           // #rows with score >= b
+    for (int j = a; j < b; ++j) cge += hist[j];  // now #rows with score >= a
+    int first = L;
+    for (int j = a; j < b; ++j) {
+        const unsigned long long h = hist[j];
+        if (h) {
+            const double ecdf = (double)cge / nd;
+            runmin = fmin(runmin, ptable[j] / ecdf);
+        }
+        cge -= h;
+        const double q = fmin(runmin, 1.0);
+        if (qtable) qtable[j] = q;
+        const double val = on_qvalue ? q : ptable[j];
+        if (first == L && val < threshold) first = j;
+    }
+    if (first < L) atomicMin(&cut_s, first);
+    __syncthreads();
+    if (tid == 0) {
+        if (cutoff_out) *cutoff_out = cut_s;
+        if (nrows_out) *nrows_out = n;
+    }
+}
+
+}  // namespace
+
+// =======================================================================================
+// host side
+struct gfm_motif {
+    int W = 0, L = 0, min_val = 0, scale = 1, ndw = 0;
+    double offset = 0.0;
+    int lo = 0, hi = 0, nb = 0;
+    int device = 0;
+    int n_cu = 256;
+    int max_slabs = 0;
+    bool lds_hist = true;
+    size_t lds_bytes = 0;
+    std::vector<int64_t> sm;
+    double bg[4] = {0, 0, 0, 0};
+    std::vector<double> h_ptable;
+    uint16_t *d_tab = nullptr;
+    double *d_pmf = nullptr;
+    double *d_ptable = nullptr;
+    unsigned *d_partials = nullptr;
+};
+
+namespace {
+
+int ensure_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(GFM_ERR_NODEVICE, "no HIP device available (%s)",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    return GFM_OK;
+}
+
+// window of reachable scores after each DP position
+void cumulative_windows(const int64_t *sm, int W, std::vector<int> &lo, std::vector<int> &hi)
+{
+    lo.resize(W);
+    hi.resize(W);
+    long long l = 0, h = 0;
+    for (int j = 0; j < W; ++j) {
+        int64_t mn = sm[j], mx = sm[j];
+        for (int nuc = 1; nuc < 4; ++nuc) {
+            mn = std::min(mn, sm[nuc * W + j]);
+            mx = std::max(mx, sm[nuc * W + j]);
+        }
+        l += mn;
+        h += mx;
+        lo[j] = (int)l;
+        hi[j] = (int)h;
+    }
+}
+
+int validate_matrix(const int64_t *sm, int W)
+{
+    if (!sm) return fail(GFM_ERR_INVALID, "score matrix is NULL");
+    if (W < 1 || W > GFM_MAX_WIDTH)
+        return fail(GFM_ERR_INVALID, "motif width %d outside [1, %d]", W, GFM_MAX_WIDTH);
+    for (int i = 0; i < 4 * W; ++i)
+        if (sm[i] < 0 || sm[i] > kRange)
+            return fail(GFM_ERR_INVALID, "scaled score %lld outside [0, %d]", (long long)sm[i], kRange);
+    return GFM_OK;
+}
+
+// runs the DP for one motif on the current device; d_pmf receives L doubles
+int run_dp(const int64_t *sm, int W, const double *bg, double *d_pmf, hipStream_t st)
+{
+    const int L = kRange * W + 1;
+    std::vector<int> lo, hi, sm32(4 * W);
+    cumulative_windows(sm, W, lo, hi);
+    for (int i = 0; i < 4 * W; ++i) sm32[i] = (int)sm[i];
+    int *d_sm = nullptr, *d_lo = nullptr, *d_hi = nullptr;
+    double *d_bg = nullptr, *d_buf = nullptr;
+    HIP_TRY(hipMalloc(&d_sm, sizeof(int) * 4 * W));
+    HIP_TRY(hipMalloc(&d_lo, sizeof(int) * W));
+    HIP_TRY(hipMalloc(&d_hi, sizeof(int) * W));
+    HIP_TRY(hipMalloc(&d_bg, sizeof(double) * 4));
+    HIP_TRY(hipMalloc(&d_buf, sizeof(double) * 2 * (size_t)L));
+    HIP_TRY(hipMemcpyAsync(d_sm, sm32.data(), sizeof(int) * 4 * W, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_lo, lo.data(), sizeof(int) * W, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_hi, hi.data(), sizeof(int) * W, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_bg, bg, sizeof(double) * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pvalue_dp_kernel, dim3(1), dim3(kDpThreads), 0, st, d_sm, d_bg, W, L, d_lo,
+                       d_hi, d_buf, d_pmf);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    (void)hipFree(d_sm);
+    (void)hipFree(d_lo);
+    (void)hipFree(d_hi);
+    (void)hipFree(d_bg);
+    (void)hipFree(d_buf);
+    return GFM_OK;
+}
+
+template <int NDW>
+int launch_score(gfm_motif *m, const uint8_t *d_kmers, long long n, int *d_scores, int use_hist,
+                 int nslabs, bool select, int cutoff, long long row_base, long long *d_hit_rows,
+                 long long cap, unsigned long long *d_hit_count, hipStream_t st)
+{
+    auto k_sel = score_hist_kernel<NDW, true>;
+    auto k_nos = score_hist_kernel<NDW, false>;
+    auto kern = select ? k_sel : k_nos;
+    if (m->lds_bytes > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes));
+    }
+    hipLaunchKernelGGL(kern, dim3(nslabs), dim3(kThreads), m->lds_bytes, st, d_kmers, n, m->W,
+                       m->d_tab, m->lo, m->nb, m->min_val, use_hist, d_scores, m->d_partials,
+                       cutoff, row_base, d_hit_rows, cap, d_hit_count);
+    HIP_TRY(hipGetLastError());
+    return GFM_OK;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------- API
+extern "C" __attribute__((visibility("hidden"))) void gfm_set_error_(const char *msg) { g_err = msg ? msg : ""; }
+
+GFM_API int gfm_abi_version(void) { return GFM_ABI_VERSION; }
+GFM_API const char *gfm_last_error(void) { return g_err.c_str(); }
+
+GFM_API int gfm_device_count(int *count)
+{
+    if (!count) return fail(GFM_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return GFM_OK;
+}
+
+GFM_API int gfm_set_device(int ordinal)
+{
+    int rc = ensure_device();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ordinal));
+    return GFM_OK;
+}
+
+GFM_API int gfm_compute_log_odds(const double *probs, int W, const double *bg, double *out)
+{
+    if (!probs || !bg || !out) return fail(GFM_ERR_INVALID, "NULL argument");
+    if (W <= 0) return fail(GFM_ERR_INVALID, "Forbidden motif width.");
+    double totBG = 0.0, totFG = 0.0;
+    for (int n = 0; n < 4; ++n) {
+        if (!(bg[n] > 0)) return fail(GFM_ERR_ASSERT, "assert bg > 0 (motif_processing.pyx:496)");
+        totBG += bg[n];
+        for (int j = 0; j < W; ++j) {
+            const double p = probs[n * W + j];
+            if (!(p > 0)) return fail(GFM_ERR_ASSERT, "assert prob > 0 (motif_processing.pyx:500)");
+            totFG += p;
+            const double odds = p / bg[n];
+            out[n * W + j] = std::log(odds) * kLogFactor;
+        }
+    }
+    if (!(totBG - 1.0 < 0.001)) return fail(GFM_ERR_ASSERT, "assert totBG - 1.0 < epsilon (motif_processing.pyx:505)");
+    if (!(totFG - (double)W < 0.001)) return fail(GFM_ERR_ASSERT, "assert totFG - width < epsilon (motif_processing.pyx:506)");
+    return GFM_OK;
+}
+
+GFM_API int gfm_scale_pwm(const double *lo, int W, int64_t *sm, int *min_val, int *max_val,
+                          int *scale, double *offset)
+{
+    if (!lo || !sm || !min_val || !max_val || !scale || !offset)
+        return fail(GFM_ERR_INVALID, "NULL argument");
+    if (W <= 0) return fail(GFM_ERR_INVALID, "Forbidden motif width.");
+    double lower = lo[0], upper = lo[0];
+    for (int i = 1; i < 4 * W; ++i) {
+        lower = std::min(lower, lo[i]);
+        upper = std::max(upper, lo[i]);
+    }
+    if (lower == upper) lower = upper - 1.0;
+    lower = std::floor(lower);
+    const double off = std::nearbyint(std::floor(lower));
+    const double sf = std::floor((double)kRange / (upper - lower));
+    int64_t mn = 0, mx = 0;
+    for (int i = 0; i < 4 * W; ++i) {
+        sm[i] = (int64_t)std::nearbyint((lo[i] - off) * sf);  // half-to-even like np.round
+        if (i == 0 || sm[i] < mn) mn = sm[i];
+        if (i == 0 || sm[i] > mx) mx = sm[i];
+    }
+    *min_val = (int)mn;
+    *max_val = (int)mx;
+    *scale = (int)sf;
+    *offset = off;
+    return GFM_OK;
+}
+
+GFM_API int gfm_comp_pval_mat(const int64_t *sm, int W, const double *bg, double *h_pmf)
+{
+    if (!bg || !h_pmf) return fail(GFM_ERR_INVALID, "NULL argument");
+    int rc = validate_matrix(sm, W);
+    if (rc) return rc;
+    for (int n = 0; n < 4; ++n)
+        if (!(bg[n] > 0)) return fail(GFM_ERR_ASSERT, "assert bg > 0 (motif_processing.pyx:592)");
+    rc = ensure_device();
+    if (rc) return rc;
+    const int L = kRange * W + 1;
+    double *d_pmf = nullptr;
+    HIP_TRY(hipMalloc(&d_pmf, sizeof(double) * (size_t)L));
+    rc = run_dp(sm, W, bg, d_pmf, nullptr);
+    if (rc == GFM_OK) {
+        hipError_t e = hipMemcpy(h_pmf, d_pmf, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(GFM_ERR_HIP, "D2H of pmf failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_pmf);
+    return rc;
+}
+
+GFM_API void gfm_motif_destroy(gfm_motif_t m)
+{
+    if (!m) return;
+    if (m->d_tab) (void)hipFree(m->d_tab);
+    if (m->d_pmf) (void)hipFree(m->d_pmf);
+    if (m->d_ptable) (void)hipFree(m->d_ptable);
+    if (m->d_partials) (void)hipFree(m->d_partials);
+    delete m;
+}
+
+GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min_val, int scale,
+                             double offset, const double *h_pmf, gfm_motif_t *out)
+{
+    if (!out || !bg) return fail(GFM_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    int rc = validate_matrix(sm, W);
+    if (rc) return rc;
+    if (scale <= 0) return fail(GFM_ERR_INVALID, "scale must be a positive integer");
+    for (int n = 0; n < 4; ++n)
+        if (!(bg[n] > 0)) return fail(GFM_ERR_ASSERT, "assert bg > 0");
+    rc = ensure_device();
+    if (rc) return rc;
+
+    gfm_motif *m = new (std::nothrow) gfm_motif();
+    if (!m) return fail(GFM_ERR_NOMEM, "out of host memory");
+    m->W = W;
+    m->L = kRange * W + 1;
+    m->min_val = min_val;
+    m->scale = scale;
+    m->offset = offset;
+    m->ndw = (W + 3) / 4;
+    m->sm.assign(sm, sm + 4 * W);
+    std::memcpy(m->bg, bg, sizeof m->bg);
+    std::vector<int> clo, chi;
+    cumulative_windows(sm, W, clo, chi);
+    m->lo = clo[W - 1];
+    m->hi = chi[W - 1];
+    m->nb = m->hi - m->lo + 1;
+
+    auto bail = [&](int code) { gfm_motif_destroy(m); return code; };
+#define HIP_TRY_M(expr)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return bail(fail(GFM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)));   \
+    } while (0)
+
+    HIP_TRY_M(hipGetDevice(&m->device));
+    hipDeviceProp_t prop;
+    HIP_TRY_M(hipGetDeviceProperties(&prop, m->device));
+    m->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    // LDS lookup table: [4*ndw positions][8 codes] uint16, code = (ascii >> 1) & 7
+    // (A 0, C 1, T 2, G 3; 4..7 poison; positions >= W all zero)
+    std::vector<uint16_t> tab((size_t)4 * m->ndw * 8, 0);
+    for (int pos = 0; pos < W; ++pos) {
+        uint16_t *row = &tab[(size_t)pos * 8];
+        row[0] = (uint16_t)sm[0 * W + pos];  // A
+        row[1] = (uint16_t)sm[1 * W + pos];  // C
+        row[2] = (uint16_t)sm[3 * W + pos];  // T
+        row[3] = (uint16_t)sm[2 * W + pos];  // G
+        row[4] = row[5] = row[6] = row[7] = (uint16_t)kPoison;
+    }
+    HIP_TRY_M(hipMalloc(&m->d_tab, tab.size() * sizeof(uint16_t)));
+    HIP_TRY_M(hipMemcpy(m->d_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+
+    HIP_TRY_M(hipMalloc(&m->d_pmf, sizeof(double) * (size_t)m->L));
+    HIP_TRY_M(hipMalloc(&m->d_ptable, sizeof(double) * (size_t)m->L));
+    if (h_pmf) {
+        HIP_TRY_M(hipMemcpy(m->d_pmf, h_pmf, sizeof(double) * (size_t)m->L, hipMemcpyHostToDevice));
+    } else {
+        rc = run_dp(sm, W, bg, m->d_pmf, nullptr);
+        if (rc) return bail(rc);
+    }
+    hipLaunchKernelGGL(ptable_kernel, dim3(1), dim3(kScanThreads), 0, nullptr, m->d_pmf, m->L,
+                       m->lo, m->hi, m->d_ptable);
+    HIP_TRY_M(hipGetLastError());
+    m->h_ptable.resize(m->L);
+    HIP_TRY_M(hipMemcpy(m->h_ptable.data(), m->d_ptable, sizeof(double) * (size_t)m->L,
+                        hipMemcpyDeviceToHost));
+
+    // score-kernel LDS plan: table | 8 wave strips | histogram window (+1 N bin)
+    const size_t fixed = (size_t)4 * m->ndw * 8 * 2 + (size_t)kWavesPerWG * stage_stride_bytes(W);
+    const size_t with_hist = fixed + sizeof(unsigned) * (size_t)(m->nb + 1);
+    m->lds_hist = with_hist <= (size_t)kMaxLdsBytes;
+    m->lds_bytes = m->lds_hist ? with_hist : fixed;
+    int per_cu = (int)std::min<size_t>(kWGsPerCU, (size_t)kMaxLdsBytes / m->lds_bytes);
+    per_cu = std::max(per_cu, 1);
+    m->max_slabs = m->n_cu * per_cu;
+    HIP_TRY_M(hipMalloc(&m->d_partials, sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->nb + 1)));
+#undef HIP_TRY_M
+    *out = m;
+    return GFM_OK;
+}
+
+GFM_API int gfm_motif_width(gfm_motif_t m) { return m ? m->W : 0; }
+GFM_API int gfm_motif_table_len(gfm_motif_t m) { return m ? m->L : 0; }
+
+GFM_API int gfm_motif_score_range(gfm_motif_t m, int32_t *lo, int32_t *hi)
+{
+    if (!m) return fail(GFM_ERR_INVALID, "motif is NULL");
+    if (lo) *lo = m->lo;
+    if (hi) *hi = m->hi;
+    return GFM_OK;
+}
+
+GFM_API int gfm_motif_tables(gfm_motif_t m, double *h_pmf, double *h_ptable)
+{
+    if (!m) return fail(GFM_ERR_INVALID, "motif is NULL");
+    if (h_pmf) HIP_TRY(hipMemcpy(h_pmf, m->d_pmf, sizeof(double) * (size_t)m->L, hipMemcpyDeviceToHost));
+    if (h_ptable) std::memcpy(h_ptable, m->h_ptable.data(), sizeof(double) * (size_t)m->L);
+    return GFM_OK;
+}
+
+GFM_API int gfm_motif_pvalue_cutoff(gfm_motif_t m, double threshold, int32_t *cutoff)
+{
+    if (!m || !cutoff) return fail(GFM_ERR_INVALID, "NULL argument");
+    // p_table is non-increasing in s: first index with p < threshold
+    int a = 0, b = m->L;
+    while (a < b) {
+        const int mid = (a + b) / 2;
+        if (m->h_ptable[mid] < threshold) b = mid; else a = mid + 1;
+    }
+    *cutoff = a;
+    return GFM_OK;
+}
+
+GFM_API int gfm_motif_annotate(gfm_motif_t m, const int32_t *scores, int64_t n, double *lo_out,
+                               double *p_out)
+{
+    if (!m || (!scores && n)) return fail(GFM_ERR_INVALID, "NULL argument");
+    for (int64_t i = 0; i < n; ++i) {
+        const int s = scores[i];
+        if (s < 0 || s >= m->L) return fail(GFM_ERR_INVALID, "score %d outside the table", s);
+        if (lo_out) lo_out[i] = ((double)s / (double)m->scale) + ((double)m->W * m->offset);
+        if (p_out) p_out[i] = m->h_ptable[s];
+    }
+    return GFM_OK;
+}
+
+GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, int32_t *d_scores,
+                            uint64_t *d_hist, int32_t select_cutoff, int64_t row_base,
+                            int64_t *d_hit_rows, int64_t hit_capacity, uint64_t *d_hit_count,
+                            void *stream)
+{
+    if (!m) return fail(GFM_ERR_INVALID, "motif is NULL");
+    if (n < 0) return fail(GFM_ERR_INVALID, "negative row count");
+    if (n == 0) return GFM_OK;
+    if (!d_kmers || !d_scores) return fail(GFM_ERR_INVALID, "NULL device buffer");
+    if ((reinterpret_cast<uintptr_t>(d_kmers) & 15u) != 0)
+        return fail(GFM_ERR_INVALID, "d_kmers must be 16-byte aligned");
+    const bool select = select_cutoff != GFM_NO_SELECT;
+    if (select && (!d_hit_rows || !d_hit_count))
+        return fail(GFM_ERR_INVALID, "selection requested without hit buffers");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int use_hist = d_hist != nullptr;
+    if (use_hist && !m->lds_hist)
+        return fail(GFM_ERR_INVALID, "score window of %d bins does not fit the LDS histogram", m->nb);
+    const long long nchunks = (n + kChunk - 1) / kChunk;
+    const long long want = (nchunks + kWavesPerWG - 1) / kWavesPerWG;
+    const int nslabs = (int)std::min<long long>(want, m->max_slabs);
+
+    int rc;
+#define GFM_CASE(N)                                                                              \
+    case N:                                                                                      \
+        rc = launch_score<N>(m, d_kmers, n, d_scores, use_hist, nslabs, select, select_cutoff,   \
+                             row_base, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,   \
+                             reinterpret_cast<unsigned long long *>(d_hit_count), st);           \
+        break;
+    switch (m->ndw) {
+        GFM_CASE(1) GFM_CASE(2) GFM_CASE(3) GFM_CASE(4) GFM_CASE(5) GFM_CASE(6) GFM_CASE(7) GFM_CASE(8)
+        GFM_CASE(9) GFM_CASE(10) GFM_CASE(11) GFM_CASE(12) GFM_CASE(13) GFM_CASE(14) GFM_CASE(15) GFM_CASE(16)
+        default: rc = fail(GFM_ERR_INVALID, "unsupported width %d", m->W);
+    }
+#undef GFM_CASE
+    if (rc) return rc;
+    if (use_hist) {
+        const int threads = 256;
+        const int blocks = (m->nb + 1 + threads - 1) / threads;
+        hipLaunchKernelGGL(hist_reduce_kernel, dim3(blocks), dim3(threads), 0, st, m->d_partials,
+                           nslabs, m->nb, m->lo, m->min_val,
+                           reinterpret_cast<unsigned long long *>(d_hist));
+        HIP_TRY(hipGetLastError());
+    }
+    return GFM_OK;
+}
+
+GFM_API int gfm_qvalue_table(gfm_motif_t m, const uint64_t *d_hist, double threshold, int on_qvalue,
+                             double *d_qtable, int32_t *d_cutoff, uint64_t *d_nrows, void *stream)
+{
+    if (!m || !d_hist) return fail(GFM_ERR_INVALID, "NULL argument");
+    hipLaunchKernelGGL(qvalue_kernel, dim3(1), dim3(kScanThreads), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const unsigned long long *>(d_hist), m->d_ptable, m->L,
+                       threshold, on_qvalue, d_qtable, d_cutoff,
+                       reinterpret_cast<unsigned long long *>(d_nrows));
+    HIP_TRY(hipGetLastError());
+    return GFM_OK;
+}
+
+GFM_API int gfm_select_hits(const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
+                            int64_t row_base, int64_t *d_hit_rows, int64_t hit_capacity,
+                            uint64_t *d_hit_count, void *stream)
+{
+    if (n < 0) return fail(GFM_ERR_INVALID, "negative row count");
+    if (n == 0) return GFM_OK;
+    if (!d_scores || !d_cutoff || !d_hit_rows || !d_hit_count)
+        return fail(GFM_ERR_INVALID, "NULL device buffer");
+    if ((reinterpret_cast<uintptr_t>(d_scores) & 15u) != 0)
+        return fail(GFM_ERR_INVALID, "d_scores must be 16-byte aligned");
+    const long long n4 = n >> 2;
+    const int threads = 256;
+    long long blocks = (n4 + threads - 1) / threads;
+    blocks = std::max<long long>(1, std::min<long long>(blocks, 2048));
+    hipLaunchKernelGGL(select_hits_kernel, dim3((unsigned)blocks), dim3(threads), 0,
+                       static_cast<hipStream_t>(stream), d_scores, (long long)n, d_cutoff,
+                       (long long)row_base, reinterpret_cast<long long *>(d_hit_rows),
+                       (long long)hit_capacity, reinterpret_cast<unsigned long long *>(d_hit_count));
+    HIP_TRY(hipGetLastError());
+    return GFM_OK;
+}
+
+GFM_API int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, double threshold,
+                          int on_qvalue, int want_qvalues, int64_t capacity, int64_t *h_rows,
+                          int32_t *h_scores, double *h_logodds, double *h_pvalue, double *h_qvalue,
+                          int64_t *n_hits)
+{
+    if (!m || !n_hits) return fail(GFM_ERR_INVALID, "NULL argument");
+    *n_hits = 0;
+    if (n < 0 || capacity < 0) return fail(GFM_ERR_INVALID, "negative size");
+    if (!(threshold > 0 && threshold <= 1)) return fail(GFM_ERR_INVALID, "threshold must be in (0, 1]");
+    if (on_qvalue && !want_qvalues) return fail(GFM_ERR_INVALID, "q-value threshold without q-values");
+    if (n == 0) return GFM_OK;
+    if (!h_kmers) return fail(GFM_ERR_INVALID, "h_kmers is NULL");
+
+    const size_t kbytes = (size_t)n * (size_t)m->W;
+    uint8_t *d_kmers = nullptr;
+    int *d_scores = nullptr, *d_cutoff = nullptr, *d_hscores = nullptr;
+    unsigned long long *d_hist = nullptr, *d_count = nullptr;
+    long long *d_rows = nullptr;
+    double *d_q = nullptr;
+    hipStream_t st = nullptr;
+    int rc = GFM_OK;
+    std::vector<long long> rows;
+    std::vector<int> hs;
+    std::vector<double> q;
+    unsigned long long cnt = 0;
+    const long long cap = std::max<long long>(capacity, 1);
+    const bool need_hist = want_qvalues != 0;
+
+#define SCAN_TRY(expr)                                                                  \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            rc = fail(GFM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+            goto done;                                                                  \
+        }                                                                               \
+    } while (0)
+#define SCAN_RC(expr)            \
+    do {                         \
+        rc = (expr);             \
+        if (rc) goto done;       \
+    } while (0)
+
+    SCAN_TRY(hipStreamCreate(&st));
+    SCAN_TRY(hipMalloc(&d_kmers, kbytes + 16));
+    SCAN_TRY(hipMalloc(&d_scores, sizeof(int) * (size_t)n));
+    SCAN_TRY(hipMalloc(&d_rows, sizeof(long long) * (size_t)cap));
+    SCAN_TRY(hipMalloc(&d_hscores, sizeof(int) * (size_t)cap));
+    SCAN_TRY(hipMalloc(&d_count, sizeof(unsigned long long)));
+    SCAN_TRY(hipMalloc(&d_cutoff, sizeof(int)));
+    SCAN_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st));
+    if (need_hist) {
+        SCAN_TRY(hipMalloc(&d_hist, sizeof(unsigned long long) * (size_t)m->L));
+        SCAN_TRY(hipMalloc(&d_q, sizeof(double) * (size_t)m->L));
+        SCAN_TRY(hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * (size_t)m->L, st));
+    }
+    SCAN_TRY(hipMemcpyAsync(d_kmers, h_kmers, kbytes, hipMemcpyHostToDevice, st));
+    if (!on_qvalue) {
+        int32_t cutoff = 0;
+        SCAN_RC(gfm_motif_pvalue_cutoff(m, threshold, &cutoff));
+        SCAN_RC(gfm_score_kmers(m, d_kmers, n, d_scores, reinterpret_cast<uint64_t *>(d_hist), cutoff,
+                                0, reinterpret_cast<int64_t *>(d_rows), cap,
+                                reinterpret_cast<uint64_t *>(d_count), st));
+        if (need_hist)
+            SCAN_RC(gfm_qvalue_table(m, reinterpret_cast<uint64_t *>(d_hist), threshold, 0, d_q,
+                                     nullptr, nullptr, st));
+    } else {
+        SCAN_RC(gfm_score_kmers(m, d_kmers, n, d_scores, reinterpret_cast<uint64_t *>(d_hist),
+                                GFM_NO_SELECT, 0, nullptr, 0, nullptr, st));
+        SCAN_RC(gfm_qvalue_table(m, reinterpret_cast<uint64_t *>(d_hist), threshold, 1, d_q, d_cutoff,
+                                 nullptr, st));
+        SCAN_RC(gfm_select_hits(d_scores, n, d_cutoff, 0, reinterpret_cast<int64_t *>(d_rows), cap,
+                                reinterpret_cast<uint64_t *>(d_count), st));
+    }
+    SCAN_TRY(hipMemcpyAsync(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost, st));
+    SCAN_TRY(hipStreamSynchronize(st));
+    *n_hits = (int64_t)cnt;
+    if ((long long)cnt > capacity) {
+        rc = fail(GFM_ERR_OVERFLOW, "%llu hits exceed the capacity of %lld rows", cnt, (long long)capacity);
+        goto done;
+    }
+    if (cnt) {
+        hipLaunchKernelGGL(gather_scores_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
+                           d_scores, d_rows, 0ll, (long long)cnt, d_hscores);
+        SCAN_TRY(hipGetLastError());
+        rows.resize(cnt);
+        hs.resize(cnt);
+        SCAN_TRY(hipMemcpyAsync(rows.data(), d_rows, sizeof(long long) * cnt, hipMemcpyDeviceToHost, st));
+        SCAN_TRY(hipMemcpyAsync(hs.data(), d_hscores, sizeof(int) * cnt, hipMemcpyDeviceToHost, st));
+        if (need_hist) {
+            q.resize(m->L);
+            SCAN_TRY(hipMemcpyAsync(q.data(), d_q, sizeof(double) * (size_t)m->L, hipMemcpyDeviceToHost, st));
+        }
+        SCAN_TRY(hipStreamSynchronize(st));
+        std::vector<size_t> order(cnt);
+        for (size_t i = 0; i < cnt; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return rows[a] < rows[b]; });
+        for (size_t i = 0; i < cnt; ++i) {
+            const size_t k = order[i];
+            const int s = hs[k];
+            if (h_rows) h_rows[i] = rows[k];
+            if (h_scores) h_scores[i] = s;
+            if (h_logodds) h_logodds[i] = ((double)s / (double)m->scale) + ((double)m->W * m->offset);
+            if (h_pvalue) h_pvalue[i] = m->h_ptable[s];
+            if (h_qvalue && need_hist) h_qvalue[i] = q[s];
+        }
+    }
+done:
+#undef SCAN_TRY
+#undef SCAN_RC
+    if (d_kmers) (void)hipFree(d_kmers);
+    if (d_scores) (void)hipFree(d_scores);
+    if (d_rows) (void)hipFree(d_rows);
+    if (d_hscores) (void)hipFree(d_hscores);
+    if (d_count) (void)hipFree(d_count);
+    if (d_cutoff) (void)hipFree(d_cutoff);
+    if (d_hist) (void)hipFree(d_hist);
+    if (d_q) (void)hipFree(d_q);
+    if (st) (void)hipStreamDestroy(st);
+    return rc;
+}

@@ -1,0 +1,299 @@
+// tsv_ingest.cpp -- host-side parser of vg's k-mer TSV rows into columnar arrays.
+//
+// Replaces the text handling of score_seqs (score_sequences.py:273-293, :305-307, paths
+// relative to /root/reference/src/grafimo/): one row per haplotype k-mer,
+//   REGION \t KMER \t CHR:START(+|-) \t CHR:STOP(+|-) \t COUNT \t ref|non.ref \t NODEPATH
+// split on whitespace; strand = last char of column 3; start/stop = the integer after the
+// first ':' of columns 3/4 minus the strand char; '-' rows dropped before counting when
+// skip_reverse; "ref" rows whose |stop-start| != W become "non.ref".
+// Files are mmap'ed and parsed by a small pool of host threads (one file at a time each).
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "grafimo_hip.h"
+
+#define GFM_API extern "C" __attribute__((visibility("default")))
+
+// shared thread-local error slot, defined in grafimo_hip.hip
+extern "C" void gfm_set_error_(const char *msg);
+
+namespace {
+
+struct ErrSlot {
+    ErrSlot &operator=(const std::string &m) { gfm_set_error_(m.c_str()); return *this; }
+    ErrSlot &operator=(const char *m) { gfm_set_error_(m); return *this; }
+} t_err;
+
+struct FileCols {
+    std::vector<uint8_t> kmers;
+    std::vector<int64_t> start, stop, freq;
+    std::vector<uint8_t> strand, is_ref;
+    std::vector<int32_t> local_name;       // index into names
+    std::vector<std::string> names;
+    std::string error;
+};
+
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
+
+// CHR:NUM(+|-) -> NUM and strand; the reference takes split(":")[1] and drops its last char
+bool parse_pos(const char *b, const char *e, int64_t *val, char *strand)
+{
+    if (e - b < 3) return false;
+    const char *colon = static_cast<const char *>(memchr(b, ':', (size_t)(e - b)));
+    if (!colon) return false;
+    const char *p = colon + 1;
+    const char *q = static_cast<const char *>(memchr(p, ':', (size_t)(e - p)));
+    const char *fe = q ? q : e;      // field after the first ':' (up to a second ':', if any)
+    if (fe - p < 2) return false;
+    *strand = e[-1];                 // data[2][-1]: last char of the whole column
+    const char *ne = fe - 1;         // [:-1]
+    bool neg = false;
+    if (p < ne && (*p == '-' || *p == '+')) { neg = *p == '-'; ++p; }
+    if (p >= ne) return false;
+    int64_t v = 0;
+    for (; p < ne; ++p) {
+        if (*p < '0' || *p > '9') return false;
+        v = v * 10 + (*p - '0');
+    }
+    *val = neg ? -v : v;
+    return true;
+}
+
+bool parse_int(const char *b, const char *e, int64_t *val)
+{
+    if (b >= e) return false;
+    bool neg = false;
+    if (*b == '-' || *b == '+') { neg = *b == '-'; ++b; }
+    if (b >= e) return false;
+    int64_t v = 0;
+    for (; b < e; ++b) {
+        if (*b < '0' || *b > '9') return false;
+        v = v * 10 + (*b - '0');
+    }
+    *val = neg ? -v : v;
+    return true;
+}
+
+void parse_file(const char *path, int W, bool skip_rev, FileCols &out)
+{
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) { out.error = std::string("Unable to open ") + path; return; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); out.error = std::string("Unable to stat ") + path; return; }
+    const size_t len = (size_t)sb.st_size;
+    if (len == 0) { close(fd); return; }
+    void *map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) { out.error = std::string("Unable to mmap ") + path; return; }
+    madvise(map, len, MADV_SEQUENTIAL);
+    const char *p = static_cast<const char *>(map), *end = p + len;
+    const size_t guess = len / (size_t)(2 * W + 60) + 16;
+    out.kmers.reserve(guess * (size_t)W);
+    out.start.reserve(guess); out.stop.reserve(guess); out.freq.reserve(guess);
+    out.strand.reserve(guess); out.is_ref.reserve(guess); out.local_name.reserve(guess);
+    std::unordered_map<std::string, int32_t> name_ix;
+    const char *last_name = nullptr;
+    size_t last_len = 0;
+    int32_t last_id = -1;
+    int64_t lineno = 0;
+    while (p < end) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+        const char *le = nl ? nl : end;
+        ++lineno;
+        // split the first six whitespace-separated fields
+        const char *fb[6], *fe[6];
+        int nf = 0;
+        const char *c = p;
+        while (c < le && nf < 6) {
+            while (c < le && is_ws(*c)) ++c;
+            if (c >= le) break;
+            fb[nf] = c;
+            while (c < le && !is_ws(*c)) ++c;
+            fe[nf] = c;
+            ++nf;
+        }
+        const char *next = nl ? nl + 1 : end;
+        if (nf == 0) { p = next; continue; }  // blank line
+        auto bad = [&](const char *what) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "%s:%lld: %s", path, (long long)lineno, what);
+            out.error = buf;
+        };
+        if (nf < 6) { bad("expected at least 6 columns"); break; }
+        int64_t st = 0, sp = 0, fr = 0;
+        char s1 = 0, s2 = 0;
+        if (!parse_pos(fb[2], fe[2], &st, &s1)) { bad("malformed start column"); break; }
+        if (skip_rev && s1 == '-') { p = next; continue; }
+        if (!parse_pos(fb[3], fe[3], &sp, &s2)) { bad("malformed stop column"); break; }
+        if (fe[1] - fb[1] != W) { bad("k-mer length differs from the motif width"); break; }
+        if (!parse_int(fb[4], fe[4], &fr)) { bad("malformed haplotype count"); break; }
+        const size_t nlen = (size_t)(fe[0] - fb[0]);
+        int32_t nid;
+        if (last_name && nlen == last_len && memcmp(last_name, fb[0], nlen) == 0) {
+            nid = last_id;
+        } else {
+            std::string key(fb[0], nlen);
+            auto it = name_ix.find(key);
+            if (it == name_ix.end()) {
+                nid = (int32_t)out.names.size();
+                out.names.push_back(key);
+                name_ix.emplace(std::move(key), nid);
+            } else {
+                nid = it->second;
+            }
+            last_name = fb[0]; last_len = nlen; last_id = nid;
+        }
+        out.kmers.insert(out.kmers.end(), reinterpret_cast<const uint8_t *>(fb[1]),
+                         reinterpret_cast<const uint8_t *>(fe[1]));
+        out.start.push_back(st);
+        out.stop.push_back(sp);
+        out.freq.push_back(fr);
+        out.strand.push_back((uint8_t)s1);
+        const bool is_ref_str = (fe[5] - fb[5] == 3) && memcmp(fb[5], "ref", 3) == 0;
+        const int64_t dist = sp > st ? sp - st : st - sp;
+        out.is_ref.push_back((uint8_t)(is_ref_str && dist == W));  // score_sequences.py:305-307
+        out.local_name.push_back(nid);
+        p = next;
+    }
+    munmap(map, len);
+}
+
+}  // namespace
+
+struct gfm_tsv {
+    int W = 0;
+    int64_t n = 0;
+    std::vector<FileCols> files;
+    std::vector<int64_t> row_base;          // per file
+    std::vector<std::string> names;         // global distinct REGION strings
+    std::vector<std::vector<int32_t>> remap;  // per file: local name id -> global
+};
+
+GFM_API int gfm_tsv_open(const char *const *paths, int n_paths, int width, int skip_reverse,
+                         int n_threads, gfm_tsv_t *out, int64_t *n_rows)
+{
+    if (!out || !n_rows || (n_paths > 0 && !paths)) { t_err = "NULL argument"; return GFM_ERR_INVALID; }
+    *out = nullptr;
+    *n_rows = 0;
+    if (width < 1 || n_paths < 0) { t_err = "bad width or path count"; return GFM_ERR_INVALID; }
+    gfm_tsv *t = new (std::nothrow) gfm_tsv();
+    if (!t) { t_err = "out of memory"; return GFM_ERR_NOMEM; }
+    t->W = width;
+    t->files.resize((size_t)n_paths);
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > n_paths) nt = n_paths;
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_paths) break;
+            try {
+                parse_file(paths[i], width, skip_reverse != 0, t->files[(size_t)i]);
+            } catch (const std::bad_alloc &) {
+                t->files[(size_t)i].error = "out of memory";
+            }
+        }
+    };
+    if (nt <= 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        for (int k = 0; k < nt; ++k) pool.emplace_back(work);
+        for (auto &th : pool) th.join();
+    }
+    for (auto &f : t->files)
+        if (!f.error.empty()) {
+            t_err = f.error;
+            delete t;
+            return GFM_ERR_IO;
+        }
+    std::unordered_map<std::string, int32_t> gix;
+    t->row_base.resize((size_t)n_paths);
+    t->remap.resize((size_t)n_paths);
+    int64_t n = 0;
+    for (int i = 0; i < n_paths; ++i) {
+        FileCols &f = t->files[(size_t)i];
+        t->row_base[(size_t)i] = n;
+        n += (int64_t)f.start.size();
+        auto &rm = t->remap[(size_t)i];
+        rm.resize(f.names.size());
+        for (size_t k = 0; k < f.names.size(); ++k) {
+            auto it = gix.find(f.names[k]);
+            if (it == gix.end()) {
+                rm[k] = (int32_t)t->names.size();
+                gix.emplace(f.names[k], rm[k]);
+                t->names.push_back(f.names[k]);
+            } else {
+                rm[k] = it->second;
+            }
+        }
+    }
+    t->n = n;
+    *n_rows = n;
+    *out = t;
+    return GFM_OK;
+}
+
+GFM_API int gfm_tsv_read(gfm_tsv_t t, uint8_t *kmers, int64_t *start, int64_t *stop, uint8_t *strand,
+                         int64_t *freq, uint8_t *is_ref, int32_t *file_id, int32_t *name_id)
+{
+    if (!t) { t_err = "NULL handle"; return GFM_ERR_INVALID; }
+    for (size_t i = 0; i < t->files.size(); ++i) {
+        const FileCols &f = t->files[i];
+        const int64_t b = t->row_base[i];
+        const size_t m = f.start.size();
+        if (!m) continue;
+        if (kmers) memcpy(kmers + (size_t)b * (size_t)t->W, f.kmers.data(), m * (size_t)t->W);
+        if (start) memcpy(start + b, f.start.data(), m * sizeof(int64_t));
+        if (stop) memcpy(stop + b, f.stop.data(), m * sizeof(int64_t));
+        if (freq) memcpy(freq + b, f.freq.data(), m * sizeof(int64_t));
+        if (strand) memcpy(strand + b, f.strand.data(), m);
+        if (is_ref) memcpy(is_ref + b, f.is_ref.data(), m);
+        if (file_id) for (size_t k = 0; k < m; ++k) file_id[b + (int64_t)k] = (int32_t)i;
+        if (name_id) {
+            const auto &rm = t->remap[i];
+            for (size_t k = 0; k < m; ++k) name_id[b + (int64_t)k] = rm[(size_t)f.local_name[k]];
+        }
+    }
+    return GFM_OK;
+}
+
+GFM_API int gfm_tsv_name_count(gfm_tsv_t t) { return t ? (int)t->names.size() : 0; }
+
+GFM_API int64_t gfm_tsv_names_bytes(gfm_tsv_t t)
+{
+    if (!t) return 0;
+    int64_t s = 0;
+    for (const auto &x : t->names) s += (int64_t)x.size();
+    return s;
+}
+
+GFM_API int gfm_tsv_names(gfm_tsv_t t, int64_t *offsets, char *bytes)
+{
+    if (!t || !offsets || (!bytes && gfm_tsv_names_bytes(t))) { t_err = "NULL argument"; return GFM_ERR_INVALID; }
+    int64_t o = 0;
+    for (size_t i = 0; i < t->names.size(); ++i) {
+        offsets[i] = o;
+        memcpy(bytes + o, t->names[i].data(), t->names[i].size());
+        o += (int64_t)t->names[i].size();
+    }
+    offsets[t->names.size()] = o;
+    return GFM_OK;
+}
+
+GFM_API void gfm_tsv_close(gfm_tsv_t t) { delete t; }
+

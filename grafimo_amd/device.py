@@ -1,0 +1,200 @@
+"""Device-side objects: a motif resident in HBM and the scoring pipeline around it.
+
+Everything numeric is done by libgrafimo_hip.so; torch is used only for device
+buffers, streams and (in distributed.py) torch.distributed over RCCL.
+"""
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _native as nv
+
+RANGE = nv.RANGE
+
+
+def _torch():
+    import torch  # deferred: importing grafimo_amd must stay cheap and GPU-free
+    return torch
+
+
+class DeviceMotif:
+    """Numeric content of a ``Motif`` on the current HIP device (gfm_motif_t).
+
+    score_matrix int [4,W] rows A,C,G,T; bg f64[4]; pmf (``pval_matrix``) optional --
+    when omitted the Staden DP of comp_pval_mat (motif_processing.pyx:552-603) runs on
+    the device.
+    """
+
+    def __init__(self, score_matrix, bg, min_val, scale, offset, pmf: Optional[np.ndarray] = None):
+        sm = np.ascontiguousarray(score_matrix, dtype=np.int64)
+        if sm.ndim != 2 or sm.shape[0] != 4:
+            raise ValueError("score_matrix must be [4, W]")
+        bg = np.ascontiguousarray(bg, dtype=np.float64)
+        self.width = int(sm.shape[1])
+        self.L = RANGE * self.width + 1
+        self.min_val = int(min_val)
+        self.scale = int(scale)
+        self.offset = float(offset)
+        if pmf is not None:
+            pmf = np.ascontiguousarray(pmf, dtype=np.float64)
+            if pmf.shape != (self.L,):
+                raise ValueError(f"pval_matrix must have {self.L} entries")
+        h = ctypes.c_void_p()
+        nv.check(nv.lib().gfm_motif_create(nv.ptr(sm), self.width, nv.ptr(bg), self.min_val,
+                                           self.scale, self.offset, nv.ptr(pmf), ctypes.byref(h)))
+        self._h = h
+        lo, hi = ctypes.c_int32(), ctypes.c_int32()
+        nv.check(nv.lib().gfm_motif_score_range(self._h, ctypes.byref(lo), ctypes.byref(hi)))
+        self.score_lo, self.score_hi = lo.value, hi.value
+
+    @classmethod
+    def from_motif(cls, motif, use_motif_pmf=True):
+        pmf = None
+        if use_motif_pmf:
+            try:
+                pmf = motif.pval_matrix
+            except AttributeError:
+                pmf = None
+        return cls(motif.dense_score_matrix(), motif.dense_bg(), motif.min_val, motif.scale,
+                   motif.offset, pmf)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            nv.lib().gfm_motif_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- tables
+    def tables(self):
+        """(pmf, p_table) as host f64[L] arrays."""
+        pmf = np.empty(self.L, dtype=np.float64)
+        pt = np.empty(self.L, dtype=np.float64)
+        nv.check(nv.lib().gfm_motif_tables(self._h, nv.ptr(pmf), nv.ptr(pt)))
+        return pmf, pt
+
+    def pvalue_cutoff(self, threshold: float) -> int:
+        c = ctypes.c_int32()
+        nv.check(nv.lib().gfm_motif_pvalue_cutoff(self._h, float(threshold), ctypes.byref(c)))
+        return c.value
+
+    def annotate(self, scaled_scores):
+        """scaled int scores -> (log-odds f64, p-value f64) (score_sequences.py:390-393)."""
+        s = np.ascontiguousarray(scaled_scores, dtype=np.int32)
+        lo = np.empty(len(s), dtype=np.float64)
+        pv = np.empty(len(s), dtype=np.float64)
+        nv.check(nv.lib().gfm_motif_annotate(self._h, nv.ptr(s), len(s), nv.ptr(lo), nv.ptr(pv)))
+        return lo, pv
+
+    # ---- device-pointer entry points (torch tensors as buffers)
+    def score(self, kmers, scores, hist=None, select_cutoff=None, row_base=0, hit_rows=None,
+              hit_count=None, stream=None):
+        """Enqueue gfm_score_kmers.  kmers uint8 [n,W] (cuda), scores int32 [n],
+        hist int64 [L] (accumulated), hit_rows int64 [cap], hit_count int64 [1]."""
+        n = int(kmers.shape[0])
+        assert kmers.is_contiguous() and kmers.dtype == _torch().uint8
+        assert n == 0 or kmers.shape[1] == self.width
+        cut = nv.GFM_NO_SELECT if select_cutoff is None else int(select_cutoff)
+        nv.check(nv.lib().gfm_score_kmers(
+            self._h, kmers.data_ptr() if n else None, n, scores.data_ptr() if n else None,
+            hist.data_ptr() if hist is not None else None, cut, int(row_base),
+            hit_rows.data_ptr() if hit_rows is not None else None,
+            int(hit_rows.numel()) if hit_rows is not None else 0,
+            hit_count.data_ptr() if hit_count is not None else None,
+            _stream_ptr(stream)))
+
+    def qvalue_table(self, hist, threshold, on_qvalue, qtable=None, cutoff=None, nrows=None,
+                     stream=None):
+        nv.check(nv.lib().gfm_qvalue_table(
+            self._h, hist.data_ptr(), float(threshold), int(bool(on_qvalue)),
+            qtable.data_ptr() if qtable is not None else None,
+            cutoff.data_ptr() if cutoff is not None else None,
+            nrows.data_ptr() if nrows is not None else None, _stream_ptr(stream)))
+
+    @staticmethod
+    def select_hits(scores, cutoff, hit_rows, hit_count, row_base=0, stream=None):
+        n = int(scores.numel())
+        nv.check(nv.lib().gfm_select_hits(scores.data_ptr() if n else None, n, cutoff.data_ptr(),
+                                          int(row_base), hit_rows.data_ptr(), int(hit_rows.numel()),
+                                          hit_count.data_ptr(), _stream_ptr(stream)))
+
+    # ---- host one-call form
+    def scan_host(self, kmers: np.ndarray, threshold: float, on_qvalue=False, want_qvalues=True,
+                  capacity: Optional[int] = None):
+        """gfm_scan_host: returns dict(rows, scaled, logodds, pvalue[, qvalue]) for the hits,
+        ascending by row."""
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint8)
+        n = int(kmers.shape[0])
+        if n and kmers.shape[1] != self.width:
+            raise ValueError("k-mer width differs from the motif width")
+        cap = n if capacity is None else int(capacity)
+        while True:
+            rows = np.empty(cap, dtype=np.int64)
+            sc = np.empty(cap, dtype=np.int32)
+            lo = np.empty(cap, dtype=np.float64)
+            pv = np.empty(cap, dtype=np.float64)
+            qv = np.empty(cap, dtype=np.float64) if want_qvalues else None
+            nh = ctypes.c_int64(0)
+            rc = nv.lib().gfm_scan_host(self._h, nv.ptr(kmers) if n else None, n, float(threshold),
+                                        int(bool(on_qvalue)), int(bool(want_qvalues)), cap,
+                                        nv.ptr(rows), nv.ptr(sc), nv.ptr(lo), nv.ptr(pv),
+                                        nv.ptr(qv), ctypes.byref(nh))
+            if rc == nv.GFM_ERR_OVERFLOW and nh.value > cap:
+                cap = int(nh.value)
+                continue
+            nv.check(rc)
+            break
+        k = nh.value
+        out = dict(rows=rows[:k], scaled=sc[:k], logodds=lo[:k], pvalue=pv[:k])
+        if want_qvalues:
+            out["qvalue"] = qv[:k]
+        return out
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        torch = _torch()
+        return torch.cuda.current_stream().cuda_stream
+    if isinstance(stream, int):
+        return stream
+    return stream.cuda_stream
+
+
+# ---------------------------------------------------------------------------------------
+# free functions that replace the reference's motif_processing numerics (S1 seam)
+def compute_log_odds_dense(probs, bg):
+    probs = np.ascontiguousarray(probs, dtype=np.float64)
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    out = np.empty_like(probs)
+    nv.check(nv.lib().gfm_compute_log_odds(nv.ptr(probs), probs.shape[1], nv.ptr(bg), nv.ptr(out)))
+    return out
+
+
+def scale_pwm_dense(logodds):
+    lo = np.ascontiguousarray(logodds, dtype=np.float64)
+    W = lo.shape[1]
+    sm = np.empty((4, W), dtype=np.int64)
+    mn, mx, sc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    off = ctypes.c_double()
+    nv.check(nv.lib().gfm_scale_pwm(nv.ptr(lo), W, nv.ptr(sm), ctypes.byref(mn), ctypes.byref(mx),
+                                    ctypes.byref(sc), ctypes.byref(off)))
+    return sm, mn.value, mx.value, sc.value, np.double(off.value)
+
+
+def comp_pval_mat_dense(score_matrix, bg):
+    """Device DP -> host pmf f64[1000*W+1]."""
+    sm = np.ascontiguousarray(score_matrix, dtype=np.int64)
+    bg = np.ascontiguousarray(bg, dtype=np.float64)
+    W = sm.shape[1]
+    out = np.empty(RANGE * W + 1, dtype=np.float64)
+    nv.check(nv.lib().gfm_comp_pval_mat(nv.ptr(sm), W, nv.ptr(bg), nv.ptr(out)))
+    return out

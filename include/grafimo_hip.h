@@ -1,0 +1,165 @@
+/*
+ * grafimo_hip.h -- C ABI of libgrafimo_hip.so, the MI355X (gfx950) implementation of
+ * GRAFIMO's k-mer scoring hot path.
+ *
+ * GRAFIMO has no FFI of its own for this path: its native pieces are a Cython module
+ * (`motif_processing`) and a numba-jitted function.  Each entry point below names the
+ * reference interface it replaces (paths relative to /root/reference/src/grafimo/);
+ * INTEGRATION.md shows the ctypes stubs a GRAFIMO maintainer would add to call them.
+ *
+ * Conventions
+ *  - plain C types only; matrices are row-major [4][W] with rows A,C,G,T;
+ *    L = 1000*W + 1 is the length of every per-score table (RANGE=1000, utils.py:26);
+ *  - every function returns GFM_OK (0) or a negative GFM_ERR_* code and never throws;
+ *    gfm_last_error() returns a thread-local message for the last failure;
+ *  - pointers named h_* are host memory, d_* are device memory of the current HIP device
+ *    (e.g. torch tensors' data_ptr()); the library never keeps a caller pointer after return;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Functions that take
+ *    a stream only enqueue work (no allocation, no synchronisation: graph-capturable);
+ *  - HIP is initialised lazily by the first call that needs a device, never at load time,
+ *    so a host that forks workers later (extract_regions.py:128) stays legal.
+ */
+#ifndef GRAFIMO_HIP_H
+#define GRAFIMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFM_ABI_VERSION 1
+
+#define GFM_OK 0
+#define GFM_ERR_INVALID (-1)  /* bad argument (NULL, width out of range, ...)            */
+#define GFM_ERR_ASSERT (-2)   /* a reference `assert` would fire (bg<=0, prob<=0, ...)   */
+#define GFM_ERR_HIP (-3)      /* HIP runtime failure, text in gfm_last_error()           */
+#define GFM_ERR_NOMEM (-4)
+#define GFM_ERR_NODEVICE (-5) /* no usable gfx950 device                                 */
+#define GFM_ERR_IO (-6)       /* file could not be read / malformed row                  */
+#define GFM_ERR_OVERFLOW (-7) /* an output buffer was too small                          */
+
+#define GFM_MAX_WIDTH 64      /* widest motif the kernels are instantiated for           */
+#define GFM_NO_SELECT INT32_MAX
+
+/* ------------------------------------------------------------------ library / device */
+int gfm_abi_version(void);
+const char *gfm_last_error(void);
+int gfm_device_count(int *count);
+int gfm_set_device(int ordinal);
+
+/* ------------------------------------------------------------------ motif preprocessing
+ * replaces compute_log_odds(probs_matrix, width, bgs, alphabet, nucsmap, debug)
+ * (motif_processing.pyx:512-548 -> :444-507; lg2 utils.py:479-493):
+ *   out[n][j] = ln(probs[n][j] / bg[n]) * 1.44269504   (host libm, f64). */
+int gfm_compute_log_odds(const double *h_probs, int width, const double *h_bg,
+                         double *h_logodds_out);
+
+/* replaces scale_pwm(motif_matrix, alphabet, motif_width, nucsmap, debug)
+ * (motif_ops.py:1027-1111): integer scaling to [0,1000], round-half-to-even. */
+int gfm_scale_pwm(const double *h_logodds, int width, int64_t *h_score_matrix_out,
+                  int *min_val, int *max_val, int *scale, double *offset);
+
+/* replaces comp_pval_mat(motif, debug) (motif_processing.pyx:608-632 -> :552-603):
+ * Staden-1994 score-distribution DP, run ON DEVICE; h_pmf_out has L doubles
+ * (last DP row, un-normalised), bit-identical to the reference's. */
+int gfm_comp_pval_mat(const int64_t *h_score_matrix, int width, const double *h_bg,
+                      double *h_pmf_out);
+
+/* ------------------------------------------------------------------ device-resident motif
+ * The numeric content of a reference `Motif` (motif.py:18) that scoring reads:
+ * score_matrix, bg, min_val, scale, offset, width, pval_matrix. */
+typedef struct gfm_motif *gfm_motif_t;
+
+/* Uploads the tables to the current device.  If h_pmf is NULL the DP of
+ * gfm_comp_pval_mat runs on device; otherwise h_pmf (L doubles) is taken as the motif's
+ * pval_matrix.  Also builds p_table[s] = sum(pmf[s:]) / sum(pmf) on device -- the O(1)
+ * form of score_sequences.py:390-391 -- and the kernel workspace. */
+int gfm_motif_create(const int64_t *h_score_matrix, int width, const double *h_bg,
+                     int min_val, int scale, double offset, const double *h_pmf,
+                     gfm_motif_t *out);
+void gfm_motif_destroy(gfm_motif_t m);
+int gfm_motif_width(gfm_motif_t m);
+int gfm_motif_table_len(gfm_motif_t m); /* L */
+/* lowest / highest reachable scaled score (support of the pmf) */
+int gfm_motif_score_range(gfm_motif_t m, int32_t *lo, int32_t *hi);
+/* host copies of the device tables (either pointer may be NULL) */
+int gfm_motif_tables(gfm_motif_t m, double *h_pmf_out, double *h_ptable_out);
+/* smallest scaled score s with p_table[s] < threshold (strict, resultsTmp.py:303-307);
+ * L if none. */
+int gfm_motif_pvalue_cutoff(gfm_motif_t m, double threshold, int32_t *cutoff);
+/* (scaled score) -> log-odds and p-value for a few rows on the host:
+ * logodds = s/scale + W*offset (score_sequences.py:393), p = p_table[s]. */
+int gfm_motif_annotate(gfm_motif_t m, const int32_t *h_scores, int64_t n,
+                       double *h_logodds_out, double *h_pvalue_out);
+
+/* ------------------------------------------------------------------ scoring
+ * replaces the per-row body of score_seqs + compute_score_seq
+ * (score_sequences.py:273-321, :331-396) for a dense batch of k-mers.
+ *   d_kmers    uint8 [n][W], ASCII, row-major, 16-byte aligned base: the KMER column of
+ *              the vg TSV rows.  A/a C/c G/g T/t score; a row holding 'N' (or any other
+ *              byte whose bits 1-3 do not name A,C,G,T) scores min_val (:376-378).
+ *   d_scores   int32 [n] out: scaled integer scores.
+ *   d_hist     uint64 [L] in/out or NULL: d_hist[s] += #rows scored s.
+ *   select_cutoff / d_hit_*: if select_cutoff != GFM_NO_SELECT, rows with
+ *              score >= select_cutoff get (row_base + row) appended to d_hit_rows
+ *              (unordered) and *d_hit_count incremented; rows beyond hit_capacity are
+ *              counted but not stored.
+ * Enqueues on `stream`; no synchronisation. */
+int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, int32_t *d_scores,
+                    uint64_t *d_hist, int32_t select_cutoff, int64_t row_base,
+                    int64_t *d_hit_rows, int64_t hit_capacity, uint64_t *d_hit_count,
+                    void *stream);
+
+/* replaces compute_qvalues(pvalues, debug) (score_sequences.py:401-428; statsmodels
+ * fdr_bh): Benjamini-Hochberg q-value of every scaled score, from the score histogram
+ * of ALL scored rows:  q(s) = min(1, min_{s'<=s, hist[s']>0} p(s') / (C(s')/n)),
+ * C(s') = #rows with score >= s'.  Also the selection cutoff: the smallest s with
+ * (on_qvalue ? q(s) : p(s)) < threshold.  All outputs are device memory; any may be NULL. */
+int gfm_qvalue_table(gfm_motif_t m, const uint64_t *d_hist, double threshold, int on_qvalue,
+                     double *d_qtable_out, int32_t *d_cutoff_out, uint64_t *d_nrows_out,
+                     void *stream);
+
+/* replaces the threshold filter of ResultTmp.to_df (resultsTmp.py:303-307) on device:
+ * appends row_base+row for every row with d_scores[row] >= *d_cutoff. */
+int gfm_select_hits(const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
+                    int64_t row_base, int64_t *d_hit_rows, int64_t hit_capacity,
+                    uint64_t *d_hit_count, void *stream);
+
+/* ------------------------------------------------------------------ one-call host form
+ * compute_results' numeric core (score_sequences.py:44-211) for host-resident k-mers:
+ * H2D, score, histogram, q-table, threshold, D2H of the hits only.
+ *   h_kmers uint8 [n][W]; threshold in (0,1]; on_qvalue: threshold applies to q (--qvalueT);
+ *   want_qvalues: compute q-values (0 = --no-qvalue);
+ *   outputs (caller-allocated, capacity rows each; h_qvalue_out may be NULL):
+ *   hit rows ascending by row index with their scaled score, log-odds, p-value, q-value. */
+int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, double threshold,
+                  int on_qvalue, int want_qvalues, int64_t capacity, int64_t *h_hit_rows_out,
+                  int32_t *h_hit_scores_out, double *h_logodds_out, double *h_pvalue_out,
+                  double *h_qvalue_out, int64_t *n_hits_out);
+
+/* ------------------------------------------------------------------ TSV ingest (host, C++)
+ * replaces the text handling of score_seqs (score_sequences.py:273-293, :305-307):
+ * parses vg's 7-column rows  REGION KMER CHR:START(+|-) CHR:STOP(+|-) COUNT ref|non.ref PATH
+ * into columnar arrays.  Two calls: gfm_tsv_open counts, gfm_tsv_read fills. */
+typedef struct gfm_tsv *gfm_tsv_t;
+/* Parses every file (host threads) and reports the number of kept rows.
+ * skip_reverse: drop '-' rows before they are counted (--no-reverse, :281-282). */
+int gfm_tsv_open(const char *const *paths, int n_paths, int width, int skip_reverse,
+                 int n_threads, gfm_tsv_t *out, int64_t *n_rows);
+/* Copies the parsed columns out (any pointer may be NULL):
+ * kmers uint8[n][W]; start/stop int64[n]; strand uint8[n] ('+'/'-'); freq int64[n];
+ * is_ref uint8[n] (1 = "ref" after the indel fix :305-307, 0 = "non.ref");
+ * file_id int32[n] (index into paths); name_id int32[n] (index into the REGION names). */
+int gfm_tsv_read(gfm_tsv_t t, uint8_t *kmers, int64_t *start, int64_t *stop, uint8_t *strand,
+                 int64_t *freq, uint8_t *is_ref, int32_t *file_id, int32_t *name_id);
+/* distinct REGION strings: count, total bytes, then offsets[count+1] + bytes */
+int gfm_tsv_name_count(gfm_tsv_t t);
+int64_t gfm_tsv_names_bytes(gfm_tsv_t t);
+int gfm_tsv_names(gfm_tsv_t t, int64_t *offsets, char *bytes);
+void gfm_tsv_close(gfm_tsv_t t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAFIMO_HIP_H */

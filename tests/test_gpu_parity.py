@@ -1,0 +1,231 @@
+"""HIP path vs the CPU oracle / golden vectors -- through the C ABI, on a real MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REF_DATA, kmers_from_strings
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from grafimo_amd import _native as nv
+    assert os.path.exists(nv.LIB_PATH), "libgrafimo_hip.so not built"
+    assert nv.device_count() >= 1
+    return torch.device("cuda:0")
+
+
+def random_kmers(rng, n, w, n_frac=0.001, lower_frac=0.05):
+    km = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(n, w))
+    if n:
+        nn = rng.random(n) < n_frac
+        pos = rng.integers(0, w, size=n)
+        km[nn, pos[nn]] = ord("N")
+        low = rng.random(n) < lower_frac
+        km[low] |= 0x20  # lowercase (turns N into n on a few rows as well)
+        # the reference leaves lowercase 'n' undefined; keep inputs inside its domain
+        km[km == ord("n")] = ord("N")
+    return km
+
+
+def test_dp_bit_exact_all_golden_motifs(dev, golden_motifs):
+    from grafimo_amd.device import comp_pval_mat_dense
+    _, flat = golden_motifs
+    for key, m in flat.items():
+        pmf = comp_pval_mat_dense(m["score_matrix"], m["bg"])
+        assert np.array_equal(pmf, m["pmf"]), key
+
+
+def test_host_log_odds_and_scaling(dev, golden_motifs):
+    from grafimo_amd.device import compute_log_odds_dense, scale_pwm_dense
+    _, flat = golden_motifs
+    for key, m in flat.items():
+        lo = compute_log_odds_dense(m["probs"], m["bg"])
+        np.testing.assert_allclose(lo, m["logodds"], rtol=1e-14, atol=0)
+        sm, mn, mx, sc, off = scale_pwm_dense(lo)
+        assert (sm == m["score_matrix"]).all(), key
+        assert (mn, mx, sc, float(off)) == (m["min_val"], m["max_val"], m["scale"], m["offset"])
+
+
+def test_ptable_matches_per_row_tail_sums(dev, golden_motifs):
+    from grafimo_amd.device import DeviceMotif
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    lib = orc.lib()
+    for key in ["ctcf_meme_unif#0", "syn30_jaspar_bg0#0", "multi_meme_bg1#0", "gata1_meme_bgnt#0"]:
+        m = flat[key]
+        dm = DeviceMotif(m["score_matrix"], m["bg"], m["min_val"], m["scale"], m["offset"])
+        pmf, pt = dm.tables()
+        assert np.array_equal(pmf, m["pmf"])
+        assert (pt[: dm.score_lo + 1] == 1.0).all()
+        assert (np.diff(pt) <= 0).all()
+        tot = lib.orc_np_sum(pmf.ctypes.data_as(orc._c_dp), len(pmf))
+        rng = np.random.default_rng(7)
+        for s in rng.integers(dm.score_lo, dm.score_hi + 1, size=200):
+            tail = lib.orc_np_sum(pmf[s:].ctypes.data_as(orc._c_dp), len(pmf) - int(s))
+            # tolerance: north_star asks 1e-6 on floats; the tables agree to ~1e-15
+            assert abs(pt[s] - tail / tot) <= 1e-12 * max(pt[s], 1e-300), (key, s)
+        dm.close()
+
+
+@pytest.mark.parametrize("key", ["ctcf_meme_unif#0", "syn30_jaspar_bg0#0", "multi_meme_bg1#0",
+                                 "multi_meme_bg1#2", "multi_meme_bg1#5", "gata1_meme_bgnt#0"])
+def test_scores_and_histogram_vs_oracle(dev, golden_motifs, key):
+    from grafimo_amd.device import DeviceMotif
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    m = flat[key]
+    W = m["width"]
+    dm = DeviceMotif(m["score_matrix"], m["bg"], m["min_val"], m["scale"], m["offset"], m["pmf"])
+    _, pt = dm.tables()
+    rng = np.random.default_rng(W)
+    for n in [0, 1, 63, 64, 65, 127, 128, 129, 1000, 4097, 100003]:
+        km = random_kmers(rng, n, W, n_frac=0.01)
+        d_km = torch.from_numpy(km).to(dev) if n else torch.empty((0, W), dtype=torch.uint8, device=dev)
+        d_sc = torch.full((n,), -7, dtype=torch.int32, device=dev)
+        d_hist = torch.zeros(dm.L, dtype=torch.int64, device=dev)
+        dm.score(d_km, d_sc, hist=d_hist)
+        torch.cuda.synchronize()
+        got = d_sc.cpu().numpy()
+        exp, _ = orc.score_kmers_table(km, m["score_matrix"], pt, m["min_val"]) if n else (np.empty(0, np.int32), None)
+        assert np.array_equal(got, exp), (key, n)
+        hist = d_hist.cpu().numpy()
+        assert np.array_equal(hist, np.bincount(exp, minlength=dm.L)), (key, n)
+        # accumulate semantics: a second pass doubles the histogram
+        if n:
+            dm.score(d_km, d_sc, hist=d_hist)
+            torch.cuda.synchronize()
+            assert np.array_equal(d_hist.cpu().numpy(), 2 * hist)
+    dm.close()
+
+
+def test_fused_and_separate_selection(dev, golden_motifs):
+    from grafimo_amd.device import DeviceMotif
+    _, flat = golden_motifs
+    m = flat["ctcf_meme_unif#0"]
+    dm = DeviceMotif(m["score_matrix"], m["bg"], m["min_val"], m["scale"], m["offset"], m["pmf"])
+    rng = np.random.default_rng(3)
+    n = 300001
+    km = random_kmers(rng, n, 19)
+    d_km = torch.from_numpy(km).to(dev)
+    d_sc = torch.empty(n, dtype=torch.int32, device=dev)
+    for thr in [1e-1, 1e-2, 1e-3]:
+        cut = dm.pvalue_cutoff(thr)
+        rows = torch.empty(n, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        dm.score(d_km, d_sc, select_cutoff=cut, row_base=1000, hit_rows=rows, hit_count=cnt)
+        torch.cuda.synchronize()
+        sc = d_sc.cpu().numpy()
+        exp = np.nonzero(sc >= cut)[0] + 1000
+        k = int(cnt.item())
+        assert k == len(exp)
+        assert np.array_equal(np.sort(rows[:k].cpu().numpy()), exp)
+        # separate pass with a device-side cutoff
+        rows2 = torch.empty(n, dtype=torch.int64, device=dev)
+        cnt2 = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_cut = torch.tensor([cut], dtype=torch.int32, device=dev)
+        dm.select_hits(d_sc, d_cut, rows2, cnt2, row_base=1000)
+        torch.cuda.synchronize()
+        assert int(cnt2.item()) == k
+        assert np.array_equal(np.sort(rows2[:k].cpu().numpy()), exp)
+        # capacity overflow: counted, not stored past the end
+        small = torch.full((8,), -1, dtype=torch.int64, device=dev)
+        cnt3 = torch.zeros(1, dtype=torch.int64, device=dev)
+        dm.select_hits(d_sc, d_cut, small, cnt3)
+        torch.cuda.synchronize()
+        assert int(cnt3.item()) == k
+    dm.close()
+
+
+def test_qvalue_table_vs_sorted_bh(dev, golden_motifs):
+    from grafimo_amd.device import DeviceMotif
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    for key, n in [("ctcf_meme_unif#0", 50000), ("multi_meme_bg1#0", 20000), ("syn30_jaspar_bg0#0", 3000)]:
+        m = flat[key]
+        dm = DeviceMotif(m["score_matrix"], m["bg"], m["min_val"], m["scale"], m["offset"], m["pmf"])
+        _, pt = dm.tables()
+        rng = np.random.default_rng(n)
+        km = random_kmers(rng, n, m["width"], n_frac=0.01)
+        d_km = torch.from_numpy(km).to(dev)
+        d_sc = torch.empty(n, dtype=torch.int32, device=dev)
+        d_hist = torch.zeros(dm.L, dtype=torch.int64, device=dev)
+        dm.score(d_km, d_sc, hist=d_hist)
+        q = torch.empty(dm.L, dtype=torch.float64, device=dev)
+        cut = torch.zeros(1, dtype=torch.int32, device=dev)
+        nrows = torch.zeros(1, dtype=torch.int64, device=dev)
+        for on_q, thr in [(False, 1e-2), (True, 0.5), (True, 1.0), (False, 1.0)]:
+            dm.qvalue_table(d_hist, thr, on_q, q, cut, nrows)
+            torch.cuda.synchronize()
+            sc = d_sc.cpu().numpy()
+            pv = pt[sc]
+            q_exp = orc.fdr_bh(pv)
+            q_got = q.cpu().numpy()[sc]
+            np.testing.assert_allclose(q_got, q_exp, rtol=1e-12, atol=0)
+            assert int(nrows.item()) == n
+            val = q_got if on_q else pv
+            exp_hits = val < thr
+            assert np.array_equal(sc >= int(cut.item()), exp_hits), (key, on_q, thr)
+        dm.close()
+
+
+def test_reference_704_row_fixture_through_scan_host(dev, golden_motifs, golden_json):
+    """BASELINE config 1: the reference's own scoring fixture, GPU path end to end
+    (numeric core; the DataFrame layer is covered by test_compute_results_gpu)."""
+    from grafimo_amd.device import DeviceMotif
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    m = flat["ctcf_meme_unif#0"]
+    cols = orc.parse_tsv_rows([os.path.join(REF_DATA, "width_19", "scoring_test_input.tsv")])
+    km = kmers_from_strings(cols["seq"])
+    dm = DeviceMotif(m["score_matrix"], m["bg"], m["min_val"], m["scale"], m["offset"])  # device DP
+    res = dm.scan_host(km, 1.0, on_qvalue=False, want_qvalues=True)
+    assert len(res["rows"]) == 704 and np.array_equal(res["rows"], np.arange(704))
+    exp = golden_json("compute_results.json")["recomb_t1"]["df"]
+    ecols = exp["columns"]
+    erows = {(r[ecols.index("start")], r[ecols.index("stop")], r[ecols.index("strand")],
+              r[ecols.index("matched_sequence")]): r for r in exp["rows"]}
+    for i in range(704):
+        r = erows[(cols["start"][i], cols["stop"][i], cols["strand"][i], cols["seq"][i])]
+        assert res["logodds"][i] == r[ecols.index("score")]
+        assert abs(res["pvalue"][i] - r[ecols.index("p-value")]) <= 1e-12 * r[ecols.index("p-value")]
+        assert abs(res["qvalue"][i] - r[ecols.index("q-value")]) <= 1e-12 * r[ecols.index("q-value")]
+    # q-value threshold mode selects the same rows as the reference
+    expq = golden_json("compute_results.json")["qvalt_t0.6"]["df"]
+    resq = dm.scan_host(km, 0.6, on_qvalue=True, want_qvalues=True)
+    # reference applied --recomb=False there: drop freq == 0 rows on the host
+    keep = [i for i in resq["rows"] if cols["freq"][i] > 0]
+    assert len(keep) == len(expq["rows"])
+    dm.close()
+
+
+def test_full_size_config2_scores_exact(dev, golden_motifs):
+    """BASELINE config 2 size (2e7 k-mers, W=19): every integer score equals the CPU
+    restatement's, the histogram is the bincount, totals are conserved."""
+    from grafimo_amd.device import DeviceMotif
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    m = flat["ctcf_meme_unif#0"]
+    dm = DeviceMotif(m["score_matrix"], m["bg"], m["min_val"], m["scale"], m["offset"], m["pmf"])
+    _, pt = dm.tables()
+    n = 20_000_000
+    rng = np.random.default_rng(20240139 + 2)
+    km = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(n, 19))
+    km[rng.integers(0, n, size=n // 1000), rng.integers(0, 19, size=n // 1000)] = ord("N")
+    d_km = torch.from_numpy(km).to(dev)
+    d_sc = torch.empty(n, dtype=torch.int32, device=dev)
+    d_hist = torch.zeros(dm.L, dtype=torch.int64, device=dev)
+    dm.score(d_km, d_sc, hist=d_hist)
+    torch.cuda.synchronize()
+    got = d_sc.cpu().numpy()
+    exp, _ = orc.score_kmers_table(km, m["score_matrix"], pt, m["min_val"])
+    assert np.array_equal(got, exp)
+    hist = d_hist.cpu().numpy()
+    assert hist.sum() == n
+    assert np.array_equal(hist, np.bincount(exp, minlength=dm.L))
+    dm.close()
