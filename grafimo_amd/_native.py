@@ -52,6 +52,8 @@ PROTOTYPES = {
     "gfm_motif_annotate": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "gfm_score_kmers": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_i64,
                                 c_void_p, c_i64, c_void_p, c_void_p]),
+    "gfm_profile_enable": (c_int, [c_void_p, c_int]),
+    "gfm_profile_read": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
     "gfm_qvalue_table": (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
     "gfm_select_hits": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
@@ -78,6 +80,32 @@ class NativeError(RuntimeError):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (SONAME libamdhip64.so.7, the same as /opt/rocm's) but link it by file name,
+    so if /opt/rocm's copy were loaded first torch would load a second runtime next to it and
+    every later HIP call would misbehave.  When torch is installed, load ITS runtime first
+    (without importing torch): our NEEDED libamdhip64.so.7 then binds to that copy by SONAME.
+    GRAFIMO_HIP_RUNTIME=/path/to/libamdhip64.so overrides; "system" skips the preload."""
+    import importlib.util
+    override = os.environ.get("GRAFIMO_HIP_RUNTIME", "")
+    if override == "system":
+        return None
+    path = override
+    if not path:
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is not None and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                path = cand
+    if path:
+        return ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    return None
+
+
 def lib():
     """The loaded library (loads on first use; raises if it was not built)."""
     global _lib
@@ -88,6 +116,7 @@ def lib():
                 "(or python -c 'import __graft_entry__ as g; g.build()'). "
                 "grafimo_amd has no CPU fallback."
             )
+        _preload_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol

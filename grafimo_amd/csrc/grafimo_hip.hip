@@ -57,8 +57,12 @@ constexpr int kChunk = 128;                    // k-mers per wave per iteration 
 constexpr unsigned kPoison = 0xFFFFu;          // table entry of a byte that is not A,C,G,T (> 1000*64)
 constexpr int kMaxLdsBytes = 160 * 1024;
 constexpr int kWGsPerCU = 3;                   // target residency of the score kernel
+constexpr int kHitQueue = 128;                 // per-wave LDS hit queue (entries)
 
-__host__ __device__ inline int stage_stride_bytes(int W) { return ((kChunk * W + 15) & ~15) + 16; }
+// per-wave LDS strip: the staged chunk (+16 B slack for the last row's trailing dword),
+// followed by the wave's hit queue
+__host__ __device__ inline int stage_data_bytes(int W) { return ((kChunk * W + 15) & ~15) + 16; }
+__host__ __device__ inline int stage_stride_bytes(int W) { return stage_data_bytes(W) + kHitQueue * 8; }
 
 // ---------------------------------------------------------------------------------------
 // score_hist_kernel<NDW, SELECT>
@@ -130,6 +134,22 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
         }
     };
 
+    // Hits are queued per wave in LDS and flushed with ONE global atomic per ~128 hits: a
+    // returning atomic on a single counter word saturates near 88 ops/us chip-wide
+    // (MI355X_MICROARCH "dequeue"), which at one atomic per hitting wave cost 1.7 ms here.
+    long long *hitq = reinterpret_cast<long long *>(stage + stage_data_bytes(W));
+    int qn = 0;  // wave-uniform
+    auto flush_hits = [&]() {
+        if (qn > 0) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(hit_count, (unsigned long long)qn);
+            base = __shfl(base, 0);
+            for (int i = lane; i < qn; i += kWave)
+                if ((long long)(base + i) < hit_cap) hit_rows[base + i] = hitq[i];
+            qn = 0;
+        }
+    };
+
     long long c = (long long)blockIdx.x * kWavesPerWG + wave;
     if (c < nchunks) fetch(c);
     for (; c < nchunks; c += cstride) {
@@ -175,14 +195,12 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
                 const bool hit = live && score >= cutoff;
                 const unsigned long long mask = __ballot(hit);
                 if (mask) {
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(hit_count, (unsigned long long)__popcll(mask));
-                    base = __shfl(base, 0);
-                    if (hit) {
-                        const unsigned long long slot =
-                            base + __popcll(mask & ((1ull << lane) - 1ull));
-                        if ((long long)slot < hit_cap) hit_rows[slot] = row_base + row;
-                    }
+                    const int nh = __popcll(mask);
+                    if (qn + nh > kHitQueue) flush_hits();
+                    if (hit)
+                        hitq[qn + __popcll(mask & ((1ull << lane) - 1ull))] =
+                            ((row_base + row) << GFM_HIT_SCORE_BITS) | (long long)score;
+                    qn += nh;
                 }
             }
         }
@@ -190,6 +208,8 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+
+    if (SELECT) flush_hits();
 
     if (use_hist) {
         __syncthreads();
@@ -199,16 +219,22 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
 }
 
 // Sums the per-workgroup slabs into the caller's uint64 histogram (bin lo+b; the extra
-// slab bin counts N rows, which score min_val).
+// slab bin counts N rows, which score min_val).  grid.x walks the bins, grid.y groups of
+// kSlabsPerGroup slabs: enough blocks to pull the slabs at HBM/L2 rate instead of one
+// latency-bound column walk per bin.
+constexpr int kSlabsPerGroup = 16;
 __global__ void __launch_bounds__(256)
 hist_reduce_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo,
                    int min_val, unsigned long long *__restrict__ hist64)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
+    const int g0 = blockIdx.y * kSlabsPerGroup;
+    const int g1 = min(g0 + kSlabsPerGroup, nslabs);
     unsigned long long s = 0;
     const size_t stride = (size_t)(nb + 1);
-    for (int g = 0; g < nslabs; ++g) s += partials[g * stride + b];
+#pragma unroll 8
+    for (int g = g0; g < g1; ++g) s += partials[g * stride + b];
     if (s) atomicAdd(&hist64[b == nb ? min_val : lo + b], s);
 }
 
@@ -240,7 +266,8 @@ select_hits_kernel(const int *__restrict__ scores, long long n, const int *__res
                 base = __shfl(base, 0);
                 if (hit) {
                     const unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-                    if ((long long)slot < hit_cap) hit_rows[slot] = row_base + i * 4 + j;
+                    if ((long long)slot < hit_cap)
+                        hit_rows[slot] = ((row_base + i * 4 + j) << GFM_HIT_SCORE_BITS) | (long long)s[j];
                 }
             }
         }
@@ -250,17 +277,10 @@ select_hits_kernel(const int *__restrict__ scores, long long n, const int *__res
         for (long long r = n4 * 4; r < n; ++r)
             if (scores[r] >= cutoff) {
                 const unsigned long long slot = atomicAdd(hit_count, 1ull);
-                if ((long long)slot < hit_cap) hit_rows[slot] = row_base + r;
+                if ((long long)slot < hit_cap)
+                    hit_rows[slot] = ((row_base + r) << GFM_HIT_SCORE_BITS) | (long long)scores[r];
             }
     }
-}
-
-__global__ void gather_scores_kernel(const int *__restrict__ scores,
-                                     const long long *__restrict__ rows, long long row_base,
-                                     long long cnt, int *__restrict__ out)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cnt) out[i] = scores[rows[i] - row_base];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -355,18 +375,25 @@ ptable_kernel(const double *__restrict__ pmf, int L, int lo, int hi, double *__r
 // plus the selection cutoff.  Ranks: all rows sharing a score share a p-value; the
 // largest rank in the tie group is C(s) = #rows with score >= s, and the cumulative
 // minimum makes the whole group take p(s) / (C(s)/n).
+// Only the reachable window [lo, hi] can hold counts, plus bin min_val for rows with an N
+// (below the window: p = 1, rank = n, raw = 1): the scans run over the window, split into
+// 1024 contiguous segments.
 __global__ void __launch_bounds__(kScanThreads)
 qvalue_kernel(const unsigned long long *__restrict__ hist, const double *__restrict__ ptable,
-              int L, double threshold, int on_qvalue, double *__restrict__ qtable,
-              int *__restrict__ cutoff_out, unsigned long long *__restrict__ nrows_out)
+              int L, int lo, int hi, int min_val, double threshold, int on_qvalue,
+              double *__restrict__ qtable, int *__restrict__ cutoff_out,
+              unsigned long long *__restrict__ nrows_out)
 {
     __shared__ unsigned long long cseg[kScanThreads];
     __shared__ double mseg[kScanThreads];
     __shared__ int cut_s;
     const int tid = threadIdx.x;
-    const int per = (L + kScanThreads - 1) / kScanThreads;
-    const int a = min(tid * per, L), b = min(a + per, L);
+    const int nb = hi - lo + 1;
+    const int per = (nb + kScanThreads - 1) / kScanThreads;
+    const int a = lo + min(tid * per, nb), b = lo + min(tid * per + per, nb);
     if (tid == 0) cut_s = L;
+    const bool n_outside = min_val < lo || min_val > hi;
+    const unsigned long long n_rows_N = n_outside ? hist[min_val] : 0ull;
 
     unsigned long long c = 0;
     for (int j = a; j < b; ++j) c += hist[j];
@@ -378,22 +405,18 @@ qvalue_kernel(const unsigned long long *__restrict__ hist, const double *__restr
         cseg[tid] += v;
         __syncthreads();
     }
-    const unsigned long long n = cseg[0];
+    const unsigned long long n = cseg[0] + n_rows_N;
     const double nd = (double)n;
-    unsigned long long above = (tid + 1 < kScanThreads) ? cseg[tid + 1] : 0ull;
+    const unsigned long long above = (tid + 1 < kScanThreads) ? cseg[tid + 1] : 0ull;
 
-    // raw BH value per occupied bin, segment minimum
+    // raw BH value of every occupied bin of the segment; segment minimum
     double m = INFINITY;
     {
         unsigned long long run = above;
         for (int j = b - 1; j >= a; --j) {
             const unsigned long long h = hist[j];
             run += h;
-            if (h) {
-                const double ecdf = (double)run / nd;
-                const double raw = ptable[j] / ecdf;
-                m = fmin(m, raw);
-            }
+            if (h) m = fmin(m, ptable[j] / ((double)run / nd));
         }
     }
     mseg[tid] = m;
@@ -404,22 +427,25 @@ qvalue_kernel(const unsigned long long *__restrict__ hist, const double *__restr
         mseg[tid] = fmin(mseg[tid], v);
         __syncthreads();
     }
-    double runmin = (tid > 0) ? mseg[tid - 1] : INFINITY;
-    // walk the segment upward: counts above bin j shrink as j grows
-    unsigned long long cge = above;           // #rows with score >= b
-    for (int j = a; j < b; ++j) cge += hist[j];  // now #rows with score >= a
+    // rows holding an N sit below every other score: rank n, p = p_table[min_val] (= 1)
+    const double base = n_rows_N ? ptable[min_val] / (nd / nd) : INFINITY;
+    double runmin = fmin(base, (tid > 0) ? mseg[tid - 1] : INFINITY);
+    const double q_above = fmin(fmin(base, mseg[kScanThreads - 1]), 1.0);
+    unsigned long long cge = above;
+    for (int j = a; j < b; ++j) cge += hist[j];  // #rows with score >= a
     int first = L;
     for (int j = a; j < b; ++j) {
         const unsigned long long h = hist[j];
-        if (h) {
-            const double ecdf = (double)cge / nd;
-            runmin = fmin(runmin, ptable[j] / ecdf);
-        }
+        if (h) runmin = fmin(runmin, ptable[j] / ((double)cge / nd));
         cge -= h;
         const double q = fmin(runmin, 1.0);
         if (qtable) qtable[j] = q;
         const double val = on_qvalue ? q : ptable[j];
         if (first == L && val < threshold) first = j;
+    }
+    if (qtable) {  // outside the window: 1 below (p = 1 there), the last running minimum above
+        for (int j = tid; j < lo; j += kScanThreads) qtable[j] = fmin(base, 1.0);
+        for (int j = hi + 1 + tid; j < L; j += kScanThreads) qtable[j] = q_above;
     }
     if (first < L) atomicMin(&cut_s, first);
     __syncthreads();
@@ -449,6 +475,9 @@ struct gfm_motif {
     double *d_pmf = nullptr;
     double *d_ptable = nullptr;
     unsigned *d_partials = nullptr;
+    // measurement aid: ring of event pairs around the score kernel
+    std::vector<hipEvent_t> ev0, ev1;
+    int ev_next = 0, ev_used = 0;
 };
 
 namespace {
@@ -528,20 +557,49 @@ int run_dp(const int64_t *sm, int W, const double *bg, double *d_pmf, hipStream_
 template <int NDW>
 int launch_score(gfm_motif *m, const uint8_t *d_kmers, long long n, int *d_scores, int use_hist,
                  int nslabs, bool select, int cutoff, long long row_base, long long *d_hit_rows,
-                 long long cap, unsigned long long *d_hit_count, hipStream_t st)
+                 long long cap, unsigned long long *d_hit_count, hipStream_t st, bool prepare_only)
 {
     auto k_sel = score_hist_kernel<NDW, true>;
     auto k_nos = score_hist_kernel<NDW, false>;
     auto kern = select ? k_sel : k_nos;
-    if (m->lds_bytes > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes));
+    if (prepare_only) {  // called once from gfm_motif_create (never inside a stream capture)
+        if (m->lds_bytes > 64 * 1024) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_nos),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes));
+        }
+        return GFM_OK;
     }
+    const bool prof = !m->ev0.empty();
+    const int slot = m->ev_next;
+    if (prof) HIP_TRY(hipEventRecord(m->ev0[slot], st));
     hipLaunchKernelGGL(kern, dim3(nslabs), dim3(kThreads), m->lds_bytes, st, d_kmers, n, m->W,
                        m->d_tab, m->lo, m->nb, m->min_val, use_hist, d_scores, m->d_partials,
                        cutoff, row_base, d_hit_rows, cap, d_hit_count);
     HIP_TRY(hipGetLastError());
+    if (prof) {
+        HIP_TRY(hipEventRecord(m->ev1[slot], st));
+        m->ev_next = (slot + 1) % (int)m->ev0.size();
+        m->ev_used = std::min(m->ev_used + 1, (int)m->ev0.size());
+    }
     return GFM_OK;
+}
+
+int dispatch_score(gfm_motif *m, const uint8_t *d_kmers, long long n, int *d_scores, int use_hist,
+                   int nslabs, bool select, int cutoff, long long row_base, long long *d_hit_rows,
+                   long long cap, unsigned long long *d_hit_count, hipStream_t st, bool prepare_only)
+{
+#define GFM_CASE(N)                                                                             \
+    case N:                                                                                     \
+        return launch_score<N>(m, d_kmers, n, d_scores, use_hist, nslabs, select, cutoff,       \
+                               row_base, d_hit_rows, cap, d_hit_count, st, prepare_only);
+    switch (m->ndw) {
+        GFM_CASE(1) GFM_CASE(2) GFM_CASE(3) GFM_CASE(4) GFM_CASE(5) GFM_CASE(6) GFM_CASE(7) GFM_CASE(8)
+        GFM_CASE(9) GFM_CASE(10) GFM_CASE(11) GFM_CASE(12) GFM_CASE(13) GFM_CASE(14) GFM_CASE(15) GFM_CASE(16)
+        default: return fail(GFM_ERR_INVALID, "unsupported width %d", m->W);
+    }
+#undef GFM_CASE
 }
 
 }  // namespace
@@ -650,6 +708,8 @@ GFM_API void gfm_motif_destroy(gfm_motif_t m)
     if (m->d_pmf) (void)hipFree(m->d_pmf);
     if (m->d_ptable) (void)hipFree(m->d_ptable);
     if (m->d_partials) (void)hipFree(m->d_partials);
+    for (auto e : m->ev0) (void)hipEventDestroy(e);
+    for (auto e : m->ev1) (void)hipEventDestroy(e);
     delete m;
 }
 
@@ -734,6 +794,8 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     m->max_slabs = m->n_cu * per_cu;
     HIP_TRY_M(hipMalloc(&m->d_partials, sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->nb + 1)));
 #undef HIP_TRY_M
+    rc = dispatch_score(m, nullptr, 0, nullptr, 0, 1, false, 0, 0, nullptr, 0, nullptr, nullptr, true);
+    if (rc) return bail(rc);
     *out = m;
     return GFM_OK;
 }
@@ -805,28 +867,52 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     const long long want = (nchunks + kWavesPerWG - 1) / kWavesPerWG;
     const int nslabs = (int)std::min<long long>(want, m->max_slabs);
 
-    int rc;
-#define GFM_CASE(N)                                                                              \
-    case N:                                                                                      \
-        rc = launch_score<N>(m, d_kmers, n, d_scores, use_hist, nslabs, select, select_cutoff,   \
-                             row_base, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,   \
-                             reinterpret_cast<unsigned long long *>(d_hit_count), st);           \
-        break;
-    switch (m->ndw) {
-        GFM_CASE(1) GFM_CASE(2) GFM_CASE(3) GFM_CASE(4) GFM_CASE(5) GFM_CASE(6) GFM_CASE(7) GFM_CASE(8)
-        GFM_CASE(9) GFM_CASE(10) GFM_CASE(11) GFM_CASE(12) GFM_CASE(13) GFM_CASE(14) GFM_CASE(15) GFM_CASE(16)
-        default: rc = fail(GFM_ERR_INVALID, "unsupported width %d", m->W);
-    }
-#undef GFM_CASE
+    int rc = dispatch_score(m, d_kmers, n, d_scores, use_hist, nslabs, select, select_cutoff, row_base,
+                            reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
+                            reinterpret_cast<unsigned long long *>(d_hit_count), st, false);
     if (rc) return rc;
     if (use_hist) {
         const int threads = 256;
         const int blocks = (m->nb + 1 + threads - 1) / threads;
-        hipLaunchKernelGGL(hist_reduce_kernel, dim3(blocks), dim3(threads), 0, st, m->d_partials,
+        const int groups = (nslabs + kSlabsPerGroup - 1) / kSlabsPerGroup;
+        hipLaunchKernelGGL(hist_reduce_kernel, dim3(blocks, groups), dim3(threads), 0, st, m->d_partials,
                            nslabs, m->nb, m->lo, m->min_val,
                            reinterpret_cast<unsigned long long *>(d_hist));
         HIP_TRY(hipGetLastError());
     }
+    return GFM_OK;
+}
+
+GFM_API int gfm_profile_enable(gfm_motif_t m, int slots)
+{
+    if (!m || slots < 0) return fail(GFM_ERR_INVALID, "bad argument");
+    for (auto e : m->ev0) (void)hipEventDestroy(e);
+    for (auto e : m->ev1) (void)hipEventDestroy(e);
+    m->ev0.clear();
+    m->ev1.clear();
+    m->ev_next = m->ev_used = 0;
+    for (int i = 0; i < slots; ++i) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        m->ev0.push_back(a);
+        m->ev1.push_back(b);
+    }
+    return GFM_OK;
+}
+
+GFM_API int gfm_profile_read(gfm_motif_t m, float *h_ms, int capacity, int *n_out)
+{
+    if (!m || !n_out || (!h_ms && capacity)) return fail(GFM_ERR_INVALID, "NULL argument");
+    const int slots = (int)m->ev0.size();
+    const int used = std::min(m->ev_used, capacity);
+    for (int i = 0; i < used; ++i) {
+        const int slot = ((m->ev_next - m->ev_used + i) % slots + slots) % slots;
+        HIP_TRY(hipEventSynchronize(m->ev1[slot]));
+        HIP_TRY(hipEventElapsedTime(&h_ms[i], m->ev0[slot], m->ev1[slot]));
+    }
+    *n_out = used;
+    m->ev_used = 0;
     return GFM_OK;
 }
 
@@ -836,7 +922,7 @@ GFM_API int gfm_qvalue_table(gfm_motif_t m, const uint64_t *d_hist, double thres
     if (!m || !d_hist) return fail(GFM_ERR_INVALID, "NULL argument");
     hipLaunchKernelGGL(qvalue_kernel, dim3(1), dim3(kScanThreads), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const unsigned long long *>(d_hist), m->d_ptable, m->L,
-                       threshold, on_qvalue, d_qtable, d_cutoff,
+                       m->lo, m->hi, m->min_val, threshold, on_qvalue, d_qtable, d_cutoff,
                        reinterpret_cast<unsigned long long *>(d_nrows));
     HIP_TRY(hipGetLastError());
     return GFM_OK;
@@ -879,14 +965,13 @@ GFM_API int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, doub
 
     const size_t kbytes = (size_t)n * (size_t)m->W;
     uint8_t *d_kmers = nullptr;
-    int *d_scores = nullptr, *d_cutoff = nullptr, *d_hscores = nullptr;
+    int *d_scores = nullptr, *d_cutoff = nullptr;
     unsigned long long *d_hist = nullptr, *d_count = nullptr;
     long long *d_rows = nullptr;
     double *d_q = nullptr;
     hipStream_t st = nullptr;
     int rc = GFM_OK;
     std::vector<long long> rows;
-    std::vector<int> hs;
     std::vector<double> q;
     unsigned long long cnt = 0;
     const long long cap = std::max<long long>(capacity, 1);
@@ -910,7 +995,6 @@ GFM_API int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, doub
     SCAN_TRY(hipMalloc(&d_kmers, kbytes + 16));
     SCAN_TRY(hipMalloc(&d_scores, sizeof(int) * (size_t)n));
     SCAN_TRY(hipMalloc(&d_rows, sizeof(long long) * (size_t)cap));
-    SCAN_TRY(hipMalloc(&d_hscores, sizeof(int) * (size_t)cap));
     SCAN_TRY(hipMalloc(&d_count, sizeof(unsigned long long)));
     SCAN_TRY(hipMalloc(&d_cutoff, sizeof(int)));
     SCAN_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st));
@@ -945,25 +1029,17 @@ GFM_API int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, doub
         goto done;
     }
     if (cnt) {
-        hipLaunchKernelGGL(gather_scores_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
-                           d_scores, d_rows, 0ll, (long long)cnt, d_hscores);
-        SCAN_TRY(hipGetLastError());
         rows.resize(cnt);
-        hs.resize(cnt);
         SCAN_TRY(hipMemcpyAsync(rows.data(), d_rows, sizeof(long long) * cnt, hipMemcpyDeviceToHost, st));
-        SCAN_TRY(hipMemcpyAsync(hs.data(), d_hscores, sizeof(int) * cnt, hipMemcpyDeviceToHost, st));
         if (need_hist) {
             q.resize(m->L);
             SCAN_TRY(hipMemcpyAsync(q.data(), d_q, sizeof(double) * (size_t)m->L, hipMemcpyDeviceToHost, st));
         }
         SCAN_TRY(hipStreamSynchronize(st));
-        std::vector<size_t> order(cnt);
-        for (size_t i = 0; i < cnt; ++i) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return rows[a] < rows[b]; });
+        std::sort(rows.begin(), rows.end());  // packed (row << 20 | score): ascending by row
         for (size_t i = 0; i < cnt; ++i) {
-            const size_t k = order[i];
-            const int s = hs[k];
-            if (h_rows) h_rows[i] = rows[k];
+            const int s = (int)(rows[i] & ((1ll << GFM_HIT_SCORE_BITS) - 1));
+            if (h_rows) h_rows[i] = rows[i] >> GFM_HIT_SCORE_BITS;
             if (h_scores) h_scores[i] = s;
             if (h_logodds) h_logodds[i] = ((double)s / (double)m->scale) + ((double)m->W * m->offset);
             if (h_pvalue) h_pvalue[i] = m->h_ptable[s];
@@ -976,7 +1052,6 @@ done:
     if (d_kmers) (void)hipFree(d_kmers);
     if (d_scores) (void)hipFree(d_scores);
     if (d_rows) (void)hipFree(d_rows);
-    if (d_hscores) (void)hipFree(d_hscores);
     if (d_count) (void)hipFree(d_count);
     if (d_cutoff) (void)hipFree(d_cutoff);
     if (d_hist) (void)hipFree(d_hist);

@@ -127,6 +127,16 @@ class DeviceMotif:
                                           int(row_base), hit_rows.data_ptr(), int(hit_rows.numel()),
                                           hit_count.data_ptr(), _stream_ptr(stream)))
 
+    # ---- measurement aid (bench.py)
+    def profile_enable(self, slots: int):
+        nv.check(nv.lib().gfm_profile_enable(self._h, int(slots)))
+
+    def profile_read(self, capacity: int = 4096):
+        ms = np.empty(capacity, dtype=np.float32)
+        n = ctypes.c_int(0)
+        nv.check(nv.lib().gfm_profile_read(self._h, nv.ptr(ms), capacity, ctypes.byref(n)))
+        return ms[: n.value].copy()
+
     # ---- host one-call form
     def scan_host(self, kmers: np.ndarray, threshold: float, on_qvalue=False, want_qvalues=True,
                   capacity: Optional[int] = None):

@@ -1,0 +1,136 @@
+"""Device pipeline of one motif scan: score -> histogram -> [all-reduce] -> q-table ->
+threshold -> hit list, the numeric core of compute_results (score_sequences.py:44-211).
+
+One process drives one GPU.  With a torch.distributed process group the rows are sharded
+across ranks (regions are independent: SURVEY.md section 8e) and the only exchange on the data
+path is the all-reduce of the per-motif score histogram (BH ranks are global); hit rows are
+gathered to rank 0 for the report.  The collective + table work of one batch runs on a side
+stream so that it overlaps the score kernel of the next batch.
+"""
+from typing import Optional
+
+import numpy as np
+
+from .device import DeviceMotif, _torch
+
+HIT_SCORE_BITS = 20  # GFM_HIT_SCORE_BITS: hit entry = (row << 20) | scaled score
+
+
+class ScanSlot:
+    """One set of device buffers for a batch of up to n_rows k-mers."""
+
+    def __init__(self, dm: DeviceMotif, n_rows: int, hit_capacity: int, device):
+        torch = _torch()
+        self.n_rows = int(n_rows)
+        self.hit_capacity = int(hit_capacity)
+        self.scores = torch.empty(self.n_rows, dtype=torch.int32, device=device)
+        self.hist = torch.zeros(dm.L, dtype=torch.int64, device=device)
+        self.qtable = torch.empty(dm.L, dtype=torch.float64, device=device)
+        self.cutoff = torch.zeros(1, dtype=torch.int32, device=device)
+        self.nrows = torch.zeros(1, dtype=torch.int64, device=device)
+        # [0] = hit count, [1:] = hit rows (one buffer so that one gather moves both)
+        self.hits = torch.zeros(self.hit_capacity + 1, dtype=torch.int64, device=device)
+        self.scored = torch.cuda.Event()
+        self.done = torch.cuda.Event()
+        self.gathered = None
+
+    @property
+    def hit_count(self):
+        return self.hits[:1]
+
+    @property
+    def hit_rows(self):
+        return self.hits[1:]
+
+
+class KmerScanner:
+    def __init__(self, dm: DeviceMotif, n_rows: int, hit_capacity: Optional[int] = None,
+                 device=None, group=None, n_slots: int = 2, side_stream: bool = True):
+        torch = _torch()
+        self.dm = dm
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.group = group
+        self.world = 1
+        self.rank = 0
+        if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(group)
+            self.rank = torch.distributed.get_rank(group)
+        cap = int(hit_capacity) if hit_capacity is not None else int(n_rows)
+        self.slots = [ScanSlot(dm, n_rows, cap, self.device) for _ in range(n_slots)]
+        self.side = torch.cuda.Stream(device=self.device) if side_stream else None
+        self._turn = 0
+
+    # ------------------------------------------------------------------ one batch
+    def enqueue(self, d_kmers, threshold: float, on_qvalue: bool = False, want_qvalues: bool = True,
+                row_base: int = 0, gather_hits: bool = False) -> ScanSlot:
+        """Enqueue the whole path for one batch; returns the slot holding its outputs.
+        Nothing here synchronises with the host."""
+        torch = _torch()
+        dm = self.dm
+        slot = self.slots[self._turn % len(self.slots)]
+        self._turn += 1
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(slot.done)           # the slot's previous batch has been consumed
+        slot.hist.zero_()
+        slot.hits[:1].zero_()
+        n = int(d_kmers.shape[0])
+        need_hist = want_qvalues
+        if not on_qvalue:
+            cut = dm.pvalue_cutoff(threshold)  # host lookup in p_table, known before scoring
+            dm.score(d_kmers, slot.scores[:n], hist=slot.hist if need_hist else None,
+                     select_cutoff=cut, row_base=row_base, hit_rows=slot.hit_rows,
+                     hit_count=slot.hit_count)
+        else:
+            dm.score(d_kmers, slot.scores[:n], hist=slot.hist)
+        slot.scored.record(main)
+        tail = self.side if self.side is not None else main
+        with torch.cuda.stream(tail):
+            tail.wait_event(slot.scored)
+            if need_hist:
+                if self.world > 1:
+                    torch.distributed.all_reduce(slot.hist, group=self.group)
+                dm.qvalue_table(slot.hist, threshold, on_qvalue, slot.qtable, slot.cutoff, slot.nrows,
+                                stream=tail)
+            if on_qvalue:
+                dm.select_hits(slot.scores[:n], slot.cutoff, slot.hit_rows, slot.hit_count,
+                               row_base=row_base, stream=tail)
+            if gather_hits and self.world > 1:
+                if self.rank == 0:
+                    if slot.gathered is None:
+                        slot.gathered = [torch.empty_like(slot.hits) for _ in range(self.world)]
+                    torch.distributed.gather(slot.hits, slot.gathered, dst=0, group=self.group)
+                else:
+                    torch.distributed.gather(slot.hits, None, dst=0, group=self.group)
+            slot.done.record(tail)
+        return slot
+
+    def finish(self):
+        """Make the caller's stream wait for all side-stream work."""
+        torch = _torch()
+        main = torch.cuda.current_stream(self.device)
+        for s in self.slots:
+            main.wait_event(s.done)
+
+    # ------------------------------------------------------------------ results of one slot
+    def collect(self, slot: ScanSlot, want_qvalues: bool = True):
+        """D2H of one finished batch: hit rows ascending with scaled score, log-odds,
+        p-value and q-value.  On rank 0 of a sharded scan the gathered hits of all ranks
+        are merged (rows are global ids through row_base)."""
+        torch = _torch()
+        slot.done.synchronize()
+        bufs = [slot.hits]
+        if slot.gathered is not None and self.rank == 0:
+            bufs = slot.gathered
+        packed_all = []
+        for b in bufs:
+            k = int(b[0].item())
+            if k > slot.hit_capacity:
+                raise OverflowError(f"{k} hits exceed the slot capacity {slot.hit_capacity}")
+            packed_all.append(b[1:1 + k].cpu().numpy())
+        packed = np.sort(np.concatenate(packed_all)) if packed_all else np.empty(0, np.int64)
+        rows = packed >> HIT_SCORE_BITS
+        scaled = (packed & ((1 << HIT_SCORE_BITS) - 1)).astype(np.int32)
+        out = {"rows": rows, "scaled": scaled, "n_scored": int(slot.nrows.item()) if want_qvalues else None}
+        if want_qvalues:
+            out["qtable"] = slot.qtable.cpu().numpy()
+        return out

@@ -1,0 +1,131 @@
+"""Synthetic vg-like k-mer batches for benchmarks and size-independent parity tests.
+
+Follows SURVEY.md section 8(d): region i = chr22:(16_000_000 + 1000 i)-(... + 200); per region a
+200-bp reference haplotype drawn i.i.d. from bg_nt frequencies; the 200-W+1 forward windows and
+their reverse complements ('-' rows, START > STOP) are the ``ref`` rows; the remaining rows are
+``non.ref`` variants of random reference windows with 1-2 substitutions; 1 % of the rows are
+overwritten by a sample from the motif's own PWM columns; 0.1 % get one ``N``;
+haplotype_frequency is uniform in [0, 5096] with 5 % forced to 0.
+RNG: numpy.random.Generator(PCG64(seed)), seed = 20240139 + config index (+ rank offset).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+BG_NT = np.array([0.2951, 0.2047, 0.2048, 0.2955])  # A C G T (tutorials/.../bg_nt)
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[_a] = _b
+
+REGION_LEN = 200
+REGION_STRIDE = 1000
+REGION_ORIGIN = 16_000_000
+
+
+@dataclass
+class KmerBatch:
+    kmers: np.ndarray        # uint8 [n, W] ASCII
+    region: np.ndarray       # int32 [n]   region index (global)
+    start: np.ndarray        # int64 [n]
+    stop: np.ndarray         # int64 [n]
+    strand: np.ndarray       # uint8 [n]   '+' / '-'
+    freq: np.ndarray         # int64 [n]
+    is_ref: np.ndarray       # uint8 [n]
+    width: int
+
+    def __len__(self):
+        return int(self.kmers.shape[0])
+
+    def region_name(self, i):
+        s = REGION_ORIGIN + REGION_STRIDE * int(i)
+        return f"chr22:{s}-{s + REGION_LEN}"
+
+
+def seed_for(config_index: int, rank: int = 0) -> int:
+    return 20240139 + int(config_index) + 1_000_003 * int(rank)
+
+
+def make_batch(n_regions: int, rows_per_region: int, width: int, pwm_probs: np.ndarray,
+               seed: int, region_base: int = 0, block: int = 512) -> KmerBatch:
+    """pwm_probs: f64 [4, W] column-stochastic (rows A,C,G,T) used for the 1 % planted rows."""
+    W = int(width)
+    nwin = REGION_LEN - W + 1
+    n_ref = 2 * nwin
+    if rows_per_region < n_ref:
+        raise ValueError("rows_per_region must hold the forward and reverse reference windows")
+    n_var = rows_per_region - n_ref
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cdf = np.cumsum(pwm_probs / pwm_probs.sum(0, keepdims=True), axis=0)  # [4, W]
+    out_k, out_reg, out_st, out_sp, out_sd, out_fr, out_rf = [], [], [], [], [], [], []
+    win_idx = np.arange(nwin)[:, None] + np.arange(W)[None, :]            # [nwin, W]
+    for r0 in range(0, n_regions, block):
+        R = min(block, n_regions - r0)
+        hap = _ACGT[rng.choice(4, size=(R, REGION_LEN), p=BG_NT / BG_NT.sum())]          # [R, 200]
+        fwd = hap[:, win_idx]                                             # [R, nwin, W]
+        rev = _COMP[fwd[:, :, ::-1]]
+        origin = REGION_ORIGIN + REGION_STRIDE * (region_base + r0 + np.arange(R, dtype=np.int64))
+        f_start = origin[:, None] + np.arange(nwin, dtype=np.int64)[None, :]
+        f_stop = f_start + W
+        # variants: a random reference window on a random strand with 1-2 substitutions
+        src = rng.integers(0, nwin, size=(R, n_var))
+        neg = rng.random((R, n_var)) < 0.5
+        var = np.take_along_axis(fwd, src[:, :, None], axis=1)            # [R, n_var, W]
+        var = np.where(neg[:, :, None], _COMP[var[:, :, ::-1]], var)
+        nsub = rng.integers(1, 3, size=(R, n_var))
+        for k in range(2):
+            pos = rng.integers(0, W, size=(R, n_var))
+            base = _ACGT[rng.integers(0, 4, size=(R, n_var))]
+            apply = nsub > k
+            cur = np.take_along_axis(var, pos[:, :, None], axis=2)[:, :, 0]
+            np.put_along_axis(var, pos[:, :, None], np.where(apply, base, cur)[:, :, None], axis=2)
+        v_start = origin[:, None] + src
+        v_stop = v_start + W
+        km = np.concatenate([fwd, rev, var], axis=1).reshape(R * rows_per_region, W)
+        st = np.concatenate([f_start, f_stop, np.where(neg, v_stop, v_start)], axis=1).reshape(-1)
+        sp = np.concatenate([f_stop, f_start, np.where(neg, v_start, v_stop)], axis=1).reshape(-1)
+        sd = np.concatenate([np.full((R, nwin), ord("+"), np.uint8), np.full((R, nwin), ord("-"), np.uint8),
+                             np.where(neg, ord("-"), ord("+")).astype(np.uint8)], axis=1).reshape(-1)
+        rf = np.concatenate([np.ones((R, n_ref), np.uint8), np.zeros((R, n_var), np.uint8)], axis=1).reshape(-1)
+        n = km.shape[0]
+        # 1 % planted motif instances
+        plant = np.nonzero(rng.random(n) < 0.01)[0]
+        if len(plant):
+            u = rng.random((len(plant), W))
+            code = (u[:, None, :] > cdf[None, :, :]).sum(1).clip(0, 3)    # inverse-CDF per column
+            km[plant] = _ACGT[code]
+            rf[plant] = 0
+        # 0.1 % rows with one N
+        nrow = np.nonzero(rng.random(n) < 0.001)[0]
+        if len(nrow):
+            km[nrow, rng.integers(0, W, size=len(nrow))] = ord("N")
+        fr = rng.integers(0, 5097, size=n, dtype=np.int64)
+        fr[rng.random(n) < 0.05] = 0
+        out_k.append(km)
+        out_reg.append(np.repeat(np.arange(region_base + r0, region_base + r0 + R, dtype=np.int32),
+                                 rows_per_region))
+        out_st.append(st); out_sp.append(sp); out_sd.append(sd); out_fr.append(fr); out_rf.append(rf)
+    return KmerBatch(np.ascontiguousarray(np.concatenate(out_k)), np.concatenate(out_reg),
+                     np.concatenate(out_st), np.concatenate(out_sp), np.concatenate(out_sd),
+                     np.concatenate(out_fr), np.concatenate(out_rf), W)
+
+
+def write_tsv_dir(batch: KmerBatch, out_dir: str, rows_per_file_region: bool = True):
+    """Write the batch as vg-style TSVs (one file per region) under out_dir/width_W/."""
+    import os
+    d = os.path.join(out_dir, f"width_{batch.width}")
+    os.makedirs(d, exist_ok=True)
+    order = np.argsort(batch.region, kind="stable")
+    bounds = np.nonzero(np.diff(batch.region[order]))[0] + 1
+    for idx in np.split(order, bounds):
+        reg = int(batch.region[idx[0]])
+        name = batch.region_name(reg)
+        chrom = name.split(":")[0]
+        with open(os.path.join(d, name.replace(":", "_") + ".tsv"), "w") as fh:
+            for i in idx:
+                sd = chr(batch.strand[i])
+                fh.write(
+                    f"{name}\t{batch.kmers[i].tobytes().decode()}\t{chrom}:{batch.start[i]}{sd}\t"
+                    f"{chrom}:{batch.stop[i]}{sd}\t{batch.freq[i]}\t"
+                    f"{'ref' if batch.is_ref[i] else 'non.ref'}\t1{sd},\n")
+    return d

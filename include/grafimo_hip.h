@@ -41,6 +41,9 @@ extern "C" {
 
 #define GFM_MAX_WIDTH 64      /* widest motif the kernels are instantiated for           */
 #define GFM_NO_SELECT INT32_MAX
+/* a hit-list entry packs the global row id and the row's scaled score:
+ * entry = (row << GFM_HIT_SCORE_BITS) | score   (score <= 1000*64 < 2^20) */
+#define GFM_HIT_SCORE_BITS 20
 
 /* ------------------------------------------------------------------ library / device */
 int gfm_abi_version(void);
@@ -102,14 +105,21 @@ int gfm_motif_annotate(gfm_motif_t m, const int32_t *h_scores, int64_t n,
  *   d_scores   int32 [n] out: scaled integer scores.
  *   d_hist     uint64 [L] in/out or NULL: d_hist[s] += #rows scored s.
  *   select_cutoff / d_hit_*: if select_cutoff != GFM_NO_SELECT, rows with
- *              score >= select_cutoff get (row_base + row) appended to d_hit_rows
- *              (unordered) and *d_hit_count incremented; rows beyond hit_capacity are
- *              counted but not stored.
+ *              score >= select_cutoff get the entry ((row_base + row) << 20 | score)
+ *              appended to d_hit_rows (unordered) and *d_hit_count incremented; hits beyond
+ *              hit_capacity are counted but not stored.
  * Enqueues on `stream`; no synchronisation. */
 int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, int32_t *d_scores,
                     uint64_t *d_hist, int32_t select_cutoff, int64_t row_base,
                     int64_t *d_hit_rows, int64_t hit_capacity, uint64_t *d_hit_count,
                     void *stream);
+
+/* Measurement aid (bench.py): with slots > 0 every later gfm_score_kmers call brackets the
+ * score kernel ALONE (not the histogram reduction that follows it) with a hipEvent pair on
+ * the launch stream, in a ring of `slots` pairs; slots = 0 turns it off.  gfm_profile_read
+ * waits for the recorded events and returns the kernel durations in ms, oldest first. */
+int gfm_profile_enable(gfm_motif_t m, int slots);
+int gfm_profile_read(gfm_motif_t m, float *h_ms_out, int capacity, int *n_out);
 
 /* replaces compute_qvalues(pvalues, debug) (score_sequences.py:401-428; statsmodels
  * fdr_bh): Benjamini-Hochberg q-value of every scaled score, from the score histogram
@@ -121,7 +131,7 @@ int gfm_qvalue_table(gfm_motif_t m, const uint64_t *d_hist, double threshold, in
                      void *stream);
 
 /* replaces the threshold filter of ResultTmp.to_df (resultsTmp.py:303-307) on device:
- * appends row_base+row for every row with d_scores[row] >= *d_cutoff. */
+ * appends the packed entry of every row with d_scores[row] >= *d_cutoff. */
 int gfm_select_hits(const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
                     int64_t row_base, int64_t *d_hit_rows, int64_t hit_capacity,
                     uint64_t *d_hit_count, void *stream);
