@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgrafimo_hip.so")
+LIB_PATH = os.environ.get("GRAFIMO_HIP_LIB") or os.path.join(_HERE, "csrc", "libgrafimo_hip.so")
 
 GFM_OK = 0
 GFM_ERR_INVALID = -1
@@ -22,6 +22,8 @@ GFM_ERR_NODEVICE = -5
 GFM_ERR_IO = -6
 GFM_ERR_OVERFLOW = -7
 GFM_NO_SELECT = 2**31 - 1
+GFM_FLAG_RESET_HITS = 1
+GFM_FLAG_CLEAR_HIST = 2
 GFM_MAX_WIDTH = 64
 RANGE = 1000
 
@@ -51,12 +53,13 @@ PROTOTYPES = {
     "gfm_motif_pvalue_cutoff": (c_int, [c_void_p, c_double, P(c_i32)]),
     "gfm_motif_annotate": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "gfm_score_kmers": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_i64,
-                                c_void_p, c_i64, c_void_p, c_void_p]),
+                                c_void_p, c_i64, c_void_p, ctypes.c_uint32, c_void_p]),
     "gfm_profile_enable": (c_int, [c_void_p, c_int]),
     "gfm_profile_read": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
     "gfm_qvalue_table": (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
-                                 c_void_p]),
-    "gfm_select_hits": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
+                                 ctypes.c_uint32, c_void_p]),
+    "gfm_select_hits": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p,
+                                ctypes.c_uint32, c_void_p]),
     "gfm_scan_host": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_int, c_i64, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, P(c_i64)]),
     "gfm_tsv_open": (c_int, [P(ctypes.c_char_p), c_int, c_int, c_int, c_int, P(c_void_p), P(c_i64)]),

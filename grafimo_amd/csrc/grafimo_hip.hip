@@ -57,12 +57,66 @@ constexpr int kChunk = 128;                    // k-mers per wave per iteration 
 constexpr unsigned kPoison = 0xFFFFu;          // table entry of a byte that is not A,C,G,T (> 1000*64)
 constexpr int kMaxLdsBytes = 160 * 1024;
 constexpr int kWGsPerCU = 3;                   // target residency of the score kernel
-constexpr int kHitQueue = 128;                 // per-wave LDS hit queue (entries)
+constexpr int kHitQueue = 64;                  // per-wave LDS hit queue (entries, >= 64)
+constexpr int kDepth = 2;                      // chunks prefetched ahead per wave
 
 // per-wave LDS strip: the staged chunk (+16 B slack for the last row's trailing dword),
 // followed by the wave's hit queue
 __host__ __device__ inline int stage_data_bytes(int W) { return ((kChunk * W + 15) & ~15) + 16; }
 __host__ __device__ inline int stage_stride_bytes(int W) { return stage_data_bytes(W) + kHitQueue * 8; }
+
+// ---------------------------------------------------------------------------------------
+// Hit list plumbing shared by the fused and the separate selection.
+// Every wave queues its hits in LDS (kHitQueue entries).  A full queue is flushed to the dense
+// list with ONE returning global atomic (rare, spread over the run).  What is still queued at
+// the end goes to the workgroup's slab of a staging area with plain stores; post_kernel
+// appends the slabs.  No returning atomic sits on the kernel's tail: per wave or per
+// workgroup, 512..4096 same-word atomics there cost +30..45 us on a 100 us kernel (measured;
+// one word sustains ~88 returning atomics/us, MI355X_MICROARCH "dequeue").
+// HitCtl rotates three mid-run counters so that the kernel that zeroes one never races a
+// kernel that uses it: call k uses slot k%3, its post_kernel zeroes slot (k+2)%3.
+struct HitCtl {
+    unsigned long long mid[3];   // entries flushed mid-run by the current call
+    unsigned long long snap[3];  // *hit_count as the call found it
+};
+constexpr int kResidPerWG = 8 * kHitQueue;  // staging slab entries per workgroup
+
+__device__ inline void hitq_push(long long *hitq, int &qn, bool hit, long long entry, int lane,
+                                 const unsigned long long *hit_count, unsigned long long *mid,
+                                 long long *hit_rows, long long hit_cap)
+{
+    const unsigned long long mask = __ballot(hit);
+    if (!mask) return;
+    const int nh = __popcll(mask);
+    if (qn + nh > kHitQueue) {
+        unsigned long long base = 0;
+        if (lane == 0) base = (hit_count ? *hit_count : 0ull) + atomicAdd(mid, (unsigned long long)qn);
+        base = __shfl(base, 0);
+        for (int i = lane; i < qn; i += kWave)
+            if ((long long)(base + i) < hit_cap) hit_rows[base + i] = hitq[i];
+        qn = 0;
+    }
+    if (hit) hitq[qn + __popcll(mask & ((1ull << lane) - 1ull))] = entry;
+    qn += nh;
+}
+
+// all waves of the workgroup call this once, after their last push
+template <int WAVES>
+__device__ inline void hitq_finish(const long long *hitq, int qn, int *wq_n /* shared [WAVES] */,
+                                   int wave, int lane, int tid, long long *resid, int *resid_n)
+{
+    if (lane == 0) wq_n[wave] = qn;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        if (w < wave) base += wq_n[w];
+        tot += wq_n[w];
+    }
+    long long *slab = resid + (size_t)blockIdx.x * kResidPerWG;
+    for (int i = lane; i < qn; i += kWave) slab[base + i] = hitq[i];
+    if (tid == 0) resid_n[blockIdx.x] = tot;
+}
 
 // ---------------------------------------------------------------------------------------
 // score_hist_kernel<NDW, SELECT>
@@ -85,8 +139,11 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
                   const uint16_t *__restrict__ g_tab, int lo, int nb, int min_val,
                   int use_hist, int *__restrict__ scores, unsigned *__restrict__ partials,
                   int cutoff, long long row_base, long long *__restrict__ hit_rows,
-                  long long hit_cap, unsigned long long *__restrict__ hit_count)
+                  long long hit_cap, const unsigned long long *__restrict__ hit_count,
+                  HitCtl *__restrict__ ctl, int par, long long *__restrict__ resid,
+                  int *__restrict__ resid_n)
 {
+    // hit_count == nullptr: the list restarts at 0 (GFM_FLAG_RESET_HITS); the old count is not read
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kTabBytes = 4 * NDW * 8 * 2;
     constexpr int kLoads = (kChunk * 4 * NDW + 1023) / 1024;  // 16 B loads per lane per chunk
@@ -112,8 +169,8 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
     const int chunk_bytes = kChunk * W;
     const long long cstride = (long long)gridDim.x * kWavesPerWG;
 
-    uint4 pre[kLoads];
-    auto fetch = [&](long long c) {
+    uint4 pre[kDepth][kLoads];
+    auto fetch = [&](uint4 (&dst)[kLoads], long long c) {
         const long long cbase = c * (long long)chunk_bytes;
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
@@ -130,35 +187,28 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
                     v = make_uint4(t[0], t[1], t[2], t[3]);
                 }
             }
-            pre[i] = v;
+            dst[i] = v;
         }
     };
 
-    // Hits are queued per wave in LDS and flushed with ONE global atomic per ~128 hits: a
-    // returning atomic on a single counter word saturates near 88 ops/us chip-wide
-    // (MI355X_MICROARCH "dequeue"), which at one atomic per hitting wave cost 1.7 ms here.
     long long *hitq = reinterpret_cast<long long *>(stage + stage_data_bytes(W));
     int qn = 0;  // wave-uniform
-    auto flush_hits = [&]() {
-        if (qn > 0) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(hit_count, (unsigned long long)qn);
-            base = __shfl(base, 0);
-            for (int i = lane; i < qn; i += kWave)
-                if ((long long)(base + i) < hit_cap) hit_rows[base + i] = hitq[i];
-            qn = 0;
-        }
-    };
+    if (SELECT && blockIdx.x == 0 && tid == 0) ctl->snap[par] = hit_count ? *hit_count : 0ull;
 
     long long c = (long long)blockIdx.x * kWavesPerWG + wave;
-    if (c < nchunks) fetch(c);
-    for (; c < nchunks; c += cstride) {
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d)
+        if (c + d * cstride < nchunks) fetch(pre[d], c + d * cstride);
+    while (c < nchunks) {
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) {
+        if (c >= nchunks) break;
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
             const int off = i * 1024 + lane * 16;
-            if (off < chunk_bytes) *reinterpret_cast<uint4 *>(stage + off) = pre[i];
+            if (off < chunk_bytes) *reinterpret_cast<uint4 *>(stage + off) = pre[d][i];
         }
-        if (c + cstride < nchunks) fetch(c + cstride);
+        if (c + kDepth * cstride < nchunks) fetch(pre[d], c + kDepth * cstride);
         // LDS ops of one wave execute in program order; the fence only pins the compiler.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -191,25 +241,22 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
                 scores[row] = score;
                 if (use_hist) atomicAdd(&hist[is_n ? nb : score - lo], 1u);
             }
-            if (SELECT) {
-                const bool hit = live && score >= cutoff;
-                const unsigned long long mask = __ballot(hit);
-                if (mask) {
-                    const int nh = __popcll(mask);
-                    if (qn + nh > kHitQueue) flush_hits();
-                    if (hit)
-                        hitq[qn + __popcll(mask & ((1ull << lane) - 1ull))] =
-                            ((row_base + row) << GFM_HIT_SCORE_BITS) | (long long)score;
-                    qn += nh;
-                }
-            }
+            if (SELECT)
+                hitq_push(hitq, qn, live && score >= cutoff,
+                          ((row_base + row) << GFM_HIT_SCORE_BITS) | (long long)score, lane,
+                          hit_count, &ctl->mid[par], hit_rows, hit_cap);
         }
         // the strip is rewritten next iteration: keep this iteration's reads ahead of it
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        c += cstride;
+    }
     }
 
-    if (SELECT) flush_hits();
+    if (SELECT) {
+        __shared__ int wq_n[kWavesPerWG];
+        hitq_finish<kWavesPerWG>(hitq, qn, wq_n, wave, lane, tid, resid, resid_n);
+    }
 
     if (use_hist) {
         __syncthreads();
@@ -218,69 +265,101 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
     }
 }
 
-// Sums the per-workgroup slabs into the caller's uint64 histogram (bin lo+b; the extra
-// slab bin counts N rows, which score min_val).  grid.x walks the bins, grid.y groups of
-// kSlabsPerGroup slabs: enough blocks to pull the slabs at HBM/L2 rate instead of one
-// latency-bound column walk per bin.
+// post_kernel: everything that follows a scoring / selection kernel, in one launch.
+//  blocks [0, hist_blocks): sum the per-workgroup histogram slabs into the caller's uint64
+//    histogram (bin lo+b; the extra slab bin counts N rows, which score min_val).  A block owns
+//    256 bins x kSlabsPerGroup slabs: enough blocks to pull the slabs at L2/HBM rate instead of
+//    one latency-bound column walk per bin.
+//  blocks [hist_blocks, hist_blocks + hit_slabs): append residual hit slab g to the dense list at
+//    snap + mid + (counts of slabs < g); the first of them publishes the new *hit_count and
+//    zeroes the mid-run counter two calls ahead.
 constexpr int kSlabsPerGroup = 16;
 __global__ void __launch_bounds__(256)
-hist_reduce_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo,
-                   int min_val, unsigned long long *__restrict__ hist64)
+post_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, int min_val,
+            unsigned long long *__restrict__ hist64, int bin_blocks, int hist_blocks,
+            const long long *__restrict__ resid, const int *__restrict__ resid_n, int hit_slabs,
+            HitCtl *__restrict__ ctl, int par, long long *__restrict__ hit_rows, long long hit_cap,
+            unsigned long long *__restrict__ hit_count)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > nb) return;
-    const int g0 = blockIdx.y * kSlabsPerGroup;
-    const int g1 = min(g0 + kSlabsPerGroup, nslabs);
-    unsigned long long s = 0;
-    const size_t stride = (size_t)(nb + 1);
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < hist_blocks) {
+        const int bx = blockIdx.x % bin_blocks, by = blockIdx.x / bin_blocks;
+        const int b = bx * 256 + tid;
+        if (b > nb) return;
+        const int g0 = by * kSlabsPerGroup;
+        const int g1 = min(g0 + kSlabsPerGroup, nslabs);
+        unsigned long long s = 0;
+        const size_t stride = (size_t)(nb + 1);
 #pragma unroll 8
-    for (int g = g0; g < g1; ++g) s += partials[g * stride + b];
-    if (s) atomicAdd(&hist64[b == nb ? min_val : lo + b], s);
+        for (int g = g0; g < g1; ++g) s += partials[g * stride + b];
+        if (s) atomicAdd(&hist64[b == nb ? min_val : lo + b], s);
+        return;
+    }
+    __shared__ int part[256];
+    __shared__ int part_all[256];
+    const int g = blockIdx.x - hist_blocks;
+    int s = 0, sa = 0;
+    for (int k = tid; k < hit_slabs; k += 256) {
+        const int v = resid_n[k];
+        sa += v;
+        if (k < g) s += v;
+    }
+    part[tid] = s;
+    part_all[tid] = sa;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (tid < d) { part[tid] += part[tid + d]; part_all[tid] += part_all[tid + d]; }
+        __syncthreads();
+    }
+    const unsigned long long start = ctl->snap[par] + ctl->mid[par];
+    const unsigned long long base = start + (unsigned long long)part[0];
+    const int cnt = resid_n[g];
+    const long long *slab = resid + (size_t)g * kResidPerWG;
+    for (int i = tid; i < cnt; i += 256)
+        if ((long long)(base + i) < hit_cap) hit_rows[base + i] = slab[i];
+    if (g == 0 && tid == 0) {
+        *hit_count = start + (unsigned long long)part_all[0];
+        ctl->mid[(par + 2) % 3] = 0ull;
+    }
 }
 
 // Rows with score >= *cutoff -> hit list (separate pass; used when the cutoff depends on
-// the global histogram, i.e. --qvalueT).
-__global__ void __launch_bounds__(256)
+// the global histogram, i.e. --qvalueT).  Same queue / slab scheme as the fused selection.
+constexpr int kSelThreads = 256;
+__global__ void __launch_bounds__(kSelThreads)
 select_hits_kernel(const int *__restrict__ scores, long long n, const int *__restrict__ cutoff_ptr,
                    long long row_base, long long *__restrict__ hit_rows, long long hit_cap,
-                   unsigned long long *__restrict__ hit_count)
+                   const unsigned long long *__restrict__ hit_count, HitCtl *__restrict__ ctl,
+                   int par, long long *__restrict__ resid, int *__restrict__ resid_n)
 {
+    __shared__ long long hq[kSelThreads / kWave][kHitQueue];
+    __shared__ int wq_n[kSelThreads / kWave];
     const int cutoff = *cutoff_ptr;
-    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long *hitq = hq[wave];
+    int qn = 0;
+    if (blockIdx.x == 0 && tid == 0) ctl->snap[par] = hit_count ? *hit_count : 0ull;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
-    const long long n4 = n >> 2;
+    const long long n4 = (n + 3) >> 2;
     const long long iters = (n4 + nthreads - 1) / nthreads;  // wave-uniform trip count
-    const long long t0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long t0 = (long long)blockIdx.x * blockDim.x + tid;
     for (long long it = 0; it < iters; ++it) {
         const long long i = t0 + it * nthreads;
-        int4 v = make_int4(INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN);
-        if (i < n4) v = reinterpret_cast<const int4 *>(scores)[i];
-        const int s[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool hit = s[j] >= cutoff;
-            const unsigned long long mask = __ballot(hit);
-            if (mask) {
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(hit_count, (unsigned long long)__popcll(mask));
-                base = __shfl(base, 0);
-                if (hit) {
-                    const unsigned long long slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-                    if ((long long)slot < hit_cap)
-                        hit_rows[slot] = ((row_base + i * 4 + j) << GFM_HIT_SCORE_BITS) | (long long)s[j];
-                }
-            }
+        int sc[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
+        if (i * 4 + 4 <= n) {
+            const int4 v = reinterpret_cast<const int4 *>(scores)[i];
+            sc[0] = v.x; sc[1] = v.y; sc[2] = v.z; sc[3] = v.w;
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (i * 4 + j < n) sc[j] = scores[i * 4 + j];
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            hitq_push(hitq, qn, sc[j] >= cutoff,
+                      ((row_base + i * 4 + j) << GFM_HIT_SCORE_BITS) | (long long)sc[j], lane,
+                      hit_count, &ctl->mid[par], hit_rows, hit_cap);
     }
-    // ragged tail (n % 4 rows), one thread
-    if (t0 == 0) {
-        for (long long r = n4 * 4; r < n; ++r)
-            if (scores[r] >= cutoff) {
-                const unsigned long long slot = atomicAdd(hit_count, 1ull);
-                if ((long long)slot < hit_cap)
-                    hit_rows[slot] = ((row_base + r) << GFM_HIT_SCORE_BITS) | (long long)scores[r];
-            }
-    }
+    hitq_finish<kSelThreads / kWave>(hitq, qn, wq_n, wave, lane, tid, resid, resid_n);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -379,10 +458,10 @@ ptable_kernel(const double *__restrict__ pmf, int L, int lo, int hi, double *__r
 // (below the window: p = 1, rank = n, raw = 1): the scans run over the window, split into
 // 1024 contiguous segments.
 __global__ void __launch_bounds__(kScanThreads)
-qvalue_kernel(const unsigned long long *__restrict__ hist, const double *__restrict__ ptable,
+qvalue_kernel_generic(const unsigned long long *hist, const double *__restrict__ ptable,
               int L, int lo, int hi, int min_val, double threshold, int on_qvalue,
               double *__restrict__ qtable, int *__restrict__ cutoff_out,
-              unsigned long long *__restrict__ nrows_out)
+              unsigned long long *__restrict__ nrows_out, unsigned long long *__restrict__ clear)
 {
     __shared__ unsigned long long cseg[kScanThreads];
     __shared__ double mseg[kScanThreads];
@@ -453,6 +532,159 @@ qvalue_kernel(const unsigned long long *__restrict__ hist, const double *__restr
         if (cutoff_out) *cutoff_out = cut_s;
         if (nrows_out) *nrows_out = n;
     }
+    if (clear) {  // GFM_FLAG_CLEAR_HIST: hand the histogram back zeroed (each thread its own bins)
+        for (int j = a; j < b; ++j) clear[j] = 0ull;
+        if (tid == 0 && n_outside) clear[min_val] = 0ull;
+    }
+}
+
+// Fast form for windows of up to 1024*PER bins.  The window is viewed as PER rows of 1024
+// consecutive bins; thread t owns column t (bins lo + k*1024 + t), so every load and store is
+// fully coalesced and all 2*PER loads of a thread are issued at once.  A scan over the window =
+// wave-level shuffles per row, ONE barrier to exchange the PER x 16 wave totals, then each thread
+// adds the totals of the waves / rows that lie beyond it.
+template <int PER>
+__global__ void __launch_bounds__(kScanThreads)
+qvalue_kernel_reg(const unsigned long long *hist, const double *__restrict__ ptable, int L, int lo,
+                  int hi, int min_val, double threshold, int on_qvalue, double *__restrict__ qtable,
+                  int *__restrict__ cutoff_out, unsigned long long *__restrict__ nrows_out,
+                  unsigned long long *__restrict__ clear)
+{
+    constexpr int T = kScanThreads, NW = T / kWave;
+    __shared__ unsigned long long cw[PER][NW], cwx[PER][NW];
+    __shared__ double mw[PER][NW], mwx[PER][NW];
+    __shared__ unsigned long long n_window_s;
+    __shared__ double all_min_s;
+    __shared__ int cut_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) cut_s = L;
+    const bool n_outside = min_val < lo || min_val > hi;
+    const unsigned long long n_rows_N = n_outside ? hist[min_val] : 0ull;
+
+    unsigned long long h[PER];
+    double p[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int j = lo + k * T + tid;
+        const bool ok = j <= hi;
+        h[k] = ok ? hist[j] : 0ull;
+        p[k] = ok ? ptable[j] : 0.0;
+    }
+    // ---- C(j) = #rows with score >= j : inclusive suffix sums
+    unsigned long long cs[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        unsigned long long v = h[k];
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const unsigned long long t = __shfl_down(v, d);
+            if (lane + d < kWave) v += t;
+        }
+        cs[k] = v;
+        if (lane == 0) cw[k][wave] = v;
+    }
+    __syncthreads();
+    // wave 0 turns the PER*NW wave totals (row-major = ascending score) into "everything above
+    // wave w of row k": an exclusive suffix sum over the flattened array, by shuffles
+    constexpr int M = PER * NW, IT = (M + kWave - 1) / kWave;
+    if (wave == 0) {
+        unsigned long long loc[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int f = lane * IT + i;
+            loc[i] = f < M ? (&cw[0][0])[f] : 0ull;
+        }
+#pragma unroll
+        for (int i = IT - 2; i >= 0; --i) loc[i] += loc[i + 1];
+        unsigned long long v = loc[0];
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const unsigned long long t = __shfl_down(v, d);
+            if (lane + d < kWave) v += t;
+        }
+        const unsigned long long excl = v - loc[0];  // lanes above this one
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int f = lane * IT + i;
+            if (f < M) (&cwx[0][0])[f] = excl + (i + 1 < IT ? loc[i + 1] : 0ull);
+        }
+        if (lane == 0) n_window_s = v;
+    }
+    __syncthreads();
+    unsigned long long c_ge[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) c_ge[k] = cs[k] + cwx[k][wave];
+    const unsigned long long n_window = n_window_s;
+    const unsigned long long n = n_window + n_rows_N;
+    const double nd = (double)n;
+
+    // ---- raw BH value of every occupied bin, then inclusive prefix minimum
+    double raw[PER], ms[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        raw[k] = h[k] ? p[k] / ((double)c_ge[k] / nd) : INFINITY;
+        double v = raw[k];
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const double t = __shfl_up(v, d);
+            if (lane >= d) v = fmin(v, t);
+        }
+        ms[k] = v;
+        if (lane == kWave - 1) mw[k][wave] = v;
+    }
+    __syncthreads();
+    // rows holding an N sit below every other score: rank n, p = p_table[min_val] (= 1)
+    const double base = n_rows_N ? ptable[min_val] / (nd / nd) : INFINITY;
+    if (wave == 0) {  // minimum of everything below wave w of row k (exclusive prefix min)
+        double loc[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int f = lane * IT + i;
+            loc[i] = f < M ? (&mw[0][0])[f] : INFINITY;
+        }
+#pragma unroll
+        for (int i = 1; i < IT; ++i) loc[i] = fmin(loc[i], loc[i - 1]);
+        double v = loc[IT - 1];
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const double t = __shfl_up(v, d);
+            if (lane >= d) v = fmin(v, t);
+        }
+        double excl = __shfl_up(v, 1);
+        if (lane == 0) excl = INFINITY;
+        excl = fmin(excl, base);
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int f = lane * IT + i;
+            if (f < M) (&mwx[0][0])[f] = i ? fmin(excl, loc[i - 1]) : excl;
+        }
+        if (lane == kWave - 1) all_min_s = fmin(v, base);
+    }
+    __syncthreads();
+    int first = L;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const double q = fmin(fmin(ms[k], mwx[k][wave]), 1.0);
+        const int j = lo + k * T + tid;
+        if (j <= hi) {
+            if (qtable) qtable[j] = q;
+            const double val = on_qvalue ? q : p[k];
+            if (first == L && val < threshold) first = j;
+            if (clear) clear[j] = 0ull;
+        }
+    }
+    if (qtable) {  // outside the window: 1 below (p = 1 there), the last running minimum above
+        const double q_above = fmin(all_min_s, 1.0);
+        for (int j = tid; j < lo; j += T) qtable[j] = fmin(base, 1.0);
+        for (int j = hi + 1 + tid; j < L; j += T) qtable[j] = q_above;
+    }
+    if (first < L) atomicMin(&cut_s, first);
+    __syncthreads();
+    if (tid == 0) {
+        if (cutoff_out) *cutoff_out = cut_s;
+        if (nrows_out) *nrows_out = n;
+        if (clear && n_outside) clear[min_val] = 0ull;
+    }
 }
 
 }  // namespace
@@ -475,6 +707,10 @@ struct gfm_motif {
     double *d_pmf = nullptr;
     double *d_ptable = nullptr;
     unsigned *d_partials = nullptr;
+    long long *d_resid = nullptr;   // [max_slabs][8 waves * kHitQueue] residual hits per workgroup
+    int *d_resid_n = nullptr;       // [max_slabs]
+    HitCtl *d_ctl = nullptr;
+    unsigned call_no = 0;           // selects the HitCtl slot (call_no % 3)
     // measurement aid: ring of event pairs around the score kernel
     std::vector<hipEvent_t> ev0, ev1;
     int ev_next = 0, ev_used = 0;
@@ -557,7 +793,8 @@ int run_dp(const int64_t *sm, int W, const double *bg, double *d_pmf, hipStream_
 template <int NDW>
 int launch_score(gfm_motif *m, const uint8_t *d_kmers, long long n, int *d_scores, int use_hist,
                  int nslabs, bool select, int cutoff, long long row_base, long long *d_hit_rows,
-                 long long cap, unsigned long long *d_hit_count, hipStream_t st, bool prepare_only)
+                 long long cap, unsigned long long *d_hit_count, hipStream_t st, bool prepare_only,
+                 int par)
 {
     auto k_sel = score_hist_kernel<NDW, true>;
     auto k_nos = score_hist_kernel<NDW, false>;
@@ -576,7 +813,8 @@ int launch_score(gfm_motif *m, const uint8_t *d_kmers, long long n, int *d_score
     if (prof) HIP_TRY(hipEventRecord(m->ev0[slot], st));
     hipLaunchKernelGGL(kern, dim3(nslabs), dim3(kThreads), m->lds_bytes, st, d_kmers, n, m->W,
                        m->d_tab, m->lo, m->nb, m->min_val, use_hist, d_scores, m->d_partials,
-                       cutoff, row_base, d_hit_rows, cap, d_hit_count);
+                       cutoff, row_base, d_hit_rows, cap, d_hit_count, m->d_ctl, par, m->d_resid,
+                       m->d_resid_n);
     HIP_TRY(hipGetLastError());
     if (prof) {
         HIP_TRY(hipEventRecord(m->ev1[slot], st));
@@ -586,14 +824,31 @@ int launch_score(gfm_motif *m, const uint8_t *d_kmers, long long n, int *d_score
     return GFM_OK;
 }
 
+// one launch after a scoring / selection kernel: histogram slabs -> hist64, hit slabs -> list
+int launch_post(gfm_motif *m, int hist_slabs, unsigned long long *d_hist, int hit_slabs, int par,
+                long long *d_hit_rows, long long cap, unsigned long long *d_hit_count, hipStream_t st)
+{
+    const int bin_blocks = (m->nb + 1 + 255) / 256;
+    const int groups = (hist_slabs + kSlabsPerGroup - 1) / kSlabsPerGroup;
+    const int hist_blocks = d_hist ? bin_blocks * groups : 0;
+    const int total = hist_blocks + hit_slabs;
+    if (total == 0) return GFM_OK;
+    hipLaunchKernelGGL(post_kernel, dim3(total), dim3(256), 0, st, m->d_partials, hist_slabs, m->nb,
+                       m->lo, m->min_val, d_hist, bin_blocks, hist_blocks, m->d_resid, m->d_resid_n,
+                       hit_slabs, m->d_ctl, par, d_hit_rows, cap, d_hit_count);
+    HIP_TRY(hipGetLastError());
+    return GFM_OK;
+}
+
 int dispatch_score(gfm_motif *m, const uint8_t *d_kmers, long long n, int *d_scores, int use_hist,
                    int nslabs, bool select, int cutoff, long long row_base, long long *d_hit_rows,
-                   long long cap, unsigned long long *d_hit_count, hipStream_t st, bool prepare_only)
+                   long long cap, unsigned long long *d_hit_count, hipStream_t st, bool prepare_only,
+                   int par)
 {
 #define GFM_CASE(N)                                                                             \
     case N:                                                                                     \
         return launch_score<N>(m, d_kmers, n, d_scores, use_hist, nslabs, select, cutoff,       \
-                               row_base, d_hit_rows, cap, d_hit_count, st, prepare_only);
+                               row_base, d_hit_rows, cap, d_hit_count, st, prepare_only, par);
     switch (m->ndw) {
         GFM_CASE(1) GFM_CASE(2) GFM_CASE(3) GFM_CASE(4) GFM_CASE(5) GFM_CASE(6) GFM_CASE(7) GFM_CASE(8)
         GFM_CASE(9) GFM_CASE(10) GFM_CASE(11) GFM_CASE(12) GFM_CASE(13) GFM_CASE(14) GFM_CASE(15) GFM_CASE(16)
@@ -708,6 +963,9 @@ GFM_API void gfm_motif_destroy(gfm_motif_t m)
     if (m->d_pmf) (void)hipFree(m->d_pmf);
     if (m->d_ptable) (void)hipFree(m->d_ptable);
     if (m->d_partials) (void)hipFree(m->d_partials);
+    if (m->d_resid) (void)hipFree(m->d_resid);
+    if (m->d_resid_n) (void)hipFree(m->d_resid_n);
+    if (m->d_ctl) (void)hipFree(m->d_ctl);
     for (auto e : m->ev0) (void)hipEventDestroy(e);
     for (auto e : m->ev1) (void)hipEventDestroy(e);
     delete m;
@@ -793,8 +1051,12 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     per_cu = std::max(per_cu, 1);
     m->max_slabs = m->n_cu * per_cu;
     HIP_TRY_M(hipMalloc(&m->d_partials, sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->nb + 1)));
+    HIP_TRY_M(hipMalloc(&m->d_resid, sizeof(long long) * (size_t)m->max_slabs * kResidPerWG));
+    HIP_TRY_M(hipMalloc(&m->d_resid_n, sizeof(int) * (size_t)m->max_slabs));
+    HIP_TRY_M(hipMalloc(&m->d_ctl, sizeof(HitCtl)));
+    HIP_TRY_M(hipMemset(m->d_ctl, 0, sizeof(HitCtl)));
 #undef HIP_TRY_M
-    rc = dispatch_score(m, nullptr, 0, nullptr, 0, 1, false, 0, 0, nullptr, 0, nullptr, nullptr, true);
+    rc = dispatch_score(m, nullptr, 0, nullptr, 0, 1, false, 0, 0, nullptr, 0, nullptr, nullptr, true, 0);
     if (rc) return bail(rc);
     *out = m;
     return GFM_OK;
@@ -848,11 +1110,15 @@ GFM_API int gfm_motif_annotate(gfm_motif_t m, const int32_t *scores, int64_t n, 
 GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, int32_t *d_scores,
                             uint64_t *d_hist, int32_t select_cutoff, int64_t row_base,
                             int64_t *d_hit_rows, int64_t hit_capacity, uint64_t *d_hit_count,
-                            void *stream)
+                            uint32_t flags, void *stream)
 {
     if (!m) return fail(GFM_ERR_INVALID, "motif is NULL");
     if (n < 0) return fail(GFM_ERR_INVALID, "negative row count");
-    if (n == 0) return GFM_OK;
+    if (n == 0) {
+        if ((flags & GFM_FLAG_RESET_HITS) && d_hit_count)
+            HIP_TRY(hipMemsetAsync(d_hit_count, 0, sizeof(uint64_t), static_cast<hipStream_t>(stream)));
+        return GFM_OK;
+    }
     if (!d_kmers || !d_scores) return fail(GFM_ERR_INVALID, "NULL device buffer");
     if ((reinterpret_cast<uintptr_t>(d_kmers) & 15u) != 0)
         return fail(GFM_ERR_INVALID, "d_kmers must be 16-byte aligned");
@@ -867,20 +1133,16 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     const long long want = (nchunks + kWavesPerWG - 1) / kWavesPerWG;
     const int nslabs = (int)std::min<long long>(want, m->max_slabs);
 
+    const int par = select ? (int)(m->call_no++ % 3u) : 0;
+    const bool reset = (flags & GFM_FLAG_RESET_HITS) != 0;
     int rc = dispatch_score(m, d_kmers, n, d_scores, use_hist, nslabs, select, select_cutoff, row_base,
                             reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
-                            reinterpret_cast<unsigned long long *>(d_hit_count), st, false);
+                            reset ? nullptr : reinterpret_cast<unsigned long long *>(d_hit_count), st,
+                            false, par);
     if (rc) return rc;
-    if (use_hist) {
-        const int threads = 256;
-        const int blocks = (m->nb + 1 + threads - 1) / threads;
-        const int groups = (nslabs + kSlabsPerGroup - 1) / kSlabsPerGroup;
-        hipLaunchKernelGGL(hist_reduce_kernel, dim3(blocks, groups), dim3(threads), 0, st, m->d_partials,
-                           nslabs, m->nb, m->lo, m->min_val,
-                           reinterpret_cast<unsigned long long *>(d_hist));
-        HIP_TRY(hipGetLastError());
-    }
-    return GFM_OK;
+    return launch_post(m, nslabs, reinterpret_cast<unsigned long long *>(d_hist), select ? nslabs : 0,
+                       par, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
+                       reinterpret_cast<unsigned long long *>(d_hit_count), st);
 }
 
 GFM_API int gfm_profile_enable(gfm_motif_t m, int slots)
@@ -916,38 +1178,60 @@ GFM_API int gfm_profile_read(gfm_motif_t m, float *h_ms, int capacity, int *n_ou
     return GFM_OK;
 }
 
-GFM_API int gfm_qvalue_table(gfm_motif_t m, const uint64_t *d_hist, double threshold, int on_qvalue,
-                             double *d_qtable, int32_t *d_cutoff, uint64_t *d_nrows, void *stream)
+GFM_API int gfm_qvalue_table(gfm_motif_t m, uint64_t *d_hist, double threshold, int on_qvalue,
+                             double *d_qtable, int32_t *d_cutoff, uint64_t *d_nrows, uint32_t flags,
+                             void *stream)
 {
     if (!m || !d_hist) return fail(GFM_ERR_INVALID, "NULL argument");
-    hipLaunchKernelGGL(qvalue_kernel, dim3(1), dim3(kScanThreads), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const unsigned long long *>(d_hist), m->d_ptable, m->L,
-                       m->lo, m->hi, m->min_val, threshold, on_qvalue, d_qtable, d_cutoff,
-                       reinterpret_cast<unsigned long long *>(d_nrows));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const unsigned long long *hc = reinterpret_cast<const unsigned long long *>(d_hist);
+    unsigned long long *clr =
+        (flags & GFM_FLAG_CLEAR_HIST) ? reinterpret_cast<unsigned long long *>(d_hist) : nullptr;
+    unsigned long long *nr = reinterpret_cast<unsigned long long *>(d_nrows);
+#define GFM_Q_ARGS hc, m->d_ptable, m->L, m->lo, m->hi, m->min_val, threshold, on_qvalue, d_qtable, d_cutoff, nr, clr
+    if (m->nb <= kScanThreads * 4)
+        hipLaunchKernelGGL(qvalue_kernel_reg<4>, dim3(1), dim3(kScanThreads), 0, st, GFM_Q_ARGS);
+    else if (m->nb <= kScanThreads * 8)
+        hipLaunchKernelGGL(qvalue_kernel_reg<8>, dim3(1), dim3(kScanThreads), 0, st, GFM_Q_ARGS);
+    else if (m->nb <= kScanThreads * 16)
+        hipLaunchKernelGGL(qvalue_kernel_reg<16>, dim3(1), dim3(kScanThreads), 0, st, GFM_Q_ARGS);
+    else
+        hipLaunchKernelGGL(qvalue_kernel_generic, dim3(1), dim3(kScanThreads), 0, st, GFM_Q_ARGS);
+#undef GFM_Q_ARGS
     HIP_TRY(hipGetLastError());
     return GFM_OK;
 }
 
-GFM_API int gfm_select_hits(const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
+GFM_API int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
                             int64_t row_base, int64_t *d_hit_rows, int64_t hit_capacity,
-                            uint64_t *d_hit_count, void *stream)
+                            uint64_t *d_hit_count, uint32_t flags, void *stream)
 {
+    if (!m) return fail(GFM_ERR_INVALID, "motif is NULL");
     if (n < 0) return fail(GFM_ERR_INVALID, "negative row count");
-    if (n == 0) return GFM_OK;
+    if (n == 0) {
+        if ((flags & GFM_FLAG_RESET_HITS) && d_hit_count)
+            HIP_TRY(hipMemsetAsync(d_hit_count, 0, sizeof(uint64_t), static_cast<hipStream_t>(stream)));
+        return GFM_OK;
+    }
     if (!d_scores || !d_cutoff || !d_hit_rows || !d_hit_count)
         return fail(GFM_ERR_INVALID, "NULL device buffer");
     if ((reinterpret_cast<uintptr_t>(d_scores) & 15u) != 0)
         return fail(GFM_ERR_INVALID, "d_scores must be 16-byte aligned");
-    const long long n4 = n >> 2;
-    const int threads = 256;
-    long long blocks = (n4 + threads - 1) / threads;
-    blocks = std::max<long long>(1, std::min<long long>(blocks, 2048));
-    hipLaunchKernelGGL(select_hits_kernel, dim3((unsigned)blocks), dim3(threads), 0,
-                       static_cast<hipStream_t>(stream), d_scores, (long long)n, d_cutoff,
-                       (long long)row_base, reinterpret_cast<long long *>(d_hit_rows),
-                       (long long)hit_capacity, reinterpret_cast<unsigned long long *>(d_hit_count));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long n4 = (n + 3) >> 2;
+    long long blocks = (n4 + kSelThreads - 1) / kSelThreads;
+    blocks = std::max<long long>(1, std::min<long long>(blocks, m->max_slabs));
+    const int par = (int)(m->call_no++ % 3u);
+    hipLaunchKernelGGL(select_hits_kernel, dim3((unsigned)blocks), dim3(kSelThreads), 0, st, d_scores,
+                       (long long)n, d_cutoff, (long long)row_base,
+                       reinterpret_cast<long long *>(d_hit_rows), (long long)hit_capacity,
+                       (flags & GFM_FLAG_RESET_HITS)
+                           ? nullptr
+                           : reinterpret_cast<const unsigned long long *>(d_hit_count),
+                       m->d_ctl, par, m->d_resid, m->d_resid_n);
     HIP_TRY(hipGetLastError());
-    return GFM_OK;
+    return launch_post(m, 0, nullptr, (int)blocks, par, reinterpret_cast<long long *>(d_hit_rows),
+                       hit_capacity, reinterpret_cast<unsigned long long *>(d_hit_count), st);
 }
 
 GFM_API int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, double threshold,
@@ -1009,17 +1293,17 @@ GFM_API int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, doub
         SCAN_RC(gfm_motif_pvalue_cutoff(m, threshold, &cutoff));
         SCAN_RC(gfm_score_kmers(m, d_kmers, n, d_scores, reinterpret_cast<uint64_t *>(d_hist), cutoff,
                                 0, reinterpret_cast<int64_t *>(d_rows), cap,
-                                reinterpret_cast<uint64_t *>(d_count), st));
+                                reinterpret_cast<uint64_t *>(d_count), GFM_FLAG_RESET_HITS, st));
         if (need_hist)
             SCAN_RC(gfm_qvalue_table(m, reinterpret_cast<uint64_t *>(d_hist), threshold, 0, d_q,
-                                     nullptr, nullptr, st));
+                                     nullptr, nullptr, 0, st));
     } else {
         SCAN_RC(gfm_score_kmers(m, d_kmers, n, d_scores, reinterpret_cast<uint64_t *>(d_hist),
-                                GFM_NO_SELECT, 0, nullptr, 0, nullptr, st));
+                                GFM_NO_SELECT, 0, nullptr, 0, nullptr, 0, st));
         SCAN_RC(gfm_qvalue_table(m, reinterpret_cast<uint64_t *>(d_hist), threshold, 1, d_q, d_cutoff,
-                                 nullptr, st));
-        SCAN_RC(gfm_select_hits(d_scores, n, d_cutoff, 0, reinterpret_cast<int64_t *>(d_rows), cap,
-                                reinterpret_cast<uint64_t *>(d_count), st));
+                                 nullptr, 0, st));
+        SCAN_RC(gfm_select_hits(m, d_scores, n, d_cutoff, 0, reinterpret_cast<int64_t *>(d_rows), cap,
+                                reinterpret_cast<uint64_t *>(d_count), GFM_FLAG_RESET_HITS, st));
     }
     SCAN_TRY(hipMemcpyAsync(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost, st));
     SCAN_TRY(hipStreamSynchronize(st));

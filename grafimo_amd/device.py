@@ -97,7 +97,7 @@ class DeviceMotif:
 
     # ---- device-pointer entry points (torch tensors as buffers)
     def score(self, kmers, scores, hist=None, select_cutoff=None, row_base=0, hit_rows=None,
-              hit_count=None, stream=None):
+              hit_count=None, stream=None, reset_hits=False):
         """Enqueue gfm_score_kmers.  kmers uint8 [n,W] (cuda), scores int32 [n],
         hist int64 [L] (accumulated), hit_rows int64 [cap], hit_count int64 [1]."""
         n = int(kmers.shape[0])
@@ -110,22 +110,25 @@ class DeviceMotif:
             hit_rows.data_ptr() if hit_rows is not None else None,
             int(hit_rows.numel()) if hit_rows is not None else 0,
             hit_count.data_ptr() if hit_count is not None else None,
-            _stream_ptr(stream)))
+            nv.GFM_FLAG_RESET_HITS if reset_hits else 0, _stream_ptr(stream)))
 
     def qvalue_table(self, hist, threshold, on_qvalue, qtable=None, cutoff=None, nrows=None,
-                     stream=None):
+                     stream=None, clear_hist=False):
         nv.check(nv.lib().gfm_qvalue_table(
             self._h, hist.data_ptr(), float(threshold), int(bool(on_qvalue)),
             qtable.data_ptr() if qtable is not None else None,
             cutoff.data_ptr() if cutoff is not None else None,
-            nrows.data_ptr() if nrows is not None else None, _stream_ptr(stream)))
+            nrows.data_ptr() if nrows is not None else None,
+            nv.GFM_FLAG_CLEAR_HIST if clear_hist else 0, _stream_ptr(stream)))
 
-    @staticmethod
-    def select_hits(scores, cutoff, hit_rows, hit_count, row_base=0, stream=None):
+    def select_hits(self, scores, cutoff, hit_rows, hit_count, row_base=0, stream=None,
+                    reset_hits=False):
         n = int(scores.numel())
-        nv.check(nv.lib().gfm_select_hits(scores.data_ptr() if n else None, n, cutoff.data_ptr(),
+        nv.check(nv.lib().gfm_select_hits(self._h, scores.data_ptr() if n else None, n, cutoff.data_ptr(),
                                           int(row_base), hit_rows.data_ptr(), int(hit_rows.numel()),
-                                          hit_count.data_ptr(), _stream_ptr(stream)))
+                                          hit_count.data_ptr(),
+                                          nv.GFM_FLAG_RESET_HITS if reset_hits else 0,
+                                          _stream_ptr(stream)))
 
     # ---- measurement aid (bench.py)
     def profile_enable(self, slots: int):

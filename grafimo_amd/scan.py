@@ -71,15 +71,15 @@ class KmerScanner:
         self._turn += 1
         main = torch.cuda.current_stream(self.device)
         main.wait_event(slot.done)           # the slot's previous batch has been consumed
-        slot.hist.zero_()
-        slot.hits[:1].zero_()
+        # no zeroing on the critical path: the q-value kernel hands the histogram back cleared
+        # (GFM_FLAG_CLEAR_HIST) and the hit list restarts through GFM_FLAG_RESET_HITS
         n = int(d_kmers.shape[0])
         need_hist = want_qvalues
         if not on_qvalue:
             cut = dm.pvalue_cutoff(threshold)  # host lookup in p_table, known before scoring
             dm.score(d_kmers, slot.scores[:n], hist=slot.hist if need_hist else None,
                      select_cutoff=cut, row_base=row_base, hit_rows=slot.hit_rows,
-                     hit_count=slot.hit_count)
+                     hit_count=slot.hit_count, reset_hits=True)
         else:
             dm.score(d_kmers, slot.scores[:n], hist=slot.hist)
         slot.scored.record(main)
@@ -90,10 +90,10 @@ class KmerScanner:
                 if self.world > 1:
                     torch.distributed.all_reduce(slot.hist, group=self.group)
                 dm.qvalue_table(slot.hist, threshold, on_qvalue, slot.qtable, slot.cutoff, slot.nrows,
-                                stream=tail)
+                                stream=tail, clear_hist=True)
             if on_qvalue:
                 dm.select_hits(slot.scores[:n], slot.cutoff, slot.hit_rows, slot.hit_count,
-                               row_base=row_base, stream=tail)
+                               row_base=row_base, stream=tail, reset_hits=True)
             if gather_hits and self.world > 1:
                 if self.rank == 0:
                     if slot.gathered is None:

@@ -41,6 +41,9 @@ extern "C" {
 
 #define GFM_MAX_WIDTH 64      /* widest motif the kernels are instantiated for           */
 #define GFM_NO_SELECT INT32_MAX
+/* flags */
+#define GFM_FLAG_RESET_HITS 1u /* start the hit list at 0 instead of appending at *d_hit_count */
+#define GFM_FLAG_CLEAR_HIST 2u /* gfm_qvalue_table: zero the histogram after reading it        */
 /* a hit-list entry packs the global row id and the row's scaled score:
  * entry = (row << GFM_HIT_SCORE_BITS) | score   (score <= 1000*64 < 2^20) */
 #define GFM_HIT_SCORE_BITS 20
@@ -106,13 +109,14 @@ int gfm_motif_annotate(gfm_motif_t m, const int32_t *h_scores, int64_t n,
  *   d_hist     uint64 [L] in/out or NULL: d_hist[s] += #rows scored s.
  *   select_cutoff / d_hit_*: if select_cutoff != GFM_NO_SELECT, rows with
  *              score >= select_cutoff get the entry ((row_base + row) << 20 | score)
- *              appended to d_hit_rows (unordered) and *d_hit_count incremented; hits beyond
- *              hit_capacity are counted but not stored.
+ *              appended to d_hit_rows (unordered) starting at *d_hit_count (at 0 with
+ *              GFM_FLAG_RESET_HITS) and *d_hit_count updated; hits beyond hit_capacity are
+ *              counted but not stored.
  * Enqueues on `stream`; no synchronisation. */
 int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, int32_t *d_scores,
                     uint64_t *d_hist, int32_t select_cutoff, int64_t row_base,
                     int64_t *d_hit_rows, int64_t hit_capacity, uint64_t *d_hit_count,
-                    void *stream);
+                    uint32_t flags, void *stream);
 
 /* Measurement aid (bench.py): with slots > 0 every later gfm_score_kmers call brackets the
  * score kernel ALONE (not the histogram reduction that follows it) with a hipEvent pair on
@@ -126,15 +130,15 @@ int gfm_profile_read(gfm_motif_t m, float *h_ms_out, int capacity, int *n_out);
  * of ALL scored rows:  q(s) = min(1, min_{s'<=s, hist[s']>0} p(s') / (C(s')/n)),
  * C(s') = #rows with score >= s'.  Also the selection cutoff: the smallest s with
  * (on_qvalue ? q(s) : p(s)) < threshold.  All outputs are device memory; any may be NULL. */
-int gfm_qvalue_table(gfm_motif_t m, const uint64_t *d_hist, double threshold, int on_qvalue,
+int gfm_qvalue_table(gfm_motif_t m, uint64_t *d_hist, double threshold, int on_qvalue,
                      double *d_qtable_out, int32_t *d_cutoff_out, uint64_t *d_nrows_out,
-                     void *stream);
+                     uint32_t flags, void *stream);
 
 /* replaces the threshold filter of ResultTmp.to_df (resultsTmp.py:303-307) on device:
  * appends the packed entry of every row with d_scores[row] >= *d_cutoff. */
-int gfm_select_hits(const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
+int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
                     int64_t row_base, int64_t *d_hit_rows, int64_t hit_capacity,
-                    uint64_t *d_hit_count, void *stream);
+                    uint64_t *d_hit_count, uint32_t flags, void *stream);
 
 /* ------------------------------------------------------------------ one-call host form
  * compute_results' numeric core (score_sequences.py:44-211) for host-resident k-mers:
