@@ -85,7 +85,9 @@ def main():
     ap.add_argument("--threshold", type=float, default=1e-4)
     ap.add_argument("--qvalue-threshold", action="store_true", help="--qvalueT: threshold on q")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="run the tail on the main stream")
+    ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
+                    help="run the per-step tail (collective + q-table) on a side stream; auto = only "
+                         "when there is a collective to hide (N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,7 +129,7 @@ def main():
     d_kmers = torch.from_numpy(batch.kmers).to(dev)
     hit_cap = max(4096, n // 32)
     scanner = KmerScanner(dm, n, hit_capacity=hit_cap, device=dev,
-                          group=None, side_stream=not args.no_overlap)
+                          group=None, side_stream=(args.overlap == "on" or (args.overlap == "auto" and world > 1)))
 
     def step():
         return scanner.enqueue(d_kmers, args.threshold, on_qvalue=args.qvalue_threshold,

@@ -1,0 +1,172 @@
+"""compute_results: the scoring step of ``grafimo findmotif`` on the GPU (seam S3).
+
+Drop-in for the reference's score_sequences.py (paths relative to /root/reference/src/grafimo/):
+
+  compute_results(motif, sequence_loc, debug, args_obj=None, testmode=False) -> DataFrame   :44-211
+  compute_qvalues(pvalues, debug)                                                           :401-428
+  print_scoring_msg(motif, noreverse, debug)                                                :433-464
+
+Same arguments, same printed lines, same DataFrame schema.  What changes is the inside: the
+reference forks ``cores`` Python workers that parse the vg TSVs line by line and score every
+k-mer with two O(1000*W) sums (:216-328, :331-396); here the TSVs are parsed by the C++ mmap
+ingest (``cores`` host threads), the k-mer matrix is scored by the HIP kernels, BH q-values come
+from the device score histogram, the threshold is applied on the device and only hit rows come
+back.  There is no CPU scoring fallback: without libgrafimo_hip.so or a GPU the call fails.
+"""
+import ctypes
+import glob
+import os
+import time
+from typing import List, Optional
+
+import numpy as np
+import pandas as pd
+
+from . import _native as nv
+from .device import DeviceMotif
+from .motif import Motif
+from .resultsTmp import build_frame
+from .utils import die, exception_handler, print_progress_bar
+from .workflow import is_findmotif_like
+
+
+class KmerTable:
+    """Columnar view of the vg TSV rows of one motif width (gfm_tsv_* ingest)."""
+
+    def __init__(self, paths: List[str], width: int, skip_reverse: bool, threads: int):
+        arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+        h = ctypes.c_void_p()
+        n = ctypes.c_int64()
+        nv.check(nv.lib().gfm_tsv_open(arr, len(paths), int(width), int(bool(skip_reverse)),
+                                       int(threads), ctypes.byref(h), ctypes.byref(n)))
+        try:
+            self.n = int(n.value)
+            self.width = int(width)
+            self.kmers = np.empty((self.n, width), dtype=np.uint8)
+            self.start = np.empty(self.n, dtype=np.int64)
+            self.stop = np.empty(self.n, dtype=np.int64)
+            self.strand = np.empty(self.n, dtype=np.uint8)
+            self.freq = np.empty(self.n, dtype=np.int64)
+            self.is_ref = np.empty(self.n, dtype=np.uint8)
+            self.name_id = np.empty(self.n, dtype=np.int32)
+            nv.check(nv.lib().gfm_tsv_read(h, nv.ptr(self.kmers), nv.ptr(self.start), nv.ptr(self.stop),
+                                           nv.ptr(self.strand), nv.ptr(self.freq), nv.ptr(self.is_ref),
+                                           None, nv.ptr(self.name_id)))
+            k = nv.lib().gfm_tsv_name_count(h)
+            nbytes = int(nv.lib().gfm_tsv_names_bytes(h))
+            off = np.empty(k + 1, dtype=np.int64)
+            buf = np.empty(max(nbytes, 1), dtype=np.uint8)
+            nv.check(nv.lib().gfm_tsv_names(h, nv.ptr(off), nv.ptr(buf)))
+            raw = buf.tobytes()
+            self.names = [raw[off[i]:off[i + 1]].decode() for i in range(k)]
+        finally:
+            nv.lib().gfm_tsv_close(h)
+
+
+def print_scoring_msg(motif: Motif, noreverse: bool, debug: bool) -> None:
+    """'Scoring hits for motif +ID.' / '-ID.' (score_sequences.py:433-464)."""
+    if not isinstance(motif, Motif):
+        exception_handler(TypeError, f"Expected Motif, got {type(motif).__name__}.\n", debug)
+    if not isinstance(noreverse, bool):
+        exception_handler(TypeError, f"Expected bool, got {type(noreverse).__name__}.\n", debug)
+    msg = "Scoring hits for motif {}."
+    print(msg.format("+" + motif.motif_id))
+    if not noreverse:
+        print(msg.format("-" + motif.motif_id), end="\n\n")
+
+
+def compute_qvalues(pvalues: List[np.double], debug: bool) -> List[np.double]:
+    """Benjamini-Hochberg q-values of a list of p-values (score_sequences.py:401-428).
+    Host-side equivalent kept for API compatibility (sort, p/(rank/n), reverse cumulative
+    minimum, clip at 1); compute_results itself derives q-values from the device histogram."""
+    if not isinstance(pvalues, list):
+        exception_handler(TypeError, f"Expected list, got {type(pvalues).__name__}.\n", debug)
+    print("\nComputing q-values...\n")
+    p = np.asarray(pvalues, dtype=np.float64)
+    n = len(p)
+    order = np.argsort(p, kind="stable")
+    raw = p[order] / (np.arange(1, n + 1) / float(n))
+    corr = np.minimum.accumulate(raw[::-1])[::-1]
+    corr[corr > 1] = 1
+    out = np.empty(n, dtype=np.float64)
+    out[order] = corr
+    return list(out)
+
+
+def compute_results(motif: Motif, sequence_loc: str, debug: bool, args_obj=None,
+                    testmode: Optional[bool] = False) -> pd.DataFrame:
+    """Score the k-mers extracted from the genome variation graph and build the report table.
+
+    ``args_obj`` is the reference's ``Findmotif`` (or grafimo_amd.workflow.Findmotif): .cores,
+    .threshold, .noqvalue, .qvalueT, .noreverse, .recomb, .verbose are read.  ``testmode``
+    hard-codes the reference's test settings (score_sequences.py:100-107)."""
+    if not isinstance(motif, Motif):
+        exception_handler(TypeError, f"Expected Motif, got {type(motif).__name__}.\n", debug)
+    if not isinstance(sequence_loc, str):
+        exception_handler(TypeError, f"Expected str, got {type(sequence_loc).__name__}.\n", debug)
+    if not os.path.isdir(sequence_loc):
+        exception_handler(FileNotFoundError, f"Unable to locate {sequence_loc}.\n", debug)
+    if not testmode:
+        if not is_findmotif_like(args_obj):
+            exception_handler(TypeError, f"Expected Findmotif, got {type(args_obj).__name__}.\n", debug)
+        cores, threshold = args_obj.cores, args_obj.threshold
+        no_qvalue, qval_t = args_obj.noqvalue, args_obj.qvalueT
+        no_reverse, recomb, verbose = args_obj.noreverse, args_obj.recomb, args_obj.verbose
+    else:
+        cores, threshold, recomb = 1, float(1), True
+        no_qvalue = qval_t = no_reverse = verbose = False
+    assert threshold > 0 and threshold <= 1
+    assert cores >= 1
+    print_scoring_msg(motif, no_reverse, debug)
+
+    width = motif.width
+    files = sorted(glob.glob(os.path.join(sequence_loc, f"width_{width}", "*.tsv")))
+    start_s = time.time()
+    print_progress_bar(0, 1, prefix="Progress:", suffix="Complete", length=50)
+    try:
+        table = KmerTable(files, width, no_reverse, cores)
+    except nv.NativeError as e:
+        exception_handler(ValueError if e.code == nv.GFM_ERR_IO else RuntimeError, e.msg + "\n", debug)
+    except KeyboardInterrupt:
+        print("\nCaught SIGINT. GRAFIMO will exit")
+        die(2)
+    if table.n == 0:
+        errmsg = "No result retrieved. Unable to proceed.\n"
+        errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
+        exception_handler(ValueError, errmsg, debug)
+
+    dm = DeviceMotif.from_motif(motif)
+    try:
+        if not no_qvalue:
+            print("\nComputing q-values...\n")
+        hits = dm.scan_host(table.kmers, float(threshold), on_qvalue=bool(qval_t),
+                            want_qvalues=not no_qvalue)
+    finally:
+        dm.close()
+    print_progress_bar(1, 1, prefix="Progress:", suffix="Complete", length=50)
+    if verbose:
+        print("Sequences scored in %.2fs" % (time.time() - start_s))
+    print(f"Scanned sequences:\t{table.n}")
+    print(f"Scanned nucleotides:\t{table.n * width}")
+
+    start_df = time.time()
+    rows = hits["rows"]
+    names = np.array(table.names, dtype=object)
+    seqs = [bytes(k).decode() for k in table.kmers[rows]]
+    df = build_frame(
+        motif,
+        seqnames=list(names[table.name_id[rows]]),
+        starts=table.start[rows],
+        stops=table.stop[rows],
+        strands=[chr(c) for c in table.strand[rows]],
+        scores=hits["logodds"],
+        pvalues=hits["pvalue"],
+        qvalues=None if no_qvalue else hits["qvalue"],
+        seqs=seqs,
+        frequencies=table.freq[rows],
+        references=["ref" if r else "non.ref" for r in table.is_ref[rows]],
+        threshold=None, recomb=bool(recomb),
+    )
+    if verbose:
+        print("\nResults summary built in %.2fs" % (time.time() - start_df))
+    return df

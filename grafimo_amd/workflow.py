@@ -1,0 +1,40 @@
+"""Argument container for the scoring step.
+
+The reference passes its ``Findmotif`` workflow object (workflow.py:233-634) into
+``compute_results`` and ``get_motif_pwm``; only a handful of read-only properties are used on
+the hot path.  ``Findmotif`` here carries exactly those (same property names and defaults as
+the CLI: __main__.py:119-415), so either this object or the reference's own instance can be
+passed to ``grafimo_amd.score_sequences.compute_results``.
+"""
+from .utils import UNIF
+
+
+class Findmotif(object):
+    def __init__(self, cores=1, threshold=1e-4, no_qvalue=False, qval_t=False, no_reverse=False,
+                 recomb=False, verbose=False, bgfile=UNIF, pseudo=0.1):
+        self._cores = int(cores)
+        self._thresh = float(threshold)
+        self._no_qvalue = bool(no_qvalue)
+        self._qvalueT = bool(qval_t)
+        self._no_rev = bool(no_reverse)
+        self._recomb = bool(recomb)
+        self._verbose = bool(verbose)
+        self._bgfile = bgfile
+        self._pseudo = float(pseudo)
+
+    cores = property(lambda self: self._cores)
+    threshold = property(lambda self: self._thresh)
+    noqvalue = property(lambda self: self._no_qvalue)
+    qvalueT = property(lambda self: self._qvalueT)
+    noreverse = property(lambda self: self._no_rev)
+    recomb = property(lambda self: self._recomb)
+    verbose = property(lambda self: self._verbose)
+    bgfile = property(lambda self: self._bgfile)
+    pseudo = property(lambda self: self._pseudo)
+
+
+REQUIRED_FLAGS = ("cores", "threshold", "noqvalue", "qvalueT", "noreverse", "recomb", "verbose")
+
+
+def is_findmotif_like(obj) -> bool:
+    return all(hasattr(obj, k) for k in REQUIRED_FLAGS)

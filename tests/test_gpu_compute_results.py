@@ -1,0 +1,111 @@
+"""compute_results (the S3 drop-in) on a real MI355X vs the reference's golden tables.
+Written like the reference's own test_scoring (tests/grafimo_run_test.py:119-140)."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN, REF_DATA
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+FLOAT_RTOL = 1e-9   # north_star: within 1e-6 of the reference; the tables agree to ~1e-15
+
+
+def _ctcf(pvalue_matrix):
+    from grafimo_amd.motif_ops import build_motif_meme
+    with contextlib.redirect_stdout(io.StringIO()):
+        return build_motif_meme(os.path.join(REF_DATA, "MA0139.1.meme"), "unfrm_dst", 0.1, False,
+                                os.cpu_count(), False, True, pvalue_matrix=pvalue_matrix)[0]
+
+
+def _compare(df, exp):
+    assert list(df.columns) == list(exp.columns)
+    key = ["p-value", "start", "stop", "strand"]
+    a = df.sort_values(key).reset_index(drop=True)
+    b = exp.sort_values(key).reset_index(drop=True)
+    assert len(a) == len(b)
+    for c in exp.columns:
+        if c in ("p-value", "q-value"):
+            np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=FLOAT_RTOL, atol=0)
+        elif c == "score":
+            assert np.array_equal(a[c].to_numpy(float), b[c].to_numpy(float))   # exact: s/scale + W*offset
+        else:
+            assert (a[c].astype(str) == b[c].astype(str)).all(), c
+
+
+def test_motif_processing_with_device_dp_matches_reference(golden_motifs):
+    """process_motif_for_logodds end to end (DP on the GPU): pval_matrix bit-identical."""
+    _, flat = golden_motifs
+    m = _ctcf(True)
+    assert np.array_equal(m.pval_matrix, flat["ctcf_meme_unif#0"]["pmf"])
+    assert m.pval_matrix.dtype == np.float64 and len(m.pval_matrix) == 19001
+
+
+def test_scoring_like_the_reference_test(capsys):
+    """test_scoring: compute_results(motif, dir, True, None, testmode=True) vs scoring_results.tsv"""
+    from grafimo_amd.score_sequences import compute_results
+    motif = _ctcf(True)
+    exp = pd.read_csv(os.path.join(REF_DATA, "scoring_results.tsv"), sep="\t", index_col=0)
+    res = compute_results(motif, REF_DATA, True, None, testmode=True)
+    out = capsys.readouterr().out
+    assert "Scoring hits for motif +MA0139.1." in out and "Scoring hits for motif -MA0139.1." in out
+    assert "Scanned sequences:\t704" in out and "Scanned nucleotides:\t13376" in out
+    assert "Computing q-values" in out
+    tmp = os.path.join("/tmp", f"gpu_scoring_{os.getpid()}.tsv")
+    res.to_csv(tmp, sep="\t")
+    got = pd.read_csv(tmp, sep="\t", index_col=0)
+    os.remove(tmp)
+    _compare(got, exp)
+    assert (np.diff(res["p-value"].to_numpy()) >= 0).all()     # sorted by p-value
+
+
+@pytest.mark.parametrize("name", ["default_t1e-2", "qvalt_t0.6", "noqvalue_t5e-3", "norev_t1e-1",
+                                  "recomb_t1", "norecomb_t1", "cores4_t5e-2"])
+def test_flag_settings(golden_json, name):
+    from grafimo_amd.score_sequences import compute_results
+    from grafimo_amd.workflow import Findmotif
+    case = golden_json("compute_results.json")[name]
+    kw = case["kwargs"]
+    wf = Findmotif(cores=kw.get("cores", 1), threshold=kw.get("threshold", 1e-4),
+                   no_qvalue=kw.get("no_qvalue", False), qval_t=kw.get("qval_t", False),
+                   no_reverse=kw.get("no_reverse", False), recomb=kw.get("recomb", False))
+    motif = _ctcf(False)          # no pval_matrix on the Motif: the device computes it
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        df = compute_results(motif, REF_DATA, True, wf)
+    exp = pd.DataFrame(case["df"]["rows"], columns=case["df"]["columns"])
+    _compare(df, exp)
+    # same user-visible counters as the reference printed
+    for line in case["stdout"].splitlines():
+        if line.startswith("Scanned"):
+            assert line in buf.getvalue()
+
+
+def test_synthetic_tsv_directory_end_to_end(tmp_path, golden_motifs):
+    """vg-style TSV files written from a synthetic batch -> ingest -> GPU -> table, against the
+    CPU oracle's compute_results on the same directory (multi-file, N rows, both strands)."""
+    from grafimo_amd import synth
+    from grafimo_amd.score_sequences import compute_results
+    from grafimo_amd.workflow import Findmotif
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    g = flat["ctcf_meme_unif#0"]
+    motif = _ctcf(True)
+    batch = synth.make_batch(6, 500, 19, g["probs"], synth.seed_for(1))
+    synth.write_tsv_dir(batch, str(tmp_path))
+    for kw in [dict(threshold=1e-3), dict(threshold=0.2, qval_t=True), dict(threshold=1e-2, no_reverse=True, recomb=True)]:
+        wf = Findmotif(cores=3, **kw)
+        with contextlib.redirect_stdout(io.StringIO()):
+            df = compute_results(motif, str(tmp_path), True, wf)
+        md = dict(score_matrix=g["score_matrix"], pmf=g["pmf"], min_val=g["min_val"], scale=g["scale"],
+                  offset=g["offset"], width=19, motif_id=g["motif_id"], motif_name=g["motif_name"])
+        ref = orc.compute_results(md, str(tmp_path), threshold=kw["threshold"], qval_t=kw.get("qval_t", False),
+                                  no_reverse=kw.get("no_reverse", False), recomb=kw.get("recomb", False))
+        cols = [c for c in ref if not c.startswith("_")]
+        exp = pd.DataFrame({c: ref[c] for c in cols})
+        assert len(df) > 0
+        _compare(df, exp)
