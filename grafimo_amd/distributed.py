@@ -1,0 +1,242 @@
+"""Sharded motif scan across the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm).
+
+Regions (TSV files) are independent (the reference already splits files over worker processes,
+score_sequences.py:123), so rows shard with no data-path exchange except the one the statistics
+need:
+
+  * all-reduce(sum) of the per-motif score histogram  -- BH ranks and n are global; 1000*W+1
+    int64 bins (152 KB at W=19): latency-bound on 7 x ~153 GB/s xGMI links, so one flat
+    all-reduce per motif, no bucketing;
+  * gather of the hit rows to rank 0 for the report (hits are ~1e-4..1e-2 of the rows).
+
+With --no-qvalue and a p-value threshold no collective is needed before the gather.
+
+The collective logic is backend-agnostic (``ScanBackend``): the product backend is the HIP path
+(``HipBackend``); the CPU test-suite drives the same orchestration over gloo with a stand-in
+backend, which is how the N > 1 path is covered without GPUs.
+"""
+import glob
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+import pandas as pd
+
+from .motif import Motif
+from .resultsTmp import build_frame
+from .utils import exception_handler
+
+HIT_SCORE_BITS = 20
+
+
+# ------------------------------------------------------------------------------ sharding
+def shard_bounds(n_items: int, world: int, rank: int):
+    """Contiguous balanced split [lo, hi) of n_items over `world` ranks (np.array_split rule:
+    the first n % world shards get one extra item)."""
+    base, extra = divmod(int(n_items), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_files(files: Sequence[str], world: int, rank: int, by_size: bool = True) -> List[str]:
+    """Contiguous range of the (sorted) file list for this rank, balanced by file size so that
+    every GPU scores about the same number of rows; each region's TSV stays on one device."""
+    files = list(files)
+    if not by_size or not files:
+        lo, hi = shard_bounds(len(files), world, rank)
+        return files[lo:hi]
+    sizes = np.array([max(os.path.getsize(f), 1) for f in files], dtype=np.float64)
+    cum = np.cumsum(sizes)
+    total = cum[-1]
+    # file i goes to the rank whose share of the total its midpoint falls into
+    owner = np.minimum(((cum - sizes / 2) / total * world).astype(int), world - 1)
+    return [f for f, o in zip(files, owner) if o == rank]
+
+
+# ------------------------------------------------------------------------------ backends
+class ScanBackend:
+    """What the sharded orchestration needs from a scorer.  All arrays are numpy on return;
+    `hist` is exchanged as a torch tensor on `self.device` so that the collective runs where
+    the data lives."""
+    device = None
+    L = 0
+
+    def score(self, kmers: np.ndarray):
+        """-> (scaled int32[n], hist torch.int64[L] on self.device)"""
+        raise NotImplementedError
+
+    def tables(self, hist, threshold: float, on_qvalue: bool):
+        """global hist -> (qtable f64[L] numpy, cutoff int, n_rows int)"""
+        raise NotImplementedError
+
+    def pvalue_cutoff(self, threshold: float) -> int:
+        raise NotImplementedError
+
+    def annotate(self, scaled: np.ndarray):
+        """-> (logodds f64, pvalue f64)"""
+        raise NotImplementedError
+
+
+class HipBackend(ScanBackend):
+    """The product backend: DeviceMotif on the current GPU."""
+
+    def __init__(self, motif: Motif, device=None):
+        import torch
+        from .device import DeviceMotif
+        self.torch = torch
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.dm = DeviceMotif.from_motif(motif)
+        self.L = self.dm.L
+        self._scores = None
+
+    def score(self, kmers):
+        torch = self.torch
+        n = int(kmers.shape[0])
+        d_k = torch.from_numpy(np.ascontiguousarray(kmers)).to(self.device) if n else \
+            torch.empty((0, self.dm.width), dtype=torch.uint8, device=self.device)
+        self._scores = torch.empty(n, dtype=torch.int32, device=self.device)
+        hist = torch.zeros(self.L, dtype=torch.int64, device=self.device)
+        self.dm.score(d_k, self._scores, hist=hist)
+        return None, hist   # scores stay on the device; hits are selected there
+
+    def tables(self, hist, threshold, on_qvalue):
+        torch = self.torch
+        q = torch.empty(self.L, dtype=torch.float64, device=self.device)
+        cut = torch.zeros(1, dtype=torch.int32, device=self.device)
+        nrows = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.dm.qvalue_table(hist, threshold, on_qvalue, q, cut, nrows)
+        return q.cpu().numpy(), int(cut.item()), int(nrows.item())
+
+    def pvalue_cutoff(self, threshold):
+        return self.dm.pvalue_cutoff(threshold)
+
+    def select(self, cutoff: int, row_base: int):
+        """rows with score >= cutoff -> (global rows int64, scaled int32), ascending by row"""
+        torch = self.torch
+        n = int(self._scores.numel())
+        cap = max(n, 1)
+        hits = torch.zeros(cap + 1, dtype=torch.int64, device=self.device)
+        d_cut = torch.tensor([cutoff], dtype=torch.int32, device=self.device)
+        self.dm.select_hits(self._scores, d_cut, hits[1:], hits[:1], row_base=row_base, reset_hits=True)
+        k = int(hits[0].item())
+        packed = np.sort(hits[1:1 + k].cpu().numpy())
+        return packed >> HIT_SCORE_BITS, (packed & ((1 << HIT_SCORE_BITS) - 1)).astype(np.int32)
+
+    def annotate(self, scaled):
+        return self.dm.annotate(scaled)
+
+    def close(self):
+        self.dm.close()
+
+
+# ------------------------------------------------------------------------------ orchestration
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def sharded_scan(backend: ScanBackend, kmers: np.ndarray, threshold: float, on_qvalue: bool,
+                 want_qvalues: bool, group=None, select=None):
+    """One motif over this rank's rows.  Returns dict(rows (global ids), scaled, logodds,
+    pvalue[, qvalue], n_scored (global), row_base).  Collectives: all_gather of the row counts
+    (global row ids), all_reduce of the histogram when q-values are wanted."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_local = int(kmers.shape[0])
+    counts = torch.zeros(world, dtype=torch.int64, device=backend.device)
+    counts[rank] = n_local
+    if world > 1:
+        dist.all_reduce(counts, group=group)
+    counts = counts.cpu().numpy()
+    row_base = int(counts[:rank].sum())
+    n_global = int(counts.sum())
+
+    scaled_all, hist = backend.score(kmers)
+    qtable = None
+    if want_qvalues:
+        if world > 1:
+            dist.all_reduce(hist, group=group)          # the one data-path exchange
+        qtable, cutoff_q, n_hist = backend.tables(hist, threshold, on_qvalue)
+        assert n_hist == n_global, (n_hist, n_global)
+    cutoff = cutoff_q if on_qvalue else backend.pvalue_cutoff(threshold)
+    if select is not None:
+        rows, scaled = select(scaled_all, cutoff, row_base)
+    else:
+        rows, scaled = backend.select(cutoff, row_base)
+    lo, pv = backend.annotate(scaled)
+    out = dict(rows=rows, scaled=scaled, logodds=lo, pvalue=pv, n_scored=n_global, row_base=row_base)
+    if want_qvalues:
+        out["qvalue"] = qtable[scaled]
+    return out
+
+
+def gather_frames(df_local: pd.DataFrame, group=None) -> Optional[pd.DataFrame]:
+    """Hit tables of all ranks -> one table on rank 0 (None elsewhere), ascending by p-value
+    (stable: ties keep global row order because shards are contiguous and gathered in rank order)."""
+    dist = _dist()
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return df_local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    bucket = [None] * world if rank == 0 else None
+    dist.gather_object(df_local, bucket, dst=0, group=group)
+    if rank != 0:
+        return None
+    df = pd.concat(bucket, ignore_index=True)
+    df = df.sort_values(["p-value"], ascending=True, kind="stable")
+    df.reset_index(drop=True, inplace=True)
+    return df
+
+
+def compute_results_sharded(motif: Motif, sequence_loc: str, debug: bool, args_obj, group=None,
+                            backend: Optional[ScanBackend] = None) -> Optional[pd.DataFrame]:
+    """compute_results (score_sequences.py:44-211) with the TSV files sharded over the ranks of
+    `group`.  Every rank calls it; rank 0 gets the report table, the others None."""
+    from .score_sequences import KmerTable, print_scoring_msg
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    threshold = float(args_obj.threshold)
+    no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
+    no_reverse, recomb = bool(args_obj.noreverse), bool(args_obj.recomb)
+    if rank == 0:
+        print_scoring_msg(motif, no_reverse, debug)
+    width = motif.width
+    files = sorted(glob.glob(os.path.join(sequence_loc, f"width_{width}", "*.tsv")))
+    mine = shard_files(files, world, rank)
+    table = KmerTable(mine, width, no_reverse, max(1, int(args_obj.cores)))
+    own_backend = backend is None
+    if own_backend:
+        backend = HipBackend(motif)
+    try:
+        res = sharded_scan(backend, table.kmers, threshold, qval_t, not no_qvalue, group=group,
+                           select=getattr(backend, "select_host", None))
+    finally:
+        if own_backend:
+            backend.close()
+    if res["n_scored"] == 0:
+        errmsg = "No result retrieved. Unable to proceed.\n"
+        errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
+        exception_handler(ValueError, errmsg, debug)
+    local = res["rows"] - res["row_base"]
+    names = np.array(table.names, dtype=object)
+    df = build_frame(
+        motif,
+        seqnames=list(names[table.name_id[local]]) if len(local) else [],
+        starts=table.start[local], stops=table.stop[local],
+        strands=[chr(c) for c in table.strand[local]],
+        scores=res["logodds"], pvalues=res["pvalue"],
+        qvalues=None if no_qvalue else res["qvalue"],
+        seqs=[bytes(k).decode() for k in table.kmers[local]],
+        frequencies=table.freq[local],
+        references=["ref" if r else "non.ref" for r in table.is_ref[local]],
+        threshold=None, recomb=recomb,
+    )
+    out = gather_frames(df, group)
+    if rank == 0:
+        print(f"Scanned sequences:\t{res['n_scored']}")
+        print(f"Scanned nucleotides:\t{res['n_scored'] * width}")
+    return out

@@ -45,7 +45,8 @@ class ScanSlot:
 
 class KmerScanner:
     def __init__(self, dm: DeviceMotif, n_rows: int, hit_capacity: Optional[int] = None,
-                 device=None, group=None, n_slots: int = 2, side_stream: bool = True):
+                 device=None, group=None, n_slots: int = 2, side_stream: bool = True,
+                 always_collective: bool = False):
         torch = _torch()
         self.dm = dm
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -55,6 +56,10 @@ class KmerScanner:
         if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(group)
             self.rank = torch.distributed.get_rank(group)
+        # always_collective: issue the collectives even in a world of one (exercises the RCCL
+        # calls on a single-GPU box)
+        self.collective = self.world > 1 or (always_collective and torch.distributed.is_initialized())
+        self._gather_ok = True
         cap = int(hit_capacity) if hit_capacity is not None else int(n_rows)
         self.slots = [ScanSlot(dm, n_rows, cap, self.device) for _ in range(n_slots)]
         self.side = torch.cuda.Stream(device=self.device) if side_stream else None
@@ -87,22 +92,34 @@ class KmerScanner:
         with torch.cuda.stream(tail):
             tail.wait_event(slot.scored)
             if need_hist:
-                if self.world > 1:
+                if self.collective:
                     torch.distributed.all_reduce(slot.hist, group=self.group)
                 dm.qvalue_table(slot.hist, threshold, on_qvalue, slot.qtable, slot.cutoff, slot.nrows,
                                 stream=tail, clear_hist=True)
             if on_qvalue:
                 dm.select_hits(slot.scores[:n], slot.cutoff, slot.hit_rows, slot.hit_count,
                                row_base=row_base, stream=tail, reset_hits=True)
-            if gather_hits and self.world > 1:
-                if self.rank == 0:
-                    if slot.gathered is None:
-                        slot.gathered = [torch.empty_like(slot.hits) for _ in range(self.world)]
-                    torch.distributed.gather(slot.hits, slot.gathered, dst=0, group=self.group)
-                else:
-                    torch.distributed.gather(slot.hits, None, dst=0, group=self.group)
+            if gather_hits and self.collective:
+                self._gather(slot)
             slot.done.record(tail)
         return slot
+
+    def _gather(self, slot: ScanSlot):
+        """hit buffers ([count | entries], fixed size) of all ranks -> rank 0.  gather moves
+        (world-1) buffers into rank 0 only; if the backend lacks it, all_gather is the fallback."""
+        torch = _torch()
+        dist = torch.distributed
+        if slot.gathered is None and (self.rank == 0 or not self._gather_ok):
+            slot.gathered = [torch.empty_like(slot.hits) for _ in range(self.world)]
+        if self._gather_ok:
+            try:
+                dist.gather(slot.hits, slot.gathered if self.rank == 0 else None, dst=0, group=self.group)
+                return
+            except (RuntimeError, NotImplementedError):
+                self._gather_ok = False
+                if slot.gathered is None:
+                    slot.gathered = [torch.empty_like(slot.hits) for _ in range(self.world)]
+        dist.all_gather(slot.gathered, slot.hits, group=self.group)
 
     def finish(self):
         """Make the caller's stream wait for all side-stream work."""

@@ -1,0 +1,182 @@
+"""The N > 1 path on CPU: world_size-2 gloo runs of the sharded orchestration
+(grafimo_amd/distributed.py) with a stand-in scoring backend built on the CPU oracle.
+What is under test is the sharding, the histogram all-reduce, global row ids, the q-table
+from the GLOBAL histogram and the gather/merge of hit tables -- not the kernels."""
+import contextlib
+import io
+import os
+import socket
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import GOLDEN, REF_DATA, ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _golden_ctcf():
+    import json
+    with open(os.path.join(GOLDEN, "motifs.json")) as fh:
+        g = json.load(fh)["ctcf_meme_unif"]["motifs"][0]
+    g["pmf"] = np.load(os.path.join(GOLDEN, "pmf.npz"))[g["pmf_key"]]
+    return g
+
+
+def _make_backend(g):
+    import torch
+    from grafimo_amd.distributed import ScanBackend
+    from oracle import oracle as orc
+
+    class OracleBackend(ScanBackend):
+        """test stand-in: oracle arithmetic, torch CPU tensors for the collectives"""
+        device = torch.device("cpu")
+        L = 19001
+
+        def __init__(self):
+            self.ptab = orc.p_table(g["pmf"])
+            self.sm = np.array(g["score_matrix"], dtype=np.int64)
+
+        def score(self, kmers):
+            if len(kmers) == 0:
+                return np.empty(0, np.int32), torch.zeros(self.L, dtype=torch.int64)
+            sc, _ = orc.score_kmers_table(kmers, self.sm, self.ptab, g["min_val"])
+            return sc, torch.from_numpy(np.bincount(sc, minlength=self.L).astype(np.int64))
+
+        def tables(self, hist, threshold, on_qvalue):
+            h = hist.numpy()
+            scores = np.repeat(np.arange(self.L), h)
+            q_rows = orc.fdr_bh(self.ptab[scores])
+            q = np.ones(self.L)
+            q[scores] = q_rows                      # all rows of one score share q
+            val = q if on_qvalue else self.ptab
+            occ = np.nonzero(h)[0]
+            ok = occ[val[occ] < threshold]
+            # cutoff semantics of gfm_qvalue_table: smallest score whose value is < threshold
+            cutoff = int(ok.min()) if len(ok) else self.L
+            return q, cutoff, int(h.sum())
+
+        def pvalue_cutoff(self, threshold):
+            idx = np.nonzero(self.ptab < threshold)[0]
+            return int(idx.min()) if len(idx) else self.L
+
+        def select_host(self, scaled_all, cutoff, row_base):
+            rows = np.nonzero(scaled_all >= cutoff)[0]
+            return rows + row_base, scaled_all[rows]
+
+        def annotate(self, scaled):
+            lo = scaled / g["scale"] + 19 * g["offset"]
+            return lo.astype(np.float64), self.ptab[scaled]
+
+    return OracleBackend()
+
+
+def _worker(rank, world, port, seqdir, kw, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    from grafimo_amd.distributed import compute_results_sharded
+    from grafimo_amd.motif import Motif
+    from grafimo_amd.workflow import Findmotif
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = _golden_ctcf()
+        m = Motif(np.array(g["probs"]), 19, ["A", "C", "G", "T"], g["motif_id"], g["motif_name"],
+                  {n: i for i, n in enumerate("ACGT")})
+        with contextlib.redirect_stdout(io.StringIO()) as buf:
+            df = compute_results_sharded(m, seqdir, True, Findmotif(**kw), backend=_make_backend(g))
+        if rank == 0:
+            df.to_pickle(os.path.join(outdir, "df.pkl"))
+            with open(os.path.join(outdir, "stdout.txt"), "w") as fh:
+                fh.write(buf.getvalue())
+        else:
+            assert df is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, seqdir, kw, outdir):
+    import torch.multiprocessing as mp
+    mp.spawn(_worker, args=(world, _free_port(), seqdir, kw, outdir), nprocs=world, join=True)
+    with open(os.path.join(outdir, "stdout.txt")) as fh:
+        return pd.read_pickle(os.path.join(outdir, "df.pkl")), fh.read()
+
+
+@pytest.fixture(scope="module")
+def tsv_dir(tmp_path_factory):
+    from grafimo_amd import synth
+    g = _golden_ctcf()
+    d = tmp_path_factory.mktemp("seqs")
+    batch = synth.make_batch(7, 400, 19, np.array(g["probs"]), synth.seed_for(1))   # 7 files: ragged split
+    synth.write_tsv_dir(batch, str(d))
+    return str(d)
+
+
+def _oracle_table(seqdir, kw):
+    from oracle import oracle as orc
+    g = _golden_ctcf()
+    md = dict(score_matrix=np.array(g["score_matrix"]), pmf=g["pmf"], min_val=g["min_val"],
+              scale=g["scale"], offset=g["offset"], width=19, motif_id=g["motif_id"],
+              motif_name=g["motif_name"])
+    ref = orc.compute_results(md, seqdir, threshold=kw["threshold"], qval_t=kw.get("qval_t", False),
+                              no_qvalue=kw.get("no_qvalue", False), no_reverse=kw.get("no_reverse", False),
+                              recomb=kw.get("recomb", False))
+    return pd.DataFrame({c: ref[c] for c in ref if not c.startswith("_")}), ref["_scanned"]
+
+
+@pytest.mark.parametrize("kw", [dict(threshold=1e-3), dict(threshold=0.3, qval_t=True),
+                                dict(threshold=1e-2, no_qvalue=True, recomb=True),
+                                dict(threshold=5e-2, no_reverse=True)])
+def test_two_ranks_equal_the_single_process_table(tsv_dir, tmp_path, kw):
+    df, out = _run(2, tsv_dir, kw, str(tmp_path))
+    exp, scanned = _oracle_table(tsv_dir, kw)
+    assert f"Scanned sequences:\t{scanned}" in out
+    assert list(df.columns) == list(exp.columns) and len(df) == len(exp) and len(df) > 0
+    key = ["p-value", "start", "stop", "strand", "matched_sequence"]
+    a = df.sort_values(key).reset_index(drop=True)
+    b = exp.sort_values(key).reset_index(drop=True)
+    for c in exp.columns:
+        if b[c].dtype.kind == "f":
+            np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-12, atol=0)
+        else:
+            assert (a[c].astype(str) == b[c].astype(str)).all(), c
+    assert (np.diff(df["p-value"].to_numpy()) >= 0).all()
+
+
+def test_world_of_one_and_empty_shard(tsv_dir, tmp_path):
+    """world_size 3 over 7 files of which a rank may get few; and the reference's 1-file fixture
+    over 2 ranks leaves rank 1 with an EMPTY shard -- its histogram still joins the all-reduce."""
+    kw = dict(threshold=0.5, qval_t=True, recomb=True)
+    d3 = tmp_path / "w3"; d3.mkdir()
+    df3, _ = _run(3, tsv_dir, kw, str(d3))
+    exp, _ = _oracle_table(tsv_dir, kw)
+    assert len(df3) == len(exp)
+    d2 = tmp_path / "w2"; d2.mkdir()
+    df, out = _run(2, REF_DATA, dict(threshold=1.0, recomb=True), str(d2))
+    assert len(df) == 704 and "Scanned sequences:\t704" in out
+
+
+def test_shard_helpers(tmp_path):
+    from grafimo_amd.distributed import shard_bounds, shard_files
+    for n in [0, 1, 7, 8, 1000]:
+        for w in [1, 2, 3, 8]:
+            parts = [shard_bounds(n, w, r) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+    files = []
+    for i, sz in enumerate([10, 10, 10, 500, 10, 10, 10, 10]):
+        p = tmp_path / f"f{i:02d}.tsv"
+        p.write_bytes(b"x" * sz)
+        files.append(str(p))
+    for w in [1, 2, 4, 8]:
+        shards = [shard_files(files, w, r) for r in range(w)]
+        assert sum(shards, []) == files                    # contiguous cover, order kept
+    assert shard_files([], 4, 2) == []

@@ -109,3 +109,54 @@ def test_synthetic_tsv_directory_end_to_end(tmp_path, golden_motifs):
         exp = pd.DataFrame({c: ref[c] for c in cols})
         assert len(df) > 0
         _compare(df, exp)
+
+
+def test_sharded_entry_point_on_one_gpu(golden_json):
+    """compute_results_sharded with the HIP backend and no process group == compute_results."""
+    from grafimo_amd.distributed import compute_results_sharded
+    from grafimo_amd.score_sequences import compute_results
+    from grafimo_amd.workflow import Findmotif
+    motif = _ctcf(True)
+    for kw in [dict(threshold=1e-2), dict(threshold=0.6, qval_t=True), dict(threshold=1.0, recomb=True)]:
+        with contextlib.redirect_stdout(io.StringIO()):
+            a = compute_results_sharded(motif, REF_DATA, True, Findmotif(**kw))
+            b = compute_results(motif, REF_DATA, True, Findmotif(**kw))
+        assert len(a) == len(b) and len(a) > 0
+        _compare(a, b)
+
+
+def test_scanner_collectives_on_one_gpu_rccl(golden_motifs):
+    """KmerScanner with an RCCL process group of one rank: the all-reduce of the histogram and
+    the gather of hits are really issued (same calls as at N = 8), results unchanged."""
+    import socket
+    import torch.distributed as dist
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.scan import KmerScanner
+    from grafimo_amd import synth
+    _, flat = golden_motifs
+    g = flat["ctcf_meme_unif#0"]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        dm = DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"], g["pmf"])
+        batch = synth.make_batch(50, 500, 19, g["probs"], synth.seed_for(3))
+        d_k = torch.from_numpy(batch.kmers).to(dev)
+        n = len(batch)
+        plain = KmerScanner(dm, n, device=dev, side_stream=False)
+        coll = KmerScanner(dm, n, device=dev, side_stream=True, always_collective=True)
+        for on_q, thr in [(False, 1e-3), (True, 0.2)]:
+            r0 = plain.collect(plain.enqueue(d_k, thr, on_qvalue=on_q))
+            for _ in range(3):   # slots rotate; the side stream hands buffers back cleared
+                slot = coll.enqueue(d_k, thr, on_qvalue=on_q, gather_hits=True)
+            r1 = coll.collect(slot)
+            assert np.array_equal(r0["rows"], r1["rows"]) and np.array_equal(r0["scaled"], r1["scaled"])
+            assert np.array_equal(r0["qtable"], r1["qtable"]) and r0["n_scored"] == r1["n_scored"] == n
+            assert len(r0["rows"]) > 0
+        dm.close()
+    finally:
+        dist.destroy_process_group()
