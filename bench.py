@@ -85,9 +85,14 @@ def main():
     ap.add_argument("--threshold", type=float, default=1e-4)
     ap.add_argument("--qvalue-threshold", action="store_true", help="--qvalueT: threshold on q")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slots", type=int, default=2, help="buffer slots of the scan pipeline")
+    ap.add_argument("--event-every", type=int, default=5,
+                    help="bracket the score kernel of every n-th step with a hipEvent pair")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="diagnostic: do not bracket the score kernel with events in the timed region")
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
-                    help="run the per-step tail (collective + q-table) on a side stream; auto = only "
-                         "when there is a collective to hide (N > 1)")
+                    help="run the per-step tail (post kernel, collective, q-table, gather) on a side "
+                         "stream so that it overlaps the next step's score kernel; auto = on")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,7 +134,7 @@ def main():
     d_kmers = torch.from_numpy(batch.kmers).to(dev)
     hit_cap = max(4096, n // 32)
     scanner = KmerScanner(dm, n, hit_capacity=hit_cap, device=dev,
-                          group=None, side_stream=(args.overlap == "on" or (args.overlap == "auto" and world > 1)))
+                          group=None, side_stream=args.overlap != "off", n_slots=args.slots)
 
     def step():
         return scanner.enqueue(d_kmers, args.threshold, on_qvalue=args.qvalue_threshold,
@@ -145,7 +150,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    dm.profile_enable(min(args.steps, 1024))
+    if not args.no_kernel_events:
+        dm.profile_enable(min(args.steps, 1024), every=args.event_every)
     fence()
     t0 = time.perf_counter()
     slot = None

@@ -24,6 +24,7 @@ GFM_ERR_OVERFLOW = -7
 GFM_NO_SELECT = 2**31 - 1
 GFM_FLAG_RESET_HITS = 1
 GFM_FLAG_CLEAR_HIST = 2
+GFM_FLAG_CALLER_ORDERS_REUSE = 4
 GFM_MAX_WIDTH = 64
 RANGE = 1000
 
@@ -53,8 +54,8 @@ PROTOTYPES = {
     "gfm_motif_pvalue_cutoff": (c_int, [c_void_p, c_double, P(c_i32)]),
     "gfm_motif_annotate": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "gfm_score_kmers": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_i64,
-                                c_void_p, c_i64, c_void_p, ctypes.c_uint32, c_void_p]),
-    "gfm_profile_enable": (c_int, [c_void_p, c_int]),
+                                c_void_p, c_i64, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
+    "gfm_profile_enable": (c_int, [c_void_p, c_int, c_int]),
     "gfm_profile_read": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
     "gfm_qvalue_table": (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                  ctypes.c_uint32, c_void_p]),

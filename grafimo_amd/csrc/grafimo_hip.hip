@@ -51,18 +51,19 @@ int fail(int code, const char *fmt, ...)
 // ---------------------------------------------------------------------------------------
 // score kernel geometry
 constexpr int kWave = 64;
-constexpr int kThreads = 512;                  // 8 waves per workgroup
+constexpr int kThreads = 1024;                 // 16 waves per workgroup, one workgroup per CU
 constexpr int kWavesPerWG = kThreads / kWave;
 constexpr int kChunk = 128;                    // k-mers per wave per iteration (multiple of 64)
 constexpr unsigned kPoison = 0xFFFFu;          // table entry of a byte that is not A,C,G,T (> 1000*64)
 constexpr int kMaxLdsBytes = 160 * 1024;
-constexpr int kWGsPerCU = 3;                   // target residency of the score kernel
+constexpr int kWGsPerCU = 1;                   // target residency of the score kernel
+constexpr int kReserveCUs = 4;                 // CUs left to tail-stream kernels when one is given
 constexpr int kHitQueue = 64;                  // per-wave LDS hit queue (entries, >= 64)
-constexpr int kDepth = 2;                      // chunks prefetched ahead per wave
+constexpr int kDepth = 3;                      // chunks prefetched ahead per wave
 
-// per-wave LDS strip: the staged chunk (+16 B slack for the last row's trailing dword),
+// per-wave LDS strip: the staged chunk (+8 B slack for the last row's trailing dword),
 // followed by the wave's hit queue
-__host__ __device__ inline int stage_data_bytes(int W) { return ((kChunk * W + 15) & ~15) + 16; }
+__host__ __device__ inline int stage_data_bytes(int W) { return ((kChunk * W + 15) & ~15) + 8; }
 __host__ __device__ inline int stage_stride_bytes(int W) { return stage_data_bytes(W) + kHitQueue * 8; }
 
 // ---------------------------------------------------------------------------------------
@@ -79,7 +80,7 @@ struct HitCtl {
     unsigned long long mid[3];   // entries flushed mid-run by the current call
     unsigned long long snap[3];  // *hit_count as the call found it
 };
-constexpr int kResidPerWG = 8 * kHitQueue;  // staging slab entries per workgroup
+constexpr int kResidPerWG = kWavesPerWG * kHitQueue;  // staging slab entries per workgroup
 
 __device__ inline void hitq_push(long long *hitq, int &qn, bool hit, long long entry, int lane,
                                  const unsigned long long *hit_count, unsigned long long *mid,
@@ -125,12 +126,14 @@ __device__ inline void hitq_finish(const long long *hitq, int qn, int *wq_n /* s
 // row-major uint8 [n][W] matrix (16-byte aligned because 128*W % 16 == 0), fetched with
 // fully coalesced 16 B/lane loads into registers one chunk ahead, parked in a wave-private
 // LDS strip, and re-read row-wise: lane r takes k-mer r as NDW+1 aligned dwords that
-// v_alignbit turns into NDW dwords of consecutive bases.  Each base indexes a (4*NDW) x 8
-// uint16 log-odds table in LDS by bits 1..3 of its ASCII code ((c>>1)&7: A/a 0, C/c 1,
-// T/t 2, G/g 3, N/n 7): 4 hot entries per position sit in 2 banks and broadcast, so the
-// lookup is conflict free.  Entries 4..7 hold kPoison: a k-mer that touched one scores
-// min_val (score_sequences.py:376-378).  Positions >= W have zero entries, so the tail of
-// the last dword needs no masking.  Scores go out as coalesced int32; the score histogram
+// v_alignbit turns into NDW dwords of consecutive bases.  Bases are looked up TWO at a time:
+// bits 1..3 of an ASCII code ((c>>1)&7: A/a 0, C/c 1, T/t 2, G/g 3, N/n 7) of two
+// neighbouring bases form a 6-bit index into that pair's 64-entry uint16 table in LDS
+// (entry = sm[b0][2p] + sm[b1][2p+1]); the 16 hot entries of a pair sit in 8 distinct banks, so
+// the lookup is conflict free, and a dword of 4 bases costs 7 VALU + 2 LDS instead of 9 + 4.
+// Entries with a code 4..7 hold kPoison: a k-mer that touched one scores min_val
+// (score_sequences.py:376-378).  A position >= W contributes 0 whatever its byte, so the tail
+// of the last dword needs no masking.  Scores go out as coalesced int32; the score histogram
 // is built with LDS atomics in a per-workgroup window [lo, lo+nb) (+1 bin for N rows)
 // and flushed once per workgroup as a plain-store slab (no global atomics).
 template <int NDW, bool SELECT>
@@ -145,7 +148,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
 {
     // hit_count == nullptr: the list restarts at 0 (GFM_FLAG_RESET_HITS); the old count is not read
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int kTabBytes = 4 * NDW * 8 * 2;
+    constexpr int kTabBytes = 2 * NDW * 64 * 2;  // 2*NDW base pairs x (8 x 8 codes) x uint16
     constexpr int kLoads = (kChunk * 4 * NDW + 1023) / 1024;  // 16 B loads per lane per chunk
 
     unsigned char *tab = smem;
@@ -227,12 +230,12 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
 #pragma unroll
             for (int d = 0; d < NDW; ++d) {
                 const unsigned x = __builtin_amdgcn_alignbit(w[d + 1], w[d], sh);
-                const unsigned xm = x & 0x0E0E0E0Eu;  // 2 * ((c >> 1) & 7) per byte
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const unsigned e = (xm >> (8 * b)) & 0xFFu;
-                    acc += *reinterpret_cast<const uint16_t *>(tab + (4 * d + b) * 16 + e);
-                }
+                const unsigned xm = x & 0x0E0E0E0Eu;   // 2 * ((c >> 1) & 7) per byte
+                const unsigned y = xm | (xm >> 5);     // bytes 0 and 2: 2*(code_lo + 8*code_hi)
+                const unsigned e0 = y & 0x7Eu;
+                const unsigned e1 = (y >> 16) & 0x7Eu;
+                acc += *reinterpret_cast<const uint16_t *>(tab + (2 * d) * 128 + e0);
+                acc += *reinterpret_cast<const uint16_t *>(tab + (2 * d + 1) * 128 + e1);
             }
             const bool is_n = (unsigned)acc >= kPoison;
             const int score = is_n ? min_val : acc;
@@ -254,8 +257,10 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
     }
 
     if (SELECT) {
-        __shared__ int wq_n[kWavesPerWG];
-        hitq_finish<kWavesPerWG>(hitq, qn, wq_n, wave, lane, tid, resid, resid_n);
+        // the lookup tables are dead once every wave has left the loop: their LDS holds the
+        // per-wave queue lengths (no static LDS: 3 workgroups/CU fit with 40 bytes to spare)
+        __syncthreads();
+        hitq_finish<kWavesPerWG>(hitq, qn, reinterpret_cast<int *>(tab), wave, lane, tid, resid, resid_n);
     }
 
     if (use_hist) {
@@ -455,235 +460,174 @@ ptable_kernel(const double *__restrict__ pmf, int L, int lo, int hi, double *__r
 // largest rank in the tie group is C(s) = #rows with score >= s, and the cumulative
 // minimum makes the whole group take p(s) / (C(s)/n).
 // Only the reachable window [lo, hi] can hold counts, plus bin min_val for rows with an N
-// (below the window: p = 1, rank = n, raw = 1): the scans run over the window, split into
-// 1024 contiguous segments.
-__global__ void __launch_bounds__(kScanThreads)
-qvalue_kernel_generic(const unsigned long long *hist, const double *__restrict__ ptable,
-              int L, int lo, int hi, int min_val, double threshold, int on_qvalue,
-              double *__restrict__ qtable, int *__restrict__ cutoff_out,
-              unsigned long long *__restrict__ nrows_out, unsigned long long *__restrict__ clear)
+// (below the window: p = 1, rank = n, raw = 1).
+//
+// Three small multi-block kernels, one bin per thread (256-thread blocks, a handful of
+// registers), instead of one big workgroup: a 1024-thread workgroup holding the window in
+// registers needs an EMPTY CU, and next to the persistent score grid it found none -- on the
+// tail stream it simply waited for the score kernel to end (measured: 19 us alone, 76-95 us
+// "overlapped", gating the pipeline).  Small blocks slot in beside resident score workgroups.
+//   q_count_kernel : per-block bin totals
+//   q_raw_kernel   : C(s) by block-suffix + in-block scan, raw(s) -> qtable (temporary), block minima
+//   q_final_kernel : prefix minimum -> q(s), cutoff, clears
+constexpr int kQThreads = 256;
+struct QWork {
+    unsigned long long blk_cnt[256];
+    double blk_min[256];
+    unsigned long long n_rows_N;
+};
+
+__device__ inline unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh)
 {
-    __shared__ unsigned long long cseg[kScanThreads];
-    __shared__ double mseg[kScanThreads];
-    __shared__ int cut_s;
-    const int tid = threadIdx.x;
-    const int nb = hi - lo + 1;
-    const int per = (nb + kScanThreads - 1) / kScanThreads;
-    const int a = lo + min(tid * per, nb), b = lo + min(tid * per + per, nb);
-    if (tid == 0) cut_s = L;
-    const bool n_outside = min_val < lo || min_val > hi;
-    const unsigned long long n_rows_N = n_outside ? hist[min_val] : 0ull;
-
-    unsigned long long c = 0;
-    for (int j = a; j < b; ++j) c += hist[j];
-    cseg[tid] = c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    if (lane == 0) sh[wave] = v;
     __syncthreads();
-    for (int d = 1; d < kScanThreads; d <<= 1) {  // inclusive suffix scan of counts
-        const unsigned long long v = (tid + d < kScanThreads) ? cseg[tid + d] : 0ull;
-        __syncthreads();
-        cseg[tid] += v;
-        __syncthreads();
-    }
-    const unsigned long long n = cseg[0] + n_rows_N;
-    const double nd = (double)n;
-    const unsigned long long above = (tid + 1 < kScanThreads) ? cseg[tid + 1] : 0ull;
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < kQThreads / kWave; ++w) t += sh[w];
+    __syncthreads();
+    return t;
+}
 
-    // raw BH value of every occupied bin of the segment; segment minimum
-    double m = INFINITY;
-    {
-        unsigned long long run = above;
-        for (int j = b - 1; j >= a; --j) {
-            const unsigned long long h = hist[j];
-            run += h;
-            if (h) m = fmin(m, ptable[j] / ((double)run / nd));
+__global__ void __launch_bounds__(kQThreads)
+q_count_kernel(const unsigned long long *__restrict__ hist, int L, int lo, int hi, int min_val,
+               QWork *__restrict__ ws, int *__restrict__ cutoff_out)
+{
+    __shared__ unsigned long long sh[kQThreads / kWave];
+    const int j = lo + blockIdx.x * kQThreads + threadIdx.x;
+    const unsigned long long h = j <= hi ? hist[j] : 0ull;
+    const unsigned long long tot = block_sum_u64(h, sh);
+    if (threadIdx.x == 0) {
+        ws->blk_cnt[blockIdx.x] = tot;
+        if (blockIdx.x == 0) {
+            const bool n_outside = min_val < lo || min_val > hi;
+            ws->n_rows_N = n_outside ? hist[min_val] : 0ull;
+            if (cutoff_out) *cutoff_out = L;
         }
-    }
-    mseg[tid] = m;
-    __syncthreads();
-    for (int d = 1; d < kScanThreads; d <<= 1) {  // inclusive prefix-min scan
-        const double v = (tid >= d) ? mseg[tid - d] : INFINITY;
-        __syncthreads();
-        mseg[tid] = fmin(mseg[tid], v);
-        __syncthreads();
-    }
-    // rows holding an N sit below every other score: rank n, p = p_table[min_val] (= 1)
-    const double base = n_rows_N ? ptable[min_val] / (nd / nd) : INFINITY;
-    double runmin = fmin(base, (tid > 0) ? mseg[tid - 1] : INFINITY);
-    const double q_above = fmin(fmin(base, mseg[kScanThreads - 1]), 1.0);
-    unsigned long long cge = above;
-    for (int j = a; j < b; ++j) cge += hist[j];  // #rows with score >= a
-    int first = L;
-    for (int j = a; j < b; ++j) {
-        const unsigned long long h = hist[j];
-        if (h) runmin = fmin(runmin, ptable[j] / ((double)cge / nd));
-        cge -= h;
-        const double q = fmin(runmin, 1.0);
-        if (qtable) qtable[j] = q;
-        const double val = on_qvalue ? q : ptable[j];
-        if (first == L && val < threshold) first = j;
-    }
-    if (qtable) {  // outside the window: 1 below (p = 1 there), the last running minimum above
-        for (int j = tid; j < lo; j += kScanThreads) qtable[j] = fmin(base, 1.0);
-        for (int j = hi + 1 + tid; j < L; j += kScanThreads) qtable[j] = q_above;
-    }
-    if (first < L) atomicMin(&cut_s, first);
-    __syncthreads();
-    if (tid == 0) {
-        if (cutoff_out) *cutoff_out = cut_s;
-        if (nrows_out) *nrows_out = n;
-    }
-    if (clear) {  // GFM_FLAG_CLEAR_HIST: hand the histogram back zeroed (each thread its own bins)
-        for (int j = a; j < b; ++j) clear[j] = 0ull;
-        if (tid == 0 && n_outside) clear[min_val] = 0ull;
     }
 }
 
-// Fast form for windows of up to 1024*PER bins.  The window is viewed as PER rows of 1024
-// consecutive bins; thread t owns column t (bins lo + k*1024 + t), so every load and store is
-// fully coalesced and all 2*PER loads of a thread are issued at once.  A scan over the window =
-// wave-level shuffles per row, ONE barrier to exchange the PER x 16 wave totals, then each thread
-// adds the totals of the waves / rows that lie beyond it.
-template <int PER>
-__global__ void __launch_bounds__(kScanThreads)
-qvalue_kernel_reg(const unsigned long long *hist, const double *__restrict__ ptable, int L, int lo,
-                  int hi, int min_val, double threshold, int on_qvalue, double *__restrict__ qtable,
-                  int *__restrict__ cutoff_out, unsigned long long *__restrict__ nrows_out,
-                  unsigned long long *__restrict__ clear)
+__global__ void __launch_bounds__(kQThreads)
+q_raw_kernel(const unsigned long long *__restrict__ hist, const double *__restrict__ ptable, int lo,
+             int hi, QWork *__restrict__ ws, double *__restrict__ raw_out)
 {
-    constexpr int T = kScanThreads, NW = T / kWave;
-    __shared__ unsigned long long cw[PER][NW], cwx[PER][NW];
-    __shared__ double mw[PER][NW], mwx[PER][NW];
-    __shared__ unsigned long long n_window_s;
-    __shared__ double all_min_s;
-    __shared__ int cut_s;
+    __shared__ unsigned long long sh[kQThreads / kWave];
+    __shared__ double shm[kQThreads / kWave];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) cut_s = L;
-    const bool n_outside = min_val < lo || min_val > hi;
-    const unsigned long long n_rows_N = n_outside ? hist[min_val] : 0ull;
-
-    unsigned long long h[PER];
-    double p[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int j = lo + k * T + tid;
-        const bool ok = j <= hi;
-        h[k] = ok ? hist[j] : 0ull;
-        p[k] = ok ? ptable[j] : 0.0;
+    const int nblk = gridDim.x, blk = blockIdx.x;
+    // totals: all rows, and the rows in blocks above this one
+    unsigned long long a = 0, t = 0;
+    for (int b = tid; b < nblk; b += kQThreads) {
+        const unsigned long long v = ws->blk_cnt[b];
+        t += v;
+        if (b > blk) a += v;
     }
-    // ---- C(j) = #rows with score >= j : inclusive suffix sums
-    unsigned long long cs[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        unsigned long long v = h[k];
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const unsigned long long t = __shfl_down(v, d);
-            if (lane + d < kWave) v += t;
-        }
-        cs[k] = v;
-        if (lane == 0) cw[k][wave] = v;
-    }
-    __syncthreads();
-    // wave 0 turns the PER*NW wave totals (row-major = ascending score) into "everything above
-    // wave w of row k": an exclusive suffix sum over the flattened array, by shuffles
-    constexpr int M = PER * NW, IT = (M + kWave - 1) / kWave;
-    if (wave == 0) {
-        unsigned long long loc[IT];
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int f = lane * IT + i;
-            loc[i] = f < M ? (&cw[0][0])[f] : 0ull;
-        }
-#pragma unroll
-        for (int i = IT - 2; i >= 0; --i) loc[i] += loc[i + 1];
-        unsigned long long v = loc[0];
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const unsigned long long t = __shfl_down(v, d);
-            if (lane + d < kWave) v += t;
-        }
-        const unsigned long long excl = v - loc[0];  // lanes above this one
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int f = lane * IT + i;
-            if (f < M) (&cwx[0][0])[f] = excl + (i + 1 < IT ? loc[i + 1] : 0ull);
-        }
-        if (lane == 0) n_window_s = v;
-    }
-    __syncthreads();
-    unsigned long long c_ge[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) c_ge[k] = cs[k] + cwx[k][wave];
-    const unsigned long long n_window = n_window_s;
-    const unsigned long long n = n_window + n_rows_N;
+    const unsigned long long n = block_sum_u64(t, sh) + ws->n_rows_N;
+    const unsigned long long above_blocks = block_sum_u64(a, sh);
     const double nd = (double)n;
-
-    // ---- raw BH value of every occupied bin, then inclusive prefix minimum
-    double raw[PER], ms[PER];
+    const int j = lo + blk * kQThreads + tid;
+    const bool ok = j <= hi;
+    const unsigned long long h = ok ? hist[j] : 0ull;
+    // inclusive suffix sum inside the block
+    unsigned long long cs = h;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        raw[k] = h[k] ? p[k] / ((double)c_ge[k] / nd) : INFINITY;
-        double v = raw[k];
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const double t = __shfl_up(v, d);
-            if (lane >= d) v = fmin(v, t);
-        }
-        ms[k] = v;
-        if (lane == kWave - 1) mw[k][wave] = v;
+    for (int d = 1; d < kWave; d <<= 1) {
+        const unsigned long long v = __shfl_down(cs, d);
+        if (lane + d < kWave) cs += v;
     }
+    if (lane == 0) sh[wave] = cs;
     __syncthreads();
-    // rows holding an N sit below every other score: rank n, p = p_table[min_val] (= 1)
-    const double base = n_rows_N ? ptable[min_val] / (nd / nd) : INFINITY;
-    if (wave == 0) {  // minimum of everything below wave w of row k (exclusive prefix min)
-        double loc[IT];
+    unsigned long long waves_above = 0;
 #pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int f = lane * IT + i;
-            loc[i] = f < M ? (&mw[0][0])[f] : INFINITY;
-        }
+    for (int w = 0; w < kQThreads / kWave; ++w)
+        if (w > wave) waves_above += sh[w];
+    const unsigned long long c_ge = cs + waves_above + above_blocks;
+    const double raw = h ? ptable[j] / ((double)c_ge / nd) : INFINITY;
+    if (ok) raw_out[j] = raw;
+    double m = raw;
 #pragma unroll
-        for (int i = 1; i < IT; ++i) loc[i] = fmin(loc[i], loc[i - 1]);
-        double v = loc[IT - 1];
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const double t = __shfl_up(v, d);
-            if (lane >= d) v = fmin(v, t);
-        }
-        double excl = __shfl_up(v, 1);
-        if (lane == 0) excl = INFINITY;
-        excl = fmin(excl, base);
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const int f = lane * IT + i;
-            if (f < M) (&mwx[0][0])[f] = i ? fmin(excl, loc[i - 1]) : excl;
-        }
-        if (lane == kWave - 1) all_min_s = fmin(v, base);
-    }
-    __syncthreads();
-    int first = L;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const double q = fmin(fmin(ms[k], mwx[k][wave]), 1.0);
-        const int j = lo + k * T + tid;
-        if (j <= hi) {
-            if (qtable) qtable[j] = q;
-            const double val = on_qvalue ? q : p[k];
-            if (first == L && val < threshold) first = j;
-            if (clear) clear[j] = 0ull;
-        }
-    }
-    if (qtable) {  // outside the window: 1 below (p = 1 there), the last running minimum above
-        const double q_above = fmin(all_min_s, 1.0);
-        for (int j = tid; j < lo; j += T) qtable[j] = fmin(base, 1.0);
-        for (int j = hi + 1 + tid; j < L; j += T) qtable[j] = q_above;
-    }
-    if (first < L) atomicMin(&cut_s, first);
+    for (int d = 32; d > 0; d >>= 1) m = fmin(m, __shfl_down(m, d));
+    if (lane == 0) shm[wave] = m;
     __syncthreads();
     if (tid == 0) {
-        if (cutoff_out) *cutoff_out = cut_s;
-        if (nrows_out) *nrows_out = n;
-        if (clear && n_outside) clear[min_val] = 0ull;
+        double bm = INFINITY;
+        for (int w = 0; w < kQThreads / kWave; ++w) bm = fmin(bm, shm[w]);
+        ws->blk_min[blk] = bm;
+    }
+}
+
+__global__ void __launch_bounds__(kQThreads)
+q_final_kernel(const unsigned long long *hist, const double *__restrict__ ptable, int L, int lo,
+               int hi, int min_val, double threshold, int on_qvalue, const QWork *__restrict__ ws,
+               double *qtable, int *__restrict__ cutoff_out, unsigned long long *__restrict__ nrows_out,
+               unsigned long long *__restrict__ clear)
+{
+    __shared__ unsigned long long sh[kQThreads / kWave];
+    __shared__ double shm[kQThreads / kWave];
+    __shared__ int first_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = gridDim.x, blk = blockIdx.x;
+    if (tid == 0) first_s = L;
+    unsigned long long t = 0;
+    double below = INFINITY, all = INFINITY;
+    for (int b = tid; b < nblk; b += kQThreads) {
+        t += ws->blk_cnt[b];
+        const double v = ws->blk_min[b];
+        all = fmin(all, v);
+        if (b < blk) below = fmin(below, v);
+    }
+    const unsigned long long n_rows_N = ws->n_rows_N;
+    const unsigned long long n = block_sum_u64(t, sh) + n_rows_N;
+    const double nd = (double)n;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        below = fmin(below, __shfl_down(below, d));
+        all = fmin(all, __shfl_down(all, d));
+    }
+    __shared__ double shb[kQThreads / kWave], sha[kQThreads / kWave];
+    if (lane == 0) { shb[wave] = below; sha[wave] = all; }
+    __syncthreads();
+    below = INFINITY; all = INFINITY;
+#pragma unroll
+    for (int w = 0; w < kQThreads / kWave; ++w) { below = fmin(below, shb[w]); all = fmin(all, sha[w]); }
+    // rows holding an N sit below every other score: rank n, p = p_table[min_val] (= 1)
+    const double base = n_rows_N ? ptable[min_val] / (nd / nd) : INFINITY;
+    const int j = lo + blk * kQThreads + tid;
+    const bool ok = j <= hi;
+    double ms = ok ? qtable[j] : INFINITY;   // raw value left by q_raw_kernel
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const double v = __shfl_up(ms, d);
+        if (lane >= d) ms = fmin(ms, v);
+    }
+    if (lane == kWave - 1) shm[wave] = ms;
+    __syncthreads();
+    double waves_below = INFINITY;
+#pragma unroll
+    for (int w = 0; w < kQThreads / kWave; ++w)
+        if (w < wave) waves_below = fmin(waves_below, shm[w]);
+    const double q = fmin(fmin(fmin(ms, waves_below), fmin(below, base)), 1.0);
+    if (ok) {
+        qtable[j] = q;
+        const double val = on_qvalue ? q : ptable[j];
+        if (val < threshold) atomicMin(&first_s, j);
+        if (clear) clear[j] = 0ull;
+    }
+    // outside the window: 1 below it (p = 1 there), the last running minimum above it
+    const int gtid = blk * kQThreads + tid, gsz = nblk * kQThreads;
+    const double q_above = fmin(fmin(base, all), 1.0);
+    for (int jj = gtid; jj < lo; jj += gsz) qtable[jj] = fmin(base, 1.0);
+    for (int jj = hi + 1 + gtid; jj < L; jj += gsz) qtable[jj] = q_above;
+    __syncthreads();
+    if (tid == 0) {
+        if (cutoff_out && first_s < L) atomicMin(cutoff_out, first_s);
+        if (blk == 0) {
+            if (nrows_out) *nrows_out = n;
+            const bool n_outside = min_val < lo || min_val > hi;
+            if (clear && n_outside) clear[min_val] = 0ull;
+        }
     }
 }
 
@@ -698,6 +642,7 @@ struct gfm_motif {
     int device = 0;
     int n_cu = 256;
     int max_slabs = 0;
+    int sel_slabs = 0;
     bool lds_hist = true;
     size_t lds_bytes = 0;
     std::vector<int64_t> sm;
@@ -706,14 +651,27 @@ struct gfm_motif {
     uint16_t *d_tab = nullptr;
     double *d_pmf = nullptr;
     double *d_ptable = nullptr;
-    unsigned *d_partials = nullptr;
-    long long *d_resid = nullptr;   // [max_slabs][8 waves * kHitQueue] residual hits per workgroup
-    int *d_resid_n = nullptr;       // [max_slabs]
+    // Scoring workspace, double-buffered by call parity so that the post kernel of call k (on a
+    // tail stream) may run while the score kernel of call k+1 fills the other set.
+    unsigned *d_partials[2] = {nullptr, nullptr};   // [max_slabs][nb+1] histogram slabs
+    long long *d_resid[2] = {nullptr, nullptr};     // [max_slabs][kResidPerWG] residual hits
+    int *d_resid_n[2] = {nullptr, nullptr};         // [max_slabs]
+    QWork *d_qwork = nullptr;        // q-value kernels' block totals / minima
+    double *d_qscratch = nullptr;    // [L] raw BH values when the caller wants no q-table
     HitCtl *d_ctl = nullptr;
-    unsigned call_no = 0;           // selects the HitCtl slot (call_no % 3)
+    unsigned call_no = 0;           // score calls: HitCtl slot call_no % 3, workspace call_no % 2
+    hipEvent_t ev_scored[2] = {nullptr, nullptr};   // score kernel of the last call of a parity done
+    hipEvent_t ev_posted[2] = {nullptr, nullptr};   // its post kernel done (workspace free again)
+    bool posted_valid[2] = {false, false};
+    // separate workspace of gfm_select_hits (runs on the caller's tail stream, next to scoring)
+    long long *d_sel_resid = nullptr;
+    int *d_sel_resid_n = nullptr;
+    HitCtl *d_sel_ctl = nullptr;
+    unsigned sel_call_no = 0;
     // measurement aid: ring of event pairs around the score kernel
     std::vector<hipEvent_t> ev0, ev1;
-    int ev_next = 0, ev_used = 0;
+    int ev_next = 0, ev_used = 0, ev_every = 1;
+    unsigned ev_calls = 0;
 };
 
 namespace {
@@ -808,13 +766,13 @@ int launch_score(gfm_motif *m, const uint8_t *d_kmers, long long n, int *d_score
         }
         return GFM_OK;
     }
-    const bool prof = !m->ev0.empty();
+    const bool prof = !m->ev0.empty() && (m->ev_calls++ % (unsigned)m->ev_every) == 0;
     const int slot = m->ev_next;
     if (prof) HIP_TRY(hipEventRecord(m->ev0[slot], st));
     hipLaunchKernelGGL(kern, dim3(nslabs), dim3(kThreads), m->lds_bytes, st, d_kmers, n, m->W,
-                       m->d_tab, m->lo, m->nb, m->min_val, use_hist, d_scores, m->d_partials,
-                       cutoff, row_base, d_hit_rows, cap, d_hit_count, m->d_ctl, par, m->d_resid,
-                       m->d_resid_n);
+                       m->d_tab, m->lo, m->nb, m->min_val, use_hist, d_scores, m->d_partials[par & 1],
+                       cutoff, row_base, d_hit_rows, cap, d_hit_count, m->d_ctl, par >> 1,
+                       m->d_resid[par & 1], m->d_resid_n[par & 1]);
     HIP_TRY(hipGetLastError());
     if (prof) {
         HIP_TRY(hipEventRecord(m->ev1[slot], st));
@@ -825,7 +783,8 @@ int launch_score(gfm_motif *m, const uint8_t *d_kmers, long long n, int *d_score
 }
 
 // one launch after a scoring / selection kernel: histogram slabs -> hist64, hit slabs -> list
-int launch_post(gfm_motif *m, int hist_slabs, unsigned long long *d_hist, int hit_slabs, int par,
+int launch_post(gfm_motif *m, const unsigned *partials, int hist_slabs, unsigned long long *d_hist,
+                const long long *resid, const int *resid_n, int hit_slabs, HitCtl *ctl, int ctl_slot,
                 long long *d_hit_rows, long long cap, unsigned long long *d_hit_count, hipStream_t st)
 {
     const int bin_blocks = (m->nb + 1 + 255) / 256;
@@ -833,9 +792,9 @@ int launch_post(gfm_motif *m, int hist_slabs, unsigned long long *d_hist, int hi
     const int hist_blocks = d_hist ? bin_blocks * groups : 0;
     const int total = hist_blocks + hit_slabs;
     if (total == 0) return GFM_OK;
-    hipLaunchKernelGGL(post_kernel, dim3(total), dim3(256), 0, st, m->d_partials, hist_slabs, m->nb,
-                       m->lo, m->min_val, d_hist, bin_blocks, hist_blocks, m->d_resid, m->d_resid_n,
-                       hit_slabs, m->d_ctl, par, d_hit_rows, cap, d_hit_count);
+    hipLaunchKernelGGL(post_kernel, dim3(total), dim3(256), 0, st, partials, hist_slabs, m->nb, m->lo,
+                       m->min_val, d_hist, bin_blocks, hist_blocks, resid, resid_n, hit_slabs, ctl,
+                       ctl_slot, d_hit_rows, cap, d_hit_count);
     HIP_TRY(hipGetLastError());
     return GFM_OK;
 }
@@ -962,10 +921,19 @@ GFM_API void gfm_motif_destroy(gfm_motif_t m)
     if (m->d_tab) (void)hipFree(m->d_tab);
     if (m->d_pmf) (void)hipFree(m->d_pmf);
     if (m->d_ptable) (void)hipFree(m->d_ptable);
-    if (m->d_partials) (void)hipFree(m->d_partials);
-    if (m->d_resid) (void)hipFree(m->d_resid);
-    if (m->d_resid_n) (void)hipFree(m->d_resid_n);
+    for (int i = 0; i < 2; ++i) {
+        if (m->d_partials[i]) (void)hipFree(m->d_partials[i]);
+        if (m->d_resid[i]) (void)hipFree(m->d_resid[i]);
+        if (m->d_resid_n[i]) (void)hipFree(m->d_resid_n[i]);
+        if (m->ev_scored[i]) (void)hipEventDestroy(m->ev_scored[i]);
+        if (m->ev_posted[i]) (void)hipEventDestroy(m->ev_posted[i]);
+    }
     if (m->d_ctl) (void)hipFree(m->d_ctl);
+    if (m->d_qwork) (void)hipFree(m->d_qwork);
+    if (m->d_qscratch) (void)hipFree(m->d_qscratch);
+    if (m->d_sel_resid) (void)hipFree(m->d_sel_resid);
+    if (m->d_sel_resid_n) (void)hipFree(m->d_sel_resid_n);
+    if (m->d_sel_ctl) (void)hipFree(m->d_sel_ctl);
     for (auto e : m->ev0) (void)hipEventDestroy(e);
     for (auto e : m->ev1) (void)hipEventDestroy(e);
     delete m;
@@ -1013,17 +981,24 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     HIP_TRY_M(hipGetDeviceProperties(&prop, m->device));
     m->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
-    // LDS lookup table: [4*ndw positions][8 codes] uint16, code = (ascii >> 1) & 7
-    // (A 0, C 1, T 2, G 3; 4..7 poison; positions >= W all zero)
-    std::vector<uint16_t> tab((size_t)4 * m->ndw * 8, 0);
-    for (int pos = 0; pos < W; ++pos) {
-        uint16_t *row = &tab[(size_t)pos * 8];
-        row[0] = (uint16_t)sm[0 * W + pos];  // A
-        row[1] = (uint16_t)sm[1 * W + pos];  // C
-        row[2] = (uint16_t)sm[3 * W + pos];  // T
-        row[3] = (uint16_t)sm[2 * W + pos];  // G
-        row[4] = row[5] = row[6] = row[7] = (uint16_t)kPoison;
-    }
+    // LDS lookup tables: [2*ndw base pairs][8 x 8 codes] uint16, code = (ascii >> 1) & 7
+    // (A 0, C 1, T 2, G 3; 4..7 invalid), index = code(first) + 8 * code(second).
+    // A valid pair holds sm[first][2p] + sm[second][2p+1]; a pair with an invalid code holds
+    // kPoison; a position >= W contributes 0 and accepts any code.
+    std::vector<uint16_t> tab((size_t)2 * m->ndw * 64, 0);
+    auto base_score = [&](int pos, int code, bool *bad) -> unsigned {
+        if (pos >= W) return 0u;
+        static const int nuc_of_code[4] = {0, 1, 3, 2};  // code 2 = T (row 3), code 3 = G (row 2)
+        if (code > 3) { *bad = true; return 0u; }
+        return (unsigned)sm[nuc_of_code[code] * W + pos];
+    };
+    for (int pr = 0; pr < 2 * m->ndw; ++pr)
+        for (int c1 = 0; c1 < 8; ++c1)
+            for (int c0 = 0; c0 < 8; ++c0) {
+                bool bad = false;
+                const unsigned v = base_score(2 * pr, c0, &bad) + base_score(2 * pr + 1, c1, &bad);
+                tab[(size_t)pr * 64 + c0 + 8 * c1] = (uint16_t)(bad ? kPoison : v);
+            }
     HIP_TRY_M(hipMalloc(&m->d_tab, tab.size() * sizeof(uint16_t)));
     HIP_TRY_M(hipMemcpy(m->d_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
 
@@ -1043,18 +1018,29 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
                         hipMemcpyDeviceToHost));
 
     // score-kernel LDS plan: table | 8 wave strips | histogram window (+1 N bin)
-    const size_t fixed = (size_t)4 * m->ndw * 8 * 2 + (size_t)kWavesPerWG * stage_stride_bytes(W);
+    const size_t fixed = (size_t)2 * m->ndw * 64 * 2 + (size_t)kWavesPerWG * stage_stride_bytes(W);
     const size_t with_hist = fixed + sizeof(unsigned) * (size_t)(m->nb + 1);
     m->lds_hist = with_hist <= (size_t)kMaxLdsBytes;
     m->lds_bytes = m->lds_hist ? with_hist : fixed;
     int per_cu = (int)std::min<size_t>(kWGsPerCU, (size_t)kMaxLdsBytes / m->lds_bytes);
     per_cu = std::max(per_cu, 1);
     m->max_slabs = m->n_cu * per_cu;
-    HIP_TRY_M(hipMalloc(&m->d_partials, sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->nb + 1)));
-    HIP_TRY_M(hipMalloc(&m->d_resid, sizeof(long long) * (size_t)m->max_slabs * kResidPerWG));
-    HIP_TRY_M(hipMalloc(&m->d_resid_n, sizeof(int) * (size_t)m->max_slabs));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY_M(hipMalloc(&m->d_partials[i], sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->nb + 1)));
+        HIP_TRY_M(hipMalloc(&m->d_resid[i], sizeof(long long) * (size_t)m->max_slabs * kResidPerWG));
+        HIP_TRY_M(hipMalloc(&m->d_resid_n[i], sizeof(int) * (size_t)m->max_slabs));
+        HIP_TRY_M(hipEventCreateWithFlags(&m->ev_scored[i], hipEventDisableTiming));
+        HIP_TRY_M(hipEventCreateWithFlags(&m->ev_posted[i], hipEventDisableTiming));
+    }
     HIP_TRY_M(hipMalloc(&m->d_ctl, sizeof(HitCtl)));
     HIP_TRY_M(hipMemset(m->d_ctl, 0, sizeof(HitCtl)));
+    HIP_TRY_M(hipMalloc(&m->d_qwork, sizeof(QWork)));
+    HIP_TRY_M(hipMalloc(&m->d_qscratch, sizeof(double) * (size_t)m->L));
+    m->sel_slabs = 4 * m->n_cu;
+    HIP_TRY_M(hipMalloc(&m->d_sel_resid, sizeof(long long) * (size_t)m->sel_slabs * kResidPerWG));
+    HIP_TRY_M(hipMalloc(&m->d_sel_resid_n, sizeof(int) * (size_t)m->sel_slabs));
+    HIP_TRY_M(hipMalloc(&m->d_sel_ctl, sizeof(HitCtl)));
+    HIP_TRY_M(hipMemset(m->d_sel_ctl, 0, sizeof(HitCtl)));
 #undef HIP_TRY_M
     rc = dispatch_score(m, nullptr, 0, nullptr, 0, 1, false, 0, 0, nullptr, 0, nullptr, nullptr, true, 0);
     if (rc) return bail(rc);
@@ -1110,44 +1096,78 @@ GFM_API int gfm_motif_annotate(gfm_motif_t m, const int32_t *scores, int64_t n, 
 GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, int32_t *d_scores,
                             uint64_t *d_hist, int32_t select_cutoff, int64_t row_base,
                             int64_t *d_hit_rows, int64_t hit_capacity, uint64_t *d_hit_count,
-                            uint32_t flags, void *stream)
+                            uint32_t flags, void *stream, void *tail_stream)
 {
     if (!m) return fail(GFM_ERR_INVALID, "motif is NULL");
     if (n < 0) return fail(GFM_ERR_INVALID, "negative row count");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipStream_t tail = tail_stream ? static_cast<hipStream_t>(tail_stream) : st;
+    const bool split = tail != st;
     if (n == 0) {
-        if ((flags & GFM_FLAG_RESET_HITS) && d_hit_count)
-            HIP_TRY(hipMemsetAsync(d_hit_count, 0, sizeof(uint64_t), static_cast<hipStream_t>(stream)));
+        if ((flags & GFM_FLAG_RESET_HITS) && d_hit_count) {
+            if (split) {  // keep the tail stream ordered behind what the main stream holds
+                HIP_TRY(hipEventRecord(m->ev_scored[0], st));
+                HIP_TRY(hipStreamWaitEvent(tail, m->ev_scored[0], 0));
+            }
+            HIP_TRY(hipMemsetAsync(d_hit_count, 0, sizeof(uint64_t), tail));
+        }
         return GFM_OK;
     }
     if (!d_kmers || !d_scores) return fail(GFM_ERR_INVALID, "NULL device buffer");
     if ((reinterpret_cast<uintptr_t>(d_kmers) & 15u) != 0)
         return fail(GFM_ERR_INVALID, "d_kmers must be 16-byte aligned");
+    if (n > (int64_t)kChunk * 0x7fffff00ll)
+        return fail(GFM_ERR_INVALID, "too many rows for one launch (split the batch)");
     const bool select = select_cutoff != GFM_NO_SELECT;
     if (select && (!d_hit_rows || !d_hit_count))
         return fail(GFM_ERR_INVALID, "selection requested without hit buffers");
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const int use_hist = d_hist != nullptr;
     if (use_hist && !m->lds_hist)
         return fail(GFM_ERR_INVALID, "score window of %d bins does not fit the LDS histogram", m->nb);
     const long long nchunks = (n + kChunk - 1) / kChunk;
     const long long want = (nchunks + kWavesPerWG - 1) / kWavesPerWG;
-    const int nslabs = (int)std::min<long long>(want, m->max_slabs);
+    // with a tail stream a few CUs are left free so that its kernels (post, q-table, RCCL) find
+    // room without evicting a persistent score workgroup (which would delay the whole grid)
+    const int avail = split ? std::max(1, m->max_slabs - kReserveCUs * (m->max_slabs / m->n_cu)) : m->max_slabs;
+    const int nslabs = (int)std::min<long long>(want, avail);
 
-    const int par = select ? (int)(m->call_no++ % 3u) : 0;
+    const unsigned k = m->call_no++;
+    const int ws = (int)(k & 1u), slot = (int)(k % 3u);
     const bool reset = (flags & GFM_FLAG_RESET_HITS) != 0;
+    // workspace `ws` was last used by call k-2: its post kernel must be done.  Appending to a
+    // hit list additionally needs the count published by call k-1.
+    if (m->posted_valid[ws] && !(flags & GFM_FLAG_CALLER_ORDERS_REUSE))
+        HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws], 0));
+    if (split && select && !reset && m->posted_valid[ws ^ 1])
+        HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws ^ 1], 0));
     int rc = dispatch_score(m, d_kmers, n, d_scores, use_hist, nslabs, select, select_cutoff, row_base,
                             reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                             reset ? nullptr : reinterpret_cast<unsigned long long *>(d_hit_count), st,
-                            false, par);
+                            false, (slot << 1) | ws);
     if (rc) return rc;
-    return launch_post(m, nslabs, reinterpret_cast<unsigned long long *>(d_hist), select ? nslabs : 0,
-                       par, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
-                       reinterpret_cast<unsigned long long *>(d_hit_count), st);
+    if (split) {
+        HIP_TRY(hipEventRecord(m->ev_scored[ws], st));
+        HIP_TRY(hipStreamWaitEvent(tail, m->ev_scored[ws], 0));
+    }
+    rc = launch_post(m, m->d_partials[ws], nslabs, reinterpret_cast<unsigned long long *>(d_hist),
+                     m->d_resid[ws], m->d_resid_n[ws], select ? nslabs : 0, m->d_ctl, slot,
+                     reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
+                     reinterpret_cast<unsigned long long *>(d_hit_count), tail);
+    if (rc) return rc;
+    if (split) {
+        HIP_TRY(hipEventRecord(m->ev_posted[ws], tail));
+        m->posted_valid[ws] = true;
+    } else {
+        m->posted_valid[ws] = false;  // same stream: plain stream order already protects the workspace
+    }
+    return GFM_OK;
 }
 
-GFM_API int gfm_profile_enable(gfm_motif_t m, int slots)
+GFM_API int gfm_profile_enable(gfm_motif_t m, int slots, int every)
 {
-    if (!m || slots < 0) return fail(GFM_ERR_INVALID, "bad argument");
+    if (!m || slots < 0 || every < 1) return fail(GFM_ERR_INVALID, "bad argument");
+    m->ev_every = every;
+    m->ev_calls = 0;
     for (auto e : m->ev0) (void)hipEventDestroy(e);
     for (auto e : m->ev1) (void)hipEventDestroy(e);
     m->ev0.clear();
@@ -1188,16 +1208,15 @@ GFM_API int gfm_qvalue_table(gfm_motif_t m, uint64_t *d_hist, double threshold, 
     unsigned long long *clr =
         (flags & GFM_FLAG_CLEAR_HIST) ? reinterpret_cast<unsigned long long *>(d_hist) : nullptr;
     unsigned long long *nr = reinterpret_cast<unsigned long long *>(d_nrows);
-#define GFM_Q_ARGS hc, m->d_ptable, m->L, m->lo, m->hi, m->min_val, threshold, on_qvalue, d_qtable, d_cutoff, nr, clr
-    if (m->nb <= kScanThreads * 4)
-        hipLaunchKernelGGL(qvalue_kernel_reg<4>, dim3(1), dim3(kScanThreads), 0, st, GFM_Q_ARGS);
-    else if (m->nb <= kScanThreads * 8)
-        hipLaunchKernelGGL(qvalue_kernel_reg<8>, dim3(1), dim3(kScanThreads), 0, st, GFM_Q_ARGS);
-    else if (m->nb <= kScanThreads * 16)
-        hipLaunchKernelGGL(qvalue_kernel_reg<16>, dim3(1), dim3(kScanThreads), 0, st, GFM_Q_ARGS);
-    else
-        hipLaunchKernelGGL(qvalue_kernel_generic, dim3(1), dim3(kScanThreads), 0, st, GFM_Q_ARGS);
-#undef GFM_Q_ARGS
+    const int nblk = (m->nb + kQThreads - 1) / kQThreads;   // <= 251 for W <= 64
+    hipLaunchKernelGGL(q_count_kernel, dim3(nblk), dim3(kQThreads), 0, st, hc, m->L, m->lo, m->hi,
+                       m->min_val, m->d_qwork, d_cutoff);
+    // q_raw leaves raw(s) in a table of L doubles: the caller's q-table, or ours when none is asked
+    double *qt = d_qtable ? d_qtable : m->d_qscratch;
+    hipLaunchKernelGGL(q_raw_kernel, dim3(nblk), dim3(kQThreads), 0, st, hc, m->d_ptable, m->lo, m->hi,
+                       m->d_qwork, qt);
+    hipLaunchKernelGGL(q_final_kernel, dim3(nblk), dim3(kQThreads), 0, st, hc, m->d_ptable, m->L, m->lo,
+                       m->hi, m->min_val, threshold, on_qvalue, m->d_qwork, qt, d_cutoff, nr, clr);
     HIP_TRY(hipGetLastError());
     return GFM_OK;
 }
@@ -1220,18 +1239,19 @@ GFM_API int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long long n4 = (n + 3) >> 2;
     long long blocks = (n4 + kSelThreads - 1) / kSelThreads;
-    blocks = std::max<long long>(1, std::min<long long>(blocks, m->max_slabs));
-    const int par = (int)(m->call_no++ % 3u);
+    blocks = std::max<long long>(1, std::min<long long>(blocks, m->sel_slabs));
+    const int slot = (int)(m->sel_call_no++ % 3u);
     hipLaunchKernelGGL(select_hits_kernel, dim3((unsigned)blocks), dim3(kSelThreads), 0, st, d_scores,
                        (long long)n, d_cutoff, (long long)row_base,
                        reinterpret_cast<long long *>(d_hit_rows), (long long)hit_capacity,
                        (flags & GFM_FLAG_RESET_HITS)
                            ? nullptr
                            : reinterpret_cast<const unsigned long long *>(d_hit_count),
-                       m->d_ctl, par, m->d_resid, m->d_resid_n);
+                       m->d_sel_ctl, slot, m->d_sel_resid, m->d_sel_resid_n);
     HIP_TRY(hipGetLastError());
-    return launch_post(m, 0, nullptr, (int)blocks, par, reinterpret_cast<long long *>(d_hit_rows),
-                       hit_capacity, reinterpret_cast<unsigned long long *>(d_hit_count), st);
+    return launch_post(m, nullptr, 0, nullptr, m->d_sel_resid, m->d_sel_resid_n, (int)blocks,
+                       m->d_sel_ctl, slot, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
+                       reinterpret_cast<unsigned long long *>(d_hit_count), st);
 }
 
 GFM_API int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, double threshold,
@@ -1293,13 +1313,13 @@ GFM_API int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, doub
         SCAN_RC(gfm_motif_pvalue_cutoff(m, threshold, &cutoff));
         SCAN_RC(gfm_score_kmers(m, d_kmers, n, d_scores, reinterpret_cast<uint64_t *>(d_hist), cutoff,
                                 0, reinterpret_cast<int64_t *>(d_rows), cap,
-                                reinterpret_cast<uint64_t *>(d_count), GFM_FLAG_RESET_HITS, st));
+                                reinterpret_cast<uint64_t *>(d_count), GFM_FLAG_RESET_HITS, st, nullptr));
         if (need_hist)
             SCAN_RC(gfm_qvalue_table(m, reinterpret_cast<uint64_t *>(d_hist), threshold, 0, d_q,
                                      nullptr, nullptr, 0, st));
     } else {
         SCAN_RC(gfm_score_kmers(m, d_kmers, n, d_scores, reinterpret_cast<uint64_t *>(d_hist),
-                                GFM_NO_SELECT, 0, nullptr, 0, nullptr, 0, st));
+                                GFM_NO_SELECT, 0, nullptr, 0, nullptr, 0, st, nullptr));
         SCAN_RC(gfm_qvalue_table(m, reinterpret_cast<uint64_t *>(d_hist), threshold, 1, d_q, d_cutoff,
                                  nullptr, 0, st));
         SCAN_RC(gfm_select_hits(m, d_scores, n, d_cutoff, 0, reinterpret_cast<int64_t *>(d_rows), cap,

@@ -97,7 +97,7 @@ class DeviceMotif:
 
     # ---- device-pointer entry points (torch tensors as buffers)
     def score(self, kmers, scores, hist=None, select_cutoff=None, row_base=0, hit_rows=None,
-              hit_count=None, stream=None, reset_hits=False):
+              hit_count=None, stream=None, reset_hits=False, tail_stream=None):
         """Enqueue gfm_score_kmers.  kmers uint8 [n,W] (cuda), scores int32 [n],
         hist int64 [L] (accumulated), hit_rows int64 [cap], hit_count int64 [1]."""
         n = int(kmers.shape[0])
@@ -110,7 +110,8 @@ class DeviceMotif:
             hit_rows.data_ptr() if hit_rows is not None else None,
             int(hit_rows.numel()) if hit_rows is not None else 0,
             hit_count.data_ptr() if hit_count is not None else None,
-            nv.GFM_FLAG_RESET_HITS if reset_hits else 0, _stream_ptr(stream)))
+            nv.GFM_FLAG_RESET_HITS if reset_hits else 0, _stream_ptr(stream),
+            _stream_ptr(tail_stream) if tail_stream is not None else None))
 
     def qvalue_table(self, hist, threshold, on_qvalue, qtable=None, cutoff=None, nrows=None,
                      stream=None, clear_hist=False):
@@ -131,8 +132,8 @@ class DeviceMotif:
                                           _stream_ptr(stream)))
 
     # ---- measurement aid (bench.py)
-    def profile_enable(self, slots: int):
-        nv.check(nv.lib().gfm_profile_enable(self._h, int(slots)))
+    def profile_enable(self, slots: int, every: int = 1):
+        nv.check(nv.lib().gfm_profile_enable(self._h, int(slots), int(every)))
 
     def profile_read(self, capacity: int = 4096):
         ms = np.empty(capacity, dtype=np.float32)

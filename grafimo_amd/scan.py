@@ -11,6 +11,7 @@ from typing import Optional
 
 import numpy as np
 
+from . import _native as _nv
 from .device import DeviceMotif, _torch
 
 HIT_SCORE_BITS = 20  # GFM_HIT_SCORE_BITS: hit entry = (row << 20) | scaled score
@@ -30,9 +31,16 @@ class ScanSlot:
         self.nrows = torch.zeros(1, dtype=torch.int64, device=device)
         # [0] = hit count, [1:] = hit rows (one buffer so that one gather moves both)
         self.hits = torch.zeros(self.hit_capacity + 1, dtype=torch.int64, device=device)
-        self.scored = torch.cuda.Event()
         self.done = torch.cuda.Event()
         self.gathered = None
+        # raw addresses for the ctypes fast path
+        self.p_scores = self.scores.data_ptr()
+        self.p_hist = self.hist.data_ptr()
+        self.p_qtable = self.qtable.data_ptr()
+        self.p_cutoff = self.cutoff.data_ptr()
+        self.p_nrows = self.nrows.data_ptr()
+        self.p_hit_count = self.hits.data_ptr()
+        self.p_hit_rows = self.hits.data_ptr() + 8
 
     @property
     def hit_count(self):
@@ -62,46 +70,66 @@ class KmerScanner:
         self._gather_ok = True
         cap = int(hit_capacity) if hit_capacity is not None else int(n_rows)
         self.slots = [ScanSlot(dm, n_rows, cap, self.device) for _ in range(n_slots)]
-        self.side = torch.cuda.Stream(device=self.device) if side_stream else None
+        # high priority: tail kernels are tiny and sit on the critical path of slot reuse
+        self.side = torch.cuda.Stream(device=self.device, priority=-1) if side_stream else None
+        self._side_p = self.side.cuda_stream if self.side is not None else None
+        self._lib = _nv.lib()
+        self._cutoffs = {}
+        # with exactly two slots, waiting for slot.done of step k-2 (below) already implies that
+        # the library's workspace of call k-2 is free again: skip its own event wait
+        self._reuse_flag = _nv.GFM_FLAG_CALLER_ORDERS_REUSE if n_slots == 2 else 0
         self._turn = 0
 
     # ------------------------------------------------------------------ one batch
     def enqueue(self, d_kmers, threshold: float, on_qvalue: bool = False, want_qvalues: bool = True,
                 row_base: int = 0, gather_hits: bool = False) -> ScanSlot:
         """Enqueue the whole path for one batch; returns the slot holding its outputs.
-        Nothing here synchronises with the host."""
+        Nothing here synchronises with the host.  Kept lean on purpose: a step is ~100 us of GPU
+        time, so the host side (ctypes calls with cached raw pointers, no torch dispatch unless a
+        collective is needed) must stay well below that or the GPU starves."""
         torch = _torch()
+        lib = self._lib
         dm = self.dm
         slot = self.slots[self._turn % len(self.slots)]
         self._turn += 1
         main = torch.cuda.current_stream(self.device)
+        main_p = main.cuda_stream
+        tail = self.side if self.side is not None else main
+        tail_p = self._side_p if self.side is not None else main_p
         main.wait_event(slot.done)           # the slot's previous batch has been consumed
         # no zeroing on the critical path: the q-value kernel hands the histogram back cleared
         # (GFM_FLAG_CLEAR_HIST) and the hit list restarts through GFM_FLAG_RESET_HITS
         n = int(d_kmers.shape[0])
-        need_hist = want_qvalues
+        kp = d_kmers.data_ptr() if n else None
+        h = dm.handle
+        # the score kernel goes to the main stream; the library puts its post kernel (histogram
+        # slabs -> slot.hist, residual hits -> slot.hits) on the tail stream behind an event
         if not on_qvalue:
-            cut = dm.pvalue_cutoff(threshold)  # host lookup in p_table, known before scoring
-            dm.score(d_kmers, slot.scores[:n], hist=slot.hist if need_hist else None,
-                     select_cutoff=cut, row_base=row_base, hit_rows=slot.hit_rows,
-                     hit_count=slot.hit_count, reset_hits=True)
+            key = float(threshold)
+            cut = self._cutoffs.get(key)
+            if cut is None:                   # host lookup in p_table, known before scoring
+                cut = self._cutoffs[key] = dm.pvalue_cutoff(key)
+            _nv.check(lib.gfm_score_kmers(h, kp, n, slot.p_scores, slot.p_hist if want_qvalues else None,
+                                          cut, int(row_base), slot.p_hit_rows, slot.hit_capacity,
+                                          slot.p_hit_count, _nv.GFM_FLAG_RESET_HITS | self._reuse_flag, main_p, tail_p))
         else:
-            dm.score(d_kmers, slot.scores[:n], hist=slot.hist)
-        slot.scored.record(main)
-        tail = self.side if self.side is not None else main
-        with torch.cuda.stream(tail):
-            tail.wait_event(slot.scored)
-            if need_hist:
-                if self.collective:
+            _nv.check(lib.gfm_score_kmers(h, kp, n, slot.p_scores, slot.p_hist, _nv.GFM_NO_SELECT, 0,
+                                          None, 0, None, self._reuse_flag, main_p, tail_p))
+        if want_qvalues:
+            if self.collective:
+                with torch.cuda.stream(tail):
                     torch.distributed.all_reduce(slot.hist, group=self.group)
-                dm.qvalue_table(slot.hist, threshold, on_qvalue, slot.qtable, slot.cutoff, slot.nrows,
-                                stream=tail, clear_hist=True)
-            if on_qvalue:
-                dm.select_hits(slot.scores[:n], slot.cutoff, slot.hit_rows, slot.hit_count,
-                               row_base=row_base, stream=tail, reset_hits=True)
-            if gather_hits and self.collective:
+            _nv.check(lib.gfm_qvalue_table(h, slot.p_hist, float(threshold), int(bool(on_qvalue)),
+                                           slot.p_qtable, slot.p_cutoff, slot.p_nrows,
+                                           _nv.GFM_FLAG_CLEAR_HIST, tail_p))
+        if on_qvalue:
+            _nv.check(lib.gfm_select_hits(h, slot.p_scores, n, slot.p_cutoff, int(row_base),
+                                          slot.p_hit_rows, slot.hit_capacity, slot.p_hit_count,
+                                          _nv.GFM_FLAG_RESET_HITS, tail_p))
+        if gather_hits and self.collective:
+            with torch.cuda.stream(tail):
                 self._gather(slot)
-            slot.done.record(tail)
+        slot.done.record(tail)
         return slot
 
     def _gather(self, slot: ScanSlot):

@@ -44,6 +44,10 @@ extern "C" {
 /* flags */
 #define GFM_FLAG_RESET_HITS 1u /* start the hit list at 0 instead of appending at *d_hit_count */
 #define GFM_FLAG_CLEAR_HIST 2u /* gfm_qvalue_table: zero the histogram after reading it        */
+/* gfm_score_kmers with a tail stream: the caller guarantees (by its own stream order) that the
+ * tail work of the call two before this one has finished, so the library need not make the
+ * main stream wait for it (an event wait costs ~5 us of stream time per step). */
+#define GFM_FLAG_CALLER_ORDERS_REUSE 4u
 /* a hit-list entry packs the global row id and the row's scaled score:
  * entry = (row << GFM_HIT_SCORE_BITS) | score   (score <= 1000*64 < 2^20) */
 #define GFM_HIT_SCORE_BITS 20
@@ -112,17 +116,21 @@ int gfm_motif_annotate(gfm_motif_t m, const int32_t *h_scores, int64_t n,
  *              appended to d_hit_rows (unordered) starting at *d_hit_count (at 0 with
  *              GFM_FLAG_RESET_HITS) and *d_hit_count updated; hits beyond hit_capacity are
  *              counted but not stored.
- * Enqueues on `stream`; no synchronisation. */
+ * Enqueues the score kernel on `stream` and the small kernel that finishes d_hist and the hit
+ * list on `tail_stream` (NULL = `stream`), ordered by events inside the library; with a separate
+ * tail stream the next score kernel overlaps that tail and d_hist / d_hit_* are complete when
+ * `tail_stream` reaches this point.  No host synchronisation. */
 int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, int32_t *d_scores,
                     uint64_t *d_hist, int32_t select_cutoff, int64_t row_base,
                     int64_t *d_hit_rows, int64_t hit_capacity, uint64_t *d_hit_count,
-                    uint32_t flags, void *stream);
+                    uint32_t flags, void *stream, void *tail_stream);
 
-/* Measurement aid (bench.py): with slots > 0 every later gfm_score_kmers call brackets the
- * score kernel ALONE (not the histogram reduction that follows it) with a hipEvent pair on
- * the launch stream, in a ring of `slots` pairs; slots = 0 turns it off.  gfm_profile_read
- * waits for the recorded events and returns the kernel durations in ms, oldest first. */
-int gfm_profile_enable(gfm_motif_t m, int slots);
+/* Measurement aid (bench.py): with slots > 0 every `every`-th later gfm_score_kmers call
+ * brackets the score kernel ALONE (not the post kernel that follows it) with a hipEvent pair
+ * on the launch stream, in a ring of `slots` pairs; slots = 0 turns it off.  (An event pair
+ * costs ~7 us of stream time, hence the sampling.)  gfm_profile_read waits for the recorded
+ * events and returns the kernel durations in ms, oldest first. */
+int gfm_profile_enable(gfm_motif_t m, int slots, int every);
 int gfm_profile_read(gfm_motif_t m, float *h_ms_out, int capacity, int *n_out);
 
 /* replaces compute_qvalues(pvalues, debug) (score_sequences.py:401-428; statsmodels
