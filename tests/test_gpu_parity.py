@@ -231,3 +231,63 @@ def test_full_size_config2_scores_exact(dev, golden_motifs):
     assert hist.sum() == n
     assert np.array_equal(hist, np.bincount(exp, minlength=dm.L))
     dm.close()
+
+
+def test_config4_shape_w30_qvalue_threshold(dev, golden_motifs):
+    """BASELINE config 4 shape (W=30 JASPAR-style motif, both strands, --qvalueT -t 1e-4), scaled to
+    2e6 rows so that the CPU side (C restatement + sorted BH) finishes in seconds."""
+    from grafimo_amd import synth
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.scan import KmerScanner
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    g = flat["syn30_jaspar_unif#0"]
+    batch = synth.make_batch(1000, 2000, 30, g["probs"], synth.seed_for(4))
+    n = len(batch)
+    dm = DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"])   # device DP
+    pmf, pt = dm.tables()
+    assert np.array_equal(pmf, g["pmf"])
+    sc_exp, pv = orc.score_kmers_table(batch.kmers, g["score_matrix"], pt, g["min_val"])
+    q_exp = orc.fdr_bh(pv)
+    scanner = KmerScanner(dm, n, device=dev)
+    d_k = torch.from_numpy(batch.kmers).to(dev)
+    for thr in (1e-4, 1e-2):
+        slot = scanner.enqueue(d_k, thr, on_qvalue=True, want_qvalues=True)
+        res = scanner.collect(slot)
+        assert np.array_equal(slot.scores.cpu().numpy(), sc_exp)
+        hits = np.nonzero(q_exp < thr)[0]
+        assert len(hits) > 100
+        assert np.array_equal(res["rows"], hits)
+        assert np.array_equal(res["scaled"], sc_exp[hits])
+        np.testing.assert_allclose(res["qtable"][res["scaled"]], q_exp[hits], rtol=1e-12, atol=0)
+        assert res["n_scored"] == n
+    dm.close()
+
+
+def test_config5_shape_multi_motif_per_motif_background(dev, golden_motifs):
+    """BASELINE config 5 shape: several PWMs of different widths (8..25), each with its own
+    background, scanned one after the other the way grafimo.findmotif loops over a MotifSet
+    (grafimo.py:177-183)."""
+    from grafimo_amd import synth
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.scan import KmerScanner
+    from oracle import oracle as orc
+    cases, flat = golden_motifs
+    keys = [f"multi_meme_bg1#{i}" for i in range(6)] + ["multi_meme_bg2_norev#3", "gata1_meme_bgnt#0",
+                                                         "atf3_meme_unif#0", "example_meme_unif#0"]
+    for key in keys:
+        g = flat[key]
+        W = g["width"]
+        batch = synth.make_batch(60, 1000, W, g["probs"], synth.seed_for(5) + W)
+        dm = DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"])
+        pmf, pt = dm.tables()
+        assert np.array_equal(pmf, g["pmf"]), key                     # per-motif bg enters the DP
+        sc_exp, pv = orc.score_kmers_table(batch.kmers, g["score_matrix"], pt, g["min_val"])
+        scanner = KmerScanner(dm, len(batch), device=dev, side_stream=False)
+        res = scanner.collect(scanner.enqueue(torch.from_numpy(batch.kmers).to(dev), 1e-3))
+        hits = np.nonzero(pv < 1e-3)[0]
+        assert np.array_equal(res["rows"], hits), key
+        lo, p = dm.annotate(res["scaled"])
+        assert np.array_equal(lo, sc_exp[hits] / g["scale"] + W * g["offset"]), key
+        np.testing.assert_allclose(res["qtable"][res["scaled"]], orc.fdr_bh(pv)[hits], rtol=1e-12, atol=0)
+        dm.close()
