@@ -160,3 +160,23 @@ def test_scanner_collectives_on_one_gpu_rccl(golden_motifs):
         dm.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_cli_scoring_stage_writes_the_reference_reports(tmp_path, golden_json, capsys):
+    """python -m grafimo_amd -m MA0139.1.meme -s <dir> -t 1e-2 -o out  vs the reference's report"""
+    from grafimo_amd.__main__ import main
+    out = tmp_path / "out"
+    main(["-m", os.path.join(REF_DATA, "MA0139.1.meme"), "-s", REF_DATA, "-t", "1e-2", "-o", str(out), "-j", "2"])
+    text = capsys.readouterr().out
+    assert "Scanned sequences:\t704" in text and "Elapsed time" in text
+    got = pd.read_csv(out / "grafimo_out.tsv", sep="\t", index_col=0)
+    exp = pd.read_csv(os.path.join(GOLDEN, "report", "default_t1e-2.tsv"), sep="\t", index_col=0)
+    _compare(got, exp)
+    gff = open(out / "grafimo_out.gff").read().splitlines()
+    ref = open(os.path.join(GOLDEN, "report", "default_t1e-2.gff")).read().splitlines()
+    assert len(gff) == len(ref) and gff[0] == "##gff-version 3"
+    # columns 1-8 (coordinates, rounded score, strand) are identical text; p/q differ at 1e-16 at most
+    assert sorted(l.split("\t")[:8] for l in gff[1:]) == sorted(l.split("\t")[:8] for l in ref[1:])
+    assert os.path.isfile(out / "grafimo_out.html")
+    main(["-m", os.path.join(REF_DATA, "MA0139.1.jaspar"), "-s", REF_DATA, "-t", "5e-3", "-q", "-f"])
+    assert "matched_sequence" in capsys.readouterr().out
