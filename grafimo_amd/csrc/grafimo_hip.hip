@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -643,6 +644,7 @@ struct gfm_motif {
     int n_cu = 256;
     int max_slabs = 0;
     int sel_slabs = 0;
+    int reserve_cus = kReserveCUs;  // GRAFIMO_RESERVE_CUS overrides
     bool lds_hist = true;
     size_t lds_bytes = 0;
     std::vector<int64_t> sm;
@@ -980,6 +982,7 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     hipDeviceProp_t prop;
     HIP_TRY_M(hipGetDeviceProperties(&prop, m->device));
     m->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = std::getenv("GRAFIMO_RESERVE_CUS")) m->reserve_cus = std::max(0, std::min(atoi(e), m->n_cu - 1));
 
     // LDS lookup tables: [2*ndw base pairs][8 x 8 codes] uint16, code = (ascii >> 1) & 7
     // (A 0, C 1, T 2, G 3; 4..7 invalid), index = code(first) + 8 * code(second).
@@ -1128,7 +1131,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     const long long want = (nchunks + kWavesPerWG - 1) / kWavesPerWG;
     // with a tail stream a few CUs are left free so that its kernels (post, q-table, RCCL) find
     // room without evicting a persistent score workgroup (which would delay the whole grid)
-    const int avail = split ? std::max(1, m->max_slabs - kReserveCUs * (m->max_slabs / m->n_cu)) : m->max_slabs;
+    const int avail = split ? std::max(1, m->max_slabs - m->reserve_cus * (m->max_slabs / m->n_cu)) : m->max_slabs;
     const int nslabs = (int)std::min<long long>(want, avail);
 
     const unsigned k = m->call_no++;

@@ -291,3 +291,59 @@ def test_config5_shape_multi_motif_per_motif_background(dev, golden_motifs):
         assert np.array_equal(lo, sc_exp[hits] / g["scale"] + W * g["offset"]), key
         np.testing.assert_allclose(res["qtable"][res["scaled"]], orc.fdr_bh(pv)[hits], rtol=1e-12, atol=0)
         dm.close()
+
+
+def test_config3_shard_size_invariants(dev, golden_motifs):
+    """BASELINE config 3's per-GPU shard (1.25e8 k-mers, W=19; 2.4 GB of k-mers generated on the
+    device).  Too big for a row-by-row CPU check, so: (1) a 2e6-row slice is compared with the CPU
+    restatement exactly, (2) size-independent properties on the full batch -- the histogram sums to
+    N and equals torch.bincount of the scores, hits == rows with score >= cutoff, the batch scored
+    as two halves (row_base, appended hit list, accumulated histogram) equals the single launch."""
+    from grafimo_amd.device import DeviceMotif
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    g = flat["ctcf_meme_unif#0"]
+    dm = DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"], g["pmf"])
+    _, pt = dm.tables()
+    n = 125_000_000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20240139 + 3)
+    alphabet = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    d_k = alphabet[torch.randint(0, 4, (n, 19), generator=gen, device=dev, dtype=torch.int64)]
+    d_k[torch.randint(0, n, (n // 1000,), generator=gen, device=dev), 7] = ord("N")
+    d_sc = torch.empty(n, dtype=torch.int32, device=dev)
+    d_hist = torch.zeros(dm.L, dtype=torch.int64, device=dev)
+    cut = dm.pvalue_cutoff(1e-4)
+    cap = n // 1000
+    hits = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
+    dm.score(d_k, d_sc, hist=d_hist, select_cutoff=cut, hit_rows=hits[1:], hit_count=hits[:1], reset_hits=True)
+    torch.cuda.synchronize()
+    # (1) slice vs CPU
+    lo_, hi_ = 61_000_000, 63_000_000
+    exp, _ = orc.score_kmers_table(d_k[lo_:hi_].cpu().numpy(), g["score_matrix"], pt, g["min_val"])
+    assert np.array_equal(d_sc[lo_:hi_].cpu().numpy(), exp)
+    # (2) invariants
+    assert int(d_hist.sum().item()) == n
+    assert torch.equal(d_hist, torch.bincount(d_sc, minlength=dm.L))
+    k = int(hits[0].item())
+    assert 0 < k <= cap
+    got = torch.sort(hits[1:1 + k]).values
+    exp_rows = torch.nonzero(d_sc >= cut).flatten()
+    assert torch.equal(got >> 20, exp_rows)
+    assert torch.equal((got & 0xFFFFF).to(torch.int32), d_sc[exp_rows])
+    # two halves == one launch
+    h2 = torch.zeros(dm.L, dtype=torch.int64, device=dev)
+    hits2 = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
+    half = 62_500_037   # ragged split
+    sc2 = torch.empty(n, dtype=torch.int32, device=dev)
+    dm.score(d_k[:half], sc2[:half], hist=h2, select_cutoff=cut, hit_rows=hits2[1:], hit_count=hits2[:1],
+             reset_hits=True)
+    # the second half's k-mer matrix starts at a 16-byte aligned row: 62_500_037 * 19 is not, so copy
+    second = d_k[half:].clone()
+    dm.score(second, sc2[half:], hist=h2, select_cutoff=cut, row_base=half, hit_rows=hits2[1:],
+             hit_count=hits2[:1])
+    torch.cuda.synchronize()
+    assert torch.equal(h2, d_hist) and torch.equal(sc2, d_sc)
+    assert int(hits2[0].item()) == k
+    assert torch.equal(torch.sort(hits2[1:1 + k]).values, got)
+    dm.close()
