@@ -163,7 +163,9 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
 
     for (int i = tid; i < kTabBytes / 2; i += kThreads)
         reinterpret_cast<uint16_t *>(tab)[i] = g_tab[i];
-    if (use_hist)
+    // use_hist: 0 = none, 1 = per-workgroup LDS window, 2 = the window does not fit the LDS
+    // (very wide motifs): global atomics straight into slab 0 (zeroed by the host side)
+    if (use_hist == 1)
         for (int i = tid; i <= nb; i += kThreads) hist[i] = 0u;
     __syncthreads();
 
@@ -243,7 +245,8 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
             const bool live = row < n;
             if (live) {
                 scores[row] = score;
-                if (use_hist) atomicAdd(&hist[is_n ? nb : score - lo], 1u);
+                if (use_hist == 1) atomicAdd(&hist[is_n ? nb : score - lo], 1u);
+                else if (use_hist == 2) atomicAdd(&partials[is_n ? nb : score - lo], 1u);
             }
             if (SELECT)
                 hitq_push(hitq, qn, live && score >= cutoff,
@@ -264,7 +267,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
         hitq_finish<kWavesPerWG>(hitq, qn, reinterpret_cast<int *>(tab), wave, lane, tid, resid, resid_n);
     }
 
-    if (use_hist) {
+    if (use_hist == 1) {
         __syncthreads();
         unsigned *slab = partials + (size_t)blockIdx.x * (size_t)(nb + 1);
         for (int i = tid; i <= nb; i += kThreads) slab[i] = hist[i];
@@ -1032,8 +1035,8 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
         HIP_TRY_M(hipMalloc(&m->d_partials[i], sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->nb + 1)));
         HIP_TRY_M(hipMalloc(&m->d_resid[i], sizeof(long long) * (size_t)m->max_slabs * kResidPerWG));
         HIP_TRY_M(hipMalloc(&m->d_resid_n[i], sizeof(int) * (size_t)m->max_slabs));
-        HIP_TRY_M(hipEventCreateWithFlags(&m->ev_scored[i], hipEventDisableTiming));
-        HIP_TRY_M(hipEventCreateWithFlags(&m->ev_posted[i], hipEventDisableTiming));
+        HIP_TRY_M(hipEventCreateWithFlags(&m->ev_scored[i], hipEventDisableTiming | hipEventReleaseToDevice));
+        HIP_TRY_M(hipEventCreateWithFlags(&m->ev_posted[i], hipEventDisableTiming | hipEventReleaseToDevice));
     }
     HIP_TRY_M(hipMalloc(&m->d_ctl, sizeof(HitCtl)));
     HIP_TRY_M(hipMemset(m->d_ctl, 0, sizeof(HitCtl)));
@@ -1124,9 +1127,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     const bool select = select_cutoff != GFM_NO_SELECT;
     if (select && (!d_hit_rows || !d_hit_count))
         return fail(GFM_ERR_INVALID, "selection requested without hit buffers");
-    const int use_hist = d_hist != nullptr;
-    if (use_hist && !m->lds_hist)
-        return fail(GFM_ERR_INVALID, "score window of %d bins does not fit the LDS histogram", m->nb);
+    const int use_hist = d_hist ? (m->lds_hist ? 1 : 2) : 0;
     const long long nchunks = (n + kChunk - 1) / kChunk;
     const long long want = (nchunks + kWavesPerWG - 1) / kWavesPerWG;
     // with a tail stream a few CUs are left free so that its kernels (post, q-table, RCCL) find
@@ -1143,6 +1144,8 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws], 0));
     if (split && select && !reset && m->posted_valid[ws ^ 1])
         HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws ^ 1], 0));
+    if (use_hist == 2)
+        HIP_TRY(hipMemsetAsync(m->d_partials[ws], 0, sizeof(unsigned) * (size_t)(m->nb + 1), st));
     int rc = dispatch_score(m, d_kmers, n, d_scores, use_hist, nslabs, select, select_cutoff, row_base,
                             reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                             reset ? nullptr : reinterpret_cast<unsigned long long *>(d_hit_count), st,
@@ -1152,7 +1155,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         HIP_TRY(hipEventRecord(m->ev_scored[ws], st));
         HIP_TRY(hipStreamWaitEvent(tail, m->ev_scored[ws], 0));
     }
-    rc = launch_post(m, m->d_partials[ws], nslabs, reinterpret_cast<unsigned long long *>(d_hist),
+    rc = launch_post(m, m->d_partials[ws], use_hist == 2 ? 1 : nslabs, reinterpret_cast<unsigned long long *>(d_hist),
                      m->d_resid[ws], m->d_resid_n[ws], select ? nslabs : 0, m->d_ctl, slot,
                      reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                      reinterpret_cast<unsigned long long *>(d_hit_count), tail);

@@ -347,3 +347,51 @@ def test_config3_shard_size_invariants(dev, golden_motifs):
     assert int(hits2[0].item()) == k
     assert torch.equal(torch.sort(hits2[1:1 + k]).values, got)
     dm.close()
+
+
+@pytest.mark.parametrize("W", [1, 2, 3, 4, 5, 7, 8, 16, 33, 40, 63, 64])
+def test_width_sweep_random_matrices(dev, W):
+    """Every kernel instantiation (NDW = 1..16), incl. score windows too wide for the LDS histogram
+    (W >= 40 with full-range columns -> global-atomic fallback): DP bit-exact, scores/histogram
+    exact, q-table and selection vs sorted BH, on random integer matrices."""
+    from grafimo_amd.device import DeviceMotif
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1000 + W)
+    sm = rng.integers(0, 1001, size=(4, W)).astype(np.int64)
+    sm[rng.integers(0, 4), 0] = 0
+    sm[rng.integers(0, 4), W - 1] = 1000          # keep the [0, 1000] span of scale_pwm
+    if W >= 40:                                    # force a window wider than any LDS budget
+        sm[0, :] = 0
+        sm[3, :] = 1000
+    bg = rng.dirichlet([20, 20, 20, 20])
+    min_val, scale, offset = int(sm.min()), int(rng.integers(20, 200)), float(-rng.integers(3, 20))
+    dm = DeviceMotif(sm, bg, min_val, scale, offset)
+    pmf, pt = dm.tables()
+    assert np.array_equal(pmf, orc.comp_pval_mat(sm, bg))
+    assert dm.score_lo == int(sm.min(0).sum()) and dm.score_hi == int(sm.max(0).sum())
+    n = 50_017
+    km = random_kmers(rng, n, W, n_frac=0.02)
+    exp, pv = orc.score_kmers_table(km, sm, pt, min_val)
+    d_k = torch.from_numpy(km).to(dev)
+    d_sc = torch.empty(n, dtype=torch.int32, device=dev)
+    d_hist = torch.zeros(dm.L, dtype=torch.int64, device=dev)
+    thr = 0.05
+    cut = dm.pvalue_cutoff(thr)
+    hits = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    dm.score(d_k, d_sc, hist=d_hist, select_cutoff=cut, hit_rows=hits[1:], hit_count=hits[:1], reset_hits=True)
+    q = torch.empty(dm.L, dtype=torch.float64, device=dev)
+    dcut = torch.zeros(1, dtype=torch.int32, device=dev)
+    nrows = torch.zeros(1, dtype=torch.int64, device=dev)
+    dm.qvalue_table(d_hist, 0.5, True, q, dcut, nrows)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_sc.cpu().numpy(), exp)
+    assert np.array_equal(d_hist.cpu().numpy(), np.bincount(exp, minlength=dm.L))
+    k = int(hits[0].item())
+    got = np.sort(hits[1:1 + k].cpu().numpy())
+    assert np.array_equal(got >> 20, np.nonzero(pv < thr)[0])
+    q_exp = orc.fdr_bh(pv)
+    np.testing.assert_allclose(q.cpu().numpy()[exp], q_exp, rtol=1e-12, atol=0)
+    assert np.array_equal(exp >= int(dcut.item()), q_exp < 0.5)
+    lo, p = dm.annotate(exp[:100])
+    assert np.array_equal(lo, exp[:100] / scale + W * offset) and np.array_equal(p, pt[exp[:100]])
+    dm.close()
