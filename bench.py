@@ -78,15 +78,15 @@ def cpu_baseline(kmers, sm, pmf, min_val, scale, offset, target_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--regions", type=int, default=10_000)
     ap.add_argument("--rows-per-region", type=int, default=2_000)
     ap.add_argument("--threshold", type=float, default=1e-4)
     ap.add_argument("--qvalue-threshold", action="store_true", help="--qvalueT: threshold on q")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slots", type=int, default=2, help="buffer slots of the scan pipeline")
-    ap.add_argument("--event-every", type=int, default=5,
+    ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the score kernel of every n-th step with a hipEvent pair")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: do not bracket the score kernel with events in the timed region")
