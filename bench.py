@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--qvalue-threshold", action="store_true", help="--qvalueT: threshold on q")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slots", type=int, default=2, help="buffer slots of the scan pipeline")
+    ap.add_argument("--gather-group", action="store_true",
+                    help="N > 1: run the hit gather on a second RCCL communicator and stream")
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the score kernel of every n-th step with a hipEvent pair")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -137,7 +139,11 @@ def main():
     dm = DeviceMotif(sm, motif.dense_bg(), motif.min_val, motif.scale, motif.offset)  # device DP
     d_kmers = torch.from_numpy(batch.kmers).to(dev)
     hit_cap = max(4096, n // 64)   # fixed-size hit buffer (what the gather to rank 0 moves): 1.6 % of the rows
-    scanner = KmerScanner(dm, n, hit_capacity=hit_cap, device=dev,
+    # optional: hits on their own communicator so that gather(k) overlaps all-reduce(k+1).  Off by
+    # default: two communicators whose kernels become ready in different orders on different ranks
+    # are a classic deadlock hazard, and this path cannot be exercised on the 1-GPU test boxes.
+    gather_group = dist.new_group(backend="nccl") if (world > 1 and args.gather_group) else None
+    scanner = KmerScanner(dm, n, hit_capacity=hit_cap, device=dev, gather_group=gather_group,
                           group=None, side_stream=args.overlap != "off", n_slots=args.slots)
 
     def step():

@@ -34,6 +34,7 @@ class ScanSlot:
         # [0] = hit count, [1:] = hit rows (one buffer so that one gather moves both)
         self.hits = torch.zeros(self.hit_capacity + 1, dtype=torch.int64, device=device)
         self.done = torch.cuda.Event()
+        self.tail_done = torch.cuda.Event()
         self.gathered = None
         # raw addresses for the ctypes fast path
         self.p_scores = self.scores.data_ptr()
@@ -56,7 +57,7 @@ class ScanSlot:
 class KmerScanner:
     def __init__(self, dm: DeviceMotif, n_rows: int, hit_capacity: Optional[int] = None,
                  device=None, group=None, n_slots: int = 2, side_stream: bool = True,
-                 always_collective: bool = False):
+                 always_collective: bool = False, gather_group=None):
         torch = _torch()
         self.dm = dm
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -70,6 +71,13 @@ class KmerScanner:
         # calls on a single-GPU box)
         self.collective = self.world > 1 or (always_collective and torch.distributed.is_initialized())
         self._gather_ok = True
+        # A second process group (its own RCCL communicator and stream) for the hit gather lets
+        # gather(k) run beside all-reduce(k+1): collectives of ONE group execute in issue order.
+        self.gather_group = gather_group if gather_group is not None else group
+        self._gather_stream = None
+        self.tail_done = None
+        if gather_group is not None and side_stream:
+            self._gather_stream = torch.cuda.Stream(device=self.device, priority=-1)
         cap = int(hit_capacity) if hit_capacity is not None else int(n_rows)
         self.slots = [ScanSlot(dm, n_rows, cap, self.device) for _ in range(n_slots)]
         # high priority: tail kernels are tiny and sit on the critical path of slot reuse
@@ -130,6 +138,14 @@ class KmerScanner:
                                           slot.p_hit_rows, slot.hit_capacity, slot.p_hit_count,
                                           _nv.GFM_FLAG_RESET_HITS, tail_p))
         if gather_hits and self.collective:
+            gs = self._gather_stream
+            if gs is not None:                 # gather on its own stream, behind this step's tail
+                slot.tail_done.record(tail)
+                gs.wait_event(slot.tail_done)
+                with torch.cuda.stream(gs):
+                    self._gather(slot)
+                slot.done.record(gs)
+                return slot
             with torch.cuda.stream(tail):
                 self._gather(slot)
         slot.done.record(tail)
@@ -144,13 +160,14 @@ class KmerScanner:
             slot.gathered = [torch.empty_like(slot.hits) for _ in range(self.world)]
         if self._gather_ok:
             try:
-                dist.gather(slot.hits, slot.gathered if self.rank == 0 else None, dst=0, group=self.group)
+                dist.gather(slot.hits, slot.gathered if self.rank == 0 else None, dst=0,
+                            group=self.gather_group)
                 return
             except (RuntimeError, NotImplementedError):
                 self._gather_ok = False
                 if slot.gathered is None:
                     slot.gathered = [torch.empty_like(slot.hits) for _ in range(self.world)]
-        dist.all_gather(slot.gathered, slot.hits, group=self.group)
+        dist.all_gather(slot.gathered, slot.hits, group=self.gather_group)
 
     def finish(self):
         """Make the caller's stream wait for all side-stream work."""

@@ -148,7 +148,8 @@ def test_scanner_collectives_on_one_gpu_rccl(golden_motifs):
         d_k = torch.from_numpy(batch.kmers).to(dev)
         n = len(batch)
         plain = KmerScanner(dm, n, device=dev, side_stream=False)
-        coll = KmerScanner(dm, n, device=dev, side_stream=True, always_collective=True)
+        coll = KmerScanner(dm, n, device=dev, side_stream=True, always_collective=True,
+                           gather_group=dist.new_group(backend="nccl"))
         for on_q, thr in [(False, 1e-3), (True, 0.2)]:
             r0 = plain.collect(plain.enqueue(d_k, thr, on_qvalue=on_q))
             for _ in range(3):   # slots rotate; the side stream hands buffers back cleared
