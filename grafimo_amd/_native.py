@@ -55,6 +55,8 @@ PROTOTYPES = {
     "gfm_motif_annotate": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "gfm_score_kmers": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_i64,
                                 c_void_p, c_i64, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
+    "gfm_score_kmers_multi": (c_int, [c_void_p, c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
+                                      c_void_p, c_void_p, c_void_p, ctypes.c_uint32, c_void_p]),
     "gfm_profile_enable": (c_int, [c_void_p, c_int, c_int]),
     "gfm_profile_read": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
     "gfm_qvalue_table": (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,

@@ -63,9 +63,9 @@ constexpr int kHitQueue = 64;                  // per-wave LDS hit queue (entrie
 constexpr int kDepth = 3;                      // chunks prefetched ahead per wave
 
 // per-wave LDS strip: the staged chunk (+8 B slack for the last row's trailing dword),
-// followed by the wave's hit queue
+// followed by the wave's hit queue(s), one per motif of the launch
 __host__ __device__ inline int stage_data_bytes(int W) { return ((kChunk * W + 15) & ~15) + 8; }
-__host__ __device__ inline int stage_stride_bytes(int W) { return stage_data_bytes(W) + kHitQueue * 8; }
+__host__ __device__ inline int stage_stride_bytes(int W, int mm) { return stage_data_bytes(W) + mm * kHitQueue * 8; }
 
 // ---------------------------------------------------------------------------------------
 // Hit list plumbing shared by the fused and the separate selection.
@@ -137,36 +137,61 @@ __device__ inline void hitq_finish(const long long *hitq, int qn, int *wq_n /* s
 // of the last dword needs no masking.  Scores go out as coalesced int32; the score histogram
 // is built with LDS atomics in a per-workgroup window [lo, lo+nb) (+1 bin for N rows)
 // and flushed once per workgroup as a plain-store slab (no global atomics).
-template <int NDW, bool SELECT>
+// MM motifs of the same width can share ONE read of the k-mers (BASELINE config 5: per
+// (k-mer, motif) pair the algorithmic bytes drop from W + 4 to W/MM + 4): the staged strip is
+// scored against MM table sets, each motif has its own histogram window, hit queue and outputs.
+struct MotifArgs {
+    const uint16_t *tab;      // [2*NDW][64] pair tables (global)
+    int lo, nb, min_val;
+    int use_hist;             // 0 none, 1 LDS window -> slab, 2 global atomics into slab 0
+    int cutoff;               // rows with score >= cutoff are hits; GFM_NO_SELECT: none
+    int slot;                 // HitCtl slot of this call
+    int *scores;
+    unsigned *partials;
+    long long *hit_rows;
+    long long hit_cap;
+    const unsigned long long *hit_count;   // nullptr: the list restarts at 0 (GFM_FLAG_RESET_HITS)
+    HitCtl *ctl;
+    long long *resid;
+    int *resid_n;
+};
+template <int MM> struct ScoreArgs { MotifArgs m[MM]; };
+
+template <int NDW, int MM>
 __global__ void __launch_bounds__(kThreads)
-score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
-                  const uint16_t *__restrict__ g_tab, int lo, int nb, int min_val,
-                  int use_hist, int *__restrict__ scores, unsigned *__restrict__ partials,
-                  int cutoff, long long row_base, long long *__restrict__ hit_rows,
-                  long long hit_cap, const unsigned long long *__restrict__ hit_count,
-                  HitCtl *__restrict__ ctl, int par, long long *__restrict__ resid,
-                  int *__restrict__ resid_n)
+score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long long row_base,
+                  const ScoreArgs<MM> a)
 {
-    // hit_count == nullptr: the list restarts at 0 (GFM_FLAG_RESET_HITS); the old count is not read
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kTabBytes = 2 * NDW * 64 * 2;  // 2*NDW base pairs x (8 x 8 codes) x uint16
     constexpr int kLoads = (kChunk * 4 * NDW + 1023) / 1024;  // 16 B loads per lane per chunk
 
-    unsigned char *tab = smem;
-    unsigned char *stage_base = smem + kTabBytes;
-    const int sstride = stage_stride_bytes(W);
-    unsigned *hist = reinterpret_cast<unsigned *>(stage_base + kWavesPerWG * sstride);
+    unsigned char *tab = smem;                       // MM table sets
+    unsigned char *stage_base = smem + MM * kTabBytes;
+    const int sstride = stage_stride_bytes(W, MM);
+    unsigned *hist[MM];
+    {
+        unsigned *h = reinterpret_cast<unsigned *>(stage_base + kWavesPerWG * sstride);
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            hist[m] = h;
+            if (a.m[m].use_hist == 1) h += a.m[m].nb + 1;
+        }
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
 
-    for (int i = tid; i < kTabBytes / 2; i += kThreads)
-        reinterpret_cast<uint16_t *>(tab)[i] = g_tab[i];
-    // use_hist: 0 = none, 1 = per-workgroup LDS window, 2 = the window does not fit the LDS
-    // (very wide motifs): global atomics straight into slab 0 (zeroed by the host side)
-    if (use_hist == 1)
-        for (int i = tid; i <= nb; i += kThreads) hist[i] = 0u;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        for (int i = tid; i < kTabBytes / 2; i += kThreads)
+            reinterpret_cast<uint16_t *>(tab + m * kTabBytes)[i] = a.m[m].tab[i];
+        // use_hist: 0 = none, 1 = per-workgroup LDS window, 2 = the window does not fit the LDS
+        // (very wide motifs): global atomics straight into slab 0 (zeroed by the host side)
+        if (a.m[m].use_hist == 1)
+            for (int i = tid; i <= a.m[m].nb; i += kThreads) hist[m][i] = 0u;
+    }
     __syncthreads();
 
     unsigned char *stage = stage_base + wave * sstride;
@@ -197,9 +222,15 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
         }
     };
 
-    long long *hitq = reinterpret_cast<long long *>(stage + stage_data_bytes(W));
-    int qn = 0;  // wave-uniform
-    if (SELECT && blockIdx.x == 0 && tid == 0) ctl->snap[par] = hit_count ? *hit_count : 0ull;
+    long long *hitq[MM];
+    int qn[MM];  // wave-uniform
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        hitq[m] = reinterpret_cast<long long *>(stage + stage_data_bytes(W)) + m * kHitQueue;
+        qn[m] = 0;
+        if (a.m[m].cutoff != GFM_NO_SELECT && blockIdx.x == 0 && tid == 0)
+            a.m[m].ctl->snap[a.m[m].slot] = a.m[m].hit_count ? *a.m[m].hit_count : 0ull;
+    }
 
     long long c = (long long)blockIdx.x * kWavesPerWG + wave;
 #pragma unroll
@@ -228,30 +259,40 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
             const unsigned *src = reinterpret_cast<const unsigned *>(stage + (boff & ~3));
             unsigned w[NDW + 1];
 #pragma unroll
-            for (int d = 0; d <= NDW; ++d) w[d] = src[d];
-            int acc = 0;
+            for (int d2 = 0; d2 <= NDW; ++d2) w[d2] = src[d2];
+            int acc[MM];
 #pragma unroll
-            for (int d = 0; d < NDW; ++d) {
-                const unsigned x = __builtin_amdgcn_alignbit(w[d + 1], w[d], sh);
+            for (int m = 0; m < MM; ++m) acc[m] = 0;
+#pragma unroll
+            for (int d2 = 0; d2 < NDW; ++d2) {
+                const unsigned x = __builtin_amdgcn_alignbit(w[d2 + 1], w[d2], sh);
                 const unsigned xm = x & 0x0E0E0E0Eu;   // 2 * ((c >> 1) & 7) per byte
                 const unsigned y = xm | (xm >> 5);     // bytes 0 and 2: 2*(code_lo + 8*code_hi)
                 const unsigned e0 = y & 0x7Eu;
                 const unsigned e1 = (y >> 16) & 0x7Eu;
-                acc += *reinterpret_cast<const uint16_t *>(tab + (2 * d) * 128 + e0);
-                acc += *reinterpret_cast<const uint16_t *>(tab + (2 * d + 1) * 128 + e1);
+#pragma unroll
+                for (int m = 0; m < MM; ++m) {
+                    const unsigned char *t = tab + m * kTabBytes;
+                    acc[m] += *reinterpret_cast<const uint16_t *>(t + (2 * d2) * 128 + e0);
+                    acc[m] += *reinterpret_cast<const uint16_t *>(t + (2 * d2 + 1) * 128 + e1);
+                }
             }
-            const bool is_n = (unsigned)acc >= kPoison;
-            const int score = is_n ? min_val : acc;
             const bool live = row < n;
-            if (live) {
-                scores[row] = score;
-                if (use_hist == 1) atomicAdd(&hist[is_n ? nb : score - lo], 1u);
-                else if (use_hist == 2) atomicAdd(&partials[is_n ? nb : score - lo], 1u);
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                const MotifArgs &ma = a.m[m];
+                const bool is_n = (unsigned)acc[m] >= kPoison;
+                const int score = is_n ? ma.min_val : acc[m];
+                if (live) {
+                    ma.scores[row] = score;
+                    if (ma.use_hist == 1) atomicAdd(&hist[m][is_n ? ma.nb : score - ma.lo], 1u);
+                    else if (ma.use_hist == 2) atomicAdd(&ma.partials[is_n ? ma.nb : score - ma.lo], 1u);
+                }
+                if (ma.cutoff != GFM_NO_SELECT)
+                    hitq_push(hitq[m], qn[m], live && score >= ma.cutoff,
+                              ((row_base + row) << GFM_HIT_SCORE_BITS) | (long long)score, lane,
+                              ma.hit_count, &ma.ctl->mid[ma.slot], ma.hit_rows, ma.hit_cap);
             }
-            if (SELECT)
-                hitq_push(hitq, qn, live && score >= cutoff,
-                          ((row_base + row) << GFM_HIT_SCORE_BITS) | (long long)score, lane,
-                          hit_count, &ctl->mid[par], hit_rows, hit_cap);
         }
         // the strip is rewritten next iteration: keep this iteration's reads ahead of it
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -260,17 +301,19 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W,
     }
     }
 
-    if (SELECT) {
-        // the lookup tables are dead once every wave has left the loop: their LDS holds the
-        // per-wave queue lengths (no static LDS: 3 workgroups/CU fit with 40 bytes to spare)
-        __syncthreads();
-        hitq_finish<kWavesPerWG>(hitq, qn, reinterpret_cast<int *>(tab), wave, lane, tid, resid, resid_n);
-    }
-
-    if (use_hist == 1) {
-        __syncthreads();
-        unsigned *slab = partials + (size_t)blockIdx.x * (size_t)(nb + 1);
-        for (int i = tid; i <= nb; i += kThreads) slab[i] = hist[i];
+    // the lookup tables are dead once every wave has left the loop: their LDS holds the per-wave
+    // queue lengths (no static LDS)
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        const MotifArgs &ma = a.m[m];
+        if (ma.cutoff != GFM_NO_SELECT)
+            hitq_finish<kWavesPerWG>(hitq[m], qn[m], reinterpret_cast<int *>(tab + m * kTabBytes), wave,
+                                     lane, tid, ma.resid, ma.resid_n);
+        if (ma.use_hist == 1) {
+            unsigned *slab = ma.partials + (size_t)blockIdx.x * (size_t)(ma.nb + 1);
+            for (int i = tid; i <= ma.nb; i += kThreads) slab[i] = hist[m][i];
+        }
     }
 }
 
@@ -753,38 +796,52 @@ int run_dp(const int64_t *sm, int W, const double *bg, double *d_pmf, hipStream_
     return GFM_OK;
 }
 
-template <int NDW>
-int launch_score(gfm_motif *m, const uint8_t *d_kmers, long long n, int *d_scores, int use_hist,
-                 int nslabs, bool select, int cutoff, long long row_base, long long *d_hit_rows,
-                 long long cap, unsigned long long *d_hit_count, hipStream_t st, bool prepare_only,
-                 int par)
+// LDS bytes of one score launch: MM table sets | 16 wave strips (chunk + MM hit queues) | the
+// LDS histogram windows of the motifs that use one
+size_t score_lds_bytes(int W, int ndw, int mm, const int *nb_lds /* nb+1 or 0 per motif */)
 {
-    auto k_sel = score_hist_kernel<NDW, true>;
-    auto k_nos = score_hist_kernel<NDW, false>;
-    auto kern = select ? k_sel : k_nos;
-    if (prepare_only) {  // called once from gfm_motif_create (never inside a stream capture)
-        if (m->lds_bytes > 64 * 1024) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_nos),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes));
-        }
+    size_t b = (size_t)mm * (2 * ndw * 64 * 2) + (size_t)kWavesPerWG * stage_stride_bytes(W, mm);
+    for (int i = 0; i < mm; ++i) b += sizeof(unsigned) * (size_t)nb_lds[i];
+    return b;
+}
+
+template <int NDW, int MM>
+int launch_score_t(gfm_motif *timer, const uint8_t *d_kmers, long long n, int W, long long row_base,
+                   const ScoreArgs<MM> &args, size_t lds, int nslabs, hipStream_t st, bool prepare_only)
+{
+    auto kern = score_hist_kernel<NDW, MM>;
+    if (prepare_only) {  // once per width from gfm_motif_create (never inside a stream capture)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
         return GFM_OK;
     }
-    const bool prof = !m->ev0.empty() && (m->ev_calls++ % (unsigned)m->ev_every) == 0;
-    const int slot = m->ev_next;
-    if (prof) HIP_TRY(hipEventRecord(m->ev0[slot], st));
-    hipLaunchKernelGGL(kern, dim3(nslabs), dim3(kThreads), m->lds_bytes, st, d_kmers, n, m->W,
-                       m->d_tab, m->lo, m->nb, m->min_val, use_hist, d_scores, m->d_partials[par & 1],
-                       cutoff, row_base, d_hit_rows, cap, d_hit_count, m->d_ctl, par >> 1,
-                       m->d_resid[par & 1], m->d_resid_n[par & 1]);
+    const bool prof = timer && !timer->ev0.empty() && (timer->ev_calls++ % (unsigned)timer->ev_every) == 0;
+    const int slot = prof ? timer->ev_next : 0;
+    if (prof) HIP_TRY(hipEventRecord(timer->ev0[slot], st));
+    hipLaunchKernelGGL(kern, dim3(nslabs), dim3(kThreads), lds, st, d_kmers, n, W, row_base, args);
     HIP_TRY(hipGetLastError());
     if (prof) {
-        HIP_TRY(hipEventRecord(m->ev1[slot], st));
-        m->ev_next = (slot + 1) % (int)m->ev0.size();
-        m->ev_used = std::min(m->ev_used + 1, (int)m->ev0.size());
+        HIP_TRY(hipEventRecord(timer->ev1[slot], st));
+        timer->ev_next = (slot + 1) % (int)timer->ev0.size();
+        timer->ev_used = std::min(timer->ev_used + 1, (int)timer->ev0.size());
     }
     return GFM_OK;
+}
+
+template <int MM>
+int dispatch_score(int ndw, gfm_motif *timer, const uint8_t *d_kmers, long long n, int W,
+                   long long row_base, const ScoreArgs<MM> &args, size_t lds, int nslabs,
+                   hipStream_t st, bool prepare_only)
+{
+#define GFM_CASE(N)                                                                               \
+    case N:                                                                                       \
+        return launch_score_t<N, MM>(timer, d_kmers, n, W, row_base, args, lds, nslabs, st, prepare_only);
+    switch (ndw) {
+        GFM_CASE(1) GFM_CASE(2) GFM_CASE(3) GFM_CASE(4) GFM_CASE(5) GFM_CASE(6) GFM_CASE(7) GFM_CASE(8)
+        GFM_CASE(9) GFM_CASE(10) GFM_CASE(11) GFM_CASE(12) GFM_CASE(13) GFM_CASE(14) GFM_CASE(15) GFM_CASE(16)
+        default: return fail(GFM_ERR_INVALID, "unsupported width %d", W);
+    }
+#undef GFM_CASE
 }
 
 // one launch after a scoring / selection kernel: histogram slabs -> hist64, hit slabs -> list
@@ -804,21 +861,25 @@ int launch_post(gfm_motif *m, const unsigned *partials, int hist_slabs, unsigned
     return GFM_OK;
 }
 
-int dispatch_score(gfm_motif *m, const uint8_t *d_kmers, long long n, int *d_scores, int use_hist,
-                   int nslabs, bool select, int cutoff, long long row_base, long long *d_hit_rows,
-                   long long cap, unsigned long long *d_hit_count, hipStream_t st, bool prepare_only,
-                   int par)
+void fill_motif_args(MotifArgs &a, gfm_motif *m, int ws, int slot, int use_hist, int cutoff,
+                     int *d_scores, long long *d_hit_rows, long long cap,
+                     const unsigned long long *d_hit_count_or_null)
 {
-#define GFM_CASE(N)                                                                             \
-    case N:                                                                                     \
-        return launch_score<N>(m, d_kmers, n, d_scores, use_hist, nslabs, select, cutoff,       \
-                               row_base, d_hit_rows, cap, d_hit_count, st, prepare_only, par);
-    switch (m->ndw) {
-        GFM_CASE(1) GFM_CASE(2) GFM_CASE(3) GFM_CASE(4) GFM_CASE(5) GFM_CASE(6) GFM_CASE(7) GFM_CASE(8)
-        GFM_CASE(9) GFM_CASE(10) GFM_CASE(11) GFM_CASE(12) GFM_CASE(13) GFM_CASE(14) GFM_CASE(15) GFM_CASE(16)
-        default: return fail(GFM_ERR_INVALID, "unsupported width %d", m->W);
-    }
-#undef GFM_CASE
+    a.tab = m->d_tab;
+    a.lo = m->lo;
+    a.nb = m->nb;
+    a.min_val = m->min_val;
+    a.use_hist = use_hist;
+    a.cutoff = cutoff;
+    a.slot = slot;
+    a.scores = d_scores;
+    a.partials = m->d_partials[ws];
+    a.hit_rows = d_hit_rows;
+    a.hit_cap = cap;
+    a.hit_count = d_hit_count_or_null;
+    a.ctl = m->d_ctl;
+    a.resid = m->d_resid[ws];
+    a.resid_n = m->d_resid_n[ws];
 }
 
 }  // namespace
@@ -1024,7 +1085,8 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
                         hipMemcpyDeviceToHost));
 
     // score-kernel LDS plan: table | 8 wave strips | histogram window (+1 N bin)
-    const size_t fixed = (size_t)2 * m->ndw * 64 * 2 + (size_t)kWavesPerWG * stage_stride_bytes(W);
+    const int zero_nb = 0;
+    const size_t fixed = score_lds_bytes(W, m->ndw, 1, &zero_nb);
     const size_t with_hist = fixed + sizeof(unsigned) * (size_t)(m->nb + 1);
     m->lds_hist = with_hist <= (size_t)kMaxLdsBytes;
     m->lds_bytes = m->lds_hist ? with_hist : fixed;
@@ -1048,8 +1110,15 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     HIP_TRY_M(hipMalloc(&m->d_sel_ctl, sizeof(HitCtl)));
     HIP_TRY_M(hipMemset(m->d_sel_ctl, 0, sizeof(HitCtl)));
 #undef HIP_TRY_M
-    rc = dispatch_score(m, nullptr, 0, nullptr, 0, 1, false, 0, 0, nullptr, 0, nullptr, nullptr, true, 0);
-    if (rc) return bail(rc);
+    {   // allow up to the whole LDS for every instantiation this width can use
+        ScoreArgs<1> a1{};
+        ScoreArgs<2> a2{};
+        ScoreArgs<3> a3{};
+        rc = dispatch_score<1>(m->ndw, nullptr, nullptr, 0, W, 0, a1, 0, 1, nullptr, true);
+        if (!rc) rc = dispatch_score<2>(m->ndw, nullptr, nullptr, 0, W, 0, a2, 0, 1, nullptr, true);
+        if (!rc) rc = dispatch_score<3>(m->ndw, nullptr, nullptr, 0, W, 0, a3, 0, 1, nullptr, true);
+        if (rc) return bail(rc);
+    }
     *out = m;
     return GFM_OK;
 }
@@ -1146,10 +1215,11 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws ^ 1], 0));
     if (use_hist == 2)
         HIP_TRY(hipMemsetAsync(m->d_partials[ws], 0, sizeof(unsigned) * (size_t)(m->nb + 1), st));
-    int rc = dispatch_score(m, d_kmers, n, d_scores, use_hist, nslabs, select, select_cutoff, row_base,
-                            reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
-                            reset ? nullptr : reinterpret_cast<unsigned long long *>(d_hit_count), st,
-                            false, (slot << 1) | ws);
+    ScoreArgs<1> args{};
+    fill_motif_args(args.m[0], m, ws, slot, use_hist, select_cutoff, d_scores,
+                    reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
+                    reset ? nullptr : reinterpret_cast<unsigned long long *>(d_hit_count));
+    int rc = dispatch_score<1>(m->ndw, m, d_kmers, n, m->W, row_base, args, m->lds_bytes, nslabs, st, false);
     if (rc) return rc;
     if (split) {
         HIP_TRY(hipEventRecord(m->ev_scored[ws], st));
@@ -1165,6 +1235,105 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         m->posted_valid[ws] = true;
     } else {
         m->posted_valid[ws] = false;  // same stream: plain stream order already protects the workspace
+    }
+    return GFM_OK;
+}
+
+GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const uint8_t *d_kmers,
+                                  int64_t n, int32_t *const *d_scores, uint64_t *const *d_hist,
+                                  const int32_t *select_cutoffs, int64_t row_base,
+                                  int64_t *const *d_hit_rows, const int64_t *hit_capacity,
+                                  uint64_t *const *d_hit_count, uint32_t flags, void *stream)
+{
+    if (!motifs || n_motifs < 1 || !d_scores) return fail(GFM_ERR_INVALID, "NULL argument");
+    if (n < 0) return fail(GFM_ERR_INVALID, "negative row count");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool reset = (flags & GFM_FLAG_RESET_HITS) != 0;
+    for (int i = 0; i < n_motifs; ++i) {
+        if (!motifs[i]) return fail(GFM_ERR_INVALID, "motif %d is NULL", i);
+        if (motifs[i]->W != motifs[0]->W)
+            return fail(GFM_ERR_INVALID, "motifs of one batched launch must share their width (%d vs %d)",
+                        motifs[i]->W, motifs[0]->W);
+        for (int j = 0; j < i; ++j)
+            if (motifs[j] == motifs[i]) return fail(GFM_ERR_INVALID, "motif %d listed twice", i);
+        const bool sel = select_cutoffs && select_cutoffs[i] != GFM_NO_SELECT;
+        if (sel && (!d_hit_rows || !d_hit_rows[i] || !d_hit_count || !d_hit_count[i] || !hit_capacity))
+            return fail(GFM_ERR_INVALID, "selection requested for motif %d without hit buffers", i);
+        if (!d_scores[i]) return fail(GFM_ERR_INVALID, "d_scores[%d] is NULL", i);
+    }
+    if (n == 0) {
+        if (reset && d_hit_count)
+            for (int i = 0; i < n_motifs; ++i)
+                if (d_hit_count[i]) HIP_TRY(hipMemsetAsync(d_hit_count[i], 0, sizeof(uint64_t), st));
+        return GFM_OK;
+    }
+    if (!d_kmers) return fail(GFM_ERR_INVALID, "NULL device buffer");
+    if ((reinterpret_cast<uintptr_t>(d_kmers) & 15u) != 0)
+        return fail(GFM_ERR_INVALID, "d_kmers must be 16-byte aligned");
+    if (n > (int64_t)kChunk * 0x7fffff00ll)
+        return fail(GFM_ERR_INVALID, "too many rows for one launch (split the batch)");
+    const int W = motifs[0]->W, ndw = motifs[0]->ndw;
+    const long long nchunks = (n + kChunk - 1) / kChunk;
+    const long long want = (nchunks + kWavesPerWG - 1) / kWavesPerWG;
+
+    // greedy grouping: up to 3 motifs per launch while tables + strips + LDS windows fit
+    int i = 0;
+    while (i < n_motifs) {
+        int mm = 1, nb_lds[3] = {0, 0, 0};
+        auto lds_need = [&](int idx) {
+            gfm_motif *mo = motifs[idx];
+            const bool want_hist = d_hist && d_hist[idx];
+            return (want_hist && mo->lds_hist) ? mo->nb + 1 : 0;
+        };
+        nb_lds[0] = lds_need(i);
+        while (mm < 3 && i + mm < n_motifs) {
+            nb_lds[mm] = lds_need(i + mm);
+            if (score_lds_bytes(W, ndw, mm + 1, nb_lds) > (size_t)kMaxLdsBytes) { nb_lds[mm] = 0; break; }
+            ++mm;
+        }
+        const size_t lds = score_lds_bytes(W, ndw, mm, nb_lds);
+        int nslabs = (int)std::min<long long>(want, motifs[i]->max_slabs);
+        for (int k = 1; k < mm; ++k) nslabs = std::min(nslabs, motifs[i + k]->max_slabs);
+        int ws[3], slot[3], uh[3];
+        ScoreArgs<1> a1{};
+        ScoreArgs<2> a2{};
+        ScoreArgs<3> a3{};
+        for (int k = 0; k < mm; ++k) {
+            gfm_motif *mo = motifs[i + k];
+            const unsigned c = mo->call_no++;
+            ws[k] = (int)(c & 1u);
+            slot[k] = (int)(c % 3u);
+            mo->posted_valid[ws[k]] = false;   // single stream: stream order protects the workspace
+            uh[k] = (d_hist && d_hist[i + k]) ? (mo->lds_hist ? 1 : 2) : 0;
+            if (uh[k] == 2)
+                HIP_TRY(hipMemsetAsync(mo->d_partials[ws[k]], 0, sizeof(unsigned) * (size_t)(mo->nb + 1), st));
+            const int cut = select_cutoffs ? select_cutoffs[i + k] : GFM_NO_SELECT;
+            const bool sel = cut != GFM_NO_SELECT;
+            MotifArgs &dst = mm == 1 ? a1.m[k] : (mm == 2 ? a2.m[k] : a3.m[k]);
+            fill_motif_args(dst, mo, ws[k], slot[k], uh[k], cut, d_scores[i + k],
+                            sel ? reinterpret_cast<long long *>(d_hit_rows[i + k]) : nullptr,
+                            sel ? hit_capacity[i + k] : 0,
+                            (sel && !reset) ? reinterpret_cast<const unsigned long long *>(d_hit_count[i + k])
+                                            : nullptr);
+        }
+        int rc;
+        if (mm == 1) rc = dispatch_score<1>(ndw, motifs[i], d_kmers, n, W, row_base, a1, lds, nslabs, st, false);
+        else if (mm == 2) rc = dispatch_score<2>(ndw, motifs[i], d_kmers, n, W, row_base, a2, lds, nslabs, st, false);
+        else rc = dispatch_score<3>(ndw, motifs[i], d_kmers, n, W, row_base, a3, lds, nslabs, st, false);
+        if (rc) return rc;
+        for (int k = 0; k < mm; ++k) {
+            gfm_motif *mo = motifs[i + k];
+            const int cut = select_cutoffs ? select_cutoffs[i + k] : GFM_NO_SELECT;
+            const bool sel = cut != GFM_NO_SELECT;
+            rc = launch_post(mo, mo->d_partials[ws[k]], uh[k] == 2 ? 1 : nslabs,
+                             uh[k] ? reinterpret_cast<unsigned long long *>(d_hist[i + k]) : nullptr,
+                             mo->d_resid[ws[k]], mo->d_resid_n[ws[k]], sel ? nslabs : 0, mo->d_ctl, slot[k],
+                             sel ? reinterpret_cast<long long *>(d_hit_rows[i + k]) : nullptr,
+                             sel ? hit_capacity[i + k] : 0,
+                             sel ? reinterpret_cast<unsigned long long *>(d_hit_count[i + k]) : nullptr, st);
+            if (rc) return rc;
+        }
+        i += mm;
     }
     return GFM_OK;
 }

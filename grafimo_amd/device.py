@@ -174,6 +174,33 @@ class DeviceMotif:
         return out
 
 
+def score_multi(motifs, kmers, scores, hists=None, cutoffs=None, row_base=0, hit_rows=None,
+                hit_counts=None, stream=None, reset_hits=False):
+    """gfm_score_kmers_multi: several DeviceMotifs of one width over one k-mer matrix.
+    scores / hists / hit_rows / hit_counts: lists of torch tensors (entries may be None where the
+    scalar call allows it); cutoffs: list of ints or None."""
+    M = len(motifs)
+    n = int(kmers.shape[0])
+    vp = ctypes.c_void_p
+
+    def ptr_array(tensors):
+        if tensors is None:
+            return None
+        return (vp * M)(*[(t.data_ptr() if t is not None else None) for t in tensors])
+
+    handles = (vp * M)(*[m.handle for m in motifs])
+    cuts = None
+    if cutoffs is not None:
+        cuts = (ctypes.c_int32 * M)(*[nv.GFM_NO_SELECT if c is None else int(c) for c in cutoffs])
+    caps = None
+    if hit_rows is not None:
+        caps = (ctypes.c_int64 * M)(*[(int(t.numel()) if t is not None else 0) for t in hit_rows])
+    nv.check(nv.lib().gfm_score_kmers_multi(
+        handles, M, kmers.data_ptr() if n else None, n, ptr_array(scores), ptr_array(hists), cuts,
+        int(row_base), ptr_array(hit_rows), caps, ptr_array(hit_counts),
+        nv.GFM_FLAG_RESET_HITS if reset_hits else 0, _stream_ptr(stream)))
+
+
 def _stream_ptr(stream):
     if stream is None:
         torch = _torch()

@@ -199,3 +199,47 @@ class KmerScanner:
         if want_qvalues:
             out["qtable"] = slot.qtable.cpu().numpy()
         return out
+
+
+def scan_same_width(motifs, d_kmers, threshold: float, on_qvalue: bool = False,
+                    want_qvalues: bool = True, row_base: int = 0, hit_capacity: Optional[int] = None):
+    """Several motifs of ONE width over one device-resident k-mer matrix (BASELINE config 5): the
+    batched launch reads the k-mers once per group of up to three motifs; q-tables and selection
+    then run per motif.  Returns one dict per motif like KmerScanner.collect()."""
+    torch = _torch()
+    from .device import score_multi
+    n = int(d_kmers.shape[0])
+    dev = d_kmers.device
+    cap = int(hit_capacity) if hit_capacity is not None else n
+    scores = [torch.empty(n, dtype=torch.int32, device=dev) for _ in motifs]
+    hists = [torch.zeros(m.L, dtype=torch.int64, device=dev) for m in motifs] if want_qvalues else None
+    hits = [torch.zeros(cap + 1, dtype=torch.int64, device=dev) for _ in motifs]
+    qtabs = [torch.empty(m.L, dtype=torch.float64, device=dev) for m in motifs] if want_qvalues else None
+    cut_d = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in motifs]
+    nrows = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in motifs]
+    if not on_qvalue:
+        cuts = [m.pvalue_cutoff(threshold) for m in motifs]
+        score_multi(motifs, d_kmers, scores, hists=hists, cutoffs=cuts, row_base=row_base,
+                    hit_rows=[h[1:] for h in hits], hit_counts=[h[:1] for h in hits], reset_hits=True)
+    else:
+        score_multi(motifs, d_kmers, scores, hists=hists)
+    out = []
+    for j, m in enumerate(motifs):
+        if want_qvalues:
+            m.qvalue_table(hists[j], threshold, on_qvalue, qtabs[j], cut_d[j], nrows[j])
+        if on_qvalue:
+            m.select_hits(scores[j], cut_d[j], hits[j][1:], hits[j][:1], row_base=row_base, reset_hits=True)
+    torch.cuda.synchronize(dev)
+    for j, m in enumerate(motifs):
+        k = int(hits[j][0].item())
+        if k > cap:
+            raise OverflowError(f"{k} hits exceed the capacity {cap}")
+        packed = np.sort(hits[j][1:1 + k].cpu().numpy())
+        res = {"rows": packed >> HIT_SCORE_BITS,
+               "scaled": (packed & ((1 << HIT_SCORE_BITS) - 1)).astype(np.int32),
+               "n_scored": int(nrows[j].item()) if want_qvalues else None,
+               "scores": scores[j]}
+        if want_qvalues:
+            res["qtable"] = qtabs[j].cpu().numpy()
+        out.append(res)
+    return out

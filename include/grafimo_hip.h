@@ -125,6 +125,18 @@ int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, int32_t *d
                     int64_t *d_hit_rows, int64_t hit_capacity, uint64_t *d_hit_count,
                     uint32_t flags, void *stream, void *tail_stream);
 
+/* Batched form for motifs of ONE width (BASELINE config 5): the k-mer matrix is read once per
+ * group of up to three motifs (as many as fit the LDS: tables, per-motif histogram windows and hit
+ * queues), so per (k-mer, motif) pair the bytes moved drop from W + 4 to W/M + 4.  Arrays of
+ * n_motifs entries; d_hist / select_cutoffs / d_hit_* may be NULL (or hold NULL / GFM_NO_SELECT
+ * entries) exactly like the scalar arguments of gfm_score_kmers.  Results are identical to
+ * n_motifs separate gfm_score_kmers calls.  Single stream. */
+int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const uint8_t *d_kmers,
+                          int64_t n, int32_t *const *d_scores, uint64_t *const *d_hist,
+                          const int32_t *select_cutoffs, int64_t row_base,
+                          int64_t *const *d_hit_rows, const int64_t *hit_capacity,
+                          uint64_t *const *d_hit_count, uint32_t flags, void *stream);
+
 /* Measurement aid (bench.py): with slots > 0 every `every`-th later gfm_score_kmers call
  * brackets the score kernel ALONE (not the post kernel that follows it) with a hipEvent pair
  * on the launch stream, in a ring of `slots` pairs; slots = 0 turns it off.  (An event pair

@@ -395,3 +395,87 @@ def test_width_sweep_random_matrices(dev, W):
     lo, p = dm.annotate(exp[:100])
     assert np.array_equal(lo, exp[:100] / scale + W * offset) and np.array_equal(p, pt[exp[:100]])
     dm.close()
+
+
+def test_batched_same_width_motifs_share_one_read(dev, golden_motifs):
+    """gfm_score_kmers_multi (BASELINE config 5: several PWMs of one width, each with its own
+    background): scores, histograms and hit lists of every motif equal the single-motif launches
+    and the CPU restatement, for 1..5 motifs per call (groups of <= 3 share one pass)."""
+    from grafimo_amd.device import DeviceMotif, score_multi
+    from oracle import oracle as orc
+    rng = np.random.default_rng(505)
+    for W, n in [(19, 70_001), (8, 30_000), (25, 20_003)]:
+        motifs, mats = [], []
+        for k in range(5):
+            sm = rng.integers(0, 1001, size=(4, W)).astype(np.int64)
+            sm[rng.integers(0, 4), 0] = 0
+            sm[rng.integers(0, 4), W - 1] = 1000
+            bg = rng.dirichlet([30, 20, 20, 30])
+            mats.append((sm, bg))
+            motifs.append(DeviceMotif(sm, bg, int(sm.min()), 50 + k, -10.0 - k))
+        km = random_kmers(rng, n, W, n_frac=0.01)
+        d_k = torch.from_numpy(km).to(dev)
+        for M in (1, 2, 3, 5):
+            ms = motifs[:M]
+            scores = [torch.empty(n, dtype=torch.int32, device=dev) for _ in ms]
+            hists = [torch.zeros(m.L, dtype=torch.int64, device=dev) for m in ms]
+            hits = [torch.zeros(n + 1, dtype=torch.int64, device=dev) for _ in ms]
+            cuts = [m.pvalue_cutoff(0.02) for m in ms]
+            if M == 3:
+                cuts[1] = None                      # one motif without selection
+            score_multi(ms, d_k, scores, hists=hists, cutoffs=cuts, row_base=7,
+                        hit_rows=[h[1:] for h in hits], hit_counts=[h[:1] for h in hits], reset_hits=True)
+            torch.cuda.synchronize()
+            for j, m in enumerate(ms):
+                _, pt = m.tables()
+                exp, pv = orc.score_kmers_table(km, mats[j][0], pt, int(mats[j][0].min()))
+                assert np.array_equal(scores[j].cpu().numpy(), exp), (W, M, j)
+                assert np.array_equal(hists[j].cpu().numpy(), np.bincount(exp, minlength=m.L)), (W, M, j)
+                k = int(hits[j][0].item())
+                if cuts[j] is None:
+                    assert k == 0
+                    continue
+                got = np.sort(hits[j][1:1 + k].cpu().numpy())
+                rows = np.nonzero(exp >= cuts[j])[0]
+                assert np.array_equal(got >> 20, rows + 7) and np.array_equal(got & 0xFFFFF, exp[rows])
+        # a second batched call appends to the lists and accumulates the histograms
+        score_multi(motifs[:2], d_k, scores[:2], hists=hists[:2], cutoffs=[cuts[0], cuts[0]], row_base=n + 7,
+                    hit_rows=[h[1:] for h in hits[:2]], hit_counts=[h[:1] for h in hits[:2]])
+        torch.cuda.synchronize()
+        _, pt = motifs[0].tables()
+        exp, _ = orc.score_kmers_table(km, mats[0][0], pt, int(mats[0][0].min()))
+        assert np.array_equal(hists[0].cpu().numpy(), 2 * np.bincount(exp, minlength=motifs[0].L))
+        assert int(hits[0][0].item()) == 2 * int((exp >= cuts[0]).sum())
+        with pytest.raises(Exception):
+            score_multi([motifs[0], motifs[0]], d_k, scores[:2])           # same motif twice
+        for m in motifs:
+            m.close()
+    a = DeviceMotif(np.zeros((4, 5), np.int64) + 3, [0.25] * 4, 3, 10, -1.0)
+    b = DeviceMotif(np.zeros((4, 6), np.int64) + 3, [0.25] * 4, 3, 10, -1.0)
+    with pytest.raises(Exception):                                          # widths differ
+        score_multi([a, b], torch.zeros((16, 5), dtype=torch.uint8, device=dev),
+                    [torch.empty(16, dtype=torch.int32, device=dev)] * 2)
+
+
+def test_scan_same_width_equals_single_motif_scans(dev, golden_motifs):
+    from grafimo_amd import synth
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.scan import KmerScanner, scan_same_width
+    _, flat = golden_motifs
+    # three W=19 motifs with different backgrounds / matrices
+    keys = ["ctcf_meme_unif#0", "ctcf_meme_bgnt#0", "multi_meme_bg1#3", "ctcf_jaspar_bgnt_p1#0"]
+    gs = [flat[k] for k in keys]
+    assert all(g["width"] == 19 for g in gs)
+    dms = [DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"], g["pmf"]) for g in gs]
+    batch = synth.make_batch(40, 1000, 19, gs[0]["probs"], synth.seed_for(5))
+    d_k = torch.from_numpy(batch.kmers).to(dev)
+    for on_q, thr in [(False, 1e-3), (True, 0.3)]:
+        multi = scan_same_width(dms, d_k, thr, on_qvalue=on_q)
+        for dm, res in zip(dms, multi):
+            sc = KmerScanner(dm, len(batch), device=dev, side_stream=False)
+            one = sc.collect(sc.enqueue(d_k, thr, on_qvalue=on_q))
+            assert np.array_equal(res["rows"], one["rows"]) and np.array_equal(res["scaled"], one["scaled"])
+            assert np.array_equal(res["qtable"], one["qtable"]) and res["n_scored"] == one["n_scored"]
+        assert sum(len(r["rows"]) for r in multi) > 0
+    for dm in dms:
+        dm.close()
