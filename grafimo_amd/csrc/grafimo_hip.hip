@@ -166,8 +166,13 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
     constexpr int kTabBytes = 2 * NDW * 64 * 2;  // 2*NDW base pairs x (8 x 8 codes) x uint16
     constexpr int kLoads = (kChunk * 4 * NDW + 1023) / 1024;  // 16 B loads per lane per chunk
 
-    unsigned char *tab = smem;                       // MM table sets
-    unsigned char *stage_base = smem + MM * kTabBytes;
+    // MM == 1: uint16 pair tables.  MM > 1: ONE table of 64-bit entries packing the motifs' partial
+    // scores in 19-bit fields (a k-mer's score is <= 64000 < 2^19, so fields never carry) plus, in
+    // bits 57.., a count of invalid codes: one ds_read_b64 + one 64-bit add per base pair serves
+    // all motifs of the launch, so the inner loop costs the same for 1, 2 or 3 motifs.
+    constexpr int kTabRegion = (MM == 1 ? 1 : 4) * kTabBytes;
+    unsigned char *tab = smem;
+    unsigned char *stage_base = smem + kTabRegion;
     const int sstride = stage_stride_bytes(W, MM);
     unsigned *hist[MM];
     {
@@ -183,10 +188,24 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
 
+    if constexpr (MM == 1) {
+        for (int i = tid; i < kTabBytes / 2; i += kThreads)
+            reinterpret_cast<uint16_t *>(tab)[i] = a.m[0].tab[i];
+    } else {
+        for (int i = tid; i < kTabBytes / 2; i += kThreads) {
+            unsigned long long v = 0;
+            const unsigned t0 = a.m[0].tab[i];
+            if (t0 == kPoison) {
+                v = 1ull << 57;                       // same codes are invalid for every motif
+            } else {
+#pragma unroll
+                for (int m = 0; m < MM; ++m) v |= (unsigned long long)a.m[m].tab[i] << (19 * m);
+            }
+            reinterpret_cast<unsigned long long *>(tab)[i] = v;
+        }
+    }
 #pragma unroll
     for (int m = 0; m < MM; ++m) {
-        for (int i = tid; i < kTabBytes / 2; i += kThreads)
-            reinterpret_cast<uint16_t *>(tab + m * kTabBytes)[i] = a.m[m].tab[i];
         // use_hist: 0 = none, 1 = per-workgroup LDS window, 2 = the window does not fit the LDS
         // (very wide motifs): global atomics straight into slab 0 (zeroed by the host side)
         if (a.m[m].use_hist == 1)
@@ -261,27 +280,42 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
 #pragma unroll
             for (int d2 = 0; d2 <= NDW; ++d2) w[d2] = src[d2];
             int acc[MM];
+            bool any_n;
+            if constexpr (MM == 1) {
+                int s1 = 0;
 #pragma unroll
-            for (int m = 0; m < MM; ++m) acc[m] = 0;
-#pragma unroll
-            for (int d2 = 0; d2 < NDW; ++d2) {
-                const unsigned x = __builtin_amdgcn_alignbit(w[d2 + 1], w[d2], sh);
-                const unsigned xm = x & 0x0E0E0E0Eu;   // 2 * ((c >> 1) & 7) per byte
-                const unsigned y = xm | (xm >> 5);     // bytes 0 and 2: 2*(code_lo + 8*code_hi)
-                const unsigned e0 = y & 0x7Eu;
-                const unsigned e1 = (y >> 16) & 0x7Eu;
-#pragma unroll
-                for (int m = 0; m < MM; ++m) {
-                    const unsigned char *t = tab + m * kTabBytes;
-                    acc[m] += *reinterpret_cast<const uint16_t *>(t + (2 * d2) * 128 + e0);
-                    acc[m] += *reinterpret_cast<const uint16_t *>(t + (2 * d2 + 1) * 128 + e1);
+                for (int d2 = 0; d2 < NDW; ++d2) {
+                    const unsigned x = __builtin_amdgcn_alignbit(w[d2 + 1], w[d2], sh);
+                    const unsigned xm = x & 0x0E0E0E0Eu;   // 2 * ((c >> 1) & 7) per byte
+                    const unsigned y = xm | (xm >> 5);     // bytes 0 and 2: 2*(code_lo + 8*code_hi)
+                    const unsigned e0 = y & 0x7Eu;
+                    const unsigned e1 = (y >> 16) & 0x7Eu;
+                    s1 += *reinterpret_cast<const uint16_t *>(tab + (2 * d2) * 128 + e0);
+                    s1 += *reinterpret_cast<const uint16_t *>(tab + (2 * d2 + 1) * 128 + e1);
                 }
+                any_n = (unsigned)s1 >= kPoison;
+                acc[0] = s1;
+            } else {
+                unsigned long long s64 = 0;
+#pragma unroll
+                for (int d2 = 0; d2 < NDW; ++d2) {
+                    const unsigned x = __builtin_amdgcn_alignbit(w[d2 + 1], w[d2], sh);
+                    const unsigned xm = x & 0x0E0E0E0Eu;
+                    const unsigned y = xm | (xm >> 5);
+                    const unsigned e0 = (y & 0x7Eu) << 2;            // 8-byte entries
+                    const unsigned e1 = ((y >> 16) & 0x7Eu) << 2;
+                    s64 += *reinterpret_cast<const unsigned long long *>(tab + (2 * d2) * 512 + e0);
+                    s64 += *reinterpret_cast<const unsigned long long *>(tab + (2 * d2 + 1) * 512 + e1);
+                }
+                any_n = (s64 >> 57) != 0;
+#pragma unroll
+                for (int m = 0; m < MM; ++m) acc[m] = (int)((s64 >> (19 * m)) & 0x7FFFFull);
             }
             const bool live = row < n;
 #pragma unroll
             for (int m = 0; m < MM; ++m) {
                 const MotifArgs &ma = a.m[m];
-                const bool is_n = (unsigned)acc[m] >= kPoison;
+                const bool is_n = any_n;
                 const int score = is_n ? ma.min_val : acc[m];
                 if (live) {
                     ma.scores[row] = score;
@@ -800,7 +834,8 @@ int run_dp(const int64_t *sm, int W, const double *bg, double *d_pmf, hipStream_
 // LDS histogram windows of the motifs that use one
 size_t score_lds_bytes(int W, int ndw, int mm, const int *nb_lds /* nb+1 or 0 per motif */)
 {
-    size_t b = (size_t)mm * (2 * ndw * 64 * 2) + (size_t)kWavesPerWG * stage_stride_bytes(W, mm);
+    // one motif: uint16 pair tables; 2-3 motifs: ONE table of packed 64-bit entries (4x the bytes)
+    size_t b = (size_t)(mm == 1 ? 1 : 4) * (2 * ndw * 64 * 2) + (size_t)kWavesPerWG * stage_stride_bytes(W, mm);
     for (int i = 0; i < mm; ++i) b += sizeof(unsigned) * (size_t)nb_lds[i];
     return b;
 }
