@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--qvalue-threshold", action="store_true", help="--qvalueT: threshold on q")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slots", type=int, default=2, help="buffer slots of the scan pipeline")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="diagnostic: initialise torch.distributed and issue the collectives even with "
+                         "one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--gather-group", action="store_true",
                     help="N > 1: run the hit gather on a second RCCL communicator and stream")
     ap.add_argument("--event-every", type=int, default=8,
@@ -128,11 +131,13 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    if world > 1:
+    if use_dist:
         # RCCL's kernels need CUs of their own next to the persistent score grid: leave 16 free
         # (the score kernel is HBM-bound; 240 CUs move the same bytes, measured -1 %)
         os.environ.setdefault("GRAFIMO_RESERVE_CUS", "16")
@@ -142,18 +147,19 @@ def main():
     # optional: hits on their own communicator so that gather(k) overlaps all-reduce(k+1).  Off by
     # default: two communicators whose kernels become ready in different orders on different ranks
     # are a classic deadlock hazard, and this path cannot be exercised on the 1-GPU test boxes.
-    gather_group = dist.new_group(backend="nccl") if (world > 1 and args.gather_group) else None
+    gather_group = dist.new_group(backend="nccl") if (use_dist and args.gather_group) else None
     scanner = KmerScanner(dm, n, hit_capacity=hit_cap, device=dev, gather_group=gather_group,
-                          group=None, side_stream=args.overlap != "off", n_slots=args.slots)
+                          group=None, side_stream=args.overlap != "off", n_slots=args.slots,
+                          always_collective=args.force_dist)
 
     def step():
         return scanner.enqueue(d_kmers, args.threshold, on_qvalue=args.qvalue_threshold,
-                               want_qvalues=True, row_base=rank * n, gather_hits=world > 1)
+                               want_qvalues=True, row_base=rank * n, gather_hits=use_dist)
 
     def fence():
         scanner.finish()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -178,7 +184,7 @@ def main():
     assert res["n_scored"] == n * world, (res["n_scored"], n, world)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -234,7 +240,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
