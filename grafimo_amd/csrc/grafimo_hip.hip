@@ -49,6 +49,17 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
+// device allocation that frees itself (error paths of the host-side helpers)
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(&p, sizeof(T) * count); }
+    operator T *() const { return p; }
+};
+
 // ---------------------------------------------------------------------------------------
 // score kernel geometry
 constexpr int kWave = 64;
@@ -807,26 +818,21 @@ int run_dp(const int64_t *sm, int W, const double *bg, double *d_pmf, hipStream_
     std::vector<int> lo, hi, sm32(4 * W);
     cumulative_windows(sm, W, lo, hi);
     for (int i = 0; i < 4 * W; ++i) sm32[i] = (int)sm[i];
-    int *d_sm = nullptr, *d_lo = nullptr, *d_hi = nullptr;
-    double *d_bg = nullptr, *d_buf = nullptr;
-    HIP_TRY(hipMalloc(&d_sm, sizeof(int) * 4 * W));
-    HIP_TRY(hipMalloc(&d_lo, sizeof(int) * W));
-    HIP_TRY(hipMalloc(&d_hi, sizeof(int) * W));
-    HIP_TRY(hipMalloc(&d_bg, sizeof(double) * 4));
-    HIP_TRY(hipMalloc(&d_buf, sizeof(double) * 2 * (size_t)L));
+    DevBuf<int> d_sm, d_lo, d_hi;
+    DevBuf<double> d_bg, d_buf;
+    HIP_TRY(d_sm.alloc(4 * (size_t)W));
+    HIP_TRY(d_lo.alloc(W));
+    HIP_TRY(d_hi.alloc(W));
+    HIP_TRY(d_bg.alloc(4));
+    HIP_TRY(d_buf.alloc(2 * (size_t)L));
     HIP_TRY(hipMemcpyAsync(d_sm, sm32.data(), sizeof(int) * 4 * W, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_lo, lo.data(), sizeof(int) * W, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_hi, hi.data(), sizeof(int) * W, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_bg, bg, sizeof(double) * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(pvalue_dp_kernel, dim3(1), dim3(kDpThreads), 0, st, d_sm, d_bg, W, L, d_lo,
-                       d_hi, d_buf, d_pmf);
+    hipLaunchKernelGGL(pvalue_dp_kernel, dim3(1), dim3(kDpThreads), 0, st, d_sm.p, d_bg.p, W, L, d_lo.p,
+                       d_hi.p, d_buf.p, d_pmf);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-    (void)hipFree(d_sm);
-    (void)hipFree(d_lo);
-    (void)hipFree(d_hi);
-    (void)hipFree(d_bg);
-    (void)hipFree(d_buf);
+    HIP_TRY(hipStreamSynchronize(st));   // the temporaries are freed on return
     return GFM_OK;
 }
 
@@ -1005,15 +1011,12 @@ GFM_API int gfm_comp_pval_mat(const int64_t *sm, int W, const double *bg, double
     rc = ensure_device();
     if (rc) return rc;
     const int L = kRange * W + 1;
-    double *d_pmf = nullptr;
-    HIP_TRY(hipMalloc(&d_pmf, sizeof(double) * (size_t)L));
+    DevBuf<double> d_pmf;
+    HIP_TRY(d_pmf.alloc((size_t)L));
     rc = run_dp(sm, W, bg, d_pmf, nullptr);
-    if (rc == GFM_OK) {
-        hipError_t e = hipMemcpy(h_pmf, d_pmf, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(GFM_ERR_HIP, "D2H of pmf failed: %s", hipGetErrorString(e));
-    }
-    (void)hipFree(d_pmf);
-    return rc;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(h_pmf, d_pmf, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
+    return GFM_OK;
 }
 
 GFM_API void gfm_motif_destroy(gfm_motif_t m)

@@ -479,3 +479,46 @@ def test_scan_same_width_equals_single_motif_scans(dev, golden_motifs):
         assert sum(len(r["rows"]) for r in multi) > 0
     for dm in dms:
         dm.close()
+
+
+def test_single_stream_path_is_graph_capturable(dev, golden_motifs):
+    """include/grafimo_hip.h promises that the stream-taking entry points only enqueue (no
+    allocation, no synchronisation): capture two steps (both workspace parities) into a HIP graph,
+    replay, compare with the eager results."""
+    from grafimo_amd import synth
+    from grafimo_amd.device import DeviceMotif
+    _, flat = golden_motifs
+    g = flat["ctcf_meme_unif#0"]
+    dm = DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"], g["pmf"])
+    batch = synth.make_batch(100, 1000, 19, g["probs"], synth.seed_for(2))
+    n = len(batch)
+    d = torch.from_numpy(batch.kmers).to(dev)
+    sc = torch.empty(n, dtype=torch.int32, device=dev)
+    hist = torch.zeros(dm.L, dtype=torch.int64, device=dev)
+    hits = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    q = torch.empty(dm.L, dtype=torch.float64, device=dev)
+    cut = torch.zeros(1, dtype=torch.int32, device=dev)
+    nr = torch.zeros(1, dtype=torch.int64, device=dev)
+    c = dm.pvalue_cutoff(1e-3)
+
+    def step():
+        dm.score(d, sc, hist=hist, select_cutoff=c, hit_rows=hits[1:], hit_count=hits[:1], reset_hits=True)
+        dm.qvalue_table(hist, 1e-3, False, q, cut, nr, clear_hist=True)
+
+    step(); step()
+    torch.cuda.synchronize()
+    ref = (sc.clone(), hits.clone().sort().values, q.clone(), int(nr))
+    graph = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        step(); step()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=s):
+            step(); step()
+    sc.zero_(); hits.zero_(); q.zero_()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(sc, ref[0]) and torch.equal(hits.sort().values, ref[1])
+    assert torch.equal(q, ref[2]) and int(nr) == ref[3] == n
+    dm.close()

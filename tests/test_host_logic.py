@@ -181,3 +181,40 @@ def test_compute_results_argument_errors(tmp_path):
     with pytest.raises(ValueError) as e:
         compute_results(m, str(tmp_path), True, Findmotif())
     assert "No result retrieved" in str(e.value)
+
+
+def test_tsv_ingest_property_random_rows(tmp_path):
+    """Randomised rows (hypothesis): the C++ ingest and the Python restatement of the reference's
+    row handling agree on every column, for any mix of strands, ref flags, widths and spacing."""
+    from hypothesis import given, settings, strategies as st
+
+    row = st.tuples(
+        st.text(alphabet="ACGTNacgt", min_size=7, max_size=7),
+        st.integers(0, 10**9), st.integers(-30, 30), st.sampled_from("+-"), st.integers(0, 6000),
+        st.sampled_from(["ref", "non.ref"]), st.sampled_from(["\t", "  ", " \t "]),
+        st.sampled_from(["chr1:5-90", "22:100-300", "x:0-20"]))
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.lists(row, min_size=0, max_size=30), st.booleans())
+    def check(rows, skip_rev):
+        d = tmp_path / "width_7"
+        d.mkdir(exist_ok=True)
+        f = d / "r.tsv"
+        with open(f, "w") as fh:
+            for seq, start, delta, strand, freq, ref, sep, region in rows:
+                chrom = region.split(":")[0]
+                stop = start + delta
+                fh.write(sep.join([region, seq, f"{chrom}:{start}{strand}", f"{chrom}:{stop}{strand}",
+                                   str(freq), ref, f"1{strand},2{strand},"]) + "\n")
+        t = KmerTable([str(f)], 7, skip_rev, 1)
+        cols = orc.parse_tsv_rows([str(f)], no_reverse=skip_rev)
+        assert t.n == len(cols["seq"])
+        assert [bytes(k).decode() for k in t.kmers] == cols["seq"]
+        assert list(t.start) == cols["start"] and list(t.stop) == cols["stop"]
+        assert [chr(c) for c in t.strand] == cols["strand"] and list(t.freq) == cols["freq"]
+        exp_ref = [int(r == "ref" and abs(b - a) == 7)
+                   for r, a, b in zip(cols["ref"], cols["start"], cols["stop"])]
+        assert list(t.is_ref) == exp_ref
+        assert [t.names[i] for i in t.name_id] == cols["seqname"]
+
+    check()
