@@ -525,29 +525,43 @@ constexpr int kScanThreads = 1024;
 
 // p_table[s] = (sum_{t>=s} pmf[t]) / (sum_t pmf[t])   -- O(1) form of
 // `pval_mat[score:].sum() / pval_mat.sum()` (score_sequences.py:390-391).
-// The suffix sums are ONE sequential top-down chain over the reachable window (one lane,
-// <= 64k dependent f64 adds, once per motif): that makes the table exactly monotone and
-// p_table[s] == 1.0 exactly for every s at or below the lowest reachable score, which a
-// blocked scan's mixed association orders would not guarantee.  The division runs in parallel.
+// Blocked suffix sum that stays EXACTLY monotone: thread t sums its contiguous segment top-down
+// (local running sums L_j), one lane chains the 1024 segment totals top-down (carry c_t), and
+// suffix[j] = c_t + L_j.  fl(c + L) is monotone in L, and at a segment's bottom c_t + L = c_t + s_t
+// is the very operation that produced the carry of the segment below, so no boundary can step
+// the wrong way; p_table[s] == 1.0 exactly for every s at or below the lowest reachable score.
+// (A scan with mixed association orders broke monotonicity by 1 ulp; a fully sequential chain
+// took 0.5 ms.)
 __global__ void __launch_bounds__(kScanThreads)
 ptable_kernel(const double *__restrict__ pmf, int L, int lo, int hi, double *__restrict__ ptable)
 {
+    __shared__ double carry[kScanThreads];
     __shared__ double tot_s;
     const int tid = threadIdx.x;
+    const int nb = hi - lo + 1;
+    const int per = (nb + kScanThreads - 1) / kScanThreads;
+    const int a = lo + min(tid * per, nb), b = lo + min(tid * per + per, nb);
+    double run = 0.0;
+    for (int j = b - 1; j >= a; --j) {
+        run += pmf[j];
+        ptable[j] = run;        // local running sum, finished below
+    }
+    carry[tid] = run;
+    __syncthreads();
     if (tid == 0) {
-        double run = 0.0;
-        for (int j = hi; j >= lo; --j) {
-            run += pmf[j];
-            ptable[j] = run;
+        double c = 0.0;
+        for (int t = kScanThreads - 1; t >= 0; --t) {
+            const double s = carry[t];
+            carry[t] = c;       // everything above segment t
+            c = c + s;
         }
-        tot_s = run;
+        tot_s = c;
     }
     __syncthreads();
-    const double tot = tot_s;
-    for (int j = tid; j < L; j += kScanThreads) {
-        const double suffix = j < lo ? tot : (j > hi ? 0.0 : ptable[j]);
-        ptable[j] = suffix / tot;
-    }
+    const double c = carry[tid], tot = tot_s;
+    for (int j = a; j < b; ++j) ptable[j] = (c + ptable[j]) / tot;
+    for (int j = tid; j < lo; j += kScanThreads) ptable[j] = tot / tot;
+    for (int j = hi + 1 + tid; j < L; j += kScanThreads) ptable[j] = 0.0;
 }
 
 // q-value of every score from the histogram (Benjamini-Hochberg as statsmodels'
