@@ -147,14 +147,18 @@ __device__ inline void hitq_finish(const long long *hitq, int qn, int *wq_n /* s
 // (score_sequences.py:376-378).  A position >= W contributes 0 whatever its byte, so the tail
 // of the last dword needs no masking.  Scores go out as coalesced int32; the score histogram
 // is built with LDS atomics in a per-workgroup window [lo, lo+nb) (+1 bin for N rows)
-// and flushed once per workgroup as a plain-store slab (no global atomics).
+// and flushed once per workgroup as a plain-store slab (no global atomics).  Wide motifs whose
+// whole score range does not fit next to the strips keep the window over the densest part of the
+// background score distribution; the few rows outside it go to a global spill array.
 // MM motifs of the same width can share ONE read of the k-mers (BASELINE config 5: per
 // (k-mer, motif) pair the algorithmic bytes drop from W + 4 to W/MM + 4): the staged strip is
 // scored against MM table sets, each motif has its own histogram window, hit queue and outputs.
 struct MotifArgs {
     const uint16_t *tab;      // [2*NDW][64] pair tables (global)
-    int lo, nb, min_val;
-    int use_hist;             // 0 none, 1 LDS window -> slab, 2 global atomics into slab 0
+    int lo, nb, min_val;      // LDS histogram window [lo, lo+nb) (+ the N bin at nb)
+    int use_hist;             // 0 none, 1 LDS window -> slab (+ spill outside the window)
+    int spill_lo;             // first score of the motif's full range
+    unsigned *spill;          // [full range] counters of rows outside the window (post re-zeroes)
     int cutoff;               // rows with score >= cutoff are hits; GFM_NO_SELECT: none
     int slot;                 // HitCtl slot of this call
     int *scores;
@@ -191,7 +195,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
 #pragma unroll
         for (int m = 0; m < MM; ++m) {
             hist[m] = h;
-            if (a.m[m].use_hist == 1) h += a.m[m].nb + 1;
+            if (a.m[m].use_hist) h += a.m[m].nb + 1;
         }
     }
 
@@ -217,9 +221,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
     }
 #pragma unroll
     for (int m = 0; m < MM; ++m) {
-        // use_hist: 0 = none, 1 = per-workgroup LDS window, 2 = the window does not fit the LDS
-        // (very wide motifs): global atomics straight into slab 0 (zeroed by the host side)
-        if (a.m[m].use_hist == 1)
+        if (a.m[m].use_hist)
             for (int i = tid; i <= a.m[m].nb; i += kThreads) hist[m][i] = 0u;
     }
     __syncthreads();
@@ -334,8 +336,13 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
                 const int score = is_n ? ma.min_val : acc[m];
                 if (live) {
                     __builtin_nontemporal_store(score, ma.scores + row);   // written once, read later
-                    if (ma.use_hist == 1) atomicAdd(&hist[m][is_n ? ma.nb : score - ma.lo], 1u);
-                    else if (ma.use_hist == 2) atomicAdd(&ma.partials[is_n ? ma.nb : score - ma.lo], 1u);
+                    if (ma.use_hist) {
+                        const unsigned off = (unsigned)(score - ma.lo);
+                        if (is_n || off < (unsigned)ma.nb)
+                            atomicAdd(&hist[m][is_n ? (unsigned)ma.nb : off], 1u);
+                        else
+                            atomicAdd(&ma.spill[score - ma.spill_lo], 1u);   // outside the window: rare
+                    }
                 }
                 if (ma.cutoff != GFM_NO_SELECT)
                     hitq_push(hitq[m], qn[m], live && score >= ma.cutoff,
@@ -359,7 +366,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
         if (ma.cutoff != GFM_NO_SELECT)
             hitq_finish<kWavesPerWG>(hitq[m], qn[m], reinterpret_cast<int *>(tab + m * kTabBytes), wave,
                                      lane, tid, ma.resid, ma.resid_n);
-        if (ma.use_hist == 1) {
+        if (ma.use_hist) {
             unsigned *slab = ma.partials + (size_t)blockIdx.x * (size_t)(ma.nb + 1);
             for (int i = tid; i <= ma.nb; i += kThreads) slab[i] = hist[m][i];
         }
@@ -371,13 +378,16 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
 //    histogram (bin lo+b; the extra slab bin counts N rows, which score min_val).  A block owns
 //    256 bins x kSlabsPerGroup slabs: enough blocks to pull the slabs at L2/HBM rate instead of
 //    one latency-bound column walk per bin.
-//  blocks [hist_blocks, hist_blocks + hit_slabs): append residual hit slab g to the dense list at
+//  blocks [hist_blocks, hist_blocks + spill_blocks): add the spill counters (rows outside a partial
+//    LDS window) and hand them back zeroed.
+//  the remaining hit_slabs blocks: append residual hit slab g to the dense list at
 //    snap + mid + (counts of slabs < g); the first of them publishes the new *hit_count and
 //    zeroes the mid-run counter two calls ahead.
 constexpr int kSlabsPerGroup = 16;
 __global__ void __launch_bounds__(256)
 post_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, int min_val,
             unsigned long long *__restrict__ hist64, int bin_blocks, int hist_blocks,
+            unsigned *__restrict__ spill, int spill_lo, int spill_n, int spill_blocks,
             const long long *__restrict__ resid, const int *__restrict__ resid_n, int hit_slabs,
             HitCtl *__restrict__ ctl, int par, long long *__restrict__ hit_rows, long long hit_cap,
             unsigned long long *__restrict__ hit_count)
@@ -396,9 +406,20 @@ post_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, i
         if (s) atomicAdd(&hist64[b == nb ? min_val : lo + b], s);
         return;
     }
+    if ((int)blockIdx.x < hist_blocks + spill_blocks) {
+        const int b = ((int)blockIdx.x - hist_blocks) * 256 + tid;
+        if (b < spill_n) {
+            const unsigned v = spill[b];
+            if (v) {
+                atomicAdd(&hist64[spill_lo + b], (unsigned long long)v);
+                spill[b] = 0u;
+            }
+        }
+        return;
+    }
     __shared__ int part[256];
     __shared__ int part_all[256];
-    const int g = blockIdx.x - hist_blocks;
+    const int g = blockIdx.x - hist_blocks - spill_blocks;
     int s = 0, sa = 0;
     for (int k = tid; k < hit_slabs; k += 256) {
         const int v = resid_n[k];
@@ -748,13 +769,13 @@ q_final_kernel(const unsigned long long *hist, const double *__restrict__ ptable
 struct gfm_motif {
     int W = 0, L = 0, min_val = 0, scale = 1, ndw = 0;
     double offset = 0.0;
-    int lo = 0, hi = 0, nb = 0;
+    int lo = 0, hi = 0, nb = 0;      // reachable score range [lo, hi], nb bins
+    int hlo = 0, hnb = 0;            // LDS histogram window of the score kernel (== lo, nb when it fits)
     int device = 0;
     int n_cu = 256;
     int max_slabs = 0;
     int sel_slabs = 0;
     int reserve_cus = kReserveCUs;  // GRAFIMO_RESERVE_CUS overrides
-    bool lds_hist = true;
     size_t lds_bytes = 0;
     std::vector<int64_t> sm;
     double bg[4] = {0, 0, 0, 0};
@@ -764,7 +785,8 @@ struct gfm_motif {
     double *d_ptable = nullptr;
     // Scoring workspace, double-buffered by call parity so that the post kernel of call k (on a
     // tail stream) may run while the score kernel of call k+1 fills the other set.
-    unsigned *d_partials[2] = {nullptr, nullptr};   // [max_slabs][nb+1] histogram slabs
+    unsigned *d_partials[2] = {nullptr, nullptr};   // [max_slabs][hnb+1] histogram slabs
+    unsigned *d_spill[2] = {nullptr, nullptr};      // [nb] rows outside a partial window (else null)
     long long *d_resid[2] = {nullptr, nullptr};     // [max_slabs][kResidPerWG] residual hits
     int *d_resid_n[2] = {nullptr, nullptr};         // [max_slabs]
     QWork *d_qwork = nullptr;        // q-value kernels' block totals / minima
@@ -905,17 +927,18 @@ int dispatch_score(int ndw, gfm_motif *timer, const uint8_t *d_kmers, long long 
 
 // one launch after a scoring / selection kernel: histogram slabs -> hist64, hit slabs -> list
 int launch_post(gfm_motif *m, const unsigned *partials, int hist_slabs, unsigned long long *d_hist,
-                const long long *resid, const int *resid_n, int hit_slabs, HitCtl *ctl, int ctl_slot,
+                unsigned *spill, const long long *resid, const int *resid_n, int hit_slabs, HitCtl *ctl, int ctl_slot,
                 long long *d_hit_rows, long long cap, unsigned long long *d_hit_count, hipStream_t st)
 {
-    const int bin_blocks = (m->nb + 1 + 255) / 256;
+    const int bin_blocks = (m->hnb + 1 + 255) / 256;
     const int groups = (hist_slabs + kSlabsPerGroup - 1) / kSlabsPerGroup;
     const int hist_blocks = d_hist ? bin_blocks * groups : 0;
-    const int total = hist_blocks + hit_slabs;
+    const int spill_blocks = (d_hist && spill) ? (m->nb + 255) / 256 : 0;
+    const int total = hist_blocks + spill_blocks + hit_slabs;
     if (total == 0) return GFM_OK;
-    hipLaunchKernelGGL(post_kernel, dim3(total), dim3(256), 0, st, partials, hist_slabs, m->nb, m->lo,
-                       m->min_val, d_hist, bin_blocks, hist_blocks, resid, resid_n, hit_slabs, ctl,
-                       ctl_slot, d_hit_rows, cap, d_hit_count);
+    hipLaunchKernelGGL(post_kernel, dim3(total), dim3(256), 0, st, partials, hist_slabs, m->hnb, m->hlo,
+                       m->min_val, d_hist, bin_blocks, hist_blocks, spill, m->lo, m->nb, spill_blocks,
+                       resid, resid_n, hit_slabs, ctl, ctl_slot, d_hit_rows, cap, d_hit_count);
     HIP_TRY(hipGetLastError());
     return GFM_OK;
 }
@@ -925,10 +948,12 @@ void fill_motif_args(MotifArgs &a, gfm_motif *m, int ws, int slot, int use_hist,
                      const unsigned long long *d_hit_count_or_null)
 {
     a.tab = m->d_tab;
-    a.lo = m->lo;
-    a.nb = m->nb;
+    a.lo = m->hlo;
+    a.nb = m->hnb;
     a.min_val = m->min_val;
     a.use_hist = use_hist;
+    a.spill_lo = m->lo;
+    a.spill = m->d_spill[ws];
     a.cutoff = cutoff;
     a.slot = slot;
     a.scores = d_scores;
@@ -1045,6 +1070,7 @@ GFM_API void gfm_motif_destroy(gfm_motif_t m)
     if (m->d_ptable) (void)hipFree(m->d_ptable);
     for (int i = 0; i < 2; ++i) {
         if (m->d_partials[i]) (void)hipFree(m->d_partials[i]);
+        if (m->d_spill[i]) (void)hipFree(m->d_spill[i]);
         if (m->d_resid[i]) (void)hipFree(m->d_resid[i]);
         if (m->d_resid_n[i]) (void)hipFree(m->d_resid_n[i]);
         if (m->ev_scored[i]) (void)hipEventDestroy(m->ev_scored[i]);
@@ -1143,14 +1169,30 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     // score-kernel LDS plan: table | 8 wave strips | histogram window (+1 N bin)
     const int zero_nb = 0;
     const size_t fixed = score_lds_bytes(W, m->ndw, 1, &zero_nb);
-    const size_t with_hist = fixed + sizeof(unsigned) * (size_t)(m->nb + 1);
-    m->lds_hist = with_hist <= (size_t)kMaxLdsBytes;
-    m->lds_bytes = m->lds_hist ? with_hist : fixed;
+    const long long room = ((long long)kMaxLdsBytes - (long long)fixed) / (long long)sizeof(unsigned) - 1;
+    if (room < 256) return bail(fail(GFM_ERR_INVALID, "no LDS left for a histogram window at width %d", W));
+    m->hnb = (int)std::min<long long>(m->nb, room);
+    m->hlo = m->lo;
+    if (m->hnb < m->nb) {
+        // partial window: the hnb consecutive scores that hold the most background probability
+        // (P(s >= a) - P(s >= a + hnb) from the tail table); the rest spills to global counters
+        double best = -1.0;
+        for (int a = m->lo; a + m->hnb - 1 <= m->hi; ++a) {
+            const int e = a + m->hnb;
+            const double mass = m->h_ptable[a] - (e < m->L ? m->h_ptable[e] : 0.0);
+            if (mass > best) { best = mass; m->hlo = a; }
+        }
+    }
+    m->lds_bytes = fixed + sizeof(unsigned) * (size_t)(m->hnb + 1);
     int per_cu = (int)std::min<size_t>(kWGsPerCU, (size_t)kMaxLdsBytes / m->lds_bytes);
     per_cu = std::max(per_cu, 1);
     m->max_slabs = m->n_cu * per_cu;
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY_M(hipMalloc(&m->d_partials[i], sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->nb + 1)));
+        HIP_TRY_M(hipMalloc(&m->d_partials[i], sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->hnb + 1)));
+        if (m->hnb < m->nb) {
+            HIP_TRY_M(hipMalloc(&m->d_spill[i], sizeof(unsigned) * (size_t)m->nb));
+            HIP_TRY_M(hipMemset(m->d_spill[i], 0, sizeof(unsigned) * (size_t)m->nb));
+        }
         HIP_TRY_M(hipMalloc(&m->d_resid[i], sizeof(long long) * (size_t)m->max_slabs * kResidPerWG));
         HIP_TRY_M(hipMalloc(&m->d_resid_n[i], sizeof(int) * (size_t)m->max_slabs));
         HIP_TRY_M(hipEventCreateWithFlags(&m->ev_scored[i], hipEventDisableTiming | hipEventReleaseToDevice));
@@ -1252,7 +1294,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     const bool select = select_cutoff != GFM_NO_SELECT;
     if (select && (!d_hit_rows || !d_hit_count))
         return fail(GFM_ERR_INVALID, "selection requested without hit buffers");
-    const int use_hist = d_hist ? (m->lds_hist ? 1 : 2) : 0;
+    const int use_hist = d_hist ? 1 : 0;
     const long long nchunks = (n + kChunk - 1) / kChunk;
     const long long want = (nchunks + kWavesPerWG - 1) / kWavesPerWG;
     // with a tail stream a few CUs are left free so that its kernels (post, q-table, RCCL) find
@@ -1269,8 +1311,6 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws], 0));
     if (split && select && !reset && m->posted_valid[ws ^ 1])
         HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws ^ 1], 0));
-    if (use_hist == 2)
-        HIP_TRY(hipMemsetAsync(m->d_partials[ws], 0, sizeof(unsigned) * (size_t)(m->nb + 1), st));
     ScoreArgs<1> args{};
     fill_motif_args(args.m[0], m, ws, slot, use_hist, select_cutoff, d_scores,
                     reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
@@ -1281,8 +1321,8 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         HIP_TRY(hipEventRecord(m->ev_scored[ws], st));
         HIP_TRY(hipStreamWaitEvent(tail, m->ev_scored[ws], 0));
     }
-    rc = launch_post(m, m->d_partials[ws], use_hist == 2 ? 1 : nslabs, reinterpret_cast<unsigned long long *>(d_hist),
-                     m->d_resid[ws], m->d_resid_n[ws], select ? nslabs : 0, m->d_ctl, slot,
+    rc = launch_post(m, m->d_partials[ws], nslabs, reinterpret_cast<unsigned long long *>(d_hist),
+                     m->d_spill[ws], m->d_resid[ws], m->d_resid_n[ws], select ? nslabs : 0, m->d_ctl, slot,
                      reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                      reinterpret_cast<unsigned long long *>(d_hit_count), tail);
     if (rc) return rc;
@@ -1339,7 +1379,7 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
         auto lds_need = [&](int idx) {
             gfm_motif *mo = motifs[idx];
             const bool want_hist = d_hist && d_hist[idx];
-            return (want_hist && mo->lds_hist) ? mo->nb + 1 : 0;
+            return want_hist ? mo->hnb + 1 : 0;
         };
         nb_lds[0] = lds_need(i);
         while (mm < 3 && i + mm < n_motifs) {
@@ -1360,9 +1400,7 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
             ws[k] = (int)(c & 1u);
             slot[k] = (int)(c % 3u);
             mo->posted_valid[ws[k]] = false;   // single stream: stream order protects the workspace
-            uh[k] = (d_hist && d_hist[i + k]) ? (mo->lds_hist ? 1 : 2) : 0;
-            if (uh[k] == 2)
-                HIP_TRY(hipMemsetAsync(mo->d_partials[ws[k]], 0, sizeof(unsigned) * (size_t)(mo->nb + 1), st));
+            uh[k] = (d_hist && d_hist[i + k]) ? 1 : 0;
             const int cut = select_cutoffs ? select_cutoffs[i + k] : GFM_NO_SELECT;
             const bool sel = cut != GFM_NO_SELECT;
             MotifArgs &dst = mm == 1 ? a1.m[k] : (mm == 2 ? a2.m[k] : a3.m[k]);
@@ -1381,9 +1419,9 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
             gfm_motif *mo = motifs[i + k];
             const int cut = select_cutoffs ? select_cutoffs[i + k] : GFM_NO_SELECT;
             const bool sel = cut != GFM_NO_SELECT;
-            rc = launch_post(mo, mo->d_partials[ws[k]], uh[k] == 2 ? 1 : nslabs,
+            rc = launch_post(mo, mo->d_partials[ws[k]], nslabs,
                              uh[k] ? reinterpret_cast<unsigned long long *>(d_hist[i + k]) : nullptr,
-                             mo->d_resid[ws[k]], mo->d_resid_n[ws[k]], sel ? nslabs : 0, mo->d_ctl, slot[k],
+                             mo->d_spill[ws[k]], mo->d_resid[ws[k]], mo->d_resid_n[ws[k]], sel ? nslabs : 0, mo->d_ctl, slot[k],
                              sel ? reinterpret_cast<long long *>(d_hit_rows[i + k]) : nullptr,
                              sel ? hit_capacity[i + k] : 0,
                              sel ? reinterpret_cast<unsigned long long *>(d_hit_count[i + k]) : nullptr, st);
@@ -1480,7 +1518,7 @@ GFM_API int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, c
                            : reinterpret_cast<const unsigned long long *>(d_hit_count),
                        m->d_sel_ctl, slot, m->d_sel_resid, m->d_sel_resid_n);
     HIP_TRY(hipGetLastError());
-    return launch_post(m, nullptr, 0, nullptr, m->d_sel_resid, m->d_sel_resid_n, (int)blocks,
+    return launch_post(m, nullptr, 0, nullptr, nullptr, m->d_sel_resid, m->d_sel_resid_n, (int)blocks,
                        m->d_sel_ctl, slot, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                        reinterpret_cast<unsigned long long *>(d_hit_count), st);
 }

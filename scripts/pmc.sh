@@ -4,7 +4,7 @@
 set -u
 tag="$1"; shift
 out="$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag"
-mkdir -p "$out"
+rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 run() { name="$1"; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$out/$name" -- python3 "$GRAFT_REPO_ROOT/scripts/prof_score.py" $ARGS > "$out/$name.log" 2>&1; }
 ARGS="$*"
@@ -14,12 +14,15 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE
 python3 - "$out" <<'PY'
-import sys, glob, csv, collections
+import sys, glob, csv, collections, os
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(out + "/*/*/*counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-40:]
+for d in sorted(glob.glob(out + "/*/")):
+    files = sorted(glob.glob(d + "*/*counter_collection.csv"), key=os.path.getmtime)
+    if not files:
+        continue
+    for r in csv.DictReader(open(files[-1])):      # newest process of this pass only
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-40:]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fh:
     for k, d in agg.items():

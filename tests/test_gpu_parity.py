@@ -351,9 +351,9 @@ def test_config3_shard_size_invariants(dev, golden_motifs):
 
 @pytest.mark.parametrize("W", [1, 2, 3, 4, 5, 7, 8, 16, 33, 40, 63, 64])
 def test_width_sweep_random_matrices(dev, W):
-    """Every kernel instantiation (NDW = 1..16), incl. score windows too wide for the LDS histogram
-    (W >= 40 with full-range columns -> global-atomic fallback): DP bit-exact, scores/histogram
-    exact, q-table and selection vs sorted BH, on random integer matrices."""
+    """Every kernel instantiation (NDW = 1..16), incl. score ranges too wide for the LDS histogram
+    (W >= 40 with full-range columns -> partial LDS window + global spill counters): DP bit-exact,
+    scores/histogram exact, q-table and selection vs sorted BH, on random integer matrices."""
     from grafimo_amd.device import DeviceMotif
     from oracle import oracle as orc
     rng = np.random.default_rng(1000 + W)
@@ -394,6 +394,12 @@ def test_width_sweep_random_matrices(dev, W):
     assert np.array_equal(exp >= int(dcut.item()), q_exp < 0.5)
     lo, p = dm.annotate(exp[:100])
     assert np.array_equal(lo, exp[:100] / scale + W * offset) and np.array_equal(p, pt[exp[:100]])
+    # the workspaces (slabs, spill counters) come back clean: three more calls accumulate exactly
+    h3 = torch.zeros(dm.L, dtype=torch.int64, device=dev)
+    for _ in range(3):
+        dm.score(d_k, d_sc, hist=h3)
+    torch.cuda.synchronize()
+    assert np.array_equal(h3.cpu().numpy(), 3 * np.bincount(exp, minlength=dm.L))
     dm.close()
 
 
