@@ -100,6 +100,23 @@ class HipBackend(ScanBackend):
         self.dm.score(d_k, self._scores, hist=hist)
         return None, hist   # scores stay on the device; hits are selected there
 
+    @staticmethod
+    def score_many(backends, kmers):
+        """Same-width motifs over ONE upload and ONE read of the k-mers per group of up to three
+        motifs (gfm_score_kmers_multi).  -> hist torch.int64[M, L]; scores stay on the device."""
+        from .device import score_multi
+        first = backends[0]
+        torch = first.torch
+        n = int(kmers.shape[0])
+        d_k = torch.from_numpy(np.ascontiguousarray(kmers)).to(first.device) if n else \
+            torch.empty((0, first.dm.width), dtype=torch.uint8, device=first.device)
+        hist = torch.zeros((len(backends), first.L), dtype=torch.int64, device=first.device)
+        for b in backends:
+            b._scores = torch.empty(n, dtype=torch.int32, device=first.device)
+        score_multi([b.dm for b in backends], d_k, [b._scores for b in backends],
+                    hists=[hist[j] for j in range(len(backends))])
+        return hist
+
     def tables(self, hist, threshold, on_qvalue):
         torch = self.torch
         q = torch.empty(self.L, dtype=torch.float64, device=self.device)
@@ -170,6 +187,58 @@ def sharded_scan(backend: ScanBackend, kmers: np.ndarray, threshold: float, on_q
     out = dict(rows=rows, scaled=scaled, logodds=lo, pvalue=pv, n_scored=n_global, row_base=row_base)
     if want_qvalues:
         out["qvalue"] = qtable[scaled]
+    return out
+
+
+def sharded_scan_same_width(backends: Sequence[ScanBackend], kmers: np.ndarray, threshold: float,
+                            on_qvalue: bool, want_qvalues: bool, group=None, score_many=None):
+    """Several motifs of ONE width over this rank's rows (BASELINE config 5 on N GPUs).  The k-mers
+    are scored once for the whole set (`score_many`, default: the backend class's own -- for
+    HipBackend the batched launch that shares one k-mer read between up to three motifs) and the M
+    histograms cross the ranks as ONE all-reduce of an [M, L] tensor: xGMI collectives of this
+    size are latency-bound, so M motifs cost one latency instead of M.  Returns one dict per motif
+    like sharded_scan."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if len({b.L for b in backends}) != 1:
+        raise ValueError("sharded_scan_same_width: the motifs must share one width")
+    dev = backends[0].device
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    counts[rank] = int(kmers.shape[0])
+    if world > 1:
+        dist.all_reduce(counts, group=group)
+    counts = counts.cpu().numpy()
+    row_base, n_global = int(counts[:rank].sum()), int(counts.sum())
+
+    if score_many is None:
+        score_many = getattr(type(backends[0]), "score_many", None)
+    scaled_all = [None] * len(backends)
+    if score_many is not None:
+        hist = score_many(backends, kmers)
+    else:
+        parts = [b.score(kmers) for b in backends]
+        scaled_all = [p[0] for p in parts]
+        hist = torch.stack([p[1] for p in parts])
+    if want_qvalues and world > 1:
+        dist.all_reduce(hist, group=group)              # one exchange for the whole set
+    out = []
+    for j, b in enumerate(backends):
+        qtable = None
+        if want_qvalues:
+            qtable, cutoff_q, n_hist = b.tables(hist[j], threshold, on_qvalue)
+            assert n_hist == n_global, (n_hist, n_global)
+        cutoff = cutoff_q if on_qvalue else b.pvalue_cutoff(threshold)
+        if scaled_all[j] is not None:
+            rows, scaled = b.select_host(scaled_all[j], cutoff, row_base)
+        else:
+            rows, scaled = b.select(cutoff, row_base)
+        lo, pv = b.annotate(scaled)
+        res = dict(rows=rows, scaled=scaled, logodds=lo, pvalue=pv, n_scored=n_global, row_base=row_base)
+        if want_qvalues:
+            res["qvalue"] = qtable[scaled]
+        out.append(res)
     return out
 
 

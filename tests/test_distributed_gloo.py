@@ -180,3 +180,77 @@ def test_shard_helpers(tmp_path):
         shards = [shard_files(files, w, r) for r in range(w)]
         assert sum(shards, []) == files                    # contiguous cover, order kept
     assert shard_files([], 4, 2) == []
+
+
+def _golden(key):
+    import json
+    with open(os.path.join(GOLDEN, "motifs.json")) as fh:
+        g = json.load(fh)[key]["motifs"][0]
+    g["pmf"] = np.load(os.path.join(GOLDEN, "pmf.npz"))[g["pmf_key"]]
+    return g
+
+
+_SAME_WIDTH = ["ctcf_meme_unif", "ctcf_meme_bgnt", "ctcf_jaspar_bgnt_p1"]   # three W=19 motifs
+
+
+def _same_width_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import pickle
+    import torch.distributed as dist
+    from grafimo_amd import synth
+    from grafimo_amd.distributed import shard_bounds, sharded_scan, sharded_scan_same_width
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gs = [_golden(k) for k in _SAME_WIDTH]
+        batch = synth.make_batch(5, 600, 19, np.array(gs[0]["probs"]), synth.seed_for(7))
+        lo, hi = shard_bounds(len(batch), world, rank)
+        mine = batch.kmers[lo:hi]
+        backends = [_make_backend(g) for g in gs]
+        calls = {"all_reduce": 0}
+        real = dist.all_reduce
+
+        def counting(t, *a, **k):
+            calls["all_reduce"] += 1
+            return real(t, *a, **k)
+        dist.all_reduce = counting
+        try:
+            many = sharded_scan_same_width(backends, mine, 0.2, True, True)
+        finally:
+            dist.all_reduce = real
+        assert calls["all_reduce"] == 2                       # row counts + ONE [M, L] histogram exchange
+        for j, b in enumerate(backends):
+            one = sharded_scan(b, mine, 0.2, True, True, select=b.select_host)
+            for key in ("rows", "scaled", "logodds", "pvalue", "qvalue"):
+                assert np.array_equal(many[j][key], one[key]), (j, key)
+            assert many[j]["n_scored"] == one["n_scored"] == len(batch) and many[j]["row_base"] == lo
+        bucket = [None] * world if rank == 0 else None
+        dist.gather_object([(r["rows"], r["qvalue"]) for r in many], bucket, dst=0)
+        if rank == 0:
+            with open(os.path.join(outdir, "many.pkl"), "wb") as fh:
+                pickle.dump(bucket, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_same_width_set_shares_one_histogram_exchange(tmp_path):
+    """Config 5 on N ranks: three W=19 motifs over sharded rows -- one [M, L] all-reduce for the
+    set, results identical to per-motif sharded scans and to a single-process oracle run."""
+    import pickle
+    import torch.multiprocessing as mp
+    from grafimo_amd import synth
+    from oracle import oracle as orc
+    mp.spawn(_same_width_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    with open(os.path.join(str(tmp_path), "many.pkl"), "rb") as fh:
+        bucket = pickle.load(fh)
+    gs = [_golden(k) for k in _SAME_WIDTH]
+    batch = synth.make_batch(5, 600, 19, np.array(gs[0]["probs"]), synth.seed_for(7))
+    for j, g in enumerate(gs):
+        ptab = orc.p_table(g["pmf"])
+        sc, pv = orc.score_kmers_table(batch.kmers, np.array(g["score_matrix"], dtype=np.int64), ptab, g["min_val"])
+        q = orc.fdr_bh(pv)
+        exp_rows = np.nonzero(q < 0.2)[0]
+        rows = np.concatenate([bucket[r][j][0] for r in range(2)])
+        qs = np.concatenate([bucket[r][j][1] for r in range(2)])
+        assert np.array_equal(rows, exp_rows) and len(rows) > 0
+        np.testing.assert_allclose(qs, q[exp_rows], rtol=1e-12, atol=0)

@@ -125,6 +125,30 @@ def test_sharded_entry_point_on_one_gpu(golden_json):
         _compare(a, b)
 
 
+def test_sharded_same_width_set_uses_the_batched_launch(golden_motifs):
+    """sharded_scan_same_width with HipBackends (gfm_score_kmers_multi under it) == one sharded_scan
+    per motif: three W=19 motifs (CTCF with three pseudocounts)."""
+    from grafimo_amd import synth
+    from grafimo_amd.distributed import HipBackend, sharded_scan, sharded_scan_same_width
+    from grafimo_amd.motif_ops import build_motif_meme_host
+    path = os.path.join(REF_DATA, "MA0139.1.meme")
+    motifs = [build_motif_meme_host(path, "unfrm_dst", pc, False)[0] for pc in (0.1, 0.5, 2.0)]
+    assert len({m.scale for m in motifs} | {m.min_val for m in motifs}) > 2     # really different matrices
+    batch = synth.make_batch(40, 500, 19, np.asarray(motifs[0].count_matrix), synth.seed_for(9))
+    backends = [HipBackend(m) for m in motifs]
+    try:
+        for on_q, thr in [(False, 1e-3), (True, 0.3)]:
+            many = sharded_scan_same_width(backends, batch.kmers, thr, on_q, True)
+            for j, b in enumerate(backends):
+                one = sharded_scan(b, batch.kmers, thr, on_q, True)
+                assert len(one["rows"]) > 0 and many[j]["n_scored"] == len(batch)
+                for key in ("rows", "scaled", "logodds", "pvalue", "qvalue"):
+                    assert np.array_equal(many[j][key], one[key]), (j, key)
+    finally:
+        for b in backends:
+            b.close()
+
+
 def test_scanner_collectives_on_one_gpu_rccl(golden_motifs):
     """KmerScanner with an RCCL process group of one rank: the all-reduce of the histogram and
     the gather of hits are really issued (same calls as at N = 8), results unchanged."""
