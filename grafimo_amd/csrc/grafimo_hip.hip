@@ -65,6 +65,10 @@ template <typename T> struct DevBuf {
 constexpr int kWave = 64;
 constexpr int kThreads = 1024;                 // 16 waves per workgroup, one workgroup per CU
 constexpr int kWavesPerWG = kThreads / kWave;
+// Widths above 44 (NDW >= 12) run 8 waves per workgroup: 16 strips of 128 x W bytes would leave the
+// LDS histogram window only a few thousand bins (W=64: 4 K), and the rows outside the window pay a
+// global atomic each.
+__host__ __device__ constexpr int waves_for_ndw(int ndw) { return ndw >= 12 ? kWavesPerWG / 2 : kWavesPerWG; }
 constexpr int kChunk = 128;                    // k-mers per wave per iteration (multiple of 64)
 constexpr unsigned kPoison = 0xFFFFu;          // table entry of a byte that is not A,C,G,T (> 1000*64)
 constexpr int kMaxLdsBytes = 160 * 1024;
@@ -75,7 +79,14 @@ constexpr int kDepth = 3;                      // chunks prefetched ahead per wa
 
 // per-wave LDS strip: the staged chunk (+8 B slack for the last row's trailing dword),
 // followed by the wave's hit queue(s), one per motif of the launch
-__host__ __device__ inline int stage_data_bytes(int W) { return ((kChunk * W + 15) & ~15) + 8; }
+// Rows of W % 16 == 0 bytes would start 4, 8, 12 or 16 dwords apart in the strip: the 64 lanes of a
+// row-wise read then share 8, 4, 8 or 2 LDS banks (W=32: 189 us for 2e7 rows).  Those widths are
+// staged one dword apart (row stride W + 4: an odd number of dwords, conflict free: 142 us).
+__host__ __device__ inline int row_pad_bytes(int W) { return (W % 16 == 0) ? 4 : 0; }
+__host__ __device__ inline int stage_data_bytes(int W)
+{
+    return ((kChunk * (W + row_pad_bytes(W)) + 15) & ~15) + 8;
+}
 __host__ __device__ inline int stage_stride_bytes(int W, int mm) { return stage_data_bytes(W) + mm * kHitQueue * 8; }
 
 // ---------------------------------------------------------------------------------------
@@ -173,11 +184,13 @@ struct MotifArgs {
 template <int MM> struct ScoreArgs { MotifArgs m[MM]; };
 
 template <int NDW, int MM>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(waves_for_ndw(NDW) * kWave)
 score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long long row_base,
                   const ScoreArgs<MM> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kWaves = waves_for_ndw(NDW);     // waves of this workgroup
+    constexpr int kWgThreads = kWaves * kWave;
     constexpr int kTabBytes = 2 * NDW * 64 * 2;  // 2*NDW base pairs x (8 x 8 codes) x uint16
     constexpr int kLoads = (kChunk * 4 * NDW + 1023) / 1024;  // 16 B loads per lane per chunk
 
@@ -191,7 +204,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
     const int sstride = stage_stride_bytes(W, MM);
     unsigned *hist[MM];
     {
-        unsigned *h = reinterpret_cast<unsigned *>(stage_base + kWavesPerWG * sstride);
+        unsigned *h = reinterpret_cast<unsigned *>(stage_base + kWaves * sstride);
 #pragma unroll
         for (int m = 0; m < MM; ++m) {
             hist[m] = h;
@@ -204,10 +217,10 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
     const int wave = tid >> 6;
 
     if constexpr (MM == 1) {
-        for (int i = tid; i < kTabBytes / 2; i += kThreads)
+        for (int i = tid; i < kTabBytes / 2; i += kWgThreads)
             reinterpret_cast<uint16_t *>(tab)[i] = a.m[0].tab[i];
     } else {
-        for (int i = tid; i < kTabBytes / 2; i += kThreads) {
+        for (int i = tid; i < kTabBytes / 2; i += kWgThreads) {
             unsigned long long v = 0;
             const unsigned t0 = a.m[0].tab[i];
             if (t0 == kPoison) {
@@ -222,7 +235,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
 #pragma unroll
     for (int m = 0; m < MM; ++m) {
         if (a.m[m].use_hist)
-            for (int i = tid; i <= a.m[m].nb; i += kThreads) hist[m][i] = 0u;
+            for (int i = tid; i <= a.m[m].nb; i += kWgThreads) hist[m][i] = 0u;
     }
     __syncthreads();
 
@@ -230,8 +243,11 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
     const long long total_bytes = n * (long long)W;
     const long long nchunks = (n + kChunk - 1) / kChunk;
     const int chunk_bytes = kChunk * W;
-    const long long cstride = (long long)gridDim.x * kWavesPerWG;
+    const long long cstride = (long long)gridDim.x * kWaves;
 
+    // only the instantiations that can see a width of 16, 32, 48 or 64 carry the padded staging
+    const int pad = (NDW % 4 == 0) ? row_pad_bytes(W) : 0;
+    const unsigned pad_inv = pad ? (65536u + (unsigned)(W >> 4) - 1u) / (unsigned)(W >> 4) : 0u;  // ceil(2^16 / (W/16))
     uint4 pre[kDepth][kLoads];
     auto fetch = [&](uint4 (&dst)[kLoads], long long c) {
         const long long cbase = c * (long long)chunk_bytes;
@@ -268,7 +284,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
             a.m[m].ctl->snap[a.m[m].slot] = a.m[m].hit_count ? *a.m[m].hit_count : 0ull;
     }
 
-    long long c = (long long)blockIdx.x * kWavesPerWG + wave;
+    long long c = (long long)blockIdx.x * kWaves + wave;
 #pragma unroll
     for (int d = 0; d < kDepth; ++d)
         if (c + d * cstride < nchunks) fetch(pre[d], c + d * cstride);
@@ -279,7 +295,18 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
             const int off = i * 1024 + lane * 16;
-            if (off < chunk_bytes) *reinterpret_cast<uint4 *>(stage + off) = pre[d][i];
+            if (off < chunk_bytes) {
+                if (pad) {   // W % 16 == 0: the 16-byte piece lies inside row off / W
+                    const unsigned r = ((unsigned)(off >> 4) * pad_inv) >> 16;
+                    unsigned *dst = reinterpret_cast<unsigned *>(stage + off + 4 * r);
+                    dst[0] = pre[d][i].x;
+                    dst[1] = pre[d][i].y;
+                    dst[2] = pre[d][i].z;
+                    dst[3] = pre[d][i].w;
+                } else {
+                    *reinterpret_cast<uint4 *>(stage + off) = pre[d][i];
+                }
+            }
         }
         if (c + kDepth * cstride < nchunks) fetch(pre[d], c + kDepth * cstride);
         // LDS ops of one wave execute in program order; the fence only pins the compiler.
@@ -290,7 +317,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
         for (int p = 0; p < kChunk / kWave; ++p) {
             const int k = p * kWave + lane;
             const long long row = c * kChunk + k;
-            const int boff = k * W;
+            const int boff = k * (W + pad);
             const unsigned sh = (unsigned)(boff & 3) * 8u;
             const unsigned *src = reinterpret_cast<const unsigned *>(stage + (boff & ~3));
             unsigned w[NDW + 1];
@@ -364,11 +391,11 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
     for (int m = 0; m < MM; ++m) {
         const MotifArgs &ma = a.m[m];
         if (ma.cutoff != GFM_NO_SELECT)
-            hitq_finish<kWavesPerWG>(hitq[m], qn[m], reinterpret_cast<int *>(tab + m * kTabBytes), wave,
+            hitq_finish<kWaves>(hitq[m], qn[m], reinterpret_cast<int *>(tab + m * kTabBytes), wave,
                                      lane, tid, ma.resid, ma.resid_n);
         if (ma.use_hist) {
             unsigned *slab = ma.partials + (size_t)blockIdx.x * (size_t)(ma.nb + 1);
-            for (int i = tid; i <= ma.nb; i += kThreads) slab[i] = hist[m][i];
+            for (int i = tid; i <= ma.nb; i += kWgThreads) slab[i] = hist[m][i];
         }
     }
 }
@@ -770,7 +797,9 @@ struct gfm_motif {
     int W = 0, L = 0, min_val = 0, scale = 1, ndw = 0;
     double offset = 0.0;
     int lo = 0, hi = 0, nb = 0;      // reachable score range [lo, hi], nb bins
-    int hlo = 0, hnb = 0;            // LDS histogram window of the score kernel (== lo, nb when it fits)
+    int hlo = 0, hnb = 0;            // LDS histogram window of a single-motif launch (== lo, nb when it fits)
+    struct Window { int bins, lo; double mass; };
+    std::vector<Window> windows;     // cache of best_window() per window size
     int device = 0;
     int n_cu = 256;
     int max_slabs = 0;
@@ -786,7 +815,7 @@ struct gfm_motif {
     // Scoring workspace, double-buffered by call parity so that the post kernel of call k (on a
     // tail stream) may run while the score kernel of call k+1 fills the other set.
     unsigned *d_partials[2] = {nullptr, nullptr};   // [max_slabs][hnb+1] histogram slabs
-    unsigned *d_spill[2] = {nullptr, nullptr};      // [nb] rows outside a partial window (else null)
+    unsigned *d_spill[2] = {nullptr, nullptr};      // [nb] rows outside a partial window
     long long *d_resid[2] = {nullptr, nullptr};     // [max_slabs][kResidPerWG] residual hits
     int *d_resid_n[2] = {nullptr, nullptr};         // [max_slabs]
     QWork *d_qwork = nullptr;        // q-value kernels' block totals / minima
@@ -881,7 +910,7 @@ int run_dp(const int64_t *sm, int W, const double *bg, double *d_pmf, hipStream_
 size_t score_lds_bytes(int W, int ndw, int mm, const int *nb_lds /* nb+1 or 0 per motif */)
 {
     // one motif: uint16 pair tables; 2-3 motifs: ONE table of packed 64-bit entries (4x the bytes)
-    size_t b = (size_t)(mm == 1 ? 1 : 4) * (2 * ndw * 64 * 2) + (size_t)kWavesPerWG * stage_stride_bytes(W, mm);
+    size_t b = (size_t)(mm == 1 ? 1 : 4) * (2 * ndw * 64 * 2) + (size_t)waves_for_ndw(ndw) * stage_stride_bytes(W, mm);
     for (int i = 0; i < mm; ++i) b += sizeof(unsigned) * (size_t)nb_lds[i];
     return b;
 }
@@ -899,7 +928,7 @@ int launch_score_t(gfm_motif *timer, const uint8_t *d_kmers, long long n, int W,
     const bool prof = timer && !timer->ev0.empty() && (timer->ev_calls++ % (unsigned)timer->ev_every) == 0;
     const int slot = prof ? timer->ev_next : 0;
     if (prof) HIP_TRY(hipEventRecord(timer->ev0[slot], st));
-    hipLaunchKernelGGL(kern, dim3(nslabs), dim3(kThreads), lds, st, d_kmers, n, W, row_base, args);
+    hipLaunchKernelGGL(kern, dim3(nslabs), dim3(waves_for_ndw(NDW) * kWave), lds, st, d_kmers, n, W, row_base, args);
     HIP_TRY(hipGetLastError());
     if (prof) {
         HIP_TRY(hipEventRecord(timer->ev1[slot], st));
@@ -925,31 +954,49 @@ int dispatch_score(int ndw, gfm_motif *timer, const uint8_t *d_kmers, long long 
 #undef GFM_CASE
 }
 
+// The `bins` consecutive scores that hold the most background probability
+// (P(s >= a) - P(s >= a + bins) from the tail table): where a partial LDS histogram window goes.
+gfm_motif::Window best_window(gfm_motif *m, int bins)
+{
+    if (bins >= m->nb) return {m->nb, m->lo, 1.0};
+    for (const auto &w : m->windows)
+        if (w.bins == bins) return w;
+    gfm_motif::Window best{bins, m->lo, -1.0};
+    for (int a = m->lo; a + bins - 1 <= m->hi; ++a) {
+        const int e = a + bins;
+        const double mass = m->h_ptable[a] - (e < m->L ? m->h_ptable[e] : 0.0);
+        if (mass > best.mass) { best.mass = mass; best.lo = a; }
+    }
+    m->windows.push_back(best);
+    return best;
+}
+
 // one launch after a scoring / selection kernel: histogram slabs -> hist64, hit slabs -> list
 int launch_post(gfm_motif *m, const unsigned *partials, int hist_slabs, unsigned long long *d_hist,
-                unsigned *spill, const long long *resid, const int *resid_n, int hit_slabs, HitCtl *ctl, int ctl_slot,
+                int win_lo, int win_nb, unsigned *spill, const long long *resid, const int *resid_n, int hit_slabs, HitCtl *ctl, int ctl_slot,
                 long long *d_hit_rows, long long cap, unsigned long long *d_hit_count, hipStream_t st)
 {
-    const int bin_blocks = (m->hnb + 1 + 255) / 256;
+    const int bin_blocks = (win_nb + 1 + 255) / 256;
     const int groups = (hist_slabs + kSlabsPerGroup - 1) / kSlabsPerGroup;
     const int hist_blocks = d_hist ? bin_blocks * groups : 0;
-    const int spill_blocks = (d_hist && spill) ? (m->nb + 255) / 256 : 0;
+    const int spill_blocks = (d_hist && spill && win_nb < m->nb) ? (m->nb + 255) / 256 : 0;
     const int total = hist_blocks + spill_blocks + hit_slabs;
     if (total == 0) return GFM_OK;
-    hipLaunchKernelGGL(post_kernel, dim3(total), dim3(256), 0, st, partials, hist_slabs, m->hnb, m->hlo,
+    hipLaunchKernelGGL(post_kernel, dim3(total), dim3(256), 0, st, partials, hist_slabs, win_nb, win_lo,
                        m->min_val, d_hist, bin_blocks, hist_blocks, spill, m->lo, m->nb, spill_blocks,
                        resid, resid_n, hit_slabs, ctl, ctl_slot, d_hit_rows, cap, d_hit_count);
     HIP_TRY(hipGetLastError());
     return GFM_OK;
 }
 
-void fill_motif_args(MotifArgs &a, gfm_motif *m, int ws, int slot, int use_hist, int cutoff,
+void fill_motif_args(MotifArgs &a, gfm_motif *m, int ws, int slot, int use_hist, int win_lo, int win_nb,
+                     int cutoff,
                      int *d_scores, long long *d_hit_rows, long long cap,
                      const unsigned long long *d_hit_count_or_null)
 {
     a.tab = m->d_tab;
-    a.lo = m->hlo;
-    a.nb = m->hnb;
+    a.lo = win_lo;
+    a.nb = win_nb;
     a.min_val = m->min_val;
     a.use_hist = use_hist;
     a.spill_lo = m->lo;
@@ -1172,27 +1219,15 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     const long long room = ((long long)kMaxLdsBytes - (long long)fixed) / (long long)sizeof(unsigned) - 1;
     if (room < 256) return bail(fail(GFM_ERR_INVALID, "no LDS left for a histogram window at width %d", W));
     m->hnb = (int)std::min<long long>(m->nb, room);
-    m->hlo = m->lo;
-    if (m->hnb < m->nb) {
-        // partial window: the hnb consecutive scores that hold the most background probability
-        // (P(s >= a) - P(s >= a + hnb) from the tail table); the rest spills to global counters
-        double best = -1.0;
-        for (int a = m->lo; a + m->hnb - 1 <= m->hi; ++a) {
-            const int e = a + m->hnb;
-            const double mass = m->h_ptable[a] - (e < m->L ? m->h_ptable[e] : 0.0);
-            if (mass > best) { best = mass; m->hlo = a; }
-        }
-    }
+    m->hlo = best_window(m, m->hnb).lo;   // partial when the range does not fit: the rest spills
     m->lds_bytes = fixed + sizeof(unsigned) * (size_t)(m->hnb + 1);
     int per_cu = (int)std::min<size_t>(kWGsPerCU, (size_t)kMaxLdsBytes / m->lds_bytes);
     per_cu = std::max(per_cu, 1);
     m->max_slabs = m->n_cu * per_cu;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY_M(hipMalloc(&m->d_partials[i], sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->hnb + 1)));
-        if (m->hnb < m->nb) {
-            HIP_TRY_M(hipMalloc(&m->d_spill[i], sizeof(unsigned) * (size_t)m->nb));
-            HIP_TRY_M(hipMemset(m->d_spill[i], 0, sizeof(unsigned) * (size_t)m->nb));
-        }
+        HIP_TRY_M(hipMalloc(&m->d_spill[i], sizeof(unsigned) * (size_t)m->nb));
+        HIP_TRY_M(hipMemset(m->d_spill[i], 0, sizeof(unsigned) * (size_t)m->nb));
         HIP_TRY_M(hipMalloc(&m->d_resid[i], sizeof(long long) * (size_t)m->max_slabs * kResidPerWG));
         HIP_TRY_M(hipMalloc(&m->d_resid_n[i], sizeof(int) * (size_t)m->max_slabs));
         HIP_TRY_M(hipEventCreateWithFlags(&m->ev_scored[i], hipEventDisableTiming | hipEventReleaseToDevice));
@@ -1296,7 +1331,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         return fail(GFM_ERR_INVALID, "selection requested without hit buffers");
     const int use_hist = d_hist ? 1 : 0;
     const long long nchunks = (n + kChunk - 1) / kChunk;
-    const long long want = (nchunks + kWavesPerWG - 1) / kWavesPerWG;
+    const long long want = (nchunks + waves_for_ndw(m->ndw) - 1) / waves_for_ndw(m->ndw);
     // with a tail stream a few CUs are left free so that its kernels (post, q-table, RCCL) find
     // room without evicting a persistent score workgroup (which would delay the whole grid)
     const int avail = split ? std::max(1, m->max_slabs - m->reserve_cus * (m->max_slabs / m->n_cu)) : m->max_slabs;
@@ -1312,7 +1347,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     if (split && select && !reset && m->posted_valid[ws ^ 1])
         HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws ^ 1], 0));
     ScoreArgs<1> args{};
-    fill_motif_args(args.m[0], m, ws, slot, use_hist, select_cutoff, d_scores,
+    fill_motif_args(args.m[0], m, ws, slot, use_hist, m->hlo, m->hnb, select_cutoff, d_scores,
                     reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                     reset ? nullptr : reinterpret_cast<unsigned long long *>(d_hit_count));
     int rc = dispatch_score<1>(m->ndw, m, d_kmers, n, m->W, row_base, args, m->lds_bytes, nslabs, st, false);
@@ -1322,7 +1357,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         HIP_TRY(hipStreamWaitEvent(tail, m->ev_scored[ws], 0));
     }
     rc = launch_post(m, m->d_partials[ws], nslabs, reinterpret_cast<unsigned long long *>(d_hist),
-                     m->d_spill[ws], m->d_resid[ws], m->d_resid_n[ws], select ? nslabs : 0, m->d_ctl, slot,
+                     m->hlo, m->hnb, m->d_spill[ws], m->d_resid[ws], m->d_resid_n[ws], select ? nslabs : 0, m->d_ctl, slot,
                      reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                      reinterpret_cast<unsigned long long *>(d_hit_count), tail);
     if (rc) return rc;
@@ -1370,23 +1405,58 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
         return fail(GFM_ERR_INVALID, "too many rows for one launch (split the batch)");
     const int W = motifs[0]->W, ndw = motifs[0]->ndw;
     const long long nchunks = (n + kChunk - 1) / kChunk;
-    const long long want = (nchunks + kWavesPerWG - 1) / kWavesPerWG;
+    const long long want = (nchunks + waves_for_ndw(ndw) - 1) / waves_for_ndw(ndw);
 
-    // greedy grouping: up to 3 motifs per launch while tables + strips + LDS windows fit
+    // grouping: the largest group (<= 3 motifs) whose LDS histogram windows still hold
+    // kMinWindowMass of each motif's background score distribution.  Windows share what the tables
+    // and strips leave: a motif whose whole range fits takes it, the others split the rest and
+    // spill the rows outside their window (partial windows, see score_hist_kernel).
+    constexpr double kMinWindowMass = 0.999;
     int i = 0;
     while (i < n_motifs) {
-        int mm = 1, nb_lds[3] = {0, 0, 0};
-        auto lds_need = [&](int idx) {
-            gfm_motif *mo = motifs[idx];
-            const bool want_hist = d_hist && d_hist[idx];
-            return want_hist ? mo->hnb + 1 : 0;
-        };
-        nb_lds[0] = lds_need(i);
-        while (mm < 3 && i + mm < n_motifs) {
-            nb_lds[mm] = lds_need(i + mm);
-            if (score_lds_bytes(W, ndw, mm + 1, nb_lds) > (size_t)kMaxLdsBytes) { nb_lds[mm] = 0; break; }
-            ++mm;
+        int mm = std::min(3, n_motifs - i), nb_lds[3] = {0, 0, 0};
+        int win_lo[3] = {0, 0, 0}, win_nb[3] = {0, 0, 0};
+        for (; mm >= 1; --mm) {
+            const int zero[3] = {0, 0, 0};
+            long long room = ((long long)kMaxLdsBytes - (long long)score_lds_bytes(W, ndw, mm, zero)) /
+                             (long long)sizeof(unsigned);
+            bool open[3] = {false, false, false};
+            int users = 0;
+            for (int k = 0; k < mm; ++k) {
+                win_nb[k] = 0;
+                win_lo[k] = motifs[i + k]->lo;
+                open[k] = d_hist && d_hist[i + k];
+                users += open[k];
+            }
+            bool ok = room > 0 || users == 0;
+            // water-filling: ranges that fit their equal share are served whole, the rest share again
+            for (bool again = true; ok && again && users > 0;) {
+                again = false;
+                const long long share = room / users - 1;
+                for (int k = 0; k < mm; ++k)
+                    if (open[k] && motifs[i + k]->nb <= share) {
+                        win_nb[k] = motifs[i + k]->nb;
+                        room -= win_nb[k] + 1;
+                        open[k] = false;
+                        --users;
+                        again = true;
+                    }
+            }
+            if (ok && users > 0) {
+                const long long share = room / users - 1;
+                if (share < 256) ok = false;
+                for (int k = 0; ok && k < mm; ++k)
+                    if (open[k]) {
+                        const gfm_motif::Window w = best_window(motifs[i + k], (int)share);
+                        win_nb[k] = w.bins;
+                        win_lo[k] = w.lo;
+                        if (mm > 1 && w.mass < kMinWindowMass) ok = false;
+                    }
+            }
+            if (ok || mm == 1) break;
         }
+        if (mm < 1) mm = 1;
+        for (int k = 0; k < mm; ++k) nb_lds[k] = (d_hist && d_hist[i + k]) ? win_nb[k] + 1 : 0;
         const size_t lds = score_lds_bytes(W, ndw, mm, nb_lds);
         int nslabs = (int)std::min<long long>(want, motifs[i]->max_slabs);
         for (int k = 1; k < mm; ++k) nslabs = std::min(nslabs, motifs[i + k]->max_slabs);
@@ -1404,7 +1474,7 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
             const int cut = select_cutoffs ? select_cutoffs[i + k] : GFM_NO_SELECT;
             const bool sel = cut != GFM_NO_SELECT;
             MotifArgs &dst = mm == 1 ? a1.m[k] : (mm == 2 ? a2.m[k] : a3.m[k]);
-            fill_motif_args(dst, mo, ws[k], slot[k], uh[k], cut, d_scores[i + k],
+            fill_motif_args(dst, mo, ws[k], slot[k], uh[k], win_lo[k], win_nb[k], cut, d_scores[i + k],
                             sel ? reinterpret_cast<long long *>(d_hit_rows[i + k]) : nullptr,
                             sel ? hit_capacity[i + k] : 0,
                             (sel && !reset) ? reinterpret_cast<const unsigned long long *>(d_hit_count[i + k])
@@ -1421,7 +1491,7 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
             const bool sel = cut != GFM_NO_SELECT;
             rc = launch_post(mo, mo->d_partials[ws[k]], nslabs,
                              uh[k] ? reinterpret_cast<unsigned long long *>(d_hist[i + k]) : nullptr,
-                             mo->d_spill[ws[k]], mo->d_resid[ws[k]], mo->d_resid_n[ws[k]], sel ? nslabs : 0, mo->d_ctl, slot[k],
+                             win_lo[k], win_nb[k], mo->d_spill[ws[k]], mo->d_resid[ws[k]], mo->d_resid_n[ws[k]], sel ? nslabs : 0, mo->d_ctl, slot[k],
                              sel ? reinterpret_cast<long long *>(d_hit_rows[i + k]) : nullptr,
                              sel ? hit_capacity[i + k] : 0,
                              sel ? reinterpret_cast<unsigned long long *>(d_hit_count[i + k]) : nullptr, st);
@@ -1518,7 +1588,7 @@ GFM_API int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, c
                            : reinterpret_cast<const unsigned long long *>(d_hit_count),
                        m->d_sel_ctl, slot, m->d_sel_resid, m->d_sel_resid_n);
     HIP_TRY(hipGetLastError());
-    return launch_post(m, nullptr, 0, nullptr, nullptr, m->d_sel_resid, m->d_sel_resid_n, (int)blocks,
+    return launch_post(m, nullptr, 0, nullptr, 0, 0, nullptr, m->d_sel_resid, m->d_sel_resid_n, (int)blocks,
                        m->d_sel_ctl, slot, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                        reinterpret_cast<unsigned long long *>(d_hit_count), st);
 }

@@ -349,7 +349,7 @@ def test_config3_shard_size_invariants(dev, golden_motifs):
     dm.close()
 
 
-@pytest.mark.parametrize("W", [1, 2, 3, 4, 5, 7, 8, 16, 33, 40, 63, 64])
+@pytest.mark.parametrize("W", [1, 2, 3, 4, 5, 7, 8, 16, 32, 33, 40, 48, 63, 64])
 def test_width_sweep_random_matrices(dev, W):
     """Every kernel instantiation (NDW = 1..16), incl. score ranges too wide for the LDS histogram
     (W >= 40 with full-range columns -> partial LDS window + global spill counters): DP bit-exact,
