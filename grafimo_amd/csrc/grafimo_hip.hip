@@ -1,4 +1,6 @@
-// grafimo_hip.hip -- MI355X (gfx950 / CDNA4) kernels + C ABI for GRAFIMO's k-mer scoring path.
+// grafimo_hip.hip -- host side and C ABI of the MI355X (gfx950 / CDNA4) k-mer scoring path of GRAFIMO.
+// The kernels live in gfm_score_kernels.hpp (scoring, histogram, selection) and
+// gfm_stats_kernels.hpp (p-value DP, tail table, BH q-values), included below: one translation unit.
 //
 // Written for gfx950 only: 64-lane wavefronts, 160 KiB LDS per CU, 256 CUs in 8 XCDs.
 // The hot op is an HBM-bound gather (W table lookups + W integer adds per k-mer,
@@ -23,773 +25,9 @@
 
 #define GFM_API extern "C" __attribute__((visibility("default")))
 
-namespace {
-
-constexpr int kRange = 1000;             // utils.py:26
-constexpr double kLogFactor = 1.44269504;  // utils.py:25 (truncated 1/ln2, verbatim)
-
-thread_local std::string g_err;
-
-int fail(int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_err = buf;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return fail(GFM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
-                        __FILE__, __LINE__);                                                 \
-    } while (0)
-
-// device allocation that frees itself (error paths of the host-side helpers)
-template <typename T> struct DevBuf {
-    T *p = nullptr;
-    DevBuf() = default;
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t count) { return hipMalloc(&p, sizeof(T) * count); }
-    operator T *() const { return p; }
-};
-
-// ---------------------------------------------------------------------------------------
-// score kernel geometry
-constexpr int kWave = 64;
-constexpr int kThreads = 1024;                 // 16 waves per workgroup, one workgroup per CU
-constexpr int kWavesPerWG = kThreads / kWave;
-// Widths above 44 (NDW >= 12) run 8 waves per workgroup: 16 strips of 128 x W bytes would leave the
-// LDS histogram window only a few thousand bins (W=64: 4 K), and the rows outside the window pay a
-// global atomic each.
-__host__ __device__ constexpr int waves_for_ndw(int ndw) { return ndw >= 12 ? kWavesPerWG / 2 : kWavesPerWG; }
-constexpr int kChunk = 128;                    // k-mers per wave per iteration (multiple of 64)
-constexpr unsigned kPoison = 0xFFFFu;          // table entry of a byte that is not A,C,G,T (> 1000*64)
-constexpr int kMaxLdsBytes = 160 * 1024;
-constexpr int kWGsPerCU = 1;                   // target residency of the score kernel
-constexpr int kReserveCUs = 4;                 // CUs left to tail-stream kernels when one is given
-constexpr int kHitQueue = 64;                  // per-wave LDS hit queue (entries, >= 64)
-constexpr int kDepth = 3;                      // chunks prefetched ahead per wave
-
-// per-wave LDS strip: the staged chunk (+8 B slack for the last row's trailing dword),
-// followed by the wave's hit queue(s), one per motif of the launch
-// Rows of W % 16 == 0 bytes would start 4, 8, 12 or 16 dwords apart in the strip: the 64 lanes of a
-// row-wise read then share 8, 4, 8 or 2 LDS banks (W=32: 189 us for 2e7 rows).  Those widths are
-// staged one dword apart (row stride W + 4: an odd number of dwords, conflict free: 142 us).
-__host__ __device__ inline int row_pad_bytes(int W) { return (W % 16 == 0) ? 4 : 0; }
-__host__ __device__ inline int stage_data_bytes(int W)
-{
-    return ((kChunk * (W + row_pad_bytes(W)) + 15) & ~15) + 8;
-}
-__host__ __device__ inline int stage_stride_bytes(int W, int mm) { return stage_data_bytes(W) + mm * kHitQueue * 8; }
-
-// ---------------------------------------------------------------------------------------
-// Hit list plumbing shared by the fused and the separate selection.
-// Every wave queues its hits in LDS (kHitQueue entries).  A full queue is flushed to the dense
-// list with ONE returning global atomic (rare, spread over the run).  What is still queued at
-// the end goes to the workgroup's slab of a staging area with plain stores; post_kernel
-// appends the slabs.  No returning atomic sits on the kernel's tail: per wave or per
-// workgroup, 512..4096 same-word atomics there cost +30..45 us on a 100 us kernel (measured;
-// one word sustains ~88 returning atomics/us, MI355X_MICROARCH "dequeue").
-// HitCtl rotates three mid-run counters so that the kernel that zeroes one never races a
-// kernel that uses it: call k uses slot k%3, its post_kernel zeroes slot (k+2)%3.
-struct HitCtl {
-    unsigned long long mid[3];   // entries flushed mid-run by the current call
-    unsigned long long snap[3];  // *hit_count as the call found it
-};
-constexpr int kResidPerWG = kWavesPerWG * kHitQueue;  // staging slab entries per workgroup
-
-__device__ inline void hitq_push(long long *hitq, int &qn, bool hit, long long entry, int lane,
-                                 const unsigned long long *hit_count, unsigned long long *mid,
-                                 long long *hit_rows, long long hit_cap)
-{
-    const unsigned long long mask = __ballot(hit);
-    if (!mask) return;
-    const int nh = __popcll(mask);
-    if (qn + nh > kHitQueue) {
-        unsigned long long base = 0;
-        if (lane == 0) base = (hit_count ? *hit_count : 0ull) + atomicAdd(mid, (unsigned long long)qn);
-        base = __shfl(base, 0);
-        for (int i = lane; i < qn; i += kWave)
-            if ((long long)(base + i) < hit_cap) hit_rows[base + i] = hitq[i];
-        qn = 0;
-    }
-    if (hit) hitq[qn + __popcll(mask & ((1ull << lane) - 1ull))] = entry;
-    qn += nh;
-}
-
-// all waves of the workgroup call this once, after their last push
-template <int WAVES>
-__device__ inline void hitq_finish(const long long *hitq, int qn, int *wq_n /* shared [WAVES] */,
-                                   int wave, int lane, int tid, long long *resid, int *resid_n)
-{
-    if (lane == 0) wq_n[wave] = qn;
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        if (w < wave) base += wq_n[w];
-        tot += wq_n[w];
-    }
-    long long *slab = resid + (size_t)blockIdx.x * kResidPerWG;
-    for (int i = lane; i < qn; i += kWave) slab[base + i] = hitq[i];
-    if (tid == 0) resid_n[blockIdx.x] = tot;
-}
-
-// ---------------------------------------------------------------------------------------
-// score_hist_kernel<NDW, SELECT>
-//
-// One wave owns a stream of 128-k-mer chunks.  A chunk is W*128 contiguous bytes of the
-// row-major uint8 [n][W] matrix (16-byte aligned because 128*W % 16 == 0), fetched with
-// fully coalesced 16 B/lane loads into registers one chunk ahead, parked in a wave-private
-// LDS strip, and re-read row-wise: lane r takes k-mer r as NDW+1 aligned dwords that
-// v_alignbit turns into NDW dwords of consecutive bases.  Bases are looked up TWO at a time:
-// bits 1..3 of an ASCII code ((c>>1)&7: A/a 0, C/c 1, T/t 2, G/g 3, N/n 7) of two
-// neighbouring bases form a 6-bit index into that pair's 64-entry uint16 table in LDS
-// (entry = sm[b0][2p] + sm[b1][2p+1]); the 16 hot entries of a pair sit in 8 distinct banks, so
-// the lookup is conflict free, and a dword of 4 bases costs 7 VALU + 2 LDS instead of 9 + 4.
-// Entries with a code 4..7 hold kPoison: a k-mer that touched one scores min_val
-// (score_sequences.py:376-378).  A position >= W contributes 0 whatever its byte, so the tail
-// of the last dword needs no masking.  Scores go out as coalesced int32; the score histogram
-// is built with LDS atomics in a per-workgroup window [lo, lo+nb) (+1 bin for N rows)
-// and flushed once per workgroup as a plain-store slab (no global atomics).  Wide motifs whose
-// whole score range does not fit next to the strips keep the window over the densest part of the
-// background score distribution; the few rows outside it go to a global spill array.
-// MM motifs of the same width can share ONE read of the k-mers (BASELINE config 5: per
-// (k-mer, motif) pair the algorithmic bytes drop from W + 4 to W/MM + 4): the staged strip is
-// scored against MM table sets, each motif has its own histogram window, hit queue and outputs.
-struct MotifArgs {
-    const uint16_t *tab;      // [2*NDW][64] pair tables (global)
-    int lo, nb, min_val;      // LDS histogram window [lo, lo+nb) (+ the N bin at nb)
-    int use_hist;             // 0 none, 1 LDS window -> slab (+ spill outside the window)
-    int spill_lo;             // first score of the motif's full range
-    unsigned *spill;          // [full range] counters of rows outside the window (post re-zeroes)
-    int cutoff;               // rows with score >= cutoff are hits; GFM_NO_SELECT: none
-    int slot;                 // HitCtl slot of this call
-    int *scores;
-    unsigned *partials;
-    long long *hit_rows;
-    long long hit_cap;
-    const unsigned long long *hit_count;   // nullptr: the list restarts at 0 (GFM_FLAG_RESET_HITS)
-    HitCtl *ctl;
-    long long *resid;
-    int *resid_n;
-};
-template <int MM> struct ScoreArgs { MotifArgs m[MM]; };
-
-template <int NDW, int MM>
-__global__ void __launch_bounds__(waves_for_ndw(NDW) * kWave)
-score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long long row_base,
-                  const ScoreArgs<MM> a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int kWaves = waves_for_ndw(NDW);     // waves of this workgroup
-    constexpr int kWgThreads = kWaves * kWave;
-    constexpr int kTabBytes = 2 * NDW * 64 * 2;  // 2*NDW base pairs x (8 x 8 codes) x uint16
-    constexpr int kLoads = (kChunk * 4 * NDW + 1023) / 1024;  // 16 B loads per lane per chunk
-
-    // MM == 1: uint16 pair tables.  MM > 1: ONE table of 64-bit entries packing the motifs' partial
-    // scores in 19-bit fields (a k-mer's score is <= 64000 < 2^19, so fields never carry) plus, in
-    // bits 57.., a count of invalid codes: one ds_read_b64 + one 64-bit add per base pair serves
-    // all motifs of the launch, so the inner loop costs the same for 1, 2 or 3 motifs.
-    constexpr int kTabRegion = (MM == 1 ? 1 : 4) * kTabBytes;
-    unsigned char *tab = smem;
-    unsigned char *stage_base = smem + kTabRegion;
-    const int sstride = stage_stride_bytes(W, MM);
-    unsigned *hist[MM];
-    {
-        unsigned *h = reinterpret_cast<unsigned *>(stage_base + kWaves * sstride);
-#pragma unroll
-        for (int m = 0; m < MM; ++m) {
-            hist[m] = h;
-            if (a.m[m].use_hist) h += a.m[m].nb + 1;
-        }
-    }
-
-    const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const int wave = tid >> 6;
-
-    if constexpr (MM == 1) {
-        for (int i = tid; i < kTabBytes / 2; i += kWgThreads)
-            reinterpret_cast<uint16_t *>(tab)[i] = a.m[0].tab[i];
-    } else {
-        for (int i = tid; i < kTabBytes / 2; i += kWgThreads) {
-            unsigned long long v = 0;
-            const unsigned t0 = a.m[0].tab[i];
-            if (t0 == kPoison) {
-                v = 1ull << 57;                       // same codes are invalid for every motif
-            } else {
-#pragma unroll
-                for (int m = 0; m < MM; ++m) v |= (unsigned long long)a.m[m].tab[i] << (19 * m);
-            }
-            reinterpret_cast<unsigned long long *>(tab)[i] = v;
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < MM; ++m) {
-        if (a.m[m].use_hist)
-            for (int i = tid; i <= a.m[m].nb; i += kWgThreads) hist[m][i] = 0u;
-    }
-    __syncthreads();
-
-    unsigned char *stage = stage_base + wave * sstride;
-    const long long total_bytes = n * (long long)W;
-    const long long nchunks = (n + kChunk - 1) / kChunk;
-    const int chunk_bytes = kChunk * W;
-    const long long cstride = (long long)gridDim.x * kWaves;
-
-    // only the instantiations that can see a width of 16, 32, 48 or 64 carry the padded staging
-    const int pad = (NDW % 4 == 0) ? row_pad_bytes(W) : 0;
-    const unsigned pad_inv = pad ? (65536u + (unsigned)(W >> 4) - 1u) / (unsigned)(W >> 4) : 0u;  // ceil(2^16 / (W/16))
-    uint4 pre[kDepth][kLoads];
-    auto fetch = [&](uint4 (&dst)[kLoads], long long c) {
-        const long long cbase = c * (long long)chunk_bytes;
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) {
-            const int off = i * 1024 + lane * 16;
-            const long long g = cbase + off;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (off < chunk_bytes) {
-                if (g + 16 <= total_bytes) {
-                    // once-read stream: non-temporal policy (plain loads: 5.1 TB/s, nt: 6.2 TB/s on
-                    // the same byte mix, scripts/micro/stream_bw_nt.hip)
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(kmers + g));
-                    v = make_uint4(t.x, t.y, t.z, t.w);
-                } else if (g < total_bytes) {  // ragged end of the matrix: byte loads
-                    unsigned t[4] = {0u, 0u, 0u, 0u};
-                    for (int b = 0; b < 16 && g + b < total_bytes; ++b)
-                        t[b >> 2] |= (unsigned)kmers[g + b] << (8 * (b & 3));
-                    v = make_uint4(t[0], t[1], t[2], t[3]);
-                }
-            }
-            dst[i] = v;
-        }
-    };
-
-    long long *hitq[MM];
-    int qn[MM];  // wave-uniform
-#pragma unroll
-    for (int m = 0; m < MM; ++m) {
-        hitq[m] = reinterpret_cast<long long *>(stage + stage_data_bytes(W)) + m * kHitQueue;
-        qn[m] = 0;
-        if (a.m[m].cutoff != GFM_NO_SELECT && blockIdx.x == 0 && tid == 0)
-            a.m[m].ctl->snap[a.m[m].slot] = a.m[m].hit_count ? *a.m[m].hit_count : 0ull;
-    }
-
-    long long c = (long long)blockIdx.x * kWaves + wave;
-#pragma unroll
-    for (int d = 0; d < kDepth; ++d)
-        if (c + d * cstride < nchunks) fetch(pre[d], c + d * cstride);
-    while (c < nchunks) {
-#pragma unroll
-    for (int d = 0; d < kDepth; ++d) {
-        if (c >= nchunks) break;
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) {
-            const int off = i * 1024 + lane * 16;
-            if (off < chunk_bytes) {
-                if (pad) {   // W % 16 == 0: the 16-byte piece lies inside row off / W
-                    const unsigned r = ((unsigned)(off >> 4) * pad_inv) >> 16;
-                    unsigned *dst = reinterpret_cast<unsigned *>(stage + off + 4 * r);
-                    dst[0] = pre[d][i].x;
-                    dst[1] = pre[d][i].y;
-                    dst[2] = pre[d][i].z;
-                    dst[3] = pre[d][i].w;
-                } else {
-                    *reinterpret_cast<uint4 *>(stage + off) = pre[d][i];
-                }
-            }
-        }
-        if (c + kDepth * cstride < nchunks) fetch(pre[d], c + kDepth * cstride);
-        // LDS ops of one wave execute in program order; the fence only pins the compiler.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-#pragma unroll
-        for (int p = 0; p < kChunk / kWave; ++p) {
-            const int k = p * kWave + lane;
-            const long long row = c * kChunk + k;
-            const int boff = k * (W + pad);
-            const unsigned sh = (unsigned)(boff & 3) * 8u;
-            const unsigned *src = reinterpret_cast<const unsigned *>(stage + (boff & ~3));
-            unsigned w[NDW + 1];
-#pragma unroll
-            for (int d2 = 0; d2 <= NDW; ++d2) w[d2] = src[d2];
-            int acc[MM];
-            bool any_n;
-            if constexpr (MM == 1) {
-                int s1 = 0;
-#pragma unroll
-                for (int d2 = 0; d2 < NDW; ++d2) {
-                    const unsigned x = __builtin_amdgcn_alignbit(w[d2 + 1], w[d2], sh);
-                    const unsigned xm = x & 0x0E0E0E0Eu;   // 2 * ((c >> 1) & 7) per byte
-                    const unsigned y = xm | (xm >> 5);     // bytes 0 and 2: 2*(code_lo + 8*code_hi)
-                    const unsigned e0 = y & 0x7Eu;
-                    const unsigned e1 = (y >> 16) & 0x7Eu;
-                    s1 += *reinterpret_cast<const uint16_t *>(tab + (2 * d2) * 128 + e0);
-                    s1 += *reinterpret_cast<const uint16_t *>(tab + (2 * d2 + 1) * 128 + e1);
-                }
-                any_n = (unsigned)s1 >= kPoison;
-                acc[0] = s1;
-            } else {
-                unsigned long long s64 = 0;
-#pragma unroll
-                for (int d2 = 0; d2 < NDW; ++d2) {
-                    const unsigned x = __builtin_amdgcn_alignbit(w[d2 + 1], w[d2], sh);
-                    const unsigned xm = x & 0x0E0E0E0Eu;
-                    const unsigned y = xm | (xm >> 5);
-                    const unsigned e0 = (y & 0x7Eu) << 2;            // 8-byte entries
-                    const unsigned e1 = ((y >> 16) & 0x7Eu) << 2;
-                    s64 += *reinterpret_cast<const unsigned long long *>(tab + (2 * d2) * 512 + e0);
-                    s64 += *reinterpret_cast<const unsigned long long *>(tab + (2 * d2 + 1) * 512 + e1);
-                }
-                any_n = (s64 >> 57) != 0;
-#pragma unroll
-                for (int m = 0; m < MM; ++m) acc[m] = (int)((s64 >> (19 * m)) & 0x7FFFFull);
-            }
-            const bool live = row < n;
-#pragma unroll
-            for (int m = 0; m < MM; ++m) {
-                const MotifArgs &ma = a.m[m];
-                const bool is_n = any_n;
-                const int score = is_n ? ma.min_val : acc[m];
-                if (live) {
-                    __builtin_nontemporal_store(score, ma.scores + row);   // written once, read later
-                    if (ma.use_hist) {
-                        const unsigned off = (unsigned)(score - ma.lo);
-                        if (is_n || off < (unsigned)ma.nb)
-                            atomicAdd(&hist[m][is_n ? (unsigned)ma.nb : off], 1u);
-                        else
-                            atomicAdd(&ma.spill[score - ma.spill_lo], 1u);   // outside the window: rare
-                    }
-                }
-                if (ma.cutoff != GFM_NO_SELECT)
-                    hitq_push(hitq[m], qn[m], live && score >= ma.cutoff,
-                              ((row_base + row) << GFM_HIT_SCORE_BITS) | (long long)score, lane,
-                              ma.hit_count, &ma.ctl->mid[ma.slot], ma.hit_rows, ma.hit_cap);
-            }
-        }
-        // the strip is rewritten next iteration: keep this iteration's reads ahead of it
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        c += cstride;
-    }
-    }
-
-    // the lookup tables are dead once every wave has left the loop: their LDS holds the per-wave
-    // queue lengths (no static LDS)
-    __syncthreads();
-#pragma unroll
-    for (int m = 0; m < MM; ++m) {
-        const MotifArgs &ma = a.m[m];
-        if (ma.cutoff != GFM_NO_SELECT)
-            hitq_finish<kWaves>(hitq[m], qn[m], reinterpret_cast<int *>(tab + m * kTabBytes), wave,
-                                     lane, tid, ma.resid, ma.resid_n);
-        if (ma.use_hist) {
-            unsigned *slab = ma.partials + (size_t)blockIdx.x * (size_t)(ma.nb + 1);
-            for (int i = tid; i <= ma.nb; i += kWgThreads) slab[i] = hist[m][i];
-        }
-    }
-}
-
-// post_kernel: everything that follows a scoring / selection kernel, in one launch.
-//  blocks [0, hist_blocks): sum the per-workgroup histogram slabs into the caller's uint64
-//    histogram (bin lo+b; the extra slab bin counts N rows, which score min_val).  A block owns
-//    256 bins x kSlabsPerGroup slabs: enough blocks to pull the slabs at L2/HBM rate instead of
-//    one latency-bound column walk per bin.
-//  blocks [hist_blocks, hist_blocks + spill_blocks): add the spill counters (rows outside a partial
-//    LDS window) and hand them back zeroed.
-//  the remaining hit_slabs blocks: append residual hit slab g to the dense list at
-//    snap + mid + (counts of slabs < g); the first of them publishes the new *hit_count and
-//    zeroes the mid-run counter two calls ahead.
-constexpr int kSlabsPerGroup = 16;
-__global__ void __launch_bounds__(256)
-post_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, int min_val,
-            unsigned long long *__restrict__ hist64, int bin_blocks, int hist_blocks,
-            unsigned *__restrict__ spill, int spill_lo, int spill_n, int spill_blocks,
-            const long long *__restrict__ resid, const int *__restrict__ resid_n, int hit_slabs,
-            HitCtl *__restrict__ ctl, int par, long long *__restrict__ hit_rows, long long hit_cap,
-            unsigned long long *__restrict__ hit_count)
-{
-    const int tid = threadIdx.x;
-    if ((int)blockIdx.x < hist_blocks) {
-        const int bx = blockIdx.x % bin_blocks, by = blockIdx.x / bin_blocks;
-        const int b = bx * 256 + tid;
-        if (b > nb) return;
-        const int g0 = by * kSlabsPerGroup;
-        const int g1 = min(g0 + kSlabsPerGroup, nslabs);
-        unsigned long long s = 0;
-        const size_t stride = (size_t)(nb + 1);
-#pragma unroll 8
-        for (int g = g0; g < g1; ++g) s += partials[g * stride + b];
-        if (s) atomicAdd(&hist64[b == nb ? min_val : lo + b], s);
-        return;
-    }
-    if ((int)blockIdx.x < hist_blocks + spill_blocks) {
-        const int b = ((int)blockIdx.x - hist_blocks) * 256 + tid;
-        if (b < spill_n) {
-            const unsigned v = spill[b];
-            if (v) {
-                atomicAdd(&hist64[spill_lo + b], (unsigned long long)v);
-                spill[b] = 0u;
-            }
-        }
-        return;
-    }
-    __shared__ int part[256];
-    __shared__ int part_all[256];
-    const int g = blockIdx.x - hist_blocks - spill_blocks;
-    int s = 0, sa = 0;
-    for (int k = tid; k < hit_slabs; k += 256) {
-        const int v = resid_n[k];
-        sa += v;
-        if (k < g) s += v;
-    }
-    part[tid] = s;
-    part_all[tid] = sa;
-    __syncthreads();
-    for (int d = 128; d > 0; d >>= 1) {
-        if (tid < d) { part[tid] += part[tid + d]; part_all[tid] += part_all[tid + d]; }
-        __syncthreads();
-    }
-    const unsigned long long start = ctl->snap[par] + ctl->mid[par];
-    const unsigned long long base = start + (unsigned long long)part[0];
-    const int cnt = resid_n[g];
-    const long long *slab = resid + (size_t)g * kResidPerWG;
-    for (int i = tid; i < cnt; i += 256)
-        if ((long long)(base + i) < hit_cap) hit_rows[base + i] = slab[i];
-    if (g == 0 && tid == 0) {
-        *hit_count = start + (unsigned long long)part_all[0];
-        ctl->mid[(par + 2) % 3] = 0ull;
-    }
-}
-
-// Rows with score >= *cutoff -> hit list (separate pass; used when the cutoff depends on
-// the global histogram, i.e. --qvalueT).  Same queue / slab scheme as the fused selection.
-constexpr int kSelThreads = 256;
-__global__ void __launch_bounds__(kSelThreads)
-select_hits_kernel(const int *__restrict__ scores, long long n, const int *__restrict__ cutoff_ptr,
-                   long long row_base, long long *__restrict__ hit_rows, long long hit_cap,
-                   const unsigned long long *__restrict__ hit_count, HitCtl *__restrict__ ctl,
-                   int par, long long *__restrict__ resid, int *__restrict__ resid_n)
-{
-    __shared__ long long hq[kSelThreads / kWave][kHitQueue];
-    __shared__ int wq_n[kSelThreads / kWave];
-    const int cutoff = *cutoff_ptr;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    long long *hitq = hq[wave];
-    int qn = 0;
-    if (blockIdx.x == 0 && tid == 0) ctl->snap[par] = hit_count ? *hit_count : 0ull;
-    const long long nthreads = (long long)gridDim.x * blockDim.x;
-    const long long n4 = (n + 3) >> 2;
-    const long long iters = (n4 + nthreads - 1) / nthreads;  // wave-uniform trip count
-    const long long t0 = (long long)blockIdx.x * blockDim.x + tid;
-    for (long long it = 0; it < iters; ++it) {
-        const long long i = t0 + it * nthreads;
-        int sc[4] = {INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN};
-        if (i * 4 + 4 <= n) {
-            const int4 v = reinterpret_cast<const int4 *>(scores)[i];
-            sc[0] = v.x; sc[1] = v.y; sc[2] = v.z; sc[3] = v.w;
-        } else {
-            for (int j = 0; j < 4; ++j)
-                if (i * 4 + j < n) sc[j] = scores[i * 4 + j];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            hitq_push(hitq, qn, sc[j] >= cutoff,
-                      ((row_base + i * 4 + j) << GFM_HIT_SCORE_BITS) | (long long)sc[j], lane,
-                      hit_count, &ctl->mid[par], hit_rows, hit_cap);
-    }
-    hitq_finish<kSelThreads / kWave>(hitq, qn, wq_n, wave, lane, tid, resid, resid_n);
-}
-
-// ---------------------------------------------------------------------------------------
-// pvalue_dp_kernel: score-distribution DP of comp_pval_mat (motif_processing.pyx:552-603),
-// one 1024-thread workgroup per motif, gather form:
-//   cur[t] = sum over n in A,C,G,T of prev[t - sm[n][pos]] * bg[n]
-// accumulated per target in A->C->G->T order with the product rounded before the add
-// (__dmul_rn/__dadd_rn: no FMA contraction) and the reference's `> 0` support test.  The
-// reference scatters, but each (n, idx) pair hits a distinct target once per n and n runs
-// outermost, so per target the additions arrive in exactly this order: bit-identical.
-// Rows ping-pong in global memory (they live in L2: 2*L*8 B <= 1 MB); only the reachable
-// window [cum_lo[pos], cum_hi[pos]] of a row is computed or read.
-constexpr int kDpThreads = 1024;
-
-__global__ void __launch_bounds__(kDpThreads)
-pvalue_dp_kernel(const int *__restrict__ sm, const double *__restrict__ bg, int W, int L,
-                 const int *__restrict__ cum_lo, const int *__restrict__ cum_hi,
-                 double *__restrict__ buf, double *__restrict__ pmf_out)
-{
-    double *cur = buf;
-    double *prev = buf + L;
-    const int tid = threadIdx.x;
-    {   // position 0 (motif_processing.pyx:593-594)
-        const int l0 = cum_lo[0], h0 = cum_hi[0];
-        for (int t = l0 + tid; t <= h0; t += kDpThreads) cur[t] = 0.0;
-        __syncthreads();
-        if (tid == 0)
-            for (int nuc = 0; nuc < 4; ++nuc) {
-                const int s = sm[nuc * W];
-                cur[s] = __dadd_rn(cur[s], __dmul_rn(1.0, bg[nuc]));
-            }
-        __syncthreads();
-    }
-    for (int pos = 1; pos < W; ++pos) {
-        double *tmp = cur; cur = prev; prev = tmp;
-        const int lp = cum_lo[pos - 1], hp = cum_hi[pos - 1];
-        const int lc = cum_lo[pos], hc = cum_hi[pos];
-        const int s0 = sm[0 * W + pos], s1 = sm[1 * W + pos], s2 = sm[2 * W + pos],
-                  s3 = sm[3 * W + pos];
-        const double b0 = bg[0], b1 = bg[1], b2 = bg[2], b3 = bg[3];
-        for (int t = lc + tid; t <= hc; t += kDpThreads) {
-            double acc = 0.0;
-            int idx = t - s0;
-            if (idx >= lp && idx <= hp) { const double v = prev[idx]; if (v > 0) acc = __dadd_rn(acc, __dmul_rn(v, b0)); }
-            idx = t - s1;
-            if (idx >= lp && idx <= hp) { const double v = prev[idx]; if (v > 0) acc = __dadd_rn(acc, __dmul_rn(v, b1)); }
-            idx = t - s2;
-            if (idx >= lp && idx <= hp) { const double v = prev[idx]; if (v > 0) acc = __dadd_rn(acc, __dmul_rn(v, b2)); }
-            idx = t - s3;
-            if (idx >= lp && idx <= hp) { const double v = prev[idx]; if (v > 0) acc = __dadd_rn(acc, __dmul_rn(v, b3)); }
-            cur[t] = acc;
-        }
-        __syncthreads();
-    }
-    const int lf = cum_lo[W - 1], hf = cum_hi[W - 1];
-    for (int t = tid; t < L; t += kDpThreads) pmf_out[t] = (t >= lf && t <= hf) ? cur[t] : 0.0;
-}
-
-// ---------------------------------------------------------------------------------------
-// block-wide scans over a table of L entries split into 1024 contiguous segments
-constexpr int kScanThreads = 1024;
-
-// p_table[s] = (sum_{t>=s} pmf[t]) / (sum_t pmf[t])   -- O(1) form of
-// `pval_mat[score:].sum() / pval_mat.sum()` (score_sequences.py:390-391).
-// Blocked suffix sum that stays EXACTLY monotone: thread t sums its contiguous segment top-down
-// (local running sums L_j), one lane chains the 1024 segment totals top-down (carry c_t), and
-// suffix[j] = c_t + L_j.  fl(c + L) is monotone in L, and at a segment's bottom c_t + L = c_t + s_t
-// is the very operation that produced the carry of the segment below, so no boundary can step
-// the wrong way; p_table[s] == 1.0 exactly for every s at or below the lowest reachable score.
-// (A scan with mixed association orders broke monotonicity by 1 ulp; a fully sequential chain
-// took 0.5 ms.)
-__global__ void __launch_bounds__(kScanThreads)
-ptable_kernel(const double *__restrict__ pmf, int L, int lo, int hi, double *__restrict__ ptable)
-{
-    __shared__ double carry[kScanThreads];
-    __shared__ double tot_s;
-    const int tid = threadIdx.x;
-    const int nb = hi - lo + 1;
-    const int per = (nb + kScanThreads - 1) / kScanThreads;
-    const int a = lo + min(tid * per, nb), b = lo + min(tid * per + per, nb);
-    double run = 0.0;
-    for (int j = b - 1; j >= a; --j) {
-        run += pmf[j];
-        ptable[j] = run;        // local running sum, finished below
-    }
-    carry[tid] = run;
-    __syncthreads();
-    if (tid == 0) {
-        double c = 0.0;
-        for (int t = kScanThreads - 1; t >= 0; --t) {
-            const double s = carry[t];
-            carry[t] = c;       // everything above segment t
-            c = c + s;
-        }
-        tot_s = c;
-    }
-    __syncthreads();
-    const double c = carry[tid], tot = tot_s;
-    for (int j = a; j < b; ++j) ptable[j] = (c + ptable[j]) / tot;
-    for (int j = tid; j < lo; j += kScanThreads) ptable[j] = tot / tot;
-    for (int j = hi + 1 + tid; j < L; j += kScanThreads) ptable[j] = 0.0;
-}
-
-// q-value of every score from the histogram (Benjamini-Hochberg as statsmodels'
-// fdrcorrection evaluates it: raw = p / (rank/n), reverse cumulative minimum, clip 1),
-// plus the selection cutoff.  Ranks: all rows sharing a score share a p-value; the
-// largest rank in the tie group is C(s) = #rows with score >= s, and the cumulative
-// minimum makes the whole group take p(s) / (C(s)/n).
-// Only the reachable window [lo, hi] can hold counts, plus bin min_val for rows with an N
-// (below the window: p = 1, rank = n, raw = 1).
-//
-// Three small multi-block kernels, one bin per thread (256-thread blocks, a handful of
-// registers), instead of one big workgroup: a 1024-thread workgroup holding the window in
-// registers needs an EMPTY CU, and next to the persistent score grid it found none -- on the
-// tail stream it simply waited for the score kernel to end (measured: 19 us alone, 76-95 us
-// "overlapped", gating the pipeline).  Small blocks slot in beside resident score workgroups.
-//   q_count_kernel : per-block bin totals
-//   q_raw_kernel   : C(s) by block-suffix + in-block scan, raw(s) -> qtable (temporary), block minima
-//   q_final_kernel : prefix minimum -> q(s), cutoff, clears
-constexpr int kQThreads = 256;
-struct QWork {
-    unsigned long long blk_cnt[256];
-    double blk_min[256];
-    unsigned long long n_rows_N;
-};
-
-__device__ inline unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sh)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
-    if (lane == 0) sh[wave] = v;
-    __syncthreads();
-    unsigned long long t = 0;
-#pragma unroll
-    for (int w = 0; w < kQThreads / kWave; ++w) t += sh[w];
-    __syncthreads();
-    return t;
-}
-
-__global__ void __launch_bounds__(kQThreads)
-q_count_kernel(const unsigned long long *__restrict__ hist, int L, int lo, int hi, int min_val,
-               QWork *__restrict__ ws, int *__restrict__ cutoff_out)
-{
-    __shared__ unsigned long long sh[kQThreads / kWave];
-    const int j = lo + blockIdx.x * kQThreads + threadIdx.x;
-    const unsigned long long h = j <= hi ? hist[j] : 0ull;
-    const unsigned long long tot = block_sum_u64(h, sh);
-    if (threadIdx.x == 0) {
-        ws->blk_cnt[blockIdx.x] = tot;
-        if (blockIdx.x == 0) {
-            const bool n_outside = min_val < lo || min_val > hi;
-            ws->n_rows_N = n_outside ? hist[min_val] : 0ull;
-            if (cutoff_out) *cutoff_out = L;
-        }
-    }
-}
-
-__global__ void __launch_bounds__(kQThreads)
-q_raw_kernel(const unsigned long long *__restrict__ hist, const double *__restrict__ ptable, int lo,
-             int hi, QWork *__restrict__ ws, double *__restrict__ raw_out)
-{
-    __shared__ unsigned long long sh[kQThreads / kWave];
-    __shared__ double shm[kQThreads / kWave];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nblk = gridDim.x, blk = blockIdx.x;
-    // totals: all rows, and the rows in blocks above this one
-    unsigned long long a = 0, t = 0;
-    for (int b = tid; b < nblk; b += kQThreads) {
-        const unsigned long long v = ws->blk_cnt[b];
-        t += v;
-        if (b > blk) a += v;
-    }
-    const unsigned long long n = block_sum_u64(t, sh) + ws->n_rows_N;
-    const unsigned long long above_blocks = block_sum_u64(a, sh);
-    const double nd = (double)n;
-    const int j = lo + blk * kQThreads + tid;
-    const bool ok = j <= hi;
-    const unsigned long long h = ok ? hist[j] : 0ull;
-    // inclusive suffix sum inside the block
-    unsigned long long cs = h;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const unsigned long long v = __shfl_down(cs, d);
-        if (lane + d < kWave) cs += v;
-    }
-    if (lane == 0) sh[wave] = cs;
-    __syncthreads();
-    unsigned long long waves_above = 0;
-#pragma unroll
-    for (int w = 0; w < kQThreads / kWave; ++w)
-        if (w > wave) waves_above += sh[w];
-    const unsigned long long c_ge = cs + waves_above + above_blocks;
-    const double raw = h ? ptable[j] / ((double)c_ge / nd) : INFINITY;
-    if (ok) raw_out[j] = raw;
-    double m = raw;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) m = fmin(m, __shfl_down(m, d));
-    if (lane == 0) shm[wave] = m;
-    __syncthreads();
-    if (tid == 0) {
-        double bm = INFINITY;
-        for (int w = 0; w < kQThreads / kWave; ++w) bm = fmin(bm, shm[w]);
-        ws->blk_min[blk] = bm;
-    }
-}
-
-__global__ void __launch_bounds__(kQThreads)
-q_final_kernel(const unsigned long long *hist, const double *__restrict__ ptable, int L, int lo,
-               int hi, int min_val, double threshold, int on_qvalue, const QWork *__restrict__ ws,
-               double *qtable, int *__restrict__ cutoff_out, unsigned long long *__restrict__ nrows_out,
-               unsigned long long *__restrict__ clear)
-{
-    __shared__ unsigned long long sh[kQThreads / kWave];
-    __shared__ double shm[kQThreads / kWave];
-    __shared__ int first_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nblk = gridDim.x, blk = blockIdx.x;
-    if (tid == 0) first_s = L;
-    unsigned long long t = 0;
-    double below = INFINITY, all = INFINITY;
-    for (int b = tid; b < nblk; b += kQThreads) {
-        t += ws->blk_cnt[b];
-        const double v = ws->blk_min[b];
-        all = fmin(all, v);
-        if (b < blk) below = fmin(below, v);
-    }
-    const unsigned long long n_rows_N = ws->n_rows_N;
-    const unsigned long long n = block_sum_u64(t, sh) + n_rows_N;
-    const double nd = (double)n;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        below = fmin(below, __shfl_down(below, d));
-        all = fmin(all, __shfl_down(all, d));
-    }
-    __shared__ double shb[kQThreads / kWave], sha[kQThreads / kWave];
-    if (lane == 0) { shb[wave] = below; sha[wave] = all; }
-    __syncthreads();
-    below = INFINITY; all = INFINITY;
-#pragma unroll
-    for (int w = 0; w < kQThreads / kWave; ++w) { below = fmin(below, shb[w]); all = fmin(all, sha[w]); }
-    // rows holding an N sit below every other score: rank n, p = p_table[min_val] (= 1)
-    const double base = n_rows_N ? ptable[min_val] / (nd / nd) : INFINITY;
-    const int j = lo + blk * kQThreads + tid;
-    const bool ok = j <= hi;
-    double ms = ok ? qtable[j] : INFINITY;   // raw value left by q_raw_kernel
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const double v = __shfl_up(ms, d);
-        if (lane >= d) ms = fmin(ms, v);
-    }
-    if (lane == kWave - 1) shm[wave] = ms;
-    __syncthreads();
-    double waves_below = INFINITY;
-#pragma unroll
-    for (int w = 0; w < kQThreads / kWave; ++w)
-        if (w < wave) waves_below = fmin(waves_below, shm[w]);
-    const double q = fmin(fmin(fmin(ms, waves_below), fmin(below, base)), 1.0);
-    if (ok) {
-        qtable[j] = q;
-        const double val = on_qvalue ? q : ptable[j];
-        if (val < threshold) atomicMin(&first_s, j);
-        if (clear) clear[j] = 0ull;
-    }
-    // outside the window: 1 below it (p = 1 there), the last running minimum above it
-    const int gtid = blk * kQThreads + tid, gsz = nblk * kQThreads;
-    const double q_above = fmin(fmin(base, all), 1.0);
-    for (int jj = gtid; jj < lo; jj += gsz) qtable[jj] = fmin(base, 1.0);
-    for (int jj = hi + 1 + gtid; jj < L; jj += gsz) qtable[jj] = q_above;
-    __syncthreads();
-    if (tid == 0) {
-        if (cutoff_out && first_s < L) atomicMin(cutoff_out, first_s);
-        if (blk == 0) {
-            if (nrows_out) *nrows_out = n;
-            const bool n_outside = min_val < lo || min_val > hi;
-            if (clear && n_outside) clear[min_val] = 0ull;
-        }
-    }
-}
-
-}  // namespace
+#include "gfm_common.hpp"
+#include "gfm_score_kernels.hpp"
+#include "gfm_stats_kernels.hpp"
 
 // =======================================================================================
 // host side
