@@ -56,7 +56,8 @@ __device__ inline void hitq_push(long long *hitq, int &qn, bool hit, long long e
                                  const unsigned long long *hit_count, unsigned long long *mid,
                                  long long *hit_rows, long long hit_cap)
 {
-    const unsigned long long mask = __ballot(hit);
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);   // (HIP's __ballot(int) would
+                                                                          // materialise the bool in a VGPR)
     if (!mask) return;
     const int nh = __popcll(mask);
     if (qn + nh > kHitQueue) {
@@ -130,6 +131,17 @@ struct MotifArgs {
 };
 template <int MM> struct ScoreArgs { MotifArgs m[MM]; };
 
+// LDS reads of the inner loop go through address-space-3 pointers built from 32-bit offsets: the
+// dynamic LDS of this kernel starts at offset 0 (it has no static LDS; checked at entry), so a table
+// index IS the address and constant offsets fold into the instruction instead of costing a v_add each
+typedef __attribute__((address_space(3))) const unsigned lds_cu32;
+typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+__device__ inline unsigned lds_offset(const void *p)
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
+}
+
 template <int NDW, int MM>
 __global__ void __launch_bounds__(waves_for_ndw(NDW) * kWave)
 score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long long row_base,
@@ -146,6 +158,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
     // bits 57.., a count of invalid codes: one ds_read_b64 + one 64-bit add per base pair serves
     // all motifs of the launch, so the inner loop costs the same for 1, 2 or 3 motifs.
     constexpr int kTabRegion = (MM == 1 ? 1 : 4) * kTabBytes;
+    if (lds_offset(smem) != 0u) __builtin_trap();   // the lookups below use absolute LDS offsets
     unsigned char *tab = smem;
     unsigned char *stage_base = smem + kTabRegion;
     const int sstride = stage_stride_bytes(W, MM);
@@ -161,7 +174,9 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
-    const int wave = tid >> 6;
+    // wave-uniform by construction; readfirstlane tells the compiler, so the chunk index, the strip
+    // address and the row/score addressing of a chunk stay in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     if constexpr (MM == 1) {
         for (int i = tid; i < kTabBytes / 2; i += kWgThreads)
@@ -187,6 +202,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
     __syncthreads();
 
     unsigned char *stage = stage_base + wave * sstride;
+    const unsigned stage_off = (unsigned)(kTabRegion + wave * sstride);   // its absolute LDS offset
     const long long total_bytes = n * (long long)W;
     const long long nchunks = (n + kChunk - 1) / kChunk;
     const int chunk_bytes = kChunk * W;
@@ -239,6 +255,8 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) {
         if (c >= nchunks) break;
+        const long long crow = c * kChunk;                                        // first row of the chunk
+        const int rem = (int)((n - crow) < (long long)kChunk ? (n - crow) : (long long)kChunk);  // live rows
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
             const int off = i * 1024 + lane * 16;
@@ -263,10 +281,9 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
 #pragma unroll
         for (int p = 0; p < kChunk / kWave; ++p) {
             const int k = p * kWave + lane;
-            const long long row = c * kChunk + k;
             const int boff = k * (W + pad);
             const unsigned sh = (unsigned)(boff & 3) * 8u;
-            const unsigned *src = reinterpret_cast<const unsigned *>(stage + (boff & ~3));
+            lds_cu32 *src = (lds_cu32 *)(stage_off + (unsigned)(boff & ~3));
             unsigned w[NDW + 1];
 #pragma unroll
             for (int d2 = 0; d2 <= NDW; ++d2) w[d2] = src[d2];
@@ -277,12 +294,14 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
 #pragma unroll
                 for (int d2 = 0; d2 < NDW; ++d2) {
                     const unsigned x = __builtin_amdgcn_alignbit(w[d2 + 1], w[d2], sh);
-                    const unsigned xm = x & 0x0E0E0E0Eu;   // 2 * ((c >> 1) & 7) per byte
-                    const unsigned y = xm | (xm >> 5);     // bytes 0 and 2: 2*(code_lo + 8*code_hi)
+                    // one bit-select: bits 1..3 of each 16-bit half from x (first base of a pair), the
+                    // other bits from x >> 5 (bits 4..6: second base); then one mask per table offset
+                    unsigned y;
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(0x000E000Eu), "v"(x), "v"(x >> 5));
                     const unsigned e0 = y & 0x7Eu;
                     const unsigned e1 = (y >> 16) & 0x7Eu;
-                    s1 += *reinterpret_cast<const uint16_t *>(tab + (2 * d2) * 128 + e0);
-                    s1 += *reinterpret_cast<const uint16_t *>(tab + (2 * d2 + 1) * 128 + e1);
+                    s1 += *(lds_cu16 *)(e0 + (unsigned)((2 * d2) * 128));
+                    s1 += *(lds_cu16 *)(e1 + (unsigned)((2 * d2 + 1) * 128));
                 }
                 any_n = (unsigned)s1 >= kPoison;
                 acc[0] = s1;
@@ -291,25 +310,25 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
 #pragma unroll
                 for (int d2 = 0; d2 < NDW; ++d2) {
                     const unsigned x = __builtin_amdgcn_alignbit(w[d2 + 1], w[d2], sh);
-                    const unsigned xm = x & 0x0E0E0E0Eu;
-                    const unsigned y = xm | (xm >> 5);
+                    unsigned y;
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(0x000E000Eu), "v"(x), "v"(x >> 5));
                     const unsigned e0 = (y & 0x7Eu) << 2;            // 8-byte entries
                     const unsigned e1 = ((y >> 16) & 0x7Eu) << 2;
-                    s64 += *reinterpret_cast<const unsigned long long *>(tab + (2 * d2) * 512 + e0);
-                    s64 += *reinterpret_cast<const unsigned long long *>(tab + (2 * d2 + 1) * 512 + e1);
+                    s64 += *(lds_cu64 *)(e0 + (unsigned)((2 * d2) * 512));
+                    s64 += *(lds_cu64 *)(e1 + (unsigned)((2 * d2 + 1) * 512));
                 }
                 any_n = (s64 >> 57) != 0;
 #pragma unroll
                 for (int m = 0; m < MM; ++m) acc[m] = (int)((s64 >> (19 * m)) & 0x7FFFFull);
             }
-            const bool live = row < n;
+            const bool live = k < rem;
 #pragma unroll
             for (int m = 0; m < MM; ++m) {
                 const MotifArgs &ma = a.m[m];
                 const bool is_n = any_n;
                 const int score = is_n ? ma.min_val : acc[m];
                 if (live) {
-                    __builtin_nontemporal_store(score, ma.scores + row);   // written once, read later
+                    __builtin_nontemporal_store(score, ma.scores + crow + k);   // scalar base + lane offset
                     if (ma.use_hist) {
                         const unsigned off = (unsigned)(score - ma.lo);
                         if (is_n || off < (unsigned)ma.nb)
@@ -320,7 +339,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
                 }
                 if (ma.cutoff != GFM_NO_SELECT)
                     hitq_push(hitq[m], qn[m], live && score >= ma.cutoff,
-                              ((row_base + row) << GFM_HIT_SCORE_BITS) | (long long)score, lane,
+                              ((row_base + crow + k) << GFM_HIT_SCORE_BITS) | (long long)score, lane,
                               ma.hit_count, &ma.ctl->mid[ma.slot], ma.hit_rows, ma.hit_cap);
             }
         }
