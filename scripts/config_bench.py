@@ -34,6 +34,31 @@ def device_kmers(n, W, probs, seed):
     return out
 
 
+def torch_scores(d, sm, min_val):
+    """plain torch restatement of compute_score_seq's integer part (score_sequences.py:370-388) on the
+    device: the full-size cross-check of the HIP scores (exact integers)"""
+    n, W = d.shape
+    lut = torch.full((256,), 4, dtype=torch.int64, device=dev)
+    for ch, c in ((b"Aa", 0), (b"Cc", 1), (b"Gg", 2), (b"Tt", 3)):
+        for b_ in ch:
+            lut[b_] = c
+    smt = torch.tensor(np.asarray(sm, dtype=np.int64), device=dev)            # [4, W]
+    smt = torch.cat([smt, torch.zeros((1, W), dtype=torch.int64, device=dev)])  # row 4: N
+    out = torch.empty(n, dtype=torch.int32, device=dev)
+    step = 10_000_000
+    for a in range(0, n, step):
+        blk = d[a:a + step]
+        acc = torch.zeros(blk.shape[0], dtype=torch.int64, device=dev)
+        has_n = torch.zeros(blk.shape[0], dtype=torch.bool, device=dev)
+        for j in range(W):
+            code = lut[blk[:, j].long()]
+            acc += smt[:, j][code]
+            has_n |= code == 4
+        acc[has_n] = min_val
+        out[a:a + step] = acc.to(torch.int32)
+    return out
+
+
 def timed(f, reps):
     f(); torch.cuda.synchronize()
     t = time.perf_counter()
@@ -53,8 +78,12 @@ sc = KmerScanner(dm, n, hit_capacity=n // 32, device=dev)
 dm.profile_enable(64, 1)
 dt = timed(lambda: sc.enqueue(d, 1e-4), 20); sc.finish(); torch.cuda.synchronize()
 kms = dm.profile_read(); dm.profile_enable(0)
+slot = sc.slots[(sc._turn - 1) % 2]
+ref = torch_scores(d, m.dense_score_matrix(), m.min_val)
+ok = bool(torch.equal(slot.scores[:n], ref))
 res["config3_shard"] = dict(rows=n, W=19, step_ms=dt * 1e3, kmers_per_s=n / dt, score_kernel_ms=float(kms.mean()),
-                            achieved_GBps=n * 23 / (float(kms.mean()) * 1e-3) / 1e9)
+                            achieved_GBps=n * 23 / (float(kms.mean()) * 1e-3) / 1e9, scores_equal_torch_reference=ok)
+del ref
 del d, sc; dm.close(); torch.cuda.empty_cache()
 
 # ---- config 4: W=30 JASPAR-style, 1e8 rows, --qvalueT -t 1e-4
@@ -71,7 +100,10 @@ dm.profile_enable(64, 1)
 dt = timed(lambda: sc.enqueue(d, 1e-4, on_qvalue=True), 20); sc.finish(); torch.cuda.synchronize()
 kms = dm.profile_read(); dm.profile_enable(0)
 r = sc.collect(sc.slots[(sc._turn - 1) % 2])
-res["config4"] = dict(rows=n, W=30, window_bins=dm.score_hi - dm.score_lo + 1, threshold="q<1e-4", hits=int(len(r["rows"])),
+ref = torch_scores(d, sm, mn)
+ok4 = bool(torch.equal(sc.slots[(sc._turn - 1) % 2].scores[:n], ref))
+del ref
+res["config4"] = dict(scores_equal_torch_reference=ok4, rows=n, W=30, window_bins=dm.score_hi - dm.score_lo + 1, threshold="q<1e-4", hits=int(len(r["rows"])),
                       step_ms=dt * 1e3, kmers_per_s=n / dt, score_kernel_ms=float(kms.mean()),
                       achieved_GBps=n * 34 / (float(kms.mean()) * 1e-3) / 1e9)
 del d, sc; dm.close(); torch.cuda.empty_cache()
@@ -85,6 +117,7 @@ for W in (8, 12, 19, 25):
         bg = rng.dirichlet(50 * synth.BG_NT)
         smk, mnk, mxk, sck, offk = scale_pwm_dense(compute_log_odds_dense(pr, bg))
         motifs.append(DeviceMotif(smk, bg, mnk, sck, offk)); pl = pr
+        motifs[-1].sm_host, motifs[-1].min_val_host = smk, mnk
     n = 100_000_000
     d = device_kmers(n, W, pl, 50 + W)
     scores = [torch.empty(n, dtype=torch.int32, device=dev) for _ in motifs]
@@ -99,8 +132,10 @@ for W in (8, 12, 19, 25):
             mo.score(d, scores[j], hist=hists[j], select_cutoff=cuts[j], hit_rows=hits[j][1:], hit_count=hits[j][:1],
                      reset_hits=True)
     tb, ts = timed(batched, 10), timed(separate, 10)
+    batched(); torch.cuda.synchronize()
+    ok5 = all(bool(torch.equal(scores[j], torch_scores(d, mo.sm_host, mo.min_val_host))) for j, mo in enumerate(motifs))
     cfg5.append(dict(W=W, motifs=3, rows=n, batched_ms=tb * 1e3, separate_ms=ts * 1e3, pairs_per_s_batched=3 * n / tb,
-                     pairs_per_s_separate=3 * n / ts, speedup=ts / tb))
+                     pairs_per_s_separate=3 * n / ts, speedup=ts / tb, scores_equal_torch_reference=ok5))
     for mo in motifs: mo.close()
     del d, scores, hits; torch.cuda.empty_cache()
 res["config5_same_width_batches"] = cfg5
