@@ -14,8 +14,6 @@ import numpy as np
 from . import _native as _nv
 from .device import DeviceMotif, _torch
 
-import os as _os
-_EXP_NOWAIT = bool(_os.environ.get("GFM_EXP_NOWAIT"))  # measurement experiment only (unsafe)
 HIT_SCORE_BITS = 20  # GFM_HIT_SCORE_BITS: hit entry = (row << 20) | scaled score
 
 
@@ -106,8 +104,7 @@ class KmerScanner:
         main_p = main.cuda_stream
         tail = self.side if self.side is not None else main
         tail_p = self._side_p if self.side is not None else main_p
-        if not _EXP_NOWAIT:
-            main.wait_event(slot.done)       # the slot's previous batch has been consumed
+        main.wait_event(slot.done)           # the slot's previous batch has been consumed
         # no zeroing on the critical path: the q-value kernel hands the histogram back cleared
         # (GFM_FLAG_CLEAR_HIST) and the hit list restarts through GFM_FLAG_RESET_HITS
         n = int(d_kmers.shape[0])
