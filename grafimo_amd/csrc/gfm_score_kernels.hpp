@@ -283,7 +283,7 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
             const int k = p * kWave + lane;
             const int boff = k * (W + pad);
             const unsigned sh = (unsigned)(boff & 3) * 8u;
-            lds_cu32 *src = (lds_cu32 *)(stage_off + (unsigned)(boff & ~3));
+            lds_cu32 *src = (lds_cu32 *)(uintptr_t)(stage_off + (unsigned)(boff & ~3));
             unsigned w[NDW + 1];
 #pragma unroll
             for (int d2 = 0; d2 <= NDW; ++d2) w[d2] = src[d2];
@@ -300,8 +300,8 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
                     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(0x000E000Eu), "v"(x), "v"(x >> 5));
                     const unsigned e0 = y & 0x7Eu;
                     const unsigned e1 = (y >> 16) & 0x7Eu;
-                    s1 += *(lds_cu16 *)(e0 + (unsigned)((2 * d2) * 128));
-                    s1 += *(lds_cu16 *)(e1 + (unsigned)((2 * d2 + 1) * 128));
+                    s1 += *(lds_cu16 *)(uintptr_t)(e0 + (unsigned)((2 * d2) * 128));
+                    s1 += *(lds_cu16 *)(uintptr_t)(e1 + (unsigned)((2 * d2 + 1) * 128));
                 }
                 any_n = (unsigned)s1 >= kPoison;
                 acc[0] = s1;
@@ -314,8 +314,8 @@ score_hist_kernel(const uint8_t *__restrict__ kmers, long long n, int W, long lo
                     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(0x000E000Eu), "v"(x), "v"(x >> 5));
                     const unsigned e0 = (y & 0x7Eu) << 2;            // 8-byte entries
                     const unsigned e1 = ((y >> 16) & 0x7Eu) << 2;
-                    s64 += *(lds_cu64 *)(e0 + (unsigned)((2 * d2) * 512));
-                    s64 += *(lds_cu64 *)(e1 + (unsigned)((2 * d2 + 1) * 512));
+                    s64 += *(lds_cu64 *)(uintptr_t)(e0 + (unsigned)((2 * d2) * 512));
+                    s64 += *(lds_cu64 *)(uintptr_t)(e1 + (unsigned)((2 * d2 + 1) * 512));
                 }
                 any_n = (s64 >> 57) != 0;
 #pragma unroll

@@ -1,0 +1,80 @@
+"""K-mer extraction, CPU side: the oracle against the reference's own golden file, and the product's
+host-side graph index (FASTA / VCF reading, haplotype bitsets, vg node numbering) against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REF_DATA
+from extract_helpers import make_graph_files
+
+
+def test_oracle_reproduces_the_reference_golden_file():
+    """tests/grafimo_run_test.py:49-63 (test_sequence_extraction): `vg find -x test.xg -E -p x:0-20 -K 19`
+    == expected_seqs.tsv after sorting.  Same comparison, oracle instead of vg."""
+    from oracle import extract_oracle as xo
+    ref = xo.read_fasta(os.path.join(REF_DATA, "test.fa"))["x"]
+    sites = xo.read_vcf_snps(os.path.join(REF_DATA, "test.vcf.gz"), "x")
+    assert sites.skipped == 0 and sites.pos.tolist() == [8, 9, 13, 33, 38]
+    rows = xo.enumerate_region("x", ref, sites, 0, 20, 19, with_counts=False, nodes=xo.NodeTable(len(ref), sites))
+    got = sorted(tuple(str(x) for x in r) for r in rows)
+    with open(os.path.join(REF_DATA, "expected_seqs.tsv")) as fh:
+        exp = sorted(tuple(line.rstrip("\n").split("\t")) for line in fh)
+    assert len(got) == 32 and got == exp
+
+
+def test_oracle_haplotype_counts_on_the_test_graph():
+    """-H semantics restated: sample 1 is 1|0, 1|1, 1|0 at the three sites of x:0-20, so exactly two
+    walks per window are carried by a haplotype (A,T,A and G,T,G), once each."""
+    from oracle import extract_oracle as xo
+    ref = xo.read_fasta(os.path.join(REF_DATA, "test.fa"))["x"]
+    sites = xo.read_vcf_snps(os.path.join(REF_DATA, "test.vcf.gz"), "x")
+    rows = xo.enumerate_region("x", ref, sites, 0, 20, 19, with_counts=True)
+    carried = {(r[1], r[4]) for r in rows if r[4]}
+    assert carried == {("CAAATAAGATTTGAAAATT", 1), ("CAAATAAGGTTTGGAAATT", 1), ("AAATAAGATTTGAAAATTT", 1),
+                       ("AAATAAGGTTTGGAAATTT", 1), ("AATTTTCAAATCTTATTTG", 1), ("AATTTCCAAACCTTATTTG", 1),
+                       ("AAATTTTCAAATCTTATTT", 1), ("AAATTTCCAAACCTTATTT", 1)}
+    assert sum(r[4] for r in rows) == 8
+
+
+def test_graph_index_matches_the_oracle_readers(tmp_path):
+    from grafimo_amd.extract_regions import GraphIndex
+    from oracle import extract_oracle as xo
+    for gz in (True, False):
+        d = tmp_path / f"g{int(gz)}"
+        d.mkdir()
+        fasta, vcf = make_graph_files(str(d), chrom="7", gz=gz)
+        idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
+        ref = xo.read_fasta(fasta)["7"]
+        sites = xo.read_vcf_snps(vcf, "7")
+        assert idx.ref.tobytes() == ref and idx.skipped == sites.skipped > 0
+        assert np.array_equal(idx.pos, sites.pos) and idx.n_haplotypes == sites.n_haplotypes == 130
+        assert [list(map(chr, b[:n])) for b, n in zip(idx.alt_bases, idx.n_alts)] == sites.alts
+        assert any(n == 3 for n in idx.n_alts) and any(n == 2 for n in idx.n_alts)
+        # bit h of word h // 64 <=> haplotype h carries that alternate allele
+        for a in range(3):
+            bits = np.unpackbits(idx.alt_bits[:, a, :].view(np.uint8), axis=1, bitorder="little")[:, :130]
+            assert np.array_equal(bits.astype(bool), sites.hap == a + 1)
+    with pytest.raises(ValueError):
+        GraphIndex.from_fasta_vcf(fasta, vcf, "no_such_chromosome")
+
+
+def test_node_numbering_matches_the_oracle(tmp_path):
+    from grafimo_amd.extract_regions import GraphIndex
+    from oracle import extract_oracle as xo
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=1200, n_sites=120)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7", with_haplotypes=False)
+    assert idx.alt_bits is None and idx.n_haplotypes == 0
+    sites = xo.read_vcf_snps(vcf, "7")
+    nodes = xo.NodeTable(len(idx.ref), sites)
+    rng = np.random.default_rng(3)
+    for W in (5, 19, 40):
+        for p in rng.integers(0, len(idx.ref) - W, 60):
+            i0, alleles = idx.walk_alleles(int(p), W, 0)
+            n_walks = int(np.prod([1 + idx.n_alts[i0 + k] for k in range(len(alleles))])) if alleles else 1
+            q = int(rng.integers(0, n_walks))
+            i0, alleles = idx.walk_alleles(int(p), W, q)
+            assert idx.node_path(int(p), W, q) == nodes.path(sites, int(p), W, i0, alleles)
+    # the reference's test graph: ids 1..9 as in expected_seqs.tsv
+    t = GraphIndex.from_fasta_vcf(os.path.join(REF_DATA, "test.fa"), os.path.join(REF_DATA, "test.vcf.gz"), "x")
+    assert t.node_path(0, 19, 0) == [1, 3, 5, 6, 8, 9] and t.node_path(0, 19, 7) == [1, 2, 4, 6, 7, 9]

@@ -1,0 +1,144 @@
+"""K-mer extraction on the MI355X (gfm_graph_* through grafimo_amd.extract_regions) against the
+oracle, the reference's golden file, and end to end into the scoring path."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import REF_DATA
+from extract_helpers import make_graph_files
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _oracle_rows(fasta, vcf, chrom, regions, W, counts=True):
+    from oracle import extract_oracle as xo
+    ref = xo.read_fasta(fasta)[chrom]
+    sites = xo.read_vcf_snps(vcf, chrom)
+    nodes = xo.NodeTable(len(ref), sites)
+    rows = []
+    for s, e in regions:
+        rows += xo.enumerate_region(chrom, ref, sites, s, e, W, with_counts=counts, nodes=nodes)
+    return rows
+
+
+def test_reference_golden_file_through_the_gpu(tmp_path):
+    """The reference's test_sequence_extraction (tests/grafimo_run_test.py:49-63) with the extraction
+    kernel in vg's place: the written TSV equals expected_seqs.tsv after sorting, like the test does."""
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, write_region_tsvs
+    idx = GraphIndex.from_fasta_vcf(os.path.join(REF_DATA, "test.fa"), os.path.join(REF_DATA, "test.vcf.gz"), "x",
+                                    with_haplotypes=False)            # the test runs vg without -H
+    g = DeviceGraph(idx)
+    rows = g.extract([(0, 20)], 19)
+    assert len(rows) == 32
+    paths = write_region_tsvs(idx, rows, str(tmp_path))
+    assert paths == [os.path.join(str(tmp_path), "width_19", "x_0-20.tsv")]
+    result = pd.read_csv(paths[0], sep="\t", header=None).sort_values([1, 2, 3])
+    result.index = range(len(result))
+    expected = pd.read_csv(os.path.join(REF_DATA, "expected_seqs.tsv"), sep="\t", header=None).sort_values([1, 2, 3])
+    expected.index = range(len(expected))
+    assert result.equals(expected)
+    g.close()
+
+
+@pytest.mark.parametrize("W", [1, 8, 19, 32, 64])
+def test_rows_equal_the_oracle_on_a_synthetic_graph(tmp_path, W):
+    """Every column of every row, in order: clustered multi-allelic sites, 130 haplotypes (ragged last
+    bitset word), regions that touch both ends of the chromosome, overlap, or are shorter than W."""
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, write_region_tsvs
+    # (a 64-base window over the dense graph holds thousands of walks: keep the oracle's Python loop short)
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", seed=40 + W, n_sites=260 if W < 64 else 100)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
+    regions = [(0, 150), (100, 400), (2900, 3000), (1500, 1500 + W - 1), (1000, 1700), (2990, 3050), (-20, 90)]
+    g = DeviceGraph(idx)
+    rows = g.extract(regions, W)
+    exp = _oracle_rows(fasta, vcf, "7", [(max(s, 0), min(e, 3000)) for s, e in regions], W)
+    assert len(rows) == len(exp) > 0
+    km = rows.kmers.cpu().numpy()
+    assert [k.tobytes().decode() for k in km] == [r[1] for r in exp]
+    strand = [chr(c) for c in rows.strand.cpu().numpy()]
+    assert [f"7:{a}{s}" for a, s in zip(rows.start.cpu().numpy(), strand)] == [r[2] for r in exp]
+    assert [f"7:{a}{s}" for a, s in zip(rows.stop.cpu().numpy(), strand)] == [r[3] for r in exp]
+    assert rows.freq.cpu().numpy().tolist() == [r[4] for r in exp]
+    assert ["ref" if x else "non.ref" for x in rows.is_ref.cpu().numpy()] == [r[5] for r in exp]
+    assert max(r[4] for r in exp) == 130 and any(0 < r[4] < 130 for r in exp)
+    # the TSV files: same text as the oracle's rows (labels carry the caller's region bounds)
+    paths = write_region_tsvs(idx, rows, str(tmp_path / "out"))
+    text = "".join(open(p).read() for p in paths)
+    lab = {f"7:{max(s, 0)}-{min(e, 3000)}": f"7:{s}-{e}" for s, e in regions}
+    exp_text = "".join("\t".join([lab[r[0]]] + [str(x) for x in r[1:]]) + "\n" for r in exp)
+    assert sorted(text.splitlines()) == sorted(exp_text.splitlines())
+    g.close()
+
+
+def test_graph_without_sites_and_plan_errors(tmp_path):
+    from grafimo_amd import _native as nv
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
+    ref = np.frombuffer(b"ACGTTGCANNACGT" * 10, dtype=np.uint8)
+    idx = GraphIndex("c", ref, [], [], np.zeros((0, 3), np.uint8), None, 0)
+    g = DeviceGraph(idx)
+    rows = g.extract([(0, len(ref))], 6)
+    assert len(rows) == 2 * (len(ref) - 6 + 1) and int(rows.is_ref.min()) == 1 and int(rows.freq.max()) == 0
+    k = rows.kmers.cpu().numpy()
+    assert k[0].tobytes() == b"ACGTTG" and k[1].tobytes() == b"CAACGT"        # reverse complement, N kept
+    assert k[2 * 4].tobytes() == b"TGCANN" and k[2 * 4 + 1].tobytes() == b"NNTGCA"
+    assert len(g.extract([], 6)) == 0 and len(g.extract([(5, 7)], 6)) == 0
+    with pytest.raises(nv.NativeError):
+        g.extract([(0, 50)], 65)
+    g.close()
+    # 25 sites with 3 alternates each inside one window: 4^25 walks -> refused, not attempted
+    n = 25
+    big = GraphIndex("c", ref, list(range(n)), [3] * n, np.tile(np.frombuffer(b"CGT", np.uint8), (n, 1)), None, 0)
+    g = DeviceGraph(big)
+    with pytest.raises(nv.NativeError) as ei:
+        g.extract([(0, 40)], 30)
+    assert ei.value.code == nv.GFM_ERR_OVERFLOW
+    g.close()
+
+
+def test_extraction_feeds_scoring_without_a_tsv(tmp_path):
+    """compute_results_from_graph (extraction kernel -> score kernel in HBM) == the oracle's
+    compute_results over the oracle's TSV rows, for the flag combinations that change the row set."""
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, compute_results_from_graph
+    from grafimo_amd.motif_ops import build_motif_meme_host
+    from grafimo_amd.workflow import Findmotif
+    from oracle import oracle as orc
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=6000, n_sites=400, seed=77)
+    regions = [(0, 900), (1200, 2500), (3000, 5990)]
+    motif = build_motif_meme_host(os.path.join(REF_DATA, "MA0139.1.meme"), "unfrm_dst", 0.1, False)[0]
+    rows = _oracle_rows(fasta, vcf, "7", regions, 19)
+    seqdir = tmp_path / "oracle_tsv" / "width_19"
+    seqdir.mkdir(parents=True)
+    for s, e in regions:
+        with open(seqdir / f"7_{s}-{e}.tsv", "w") as fh:
+            for r in rows:
+                if r[0] == f"7:{s}-{e}":
+                    fh.write("\t".join(str(x) for x in r) + "\n")
+    md = dict(score_matrix=motif.dense_score_matrix(),
+              pmf=orc.comp_pval_mat(motif.dense_score_matrix(), motif.dense_bg()), min_val=motif.min_val,
+              scale=motif.scale, offset=float(motif.offset), width=19, motif_id=motif.motif_id,
+              motif_name=motif.motif_name)
+    g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7"))
+    for kw in [dict(threshold=0.05), dict(threshold=0.5, qval_t=True, recomb=True),
+               dict(threshold=0.02, no_reverse=True), dict(threshold=0.05, no_qvalue=True, recomb=True)]:
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            df = compute_results_from_graph(motif, g, regions, True, Findmotif(**kw))
+        ref = orc.compute_results(md, str(tmp_path / "oracle_tsv"), threshold=kw["threshold"],
+                                  qval_t=kw.get("qval_t", False), no_qvalue=kw.get("no_qvalue", False),
+                                  no_reverse=kw.get("no_reverse", False), recomb=kw.get("recomb", False))
+        exp = pd.DataFrame({c: ref[c] for c in ref if not c.startswith("_")})
+        assert f"Scanned sequences:\t{ref['_scanned']}" in out.getvalue()
+        assert list(df.columns) == list(exp.columns) and len(df) == len(exp) > 0, kw
+        key = ["p-value", "sequence_name", "start", "stop", "strand", "matched_sequence", "haplotype_frequency"]
+        a = df.sort_values(key).reset_index(drop=True)
+        b = exp.sort_values(key).reset_index(drop=True)
+        for c in exp.columns:
+            if b[c].dtype.kind == "f":
+                np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-9, atol=0)
+            else:
+                assert (a[c].astype(str) == b[c].astype(str)).all(), (kw, c)
+    g.close()
