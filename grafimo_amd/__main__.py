@@ -8,6 +8,12 @@ produced (``width_W/REGION.tsv``).  Flags keep the names, defaults and meaning o
 -r/--no-reverse, -f/--text-only, --recomb, --qvalueT, -j/--cores, -o/--out, --verbose, --debug.
 
     python -m grafimo_amd -m MA0139.1.meme -s /tmp/grafimo_XXXX -t 1e-4 -o out_dir
+
+Without vg, the k-mers can also come from the extraction kernel: give the inputs of ``grafimo buildvg``
+(-l/--linear-genome FASTA, -v/--vcf phased VCF) and the -b/--bedfile of ``findmotif`` instead of -s;
+only the single-base substitutions of the VCF are part of that graph (grafimo_amd/extract_regions.py).
+
+    python -m grafimo_amd -m MA0139.1.meme -l chr22.fa -v chr22.vcf.gz -b peaks.bed -o out_dir
 """
 import argparse
 import sys
@@ -34,8 +40,12 @@ def get_parser():
     p = argparse.ArgumentParser(prog="python -m grafimo_amd", description=__doc__,
                                 formatter_class=argparse.RawDescriptionHelpFormatter)
     p.add_argument("-m", "--motif", nargs="+", required=True, metavar="MOTIF-FILE")
-    p.add_argument("-s", "--sequences", required=True, metavar="DIR",
+    p.add_argument("-s", "--sequences", metavar="DIR",
                    help="directory holding width_W/*.tsv as written by vg find -K W -E")
+    p.add_argument("-l", "--linear-genome", dest="linear_genome", metavar="FASTA",
+                   help="reference FASTA (with -v and -b: extract the k-mers on the GPU instead of -s)")
+    p.add_argument("-v", "--vcf", metavar="VCF", help="phased VCF (.vcf or .vcf.gz); its SNP records form the graph")
+    p.add_argument("-b", "--bedfile", metavar="BED", help="regions to scan")
     p.add_argument("-k", "--bgfile", default=UNIF)
     p.add_argument("-p", "--pseudo", type=float, default=0.1)
     p.add_argument("-t", "--threshold", type=float, default=1e-4)
@@ -57,6 +67,9 @@ def main(argv=None):
         sys.exit("ERROR: the threshold must be in (0, 1]")
     if a.qval_t and a.no_qvalue:
         sys.exit("ERROR: --qvalueT needs q-values (drop -q)")
+    from_graph = bool(a.linear_genome or a.vcf or a.bedfile)
+    if from_graph == bool(a.sequences) or (from_graph and not (a.linear_genome and a.vcf and a.bedfile)):
+        sys.exit("ERROR: give either -s DIR or all of -l FASTA -v VCF -b BED")
     if a.cores <= 0:
         import os
         a.cores = os.cpu_count() or 1
@@ -67,8 +80,21 @@ def main(argv=None):
         # the Motif objects come back without their score distribution: the DP runs on the GPU
         # when compute_results uploads the motif
         motifs += get_motif_pwm(mfile, wf, a.cores, a.debug, pvalue_matrix=False)
+    graphs, region_lists = [], []
+    if from_graph:
+        from .extract_regions import DeviceGraph, GraphIndex, compute_results_from_graph, read_bed_regions
+        for chrom, regs in read_bed_regions(a.bedfile).items():
+            index = GraphIndex.from_fasta_vcf(a.linear_genome, a.vcf, chrom)
+            if a.verbose:
+                print(f"{chrom}: {len(index.pos)} SNP sites, {index.n_haplotypes} haplotypes, "
+                      f"{index.skipped} other VCF records left out")
+            graphs.append(DeviceGraph(index))
+            region_lists.append(regs)
     for motif in motifs:
-        res = compute_results(motif, a.sequences, a.debug, wf)
+        if from_graph:
+            res = compute_results_from_graph(motif, graphs, region_lists, a.debug, wf)
+        else:
+            res = compute_results(motif, a.sequences, a.debug, wf)
         if a.text_only:
             print_results(res, a.debug)
         else:

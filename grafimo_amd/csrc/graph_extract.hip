@@ -15,6 +15,7 @@
 // (sites-in-window x ceil(H/64) x 8 B per walk, re-used across the W overlapping windows of a site).
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdint>
@@ -85,7 +86,8 @@ __device__ inline int region_of(const long long *region_off, int n_regions, long
 __global__ void __launch_bounds__(kCountThreads)
 graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ region_off,
                    const long long *__restrict__ first_start, int W, long long n_windows,
-                   int *__restrict__ first_site, int *__restrict__ n_walks)
+                   int *__restrict__ first_site, long long *__restrict__ n_walks, int *__restrict__ win_region,
+                   long long *__restrict__ win_start, int *__restrict__ overflow)
 {
     const long long w = (long long)blockIdx.x * kCountThreads + threadIdx.x;
     if (w >= n_windows) return;
@@ -95,10 +97,12 @@ graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ regi
     long long walks = 1;
     for (int i = i0; i < g.n_sites && g.pos[i] < p + W; ++i) {
         walks *= 1 + g.n_alts[i];
-        if (walks > kMaxWalksPerWindow) { walks = -1; break; }
+        if (walks > kMaxWalksPerWindow) { walks = 0; atomicMax(overflow, 1); break; }
     }
     first_site[w] = i0;
-    n_walks[w] = (int)walks;
+    n_walks[w] = walks;
+    win_region[w] = r;      // the emit kernel reads these instead of repeating the search: its waves
+    win_start[w] = p;       // are latency-bound, and a binary search is a chain of dependent loads
 }
 
 __device__ inline uint8_t complement(uint8_t c)
@@ -114,9 +118,8 @@ __device__ inline uint8_t complement(uint8_t c)
 // site k (its allele of the current walk, last site varying fastest: itertools.product order);
 // lane j < W owns base j of the k-mer; lanes own words of the haplotype bitsets.
 __global__ void __launch_bounds__(kEmitThreads)
-graph_emit_kernel(GraphDev g, int n_regions, const long long *__restrict__ region_off,
-                  const long long *__restrict__ first_start, int W, long long n_windows,
-                  const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+graph_emit_kernel(GraphDev g, const int *__restrict__ win_region, const long long *__restrict__ win_start,
+                  int W, long long n_windows, const int *__restrict__ first_site, const long long *__restrict__ walk_base,
                   uint8_t *__restrict__ kmers, long long *__restrict__ start, long long *__restrict__ stop,
                   uint8_t *__restrict__ strand, long long *__restrict__ freq, uint8_t *__restrict__ is_ref,
                   int *__restrict__ region, int *__restrict__ walk)
@@ -126,8 +129,8 @@ graph_emit_kernel(GraphDev g, int n_regions, const long long *__restrict__ regio
     const int wv = threadIdx.x >> 6;
     const long long stride = (long long)gridDim.x * (kEmitThreads / kWave);
     for (long long w = (long long)blockIdx.x * (kEmitThreads / kWave) + wv; w < n_windows; w += stride) {
-        const int r = region_of(region_off, n_regions, w);
-        const long long p = first_start[r] + (w - region_off[r]);
+        const int r = win_region[w];
+        const long long p = win_start[w];
         const int i0 = first_site[w];
         const long long base = walk_base[w];
         const int walks = (int)(walk_base[w + 1] - base);
@@ -161,8 +164,8 @@ graph_emit_kernel(GraphDev g, int n_regions, const long long *__restrict__ regio
                 kmers[(row + 1) * W + lane] = complement(kbuf[wv][W - 1 - lane]);
             }
             // haplotypes that carry every allele of the walk
-            long long count = 0;
-            if (g.alt_bits) {
+            long long count = ns == 0 ? g.n_hap : 0;     // no site in the window: every haplotype carries it
+            if (g.alt_bits && ns > 0) {
                 for (int w0 = 0; w0 < g.hw; w0 += kWave) {     // every lane takes part in the shuffles
                     const int word = w0 + lane;
                     const bool live = word < g.hw;
@@ -189,13 +192,14 @@ graph_emit_kernel(GraphDev g, int n_regions, const long long *__restrict__ regio
                 for (int d = 32; d > 0; d >>= 1) count += __shfl_xor(count, d);
             }
             const bool any_alt = __builtin_amdgcn_ballot_w64(my_allele > 0) != 0ull;
-            if (lane == 0) {
-                start[row] = p;           stop[row] = p + W;      strand[row] = '+';
-                start[row + 1] = p + W;   stop[row + 1] = p;      strand[row + 1] = '-';
-                freq[row] = freq[row + 1] = count;
-                is_ref[row] = is_ref[row + 1] = any_alt ? 0 : 1;
-                region[row] = region[row + 1] = r;
-                walk[row] = walk[row + 1] = q;
+            if (lane < 2) {      // lane 0: forward row, lane 1: its reverse complement
+                start[row + lane] = lane ? p + W : p;
+                stop[row + lane] = lane ? p : p + W;
+                strand[row + lane] = lane ? '-' : '+';
+                freq[row + lane] = count;
+                is_ref[row + lane] = any_alt ? 0 : 1;
+                region[row + lane] = r;
+                walk[row + lane] = q;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // kbuf is rewritten by the next walk
             __builtin_amdgcn_wave_barrier();
@@ -224,13 +228,14 @@ struct gfm_graph {
     int n_regions = 0, width = 0;
     long long n_windows = 0, n_walks = 0;
     long long *d_region_off = nullptr, *d_first_start = nullptr, *d_walk_base = nullptr;
-    int *d_first_site = nullptr;
+    int *d_first_site = nullptr, *d_win_region = nullptr;
+    long long *d_win_start = nullptr;
     void drop_plan()
     {
         (void)hipFree(d_region_off); (void)hipFree(d_first_start); (void)hipFree(d_walk_base);
-        (void)hipFree(d_first_site);
-        d_region_off = d_first_start = d_walk_base = nullptr;
-        d_first_site = nullptr;
+        (void)hipFree(d_first_site); (void)hipFree(d_win_region); (void)hipFree(d_win_start);
+        d_region_off = d_first_start = d_walk_base = d_win_start = nullptr;
+        d_first_site = d_win_region = nullptr;
         n_regions = 0; n_windows = n_walks = 0;
     }
 };
@@ -308,28 +313,41 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     if (n_windows) *n_windows = g->n_windows;
     if (n_rows) *n_rows = 0;
     if (g->n_windows == 0) return GFM_OK;
+    if (g->n_windows > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "too many windows in one plan (split the regions)");
     GX_TRY(upload(&g->d_region_off, off.data(), off.size()));
     GX_TRY(upload(&g->d_first_start, first.data(), first.size()));
-    int *d_walks = nullptr;
-    GX_TRY(hipMalloc(&g->d_first_site, sizeof(int) * (size_t)g->n_windows));
-    GX_TRY(hipMalloc(&d_walks, sizeof(int) * (size_t)g->n_windows));
+    // walks per window -> exclusive prefix (row base of every window), all on the device: only the
+    // total and the overflow flag come back
+    struct Scratch {
+        long long *walks = nullptr;
+        int *flag = nullptr;
+        void *tmp = nullptr;
+        ~Scratch() { (void)hipFree(walks); (void)hipFree(flag); (void)hipFree(tmp); }
+    } sc;
+    const size_t nw = (size_t)g->n_windows;
+    GX_TRY(hipMalloc(&g->d_first_site, sizeof(int) * nw));
+    GX_TRY(hipMalloc(&sc.walks, sizeof(long long) * nw));
+    GX_TRY(hipMalloc(&sc.flag, sizeof(int)));
+    GX_TRY(hipMemsetAsync(sc.flag, 0, sizeof(int), nullptr));
+    GX_TRY(hipMalloc(&g->d_win_region, sizeof(int) * nw));
+    GX_TRY(hipMalloc(&g->d_win_start, sizeof(long long) * nw));
+    GX_TRY(hipMalloc(&g->d_walk_base, sizeof(long long) * (nw + 1)));
+    GX_TRY(hipMemsetAsync(g->d_walk_base, 0, sizeof(long long), nullptr));
     const unsigned blocks = (unsigned)((g->n_windows + kCountThreads - 1) / kCountThreads);
     hipLaunchKernelGGL(graph_count_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->dev, n_regions,
-                       g->d_region_off, g->d_first_start, width, g->n_windows, g->d_first_site, d_walks);
-    std::vector<int> walks((size_t)g->n_windows);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess)
-        e = hipMemcpy(walks.data(), d_walks, sizeof(int) * walks.size(), hipMemcpyDeviceToHost);
-    (void)hipFree(d_walks);
-    if (e != hipSuccess) return gfail(GFM_ERR_HIP, std::string("window count failed: ") + hipGetErrorString(e));
-    std::vector<long long> base((size_t)g->n_windows + 1, 0);
-    for (long long w = 0; w < g->n_windows; ++w) {
-        if (walks[(size_t)w] < 0)
-            return gfail(GFM_ERR_OVERFLOW, "a window holds more than 2^20 walks (window " + std::to_string(w) + ")");
-        base[(size_t)w + 1] = base[(size_t)w] + walks[(size_t)w];
-    }
-    g->n_walks = base.back();
-    GX_TRY(upload(&g->d_walk_base, base.data(), base.size()));
+                       g->d_region_off, g->d_first_start, width, g->n_windows, g->d_first_site, sc.walks,
+                       g->d_win_region, g->d_win_start, sc.flag);
+    GX_TRY(hipGetLastError());
+    size_t tmp_bytes = 0;
+    GX_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, sc.walks, g->d_walk_base + 1, (int)nw, nullptr));
+    GX_TRY(hipMalloc(&sc.tmp, tmp_bytes));
+    GX_TRY(hipcub::DeviceScan::InclusiveSum(sc.tmp, tmp_bytes, sc.walks, g->d_walk_base + 1, (int)nw, nullptr));
+    long long total = 0;
+    int overflow = 0;
+    GX_TRY(hipMemcpy(&total, g->d_walk_base + nw, sizeof total, hipMemcpyDeviceToHost));
+    GX_TRY(hipMemcpy(&overflow, sc.flag, sizeof overflow, hipMemcpyDeviceToHost));
+    if (overflow) return gfail(GFM_ERR_OVERFLOW, "a window holds more than 2^20 walks through its sites");
+    g->n_walks = total;
     if (n_rows) *n_rows = 2 * g->n_walks;
     return GFM_OK;
 }
@@ -345,7 +363,7 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
     const long long waves = g->n_windows;
     const unsigned blocks = (unsigned)std::min<long long>((waves + 3) / 4, 256 * 32);
     hipLaunchKernelGGL(graph_emit_kernel, dim3(blocks), dim3(kEmitThreads), 0, static_cast<hipStream_t>(stream),
-                       g->dev, g->n_regions, g->d_region_off, g->d_first_start, g->width, g->n_windows,
+                       g->dev, g->d_win_region, g->d_win_start, g->width, g->n_windows,
                        g->d_first_site, g->d_walk_base, d_kmers, reinterpret_cast<long long *>(d_start),
                        reinterpret_cast<long long *>(d_stop), d_strand, reinterpret_cast<long long *>(d_freq),
                        d_is_ref, d_region, d_walk);

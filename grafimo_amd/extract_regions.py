@@ -266,23 +266,47 @@ def write_region_tsvs(index: GraphIndex, rows: ExtractedKmers, out_dir: str) -> 
     return paths
 
 
-def compute_results_from_graph(motif: Motif, graph: DeviceGraph, regions: Sequence[Tuple[int, int]], debug: bool,
-                               args_obj) -> pd.DataFrame:
+def read_bed_regions(bedfile: str) -> Dict[str, List[Tuple[int, int]]]:
+    """chromosome -> [(start, stop)] in file order (the first three BED columns, extract_regions.py:422-426)."""
+    out: Dict[str, List[Tuple[int, int]]] = {}
+    with open(bedfile) as fh:
+        for line in fh:
+            f = line.split()
+            if len(f) < 3 or line.startswith(("#", "track", "browser")):
+                continue
+            out.setdefault(f[0], []).append((int(f[1]), int(f[2])))
+    return out
+
+
+def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_obj) -> pd.DataFrame:
     """extract_regions.scan_graph + score_sequences.compute_results in one device pipeline: the rows go
-    from the extraction kernel to the score kernel in HBM; only the hits and their metadata come back."""
+    from the extraction kernel to the score kernel in HBM; only the hits and their metadata come back.
+    `graph` / `regions`: one DeviceGraph with its [(S, E)] list, or lists of both (one entry per
+    chromosome) -- the q-values are computed over the rows of all of them, like the reference does over
+    all TSV files of a motif."""
     from .scan import KmerScanner
     from .score_sequences import print_scoring_msg
     torch = _torch()
+    graphs = list(graph) if isinstance(graph, (list, tuple)) else [graph]
+    region_lists = list(regions) if isinstance(graph, (list, tuple)) else [regions]
     threshold = float(args_obj.threshold)
     no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
     no_reverse, recomb = bool(args_obj.noreverse), bool(args_obj.recomb)
     print_scoring_msg(motif, no_reverse, debug)
     W = motif.width
-    rows = graph.extract(regions, W)
+    parts = [g.extract(r, W) for g, r in zip(graphs, region_lists)]
+    labels: List[str] = []
+    region_ids = []
+    for part in parts:                               # region ids of all chromosomes in one label table
+        region_ids.append(part.region + len(labels))
+        labels += [part.region_label(r) for r in range(len(part.regions))]
+    cat = lambda name: torch.cat([getattr(p_, name) for p_ in parts]) if len(parts) > 1 else getattr(parts[0], name)
+    all_kmers, region = cat("kmers"), (torch.cat(region_ids) if len(parts) > 1 else region_ids[0])
+    n_all = int(all_kmers.shape[0])
     keep = None
-    kmers = rows.kmers
+    kmers = all_kmers
     if no_reverse:                                   # '-' rows are skipped before scoring (score_sequences.py:281)
-        keep = torch.arange(0, len(rows), 2, device=kmers.device)
+        keep = torch.arange(0, n_all, 2, device=kmers.device)
         kmers = kmers[keep].contiguous()
     n = int(kmers.shape[0])
     if n == 0:
@@ -304,16 +328,15 @@ def compute_results_from_graph(motif: Motif, graph: DeviceGraph, regions: Sequen
     hit = torch.from_numpy(res["rows"]).to(kmers.device)
     src = keep[hit] if keep is not None else hit
     take = lambda t: t[src].cpu().numpy()
-    region = take(rows.region)
     return build_frame(
         motif,
-        seqnames=[rows.region_label(int(r)) for r in region],
-        starts=take(rows.start), stops=take(rows.stop),
-        strands=[chr(c) for c in take(rows.strand)],
+        seqnames=[labels[int(r)] for r in take(region)],
+        starts=take(cat("start")), stops=take(cat("stop")),
+        strands=[chr(c) for c in take(cat("strand"))],
         scores=lo, pvalues=pv,
         qvalues=None if no_qvalue else res["qtable"][res["scaled"]],
-        seqs=[bytes(k).decode() for k in take(rows.kmers)],
-        frequencies=take(rows.freq),
-        references=["ref" if r else "non.ref" for r in take(rows.is_ref)],
+        seqs=[bytes(k).decode() for k in take(all_kmers)],
+        frequencies=take(cat("freq")),
+        references=["ref" if r else "non.ref" for r in take(cat("is_ref"))],
         threshold=None, recomb=recomb,
     )

@@ -142,3 +142,34 @@ def test_extraction_feeds_scoring_without_a_tsv(tmp_path):
             else:
                 assert (a[c].astype(str) == b[c].astype(str)).all(), (kw, c)
     g.close()
+
+
+def test_several_graphs_share_one_scoring_pass_and_cli_mode(tmp_path, capsys):
+    """q-values are global per motif: two (graph, regions) entries == one entry with all regions; and the
+    command line without vg: -l FASTA -v VCF -b BED writes the same table."""
+    from grafimo_amd.__main__ import main
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, compute_results_from_graph, read_bed_regions
+    from grafimo_amd.motif_ops import build_motif_meme_host
+    from grafimo_amd.workflow import Findmotif
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=4000, n_sites=300, seed=91, gz=False)
+    r1, r2 = [(10, 800), (900, 1500)], [(2000, 3900)]
+    bed = tmp_path / "regions.bed"
+    bed.write_text("track name=test\n" + "".join(f"7\t{s}\t{e}\tpeak\n" for s, e in r1 + r2))
+    assert read_bed_regions(str(bed)) == {"7": r1 + r2}
+    motif = build_motif_meme_host(os.path.join(REF_DATA, "MA0139.1.meme"), "unfrm_dst", 0.1, False)[0]
+    g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7"))
+    kw = Findmotif(threshold=0.05, recomb=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        one = compute_results_from_graph(motif, g, r1 + r2, True, kw)
+        two = compute_results_from_graph(motif, [g, g], [r1, r2], True, kw)
+    assert len(one) > 0 and one.equals(two)
+    g.close()
+    out = tmp_path / "cli_out"
+    main(["-m", os.path.join(REF_DATA, "MA0139.1.meme"), "-l", fasta, "-v", vcf, "-b", str(bed), "-t", "0.05",
+          "--recomb", "-o", str(out), "--verbose"])
+    assert "SNP sites, 130 haplotypes" in capsys.readouterr().out
+    tsv = pd.read_csv(out / "grafimo_out.tsv", sep="\t", index_col=0)
+    assert len(tsv) == len(one) and list(tsv["matched_sequence"]) == list(one["matched_sequence"])
+    np.testing.assert_allclose(tsv["q-value"].to_numpy(), one["q-value"].to_numpy(), rtol=1e-12)
+    with pytest.raises(SystemExit):
+        main(["-m", "x.meme", "-l", fasta])            # incomplete graph inputs
