@@ -44,7 +44,6 @@ int gfail(int code, const std::string &msg)
             return gfail(GFM_ERR_HIP, std::string(#expr " failed: ") + hipGetErrorString(e_));    \
     } while (0)
 
-constexpr int kWave = 64;
 constexpr int kMaxAlts = 3;
 constexpr int kCountThreads = 256;
 constexpr int kEmitThreads = 256;                    // 4 waves, one window per wave at a time
@@ -114,97 +113,147 @@ __device__ inline uint8_t complement(uint8_t c)
     }
 }
 
-// One wave per window, walks of the window one after the other.  Lane k < n_sites_in_window owns
-// site k (its allele of the current walk, last site varying fastest: itertools.product order);
-// lane j < W owns base j of the k-mer; lanes own words of the haplotype bitsets.
+// haplotypes per allele of every site (allele 0 = reference): a walk through ONE site needs no bitset
+// read at all, and most windows hold at most one site
+__global__ void __launch_bounds__(256)
+graph_allele_count_kernel(GraphDev g, int *__restrict__ allele_count /* [n_sites][4] */)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n_sites) return;
+    int c[4] = {0, 0, 0, 0};
+    for (int word = 0; word < g.hw; ++word) {
+        const unsigned long long *b = g.alt_bits + ((size_t)i * kMaxAlts) * g.hw + word;
+        unsigned long long any = 0ull;
+        for (int a = 0; a < g.n_alts[i]; ++a) {
+            const unsigned long long v = b[(size_t)a * g.hw];
+            c[a + 1] += __popcll(v);
+            any |= v;
+        }
+        unsigned long long valid = ~0ull;
+        if (word == g.hw - 1 && (g.n_hap & 63)) valid = (1ull << (g.n_hap & 63)) - 1ull;
+        c[0] += __popcll(~any & valid);
+    }
+    for (int a = 0; a < 4; ++a) allele_count[(size_t)i * 4 + a] = c[a];
+}
+
+// thread per window: walk t of the plan belongs to window walk_window[t]
+__global__ void __launch_bounds__(kCountThreads)
+graph_map_kernel(long long n_windows, const long long *__restrict__ walk_base, int *__restrict__ walk_window)
+{
+    const long long w = (long long)blockIdx.x * kCountThreads + threadIdx.x;
+    if (w >= n_windows) return;
+    const long long b = walk_base[w], e = walk_base[w + 1];
+    for (long long t = b; t < e; ++t) walk_window[t] = (int)w;
+}
+
+// Thread per walk.  Neighbouring threads are walks of one window or of overlapping windows: their
+// reference bytes, site records and bitset words are the same cache lines, and every per-row column
+// is written fully coalesced (rows 2t and 2t+1 of thread t).  The walk index is a mixed-radix number
+// over the sites of the window, last site fastest (itertools.product order); the allele digits are
+// kept packed two bits each.
 __global__ void __launch_bounds__(kEmitThreads)
-graph_emit_kernel(GraphDev g, const int *__restrict__ win_region, const long long *__restrict__ win_start,
-                  int W, long long n_windows, const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ walk_window,
+                  const int *__restrict__ win_region, const long long *__restrict__ win_start, int W,
+                  long long n_walks, const int *__restrict__ first_site, const long long *__restrict__ walk_base,
                   uint8_t *__restrict__ kmers, long long *__restrict__ start, long long *__restrict__ stop,
                   uint8_t *__restrict__ strand, long long *__restrict__ freq, uint8_t *__restrict__ is_ref,
                   int *__restrict__ region, int *__restrict__ walk)
 {
-    __shared__ uint8_t kbuf[kEmitThreads / kWave][kWave];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x >> 6;
-    const long long stride = (long long)gridDim.x * (kEmitThreads / kWave);
-    for (long long w = (long long)blockIdx.x * (kEmitThreads / kWave) + wv; w < n_windows; w += stride) {
-        const int r = win_region[w];
-        const long long p = win_start[w];
-        const int i0 = first_site[w];
-        const long long base = walk_base[w];
-        const int walks = (int)(walk_base[w + 1] - base);
-        // sites of the window: lane k owns site i0 + k (at most W <= 64 of them)
-        int my_pos = -1, my_nall = 1;
-        if (i0 + lane < g.n_sites && g.pos[i0 + lane] < p + W && lane < W) {
-            my_pos = g.pos[i0 + lane];
-            my_nall = 1 + g.n_alts[i0 + lane];
-        }
-        const int ns = __popcll(__builtin_amdgcn_ballot_w64(my_pos >= 0));
-        // suffix products of the allele counts: stride of site k in the mixed-radix walk index
-        int my_stride = 1;
-        for (int k = ns - 1; k >= 0; --k) {
-            const int nk = __shfl(my_nall, k);
-            if (lane < k) my_stride *= nk;
-        }
-        const uint8_t ref_base = lane < W ? g.ref[p + lane] : (uint8_t)0;
-        for (int q = 0; q < walks; ++q) {
-            const int my_allele = my_pos >= 0 ? (q / my_stride) % my_nall : 0;
-            // k-mer bytes: reference window, then the alternate bases of this walk
-            kbuf[wv][lane] = ref_base;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (my_allele > 0)
-                kbuf[wv][my_pos - p] = g.alt_bases[(size_t)(i0 + lane) * kMaxAlts + (my_allele - 1)];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const long long row = 2 * (base + q);
-            if (lane < W) {
-                kmers[row * W + lane] = kbuf[wv][lane];
-                kmers[(row + 1) * W + lane] = complement(kbuf[wv][W - 1 - lane]);
-            }
-            // haplotypes that carry every allele of the walk
-            long long count = ns == 0 ? g.n_hap : 0;     // no site in the window: every haplotype carries it
-            if (g.alt_bits && ns > 0) {
-                for (int w0 = 0; w0 < g.hw; w0 += kWave) {     // every lane takes part in the shuffles
-                    const int word = w0 + lane;
-                    const bool live = word < g.hw;
-                    unsigned long long acc = ~0ull;
-                    if (word == g.hw - 1 && (g.n_hap & 63)) acc = (1ull << (g.n_hap & 63)) - 1ull;
-                    for (int k = 0; k < ns; ++k) {
-                        const int a = __shfl(my_allele, k);
-                        const int na = __shfl(my_nall, k) - 1;
-                        if (!live) continue;
-                        const unsigned long long *b = g.alt_bits + ((size_t)(i0 + k) * kMaxAlts) * g.hw + word;
-                        unsigned long long bits;
-                        if (a > 0) {
-                            bits = b[(size_t)(a - 1) * g.hw];
-                        } else {
-                            bits = b[0];
-                            if (na > 1) bits |= b[(size_t)g.hw];
-                            if (na > 2) bits |= b[(size_t)2 * g.hw];
-                            bits = ~bits;
-                        }
-                        acc &= bits;
-                    }
-                    if (live) count += __popcll(acc);
-                }
-                for (int d = 32; d > 0; d >>= 1) count += __shfl_xor(count, d);
-            }
-            const bool any_alt = __builtin_amdgcn_ballot_w64(my_allele > 0) != 0ull;
-            if (lane < 2) {      // lane 0: forward row, lane 1: its reverse complement
-                start[row + lane] = lane ? p + W : p;
-                stop[row + lane] = lane ? p : p + W;
-                strand[row + lane] = lane ? '-' : '+';
-                freq[row + lane] = count;
-                is_ref[row + lane] = any_alt ? 0 : 1;
-                region[row + lane] = r;
-                walk[row + lane] = q;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // kbuf is rewritten by the next walk
-            __builtin_amdgcn_wave_barrier();
+    // the block's 2 x 256 k-mer rows are contiguous in the output: they are assembled in LDS with
+    // byte writes and leave with 16-byte coalesced stores (row starts are not even dword aligned)
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+    const long long t0 = (long long)blockIdx.x * kEmitThreads;
+    const long long t = t0 + threadIdx.x;
+    const bool valid = t < n_walks;
+    const long long tt = valid ? t : n_walks - 1;       // idle threads of the last block shadow a real walk
+    const int w = walk_window[tt];
+    const long long p = win_start[w];
+    const int i0 = first_site[w];
+    int q = (int)(tt - walk_base[w]);
+    const int q0 = q;
+    int ns = 0;
+    while (i0 + ns < g.n_sites && g.pos[i0 + ns] < p + W) ++ns;
+    // allele digits, last site first
+    unsigned long long dig[2] = {0ull, 0ull};     // 2 bits per site, up to 64 sites
+    for (int k = ns - 1; k >= 0; --k) {
+        const int nall = 1 + g.n_alts[i0 + k];
+        const unsigned long long a = (unsigned long long)(q % nall);
+        q /= nall;
+        dig[k >> 5] |= a << (2 * (k & 31));
+    }
+    auto allele = [&](int k) { return (int)((dig[k >> 5] >> (2 * (k & 31))) & 3ull); };
+    const bool any_alt = (dig[0] | dig[1]) != 0ull;
+
+    // rows 2t (forward) and 2t+1 (reverse complement): reference window first, then the alternates
+    uint8_t *fwd = stage + (size_t)(2 * threadIdx.x) * W, *rev = fwd + W;
+    for (int j = 0; j < W; ++j) {
+        const uint8_t c = g.ref[p + j];
+        fwd[j] = c;
+        rev[W - 1 - j] = complement(c);
+    }
+    for (int k = 0; k < ns; ++k) {
+        const int a = allele(k);
+        if (a) {
+            const uint8_t c = g.alt_bases[(size_t)(i0 + k) * kMaxAlts + (a - 1)];
+            const int j = (int)(g.pos[i0 + k] - p);
+            fwd[j] = c;                      // same thread, same address: ordered after the reference byte
+            rev[W - 1 - j] = complement(c);
         }
     }
+
+    // haplotypes that carry every allele of the walk
+    long long count = 0;
+    if (g.alt_bits) {
+        if (ns == 0) {
+            count = g.n_hap;
+        } else if (ns == 1) {
+            count = allele_count[(size_t)i0 * 4 + allele(0)];
+        } else {
+            for (int word = 0; word < g.hw; ++word) {
+                unsigned long long acc = ~0ull;
+                if (word == g.hw - 1 && (g.n_hap & 63)) acc = (1ull << (g.n_hap & 63)) - 1ull;
+                for (int k = 0; k < ns && acc; ++k) {
+                    const unsigned long long *b = g.alt_bits + ((size_t)(i0 + k) * kMaxAlts) * g.hw + word;
+                    const int a = allele(k);
+                    unsigned long long bits;
+                    if (a > 0) {
+                        bits = b[(size_t)(a - 1) * g.hw];
+                    } else {
+                        const int na = g.n_alts[i0 + k];
+                        bits = b[0];
+                        if (na > 1) bits |= b[(size_t)g.hw];
+                        if (na > 2) bits |= b[(size_t)2 * g.hw];
+                        bits = ~bits;
+                    }
+                    acc &= bits;
+                }
+                count += __popcll(acc);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const long long rows_here = 2 * ((n_walks - t0) < (long long)kEmitThreads ? (n_walks - t0) : (long long)kEmitThreads);
+        const long long nbytes = rows_here * W;
+        uint8_t *dst = kmers + (size_t)(2 * t0) * W;     // 512 * W * blockIdx: a multiple of 16
+        for (long long o = (long long)threadIdx.x * 16; o < nbytes; o += (long long)kEmitThreads * 16) {
+            if (o + 16 <= nbytes) {
+                *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(stage + o);
+            } else {
+                for (long long b = o; b < nbytes; ++b) dst[b] = stage[b];
+            }
+        }
+    }
+    if (!valid) return;
+    const int r = win_region[w];
+    const long long row = 2 * t;
+    start[row] = p;          start[row + 1] = p + W;
+    stop[row] = p + W;       stop[row + 1] = p;
+    strand[row] = '+';       strand[row + 1] = '-';
+    freq[row] = count;       freq[row + 1] = count;
+    is_ref[row] = is_ref[row + 1] = any_alt ? 0 : 1;
+    region[row] = region[row + 1] = r;
+    walk[row] = walk[row + 1] = q0;
 }
 
 template <typename T> hipError_t upload(T **dst, const T *src, size_t count)
@@ -216,6 +265,24 @@ template <typename T> hipError_t upload(T **dst, const T *src, size_t count)
     return hipMemcpy(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice);
 }
 
+// grow-only device buffer: plans are made over and over (one per motif width); hipMalloc / hipFree per
+// plan cost more than the kernels
+template <typename T> struct Buf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t count)
+    {
+        if (count <= cap) return hipSuccess;
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, sizeof(T) * count);
+        if (e == hipSuccess) cap = count;
+        return e;
+    }
+    void release() { (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
 }  // namespace
 
 struct gfm_graph {
@@ -224,19 +291,19 @@ struct gfm_graph {
     int *d_pos = nullptr;
     uint8_t *d_n_alts = nullptr, *d_alt_bases = nullptr;
     unsigned long long *d_alt_bits = nullptr;
-    // last plan
+    int *d_allele_count = nullptr;   // [n_sites][4] haplotypes per allele (0 = reference)
+    // last plan (buffers are kept between plans)
     int n_regions = 0, width = 0;
     long long n_windows = 0, n_walks = 0;
-    long long *d_region_off = nullptr, *d_first_start = nullptr, *d_walk_base = nullptr;
-    int *d_first_site = nullptr, *d_win_region = nullptr;
-    long long *d_win_start = nullptr;
+    Buf<long long> region_off, first_start, walk_base, win_start, walks;
+    Buf<int> first_site, win_region, walk_window, flag;
+    Buf<unsigned char> scan_tmp;
     void drop_plan()
     {
-        (void)hipFree(d_region_off); (void)hipFree(d_first_start); (void)hipFree(d_walk_base);
-        (void)hipFree(d_first_site); (void)hipFree(d_win_region); (void)hipFree(d_win_start);
-        d_region_off = d_first_start = d_walk_base = d_win_start = nullptr;
-        d_first_site = d_win_region = nullptr;
-        n_regions = 0; n_windows = n_walks = 0;
+        region_off.release(); first_start.release(); walk_base.release(); win_start.release(); walks.release();
+        first_site.release(); win_region.release(); walk_window.release(); flag.release(); scan_tmp.release();
+        n_regions = 0;
+        n_windows = n_walks = 0;
     }
 };
 
@@ -278,6 +345,19 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     }
     g->dev = GraphDev{g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
                       bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0};
+    if (bits) {
+        e = hipMalloc(&g->d_allele_count, sizeof(int) * 4 * (size_t)n_sites);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(graph_allele_count_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, nullptr, g->dev,
+                               g->d_allele_count);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            gfm_graph_destroy(g);
+            return gfail(GFM_ERR_HIP, std::string("allele counts failed: ") + hipGetErrorString(e));
+        }
+    }
     *out = g;
     return GFM_OK;
 }
@@ -287,7 +367,7 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     if (!g) return;
     g->drop_plan();
     (void)hipFree(g->d_ref); (void)hipFree(g->d_pos); (void)hipFree(g->d_n_alts);
-    (void)hipFree(g->d_alt_bases); (void)hipFree(g->d_alt_bits);
+    (void)hipFree(g->d_alt_bases); (void)hipFree(g->d_alt_bits); (void)hipFree(g->d_allele_count);
     delete g;
 }
 
@@ -297,7 +377,7 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     if (!g || n_regions < 0 || (n_regions && (!h_starts || !h_stops)))
         return gfail(GFM_ERR_INVALID, "bad argument");
     if (width < 1 || width > GFM_MAX_WIDTH) return gfail(GFM_ERR_INVALID, "width outside [1, 64]");
-    g->drop_plan();
+    g->n_windows = g->n_walks = 0;
     g->width = width;
     g->n_regions = n_regions;
     // windows of region r: starts p in [max(S,0), min(E, ref_len) - W]  (vg find -p S-E -K W, pinned by
@@ -309,44 +389,47 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
         first[r] = s;
         off[r + 1] = off[r] + std::max<long long>(0, e - width - s + 1);
     }
-    g->n_windows = off[n_regions];
-    if (n_windows) *n_windows = g->n_windows;
+    if (n_windows) *n_windows = off[n_regions];
     if (n_rows) *n_rows = 0;
-    if (g->n_windows == 0) return GFM_OK;
-    if (g->n_windows > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "too many windows in one plan (split the regions)");
-    GX_TRY(upload(&g->d_region_off, off.data(), off.size()));
-    GX_TRY(upload(&g->d_first_start, first.data(), first.size()));
-    // walks per window -> exclusive prefix (row base of every window), all on the device: only the
-    // total and the overflow flag come back
-    struct Scratch {
-        long long *walks = nullptr;
-        int *flag = nullptr;
-        void *tmp = nullptr;
-        ~Scratch() { (void)hipFree(walks); (void)hipFree(flag); (void)hipFree(tmp); }
-    } sc;
-    const size_t nw = (size_t)g->n_windows;
-    GX_TRY(hipMalloc(&g->d_first_site, sizeof(int) * nw));
-    GX_TRY(hipMalloc(&sc.walks, sizeof(long long) * nw));
-    GX_TRY(hipMalloc(&sc.flag, sizeof(int)));
-    GX_TRY(hipMemsetAsync(sc.flag, 0, sizeof(int), nullptr));
-    GX_TRY(hipMalloc(&g->d_win_region, sizeof(int) * nw));
-    GX_TRY(hipMalloc(&g->d_win_start, sizeof(long long) * nw));
-    GX_TRY(hipMalloc(&g->d_walk_base, sizeof(long long) * (nw + 1)));
-    GX_TRY(hipMemsetAsync(g->d_walk_base, 0, sizeof(long long), nullptr));
-    const unsigned blocks = (unsigned)((g->n_windows + kCountThreads - 1) / kCountThreads);
+    if (off[n_regions] == 0) return GFM_OK;
+    if (off[n_regions] > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "too many windows in one plan (split the regions)");
+    const size_t nw = (size_t)off[n_regions];
+    GX_TRY(g->region_off.reserve(off.size()));
+    GX_TRY(g->first_start.reserve(first.size()));
+    GX_TRY(g->first_site.reserve(nw));
+    GX_TRY(g->walks.reserve(nw));
+    GX_TRY(g->flag.reserve(1));
+    GX_TRY(g->win_region.reserve(nw));
+    GX_TRY(g->win_start.reserve(nw));
+    GX_TRY(g->walk_base.reserve(nw + 1));
+    GX_TRY(hipMemcpyAsync(g->region_off.p, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, nullptr));
+    GX_TRY(hipMemcpyAsync(g->first_start.p, first.data(), sizeof(long long) * first.size(), hipMemcpyHostToDevice, nullptr));
+    GX_TRY(hipMemsetAsync(g->flag.p, 0, sizeof(int), nullptr));
+    GX_TRY(hipMemsetAsync(g->walk_base.p, 0, sizeof(long long), nullptr));
+    // walks per window -> inclusive prefix (row base of every window) on the device: only the total and the
+    // overflow flag come back
+    const unsigned blocks = (unsigned)((nw + kCountThreads - 1) / kCountThreads);
     hipLaunchKernelGGL(graph_count_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->dev, n_regions,
-                       g->d_region_off, g->d_first_start, width, g->n_windows, g->d_first_site, sc.walks,
-                       g->d_win_region, g->d_win_start, sc.flag);
+                       g->region_off.p, g->first_start.p, width, (long long)nw, g->first_site.p, g->walks.p,
+                       g->win_region.p, g->win_start.p, g->flag.p);
     GX_TRY(hipGetLastError());
     size_t tmp_bytes = 0;
-    GX_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, sc.walks, g->d_walk_base + 1, (int)nw, nullptr));
-    GX_TRY(hipMalloc(&sc.tmp, tmp_bytes));
-    GX_TRY(hipcub::DeviceScan::InclusiveSum(sc.tmp, tmp_bytes, sc.walks, g->d_walk_base + 1, (int)nw, nullptr));
+    GX_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, g->walks.p, g->walk_base.p + 1, (int)nw, nullptr));
+    GX_TRY(g->scan_tmp.reserve(tmp_bytes));
+    GX_TRY(hipcub::DeviceScan::InclusiveSum(g->scan_tmp.p, tmp_bytes, g->walks.p, g->walk_base.p + 1, (int)nw, nullptr));
     long long total = 0;
     int overflow = 0;
-    GX_TRY(hipMemcpy(&total, g->d_walk_base + nw, sizeof total, hipMemcpyDeviceToHost));
-    GX_TRY(hipMemcpy(&overflow, sc.flag, sizeof overflow, hipMemcpyDeviceToHost));
+    GX_TRY(hipMemcpy(&total, g->walk_base.p + nw, sizeof total, hipMemcpyDeviceToHost));   // also orders the host vectors
+    GX_TRY(hipMemcpy(&overflow, g->flag.p, sizeof overflow, hipMemcpyDeviceToHost));
     if (overflow) return gfail(GFM_ERR_OVERFLOW, "a window holds more than 2^20 walks through its sites");
+    if (total > 0x3fffffffll) return gfail(GFM_ERR_INVALID, "too many rows in one plan (split the regions)");
+    if (total > 0) {
+        GX_TRY(g->walk_window.reserve((size_t)total));
+        hipLaunchKernelGGL(graph_map_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, (long long)nw,
+                           g->walk_base.p, g->walk_window.p);
+        GX_TRY(hipGetLastError());
+    }
+    g->n_windows = (long long)nw;
     g->n_walks = total;
     if (n_rows) *n_rows = 2 * g->n_walks;
     return GFM_OK;
@@ -360,11 +443,10 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
     if (g->n_walks == 0) return GFM_OK;
     if (!d_kmers || !d_start || !d_stop || !d_strand || !d_freq || !d_is_ref || !d_region || !d_walk)
         return gfail(GFM_ERR_INVALID, "NULL output buffer");
-    const long long waves = g->n_windows;
-    const unsigned blocks = (unsigned)std::min<long long>((waves + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(graph_emit_kernel, dim3(blocks), dim3(kEmitThreads), 0, static_cast<hipStream_t>(stream),
-                       g->dev, g->d_win_region, g->d_win_start, g->width, g->n_windows,
-                       g->d_first_site, g->d_walk_base, d_kmers, reinterpret_cast<long long *>(d_start),
+    const unsigned blocks = (unsigned)((g->n_walks + kEmitThreads - 1) / kEmitThreads);
+    hipLaunchKernelGGL(graph_emit_kernel, dim3(blocks), dim3(kEmitThreads), (size_t)2 * kEmitThreads * g->width,
+                       static_cast<hipStream_t>(stream), g->dev, g->d_allele_count, g->walk_window.p,
+                       g->win_region.p, g->win_start.p, g->width, g->n_walks, g->first_site.p, g->walk_base.p, d_kmers, reinterpret_cast<long long *>(d_start),
                        reinterpret_cast<long long *>(d_stop), d_strand, reinterpret_cast<long long *>(d_freq),
                        d_is_ref, d_region, d_walk);
     GX_TRY(hipGetLastError());
