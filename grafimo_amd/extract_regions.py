@@ -278,21 +278,34 @@ def read_bed_regions(bedfile: str) -> Dict[str, List[Tuple[int, int]]]:
     return out
 
 
-def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_obj) -> pd.DataFrame:
+def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_obj, group=None,
+                               always_collective: bool = False) -> Optional[pd.DataFrame]:
     """extract_regions.scan_graph + score_sequences.compute_results in one device pipeline: the rows go
     from the extraction kernel to the score kernel in HBM; only the hits and their metadata come back.
     `graph` / `regions`: one DeviceGraph with its [(S, E)] list, or lists of both (one entry per
     chromosome) -- the q-values are computed over the rows of all of them, like the reference does over
-    all TSV files of a motif."""
+    all TSV files of a motif.
+    Under torch.distributed (one process per GPU, every rank calls this with the same arguments and its
+    own replica of the graphs) the regions are split over the ranks, the score histogram is all-reduced
+    so that q-values stay global, and rank 0 returns the merged table (the others None)."""
     from .scan import KmerScanner
     from .score_sequences import print_scoring_msg
     torch = _torch()
     graphs = list(graph) if isinstance(graph, (list, tuple)) else [graph]
-    region_lists = list(regions) if isinstance(graph, (list, tuple)) else [regions]
+    region_lists = [list(r) for r in regions] if isinstance(graph, (list, tuple)) else [list(regions)]
+    dist = torch.distributed
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 or (dist.is_available() and dist.is_initialized()) else 0
+    if world > 1:                                    # contiguous shard of the flattened (graph, region) list
+        from .distributed import shard_bounds
+        flat = [(gi, r) for gi, regs in enumerate(region_lists) for r in regs]
+        lo_, hi_ = shard_bounds(len(flat), world, rank)
+        region_lists = [[r for gi2, r in flat[lo_:hi_] if gi2 == gi] for gi in range(len(graphs))]
     threshold = float(args_obj.threshold)
     no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
     no_reverse, recomb = bool(args_obj.noreverse), bool(args_obj.recomb)
-    print_scoring_msg(motif, no_reverse, debug)
+    if rank == 0:
+        print_scoring_msg(motif, no_reverse, debug)
     W = motif.width
     parts = [g.extract(r, W) for g, r in zip(graphs, region_lists)]
     labels: List[str] = []
@@ -309,26 +322,35 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
         keep = torch.arange(0, n_all, 2, device=kmers.device)
         kmers = kmers[keep].contiguous()
     n = int(kmers.shape[0])
-    if n == 0:
+    n_global = n
+    if world > 1 or always_collective:
+        tot = torch.tensor([n], dtype=torch.int64, device=kmers.device)
+        dist.all_reduce(tot, group=group)
+        n_global = int(tot.item())
+    if n_global == 0:
         errmsg = "No result retrieved. Unable to proceed.\n"
         errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
         exception_handler(ValueError, errmsg, debug)
     dm = DeviceMotif.from_motif(motif)
     try:
-        if not no_qvalue:
+        if not no_qvalue and rank == 0:
             print("\nComputing q-values...\n")
-        sc = KmerScanner(dm, n, device=kmers.device, side_stream=False)
+        # with a process group the scanner all-reduces the histogram before the q-table; hits stay local
+        # (their metadata lives on this rank) and travel as finished table rows below
+        sc = KmerScanner(dm, max(n, 1), device=kmers.device, side_stream=False, group=group,
+                         always_collective=always_collective)
         res = sc.collect(sc.enqueue(kmers, threshold, on_qvalue=qval_t, want_qvalues=not no_qvalue),
                          want_qvalues=not no_qvalue)
         lo, pv = dm.annotate(res["scaled"])
     finally:
         dm.close()
-    print(f"Scanned sequences:\t{n}")
-    print(f"Scanned nucleotides:\t{n * W}")
+    if rank == 0:
+        print(f"Scanned sequences:\t{n_global}")
+        print(f"Scanned nucleotides:\t{n_global * W}")
     hit = torch.from_numpy(res["rows"]).to(kmers.device)
     src = keep[hit] if keep is not None else hit
     take = lambda t: t[src].cpu().numpy()
-    return build_frame(
+    df = build_frame(
         motif,
         seqnames=[labels[int(r)] for r in take(region)],
         starts=take(cat("start")), stops=take(cat("stop")),
@@ -340,3 +362,7 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
         references=["ref" if r else "non.ref" for r in take(cat("is_ref"))],
         threshold=None, recomb=recomb,
     )
+    if world > 1:
+        from .distributed import gather_frames
+        return gather_frames(df, group)
+    return df

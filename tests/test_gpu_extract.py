@@ -173,3 +173,33 @@ def test_several_graphs_share_one_scoring_pass_and_cli_mode(tmp_path, capsys):
     np.testing.assert_allclose(tsv["q-value"].to_numpy(), one["q-value"].to_numpy(), rtol=1e-12)
     with pytest.raises(SystemExit):
         main(["-m", "x.meme", "-l", fasta])            # incomplete graph inputs
+
+
+def test_graph_pipeline_under_a_process_group(tmp_path):
+    """The sharded form of compute_results_from_graph with an RCCL group of one rank: the row-count and
+    histogram all-reduces are really issued, the table is unchanged."""
+    import socket
+    import torch.distributed as dist
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, compute_results_from_graph
+    from grafimo_amd.motif_ops import build_motif_meme_host
+    from grafimo_amd.workflow import Findmotif
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=3000, n_sites=200, seed=12)
+    regions = [(0, 1000), (1500, 2990)]
+    motif = build_motif_meme_host(os.path.join(REF_DATA, "MA0139.1.meme"), "unfrm_dst", 0.1, False)[0]
+    g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7"))
+    kw = Findmotif(threshold=0.05, recomb=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        plain = compute_results_from_graph(motif, g, regions, True, kw)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            coll = compute_results_from_graph(motif, g, regions, True, kw, always_collective=True)
+        assert "Scanned sequences" in out.getvalue()
+    finally:
+        dist.destroy_process_group()
+    assert len(plain) > 0 and plain.equals(coll)
+    g.close()
