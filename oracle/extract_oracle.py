@@ -17,6 +17,12 @@ quay.io/vgteam/vg:v1.27.1).  Pinning:
     the structure seen in the reference's scoring fixture: 5096 on invariant windows, n / 5096-n on
     the two arms of a SNP), node chopping at 32 bp, and anything involving indels (records whose
     REF or ALT is not a single base are skipped and counted).
+What the reference's scoring fixture (tests/test_data/input/width_19/scoring_test_input.tsv) shows about
+deletions, for the round that adds them: a walk that skips a deleted reference node (849133+,849135+ around
+22:19723468, a 2-bp deletion carried by 1 of 5096 haplotypes) keeps its start, reports stop = start + W + 2
+(reference coordinate after its last base), and is labelled `ref` by vg because every node it visits is on
+the reference path -- which is exactly what GRAFIMO's `ref -> non.ref if |stop-start| != W` rule repairs
+(score_sequences.py:305-307).  Insertions do not occur in that fixture.
 """
 import gzip
 import itertools
