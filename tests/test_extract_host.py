@@ -78,3 +78,27 @@ def test_node_numbering_matches_the_oracle(tmp_path):
     # the reference's test graph: ids 1..9 as in expected_seqs.tsv
     t = GraphIndex.from_fasta_vcf(os.path.join(REF_DATA, "test.fa"), os.path.join(REF_DATA, "test.vcf.gz"), "x")
     assert t.node_path(0, 19, 0) == [1, 3, 5, 6, 8, 9] and t.node_path(0, 19, 7) == [1, 2, 4, 6, 7, 9]
+
+
+def test_graph_abi_validates_before_touching_a_device():
+    import ctypes
+    from grafimo_amd import _native as nv
+    lib = nv.lib()
+    h = ctypes.c_void_p()
+    ref = np.frombuffer(b"ACGTACGTAC", dtype=np.uint8)
+    pos = np.array([5, 2], dtype=np.int32)
+    n_alts = np.array([1, 1], dtype=np.uint8)
+    alt = np.zeros((2, 3), dtype=np.uint8)
+    assert lib.gfm_graph_create(None, 10, 0, None, None, None, None, 0, ctypes.byref(h)) == nv.GFM_ERR_INVALID
+    rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt), None, 0, ctypes.byref(h))
+    assert rc == nv.GFM_ERR_INVALID and b"ascending" in lib.gfm_last_error()
+    pos = np.array([2, 5], dtype=np.int32)
+    n_alts[1] = 4
+    rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt), None, 0, ctypes.byref(h))
+    assert rc == nv.GFM_ERR_INVALID and b"1..3" in lib.gfm_last_error()
+    assert lib.gfm_graph_plan(None, 0, None, None, 19, None, None) == nv.GFM_ERR_INVALID
+    import torch
+    if not torch.cuda.is_available():          # no CPU fallback: a valid graph still needs a GPU
+        n_alts[1] = 1
+        rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt), None, 0, ctypes.byref(h))
+        assert rc == nv.GFM_ERR_NODEVICE and not h.value
