@@ -21,7 +21,7 @@ import time
 
 from .motif_ops import get_motif_pwm
 from .res_writer import DEFAULT_OUTDIR, print_results, write_results
-from .score_sequences import compute_results
+from .score_sequences import compute_results, compute_results_many
 from .utils import UNIF
 from .workflow import Findmotif
 
@@ -90,9 +90,12 @@ def main(argv=None):
                       f"{index.skipped} other VCF records left out")
             graphs.append(DeviceGraph(index))
             region_lists.append(regs)
-    for motif in motifs:
+    shared = None if from_graph or len(motifs) < 2 else compute_results_many(motifs, a.sequences, a.debug, wf)
+    for k, motif in enumerate(motifs):
         if from_graph:
             res = compute_results_from_graph(motif, graphs, region_lists, a.debug, wf)
+        elif shared is not None:
+            res = shared[k]              # one ingest / upload per width, batched launches
         else:
             res = compute_results(motif, a.sequences, a.debug, wf)
         if a.text_only:

@@ -170,3 +170,67 @@ def compute_results(motif: Motif, sequence_loc: str, debug: bool, args_obj=None,
     if verbose:
         print("\nResults summary built in %.2fs" % (time.time() - start_df))
     return df
+
+
+def _frame_from_hits(motif: Motif, table: "KmerTable", rows, logodds, pvalue, qvalue, recomb: bool) -> pd.DataFrame:
+    names = np.array(table.names, dtype=object)
+    return build_frame(
+        motif,
+        seqnames=list(names[table.name_id[rows]]),
+        starts=table.start[rows], stops=table.stop[rows],
+        strands=[chr(c) for c in table.strand[rows]],
+        scores=logodds, pvalues=pvalue, qvalues=qvalue,
+        seqs=[bytes(k).decode() for k in table.kmers[rows]],
+        frequencies=table.freq[rows],
+        references=["ref" if r else "non.ref" for r in table.is_ref[rows]],
+        threshold=None, recomb=bool(recomb),
+    )
+
+
+def compute_results_many(motifs: List[Motif], sequence_loc: str, debug: bool, args_obj) -> List[pd.DataFrame]:
+    """compute_results for a whole motif set (the `for motif in motif_set` loop of grafimo.findmotif,
+    grafimo.py:177-183) without repeating the shared work: the TSV files of a width are parsed and
+    uploaded ONCE for all motifs of that width, and up to three motifs share each read of the k-mers
+    on the device (gfm_score_kmers_multi).  Returns the tables in the order of `motifs`; every table
+    equals compute_results(motif, ...) and the same lines are printed per motif."""
+    import torch
+    from .scan import scan_same_width
+    if not is_findmotif_like(args_obj):
+        exception_handler(TypeError, f"Expected Findmotif, got {type(args_obj).__name__}.\n", debug)
+    threshold = float(args_obj.threshold)
+    no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
+    no_reverse, recomb = bool(args_obj.noreverse), bool(args_obj.recomb)
+    assert 0 < threshold <= 1
+    out: List[Optional[pd.DataFrame]] = [None] * len(motifs)
+    by_width = {}
+    for i, m in enumerate(motifs):
+        if not isinstance(m, Motif):
+            exception_handler(TypeError, f"Expected Motif, got {type(m).__name__}.\n", debug)
+        by_width.setdefault(m.width, []).append(i)
+    for width, idxs in by_width.items():
+        files = sorted(glob.glob(os.path.join(sequence_loc, f"width_{width}", "*.tsv")))
+        try:
+            table = KmerTable(files, width, no_reverse, max(1, int(args_obj.cores)))
+        except nv.NativeError as e:
+            exception_handler(ValueError if e.code == nv.GFM_ERR_IO else RuntimeError, e.msg + "\n", debug)
+        if table.n == 0:
+            errmsg = "No result retrieved. Unable to proceed.\n"
+            errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
+            exception_handler(ValueError, errmsg, debug)
+        d_kmers = torch.from_numpy(table.kmers).cuda()
+        dms = [DeviceMotif.from_motif(motifs[i]) for i in idxs]
+        try:
+            results = scan_same_width(dms, d_kmers, threshold, on_qvalue=qval_t, want_qvalues=not no_qvalue)
+            for i, dm, res in zip(idxs, dms, results):
+                print_scoring_msg(motifs[i], no_reverse, debug)
+                if not no_qvalue:
+                    print("\nComputing q-values...\n")
+                lo, pv = dm.annotate(res["scaled"])
+                print(f"Scanned sequences:\t{table.n}")
+                print(f"Scanned nucleotides:\t{table.n * width}")
+                out[i] = _frame_from_hits(motifs[i], table, res["rows"], lo, pv,
+                                          None if no_qvalue else res["qtable"][res["scaled"]], recomb)
+        finally:
+            for dm in dms:
+                dm.close()
+    return out

@@ -205,3 +205,35 @@ def test_cli_scoring_stage_writes_the_reference_reports(tmp_path, golden_json, c
     assert os.path.isfile(out / "grafimo_out.html")
     main(["-m", os.path.join(REF_DATA, "MA0139.1.jaspar"), "-s", REF_DATA, "-t", "5e-3", "-q", "-f"])
     assert "matched_sequence" in capsys.readouterr().out
+
+
+def test_compute_results_many_equals_per_motif_calls(tmp_path):
+    """The motif-set form (one ingest and one upload per width, batched launches) returns, motif by
+    motif, the table compute_results returns: the six motifs of a MEME file over TSV directories of
+    their widths, p- and q-value thresholds, and the CLI path that uses it."""
+    from grafimo_amd import synth
+    from grafimo_amd.__main__ import main
+    from grafimo_amd.motif_ops import build_motif_meme_host
+    from grafimo_amd.score_sequences import compute_results, compute_results_many
+    from grafimo_amd.workflow import Findmotif
+    meme = os.path.join(GOLDEN, "synth", "multi.meme")
+    motifs = build_motif_meme_host(meme, os.path.join(GOLDEN, "synth", "bg_1.txt"), 0.1, False)
+    motifs += build_motif_meme_host(os.path.join(REF_DATA, "MA0139.1.meme"), "unfrm_dst", 0.1, False)
+    widths = sorted({m.width for m in motifs})
+    assert len(motifs) == 7 and len(widths) < len(motifs)          # some widths are shared
+    for w in widths:
+        probs = np.asarray([m for m in motifs if m.width == w][0].count_matrix)
+        synth.write_tsv_dir(synth.make_batch(3, 400, w, probs, synth.seed_for(w)), str(tmp_path))
+    for kw in [dict(threshold=1e-2), dict(threshold=0.5, qval_t=True, recomb=True), dict(threshold=1e-2, no_qvalue=True)]:
+        wf = Findmotif(cores=2, **kw)
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            many = compute_results_many(motifs, str(tmp_path), True, wf)
+        assert out.getvalue().count("Scanned sequences:") == len(motifs)
+        for m, df in zip(motifs, many):
+            with contextlib.redirect_stdout(io.StringIO()):
+                one = compute_results(m, str(tmp_path), True, wf)
+            assert len(df) == len(one) > 0, (m.motif_id, kw)
+            _compare(df, one)
+    main(["-m", meme, "-k", os.path.join(GOLDEN, "synth", "bg_1.txt"), "-s", str(tmp_path), "-t", "1e-2",
+          "-o", str(tmp_path / "out")])
+    assert len([f for f in os.listdir(tmp_path / "out") if f.endswith(".tsv")]) == 6
