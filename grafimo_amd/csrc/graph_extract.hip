@@ -46,7 +46,7 @@ int gfail(int code, const std::string &msg)
 
 constexpr int kMaxAlts = 3;
 constexpr int kCountThreads = 256;
-constexpr int kEmitThreads = 256;                    // 4 waves, one window per wave at a time
+constexpr int kEmitThreads = 256;                    // walks (threads) per workgroup of the emit kernel
 constexpr long long kMaxWalksPerWindow = 1ll << 20;  // refuse pathological windows (2^20 walks)
 
 struct GraphDev {
@@ -209,25 +209,38 @@ graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *_
         } else if (ns == 1) {
             count = allele_count[(size_t)i0 * 4 + allele(0)];
         } else {
-            for (int word = 0; word < g.hw; ++word) {
-                unsigned long long acc = ~0ull;
-                if (word == g.hw - 1 && (g.n_hap & 63)) acc = (1ull << (g.n_hap & 63)) - 1ull;
-                for (int k = 0; k < ns && acc; ++k) {
-                    const unsigned long long *b = g.alt_bits + ((size_t)(i0 + k) * kMaxAlts) * g.hw + word;
-                    const int a = allele(k);
-                    unsigned long long bits;
-                    if (a > 0) {
-                        bits = b[(size_t)(a - 1) * g.hw];
-                    } else {
-                        const int na = g.n_alts[i0 + k];
-                        bits = b[0];
-                        if (na > 1) bits |= b[(size_t)g.hw];
-                        if (na > 2) bits |= b[(size_t)2 * g.hw];
-                        bits = ~bits;
-                    }
-                    acc &= bits;
+            // words are independent: a few of them per trip, so that their loads are in flight together
+            // (one word per trip made every such walk a chain of ~hw dependent L2 latencies)
+            constexpr int kWordsPerTrip = 8;
+            for (int w0 = 0; w0 < g.hw; w0 += kWordsPerTrip) {
+                unsigned long long acc[kWordsPerTrip];
+#pragma unroll
+                for (int j = 0; j < kWordsPerTrip; ++j) {
+                    const int word = w0 + j;
+                    acc[j] = word < g.hw ? ~0ull : 0ull;
+                    if (word == g.hw - 1 && (g.n_hap & 63)) acc[j] = (1ull << (g.n_hap & 63)) - 1ull;
                 }
-                count += __popcll(acc);
+                for (int k = 0; k < ns; ++k) {
+                    const unsigned long long *b = g.alt_bits + ((size_t)(i0 + k) * kMaxAlts) * g.hw + w0;
+                    const int a = allele(k);
+                    const int na = g.n_alts[i0 + k];
+#pragma unroll
+                    for (int j = 0; j < kWordsPerTrip; ++j) {
+                        if (w0 + j >= g.hw) continue;
+                        unsigned long long bits;
+                        if (a > 0) {
+                            bits = b[(size_t)(a - 1) * g.hw + j];
+                        } else {
+                            bits = b[j];
+                            if (na > 1) bits |= b[(size_t)g.hw + j];
+                            if (na > 2) bits |= b[(size_t)2 * g.hw + j];
+                            bits = ~bits;
+                        }
+                        acc[j] &= bits;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < kWordsPerTrip; ++j) count += __popcll(acc[j]);
             }
         }
     }

@@ -31,7 +31,7 @@ for s in range(0, V, blk):
     carry = rng.random((e - s, hw * 64)) < af[s:e, None]
     carry[:, H:] = False
     bits[s:e, 0, :] = np.packbits(carry, axis=1, bitorder="little").view(np.uint64)
-idx = GraphIndex("22", ref, pos, n_alts, alt_bases, bits, H)
+idx = GraphIndex("22", ref, pos, n_alts, alt_bases, None if os.environ.get("EXTRACT_NO_COUNTS") else bits, H)
 regions = [(16_000 + 1000 * i, 16_000 + 1000 * i + 200) for i in range(n_regions)]
 t = time.perf_counter(); g = DeviceGraph(idx); torch.cuda.synchronize(); t_up = time.perf_counter() - t
 
