@@ -72,6 +72,14 @@ def test_rows_equal_the_oracle_on_a_synthetic_graph(tmp_path, W):
     lab = {f"7:{max(s, 0)}-{min(e, 3000)}": f"7:{s}-{e}" for s, e in regions}
     exp_text = "".join("\t".join([lab[r[0]]] + [str(x) for x in r[1:]]) + "\n" for r in exp)
     assert sorted(text.splitlines()) == sorted(exp_text.splitlines())
+    # the handle keeps its plan buffers: a smaller and then a larger plan on the same graph
+    small = g.extract([(100, 400)], W)
+    assert [k.tobytes().decode() for k in small.kmers.cpu().numpy()] == \
+        [r[1] for r in _oracle_rows(fasta, vcf, "7", [(100, 400)], W)]
+    again = g.extract(regions + [(200, 2800)], W)
+    exp2 = exp + _oracle_rows(fasta, vcf, "7", [(200, 2800)], W)
+    assert again.freq.cpu().numpy().tolist() == [r[4] for r in exp2]
+    assert [k.tobytes().decode() for k in again.kmers.cpu().numpy()] == [r[1] for r in exp2]
     g.close()
 
 
