@@ -12,17 +12,19 @@ quay.io/vgteam/vg:v1.27.1).  Pinning:
     (32 rows, region x:0-20, W=19, test graph = tests/test_data/input/test.fa + test.vcf.gz; used by
     tests/grafimo_run_test.py:49-63): k-mer strings, start/stop strings, strand handling, the
     ref / non.ref flag and the node-id paths of every walk through the SNP bubbles;
-  * NOT pinned (no vg binary here, "parity unpinned"): the haplotype counts of ``-H`` (restated as
-    "number of phased haplotypes of the VCF that carry every allele of the walk", which reproduces
-    the structure seen in the reference's scoring fixture: 5096 on invariant windows, n / 5096-n on
-    the two arms of a SNP), node chopping at 32 bp, and anything involving indels (records whose
-    REF or ALT is not a single base are skipped and counted).
-What the reference's scoring fixture (tests/test_data/input/width_19/scoring_test_input.tsv) shows about
-deletions, for the round that adds them: a walk that skips a deleted reference node (849133+,849135+ around
-22:19723468, a 2-bp deletion carried by 1 of 5096 haplotypes) keeps its start, reports stop = start + W + 2
-(reference coordinate after its last base), and is labelled `ref` by vg because every node it visits is on
-the reference path -- which is exactly what GRAFIMO's `ref -> non.ref if |stop-start| != W` rule repairs
-(score_sequences.py:305-307).  Insertions do not occur in that fixture.
+  * PINNED by the reference's scoring fixture tests/test_data/input/width_19/scoring_test_input.tsv
+    (704 rows of real `vg find -K 19 -E -H` output for 22:19723256-19723526): the local graph --
+    270 reference bases, five SNPs, one 2-bp deletion, carrier counts -- is recoverable from the
+    fixture itself, and `enumerate_region_graph` reproduces every row: haplotype counts of -H
+    (haplotypes with every SNP allele of the walk, with every deletion it takes, and without any
+    deletion whose bases it uses), deletion rows (same start, stop = start + W + deleted length,
+    flag `ref` because only reference-path nodes are visited -- the case GRAFIMO's
+    `ref -> non.ref if |stop-start| != W` rule repairs, score_sequences.py:305-307), node ids
+    incl. chopping at 32 bases and the cuts a deletion makes;
+  * NOT pinned (no vg binary here): insertions and other non-SNP, non-deletion records (skipped and
+    counted), overlapping deletions (the later one is skipped), multi-allelic sites' node order
+    beyond "alternates first", and whether vg drops a deletion-crossing walk whose stop lies beyond
+    the region end (here the start decides).
 """
 import gzip
 import itertools
@@ -180,4 +182,160 @@ def enumerate_region(chrom: str, ref: bytes, sites: Sites, S: int, E: int, W: in
             kmer = bytes(k)
             rows.append((label, kmer.decode(), f"{chrom}:{p}+", f"{chrom}:{p + W}+", count, is_ref, fwd))
             rows.append((label, revcomp(kmer).decode(), f"{chrom}:{p + W}-", f"{chrom}:{p}-", count, is_ref, rev))
+    return rows
+
+
+# =====================================================================================
+# Graphs with deletions.  Pinned by the reference's scoring fixture: the local graph of
+# 22:19723256-19723526 (270 reference bases, five SNPs and one 2-bp deletion, all recoverable from
+# tests/test_data/input/width_19/scoring_test_input.tsv itself) reproduces all 704 rows of vg's
+# `find -K 19 -E -H` output -- k-mers, coordinates, haplotype counts, ref flags and node paths
+# (tests/test_extract_host.py::test_oracle_reproduces_vg_rows_of_the_scoring_fixture).
+class Dels:
+    """Deletions: anchor (0-based position of the base before the deleted ones), length, and per
+    haplotype whether it carries the deletion.  Deleted bases are anchor+1 .. anchor+length."""
+
+    def __init__(self, anchor, length, hap):
+        self.anchor = np.asarray(anchor, dtype=np.int64)
+        self.length = np.asarray(length, dtype=np.int64)
+        hap = np.asarray(hap, dtype=bool)
+        self.hap = hap.reshape(len(self.anchor), -1) if hap.size else np.zeros((len(self.anchor), hap.shape[-1] if hap.ndim > 1 else 0), bool)
+
+    def __len__(self):
+        return len(self.anchor)
+
+
+def read_vcf_graph(path: str, chrom: Optional[str] = None):
+    """-> (Sites, Dels, skipped).  SNP records as read_vcf_snps; a record REF = anchor base + deleted
+    bases, ALT = anchor base is a deletion; it is left out (counted in skipped) when its anchor or
+    span touches a deletion accepted before it.  Everything else (insertions, MNPs, ...) is skipped."""
+    pos, ref, alts, hap = [], [], [], []
+    d_anchor, d_len, d_hap, skipped, busy = [], [], [], 0, -1
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "rt") as fh:
+        for line in fh:
+            if line.startswith("#"):
+                continue
+            f = line.rstrip("\n").split("\t")
+            if chrom is not None and f[0] != chrom:
+                continue
+            r, a = f[3].upper(), f[4].upper().split(",")
+            gts = []
+            for s in f[9:]:
+                gt = s.split(":")[0].replace("/", "|").split("|")
+                if len(gt) == 1:
+                    gt = gt * 2
+                gts += [int(x) if x.isdigit() else 0 for x in gt[:2]]
+            p = int(f[1]) - 1
+            if len(r) == 1 and len(a) <= 3 and all(len(x) == 1 and x in "ACGT" for x in a):
+                if pos and p == pos[-1]:
+                    skipped += 1
+                    continue
+                pos.append(p); ref.append(r); alts.append(a); hap.append(gts)
+            elif len(r) > 1 and len(a) == 1 and a[0] == r[0] and p > busy:
+                d_anchor.append(p); d_len.append(len(r) - 1); d_hap.append([g == 1 for g in gts])
+                busy = p + len(r) - 1
+            else:
+                skipped += 1
+    H = len(hap[0]) if hap else (len(d_hap[0]) if d_hap else 0)
+    sites = Sites(pos, ref, alts, hap if hap else np.zeros((0, H), np.int8), skipped)
+    return sites, Dels(d_anchor, d_len, d_hap if d_hap else np.zeros((0, H), bool)), skipped
+
+
+class GraphNodeTable:
+    """vg construct's node ids on a reference + SNP + deletion graph: the reference is cut at every
+    SNP (the site is a node of its own: alternates numbered first, then the reference allele) and at
+    both ends of every deleted stretch; what lies between two cuts is chopped into nodes of at most
+    NODE_MAX bases.  `first_id` / `forced_cuts` let a test start inside a chromosome."""
+
+    def __init__(self, ref_len: int, sites: Sites, dels: Dels, first_id: int = 1, forced_cuts=(),
+                 node_max: int = NODE_MAX):
+        cuts = {0, ref_len} | set(int(c) for c in forced_cuts)
+        snp_at = {int(p): i for i, p in enumerate(sites.pos)}
+        for p in snp_at:
+            cuts |= {p, p + 1}
+        for a, ln in zip(dels.anchor, dels.length):
+            cuts |= {int(a) + 1, int(a) + int(ln) + 1}
+        cuts = sorted(c for c in cuts if 0 <= c <= ref_len)
+        self.ref_node = np.zeros(ref_len, dtype=np.int64)      # node id of the reference base at x
+        self.alt_node = {}                                     # (site index, alt number 1..) -> id
+        nid = first_id
+        for b, e in zip(cuts[:-1], cuts[1:]):
+            if e - b == 1 and b in snp_at:
+                i = snp_at[b]
+                for k in range(len(sites.alts[i])):
+                    self.alt_node[(i, k + 1)] = nid
+                    nid += 1
+                self.ref_node[b] = nid
+                nid += 1
+                continue
+            cur = b
+            while cur < e:
+                nxt = min(cur + node_max, e)
+                self.ref_node[cur:nxt] = nid
+                nid += 1
+                cur = nxt
+
+
+def enumerate_region_graph(chrom: str, ref: bytes, sites: Sites, dels: Dels, S: int, E: int, W: int,
+                           with_counts: bool = False, nodes: Optional[GraphNodeTable] = None):
+    """Rows of `vg find -p chrom:S-E -K W -E [-H]` on a graph with SNPs and deletions: every walk of
+    W bases from every start p in [S, E-W].  At a SNP the alleles are taken in order (reference
+    first); at the anchor of a deletion a walk that needs more bases first continues on the
+    reference, then takes the deletion.  stop = reference coordinate after the last base; the flag
+    is vg's (`ref` = only reference-path nodes: a taken deletion does not change it -- GRAFIMO's
+    own rule flips such rows, score_sequences.py:305-307); count = haplotypes with every SNP allele
+    of the walk, with every deletion it takes, and without any deletion whose bases it uses."""
+    label = f"{chrom}:{S}-{E}"
+    snp_at = {int(p): i for i, p in enumerate(sites.pos)}
+    del_at = {int(a): j for j, a in enumerate(dels.anchor)}
+    H = sites.n_haplotypes if len(sites.pos) else (dels.hap.shape[1] if len(dels) else 0)
+    rows = []
+
+    def emit(p, bases, used, snps, taken):
+        last = used[-1]
+        is_ref = "ref" if not any(a for _, a in snps) else "non.ref"
+        count = 0
+        if with_counts and H:
+            ok = np.ones(H, dtype=bool)
+            for i, a in snps:
+                ok &= sites.hap[i] == a
+            for j in taken:
+                ok &= dels.hap[j]
+            for j in range(len(dels)):
+                lo, hi = int(dels.anchor[j]) + 1, int(dels.anchor[j]) + int(dels.length[j])
+                if j not in taken and any(lo <= x <= hi for x in used):
+                    ok &= ~dels.hap[j]
+            count = int(ok.sum())
+        path = []
+        if nodes is not None:
+            alt_of = {int(sites.pos[i]): (i, a) for i, a in snps if a}
+            for x in used:
+                nid = nodes.alt_node[alt_of[x]] if x in alt_of else int(nodes.ref_node[x])
+                if not path or path[-1] != nid:
+                    path.append(nid)
+        kmer = bytes(bases)
+        rows.append((label, kmer.decode(), f"{chrom}:{p}+", f"{chrom}:{last + 1}+", count, is_ref,
+                     "".join(f"{n}+," for n in path)))
+        rows.append((label, revcomp(kmer).decode(), f"{chrom}:{last + 1}-", f"{chrom}:{p}-", count, is_ref,
+                     "".join(f"{n}-," for n in reversed(path))))
+
+    def rec(p, x, bases, used, snps, taken):
+        if x >= len(ref):
+            return
+        i = snp_at.get(x)
+        for a in range(1 + (len(sites.alts[i]) if i is not None else 0)):
+            b = ref[x] if a == 0 else ord(sites.alts[i][a - 1])
+            nb, nu = bases + [b], used + [x]
+            ns = snps + [(i, a)] if i is not None else snps
+            if len(nb) == W:
+                emit(p, nb, nu, ns, taken)
+                continue
+            rec(p, x + 1, nb, nu, ns, taken)
+            j = del_at.get(x)
+            if j is not None:
+                rec(p, x + int(dels.length[j]) + 1, nb, nu, ns, taken + [j])
+
+    for p in range(max(S, 0), min(E, len(ref)) - W + 1):
+        rec(p, p, [], [], [], [])
     return rows

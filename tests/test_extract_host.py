@@ -102,3 +102,67 @@ def test_graph_abi_validates_before_touching_a_device():
         n_alts[1] = 1
         rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt), None, 0, ctypes.byref(h))
         assert rc == nv.GFM_ERR_NODEVICE and not h.value
+
+
+def scoring_fixture_graph():
+    """The local graph behind the reference's scoring fixture (22:19723256-19723526), recovered from
+    the fixture itself: reference bases from the `ref` rows, five SNPs (alt base + carrier count from
+    the single-difference `non.ref` rows), one 2-bp deletion after 22:19723467 carried by one of the
+    5096 haplotypes.  Carrier sets are disjoint (the one window that holds two SNPs reports 0
+    haplotypes with both alternates).  Coordinates are shifted so that the region starts at 0."""
+    from oracle import extract_oracle as xo
+    with open(os.path.join(REF_DATA, "width_19", "scoring_test_input.tsv")) as fh:
+        rows = [tuple(line.rstrip("\n").split("\t")) for line in fh]
+    at = lambda s: int(s.split(":")[1][:-1])
+    S, E, H = 19723256, 19723526, 5096
+    refd, snps = {}, {}
+    for r in rows:
+        if r[2].endswith("+") and r[5] == "ref" and at(r[3]) - at(r[2]) == 19:
+            for j, c in enumerate(r[1]):
+                refd[at(r[2]) + j] = c
+    for r in rows:
+        if r[2].endswith("+") and r[5] == "non.ref" and at(r[3]) - at(r[2]) == 19:
+            diffs = [(at(r[2]) + j, c) for j, c in enumerate(r[1]) if refd[at(r[2]) + j] != c]
+            if len(diffs) == 1:
+                snps[diffs[0]] = int(r[4])
+    refseq = "".join(refd[x] for x in range(S, E)).encode()
+    order = sorted(snps)
+    hap = np.zeros((len(order), H), np.int8)
+    nxt = 0
+    for i, key in enumerate(order):
+        hap[i, nxt:nxt + snps[key]] = 1
+        nxt += snps[key]
+    dhap = np.zeros((1, H), bool)
+    dhap[0, nxt] = True
+    sites = xo.Sites([p - S for p, _ in order], [refd[p] for p, _ in order], [[a] for _, a in order], hap)
+    dels = xo.Dels([19723467 - S], [2], dhap)
+    return rows, refseq, sites, dels, S, E
+
+
+def test_oracle_reproduces_vg_rows_of_the_scoring_fixture():
+    """All 704 rows of real `vg find -p 22:19723256-19723526 -K 19 -E -H` output (the input of the
+    reference's test_scoring): k-mer, start, stop, haplotype count, ref flag and node path of every
+    walk, including the 36 rows that cross the deletion (stop - start = 21, flag `ref`, count 1)."""
+    from oracle import extract_oracle as xo
+    rows, refseq, sites, dels, S, E = scoring_fixture_graph()
+    assert len(refseq) == 270 and len(sites.pos) == 5 and len(dels) == 1
+    nodes = xo.GraphNodeTable(len(refseq), sites, dels, first_id=849116, forced_cuts=[1])
+    got = xo.enumerate_region_graph("c", refseq, sites, dels, 0, E - S, 19, with_counts=True, nodes=nodes)
+    back = lambda s: f"22:{int(s.split(':')[1][:-1]) + S}{s[-1]}"
+    got = [("22:19723256-19723526", r[1], back(r[2]), back(r[3]), str(r[4]), r[5], r[6]) for r in got]
+    assert len(got) == 704 and sorted(got) == sorted(rows)
+    assert sum(1 for r in rows if abs(int(r[3].split(":")[1][:-1]) - int(r[2].split(":")[1][:-1])) == 21) == 36
+
+
+def test_graph_oracle_equals_the_snp_oracle_without_deletions(tmp_path):
+    from oracle import extract_oracle as xo
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=800, n_sites=90, seed=8)
+    ref = xo.read_fasta(fasta)["7"]
+    snp_only = xo.read_vcf_snps(vcf, "7")
+    sites, dels, skipped = xo.read_vcf_graph(vcf, "7")
+    assert len(dels) > 0 and skipped < snp_only.skipped            # the deletion records are now used
+    no_dels = xo.Dels([], [], np.zeros((0, sites.n_haplotypes), bool))
+    a = xo.enumerate_region("7", ref, snp_only, 0, 400, 19, True, xo.NodeTable(len(ref), snp_only))
+    b = xo.enumerate_region_graph("7", ref, sites, no_dels, 0, 400, 19, True,
+                                  xo.GraphNodeTable(len(ref), sites, no_dels))
+    assert a == b
