@@ -71,7 +71,7 @@ PROTOTYPES = {
     "gfm_tsv_names_bytes": (c_i64, [c_void_p]),
     "gfm_tsv_names": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gfm_tsv_close": (None, [c_void_p]),
-    "gfm_graph_create": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
+    "gfm_graph_create": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
                                  P(c_void_p)]),
     "gfm_graph_destroy": (None, [c_void_p]),
     "gfm_graph_plan": (c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_i32, P(c_i64), P(c_i64)]),
@@ -133,7 +133,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if L.gfm_abi_version() != 2:
+        if L.gfm_abi_version() != 3:
             raise ImportError("libgrafimo_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -53,12 +53,95 @@ struct GraphDev {
     const uint8_t *ref;         // [ref_len]
     long long ref_len;
     int n_sites;
-    const int *pos;             // [n_sites] ascending, 0-based
-    const uint8_t *n_alts;      // [n_sites] 1..3
+    const int *pos;             // [n_sites] non-decreasing, 0-based: SNP position / anchor of a deletion
+    const uint8_t *n_alts;      // [n_sites] SNP: 1..3 alternate bases; deletion: 1
     const uint8_t *alt_bases;   // [n_sites][3]
-    const unsigned long long *alt_bits;   // [n_sites][3][hw] or nullptr
+    const unsigned long long *alt_bits;   // [n_sites][3][hw] or nullptr (deletion carriers in slot 0)
     int n_hap, hw;
+    const int *del_len;         // [n_sites] 0 for a SNP, else the number of deleted bases after the anchor
+    int n_dels;
+    const int *del_site;        // [n_dels] site indices of the deletions, ascending anchors
 };
+
+// -------------------------------------------------------------------------------------------
+// Walks through windows that touch a deletion.  A walk is a vector of decisions met while W bases
+// are consumed from p: at a SNP the allele (reference first), at the anchor of a deletion -- when
+// more bases are needed -- 0 = go on along the reference, 1 = jump over the deleted bases.  The
+// walks of a window are enumerated in lexicographic order of their decision vectors (an odometer
+// over simulate()); oracle/extract_oracle.py enumerate_region_graph recurses in the same order.
+constexpr int kMaxDecisions = 24;
+struct WalkState {
+    int nd = 0;
+    long long last = 0;                       // reference position of the last base
+    unsigned char choice[kMaxDecisions];
+    unsigned char nchoice[kMaxDecisions];
+};
+enum { WALK_OK = 0, WALK_DEAD = 1, WALK_OVERFLOW = 2 };
+
+struct NoVisitor {
+    __device__ void base(int, long long, int, int) {}
+    __device__ void took(int) {}
+    __device__ void passed(int) {}
+};
+
+// follows st.choice[0 .. prefix) and takes choice 0 at every later decision
+template <class V>
+__device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, int prefix, WalkState &st, V &vis)
+{
+    long long x = p;
+    int n = 0, d = 0, i = i0;
+    for (;;) {
+        if (x >= g.ref_len) { st.nd = d; return WALK_DEAD; }
+        while (i < g.n_sites && g.pos[i] < x) ++i;
+        int snp = -1, del = -1;
+        for (int k = i; k < g.n_sites && g.pos[k] == x; ++k) {
+            if (g.del_len[k] == 0) snp = k; else del = k;
+        }
+        int a = 0;
+        if (snp >= 0) {
+            if (d >= kMaxDecisions) { st.nd = d; return WALK_OVERFLOW; }
+            a = d < prefix ? st.choice[d] : 0;
+            st.choice[d] = (unsigned char)a;
+            st.nchoice[d] = (unsigned char)(1 + g.n_alts[snp]);
+            ++d;
+        }
+        vis.base(n, x, snp, a);
+        if (++n == W) { st.nd = d; st.last = x; return WALK_OK; }
+        if (del >= 0) {
+            if (d >= kMaxDecisions) { st.nd = d; return WALK_OVERFLOW; }
+            const int c = d < prefix ? st.choice[d] : 0;
+            st.choice[d] = (unsigned char)c;
+            st.nchoice[d] = 2;
+            ++d;
+            if (c) { vis.took(del); x += g.del_len[del] + 1; continue; }
+            vis.passed(del);
+        }
+        ++x;
+    }
+}
+
+// advances the odometer; returns the new prefix length or -1 when the window is exhausted
+__device__ inline int next_walk(WalkState &st)
+{
+    int t = st.nd - 1;
+    while (t >= 0 && st.choice[t] + 1 >= st.nchoice[t]) --t;
+    if (t < 0) return -1;
+    ++st.choice[t];
+    return t + 1;
+}
+
+// deletion whose deleted bases contain p (the window starts inside it), or -1
+__device__ inline int cover_deletion(const GraphDev &g, long long p)
+{
+    int lo = 0, hi = g.n_dels;           // last deletion with anchor < p
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (g.pos[g.del_site[mid]] < p) lo = mid + 1; else hi = mid;
+    }
+    if (lo == 0) return -1;
+    const int sidx = g.del_site[lo - 1];
+    return p <= (long long)g.pos[sidx] + g.del_len[sidx] ? sidx : -1;
+}
 
 __device__ inline int lower_bound_pos(const int *pos, int n, long long v)
 {
@@ -86,7 +169,8 @@ __global__ void __launch_bounds__(kCountThreads)
 graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ region_off,
                    const long long *__restrict__ first_start, int W, long long n_windows,
                    int *__restrict__ first_site, long long *__restrict__ n_walks, int *__restrict__ win_region,
-                   long long *__restrict__ win_start, int *__restrict__ overflow)
+                   long long *__restrict__ win_start, int *__restrict__ overflow, int *__restrict__ del_list,
+                   int *__restrict__ del_count)
 {
     const long long w = (long long)blockIdx.x * kCountThreads + threadIdx.x;
     if (w >= n_windows) return;
@@ -94,10 +178,25 @@ graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ regi
     const long long p = first_start[r] + (w - region_off[r]);
     const int i0 = lower_bound_pos(g.pos, g.n_sites, p);
     long long walks = 1;
+    bool touches_del = g.n_dels > 0 && cover_deletion(g, p) >= 0;
     for (int i = i0; i < g.n_sites && g.pos[i] < p + W; ++i) {
+        if (g.del_len[i]) touches_del = true;
         walks *= 1 + g.n_alts[i];
         if (walks > kMaxWalksPerWindow) { walks = 0; atomicMax(overflow, 1); break; }
     }
+    if (touches_del) {           // the sites a walk meets depend on the deletions it takes: enumerate
+        WalkState st;
+        NoVisitor nv;
+        walks = 0;
+        int prefix = 0;
+        do {
+            const int rc = simulate(g, p, W, i0, prefix, st, nv);
+            if (rc == WALK_OK) ++walks;
+            if (rc == WALK_OVERFLOW || walks > kMaxWalksPerWindow) { walks = 0; atomicMax(overflow, 1); break; }
+            prefix = next_walk(st);
+        } while (prefix >= 0);
+    }
+    if (touches_del && walks > 0) del_list[atomicAdd(del_count, 1)] = (int)w;
     first_site[w] = i0;
     n_walks[w] = walks;
     win_region[w] = r;      // the emit kernel reads these instead of repeating the search: its waves
@@ -171,6 +270,13 @@ graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *_
     const int i0 = first_site[w];
     int q = (int)(tt - walk_base[w]);
     const int q0 = q;
+    uint8_t *fwd = stage + (size_t)(2 * threadIdx.x) * W, *rev = fwd + W;
+    // (windows that touch a deletion are written here as if they did not -- harmless bytes -- and
+    // rewritten by graph_emit_del_kernel, which runs next on the same stream)
+    long long count = 0;
+    const long long end_pos = p + W;
+    bool any_alt = false;
+    {
     int ns = 0;
     while (i0 + ns < g.n_sites && g.pos[i0 + ns] < p + W) ++ns;
     // allele digits, last site first
@@ -182,10 +288,9 @@ graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *_
         dig[k >> 5] |= a << (2 * (k & 31));
     }
     auto allele = [&](int k) { return (int)((dig[k >> 5] >> (2 * (k & 31))) & 3ull); };
-    const bool any_alt = (dig[0] | dig[1]) != 0ull;
+    any_alt = (dig[0] | dig[1]) != 0ull;
 
     // rows 2t (forward) and 2t+1 (reverse complement): reference window first, then the alternates
-    uint8_t *fwd = stage + (size_t)(2 * threadIdx.x) * W, *rev = fwd + W;
     for (int j = 0; j < W; ++j) {
         const uint8_t c = g.ref[p + j];
         fwd[j] = c;
@@ -202,7 +307,6 @@ graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *_
     }
 
     // haplotypes that carry every allele of the walk
-    long long count = 0;
     if (g.alt_bits) {
         if (ns == 0) {
             count = g.n_hap;
@@ -244,6 +348,7 @@ graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *_
             }
         }
     }
+    }   // plain window
     __syncthreads();
     {
         const long long rows_here = 2 * ((n_walks - t0) < (long long)kEmitThreads ? (n_walks - t0) : (long long)kEmitThreads);
@@ -260,13 +365,107 @@ graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *_
     if (!valid) return;
     const int r = win_region[w];
     const long long row = 2 * t;
-    start[row] = p;          start[row + 1] = p + W;
-    stop[row] = p + W;       stop[row + 1] = p;
+    start[row] = p;          start[row + 1] = end_pos;
+    stop[row] = end_pos;     stop[row + 1] = p;
     strand[row] = '+';       strand[row + 1] = '-';
     freq[row] = count;       freq[row + 1] = count;
     is_ref[row] = is_ref[row + 1] = any_alt ? 0 : 1;
     region[row] = region[row + 1] = r;
     walk[row] = walk[row + 1] = q0;
+}
+
+// Windows that touch a deletion: one thread per window walks its odometer once and writes the rows of
+// its walks directly (they are few: plain byte stores).  Runs after graph_emit_kernel on the same stream.
+__global__ void __launch_bounds__(kCountThreads)
+graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ del_list,
+                      const int *__restrict__ del_count, const long long *__restrict__ win_start, int W,
+                      const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+                      uint8_t *__restrict__ kmers, long long *__restrict__ start, long long *__restrict__ stop,
+                      long long *__restrict__ freq, uint8_t *__restrict__ is_ref, int *__restrict__ walk)
+{
+    const int m = blockIdx.x * kCountThreads + threadIdx.x;
+    if (m >= *del_count) return;
+    const int w = del_list[m];
+    const long long p = win_start[w];
+    const int i0 = first_site[w];
+    const long long base = walk_base[w];
+    const int cover = cover_deletion(g, p);      // the window starts on deleted bases: carriers lack them
+    struct Emit {
+        const GraphDev &g;
+        uint8_t *fwd, *rev;
+        int W;
+        int n_cons;
+        int csite[kMaxDecisions + 1];
+        unsigned char ccode[kMaxDecisions + 1];     // 0..3 SNP allele, 4 deletion taken, 5 deletion not carried
+        bool alt;
+        __device__ void add(int site, int code)
+        {
+            if (n_cons <= kMaxDecisions) { csite[n_cons] = site; ccode[n_cons] = (unsigned char)code; ++n_cons; }
+        }
+        __device__ void base(int j, long long x, int snp, int a)
+        {
+            uint8_t c = g.ref[x];
+            if (snp >= 0) {
+                if (a) { c = g.alt_bases[(size_t)snp * kMaxAlts + (a - 1)]; alt = true; }
+                add(snp, a);
+            }
+            fwd[j] = c;
+            rev[W - 1 - j] = complement(c);
+        }
+        __device__ void took(int site) { add(site, 4); }
+        __device__ void passed(int site) { add(site, 5); }
+    };
+    WalkState st;
+    int prefix = 0, q = 0;
+    do {
+        uint8_t *fwd = kmers + (size_t)(2 * (base + q)) * W;
+        Emit em{g, fwd, fwd + W, W, 0, {}, {}, false};
+        // the rows of walk q are overwritten by later attempts until one succeeds (dead ends write too)
+        const int rc = simulate(g, p, W, i0, prefix, st, em);
+        if (rc == WALK_OK) {
+            if (cover >= 0) em.add(cover, 5);
+            long long count = 0;
+            if (g.alt_bits) {
+                if (em.n_cons == 0) {
+                    count = g.n_hap;
+                } else if (em.n_cons == 1) {
+                    const int code = em.ccode[0];
+                    count = allele_count[(size_t)em.csite[0] * 4 + (code == 4 ? 1 : code == 5 ? 0 : code)];
+                } else {
+                    for (int word = 0; word < g.hw; ++word) {
+                        unsigned long long acc = ~0ull;
+                        if (word == g.hw - 1 && (g.n_hap & 63)) acc = (1ull << (g.n_hap & 63)) - 1ull;
+                        for (int k = 0; k < em.n_cons; ++k) {
+                            const unsigned long long *b = g.alt_bits + ((size_t)em.csite[k] * kMaxAlts) * g.hw + word;
+                            const int code = em.ccode[k];
+                            unsigned long long bits;
+                            if (code >= 1 && code <= 3) {
+                                bits = b[(size_t)(code - 1) * g.hw];
+                            } else if (code == 4) {
+                                bits = b[0];
+                            } else {                       // reference allele / deletion not carried
+                                const int na = g.n_alts[em.csite[k]];
+                                bits = b[0];
+                                if (na > 1) bits |= b[(size_t)g.hw];
+                                if (na > 2) bits |= b[(size_t)2 * g.hw];
+                                bits = ~bits;
+                            }
+                            acc &= bits;
+                        }
+                        count += __popcll(acc);
+                    }
+                }
+            }
+            const long long row = 2 * (base + q), end_pos = st.last + 1;
+            start[row] = p;          start[row + 1] = end_pos;
+            stop[row] = end_pos;     stop[row + 1] = p;
+            freq[row] = count;       freq[row + 1] = count;
+            is_ref[row] = is_ref[row + 1] = em.alt ? 0 : 1;
+            walk[row] = walk[row + 1] = q;
+            ++q;
+        }
+        prefix = next_walk(st);
+    } while (prefix >= 0 && base + q < walk_base[w + 1]);
 }
 
 template <typename T> hipError_t upload(T **dst, const T *src, size_t count)
@@ -305,23 +504,26 @@ struct gfm_graph {
     uint8_t *d_n_alts = nullptr, *d_alt_bases = nullptr;
     unsigned long long *d_alt_bits = nullptr;
     int *d_allele_count = nullptr;   // [n_sites][4] haplotypes per allele (0 = reference)
+    int *d_del_len = nullptr, *d_del_site = nullptr;
     // last plan (buffers are kept between plans)
     int n_regions = 0, width = 0;
     long long n_windows = 0, n_walks = 0;
     Buf<long long> region_off, first_start, walk_base, win_start, walks;
     Buf<int> first_site, win_region, walk_window, flag;
     Buf<unsigned char> scan_tmp;
+    Buf<int> del_list;
     void drop_plan()
     {
         region_off.release(); first_start.release(); walk_base.release(); win_start.release(); walks.release();
         first_site.release(); win_region.release(); walk_window.release(); flag.release(); scan_tmp.release();
+        del_list.release();
         n_regions = 0;
         n_windows = n_walks = 0;
     }
 };
 
 GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_sites, const int32_t *h_pos,
-                             const uint8_t *h_n_alts, const uint8_t *h_alt_bases,
+                             const uint8_t *h_n_alts, const uint8_t *h_alt_bases, const int32_t *h_del_len,
                              const uint64_t *h_alt_bits, int32_t n_haplotypes, gfm_graph_t *out)
 {
     if (!out) return gfail(GFM_ERR_INVALID, "NULL output handle");
@@ -329,12 +531,27 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (!h_ref || ref_len <= 0 || n_sites < 0 || n_haplotypes < 0)
         return gfail(GFM_ERR_INVALID, "bad reference / site count");
     if (n_sites && (!h_pos || !h_n_alts || !h_alt_bases)) return gfail(GFM_ERR_INVALID, "NULL site arrays");
+    std::vector<int> del_len((size_t)n_sites, 0), del_site;
+    long long deleted_until = -1;        // last reference position removed by an earlier deletion
     for (int i = 0; i < n_sites; ++i) {
-        if (h_pos[i] < 0 || h_pos[i] >= ref_len || (i && h_pos[i] <= h_pos[i - 1]))
-            return gfail(GFM_ERR_INVALID, "site positions must be strictly ascending inside the reference (site " +
+        const int dl = h_del_len ? h_del_len[i] : 0;
+        const bool tie_ok = i && h_pos[i] == h_pos[i - 1] && dl > 0 && del_len[(size_t)i - 1] == 0;
+        if (h_pos[i] < 0 || h_pos[i] >= ref_len || (i && h_pos[i] <= h_pos[i - 1] && !tie_ok))
+            return gfail(GFM_ERR_INVALID, "site positions must be ascending inside the reference; only a deletion "
+                                          "may share its anchor with the SNP listed before it (site " +
                                               std::to_string(i) + ")");
         if (h_n_alts[i] < 1 || h_n_alts[i] > kMaxAlts)
             return gfail(GFM_ERR_INVALID, "a site needs 1..3 alternate alleles (site " + std::to_string(i) + ")");
+        if (dl < 0 || (dl > 0 && h_n_alts[i] != 1))
+            return gfail(GFM_ERR_INVALID, "a deletion has one alternate allele and a positive length (site " +
+                                              std::to_string(i) + ")");
+        if (dl > 0) {
+            if (h_pos[i] <= deleted_until)
+                return gfail(GFM_ERR_INVALID, "deletions must not overlap (site " + std::to_string(i) + ")");
+            deleted_until = (long long)h_pos[i] + dl;
+            del_site.push_back(i);
+        }
+        del_len[(size_t)i] = dl;
     }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
@@ -349,6 +566,8 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = upload(&g->d_pos, h_pos, (size_t)n_sites);
     if (e == hipSuccess) e = upload(&g->d_n_alts, h_n_alts, (size_t)n_sites);
     if (e == hipSuccess) e = upload(&g->d_alt_bases, h_alt_bases, (size_t)n_sites * kMaxAlts);
+    if (e == hipSuccess) e = upload(&g->d_del_len, del_len.data(), del_len.size());
+    if (e == hipSuccess) e = upload(&g->d_del_site, del_site.data(), del_site.size());
     if (e == hipSuccess && bits)
         e = upload(&g->d_alt_bits, reinterpret_cast<const unsigned long long *>(h_alt_bits),
                    (size_t)n_sites * kMaxAlts * hw);
@@ -357,7 +576,8 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
         return gfail(GFM_ERR_HIP, std::string("graph upload failed: ") + hipGetErrorString(e));
     }
     g->dev = GraphDev{g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
-                      bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0};
+                      bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0,
+                      g->d_del_len, (int)del_site.size(), g->d_del_site};
     if (bits) {
         e = hipMalloc(&g->d_allele_count, sizeof(int) * 4 * (size_t)n_sites);
         if (e == hipSuccess) {
@@ -381,6 +601,7 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     g->drop_plan();
     (void)hipFree(g->d_ref); (void)hipFree(g->d_pos); (void)hipFree(g->d_n_alts);
     (void)hipFree(g->d_alt_bases); (void)hipFree(g->d_alt_bits); (void)hipFree(g->d_allele_count);
+    (void)hipFree(g->d_del_len); (void)hipFree(g->d_del_site);
     delete g;
 }
 
@@ -411,20 +632,21 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     GX_TRY(g->first_start.reserve(first.size()));
     GX_TRY(g->first_site.reserve(nw));
     GX_TRY(g->walks.reserve(nw));
-    GX_TRY(g->flag.reserve(1));
+    GX_TRY(g->flag.reserve(2));          // [0] overflow flag, [1] number of windows that touch a deletion
     GX_TRY(g->win_region.reserve(nw));
     GX_TRY(g->win_start.reserve(nw));
     GX_TRY(g->walk_base.reserve(nw + 1));
+    GX_TRY(g->del_list.reserve(g->dev.n_dels ? nw : 1));
     GX_TRY(hipMemcpyAsync(g->region_off.p, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, nullptr));
     GX_TRY(hipMemcpyAsync(g->first_start.p, first.data(), sizeof(long long) * first.size(), hipMemcpyHostToDevice, nullptr));
-    GX_TRY(hipMemsetAsync(g->flag.p, 0, sizeof(int), nullptr));
+    GX_TRY(hipMemsetAsync(g->flag.p, 0, 2 * sizeof(int), nullptr));
     GX_TRY(hipMemsetAsync(g->walk_base.p, 0, sizeof(long long), nullptr));
     // walks per window -> inclusive prefix (row base of every window) on the device: only the total and the
     // overflow flag come back
     const unsigned blocks = (unsigned)((nw + kCountThreads - 1) / kCountThreads);
     hipLaunchKernelGGL(graph_count_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->dev, n_regions,
                        g->region_off.p, g->first_start.p, width, (long long)nw, g->first_site.p, g->walks.p,
-                       g->win_region.p, g->win_start.p, g->flag.p);
+                       g->win_region.p, g->win_start.p, g->flag.p, g->del_list.p, g->flag.p + 1);
     GX_TRY(hipGetLastError());
     size_t tmp_bytes = 0;
     GX_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, g->walks.p, g->walk_base.p + 1, (int)nw, nullptr));
@@ -462,6 +684,14 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
                        g->win_region.p, g->win_start.p, g->width, g->n_walks, g->first_site.p, g->walk_base.p, d_kmers, reinterpret_cast<long long *>(d_start),
                        reinterpret_cast<long long *>(d_stop), d_strand, reinterpret_cast<long long *>(d_freq),
                        d_is_ref, d_region, d_walk);
+    if (g->dev.n_dels) {
+        // at most every window; the kernel reads the real count from the device
+        const unsigned dblocks = (unsigned)((g->n_windows + kCountThreads - 1) / kCountThreads);
+        hipLaunchKernelGGL(graph_emit_del_kernel, dim3(dblocks), dim3(kCountThreads), 0, static_cast<hipStream_t>(stream),
+                           g->dev, g->d_allele_count, g->del_list.p, g->flag.p + 1, g->win_start.p, g->width,
+                           g->first_site.p, g->walk_base.p, d_kmers, reinterpret_cast<long long *>(d_start),
+                           reinterpret_cast<long long *>(d_stop), reinterpret_cast<long long *>(d_freq), d_is_ref, d_walk);
+    }
     GX_TRY(hipGetLastError());
     return GFM_OK;
 }

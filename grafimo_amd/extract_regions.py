@@ -8,11 +8,12 @@ of a phased VCF (what `grafimo buildvg` feeds `vg construct`, constructVG.py:332
     df    = compute_results_from_graph(motif, graph, regions, args)  # extraction -> scoring, no TSV
     write_region_tsvs(index, rows, "out")                            # or the files GRAFIMO expects
 
-Row semantics are those of vg's output as far as the reference's golden file pins them (32 rows of
-tests/test_data/expected_results/expected_seqs.tsv, reproduced exactly incl. node paths); haplotype
-counts follow "phased haplotypes of the VCF that carry every allele of the walk".  VCF records that
-are not single-base substitutions (indels, MNPs) are not part of the graph: `GraphIndex.skipped`
-counts them.  There is no CPU fallback: extraction needs libgrafimo_hip.so and a GPU.
+Row semantics are those of vg's output as the reference's files pin them: the 32 rows of
+tests/test_data/expected_results/expected_seqs.tsv and the 704 rows of real `vg find -K 19 -E -H` output
+in its scoring fixture (SNPs, a deletion, haplotype counts, node paths) are reproduced exactly.  The
+graph holds the single-base substitutions and the plain deletions of the VCF; other records
+(insertions, MNPs, a deletion overlapping an earlier one) are left out and counted in
+`GraphIndex.skipped`.  There is no CPU fallback: extraction needs libgrafimo_hip.so and a GPU.
 """
 import ctypes
 import gzip
@@ -52,10 +53,13 @@ class GraphIndex:
     alternate allele, the bitset of haplotypes that carry it."""
 
     def __init__(self, chrom: str, ref: np.ndarray, pos, n_alts, alt_bases, alt_bits, n_haplotypes: int,
-                 skipped: int = 0):
+                 skipped: int = 0, del_len=None):
         self.chrom = chrom
         self.ref = np.ascontiguousarray(ref, dtype=np.uint8)
         self.pos = np.ascontiguousarray(pos, dtype=np.int32)
+        # 0 for a SNP site; for a deletion the number of bases removed after the anchor `pos`
+        self.del_len = (np.zeros(len(self.pos), dtype=np.int32) if del_len is None
+                        else np.ascontiguousarray(del_len, dtype=np.int32))
         self.n_alts = np.ascontiguousarray(n_alts, dtype=np.uint8)
         self.alt_bases = np.ascontiguousarray(alt_bases, dtype=np.uint8).reshape(len(self.pos), MAX_ALTS)
         self.n_haplotypes = int(n_haplotypes)
@@ -65,11 +69,13 @@ class GraphIndex:
             self.alt_bits = np.ascontiguousarray(alt_bits, dtype=np.uint64).reshape(len(self.pos), MAX_ALTS, self.hw)
         self.skipped = int(skipped)
         self._nodes = None
+        self._dels = None
+        self._site_at = None
 
     @classmethod
     def from_fasta_vcf(cls, fasta: str, vcf: str, chrom: str, with_haplotypes: bool = True) -> "GraphIndex":
         ref = _read_fasta_record(fasta, chrom)
-        pos, alts, gts, skipped = [], [], [], 0
+        recs, skipped, last_snp, deleted_until = [], 0, -1, -1     # (pos, kind, alts, del_len, genotypes)
         op = gzip.open if vcf.endswith(".gz") else open
         with op(vcf, "rt") as fh:
             for line in fh:
@@ -79,34 +85,35 @@ class GraphIndex:
                 if f[0] != chrom:
                     continue
                 r, a = f[3].upper(), f[4].upper().split(",")
-                if len(r) != 1 or len(a) > MAX_ALTS or any(len(x) != 1 or x not in "ACGT" for x in a):
-                    skipped += 1            # indel / MNP / symbolic allele: not part of this graph
-                    continue
                 p = int(f[1]) - 1
-                if pos and p <= pos[-1]:
-                    if p == pos[-1]:
-                        skipped += 1        # second record at one position
-                        continue
-                    raise ValueError(f"{vcf}: records of {chrom} are not sorted by position")
-                pos.append(p)
-                alts.append(a)
+                is_snp = len(r) == 1 and len(a) <= MAX_ALTS and all(len(x) == 1 and x in "ACGT" for x in a)
+                is_del = len(r) > 1 and len(a) == 1 and a[0] == r[0]
+                if is_snp and p != last_snp:
+                    last_snp = p
+                elif is_del and p > deleted_until:       # no overlap with a deletion accepted before
+                    deleted_until = p + len(r) - 1
+                else:
+                    skipped += 1                           # insertion / MNP / symbolic / overlapping record
+                    continue
+                row = []
                 if with_haplotypes:
-                    row = []
-                    for s in f[9:]:
-                        gt = s.split(":", 1)[0].replace("/", "|").split("|")
+                    for s_ in f[9:]:
+                        gt = s_.split(":", 1)[0].replace("/", "|").split("|")
                         if len(gt) == 1:
                             gt = gt * 2
                         row += [int(x) if x.isdigit() else 0 for x in gt[:2]]
-                    gts.append(row)
-        V = len(pos)
-        n_alts = np.array([len(a) for a in alts], dtype=np.uint8)
+                recs.append((p, 0 if is_snp else 1, a if is_snp else [], 0 if is_snp else len(r) - 1, row))
+        recs.sort(key=lambda t: (t[0], t[1]))             # a deletion follows the SNP at its anchor
+        V = len(recs)
+        pos = [t[0] for t in recs]
+        n_alts = np.array([len(t[2]) if t[1] == 0 else 1 for t in recs], dtype=np.uint8)
         alt_bases = np.zeros((V, MAX_ALTS), dtype=np.uint8)
-        for i, a in enumerate(alts):
-            alt_bases[i, :len(a)] = [ord(x) for x in a]
-        H = len(gts[0]) if gts else 0
+        for i, t in enumerate(recs):
+            alt_bases[i, :len(t[2])] = [ord(x) for x in t[2]]
+        H = len(recs[0][4]) if recs and with_haplotypes else 0
         bits = None
         if H:
-            g = np.asarray(gts, dtype=np.int8)                       # [V, H]
+            g = np.asarray([t[4] for t in recs], dtype=np.int8)      # [V, H]
             hw = (H + 63) // 64
             bits = np.zeros((V, MAX_ALTS, hw), dtype=np.uint64)
             padded = np.zeros((V, hw * 64), dtype=bool)
@@ -114,34 +121,62 @@ class GraphIndex:
                 padded[:, :H] = g == a + 1
                 # bit h of word h // 64: little-endian bit order inside little-endian 64-bit words
                 bits[:, a, :] = np.packbits(padded, axis=1, bitorder="little").view(np.uint64)
-        return cls(chrom, ref, pos, n_alts, alt_bases, bits, H, skipped)
+        return cls(chrom, ref, pos, n_alts, alt_bases, bits, H, skipped, del_len=[t[3] for t in recs])
 
     # ---- node ids of `vg construct` on this graph (column 7 of the TSV; not used by GRAFIMO's scoring)
     def _node_table(self):
+        """The reference is cut at every SNP (the site is a node of its own: alternates numbered first,
+        then the reference allele) and at both ends of every deleted stretch; what lies between two
+        cuts is chopped into nodes of at most NODE_MAX bases (all of it pinned by the node paths of the
+        reference's two fixtures)."""
         if self._nodes is None:
-            seg_start, seg_end, seg_id, site_ids = [], [], [], []
-            nid, cur = 1, 0
-            for p, na in zip(self.pos.tolist(), self.n_alts.tolist()):
-                while cur < p:
-                    e = min(cur + NODE_MAX, p)
-                    seg_start.append(cur); seg_end.append(e); seg_id.append(nid)
-                    nid += 1
-                    cur = e
-                alt_ids = list(range(nid, nid + na))     # alternate alleles first, then the reference allele
-                nid += na
-                site_ids.append([nid] + alt_ids)
-                nid += 1
-                cur = p + 1
-            while cur < len(self.ref):
-                e = min(cur + NODE_MAX, len(self.ref))
-                seg_start.append(cur); seg_end.append(e); seg_id.append(nid)
-                nid += 1
-                cur = e
-            self._nodes = (np.asarray(seg_start, dtype=np.int64), seg_end, seg_id, site_ids)
+            snp = self.del_len == 0
+            cuts = {0, len(self.ref)}
+            for p in self.pos[snp].tolist():
+                cuts.update((p, p + 1))
+            for p, ln in zip(self.pos[~snp].tolist(), self.del_len[~snp].tolist()):
+                cuts.update((p + 1, p + ln + 1))
+            cuts = np.array(sorted(c for c in cuts if 0 <= c <= len(self.ref)), dtype=np.int64)
+            snp_site = {int(p): i for i, p in enumerate(self.pos.tolist()) if self.del_len[i] == 0}
+            first = np.zeros(len(cuts) - 1, dtype=np.int64)      # id of the first node of the interval
+            site_of = np.full(len(cuts) - 1, -1, dtype=np.int64)  # SNP intervals: their site
+            nid = 1
+            for j in range(len(cuts) - 1):
+                b, e = int(cuts[j]), int(cuts[j + 1])
+                if e - b == 1 and b in snp_site:
+                    i = snp_site[b]
+                    site_of[j] = i
+                    first[j] = nid                               # alternates nid .. nid+n_alts-1, reference after
+                    nid += int(self.n_alts[i]) + 1
+                else:
+                    first[j] = nid
+                    nid += -(-(e - b) // NODE_MAX)
+            self._nodes = (cuts, first, site_of)
         return self._nodes
 
+    def _node_at(self, x: int, allele: int = 0) -> int:
+        cuts, first, site_of = self._node_table()
+        j = int(np.searchsorted(cuts, x, side="right")) - 1
+        i = int(site_of[j])
+        if i >= 0:
+            return int(first[j]) + (allele - 1 if allele else int(self.n_alts[i]))
+        return int(first[j]) + (x - int(cuts[j])) // NODE_MAX
+
+    def touches_deletion(self, p: int, width: int) -> bool:
+        i0 = int(np.searchsorted(self.pos, p, side="left"))
+        i1 = int(np.searchsorted(self.pos, p + width, side="left"))
+        if self.del_len[i0:i1].any():
+            return True
+        if self._dels is None:
+            d = np.nonzero(self.del_len)[0]
+            self._dels = (self.pos[d].astype(np.int64), self.pos[d].astype(np.int64) + self.del_len[d])
+        anchors, ends = self._dels
+        k = int(np.searchsorted(anchors, p, side="left")) - 1          # last deletion anchored before p
+        return k >= 0 and p <= int(ends[k])
+
     def walk_alleles(self, p: int, width: int, walk: int) -> Tuple[int, List[int]]:
-        """(first site, allele per site) of walk number `walk` of window p (last site fastest)."""
+        """(first site, allele per site) of walk number `walk` of a window without deletions
+        (mixed radix, last site fastest)."""
         i0 = int(np.searchsorted(self.pos, p, side="left"))
         i1 = int(np.searchsorted(self.pos, p + width, side="left"))
         alleles = [0] * (i1 - i0)
@@ -151,20 +186,84 @@ class GraphIndex:
             walk //= n
         return i0, alleles
 
-    def node_path(self, p: int, width: int, walk: int) -> List[int]:
-        seg_start, seg_end, seg_id, site_ids = self._node_table()
-        i0, alleles = self.walk_alleles(p, width, walk)
-        out, cur, k = [], p, 0
-        while cur < p + width:
-            if k < len(alleles) and int(self.pos[i0 + k]) == cur:
-                out.append(site_ids[i0 + k][alleles[k]])
-                cur += 1
-                k += 1
-            else:
-                j = int(np.searchsorted(seg_start, cur, side="right")) - 1
-                out.append(seg_id[j])
-                cur = seg_end[j]
+    def window_walks(self, p: int, width: int):
+        """Yields, in the enumeration order of the extraction kernel, the walks of window p as
+        [(reference position, SNP allele)] per base: mixed radix (last site fastest) for plain windows;
+        for windows that touch a deletion the lexicographic order of the decisions met on the way (SNP
+        allele, reference first; at a deletion's anchor 0 = stay on the reference, 1 = jump), a jump
+        needing a landing position inside the chromosome."""
+        if not self.touches_deletion(p, width):
+            i0 = int(np.searchsorted(self.pos, p, side="left"))
+            i1 = int(np.searchsorted(self.pos, p + width, side="left"))
+            site_pos = [int(x) for x in self.pos[i0:i1]]
+            radix = [1 + int(n) for n in self.n_alts[i0:i1]]
+            total = int(np.prod(radix)) if radix else 1
+            for q in range(total):
+                at, qq = {}, q
+                for k in range(len(radix) - 1, -1, -1):
+                    at[site_pos[k]] = qq % radix[k]
+                    qq //= radix[k]
+                yield [(x, at.get(x, 0)) for x in range(p, p + width)]
+            return
+        if self._site_at is None:
+            self._site_at = {}
+            for i, x in enumerate(self.pos.tolist()):
+                self._site_at.setdefault(x, []).append(i)
+        site_at = self._site_at
+
+        def simulate(choices):
+            out, x, d, made = [], p, 0, []
+            while True:
+                if x >= len(self.ref):
+                    return None, made
+                here = site_at.get(x, ())
+                snp = next((i for i in here if self.del_len[i] == 0), None)
+                dele = next((i for i in here if self.del_len[i] > 0), None)
+                a = 0
+                if snp is not None:
+                    a = choices[d] if d < len(choices) else 0
+                    made.append((a, 1 + int(self.n_alts[snp])))
+                    d += 1
+                out.append((x, a))
+                if len(out) == width:
+                    return out, made
+                if dele is not None:
+                    c = choices[d] if d < len(choices) else 0
+                    made.append((c, 2))
+                    d += 1
+                    if c:
+                        x += int(self.del_len[dele]) + 1
+                        continue
+                x += 1
+
+        choices = []
+        while True:
+            out, made = simulate(choices)
+            if out is not None:
+                yield out
+            t = len(made) - 1
+            while t >= 0 and made[t][0] + 1 >= made[t][1]:
+                t -= 1
+            if t < 0:
+                return
+            choices = [m[0] for m in made[:t]] + [made[t][0] + 1]
+
+    def walk_bases(self, p: int, width: int, walk: int) -> List[Tuple[int, int]]:
+        for q, bases in enumerate(self.window_walks(p, width)):
+            if q == walk:
+                return bases
+        raise IndexError(f"window {p} has no walk {walk}")
+
+    def nodes_of(self, bases: List[Tuple[int, int]]) -> List[int]:
+        out: List[int] = []
+        for x, a in bases:
+            nid = self._node_at(x, a)
+            if not out or out[-1] != nid:
+                out.append(nid)
         return out
+
+    def node_path(self, p: int, width: int, walk: int) -> List[int]:
+        return self.nodes_of(self.walk_bases(p, width, walk))
 
 
 class ExtractedKmers:
@@ -194,7 +293,8 @@ class DeviceGraph:
         with torch.cuda.device(self.device):
             nv.check(nv.lib().gfm_graph_create(
                 nv.ptr(index.ref), len(index.ref), len(index.pos), nv.ptr(index.pos), nv.ptr(index.n_alts),
-                nv.ptr(index.alt_bases), nv.ptr(index.alt_bits) if index.alt_bits is not None else None,
+                nv.ptr(index.alt_bases), nv.ptr(index.del_len),
+                nv.ptr(index.alt_bits) if index.alt_bits is not None else None,
                 index.n_haplotypes if index.alt_bits is not None else 0, ctypes.byref(h)))
         self._h = h
 
@@ -252,10 +352,13 @@ def write_region_tsvs(index: GraphIndex, rows: ExtractedKmers, out_dir: str) -> 
         label = rows.region_label(r)
         path = os.path.join(d, label.replace(":", "_") + ".tsv")
         with open(path, "w") as fh:
+            cur_p, node_paths = None, []
             for i in range(bounds[r], bounds[r + 1]):
                 sg = chr(strand[i])
                 p = int(start[i]) if sg == "+" else int(stop[i])
-                nodes = index.node_path(p, W, int(walk[i]))
+                if p != cur_p:                    # rows are window-major: enumerate a window's walks once
+                    cur_p, node_paths = p, [index.nodes_of(b) for b in index.window_walks(p, W)]
+                nodes = node_paths[int(walk[i])]
                 if sg == "-":
                     nodes = nodes[::-1]
                 fh.write("\t".join([
@@ -359,7 +462,9 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
         qvalues=None if no_qvalue else res["qtable"][res["scaled"]],
         seqs=[bytes(k).decode() for k in take(all_kmers)],
         frequencies=take(cat("freq")),
-        references=["ref" if r else "non.ref" for r in take(cat("is_ref"))],
+        # vg flags a walk over a deletion `ref`; GRAFIMO repairs that on ingest (score_sequences.py:305-307)
+        references=["ref" if r and abs(int(e) - int(b_)) == W else "non.ref"
+                    for r, b_, e in zip(take(cat("is_ref")), take(cat("start")), take(cat("stop")))],
         threshold=None, recomb=recomb,
     )
     if world > 1:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFM_ABI_VERSION 2
+#define GFM_ABI_VERSION 3
 
 #define GFM_OK 0
 #define GFM_ERR_INVALID (-1)  /* bad argument (NULL, width out of range, ...)            */
@@ -196,25 +196,31 @@ void gfm_tsv_close(gfm_tsv_t t);
 /* ------------------------------------------------------------------ k-mer extraction
  * Replaces the rows of `vg find -p CHR:S-E -x XG -H GBWT -K W -E` (extract_regions.py:180,225,326;
  * consumed by score_sequences.py:273-307) for graphs made of a linear reference plus SNP sites
- * (the inputs of `vg construct -r REF -v VCF`, constructVG.py:332).  Rows are written on the device
+ * and deletions (the inputs of `vg construct -r REF -v VCF`, constructVG.py:332).  Rows are written on the device
  * in the layout gfm_score_kmers reads, so extraction -> scoring needs no TSV.  Pinned by the
- * reference's expected_seqs.tsv as far as that file goes (oracle/extract_oracle.py lists what is
- * not pinned: haplotype counts, indels -- such VCF records are not part of the graph).
+ * reference's expected_seqs.tsv and by the 704 rows of real vg output in its scoring fixture
+ * (oracle/extract_oracle.py lists what is not pinned: insertions and other records -- they are not part
+ * of the graph).
  *
  * gfm_graph_create: h_ref [ref_len] bases; sites ascending 0-based h_pos [n_sites], h_n_alts [n_sites]
- *   in 1..3, h_alt_bases [n_sites][3]; h_alt_bits [n_sites][3][ceil(H/64)] = haplotypes carrying each
- *   alternate allele (bit h of word h/64), or NULL / H = 0 for no haplotype counts (freq = 0).
+ *   in 1..3, h_alt_bases [n_sites][3]; h_del_len [n_sites] (or NULL): 0 for a SNP, else the site is a
+ *   deletion of that many bases after the anchor h_pos (one alternate allele; deletions must not
+ *   overlap; a deletion may follow a SNP at the same position); h_alt_bits [n_sites][3][ceil(H/64)] =
+ *   haplotypes carrying each alternate allele (bit h of word h/64; deletion carriers in slot 0), or
+ *   NULL / H = 0 for no haplotype counts (freq = 0).
  * gfm_graph_plan: regions [S, E] as vg takes them (windows start at p in [S, E - W]); returns the
  *   number of windows and of rows (2 per walk: forward, reverse complement).  Synchronous.
  * gfm_graph_emit: rows of the last plan, window-major, walks in mixed-radix order with the LAST site
- *   of the window varying fastest, forward row then '-' row:  d_kmers [rows][W], d_start / d_stop
- *   (forward: p, p+W; '-': p+W, p), d_strand ('+'/'-'), d_freq, d_is_ref (1 = every allele is the
- *   reference's), d_region (index into the plan's regions), d_walk (walk index inside its window).
- *   Enqueue only. */
+ *   of the window varying fastest (windows that touch a deletion: lexicographic order of the walk's
+ *   decisions, reference allele / no jump first), forward row then '-' row:  d_kmers [rows][W],
+ *   d_start / d_stop (forward: p, e; '-': e, p; e = reference coordinate after the last base, p + W
+ *   unless the walk jumps a deletion), d_strand ('+'/'-'), d_freq, d_is_ref (vg's flag: 1 = every SNP
+ *   allele is the reference's, also when a deletion is taken), d_region (index into the plan's
+ *   regions), d_walk (walk index inside its window).  Enqueue only. */
 typedef struct gfm_graph *gfm_graph_t;
 int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_sites, const int32_t *h_pos,
-                     const uint8_t *h_n_alts, const uint8_t *h_alt_bases, const uint64_t *h_alt_bits,
-                     int32_t n_haplotypes, gfm_graph_t *out);
+                     const uint8_t *h_n_alts, const uint8_t *h_alt_bases, const int32_t *h_del_len,
+                     const uint64_t *h_alt_bits, int32_t n_haplotypes, gfm_graph_t *out);
 void gfm_graph_destroy(gfm_graph_t g);
 int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_starts, const int64_t *h_stops,
                    int32_t width, int64_t *n_windows, int64_t *n_rows);

@@ -46,35 +46,50 @@ def test_graph_index_matches_the_oracle_readers(tmp_path):
         fasta, vcf = make_graph_files(str(d), chrom="7", gz=gz)
         idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
         ref = xo.read_fasta(fasta)["7"]
-        sites = xo.read_vcf_snps(vcf, "7")
-        assert idx.ref.tobytes() == ref and idx.skipped == sites.skipped > 0
-        assert np.array_equal(idx.pos, sites.pos) and idx.n_haplotypes == sites.n_haplotypes == 130
-        assert [list(map(chr, b[:n])) for b, n in zip(idx.alt_bases, idx.n_alts)] == sites.alts
+        sites, dels, skipped = xo.read_vcf_graph(vcf, "7")
+        assert idx.ref.tobytes() == ref and idx.skipped == skipped > 0 and len(dels) > 0
+        snp, dele = idx.del_len == 0, idx.del_len > 0
+        assert np.array_equal(idx.pos[snp], sites.pos) and idx.n_haplotypes == sites.n_haplotypes == 130
+        assert np.array_equal(idx.pos[dele], dels.anchor) and np.array_equal(idx.del_len[dele], dels.length)
+        assert (np.diff(idx.pos) >= 0).all()
+        assert [list(map(chr, b[:n])) for b, n in zip(idx.alt_bases[snp], idx.n_alts[snp])] == sites.alts
         assert any(n == 3 for n in idx.n_alts) and any(n == 2 for n in idx.n_alts)
-        # bit h of word h // 64 <=> haplotype h carries that alternate allele
+        # bit h of word h // 64 <=> haplotype h carries that alternate allele / the deletion
         for a in range(3):
             bits = np.unpackbits(idx.alt_bits[:, a, :].view(np.uint8), axis=1, bitorder="little")[:, :130]
-            assert np.array_equal(bits.astype(bool), sites.hap == a + 1)
+            assert np.array_equal(bits[snp].astype(bool), sites.hap == a + 1)
+        bits = np.unpackbits(idx.alt_bits[:, 0, :].view(np.uint8), axis=1, bitorder="little")[:, :130]
+        assert np.array_equal(bits[dele].astype(bool), dels.hap)
     with pytest.raises(ValueError):
         GraphIndex.from_fasta_vcf(fasta, vcf, "no_such_chromosome")
 
 
 def test_node_numbering_matches_the_oracle(tmp_path):
+    """GraphIndex.node_path (vg construct's ids, the walk order of the extraction kernel) against the
+    oracle's rows: every walk of every window, windows with deletions included."""
     from grafimo_amd.extract_regions import GraphIndex
     from oracle import extract_oracle as xo
-    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=1200, n_sites=120)
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=600, n_sites=48)
     idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7", with_haplotypes=False)
-    assert idx.alt_bits is None and idx.n_haplotypes == 0
-    sites = xo.read_vcf_snps(vcf, "7")
-    nodes = xo.NodeTable(len(idx.ref), sites)
-    rng = np.random.default_rng(3)
-    for W in (5, 19, 40):
-        for p in rng.integers(0, len(idx.ref) - W, 60):
-            i0, alleles = idx.walk_alleles(int(p), W, 0)
-            n_walks = int(np.prod([1 + idx.n_alts[i0 + k] for k in range(len(alleles))])) if alleles else 1
-            q = int(rng.integers(0, n_walks))
-            i0, alleles = idx.walk_alleles(int(p), W, q)
-            assert idx.node_path(int(p), W, q) == nodes.path(sites, int(p), W, i0, alleles)
+    assert idx.alt_bits is None and idx.n_haplotypes == 0 and (idx.del_len > 0).any()
+    ref = xo.read_fasta(fasta)["7"]
+    sites, dels, _ = xo.read_vcf_graph(vcf, "7")
+    nodes = xo.GraphNodeTable(len(ref), sites, dels)
+    for W in (5, 19, 30):
+        rows = xo.enumerate_region_graph("7", ref, sites, dels, 0, 600, W, nodes=nodes)[0::2]   # forward rows
+        by_start = {}
+        for r in rows:
+            by_start.setdefault(int(r[2].split(":")[1][:-1]), []).append(r)
+        touched = 0
+        for p, walks in by_start.items():
+            if len(walks) > 64:
+                continue                                 # (the host replay is O(walks) per walk)
+            touched += idx.touches_deletion(p, W)
+            for q, r in enumerate(walks):
+                assert "".join(f"{n}+," for n in idx.node_path(p, W, q)) == r[6], (W, p, q)
+                bases = idx.walk_bases(p, W, q)
+                assert bases[-1][0] + 1 == int(r[3].split(":")[1][:-1])
+        assert touched > 0
     # the reference's test graph: ids 1..9 as in expected_seqs.tsv
     t = GraphIndex.from_fasta_vcf(os.path.join(REF_DATA, "test.fa"), os.path.join(REF_DATA, "test.vcf.gz"), "x")
     assert t.node_path(0, 19, 0) == [1, 3, 5, 6, 8, 9] and t.node_path(0, 19, 7) == [1, 2, 4, 6, 7, 9]
@@ -89,18 +104,22 @@ def test_graph_abi_validates_before_touching_a_device():
     pos = np.array([5, 2], dtype=np.int32)
     n_alts = np.array([1, 1], dtype=np.uint8)
     alt = np.zeros((2, 3), dtype=np.uint8)
-    assert lib.gfm_graph_create(None, 10, 0, None, None, None, None, 0, ctypes.byref(h)) == nv.GFM_ERR_INVALID
-    rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt), None, 0, ctypes.byref(h))
+    assert lib.gfm_graph_create(None, 10, 0, None, None, None, None, None, 0, ctypes.byref(h)) == nv.GFM_ERR_INVALID
+    rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt), None, None, 0, ctypes.byref(h))
     assert rc == nv.GFM_ERR_INVALID and b"ascending" in lib.gfm_last_error()
+    dl = np.array([3, 2], dtype=np.int32)            # overlapping deletions
+    p2 = np.array([2, 4], dtype=np.int32)
+    rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(p2), nv.ptr(n_alts), nv.ptr(alt), nv.ptr(dl), None, 0, ctypes.byref(h))
+    assert rc == nv.GFM_ERR_INVALID and b"overlap" in lib.gfm_last_error()
     pos = np.array([2, 5], dtype=np.int32)
     n_alts[1] = 4
-    rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt), None, 0, ctypes.byref(h))
+    rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt), None, None, 0, ctypes.byref(h))
     assert rc == nv.GFM_ERR_INVALID and b"1..3" in lib.gfm_last_error()
     assert lib.gfm_graph_plan(None, 0, None, None, 19, None, None) == nv.GFM_ERR_INVALID
     import torch
     if not torch.cuda.is_available():          # no CPU fallback: a valid graph still needs a GPU
         n_alts[1] = 1
-        rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt), None, 0, ctypes.byref(h))
+        rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt), None, None, 0, ctypes.byref(h))
         assert rc == nv.GFM_ERR_NODEVICE and not h.value
 
 

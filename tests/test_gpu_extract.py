@@ -18,11 +18,11 @@ torch = pytest.importorskip("torch")
 def _oracle_rows(fasta, vcf, chrom, regions, W, counts=True):
     from oracle import extract_oracle as xo
     ref = xo.read_fasta(fasta)[chrom]
-    sites = xo.read_vcf_snps(vcf, chrom)
-    nodes = xo.NodeTable(len(ref), sites)
+    sites, dels, _ = xo.read_vcf_graph(vcf, chrom)
+    nodes = xo.GraphNodeTable(len(ref), sites, dels)
     rows = []
     for s, e in regions:
-        rows += xo.enumerate_region(chrom, ref, sites, s, e, W, with_counts=counts, nodes=nodes)
+        rows += xo.enumerate_region_graph(chrom, ref, sites, dels, s, e, W, with_counts=counts, nodes=nodes)
     return rows
 
 
@@ -53,7 +53,7 @@ def test_rows_equal_the_oracle_on_a_synthetic_graph(tmp_path, W):
     # (a 64-base window over the dense graph holds thousands of walks: keep the oracle's Python loop short)
     fasta, vcf = make_graph_files(str(tmp_path), chrom="7", seed=40 + W, n_sites=260 if W < 64 else 100)
     idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
-    regions = [(0, 150), (100, 400), (2900, 3000), (1500, 1500 + W - 1), (1000, 1700), (2990, 3050), (-20, 90)]
+    regions = [(0, 150), (100, 300), (2900, 3000), (1500, 1500 + W - 1), (1000, 1250), (2990, 3050), (-20, 90)]
     g = DeviceGraph(idx)
     rows = g.extract(regions, W)
     exp = _oracle_rows(fasta, vcf, "7", [(max(s, 0), min(e, 3000)) for s, e in regions], W)
@@ -66,6 +66,8 @@ def test_rows_equal_the_oracle_on_a_synthetic_graph(tmp_path, W):
     assert rows.freq.cpu().numpy().tolist() == [r[4] for r in exp]
     assert ["ref" if x else "non.ref" for x in rows.is_ref.cpu().numpy()] == [r[5] for r in exp]
     assert max(r[4] for r in exp) == 130 and any(0 < r[4] < 130 for r in exp)
+    span = lambda r: abs(int(r[3].split(":")[1][:-1]) - int(r[2].split(":")[1][:-1]))
+    assert W == 1 or any(span(r) != W for r in exp)           # walks that jump a deletion are in the set
     # the TSV files: same text as the oracle's rows (labels carry the caller's region bounds)
     paths = write_region_tsvs(idx, rows, str(tmp_path / "out"))
     text = "".join(open(p).read() for p in paths)
@@ -73,11 +75,11 @@ def test_rows_equal_the_oracle_on_a_synthetic_graph(tmp_path, W):
     exp_text = "".join("\t".join([lab[r[0]]] + [str(x) for x in r[1:]]) + "\n" for r in exp)
     assert sorted(text.splitlines()) == sorted(exp_text.splitlines())
     # the handle keeps its plan buffers: a smaller and then a larger plan on the same graph
-    small = g.extract([(100, 400)], W)
+    small = g.extract([(100, 300)], W)
     assert [k.tobytes().decode() for k in small.kmers.cpu().numpy()] == \
-        [r[1] for r in _oracle_rows(fasta, vcf, "7", [(100, 400)], W)]
-    again = g.extract(regions + [(200, 2800)], W)
-    exp2 = exp + _oracle_rows(fasta, vcf, "7", [(200, 2800)], W)
+        [r[1] for r in _oracle_rows(fasta, vcf, "7", [(100, 300)], W)]
+    again = g.extract(regions + [(200, 700)], W)
+    exp2 = exp + _oracle_rows(fasta, vcf, "7", [(200, 700)], W)
     assert again.freq.cpu().numpy().tolist() == [r[4] for r in exp2]
     assert [k.tobytes().decode() for k in again.kmers.cpu().numpy()] == [r[1] for r in exp2]
     g.close()
@@ -210,4 +212,66 @@ def test_graph_pipeline_under_a_process_group(tmp_path):
     finally:
         dist.destroy_process_group()
     assert len(plain) > 0 and plain.equals(coll)
+    g.close()
+
+
+def test_scoring_fixture_rows_through_the_gpu(tmp_path):
+    """The 704 rows of real vg output behind the reference's test_scoring, regenerated by the extraction
+    kernel from the fixture's local graph (5 SNPs, one deletion, 5096 haplotypes), then scored: the same
+    table the reference's expected scoring_results.tsv holds."""
+    from test_extract_host import scoring_fixture_graph
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, compute_results_from_graph, write_region_tsvs
+    from grafimo_amd.motif_ops import build_motif_meme_host
+    from grafimo_amd.workflow import Findmotif
+    rows, refseq, sites, dels, S, E = scoring_fixture_graph()
+    H = sites.n_haplotypes
+    recs = [(int(p), 0, i) for i, p in enumerate(sites.pos)] + [(int(a), 1, j) for j, a in enumerate(dels.anchor)]
+    recs.sort()
+    hw = (H + 63) // 64
+    bits = np.zeros((len(recs), 3, hw), dtype=np.uint64)
+    alt = np.zeros((len(recs), 3), dtype=np.uint8)
+    for k, (_, kind, j) in enumerate(recs):
+        carry = np.zeros(hw * 64, dtype=bool)
+        carry[:H] = dels.hap[j] if kind else sites.hap[j] == 1
+        bits[k, 0] = np.packbits(carry, bitorder="little").view(np.uint64)
+        if not kind:
+            alt[k, 0] = ord(sites.alts[j][0])
+    ref = np.frombuffer(refseq, dtype=np.uint8)
+    idx = GraphIndex("22", ref, [r[0] for r in recs], [1] * len(recs), alt, bits, H,
+                     del_len=[int(dels.length[j]) if kind else 0 for _, kind, j in recs])
+    g = DeviceGraph(idx)
+    ext = g.extract([(0, E - S)], 19)
+    assert len(ext) == 704
+    at = lambda s_: int(s_.split(":")[1][:-1])
+    exp = sorted((r[1], at(r[2]) - S, at(r[3]) - S, r[2][-1], int(r[4]), r[5]) for r in rows)
+    km = ext.kmers.cpu().numpy()
+    got = sorted((km[i].tobytes().decode(), int(ext.start[i]), int(ext.stop[i]), chr(int(ext.strand[i])),
+                  int(ext.freq[i]), "ref" if int(ext.is_ref[i]) else "non.ref") for i in range(704))
+    assert got == exp
+    # the TSV writer: node paths too (ids start at 1 here; vg's 849116.. are the same ids shifted, and its first
+    # node ends after one base, which a chromosome starting at the region cannot reproduce: compare the rest)
+    path = write_region_tsvs(idx, ext, str(tmp_path))[0]
+    mine = {}
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        mine[(f[1], f[2], f[3])] = f[6]
+    for r in rows:
+        key = (r[1], f"22:{at(r[2]) - S}{r[2][-1]}", f"22:{at(r[3]) - S}{r[3][-1]}")
+        ids = [int(x[:-1]) - 849116 for x in r[6].strip(",").split(",")]
+        got_ids = [int(x[:-1]) for x in mine[key].strip(",").split(",")]
+        if 0 not in ids:                       # walks that do not touch vg's one-base first node
+            assert [i - 1 for i in ids] == [i - 1 for i in got_ids] or ids == got_ids, key
+    # scoring them reproduces the reference's expected table (test_scoring: threshold 1, recomb, q-values)
+    motif = build_motif_meme_host(os.path.join(REF_DATA, "MA0139.1.meme"), "unfrm_dst", 0.1, False)[0]
+    with contextlib.redirect_stdout(io.StringIO()):
+        df = compute_results_from_graph(motif, g, [(0, E - S)], True, Findmotif(threshold=1.0, recomb=True))
+    ref_df = pd.read_csv(os.path.join(REF_DATA, "scoring_results.tsv"), sep="\t", index_col=0)
+    assert len(df) == len(ref_df) == 704
+    key = ["matched_sequence", "strand", "haplotype_frequency"]
+    a = df.assign(start=df["start"] + S, stop=df["stop"] + S).sort_values(key + ["start"]).reset_index(drop=True)
+    b = ref_df.sort_values(key + ["start"]).reset_index(drop=True)
+    for c in ("start", "stop", "strand", "matched_sequence", "haplotype_frequency", "reference"):
+        assert (a[c].astype(str) == b[c].astype(str)).all(), c
+    for c in ("score", "p-value", "q-value"):
+        np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-9, atol=0)
     g.close()
