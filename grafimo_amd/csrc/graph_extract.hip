@@ -79,6 +79,7 @@ struct WalkState {
 enum { WALK_OK = 0, WALK_DEAD = 1, WALK_OVERFLOW = 2 };
 
 struct NoVisitor {
+    static constexpr bool kWantsBases = false;     // stretches without a site are skipped in one step
     __device__ void base(int, long long, int, int) {}
     __device__ void took(int) {}
     __device__ void passed(int) {}
@@ -88,11 +89,33 @@ struct NoVisitor {
 template <class V>
 __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, int prefix, WalkState &st, V &vis)
 {
+    constexpr long long kNoSite = 0x7fffffffffffffffll;
     long long x = p;
     int n = 0, d = 0, i = i0;
+    long long next_pos = i < g.n_sites ? (long long)g.pos[i] : kNoSite;   // position of site i, kept in a register
     for (;;) {
         if (x >= g.ref_len) { st.nd = d; return WALK_DEAD; }
-        while (i < g.n_sites && g.pos[i] < x) ++i;
+        while (next_pos < x) {                         // only after a jump over deleted bases
+            ++i;
+            next_pos = i < g.n_sites ? (long long)g.pos[i] : kNoSite;
+        }
+        if (next_pos > x) {                            // no site here
+            if constexpr (!V::kWantsBases) {
+                // nobody looks at the bases: take the whole site-free stretch at once
+                long long run = next_pos - x;
+                if (run > W - n) run = W - n;
+                if (x + run > g.ref_len) { st.nd = d; return WALK_DEAD; }
+                n += (int)run;
+                x += run;
+                if (n == W) { st.nd = d; st.last = x - 1; return WALK_OK; }
+                continue;
+            } else {
+                vis.base(n, x, -1, 0);
+                if (++n == W) { st.nd = d; st.last = x; return WALK_OK; }
+                ++x;
+                continue;
+            }
+        }
         int snp = -1, del = -1;
         for (int k = i; k < g.n_sites && g.pos[k] == x; ++k) {
             if (g.del_len[k] == 0) snp = k; else del = k;
@@ -169,8 +192,7 @@ __global__ void __launch_bounds__(kCountThreads)
 graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ region_off,
                    const long long *__restrict__ first_start, int W, long long n_windows,
                    int *__restrict__ first_site, long long *__restrict__ n_walks, int *__restrict__ win_region,
-                   long long *__restrict__ win_start, int *__restrict__ overflow, int *__restrict__ del_list,
-                   int *__restrict__ del_count)
+                   long long *__restrict__ win_start, int *__restrict__ overflow, unsigned char *__restrict__ win_del)
 {
     const long long w = (long long)blockIdx.x * kCountThreads + threadIdx.x;
     if (w >= n_windows) return;
@@ -196,7 +218,7 @@ graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ regi
             prefix = next_walk(st);
         } while (prefix >= 0);
     }
-    if (touches_del && walks > 0) del_list[atomicAdd(del_count, 1)] = (int)w;
+    win_del[w] = touches_del ? 1 : 0;
     first_site[w] = i0;
     n_walks[w] = walks;
     win_region[w] = r;      // the emit kernel reads these instead of repeating the search: its waves
@@ -374,98 +396,117 @@ graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *_
     walk[row] = walk[row + 1] = q0;
 }
 
-// Windows that touch a deletion: one thread per window walks its odometer once and writes the rows of
-// its walks directly (they are few: plain byte stores).  Runs after graph_emit_kernel on the same stream.
-__global__ void __launch_bounds__(kCountThreads)
-graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ del_list,
-                      const int *__restrict__ del_count, const long long *__restrict__ win_start, int W,
-                      const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+// visitor of simulate() that writes the bases of a walk and collects what its haplotypes must carry
+struct DelEmit {
+    const GraphDev &g;
+    uint8_t *fwd, *rev;
+    int W;
+    int n_cons;
+    int csite[kMaxDecisions + 1];
+    unsigned char ccode[kMaxDecisions + 1];     // 0..3 SNP allele, 4 deletion taken, 5 deletion not carried
+    bool alt;
+    static constexpr bool kWantsBases = true;
+    __device__ void add(int site, int code)
+    {
+        if (n_cons <= kMaxDecisions) { csite[n_cons] = site; ccode[n_cons] = (unsigned char)code; ++n_cons; }
+    }
+    __device__ void base(int j, long long x, int snp, int a)
+    {
+        uint8_t c = g.ref[x];
+        if (snp >= 0) {
+            if (a) { c = g.alt_bases[(size_t)snp * kMaxAlts + (a - 1)]; alt = true; }
+            add(snp, a);
+        }
+        fwd[j] = c;
+        rev[W - 1 - j] = complement(c);
+    }
+    __device__ void took(int site) { add(site, 4); }
+    __device__ void passed(int site) { add(site, 5); }
+};
+
+
+// Windows that touch a deletion: one thread per walk (threads of plain windows leave at once).  The
+// thread runs its window's odometer up to its own rank, replays that walk writing the bases of its
+// two rows (plain byte stores: these walks are few) and counts the haplotypes.  Runs after
+// graph_emit_kernel on the same stream and overwrites what that kernel wrote for these rows.
+__global__ void __launch_bounds__(kEmitThreads)
+graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ walk_window,
+                      const unsigned char *__restrict__ win_del, const long long *__restrict__ win_start, int W,
+                      long long n_walks, const int *__restrict__ first_site, const long long *__restrict__ walk_base,
                       uint8_t *__restrict__ kmers, long long *__restrict__ start, long long *__restrict__ stop,
-                      long long *__restrict__ freq, uint8_t *__restrict__ is_ref, int *__restrict__ walk)
+                      long long *__restrict__ freq, uint8_t *__restrict__ is_ref)
 {
-    const int m = blockIdx.x * kCountThreads + threadIdx.x;
-    if (m >= *del_count) return;
-    const int w = del_list[m];
+    const long long t = (long long)blockIdx.x * kEmitThreads + threadIdx.x;
+    if (t >= n_walks) return;
+    const int w = walk_window[t];
+    if (!win_del[w]) return;
     const long long p = win_start[w];
     const int i0 = first_site[w];
-    const long long base = walk_base[w];
-    const int cover = cover_deletion(g, p);      // the window starts on deleted bases: carriers lack them
-    struct Emit {
-        const GraphDev &g;
-        uint8_t *fwd, *rev;
-        int W;
-        int n_cons;
-        int csite[kMaxDecisions + 1];
-        unsigned char ccode[kMaxDecisions + 1];     // 0..3 SNP allele, 4 deletion taken, 5 deletion not carried
-        bool alt;
-        __device__ void add(int site, int code)
-        {
-            if (n_cons <= kMaxDecisions) { csite[n_cons] = site; ccode[n_cons] = (unsigned char)code; ++n_cons; }
-        }
-        __device__ void base(int j, long long x, int snp, int a)
-        {
-            uint8_t c = g.ref[x];
-            if (snp >= 0) {
-                if (a) { c = g.alt_bases[(size_t)snp * kMaxAlts + (a - 1)]; alt = true; }
-                add(snp, a);
-            }
-            fwd[j] = c;
-            rev[W - 1 - j] = complement(c);
-        }
-        __device__ void took(int site) { add(site, 4); }
-        __device__ void passed(int site) { add(site, 5); }
-    };
+    const int q0 = (int)(t - walk_base[w]);
     WalkState st;
-    int prefix = 0, q = 0;
-    do {
-        uint8_t *fwd = kmers + (size_t)(2 * (base + q)) * W;
-        Emit em{g, fwd, fwd + W, W, 0, {}, {}, false};
-        // the rows of walk q are overwritten by later attempts until one succeeds (dead ends write too)
-        const int rc = simulate(g, p, W, i0, prefix, st, em);
-        if (rc == WALK_OK) {
-            if (cover >= 0) em.add(cover, 5);
-            long long count = 0;
-            if (g.alt_bits) {
-                if (em.n_cons == 0) {
-                    count = g.n_hap;
-                } else if (em.n_cons == 1) {
-                    const int code = em.ccode[0];
-                    count = allele_count[(size_t)em.csite[0] * 4 + (code == 4 ? 1 : code == 5 ? 0 : code)];
-                } else {
-                    for (int word = 0; word < g.hw; ++word) {
-                        unsigned long long acc = ~0ull;
-                        if (word == g.hw - 1 && (g.n_hap & 63)) acc = (1ull << (g.n_hap & 63)) - 1ull;
-                        for (int k = 0; k < em.n_cons; ++k) {
-                            const unsigned long long *b = g.alt_bits + ((size_t)em.csite[k] * kMaxAlts) * g.hw + word;
-                            const int code = em.ccode[k];
-                            unsigned long long bits;
-                            if (code >= 1 && code <= 3) {
-                                bits = b[(size_t)(code - 1) * g.hw];
-                            } else if (code == 4) {
-                                bits = b[0];
-                            } else {                       // reference allele / deletion not carried
-                                const int na = g.n_alts[em.csite[k]];
-                                bits = b[0];
-                                if (na > 1) bits |= b[(size_t)g.hw];
-                                if (na > 2) bits |= b[(size_t)2 * g.hw];
-                                bits = ~bits;
-                            }
-                            acc &= bits;
+    {
+        NoVisitor nv;
+        int prefix = 0, seen = 0;
+        for (;;) {
+            const int rc = simulate(g, p, W, i0, prefix, st, nv);
+            if (rc == WALK_OK && seen++ == q0) break;
+            prefix = next_walk(st);
+            if (prefix < 0) return;          // cannot happen: q0 < walks of the window
+        }
+    }
+    uint8_t *fwd = kmers + (size_t)(2 * t) * W;
+    DelEmit em{g, fwd, fwd + W, W, 0, {}, {}, false};
+    simulate(g, p, W, i0, st.nd, st, em);
+    const int cover = cover_deletion(g, p);      // the window starts on deleted bases: carriers lack them
+    if (cover >= 0) em.add(cover, 5);
+    long long count = 0;
+    if (g.alt_bits) {
+        if (em.n_cons == 0) {
+            count = g.n_hap;
+        } else if (em.n_cons == 1) {
+            const int code = em.ccode[0];
+            count = allele_count[(size_t)em.csite[0] * 4 + (code == 4 ? 1 : code == 5 ? 0 : code)];
+        } else {
+            constexpr int kWordsPerTrip = 8;     // independent loads in flight, as in graph_emit_kernel
+            for (int w0 = 0; w0 < g.hw; w0 += kWordsPerTrip) {
+                unsigned long long acc[kWordsPerTrip];
+#pragma unroll
+                for (int j = 0; j < kWordsPerTrip; ++j) {
+                    const int word = w0 + j;
+                    acc[j] = word < g.hw ? ~0ull : 0ull;
+                    if (word == g.hw - 1 && (g.n_hap & 63)) acc[j] = (1ull << (g.n_hap & 63)) - 1ull;
+                }
+                for (int k = 0; k < em.n_cons; ++k) {
+                    const unsigned long long *b = g.alt_bits + ((size_t)em.csite[k] * kMaxAlts) * g.hw + w0;
+                    const int code = em.ccode[k];
+                    const int na = g.n_alts[em.csite[k]];
+#pragma unroll
+                    for (int j = 0; j < kWordsPerTrip; ++j) {
+                        if (w0 + j >= g.hw) continue;
+                        unsigned long long bits;
+                        if (code >= 1 && code <= 3) {
+                            bits = b[(size_t)(code - 1) * g.hw + j];
+                        } else if (code == 4) {
+                            bits = b[j];
+                        } else {                       // reference allele / deletion not carried
+                            bits = b[j];
+                            if (na > 1) bits |= b[(size_t)g.hw + j];
+                            if (na > 2) bits |= b[(size_t)2 * g.hw + j];
+                            bits = ~bits;
                         }
-                        count += __popcll(acc);
+                        acc[j] &= bits;
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < kWordsPerTrip; ++j) count += __popcll(acc[j]);
             }
-            const long long row = 2 * (base + q), end_pos = st.last + 1;
-            start[row] = p;          start[row + 1] = end_pos;
-            stop[row] = end_pos;     stop[row + 1] = p;
-            freq[row] = count;       freq[row + 1] = count;
-            is_ref[row] = is_ref[row + 1] = em.alt ? 0 : 1;
-            walk[row] = walk[row + 1] = q;
-            ++q;
         }
-        prefix = next_walk(st);
-    } while (prefix >= 0 && base + q < walk_base[w + 1]);
+    }
+    const long long row = 2 * t, end_pos = st.last + 1;
+    start[row] = p;          start[row + 1] = end_pos;
+    stop[row] = end_pos;     stop[row + 1] = p;
+    freq[row] = count;       freq[row + 1] = count;
+    is_ref[row] = is_ref[row + 1] = em.alt ? 0 : 1;
 }
 
 template <typename T> hipError_t upload(T **dst, const T *src, size_t count)
@@ -510,13 +551,12 @@ struct gfm_graph {
     long long n_windows = 0, n_walks = 0;
     Buf<long long> region_off, first_start, walk_base, win_start, walks;
     Buf<int> first_site, win_region, walk_window, flag;
-    Buf<unsigned char> scan_tmp;
-    Buf<int> del_list;
+    Buf<unsigned char> scan_tmp, win_del;
     void drop_plan()
     {
         region_off.release(); first_start.release(); walk_base.release(); win_start.release(); walks.release();
         first_site.release(); win_region.release(); walk_window.release(); flag.release(); scan_tmp.release();
-        del_list.release();
+        win_del.release();
         n_regions = 0;
         n_windows = n_walks = 0;
     }
@@ -632,21 +672,21 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     GX_TRY(g->first_start.reserve(first.size()));
     GX_TRY(g->first_site.reserve(nw));
     GX_TRY(g->walks.reserve(nw));
-    GX_TRY(g->flag.reserve(2));          // [0] overflow flag, [1] number of windows that touch a deletion
+    GX_TRY(g->flag.reserve(1));
     GX_TRY(g->win_region.reserve(nw));
     GX_TRY(g->win_start.reserve(nw));
     GX_TRY(g->walk_base.reserve(nw + 1));
-    GX_TRY(g->del_list.reserve(g->dev.n_dels ? nw : 1));
+    GX_TRY(g->win_del.reserve(nw));
     GX_TRY(hipMemcpyAsync(g->region_off.p, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, nullptr));
     GX_TRY(hipMemcpyAsync(g->first_start.p, first.data(), sizeof(long long) * first.size(), hipMemcpyHostToDevice, nullptr));
-    GX_TRY(hipMemsetAsync(g->flag.p, 0, 2 * sizeof(int), nullptr));
+    GX_TRY(hipMemsetAsync(g->flag.p, 0, sizeof(int), nullptr));
     GX_TRY(hipMemsetAsync(g->walk_base.p, 0, sizeof(long long), nullptr));
     // walks per window -> inclusive prefix (row base of every window) on the device: only the total and the
     // overflow flag come back
     const unsigned blocks = (unsigned)((nw + kCountThreads - 1) / kCountThreads);
     hipLaunchKernelGGL(graph_count_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->dev, n_regions,
                        g->region_off.p, g->first_start.p, width, (long long)nw, g->first_site.p, g->walks.p,
-                       g->win_region.p, g->win_start.p, g->flag.p, g->del_list.p, g->flag.p + 1);
+                       g->win_region.p, g->win_start.p, g->flag.p, g->win_del.p);
     GX_TRY(hipGetLastError());
     size_t tmp_bytes = 0;
     GX_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, g->walks.p, g->walk_base.p + 1, (int)nw, nullptr));
@@ -685,12 +725,10 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
                        reinterpret_cast<long long *>(d_stop), d_strand, reinterpret_cast<long long *>(d_freq),
                        d_is_ref, d_region, d_walk);
     if (g->dev.n_dels) {
-        // at most every window; the kernel reads the real count from the device
-        const unsigned dblocks = (unsigned)((g->n_windows + kCountThreads - 1) / kCountThreads);
-        hipLaunchKernelGGL(graph_emit_del_kernel, dim3(dblocks), dim3(kCountThreads), 0, static_cast<hipStream_t>(stream),
-                           g->dev, g->d_allele_count, g->del_list.p, g->flag.p + 1, g->win_start.p, g->width,
-                           g->first_site.p, g->walk_base.p, d_kmers, reinterpret_cast<long long *>(d_start),
-                           reinterpret_cast<long long *>(d_stop), reinterpret_cast<long long *>(d_freq), d_is_ref, d_walk);
+        hipLaunchKernelGGL(graph_emit_del_kernel, dim3(blocks), dim3(kEmitThreads), 0, static_cast<hipStream_t>(stream),
+                           g->dev, g->d_allele_count, g->walk_window.p, g->win_del.p, g->win_start.p, g->width,
+                           g->n_walks, g->first_site.p, g->walk_base.p, d_kmers, reinterpret_cast<long long *>(d_start),
+                           reinterpret_cast<long long *>(d_stop), reinterpret_cast<long long *>(d_freq), d_is_ref);
     }
     GX_TRY(hipGetLastError());
     return GFM_OK;

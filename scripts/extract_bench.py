@@ -1,6 +1,6 @@
 """Extraction kernel throughput at BASELINE config-2 scale: 10 000 regions x 200 bp on a synthetic
-chromosome with 1000-Genomes-like SNP density (1 site / 32 bp, 5096 haplotypes = 80 bitset words per
-allele), W = 19; then the whole extraction -> scoring pipeline on the device."""
+chromosome with 1000-Genomes-like variant density (1 site / 32 bp, 6 % of them deletions, 5096 haplotypes =
+80 bitset words per allele), W = 19; then the whole extraction -> scoring pipeline on the device."""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,7 +31,20 @@ for s in range(0, V, blk):
     carry = rng.random((e - s, hw * 64)) < af[s:e, None]
     carry[:, H:] = False
     bits[s:e, 0, :] = np.packbits(carry, axis=1, bitorder="little").view(np.uint64)
-idx = GraphIndex("22", ref, pos, n_alts, alt_bases, None if os.environ.get("EXTRACT_NO_COUNTS") else bits, H)
+# 6 % of the sites are deletions of 1..8 bases (1000-Genomes-like share), kept apart from each other
+del_len = np.zeros(V, np.int32)
+cand = np.nonzero(rng.random(V) < 0.06)[0]
+last_end = -1
+for i in cand:
+    ln = int(rng.integers(1, 9))
+    if pos[i] > last_end and pos[i] + ln < L - 1:
+        del_len[i] = ln
+        last_end = int(pos[i]) + ln
+n_alts[del_len > 0] = 1
+alt_bases[del_len > 0] = 0
+bits[del_len > 0, 1:, :] = 0
+idx = GraphIndex("22", ref, pos, n_alts, alt_bases, None if os.environ.get("EXTRACT_NO_COUNTS") else bits, H,
+                 del_len=None if os.environ.get("EXTRACT_NO_DELS") else del_len)
 regions = [(16_000 + 1000 * i, 16_000 + 1000 * i + 200) for i in range(n_regions)]
 t = time.perf_counter(); g = DeviceGraph(idx); torch.cuda.synchronize(); t_up = time.perf_counter() - t
 
@@ -57,7 +70,7 @@ for _ in range(10):
 ev1.record(); torch.cuda.synchronize()
 emit_ms = ev0.elapsed_time(ev1) / 10
 out_bytes = n * (W + 8 + 8 + 1 + 8 + 1 + 4 + 4)
-res = dict(regions=n_regions, region_bp=200, W=W, sites=V, haplotypes=H, rows=n, windows=n_regions * (200 - W + 1),
+res = dict(regions=n_regions, region_bp=200, W=W, sites=V, deletions=int((idx.del_len > 0).sum()), haplotypes=H, rows=n, windows=n_regions * (200 - W + 1),
            graph_upload_s=t_up, extract_wall_ms=1e3 * float(np.median(times)), emit_kernel_ms=emit_ms,
            rows_per_s_emit=n / (emit_ms * 1e-3), rows_per_s_wall=n / float(np.median(times)),
            emit_written_GBps=out_bytes / (emit_ms * 1e-3) / 1e9,
