@@ -60,21 +60,23 @@ struct GraphDev {
     int n_hap, hw;
     const int *del_len;         // [n_sites] 0 for a SNP, else the number of deleted bases after the anchor
     int n_dels;
-    const int *del_site;        // [n_dels] site indices of the deletions, ascending anchors
+    const int *prev_del;        // [n_sites + 1] index of the last deletion among sites [0, i), or -1
 };
 
 // -------------------------------------------------------------------------------------------
-// Walks through windows that touch a deletion.  A walk is a vector of decisions met while W bases
-// are consumed from p: at a SNP the allele (reference first), at the anchor of a deletion -- when
-// more bases are needed -- 0 = go on along the reference, 1 = jump over the deleted bases.  The
-// walks of a window are enumerated in lexicographic order of their decision vectors (an odometer
-// over simulate()); oracle/extract_oracle.py enumerate_region_graph recurses in the same order.
-constexpr int kMaxDecisions = 24;
+// Walks through windows that touch a deletion.  While W bases are consumed from p a walk decides, at
+// the anchor of every deletion it meets with bases still to go, whether to go on along the reference
+// (0) or to jump the deleted bases (1): that vector of jumps is its LAYOUT -- the reference positions
+// it uses -- and on a layout the SNP alleles are free, a plain mixed-radix product.  The walks of a
+// window are ordered layout-major: layouts in lexicographic order of their jump vectors (an odometer
+// over simulate()), inside a layout the allele digits with the last SNP varying fastest.  So counting
+// a window costs one pass per layout, not per walk, and walk q is found by skipping whole layouts.
+// oracle/extract_oracle.py enumerate_region_graph produces the same order.
+constexpr int kMaxDecisions = 24;      // jumps decided by one walk
 struct WalkState {
     int nd = 0;
     long long last = 0;                       // reference position of the last base
-    unsigned char choice[kMaxDecisions];
-    unsigned char nchoice[kMaxDecisions];
+    unsigned char choice[kMaxDecisions];      // 0 / 1 per deletion met
 };
 enum { WALK_OK = 0, WALK_DEAD = 1, WALK_OVERFLOW = 2 };
 
@@ -85,14 +87,18 @@ struct NoVisitor {
     __device__ void passed(int) {}
 };
 
-// follows st.choice[0 .. prefix) and takes choice 0 at every later decision
+// Follows st.choice[0 .. prefix) at the deletions met and does not jump at later ones.  `prod` returns
+// the number of allele combinations of the layout.  When the visitor wants bases, walk `q` of the
+// layout is decoded on the way: rem starts as the layout's product and is divided at every SNP.
 template <class V>
-__device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, int prefix, WalkState &st, V &vis)
+__device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, int prefix, WalkState &st, V &vis,
+                               long long q, long long rem, long long &prod)
 {
     constexpr long long kNoSite = 0x7fffffffffffffffll;
     long long x = p;
     int n = 0, d = 0, i = i0;
     long long next_pos = i < g.n_sites ? (long long)g.pos[i] : kNoSite;   // position of site i, kept in a register
+    prod = 1;
     for (;;) {
         if (x >= g.ref_len) { st.nd = d; return WALK_DEAD; }
         while (next_pos < x) {                         // only after a jump over deleted bases
@@ -122,11 +128,13 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, in
         }
         int a = 0;
         if (snp >= 0) {
-            if (d >= kMaxDecisions) { st.nd = d; return WALK_OVERFLOW; }
-            a = d < prefix ? st.choice[d] : 0;
-            st.choice[d] = (unsigned char)a;
-            st.nchoice[d] = (unsigned char)(1 + g.n_alts[snp]);
-            ++d;
+            const int nall = 1 + g.n_alts[snp];
+            prod *= nall;
+            if (prod > kMaxWalksPerWindow) { st.nd = d; return WALK_OVERFLOW; }
+            if constexpr (V::kWantsBases) {
+                rem /= nall;
+                a = (int)((q / rem) % nall);
+            }
         }
         vis.base(n, x, snp, a);
         if (++n == W) { st.nd = d; st.last = x; return WALK_OK; }
@@ -134,7 +142,6 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, in
             if (d >= kMaxDecisions) { st.nd = d; return WALK_OVERFLOW; }
             const int c = d < prefix ? st.choice[d] : 0;
             st.choice[d] = (unsigned char)c;
-            st.nchoice[d] = 2;
             ++d;
             if (c) { vis.took(del); x += g.del_len[del] + 1; continue; }
             vis.passed(del);
@@ -143,27 +150,22 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, in
     }
 }
 
-// advances the odometer; returns the new prefix length or -1 when the window is exhausted
+// next layout: the last jump decision that is still 0 becomes 1; returns the new prefix length or -1
 __device__ inline int next_walk(WalkState &st)
 {
     int t = st.nd - 1;
-    while (t >= 0 && st.choice[t] + 1 >= st.nchoice[t]) --t;
+    while (t >= 0 && st.choice[t]) --t;
     if (t < 0) return -1;
-    ++st.choice[t];
+    st.choice[t] = 1;
     return t + 1;
 }
 
-// deletion whose deleted bases contain p (the window starts inside it), or -1
-__device__ inline int cover_deletion(const GraphDev &g, long long p)
+// deletion whose deleted bases contain p (the window starts inside it), or -1.  i0 = first site at or
+// after p: deletions do not overlap, so only the last one anchored before p can reach p.
+__device__ inline int cover_deletion(const GraphDev &g, long long p, int i0)
 {
-    int lo = 0, hi = g.n_dels;           // last deletion with anchor < p
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (g.pos[g.del_site[mid]] < p) lo = mid + 1; else hi = mid;
-    }
-    if (lo == 0) return -1;
-    const int sidx = g.del_site[lo - 1];
-    return p <= (long long)g.pos[sidx] + g.del_len[sidx] ? sidx : -1;
+    const int d = g.prev_del[i0];
+    return (d >= 0 && p <= (long long)g.pos[d] + g.del_len[d]) ? d : -1;
 }
 
 __device__ inline int lower_bound_pos(const int *pos, int n, long long v)
@@ -192,7 +194,8 @@ __global__ void __launch_bounds__(kCountThreads)
 graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ region_off,
                    const long long *__restrict__ first_start, int W, long long n_windows,
                    int *__restrict__ first_site, long long *__restrict__ n_walks, int *__restrict__ win_region,
-                   long long *__restrict__ win_start, int *__restrict__ overflow, unsigned char *__restrict__ win_del)
+                   long long *__restrict__ win_start, int *__restrict__ overflow, int *__restrict__ del_list,
+                   int *__restrict__ del_count)
 {
     const long long w = (long long)blockIdx.x * kCountThreads + threadIdx.x;
     if (w >= n_windows) return;
@@ -200,25 +203,18 @@ graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ regi
     const long long p = first_start[r] + (w - region_off[r]);
     const int i0 = lower_bound_pos(g.pos, g.n_sites, p);
     long long walks = 1;
-    bool touches_del = g.n_dels > 0 && cover_deletion(g, p) >= 0;
+    bool touches_del = g.n_dels > 0 && cover_deletion(g, p, i0) >= 0;
     for (int i = i0; i < g.n_sites && g.pos[i] < p + W; ++i) {
         if (g.del_len[i]) touches_del = true;
         walks *= 1 + g.n_alts[i];
         if (walks > kMaxWalksPerWindow) { walks = 0; atomicMax(overflow, 1); break; }
     }
-    if (touches_del) {           // the sites a walk meets depend on the deletions it takes: enumerate
-        WalkState st;
-        NoVisitor nv;
+    if (touches_del) {
+        // the sites a walk meets depend on the deletions it takes: graph_count_del_kernel enumerates them.
+        // (Done here, the few deletion windows of a wave made all of its lanes wait for their odometers.)
         walks = 0;
-        int prefix = 0;
-        do {
-            const int rc = simulate(g, p, W, i0, prefix, st, nv);
-            if (rc == WALK_OK) ++walks;
-            if (rc == WALK_OVERFLOW || walks > kMaxWalksPerWindow) { walks = 0; atomicMax(overflow, 1); break; }
-            prefix = next_walk(st);
-        } while (prefix >= 0);
+        del_list[atomicAdd(del_count, 1)] = (int)w;
     }
-    win_del[w] = touches_del ? 1 : 0;
     first_site[w] = i0;
     n_walks[w] = walks;
     win_region[w] = r;      // the emit kernel reads these instead of repeating the search: its waves
@@ -232,6 +228,42 @@ __device__ inline uint8_t complement(uint8_t c)
     case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
     default: return c;   // N stays N
     }
+}
+
+// thread per listed deletion window: number of walks by running the odometer
+__global__ void __launch_bounds__(kCountThreads)
+graph_count_del_kernel(GraphDev g, const int *__restrict__ del_list, const int *__restrict__ del_count,
+                       const long long *__restrict__ win_start, int W, const int *__restrict__ first_site,
+                       long long *__restrict__ n_walks, long long *__restrict__ del_walks, int *__restrict__ overflow)
+{
+    const int m = blockIdx.x * kCountThreads + threadIdx.x;
+    if (m >= *del_count) return;
+    const int w = del_list[m];
+    const long long p = win_start[w];
+    const int i0 = first_site[w];
+    WalkState st;
+    NoVisitor nv;
+    long long walks = 0;
+    int prefix = 0;
+    do {                                             // one pass per layout
+        long long prod = 0;
+        const int rc = simulate(g, p, W, i0, prefix, st, nv, 0, 0, prod);
+        if (rc == WALK_OK) walks += prod;
+        if (rc == WALK_OVERFLOW || walks > kMaxWalksPerWindow) { walks = 0; atomicMax(overflow, 1); break; }
+        prefix = next_walk(st);
+    } while (prefix >= 0);
+    n_walks[w] = walks;
+    del_walks[m] = walks;
+}
+
+// thread per listed deletion window: walk t of the deletion walks belongs to list entry del_entry[t]
+__global__ void __launch_bounds__(kCountThreads)
+graph_del_map_kernel(const int *__restrict__ del_count, const long long *__restrict__ del_base,
+                     int *__restrict__ del_entry)
+{
+    const int m = blockIdx.x * kCountThreads + threadIdx.x;
+    if (m >= *del_count) return;
+    for (long long t = del_base[m]; t < del_base[m + 1]; ++t) del_entry[t] = m;
 }
 
 // haplotypes per allele of every site (allele 0 = reference): a walk through ONE site needs no bitset
@@ -425,39 +457,46 @@ struct DelEmit {
 };
 
 
-// Windows that touch a deletion: one thread per walk (threads of plain windows leave at once).  The
-// thread runs its window's odometer up to its own rank, replays that walk writing the bases of its
+// Windows that touch a deletion: one thread per walk of those windows (compacted: a kernel over all
+// walks spent its time in waves with one or two such lanes).  The thread runs its window's odometer up to its own rank, replays that walk writing the bases of its
 // two rows (plain byte stores: these walks are few) and counts the haplotypes.  Runs after
 // graph_emit_kernel on the same stream and overwrites what that kernel wrote for these rows.
 __global__ void __launch_bounds__(kEmitThreads)
-graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ walk_window,
-                      const unsigned char *__restrict__ win_del, const long long *__restrict__ win_start, int W,
-                      long long n_walks, const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ del_list,
+                      const int *__restrict__ del_entry, const long long *__restrict__ del_base,
+                      const long long *__restrict__ win_start, int W, long long n_del_walks,
+                      const int *__restrict__ first_site, const long long *__restrict__ walk_base,
                       uint8_t *__restrict__ kmers, long long *__restrict__ start, long long *__restrict__ stop,
                       long long *__restrict__ freq, uint8_t *__restrict__ is_ref)
 {
-    const long long t = (long long)blockIdx.x * kEmitThreads + threadIdx.x;
-    if (t >= n_walks) return;
-    const int w = walk_window[t];
-    if (!win_del[w]) return;
+    const long long td = (long long)blockIdx.x * kEmitThreads + threadIdx.x;
+    if (td >= n_del_walks) return;
+    const int m = del_entry[td];
+    const int w = del_list[m];
     const long long p = win_start[w];
     const int i0 = first_site[w];
-    const int q0 = (int)(t - walk_base[w]);
+    const int q0 = (int)(td - del_base[m]);
+    const long long t = walk_base[w] + q0;          // its place among all walks
     WalkState st;
+    long long q = q0, prod = 0;
     {
         NoVisitor nv;
-        int prefix = 0, seen = 0;
-        for (;;) {
-            const int rc = simulate(g, p, W, i0, prefix, st, nv);
-            if (rc == WALK_OK && seen++ == q0) break;
+        int prefix = 0;
+        for (;;) {                                   // skip the layouts that lie before walk q0
+            const int rc = simulate(g, p, W, i0, prefix, st, nv, 0, 0, prod);
+            if (rc == WALK_OK) {
+                if (q < prod) break;
+                q -= prod;
+            }
             prefix = next_walk(st);
-            if (prefix < 0) return;          // cannot happen: q0 < walks of the window
+            if (prefix < 0) return;                  // cannot happen: q0 < walks of the window
         }
     }
     uint8_t *fwd = kmers + (size_t)(2 * t) * W;
     DelEmit em{g, fwd, fwd + W, W, 0, {}, {}, false};
-    simulate(g, p, W, i0, st.nd, st, em);
-    const int cover = cover_deletion(g, p);      // the window starts on deleted bases: carriers lack them
+    long long again = 0;
+    simulate(g, p, W, i0, st.nd, st, em, q, prod, again);
+    const int cover = cover_deletion(g, p, i0);  // the window starts on deleted bases: carriers lack them
     if (cover >= 0) em.add(cover, 5);
     long long count = 0;
     if (g.alt_bits) {
@@ -545,18 +584,22 @@ struct gfm_graph {
     uint8_t *d_n_alts = nullptr, *d_alt_bases = nullptr;
     unsigned long long *d_alt_bits = nullptr;
     int *d_allele_count = nullptr;   // [n_sites][4] haplotypes per allele (0 = reference)
-    int *d_del_len = nullptr, *d_del_site = nullptr;
+    int *d_del_len = nullptr, *d_prev_del = nullptr;
     // last plan (buffers are kept between plans)
     int n_regions = 0, width = 0;
     long long n_windows = 0, n_walks = 0;
     Buf<long long> region_off, first_start, walk_base, win_start, walks;
     Buf<int> first_site, win_region, walk_window, flag;
-    Buf<unsigned char> scan_tmp, win_del;
+    Buf<unsigned char> scan_tmp;
+    Buf<int> del_list, del_entry;
+    Buf<long long> del_walks, del_base;
+    long long n_del_walks = 0;
     void drop_plan()
     {
         region_off.release(); first_start.release(); walk_base.release(); win_start.release(); walks.release();
         first_site.release(); win_region.release(); walk_window.release(); flag.release(); scan_tmp.release();
-        win_del.release();
+        del_list.release(); del_entry.release(); del_walks.release(); del_base.release();
+        n_del_walks = 0;
         n_regions = 0;
         n_windows = n_walks = 0;
     }
@@ -571,7 +614,8 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (!h_ref || ref_len <= 0 || n_sites < 0 || n_haplotypes < 0)
         return gfail(GFM_ERR_INVALID, "bad reference / site count");
     if (n_sites && (!h_pos || !h_n_alts || !h_alt_bases)) return gfail(GFM_ERR_INVALID, "NULL site arrays");
-    std::vector<int> del_len((size_t)n_sites, 0), del_site;
+    std::vector<int> del_len((size_t)n_sites, 0), prev_del((size_t)n_sites + 1, -1);
+    int n_dels = 0;
     long long deleted_until = -1;        // last reference position removed by an earlier deletion
     for (int i = 0; i < n_sites; ++i) {
         const int dl = h_del_len ? h_del_len[i] : 0;
@@ -589,9 +633,10 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
             if (h_pos[i] <= deleted_until)
                 return gfail(GFM_ERR_INVALID, "deletions must not overlap (site " + std::to_string(i) + ")");
             deleted_until = (long long)h_pos[i] + dl;
-            del_site.push_back(i);
+            ++n_dels;
         }
         del_len[(size_t)i] = dl;
+        prev_del[(size_t)i + 1] = dl > 0 ? i : prev_del[(size_t)i];
     }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
@@ -607,7 +652,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = upload(&g->d_n_alts, h_n_alts, (size_t)n_sites);
     if (e == hipSuccess) e = upload(&g->d_alt_bases, h_alt_bases, (size_t)n_sites * kMaxAlts);
     if (e == hipSuccess) e = upload(&g->d_del_len, del_len.data(), del_len.size());
-    if (e == hipSuccess) e = upload(&g->d_del_site, del_site.data(), del_site.size());
+    if (e == hipSuccess) e = upload(&g->d_prev_del, prev_del.data(), prev_del.size());
     if (e == hipSuccess && bits)
         e = upload(&g->d_alt_bits, reinterpret_cast<const unsigned long long *>(h_alt_bits),
                    (size_t)n_sites * kMaxAlts * hw);
@@ -617,7 +662,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     }
     g->dev = GraphDev{g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
                       bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0,
-                      g->d_del_len, (int)del_site.size(), g->d_del_site};
+                      g->d_del_len, n_dels, g->d_prev_del};
     if (bits) {
         e = hipMalloc(&g->d_allele_count, sizeof(int) * 4 * (size_t)n_sites);
         if (e == hipSuccess) {
@@ -641,7 +686,7 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     g->drop_plan();
     (void)hipFree(g->d_ref); (void)hipFree(g->d_pos); (void)hipFree(g->d_n_alts);
     (void)hipFree(g->d_alt_bases); (void)hipFree(g->d_alt_bits); (void)hipFree(g->d_allele_count);
-    (void)hipFree(g->d_del_len); (void)hipFree(g->d_del_site);
+    (void)hipFree(g->d_del_len); (void)hipFree(g->d_prev_del);
     delete g;
 }
 
@@ -672,26 +717,43 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     GX_TRY(g->first_start.reserve(first.size()));
     GX_TRY(g->first_site.reserve(nw));
     GX_TRY(g->walks.reserve(nw));
-    GX_TRY(g->flag.reserve(1));
+    GX_TRY(g->flag.reserve(2));          // [0] overflow flag, [1] number of windows that touch a deletion
     GX_TRY(g->win_region.reserve(nw));
     GX_TRY(g->win_start.reserve(nw));
     GX_TRY(g->walk_base.reserve(nw + 1));
-    GX_TRY(g->win_del.reserve(nw));
+    const bool dels = g->dev.n_dels > 0;
+    GX_TRY(g->del_list.reserve(dels ? nw : 1));
+    GX_TRY(g->del_walks.reserve(dels ? nw : 1));
+    GX_TRY(g->del_base.reserve(dels ? nw + 1 : 1));
     GX_TRY(hipMemcpyAsync(g->region_off.p, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, nullptr));
     GX_TRY(hipMemcpyAsync(g->first_start.p, first.data(), sizeof(long long) * first.size(), hipMemcpyHostToDevice, nullptr));
-    GX_TRY(hipMemsetAsync(g->flag.p, 0, sizeof(int), nullptr));
+    GX_TRY(hipMemsetAsync(g->flag.p, 0, 2 * sizeof(int), nullptr));
+    if (dels) {
+        GX_TRY(hipMemsetAsync(g->del_walks.p, 0, sizeof(long long) * nw, nullptr));
+        GX_TRY(hipMemsetAsync(g->del_base.p, 0, sizeof(long long), nullptr));
+    }
     GX_TRY(hipMemsetAsync(g->walk_base.p, 0, sizeof(long long), nullptr));
     // walks per window -> inclusive prefix (row base of every window) on the device: only the total and the
     // overflow flag come back
     const unsigned blocks = (unsigned)((nw + kCountThreads - 1) / kCountThreads);
     hipLaunchKernelGGL(graph_count_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->dev, n_regions,
                        g->region_off.p, g->first_start.p, width, (long long)nw, g->first_site.p, g->walks.p,
-                       g->win_region.p, g->win_start.p, g->flag.p, g->win_del.p);
+                       g->win_region.p, g->win_start.p, g->flag.p, g->del_list.p, g->flag.p + 1);
     GX_TRY(hipGetLastError());
+    if (dels) {   // the grid covers every window; the kernel reads the real number of listed windows
+        hipLaunchKernelGGL(graph_count_del_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->dev, g->del_list.p,
+                           g->flag.p + 1, g->win_start.p, width, g->first_site.p, g->walks.p, g->del_walks.p, g->flag.p);
+        GX_TRY(hipGetLastError());
+    }
     size_t tmp_bytes = 0;
     GX_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, g->walks.p, g->walk_base.p + 1, (int)nw, nullptr));
     GX_TRY(g->scan_tmp.reserve(tmp_bytes));
     GX_TRY(hipcub::DeviceScan::InclusiveSum(g->scan_tmp.p, tmp_bytes, g->walks.p, g->walk_base.p + 1, (int)nw, nullptr));
+    long long total_del = 0;
+    if (dels) {   // same scan over the listed windows (entries past the list are zero)
+        GX_TRY(hipcub::DeviceScan::InclusiveSum(g->scan_tmp.p, tmp_bytes, g->del_walks.p, g->del_base.p + 1, (int)nw, nullptr));
+        GX_TRY(hipMemcpy(&total_del, g->del_base.p + nw, sizeof total_del, hipMemcpyDeviceToHost));
+    }
     long long total = 0;
     int overflow = 0;
     GX_TRY(hipMemcpy(&total, g->walk_base.p + nw, sizeof total, hipMemcpyDeviceToHost));   // also orders the host vectors
@@ -704,8 +766,15 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
                            g->walk_base.p, g->walk_window.p);
         GX_TRY(hipGetLastError());
     }
+    if (total_del > 0) {
+        GX_TRY(g->del_entry.reserve((size_t)total_del));
+        hipLaunchKernelGGL(graph_del_map_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->flag.p + 1,
+                           g->del_base.p, g->del_entry.p);
+        GX_TRY(hipGetLastError());
+    }
     g->n_windows = (long long)nw;
     g->n_walks = total;
+    g->n_del_walks = total_del;
     if (n_rows) *n_rows = 2 * g->n_walks;
     return GFM_OK;
 }
@@ -724,11 +793,13 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
                        g->win_region.p, g->win_start.p, g->width, g->n_walks, g->first_site.p, g->walk_base.p, d_kmers, reinterpret_cast<long long *>(d_start),
                        reinterpret_cast<long long *>(d_stop), d_strand, reinterpret_cast<long long *>(d_freq),
                        d_is_ref, d_region, d_walk);
-    if (g->dev.n_dels) {
-        hipLaunchKernelGGL(graph_emit_del_kernel, dim3(blocks), dim3(kEmitThreads), 0, static_cast<hipStream_t>(stream),
-                           g->dev, g->d_allele_count, g->walk_window.p, g->win_del.p, g->win_start.p, g->width,
-                           g->n_walks, g->first_site.p, g->walk_base.p, d_kmers, reinterpret_cast<long long *>(d_start),
-                           reinterpret_cast<long long *>(d_stop), reinterpret_cast<long long *>(d_freq), d_is_ref);
+    if (g->n_del_walks > 0) {
+        const unsigned dblocks = (unsigned)((g->n_del_walks + kEmitThreads - 1) / kEmitThreads);
+        hipLaunchKernelGGL(graph_emit_del_kernel, dim3(dblocks), dim3(kEmitThreads), 0, static_cast<hipStream_t>(stream),
+                           g->dev, g->d_allele_count, g->del_list.p, g->del_entry.p, g->del_base.p, g->win_start.p,
+                           g->width, g->n_del_walks, g->first_site.p, g->walk_base.p, d_kmers,
+                           reinterpret_cast<long long *>(d_start), reinterpret_cast<long long *>(d_stop),
+                           reinterpret_cast<long long *>(d_freq), d_is_ref);
     }
     GX_TRY(hipGetLastError());
     return GFM_OK;

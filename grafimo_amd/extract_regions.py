@@ -189,9 +189,9 @@ class GraphIndex:
     def window_walks(self, p: int, width: int):
         """Yields, in the enumeration order of the extraction kernel, the walks of window p as
         [(reference position, SNP allele)] per base: mixed radix (last site fastest) for plain windows;
-        for windows that touch a deletion the lexicographic order of the decisions met on the way (SNP
-        allele, reference first; at a deletion's anchor 0 = stay on the reference, 1 = jump), a jump
-        needing a landing position inside the chromosome."""
+        for windows that touch a deletion layout-major: the jump vectors (at a deletion's anchor 0 = stay on
+        the reference, 1 = jump; a jump needs a landing position inside the chromosome) in lexicographic
+        order, and on one layout the mixed radix of its SNPs."""
         if not self.touches_deletion(p, width):
             i0 = int(np.searchsorted(self.pos, p, side="left"))
             i1 = int(np.searchsorted(self.pos, p + width, side="left"))
@@ -211,42 +211,29 @@ class GraphIndex:
                 self._site_at.setdefault(x, []).append(i)
         site_at = self._site_at
 
-        def simulate(choices):
-            out, x, d, made = [], p, 0, []
-            while True:
-                if x >= len(self.ref):
-                    return None, made
-                here = site_at.get(x, ())
-                snp = next((i for i in here if self.del_len[i] == 0), None)
-                dele = next((i for i in here if self.del_len[i] > 0), None)
-                a = 0
-                if snp is not None:
-                    a = choices[d] if d < len(choices) else 0
-                    made.append((a, 1 + int(self.n_alts[snp])))
-                    d += 1
-                out.append((x, a))
-                if len(out) == width:
-                    return out, made
-                if dele is not None:
-                    c = choices[d] if d < len(choices) else 0
-                    made.append((c, 2))
-                    d += 1
-                    if c:
-                        x += int(self.del_len[dele]) + 1
-                        continue
-                x += 1
-
-        choices = []
-        while True:
-            out, made = simulate(choices)
-            if out is not None:
-                yield out
-            t = len(made) - 1
-            while t >= 0 and made[t][0] + 1 >= made[t][1]:
-                t -= 1
-            if t < 0:
+        def layouts(x, used):
+            if x >= len(self.ref):
                 return
-            choices = [m[0] for m in made[:t]] + [made[t][0] + 1]
+            used = used + [x]
+            if len(used) == width:
+                yield used
+                return
+            yield from layouts(x + 1, used)
+            dele = next((i for i in site_at.get(x, ()) if self.del_len[i] > 0), None)
+            if dele is not None:
+                yield from layouts(x + int(self.del_len[dele]) + 1, used)
+
+        for used in layouts(p, []):                     # layout-major, like the kernel
+            snps = [(x, next(i for i in site_at[x] if self.del_len[i] == 0)) for x in used
+                    if any(self.del_len[i] == 0 for i in site_at.get(x, ()))]
+            radix = [1 + int(self.n_alts[i]) for _, i in snps]
+            total = int(np.prod(radix)) if radix else 1
+            for q in range(total):
+                at, qq = {}, q
+                for k in range(len(radix) - 1, -1, -1):
+                    at[snps[k][0]] = qq % radix[k]
+                    qq //= radix[k]
+                yield [(x, at.get(x, 0)) for x in used]
 
     def walk_bases(self, p: int, width: int, walk: int) -> List[Tuple[int, int]]:
         for q, bases in enumerate(self.window_walks(p, width)):

@@ -280,9 +280,10 @@ class GraphNodeTable:
 def enumerate_region_graph(chrom: str, ref: bytes, sites: Sites, dels: Dels, S: int, E: int, W: int,
                            with_counts: bool = False, nodes: Optional[GraphNodeTable] = None):
     """Rows of `vg find -p chrom:S-E -K W -E [-H]` on a graph with SNPs and deletions: every walk of
-    W bases from every start p in [S, E-W].  At a SNP the alleles are taken in order (reference
-    first); at the anchor of a deletion a walk that needs more bases first continues on the
-    reference, then takes the deletion.  stop = reference coordinate after the last base; the flag
+    W bases from every start p in [S, E-W].  Order inside a window: layout-major -- the jump vectors
+    (at the anchor of a deletion a walk that needs more bases first continues on the reference, then
+    takes the deletion) in lexicographic order, and on one layout the SNP alleles like
+    itertools.product (reference first, last SNP fastest).  stop = reference coordinate after the last base; the flag
     is vg's (`ref` = only reference-path nodes: a taken deletion does not change it -- GRAFIMO's
     own rule flips such rows, score_sequences.py:305-307); count = haplotypes with every SNP allele
     of the walk, with every deletion it takes, and without any deletion whose bases it uses."""
@@ -320,22 +321,26 @@ def enumerate_region_graph(chrom: str, ref: bytes, sites: Sites, dels: Dels, S: 
         rows.append((label, revcomp(kmer).decode(), f"{chrom}:{last + 1}-", f"{chrom}:{p}-", count, is_ref,
                      "".join(f"{n}-," for n in reversed(path))))
 
-    def rec(p, x, bases, used, snps, taken):
+    def layouts(x, used, taken):
+        """reference positions used by the walks from x (jump vectors in lexicographic order: at the
+        anchor of a deletion first the walk that stays on the reference, then the one that jumps)"""
         if x >= len(ref):
             return
-        i = snp_at.get(x)
-        for a in range(1 + (len(sites.alts[i]) if i is not None else 0)):
-            b = ref[x] if a == 0 else ord(sites.alts[i][a - 1])
-            nb, nu = bases + [b], used + [x]
-            ns = snps + [(i, a)] if i is not None else snps
-            if len(nb) == W:
-                emit(p, nb, nu, ns, taken)
-                continue
-            rec(p, x + 1, nb, nu, ns, taken)
-            j = del_at.get(x)
-            if j is not None:
-                rec(p, x + int(dels.length[j]) + 1, nb, nu, ns, taken + [j])
+        nu = used + [x]
+        if len(nu) == W:
+            yield nu, taken
+            return
+        yield from layouts(x + 1, nu, taken)
+        j = del_at.get(x)
+        if j is not None:
+            yield from layouts(x + int(dels.length[j]) + 1, nu, taken + [j])
 
     for p in range(max(S, 0), min(E, len(ref)) - W + 1):
-        rec(p, p, [], [], [], [])
+        for used, taken in layouts(p, [], []):
+            on = [snp_at[x] for x in used if x in snp_at]
+            for combo in itertools.product(*[range(1 + len(sites.alts[i])) for i in on]):   # last SNP fastest
+                allele = dict(zip(on, combo))
+                bases = [ref[x] if not allele.get(snp_at.get(x), 0) else ord(sites.alts[snp_at[x]][allele[snp_at[x]] - 1])
+                         for x in used]
+                emit(p, bases, used, list(zip(on, combo)), taken)
     return rows
