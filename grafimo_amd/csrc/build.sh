@@ -10,6 +10,7 @@ FLAGS=(-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fvisibility
 "$HIPCC" "${FLAGS[@]}" -c "$here/grafimo_hip.hip" -o "$here/grafimo_hip.o" "$@"
 "$HIPCC" "${FLAGS[@]}" -c "$here/graph_extract.hip" -o "$here/graph_extract.o"
 "$HIPCC" "${FLAGS[@]}" -c "$here/tsv_ingest.cpp" -o "$here/tsv_ingest.o"
+"$HIPCC" "${FLAGS[@]}" -c "$here/vcf_ingest.cpp" -o "$here/vcf_ingest.o"
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$here/libgrafimo_hip.so" \
-    "$here/grafimo_hip.o" "$here/graph_extract.o" "$here/tsv_ingest.o" -lpthread
+    "$here/grafimo_hip.o" "$here/graph_extract.o" "$here/tsv_ingest.o" "$here/vcf_ingest.o" -lpthread -lz
 echo "built $here/libgrafimo_hip.so"

@@ -16,7 +16,6 @@ graph holds the single-base substitutions and the plain deletions of the VCF; ot
 `GraphIndex.skipped`.  There is no CPU fallback: extraction needs libgrafimo_hip.so and a GPU.
 """
 import ctypes
-import gzip
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -73,55 +72,29 @@ class GraphIndex:
         self._site_at = None
 
     @classmethod
-    def from_fasta_vcf(cls, fasta: str, vcf: str, chrom: str, with_haplotypes: bool = True) -> "GraphIndex":
+    def from_fasta_vcf(cls, fasta: str, vcf: str, chrom: str, with_haplotypes: bool = True,
+                       threads: int = 0) -> "GraphIndex":
+        """Reference bases of `chrom` + its VCF records through the library's reader (gfm_vcf_*: host
+        threads, plain or gzip/bgzip): SNPs and plain deletions become sites, the rest is counted in
+        `.skipped`; two haplotypes per sample in file order."""
         ref = _read_fasta_record(fasta, chrom)
-        recs, skipped, last_snp, deleted_until = [], 0, -1, -1     # (pos, kind, alts, del_len, genotypes)
-        op = gzip.open if vcf.endswith(".gz") else open
-        with op(vcf, "rt") as fh:
-            for line in fh:
-                if line[0] == "#":
-                    continue
-                f = line.rstrip("\n").split("\t")
-                if f[0] != chrom:
-                    continue
-                r, a = f[3].upper(), f[4].upper().split(",")
-                p = int(f[1]) - 1
-                is_snp = len(r) == 1 and len(a) <= MAX_ALTS and all(len(x) == 1 and x in "ACGT" for x in a)
-                is_del = len(r) > 1 and len(a) == 1 and a[0] == r[0]
-                if is_snp and p != last_snp:
-                    last_snp = p
-                elif is_del and p > deleted_until:       # no overlap with a deletion accepted before
-                    deleted_until = p + len(r) - 1
-                else:
-                    skipped += 1                           # insertion / MNP / symbolic / overlapping record
-                    continue
-                row = []
-                if with_haplotypes:
-                    for s_ in f[9:]:
-                        gt = s_.split(":", 1)[0].replace("/", "|").split("|")
-                        if len(gt) == 1:
-                            gt = gt * 2
-                        row += [int(x) if x.isdigit() else 0 for x in gt[:2]]
-                recs.append((p, 0 if is_snp else 1, a if is_snp else [], 0 if is_snp else len(r) - 1, row))
-        recs.sort(key=lambda t: (t[0], t[1]))             # a deletion follows the SNP at its anchor
-        V = len(recs)
-        pos = [t[0] for t in recs]
-        n_alts = np.array([len(t[2]) if t[1] == 0 else 1 for t in recs], dtype=np.uint8)
-        alt_bases = np.zeros((V, MAX_ALTS), dtype=np.uint8)
-        for i, t in enumerate(recs):
-            alt_bases[i, :len(t[2])] = [ord(x) for x in t[2]]
-        H = len(recs[0][4]) if recs and with_haplotypes else 0
-        bits = None
-        if H:
-            g = np.asarray([t[4] for t in recs], dtype=np.int8)      # [V, H]
-            hw = (H + 63) // 64
-            bits = np.zeros((V, MAX_ALTS, hw), dtype=np.uint64)
-            padded = np.zeros((V, hw * 64), dtype=bool)
-            for a in range(MAX_ALTS):
-                padded[:, :H] = g == a + 1
-                # bit h of word h // 64: little-endian bit order inside little-endian 64-bit words
-                bits[:, a, :] = np.packbits(padded, axis=1, bitorder="little").view(np.uint64)
-        return cls(chrom, ref, pos, n_alts, alt_bases, bits, H, skipped, del_len=[t[3] for t in recs])
+        h = ctypes.c_void_p()
+        n, H, skipped = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int64()
+        nv.check(nv.lib().gfm_vcf_open(vcf.encode(), chrom.encode(), int(bool(with_haplotypes)),
+                                       threads or (os.cpu_count() or 1), ctypes.byref(h), ctypes.byref(n),
+                                       ctypes.byref(H), ctypes.byref(skipped)))
+        try:
+            V, hw = int(n.value), (int(H.value) + 63) // 64
+            pos = np.empty(V, dtype=np.int32)
+            n_alts = np.empty(V, dtype=np.uint8)
+            alt_bases = np.empty((V, MAX_ALTS), dtype=np.uint8)
+            del_len = np.empty(V, dtype=np.int32)
+            bits = np.empty((V, MAX_ALTS, hw), dtype=np.uint64) if hw else None
+            nv.check(nv.lib().gfm_vcf_read(h, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt_bases), nv.ptr(del_len),
+                                           nv.ptr(bits) if bits is not None else None))
+        finally:
+            nv.lib().gfm_vcf_close(h)
+        return cls(chrom, ref, pos, n_alts, alt_bases, bits, int(H.value), int(skipped.value), del_len=del_len)
 
     # ---- node ids of `vg construct` on this graph (column 7 of the TSV; not used by GRAFIMO's scoring)
     def _node_table(self):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFM_ABI_VERSION 3
+#define GFM_ABI_VERSION 4
 
 #define GFM_OK 0
 #define GFM_ERR_INVALID (-1)  /* bad argument (NULL, width out of range, ...)            */
@@ -226,6 +226,20 @@ int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_starts, co
                    int32_t width, int64_t *n_windows, int64_t *n_rows);
 int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, int64_t *d_stop, uint8_t *d_strand,
                    int64_t *d_freq, uint8_t *d_is_ref, int32_t *d_region, int32_t *d_walk, void *stream);
+
+/* Phased VCF (plain or gzip/bgzip) -> the site arrays of gfm_graph_create for one chromosome; host
+ * threads parse the lines.  The reference hands the VCF to `vg construct` / `vg index -G`
+ * (constructVG.py:332,394); here its single-base substitutions become SNP sites and its plain
+ * deletions deletion sites, other records (insertions, MNPs, a second SNP at one position, a deletion
+ * touching an earlier one) are counted in *n_skipped.  Two haplotypes per sample in file order.
+ * gfm_vcf_read copies: pos [n], n_alts [n], alt_bases [n][3], del_len [n], alt_bits [n][3][ceil(H/64)]
+ * (may be NULL). */
+typedef struct gfm_vcf *gfm_vcf_t;
+int gfm_vcf_open(const char *path, const char *chrom, int with_haplotypes, int n_threads, gfm_vcf_t *out,
+                 int64_t *n_sites, int32_t *n_haplotypes, int64_t *n_skipped);
+int gfm_vcf_read(gfm_vcf_t v, int32_t *pos, uint8_t *n_alts, uint8_t *alt_bases, int32_t *del_len,
+                 uint64_t *alt_bits);
+void gfm_vcf_close(gfm_vcf_t v);
 
 #ifdef __cplusplus
 }

@@ -185,3 +185,26 @@ def test_graph_oracle_equals_the_snp_oracle_without_deletions(tmp_path):
     b = xo.enumerate_region_graph("7", ref, sites, no_dels, 0, 400, 19, True,
                                   xo.GraphNodeTable(len(ref), sites, no_dels))
     assert a == b
+
+
+def test_native_vcf_reader_threads_and_errors(tmp_path):
+    from grafimo_amd import _native as nv
+    from grafimo_amd.extract_regions import GraphIndex
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=5000, n_sites=1200, n_samples=40, seed=2)
+    a = GraphIndex.from_fasta_vcf(fasta, vcf, "7", threads=1)
+    b = GraphIndex.from_fasta_vcf(fasta, vcf, "7", threads=7)
+    for name in ("pos", "n_alts", "alt_bases", "del_len", "alt_bits"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert a.skipped == b.skipped and a.n_haplotypes == 80 and len(a.pos) > 500
+    c = GraphIndex.from_fasta_vcf(fasta, vcf, "7", with_haplotypes=False)
+    assert c.alt_bits is None and np.array_equal(c.pos, a.pos)
+    other = GraphIndex.from_fasta_vcf(fasta, vcf, "other")           # the one-record chromosome of the helper
+    assert other.pos.tolist() == [2] and other.ref.tobytes() == b"ACGTACGT"
+    with pytest.raises(nv.NativeError) as e:
+        GraphIndex.from_fasta_vcf(fasta, str(tmp_path / "missing.vcf"), "7")
+    assert e.value.code == nv.GFM_ERR_IO
+    bad = tmp_path / "unsorted.vcf"
+    bad.write_text("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts0\n"
+                   "7\t30\t.\tA\tC\t.\t.\t.\tGT\t0|1\n7\t10\t.\tA\tC\t.\t.\t.\tGT\t0|1\n")
+    with pytest.raises(nv.NativeError):
+        GraphIndex.from_fasta_vcf(fasta, str(bad), "7")
