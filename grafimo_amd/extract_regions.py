@@ -33,18 +33,43 @@ MAX_ALTS = 3
 
 
 def _read_fasta_record(path: str, chrom: str) -> np.ndarray:
-    parts, on = [], False
+    """Bases of one record as uppercase uint8.  The file is mapped and only header lines are looked at
+    (a genome FASTA is gigabytes; the record wanted is one chromosome), or `path.fai` is used."""
+    import mmap
+    want = chrom.encode()
     with open(path, "rb") as fh:
-        for line in fh:
-            if line.startswith(b">"):
-                if on:
-                    break
-                on = line[1:].split()[0].decode() == chrom
-            elif on:
-                parts.append(line.strip().upper())
-    if not parts:
+        mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+        try:
+            start = end = -1
+            fai = path + ".fai"
+            if os.path.exists(fai):
+                for line in open(fai):
+                    f = line.split("\t")
+                    if f[0] == chrom:              # name, length, offset, bases per line, bytes per line
+                        length, off, lb, lw = int(f[1]), int(f[2]), int(f[3]), int(f[4])
+                        start, end = off, off + (length // lb) * lw + length % lb
+                        break
+            if start < 0:
+                at = 0 if mm[:1] == b">" else mm.find(b"\n>") + 1
+                while at > 0 or (at == 0 and mm[:1] == b">"):
+                    eol = mm.find(b"\n", at)
+                    eol = len(mm) if eol < 0 else eol
+                    nxt = mm.find(b"\n>", eol)
+                    if mm[at + 1:eol].split()[:1] == [want]:
+                        start, end = eol + 1, (len(mm) if nxt < 0 else nxt)
+                        break
+                    if nxt < 0:
+                        break
+                    at = nxt + 1
+            if start < 0:
+                raise ValueError(f"chromosome {chrom} not found in {path}")
+            raw = np.frombuffer(mm[start:end], dtype=np.uint8)
+        finally:
+            mm.close()
+    raw = raw[(raw != 10) & (raw != 13)]           # drop line ends
+    if not len(raw):
         raise ValueError(f"chromosome {chrom} not found in {path}")
-    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+    return np.where((raw >= 97) & (raw <= 122), raw - 32, raw).astype(np.uint8)
 
 
 class GraphIndex:
