@@ -211,8 +211,9 @@ void gfm_tsv_close(gfm_tsv_t t);
  * gfm_graph_plan: regions [S, E] as vg takes them (windows start at p in [S, E - W]); returns the
  *   number of windows and of rows (2 per walk: forward, reverse complement).  Synchronous.
  * gfm_graph_emit: rows of the last plan, window-major, walks in mixed-radix order with the LAST site
- *   of the window varying fastest (windows that touch a deletion: lexicographic order of the walk's
- *   decisions, reference allele / no jump first), forward row then '-' row:  d_kmers [rows][W],
+ *   of the window varying fastest (windows that touch a deletion: layout-major -- the vectors of
+ *   jumps over deletions in lexicographic order, "no jump" first, and on one such layout the mixed
+ *   radix of the SNPs it meets), forward row then '-' row:  d_kmers [rows][W],
  *   d_start / d_stop (forward: p, e; '-': e, p; e = reference coordinate after the last base, p + W
  *   unless the walk jumps a deletion), d_strand ('+'/'-'), d_freq, d_is_ref (vg's flag: 1 = every SNP
  *   allele is the reference's, also when a deletion is taken), d_region (index into the plan's
