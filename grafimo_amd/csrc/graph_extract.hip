@@ -87,12 +87,14 @@ struct NoVisitor {
     __device__ void passed(int) {}
 };
 
-// Follows st.choice[0 .. prefix) at the deletions met and does not jump at later ones.  `prod` returns
+// Follows st.choice[0 .. prefix) at the deletions met and does not jump at later ones.  A walk whose
+// last base lies at or beyond `limit` (the region's end) does not exist, like one that runs off the
+// chromosome: vg reports a walk only if both of its ends map into the region.  `prod` returns
 // the number of allele combinations of the layout.  When the visitor wants bases, walk `q` of the
 // layout is decoded on the way: rem starts as the layout's product and is divided at every SNP.
 template <class V>
 __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, int prefix, WalkState &st, V &vis,
-                               long long q, long long rem, long long &prod)
+                               long long q, long long rem, long long &prod, long long limit)
 {
     constexpr long long kNoSite = 0x7fffffffffffffffll;
     long long x = p;
@@ -113,11 +115,11 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, in
                 if (x + run > g.ref_len) { st.nd = d; return WALK_DEAD; }
                 n += (int)run;
                 x += run;
-                if (n == W) { st.nd = d; st.last = x - 1; return WALK_OK; }
+                if (n == W) { st.nd = d; st.last = x - 1; return x <= limit ? WALK_OK : WALK_DEAD; }
                 continue;
             } else {
                 vis.base(n, x, -1, 0);
-                if (++n == W) { st.nd = d; st.last = x; return WALK_OK; }
+                if (++n == W) { st.nd = d; st.last = x; return x + 1 <= limit ? WALK_OK : WALK_DEAD; }
                 ++x;
                 continue;
             }
@@ -137,7 +139,7 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, in
             }
         }
         vis.base(n, x, snp, a);
-        if (++n == W) { st.nd = d; st.last = x; return WALK_OK; }
+        if (++n == W) { st.nd = d; st.last = x; return x + 1 <= limit ? WALK_OK : WALK_DEAD; }
         if (del >= 0) {
             if (d >= kMaxDecisions) { st.nd = d; return WALK_OVERFLOW; }
             const int c = d < prefix ? st.choice[d] : 0;
@@ -233,7 +235,8 @@ __device__ inline uint8_t complement(uint8_t c)
 // thread per listed deletion window: number of walks by running the odometer
 __global__ void __launch_bounds__(kCountThreads)
 graph_count_del_kernel(GraphDev g, const int *__restrict__ del_list, const int *__restrict__ del_count,
-                       const long long *__restrict__ win_start, int W, const int *__restrict__ first_site,
+                       const long long *__restrict__ win_start, const int *__restrict__ win_region,
+                       const long long *__restrict__ region_stop, int W, const int *__restrict__ first_site,
                        long long *__restrict__ n_walks, long long *__restrict__ del_walks, int *__restrict__ overflow)
 {
     const int m = blockIdx.x * kCountThreads + threadIdx.x;
@@ -247,7 +250,7 @@ graph_count_del_kernel(GraphDev g, const int *__restrict__ del_list, const int *
     int prefix = 0;
     do {                                             // one pass per layout
         long long prod = 0;
-        const int rc = simulate(g, p, W, i0, prefix, st, nv, 0, 0, prod);
+        const int rc = simulate(g, p, W, i0, prefix, st, nv, 0, 0, prod, region_stop[win_region[w]]);
         if (rc == WALK_OK) walks += prod;
         if (rc == WALK_OVERFLOW || walks > kMaxWalksPerWindow) { walks = 0; atomicMax(overflow, 1); break; }
         prefix = next_walk(st);
@@ -464,7 +467,8 @@ struct DelEmit {
 __global__ void __launch_bounds__(kEmitThreads)
 graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ del_list,
                       const int *__restrict__ del_entry, const long long *__restrict__ del_base,
-                      const long long *__restrict__ win_start, int W, long long n_del_walks,
+                      const long long *__restrict__ win_start, const int *__restrict__ win_region,
+                      const long long *__restrict__ region_stop, int W, long long n_del_walks,
                       const int *__restrict__ first_site, const long long *__restrict__ walk_base,
                       uint8_t *__restrict__ kmers, long long *__restrict__ start, long long *__restrict__ stop,
                       long long *__restrict__ freq, uint8_t *__restrict__ is_ref)
@@ -477,13 +481,14 @@ graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const in
     const int i0 = first_site[w];
     const int q0 = (int)(td - del_base[m]);
     const long long t = walk_base[w] + q0;          // its place among all walks
+    const long long limit = region_stop[win_region[w]];
     WalkState st;
     long long q = q0, prod = 0;
     {
         NoVisitor nv;
         int prefix = 0;
         for (;;) {                                   // skip the layouts that lie before walk q0
-            const int rc = simulate(g, p, W, i0, prefix, st, nv, 0, 0, prod);
+            const int rc = simulate(g, p, W, i0, prefix, st, nv, 0, 0, prod, limit);
             if (rc == WALK_OK) {
                 if (q < prod) break;
                 q -= prod;
@@ -495,7 +500,7 @@ graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const in
     uint8_t *fwd = kmers + (size_t)(2 * t) * W;
     DelEmit em{g, fwd, fwd + W, W, 0, {}, {}, false};
     long long again = 0;
-    simulate(g, p, W, i0, st.nd, st, em, q, prod, again);
+    simulate(g, p, W, i0, st.nd, st, em, q, prod, again, limit);
     const int cover = cover_deletion(g, p, i0);  // the window starts on deleted bases: carriers lack them
     if (cover >= 0) em.add(cover, 5);
     long long count = 0;
@@ -588,7 +593,7 @@ struct gfm_graph {
     // last plan (buffers are kept between plans)
     int n_regions = 0, width = 0;
     long long n_windows = 0, n_walks = 0;
-    Buf<long long> region_off, first_start, walk_base, win_start, walks;
+    Buf<long long> region_off, first_start, region_stop, walk_base, win_start, walks;
     Buf<int> first_site, win_region, walk_window, flag;
     Buf<unsigned char> scan_tmp;
     Buf<int> del_list, del_entry;
@@ -596,7 +601,7 @@ struct gfm_graph {
     long long n_del_walks = 0;
     void drop_plan()
     {
-        region_off.release(); first_start.release(); walk_base.release(); win_start.release(); walks.release();
+        region_off.release(); first_start.release(); region_stop.release(); walk_base.release(); win_start.release(); walks.release();
         first_site.release(); win_region.release(); walk_window.release(); flag.release(); scan_tmp.release();
         del_list.release(); del_entry.release(); del_walks.release(); del_base.release();
         n_del_walks = 0;
@@ -701,11 +706,12 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     g->n_regions = n_regions;
     // windows of region r: starts p in [max(S,0), min(E, ref_len) - W]  (vg find -p S-E -K W, pinned by
     // expected_seqs.tsv: x:0-20, W=19 -> p in {0, 1})
-    std::vector<long long> off(n_regions + 1, 0), first(n_regions, 0);
+    std::vector<long long> off(n_regions + 1, 0), first(n_regions, 0), rstop(n_regions, 0);
     for (int r = 0; r < n_regions; ++r) {
         const long long s = std::max<long long>(h_starts[r], 0);
         const long long e = std::min<long long>(h_stops[r], g->dev.ref_len);
         first[r] = s;
+        rstop[r] = e;
         off[r + 1] = off[r] + std::max<long long>(0, e - width - s + 1);
     }
     if (n_windows) *n_windows = off[n_regions];
@@ -715,6 +721,7 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     const size_t nw = (size_t)off[n_regions];
     GX_TRY(g->region_off.reserve(off.size()));
     GX_TRY(g->first_start.reserve(first.size()));
+    GX_TRY(g->region_stop.reserve(rstop.size()));
     GX_TRY(g->first_site.reserve(nw));
     GX_TRY(g->walks.reserve(nw));
     GX_TRY(g->flag.reserve(2));          // [0] overflow flag, [1] number of windows that touch a deletion
@@ -727,6 +734,7 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     GX_TRY(g->del_base.reserve(dels ? nw + 1 : 1));
     GX_TRY(hipMemcpyAsync(g->region_off.p, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, nullptr));
     GX_TRY(hipMemcpyAsync(g->first_start.p, first.data(), sizeof(long long) * first.size(), hipMemcpyHostToDevice, nullptr));
+    GX_TRY(hipMemcpyAsync(g->region_stop.p, rstop.data(), sizeof(long long) * rstop.size(), hipMemcpyHostToDevice, nullptr));
     GX_TRY(hipMemsetAsync(g->flag.p, 0, 2 * sizeof(int), nullptr));
     if (dels) {
         GX_TRY(hipMemsetAsync(g->del_walks.p, 0, sizeof(long long) * nw, nullptr));
@@ -742,7 +750,8 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     GX_TRY(hipGetLastError());
     if (dels) {   // the grid covers every window; the kernel reads the real number of listed windows
         hipLaunchKernelGGL(graph_count_del_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->dev, g->del_list.p,
-                           g->flag.p + 1, g->win_start.p, width, g->first_site.p, g->walks.p, g->del_walks.p, g->flag.p);
+                           g->flag.p + 1, g->win_start.p, g->win_region.p, g->region_stop.p, width, g->first_site.p,
+                           g->walks.p, g->del_walks.p, g->flag.p);
         GX_TRY(hipGetLastError());
     }
     size_t tmp_bytes = 0;
@@ -797,7 +806,7 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
         const unsigned dblocks = (unsigned)((g->n_del_walks + kEmitThreads - 1) / kEmitThreads);
         hipLaunchKernelGGL(graph_emit_del_kernel, dim3(dblocks), dim3(kEmitThreads), 0, static_cast<hipStream_t>(stream),
                            g->dev, g->d_allele_count, g->del_list.p, g->del_entry.p, g->del_base.p, g->win_start.p,
-                           g->width, g->n_del_walks, g->first_site.p, g->walk_base.p, d_kmers,
+                           g->win_region.p, g->region_stop.p, g->width, g->n_del_walks, g->first_site.p, g->walk_base.p, d_kmers,
                            reinterpret_cast<long long *>(d_start), reinterpret_cast<long long *>(d_stop),
                            reinterpret_cast<long long *>(d_freq), d_is_ref);
     }

@@ -184,7 +184,7 @@ class GraphIndex:
             walk //= n
         return i0, alleles
 
-    def window_walks(self, p: int, width: int):
+    def window_walks(self, p: int, width: int, stop_limit: Optional[int] = None):
         """Yields, in the enumeration order of the extraction kernel, the walks of window p as
         [(reference position, SNP allele)] per base: mixed radix (last site fastest) for plain windows;
         for windows that touch a deletion layout-major: the jump vectors (at a deletion's anchor 0 = stay on
@@ -208,13 +208,15 @@ class GraphIndex:
             for i, x in enumerate(self.pos.tolist()):
                 self._site_at.setdefault(x, []).append(i)
         site_at = self._site_at
+        limit = len(self.ref) if stop_limit is None else min(int(stop_limit), len(self.ref))
 
         def layouts(x, used):
             if x >= len(self.ref):
                 return
             used = used + [x]
             if len(used) == width:
-                yield used
+                if x + 1 <= limit:                     # a walk ends inside the region, like it starts there
+                    yield used
                 return
             yield from layouts(x + 1, used)
             dele = next((i for i in site_at.get(x, ()) if self.del_len[i] > 0), None)
@@ -342,7 +344,7 @@ def write_region_tsvs(index: GraphIndex, rows: ExtractedKmers, out_dir: str) -> 
                 sg = chr(strand[i])
                 p = int(start[i]) if sg == "+" else int(stop[i])
                 if p != cur_p:                    # rows are window-major: enumerate a window's walks once
-                    cur_p, node_paths = p, [index.nodes_of(b) for b in index.window_walks(p, W)]
+                    cur_p, node_paths = p, [index.nodes_of(b) for b in index.window_walks(p, W, rows.regions[r][1])]
                 nodes = node_paths[int(walk[i])]
                 if sg == "-":
                     nodes = nodes[::-1]

@@ -23,8 +23,9 @@ quay.io/vgteam/vg:v1.27.1).  Pinning:
     incl. chopping at 32 bases and the cuts a deletion makes;
   * NOT pinned (no vg binary here): insertions and other non-SNP, non-deletion records (skipped and
     counted), overlapping deletions (the later one is skipped), multi-allelic sites' node order
-    beyond "alternates first", and whether vg drops a deletion-crossing walk whose stop lies beyond
-    the region end (here the start decides).
+    beyond "alternates first", and the fate of a deletion-crossing walk whose stop lies beyond the
+    region end (dropped here: a walk is reported only if both of its ends lie inside the region,
+    which is what limits the plain windows to start <= E - W in expected_seqs.tsv).
 """
 import gzip
 import itertools
@@ -62,7 +63,9 @@ class Sites:
         self.pos = np.asarray(pos, dtype=np.int64)
         self.ref = list(ref)
         self.alts = [list(a) for a in alts]
-        self.hap = np.asarray(hap, dtype=np.int8).reshape(len(self.pos), -1)
+        hap = np.asarray(hap, dtype=np.int8)
+        self.hap = hap.reshape(len(self.pos), -1) if hap.size else \
+            np.zeros((len(self.pos), hap.shape[-1] if hap.ndim > 1 else 0), np.int8)
         self.skipped = int(skipped)
 
     @property
@@ -328,7 +331,8 @@ def enumerate_region_graph(chrom: str, ref: bytes, sites: Sites, dels: Dels, S: 
             return
         nu = used + [x]
         if len(nu) == W:
-            yield nu, taken
+            if x + 1 <= min(E, len(ref)):          # both ends of a walk lie inside the region
+                yield nu, taken
             return
         yield from layouts(x + 1, nu, taken)
         j = del_at.get(x)

@@ -275,3 +275,28 @@ def test_scoring_fixture_rows_through_the_gpu(tmp_path):
     for c in ("score", "p-value", "q-value"):
         np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-9, atol=0)
     g.close()
+
+
+def test_jumping_walks_must_end_inside_the_region():
+    """A walk that jumps a deletion and would end past the region's end is not reported (both ends of a
+    walk lie inside the region); the same start still yields the walk that stays on the reference."""
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
+    from oracle import extract_oracle as xo
+    rng = np.random.default_rng(4)
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=60)
+    idx = GraphIndex("c", ref, [25], [1], np.zeros((1, 3), np.uint8), None, 0, del_len=[5])
+    sites = xo.Sites([], [], [], np.zeros((0, 0), np.int8))
+    dels = xo.Dels([25], [5], np.zeros((1, 0), bool))
+    g = DeviceGraph(idx)
+    for region in [(0, 32), (0, 60), (20, 34), (26, 45)]:
+        rows = g.extract([region], 10)
+        exp = xo.enumerate_region_graph("c", ref.tobytes(), sites, dels, region[0], region[1], 10)
+        km = rows.kmers.cpu().numpy()
+        got = [(km[i].tobytes().decode(), int(rows.start[i]), int(rows.stop[i])) for i in range(len(rows))]
+        assert got == [(r[1], int(r[2].split(":")[1][:-1]), int(r[3].split(":")[1][:-1])) for r in exp], region
+    # region (0, 32): start 18 reaches base 25 with two bases to go -- the jump would end at 33 > 32
+    rows = g.extract([(0, 32)], 10)
+    starts = rows.start.cpu().numpy()[0::2].tolist()
+    stops = rows.stop.cpu().numpy()[0::2].tolist()
+    assert starts.count(18) == 1 and max(stops) <= 32 and 15 in [b - a for a, b in zip(starts, stops)]
+    g.close()
