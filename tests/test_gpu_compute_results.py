@@ -237,3 +237,16 @@ def test_compute_results_many_equals_per_motif_calls(tmp_path):
     main(["-m", meme, "-k", os.path.join(GOLDEN, "synth", "bg_1.txt"), "-s", str(tmp_path), "-t", "1e-2",
           "-o", str(tmp_path / "out")])
     assert len([f for f in os.listdir(tmp_path / "out") if f.endswith(".tsv")]) == 6
+
+
+def test_two_ranks_on_one_gpu_through_the_scanner():
+    """The N = 2 path of KmerScanner on the real kernels: two processes share this GPU over gloo (RCCL
+    refuses a duplicate GPU): histogram all-reduce, hit gather, global row ids and the merge on rank 0
+    give what one process gives over all rows (scripts/two_rank_probe.py exits 1 otherwise)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "two_rank_probe.py")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("two ranks == one process: True") == 2
