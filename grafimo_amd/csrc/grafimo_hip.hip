@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -158,9 +159,21 @@ int launch_score_t(gfm_motif *timer, const uint8_t *d_kmers, long long n, int W,
                    const ScoreArgs<MM> &args, size_t lds, int nslabs, hipStream_t st, bool prepare_only)
 {
     auto kern = score_hist_kernel<NDW, MM>;
-    if (prepare_only) {  // once per width from gfm_motif_create (never inside a stream capture)
+    if (prepare_only) {  // from gfm_motif_create (never inside a stream capture); once per process and device
+        static std::atomic<unsigned long long> done{0ull};       // one bit per device for this instantiation
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return GFM_OK;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
+        // the kernel addresses its lookup tables by absolute LDS offset: its dynamic LDS must start at 0
+        hipFuncAttributes attr;
+        HIP_TRY(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kern)));
+        if (attr.sharedSizeBytes != 0)
+            return fail(GFM_ERR_HIP, "score kernel carries %zu bytes of static LDS (expected none)",
+                        (size_t)attr.sharedSizeBytes);
+        done.fetch_or(bit, std::memory_order_release);
         return GFM_OK;
     }
     const bool prof = timer && !timer->ev0.empty() && (timer->ev_calls++ % (unsigned)timer->ev_every) == 0;
@@ -410,9 +423,16 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     } while (0)
 
     HIP_TRY_M(hipGetDevice(&m->device));
-    hipDeviceProp_t prop;
-    HIP_TRY_M(hipGetDeviceProperties(&prop, m->device));
-    m->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {   // compute-unit count of the device, queried once per process (hipGetDeviceProperties is slow)
+        static std::atomic<int> cu_of[64];
+        int cu = cu_of[m->device & 63].load(std::memory_order_acquire);
+        if (cu == 0) {
+            HIP_TRY_M(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, m->device));
+            if (cu <= 0) cu = 256;
+            cu_of[m->device & 63].store(cu, std::memory_order_release);
+        }
+        m->n_cu = cu;
+    }
     if (const char *e = std::getenv("GRAFIMO_RESERVE_CUS")) m->reserve_cus = std::max(0, std::min(atoi(e), m->n_cu - 1));
 
     // LDS lookup tables: [2*ndw base pairs][8 x 8 codes] uint16, code = (ascii >> 1) & 7
