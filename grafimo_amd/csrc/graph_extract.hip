@@ -302,6 +302,56 @@ graph_map_kernel(long long n_windows, const long long *__restrict__ walk_base, i
     for (long long t = b; t < e; ++t) walk_window[t] = (int)w;
 }
 
+// Haplotypes that carry allele a_k at site s_k for every k < n (allele 0 = none of the alternates; a
+// deletion is a site with one alternate: 1 = carries it).  No constraint: all; one: the popcount table;
+// more: AND of the bitsets, eight words per trip so that their loads are in flight together (one word
+// per trip made every such walk a chain of ~hw dependent L2 latencies).
+template <class F>
+__device__ inline long long count_carriers(const GraphDev &g, const int *__restrict__ allele_count, int n, F at)
+{
+    if (!g.alt_bits) return 0;
+    if (n == 0) return g.n_hap;
+    if (n == 1) {
+        int site, a;
+        at(0, site, a);
+        return allele_count[(size_t)site * 4 + a];
+    }
+    constexpr int kWordsPerTrip = 8;
+    long long count = 0;
+    for (int w0 = 0; w0 < g.hw; w0 += kWordsPerTrip) {
+        unsigned long long acc[kWordsPerTrip];
+#pragma unroll
+        for (int j = 0; j < kWordsPerTrip; ++j) {
+            const int word = w0 + j;
+            acc[j] = word < g.hw ? ~0ull : 0ull;
+            if (word == g.hw - 1 && (g.n_hap & 63)) acc[j] = (1ull << (g.n_hap & 63)) - 1ull;
+        }
+        for (int k = 0; k < n; ++k) {
+            int site, a;
+            at(k, site, a);
+            const unsigned long long *b = g.alt_bits + ((size_t)site * kMaxAlts) * g.hw + w0;
+            const int na = g.n_alts[site];
+#pragma unroll
+            for (int j = 0; j < kWordsPerTrip; ++j) {
+                if (w0 + j >= g.hw) continue;
+                unsigned long long bits;
+                if (a > 0) {
+                    bits = b[(size_t)(a - 1) * g.hw + j];
+                } else {
+                    bits = b[j];
+                    if (na > 1) bits |= b[(size_t)g.hw + j];
+                    if (na > 2) bits |= b[(size_t)2 * g.hw + j];
+                    bits = ~bits;
+                }
+                acc[j] &= bits;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kWordsPerTrip; ++j) count += __popcll(acc[j]);
+    }
+    return count;
+}
+
 // Thread per walk.  Neighbouring threads are walks of one window or of overlapping windows: their
 // reference bytes, site records and bitset words are the same cache lines, and every per-row column
 // is written fully coalesced (rows 2t and 2t+1 of thread t).  The walk index is a mixed-radix number
@@ -364,47 +414,7 @@ graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *_
     }
 
     // haplotypes that carry every allele of the walk
-    if (g.alt_bits) {
-        if (ns == 0) {
-            count = g.n_hap;
-        } else if (ns == 1) {
-            count = allele_count[(size_t)i0 * 4 + allele(0)];
-        } else {
-            // words are independent: a few of them per trip, so that their loads are in flight together
-            // (one word per trip made every such walk a chain of ~hw dependent L2 latencies)
-            constexpr int kWordsPerTrip = 8;
-            for (int w0 = 0; w0 < g.hw; w0 += kWordsPerTrip) {
-                unsigned long long acc[kWordsPerTrip];
-#pragma unroll
-                for (int j = 0; j < kWordsPerTrip; ++j) {
-                    const int word = w0 + j;
-                    acc[j] = word < g.hw ? ~0ull : 0ull;
-                    if (word == g.hw - 1 && (g.n_hap & 63)) acc[j] = (1ull << (g.n_hap & 63)) - 1ull;
-                }
-                for (int k = 0; k < ns; ++k) {
-                    const unsigned long long *b = g.alt_bits + ((size_t)(i0 + k) * kMaxAlts) * g.hw + w0;
-                    const int a = allele(k);
-                    const int na = g.n_alts[i0 + k];
-#pragma unroll
-                    for (int j = 0; j < kWordsPerTrip; ++j) {
-                        if (w0 + j >= g.hw) continue;
-                        unsigned long long bits;
-                        if (a > 0) {
-                            bits = b[(size_t)(a - 1) * g.hw + j];
-                        } else {
-                            bits = b[j];
-                            if (na > 1) bits |= b[(size_t)g.hw + j];
-                            if (na > 2) bits |= b[(size_t)2 * g.hw + j];
-                            bits = ~bits;
-                        }
-                        acc[j] &= bits;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < kWordsPerTrip; ++j) count += __popcll(acc[j]);
-            }
-        }
-    }
+    count = count_carriers(g, allele_count, ns, [&](int k, int &site, int &a) { site = i0 + k; a = allele(k); });
     }   // plain window
     __syncthreads();
     {
@@ -438,7 +448,7 @@ struct DelEmit {
     int W;
     int n_cons;
     int csite[kMaxDecisions + 1];
-    unsigned char ccode[kMaxDecisions + 1];     // 0..3 SNP allele, 4 deletion taken, 5 deletion not carried
+    unsigned char ccode[kMaxDecisions + 1];     // allele: SNP 0..3; deletion 1 = jumped, 0 = its bases are used
     bool alt;
     static constexpr bool kWantsBases = true;
     __device__ void add(int site, int code)
@@ -455,8 +465,8 @@ struct DelEmit {
         fwd[j] = c;
         rev[W - 1 - j] = complement(c);
     }
-    __device__ void took(int site) { add(site, 4); }
-    __device__ void passed(int site) { add(site, 5); }
+    __device__ void took(int site) { add(site, 1); }
+    __device__ void passed(int site) { add(site, 0); }
 };
 
 
@@ -502,50 +512,9 @@ graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const in
     long long again = 0;
     simulate(g, p, W, i0, st.nd, st, em, q, prod, again, limit);
     const int cover = cover_deletion(g, p, i0);  // the window starts on deleted bases: carriers lack them
-    if (cover >= 0) em.add(cover, 5);
-    long long count = 0;
-    if (g.alt_bits) {
-        if (em.n_cons == 0) {
-            count = g.n_hap;
-        } else if (em.n_cons == 1) {
-            const int code = em.ccode[0];
-            count = allele_count[(size_t)em.csite[0] * 4 + (code == 4 ? 1 : code == 5 ? 0 : code)];
-        } else {
-            constexpr int kWordsPerTrip = 8;     // independent loads in flight, as in graph_emit_kernel
-            for (int w0 = 0; w0 < g.hw; w0 += kWordsPerTrip) {
-                unsigned long long acc[kWordsPerTrip];
-#pragma unroll
-                for (int j = 0; j < kWordsPerTrip; ++j) {
-                    const int word = w0 + j;
-                    acc[j] = word < g.hw ? ~0ull : 0ull;
-                    if (word == g.hw - 1 && (g.n_hap & 63)) acc[j] = (1ull << (g.n_hap & 63)) - 1ull;
-                }
-                for (int k = 0; k < em.n_cons; ++k) {
-                    const unsigned long long *b = g.alt_bits + ((size_t)em.csite[k] * kMaxAlts) * g.hw + w0;
-                    const int code = em.ccode[k];
-                    const int na = g.n_alts[em.csite[k]];
-#pragma unroll
-                    for (int j = 0; j < kWordsPerTrip; ++j) {
-                        if (w0 + j >= g.hw) continue;
-                        unsigned long long bits;
-                        if (code >= 1 && code <= 3) {
-                            bits = b[(size_t)(code - 1) * g.hw + j];
-                        } else if (code == 4) {
-                            bits = b[j];
-                        } else {                       // reference allele / deletion not carried
-                            bits = b[j];
-                            if (na > 1) bits |= b[(size_t)g.hw + j];
-                            if (na > 2) bits |= b[(size_t)2 * g.hw + j];
-                            bits = ~bits;
-                        }
-                        acc[j] &= bits;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < kWordsPerTrip; ++j) count += __popcll(acc[j]);
-            }
-        }
-    }
+    if (cover >= 0) em.add(cover, 0);
+    const long long count = count_carriers(g, allele_count, em.n_cons,
+                                           [&](int k, int &site, int &a) { site = em.csite[k]; a = em.ccode[k]; });
     const long long row = 2 * t, end_pos = st.last + 1;
     start[row] = p;          start[row + 1] = end_pos;
     stop[row] = end_pos;     stop[row + 1] = p;
