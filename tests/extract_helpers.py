@@ -4,6 +4,8 @@ import os
 
 import numpy as np
 
+REF_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_data")
+
 
 def make_graph_files(tmpdir, chrom="7", length=3000, n_sites=260, n_samples=65, seed=5, gz=True):
     """FASTA + VCF with: clustered and isolated SNPs, multi-allelic sites, a few indel / MNP records
@@ -55,3 +57,38 @@ def make_graph_files(tmpdir, chrom="7", length=3000, n_sites=260, n_samples=65, 
                     gts.append(f"{a[0]}|{a[1]}")
             fh.write(f"{chrom}\t{p + 1}\t.\t{refa}\t{alt}\t99\t.\t.\tGT\t" + "\t".join(gts) + "\n")
     return fasta, vcf
+
+
+def scoring_fixture_graph():
+    """The local graph behind the reference's scoring fixture (22:19723256-19723526), recovered from
+    the fixture itself: reference bases from the `ref` rows, five SNPs (alt base + carrier count from
+    the single-difference `non.ref` rows), one 2-bp deletion after 22:19723467 carried by one of the
+    5096 haplotypes.  Carrier sets are disjoint (the one window that holds two SNPs reports 0
+    haplotypes with both alternates).  Coordinates are shifted so that the region starts at 0."""
+    from oracle import extract_oracle as xo
+    with open(os.path.join(REF_DATA, "width_19", "scoring_test_input.tsv")) as fh:
+        rows = [tuple(line.rstrip("\n").split("\t")) for line in fh]
+    at = lambda s: int(s.split(":")[1][:-1])
+    S, E, H = 19723256, 19723526, 5096
+    refd, snps = {}, {}
+    for r in rows:
+        if r[2].endswith("+") and r[5] == "ref" and at(r[3]) - at(r[2]) == 19:
+            for j, c in enumerate(r[1]):
+                refd[at(r[2]) + j] = c
+    for r in rows:
+        if r[2].endswith("+") and r[5] == "non.ref" and at(r[3]) - at(r[2]) == 19:
+            diffs = [(at(r[2]) + j, c) for j, c in enumerate(r[1]) if refd[at(r[2]) + j] != c]
+            if len(diffs) == 1:
+                snps[diffs[0]] = int(r[4])
+    refseq = "".join(refd[x] for x in range(S, E)).encode()
+    order = sorted(snps)
+    hap = np.zeros((len(order), H), np.int8)
+    nxt = 0
+    for i, key in enumerate(order):
+        hap[i, nxt:nxt + snps[key]] = 1
+        nxt += snps[key]
+    dhap = np.zeros((1, H), bool)
+    dhap[0, nxt] = True
+    sites = xo.Sites([p - S for p, _ in order], [refd[p] for p, _ in order], [[a] for _, a in order], hap)
+    dels = xo.Dels([19723467 - S], [2], dhap)
+    return rows, refseq, sites, dels, S, E

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import REF_DATA
-from extract_helpers import make_graph_files
+from extract_helpers import make_graph_files, scoring_fixture_graph
 
 
 def test_oracle_reproduces_the_reference_golden_file():
@@ -121,41 +121,6 @@ def test_graph_abi_validates_before_touching_a_device():
         n_alts[1] = 1
         rc = lib.gfm_graph_create(nv.ptr(ref), 10, 2, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt), None, None, 0, ctypes.byref(h))
         assert rc == nv.GFM_ERR_NODEVICE and not h.value
-
-
-def scoring_fixture_graph():
-    """The local graph behind the reference's scoring fixture (22:19723256-19723526), recovered from
-    the fixture itself: reference bases from the `ref` rows, five SNPs (alt base + carrier count from
-    the single-difference `non.ref` rows), one 2-bp deletion after 22:19723467 carried by one of the
-    5096 haplotypes.  Carrier sets are disjoint (the one window that holds two SNPs reports 0
-    haplotypes with both alternates).  Coordinates are shifted so that the region starts at 0."""
-    from oracle import extract_oracle as xo
-    with open(os.path.join(REF_DATA, "width_19", "scoring_test_input.tsv")) as fh:
-        rows = [tuple(line.rstrip("\n").split("\t")) for line in fh]
-    at = lambda s: int(s.split(":")[1][:-1])
-    S, E, H = 19723256, 19723526, 5096
-    refd, snps = {}, {}
-    for r in rows:
-        if r[2].endswith("+") and r[5] == "ref" and at(r[3]) - at(r[2]) == 19:
-            for j, c in enumerate(r[1]):
-                refd[at(r[2]) + j] = c
-    for r in rows:
-        if r[2].endswith("+") and r[5] == "non.ref" and at(r[3]) - at(r[2]) == 19:
-            diffs = [(at(r[2]) + j, c) for j, c in enumerate(r[1]) if refd[at(r[2]) + j] != c]
-            if len(diffs) == 1:
-                snps[diffs[0]] = int(r[4])
-    refseq = "".join(refd[x] for x in range(S, E)).encode()
-    order = sorted(snps)
-    hap = np.zeros((len(order), H), np.int8)
-    nxt = 0
-    for i, key in enumerate(order):
-        hap[i, nxt:nxt + snps[key]] = 1
-        nxt += snps[key]
-    dhap = np.zeros((1, H), bool)
-    dhap[0, nxt] = True
-    sites = xo.Sites([p - S for p, _ in order], [refd[p] for p, _ in order], [[a] for _, a in order], hap)
-    dels = xo.Dels([19723467 - S], [2], dhap)
-    return rows, refseq, sites, dels, S, E
 
 
 def test_oracle_reproduces_vg_rows_of_the_scoring_fixture():

@@ -9,7 +9,7 @@ import pandas as pd
 import pytest
 
 from conftest import REF_DATA
-from extract_helpers import make_graph_files
+from extract_helpers import make_graph_files, scoring_fixture_graph
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -219,7 +219,6 @@ def test_scoring_fixture_rows_through_the_gpu(tmp_path):
     """The 704 rows of real vg output behind the reference's test_scoring, regenerated by the extraction
     kernel from the fixture's local graph (5 SNPs, one deletion, 5096 haplotypes), then scored: the same
     table the reference's expected scoring_results.tsv holds."""
-    from test_extract_host import scoring_fixture_graph
     from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, compute_results_from_graph, write_region_tsvs
     from grafimo_amd.motif_ops import build_motif_meme_host
     from grafimo_amd.workflow import Findmotif
