@@ -48,6 +48,7 @@ struct gfm_motif {
     std::vector<int64_t> sm;
     double bg[4] = {0, 0, 0, 0};
     std::vector<double> h_ptable;
+    unsigned char *d_slab = nullptr;   // one allocation behind every device pointer below
     uint16_t *d_tab = nullptr;
     double *d_pmf = nullptr;
     double *d_ptable = nullptr;
@@ -120,27 +121,37 @@ int validate_matrix(const int64_t *sm, int W)
 }
 
 // runs the DP for one motif on the current device; d_pmf receives L doubles
-int run_dp(const int64_t *sm, int W, const double *bg, double *d_pmf, hipStream_t st)
+// device scratch of one DP run: [4W + W + W ints | pad to 8 | 4 + 2L doubles]
+size_t dp_scratch_bytes(int W)
+{
+    const size_t L = (size_t)kRange * W + 1;
+    return ((sizeof(int) * 6 * (size_t)W + 7) & ~(size_t)7) + sizeof(double) * (4 + 2 * L);
+}
+
+// runs the DP for one motif on the current device; d_pmf receives L doubles.  `scratch`
+// (dp_scratch_bytes, 8-byte aligned) saves the temporaries' allocations; nullptr = allocate here.
+int run_dp(const int64_t *sm, int W, const double *bg, double *d_pmf, hipStream_t st, void *scratch = nullptr)
 {
     const int L = kRange * W + 1;
-    std::vector<int> lo, hi, sm32(4 * W);
+    std::vector<int> lo, hi, ints(6 * (size_t)W);
     cumulative_windows(sm, W, lo, hi);
-    for (int i = 0; i < 4 * W; ++i) sm32[i] = (int)sm[i];
-    DevBuf<int> d_sm, d_lo, d_hi;
-    DevBuf<double> d_bg, d_buf;
-    HIP_TRY(d_sm.alloc(4 * (size_t)W));
-    HIP_TRY(d_lo.alloc(W));
-    HIP_TRY(d_hi.alloc(W));
-    HIP_TRY(d_bg.alloc(4));
-    HIP_TRY(d_buf.alloc(2 * (size_t)L));
-    HIP_TRY(hipMemcpyAsync(d_sm, sm32.data(), sizeof(int) * 4 * W, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_lo, lo.data(), sizeof(int) * W, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_hi, hi.data(), sizeof(int) * W, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_bg, bg, sizeof(double) * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(pvalue_dp_kernel, dim3(1), dim3(kDpThreads), 0, st, d_sm.p, d_bg.p, W, L, d_lo.p,
-                       d_hi.p, d_buf.p, d_pmf);
+    for (int i = 0; i < 4 * W; ++i) ints[(size_t)i] = (int)sm[i];
+    std::copy(lo.begin(), lo.end(), ints.begin() + 4 * W);
+    std::copy(hi.begin(), hi.end(), ints.begin() + 5 * W);
+    DevBuf<unsigned char> own;
+    if (!scratch) {
+        HIP_TRY(own.alloc(dp_scratch_bytes(W)));
+        scratch = own.p;
+    }
+    int *d_int = static_cast<int *>(scratch);
+    double *d_dbl = reinterpret_cast<double *>(static_cast<unsigned char *>(scratch) +
+                                               ((sizeof(int) * 6 * (size_t)W + 7) & ~(size_t)7));
+    HIP_TRY(hipMemcpyAsync(d_int, ints.data(), sizeof(int) * ints.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_dbl, bg, sizeof(double) * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pvalue_dp_kernel, dim3(1), dim3(kDpThreads), 0, st, d_int, d_dbl, W, L, d_int + 4 * W,
+                       d_int + 5 * W, d_dbl + 4, d_pmf);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));   // the temporaries are freed on return
+    HIP_TRY(hipStreamSynchronize(st));   // the host vectors and the temporaries go away on return
     return GFM_OK;
 }
 
@@ -363,23 +374,11 @@ GFM_API int gfm_comp_pval_mat(const int64_t *sm, int W, const double *bg, double
 GFM_API void gfm_motif_destroy(gfm_motif_t m)
 {
     if (!m) return;
-    if (m->d_tab) (void)hipFree(m->d_tab);
-    if (m->d_pmf) (void)hipFree(m->d_pmf);
-    if (m->d_ptable) (void)hipFree(m->d_ptable);
+    if (m->d_slab) (void)hipFree(m->d_slab);
     for (int i = 0; i < 2; ++i) {
-        if (m->d_partials[i]) (void)hipFree(m->d_partials[i]);
-        if (m->d_spill[i]) (void)hipFree(m->d_spill[i]);
-        if (m->d_resid[i]) (void)hipFree(m->d_resid[i]);
-        if (m->d_resid_n[i]) (void)hipFree(m->d_resid_n[i]);
         if (m->ev_scored[i]) (void)hipEventDestroy(m->ev_scored[i]);
         if (m->ev_posted[i]) (void)hipEventDestroy(m->ev_posted[i]);
     }
-    if (m->d_ctl) (void)hipFree(m->d_ctl);
-    if (m->d_qwork) (void)hipFree(m->d_qwork);
-    if (m->d_qscratch) (void)hipFree(m->d_qscratch);
-    if (m->d_sel_resid) (void)hipFree(m->d_sel_resid);
-    if (m->d_sel_resid_n) (void)hipFree(m->d_sel_resid_n);
-    if (m->d_sel_ctl) (void)hipFree(m->d_sel_ctl);
     for (auto e : m->ev0) (void)hipEventDestroy(e);
     for (auto e : m->ev1) (void)hipEventDestroy(e);
     delete m;
@@ -453,15 +452,67 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
                 const unsigned v = base_score(2 * pr, c0, &bad) + base_score(2 * pr + 1, c1, &bad);
                 tab[(size_t)pr * 64 + c0 + 8 * c1] = (uint16_t)(bad ? kPoison : v);
             }
-    HIP_TRY_M(hipMalloc(&m->d_tab, tab.size() * sizeof(uint16_t)));
-    HIP_TRY_M(hipMemcpy(m->d_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    // score-kernel LDS plan: table | wave strips | histogram window (+1 N bin).  The window SIZE follows
+    // from the width alone; where it sits needs the tail table (below).
+    const int zero_nb = 0;
+    const size_t fixed = score_lds_bytes(W, m->ndw, 1, &zero_nb);
+    const long long room = ((long long)kMaxLdsBytes - (long long)fixed) / (long long)sizeof(unsigned) - 1;
+    if (room < 256) return bail(fail(GFM_ERR_INVALID, "no LDS left for a histogram window at width %d", W));
+    m->hnb = (int)std::min<long long>(m->nb, room);
+    m->lds_bytes = fixed + sizeof(unsigned) * (size_t)(m->hnb + 1);
+    int per_cu = (int)std::min<size_t>(kWGsPerCU, (size_t)kMaxLdsBytes / m->lds_bytes);
+    per_cu = std::max(per_cu, 1);
+    m->max_slabs = m->n_cu * per_cu;
+    m->sel_slabs = 4 * m->n_cu;
 
-    HIP_TRY_M(hipMalloc(&m->d_pmf, sizeof(double) * (size_t)m->L));
-    HIP_TRY_M(hipMalloc(&m->d_ptable, sizeof(double) * (size_t)m->L));
+    // ONE device allocation for the motif (a motif set creates hundreds of these; ~20 hipMalloc /
+    // hipFree pairs per motif were most of the creation time)
+    size_t slab_bytes = 0;
+    auto carve = [&](size_t bytes) { const size_t at = slab_bytes; slab_bytes += (bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_tab = carve(tab.size() * sizeof(uint16_t));
+    const size_t o_pmf = carve(sizeof(double) * (size_t)m->L);
+    const size_t o_ptable = carve(sizeof(double) * (size_t)m->L);
+    const size_t o_dp = carve(dp_scratch_bytes(W));
+    const size_t o_qwork = carve(sizeof(QWork));
+    const size_t o_qscratch = carve(sizeof(double) * (size_t)m->L);
+    size_t o_partials[2], o_resid[2], o_resid_n[2], o_spill[2];
+    for (int i = 0; i < 2; ++i) {
+        o_partials[i] = carve(sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->hnb + 1));
+        o_resid[i] = carve(sizeof(long long) * (size_t)m->max_slabs * kResidPerWG);
+        o_resid_n[i] = carve(sizeof(int) * (size_t)m->max_slabs);
+    }
+    const size_t o_sel_resid = carve(sizeof(long long) * (size_t)m->sel_slabs * kResidPerWG);
+    const size_t o_sel_resid_n = carve(sizeof(int) * (size_t)m->sel_slabs);
+    const size_t o_zero = slab_bytes;                 // what follows starts out zeroed
+    o_spill[0] = carve(sizeof(unsigned) * (size_t)m->nb);
+    o_spill[1] = carve(sizeof(unsigned) * (size_t)m->nb);
+    const size_t o_ctl = carve(sizeof(HitCtl));
+    const size_t o_sel_ctl = carve(sizeof(HitCtl));
+    HIP_TRY_M(hipMalloc(&m->d_slab, slab_bytes));
+    HIP_TRY_M(hipMemsetAsync(m->d_slab + o_zero, 0, slab_bytes - o_zero, nullptr));
+    m->d_tab = reinterpret_cast<uint16_t *>(m->d_slab + o_tab);
+    m->d_pmf = reinterpret_cast<double *>(m->d_slab + o_pmf);
+    m->d_ptable = reinterpret_cast<double *>(m->d_slab + o_ptable);
+    m->d_qwork = reinterpret_cast<QWork *>(m->d_slab + o_qwork);
+    m->d_qscratch = reinterpret_cast<double *>(m->d_slab + o_qscratch);
+    for (int i = 0; i < 2; ++i) {
+        m->d_partials[i] = reinterpret_cast<unsigned *>(m->d_slab + o_partials[i]);
+        m->d_resid[i] = reinterpret_cast<long long *>(m->d_slab + o_resid[i]);
+        m->d_resid_n[i] = reinterpret_cast<int *>(m->d_slab + o_resid_n[i]);
+        m->d_spill[i] = reinterpret_cast<unsigned *>(m->d_slab + o_spill[i]);
+        HIP_TRY_M(hipEventCreateWithFlags(&m->ev_scored[i], hipEventDisableTiming | hipEventReleaseToDevice));
+        HIP_TRY_M(hipEventCreateWithFlags(&m->ev_posted[i], hipEventDisableTiming | hipEventReleaseToDevice));
+    }
+    m->d_sel_resid = reinterpret_cast<long long *>(m->d_slab + o_sel_resid);
+    m->d_sel_resid_n = reinterpret_cast<int *>(m->d_slab + o_sel_resid_n);
+    m->d_ctl = reinterpret_cast<HitCtl *>(m->d_slab + o_ctl);
+    m->d_sel_ctl = reinterpret_cast<HitCtl *>(m->d_slab + o_sel_ctl);
+
+    HIP_TRY_M(hipMemcpyAsync(m->d_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice, nullptr));
     if (h_pmf) {
-        HIP_TRY_M(hipMemcpy(m->d_pmf, h_pmf, sizeof(double) * (size_t)m->L, hipMemcpyHostToDevice));
+        HIP_TRY_M(hipMemcpyAsync(m->d_pmf, h_pmf, sizeof(double) * (size_t)m->L, hipMemcpyHostToDevice, nullptr));
     } else {
-        rc = run_dp(sm, W, bg, m->d_pmf, nullptr);
+        rc = run_dp(sm, W, bg, m->d_pmf, nullptr, m->d_slab + o_dp);
         if (rc) return bail(rc);
     }
     hipLaunchKernelGGL(ptable_kernel, dim3(1), dim3(kScanThreads), 0, nullptr, m->d_pmf, m->L,
@@ -469,37 +520,8 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     HIP_TRY_M(hipGetLastError());
     m->h_ptable.resize(m->L);
     HIP_TRY_M(hipMemcpy(m->h_ptable.data(), m->d_ptable, sizeof(double) * (size_t)m->L,
-                        hipMemcpyDeviceToHost));
-
-    // score-kernel LDS plan: table | 8 wave strips | histogram window (+1 N bin)
-    const int zero_nb = 0;
-    const size_t fixed = score_lds_bytes(W, m->ndw, 1, &zero_nb);
-    const long long room = ((long long)kMaxLdsBytes - (long long)fixed) / (long long)sizeof(unsigned) - 1;
-    if (room < 256) return bail(fail(GFM_ERR_INVALID, "no LDS left for a histogram window at width %d", W));
-    m->hnb = (int)std::min<long long>(m->nb, room);
+                        hipMemcpyDeviceToHost));       // also completes the async copies of `tab` / h_pmf
     m->hlo = best_window(m, m->hnb).lo;   // partial when the range does not fit: the rest spills
-    m->lds_bytes = fixed + sizeof(unsigned) * (size_t)(m->hnb + 1);
-    int per_cu = (int)std::min<size_t>(kWGsPerCU, (size_t)kMaxLdsBytes / m->lds_bytes);
-    per_cu = std::max(per_cu, 1);
-    m->max_slabs = m->n_cu * per_cu;
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY_M(hipMalloc(&m->d_partials[i], sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->hnb + 1)));
-        HIP_TRY_M(hipMalloc(&m->d_spill[i], sizeof(unsigned) * (size_t)m->nb));
-        HIP_TRY_M(hipMemset(m->d_spill[i], 0, sizeof(unsigned) * (size_t)m->nb));
-        HIP_TRY_M(hipMalloc(&m->d_resid[i], sizeof(long long) * (size_t)m->max_slabs * kResidPerWG));
-        HIP_TRY_M(hipMalloc(&m->d_resid_n[i], sizeof(int) * (size_t)m->max_slabs));
-        HIP_TRY_M(hipEventCreateWithFlags(&m->ev_scored[i], hipEventDisableTiming | hipEventReleaseToDevice));
-        HIP_TRY_M(hipEventCreateWithFlags(&m->ev_posted[i], hipEventDisableTiming | hipEventReleaseToDevice));
-    }
-    HIP_TRY_M(hipMalloc(&m->d_ctl, sizeof(HitCtl)));
-    HIP_TRY_M(hipMemset(m->d_ctl, 0, sizeof(HitCtl)));
-    HIP_TRY_M(hipMalloc(&m->d_qwork, sizeof(QWork)));
-    HIP_TRY_M(hipMalloc(&m->d_qscratch, sizeof(double) * (size_t)m->L));
-    m->sel_slabs = 4 * m->n_cu;
-    HIP_TRY_M(hipMalloc(&m->d_sel_resid, sizeof(long long) * (size_t)m->sel_slabs * kResidPerWG));
-    HIP_TRY_M(hipMalloc(&m->d_sel_resid_n, sizeof(int) * (size_t)m->sel_slabs));
-    HIP_TRY_M(hipMalloc(&m->d_sel_ctl, sizeof(HitCtl)));
-    HIP_TRY_M(hipMemset(m->d_sel_ctl, 0, sizeof(HitCtl)));
 #undef HIP_TRY_M
     {   // allow up to the whole LDS for every instantiation this width can use
         ScoreArgs<1> a1{};
