@@ -90,8 +90,10 @@ def read_vcf_snps(path: str, chrom: Optional[str] = None) -> Sites:
             gts = []
             for s in f[9:]:
                 gt = s.split(":")[0].replace("/", "|").split("|")
-                gts += [int(x) if x.isdigit() else 0 for x in (gt + gt)[:2]] if len(gt) == 1 else \
-                       [int(x) if x.isdigit() else 0 for x in gt[:2]]
+                if len(gt) == 1:
+                    gt = gt * 2
+                # an allele number beyond the ALT list (malformed record) counts as the reference allele
+                gts += [int(x) if x.isdigit() and int(x) <= len(a) else 0 for x in gt[:2]]
             pos.append(int(f[1]) - 1)
             ref.append(r)
             alts.append(a)
@@ -228,7 +230,7 @@ def read_vcf_graph(path: str, chrom: Optional[str] = None):
                 gt = s.split(":")[0].replace("/", "|").split("|")
                 if len(gt) == 1:
                     gt = gt * 2
-                gts += [int(x) if x.isdigit() else 0 for x in gt[:2]]
+                gts += [int(x) if x.isdigit() and int(x) <= len(a) else 0 for x in gt[:2]]
             p = int(f[1]) - 1
             if len(r) == 1 and len(a) <= 3 and all(len(x) == 1 and x in "ACGT" for x in a):
                 if pos and p == pos[-1]:

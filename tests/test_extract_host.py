@@ -173,3 +173,67 @@ def test_native_vcf_reader_threads_and_errors(tmp_path):
                    "7\t30\t.\tA\tC\t.\t.\t.\tGT\t0|1\n7\t10\t.\tA\tC\t.\t.\t.\tGT\t0|1\n")
     with pytest.raises(nv.NativeError):
         GraphIndex.from_fasta_vcf(fasta, str(bad), "7")
+
+
+def test_native_vcf_reader_property(tmp_path):
+    """Random VCF text (multi-allelic and lower-case alleles, deletions that overlap, insertions, MNPs,
+    duplicate positions, '0/1', '.', '1', 'GT:DP' cells, CRLF, other chromosomes) through the library's
+    reader and through the oracle's: same sites, deletions, skip count and carrier sets."""
+    from hypothesis import given, settings, strategies as st
+    from grafimo_amd.extract_regions import GraphIndex
+    from oracle import extract_oracle as xo
+    fasta = tmp_path / "r.fa"
+    fasta.write_text(">c\n" + "ACGT" * 50 + "\n")
+    base = st.sampled_from("ACGTacgt")
+    alt_snp = st.lists(base, min_size=1, max_size=4).map(",".join)
+    cell = st.sampled_from(["0|0", "0|1", "1|0", "1|1", "2|1", "0/1", "1/2", ".|.", ".", "1", "0", "1|0:35", "3|0", "./1"])
+
+    @st.composite
+    def record(draw):
+        kind = draw(st.sampled_from(["snp", "snp", "del", "ins", "mnp", "sym"]))
+        r = draw(base)
+        if kind == "snp":
+            ref, alt = r, draw(alt_snp)
+        elif kind == "del":
+            ref, alt = r + "".join(draw(st.lists(base, min_size=1, max_size=6))), r
+            if draw(st.booleans()):
+                alt = alt.swapcase()
+        elif kind == "ins":
+            ref, alt = r, r + "GA"
+        elif kind == "mnp":
+            ref, alt = r + "C", "GT"
+        else:
+            ref, alt = r, "<DEL>"
+        return draw(st.integers(0, 6)), ref, alt
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(record(), min_size=0, max_size=25), st.integers(1, 70), st.booleans(), st.data())
+    def check(recs, n_samples, crlf, data):
+        pos, lines = 1, ["##fileformat=VCFv4.1", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" +
+                         "\t".join(f"s{i}" for i in range(n_samples))]
+        for gap, ref, alt in recs:
+            pos += gap
+            cells = [data.draw(cell) for _ in range(n_samples)]
+            lines.append(f"c\t{pos}\t.\t{ref}\t{alt}\t.\t.\t.\tGT\t" + "\t".join(cells))
+            if gap == 3:
+                lines.append(f"other\t{pos}\t.\tA\tC\t.\t.\t.\tGT\t" + "\t".join(cells))
+        vcf = tmp_path / "v.vcf"
+        vcf.write_text(("\r\n" if crlf else "\n").join(lines) + ("\r\n" if crlf else "\n"))
+        idx = GraphIndex.from_fasta_vcf(str(fasta), str(vcf), "c", threads=3)
+        sites, dels, skipped = xo.read_vcf_graph(str(vcf), "c")
+        snp, dele = idx.del_len == 0, idx.del_len > 0
+        assert idx.skipped == skipped
+        assert idx.pos[snp].tolist() == sites.pos.tolist() and idx.pos[dele].tolist() == dels.anchor.tolist()
+        assert idx.del_len[dele].tolist() == dels.length.tolist()
+        assert [list(map(chr, b[:n])) for b, n in zip(idx.alt_bases[snp], idx.n_alts[snp])] == sites.alts
+        if len(idx.pos):
+            H = 2 * n_samples
+            assert idx.n_haplotypes == H
+            for a in range(3):
+                bits = np.unpackbits(idx.alt_bits[:, a, :].view(np.uint8), axis=1, bitorder="little")[:, :H].astype(bool)
+                # (an allele number beyond the record's ALT list counts as the reference allele in both readers)
+                assert np.array_equal(bits[snp], sites.hap == a + 1), a
+            bits = np.unpackbits(idx.alt_bits[:, 0, :].view(np.uint8), axis=1, bitorder="little")[:, :H].astype(bool)
+            assert np.array_equal(bits[dele], dels.hap)
+
+    check()
