@@ -69,12 +69,16 @@ class KmerScanner:
         # calls on a single-GPU box)
         self.collective = self.world > 1 or (always_collective and torch.distributed.is_initialized())
         self._gather_ok = True
-        # A second process group (its own RCCL communicator and stream) for the hit gather lets
-        # gather(k) run beside all-reduce(k+1): collectives of ONE group execute in issue order.
+        # The hit gather is issued from its own stream: the tail stream then goes on with the post kernel
+        # and q-table of the next batch instead of idling through the gather.  Collectives of ONE group
+        # still execute in issue order (gather(k) before all-reduce(k+1), the same on every rank), so
+        # the communication chain per batch is all-reduce + gather while the tail chain is post +
+        # all-reduce + q-table.  A second process group (`gather_group`: its own RCCL communicator) would
+        # also let gather(k) run beside all-reduce(k+1).
         self.gather_group = gather_group if gather_group is not None else group
         self._gather_stream = None
         self.tail_done = None
-        if gather_group is not None and side_stream:
+        if self.collective and side_stream:
             self._gather_stream = torch.cuda.Stream(device=self.device, priority=-1)
         cap = int(hit_capacity) if hit_capacity is not None else int(n_rows)
         self.slots = [ScanSlot(dm, n_rows, cap, self.device) for _ in range(n_slots)]
