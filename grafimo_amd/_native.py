@@ -71,6 +71,13 @@ PROTOTYPES = {
     "gfm_tsv_names_bytes": (c_i64, [c_void_p]),
     "gfm_tsv_names": (c_int, [c_void_p, c_void_p, c_void_p]),
     "gfm_tsv_close": (None, [c_void_p]),
+    "gfm_scan_tsv": (c_int, [c_void_p, P(ctypes.c_char_p), c_int, c_int, c_int, c_double, c_int, c_int, c_i64,
+                             P(c_void_p), P(c_i64), P(c_i64)]),
+    "gfm_scan_hits": (c_int, [c_void_p] * 13),
+    "gfm_scan_stats": (c_int, [c_void_p, c_void_p]),
+    "gfm_scan_table": (c_void_p, [c_void_p]),
+    "gfm_scan_close": (None, [c_void_p]),
+    "gfm_scan_release_buffers": (None, []),
     "gfm_graph_create": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
                                  P(c_void_p)]),
     "gfm_graph_destroy": (None, [c_void_p]),
@@ -81,6 +88,13 @@ PROTOTYPES = {
     "gfm_vcf_read": (c_int, [c_void_p] * 6),
     "gfm_vcf_close": (None, [c_void_p]),
 }
+
+
+class ScanStats(ctypes.Structure):
+    """gfm_scan_stats_t"""
+    _fields_ = [("n_rows", c_i64), ("n_hits", c_i64), ("n_chunks", c_i64), ("h2d_bytes", c_i64),
+                ("total_s", c_double), ("parse_s", c_double), ("h2d_s", c_double), ("tail_s", c_double),
+                ("parse_threads", c_i32), ("reserved", c_i32)]
 
 
 class NativeError(RuntimeError):
@@ -137,7 +151,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if L.gfm_abi_version() != 4:
+        if L.gfm_abi_version() != 5:
             raise ImportError("libgrafimo_hip.so ABI version mismatch")
         _lib = L
     return _lib

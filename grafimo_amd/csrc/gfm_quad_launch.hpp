@@ -1,0 +1,43 @@
+// gfm_quad_launch.hpp -- geometry of score_quad_kernel<W> and the launchers of its four translation units
+// Part of libgrafimo_hip.so (included by grafimo_hip.hip and score_quad_tu.hip).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include "gfm_score_kernels.hpp"
+
+namespace {
+
+constexpr int kQuadRows = 256;   // k-mers per wave per step: 64 lanes x 4 rows
+#ifndef GFM_QUAD_DEPTH
+#define GFM_QUAD_DEPTH 1
+#endif
+#ifndef GFM_LAB_STORE
+#define GFM_LAB_STORE 0
+#endif
+#ifndef GFM_LAB_LEVEL   // development builds only (scripts/lab_build.sh): 1..3 strip work out of the kernel for timing
+#define GFM_LAB_LEVEL 0
+#endif
+constexpr int kQuadDepth = GFM_QUAD_DEPTH;    // chunks in flight per wave beside the one being scored
+
+__host__ __device__ constexpr int quad_pad(int W) { return (W % 8 == 0) ? 16 : 0; }
+__host__ __device__ constexpr int quad_pitch(int W) { return 4 * W + quad_pad(W); }       // bytes per lane
+__host__ __device__ constexpr int quad_stage_bytes(int W) { return 64 * quad_pitch(W) + 16; }
+__host__ __device__ constexpr int quad_strip_stride(int W) { return quad_stage_bytes(W) + kHitQueue * 8; }
+__host__ __device__ constexpr int quad_tab_bytes(int W) { return 2 * ((W + 3) / 4) * 64 * 2; }
+
+
+}  // namespace
+
+// One per translation unit of score_quad_tu.hip (-DGFM_QUAD_GROUP=g holds widths 16g+1 .. 16g+16).
+// `motif_args` points at a MotifArgs; `prepare` != 0: set the kernel's LDS attribute instead of launching;
+// ev0 / ev1 (hipEvent_t or NULL) bracket the launch.  Errors go to gfm_last_error().
+#define GFM_QUAD_LAUNCH_DECL(g)                                                                                        \
+    extern "C" __attribute__((visibility("hidden"))) int gfm_quad_launch_g##g(                                        \
+        int W, const uint8_t *d_kmers, long long n, long long row_base, const void *motif_args, size_t lds, int nslabs, \
+        int waves, void *stream, int prepare, void *ev0, void *ev1);
+GFM_QUAD_LAUNCH_DECL(0)
+GFM_QUAD_LAUNCH_DECL(1)
+GFM_QUAD_LAUNCH_DECL(2)
+GFM_QUAD_LAUNCH_DECL(3)

@@ -386,6 +386,9 @@ post_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, i
             unsigned long long *__restrict__ hit_count)
 {
     const int tid = threadIdx.x;
+    // A call that selects nothing has no hit-slab block to re-zero the mid-run counter two calls ahead
+    // (below); without this a flush of call k would still be counted by call k+3.
+    if (blockIdx.x == 0 && tid == 0 && hit_slabs == 0 && ctl) ctl->mid[(par + 2) % 3] = 0ull;
     if ((int)blockIdx.x < hist_blocks) {
         const int bx = blockIdx.x % bin_blocks, by = blockIdx.x / bin_blocks;
         const int b = bx * 256 + tid;

@@ -1,0 +1,309 @@
+// gfm_score_quad.hpp -- score_quad_kernel<W>: the single-motif score kernel (the dominant, HBM-bound one)
+// Part of libgrafimo_hip.so (one translation unit: included by grafimo_hip.hip only).
+// Reference lines cited as file:line are relative to /root/reference/src/grafimo/.
+#pragma once
+
+#include "gfm_score_kernels.hpp"
+#include "gfm_quad_launch.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// score_quad_kernel<W>: compute_score_seq (score_sequences.py:331-396) for a dense batch, one motif.
+//
+// Same data path as score_hist_kernel (coalesced 16 B/lane non-temporal loads into registers ahead of
+// use, a wave-private LDS strip, pair-table lookups, LDS histogram window, queued hits) with a
+// different work split: a wave takes 256 k-mers per step and every lane scores FOUR consecutive
+// rows.  Four rows are 4*W bytes = W dwords, so lane r's rows start dword aligned at r*W dwords:
+//   * the row-wise re-read of the strip is W aligned dwords per lane, 4.75 per k-mer at W = 19
+//     instead of 6, and free of bank conflicts: the lanes of a read are W dwords apart, W odd ->
+//     32 distinct banks (W = 2 mod 4: ds_read_b64 on 64 banks; W = 4 mod 8: ds_read_b128; W = 0
+//     mod 8: ds_read_b128 with 16 bytes of padding per lane).  The row-per-lane form at a 19-byte
+//     pitch costs 8.1 LDS cycles per ds_read2_b32 against 4.4 here (scripts/micro/lds_cost.hip);
+//   * the shifts that re-align rows 1..3 are compile-time constants (W is a template parameter),
+//     row 0 needs none;
+//   * the four scores of a lane leave as ONE 16-byte store: a wave writes 1 KiB contiguous.
+// LDS of a workgroup: pair tables | per wave: strip of 64 x (4W + pad) bytes, hit queue | histogram
+// window.  8 or 16 waves per workgroup (blockDim.x), chosen by the host so that the window fits.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x2_t lds_cu32x2;
+typedef __attribute__((address_space(3))) const u32x4_t lds_cu32x4;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int W>
+__global__ void __launch_bounds__(kThreads)
+score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_base, const MotifArgs ma)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NDW = (W + 3) / 4;
+    constexpr int kTabBytes = quad_tab_bytes(W);
+    constexpr int CB = kQuadRows * W;                 // bytes of a chunk (a multiple of 256)
+    constexpr int kLoads = (CB + 1023) / 1024;        // 16 B loads per lane per chunk (== NDW)
+    constexpr int GP = quad_pitch(W);
+    constexpr int PAD = quad_pad(W);
+    constexpr int SSTRIDE = quad_strip_stride(W);
+
+    if (lds_offset(smem) != 0u) __builtin_trap();     // the lookups below use absolute LDS offsets
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_waves = (int)(blockDim.x >> 6);
+    const int wg_threads = (int)blockDim.x;
+    unsigned char *tab = smem;
+    unsigned char *stage_base = smem + kTabBytes;
+    unsigned *hist = reinterpret_cast<unsigned *>(stage_base + n_waves * SSTRIDE);
+
+    for (int i = tid; i < kTabBytes / 2; i += wg_threads) reinterpret_cast<uint16_t *>(tab)[i] = ma.tab[i];
+    if (ma.use_hist)
+        for (int i = tid; i <= ma.nb; i += wg_threads) hist[i] = 0u;
+    __syncthreads();
+
+    unsigned char *stage = stage_base + wave * SSTRIDE;
+    const unsigned stage_off = (unsigned)(kTabBytes + wave * SSTRIDE);   // its absolute LDS offset
+    // The loop below takes whole chunks only -- every byte in range, every row live: no bounds logic in
+    // the hot code (the ragged-end handling of an earlier version, unrolled per load, was most of the loop's
+    // instruction bytes).  The < 256 rows behind the last whole chunk go through score_tail_rows.
+    const long long nfull = n / kQuadRows;
+    const long long cstride = (long long)gridDim.x * n_waves;
+    const bool vec_store = (reinterpret_cast<uintptr_t>(ma.scores) & 15u) == 0;   // uniform
+
+    uint4 pre[kQuadDepth][kLoads];
+    auto fetch = [&](uint4 (&dst)[kLoads], long long c) {
+        const uint8_t *src = kmers + c * (long long)CB + lane * 16;
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+            if (i * 1024 + 1024 <= CB || i * 1024 + lane * 16 < CB) {   // the last piece may cover fewer lanes
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifdef GFM_LAB_L2ONLY   // timing-only build: every chunk re-reads the first 2 MiB (on-chip time without HBM)
+                const u32x4 t = *reinterpret_cast<const u32x4 *>(kmers + ((c * (long long)CB + lane * 16 + i * 1024) & 0x1FFFF0ll));
+#else
+                // once-read stream: non-temporal policy (plain loads: 5.1 TB/s, nt: 6.2 TB/s on the same
+                // byte mix, scripts/micro/stream_bw_nt.hip)
+                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + i * 1024));
+#endif
+                dst[i] = make_uint4(t.x, t.y, t.z, t.w);
+            }
+        }
+    };
+
+    long long *hitq = reinterpret_cast<long long *>(stage + quad_stage_bytes(W));
+    int qn = 0;   // wave-uniform
+    const bool select = ma.cutoff != GFM_NO_SELECT;
+    if (select && blockIdx.x == 0 && tid == 0) ma.ctl->snap[ma.slot] = ma.hit_count ? *ma.hit_count : 0ull;
+
+    // Histogram and hit selection of a scored chunk ("booking").  It is done one step late, at the top of the
+    // next step and in front of the wait for that step's k-mers: the LDS atomics and the queue code then run
+    // while the loads are still in flight instead of lengthening the part of the step that follows them.
+    int p_score[4] = {0, 0, 0, 0};
+    long long p_crow = -1;      // chunk whose scores are waiting to be booked (-1: none)
+    auto book = [&]() {
+        const int k0 = 4 * lane;
+        if (ma.use_hist) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned off = (unsigned)(p_score[j] - ma.lo);
+                if (off < (unsigned)ma.nb)
+                    atomicAdd(&hist[off], 1u);
+                else if (p_score[j] == ma.min_val)   // a row holding N scores min_val, below every reachable sum
+                    atomicAdd(&hist[ma.nb], 1u);     // unless W == 1, where lo == min_val and the window has it
+                else
+                    atomicAdd(&ma.spill[p_score[j] - ma.spill_lo], 1u);   // outside the window: rare
+            }
+        }
+        if (select) {
+            const int best = max(max(p_score[0], p_score[1]), max(p_score[2], p_score[3]));
+            if (__builtin_amdgcn_ballot_w64(best >= ma.cutoff)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    hitq_push(hitq, qn, p_score[j] >= ma.cutoff,
+                              ((row_base + p_crow + k0 + j) << GFM_HIT_SCORE_BITS) | (long long)p_score[j], lane,
+                              ma.hit_count, &ma.ctl->mid[ma.slot], ma.hit_rows, ma.hit_cap);
+            }
+        }
+    };
+
+    long long c = (long long)blockIdx.x * n_waves + wave;
+#pragma unroll
+    for (int d = 0; d < kQuadDepth; ++d)
+        if (c + d * cstride < nfull) fetch(pre[d], c + d * cstride);
+#ifdef GFM_LAB_DUMMY_STORE
+    // One store behind the first loads, like the score store behind every later chunk's loads: the wait at the
+    // top of the loop can then leave ONE younger vector-memory operation outstanding on every path into it
+    // (in-order counter) instead of draining the score store of the chunk before.
+    __builtin_nontemporal_store(0, ma.resid_n + blockIdx.x);
+#endif
+    while (c < nfull) {
+#pragma unroll
+        for (int d = 0; d < kQuadDepth; ++d) {
+            if (c >= nfull) break;
+            const long long crow = c * kQuadRows;   // first row of the chunk
+            if (p_crow >= 0) book();
+#pragma unroll
+            for (int i = 0; i < kLoads; ++i) {
+                const int off = i * 1024 + lane * 16;
+                if (i * 1024 + 1024 <= CB || off < CB) {
+                    // W % 8 == 0: 16 bytes of padding after every lane's 4*W bytes (a piece never
+                    // straddles two lanes' data then: 4*W is a multiple of 16)
+                    const int dst = PAD ? off + PAD * (off / (4 * W)) : off;
+#if GFM_LAB_LEVEL >= 3   // timing-only build: no strip writes
+                    asm volatile("" :: "v"(pre[d][i].x), "v"(pre[d][i].y), "v"(pre[d][i].z), "v"(pre[d][i].w), "v"(dst));
+#else
+                    *reinterpret_cast<uint4 *>(stage + dst) = pre[d][i];
+#endif
+                }
+            }
+            // the next chunk's loads go out before this chunk is scored.  ONE chunk ahead: with two or
+            // three ahead the kernel took 7 us longer (96 vs 89 us at 2e7 rows) -- a wave that finds the
+            // memory pipeline backed up stalls at the load ISSUE, in front of its own compute
+            if (c + kQuadDepth * cstride < nfull) fetch(pre[d], c + kQuadDepth * cstride);
+            // LDS ops of one wave execute in program order; the fence only pins the compiler.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            // the lane's four rows: W dwords (+ a zero behind them for the funnel shift of the last dword)
+            unsigned w[W + 1];
+#if GFM_LAB_LEVEL >= 2   // timing-only build: no row reads (the bytes come from the prefetch registers of the NEXT chunk)
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                const uint4 &pv = pre[d][(t / 4) % kLoads];
+                w[t] = (t & 3) == 0 ? pv.x : (t & 3) == 1 ? pv.y : (t & 3) == 2 ? pv.z : pv.w;
+            }
+            w[W] = 0u;
+#else
+            {
+                const unsigned base = stage_off + (unsigned)(lane * GP);
+                if constexpr (W % 2 == 1) {
+#pragma unroll
+                    for (int t = 0; t < W; ++t) w[t] = ((lds_cu32 *)(uintptr_t)base)[t];
+                } else if constexpr (W % 4 == 2) {
+#pragma unroll
+                    for (int t = 0; t < W / 2; ++t) {
+                        const u32x2_t v = ((lds_cu32x2 *)(uintptr_t)base)[t];
+                        w[2 * t] = v.x;
+                        w[2 * t + 1] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < W / 4; ++t) {
+                        const u32x4_t v = ((lds_cu32x4 *)(uintptr_t)base)[t];
+                        w[4 * t] = v.x;
+                        w[4 * t + 1] = v.y;
+                        w[4 * t + 2] = v.z;
+                        w[4 * t + 3] = v.w;
+                    }
+                }
+                w[W] = 0u;
+            }
+#endif
+            int score[4];
+            bool is_n[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = (j * W) & 3;     // byte phase of row j inside its first dword: a constant
+                int s1 = 0;
+#pragma unroll
+                for (int t = 0; t < NDW; ++t) {
+                    const int q = (j * W + 4 * t) >> 2;
+                    const unsigned x = r ? __builtin_amdgcn_alignbit(w[q + 1], w[q], (unsigned)(8 * r)) : w[q];
+                    // bits 1..3 of each 16-bit half from x (first base of a pair), the other bits from
+                    // x >> 5 (bits 4..6: second base); then one mask per table offset
+                    unsigned y;
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(0x000E000Eu), "v"(x), "v"(x >> 5));
+                    const unsigned e0 = y & 0x7Eu;
+                    const unsigned e1 = (y >> 16) & 0x7Eu;
+#if GFM_LAB_LEVEL >= 1   // timing-only build: no table lookups
+                    s1 += (int)((e0 ^ e1) & 2u);
+#else
+                    s1 += *(lds_cu16 *)(uintptr_t)(e0 + (unsigned)((2 * t) * 128));
+                    s1 += *(lds_cu16 *)(uintptr_t)(e1 + (unsigned)((2 * t + 1) * 128));
+#endif
+                }
+                is_n[j] = (unsigned)s1 >= kPoison;    // a base that is not A,C,G,T: min_val (:376-378)
+                score[j] = is_n[j] ? ma.min_val : s1;
+            }
+            const int k0 = 4 * lane;
+            if (vec_store) {   // one 16-byte store per lane: the wave writes 1 KiB contiguous
+                const i32x4 out = {score[0], score[1], score[2], score[3]};
+#if GFM_LAB_STORE == 2
+                if (out.x == 0x7ffffff1) *reinterpret_cast<i32x4 *>(ma.scores + crow + k0) = out;
+#elif defined(GFM_LAB_L2ONLY)
+                *reinterpret_cast<i32x4 *>(ma.scores + ((crow + k0) & 0x7FFFCll)) = out;
+#else
+                __builtin_nontemporal_store(out, reinterpret_cast<i32x4 *>(ma.scores + crow + k0));
+#endif
+            } else {           // a score buffer that is only 4-byte aligned
+#pragma unroll
+                for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(score[j], ma.scores + crow + k0 + j);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p_score[j] = score[j];
+            p_crow = crow;
+            // the strip is rewritten next iteration: keep this iteration's reads ahead of it
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            c += cstride;
+        }
+    }
+    if (p_crow >= 0) book();
+    // The rows the chunked loop leaves over (fewer than kQuadRows, at the end of the batch): one row per
+    // lane, bytes straight from global memory.  Cold and small (rolled loops): once per launch, one wave.
+    if (blockIdx.x == gridDim.x - 1 && wave == n_waves - 1 && nfull * kQuadRows < n) {
+        const long long first = nfull * kQuadRows;
+        const int count = (int)(n - first);
+        const uint16_t *tab16 = reinterpret_cast<const uint16_t *>(tab);
+#pragma unroll 1
+        for (int r0 = 0; r0 < count; r0 += kWave) {
+            const int k = r0 + lane;
+            const bool live = k < count;
+            const uint8_t *row = kmers + (first + (live ? k : 0)) * (long long)W;
+            unsigned s1 = 0;
+#pragma unroll 1
+            for (int p = 0; p < 2 * NDW; ++p) {
+                const unsigned b0 = 2 * p < W ? row[2 * p] : (unsigned)'A';        // positions >= W: any valid code
+                const unsigned b1 = 2 * p + 1 < W ? row[2 * p + 1] : (unsigned)'A';
+                s1 += tab16[p * 64 + ((b0 >> 1) & 7u) + 8u * ((b1 >> 1) & 7u)];
+            }
+            const bool bad = s1 >= kPoison;
+            const int sc = bad ? ma.min_val : (int)s1;
+            if (live) {
+                ma.scores[first + k] = sc;
+                if (ma.use_hist) {
+                    const unsigned off = (unsigned)(sc - ma.lo);
+                    if (bad || off < (unsigned)ma.nb)
+                        atomicAdd(&hist[bad ? (unsigned)ma.nb : off], 1u);
+                    else
+                        atomicAdd(&ma.spill[sc - ma.spill_lo], 1u);
+                }
+            }
+            if (select)
+                hitq_push(hitq, qn, live && sc >= ma.cutoff,
+                          ((row_base + first + k) << GFM_HIT_SCORE_BITS) | (long long)sc, lane, ma.hit_count,
+                          &ma.ctl->mid[ma.slot], ma.hit_rows, ma.hit_cap);
+        }
+    }
+
+    // the lookup tables are dead once every wave has left the loop: their LDS holds the per-wave
+    // queue lengths (no static LDS)
+    __syncthreads();
+    if (select) {
+        int *wq_n = reinterpret_cast<int *>(tab);
+        if (lane == 0) wq_n[wave] = qn;
+        __syncthreads();
+        int base = 0, tot = 0;
+        for (int w2 = 0; w2 < n_waves; ++w2) {
+            const int v = wq_n[w2];
+            if (w2 < wave) base += v;
+            tot += v;
+        }
+        long long *slab = ma.resid + (size_t)blockIdx.x * kResidPerWG;
+        for (int i = lane; i < qn; i += kWave) slab[base + i] = hitq[i];
+        if (tid == 0) ma.resid_n[blockIdx.x] = tot;
+    }
+    if (ma.use_hist) {
+        unsigned *slab = ma.partials + (size_t)blockIdx.x * (size_t)(ma.nb + 1);
+        for (int i = tid; i <= ma.nb; i += wg_threads) slab[i] = hist[i];
+    }
+}
+
+}  // namespace

@@ -28,6 +28,7 @@
 
 #include "gfm_common.hpp"
 #include "gfm_score_kernels.hpp"
+#include "gfm_quad_launch.hpp"
 #include "gfm_stats_kernels.hpp"
 
 // =======================================================================================
@@ -37,6 +38,8 @@ struct gfm_motif {
     double offset = 0.0;
     int lo = 0, hi = 0, nb = 0;      // reachable score range [lo, hi], nb bins
     int hlo = 0, hnb = 0;            // LDS histogram window of a single-motif launch (== lo, nb when it fits)
+    int q_waves = kWavesPerWG;       // waves per workgroup of the single-motif launch (16, or 8 when the window needs the room)
+    int part_nb = 0;                 // bins per histogram slab the workspace was sized for
     struct Window { int bins, lo; double mass; };
     std::vector<Window> windows;     // cache of best_window() per window size
     int device = 0;
@@ -209,12 +212,38 @@ int dispatch_score(int ndw, gfm_motif *timer, const uint8_t *d_kmers, long long 
     case N:                                                                                       \
         return launch_score_t<N, MM>(timer, d_kmers, n, W, row_base, args, lds, nslabs, st, prepare_only);
     switch (ndw) {
+#ifdef GFM_ONLY_W
+        GFM_CASE((GFM_ONLY_W + 3) / 4)
+#else
         GFM_CASE(1) GFM_CASE(2) GFM_CASE(3) GFM_CASE(4) GFM_CASE(5) GFM_CASE(6) GFM_CASE(7) GFM_CASE(8)
         GFM_CASE(9) GFM_CASE(10) GFM_CASE(11) GFM_CASE(12) GFM_CASE(13) GFM_CASE(14) GFM_CASE(15) GFM_CASE(16)
+#endif
         default: return fail(GFM_ERR_INVALID, "unsupported width %d", W);
     }
 #undef GFM_CASE
 }
+
+// score_quad_kernel<W> is instantiated in score_quad_tu.hip, four translation units of sixteen widths each
+// (compiled side by side: one unit with all 64 took four minutes).
+int dispatch_quad(int W, gfm_motif *timer, const uint8_t *d_kmers, long long n, long long row_base,
+                  const MotifArgs &args, size_t lds, int nslabs, int waves, hipStream_t st, bool prepare_only)
+{
+    if (W < 1 || W > GFM_MAX_WIDTH) return fail(GFM_ERR_INVALID, "unsupported width %d", W);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (!prepare_only && timer && !timer->ev0.empty() && (timer->ev_calls++ % (unsigned)timer->ev_every) == 0) {
+        e0 = timer->ev0[timer->ev_next];
+        e1 = timer->ev1[timer->ev_next];
+        timer->ev_next = (timer->ev_next + 1) % (int)timer->ev0.size();
+        timer->ev_used = std::min(timer->ev_used + 1, (int)timer->ev0.size());
+    }
+    typedef int (*launch_fn)(int, const uint8_t *, long long, long long, const void *, size_t, int, int, void *, int,
+                             void *, void *);
+    static const launch_fn groups[4] = {gfm_quad_launch_g0, gfm_quad_launch_g1, gfm_quad_launch_g2, gfm_quad_launch_g3};
+    return groups[(W - 1) / 16](W, d_kmers, n, row_base, &args, lds, nslabs, waves, st, prepare_only ? 1 : 0, e0, e1);
+}
+
+// LDS bytes of a single-motif launch before the histogram window: pair tables | strips + hit queues
+size_t quad_fixed_lds(int W, int waves) { return (size_t)quad_tab_bytes(W) + (size_t)waves * (size_t)quad_strip_stride(W); }
 
 // The `bins` consecutive scores that hold the most background probability
 // (P(s >= a) - P(s >= a + bins) from the tail table): where a partial LDS histogram window goes.
@@ -243,7 +272,10 @@ int launch_post(gfm_motif *m, const unsigned *partials, int hist_slabs, unsigned
     const int hist_blocks = d_hist ? bin_blocks * groups : 0;
     const int spill_blocks = (d_hist && spill && win_nb < m->nb) ? (m->nb + 255) / 256 : 0;
     const int total = hist_blocks + spill_blocks + hit_slabs;
-    if (total == 0) return GFM_OK;
+    if (total == 0) {   // nothing to post, but the rotating hit counter is still handed on zeroed (see post_kernel)
+        if (ctl) HIP_TRY(hipMemsetAsync(&ctl->mid[(ctl_slot + 2) % 3], 0, sizeof(unsigned long long), st));
+        return GFM_OK;
+    }
     hipLaunchKernelGGL(post_kernel, dim3(total), dim3(256), 0, st, partials, hist_slabs, win_nb, win_lo,
                        m->min_val, d_hist, bin_blocks, hist_blocks, spill, m->lo, m->nb, spill_blocks,
                        resid, resid_n, hit_slabs, ctl, ctl_slot, d_hit_rows, cap, d_hit_count);
@@ -392,6 +424,13 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     int rc = validate_matrix(sm, W);
     if (rc) return rc;
     if (scale <= 0) return fail(GFM_ERR_INVALID, "scale must be a positive integer");
+    {   // min_val indexes the histogram and the tables on the device: it must be the matrix minimum
+        // (Motif.min_val, motif_ops.py:1106), the score of a k-mer holding N (score_sequences.py:376-378)
+        int64_t mn = sm[0];
+        for (int i = 1; i < 4 * W; ++i) mn = std::min(mn, sm[i]);
+        if ((int64_t)min_val != mn)
+            return fail(GFM_ERR_INVALID, "min_val %d is not the minimum of the score matrix (%lld)", min_val, (long long)mn);
+    }
     for (int n = 0; n < 4; ++n)
         if (!(bg[n] > 0)) return fail(GFM_ERR_ASSERT, "assert bg > 0");
     rc = ensure_device();
@@ -452,17 +491,19 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
                 const unsigned v = base_score(2 * pr, c0, &bad) + base_score(2 * pr + 1, c1, &bad);
                 tab[(size_t)pr * 64 + c0 + 8 * c1] = (uint16_t)(bad ? kPoison : v);
             }
-    // score-kernel LDS plan: table | wave strips | histogram window (+1 N bin).  The window SIZE follows
-    // from the width alone; where it sits needs the tail table (below).
+    // score-kernel LDS plan: pair tables | wave strips + hit queues | histogram window (+1 N bin).  With 16 waves
+    // the strips leave room16 bins; a reachable range that does not fit gets the whole LDS of an 8-wave
+    // workgroup (half the strips) unless a 16-wave window still covers practically all of the background
+    // mass (decided below, once the tail table exists).
+    const long long room16 = ((long long)kMaxLdsBytes - (long long)quad_fixed_lds(W, kWavesPerWG)) / (long long)sizeof(unsigned) - 1;
+    const long long room8 = ((long long)kMaxLdsBytes - (long long)quad_fixed_lds(W, kWavesPerWG / 2)) / (long long)sizeof(unsigned) - 1;
+    if (room8 < 256) return bail(fail(GFM_ERR_INVALID, "no LDS left for a histogram window at width %d", W));
+    // the batched launch (score_hist_kernel<NDW, MM>) lays its LDS out differently; its windows never exceed this
     const int zero_nb = 0;
-    const size_t fixed = score_lds_bytes(W, m->ndw, 1, &zero_nb);
-    const long long room = ((long long)kMaxLdsBytes - (long long)fixed) / (long long)sizeof(unsigned) - 1;
-    if (room < 256) return bail(fail(GFM_ERR_INVALID, "no LDS left for a histogram window at width %d", W));
-    m->hnb = (int)std::min<long long>(m->nb, room);
-    m->lds_bytes = fixed + sizeof(unsigned) * (size_t)(m->hnb + 1);
-    int per_cu = (int)std::min<size_t>(kWGsPerCU, (size_t)kMaxLdsBytes / m->lds_bytes);
-    per_cu = std::max(per_cu, 1);
-    m->max_slabs = m->n_cu * per_cu;
+    const long long room_batched = ((long long)kMaxLdsBytes - (long long)score_lds_bytes(W, m->ndw, 1, &zero_nb)) /
+                                       (long long)sizeof(unsigned) - 1;
+    m->part_nb = (int)std::min<long long>(m->nb, std::max(std::max(room16, room8), room_batched));
+    m->max_slabs = m->n_cu * kWGsPerCU;
     m->sel_slabs = 4 * m->n_cu;
 
     // ONE device allocation for the motif (a motif set creates hundreds of these; ~20 hipMalloc /
@@ -477,7 +518,7 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     const size_t o_qscratch = carve(sizeof(double) * (size_t)m->L);
     size_t o_partials[2], o_resid[2], o_resid_n[2], o_spill[2];
     for (int i = 0; i < 2; ++i) {
-        o_partials[i] = carve(sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->hnb + 1));
+        o_partials[i] = carve(sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->part_nb + 1));
         o_resid[i] = carve(sizeof(long long) * (size_t)m->max_slabs * kResidPerWG);
         o_resid_n[i] = carve(sizeof(int) * (size_t)m->max_slabs);
     }
@@ -521,13 +562,34 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     m->h_ptable.resize(m->L);
     HIP_TRY_M(hipMemcpy(m->h_ptable.data(), m->d_ptable, sizeof(double) * (size_t)m->L,
                         hipMemcpyDeviceToHost));       // also completes the async copies of `tab` / h_pmf
-    m->hlo = best_window(m, m->hnb).lo;   // partial when the range does not fit: the rest spills
+    {   // waves per workgroup and histogram window of the single-motif launch
+        constexpr double kWindowMass16 = 0.9999;   // a partial window beside 16 waves must hold this much
+        m->q_waves = kWavesPerWG;
+        if (m->nb <= room16) {
+            m->hnb = m->nb;
+        } else if (room16 >= 256 && best_window(m, (int)room16).mass >= kWindowMass16) {
+            m->hnb = (int)room16;
+        } else {
+            m->q_waves = kWavesPerWG / 2;
+            m->hnb = (int)std::min<long long>(m->nb, room8);
+        }
+        if (const char *e = std::getenv("GRAFIMO_SCORE_WAVES")) {   // measurement aid: force 8 or 16 waves
+            const int wv = atoi(e);
+            if (wv == 8 || (wv == 16 && room16 >= 256)) {
+                m->q_waves = wv;
+                m->hnb = (int)std::min<long long>(m->nb, wv == 8 ? room8 : room16);
+            }
+        }
+        m->hlo = best_window(m, m->hnb).lo;   // partial when the range does not fit: the rest spills
+        m->lds_bytes = quad_fixed_lds(W, m->q_waves) + sizeof(unsigned) * (size_t)(m->hnb + 1);
+    }
 #undef HIP_TRY_M
     {   // allow up to the whole LDS for every instantiation this width can use
         ScoreArgs<1> a1{};
         ScoreArgs<2> a2{};
         ScoreArgs<3> a3{};
         rc = dispatch_score<1>(m->ndw, nullptr, nullptr, 0, W, 0, a1, 0, 1, nullptr, true);
+        if (!rc) rc = dispatch_quad(W, nullptr, nullptr, 0, 0, a1.m[0], 0, 1, m->q_waves, nullptr, true);
         if (!rc) rc = dispatch_score<2>(m->ndw, nullptr, nullptr, 0, W, 0, a2, 0, 1, nullptr, true);
         if (!rc) rc = dispatch_score<3>(m->ndw, nullptr, nullptr, 0, W, 0, a3, 0, 1, nullptr, true);
         if (rc) return bail(rc);
@@ -602,16 +664,24 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         return GFM_OK;
     }
     if (!d_kmers || !d_scores) return fail(GFM_ERR_INVALID, "NULL device buffer");
+    {
+        int dev = -1;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev != m->device)
+            return fail(GFM_ERR_INVALID, "the motif lives on device %d, the current device is %d", m->device, dev);
+    }
     if ((reinterpret_cast<uintptr_t>(d_kmers) & 15u) != 0)
         return fail(GFM_ERR_INVALID, "d_kmers must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(d_scores) & 3u) != 0)
+        return fail(GFM_ERR_INVALID, "d_scores must be 4-byte aligned");
     if (n > (int64_t)kChunk * 0x7fffff00ll)
         return fail(GFM_ERR_INVALID, "too many rows for one launch (split the batch)");
     const bool select = select_cutoff != GFM_NO_SELECT;
     if (select && (!d_hit_rows || !d_hit_count))
         return fail(GFM_ERR_INVALID, "selection requested without hit buffers");
     const int use_hist = d_hist ? 1 : 0;
-    const long long nchunks = (n + kChunk - 1) / kChunk;
-    const long long want = (nchunks + waves_for_ndw(m->ndw) - 1) / waves_for_ndw(m->ndw);
+    const long long nchunks = (n + kQuadRows - 1) / kQuadRows;
+    const long long want = (nchunks + m->q_waves - 1) / m->q_waves;
     // with a tail stream a few CUs are left free so that its kernels (post, q-table, RCCL) find
     // room without evicting a persistent score workgroup (which would delay the whole grid)
     const int avail = split ? std::max(1, m->max_slabs - m->reserve_cus * (m->max_slabs / m->n_cu)) : m->max_slabs;
@@ -630,7 +700,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     fill_motif_args(args.m[0], m, ws, slot, use_hist, m->hlo, m->hnb, select_cutoff, d_scores,
                     reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                     reset ? nullptr : reinterpret_cast<unsigned long long *>(d_hit_count));
-    int rc = dispatch_score<1>(m->ndw, m, d_kmers, n, m->W, row_base, args, m->lds_bytes, nslabs, st, false);
+    int rc = dispatch_quad(m->W, m, d_kmers, n, row_base, args.m[0], m->lds_bytes, nslabs, m->q_waves, st, false);
     if (rc) return rc;
     if (split) {
         HIP_TRY(hipEventRecord(m->ev_scored[ws], st));

@@ -568,6 +568,11 @@ struct gfm_graph {
     Buf<int> del_list, del_entry;
     Buf<long long> del_walks, del_base;
     long long n_del_walks = 0;
+    // plan runs on the NULL stream, emit on the caller's: ordered through these events (a non-blocking
+    // caller stream is not ordered against the NULL stream by itself), both ways -- emit waits for the
+    // plan's last kernels, the next plan waits for the emit that still reads the plan buffers
+    hipEvent_t ev_planned = nullptr, ev_emitted = nullptr;
+    bool emit_pending = false;
     void drop_plan()
     {
         region_off.release(); first_start.release(); region_stop.release(); walk_base.release(); win_start.release(); walks.release();
@@ -637,6 +642,12 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     g->dev = GraphDev{g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
                       bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0,
                       g->d_del_len, n_dels, g->d_prev_del};
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_planned, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_emitted, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        gfm_graph_destroy(g);
+        return gfail(GFM_ERR_HIP, std::string("event creation failed: ") + hipGetErrorString(e));
+    }
     if (bits) {
         e = hipMalloc(&g->d_allele_count, sizeof(int) * 4 * (size_t)n_sites);
         if (e == hipSuccess) {
@@ -661,6 +672,8 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     (void)hipFree(g->d_ref); (void)hipFree(g->d_pos); (void)hipFree(g->d_n_alts);
     (void)hipFree(g->d_alt_bases); (void)hipFree(g->d_alt_bits); (void)hipFree(g->d_allele_count);
     (void)hipFree(g->d_del_len); (void)hipFree(g->d_prev_del);
+    if (g->ev_planned) (void)hipEventDestroy(g->ev_planned);
+    if (g->ev_emitted) (void)hipEventDestroy(g->ev_emitted);
     delete g;
 }
 
@@ -670,6 +683,10 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     if (!g || n_regions < 0 || (n_regions && (!h_starts || !h_stops)))
         return gfail(GFM_ERR_INVALID, "bad argument");
     if (width < 1 || width > GFM_MAX_WIDTH) return gfail(GFM_ERR_INVALID, "width outside [1, 64]");
+    if (g->emit_pending) {   // the last emit may still read the plan buffers this call rewrites / frees
+        GX_TRY(hipEventSynchronize(g->ev_emitted));
+        g->emit_pending = false;
+    }
     g->n_windows = g->n_walks = 0;
     g->width = width;
     g->n_regions = n_regions;
@@ -750,6 +767,7 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
                            g->del_base.p, g->del_entry.p);
         GX_TRY(hipGetLastError());
     }
+    GX_TRY(hipEventRecord(g->ev_planned, nullptr));   // behind the map kernels
     g->n_windows = (long long)nw;
     g->n_walks = total;
     g->n_del_walks = total_del;
@@ -766,6 +784,7 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
     if (!d_kmers || !d_start || !d_stop || !d_strand || !d_freq || !d_is_ref || !d_region || !d_walk)
         return gfail(GFM_ERR_INVALID, "NULL output buffer");
     const unsigned blocks = (unsigned)((g->n_walks + kEmitThreads - 1) / kEmitThreads);
+    GX_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), g->ev_planned, 0));
     hipLaunchKernelGGL(graph_emit_kernel, dim3(blocks), dim3(kEmitThreads), (size_t)2 * kEmitThreads * g->width,
                        static_cast<hipStream_t>(stream), g->dev, g->d_allele_count, g->walk_window.p,
                        g->win_region.p, g->win_start.p, g->width, g->n_walks, g->first_site.p, g->walk_base.p, d_kmers, reinterpret_cast<long long *>(d_start),
@@ -780,5 +799,7 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
                            reinterpret_cast<long long *>(d_freq), d_is_ref);
     }
     GX_TRY(hipGetLastError());
+    GX_TRY(hipEventRecord(g->ev_emitted, static_cast<hipStream_t>(stream)));
+    g->emit_pending = true;
     return GFM_OK;
 }

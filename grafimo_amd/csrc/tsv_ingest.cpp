@@ -23,12 +23,11 @@
 #include <unordered_map>
 #include <vector>
 
-#include "grafimo_hip.h"
+#include "gfm_tsv_internal.hpp"
 
 #define GFM_API extern "C" __attribute__((visibility("default")))
 
-// shared thread-local error slot, defined in grafimo_hip.hip
-extern "C" void gfm_set_error_(const char *msg);
+using gfm_tsv_detail::FileCols;
 
 namespace {
 
@@ -36,15 +35,6 @@ struct ErrSlot {
     ErrSlot &operator=(const std::string &m) { gfm_set_error_(m.c_str()); return *this; }
     ErrSlot &operator=(const char *m) { gfm_set_error_(m); return *this; }
 } t_err;
-
-struct FileCols {
-    std::vector<uint8_t> kmers;
-    std::vector<int64_t> start, stop, freq;
-    std::vector<uint8_t> strand, is_ref;
-    std::vector<int32_t> local_name;       // index into names
-    std::vector<std::string> names;
-    std::string error;
-};
 
 inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
 
@@ -87,7 +77,9 @@ bool parse_int(const char *b, const char *e, int64_t *val)
     return true;
 }
 
-void parse_file(const char *path, int W, bool skip_rev, FileCols &out)
+}  // namespace
+
+void gfm_tsv_detail::parse_file(const char *path, int W, bool skip_rev, FileCols &out)
 {
     int fd = open(path, O_RDONLY);
     if (fd < 0) { out.error = std::string("Unable to open ") + path; return; }
@@ -171,16 +163,33 @@ void parse_file(const char *path, int W, bool skip_rev, FileCols &out)
     munmap(map, len);
 }
 
-}  // namespace
-
-struct gfm_tsv {
-    int W = 0;
-    int64_t n = 0;
-    std::vector<FileCols> files;
-    std::vector<int64_t> row_base;          // per file
-    std::vector<std::string> names;         // global distinct REGION strings
-    std::vector<std::vector<int32_t>> remap;  // per file: local name id -> global
-};
+void gfm_tsv::index_rows()
+{
+    std::unordered_map<std::string, int32_t> gix;
+    const size_t n_paths = files.size();
+    row_base.resize(n_paths);
+    remap.resize(n_paths);
+    names.clear();
+    int64_t total = 0;
+    for (size_t i = 0; i < n_paths; ++i) {
+        FileCols &f = files[i];
+        row_base[i] = total;
+        total += (int64_t)f.start.size();
+        auto &rm = remap[i];
+        rm.resize(f.names.size());
+        for (size_t k = 0; k < f.names.size(); ++k) {
+            auto it = gix.find(f.names[k]);
+            if (it == gix.end()) {
+                rm[k] = (int32_t)names.size();
+                gix.emplace(f.names[k], rm[k]);
+                names.push_back(f.names[k]);
+            } else {
+                rm[k] = it->second;
+            }
+        }
+    }
+    n = total;
+}
 
 GFM_API int gfm_tsv_open(const char *const *paths, int n_paths, int width, int skip_reverse,
                          int n_threads, gfm_tsv_t *out, int64_t *n_rows)
@@ -202,7 +211,7 @@ GFM_API int gfm_tsv_open(const char *const *paths, int n_paths, int width, int s
             const int i = next.fetch_add(1);
             if (i >= n_paths) break;
             try {
-                parse_file(paths[i], width, skip_reverse != 0, t->files[(size_t)i]);
+                gfm_tsv_detail::parse_file(paths[i], width, skip_reverse != 0, t->files[(size_t)i]);
             } catch (const std::bad_alloc &) {
                 t->files[(size_t)i].error = "out of memory";
             }
@@ -221,29 +230,8 @@ GFM_API int gfm_tsv_open(const char *const *paths, int n_paths, int width, int s
             delete t;
             return GFM_ERR_IO;
         }
-    std::unordered_map<std::string, int32_t> gix;
-    t->row_base.resize((size_t)n_paths);
-    t->remap.resize((size_t)n_paths);
-    int64_t n = 0;
-    for (int i = 0; i < n_paths; ++i) {
-        FileCols &f = t->files[(size_t)i];
-        t->row_base[(size_t)i] = n;
-        n += (int64_t)f.start.size();
-        auto &rm = t->remap[(size_t)i];
-        rm.resize(f.names.size());
-        for (size_t k = 0; k < f.names.size(); ++k) {
-            auto it = gix.find(f.names[k]);
-            if (it == gix.end()) {
-                rm[k] = (int32_t)t->names.size();
-                gix.emplace(f.names[k], rm[k]);
-                t->names.push_back(f.names[k]);
-            } else {
-                rm[k] = it->second;
-            }
-        }
-    }
-    t->n = n;
-    *n_rows = n;
+    t->index_rows();
+    *n_rows = t->n;
     *out = t;
     return GFM_OK;
 }

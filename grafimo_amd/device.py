@@ -54,10 +54,11 @@ class DeviceMotif:
         if use_motif_pmf:
             try:
                 pmf = motif.pval_matrix
-            except AttributeError:
+            except AttributeError:     # not computed yet: the DP runs on the device
                 pmf = None
-        return cls(motif.dense_score_matrix(), motif.dense_bg(), motif.min_val, motif.scale,
-                   motif.offset, pmf)
+        from .motif import dense_bg, dense_score_matrix
+        return cls(dense_score_matrix(motif), dense_bg(motif), int(motif.min_val), int(motif.scale),
+                   float(motif.offset), pmf)
 
     def close(self):
         if getattr(self, "_h", None):

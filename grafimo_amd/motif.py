@@ -219,10 +219,35 @@ class Motif(object):
 
     # ------------------------------------------------------------------ helpers (ours)
     def dense_score_matrix(self) -> np.ndarray:
-        """score_matrix as int64 [4, W] with rows in A,C,G,T order (the C-ABI layout)."""
-        sm = np.asarray(self.score_matrix)
-        idx = [self.nucsmap[n] for n in DNA_ALPHABET]
-        return np.ascontiguousarray(sm[idx], dtype=np.int64)
+        return dense_score_matrix(self)
 
     def dense_bg(self) -> np.ndarray:
-        return np.array([float(self.bg[n]) for n in DNA_ALPHABET], dtype=np.float64)
+        return dense_bg(self)
+
+
+# ---------------------------------------------------------------------- duck-typed boundary
+# What the scoring path reads from a motif (score_sequences.py:294, motif_processing.pyx:577-592).  The
+# reference's own ``grafimo.motif.Motif`` carries exactly these, so it can be handed to every entry
+# point here without conversion; nothing below needs a method the reference class does not have.
+MOTIF_FIELDS = ("score_matrix", "nucsmap", "bg", "min_val", "scale", "offset", "width", "motif_id",
+                "motif_name")
+
+
+def is_motif_like(obj) -> bool:
+    """True for this package's Motif, the reference's Motif, or any object with the same members."""
+    if isinstance(obj, Motif):
+        return True
+    return all(hasattr(type(obj), f) or f in getattr(obj, "__dict__", ()) for f in MOTIF_FIELDS)
+
+
+def dense_score_matrix(motif) -> np.ndarray:
+    """motif.score_matrix (rows in ``motif.nucsmap`` order, ndarray or DataFrame) as int64 [4, W] with
+    rows A,C,G,T -- the layout of the C ABI."""
+    sm = np.asarray(motif.score_matrix)
+    idx = [int(motif.nucsmap[n]) for n in DNA_ALPHABET]
+    return np.ascontiguousarray(sm[idx], dtype=np.int64)
+
+
+def dense_bg(motif) -> np.ndarray:
+    """motif.bg ({nucleotide: probability}) as f64 [4] in A,C,G,T order."""
+    return np.array([float(motif.bg[n]) for n in DNA_ALPHABET], dtype=np.float64)

@@ -27,7 +27,7 @@ import pandas as pd
 
 from . import _native as nv
 from .grafimo_errors import BGFileError, MotifFileFormatError, MotifFileReadError
-from .motif import Motif
+from .motif import Motif, is_motif_like
 from .motif_processing import (apply_pseudocount_jaspar_transfac_pfm, apply_pseudocount_meme,
                                comp_pval_mat, compute_log_odds, get_uniform_bg, read_bg_file)
 from .utils import (DNA_ALPHABET, PSEUDOBG, RANGE, REV_COMPL, UNIF, almost_equal,
@@ -227,7 +227,7 @@ def scale_pwm(motif_matrix: np.ndarray, alphabet: List[str], motif_width: int, n
 
 def process_motif_for_logodds(motif: Motif, debug: bool, pvalue_matrix: bool = True) -> Motif:
     """log-odds -> integer scaling -> p-value DP (motif_ops.py:971-1022)."""
-    if not isinstance(motif, Motif):
+    if not is_motif_like(motif):
         exception_handler(TypeError, f"Expected Motif, got {type(motif).__name__}.\n", debug)
     lo = compute_log_odds(motif.count_matrix, motif.width, motif.bg, motif.alphabet,
                           motif.nucsmap, debug)

@@ -17,6 +17,7 @@ import numpy as np
 from .grafimo_errors import BGFileError, MotifProcessingError
 from .utils import DNA_ALPHABET, exception_handler, isListEqual
 from . import _native as nv
+from .motif import dense_bg, dense_score_matrix
 
 
 def read_bg_file(bg_file: str, debug: bool) -> Dict[str, float]:
@@ -141,8 +142,8 @@ def comp_pval_mat(motif, debug: bool) -> np.ndarray:
     if not motif.is_scaled:
         exception_handler(MotifProcessingError,
                           "The motif score matrix has not been scaled yet.\n", debug)
-    sm = motif.dense_score_matrix()
-    bg = motif.dense_bg()
+    sm = dense_score_matrix(motif)   # any object with the reference Motif's members (motif.py:323-457)
+    bg = dense_bg(motif)
     out = np.empty(nv.RANGE * motif.width + 1, dtype=np.float64)
     rc = nv.lib().gfm_comp_pval_mat(nv.ptr(sm), int(motif.width), nv.ptr(bg), nv.ptr(out))
     if rc == nv.GFM_ERR_ASSERT:

@@ -17,7 +17,7 @@ import time
 import numpy as np
 import pandas as pd
 
-from .motif import Motif
+from .motif import Motif, is_motif_like
 from .utils import PHASE, SOURCE, TP, exception_handler
 
 DEFAULT_OUTDIR = "default_out_dir_name"   # utils.py:28
@@ -81,7 +81,7 @@ def write_results(results: pd.DataFrame, motif: Motif, motif_num: int, args_obj,
         exception_handler(TypeError, f"Expected DataFrame, got {type(results).__name__}.\n", debug)
     if len(results) == 0:
         exception_handler(ValueError, "No potential motif occurrence retreived.\n", debug)
-    if not isinstance(motif, Motif):
+    if not is_motif_like(motif):
         exception_handler(TypeError, f"Expected Motif, got {type(motif).__name__}.\n", debug)
     if not isinstance(motif_num, int):
         exception_handler(TypeError, f"Expected int, got {type(motif_num).__name__}.\n", debug)

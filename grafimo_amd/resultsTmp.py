@@ -12,7 +12,7 @@ from typing import List, Optional
 
 import pandas as pd
 
-from .motif import Motif
+from .motif import Motif, is_motif_like
 
 _COLUMNS = ("seqnames", "seqs", "chroms", "starts", "stops", "strands", "scores", "pvalues",
             "frequencies", "references")
@@ -60,7 +60,7 @@ class ResultTmp(object):
 
     def to_df(self, motif: Motif, threshold: float, qvalt: bool, recomb: bool,
               ignore_qvals: Optional[bool] = False) -> pd.DataFrame:
-        if not isinstance(motif, Motif):
+        if not is_motif_like(motif):
             raise TypeError(f"\n\nERROR: Expected Motif, got {type(motif).__name__}.\n")
         if not isinstance(threshold, float):
             raise TypeError(f"\n\nERROR: Expected float, got {type(threshold).__name__}.\n")

@@ -24,7 +24,7 @@ import pandas as pd
 
 from . import _native as nv
 from .device import DeviceMotif
-from .motif import Motif
+from .motif import Motif, is_motif_like
 from .resultsTmp import build_frame
 from .utils import die, exception_handler, print_progress_bar
 from .workflow import is_findmotif_like
@@ -63,9 +63,55 @@ class KmerTable:
             nv.lib().gfm_tsv_close(h)
 
 
+class StreamScan:
+    """gfm_scan_tsv: the TSV files of one width parsed, uploaded and scored as one pipelined pass (parse
+    threads -> pinned chunks -> copy stream -> score kernel per chunk); only the hit rows -- with the
+    columns of their TSV rows -- come back.  .n rows were scored; .stats holds the timing split."""
+
+    def __init__(self, dm: DeviceMotif, paths: List[str], skip_reverse: bool, threads: int, threshold: float,
+                 on_qvalue: bool, want_qvalues: bool, chunk_rows: int = 0):
+        arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+        h = ctypes.c_void_p()
+        n, k = ctypes.c_int64(), ctypes.c_int64()
+        nv.check(nv.lib().gfm_scan_tsv(dm.handle, arr, len(paths), int(bool(skip_reverse)), int(threads),
+                                       float(threshold), int(bool(on_qvalue)), int(bool(want_qvalues)),
+                                       int(chunk_rows), ctypes.byref(h), ctypes.byref(n), ctypes.byref(k)))
+        try:
+            self.n, self.n_hits, self.width = int(n.value), int(k.value), dm.width
+            K = self.n_hits
+            self.rows = np.empty(K, dtype=np.int64)
+            self.scaled = np.empty(K, dtype=np.int32)
+            self.logodds = np.empty(K, dtype=np.float64)
+            self.pvalue = np.empty(K, dtype=np.float64)
+            self.qvalue = np.empty(K, dtype=np.float64) if want_qvalues else None
+            self.kmers = np.empty((K, dm.width), dtype=np.uint8)
+            self.start = np.empty(K, dtype=np.int64)
+            self.stop = np.empty(K, dtype=np.int64)
+            self.strand = np.empty(K, dtype=np.uint8)
+            self.freq = np.empty(K, dtype=np.int64)
+            self.is_ref = np.empty(K, dtype=np.uint8)
+            self.name_id = np.empty(K, dtype=np.int32)
+            nv.check(nv.lib().gfm_scan_hits(h, nv.ptr(self.rows), nv.ptr(self.scaled), nv.ptr(self.logodds),
+                                            nv.ptr(self.pvalue), nv.ptr(self.qvalue), nv.ptr(self.kmers),
+                                            nv.ptr(self.start), nv.ptr(self.stop), nv.ptr(self.strand),
+                                            nv.ptr(self.freq), nv.ptr(self.is_ref), nv.ptr(self.name_id)))
+            self.stats = nv.ScanStats()
+            nv.check(nv.lib().gfm_scan_stats(h, ctypes.byref(self.stats)))
+            t = nv.lib().gfm_scan_table(h)
+            cnt = nv.lib().gfm_tsv_name_count(t)
+            nbytes = int(nv.lib().gfm_tsv_names_bytes(t))
+            off = np.empty(cnt + 1, dtype=np.int64)
+            buf = np.empty(max(nbytes, 1), dtype=np.uint8)
+            nv.check(nv.lib().gfm_tsv_names(t, nv.ptr(off), nv.ptr(buf)))
+            raw = buf.tobytes()
+            self.names = [raw[off[i]:off[i + 1]].decode() for i in range(cnt)]
+        finally:
+            nv.lib().gfm_scan_close(h)
+
+
 def print_scoring_msg(motif: Motif, noreverse: bool, debug: bool) -> None:
     """'Scoring hits for motif +ID.' / '-ID.' (score_sequences.py:433-464)."""
-    if not isinstance(motif, Motif):
+    if not is_motif_like(motif):
         exception_handler(TypeError, f"Expected Motif, got {type(motif).__name__}.\n", debug)
     if not isinstance(noreverse, bool):
         exception_handler(TypeError, f"Expected bool, got {type(noreverse).__name__}.\n", debug)
@@ -100,7 +146,7 @@ def compute_results(motif: Motif, sequence_loc: str, debug: bool, args_obj=None,
     ``args_obj`` is the reference's ``Findmotif`` (or grafimo_amd.workflow.Findmotif): .cores,
     .threshold, .noqvalue, .qvalueT, .noreverse, .recomb, .verbose are read.  ``testmode``
     hard-codes the reference's test settings (score_sequences.py:100-107)."""
-    if not isinstance(motif, Motif):
+    if not is_motif_like(motif):
         exception_handler(TypeError, f"Expected Motif, got {type(motif).__name__}.\n", debug)
     if not isinstance(sequence_loc, str):
         exception_handler(TypeError, f"Expected str, got {type(sequence_loc).__name__}.\n", debug)
@@ -123,48 +169,48 @@ def compute_results(motif: Motif, sequence_loc: str, debug: bool, args_obj=None,
     files = sorted(glob.glob(os.path.join(sequence_loc, f"width_{width}", "*.tsv")))
     start_s = time.time()
     print_progress_bar(0, 1, prefix="Progress:", suffix="Complete", length=50)
+    if not files:      # nothing was extracted for this width (score_sequences.py:189-192)
+        errmsg = "No result retrieved. Unable to proceed.\n"
+        errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
+        exception_handler(ValueError, errmsg, debug)
+    dm = DeviceMotif.from_motif(motif)
     try:
-        table = KmerTable(files, width, no_reverse, cores)
+        scan = StreamScan(dm, files, no_reverse, cores, float(threshold), bool(qval_t), not no_qvalue)
     except nv.NativeError as e:
         exception_handler(ValueError if e.code == nv.GFM_ERR_IO else RuntimeError, e.msg + "\n", debug)
     except KeyboardInterrupt:
         print("\nCaught SIGINT. GRAFIMO will exit")
         die(2)
-    if table.n == 0:
+    finally:
+        dm.close()
+    if scan.n == 0:
         errmsg = "No result retrieved. Unable to proceed.\n"
         errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
         exception_handler(ValueError, errmsg, debug)
-
-    dm = DeviceMotif.from_motif(motif)
-    try:
-        if not no_qvalue:
-            print("\nComputing q-values...\n")
-        hits = dm.scan_host(table.kmers, float(threshold), on_qvalue=bool(qval_t),
-                            want_qvalues=not no_qvalue)
-    finally:
-        dm.close()
+    if not no_qvalue:
+        print("\nComputing q-values...\n")
     print_progress_bar(1, 1, prefix="Progress:", suffix="Complete", length=50)
     if verbose:
-        print("Sequences scored in %.2fs" % (time.time() - start_s))
-    print(f"Scanned sequences:\t{table.n}")
-    print(f"Scanned nucleotides:\t{table.n * width}")
+        st = scan.stats
+        print("Sequences scored in %.2fs (parsing %.2fs on %d threads, %d chunk(s), %.1f MB to the GPU)"
+              % (time.time() - start_s, st.parse_s, st.parse_threads, st.n_chunks, st.h2d_bytes / 1e6))
+    print(f"Scanned sequences:\t{scan.n}")
+    print(f"Scanned nucleotides:\t{scan.n * width}")
 
     start_df = time.time()
-    rows = hits["rows"]
-    names = np.array(table.names, dtype=object)
-    seqs = [bytes(k).decode() for k in table.kmers[rows]]
+    names = np.array(scan.names, dtype=object)
     df = build_frame(
         motif,
-        seqnames=list(names[table.name_id[rows]]),
-        starts=table.start[rows],
-        stops=table.stop[rows],
-        strands=[chr(c) for c in table.strand[rows]],
-        scores=hits["logodds"],
-        pvalues=hits["pvalue"],
-        qvalues=None if no_qvalue else hits["qvalue"],
-        seqs=seqs,
-        frequencies=table.freq[rows],
-        references=["ref" if r else "non.ref" for r in table.is_ref[rows]],
+        seqnames=list(names[scan.name_id]) if scan.n_hits else [],
+        starts=scan.start,
+        stops=scan.stop,
+        strands=[chr(c) for c in scan.strand],
+        scores=scan.logodds,
+        pvalues=scan.pvalue,
+        qvalues=None if no_qvalue else scan.qvalue,
+        seqs=[bytes(k).decode() for k in scan.kmers],
+        frequencies=scan.freq,
+        references=["ref" if r else "non.ref" for r in scan.is_ref],
         threshold=None, recomb=bool(recomb),
     )
     if verbose:
@@ -204,7 +250,7 @@ def compute_results_many(motifs: List[Motif], sequence_loc: str, debug: bool, ar
     out: List[Optional[pd.DataFrame]] = [None] * len(motifs)
     by_width = {}
     for i, m in enumerate(motifs):
-        if not isinstance(m, Motif):
+        if not is_motif_like(m):
             exception_handler(TypeError, f"Expected Motif, got {type(m).__name__}.\n", debug)
         by_width.setdefault(m.width, []).append(i)
     for width, idxs in by_width.items():

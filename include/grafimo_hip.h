@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFM_ABI_VERSION 4
+#define GFM_ABI_VERSION 5
 
 #define GFM_OK 0
 #define GFM_ERR_INVALID (-1)  /* bad argument (NULL, width out of range, ...)            */
@@ -81,7 +81,8 @@ int gfm_comp_pval_mat(const int64_t *h_score_matrix, int width, const double *h_
  * score_matrix, bg, min_val, scale, offset, width, pval_matrix. */
 typedef struct gfm_motif *gfm_motif_t;
 
-/* Uploads the tables to the current device.  If h_pmf is NULL the DP of
+/* Uploads the tables to the current device.  min_val must be the minimum of h_score_matrix
+ * (Motif.min_val: what a k-mer holding N scores).  If h_pmf is NULL the DP of
  * gfm_comp_pval_mat runs on device; otherwise h_pmf (L doubles) is taken as the motif's
  * pval_matrix.  Also builds p_table[s] = sum(pmf[s:]) / sum(pmf) on device -- the O(1)
  * form of score_sequences.py:390-391 -- and the kernel workspace. */
@@ -109,7 +110,8 @@ int gfm_motif_annotate(gfm_motif_t m, const int32_t *h_scores, int64_t n,
  *   d_kmers    uint8 [n][W], ASCII, row-major, 16-byte aligned base: the KMER column of
  *              the vg TSV rows.  A/a C/c G/g T/t score; a row holding 'N' (or any other
  *              byte whose bits 1-3 do not name A,C,G,T) scores min_val (:376-378).
- *   d_scores   int32 [n] out: scaled integer scores.
+ *   d_scores   int32 [n] out: scaled integer scores (16-byte aligned for the fastest stores;
+ *              4-byte alignment is accepted).
  *   d_hist     uint64 [L] in/out or NULL: d_hist[s] += #rows scored s.
  *   select_cutoff / d_hit_*: if select_cutoff != GFM_NO_SELECT, rows with
  *              score >= select_cutoff get the entry ((row_base + row) << 20 | score)
@@ -192,6 +194,39 @@ int gfm_tsv_name_count(gfm_tsv_t t);
 int64_t gfm_tsv_names_bytes(gfm_tsv_t t);
 int gfm_tsv_names(gfm_tsv_t t, int64_t *offsets, char *bytes);
 void gfm_tsv_close(gfm_tsv_t t);
+
+/* ------------------------------------------------------------------ streamed scan of a TSV directory
+ * compute_results' numeric core (score_sequences.py:113-157, :194-205) as ONE pipelined pass over the
+ * width_W TSV files of a motif: host threads parse the files (in path order) while earlier rows are
+ * already copied (pinned chunk buffers, hipMemcpyAsync on a copy stream) and scored (one score launch
+ * per chunk, one histogram and one hit list for the whole scan, row ids global in path order);
+ * the q-value table and the threshold run once at the end and only the hit rows come back.
+ * Buffers are kept per device between calls (gfm_scan_release_buffers frees them).
+ *   threshold / on_qvalue / want_qvalues as gfm_scan_host; chunk_rows: rows per chunk (<= 0: default);
+ *   *n_rows = rows scored (kept rows of all files), *n_hits = rows under the threshold. */
+typedef struct gfm_scan *gfm_scan_t;
+typedef struct gfm_scan_stats {
+    int64_t n_rows, n_hits, n_chunks, h2d_bytes;
+    double total_s;      /* wall time of the call                                           */
+    double parse_s;      /* until the last file was parsed (copies and kernels overlap it)   */
+    double h2d_s;        /* sum of the host-to-device copy durations (hipEvents)             */
+    double tail_s;       /* after the last file was parsed: last chunk, tables, hits back    */
+    int32_t parse_threads, reserved;
+} gfm_scan_stats_t;
+int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, int skip_reverse, int n_threads,
+                 double threshold, int on_qvalue, int want_qvalues, int64_t chunk_rows, gfm_scan_t *out,
+                 int64_t *n_rows, int64_t *n_hits);
+/* The hit rows ascending by row id, each with the columns of its TSV row (any pointer may be NULL;
+ * n_hits entries each, kmers n_hits x W bytes; qvalue only if the scan computed q-values). */
+int gfm_scan_hits(gfm_scan_t s, int64_t *rows, int32_t *scaled, double *logodds, double *pvalue,
+                  double *qvalue, uint8_t *kmers, int64_t *start, int64_t *stop, uint8_t *strand,
+                  int64_t *freq, uint8_t *is_ref, int32_t *name_id);
+int gfm_scan_stats(gfm_scan_t s, gfm_scan_stats_t *out);
+/* the parsed table behind the scan (REGION names: gfm_tsv_name_count / gfm_tsv_names); owned by the scan
+ * handle -- do not gfm_tsv_close it */
+gfm_tsv_t gfm_scan_table(gfm_scan_t s);
+void gfm_scan_close(gfm_scan_t s);
+void gfm_scan_release_buffers(void);
 
 /* ------------------------------------------------------------------ k-mer extraction
  * Replaces the rows of `vg find -p CHR:S-E -x XG -H GBWT -K W -E` (extract_regions.py:180,225,326;

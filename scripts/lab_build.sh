@@ -1,0 +1,20 @@
+#!/usr/bin/env bash
+# Development aid: builds one-width variants of libgrafimo_hip.so into lab/ (seconds each) so that
+# kernel experiments can be timed side by side on one GPU box:
+#   scripts/lab_build.sh <tag> [-DGFM_...]...        ->  lab/libgfm_<tag>.so   (width: $LAB_W, default 19)
+set -euo pipefail
+root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+tag="$1"; shift
+W="${LAB_W:-19}"
+src="$root/grafimo_amd/csrc"
+mkdir -p "$root/lab"
+CC=(/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fvisibility=hidden
+    -I"$root/include" -DGFM_ONLY_W="$W" "$@")
+"${CC[@]}" -c "$src/grafimo_hip.hip" -o "$root/lab/gfm_$tag.o" &
+for g in 0 1 2 3; do "${CC[@]}" -DGFM_QUAD_GROUP=$g -c "$src/score_quad_tu.hip" -o "$root/lab/gfm_${tag}_g$g.o" & done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/lab/libgfm_$tag.so" "$root/lab/gfm_$tag.o" \
+    "$root/lab"/gfm_${tag}_g{0,1,2,3}.o "$src/graph_extract.o" "$src/tsv_ingest.o" "$src/vcf_ingest.o" \
+    "$src/scan_stream.o" -lpthread -lz
+rm -f "$root/lab/gfm_$tag.o" "$root/lab"/gfm_${tag}_g?.o
+echo "built lab/libgfm_$tag.so"

@@ -31,6 +31,8 @@ for _ in range(reps):
         dm.score(d, sc, hist=hist, select_cutoff=cut, hit_rows=hits[1:], hit_count=hits[:1])
     elif mode == "nohist":
         dm.score(d, sc)
+    elif mode == "selonly":
+        dm.score(d, sc, select_cutoff=cut, hit_rows=hits[1:], hit_count=hits[:1])
     else:
         dm.score(d, sc, hist=hist)
 if os.environ.get("PROF_Q"):
@@ -41,4 +43,7 @@ if os.environ.get("PROF_Q"):
         dm.qvalue_table(hist, 1e-4, False, q, cutd, nr)
 torch.cuda.synchronize()
 ms = dm.profile_read()
-print("kernel ms:", ms, "GB/s alg:", n * (m.width + 4) / (ms.min() * 1e-3) / 1e9)
+ms = np.sort(ms[1:]) if len(ms) > 2 else ms
+print(f"{os.environ.get('GRAFIMO_HIP_LIB', 'default').split('/')[-1]:28s} {mode:8s} kernel us: min {ms.min()*1e3:6.1f} "
+      f"median {np.median(ms)*1e3:6.1f} max {ms.max()*1e3:6.1f}   GB/s alg at median: "
+      f"{n * (m.width + 4) / (np.median(ms) * 1e-3) / 1e9:7.1f}")

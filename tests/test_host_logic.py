@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared but not exported"
         assert name in nv.PROTOTYPES, f"{name} has no ctypes prototype"
     assert set(nv.PROTOTYPES) == declared
-    assert lib.gfm_abi_version() == 4
+    assert lib.gfm_abi_version() == 5
     # importing / loading must not have initialised a device; counting devices is allowed
     assert nv.device_count() >= 0
 
@@ -218,3 +218,18 @@ def test_tsv_ingest_property_random_rows(tmp_path):
         assert [t.names[i] for i in t.name_id] == cols["seqname"]
 
     check()
+
+
+def test_reference_shaped_motif_is_accepted_by_the_boundary_helpers(golden_motifs):
+    """Duck-typed boundary: an object with the reference Motif's members --
+    rows in its own nucsmap order, bg as a dict -- maps onto the dense C-ABI layout."""
+    from grafimo_amd.motif import Motif, dense_bg, dense_score_matrix, is_motif_like
+    from ref_shapes import RefShapedMotif
+    _, flat = golden_motifs
+    rec = flat["ctcf_meme_unif#0"]
+    m = RefShapedMotif(rec, with_pmf=False)
+    assert not isinstance(m, Motif) and is_motif_like(m)
+    assert not hasattr(m, "dense_score_matrix")
+    assert np.array_equal(dense_score_matrix(m), rec["score_matrix"])
+    assert np.array_equal(dense_bg(m), rec["bg"])
+    assert not is_motif_like(object()) and not is_motif_like("MA0139.1")
