@@ -55,17 +55,17 @@ double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-constexpr int kSlots = 2;                          // chunk slots in flight (double buffering)
-constexpr int64_t kDefaultChunkRows = 4 << 20;     // rows per chunk (x W bytes pinned + device, per slot)
+constexpr int kSlots = 3;                          // chunk slots: one being staged, one in flight, one spare
+constexpr int64_t kDefaultChunkRows = 1 << 20;     // rows per chunk (x W bytes pinned + device, per slot)
 
 // Per-device buffers of the streamed scan; they only grow.
 struct ScanPool {
     int device = -1;
     hipStream_t copy = nullptr, score = nullptr;
-    hipEvent_t copied[kSlots] = {nullptr, nullptr}, scored[kSlots] = {nullptr, nullptr};
-    hipEvent_t c0[kSlots] = {nullptr, nullptr}, c1[kSlots] = {nullptr, nullptr};   // H2D timing
-    uint8_t *h_pin[kSlots] = {nullptr, nullptr};
-    uint8_t *d_kmers[kSlots] = {nullptr, nullptr};
+    hipEvent_t copied[kSlots] = {}, scored[kSlots] = {};
+    hipEvent_t c0[kSlots] = {}, c1[kSlots] = {};   // H2D timing
+    uint8_t *h_pin[kSlots] = {};
+    uint8_t *d_kmers[kSlots] = {};
     size_t slot_bytes = 0;
     int64_t block_rows = 0;                 // rows per score block (== chunk rows they were made for)
     std::vector<int32_t *> score_blocks;    // one per chunk index
@@ -252,46 +252,6 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
     sc->table.files.resize((size_t)n_paths);
     const double t_begin = now_s();
 
-    // ---- parse threads: files are taken in order, so that they also finish roughly in order
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
-    nt = std::max(1, std::min(nt, std::max(n_paths, 1)));
-    std::atomic<int> next{0};
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<char> done((size_t)n_paths, 0);
-    std::atomic<bool> cancel{false};
-    double t_parse_end = t_begin;
-    auto work = [&]() {
-        for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= n_paths || cancel.load()) break;
-            FileCols &f = sc->table.files[(size_t)i];
-            try {
-                gfm_tsv_detail::parse_file(paths[i], W, skip_reverse != 0, f);
-            } catch (const std::bad_alloc &) {
-                f.error = "out of memory";
-            }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                done[(size_t)i] = 1;
-                t_parse_end = std::max(t_parse_end, now_s());
-            }
-            cv.notify_all();
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int k = 0; k < nt; ++k) pool.emplace_back(work);
-    struct Joiner {
-        std::vector<std::thread> &pool;
-        std::atomic<bool> &cancel;
-        ~Joiner()
-        {
-            cancel.store(true);
-            for (auto &th : pool)
-                if (th.joinable()) th.join();
-        }
-    } joiner{pool, cancel};
-
     // ---- device side
     ScanPool *P = nullptr;
     S_RC(acquire_pool(&P));
@@ -305,66 +265,167 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
     if (want_qvalues) S_TRY(hipMemsetAsync(P->d_hist, 0, sizeof(uint64_t) * (size_t)L, P->score));
     S_TRY(hipMemsetAsync(P->d_count, 0, sizeof(uint64_t), P->score));
 
-    int64_t total_rows = 0, slot_rows = 0;
+    // ---- host pipeline.  Worker threads parse the files (taken in path order) AND stage them: as soon as
+    // the row counts of all earlier files are known a file's global row offset is fixed, and whichever worker
+    // comes by next copies its k-mers into the pinned slot of the chunk(s) they fall into.  (One thread doing
+    // all staging copies -- 38 MB out of other cores' caches for 2e6 rows -- took longer than 256 threads
+    // needed to parse.)  The calling thread only sequences chunks: chunk k goes to the device once every row
+    // of it has been staged; its slot is handed back to the workers when the score kernel has read it.
+    const int nt = gfm_tsv_detail::pick_threads(paths, n_paths, n_threads);
+    std::mutex mu;
+    std::condition_variable cv_work, cv_main;
+    int next_parse = 0;                      // next file to parse
+    int next_assign = 0;                     // files [0, next_assign) have their row offset
+    int next_stage = 0;                      // next file to stage (offsets are assigned in order, so a counter)
+    int staged_files = 0;
+    int64_t assigned_rows = 0;
+    std::vector<char> counted((size_t)n_paths, 0);
+    std::vector<int64_t> file_off((size_t)n_paths, 0);
+    std::vector<int64_t> chunk_staged;       // rows staged so far per chunk
+    int64_t released = 0;                    // chunks whose slot may be written again: chunk k needs k < released + kSlots
+    bool failed = false;
+    std::string fail_msg;
+    double t_parse_end = t_begin;
+    auto work = [&]() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            if (failed) return;
+            if (next_stage < next_assign) {                     // stage a file whose offset is known
+                const int i = next_stage++;
+                const FileCols &f = sc->table.files[(size_t)i];
+                const int64_t rows = (int64_t)f.start.size();
+                int64_t at = 0;
+                while (at < rows) {
+                    const int64_t g = file_off[(size_t)i] + at;
+                    const int64_t k = g / chunk_rows, in = g % chunk_rows;
+                    const int64_t take = std::min(rows - at, chunk_rows - in);
+                    cv_work.wait(lk, [&] { return failed || k < released + kSlots; });
+                    if (failed) return;
+                    lk.unlock();
+                    std::memcpy(P->h_pin[k % kSlots] + (size_t)in * (size_t)W, f.kmers.data() + (size_t)at * (size_t)W,
+                                (size_t)take * (size_t)W);
+                    lk.lock();
+                    if ((int64_t)chunk_staged.size() <= k) chunk_staged.resize((size_t)k + 1, 0);
+                    chunk_staged[(size_t)k] += take;
+                    at += take;
+                    cv_main.notify_one();
+                }
+                ++staged_files;
+                cv_main.notify_one();
+                continue;
+            }
+            if (next_parse < n_paths) {                          // parse the next file
+                const int i = next_parse++;
+                FileCols &f = sc->table.files[(size_t)i];
+                lk.unlock();
+                try {
+                    gfm_tsv_detail::parse_file(paths[i], W, skip_reverse != 0, f);
+                } catch (const std::bad_alloc &) {
+                    f.error = "out of memory";
+                }
+                lk.lock();
+                if (!f.error.empty()) {
+                    if (!failed) fail_msg = f.error;
+                    failed = true;
+                    cv_work.notify_all();
+                    cv_main.notify_all();
+                    return;
+                }
+                counted[(size_t)i] = 1;
+                t_parse_end = std::max(t_parse_end, now_s());
+                while (next_assign < n_paths && counted[(size_t)next_assign]) {
+                    file_off[(size_t)next_assign] = assigned_rows;
+                    assigned_rows += (int64_t)sc->table.files[(size_t)next_assign].start.size();
+                    ++next_assign;
+                }
+                cv_work.notify_all();
+                cv_main.notify_one();
+                continue;
+            }
+            if (staged_files >= n_paths || next_stage >= n_paths) return;   // nothing left for this thread to take
+            cv_work.wait(lk);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int k = 0; k < nt; ++k) pool.emplace_back(work);
+    struct Joiner {
+        std::vector<std::thread> &pool;
+        std::mutex &mu;
+        std::condition_variable &cv;
+        bool &failed;
+        ~Joiner()
+        {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                failed = true;          // whoever still waits gives up (after a normal run nobody does)
+            }
+            cv.notify_all();
+            for (auto &th : pool)
+                if (th.joinable()) th.join();
+        }
+    } joiner{pool, mu, cv_work, failed};
+
+    int64_t total_rows = 0;
     size_t n_chunks = 0;
     std::vector<int64_t> chunk_n;          // rows of every submitted chunk
-    int slot = 0;
-    bool slot_busy[kSlots] = {false, false};
     double h2d_ms = 0.0;
     int64_t h2d_bytes = 0;
-    auto wait_slot = [&](int s) -> int {   // the slot's last chunk has been copied AND scored
-        if (!slot_busy[s]) return GFM_OK;
+    auto release_chunk = [&](int64_t k) -> int {   // chunk k has been copied AND scored: its slot is free again
+        const int s = (int)(k % kSlots);
         S_TRY(hipEventSynchronize(P->scored[s]));
         float ms = 0.f;
         S_TRY(hipEventElapsedTime(&ms, P->c0[s], P->c1[s]));
         h2d_ms += ms;
-        slot_busy[s] = false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            released = k + 1;
+        }
+        cv_work.notify_all();
         return GFM_OK;
     };
-    auto submit = [&]() -> int {
-        if (slot_rows == 0) return GFM_OK;
-        const size_t bytes = (size_t)slot_rows * (size_t)W;
+    for (int64_t k = 0;; ++k) {
+        int64_t rows_k = 0;
+        {   // wait until chunk k is fully staged (or turns out not to exist)
+            std::unique_lock<std::mutex> lk(mu);
+            cv_main.wait(lk, [&] {
+                if (failed) return true;
+                const int64_t have = (int64_t)chunk_staged.size() > k ? chunk_staged[(size_t)k] : 0;
+                if (have == chunk_rows) return true;
+                if (next_assign == n_paths)                 // every row count is known: the last chunk may be short
+                    return have == std::min(chunk_rows, std::max<int64_t>(0, assigned_rows - k * chunk_rows));
+                return false;
+            });
+            if (failed) return sfail(GFM_ERR_IO, fail_msg);
+            rows_k = (int64_t)chunk_staged.size() > k ? chunk_staged[(size_t)k] : 0;
+        }
+        if (rows_k == 0) break;
+        const int slot = (int)(k % kSlots);
+        const size_t bytes = (size_t)rows_k * (size_t)W;
         int32_t *d_sc = nullptr;
-        S_RC(P->score_block(n_chunks, chunk_rows, &d_sc));
+        S_RC(P->score_block((size_t)k, chunk_rows, &d_sc));
         S_TRY(hipEventRecord(P->c0[slot], P->copy));
         S_TRY(hipMemcpyAsync(P->d_kmers[slot], P->h_pin[slot], bytes, hipMemcpyHostToDevice, P->copy));
         S_TRY(hipEventRecord(P->c1[slot], P->copy));
         S_TRY(hipEventRecord(P->copied[slot], P->copy));
         S_TRY(hipStreamWaitEvent(P->score, P->copied[slot], 0));
-        S_RC(gfm_score_kmers(m, P->d_kmers[slot], slot_rows, d_sc, want_qvalues ? P->d_hist : nullptr, cutoff,
-                             total_rows, fused ? P->d_hits : nullptr, fused ? P->hit_cap : 0,
-                             fused ? P->d_count : nullptr, 0, P->score, nullptr));
+        S_RC(gfm_score_kmers(m, P->d_kmers[slot], rows_k, d_sc, want_qvalues ? P->d_hist : nullptr, cutoff, total_rows,
+                             fused ? P->d_hits : nullptr, fused ? P->hit_cap : 0, fused ? P->d_count : nullptr, 0,
+                             P->score, nullptr));
         S_TRY(hipEventRecord(P->scored[slot], P->score));
-        slot_busy[slot] = true;
         h2d_bytes += (int64_t)bytes;
-        chunk_n.push_back(slot_rows);
-        total_rows += slot_rows;
+        chunk_n.push_back(rows_k);
+        total_rows += rows_k;
         ++n_chunks;
-        slot_rows = 0;
-        slot = (slot + 1) % kSlots;
-        return wait_slot(slot);            // the slot that is filled next must be free again
-    };
-
-    for (int i = 0; i < n_paths; ++i) {
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return done[(size_t)i] != 0; });
-        }
-        const FileCols &f = sc->table.files[(size_t)i];
-        if (!f.error.empty()) return sfail(GFM_ERR_IO, f.error);
-        const int64_t rows = (int64_t)f.start.size();
-        int64_t at = 0;
-        while (at < rows) {
-            const int64_t take = std::min(rows - at, chunk_rows - slot_rows);
-            std::memcpy(P->h_pin[slot] + (size_t)slot_rows * (size_t)W, f.kmers.data() + (size_t)at * (size_t)W,
-                        (size_t)take * (size_t)W);
-            slot_rows += take;
-            at += take;
-            if (slot_rows == chunk_rows) S_RC(submit());
-        }
+        if (k + 1 >= kSlots) S_RC(release_chunk(k + 1 - kSlots));   // the slot chunk k+1 will be staged into
+        if (rows_k < chunk_rows) break;                             // a short chunk is the last one
     }
-    S_RC(submit());
+    for (int64_t k = std::max<int64_t>(0, (int64_t)n_chunks - (kSlots - 1)); k < (int64_t)n_chunks; ++k)
+        S_RC(release_chunk(k));
     for (auto &th : pool) th.join();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (failed) return sfail(GFM_ERR_IO, fail_msg);
+    }
     const double t_parsed = t_parse_end;
     sc->table.index_rows();
     if (sc->table.n != total_rows) return sfail(GFM_ERR_IO, "internal error: row count mismatch");
@@ -394,7 +455,6 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
             S_TRY(hipStreamSynchronize(P->score));
             if ((int64_t)cnt > P->hit_cap) return sfail(GFM_ERR_OVERFLOW, "hit list overflow");
         }
-        for (int s = 0; s < kSlots; ++s) S_RC(wait_slot(s));
         std::vector<int64_t> packed((size_t)cnt);
         std::vector<double> q;
         if (cnt)

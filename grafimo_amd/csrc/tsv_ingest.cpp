@@ -87,11 +87,31 @@ void gfm_tsv_detail::parse_file(const char *path, int W, bool skip_rev, FileCols
     if (fstat(fd, &sb) != 0) { close(fd); out.error = std::string("Unable to stat ") + path; return; }
     const size_t len = (size_t)sb.st_size;
     if (len == 0) { close(fd); return; }
-    void *map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (map == MAP_FAILED) { out.error = std::string("Unable to mmap ") + path; return; }
-    madvise(map, len, MADV_SEQUENTIAL);
-    const char *p = static_cast<const char *>(map), *end = p + len;
+    // Small files are read into a per-thread buffer: with hundreds of parse threads, mmap/munmap of
+    // thousands of region files serialise on the process's address-space lock.  Big files are mapped.
+    constexpr size_t kReadLimit = (size_t)32 << 20;
+    static thread_local std::vector<char> t_buf;
+    void *map = nullptr;
+    const char *p = nullptr;
+    if (len <= kReadLimit) {
+        t_buf.resize(len);
+        size_t got = 0;
+        while (got < len) {
+            const ssize_t r = read(fd, t_buf.data() + got, len - got);
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        close(fd);
+        if (got != len) { out.error = std::string("Unable to read ") + path; return; }
+        p = t_buf.data();
+    } else {
+        map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (map == MAP_FAILED) { out.error = std::string("Unable to mmap ") + path; return; }
+        madvise(map, len, MADV_SEQUENTIAL);
+        p = static_cast<const char *>(map);
+    }
+    const char *end = p + len;
     const size_t guess = len / (size_t)(2 * W + 60) + 16;
     out.kmers.reserve(guess * (size_t)W);
     out.start.reserve(guess); out.stop.reserve(guess); out.freq.reserve(guess);
@@ -160,7 +180,23 @@ void gfm_tsv_detail::parse_file(const char *path, int W, bool skip_rev, FileCols
         out.local_name.push_back(nid);
         p = next;
     }
-    munmap(map, len);
+    if (map) munmap(map, len);
+}
+
+int gfm_tsv_detail::pick_threads(const char *const *paths, int n_paths, int requested)
+{
+    int nt = requested > 0 ? requested : (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > n_paths) nt = n_paths;
+    if (nt <= 1) return 1;
+    unsigned long long bytes = 0;
+    for (int i = 0; i < n_paths; ++i) {
+        struct stat sb;
+        if (stat(paths[i], &sb) == 0) bytes += (unsigned long long)sb.st_size;
+    }
+    const unsigned long long by_size = bytes >> 20;
+    if ((unsigned long long)nt > by_size) nt = (int)(by_size < 1 ? 1 : by_size);
+    return nt;
 }
 
 void gfm_tsv::index_rows()
@@ -202,9 +238,7 @@ GFM_API int gfm_tsv_open(const char *const *paths, int n_paths, int width, int s
     if (!t) { t_err = "out of memory"; return GFM_ERR_NOMEM; }
     t->W = width;
     t->files.resize((size_t)n_paths);
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
-    if (nt < 1) nt = 1;
-    if (nt > n_paths) nt = n_paths;
+    const int nt = gfm_tsv_detail::pick_threads(paths, n_paths, n_threads);
     std::atomic<int> next{0};
     auto work = [&]() {
         for (;;) {

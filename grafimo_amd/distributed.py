@@ -158,6 +158,8 @@ def sharded_scan(backend: ScanBackend, kmers: np.ndarray, threshold: float, on_q
     """One motif over this rank's rows.  Returns dict(rows (global ids), scaled, logodds,
     pvalue[, qvalue], n_scored (global), row_base).  Collectives: all_gather of the row counts
     (global row ids), all_reduce of the histogram when q-values are wanted."""
+    if on_qvalue and not want_qvalues:
+        raise ValueError("q-value threshold without q-values")
     import torch
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -198,6 +200,8 @@ def sharded_scan_same_width(backends: Sequence[ScanBackend], kmers: np.ndarray, 
     histograms cross the ranks as ONE all-reduce of an [M, L] tensor: xGMI collectives of this
     size are latency-bound, so M motifs cost one latency instead of M.  Returns one dict per motif
     like sharded_scan."""
+    if on_qvalue and not want_qvalues:
+        raise ValueError("q-value threshold without q-values")
     import torch
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -271,6 +275,8 @@ def compute_results_sharded(motif: Motif, sequence_loc: str, debug: bool, args_o
     threshold = float(args_obj.threshold)
     no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
     no_reverse, recomb = bool(args_obj.noreverse), bool(args_obj.recomb)
+    if qval_t and no_qvalue:
+        raise ValueError("q-value threshold without q-values")
     if rank == 0:
         print_scoring_msg(motif, no_reverse, debug)
     width = motif.width

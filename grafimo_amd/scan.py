@@ -91,6 +91,28 @@ class KmerScanner:
         # the library's workspace of call k-2 is free again: skip its own event wait
         self._reuse_flag = _nv.GFM_FLAG_CALLER_ORDERS_REUSE if n_slots == 2 else 0
         self._turn = 0
+        # entries of a slot's hit buffer ([count | hits...]) that a gather moves: the whole buffer until
+        # size_gather() has seen how many hits a batch really holds
+        self.gather_len = cap + 1
+
+    def size_gather(self, margin: float = 1.25, granule: int = 512) -> int:
+        """Cut the per-step hit gather down to what is hit: the largest hit count of the finished batches
+        over ALL ranks (one MAX all-reduce; call it between batches, e.g. after a warm-up), times `margin`,
+        rounded up to `granule` entries (4 KiB).  The fixed-size gather of the whole hit buffer moved
+        (world - 1) x capacity x 8 bytes into rank 0 per step -- 17.5 MB at 8 ranks and 2e7-row shards
+        against ~1.5 MB of hits.  A later batch with more hits than this raises OverflowError in collect()."""
+        torch = _torch()
+        self.finish()
+        torch.cuda.synchronize(self.device)
+        m = torch.stack([s.hits[0] for s in self.slots]).max().reshape(1)
+        if self.collective:
+            torch.distributed.all_reduce(m, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        want = int(int(m.item()) * margin) + 1
+        want = -(-want // granule) * granule
+        self.gather_len = min(self.slots[0].hit_capacity, want) + 1
+        for s in self.slots:
+            s.gathered = None
+        return self.gather_len
 
     # ------------------------------------------------------------------ one batch
     def enqueue(self, d_kmers, threshold: float, on_qvalue: bool = False, want_qvalues: bool = True,
@@ -99,6 +121,8 @@ class KmerScanner:
         Nothing here synchronises with the host.  Kept lean on purpose: a step is ~100 us of GPU
         time, so the host side (ctypes calls with cached raw pointers, no torch dispatch unless a
         collective is needed) must stay well below that or the GPU starves."""
+        if on_qvalue and not want_qvalues:      # the reference asserts this in ResultTmp.to_df
+            raise ValueError("q-value threshold without q-values")
         torch = _torch()
         lib = self._lib
         dm = self.dm
@@ -157,18 +181,19 @@ class KmerScanner:
         (world-1) buffers into rank 0 only; if the backend lacks it, all_gather is the fallback."""
         torch = _torch()
         dist = torch.distributed
+        part = slot.hits[:self.gather_len]      # [count | the first gather_len - 1 hit entries]
         if slot.gathered is None and (self.rank == 0 or not self._gather_ok):
-            slot.gathered = [torch.empty_like(slot.hits) for _ in range(self.world)]
+            slot.gathered = [torch.empty_like(part) for _ in range(self.world)]
         if self._gather_ok:
             try:
-                dist.gather(slot.hits, slot.gathered if self.rank == 0 else None, dst=0,
+                dist.gather(part, slot.gathered if self.rank == 0 else None, dst=0,
                             group=self.gather_group)
                 return
             except (RuntimeError, NotImplementedError):
                 self._gather_ok = False
                 if slot.gathered is None:
-                    slot.gathered = [torch.empty_like(slot.hits) for _ in range(self.world)]
-        dist.all_gather(slot.gathered, slot.hits, group=self.gather_group)
+                    slot.gathered = [torch.empty_like(part) for _ in range(self.world)]
+        dist.all_gather(slot.gathered, part, group=self.gather_group)
 
     def finish(self):
         """Make the caller's stream wait for all side-stream work."""
@@ -190,8 +215,8 @@ class KmerScanner:
         packed_all = []
         for b in bufs:
             k = int(b[0].item())
-            if k > slot.hit_capacity:
-                raise OverflowError(f"{k} hits exceed the slot capacity {slot.hit_capacity}")
+            if k > int(b.numel()) - 1:
+                raise OverflowError(f"{k} hits exceed the {int(b.numel()) - 1} entries the slot holds / gathers")
             packed_all.append(b[1:1 + k].cpu().numpy())
         packed = np.sort(np.concatenate(packed_all)) if packed_all else np.empty(0, np.int64)
         rows = packed >> HIT_SCORE_BITS
@@ -202,11 +227,66 @@ class KmerScanner:
         return out
 
 
+class SameWidthScanner:
+    """Resident buffers for repeated batched scans of several motifs of ONE width (BASELINE config 5):
+    the k-mer matrix is read once per group of up to three motifs (gfm_score_kmers_multi); with a process
+    group the M histograms cross the ranks as ONE all-reduce of an [M, L] tensor; q-tables (and the
+    separate selection of --qvalueT) run per motif.  Nothing here synchronises with the host."""
+
+    def __init__(self, dms, n_rows: int, hit_capacity: int, device, group=None, always_collective: bool = False):
+        torch = _torch()
+        self.dms, self.device, self.group = list(dms), device, group
+        M, L = len(self.dms), self.dms[0].L
+        if any(d.L != L for d in self.dms):
+            raise ValueError("SameWidthScanner: the motifs must share one width")
+        dist = torch.distributed
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.collective = self.world > 1 or (always_collective and dist.is_initialized())
+        self.scores = [torch.empty(n_rows, dtype=torch.int32, device=device) for _ in range(M)]
+        self.hist = torch.zeros((M, L), dtype=torch.int64, device=device)
+        self.qtable = torch.empty((M, L), dtype=torch.float64, device=device)
+        self.cutoff = torch.zeros(M, dtype=torch.int32, device=device)
+        self.nrows = torch.zeros(M, dtype=torch.int64, device=device)
+        self.hits = torch.zeros((M, int(hit_capacity) + 1), dtype=torch.int64, device=device)
+        self._cuts = {}
+
+    def enqueue(self, d_kmers, threshold: float, on_qvalue: bool = False, want_qvalues: bool = True,
+                row_base: int = 0):
+        from .device import score_multi
+        torch = _torch()
+        if on_qvalue and not want_qvalues:
+            raise ValueError("q-value threshold without q-values")
+        M = len(self.dms)
+        hists = [self.hist[j] for j in range(M)] if want_qvalues else None
+        if not on_qvalue:
+            cuts = self._cuts.get(float(threshold))
+            if cuts is None:
+                cuts = self._cuts[float(threshold)] = [d.pvalue_cutoff(threshold) for d in self.dms]
+            score_multi(self.dms, d_kmers, self.scores, hists=hists, cutoffs=cuts, row_base=row_base,
+                        hit_rows=[self.hits[j, 1:] for j in range(M)], hit_counts=[self.hits[j, :1] for j in range(M)],
+                        reset_hits=True)
+        else:
+            score_multi(self.dms, d_kmers, self.scores, hists=hists)
+        if want_qvalues:
+            if self.collective:
+                torch.distributed.all_reduce(self.hist, group=self.group)   # one exchange for the whole set
+            for j, d in enumerate(self.dms):
+                d.qvalue_table(self.hist[j], threshold, on_qvalue, self.qtable[j], self.cutoff[j:j + 1],
+                               self.nrows[j:j + 1], clear_hist=True)
+        if on_qvalue:
+            n = int(d_kmers.shape[0])
+            for j, d in enumerate(self.dms):
+                d.select_hits(self.scores[j][:n], self.cutoff[j:j + 1], self.hits[j, 1:], self.hits[j, :1],
+                              row_base=row_base, reset_hits=True)
+
+
 def scan_same_width(motifs, d_kmers, threshold: float, on_qvalue: bool = False,
                     want_qvalues: bool = True, row_base: int = 0, hit_capacity: Optional[int] = None):
     """Several motifs of ONE width over one device-resident k-mer matrix (BASELINE config 5): the
     batched launch reads the k-mers once per group of up to three motifs; q-tables and selection
     then run per motif.  Returns one dict per motif like KmerScanner.collect()."""
+    if on_qvalue and not want_qvalues:
+        raise ValueError("q-value threshold without q-values")
     torch = _torch()
     from .device import score_multi
     n = int(d_kmers.shape[0])

@@ -110,22 +110,82 @@ def make_batch(n_regions: int, rows_per_region: int, width: int, pwm_probs: np.n
                      np.concatenate(out_fr), np.concatenate(out_rf), W)
 
 
-def write_tsv_dir(batch: KmerBatch, out_dir: str, rows_per_file_region: bool = True):
-    """Write the batch as vg-style TSVs (one file per region) under out_dir/width_W/."""
+def tsv_lines(batch: KmerBatch, order: np.ndarray) -> np.ndarray:
+    """The rows `order` of the batch as vg-style TSV lines (numpy bytes array, NUL padded):
+    REGION KMER CHR:START(+|-) CHR:STOP(+|-) COUNT ref|non.ref PATH.  Assembled with numpy's string
+    ufuncs instead of a Python loop per row."""
+    S = np.strings
+    reg = batch.region[order]
+    origin = REGION_ORIGIN + REGION_STRIDE * reg.astype(np.int64)
+    name = S.add(S.add(S.add(b"chr22:", origin.astype("S")), b"-"), (origin + REGION_LEN).astype("S"))
+    km = np.ascontiguousarray(batch.kmers[order]).view(f"S{batch.width}").ravel()
+    sd = np.ascontiguousarray(batch.strand[order]).view("S1").ravel()
+    tab = np.array(b"\t", dtype="S1")
+    pos = lambda v: S.add(S.add(b"chr22:", v.astype("S")), sd)
+    line = name
+    for col in (km, pos(batch.start[order]), pos(batch.stop[order]), batch.freq[order].astype("S"),
+                np.where(batch.is_ref[order] != 0, b"ref", b"non.ref").astype("S7"), S.add(S.add(b"1", sd), b",\n")):
+        line = S.add(S.add(line, tab), col)
+    return line
+
+
+def tsv_text(batch: KmerBatch, rows=None) -> bytes:
+    order = np.arange(len(batch)) if rows is None else np.asarray(rows)
+    return tsv_lines(batch, order).tobytes().replace(b"\0", b"")
+
+
+def write_tsv_dir(batch: KmerBatch, out_dir: str, regions_per_file: int = 1):
+    """Write the batch as vg-style TSVs under out_dir/width_W/, `regions_per_file` regions to a file (vg
+    writes one file per region; the ingest takes any grouping)."""
     import os
     d = os.path.join(out_dir, f"width_{batch.width}")
     os.makedirs(d, exist_ok=True)
     order = np.argsort(batch.region, kind="stable")
-    bounds = np.nonzero(np.diff(batch.region[order]))[0] + 1
-    for idx in np.split(order, bounds):
-        reg = int(batch.region[idx[0]])
-        name = batch.region_name(reg)
-        chrom = name.split(":")[0]
-        with open(os.path.join(d, name.replace(":", "_") + ".tsv"), "w") as fh:
-            for i in idx:
-                sd = chr(batch.strand[i])
-                fh.write(
-                    f"{name}\t{batch.kmers[i].tobytes().decode()}\t{chrom}:{batch.start[i]}{sd}\t"
-                    f"{chrom}:{batch.stop[i]}{sd}\t{batch.freq[i]}\t"
-                    f"{'ref' if batch.is_ref[i] else 'non.ref'}\t1{sd},\n")
+    reg = batch.region[order]
+    line = tsv_lines(batch, order)
+    bounds = np.concatenate([[0], np.nonzero(np.diff(reg))[0] + 1, [len(reg)]])
+    step = max(1, int(regions_per_file))
+    for k in range(0, len(bounds) - 1, step):
+        lo, hi = bounds[k], bounds[min(k + step, len(bounds) - 1)]
+        fname = batch.region_name(int(reg[lo])).replace(":", "_") + ".tsv"
+        with open(os.path.join(d, fname), "wb") as fh:
+            fh.write(line[lo:hi].tobytes().replace(b"\0", b""))
     return d
+
+
+# ---------------------------------------------------------------------------- device-side generators
+def make_device_kmers(n: int, width: int, pwm_probs: np.ndarray, seed: int, device):
+    """uint8 [n, W] k-mers generated ON the device for the configs that do not fit a host array
+    (BASELINE config 3's per-GPU shard, configs 4 and 5): i.i.d. bg_nt bases, 1 % of the rows a sample
+    of the motif's own PWM columns, 0.1 % of the rows with one N.  torch is used as an RNG + buffer only."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    alpha = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    bg = torch.tensor(BG_NT / BG_NT.sum(), device=device)
+    W = int(width)
+    out = torch.empty((n, W), dtype=torch.uint8, device=device)
+    step = 25_000_000
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        idx = torch.multinomial(bg, (b - a) * W, replacement=True, generator=g).view(b - a, W)
+        out[a:b] = alpha[idx]
+    k = max(1, n // 100)
+    rows = torch.randint(0, n, (k,), generator=g, device=device)
+    cdf = torch.tensor(np.cumsum(pwm_probs / pwm_probs.sum(0, keepdims=True), axis=0), device=device)   # [4, W]
+    for a in range(0, k, 1_000_000):
+        u = torch.rand((min(k, a + 1_000_000) - a, W), generator=g, device=device, dtype=torch.float64)
+        code = (u[:, None, :] > cdf[None, :, :]).sum(1).clamp(max=3)
+        out[rows[a:a + 1_000_000]] = alpha[code]
+    if n >= 1000:
+        out[torch.randint(0, n, (n // 1000,), generator=g, device=device), W // 2] = ord("N")
+    return out
+
+
+def jaspar_style_probs(width: int, rng: np.random.Generator, pseudo: float = 0.1, bg=None) -> np.ndarray:
+    """Synthetic JASPAR-style motif: columns ~ Dirichlet(0.3) * 1000 rounded
+    to counts, turned into probabilities with the count-format pseudocount rule (pyx:192-261)."""
+    counts = np.rint(rng.dirichlet([0.3] * 4, size=int(width)).T * 1000)
+    tot = counts.sum(0)
+    bg = np.full(4, 0.25) if bg is None else np.asarray(bg, dtype=np.float64)
+    return (counts / tot * tot.astype(int) + pseudo * bg[:, None]) / (tot.astype(int) + pseudo)

@@ -247,6 +247,75 @@ int orc_score_kmers_table(const uint8_t *kmers, long N, const int64_t *sm,
     return 0;
 }
 
+/* ---- score_seqs' per-row loop over TSV TEXT : score_sequences.py:273-321
+ * The CPU baseline of bench.py ("reference-faithful" incl. the text handling):
+ * for every line: split on whitespace; strand = last char of column 3 (rows on '-' skipped with
+ * no_reverse); k-mer = column 2; start/stop = int(column.split(':')[1][:-1]); frequency = int(column 5);
+ * "ref" rows whose |stop - start| != W become "non.ref" (:305-307); the k-mer is scored with the two
+ * O(L) sums (table == 0, pmf given) or one p_table lookup (table == 1, p_table given).
+ * Returns the number of rows scored (< 0: malformed row); *checksum receives sum(score) + sum(start)
+ * + #ref so that no part of the loop is dead code. */
+static long orc_field_int(const char *b, const char *e)   /* int(col.split(':')[1][:-1]) */
+{
+    const char *c = b;
+    while (c < e && *c != ':') ++c;
+    if (c >= e) return -1;
+    ++c;
+    long v = 0;
+    for (; c < e - 1; ++c) {
+        if (*c < '0' || *c > '9') return -1;
+        v = v * 10 + (*c - '0');
+    }
+    return v;
+}
+long orc_score_tsv_text(const char *text, long len, int W, const int64_t *sm, const double *tab,
+                        int min_score, int scale, double offset, int table, int no_reverse,
+                        double *checksum)
+{
+    const char *p = text, *end = text + len;
+    long rows = 0;
+    double acc = 0.0;
+    while (p < end) {
+        const char *nl = memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *fb[6], *fe[6];
+        int nf = 0;
+        const char *c = p;
+        while (c < le && nf < 6) {
+            while (c < le && (*c == ' ' || *c == '\t' || *c == '\r')) ++c;
+            if (c >= le) break;
+            fb[nf] = c;
+            while (c < le && !(*c == ' ' || *c == '\t' || *c == '\r')) ++c;
+            fe[nf++] = c;
+        }
+        p = nl ? nl + 1 : end;
+        if (nf == 0) continue;
+        if (nf < 6 || fe[1] - fb[1] != W) return -1;
+        const char strand = fe[2][-1];
+        if (no_reverse && strand == '-') continue;
+        const long start = orc_field_int(fb[2], fe[2]), stop = orc_field_int(fb[3], fe[3]);
+        long freq = 0;
+        for (c = fb[4]; c < fe[4]; ++c) freq = freq * 10 + (*c - '0');
+        if (start < 0 || stop < 0) return -1;
+        double lo = 0.0, pv = 0.0;
+        int32_t s;
+        if (!table) {
+            s = orc_compute_score_seq((const uint8_t *)fb[1], sm, tab, min_score, scale, W, offset, 0, &lo, &pv);
+            if (s == INT32_MIN) return -1;
+        } else {
+            if (orc_score_kmers_table((const uint8_t *)fb[1], 1, sm, tab, min_score, W, &s, &pv)) return -1;
+            lo = ((double)s / (double)scale) + ((double)W * offset);
+        }
+        int is_ref = (fe[5] - fb[5] == 3) && memcmp(fb[5], "ref", 3) == 0;
+        const long dist = stop > start ? stop - start : start - stop;
+        if (is_ref && dist != W) is_ref = 0;
+        acc += (double)s + lo + pv + (double)start + (double)freq + (double)is_ref;
+        ++rows;
+    }
+    if (checksum) *checksum = acc;
+    return rows;
+}
+
 /* ---- compute_qvalues : score_sequences.py:401-428 ->
  * statsmodels.stats.multitest.multipletests(method="fdr_bh") (statsmodels >= 0.11,
  * not vendored in the reference).  Published algorithm (fdrcorrection):

@@ -56,6 +56,9 @@ def lib():
         L.orc_score_kmers_table.argtypes = [_c_u8p, ctypes.c_long, _c_i64p, _c_dp,
                                             ctypes.c_int, ctypes.c_int, _c_i32p, _c_dp]
         L.orc_fdr_bh.argtypes = [_c_dp, ctypes.c_long, _c_dp]
+        L.orc_score_tsv_text.argtypes = [ctypes.c_char_p, ctypes.c_long, ctypes.c_int, _c_i64p, _c_dp, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, _c_dp]
+        L.orc_score_tsv_text.restype = ctypes.c_long
         _lib = L
     return _lib
 
@@ -166,6 +169,20 @@ def score_kmers_table(kmers, sm, ptab, min_val):
     if rc:
         raise ValueError("k-mer holds a byte outside ACGTacgtN")
     return sc, pv
+
+
+def score_tsv_text(text: bytes, W, sm, tab, min_val, scale, offset, table=False, no_reverse=False):
+    """score_seqs' loop over TSV text (score_sequences.py:273-321): parse every line, score its k-mer
+    with the per-row O(L) sums (`tab` = pmf) or one lookup (`table`, `tab` = p_table).
+    -> (rows scored, checksum)."""
+    sm = np.ascontiguousarray(sm, dtype=np.int64)
+    tab = np.ascontiguousarray(tab, dtype=np.float64)
+    chk = ctypes.c_double(0.0)
+    n = lib().orc_score_tsv_text(text, len(text), int(W), _p(sm, _c_i64p), _p(tab, _c_dp), int(min_val), int(scale),
+                                 float(offset), int(bool(table)), int(bool(no_reverse)), ctypes.byref(chk))
+    if n < 0:
+        raise ValueError("malformed TSV row")
+    return int(n), chk.value
 
 
 def fdr_bh(pvalues):

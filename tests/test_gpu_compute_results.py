@@ -133,6 +133,75 @@ def test_synthetic_tsv_directory_end_to_end(tmp_path, golden_motifs):
         _compare(df, exp)
 
 
+def test_streamed_scan_chunks_do_not_change_the_result(tmp_path, golden_motifs):
+    """gfm_scan_tsv (the pipeline under compute_results): rows cut into many ragged chunks (hit list
+    appended chunk after chunk, one histogram, row ids global) == one chunk == the monolithic
+    KmerTable + gfm_scan_host path, for p- and q-value thresholds, --no-qvalue and --no-reverse."""
+    from grafimo_amd import synth
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.score_sequences import KmerTable, StreamScan
+    import glob
+    _, flat = golden_motifs
+    g = flat["ctcf_meme_unif#0"]
+    batch = synth.make_batch(23, 700, 19, g["probs"], synth.seed_for(4))
+    synth.write_tsv_dir(batch, str(tmp_path), regions_per_file=3)
+    files = sorted(glob.glob(os.path.join(str(tmp_path), "width_19", "*.tsv")))
+    assert len(files) == 8
+    dm = DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"], g["pmf"])
+    for thr, on_q, want_q, norev in [(1e-2, False, True, False), (0.3, True, True, False), (1e-3, False, False, True),
+                                     (1.0, False, True, False)]:
+        table = KmerTable(files, 19, norev, 2)
+        ref = dm.scan_host(table.kmers, thr, on_qvalue=on_q, want_qvalues=want_q)
+        assert len(ref["rows"]) > 0
+        for chunk_rows in (0, 256 * 5, 256):
+            sc = StreamScan(dm, files, norev, 3, thr, on_q, want_q, chunk_rows=chunk_rows)
+            assert sc.n == table.n and sc.stats.n_rows == table.n
+            assert sc.stats.n_chunks == (1 if chunk_rows == 0 else -(-table.n // chunk_rows))
+            assert np.array_equal(sc.rows, ref["rows"]) and np.array_equal(sc.scaled, ref["scaled"])
+            assert np.array_equal(sc.logodds, ref["logodds"]) and np.array_equal(sc.pvalue, ref["pvalue"])
+            if want_q:
+                assert np.array_equal(sc.qvalue, ref["qvalue"])
+            r = sc.rows
+            assert np.array_equal(sc.kmers, table.kmers[r]) and np.array_equal(sc.start, table.start[r])
+            assert np.array_equal(sc.stop, table.stop[r]) and np.array_equal(sc.strand, table.strand[r])
+            assert np.array_equal(sc.freq, table.freq[r]) and np.array_equal(sc.is_ref, table.is_ref[r])
+            assert [sc.names[i] for i in sc.name_id] == [table.names[i] for i in table.name_id[r]]
+    # a malformed row anywhere fails the whole scan like the ingest does
+    with open(files[3], "a") as fh:
+        fh.write("chr22:1-2\tACGT\tchr22:1+\tchr22:5+\t1\tref\t1+,\n")
+    with pytest.raises(Exception) as e:
+        StreamScan(dm, files, False, 3, 1e-2, False, True, chunk_rows=256)
+    assert "k-mer length" in str(e.value)
+    dm.close()
+
+
+def test_streamed_scan_grows_its_hit_list(tmp_path, golden_motifs):
+    """More hits than the pooled hit list holds (threshold 1: every one of 1.2e6 rows): the scan sizes
+    the list from the count and selects again from the kept scores."""
+    from grafimo_amd import synth
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.score_sequences import StreamScan
+    import glob
+    _, flat = golden_motifs
+    g = flat["ctcf_meme_unif#0"]
+    batch = synth.make_batch(600, 2000, 19, g["probs"], synth.seed_for(5))
+    synth.write_tsv_dir(batch, str(tmp_path), regions_per_file=100)
+    files = sorted(glob.glob(os.path.join(str(tmp_path), "width_19", "*.tsv")))
+    dm = DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"], g["pmf"])
+    nv_lib = __import__("grafimo_amd._native", fromlist=["lib"]).lib()
+    nv_lib.gfm_scan_release_buffers()                   # start from the default hit capacity (2^20)
+    sc = StreamScan(dm, files, False, 4, 1.0, False, True, chunk_rows=256 * 1024)
+    order = np.argsort(batch.region, kind="stable")     # files hold the regions in ascending order
+    from oracle import oracle as orc
+    ptab = orc.p_table(g["pmf"])
+    exp_sc, exp_p = orc.score_kmers_table(batch.kmers[order], g["score_matrix"], ptab, g["min_val"])
+    exp = np.nonzero(exp_p < 1.0)[0]                    # strict: rows holding N (p = 1) are no hits
+    assert sc.n == 1_200_000 and len(exp) > (1 << 20)
+    assert np.array_equal(sc.rows, exp) and np.array_equal(sc.scaled, exp_sc[exp])
+    assert np.array_equal(sc.kmers, batch.kmers[order][exp])
+    dm.close()
+
+
 def test_sharded_entry_point_on_one_gpu(golden_json):
     """compute_results_sharded with the HIP backend and no process group == compute_results."""
     from grafimo_amd.distributed import compute_results_sharded

@@ -144,6 +144,40 @@ def test_fused_and_separate_selection(dev, golden_motifs):
     dm.close()
 
 
+def test_selecting_and_plain_calls_alternate_on_one_handle(dev, golden_motifs):
+    """a selecting call that flushes its wave queues mid-run (threshold 1.0: every
+    row is a hit), then a call that selects nothing (the score pass of --qvalueT), then selecting calls
+    again on the same handle -- every hit list must be complete and hold no stale count."""
+    from grafimo_amd.device import DeviceMotif
+    _, flat = golden_motifs
+    m = flat["ctcf_meme_unif#0"]
+    dm = DeviceMotif(m["score_matrix"], m["bg"], m["min_val"], m["scale"], m["offset"], m["pmf"])
+    rng = np.random.default_rng(11)
+    n = 200_000
+    d_km = torch.from_numpy(random_kmers(rng, n, 19)).to(dev)
+    d_sc = torch.empty(n, dtype=torch.int32, device=dev)
+    d_hist = torch.zeros(dm.L, dtype=torch.int64, device=dev)
+    for stream in (None, torch.cuda.Stream(device=dev)):          # one stream, then a separate tail stream
+        for round_ in range(3):
+            for thr, select in [(1.0, True), (None, False), (None, False), (1e-2, True), (1.0, True), (None, False),
+                                (1e-3, True)]:
+                if not select:
+                    dm.score(d_km, d_sc, hist=d_hist, tail_stream=stream)
+                    continue
+                cut = dm.pvalue_cutoff(thr)
+                rows = torch.full((n,), -1, dtype=torch.int64, device=dev)
+                cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+                dm.score(d_km, d_sc, select_cutoff=cut, hit_rows=rows, hit_count=cnt, reset_hits=True,
+                         tail_stream=stream)
+                torch.cuda.synchronize()
+                sc = d_sc.cpu().numpy()
+                exp = np.nonzero(sc >= cut)[0]
+                assert int(cnt.item()) == len(exp), (thr, round_)
+                got = np.sort(rows[:len(exp)].cpu().numpy())
+                assert np.array_equal(got >> 20, exp) and np.array_equal(got & 0xFFFFF, sc[exp])
+    dm.close()
+
+
 def test_qvalue_table_vs_sorted_bh(dev, golden_motifs):
     from grafimo_amd.device import DeviceMotif
     from oracle import oracle as orc

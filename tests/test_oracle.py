@@ -133,3 +133,25 @@ def test_compute_results_flag_settings(golden_motifs, golden_json, name):
             assert np.array_equal(got[c].to_numpy(dtype=float), exp[c].to_numpy(dtype=float)), c
         else:
             assert (got[c].astype(str) == exp[c].astype(str)).all(), c
+
+
+def test_text_loop_of_the_cpu_baseline_matches_the_row_functions(golden_motifs):
+    """orc_score_tsv_text (bench.py's CPU baseline incl. the text handling of score_sequences.py:273-321)
+    == parse_tsv_rows + score_kmers on the reference's 704-row fixture, both p-value variants."""
+    _, flat = golden_motifs
+    g = flat["ctcf_meme_unif#0"]
+    path = os.path.join(REF_DATA, "width_19", "scoring_test_input.tsv")
+    text = open(path, "rb").read()
+    cols = orc.parse_tsv_rows([path])
+    km = kmers_from_strings(cols["seq"])
+    sc, lo, pv = orc.score_kmers(km, g["score_matrix"], g["pmf"], g["min_val"], g["scale"], g["offset"])
+    refs = [r == "ref" and abs(b - a) == 19 for r, a, b in zip(cols["ref"], cols["start"], cols["stop"])]
+    want = float(sc.sum()) + float(lo.sum()) + float(pv.sum()) + float(sum(cols["start"])) + float(sum(cols["freq"])) \
+        + float(sum(refs))
+    for table in (False, True):
+        tab = orc.p_table(g["pmf"]) if table else g["pmf"]
+        n, chk = orc.score_tsv_text(text, 19, g["score_matrix"], tab, g["min_val"], g["scale"], g["offset"], table=table)
+        assert n == 704 and abs(chk - want) <= 1e-6 * abs(want)
+    n, _ = orc.score_tsv_text(text, 19, g["score_matrix"], g["pmf"], g["min_val"], g["scale"], g["offset"],
+                              no_reverse=True)
+    assert n == sum(1 for s in cols["strand"] if s == "+")
