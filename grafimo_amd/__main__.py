@@ -45,7 +45,12 @@ def get_parser():
     p.add_argument("-l", "--linear-genome", dest="linear_genome", metavar="FASTA",
                    help="reference FASTA (with -v and -b: extract the k-mers on the GPU instead of -s)")
     p.add_argument("-v", "--vcf", metavar="VCF", help="phased VCF (.vcf or .vcf.gz); its SNP records form the graph")
-    p.add_argument("-b", "--bedfile", metavar="BED", help="regions to scan")
+    p.add_argument("-b", "--bedfile", metavar="BED", help="regions to scan (UCSC BED: lines starting with chr)")
+    p.add_argument("--chroms-prefix-find", dest="chroms_prefix", default="", metavar="PREFIX",
+                   help="chromosome names in the FASTA / VCF = PREFIX + the BED name without its leading chr")
+    p.add_argument("--skip-unmodelled-variants", action="store_true", dest="skip_unmodelled",
+                   help="leave VCF records the extraction graph does not model (insertions, MNPs, overlapping "
+                        "deletions) out instead of failing on them")
     p.add_argument("-k", "--bgfile", default=UNIF)
     p.add_argument("-p", "--pseudo", type=float, default=0.1)
     p.add_argument("-t", "--threshold", type=float, default=1e-4)
@@ -83,8 +88,9 @@ def main(argv=None):
     graphs, region_lists = [], []
     if from_graph:
         from .extract_regions import DeviceGraph, GraphIndex, compute_results_from_graph, read_bed_regions
-        for chrom, regs in read_bed_regions(a.bedfile).items():
-            index = GraphIndex.from_fasta_vcf(a.linear_genome, a.vcf, chrom)
+        for bed_chrom, regs in read_bed_regions(a.bedfile, a.debug).items():
+            chrom = a.chroms_prefix + bed_chrom.split("chr")[1]      # extract_regions.py:122,137
+            index = GraphIndex.from_fasta_vcf(a.linear_genome, a.vcf, chrom, allow_skipped=a.skip_unmodelled)
             if a.verbose:
                 print(f"{chrom}: {len(index.pos)} SNP sites, {index.n_haplotypes} haplotypes, "
                       f"{index.skipped} other VCF records left out")

@@ -16,17 +16,25 @@ graph holds the single-base substitutions and the plain deletions of the VCF; ot
 `GraphIndex.skipped`.  There is no CPU fallback: extraction needs libgrafimo_hip.so and a GPU.
 """
 import ctypes
+import gzip
 import os
-from typing import Dict, List, Optional, Sequence, Tuple
+import sys
+import tempfile
+import time
+from typing import Dict, List, Optional, Sequence, Set, Tuple
 
 import numpy as np
 import pandas as pd
 
 from . import _native as nv
 from .device import DeviceMotif, _stream_ptr, _torch
+from .grafimo_errors import FileFormatError, FileReadError, VGError
 from .motif import Motif
 from .resultsTmp import build_frame
 from .utils import exception_handler
+from .workflow import ALL_CHROMS, is_scan_args_like
+
+INDEX_SUFFIX = ".gfmidx.npz"   # GraphIndex on disk; scan_graph looks for it next to the .xg the reference names
 
 NODE_MAX = 32   # vg construct -m default: an invariant stretch is chopped into nodes of <= 32 bases
 MAX_ALTS = 3
@@ -98,10 +106,12 @@ class GraphIndex:
 
     @classmethod
     def from_fasta_vcf(cls, fasta: str, vcf: str, chrom: str, with_haplotypes: bool = True,
-                       threads: int = 0) -> "GraphIndex":
+                       threads: int = 0, allow_skipped: bool = False) -> "GraphIndex":
         """Reference bases of `chrom` + its VCF records through the library's reader (gfm_vcf_*: host
-        threads, plain or gzip/bgzip): SNPs and plain deletions become sites, the rest is counted in
-        `.skipped`; two haplotypes per sample in file order."""
+        threads, plain or gzip/bgzip): SNPs and plain deletions become sites; two haplotypes per sample in
+        file order.  Records the graph does not model (insertions, multi-base substitutions, a deletion that
+        overlaps an earlier one) would make the k-mers differ from vg's: the call FAILS on them unless
+        `allow_skipped` is set, in which case they are left out, counted in `.skipped` and reported on stderr."""
         ref = _read_fasta_record(fasta, chrom)
         h = ctypes.c_void_p()
         n, H, skipped = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int64()
@@ -119,7 +129,37 @@ class GraphIndex:
                                            nv.ptr(bits) if bits is not None else None))
         finally:
             nv.lib().gfm_vcf_close(h)
+        if int(skipped.value) and not allow_skipped:
+            raise VGError(
+                f"\n\nERROR: {int(skipped.value)} VCF record(s) on {chrom} are insertions, multi-base substitutions or "
+                f"deletions overlapping an earlier one. The extraction graph does not model them, so the k-mers would "
+                f"differ from `vg find`'s. Pass allow_skipped=True (CLI: --skip-unmodelled-variants) to leave them out "
+                f"knowingly.\n")
+        if int(skipped.value):
+            print(f"WARNING: {int(skipped.value)} VCF record(s) on {chrom} (insertions, MNPs, overlapping deletions) are "
+                  f"NOT part of the graph: k-mers through them are missing and their neighbours keep the reference "
+                  f"allele.", file=sys.stderr)
+        if V == 0:
+            print(f"WARNING: no usable VCF record for chromosome {chrom!r} in {vcf}: the graph is the bare reference "
+                  f"(do the chromosome names of the VCF and the FASTA match?)", file=sys.stderr)
         return cls(chrom, ref, pos, n_alts, alt_bases, bits, int(H.value), int(skipped.value), del_len=del_len)
+
+    # ---- on disk (what a `buildvg` step leaves for scan_graph; numpy .npz, no pickles)
+    def save(self, path: str) -> str:
+        if not path.endswith(INDEX_SUFFIX):
+            path += INDEX_SUFFIX
+        np.savez_compressed(path, chrom=np.array(self.chrom), ref=self.ref, pos=self.pos, del_len=self.del_len,
+                            n_alts=self.n_alts, alt_bases=self.alt_bases, n_haplotypes=np.int64(self.n_haplotypes),
+                            skipped=np.int64(self.skipped),
+                            alt_bits=self.alt_bits if self.alt_bits is not None else np.empty(0, np.uint64))
+        return path
+
+    @classmethod
+    def load(cls, path: str) -> "GraphIndex":
+        with np.load(path, allow_pickle=False) as z:
+            bits = z["alt_bits"] if z["alt_bits"].size else None
+            return cls(str(z["chrom"]), z["ref"], z["pos"], z["n_alts"], z["alt_bases"], bits, int(z["n_haplotypes"]),
+                       int(z["skipped"]), del_len=z["del_len"])
 
     # ---- node ids of `vg construct` on this graph (column 7 of the TSV; not used by GRAFIMO's scoring)
     def _node_table(self):
@@ -323,10 +363,13 @@ class DeviceGraph:
                               region, walk)
 
 
-def write_region_tsvs(index: GraphIndex, rows: ExtractedKmers, out_dir: str) -> List[str]:
+def write_region_tsvs(index: GraphIndex, rows: ExtractedKmers, out_dir: str, labels: Optional[Sequence[str]] = None,
+                      chrom: Optional[str] = None) -> List[str]:
     """The files scan_graph leaves for compute_results: out_dir/width_W/CHR_S-E.tsv
-    (extract_regions.py:165-170,180), seven tab-separated columns per row like vg's."""
+    (extract_regions.py:165-170,180), seven tab-separated columns per row like vg's.  `labels` / `chrom`:
+    the region strings and the chromosome name to print (default: the graph's own)."""
     W = rows.width
+    cname = index.chrom if chrom is None else chrom
     d = os.path.join(out_dir, f"width_{W}")
     os.makedirs(d, exist_ok=True)
     km = rows.kmers.cpu().numpy()
@@ -336,7 +379,7 @@ def write_region_tsvs(index: GraphIndex, rows: ExtractedKmers, out_dir: str) -> 
     paths = []
     bounds = np.searchsorted(region, np.arange(len(rows.regions) + 1), side="left")
     for r in range(len(rows.regions)):
-        label = rows.region_label(r)
+        label = rows.region_label(r) if labels is None else labels[r]
         path = os.path.join(d, label.replace(":", "_") + ".tsv")
         with open(path, "w") as fh:
             cur_p, node_paths = None, []
@@ -349,23 +392,143 @@ def write_region_tsvs(index: GraphIndex, rows: ExtractedKmers, out_dir: str) -> 
                 if sg == "-":
                     nodes = nodes[::-1]
                 fh.write("\t".join([
-                    label, km[i].tobytes().decode(), f"{index.chrom}:{int(start[i])}{sg}",
-                    f"{index.chrom}:{int(stop[i])}{sg}", str(int(freq[i])), "ref" if is_ref[i] else "non.ref",
+                    label, km[i].tobytes().decode(), f"{cname}:{int(start[i])}{sg}",
+                    f"{cname}:{int(stop[i])}{sg}", str(int(freq[i])), "ref" if is_ref[i] else "non.ref",
                     "".join(f"{n}{sg}," for n in nodes)]) + "\n")
         paths.append(path)
     return paths
 
 
-def read_bed_regions(bedfile: str) -> Dict[str, List[Tuple[int, int]]]:
-    """chromosome -> [(start, stop)] in file order (the first three BED columns, extract_regions.py:422-426)."""
-    out: Dict[str, List[Tuple[int, int]]] = {}
-    with open(bedfile) as fh:
-        for line in fh:
-            f = line.split()
-            if len(f) < 3 or line.startswith(("#", "track", "browser")):
-                continue
-            out.setdefault(f[0], []).append((int(f[1]), int(f[2])))
-    return out
+def isbed(bedfile: str, debug: bool) -> bool:
+    """utils.py:408-449: the first line starting with "chr" has at least three columns."""
+    if not isinstance(bedfile, str):
+        exception_handler(TypeError, f"Expected str, got {type(bedfile).__name__}.\n", debug)
+    if not os.path.isfile(bedfile):
+        exception_handler(FileNotFoundError, f"Unble to locate {bedfile}.\n", debug)
+    opener = gzip.open if bedfile.split(".")[-1] == "gz" else open
+    with opener(bedfile, mode="rt") as handle:
+        for line in handle:
+            if line.startswith("chr"):
+                return len(line.split()) >= 3
+    return False
+
+
+def get_regions_bed(bedfile: str, debug: bool) -> Tuple[Dict[str, List[Tuple[str, str]]], int]:
+    """The reference's BED reader (extract_regions.py:371-433), rule for rule: .gz by extension; ONLY lines
+    that start with "chr" are data; the first three columns, start and stop kept as the strings they are;
+    regions grouped by chromosome in file order.  -> ({chrom: [(start, stop)]}, number of regions)."""
+    if not isinstance(bedfile, str):
+        exception_handler(TypeError, f"Expected str, got {type(bedfile).__name__}.\n", debug)
+    if not os.path.isfile(bedfile):
+        exception_handler(FileNotFoundError, f"Unable to locate {bedfile}.\n", debug)
+    if not isbed(bedfile, debug):
+        exception_handler(FileFormatError, f"{bedfile} is not a UCSC BED file.\n", debug)
+    if os.stat(bedfile).st_size == 0:
+        exception_handler(FileReadError, f"{bedfile} is empty.\n", debug)
+    regions: Dict[str, List[Tuple[str, str]]] = {}
+    region_num = 0
+    opener = gzip.open if bedfile.split(".")[-1] == "gz" else open
+    try:
+        with opener(bedfile, mode="rt") as handle:
+            for line in handle:
+                if line.startswith("chr"):
+                    chrom, start, stop = line.strip().split()[:3]
+                    regions.setdefault(chrom, []).append((start, stop))
+                    region_num += 1
+    except Exception:
+        exception_handler(FileReadError, f"An error occurred while reading {bedfile}.\n", debug)
+    return regions, region_num
+
+
+def read_bed_regions(bedfile: str, debug: bool = False) -> Dict[str, List[Tuple[int, int]]]:
+    """get_regions_bed with integer coordinates: {chromosome as the BED names it: [(start, stop)]}."""
+    regions, _ = get_regions_bed(bedfile, debug)
+    return {c: [(int(s), int(e)) for s, e in regs] for c, regs in regions.items()}
+
+
+def _index_path(xg: str) -> str:
+    return xg[:-3] + INDEX_SUFFIX if xg.endswith(".xg") else xg + INDEX_SUFFIX
+
+
+def scan_graph(widths: Set[int], args_obj, debug: bool) -> str:
+    """extract_regions.scan_graph (extract_regions.py:55-239) with the extraction kernel in place of the
+    `vg find -p REGION -x XG -H GBWT -K W -E` subprocesses: same arguments (the widths of the motif set and
+    the reference's Findmotif -- .graph_genome / .graph_genome_dir, .bedfile, .chroms, .chroms_prefix,
+    .namemap, .cores, .verbose), same result: a fresh `grafimo_XXXX` directory holding
+    width_W/CHR_START-STOP.tsv, one seven-column file per region and width, for compute_results.
+
+    vg's XG / GBWT files cannot be read here; the graph of a chromosome comes from the GraphIndex written by
+    `GraphIndex.from_fasta_vcf(...).save(...)` NEXT TO the XG the reference would open, under the same name
+    with the extension .gfmidx.npz (chr22.xg -> chr22.gfmidx.npz)."""
+    if not isinstance(widths, set):
+        exception_handler(TypeError, f"Expected set, got {type(widths).__name__}.", debug)
+    if not is_scan_args_like(args_obj):
+        exception_handler(TypeError, f"Expected Findmotif, got {type(args_obj).__name__}.", debug)
+    if args_obj.has_graphgenome():
+        vg = args_obj.graph_genome
+    elif args_obj.has_graphgenome_dir():
+        vg = args_obj.graph_genome_dir
+    else:
+        exception_handler(VGError, "Unexpected genome variation graph found.", debug)
+    bedfile, chroms = args_obj.bedfile, list(args_obj.chroms)
+    chroms_prefix, namemap, verbose = args_obj.chroms_prefix, args_obj.namemap, bool(args_obj.verbose)
+    print(f"\nExtracting regions defined in {bedfile}.\n")
+    start_bp = time.time()
+    regions, region_num = get_regions_bed(bedfile, debug)
+    if verbose:
+        print("%s parsed in %.2fs. Found %d regions.\n" % (bedfile, time.time() - start_bp, region_num))
+    if args_obj.chroms_num == 1 and chroms[0] == ALL_CHROMS:
+        chroms = [c.split("chr")[1] for c in regions.keys()]
+    tmpwd = tempfile.mkdtemp(prefix="grafimo_")
+    start_sq = time.time()
+    graphs: Dict[str, DeviceGraph] = {}
+    try:
+        for chrom in chroms:
+            # chromosome -> graph file and the name used in the region strings (extract_regions.py:136-226)
+            if not bool(namemap):
+                chrname = "".join([chroms_prefix, chrom])
+            else:
+                try:
+                    chrname = namemap[chrom.split("chr")[1]] if (args_obj.has_graphgenome_dir() and
+                                                                 chrom.startswith("chr")) else namemap[chrom]
+                except Exception:
+                    exception_handler(KeyError, f"Missing name map for chromosome {chrom}.\n", debug)
+            key = chrom if chrom.startswith("chr") else "".join(["chr", chrom])
+            if key not in regions:
+                exception_handler(KeyError, f"{chrom} does not appear among the chromosomes available in {bedfile}.\n",
+                                  debug)
+            if bool(namemap) and args_obj.has_graphgenome_dir():
+                c = namemap[chrom.split("chr")[1]] if chrom.startswith("chr") else chrom
+            elif chroms_prefix:
+                c = chrname.split(chroms_prefix)[1]
+            else:
+                c = chrname
+            xg = os.path.join(vg, ".".join([chrname, "xg"])) if args_obj.has_graphgenome_dir() else vg
+            ipath = _index_path(xg)
+            if not os.path.isfile(ipath):
+                exception_handler(VGError, f"Unable to locate {ipath} (the GPU extraction's index beside {xg}). "
+                                           "Are your VGs named with \"chr\"? Consider using --chroms-prefix-find or "
+                                           "chroms-namemap-find.\n", debug)
+            if ipath not in graphs:
+                graphs[ipath] = DeviceGraph(GraphIndex.load(ipath))
+            graph = graphs[ipath]
+            spans = [(int(s), int(e)) for s, e in regions[key]]
+            labels = ["-".join([":".join([c, str(s)]), str(e)]) for s, e in regions[key]]
+            for width in widths:
+                rows = graph.extract(spans, int(width))
+                write_region_tsvs(graph.index, rows, tmpwd, labels=labels, chrom=c)
+    except (VGError, KeyError):
+        raise
+    except Exception as e:   # the reference funnels everything into a VGError (extract_regions.py:228-234)
+        if debug:
+            raise
+        exception_handler(VGError, f"An error occurred while scanning {vg}: {e}\n", debug)
+    finally:
+        for g in graphs.values():
+            g.close()
+    if verbose:
+        print("Extracted all sequences from regions defined in %s in %.2fs.\n" % (bedfile, time.time() - start_sq))
+    return tmpwd
 
 
 def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_obj, group=None,
@@ -440,21 +603,34 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
     hit = torch.from_numpy(res["rows"]).to(kmers.device)
     src = keep[hit] if keep is not None else hit
     take = lambda t: t[src].cpu().numpy()
-    df = build_frame(
+    cols = dict(name_id=take(region).astype(np.int32), start=take(cat("start")), stop=take(cat("stop")),
+                strand=take(cat("strand")), logodds=np.asarray(lo, dtype=np.float64), pvalue=np.asarray(pv, dtype=np.float64),
+                kmers=take(all_kmers).reshape(len(res["rows"]), W), freq=take(cat("freq")), is_ref=take(cat("is_ref")),
+                owner=np.full(len(res["rows"]), rank, dtype=np.int32))
+    if not no_qvalue:
+        cols["qvalue"] = np.asarray(res["qtable"][res["scaled"]], dtype=np.float64)
+    if world > 1:      # packed columns to rank 0 (one tensor gather), the region labels of every rank beside them
+        from .distributed import gather_columns, gather_names
+        got = gather_columns(cols, kmers.device, group)
+        label_lists = gather_names(labels, kmers.device, group)
+        if rank != 0:
+            return None
+        shift = np.cumsum([0] + [len(x) for x in label_lists])[:-1]
+        name_ix = got["name_id"].astype(np.int64) + shift[got["owner"]]
+        labels = [x for lst in label_lists for x in lst]
+    else:
+        got, name_ix = cols, cols["name_id"].astype(np.int64)
+    return build_frame(
         motif,
-        seqnames=[labels[int(r)] for r in take(region)],
-        starts=take(cat("start")), stops=take(cat("stop")),
-        strands=[chr(c) for c in take(cat("strand"))],
-        scores=lo, pvalues=pv,
-        qvalues=None if no_qvalue else res["qtable"][res["scaled"]],
-        seqs=[bytes(k).decode() for k in take(all_kmers)],
-        frequencies=take(cat("freq")),
+        seqnames=[labels[int(r)] for r in name_ix],
+        starts=got["start"], stops=got["stop"],
+        strands=[chr(c) for c in got["strand"]],
+        scores=got["logodds"], pvalues=got["pvalue"],
+        qvalues=None if no_qvalue else got["qvalue"],
+        seqs=[bytes(k).decode() for k in got["kmers"]],
+        frequencies=got["freq"],
         # vg flags a walk over a deletion `ref`; GRAFIMO repairs that on ingest (score_sequences.py:305-307)
         references=["ref" if r and abs(int(e) - int(b_)) == W else "non.ref"
-                    for r, b_, e in zip(take(cat("is_ref")), take(cat("start")), take(cat("stop")))],
+                    for r, b_, e in zip(got["is_ref"], got["start"], got["stop"])],
         threshold=None, recomb=recomb,
     )
-    if world > 1:
-        from .distributed import gather_frames
-        return gather_frames(df, group)
-    return df

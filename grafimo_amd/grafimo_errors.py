@@ -39,3 +39,7 @@ class SubprocessError(GrafimoError):
 
 class VGError(GrafimoError):
     pass
+
+
+class FileFormatError(GrafimoError):
+    pass

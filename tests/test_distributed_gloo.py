@@ -162,6 +162,64 @@ def test_world_of_one_and_empty_shard(tsv_dir, tmp_path):
     assert len(df) == 704 and "Scanned sequences:\t704" in out
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_four_and_eight_ranks_with_ragged_and_empty_shards(tsv_dir, tmp_path, world):
+    """7 files over 4 and over 8 ranks (at 8 at least one rank holds nothing): the same table as one
+    process, for a p- and a q-value threshold; the hit rows reach rank 0 through gather_columns."""
+    for j, kw in enumerate([dict(threshold=2e-3), dict(threshold=0.4, qval_t=True, recomb=True)]):
+        d = tmp_path / f"w{world}_{j}"
+        d.mkdir()
+        df, out = _run(world, tsv_dir, kw, str(d))
+        exp, scanned = _oracle_table(tsv_dir, kw)
+        assert f"Scanned sequences:\t{scanned}" in out
+        assert list(df.columns) == list(exp.columns) and len(df) == len(exp) and len(df) > 0
+        key = ["p-value", "start", "stop", "strand", "matched_sequence"]
+        a, b = df.sort_values(key).reset_index(drop=True), exp.sort_values(key).reset_index(drop=True)
+        for c in exp.columns:
+            if b[c].dtype.kind == "f":
+                np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-12, atol=0)
+            else:
+                assert (a[c].astype(str) == b[c].astype(str)).all(), c
+
+
+def _gather_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import pickle
+    import torch
+    import torch.distributed as dist
+    from grafimo_amd.distributed import gather_columns, gather_names
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(100 + rank)
+        k = [0, 5, 0, 1300][rank % 4] if rank < 4 else rank       # ragged, two empty ranks, one long list
+        cols = dict(rows=np.arange(k, dtype=np.int64) + 10_000 * rank, sc=rng.integers(0, 19000, k).astype(np.int32),
+                    p=rng.random(k), kmers=rng.integers(65, 85, (k, 19)).astype(np.uint8), flag=(np.arange(k) % 2).astype(np.uint8))
+        got = gather_columns(cols, torch.device("cpu"))
+        names = gather_names([f"chr{rank}:{i}-{i + 200}" for i in range(rank)], torch.device("cpu"))
+        none_everywhere = gather_columns({"x": np.empty(0, np.int64)}, torch.device("cpu"))   # nobody has rows
+        with open(os.path.join(outdir, f"r{rank}.pkl"), "wb") as fh:
+            pickle.dump(dict(cols=cols, got=got, names=names, empty=none_everywhere), fh)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_gather_columns_moves_ragged_row_sets_to_rank_zero(tmp_path, world):
+    import pickle
+    import torch.multiprocessing as mp
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [pickle.load(open(tmp_path / f"r{r}.pkl", "rb")) for r in range(world)]
+    got = parts[0]["got"]
+    for name in ("rows", "sc", "p", "kmers", "flag"):
+        want = np.concatenate([p["cols"][name] for p in parts], axis=0)
+        assert got[name].dtype == want.dtype and np.array_equal(got[name], want), name
+    assert all(p["got"] is None for p in parts[1:])
+    assert parts[0]["names"] == [[f"chr{r}:{i}-{i + 200}" for i in range(r)] for r in range(world)]
+    assert all(p["names"] is None for p in parts[1:])
+    assert len(parts[0]["empty"]["x"]) == 0 and all(p["empty"] is None for p in parts[1:])
+
+
 def test_shard_helpers(tmp_path):
     from grafimo_amd.distributed import shard_bounds, shard_files
     for n in [0, 1, 7, 8, 1000]:

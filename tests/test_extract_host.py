@@ -44,7 +44,7 @@ def test_graph_index_matches_the_oracle_readers(tmp_path):
         d = tmp_path / f"g{int(gz)}"
         d.mkdir()
         fasta, vcf = make_graph_files(str(d), chrom="7", gz=gz)
-        idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
+        idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7", allow_skipped=True)
         ref = xo.read_fasta(fasta)["7"]
         sites, dels, skipped = xo.read_vcf_graph(vcf, "7")
         assert idx.ref.tobytes() == ref and idx.skipped == skipped > 0 and len(dels) > 0
@@ -61,7 +61,7 @@ def test_graph_index_matches_the_oracle_readers(tmp_path):
         bits = np.unpackbits(idx.alt_bits[:, 0, :].view(np.uint8), axis=1, bitorder="little")[:, :130]
         assert np.array_equal(bits[dele].astype(bool), dels.hap)
     with pytest.raises(ValueError):
-        GraphIndex.from_fasta_vcf(fasta, vcf, "no_such_chromosome")
+        GraphIndex.from_fasta_vcf(fasta, vcf, "no_such_chromosome", allow_skipped=True)
 
 
 def test_node_numbering_matches_the_oracle(tmp_path):
@@ -70,7 +70,7 @@ def test_node_numbering_matches_the_oracle(tmp_path):
     from grafimo_amd.extract_regions import GraphIndex
     from oracle import extract_oracle as xo
     fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=600, n_sites=48)
-    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7", with_haplotypes=False)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7", with_haplotypes=False, allow_skipped=True)
     assert idx.alt_bits is None and idx.n_haplotypes == 0 and (idx.del_len > 0).any()
     ref = xo.read_fasta(fasta)["7"]
     sites, dels, _ = xo.read_vcf_graph(vcf, "7")
@@ -156,23 +156,23 @@ def test_native_vcf_reader_threads_and_errors(tmp_path):
     from grafimo_amd import _native as nv
     from grafimo_amd.extract_regions import GraphIndex
     fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=5000, n_sites=1200, n_samples=40, seed=2)
-    a = GraphIndex.from_fasta_vcf(fasta, vcf, "7", threads=1)
-    b = GraphIndex.from_fasta_vcf(fasta, vcf, "7", threads=7)
+    a = GraphIndex.from_fasta_vcf(fasta, vcf, "7", threads=1, allow_skipped=True)
+    b = GraphIndex.from_fasta_vcf(fasta, vcf, "7", threads=7, allow_skipped=True)
     for name in ("pos", "n_alts", "alt_bases", "del_len", "alt_bits"):
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
     assert a.skipped == b.skipped and a.n_haplotypes == 80 and len(a.pos) > 500
-    c = GraphIndex.from_fasta_vcf(fasta, vcf, "7", with_haplotypes=False)
+    c = GraphIndex.from_fasta_vcf(fasta, vcf, "7", with_haplotypes=False, allow_skipped=True)
     assert c.alt_bits is None and np.array_equal(c.pos, a.pos)
-    other = GraphIndex.from_fasta_vcf(fasta, vcf, "other")           # the one-record chromosome of the helper
+    other = GraphIndex.from_fasta_vcf(fasta, vcf, "other", allow_skipped=True)           # the one-record chromosome of the helper
     assert other.pos.tolist() == [2] and other.ref.tobytes() == b"ACGTACGT"
     with pytest.raises(nv.NativeError) as e:
-        GraphIndex.from_fasta_vcf(fasta, str(tmp_path / "missing.vcf"), "7")
+        GraphIndex.from_fasta_vcf(fasta, str(tmp_path / "missing.vcf"), "7", allow_skipped=True)
     assert e.value.code == nv.GFM_ERR_IO
     bad = tmp_path / "unsorted.vcf"
     bad.write_text("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts0\n"
                    "7\t30\t.\tA\tC\t.\t.\t.\tGT\t0|1\n7\t10\t.\tA\tC\t.\t.\t.\tGT\t0|1\n")
     with pytest.raises(nv.NativeError):
-        GraphIndex.from_fasta_vcf(fasta, str(bad), "7")
+        GraphIndex.from_fasta_vcf(fasta, str(bad), "7", allow_skipped=True)
 
 
 def test_native_vcf_reader_property(tmp_path):
@@ -219,7 +219,7 @@ def test_native_vcf_reader_property(tmp_path):
                 lines.append(f"other\t{pos}\t.\tA\tC\t.\t.\t.\tGT\t" + "\t".join(cells))
         vcf = tmp_path / "v.vcf"
         vcf.write_text(("\r\n" if crlf else "\n").join(lines) + ("\r\n" if crlf else "\n"))
-        idx = GraphIndex.from_fasta_vcf(str(fasta), str(vcf), "c", threads=3)
+        idx = GraphIndex.from_fasta_vcf(str(fasta), str(vcf), "c", threads=3, allow_skipped=True)
         sites, dels, skipped = xo.read_vcf_graph(str(vcf), "c")
         snp, dele = idx.del_len == 0, idx.del_len > 0
         assert idx.skipped == skipped
@@ -237,3 +237,48 @@ def test_native_vcf_reader_property(tmp_path):
             assert np.array_equal(bits[dele], dels.hap)
 
     check()
+
+
+def test_bed_reader_follows_the_reference(tmp_path):
+    """get_regions_bed (extract_regions.py:371-433): only lines starting with "chr", .gz by extension, first
+    three columns as strings, grouped by chromosome; isbed / empty-file errors through exception_handler."""
+    import gzip
+    from grafimo_amd.extract_regions import get_regions_bed, read_bed_regions
+    from grafimo_amd.grafimo_errors import FileFormatError
+    text = ("track name=peaks\n#comment\nchr22\t100\t300\tp1\t0\t+\nchr1 5 9\n22\t1\t2\n"
+            "chr22\t400\t700\nbrowser position chr7:1-2\n")
+    plain = tmp_path / "a.bed"
+    plain.write_text(text)
+    gz = tmp_path / "a.bed.gz"
+    with gzip.open(gz, "wt") as fh:
+        fh.write(text)
+    for path in (plain, gz):
+        regions, n = get_regions_bed(str(path), True)
+        assert n == 3 and regions == {"chr22": [("100", "300"), ("400", "700")], "chr1": [("5", "9")]}
+        assert list(regions) == ["chr22", "chr1"]                      # file order
+    assert read_bed_regions(str(plain)) == {"chr22": [(100, 300), (400, 700)], "chr1": [(5, 9)]}
+    bad = tmp_path / "b.bed"
+    bad.write_text("22\t1\t2\nchr1\n")
+    with pytest.raises(FileFormatError):
+        get_regions_bed(str(bad), True)
+    with pytest.raises(FileNotFoundError):
+        get_regions_bed(str(tmp_path / "none.bed"), True)
+    with pytest.raises(TypeError):
+        get_regions_bed(7, True)
+
+
+def test_unmodelled_vcf_records_fail_closed(tmp_path, capsys):
+    """insertions / MNPs / overlapping deletions are refused unless the caller opts in; then they
+    are counted and reported on stderr."""
+    from grafimo_amd.extract_regions import GraphIndex
+    from grafimo_amd.grafimo_errors import VGError
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=3000, n_sites=260, seed=5)
+    with pytest.raises(VGError) as e:
+        GraphIndex.from_fasta_vcf(fasta, vcf, "7")
+    assert "does not model them" in str(e.value)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7", allow_skipped=True)
+    assert idx.skipped > 0 and "NOT part of the graph" in capsys.readouterr().err
+    saved = idx.save(str(tmp_path / "chr7"))
+    back = GraphIndex.load(saved)
+    assert back.skipped == idx.skipped and np.array_equal(back.del_len, idx.del_len)
+    assert np.array_equal(back.alt_bits, idx.alt_bits) and np.array_equal(back.alt_bases, idx.alt_bases)

@@ -273,6 +273,22 @@ def test_scanner_collectives_on_one_gpu_rccl(golden_motifs):
             assert np.array_equal(r0["rows"], r1["rows"]) and np.array_equal(r0["scaled"], r1["scaled"])
             assert np.array_equal(r0["qtable"], r1["qtable"]) and r0["n_scored"] == r1["n_scored"] == n
             assert len(r0["rows"]) > 0
+        # the per-step gather is cut down to what is hit: p < 1e-3 leaves a few hundred hits of
+        # 25 000 rows; the gathered slice shrinks from the whole hit buffer to one 512-entry granule or two ...
+        slot = coll.enqueue(d_k, 1e-3, gather_hits=True)
+        k = len(coll.collect(slot)["rows"])
+        full = coll.gather_len
+        small = coll.size_gather()
+        assert full == n + 1 and k < small - 1 <= 2 * 512 * (1 + k // 512) and small < full
+        for _ in range(3):
+            slot = coll.enqueue(d_k, 1e-3, gather_hits=True)
+        assert slot.gathered[0].numel() == small
+        r2 = coll.collect(slot)
+        assert np.array_equal(r2["rows"], r0["rows"] if False else plain.collect(plain.enqueue(d_k, 1e-3))["rows"])
+        # ... and a later batch with more hits than that is reported, not truncated
+        slot = coll.enqueue(d_k, 0.5, gather_hits=True)
+        with pytest.raises(OverflowError):
+            coll.collect(slot)
         dm.close()
     finally:
         dist.destroy_process_group()

@@ -52,7 +52,7 @@ def test_rows_equal_the_oracle_on_a_synthetic_graph(tmp_path, W):
     from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, write_region_tsvs
     # (a 64-base window over the dense graph holds thousands of walks: keep the oracle's Python loop short)
     fasta, vcf = make_graph_files(str(tmp_path), chrom="7", seed=40 + W, n_sites=260 if W < 64 else 100)
-    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7", allow_skipped=True)
     regions = [(0, 150), (100, 300), (2900, 3000), (1500, 1500 + W - 1), (1000, 1250), (2990, 3050), (-20, 90)]
     g = DeviceGraph(idx)
     rows = g.extract(regions, W)
@@ -132,7 +132,7 @@ def test_extraction_feeds_scoring_without_a_tsv(tmp_path):
               pmf=orc.comp_pval_mat(motif.dense_score_matrix(), motif.dense_bg()), min_val=motif.min_val,
               scale=motif.scale, offset=float(motif.offset), width=19, motif_id=motif.motif_id,
               motif_name=motif.motif_name)
-    g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7"))
+    g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7", allow_skipped=True))
     for kw in [dict(threshold=0.05), dict(threshold=0.5, qval_t=True, recomb=True),
                dict(threshold=0.02, no_reverse=True), dict(threshold=0.05, no_qvalue=True, recomb=True)]:
         with contextlib.redirect_stdout(io.StringIO()) as out:
@@ -164,10 +164,11 @@ def test_several_graphs_share_one_scoring_pass_and_cli_mode(tmp_path, capsys):
     fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=4000, n_sites=300, seed=91, gz=False)
     r1, r2 = [(10, 800), (900, 1500)], [(2000, 3900)]
     bed = tmp_path / "regions.bed"
-    bed.write_text("track name=test\n" + "".join(f"7\t{s}\t{e}\tpeak\n" for s, e in r1 + r2))
-    assert read_bed_regions(str(bed)) == {"7": r1 + r2}
+    # UCSC BED as the reference reads it (extract_regions.py:395-433): only lines starting with "chr" count
+    bed.write_text("track name=test\n" + "".join(f"chr7\t{s}\t{e}\tpeak\n" for s, e in r1 + r2) + "7\t5\t50\n")
+    assert read_bed_regions(str(bed)) == {"chr7": r1 + r2}
     motif = build_motif_meme_host(os.path.join(REF_DATA, "MA0139.1.meme"), "unfrm_dst", 0.1, False)[0]
-    g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7"))
+    g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7", allow_skipped=True))
     kw = Findmotif(threshold=0.05, recomb=True)
     with contextlib.redirect_stdout(io.StringIO()):
         one = compute_results_from_graph(motif, g, r1 + r2, True, kw)
@@ -175,14 +176,70 @@ def test_several_graphs_share_one_scoring_pass_and_cli_mode(tmp_path, capsys):
     assert len(one) > 0 and one.equals(two)
     g.close()
     out = tmp_path / "cli_out"
+    with pytest.raises(Exception) as e:                 # fail closed on records the graph does not model
+        main(["-m", os.path.join(REF_DATA, "MA0139.1.meme"), "-l", fasta, "-v", vcf, "-b", str(bed), "-t", "0.05",
+              "--recomb", "-o", str(out), "--debug"])
+    assert "does not model them" in str(e.value)
     main(["-m", os.path.join(REF_DATA, "MA0139.1.meme"), "-l", fasta, "-v", vcf, "-b", str(bed), "-t", "0.05",
-          "--recomb", "-o", str(out), "--verbose"])
+          "--recomb", "-o", str(out), "--verbose", "--skip-unmodelled-variants"])
     assert "SNP sites, 130 haplotypes" in capsys.readouterr().out
     tsv = pd.read_csv(out / "grafimo_out.tsv", sep="\t", index_col=0)
     assert len(tsv) == len(one) and list(tsv["matched_sequence"]) == list(one["matched_sequence"])
     np.testing.assert_allclose(tsv["q-value"].to_numpy(), one["q-value"].to_numpy(), rtol=1e-12)
     with pytest.raises(SystemExit):
         main(["-m", "x.meme", "-l", fasta])            # incomplete graph inputs
+
+
+def test_scan_graph_adapter_feeds_compute_results(tmp_path, capsys):
+    """scan_graph(widths, args_obj, debug) -> tmpdir with width_W/CHR_S-E.tsv, called the way
+    grafimo.findmotif does (grafimo.py:174-179), then compute_results on that directory == the direct
+    compute_results_from_graph table.  The graph comes from the index saved next to the XG name."""
+    import shutil
+    from grafimo_amd.extract_regions import (DeviceGraph, GraphIndex, compute_results_from_graph, scan_graph)
+    from grafimo_amd.motif_ops import build_motif_meme_host
+    from grafimo_amd.score_sequences import compute_results
+    from grafimo_amd.workflow import Findmotif
+    fasta, vcf = os.path.join(REF_DATA, "test.fa"), os.path.join(REF_DATA, "test.vcf.gz")
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "x")
+    gdir = tmp_path / "graphs"
+    gdir.mkdir()
+    saved = idx.save(str(gdir / "x"))
+    assert saved.endswith("x.gfmidx.npz")
+    back = GraphIndex.load(saved)
+    assert back.chrom == "x" and np.array_equal(back.ref, idx.ref) and np.array_equal(back.pos, idx.pos)
+    assert np.array_equal(back.alt_bits, idx.alt_bits) and back.n_haplotypes == idx.n_haplotypes
+    regions = [(0, 400), (380, 1001)]
+    bed = tmp_path / "r.bed"
+    bed.write_text("".join(f"chrx\t{s}\t{e}\n" for s, e in regions))
+    motif = build_motif_meme_host(os.path.join(REF_DATA, "MA0139.1.meme"), "unfrm_dst", 0.1, False)[0]
+    wf = Findmotif(threshold=0.05, recomb=True, graph_genome_dir=str(gdir), bedfile=str(bed), cores=2)
+    loc = scan_graph({19, 12}, wf, True)
+    try:
+        assert os.path.basename(loc).startswith("grafimo_")
+        assert sorted(os.listdir(loc)) == ["width_12", "width_19"]
+        assert sorted(os.listdir(os.path.join(loc, "width_19"))) == ["x_0-400.tsv", "x_380-1001.tsv"]
+        first = open(os.path.join(loc, "width_19", "x_0-400.tsv")).readline().split("\t")
+        assert first[0] == "x:0-400" and len(first[1]) == 19 and first[2].startswith("x:") and len(first) == 7
+        with contextlib.redirect_stdout(io.StringIO()):
+            via_files = compute_results(motif, loc, True, wf)
+            g = DeviceGraph(idx)
+            direct = compute_results_from_graph(motif, g, regions, True, wf)
+            g.close()
+    finally:
+        shutil.rmtree(loc)
+    assert len(direct) > 0
+    key = ["p-value", "sequence_name", "start", "stop", "strand"]
+    a = via_files.sort_values(key).reset_index(drop=True)
+    b = direct.sort_values(key).reset_index(drop=True)
+    assert a.equals(b)
+    # a single indexed graph (-g): the index sits beside the XG path the workflow names
+    wf1 = Findmotif(threshold=0.05, graph_genome=str(gdir / "x.xg"), bedfile=str(bed), chroms=["x"])
+    loc = scan_graph({19}, wf1, True)
+    assert sorted(os.listdir(os.path.join(loc, "width_19"))) == ["x_0-400.tsv", "x_380-1001.tsv"]
+    shutil.rmtree(loc)
+    with pytest.raises(Exception) as e:
+        scan_graph({19}, Findmotif(graph_genome_dir=str(tmp_path), bedfile=str(bed)), True)
+    assert "Unable to locate" in str(e.value)
 
 
 def test_graph_pipeline_under_a_process_group(tmp_path):
@@ -196,7 +253,7 @@ def test_graph_pipeline_under_a_process_group(tmp_path):
     fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=3000, n_sites=200, seed=12)
     regions = [(0, 1000), (1500, 2990)]
     motif = build_motif_meme_host(os.path.join(REF_DATA, "MA0139.1.meme"), "unfrm_dst", 0.1, False)[0]
-    g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7"))
+    g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7", allow_skipped=True))
     kw = Findmotif(threshold=0.05, recomb=True)
     with contextlib.redirect_stdout(io.StringIO()):
         plain = compute_results_from_graph(motif, g, regions, True, kw)
