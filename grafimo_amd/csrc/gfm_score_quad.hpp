@@ -54,16 +54,11 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
     unsigned char *stage_base = smem + kTabBytes;
     unsigned *hist = reinterpret_cast<unsigned *>(stage_base + n_waves * SSTRIDE);
 
-    for (int i = tid; i < kTabBytes / 2; i += wg_threads) reinterpret_cast<uint16_t *>(tab)[i] = ma.tab[i];
-    if (ma.use_hist)
-        for (int i = tid; i <= ma.nb; i += wg_threads) hist[i] = 0u;
-    __syncthreads();
-
     unsigned char *stage = stage_base + wave * SSTRIDE;
     const unsigned stage_off = (unsigned)(kTabBytes + wave * SSTRIDE);   // its absolute LDS offset
     // The loop below takes whole chunks only -- every byte in range, every row live: no bounds logic in
     // the hot code (the ragged-end handling of an earlier version, unrolled per load, was most of the loop's
-    // instruction bytes).  The < 256 rows behind the last whole chunk go through score_tail_rows.
+    // instruction bytes).  The < 256 rows behind the last whole chunk are scored row by row behind it.
     const long long nfull = n / kQuadRows;
     const long long cstride = (long long)gridDim.x * n_waves;
     const bool vec_store = (reinterpret_cast<uintptr_t>(ma.scores) & 15u) == 0;   // uniform
@@ -75,13 +70,9 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
         for (int i = 0; i < kLoads; ++i) {
             if (i * 1024 + 1024 <= CB || i * 1024 + lane * 16 < CB) {   // the last piece may cover fewer lanes
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#ifdef GFM_LAB_L2ONLY   // timing-only build: every chunk re-reads the first 2 MiB (on-chip time without HBM)
-                const u32x4 t = *reinterpret_cast<const u32x4 *>(kmers + ((c * (long long)CB + lane * 16 + i * 1024) & 0x1FFFF0ll));
-#else
                 // once-read stream: non-temporal policy (plain loads: 5.1 TB/s, nt: 6.2 TB/s on the same
                 // byte mix, scripts/micro/stream_bw_nt.hip)
                 const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + i * 1024));
-#endif
                 dst[i] = make_uint4(t.x, t.y, t.z, t.w);
             }
         }
@@ -127,12 +118,12 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
 #pragma unroll
     for (int d = 0; d < kQuadDepth; ++d)
         if (c + d * cstride < nfull) fetch(pre[d], c + d * cstride);
-#ifdef GFM_LAB_DUMMY_STORE
-    // One store behind the first loads, like the score store behind every later chunk's loads: the wait at the
-    // top of the loop can then leave ONE younger vector-memory operation outstanding on every path into it
-    // (in-order counter) instead of draining the score store of the chunk before.
-    __builtin_nontemporal_store(0, ma.resid_n + blockIdx.x);
-#endif
+    // tables and the zeroed window AFTER the first loads went out: their latency hides behind this
+    for (int i = tid; i < kTabBytes / 2; i += wg_threads) reinterpret_cast<uint16_t *>(tab)[i] = ma.tab[i];
+    if (ma.use_hist)
+        for (int i = tid; i <= ma.nb; i += wg_threads) hist[i] = 0u;
+    __syncthreads();
+
     while (c < nfull) {
 #pragma unroll
         for (int d = 0; d < kQuadDepth; ++d) {
@@ -146,11 +137,7 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
                     // W % 8 == 0: 16 bytes of padding after every lane's 4*W bytes (a piece never
                     // straddles two lanes' data then: 4*W is a multiple of 16)
                     const int dst = PAD ? off + PAD * (off / (4 * W)) : off;
-#if GFM_LAB_LEVEL >= 3   // timing-only build: no strip writes
-                    asm volatile("" :: "v"(pre[d][i].x), "v"(pre[d][i].y), "v"(pre[d][i].z), "v"(pre[d][i].w), "v"(dst));
-#else
                     *reinterpret_cast<uint4 *>(stage + dst) = pre[d][i];
-#endif
                 }
             }
             // the next chunk's loads go out before this chunk is scored.  ONE chunk ahead: with two or
@@ -163,14 +150,6 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
 
             // the lane's four rows: W dwords (+ a zero behind them for the funnel shift of the last dword)
             unsigned w[W + 1];
-#if GFM_LAB_LEVEL >= 2   // timing-only build: no row reads (the bytes come from the prefetch registers of the NEXT chunk)
-#pragma unroll
-            for (int t = 0; t < W; ++t) {
-                const uint4 &pv = pre[d][(t / 4) % kLoads];
-                w[t] = (t & 3) == 0 ? pv.x : (t & 3) == 1 ? pv.y : (t & 3) == 2 ? pv.z : pv.w;
-            }
-            w[W] = 0u;
-#else
             {
                 const unsigned base = stage_off + (unsigned)(lane * GP);
                 if constexpr (W % 2 == 1) {
@@ -195,7 +174,6 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
                 }
                 w[W] = 0u;
             }
-#endif
             int score[4];
             bool is_n[4];
 #pragma unroll
@@ -212,12 +190,8 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
                     asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(0x000E000Eu), "v"(x), "v"(x >> 5));
                     const unsigned e0 = y & 0x7Eu;
                     const unsigned e1 = (y >> 16) & 0x7Eu;
-#if GFM_LAB_LEVEL >= 1   // timing-only build: no table lookups
-                    s1 += (int)((e0 ^ e1) & 2u);
-#else
                     s1 += *(lds_cu16 *)(uintptr_t)(e0 + (unsigned)((2 * t) * 128));
                     s1 += *(lds_cu16 *)(uintptr_t)(e1 + (unsigned)((2 * t + 1) * 128));
-#endif
                 }
                 is_n[j] = (unsigned)s1 >= kPoison;    // a base that is not A,C,G,T: min_val (:376-378)
                 score[j] = is_n[j] ? ma.min_val : s1;
@@ -225,13 +199,7 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
             const int k0 = 4 * lane;
             if (vec_store) {   // one 16-byte store per lane: the wave writes 1 KiB contiguous
                 const i32x4 out = {score[0], score[1], score[2], score[3]};
-#if GFM_LAB_STORE == 2
-                if (out.x == 0x7ffffff1) *reinterpret_cast<i32x4 *>(ma.scores + crow + k0) = out;
-#elif defined(GFM_LAB_L2ONLY)
-                *reinterpret_cast<i32x4 *>(ma.scores + ((crow + k0) & 0x7FFFCll)) = out;
-#else
                 __builtin_nontemporal_store(out, reinterpret_cast<i32x4 *>(ma.scores + crow + k0));
-#endif
             } else {           // a score buffer that is only 4-byte aligned
 #pragma unroll
                 for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(score[j], ma.scores + crow + k0 + j);

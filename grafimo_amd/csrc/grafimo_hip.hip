@@ -685,7 +685,19 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     // with a tail stream a few CUs are left free so that its kernels (post, q-table, RCCL) find
     // room without evicting a persistent score workgroup (which would delay the whole grid)
     const int avail = split ? std::max(1, m->max_slabs - m->reserve_cus * (m->max_slabs / m->n_cu)) : m->max_slabs;
-    const int nslabs = (int)std::min<long long>(want, avail);
+    int nslabs = (int)std::min<long long>(want, avail);
+    if (want > avail) {
+        // Persistent grid, chunks dealt round-robin: every wave takes ceil(chunks / waves) turns, and the last turn
+        // is mostly idle unless the counts divide well (2e7 rows: 78 125 chunks over 4 096 waves = 19.07 turns ->
+        // 20 turns, 4.6 % of the slots empty; over 245 workgroups = 19.93 turns -> 0.4 %).  The kernel is HBM-bound
+        // and a few workgroups fewer move the same bytes, so take the grid in [7/8 avail, avail] that wastes least.
+        long long best_cap = -1;
+        for (int g = avail; g >= std::max(1, avail - avail / 8); --g) {
+            const long long per_turn = (long long)g * m->q_waves;
+            const long long cap = (nchunks + per_turn - 1) / per_turn * per_turn;
+            if (best_cap < 0 || cap < best_cap) { best_cap = cap; nslabs = g; }
+        }
+    }
 
     const unsigned k = m->call_no++;
     const int ws = (int)(k & 1u), slot = (int)(k % 3u);

@@ -18,6 +18,8 @@ run sq4 SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_IFETCH SQ_IFET
 run ta TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 run tcc TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum TCC_BUSY_sum
 run grbm GRBM_GUI_ACTIVE
+run fetch FETCH_SIZE
+run write WRITE_SIZE
 python3 - "$out" <<'PY'
 import sys, glob, csv, collections, os
 out = sys.argv[1]
