@@ -78,14 +78,16 @@ PROTOTYPES = {
     "gfm_scan_table": (c_void_p, [c_void_p]),
     "gfm_scan_close": (None, [c_void_p]),
     "gfm_scan_release_buffers": (None, []),
-    "gfm_graph_create": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
-                                 P(c_void_p)]),
+    "gfm_graph_create": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_i64, c_void_p, c_i32, P(c_void_p)]),
     "gfm_graph_destroy": (None, [c_void_p]),
     "gfm_graph_plan": (c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_i32, P(c_i64), P(c_i64)]),
     "gfm_graph_emit": (c_int, [c_void_p] * 10),
     "gfm_vcf_open": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_int, c_int, P(c_void_p), P(c_i64), P(c_i32),
                              P(c_i64)]),
     "gfm_vcf_read": (c_int, [c_void_p] * 6),
+    "gfm_vcf_ins_bytes": (c_i64, [c_void_p]),
+    "gfm_vcf_read_insertions": (c_int, [c_void_p] * 4),
     "gfm_vcf_close": (None, [c_void_p]),
 }
 
@@ -151,7 +153,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if L.gfm_abi_version() != 5:
+        if L.gfm_abi_version() != 6:
             raise ImportError("libgrafimo_hip.so ABI version mismatch")
         _lib = L
     return _lib

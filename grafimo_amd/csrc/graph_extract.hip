@@ -61,6 +61,12 @@ struct GraphDev {
     const int *del_len;         // [n_sites] 0 for a SNP, else the number of deleted bases after the anchor
     int n_dels;
     const int *prev_del;        // [n_sites + 1] index of the last deletion among sites [0, i), or -1
+    // insertions (round 2; semantics unpinned, stated in oracle/extract_oracle.py): a site with ins_len > 0 holds
+    // ins_len bases behind its anchor `pos`; several may share an anchor (after the SNP, before the deletion)
+    const int *ins_len;         // [n_sites]
+    const int *ins_off;         // [n_sites] offset of the inserted bases in ins_bases
+    const uint8_t *ins_bases;
+    int n_ins;
 };
 
 // -------------------------------------------------------------------------------------------
@@ -83,9 +89,31 @@ enum { WALK_OK = 0, WALK_DEAD = 1, WALK_OVERFLOW = 2 };
 struct NoVisitor {
     static constexpr bool kWantsBases = false;     // stretches without a site are skipped in one step
     __device__ void base(int, long long, int, int) {}
+    __device__ void ins_base(int, int, int) {}
     __device__ void took(int) {}
     __device__ void passed(int) {}
 };
+
+// A walk may start inside an insertion anchored at p - 1 (start coordinate p): `pre_site` = that site (or -1),
+// `pre_t` = offset of its first base inside the inserted string.  next_start() steps through the starts of
+// window p in enumeration order: the plain start, then per insertion anchored at p - 1 (site order) t = 0, 1, ...
+struct WalkStart { int site = -1, t = 0; };
+__device__ inline bool next_start(const GraphDev &g, long long p, int i0, WalkStart &ws)
+{
+    if (g.n_ins == 0) return false;
+    int k;
+    if (ws.site < 0) {
+        k = i0 - 1;
+        while (k >= 0 && g.pos[k] == p - 1) --k;      // first site anchored at p - 1
+        ++k;
+    } else {
+        if (ws.t + 1 < g.ins_len[ws.site]) { ++ws.t; return true; }
+        k = ws.site + 1;
+    }
+    for (; k < i0; ++k)
+        if (g.ins_len[k] > 0) { ws.site = k; ws.t = 0; return true; }
+    return false;
+}
 
 // Follows st.choice[0 .. prefix) at the deletions met and does not jump at later ones.  A walk whose
 // last base lies at or beyond `limit` (the region's end) does not exist, like one that runs off the
@@ -93,14 +121,23 @@ struct NoVisitor {
 // the number of allele combinations of the layout.  When the visitor wants bases, walk `q` of the
 // layout is decoded on the way: rem starts as the layout's product and is divided at every SNP.
 template <class V>
-__device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, int prefix, WalkState &st, V &vis,
-                               long long q, long long rem, long long &prod, long long limit)
+__device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, const WalkStart &ws, int prefix,
+                               WalkState &st, V &vis, long long q, long long rem, long long &prod, long long limit)
 {
     constexpr long long kNoSite = 0x7fffffffffffffffll;
     long long x = p;
     int n = 0, d = 0, i = i0;
     long long next_pos = i < g.n_sites ? (long long)g.pos[i] : kNoSite;   // position of site i, kept in a register
     prod = 1;
+    if (ws.site >= 0) {                                // the walk starts on base ws.t of an insertion behind p - 1
+        int take = g.ins_len[ws.site] - ws.t;
+        if (take > W) take = W;
+        if constexpr (V::kWantsBases)
+            for (int j = 0; j < take; ++j) vis.ins_base(j, ws.site, ws.t + j);
+        vis.took(ws.site);
+        n = take;
+        if (n == W) { st.nd = 0; st.last = p - 1; return p <= limit ? WALK_OK : WALK_DEAD; }
+    }
     for (;;) {
         if (x >= g.ref_len) { st.nd = d; return WALK_DEAD; }
         while (next_pos < x) {                         // only after a jump over deleted bases
@@ -124,9 +161,11 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, in
                 continue;
             }
         }
-        int snp = -1, del = -1;
+        int snp = -1, del = -1, ins0 = -1, ins1 = -1;       // insertions anchored here: sites [ins0, ins1)
         for (int k = i; k < g.n_sites && g.pos[k] == x; ++k) {
-            if (g.del_len[k] == 0) snp = k; else del = k;
+            if (g.del_len[k] > 0) del = k;
+            else if (g.ins_len[k] > 0) { if (ins0 < 0) ins0 = k; ins1 = k + 1; }
+            else snp = k;
         }
         int a = 0;
         if (snp >= 0) {
@@ -140,7 +179,24 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, in
         }
         vis.base(n, x, snp, a);
         if (++n == W) { st.nd = d; st.last = x; return x + 1 <= limit ? WALK_OK : WALK_DEAD; }
-        if (del >= 0) {
+        bool read_ins = false;
+        for (int k = ins0; k >= 0 && k < ins1; ++k) {   // read insertion k?  (0 = no, 1 = yes; a yes ends the site)
+            if (d >= kMaxDecisions) { st.nd = d; return WALK_OVERFLOW; }
+            const int c = d < prefix ? st.choice[d] : 0;
+            st.choice[d] = (unsigned char)c;
+            ++d;
+            if (!c) { vis.passed(k); continue; }
+            int take = g.ins_len[k];
+            if (take > W - n) take = W - n;
+            if constexpr (V::kWantsBases)
+                for (int j = 0; j < take; ++j) vis.ins_base(n + j, k, j);
+            vis.took(k);
+            n += take;
+            if (n == W) { st.nd = d; st.last = x; return x + 1 <= limit ? WALK_OK : WALK_DEAD; }
+            read_ins = true;
+            break;
+        }
+        if (del >= 0 && !read_ins) {
             if (d >= kMaxDecisions) { st.nd = d; return WALK_OVERFLOW; }
             const int c = d < prefix ? st.choice[d] : 0;
             st.choice[d] = (unsigned char)c;
@@ -194,10 +250,10 @@ __device__ inline int region_of(const long long *region_off, int n_regions, long
 // one thread per window: first site inside it and the number of walks (product of allele counts)
 __global__ void __launch_bounds__(kCountThreads)
 graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ region_off,
-                   const long long *__restrict__ first_start, int W, long long n_windows,
-                   int *__restrict__ first_site, long long *__restrict__ n_walks, int *__restrict__ win_region,
-                   long long *__restrict__ win_start, int *__restrict__ overflow, int *__restrict__ del_list,
-                   int *__restrict__ del_count)
+                   const long long *__restrict__ first_start, const long long *__restrict__ region_stop, int W,
+                   long long n_windows, int *__restrict__ first_site, long long *__restrict__ n_walks,
+                   int *__restrict__ win_region, long long *__restrict__ win_start, int *__restrict__ overflow,
+                   int *__restrict__ del_list, int *__restrict__ del_count)
 {
     const long long w = (long long)blockIdx.x * kCountThreads + threadIdx.x;
     if (w >= n_windows) return;
@@ -207,9 +263,16 @@ graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ regi
     long long walks = 1;
     bool touches_del = g.n_dels > 0 && cover_deletion(g, p, i0) >= 0;
     for (int i = i0; i < g.n_sites && g.pos[i] < p + W; ++i) {
-        if (g.del_len[i]) touches_del = true;
+        if (g.del_len[i] || g.ins_len[i]) touches_del = true;
         walks *= 1 + g.n_alts[i];
         if (walks > kMaxWalksPerWindow) { walks = 0; atomicMax(overflow, 1); break; }
+    }
+    if (g.n_ins > 0) {
+        for (int k = i0 - 1; k >= 0 && g.pos[k] == p - 1; --k)     // walks that start inside an insertion behind p - 1
+            if (g.ins_len[k] > 0) touches_del = true;
+        // with insertions in the graph the windows run on to the region's last base: beyond E - W only a walk
+        // that reads inserted bases ends inside the region
+        if (!touches_del && p + W > region_stop[r]) walks = 0;
     }
     if (touches_del) {
         // the sites a walk meets depend on the deletions it takes: graph_count_del_kernel enumerates them.
@@ -246,15 +309,20 @@ graph_count_del_kernel(GraphDev g, const int *__restrict__ del_list, const int *
     const int i0 = first_site[w];
     WalkState st;
     NoVisitor nv;
+    WalkStart ws;
     long long walks = 0;
-    int prefix = 0;
-    do {                                             // one pass per layout
-        long long prod = 0;
-        const int rc = simulate(g, p, W, i0, prefix, st, nv, 0, 0, prod, region_stop[win_region[w]]);
-        if (rc == WALK_OK) walks += prod;
-        if (rc == WALK_OVERFLOW || walks > kMaxWalksPerWindow) { walks = 0; atomicMax(overflow, 1); break; }
-        prefix = next_walk(st);
-    } while (prefix >= 0);
+    bool bad = false;
+    do {                                             // per start: one pass per layout
+        int prefix = 0;
+        do {
+            long long prod = 0;
+            const int rc = simulate(g, p, W, i0, ws, prefix, st, nv, 0, 0, prod, region_stop[win_region[w]]);
+            if (rc == WALK_OK) walks += prod;
+            if (rc == WALK_OVERFLOW || walks > kMaxWalksPerWindow) { bad = true; break; }
+            prefix = next_walk(st);
+        } while (prefix >= 0);
+    } while (!bad && next_start(g, p, i0, ws));
+    if (bad) { walks = 0; atomicMax(overflow, 1); }
     n_walks[w] = walks;
     del_walks[m] = walks;
 }
@@ -465,6 +533,13 @@ struct DelEmit {
         fwd[j] = c;
         rev[W - 1 - j] = complement(c);
     }
+    __device__ void ins_base(int j, int site, int t)
+    {
+        const uint8_t c = g.ins_bases[g.ins_off[site] + t];
+        fwd[j] = c;
+        rev[W - 1 - j] = complement(c);
+        alt = true;
+    }
     __device__ void took(int site) { add(site, 1); }
     __device__ void passed(int site) { add(site, 0); }
 };
@@ -493,25 +568,31 @@ graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const in
     const long long t = walk_base[w] + q0;          // its place among all walks
     const long long limit = region_stop[win_region[w]];
     WalkState st;
+    WalkStart ws;
     long long q = q0, prod = 0;
     {
         NoVisitor nv;
-        int prefix = 0;
-        for (;;) {                                   // skip the layouts that lie before walk q0
-            const int rc = simulate(g, p, W, i0, prefix, st, nv, 0, 0, prod, limit);
-            if (rc == WALK_OK) {
-                if (q < prod) break;
-                q -= prod;
+        bool found = false;
+        while (!found) {                             // starts in order, inside a start the layouts in order
+            int prefix = 0;
+            for (;;) {                               // skip the layouts that lie before walk q0
+                const int rc = simulate(g, p, W, i0, ws, prefix, st, nv, 0, 0, prod, limit);
+                if (rc == WALK_OK) {
+                    if (q < prod) { found = true; break; }
+                    q -= prod;
+                }
+                prefix = next_walk(st);
+                if (prefix < 0) break;
             }
-            prefix = next_walk(st);
-            if (prefix < 0) return;                  // cannot happen: q0 < walks of the window
+            if (!found && !next_start(g, p, i0, ws)) return;   // cannot happen: q0 < walks of the window
         }
     }
     uint8_t *fwd = kmers + (size_t)(2 * t) * W;
     DelEmit em{g, fwd, fwd + W, W, 0, {}, {}, false};
     long long again = 0;
-    simulate(g, p, W, i0, st.nd, st, em, q, prod, again, limit);
-    const int cover = cover_deletion(g, p, i0);  // the window starts on deleted bases: carriers lack them
+    simulate(g, p, W, i0, ws, st.nd, st, em, q, prod, again, limit);
+    // the window starts on deleted bases: carriers lack them (not for a walk that never leaves the insertion it starts in)
+    const int cover = (ws.site >= 0 && st.last == p - 1) ? -1 : cover_deletion(g, p, i0);
     if (cover >= 0) em.add(cover, 0);
     const long long count = count_carriers(g, allele_count, em.n_cons,
                                            [&](int k, int &site, int &a) { site = em.csite[k]; a = em.ccode[k]; });
@@ -559,6 +640,8 @@ struct gfm_graph {
     unsigned long long *d_alt_bits = nullptr;
     int *d_allele_count = nullptr;   // [n_sites][4] haplotypes per allele (0 = reference)
     int *d_del_len = nullptr, *d_prev_del = nullptr;
+    int *d_ins_len = nullptr, *d_ins_off = nullptr;
+    uint8_t *d_ins_bases = nullptr;
     // last plan (buffers are kept between plans)
     int n_regions = 0, width = 0;
     long long n_windows = 0, n_walks = 0;
@@ -586,27 +669,44 @@ struct gfm_graph {
 
 GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_sites, const int32_t *h_pos,
                              const uint8_t *h_n_alts, const uint8_t *h_alt_bases, const int32_t *h_del_len,
-                             const uint64_t *h_alt_bits, int32_t n_haplotypes, gfm_graph_t *out)
+                             const int32_t *h_ins_len, const int32_t *h_ins_off, const uint8_t *h_ins_bases,
+                             int64_t ins_bytes, const uint64_t *h_alt_bits, int32_t n_haplotypes, gfm_graph_t *out)
 {
     if (!out) return gfail(GFM_ERR_INVALID, "NULL output handle");
     *out = nullptr;
     if (!h_ref || ref_len <= 0 || n_sites < 0 || n_haplotypes < 0)
         return gfail(GFM_ERR_INVALID, "bad reference / site count");
     if (n_sites && (!h_pos || !h_n_alts || !h_alt_bases)) return gfail(GFM_ERR_INVALID, "NULL site arrays");
-    std::vector<int> del_len((size_t)n_sites, 0), prev_del((size_t)n_sites + 1, -1);
-    int n_dels = 0;
+    std::vector<int> del_len((size_t)n_sites, 0), prev_del((size_t)n_sites + 1, -1), ins_len((size_t)n_sites, 0),
+        ins_off((size_t)n_sites, 0);
+    int n_dels = 0, n_ins = 0;
     long long deleted_until = -1;        // last reference position removed by an earlier deletion
+    auto kind_of = [&](int i) { return del_len[(size_t)i] > 0 ? 2 : (ins_len[(size_t)i] > 0 ? 1 : 0); };
     for (int i = 0; i < n_sites; ++i) {
         const int dl = h_del_len ? h_del_len[i] : 0;
-        const bool tie_ok = i && h_pos[i] == h_pos[i - 1] && dl > 0 && del_len[(size_t)i - 1] == 0;
+        const int il = h_ins_len ? h_ins_len[i] : 0;
+        if (dl < 0 || il < 0 || (dl > 0 && il > 0))
+            return gfail(GFM_ERR_INVALID, "a site is a substitution, an insertion or a deletion (site " + std::to_string(i) + ")");
+        del_len[(size_t)i] = dl;
+        ins_len[(size_t)i] = il;
+        if (il > 0) {
+            const long long off = h_ins_off ? h_ins_off[i] : -1;
+            if (!h_ins_bases || off < 0 || off + il > ins_bytes)
+                return gfail(GFM_ERR_INVALID, "inserted bases outside the pool (site " + std::to_string(i) + ")");
+            ins_off[(size_t)i] = (int)off;
+            ++n_ins;
+        }
+        // same position: the substitution site first, then insertions, then the deletion
+        const bool tie_ok = i && h_pos[i] == h_pos[i - 1] &&
+                            (kind_of(i) > kind_of(i - 1) || (kind_of(i) == 1 && kind_of(i - 1) == 1));
         if (h_pos[i] < 0 || h_pos[i] >= ref_len || (i && h_pos[i] <= h_pos[i - 1] && !tie_ok))
-            return gfail(GFM_ERR_INVALID, "site positions must be ascending inside the reference; only a deletion "
-                                          "may share its anchor with the SNP listed before it (site " +
+            return gfail(GFM_ERR_INVALID, "site positions must be ascending inside the reference; at one position the "
+                                          "substitution site comes first, then insertions, then the deletion (site " +
                                               std::to_string(i) + ")");
         if (h_n_alts[i] < 1 || h_n_alts[i] > kMaxAlts)
             return gfail(GFM_ERR_INVALID, "a site needs 1..3 alternate alleles (site " + std::to_string(i) + ")");
-        if (dl < 0 || (dl > 0 && h_n_alts[i] != 1))
-            return gfail(GFM_ERR_INVALID, "a deletion has one alternate allele and a positive length (site " +
+        if ((dl > 0 || il > 0) && h_n_alts[i] != 1)
+            return gfail(GFM_ERR_INVALID, "an insertion / a deletion has one alternate allele (site " +
                                               std::to_string(i) + ")");
         if (dl > 0) {
             if (h_pos[i] <= deleted_until)
@@ -614,7 +714,6 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
             deleted_until = (long long)h_pos[i] + dl;
             ++n_dels;
         }
-        del_len[(size_t)i] = dl;
         prev_del[(size_t)i + 1] = dl > 0 ? i : prev_del[(size_t)i];
     }
     int n_dev = 0;
@@ -632,6 +731,9 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = upload(&g->d_alt_bases, h_alt_bases, (size_t)n_sites * kMaxAlts);
     if (e == hipSuccess) e = upload(&g->d_del_len, del_len.data(), del_len.size());
     if (e == hipSuccess) e = upload(&g->d_prev_del, prev_del.data(), prev_del.size());
+    if (e == hipSuccess) e = upload(&g->d_ins_len, ins_len.data(), ins_len.size());
+    if (e == hipSuccess) e = upload(&g->d_ins_off, ins_off.data(), ins_off.size());
+    if (e == hipSuccess && n_ins) e = upload(&g->d_ins_bases, h_ins_bases, (size_t)ins_bytes);
     if (e == hipSuccess && bits)
         e = upload(&g->d_alt_bits, reinterpret_cast<const unsigned long long *>(h_alt_bits),
                    (size_t)n_sites * kMaxAlts * hw);
@@ -641,7 +743,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     }
     g->dev = GraphDev{g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
                       bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0,
-                      g->d_del_len, n_dels, g->d_prev_del};
+                      g->d_del_len, n_dels, g->d_prev_del, g->d_ins_len, g->d_ins_off, g->d_ins_bases, n_ins};
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_planned, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_emitted, hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -672,6 +774,7 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     (void)hipFree(g->d_ref); (void)hipFree(g->d_pos); (void)hipFree(g->d_n_alts);
     (void)hipFree(g->d_alt_bases); (void)hipFree(g->d_alt_bits); (void)hipFree(g->d_allele_count);
     (void)hipFree(g->d_del_len); (void)hipFree(g->d_prev_del);
+    (void)hipFree(g->d_ins_len); (void)hipFree(g->d_ins_off); (void)hipFree(g->d_ins_bases);
     if (g->ev_planned) (void)hipEventDestroy(g->ev_planned);
     if (g->ev_emitted) (void)hipEventDestroy(g->ev_emitted);
     delete g;
@@ -698,7 +801,8 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
         const long long e = std::min<long long>(h_stops[r], g->dev.ref_len);
         first[r] = s;
         rstop[r] = e;
-        off[r + 1] = off[r] + std::max<long long>(0, e - width - s + 1);
+        // without insertions the last start is E - W; with them a walk that reads inserted bases may start later
+        off[r + 1] = off[r] + std::max<long long>(0, e - (g->dev.n_ins > 0 ? 1 : width) - s + 1);
     }
     if (n_windows) *n_windows = off[n_regions];
     if (n_rows) *n_rows = 0;
@@ -714,7 +818,7 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     GX_TRY(g->win_region.reserve(nw));
     GX_TRY(g->win_start.reserve(nw));
     GX_TRY(g->walk_base.reserve(nw + 1));
-    const bool dels = g->dev.n_dels > 0;
+    const bool dels = g->dev.n_dels > 0 || g->dev.n_ins > 0;   // windows that need the layout enumeration
     GX_TRY(g->del_list.reserve(dels ? nw : 1));
     GX_TRY(g->del_walks.reserve(dels ? nw : 1));
     GX_TRY(g->del_base.reserve(dels ? nw + 1 : 1));
@@ -731,7 +835,7 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     // overflow flag come back
     const unsigned blocks = (unsigned)((nw + kCountThreads - 1) / kCountThreads);
     hipLaunchKernelGGL(graph_count_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->dev, n_regions,
-                       g->region_off.p, g->first_start.p, width, (long long)nw, g->first_site.p, g->walks.p,
+                       g->region_off.p, g->first_start.p, g->region_stop.p, width, (long long)nw, g->first_site.p, g->walks.p,
                        g->win_region.p, g->win_start.p, g->flag.p, g->del_list.p, g->flag.p + 1);
     GX_TRY(hipGetLastError());
     if (dels) {   // the grid covers every window; the kernel reads the real number of listed windows

@@ -2,10 +2,12 @@
 //
 // The reference never reads a VCF itself: `grafimo buildvg` hands it to `vg construct` / `vg index -G`
 // (src/grafimo/constructVG.py:332,394).  For the extraction kernels (graph_extract.hip) the records
-// of one chromosome become: SNP sites (REF and every ALT one base of ACGT, at most 3 ALTs), deletions
-// (REF = anchor + deleted bases, one ALT = the anchor), everything else skipped and counted, as are
-// a second SNP record at one position and a deletion that touches one accepted before it -- the
-// rules oracle/extract_oracle.py read_vcf_graph states.  Genotypes: two haplotypes per sample in
+// of one chromosome are taken apart per ALT allele: single-base substitutions (one site per position, up
+// to 3 alternates, also when they come from several records), insertions (REF = anchor, ALT = anchor +
+// inserted bases), deletions (REF = anchor + deleted bases, ALT = anchor; one that touches a deletion
+// accepted before it is skipped), multi-base substitutions of equal length (one substitution per
+// mismatching position); everything else is skipped and counted -- the rules
+// oracle/extract_oracle.py read_vcf_variants states.  Genotypes: two haplotypes per sample in
 // file order ("a|b", "a/b" taken as written, a single allele doubled, "." = reference); per
 // alternate allele one bitset over the haplotypes, bit h of word h / 64.
 // Plain text is mmap'ed, .gz goes through zlib (any gzip/bgzip stream); lines are parsed by a small
@@ -36,20 +38,27 @@ namespace {
 
 constexpr int kMaxAlts = 3;
 
-struct Rec {
+// One alternate allele of a record, taken apart (oracle/extract_oracle.py read_vcf_variants states the rules):
+// kind 0 a single-base substitution at `pos`, 1 an insertion behind the anchor `pos`, 2 a deletion behind it.
+// A multi-base substitution of equal length yields one kind-0 atom per mismatching position.
+struct Atom {
     int64_t pos = 0;          // 0-based
-    uint8_t kind = 0;         // 0 SNP, 1 deletion, 2 skipped
-    uint8_t n_alts = 0;
-    uint8_t alt[kMaxAlts] = {0, 0, 0};
+    uint8_t kind = 0;
+    uint8_t base = 0;         // substitution: the alternate base
     int32_t del_len = 0;
-    size_t bits_at = 0;       // offset (words) of this record's [3][hw] block in its chunk's bit store
+    int32_t ins_len = 0;
+    size_t ins_at = 0;        // offset of the inserted bases in the chunk's pool
+    size_t bits_at = 0;       // offset (words) of the allele's carrier bitset [hw] in the chunk's bit store
 };
 
 struct Chunk {
-    std::vector<Rec> recs;
+    std::vector<Atom> atoms;
+    std::vector<int64_t> rec_pos;      // position of every record seen (sortedness check)
     std::vector<uint64_t> bits;
+    std::vector<uint8_t> ins_pool;
     std::vector<uint8_t> alleles;      // scratch of parse_line, reused from line to line
     int n_hap = -1;
+    int64_t skipped = 0;
     std::string error;
 };
 
@@ -63,7 +72,7 @@ inline bool is_base(char c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T
 inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
 
 // one data line [b, e) of the wanted chromosome
-void parse_line(const char *b, const char *e, bool want_hap, int hw_hint, Chunk &out)
+void parse_line(const char *b, const char *e, bool want_hap, Chunk &out)
 {
     const char *f[10];
     const char *p = b;
@@ -76,37 +85,52 @@ void parse_line(const char *b, const char *e, bool want_hap, int hw_hint, Chunk 
     }
     if (nf < 5) { out.error = "VCF line with fewer than 5 columns"; return; }
     auto fe = [&](int k) { return field_end(f[k], e); };
-    Rec r;
-    r.pos = strtoll(f[1], nullptr, 10) - 1;
+    const int64_t pos = strtoll(f[1], nullptr, 10) - 1;
+    out.rec_pos.push_back(pos);
     const char *ref_b = f[3], *ref_e = fe(3), *alt_b = f[4], *alt_e = fe(4);
     const long ref_len = (long)(ref_e - ref_b);
+    bool ref_ok = ref_len > 0;
+    for (const char *q = ref_b; q < ref_e && ref_ok; ++q) ref_ok = is_base(up(*q)) || up(*q) == 'N';
     // ALT list
-    const char *ab[8];
-    long al[8];
+    const char *ab[16];
+    long al[16];
     int na = 0;
-    for (const char *q = alt_b; q <= alt_e && na < 8;) {
+    for (const char *q = alt_b; q <= alt_e;) {
         const char *c = static_cast<const char *>(memchr(q, ',', (size_t)(alt_e - q)));
         const char *qe = c ? c : alt_e;
-        ab[na] = q; al[na] = (long)(qe - q); ++na;
+        if (na < 16) { ab[na] = q; al[na] = (long)(qe - q); }
+        ++na;
         if (!c) break;
         q = c + 1;
     }
-    bool snp = ref_len == 1 && na >= 1 && na <= kMaxAlts;
-    for (int k = 0; snp && k < na; ++k) snp = al[k] == 1 && is_base(up(ab[k][0]));
-    const bool del = !snp && ref_len > 1 && na == 1 && al[0] == 1 && up(ab[0][0]) == up(ref_b[0]);
-    if (snp) {
-        r.kind = 0;
-        r.n_alts = (uint8_t)na;
-        for (int k = 0; k < na; ++k) r.alt[k] = (uint8_t)up(ab[k][0]);
-    } else if (del) {
-        r.kind = 1;
-        r.n_alts = 1;
-        r.del_len = (int32_t)(ref_len - 1);
-    } else {
-        r.kind = 2;
-        out.recs.push_back(r);
-        return;
+    // what every ALT is
+    const size_t first_atom = out.atoms.size();
+    int allele_of_atom[kMaxAlts * 64];
+    int n_new = 0;
+    for (int k = 0; k < na; ++k) {
+        bool ok = ref_ok && k < kMaxAlts && k < 16 && al[k] > 0;
+        for (long j = 0; ok && j < al[k]; ++j) ok = is_base(up(ab[k][j]));
+        if (ok && ref_len == 1 && al[k] == 1) {
+            Atom a; a.pos = pos; a.kind = 0; a.base = (uint8_t)up(ab[k][0]);
+            out.atoms.push_back(a); allele_of_atom[n_new++] = k;
+        } else if (ok && ref_len > 1 && al[k] == 1 && up(ab[k][0]) == up(ref_b[0])) {
+            Atom a; a.pos = pos; a.kind = 2; a.del_len = (int32_t)(ref_len - 1);
+            out.atoms.push_back(a); allele_of_atom[n_new++] = k;
+        } else if (ok && ref_len == 1 && al[k] > 1 && up(ab[k][0]) == up(ref_b[0])) {
+            Atom a; a.pos = pos; a.kind = 1; a.ins_len = (int32_t)(al[k] - 1); a.ins_at = out.ins_pool.size();
+            for (long j = 1; j < al[k]; ++j) out.ins_pool.push_back((uint8_t)up(ab[k][j]));
+            out.atoms.push_back(a); allele_of_atom[n_new++] = k;
+        } else if (ok && ref_len == al[k] && ref_len > 1) {
+            for (long j = 0; j < ref_len && n_new < kMaxAlts * 64; ++j)
+                if (up(ref_b[j]) != up(ab[k][j])) {
+                    Atom a; a.pos = pos + j; a.kind = 0; a.base = (uint8_t)up(ab[k][j]);
+                    out.atoms.push_back(a); allele_of_atom[n_new++] = k;
+                }
+        } else {
+            ++out.skipped;
+        }
     }
+    if (n_new == 0) return;
     if (want_hap && nf == 10) {
         // genotype columns start at f[9]; count haplotypes on the first record of the chunk
         std::vector<uint8_t> &alleles = out.alleles;
@@ -141,15 +165,20 @@ void parse_line(const char *b, const char *e, bool want_hap, int hw_hint, Chunk 
         if (out.n_hap < 0) out.n_hap = H;
         if (H != out.n_hap) { out.error = "VCF records with different numbers of samples"; return; }
         const int hw = (H + 63) / 64;
-        r.bits_at = out.bits.size();
-        out.bits.resize(out.bits.size() + (size_t)kMaxAlts * hw, 0ull);
-        uint64_t *dst = out.bits.data() + r.bits_at;
-        for (int h = 0; h < H; ++h) {
-            const int a = alleles[(size_t)h];
-            if (a >= 1 && a <= kMaxAlts && a <= r.n_alts) dst[(size_t)(a - 1) * hw + (h >> 6)] |= 1ull << (h & 63);
+        // one carrier bitset per ALT of the record that yielded atoms; the atoms of one ALT share it
+        size_t at_of_allele[kMaxAlts] = {(size_t)-1, (size_t)-1, (size_t)-1};
+        for (int t = 0; t < n_new; ++t) {
+            const int k = allele_of_atom[t];
+            if (at_of_allele[k] == (size_t)-1) {
+                at_of_allele[k] = out.bits.size();
+                out.bits.resize(out.bits.size() + (size_t)hw, 0ull);
+                uint64_t *dst = out.bits.data() + at_of_allele[k];
+                for (int h = 0; h < H; ++h)
+                    if (alleles[(size_t)h] == k + 1 && k + 1 <= na) dst[h >> 6] |= 1ull << (h & 63);
+            }
+            out.atoms[first_atom + (size_t)t].bits_at = at_of_allele[k];
         }
     }
-    out.recs.push_back(r);
 }
 
 // the bytes of the file: plain text is mapped, gzip / bgzip is inflated into `store`
@@ -194,8 +223,8 @@ bool read_all(const char *path, std::string &store, const char **data, size_t *s
 }  // namespace
 
 struct gfm_vcf {
-    std::vector<int32_t> pos, del_len;
-    std::vector<uint8_t> n_alts, alt_bases;
+    std::vector<int32_t> pos, del_len, ins_len, ins_off;
+    std::vector<uint8_t> n_alts, alt_bases, ins_bases;
     std::vector<uint64_t> bits;      // [n][3][hw]
     int n_hap = 0;
     int64_t skipped = 0;
@@ -236,8 +265,7 @@ GFM_API int gfm_vcf_open(const char *path, const char *chrom, int with_haplotype
             Chunk &c = chunks[(size_t)t];
             const size_t lo = (size_t)t * per, hi = std::min(lines.size(), lo + per);
             for (size_t k = lo; k < hi && c.error.empty(); ++k)
-                parse_line(data + lines[k].first, data + lines[k].second, with_haplotypes != 0,
-                           c.n_hap > 0 ? (c.n_hap + 63) / 64 : 0, c);
+                parse_line(data + lines[k].first, data + lines[k].second, with_haplotypes != 0, c);
         });
     for (auto &th : pool) th.join();
     int H = -1;
@@ -249,56 +277,115 @@ GFM_API int gfm_vcf_open(const char *path, const char *chrom, int with_haplotype
         }
     }
     if (H < 0) H = 0;
+    int64_t prev_pos = -1;
+    for (auto &c : chunks)
+        for (int64_t rp : c.rec_pos) {
+            if (rp < prev_pos) {
+                gfm_set_error_("VCF records of the chromosome are not sorted by position");
+                return GFM_ERR_IO;
+            }
+            prev_pos = rp;
+        }
     gfm_vcf *v = new (std::nothrow) gfm_vcf();
     if (!v) { gfm_set_error_("out of host memory"); return GFM_ERR_NOMEM; }
     v->n_hap = with_haplotypes ? H : 0;
     const int hw = (v->n_hap + 63) / 64;
-    // acceptance rules in file order, then (pos, kind) order: a deletion follows the SNP at its anchor
+    // atoms in (position, kind) order -- substitution < insertion < deletion, file order inside a tie
     struct Ref { int chunk; size_t idx; };
-    std::vector<Ref> keep;
-    int64_t last_snp = -1, deleted_until = -1, prev_pos = -1;
-    bool sorted = true;
-    for (int c = 0; c < nt; ++c)
-        for (size_t k = 0; k < chunks[(size_t)c].recs.size(); ++k) {
-            const Rec &r = chunks[(size_t)c].recs[k];
-            if (r.kind == 0 && r.pos != last_snp) {
-                last_snp = r.pos;
-            } else if (r.kind == 1 && r.pos > deleted_until) {
-                deleted_until = r.pos + r.del_len;
-            } else {
-                ++v->skipped;
-                continue;
-            }
-            if (r.pos < prev_pos) sorted = false;
-            prev_pos = r.pos;
-            keep.push_back({c, k});
-        }
-    if (!sorted) {
-        delete v;
-        gfm_set_error_("VCF records of the chromosome are not sorted by position");
-        return GFM_ERR_IO;
+    std::vector<Ref> order;
+    for (int c = 0; c < nt; ++c) {
+        v->skipped += chunks[(size_t)c].skipped;
+        for (size_t k = 0; k < chunks[(size_t)c].atoms.size(); ++k) order.push_back({c, k});
     }
-    std::stable_sort(keep.begin(), keep.end(), [&](const Ref &a, const Ref &b) {
-        const Rec &ra = chunks[(size_t)a.chunk].recs[a.idx], &rb = chunks[(size_t)b.chunk].recs[b.idx];
+    auto atom = [&](const Ref &r) -> const Atom & { return chunks[(size_t)r.chunk].atoms[r.idx]; };
+    std::stable_sort(order.begin(), order.end(), [&](const Ref &a, const Ref &b) {
+        const Atom &ra = atom(a), &rb = atom(b);
         return ra.pos != rb.pos ? ra.pos < rb.pos : ra.kind < rb.kind;
     });
-    const size_t n = keep.size();
-    v->pos.resize(n); v->del_len.resize(n); v->n_alts.resize(n); v->alt_bases.assign(n * kMaxAlts, 0);
-    if (hw) v->bits.assign(n * (size_t)kMaxAlts * hw, 0ull);
-    for (size_t i = 0; i < n; ++i) {
-        const Chunk &c = chunks[(size_t)keep[i].chunk];
-        const Rec &r = c.recs[keep[i].idx];
-        v->pos[i] = (int32_t)r.pos;
-        v->del_len[i] = r.del_len;
-        v->n_alts[i] = r.n_alts;
-        for (int a = 0; a < kMaxAlts; ++a) v->alt_bases[i * kMaxAlts + a] = r.alt[a];
-        if (hw && !c.bits.empty())
-            memcpy(v->bits.data() + i * (size_t)kMaxAlts * hw, c.bits.data() + r.bits_at, sizeof(uint64_t) * kMaxAlts * hw);
+    auto add_site = [&](int64_t pos, int dl, int il, size_t ioff) {
+        v->pos.push_back((int32_t)pos);
+        v->del_len.push_back(dl);
+        v->ins_len.push_back(il);
+        v->ins_off.push_back((int32_t)ioff);
+        v->n_alts.push_back(0);
+        v->alt_bases.insert(v->alt_bases.end(), kMaxAlts, (uint8_t)0);
+        if (hw) v->bits.insert(v->bits.end(), (size_t)kMaxAlts * hw, 0ull);
+    };
+    auto or_bits = [&](size_t site, int slot, const Ref &r) {
+        if (!hw) return;
+        const Chunk &c = chunks[(size_t)r.chunk];
+        if (c.bits.empty()) return;
+        uint64_t *dst = v->bits.data() + (site * kMaxAlts + (size_t)slot) * hw;
+        const uint64_t *src = c.bits.data() + atom(r).bits_at;
+        for (int w = 0; w < hw; ++w) dst[w] |= src[w];
+    };
+    int64_t busy = -1;
+    for (const Ref &r : order) {
+        const Atom &a = atom(r);
+        const size_t n = v->pos.size();
+        if (a.kind == 0) {
+            if (n && v->pos[n - 1] == a.pos && v->del_len[n - 1] == 0 && v->ins_len[n - 1] == 0) {
+                // one site per position: another alternate, or more carriers of one it already has
+                const size_t s = n - 1;
+                int slot = -1;
+                for (int k = 0; k < v->n_alts[s]; ++k)
+                    if (v->alt_bases[s * kMaxAlts + k] == a.base) slot = k;
+                if (slot < 0) {
+                    if (v->n_alts[s] >= kMaxAlts) { ++v->skipped; continue; }
+                    slot = v->n_alts[s]++;
+                    v->alt_bases[s * kMaxAlts + slot] = a.base;
+                }
+                or_bits(s, slot, r);
+            } else {
+                add_site(a.pos, 0, 0, 0);
+                v->n_alts[n] = 1;
+                v->alt_bases[n * kMaxAlts] = a.base;
+                or_bits(n, 0, r);
+            }
+        } else if (a.kind == 1) {
+            const uint8_t *seq = chunks[(size_t)r.chunk].ins_pool.data() + a.ins_at;
+            size_t dup = (size_t)-1;
+            for (size_t s = n; s-- > 0 && v->pos[s] == a.pos;)
+                if (v->ins_len[s] == a.ins_len && memcmp(v->ins_bases.data() + v->ins_off[s], seq, (size_t)a.ins_len) == 0)
+                    dup = s;
+            if (dup != (size_t)-1) {
+                or_bits(dup, 0, r);
+            } else {
+                add_site(a.pos, 0, a.ins_len, v->ins_bases.size());
+                v->ins_bases.insert(v->ins_bases.end(), seq, seq + a.ins_len);
+                v->n_alts[n] = 1;
+                or_bits(n, 0, r);
+            }
+        } else {
+            if (a.pos > busy) {
+                add_site(a.pos, a.del_len, 0, 0);
+                v->n_alts[n] = 1;
+                or_bits(n, 0, r);
+                busy = a.pos + a.del_len;
+            } else {
+                ++v->skipped;
+            }
+        }
     }
-    if (n_sites) *n_sites = (int64_t)n;
+    if (n_sites) *n_sites = (int64_t)v->pos.size();
     if (n_haplotypes) *n_haplotypes = v->n_hap;
     if (n_skipped) *n_skipped = v->skipped;
     *out = v;
+    return GFM_OK;
+}
+
+GFM_API int64_t gfm_vcf_ins_bytes(gfm_vcf_t v) { return v ? (int64_t)v->ins_bases.size() : 0; }
+
+GFM_API int gfm_vcf_read_insertions(gfm_vcf_t v, int32_t *ins_len, int32_t *ins_off, uint8_t *ins_bases)
+{
+    if (!v) { gfm_set_error_("VCF handle is NULL"); return GFM_ERR_INVALID; }
+    const size_t n = v->pos.size();
+    if (n && (!ins_len || !ins_off)) { gfm_set_error_("NULL output buffer"); return GFM_ERR_INVALID; }
+    if (n) {
+        memcpy(ins_len, v->ins_len.data(), sizeof(int32_t) * n);
+        memcpy(ins_off, v->ins_off.data(), sizeof(int32_t) * n);
+    }
+    if (ins_bases && !v->ins_bases.empty()) memcpy(ins_bases, v->ins_bases.data(), v->ins_bases.size());
     return GFM_OK;
 }
 

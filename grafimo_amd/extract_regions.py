@@ -85,13 +85,20 @@ class GraphIndex:
     alternate allele, the bitset of haplotypes that carry it."""
 
     def __init__(self, chrom: str, ref: np.ndarray, pos, n_alts, alt_bases, alt_bits, n_haplotypes: int,
-                 skipped: int = 0, del_len=None):
+                 skipped: int = 0, del_len=None, ins_len=None, ins_off=None, ins_bases=None):
         self.chrom = chrom
         self.ref = np.ascontiguousarray(ref, dtype=np.uint8)
         self.pos = np.ascontiguousarray(pos, dtype=np.int32)
         # 0 for a SNP site; for a deletion the number of bases removed after the anchor `pos`
         self.del_len = (np.zeros(len(self.pos), dtype=np.int32) if del_len is None
                         else np.ascontiguousarray(del_len, dtype=np.int32))
+        # > 0 for an insertion site: that many bases of ins_bases[ins_off ..] sit behind the anchor `pos`
+        self.ins_len = (np.zeros(len(self.pos), dtype=np.int32) if ins_len is None
+                        else np.ascontiguousarray(ins_len, dtype=np.int32))
+        self.ins_off = (np.zeros(len(self.pos), dtype=np.int32) if ins_off is None
+                        else np.ascontiguousarray(ins_off, dtype=np.int32))
+        self.ins_bases = (np.zeros(0, dtype=np.uint8) if ins_bases is None
+                          else np.ascontiguousarray(ins_bases, dtype=np.uint8))
         self.n_alts = np.ascontiguousarray(n_alts, dtype=np.uint8)
         self.alt_bases = np.ascontiguousarray(alt_bases, dtype=np.uint8).reshape(len(self.pos), MAX_ALTS)
         self.n_haplotypes = int(n_haplotypes)
@@ -127,22 +134,29 @@ class GraphIndex:
             bits = np.empty((V, MAX_ALTS, hw), dtype=np.uint64) if hw else None
             nv.check(nv.lib().gfm_vcf_read(h, nv.ptr(pos), nv.ptr(n_alts), nv.ptr(alt_bases), nv.ptr(del_len),
                                            nv.ptr(bits) if bits is not None else None))
+            ins_len = np.empty(V, dtype=np.int32)
+            ins_off = np.empty(V, dtype=np.int32)
+            ins_bases = np.empty(int(nv.lib().gfm_vcf_ins_bytes(h)), dtype=np.uint8)
+            nv.check(nv.lib().gfm_vcf_read_insertions(h, nv.ptr(ins_len), nv.ptr(ins_off),
+                                                      nv.ptr(ins_bases) if len(ins_bases) else None))
         finally:
             nv.lib().gfm_vcf_close(h)
         if int(skipped.value) and not allow_skipped:
             raise VGError(
-                f"\n\nERROR: {int(skipped.value)} VCF record(s) on {chrom} are insertions, multi-base substitutions or "
-                f"deletions overlapping an earlier one. The extraction graph does not model them, so the k-mers would "
-                f"differ from `vg find`'s. Pass allow_skipped=True (CLI: --skip-unmodelled-variants) to leave them out "
-                f"knowingly.\n")
+                f"\n\nERROR: {int(skipped.value)} ALT allele(s) on {chrom} are complex (neither a substitution, an "
+                f"insertion behind an anchor base, a plain deletion nor an equal-length multi-base substitution), a "
+                f"fourth alternate at one position, or a deletion overlapping an earlier one. The extraction graph does "
+                f"not model them, so the k-mers would differ from `vg find`'s. Pass allow_skipped=True (CLI: "
+                f"--skip-unmodelled-variants) to leave them out knowingly.\n")
         if int(skipped.value):
-            print(f"WARNING: {int(skipped.value)} VCF record(s) on {chrom} (insertions, MNPs, overlapping deletions) are "
-                  f"NOT part of the graph: k-mers through them are missing and their neighbours keep the reference "
-                  f"allele.", file=sys.stderr)
+            print(f"WARNING: {int(skipped.value)} ALT allele(s) on {chrom} (complex alleles, a fourth alternate, "
+                  f"overlapping deletions) are NOT part of the graph: k-mers through them are missing and their "
+                  f"neighbours keep the reference allele.", file=sys.stderr)
         if V == 0:
             print(f"WARNING: no usable VCF record for chromosome {chrom!r} in {vcf}: the graph is the bare reference "
                   f"(do the chromosome names of the VCF and the FASTA match?)", file=sys.stderr)
-        return cls(chrom, ref, pos, n_alts, alt_bases, bits, int(H.value), int(skipped.value), del_len=del_len)
+        return cls(chrom, ref, pos, n_alts, alt_bases, bits, int(H.value), int(skipped.value), del_len=del_len,
+                   ins_len=ins_len, ins_off=ins_off, ins_bases=ins_bases)
 
     # ---- on disk (what a `buildvg` step leaves for scan_graph; numpy .npz, no pickles)
     def save(self, path: str) -> str:
@@ -150,7 +164,8 @@ class GraphIndex:
             path += INDEX_SUFFIX
         np.savez_compressed(path, chrom=np.array(self.chrom), ref=self.ref, pos=self.pos, del_len=self.del_len,
                             n_alts=self.n_alts, alt_bases=self.alt_bases, n_haplotypes=np.int64(self.n_haplotypes),
-                            skipped=np.int64(self.skipped),
+                            skipped=np.int64(self.skipped), ins_len=self.ins_len, ins_off=self.ins_off,
+                            ins_bases=self.ins_bases,
                             alt_bits=self.alt_bits if self.alt_bits is not None else np.empty(0, np.uint64))
         return path
 
@@ -159,25 +174,35 @@ class GraphIndex:
         with np.load(path, allow_pickle=False) as z:
             bits = z["alt_bits"] if z["alt_bits"].size else None
             return cls(str(z["chrom"]), z["ref"], z["pos"], z["n_alts"], z["alt_bases"], bits, int(z["n_haplotypes"]),
-                       int(z["skipped"]), del_len=z["del_len"])
+                       int(z["skipped"]), del_len=z["del_len"], ins_len=z["ins_len"], ins_off=z["ins_off"],
+                       ins_bases=z["ins_bases"])
 
     # ---- node ids of `vg construct` on this graph (column 7 of the TSV; not used by GRAFIMO's scoring)
     def _node_table(self):
         """The reference is cut at every SNP (the site is a node of its own: alternates numbered first,
-        then the reference allele) and at both ends of every deleted stretch; what lies between two
-        cuts is chopped into nodes of at most NODE_MAX bases (all of it pinned by the node paths of the
-        reference's two fixtures)."""
+        then the reference allele), at both ends of every deleted stretch and behind the anchor of every
+        insertion; what lies between two cuts is chopped into nodes of at most NODE_MAX bases (pinned by the
+        node paths of the reference's two fixtures as far as SNPs and deletions go).  The nodes of an
+        insertion are numbered right behind the reference interval that ends with its anchor -- vg's real
+        numbering around insertions is not known (unpinned)."""
         if self._nodes is None:
-            snp = self.del_len == 0
+            snp = (self.del_len == 0) & (self.ins_len == 0)
+            dele = self.del_len > 0
             cuts = {0, len(self.ref)}
             for p in self.pos[snp].tolist():
                 cuts.update((p, p + 1))
-            for p, ln in zip(self.pos[~snp].tolist(), self.del_len[~snp].tolist()):
+            for p, ln in zip(self.pos[dele].tolist(), self.del_len[dele].tolist()):
                 cuts.update((p + 1, p + ln + 1))
+            for p in self.pos[self.ins_len > 0].tolist():
+                cuts.add(p + 1)
             cuts = np.array(sorted(c for c in cuts if 0 <= c <= len(self.ref)), dtype=np.int64)
-            snp_site = {int(p): i for i, p in enumerate(self.pos.tolist()) if self.del_len[i] == 0}
+            snp_site = {int(p): i for i, p in enumerate(self.pos.tolist()) if snp[i]}
+            ins_behind: Dict[int, List[int]] = {}
+            for i in np.nonzero(self.ins_len > 0)[0].tolist():
+                ins_behind.setdefault(int(self.pos[i]) + 1, []).append(i)
             first = np.zeros(len(cuts) - 1, dtype=np.int64)      # id of the first node of the interval
             site_of = np.full(len(cuts) - 1, -1, dtype=np.int64)  # SNP intervals: their site
+            ins_first: Dict[int, int] = {}                        # insertion site -> id of its first node
             nid = 1
             for j in range(len(cuts) - 1):
                 b, e = int(cuts[j]), int(cuts[j + 1])
@@ -189,11 +214,14 @@ class GraphIndex:
                 else:
                     first[j] = nid
                     nid += -(-(e - b) // NODE_MAX)
-            self._nodes = (cuts, first, site_of)
+                for i in ins_behind.get(e, ()):
+                    ins_first[i] = nid
+                    nid += -(-int(self.ins_len[i]) // NODE_MAX)
+            self._nodes = (cuts, first, site_of, ins_first)
         return self._nodes
 
     def _node_at(self, x: int, allele: int = 0) -> int:
-        cuts, first, site_of = self._node_table()
+        cuts, first, site_of, _ = self._node_table()
         j = int(np.searchsorted(cuts, x, side="right")) - 1
         i = int(site_of[j])
         if i >= 0:
@@ -201,10 +229,17 @@ class GraphIndex:
         return int(first[j]) + (x - int(cuts[j])) // NODE_MAX
 
     def touches_deletion(self, p: int, width: int) -> bool:
+        """True for the windows the kernels enumerate layout by layout: a deletion or an insertion inside
+        [p, p + W), a start on deleted bases, an insertion anchored at p - 1."""
         i0 = int(np.searchsorted(self.pos, p, side="left"))
         i1 = int(np.searchsorted(self.pos, p + width, side="left"))
-        if self.del_len[i0:i1].any():
+        if self.del_len[i0:i1].any() or self.ins_len[i0:i1].any():
             return True
+        k = i0 - 1
+        while k >= 0 and int(self.pos[k]) == p - 1:
+            if self.ins_len[k] > 0:
+                return True
+            k -= 1
         if self._dels is None:
             d = np.nonzero(self.del_len)[0]
             self._dels = (self.pos[d].astype(np.int64), self.pos[d].astype(np.int64) + self.del_len[d])
@@ -225,14 +260,17 @@ class GraphIndex:
         return i0, alleles
 
     def window_walks(self, p: int, width: int, stop_limit: Optional[int] = None):
-        """Yields, in the enumeration order of the extraction kernel, the walks of window p as
-        [(reference position, SNP allele)] per base: mixed radix (last site fastest) for plain windows;
-        for windows that touch a deletion layout-major: the jump vectors (at a deletion's anchor 0 = stay on
-        the reference, 1 = jump; a jump needs a landing position inside the chromosome) in lexicographic
-        order, and on one layout the mixed radix of its SNPs."""
+        """Yields, in the enumeration order of the extraction kernel, the walks of window p, per base either
+        (reference position, SNP allele) or ("ins", site, offset): mixed radix (last site fastest) for plain
+        windows; for windows that touch a deletion or an insertion layout-major: the decision vectors (behind
+        the base at x: read insertion k anchored at x? -- a yes ends the site -- then: jump the deletion
+        anchored at x?; 0 before 1) in lexicographic order, on one layout the mixed radix of its SNPs; starts
+        inside an insertion anchored at p - 1 follow the plain start (site order, offsets ascending)."""
         if not self.touches_deletion(p, width):
             i0 = int(np.searchsorted(self.pos, p, side="left"))
             i1 = int(np.searchsorted(self.pos, p + width, side="left"))
+            if p + width > (len(self.ref) if stop_limit is None else min(int(stop_limit), len(self.ref))):
+                return
             site_pos = [int(x) for x in self.pos[i0:i1]]
             radix = [1 + int(n) for n in self.n_alts[i0:i1]]
             total = int(np.prod(radix)) if radix else 1
@@ -249,23 +287,57 @@ class GraphIndex:
                 self._site_at.setdefault(x, []).append(i)
         site_at = self._site_at
         limit = len(self.ref) if stop_limit is None else min(int(stop_limit), len(self.ref))
+        L = len(self.ref)
 
-        def layouts(x, used):
-            if x >= len(self.ref):
+        def layouts(x, plan):
+            """plan: per window base a reference position or ("ins", site, offset)"""
+            if x >= L:
                 return
-            used = used + [x]
-            if len(used) == width:
+            plan = plan + [x]
+            if len(plan) == width:
                 if x + 1 <= limit:                     # a walk ends inside the region, like it starts there
-                    yield used
+                    yield plan
                 return
-            yield from layouts(x + 1, used)
-            dele = next((i for i in site_at.get(x, ()) if self.del_len[i] > 0), None)
-            if dele is not None:
-                yield from layouts(x + int(self.del_len[dele]) + 1, used)
+            here = site_at.get(x, ())
+            ins = [i for i in here if self.ins_len[i] > 0]
+            dele = next((i for i in here if self.del_len[i] > 0), None)
 
-        for used in layouts(p, []):                     # layout-major, like the kernel
-            snps = [(x, next(i for i in site_at[x] if self.del_len[i] == 0)) for x in used
-                    if any(self.del_len[i] == 0 for i in site_at.get(x, ()))]
+            def after(k):
+                if k == len(ins):
+                    yield from layouts(x + 1, plan)
+                    if dele is not None:
+                        yield from layouts(x + int(self.del_len[dele]) + 1, plan)
+                    return
+                yield from after(k + 1)
+                i = ins[k]
+                take = min(int(self.ins_len[i]), width - len(plan))
+                plan2 = plan + [("ins", i, t) for t in range(take)]
+                if len(plan2) == width:
+                    if x + 1 <= limit:
+                        yield plan2
+                else:
+                    yield from layouts(x + 1, plan2)
+
+            yield from after(0)
+
+        def starts():
+            yield from layouts(p, [])
+            for i in site_at.get(p - 1, ()):
+                if self.ins_len[i] <= 0:
+                    continue
+                for t in range(int(self.ins_len[i])):
+                    take = min(int(self.ins_len[i]) - t, width)
+                    plan = [("ins", i, t + j) for j in range(take)]
+                    if take == width:
+                        if p <= limit:
+                            yield plan
+                    else:
+                        yield from layouts(p, plan)
+
+        is_snp = lambda i: self.del_len[i] == 0 and self.ins_len[i] == 0
+        for plan in starts():                           # layout-major, like the kernel
+            snps = [(x, next(i for i in site_at[x] if is_snp(i))) for x in plan
+                    if not isinstance(x, tuple) and any(is_snp(i) for i in site_at.get(x, ()))]
             radix = [1 + int(self.n_alts[i]) for _, i in snps]
             total = int(np.prod(radix)) if radix else 1
             for q in range(total):
@@ -273,7 +345,7 @@ class GraphIndex:
                 for k in range(len(radix) - 1, -1, -1):
                     at[snps[k][0]] = qq % radix[k]
                     qq //= radix[k]
-                yield [(x, at.get(x, 0)) for x in used]
+                yield [x if isinstance(x, tuple) else (x, at.get(x, 0)) for x in plan]
 
     def walk_bases(self, p: int, width: int, walk: int) -> List[Tuple[int, int]]:
         for q, bases in enumerate(self.window_walks(p, width)):
@@ -281,10 +353,14 @@ class GraphIndex:
                 return bases
         raise IndexError(f"window {p} has no walk {walk}")
 
-    def nodes_of(self, bases: List[Tuple[int, int]]) -> List[int]:
+    def nodes_of(self, bases) -> List[int]:
         out: List[int] = []
-        for x, a in bases:
-            nid = self._node_at(x, a)
+        ins_first = self._node_table()[3]
+        for b in bases:
+            if b[0] == "ins":
+                nid = ins_first[b[1]] + b[2] // NODE_MAX
+            else:
+                nid = self._node_at(b[0], b[1])
             if not out or out[-1] != nid:
                 out.append(nid)
         return out
@@ -320,7 +396,8 @@ class DeviceGraph:
         with torch.cuda.device(self.device):
             nv.check(nv.lib().gfm_graph_create(
                 nv.ptr(index.ref), len(index.ref), len(index.pos), nv.ptr(index.pos), nv.ptr(index.n_alts),
-                nv.ptr(index.alt_bases), nv.ptr(index.del_len),
+                nv.ptr(index.alt_bases), nv.ptr(index.del_len), nv.ptr(index.ins_len), nv.ptr(index.ins_off),
+                nv.ptr(index.ins_bases) if len(index.ins_bases) else None, len(index.ins_bases),
                 nv.ptr(index.alt_bits) if index.alt_bits is not None else None,
                 index.n_haplotypes if index.alt_bits is not None else 0, ctypes.byref(h)))
         self._h = h

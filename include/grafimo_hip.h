@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFM_ABI_VERSION 5
+#define GFM_ABI_VERSION 6
 
 #define GFM_OK 0
 #define GFM_ERR_INVALID (-1)  /* bad argument (NULL, width out of range, ...)            */
@@ -243,6 +243,13 @@ void gfm_scan_release_buffers(void);
  *   overlap; a deletion may follow a SNP at the same position); h_alt_bits [n_sites][3][ceil(H/64)] =
  *   haplotypes carrying each alternate allele (bit h of word h/64; deletion carriers in slot 0), or
  *   NULL / H = 0 for no haplotype counts (freq = 0).
+ *   Insertions (UNPINNED semantics, stated in oracle/extract_oracle.py): h_ins_len [n_sites] (or NULL): > 0 for a
+ *   site that holds that many inserted bases h_ins_bases[h_ins_off[i] ..] behind its anchor h_pos (one alternate
+ *   allele, carriers in slot 0).  At one position the substitution site comes first, then any number of
+ *   insertions, then the deletion.  A walk that reads inserted bases consumes window bases but no reference span
+ *   (stop = coordinate behind the last reference base it used); walks may start inside an insertion anchored at
+ *   p - 1 (start = p); with insertions in the graph windows start at p in [S, E - 1] and a walk is kept if its
+ *   stop lies inside the region.
  * gfm_graph_plan: regions [S, E] as vg takes them (windows start at p in [S, E - W]); returns the
  *   number of windows and of rows (2 per walk: forward, reverse complement).  Synchronous.
  * gfm_graph_emit: rows of the last plan, window-major, walks in mixed-radix order with the LAST site
@@ -256,7 +263,8 @@ void gfm_scan_release_buffers(void);
 typedef struct gfm_graph *gfm_graph_t;
 int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_sites, const int32_t *h_pos,
                      const uint8_t *h_n_alts, const uint8_t *h_alt_bases, const int32_t *h_del_len,
-                     const uint64_t *h_alt_bits, int32_t n_haplotypes, gfm_graph_t *out);
+                     const int32_t *h_ins_len, const int32_t *h_ins_off, const uint8_t *h_ins_bases,
+                     int64_t ins_bytes, const uint64_t *h_alt_bits, int32_t n_haplotypes, gfm_graph_t *out);
 void gfm_graph_destroy(gfm_graph_t g);
 int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_starts, const int64_t *h_stops,
                    int32_t width, int64_t *n_windows, int64_t *n_rows);
@@ -265,9 +273,11 @@ int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, int64_t *d
 
 /* Phased VCF (plain or gzip/bgzip) -> the site arrays of gfm_graph_create for one chromosome; host
  * threads parse the lines.  The reference hands the VCF to `vg construct` / `vg index -G`
- * (constructVG.py:332,394); here its single-base substitutions become SNP sites and its plain
- * deletions deletion sites, other records (insertions, MNPs, a second SNP at one position, a deletion
- * touching an earlier one) are counted in *n_skipped.  Two haplotypes per sample in file order.
+ * (constructVG.py:332,394); here every ALT allele is taken apart: single-base substitutions (one site per
+ * position with up to 3 alternates, also across records), insertions, plain deletions, equal-length
+ * multi-base substitutions (one substitution per mismatching position); what is left (complex alleles, a
+ * fourth alternate, a deletion touching an earlier one) is counted in *n_skipped.  Two haplotypes per
+ * sample in file order.
  * gfm_vcf_read copies: pos [n], n_alts [n], alt_bases [n][3], del_len [n], alt_bits [n][3][ceil(H/64)]
  * (may be NULL). */
 typedef struct gfm_vcf *gfm_vcf_t;
@@ -275,6 +285,9 @@ int gfm_vcf_open(const char *path, const char *chrom, int with_haplotypes, int n
                  int64_t *n_sites, int32_t *n_haplotypes, int64_t *n_skipped);
 int gfm_vcf_read(gfm_vcf_t v, int32_t *pos, uint8_t *n_alts, uint8_t *alt_bases, int32_t *del_len,
                  uint64_t *alt_bits);
+/* insertion sites: ins_len [n], ins_off [n] into ins_bases [gfm_vcf_ins_bytes()] (ins_bases may be NULL) */
+int64_t gfm_vcf_ins_bytes(gfm_vcf_t v);
+int gfm_vcf_read_insertions(gfm_vcf_t v, int32_t *ins_len, int32_t *ins_off, uint8_t *ins_bases);
 void gfm_vcf_close(gfm_vcf_t v);
 
 #ifdef __cplusplus

@@ -350,3 +350,226 @@ def enumerate_region_graph(chrom: str, ref: bytes, sites: Sites, dels: Dels, S: 
                          for x in used]
                 emit(p, bases, used, list(zip(on, combo)), taken)
     return rows
+
+
+# =====================================================================================
+# Graphs with insertions and multi-base substitutions (round 2).  **UNPINNED**: no file of the reference
+# shows what `vg find` prints for a k-mer that runs through, starts or ends inside inserted bases, and vg is
+# not in this image.  What follows is the natural extension of the rules the two fixtures pin (an insertion is
+# an alternate node behind its anchor base that consumes window bases but no reference span -- like a taken
+# deletion consumes reference span but no window bases), stated here so that the HIP kernels have something
+# exact to be compared with (tests/test_gpu_extract.py) and a reader knows what was assumed:
+#   * VCF records are taken apart per ALT allele: a single-base substitution, a deletion (REF = anchor +
+#     deleted bases, ALT = anchor), an insertion (REF = anchor, ALT = anchor + inserted bases), a
+#     multi-base substitution of equal length (one substitution per mismatching position, all carried by
+#     the same haplotypes: `vg construct` aligns ALT to REF and cuts the graph at every edit); anything else
+#     is skipped and counted.  Substitutions at one position become ONE site with up to three alternates
+#     (a fourth is skipped); a deletion that touches one accepted before it is skipped (as before).
+#   * walks start on a reference position p (first base: the reference base or a substitution), or on base
+#     t of an insertion anchored at p - 1 (start coordinate p).  Behind the base at position x, with bases
+#     still to go, the walk decides for every insertion anchored at x (in site order) whether to read it
+#     (0 = no, 1 = yes; after a yes nothing else anchored at x is considered), then for the deletion
+#     anchored at x whether to jump it.  Decision vectors in lexicographic order, on one vector the
+#     substitution alleles like itertools.product; walks without a start inside an insertion first, then
+#     per insertion anchored at p - 1 (site order) the offsets t = 0, 1, ...
+#   * stop = reference coordinate behind the last reference base consumed (the anchor, for a walk that
+#     ends inside an insertion; p for a walk that never leaves the insertion it started in); a walk is
+#     reported if p >= S and stop <= E; windows start at p in [S, E - 1] (E - W without insertions).
+#   * flag: `ref` iff no alternate substitution and no insertion was taken (a taken deletion keeps it: pinned).
+#   * count: haplotypes with every substitution allele of the walk, every insertion and deletion it takes,
+#     none of the insertions it decided against, none of the deletions whose bases it uses.
+class Variants:
+    """Sites of one chromosome in graph order (position, then substitution < insertion < deletion).
+    kind 0 substitution site (alts: 1..3 bases), 1 insertion (seq), 2 deletion (length);
+    carriers[i][k] = bool [H]: haplotypes with alternate k of site i (insertions / deletions: k = 0)."""
+
+    def __init__(self):
+        self.pos, self.kind, self.alts, self.seq, self.length, self.carriers = [], [], [], [], [], []
+        self.skipped = 0
+        self.n_haplotypes = 0
+
+    def add(self, pos, kind, alts=(), seq=b"", length=0, carriers=()):
+        self.pos.append(int(pos)); self.kind.append(kind); self.alts.append(list(alts)); self.seq.append(bytes(seq))
+        self.length.append(int(length)); self.carriers.append([np.asarray(c, dtype=bool) for c in carriers])
+
+    def __len__(self):
+        return len(self.pos)
+
+
+def read_vcf_variants(path: str, chrom: Optional[str] = None, ref: Optional[bytes] = None) -> Variants:
+    atoms = []      # (pos, kind, payload, carriers, order)
+    skipped, H = 0, 0
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "rt") as fh:
+        for line in fh:
+            if line.startswith("#"):
+                continue
+            f = line.rstrip("\n").split("\t")
+            if chrom is not None and f[0] != chrom:
+                continue
+            r, alts = f[3].upper(), f[4].upper().split(",")
+            gts = []
+            for s in f[9:]:
+                gt = s.split(":")[0].replace("/", "|").split("|")
+                if len(gt) == 1:
+                    gt = gt * 2
+                gts += [int(x) if x.isdigit() and int(x) <= len(alts) else 0 for x in gt[:2]]
+            gts = np.asarray(gts, dtype=np.int64)
+            p = int(f[1]) - 1
+            before = len(atoms)
+            for k, a in enumerate(alts):
+                car = gts == k + 1
+                ok = all(c in "ACGT" for c in a) and all(c in "ACGTN" for c in r) and len(a) > 0 and k < 3
+                if ok and len(r) == 1 and len(a) == 1:
+                    atoms.append((p, 0, a, car))
+                elif ok and len(r) > 1 and len(a) == 1 and a[0] == r[0]:
+                    atoms.append((p, 2, len(r) - 1, car))
+                elif ok and len(r) == 1 and len(a) > 1 and a[0] == r[0]:
+                    atoms.append((p, 1, a[1:].encode(), car))
+                elif ok and len(r) == len(a) and len(r) > 1:
+                    for j, (x, y) in enumerate(zip(r, a)):
+                        if x != y:
+                            atoms.append((p + j, 0, y, car))
+                else:
+                    skipped += 1
+            if len(atoms) > before:
+                H = max(H, len(gts))
+    order = sorted(range(len(atoms)), key=lambda i: (atoms[i][0], atoms[i][1]))
+    v = Variants()
+    v.n_haplotypes = H
+    busy = -1
+    for i in order:
+        p, kind, payload, car = atoms[i]
+        car = np.concatenate([car, np.zeros(H - len(car), bool)]) if len(car) < H else car
+        if kind == 0:
+            if len(v) and v.kind[-1] == 0 and v.pos[-1] == p:      # same position: one site, more alternates
+                if payload in v.alts[-1]:
+                    k = v.alts[-1].index(payload)
+                    v.carriers[-1][k] = v.carriers[-1][k] | car
+                elif len(v.alts[-1]) < 3:
+                    v.alts[-1].append(payload); v.carriers[-1].append(car)
+                else:
+                    skipped += 1
+            else:
+                v.add(p, 0, alts=[payload], carriers=[car])
+        elif kind == 1:
+            dup = [j for j in range(len(v)) if v.pos[j] == p and v.kind[j] == 1 and v.seq[j] == payload]
+            if dup:
+                v.carriers[dup[0]][0] = v.carriers[dup[0]][0] | car
+            else:
+                v.add(p, 1, seq=payload, carriers=[car])
+        else:
+            if p > busy:
+                v.add(p, 2, length=payload, carriers=[car])
+                busy = p + payload
+            else:
+                skipped += 1
+    v.skipped = skipped
+    return v
+
+
+def enumerate_region_variants(chrom: str, ref: bytes, v: Variants, S: int, E: int, W: int,
+                              with_counts: bool = False):
+    """Rows (label, kmer, start, stop, count, flag) x 2 strands per walk, in the order stated above; the
+    node-path column is left empty (vg's node numbering around insertions is not known)."""
+    label = f"{chrom}:{S}-{E}"
+    at: Dict[int, List[int]] = {}
+    for i, p in enumerate(v.pos):
+        at.setdefault(p, []).append(i)
+    has_ins = any(k == 1 for k in v.kind)
+    H = v.n_haplotypes
+    L = len(ref)
+    rows = []
+
+    def emit(p, bases, last, subs, took, passed, used):
+        stop = last + 1
+        if stop > min(E, L):
+            return
+        flag = "ref" if not any(a for _, a in subs) and not any(v.kind[i] == 1 for i in took) else "non.ref"
+        count = 0
+        if with_counts and H:
+            ok = np.ones(H, dtype=bool)
+            for i, a in subs:
+                if a:
+                    ok &= v.carriers[i][a - 1]
+                else:
+                    for c in v.carriers[i]:
+                        ok &= ~c
+            for i in took:
+                ok &= v.carriers[i][0]
+            for i in passed:
+                ok &= ~v.carriers[i][0]
+            for i in range(len(v)):
+                if v.kind[i] == 2 and i not in took:
+                    lo, hi = v.pos[i] + 1, v.pos[i] + v.length[i]
+                    if any(lo <= x <= hi for x in used):
+                        ok &= ~v.carriers[i][0]
+            count = int(ok.sum())
+        kmer = bytes(bases)
+        rows.append((label, kmer.decode(), f"{chrom}:{p}+", f"{chrom}:{stop}+", count, flag))
+        rows.append((label, revcomp(kmer).decode(), f"{chrom}:{stop}-", f"{chrom}:{p}-", count, flag))
+
+    def layouts(x, n, plan, used, took, passed):
+        """yields (plan, used, took, passed, last): plan = per window base either ('r', x) a reference position
+        or ('i', site, t) an inserted base"""
+        if x >= L:
+            return
+        plan = plan + [("r", x)]
+        used = used + [x]
+        n += 1
+        if n == W:
+            yield plan, used, took, passed, x
+            return
+        here = at.get(x, [])
+        ins = [i for i in here if v.kind[i] == 1]
+        dele = [i for i in here if v.kind[i] == 2]
+
+        def after_insertions(k, passed_now):
+            # decisions for insertions ins[k:], all answered "no" so far; then the deletion
+            if k == len(ins):
+                yield from layouts(x + 1, n, plan, used, took, passed_now)
+                if dele:
+                    j = dele[0]
+                    yield from layouts(x + v.length[j] + 1, n, plan, used, took + [j], passed_now)
+                return
+            i = ins[k]
+            yield from after_insertions(k + 1, passed_now + [i])          # 0: do not read insertion i
+            take = min(len(v.seq[i]), W - n)                                # 1: read it
+            plan2 = plan + [("i", i, t) for t in range(take)]
+            if n + take == W:
+                yield plan2, used, took + [i], passed_now, x
+            else:
+                yield from layouts(x + 1, n + take, plan2, used, took + [i], passed_now)
+
+        yield from after_insertions(0, passed)
+
+    def walks_from(p):
+        yield from layouts(p, 0, [], [], [], [])
+        for i in at.get(p - 1, []):
+            if v.kind[i] != 1:
+                continue
+            for t in range(len(v.seq[i])):
+                take = min(len(v.seq[i]) - t, W)
+                plan = [("i", i, t + j) for j in range(take)]
+                if take == W:
+                    yield plan, [], [i], [], p - 1
+                else:
+                    yield from layouts(p, take, plan, [], [i], [])
+
+    hi = min(E, L) - (1 if has_ins else W)
+    for p in range(max(S, 0), hi + 1):
+        for plan, used, took, passed, last in walks_from(p):
+            subs_sites = [i for x in used for i in at.get(x, []) if v.kind[i] == 0]
+            for combo in itertools.product(*[range(1 + len(v.alts[i])) for i in subs_sites]):
+                allele = dict(zip(subs_sites, combo))
+                bases = []
+                for step in plan:
+                    if step[0] == "i":
+                        bases.append(v.seq[step[1]][step[2]])
+                    else:
+                        x = step[1]
+                        s = [i for i in at.get(x, []) if v.kind[i] == 0]
+                        a = allele.get(s[0], 0) if s else 0
+                        bases.append(ord(v.alts[s[0]][a - 1]) if a else ref[x])
+                emit(p, bases, last, list(zip(subs_sites, combo)), took, passed, used)
+    return rows

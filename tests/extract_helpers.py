@@ -7,9 +7,11 @@ import numpy as np
 REF_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_data")
 
 
-def make_graph_files(tmpdir, chrom="7", length=3000, n_sites=260, n_samples=65, seed=5, gz=True):
-    """FASTA + VCF with: clustered and isolated SNPs, multi-allelic sites, a few indel / MNP records
-    (to be skipped), unphased and missing genotypes.  Returns (fasta, vcf)."""
+def make_graph_files(tmpdir, chrom="7", length=3000, n_sites=260, n_samples=65, seed=5, gz=True, rich=False):
+    """FASTA + VCF with: clustered and isolated SNPs, multi-allelic sites, deletions, a few complex records
+    (to be skipped), unphased and missing genotypes.  `rich`: also insertions of 1..6 bases (alone or next to a
+    substitution in one record), equal-length multi-base substitutions and second records at a position
+    already used -- what only the round-2 reader / oracle (read_vcf_variants) take apart.  Returns (fasta, vcf)."""
     rng = np.random.default_rng(seed)
     ref = rng.choice(list("ACGT"), size=length, p=[0.3, 0.2, 0.2, 0.3])
     ref[rng.integers(0, length, 5)] = "N"
@@ -31,15 +33,31 @@ def make_graph_files(tmpdir, chrom="7", length=3000, n_sites=260, n_samples=65, 
         fh.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" +
                  "\t".join(f"s{i}" for i in range(n_samples)) + "\n")
         fh.write("other\t3\t.\tG\tA\t99\t.\t.\tGT\t" + "\t".join(["0|1"] * n_samples) + "\n")
+        if rich:                                 # some positions get a second record
+            pos = sorted(pos + [p for p in pos if rng.random() < 0.08])
         for p in pos:
             r = ref[p]
             others = [b for b in "ACGT" if b != r]
             rng.shuffle(others)
             kind = rng.random()
-            if kind < 0.06:                      # deletion record: skipped by the graph
+            if kind < 0.06:                      # deletion record
                 alt, refa = r, r + "".join(ref[p + 1:p + 3])
-            elif kind < 0.10:                    # insertion
-                alt, refa = r + "GA", r
+            elif kind < 0.10 and not rich:       # complex allele (two bases replaced by one other base): skipped
+                alt, refa = others[0], r + "".join(ref[p + 1:p + 2])
+            elif kind < 0.14 and rich:           # insertion of 1..6 bases behind the anchor
+                alt, refa = r + "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 7)))), r
+            elif kind < 0.18 and rich:           # multi-base substitution (at least one base differs)
+                span = "".join(ref[p:p + 3])
+                sub = "".join(rng.choice(list("ACGT"), size=len(span)))
+                alt, refa = (sub if sub != span else others[0] + span[1:]), span
+                if "N" in span or len(span) < 2:
+                    alt, refa = others[0], r
+            elif kind < 0.21 and rich:           # complex allele: skipped
+                alt, refa = others[0], r + "".join(ref[p + 1:p + 2])
+                if len(refa) < 2:
+                    alt, refa = others[0], r
+            elif kind < 0.25 and rich:           # a substitution and an insertion in one record
+                alt, refa = others[0] + "," + r + "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4)))), r
             else:
                 n_alt = 1 if kind < 0.8 else (2 if kind < 0.95 else 3)
                 alt, refa = ",".join(others[:n_alt]), r

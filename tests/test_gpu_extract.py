@@ -85,6 +85,97 @@ def test_rows_equal_the_oracle_on_a_synthetic_graph(tmp_path, W):
     g.close()
 
 
+@pytest.mark.parametrize("W", [3, 8, 19, 30])
+def test_insertions_and_multibase_substitutions_equal_the_oracle(tmp_path, W):
+    """Round 2: graphs with insertions (1..6 bases, several per anchor), multi-base substitutions and merged
+    same-position records.  Semantics UNPINNED (no vg output shows them; oracle/extract_oracle.py states what is
+    assumed): the kernels must produce exactly the oracle's rows -- k-mers, coordinates, strands, haplotype counts,
+    flags, in order -- incl. walks that start or end inside inserted bases and windows beyond E - W."""
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, write_region_tsvs
+    from oracle import extract_oracle as xo
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=2500, n_sites=150, n_samples=65, seed=60 + W, rich=True)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7", allow_skipped=True)
+    assert (idx.ins_len > 0).sum() > 5 and (idx.del_len > 0).sum() > 2
+    ref = xo.read_fasta(fasta)["7"]
+    v = xo.read_vcf_variants(vcf, "7")
+    regions = [(0, 200), (150, 420), (2400, 2500), (1000, 1000 + W - 1), (1200, 1500), (2450, 2600), (-10, 60)]
+    g = DeviceGraph(idx)
+    rows = g.extract(regions, W)
+    exp = []
+    for s, e in regions:
+        exp += xo.enumerate_region_variants("7", ref, v, max(s, 0), min(e, 2500), W, with_counts=True)
+    assert len(rows) == len(exp) > 0
+    km = rows.kmers.cpu().numpy()
+    assert [k.tobytes().decode() for k in km] == [r[1] for r in exp]
+    strand = [chr(c) for c in rows.strand.cpu().numpy()]
+    assert [f"7:{a}{s}" for a, s in zip(rows.start.cpu().numpy(), strand)] == [r[2] for r in exp]
+    assert [f"7:{a}{s}" for a, s in zip(rows.stop.cpu().numpy(), strand)] == [r[3] for r in exp]
+    assert rows.freq.cpu().numpy().tolist() == [r[4] for r in exp]
+    assert ["ref" if x else "non.ref" for x in rows.is_ref.cpu().numpy()] == [r[5] for r in exp]
+    span = lambda r: int(r[3].split(":")[1][:-1]) - int(r[2].split(":")[1][:-1])
+    fwd = [r for r in exp if r[2].endswith("+")]
+    assert any(span(r) < W for r in fwd) and any(span(r) > W for r in fwd)     # insertions read, deletions jumped
+    assert any(0 < r[4] < 130 for r in exp)
+    # the TSV writer walks the same enumeration on the host (node paths): one line per row, same k-mers
+    paths = write_region_tsvs(idx, rows, str(tmp_path / "out"))
+    lines = [ln.split("\t") for p_ in paths for ln in open(p_).read().splitlines()]
+    assert len(lines) == len(exp) and sorted(l[1] for l in lines) == sorted(r[1] for r in exp)
+    assert all(l[6].endswith(",") and len(l) == 7 for l in lines)
+    g.close()
+
+
+def test_insertion_corner_cases_on_a_hand_made_graph():
+    """An insertion longer than the window, two insertions at one anchor, an insertion at the anchor of a
+    deletion and behind a SNP, an insertion behind the last base of the region."""
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
+    from oracle import extract_oracle as xo
+    ref = b"ACGTTGCAAGGCTTACGATCGATTACA"
+    v = xo.Variants()
+    H = 6
+    v.n_haplotypes = H
+    car = lambda *h: np.isin(np.arange(H), h)
+    v.add(3, 0, alts=["A", "C"], carriers=[car(0, 1), car(2)])
+    v.add(3, 1, seq=b"GGGGGGGG", carriers=[car(0)])            # 8 inserted bases (> W below)
+    v.add(3, 1, seq=b"T", carriers=[car(3)])
+    v.add(3, 2, length=2, carriers=[car(4)])
+    v.add(10, 1, seq=b"CA", carriers=[car(1, 5)])
+    v.add(12, 0, alts=["G"], carriers=[car(5)])
+    v.add(19, 1, seq=b"TTT", carriers=[car(2, 3)])
+    pos = np.array(v.pos, dtype=np.int32)
+    n = len(v)
+    alt = np.zeros((n, 3), np.uint8)
+    bits = np.zeros((n, 3, 1), np.uint64)
+    dl, il, io, pool = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32), b""
+    for i in range(n):
+        for k, a in enumerate(v.alts[i]):
+            alt[i, k] = ord(a)
+        for k, c in enumerate(v.carriers[i]):
+            bits[i, k, 0] = np.packbits(np.concatenate([c, np.zeros(64 - H, bool)]), bitorder="little").view(np.uint64)[0]
+        dl[i] = v.length[i]
+        if v.kind[i] == 1:
+            il[i], io[i] = len(v.seq[i]), len(pool)
+            pool += v.seq[i]
+    n_alts = np.array([max(1, len(a)) for a in v.alts], np.uint8)
+    idx = GraphIndex("c", np.frombuffer(ref, np.uint8), pos, n_alts, alt, bits, H, del_len=dl, ins_len=il, ins_off=io,
+                     ins_bases=np.frombuffer(pool, np.uint8))
+    g = DeviceGraph(idx)
+    for W, regions in ((5, [(0, 27), (4, 20), (2, 11)]), (11, [(0, 27)]), (1, [(0, 27)])):
+        rows = g.extract(regions, W)
+        exp = []
+        for s, e in regions:
+            exp += xo.enumerate_region_variants("c", ref, v, s, e, W, with_counts=True)
+        assert len(rows) == len(exp) > 0
+        strand = [chr(c) for c in rows.strand.cpu().numpy()]
+        got = list(zip([k.tobytes().decode() for k in rows.kmers.cpu().numpy()],
+                       [f"c:{a}{s}" for a, s in zip(rows.start.cpu().numpy(), strand)],
+                       [f"c:{a}{s}" for a, s in zip(rows.stop.cpu().numpy(), strand)],
+                       rows.freq.cpu().numpy().tolist(), ["ref" if x else "non.ref" for x in rows.is_ref.cpu().numpy()]))
+        assert got == [r[1:6] for r in exp], W
+        if W == 5:
+            assert ("GGGGG", "c:4+", "c:4+", 1, "non.ref") in got      # never leaves the insertion it starts in
+    g.close()
+
+
 def test_graph_without_sites_and_plan_errors(tmp_path):
     from grafimo_amd import _native as nv
     from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
