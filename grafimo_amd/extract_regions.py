@@ -1,6 +1,6 @@
 """K-mer extraction on the GPU -- the `vg find -p CHR:S-E -x XG -H GBWT -K W -E` step of
-extract_regions.py:180,225,326 for variation graphs that are a linear reference plus the SNP records
-of a phased VCF (what `grafimo buildvg` feeds `vg construct`, constructVG.py:332).
+extract_regions.py:180,225,326 for variation graphs that are a linear reference plus the substitutions,
+insertions and deletions of a phased VCF (what `grafimo buildvg` feeds `vg construct`, constructVG.py:332).
 
     index = GraphIndex.from_fasta_vcf("chr22.fa", "chr22.vcf.gz", "22")
     graph = DeviceGraph(index)
@@ -11,9 +11,10 @@ of a phased VCF (what `grafimo buildvg` feeds `vg construct`, constructVG.py:332
 Row semantics are those of vg's output as the reference's files pin them: the 32 rows of
 tests/test_data/expected_results/expected_seqs.tsv and the 704 rows of real `vg find -K 19 -E -H` output
 in its scoring fixture (SNPs, a deletion, haplotype counts, node paths) are reproduced exactly.  The
-graph holds the single-base substitutions and the plain deletions of the VCF; other records
-(insertions, MNPs, a deletion overlapping an earlier one) are left out and counted in
-`GraphIndex.skipped`.  There is no CPU fallback: extraction needs libgrafimo_hip.so and a GPU.
+graph holds the substitutions (also multi-base ones, one site per mismatching position), insertions and plain
+deletions of the VCF -- what is assumed about insertions is stated in oracle/extract_oracle.py (no vg output pins it);
+complex alleles and a deletion overlapping an earlier one are refused (or, opted in, left out and counted in
+`GraphIndex.skipped`).  There is no CPU fallback: extraction needs libgrafimo_hip.so and a GPU.
 """
 import ctypes
 import gzip
