@@ -11,7 +11,7 @@ produced (``width_W/REGION.tsv``).  Flags keep the names, defaults and meaning o
 
 Without vg, the k-mers can also come from the extraction kernel: give the inputs of ``grafimo buildvg``
 (-l/--linear-genome FASTA, -v/--vcf phased VCF) and the -b/--bedfile of ``findmotif`` instead of -s;
-only the single-base substitutions of the VCF are part of that graph (grafimo_amd/extract_regions.py).
+substitutions, insertions and deletions of the VCF are part of that graph (grafimo_amd/extract_regions.py).
 
     python -m grafimo_amd -m MA0139.1.meme -l chr22.fa -v chr22.vcf.gz -b peaks.bed -o out_dir
 """
@@ -44,7 +44,7 @@ def get_parser():
                    help="directory holding width_W/*.tsv as written by vg find -K W -E")
     p.add_argument("-l", "--linear-genome", dest="linear_genome", metavar="FASTA",
                    help="reference FASTA (with -v and -b: extract the k-mers on the GPU instead of -s)")
-    p.add_argument("-v", "--vcf", metavar="VCF", help="phased VCF (.vcf or .vcf.gz); its SNP records form the graph")
+    p.add_argument("-v", "--vcf", metavar="VCF", help="phased VCF (.vcf or .vcf.gz): substitutions, insertions, deletions")
     p.add_argument("-b", "--bedfile", metavar="BED", help="regions to scan (UCSC BED: lines starting with chr)")
     p.add_argument("--chroms-prefix-find", dest="chroms_prefix", default="", metavar="PREFIX",
                    help="chromosome names in the FASTA / VCF = PREFIX + the BED name without its leading chr")
@@ -92,8 +92,9 @@ def main(argv=None):
             chrom = a.chroms_prefix + bed_chrom.split("chr")[1]      # extract_regions.py:122,137
             index = GraphIndex.from_fasta_vcf(a.linear_genome, a.vcf, chrom, allow_skipped=a.skip_unmodelled)
             if a.verbose:
-                print(f"{chrom}: {len(index.pos)} SNP sites, {index.n_haplotypes} haplotypes, "
-                      f"{index.skipped} other VCF records left out")
+                print(f"{chrom}: {len(index.pos)} variant sites ({int((index.ins_len > 0).sum())} insertions, "
+                      f"{int((index.del_len > 0).sum())} deletions), {index.n_haplotypes} haplotypes, "
+                      f"{index.skipped} ALT alleles left out")
             graphs.append(DeviceGraph(index))
             region_lists.append(regs)
     shared = None if from_graph or len(motifs) < 2 else compute_results_many(motifs, a.sequences, a.debug, wf)

@@ -21,8 +21,10 @@ quay.io/vgteam/vg:v1.27.1).  Pinning:
     flag `ref` because only reference-path nodes are visited -- the case GRAFIMO's
     `ref -> non.ref if |stop-start| != W` rule repairs, score_sequences.py:305-307), node ids
     incl. chopping at 32 bases and the cuts a deletion makes;
-  * NOT pinned (no vg binary here): insertions and other non-SNP, non-deletion records (skipped and
-    counted), overlapping deletions (the later one is skipped), multi-allelic sites' node order
+  * NOT pinned (no vg binary here): everything about insertions and multi-base substitutions (modelled since
+    round 2 by read_vcf_variants / enumerate_region_variants at the end of this file, whose header states
+    what is assumed), complex alleles (skipped and counted), overlapping deletions (the later one is skipped),
+    haplotype counts beyond consistency with the scoring fixture, multi-allelic sites' node order
     beyond "alternates first", and the fate of a deletion-crossing walk whose stop lies beyond the
     region end (dropped here: a walk is reported only if both of its ends lie inside the region,
     which is what limits the plain windows to start <= E - W in expected_seqs.tsv).

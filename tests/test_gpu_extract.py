@@ -273,7 +273,7 @@ def test_several_graphs_share_one_scoring_pass_and_cli_mode(tmp_path, capsys):
     assert "does not model them" in str(e.value)
     main(["-m", os.path.join(REF_DATA, "MA0139.1.meme"), "-l", fasta, "-v", vcf, "-b", str(bed), "-t", "0.05",
           "--recomb", "-o", str(out), "--verbose", "--skip-unmodelled-variants"])
-    assert "SNP sites, 130 haplotypes" in capsys.readouterr().out
+    assert "deletions), 130 haplotypes" in capsys.readouterr().out
     tsv = pd.read_csv(out / "grafimo_out.tsv", sep="\t", index_col=0)
     assert len(tsv) == len(one) and list(tsv["matched_sequence"]) == list(one["matched_sequence"])
     np.testing.assert_allclose(tsv["q-value"].to_numpy(), one["q-value"].to_numpy(), rtol=1e-12)
