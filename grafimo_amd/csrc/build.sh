@@ -11,13 +11,18 @@ FLAGS=(-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fvisibility
 pids=()
 cc() { "$HIPCC" "${FLAGS[@]}" "$@" & pids+=($!); }
 cc -c "$here/grafimo_hip.hip" -o "$here/grafimo_hip.o"
-for g in 0 1 2 3; do cc -Wno-unused-function -DGFM_QUAD_GROUP=$g -c "$here/score_quad_tu.hip" -o "$here/score_quad_g$g.o"; done
+quad=()
+for gm in 0:1 1:1 2:1 3:1 0:2 1:2 0:3 1:3; do
+    cc -Wno-unused-function -DGFM_QUAD_GROUP=${gm%:*} -DGFM_QUAD_MM=${gm#*:} -c "$here/score_quad_tu.hip" \
+        -o "$here/score_quad_g${gm%:*}_m${gm#*:}.o"
+    quad+=("$here/score_quad_g${gm%:*}_m${gm#*:}.o")
+done
 cc -c "$here/graph_extract.hip" -o "$here/graph_extract.o"
 cc -c "$here/tsv_ingest.cpp" -o "$here/tsv_ingest.o"
 cc -c "$here/vcf_ingest.cpp" -o "$here/vcf_ingest.o"
 cc -c "$here/scan_stream.cpp" -o "$here/scan_stream.o"
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$here/libgrafimo_hip.so" \
-    "$here/grafimo_hip.o" "$here"/score_quad_g{0,1,2,3}.o "$here/graph_extract.o" "$here/tsv_ingest.o" \
+    "$here/grafimo_hip.o" "${quad[@]}" "$here/graph_extract.o" "$here/tsv_ingest.o" \
     "$here/vcf_ingest.o" "$here/scan_stream.o" -lpthread -lz
 echo "built $here/libgrafimo_hip.so"

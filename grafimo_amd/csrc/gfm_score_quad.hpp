@@ -1,5 +1,5 @@
-// gfm_score_quad.hpp -- score_quad_kernel<W>: the single-motif score kernel (the dominant, HBM-bound one)
-// Part of libgrafimo_hip.so (one translation unit: included by grafimo_hip.hip only).
+// gfm_score_quad.hpp -- score_quad_kernel<W, MM>: the score kernel (the dominant, HBM-bound one)
+// Part of libgrafimo_hip.so (instantiated in score_quad_tu.hip).
 // Reference lines cited as file:line are relative to /root/reference/src/grafimo/.
 #pragma once
 
@@ -9,11 +9,21 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------
-// score_quad_kernel<W>: compute_score_seq (score_sequences.py:331-396) for a dense batch, one motif.
+// score_quad_kernel<W, MM>: compute_score_seq (score_sequences.py:331-396) for a dense batch of k-mers against
+// MM motifs of width W (MM = 1: the single-motif launch; 2, 3: same-width motifs sharing ONE read of the k-mers,
+// BASELINE config 5 -- per (k-mer, motif) pair the algorithmic bytes drop from W + 4 to W/MM + 4).
 //
-// Same data path as score_hist_kernel (coalesced 16 B/lane non-temporal loads into registers ahead of
-// use, a wave-private LDS strip, pair-table lookups, LDS histogram window, queued hits) with a
-// different work split: a wave takes 256 k-mers per step and every lane scores FOUR consecutive
+// Data path: coalesced 16 B/lane non-temporal loads into registers one chunk ahead, a wave-private LDS
+// strip (no workgroup barrier in the loop), table lookups of TWO bases at a time (bits 1..3 of two ASCII codes
+// -> 6-bit index into that pair's 64-entry table; the 16 hot entries sit in 8 distinct banks: conflict free;
+// a code 4..7 -- N, any byte that is not A,C,G,T -- hits a poison entry: the k-mer scores min_val,
+// score_sequences.py:376-378; positions >= W contribute 0 whatever their byte), an LDS histogram window per motif
+// flushed once per workgroup as a plain-store slab (rows outside a partial window go to a global spill
+// array), hits compacted with ballots into per-wave LDS queues (hitq_push).  MM == 1: uint16 table entries;
+// MM > 1: ONE table of 64-bit entries packing the motifs' partial scores in 19-bit fields (a k-mer's score is
+// <= 64000 < 2^19, so fields never carry) plus, in bits 57.., a count of invalid codes: one ds_read_b64 + one
+// 64-bit add per base pair serves all motifs of the launch.
+// Work split: a wave takes 256 k-mers per step and every lane scores FOUR consecutive
 // rows.  Four rows are 4*W bytes = W dwords, so lane r's rows start dword aligned at r*W dwords:
 //   * the row-wise re-read of the strip is W aligned dwords per lane, 4.75 per k-mer at W = 19
 //     instead of 6, and free of bank conflicts: the lanes of a read are W dwords apart, W odd ->
@@ -23,26 +33,26 @@ namespace {
 //   * the shifts that re-align rows 1..3 are compile-time constants (W is a template parameter),
 //     row 0 needs none;
 //   * the four scores of a lane leave as ONE 16-byte store: a wave writes 1 KiB contiguous.
-// LDS of a workgroup: pair tables | per wave: strip of 64 x (4W + pad) bytes, hit queue | histogram
-// window.  8 or 16 waves per workgroup (blockDim.x), chosen by the host so that the window fits.
+// LDS of a workgroup: pair tables | per wave: strip of 64 x (4W + pad) bytes, MM hit queues | MM histogram
+// windows.  8 or 16 waves per workgroup (blockDim.x), chosen by the host so that the windows fit.
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const u32x2_t lds_cu32x2;
 typedef __attribute__((address_space(3))) const u32x4_t lds_cu32x4;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <int W>
+template <int W, int MM>
 __global__ void __launch_bounds__(kThreads)
-score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_base, const MotifArgs ma)
+score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_base, const ScoreArgs<MM> a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NDW = (W + 3) / 4;
-    constexpr int kTabBytes = quad_tab_bytes(W);
+    constexpr int kTabBytes = quad_tab_bytes(W, MM);
     constexpr int CB = kQuadRows * W;                 // bytes of a chunk (a multiple of 256)
     constexpr int kLoads = (CB + 1023) / 1024;        // 16 B loads per lane per chunk (== NDW)
     constexpr int GP = quad_pitch(W);
     constexpr int PAD = quad_pad(W);
-    constexpr int SSTRIDE = quad_strip_stride(W);
+    constexpr int SSTRIDE = quad_strip_stride(W, MM);
 
     if (lds_offset(smem) != 0u) __builtin_trap();     // the lookups below use absolute LDS offsets
     const int tid = threadIdx.x;
@@ -52,7 +62,15 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
     const int wg_threads = (int)blockDim.x;
     unsigned char *tab = smem;
     unsigned char *stage_base = smem + kTabBytes;
-    unsigned *hist = reinterpret_cast<unsigned *>(stage_base + n_waves * SSTRIDE);
+    unsigned *hist[MM];
+    {
+        unsigned *h = reinterpret_cast<unsigned *>(stage_base + n_waves * SSTRIDE);
+#pragma unroll
+        for (int m = 0; m < MM; ++m) {
+            hist[m] = h;
+            if (a.m[m].use_hist) h += a.m[m].nb + 1;
+        }
+    }
 
     unsigned char *stage = stage_base + wave * SSTRIDE;
     const unsigned stage_off = (unsigned)(kTabBytes + wave * SSTRIDE);   // its absolute LDS offset
@@ -61,7 +79,9 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
     // instruction bytes).  The < 256 rows behind the last whole chunk are scored row by row behind it.
     const long long nfull = n / kQuadRows;
     const long long cstride = (long long)gridDim.x * n_waves;
-    const bool vec_store = (reinterpret_cast<uintptr_t>(ma.scores) & 15u) == 0;   // uniform
+    bool vec_store = true;                            // uniform: every score buffer 16-byte aligned
+#pragma unroll
+    for (int m = 0; m < MM; ++m) vec_store = vec_store && (reinterpret_cast<uintptr_t>(a.m[m].scores) & 15u) == 0;
 
     uint4 pre[kQuadDepth][kLoads];
     auto fetch = [&](uint4 (&dst)[kLoads], long long c) {
@@ -78,38 +98,49 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
         }
     };
 
-    long long *hitq = reinterpret_cast<long long *>(stage + quad_stage_bytes(W));
-    int qn = 0;   // wave-uniform
-    const bool select = ma.cutoff != GFM_NO_SELECT;
-    if (select && blockIdx.x == 0 && tid == 0) ma.ctl->snap[ma.slot] = ma.hit_count ? *ma.hit_count : 0ull;
+    long long *hitq[MM];
+    int qn[MM];   // wave-uniform
+    bool select[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        hitq[m] = reinterpret_cast<long long *>(stage + quad_stage_bytes(W)) + m * kHitQueue;
+        qn[m] = 0;
+        select[m] = a.m[m].cutoff != GFM_NO_SELECT;
+        if (select[m] && blockIdx.x == 0 && tid == 0)
+            a.m[m].ctl->snap[a.m[m].slot] = a.m[m].hit_count ? *a.m[m].hit_count : 0ull;
+    }
 
     // Histogram and hit selection of a scored chunk ("booking").  It is done one step late, at the top of the
     // next step and in front of the wait for that step's k-mers: the LDS atomics and the queue code then run
     // while the loads are still in flight instead of lengthening the part of the step that follows them.
-    int p_score[4] = {0, 0, 0, 0};
+    int p_score[MM][4];
     long long p_crow = -1;      // chunk whose scores are waiting to be booked (-1: none)
     auto book = [&]() {
         const int k0 = 4 * lane;
-        if (ma.use_hist) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned off = (unsigned)(p_score[j] - ma.lo);
-                if (off < (unsigned)ma.nb)
-                    atomicAdd(&hist[off], 1u);
-                else if (p_score[j] == ma.min_val)   // a row holding N scores min_val, below every reachable sum
-                    atomicAdd(&hist[ma.nb], 1u);     // unless W == 1, where lo == min_val and the window has it
-                else
-                    atomicAdd(&ma.spill[p_score[j] - ma.spill_lo], 1u);   // outside the window: rare
+        for (int m = 0; m < MM; ++m) {
+            const MotifArgs &ma = a.m[m];
+            if (ma.use_hist) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned off = (unsigned)(p_score[m][j] - ma.lo);
+                    if (off < (unsigned)ma.nb)
+                        atomicAdd(&hist[m][off], 1u);
+                    else if (p_score[m][j] == ma.min_val)   // a row holding N scores min_val, below every reachable
+                        atomicAdd(&hist[m][ma.nb], 1u);     // sum unless the window holds min_val itself
+                    else
+                        atomicAdd(&ma.spill[p_score[m][j] - ma.spill_lo], 1u);   // outside the window: rare
+                }
             }
-        }
-        if (select) {
-            const int best = max(max(p_score[0], p_score[1]), max(p_score[2], p_score[3]));
-            if (__builtin_amdgcn_ballot_w64(best >= ma.cutoff)) {
+            if (select[m]) {
+                const int best = max(max(p_score[m][0], p_score[m][1]), max(p_score[m][2], p_score[m][3]));
+                if (__builtin_amdgcn_ballot_w64(best >= ma.cutoff)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    hitq_push(hitq, qn, p_score[j] >= ma.cutoff,
-                              ((row_base + p_crow + k0 + j) << GFM_HIT_SCORE_BITS) | (long long)p_score[j], lane,
-                              ma.hit_count, &ma.ctl->mid[ma.slot], ma.hit_rows, ma.hit_cap);
+                    for (int j = 0; j < 4; ++j)
+                        hitq_push(hitq[m], qn[m], p_score[m][j] >= ma.cutoff,
+                                  ((row_base + p_crow + k0 + j) << GFM_HIT_SCORE_BITS) | (long long)p_score[m][j], lane,
+                                  ma.hit_count, &ma.ctl->mid[ma.slot], ma.hit_rows, ma.hit_cap);
+                }
             }
         }
     };
@@ -118,10 +149,25 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
 #pragma unroll
     for (int d = 0; d < kQuadDepth; ++d)
         if (c + d * cstride < nfull) fetch(pre[d], c + d * cstride);
-    // tables and the zeroed window AFTER the first loads went out: their latency hides behind this
-    for (int i = tid; i < kTabBytes / 2; i += wg_threads) reinterpret_cast<uint16_t *>(tab)[i] = ma.tab[i];
-    if (ma.use_hist)
-        for (int i = tid; i <= ma.nb; i += wg_threads) hist[i] = 0u;
+    // tables and the zeroed windows AFTER the first loads went out: their latency hides behind this
+    if constexpr (MM == 1) {
+        for (int i = tid; i < kTabBytes / 2; i += wg_threads) reinterpret_cast<uint16_t *>(tab)[i] = a.m[0].tab[i];
+    } else {
+        for (int i = tid; i < kTabBytes / 8; i += wg_threads) {
+            unsigned long long v = 0;
+            if (a.m[0].tab[i] == kPoison) {
+                v = 1ull << 57;                       // the same codes are invalid for every motif
+            } else {
+#pragma unroll
+                for (int m = 0; m < MM; ++m) v |= (unsigned long long)a.m[m].tab[i] << (19 * m);
+            }
+            reinterpret_cast<unsigned long long *>(tab)[i] = v;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+        if (a.m[m].use_hist)
+            for (int i = tid; i <= a.m[m].nb; i += wg_threads) hist[m][i] = 0u;
     __syncthreads();
 
     while (c < nfull) {
@@ -174,38 +220,62 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
                 }
                 w[W] = 0u;
             }
-            int score[4];
-            bool is_n[4];
+            int score[MM][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = (j * W) & 3;     // byte phase of row j inside its first dword: a constant
-                int s1 = 0;
+                bool any_n;
+                int acc[MM];
+                if constexpr (MM == 1) {
+                    int s1 = 0;
 #pragma unroll
-                for (int t = 0; t < NDW; ++t) {
-                    const int q = (j * W + 4 * t) >> 2;
-                    const unsigned x = r ? __builtin_amdgcn_alignbit(w[q + 1], w[q], (unsigned)(8 * r)) : w[q];
-                    // bits 1..3 of each 16-bit half from x (first base of a pair), the other bits from
-                    // x >> 5 (bits 4..6: second base); then one mask per table offset
-                    unsigned y;
-                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(0x000E000Eu), "v"(x), "v"(x >> 5));
-                    const unsigned e0 = y & 0x7Eu;
-                    const unsigned e1 = (y >> 16) & 0x7Eu;
-                    s1 += *(lds_cu16 *)(uintptr_t)(e0 + (unsigned)((2 * t) * 128));
-                    s1 += *(lds_cu16 *)(uintptr_t)(e1 + (unsigned)((2 * t + 1) * 128));
+                    for (int t = 0; t < NDW; ++t) {
+                        const int q = (j * W + 4 * t) >> 2;
+                        const unsigned x = r ? __builtin_amdgcn_alignbit(w[q + 1], w[q], (unsigned)(8 * r)) : w[q];
+                        // bits 1..3 of each 16-bit half from x (first base of a pair), the other bits from
+                        // x >> 5 (bits 4..6: second base); then one mask per table offset
+                        unsigned y;
+                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(0x000E000Eu), "v"(x), "v"(x >> 5));
+                        const unsigned e0 = y & 0x7Eu;
+                        const unsigned e1 = (y >> 16) & 0x7Eu;
+                        s1 += *(lds_cu16 *)(uintptr_t)(e0 + (unsigned)((2 * t) * 128));
+                        s1 += *(lds_cu16 *)(uintptr_t)(e1 + (unsigned)((2 * t + 1) * 128));
+                    }
+                    any_n = (unsigned)s1 >= kPoison;   // a base that is not A,C,G,T: min_val (:376-378)
+                    acc[0] = s1;
+                } else {
+                    unsigned long long s64 = 0;
+#pragma unroll
+                    for (int t = 0; t < NDW; ++t) {
+                        const int q = (j * W + 4 * t) >> 2;
+                        const unsigned x = r ? __builtin_amdgcn_alignbit(w[q + 1], w[q], (unsigned)(8 * r)) : w[q];
+                        unsigned y;
+                        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(0x000E000Eu), "v"(x), "v"(x >> 5));
+                        const unsigned e0 = (y & 0x7Eu) << 2;            // 8-byte entries
+                        const unsigned e1 = ((y >> 16) & 0x7Eu) << 2;
+                        s64 += *(lds_cu64 *)(uintptr_t)(e0 + (unsigned)((2 * t) * 512));
+                        s64 += *(lds_cu64 *)(uintptr_t)(e1 + (unsigned)((2 * t + 1) * 512));
+                    }
+                    any_n = (s64 >> 57) != 0;
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) acc[m] = (int)((s64 >> (19 * m)) & 0x7FFFFull);
                 }
-                is_n[j] = (unsigned)s1 >= kPoison;    // a base that is not A,C,G,T: min_val (:376-378)
-                score[j] = is_n[j] ? ma.min_val : s1;
+#pragma unroll
+                for (int m = 0; m < MM; ++m) score[m][j] = any_n ? a.m[m].min_val : acc[m];
             }
             const int k0 = 4 * lane;
-            if (vec_store) {   // one 16-byte store per lane: the wave writes 1 KiB contiguous
-                const i32x4 out = {score[0], score[1], score[2], score[3]};
-                __builtin_nontemporal_store(out, reinterpret_cast<i32x4 *>(ma.scores + crow + k0));
-            } else {           // a score buffer that is only 4-byte aligned
 #pragma unroll
-                for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(score[j], ma.scores + crow + k0 + j);
+            for (int m = 0; m < MM; ++m) {
+                if (vec_store) {   // one 16-byte store per lane and motif: the wave writes 1 KiB contiguous
+                    const i32x4 out = {score[m][0], score[m][1], score[m][2], score[m][3]};
+                    __builtin_nontemporal_store(out, reinterpret_cast<i32x4 *>(a.m[m].scores + crow + k0));
+                } else {           // a score buffer that is only 4-byte aligned
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(score[m][j], a.m[m].scores + crow + k0 + j);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p_score[m][j] = score[m][j];
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p_score[j] = score[j];
             p_crow = crow;
             // the strip is rewritten next iteration: keep this iteration's reads ahead of it
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -219,58 +289,75 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
     if (blockIdx.x == gridDim.x - 1 && wave == n_waves - 1 && nfull * kQuadRows < n) {
         const long long first = nfull * kQuadRows;
         const int count = (int)(n - first);
-        const uint16_t *tab16 = reinterpret_cast<const uint16_t *>(tab);
 #pragma unroll 1
         for (int r0 = 0; r0 < count; r0 += kWave) {
             const int k = r0 + lane;
             const bool live = k < count;
             const uint8_t *row = kmers + (first + (live ? k : 0)) * (long long)W;
-            unsigned s1 = 0;
+            unsigned long long s64 = 0;
+            bool bad = false;
 #pragma unroll 1
             for (int p = 0; p < 2 * NDW; ++p) {
                 const unsigned b0 = 2 * p < W ? row[2 * p] : (unsigned)'A';        // positions >= W: any valid code
                 const unsigned b1 = 2 * p + 1 < W ? row[2 * p + 1] : (unsigned)'A';
-                s1 += tab16[p * 64 + ((b0 >> 1) & 7u) + 8u * ((b1 >> 1) & 7u)];
-            }
-            const bool bad = s1 >= kPoison;
-            const int sc = bad ? ma.min_val : (int)s1;
-            if (live) {
-                ma.scores[first + k] = sc;
-                if (ma.use_hist) {
-                    const unsigned off = (unsigned)(sc - ma.lo);
-                    if (bad || off < (unsigned)ma.nb)
-                        atomicAdd(&hist[bad ? (unsigned)ma.nb : off], 1u);
-                    else
-                        atomicAdd(&ma.spill[sc - ma.spill_lo], 1u);
+                const unsigned e = p * 64 + ((b0 >> 1) & 7u) + 8u * ((b1 >> 1) & 7u);
+                if constexpr (MM == 1) {
+                    const unsigned v = reinterpret_cast<const uint16_t *>(tab)[e];
+                    bad = bad || v == kPoison;
+                    s64 += v;
+                } else {
+                    s64 += reinterpret_cast<const unsigned long long *>(tab)[e];
                 }
             }
-            if (select)
-                hitq_push(hitq, qn, live && sc >= ma.cutoff,
-                          ((row_base + first + k) << GFM_HIT_SCORE_BITS) | (long long)sc, lane, ma.hit_count,
-                          &ma.ctl->mid[ma.slot], ma.hit_rows, ma.hit_cap);
+            if constexpr (MM > 1) bad = (s64 >> 57) != 0;
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                const MotifArgs &ma = a.m[m];
+                const int sc = bad ? ma.min_val : (int)((MM == 1 ? s64 : (s64 >> (19 * m))) & 0x7FFFFull);
+                if (live) {
+                    ma.scores[first + k] = sc;
+                    if (ma.use_hist) {
+                        const unsigned off = (unsigned)(sc - ma.lo);
+                        if (off < (unsigned)ma.nb)
+                            atomicAdd(&hist[m][off], 1u);
+                        else if (sc == ma.min_val)
+                            atomicAdd(&hist[m][ma.nb], 1u);
+                        else
+                            atomicAdd(&ma.spill[sc - ma.spill_lo], 1u);
+                    }
+                }
+                if (select[m])
+                    hitq_push(hitq[m], qn[m], live && sc >= ma.cutoff,
+                              ((row_base + first + k) << GFM_HIT_SCORE_BITS) | (long long)sc, lane, ma.hit_count,
+                              &ma.ctl->mid[ma.slot], ma.hit_rows, ma.hit_cap);
+            }
         }
     }
 
     // the lookup tables are dead once every wave has left the loop: their LDS holds the per-wave
     // queue lengths (no static LDS)
     __syncthreads();
-    if (select) {
-        int *wq_n = reinterpret_cast<int *>(tab);
-        if (lane == 0) wq_n[wave] = qn;
-        __syncthreads();
-        int base = 0, tot = 0;
-        for (int w2 = 0; w2 < n_waves; ++w2) {
-            const int v = wq_n[w2];
-            if (w2 < wave) base += v;
-            tot += v;
+#pragma unroll
+    for (int m = 0; m < MM; ++m) {
+        const MotifArgs &ma = a.m[m];
+        if (select[m]) {
+            int *wq_n = reinterpret_cast<int *>(tab) + m * kWavesPerWG;
+            if (lane == 0) wq_n[wave] = qn[m];
+            __syncthreads();
+            int base = 0, tot = 0;
+            for (int w2 = 0; w2 < n_waves; ++w2) {
+                const int v = wq_n[w2];
+                if (w2 < wave) base += v;
+                tot += v;
+            }
+            long long *slab = ma.resid + (size_t)blockIdx.x * kResidPerWG;
+            for (int i = lane; i < qn[m]; i += kWave) slab[base + i] = hitq[m][i];
+            if (tid == 0) ma.resid_n[blockIdx.x] = tot;
         }
-        long long *slab = ma.resid + (size_t)blockIdx.x * kResidPerWG;
-        for (int i = lane; i < qn; i += kWave) slab[base + i] = hitq[i];
-        if (tid == 0) ma.resid_n[blockIdx.x] = tot;
-    }
-    if (ma.use_hist) {
-        unsigned *slab = ma.partials + (size_t)blockIdx.x * (size_t)(ma.nb + 1);
-        for (int i = tid; i <= ma.nb; i += wg_threads) slab[i] = hist[i];
+        if (ma.use_hist) {
+            unsigned *slab = ma.partials + (size_t)blockIdx.x * (size_t)(ma.nb + 1);
+            for (int i = tid; i <= ma.nb; i += wg_threads) slab[i] = hist[m][i];
+        }
     }
 }
 

@@ -158,77 +158,14 @@ int run_dp(const int64_t *sm, int W, const double *bg, double *d_pmf, hipStream_
     return GFM_OK;
 }
 
-// LDS bytes of one score launch: MM table sets | 16 wave strips (chunk + MM hit queues) | the
-// LDS histogram windows of the motifs that use one
-size_t score_lds_bytes(int W, int ndw, int mm, const int *nb_lds /* nb+1 or 0 per motif */)
-{
-    // one motif: uint16 pair tables; 2-3 motifs: ONE table of packed 64-bit entries (4x the bytes)
-    size_t b = (size_t)(mm == 1 ? 1 : 4) * (2 * ndw * 64 * 2) + (size_t)waves_for_ndw(ndw) * stage_stride_bytes(W, mm);
-    for (int i = 0; i < mm; ++i) b += sizeof(unsigned) * (size_t)nb_lds[i];
-    return b;
-}
-
-template <int NDW, int MM>
-int launch_score_t(gfm_motif *timer, const uint8_t *d_kmers, long long n, int W, long long row_base,
-                   const ScoreArgs<MM> &args, size_t lds, int nslabs, hipStream_t st, bool prepare_only)
-{
-    auto kern = score_hist_kernel<NDW, MM>;
-    if (prepare_only) {  // from gfm_motif_create (never inside a stream capture); once per process and device
-        static std::atomic<unsigned long long> done{0ull};       // one bit per device for this instantiation
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (done.load(std::memory_order_acquire) & bit) return GFM_OK;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
-        // the kernel addresses its lookup tables by absolute LDS offset: its dynamic LDS must start at 0
-        hipFuncAttributes attr;
-        HIP_TRY(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kern)));
-        if (attr.sharedSizeBytes != 0)
-            return fail(GFM_ERR_HIP, "score kernel carries %zu bytes of static LDS (expected none)",
-                        (size_t)attr.sharedSizeBytes);
-        done.fetch_or(bit, std::memory_order_release);
-        return GFM_OK;
-    }
-    const bool prof = timer && !timer->ev0.empty() && (timer->ev_calls++ % (unsigned)timer->ev_every) == 0;
-    const int slot = prof ? timer->ev_next : 0;
-    if (prof) HIP_TRY(hipEventRecord(timer->ev0[slot], st));
-    hipLaunchKernelGGL(kern, dim3(nslabs), dim3(waves_for_ndw(NDW) * kWave), lds, st, d_kmers, n, W, row_base, args);
-    HIP_TRY(hipGetLastError());
-    if (prof) {
-        HIP_TRY(hipEventRecord(timer->ev1[slot], st));
-        timer->ev_next = (slot + 1) % (int)timer->ev0.size();
-        timer->ev_used = std::min(timer->ev_used + 1, (int)timer->ev0.size());
-    }
-    return GFM_OK;
-}
-
-template <int MM>
-int dispatch_score(int ndw, gfm_motif *timer, const uint8_t *d_kmers, long long n, int W,
-                   long long row_base, const ScoreArgs<MM> &args, size_t lds, int nslabs,
-                   hipStream_t st, bool prepare_only)
-{
-#define GFM_CASE(N)                                                                               \
-    case N:                                                                                       \
-        return launch_score_t<N, MM>(timer, d_kmers, n, W, row_base, args, lds, nslabs, st, prepare_only);
-    switch (ndw) {
-#ifdef GFM_ONLY_W
-        GFM_CASE((GFM_ONLY_W + 3) / 4)
-#else
-        GFM_CASE(1) GFM_CASE(2) GFM_CASE(3) GFM_CASE(4) GFM_CASE(5) GFM_CASE(6) GFM_CASE(7) GFM_CASE(8)
-        GFM_CASE(9) GFM_CASE(10) GFM_CASE(11) GFM_CASE(12) GFM_CASE(13) GFM_CASE(14) GFM_CASE(15) GFM_CASE(16)
-#endif
-        default: return fail(GFM_ERR_INVALID, "unsupported width %d", W);
-    }
-#undef GFM_CASE
-}
-
-// score_quad_kernel<W> is instantiated in score_quad_tu.hip, four translation units of sixteen widths each
-// (compiled side by side: one unit with all 64 took four minutes).
-int dispatch_quad(int W, gfm_motif *timer, const uint8_t *d_kmers, long long n, long long row_base,
-                  const MotifArgs &args, size_t lds, int nslabs, int waves, hipStream_t st, bool prepare_only)
+// score_quad_kernel<W, MM> is instantiated in score_quad_tu.hip: eight translation units of sixteen widths and one
+// MM each (compiled side by side: one unit with all of them took four minutes).  `args` = ScoreArgs<mm>.
+int dispatch_quad(int W, int mm, gfm_motif *timer, const uint8_t *d_kmers, long long n, long long row_base,
+                  const void *args, size_t lds, int nslabs, int waves, hipStream_t st, bool prepare_only)
 {
     if (W < 1 || W > GFM_MAX_WIDTH) return fail(GFM_ERR_INVALID, "unsupported width %d", W);
+    if (mm < 1 || mm > 3 || (mm > 1 && W > kQuadMaxBatchWidth))
+        return fail(GFM_ERR_INVALID, "no kernel for %d motifs of width %d in one launch", mm, W);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (!prepare_only && timer && !timer->ev0.empty() && (timer->ev_calls++ % (unsigned)timer->ev_every) == 0) {
         e0 = timer->ev0[timer->ev_next];
@@ -238,12 +175,18 @@ int dispatch_quad(int W, gfm_motif *timer, const uint8_t *d_kmers, long long n, 
     }
     typedef int (*launch_fn)(int, const uint8_t *, long long, long long, const void *, size_t, int, int, void *, int,
                              void *, void *);
-    static const launch_fn groups[4] = {gfm_quad_launch_g0, gfm_quad_launch_g1, gfm_quad_launch_g2, gfm_quad_launch_g3};
-    return groups[(W - 1) / 16](W, d_kmers, n, row_base, &args, lds, nslabs, waves, st, prepare_only ? 1 : 0, e0, e1);
+    static const launch_fn table[3][4] = {
+        {gfm_quad_launch_g0_m1, gfm_quad_launch_g1_m1, gfm_quad_launch_g2_m1, gfm_quad_launch_g3_m1},
+        {gfm_quad_launch_g0_m2, gfm_quad_launch_g1_m2, nullptr, nullptr},
+        {gfm_quad_launch_g0_m3, gfm_quad_launch_g1_m3, nullptr, nullptr}};
+    return table[mm - 1][(W - 1) / 16](W, d_kmers, n, row_base, args, lds, nslabs, waves, st, prepare_only ? 1 : 0, e0, e1);
 }
 
-// LDS bytes of a single-motif launch before the histogram window: pair tables | strips + hit queues
-size_t quad_fixed_lds(int W, int waves) { return (size_t)quad_tab_bytes(W) + (size_t)waves * (size_t)quad_strip_stride(W); }
+// LDS bytes of a launch of mm motifs before the histogram windows: pair tables | strips + hit queues
+size_t quad_fixed_lds(int W, int waves, int mm = 1)
+{
+    return (size_t)quad_tab_bytes(W, mm) + (size_t)waves * (size_t)quad_strip_stride(W, mm);
+}
 
 // The `bins` consecutive scores that hold the most background probability
 // (P(s >= a) - P(s >= a + bins) from the tail table): where a partial LDS histogram window goes.
@@ -498,11 +441,8 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     const long long room16 = ((long long)kMaxLdsBytes - (long long)quad_fixed_lds(W, kWavesPerWG)) / (long long)sizeof(unsigned) - 1;
     const long long room8 = ((long long)kMaxLdsBytes - (long long)quad_fixed_lds(W, kWavesPerWG / 2)) / (long long)sizeof(unsigned) - 1;
     if (room8 < 256) return bail(fail(GFM_ERR_INVALID, "no LDS left for a histogram window at width %d", W));
-    // the batched launch (score_hist_kernel<NDW, MM>) lays its LDS out differently; its windows never exceed this
-    const int zero_nb = 0;
-    const long long room_batched = ((long long)kMaxLdsBytes - (long long)score_lds_bytes(W, m->ndw, 1, &zero_nb)) /
-                                       (long long)sizeof(unsigned) - 1;
-    m->part_nb = (int)std::min<long long>(m->nb, std::max(std::max(room16, room8), room_batched));
+    // (batched launches carry bigger tables and more hit queues: their windows are never larger than these)
+    m->part_nb = (int)std::min<long long>(m->nb, std::max(room16, room8));
     m->max_slabs = m->n_cu * kWGsPerCU;
     m->sel_slabs = 4 * m->n_cu;
 
@@ -585,13 +525,10 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     }
 #undef HIP_TRY_M
     {   // allow up to the whole LDS for every instantiation this width can use
-        ScoreArgs<1> a1{};
-        ScoreArgs<2> a2{};
-        ScoreArgs<3> a3{};
-        rc = dispatch_score<1>(m->ndw, nullptr, nullptr, 0, W, 0, a1, 0, 1, nullptr, true);
-        if (!rc) rc = dispatch_quad(W, nullptr, nullptr, 0, 0, a1.m[0], 0, 1, m->q_waves, nullptr, true);
-        if (!rc) rc = dispatch_score<2>(m->ndw, nullptr, nullptr, 0, W, 0, a2, 0, 1, nullptr, true);
-        if (!rc) rc = dispatch_score<3>(m->ndw, nullptr, nullptr, 0, W, 0, a3, 0, 1, nullptr, true);
+        ScoreArgs<3> none{};
+        rc = GFM_OK;
+        for (int mm = 1; mm <= (W <= kQuadMaxBatchWidth ? 3 : 1) && !rc; ++mm)
+            rc = dispatch_quad(W, mm, nullptr, nullptr, 0, 0, &none, 0, 1, m->q_waves, nullptr, true);
         if (rc) return bail(rc);
     }
     *out = m;
@@ -674,7 +611,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         return fail(GFM_ERR_INVALID, "d_kmers must be 16-byte aligned");
     if ((reinterpret_cast<uintptr_t>(d_scores) & 3u) != 0)
         return fail(GFM_ERR_INVALID, "d_scores must be 4-byte aligned");
-    if (n > (int64_t)kChunk * 0x7fffff00ll)
+    if (n > (int64_t)kQuadRows * 0x7fffff00ll)
         return fail(GFM_ERR_INVALID, "too many rows for one launch (split the batch)");
     const bool select = select_cutoff != GFM_NO_SELECT;
     if (select && (!d_hit_rows || !d_hit_count))
@@ -712,7 +649,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     fill_motif_args(args.m[0], m, ws, slot, use_hist, m->hlo, m->hnb, select_cutoff, d_scores,
                     reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                     reset ? nullptr : reinterpret_cast<unsigned long long *>(d_hit_count));
-    int rc = dispatch_quad(m->W, m, d_kmers, n, row_base, args.m[0], m->lds_bytes, nslabs, m->q_waves, st, false);
+    int rc = dispatch_quad(m->W, 1, m, d_kmers, n, row_base, &args, m->lds_bytes, nslabs, m->q_waves, st, false);
     if (rc) return rc;
     if (split) {
         HIP_TRY(hipEventRecord(m->ev_scored[ws], st));
@@ -763,63 +700,77 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
     if (!d_kmers) return fail(GFM_ERR_INVALID, "NULL device buffer");
     if ((reinterpret_cast<uintptr_t>(d_kmers) & 15u) != 0)
         return fail(GFM_ERR_INVALID, "d_kmers must be 16-byte aligned");
-    if (n > (int64_t)kChunk * 0x7fffff00ll)
+    if (n > (int64_t)kQuadRows * 0x7fffff00ll)
         return fail(GFM_ERR_INVALID, "too many rows for one launch (split the batch)");
-    const int W = motifs[0]->W, ndw = motifs[0]->ndw;
-    const long long nchunks = (n + kChunk - 1) / kChunk;
-    const long long want = (nchunks + waves_for_ndw(ndw) - 1) / waves_for_ndw(ndw);
+    for (int i = 0; i < n_motifs; ++i)
+        if ((reinterpret_cast<uintptr_t>(d_scores[i]) & 3u) != 0)
+            return fail(GFM_ERR_INVALID, "d_scores[%d] must be 4-byte aligned", i);
+    const int W = motifs[0]->W;
+    const long long nchunks = (n + kQuadRows - 1) / kQuadRows;
 
-    // grouping: the largest group (<= 3 motifs) whose LDS histogram windows still hold
-    // kMinWindowMass of each motif's background score distribution.  Windows share what the tables
-    // and strips leave: a motif whose whole range fits takes it, the others split the rest and
-    // spill the rows outside their window (partial windows, see score_hist_kernel).
+    // grouping: the largest group (<= 3 motifs; 1 beyond kQuadMaxBatchWidth) whose LDS histogram windows still
+    // hold kMinWindowMass of each motif's background score distribution, with 16 waves per workgroup if that
+    // works and 8 (half the strips) otherwise.  Windows share what the tables and strips leave: a motif whose
+    // whole range fits takes it, the others split the rest and spill the rows outside their window.
     constexpr double kMinWindowMass = 0.999;
     int i = 0;
     while (i < n_motifs) {
-        int mm = std::min(3, n_motifs - i), nb_lds[3] = {0, 0, 0};
+        int mm = std::min(W <= kQuadMaxBatchWidth ? 3 : 1, n_motifs - i), nb_lds[3] = {0, 0, 0};
         int win_lo[3] = {0, 0, 0}, win_nb[3] = {0, 0, 0};
-        for (; mm >= 1; --mm) {
-            const int zero[3] = {0, 0, 0};
-            long long room = ((long long)kMaxLdsBytes - (long long)score_lds_bytes(W, ndw, mm, zero)) /
-                             (long long)sizeof(unsigned);
-            bool open[3] = {false, false, false};
-            int users = 0;
-            for (int k = 0; k < mm; ++k) {
-                win_nb[k] = 0;
-                win_lo[k] = motifs[i + k]->lo;
-                open[k] = d_hist && d_hist[i + k];
-                users += open[k];
+        int waves = kWavesPerWG;
+        bool found = false;
+        for (; mm >= 1 && !found; --mm) {
+            for (waves = kWavesPerWG; waves >= kWavesPerWG / 2 && !found; waves /= 2) {
+                long long room = ((long long)kMaxLdsBytes - (long long)quad_fixed_lds(W, waves, mm)) /
+                                 (long long)sizeof(unsigned);
+                bool open[3] = {false, false, false};
+                int users = 0;
+                for (int k = 0; k < mm; ++k) {
+                    win_nb[k] = 0;
+                    win_lo[k] = motifs[i + k]->lo;
+                    open[k] = d_hist && d_hist[i + k];
+                    users += open[k];
+                }
+                bool ok = room > 0 || users == 0;
+                // water-filling: ranges that fit their equal share are served whole, the rest share again
+                for (bool again = true; ok && again && users > 0;) {
+                    again = false;
+                    const long long share = room / users - 1;
+                    for (int k = 0; k < mm; ++k)
+                        if (open[k] && motifs[i + k]->nb <= share) {
+                            win_nb[k] = motifs[i + k]->nb;
+                            room -= win_nb[k] + 1;
+                            open[k] = false;
+                            --users;
+                            again = true;
+                        }
+                }
+                if (ok && users > 0) {
+                    const long long share = room / users - 1;
+                    if (share < 256) ok = false;
+                    for (int k = 0; ok && k < mm; ++k)
+                        if (open[k]) {
+                            const gfm_motif::Window w = best_window(motifs[i + k], (int)share);
+                            win_nb[k] = w.bins;
+                            win_lo[k] = w.lo;
+                            // a partial window is acceptable for a lone motif at 8 waves (nothing smaller exists)
+                            if ((mm > 1 || waves > kWavesPerWG / 2) && w.mass < kMinWindowMass) ok = false;
+                        }
+                }
+                found = ok;
+                if (found) break;
             }
-            bool ok = room > 0 || users == 0;
-            // water-filling: ranges that fit their equal share are served whole, the rest share again
-            for (bool again = true; ok && again && users > 0;) {
-                again = false;
-                const long long share = room / users - 1;
-                for (int k = 0; k < mm; ++k)
-                    if (open[k] && motifs[i + k]->nb <= share) {
-                        win_nb[k] = motifs[i + k]->nb;
-                        room -= win_nb[k] + 1;
-                        open[k] = false;
-                        --users;
-                        again = true;
-                    }
-            }
-            if (ok && users > 0) {
-                const long long share = room / users - 1;
-                if (share < 256) ok = false;
-                for (int k = 0; ok && k < mm; ++k)
-                    if (open[k]) {
-                        const gfm_motif::Window w = best_window(motifs[i + k], (int)share);
-                        win_nb[k] = w.bins;
-                        win_lo[k] = w.lo;
-                        if (mm > 1 && w.mass < kMinWindowMass) ok = false;
-                    }
-            }
-            if (ok || mm == 1) break;
+            if (found) break;
         }
-        if (mm < 1) mm = 1;
-        for (int k = 0; k < mm; ++k) nb_lds[k] = (d_hist && d_hist[i + k]) ? win_nb[k] + 1 : 0;
-        const size_t lds = score_lds_bytes(W, ndw, mm, nb_lds);
+        if (!found) return fail(GFM_ERR_INVALID, "no LDS left for a histogram window at width %d", W);
+        for (int k = 0; k < mm; ++k) {
+            if (win_nb[k] > motifs[i + k]->part_nb)
+                return fail(GFM_ERR_INVALID, "internal error: histogram window larger than the workspace");
+            nb_lds[k] = (d_hist && d_hist[i + k]) ? win_nb[k] + 1 : 0;
+        }
+        size_t lds = quad_fixed_lds(W, waves, mm);
+        for (int k = 0; k < mm; ++k) lds += sizeof(unsigned) * (size_t)nb_lds[k];
+        const long long want = (nchunks + waves - 1) / waves;
         int nslabs = (int)std::min<long long>(want, motifs[i]->max_slabs);
         for (int k = 1; k < mm; ++k) nslabs = std::min(nslabs, motifs[i + k]->max_slabs);
         int ws[3], slot[3], uh[3];
@@ -842,10 +793,8 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
                             (sel && !reset) ? reinterpret_cast<const unsigned long long *>(d_hit_count[i + k])
                                             : nullptr);
         }
-        int rc;
-        if (mm == 1) rc = dispatch_score<1>(ndw, motifs[i], d_kmers, n, W, row_base, a1, lds, nslabs, st, false);
-        else if (mm == 2) rc = dispatch_score<2>(ndw, motifs[i], d_kmers, n, W, row_base, a2, lds, nslabs, st, false);
-        else rc = dispatch_score<3>(ndw, motifs[i], d_kmers, n, W, row_base, a3, lds, nslabs, st, false);
+        const void *args = mm == 1 ? static_cast<const void *>(&a1) : (mm == 2 ? static_cast<const void *>(&a2) : &a3);
+        int rc = dispatch_quad(W, mm, motifs[i], d_kmers, n, row_base, args, lds, nslabs, waves, st, false);
         if (rc) return rc;
         for (int k = 0; k < mm; ++k) {
             gfm_motif *mo = motifs[i + k];

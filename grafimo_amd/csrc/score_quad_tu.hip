@@ -1,5 +1,6 @@
-// score_quad_tu.hip -- the instantiations of score_quad_kernel<W> (gfm_score_quad.hpp) for sixteen widths and
-// their launcher; compiled four times with -DGFM_QUAD_GROUP=0..3 into libgrafimo_hip.so.
+// score_quad_tu.hip -- the instantiations of score_quad_kernel<W, MM> (gfm_score_quad.hpp) for sixteen widths and one
+// MM, and their launcher; compiled eight times (-DGFM_QUAD_GROUP=0..3 -DGFM_QUAD_MM=1, groups 0 and 1 also with
+// MM = 2 and 3) into libgrafimo_hip.so, side by side.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -12,8 +13,8 @@
 #include "gfm_common.hpp"
 #include "gfm_score_quad.hpp"
 
-#ifndef GFM_QUAD_GROUP
-#error "compile with -DGFM_QUAD_GROUP=0..3"
+#if !defined(GFM_QUAD_GROUP) || !defined(GFM_QUAD_MM)
+#error "compile with -DGFM_QUAD_GROUP=0..3 -DGFM_QUAD_MM=1..3"
 #endif
 
 extern "C" void gfm_set_error_(const char *msg);
@@ -31,11 +32,11 @@ int qfail(int code, const std::string &msg)
         if (e_ != hipSuccess) return qfail(GFM_ERR_HIP, std::string(#expr " failed: ") + hipGetErrorString(e_)); \
     } while (0)
 
-template <int W>
-int launch_quad_t(const uint8_t *d_kmers, long long n, long long row_base, const MotifArgs &args, size_t lds,
+template <int W, int MM>
+int launch_quad_t(const uint8_t *d_kmers, long long n, long long row_base, const ScoreArgs<MM> &args, size_t lds,
                   int nslabs, int waves, hipStream_t st, bool prepare, hipEvent_t ev0, hipEvent_t ev1)
 {
-    auto kern = score_quad_kernel<W>;
+    auto kern = score_quad_kernel<W, MM>;
     if (prepare) {  // from gfm_motif_create (never inside a stream capture); once per process and device
         static std::atomic<unsigned long long> done{0ull};       // one bit per device for this instantiation
         int dev = 0;
@@ -60,17 +61,17 @@ int launch_quad_t(const uint8_t *d_kmers, long long n, long long row_base, const
 
 }  // namespace
 
-#define GFM_QUAD_NAME2(g) gfm_quad_launch_g##g
-#define GFM_QUAD_NAME(g) GFM_QUAD_NAME2(g)
+#define GFM_QUAD_NAME2(g, mm) gfm_quad_launch_g##g##_m##mm
+#define GFM_QUAD_NAME(g, mm) GFM_QUAD_NAME2(g, mm)
 
-extern "C" __attribute__((visibility("hidden"))) int GFM_QUAD_NAME(GFM_QUAD_GROUP)(
-    int W, const uint8_t *d_kmers, long long n, long long row_base, const void *motif_args, size_t lds, int nslabs,
+extern "C" __attribute__((visibility("hidden"))) int GFM_QUAD_NAME(GFM_QUAD_GROUP, GFM_QUAD_MM)(
+    int W, const uint8_t *d_kmers, long long n, long long row_base, const void *score_args, size_t lds, int nslabs,
     int waves, void *stream, int prepare, void *ev0, void *ev1)
 {
-    const MotifArgs &args = *static_cast<const MotifArgs *>(motif_args);
+    const ScoreArgs<GFM_QUAD_MM> &args = *static_cast<const ScoreArgs<GFM_QUAD_MM> *>(score_args);
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipEvent_t e0 = static_cast<hipEvent_t>(ev0), e1 = static_cast<hipEvent_t>(ev1);
-#define GFM_Q(N) case N: return launch_quad_t<N>(d_kmers, n, row_base, args, lds, nslabs, waves, st, prepare != 0, e0, e1);
+#define GFM_Q(N) case N: return launch_quad_t<N, GFM_QUAD_MM>(d_kmers, n, row_base, args, lds, nslabs, waves, st, prepare != 0, e0, e1);
     constexpr int B = 16 * GFM_QUAD_GROUP;
     switch (W) {
 #ifdef GFM_ONLY_W   // development builds (scripts/lab_build.sh): one width, seconds to compile

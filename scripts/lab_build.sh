@@ -11,10 +11,13 @@ mkdir -p "$root/lab"
 CC=(/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fvisibility=hidden
     -I"$root/include" -DGFM_ONLY_W="$W" "$@")
 "${CC[@]}" -c "$src/grafimo_hip.hip" -o "$root/lab/gfm_$tag.o" &
-for g in 0 1 2 3; do "${CC[@]}" -DGFM_QUAD_GROUP=$g -c "$src/score_quad_tu.hip" -o "$root/lab/gfm_${tag}_g$g.o" & done
+for gm in 0:1 1:1 2:1 3:1 0:2 1:2 0:3 1:3; do
+    "${CC[@]}" -DGFM_QUAD_GROUP=${gm%:*} -DGFM_QUAD_MM=${gm#*:} -c "$src/score_quad_tu.hip" \
+        -o "$root/lab/gfm_${tag}_g${gm%:*}_m${gm#*:}.o" &
+done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/lab/libgfm_$tag.so" "$root/lab/gfm_$tag.o" \
-    "$root/lab"/gfm_${tag}_g{0,1,2,3}.o "$src/graph_extract.o" "$src/tsv_ingest.o" "$src/vcf_ingest.o" \
+    "$root/lab"/gfm_${tag}_g?_m?.o "$src/graph_extract.o" "$src/tsv_ingest.o" "$src/vcf_ingest.o" \
     "$src/scan_stream.o" -lpthread -lz
-rm -f "$root/lab/gfm_$tag.o" "$root/lab"/gfm_${tag}_g?.o
+rm -f "$root/lab/gfm_$tag.o" "$root/lab"/gfm_${tag}_g?_m?.o
 echo "built lab/libgfm_$tag.so"
