@@ -331,11 +331,11 @@ def main():
         if cfg == 5:      # a step launches one batched kernel per group of <= 3 same-width motifs: sum of their means
             k_ms = float(sum(float(np.mean(k)) for k in kernel_ms if len(k)))
             timed = int(sum(len(k) for k in kernel_ms))
-            kname = "score_hist_kernel<NDW, MM> (batched, one launch per group of same-width motifs; summed per step)"
+            kname = "score_quad_kernel<W, MM> (batched, one launch per group of <= 3 same-width motifs; summed per step)"
         else:
             k_ms = float(np.mean(kernel_ms[0])) if len(kernel_ms[0]) else float("nan")
             timed = int(len(kernel_ms[0]))
-            kname = f"score_quad_kernel<{mots[0]['width']}>"
+            kname = f"score_quad_kernel<{mots[0]['width']}, 1>"
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
