@@ -170,7 +170,8 @@ def main():
     ap.add_argument("--threshold", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--slots", type=int, default=2, help="buffer slots of the scan pipeline")
+    ap.add_argument("--slots", type=int, default=3,
+                    help="buffer slots of the scan pipeline (2: the device waits for slot reuse; >= 3: the host does)")
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostic: initialise torch.distributed and issue the collectives even with "
                          "one rank (exercises the N > 1 code path on a 1-GPU box)")

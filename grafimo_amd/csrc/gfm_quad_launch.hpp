@@ -13,12 +13,9 @@ constexpr int kQuadRows = 256;   // k-mers per wave per step: 64 lanes x 4 rows
 #ifndef GFM_QUAD_DEPTH
 #define GFM_QUAD_DEPTH 1
 #endif
-#ifndef GFM_LAB_STORE
-#define GFM_LAB_STORE 0
-#endif
-#ifndef GFM_LAB_LEVEL   // development builds only (scripts/lab_build.sh): 1..3 strip work out of the kernel for timing
-#define GFM_LAB_LEVEL 0
-#endif
+// cache-policy bits of the score stores (gfx950 cpol: 1 sc0, 2 nt, 16 sc1)
+constexpr int kStoreThrough = 17;   // sc0 sc1: write-through, lines stay allocated (Infinity Cache)
+constexpr int kStoreStream = 2;     // nt: streaming
 constexpr int kQuadDepth = GFM_QUAD_DEPTH;    // chunks in flight per wave beside the one being scored
 
 __host__ __device__ constexpr int quad_pad(int W) { return (W % 8 == 0) ? 16 : 0; }

@@ -27,11 +27,17 @@ constexpr int kHitQueue = 64;                  // per-wave LDS hit queue (entrie
 // appends the slabs.  No returning atomic sits on the kernel's tail: per wave or per
 // workgroup, 512..4096 same-word atomics there cost +30..45 us on a 100 us kernel (measured;
 // one word sustains ~88 returning atomics/us, MI355X_MICROARCH "dequeue").
-// HitCtl rotates three mid-run counters so that the kernel that zeroes one never races a
-// kernel that uses it: call k uses slot k%3, its post_kernel zeroes slot (k+2)%3.
+// HitCtl rotates its mid-run counters so that the kernel that zeroes one never races a kernel
+// that uses it: call k uses slot k % kCtlSlots, its post_kernel zeroes slot (k + kCtlAhead) % kCtlSlots.
+// That slot was last used by call k - 4, whose post kernel ran before this one, and is next used by
+// call k + 4, which starts after this post kernel (the scoring workspace it shares is a ring of
+// kWorkspaces = 4: see gfm_score_kmers).
+constexpr int kWorkspaces = 4;
+constexpr int kCtlSlots = 8;
+constexpr int kCtlAhead = 4;
 struct HitCtl {
-    unsigned long long mid[3];   // entries flushed mid-run by the current call
-    unsigned long long snap[3];  // *hit_count as the call found it
+    unsigned long long mid[kCtlSlots];   // entries flushed mid-run by the current call
+    unsigned long long snap[kCtlSlots];  // *hit_count as the call found it
 };
 constexpr int kResidPerWG = kWavesPerWG * kHitQueue;  // staging slab entries per workgroup
 
@@ -92,7 +98,10 @@ struct MotifArgs {
     long long *resid;
     int *resid_n;
 };
-template <int MM> struct ScoreArgs { MotifArgs m[MM]; };
+template <int MM> struct ScoreArgs {
+    MotifArgs m[MM];
+    int store_through;   // 1: score stores write through (sc0 sc1), 0: streaming (nt); see score_store_through()
+};
 
 // LDS reads of the inner loop go through address-space-3 pointers built from 32-bit offsets: the
 // dynamic LDS of this kernel starts at offset 0 (it has no static LDS; checked at entry), so a table
@@ -127,7 +136,7 @@ post_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, i
     const int tid = threadIdx.x;
     // A call that selects nothing has no hit-slab block to re-zero the mid-run counter two calls ahead
     // (below); without this a flush of call k would still be counted by call k+3.
-    if (blockIdx.x == 0 && tid == 0 && hit_slabs == 0 && ctl) ctl->mid[(par + 2) % 3] = 0ull;
+    if (blockIdx.x == 0 && tid == 0 && hit_slabs == 0 && ctl) ctl->mid[(par + kCtlAhead) % kCtlSlots] = 0ull;
     if ((int)blockIdx.x < hist_blocks) {
         const int bx = blockIdx.x % bin_blocks, by = blockIdx.x / bin_blocks;
         const int b = bx * 256 + tid;
@@ -176,7 +185,7 @@ post_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, i
         if ((long long)(base + i) < hit_cap) hit_rows[base + i] = slab[i];
     if (g == 0 && tid == 0) {
         *hit_count = start + (unsigned long long)part_all[0];
-        ctl->mid[(par + 2) % 3] = 0ull;
+        ctl->mid[(par + kCtlAhead) % kCtlSlots] = 0ull;
     }
 }
 

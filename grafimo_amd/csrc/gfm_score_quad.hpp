@@ -80,6 +80,7 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
     const long long nfull = n / kQuadRows;
     const long long cstride = (long long)gridDim.x * n_waves;
     bool vec_store = true;                            // uniform: every score buffer 16-byte aligned
+    const bool through = a.store_through != 0;        // uniform: cache policy of the score stores
 #pragma unroll
     for (int m = 0; m < MM; ++m) vec_store = vec_store && (reinterpret_cast<uintptr_t>(a.m[m].scores) & 15u) == 0;
 
@@ -266,12 +267,27 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
             const int k0 = 4 * lane;
 #pragma unroll
             for (int m = 0; m < MM; ++m) {
+                // Scores leave through buffer stores, one descriptor per chunk and motif (base = the chunk's 1 KiB
+                // of scores: wave-uniform, SGPRs).  Two cache policies, chosen per launch by the host
+                // (score_store_through() in grafimo_hip.hip, where the measurements are): write-through while the
+                // launch's scores fit the Infinity Cache, streaming (nt) beyond.
+                const __amdgpu_buffer_rsrc_t rs =
+                    __builtin_amdgcn_make_buffer_rsrc(a.m[m].scores + crow, 0, kQuadRows * 4, 0x00020000);
                 if (vec_store) {   // one 16-byte store per lane and motif: the wave writes 1 KiB contiguous
-                    const i32x4 out = {score[m][0], score[m][1], score[m][2], score[m][3]};
-                    __builtin_nontemporal_store(out, reinterpret_cast<i32x4 *>(a.m[m].scores + crow + k0));
+                    const u32x4_t out = {(unsigned)score[m][0], (unsigned)score[m][1], (unsigned)score[m][2],
+                                         (unsigned)score[m][3]};
+                    if (through)
+                        __builtin_amdgcn_raw_buffer_store_b128(out, rs, k0 * 4, 0, kStoreThrough);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b128(out, rs, k0 * 4, 0, kStoreStream);
                 } else {           // a score buffer that is only 4-byte aligned
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(score[m][j], a.m[m].scores + crow + k0 + j);
+                    for (int j = 0; j < 4; ++j) {
+                        if (through)
+                            __builtin_amdgcn_raw_buffer_store_b32((unsigned)score[m][j], rs, (k0 + j) * 4, 0, kStoreThrough);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b32((unsigned)score[m][j], rs, (k0 + j) * 4, 0, kStoreStream);
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) p_score[m][j] = score[m][j];

@@ -55,19 +55,19 @@ struct gfm_motif {
     uint16_t *d_tab = nullptr;
     double *d_pmf = nullptr;
     double *d_ptable = nullptr;
-    // Scoring workspace, double-buffered by call parity so that the post kernel of call k (on a
-    // tail stream) may run while the score kernel of call k+1 fills the other set.
-    unsigned *d_partials[2] = {nullptr, nullptr};   // [max_slabs][hnb+1] histogram slabs
-    unsigned *d_spill[2] = {nullptr, nullptr};      // [nb] rows outside a partial window
-    long long *d_resid[2] = {nullptr, nullptr};     // [max_slabs][kResidPerWG] residual hits
-    int *d_resid_n[2] = {nullptr, nullptr};         // [max_slabs]
+    // Scoring workspace, a ring of kWorkspaces sets taken in call order, so that the post kernel of call k
+    // (on a tail stream) may run while the score kernels of calls k+1.. fill the other sets.
+    unsigned *d_partials[kWorkspaces] = {};   // [max_slabs][hnb+1] histogram slabs
+    unsigned *d_spill[kWorkspaces] = {};      // [nb] rows outside a partial window
+    long long *d_resid[kWorkspaces] = {};     // [max_slabs][kResidPerWG] residual hits
+    int *d_resid_n[kWorkspaces] = {};         // [max_slabs]
     QWork *d_qwork = nullptr;        // q-value kernels' block totals / minima
     double *d_qscratch = nullptr;    // [L] raw BH values when the caller wants no q-table
     HitCtl *d_ctl = nullptr;
-    unsigned call_no = 0;           // score calls: HitCtl slot call_no % 3, workspace call_no % 2
-    hipEvent_t ev_scored[2] = {nullptr, nullptr};   // score kernel of the last call of a parity done
-    hipEvent_t ev_posted[2] = {nullptr, nullptr};   // its post kernel done (workspace free again)
-    bool posted_valid[2] = {false, false};
+    unsigned call_no = 0;           // score calls: HitCtl slot call_no % kCtlSlots, workspace call_no % kWorkspaces
+    hipEvent_t ev_scored[kWorkspaces] = {};   // score kernel of the last call on a workspace done
+    hipEvent_t ev_posted[kWorkspaces] = {};   // its post kernel done (workspace free again)
+    bool posted_valid[kWorkspaces] = {};
     // separate workspace of gfm_select_hits (runs on the caller's tail stream, next to scoring)
     long long *d_sel_resid = nullptr;
     int *d_sel_resid_n = nullptr;
@@ -160,16 +160,21 @@ int run_dp(const int64_t *sm, int W, const double *bg, double *d_pmf, hipStream_
 
 // score_quad_kernel<W, MM> is instantiated in score_quad_tu.hip: eight translation units of sixteen widths and one
 // MM each (compiled side by side: one unit with all of them took four minutes).  `args` = ScoreArgs<mm>.
+// `done` (optional, in/out): an event to complete with this kernel (it rides on the dispatch packet).  When the
+// launch is also a timed one, the timer's stop event takes that place and is handed back through `done`: whoever
+// must wait for the kernel waits on what `done` holds after the call.
 int dispatch_quad(int W, int mm, gfm_motif *timer, const uint8_t *d_kmers, long long n, long long row_base,
-                  const void *args, size_t lds, int nslabs, int waves, hipStream_t st, bool prepare_only)
+                  const void *args, size_t lds, int nslabs, int waves, hipStream_t st, bool prepare_only,
+                  hipEvent_t *done = nullptr)
 {
     if (W < 1 || W > GFM_MAX_WIDTH) return fail(GFM_ERR_INVALID, "unsupported width %d", W);
     if (mm < 1 || mm > 3 || (mm > 1 && W > kQuadMaxBatchWidth))
         return fail(GFM_ERR_INVALID, "no kernel for %d motifs of width %d in one launch", mm, W);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = done ? *done : nullptr;
     if (!prepare_only && timer && !timer->ev0.empty() && (timer->ev_calls++ % (unsigned)timer->ev_every) == 0) {
         e0 = timer->ev0[timer->ev_next];
         e1 = timer->ev1[timer->ev_next];
+        if (done) *done = e1;
         timer->ev_next = (timer->ev_next + 1) % (int)timer->ev0.size();
         timer->ev_used = std::min(timer->ev_used + 1, (int)timer->ev0.size());
     }
@@ -180,6 +185,21 @@ int dispatch_quad(int W, int mm, gfm_motif *timer, const uint8_t *d_kmers, long 
         {gfm_quad_launch_g0_m2, gfm_quad_launch_g1_m2, nullptr, nullptr},
         {gfm_quad_launch_g0_m3, gfm_quad_launch_g1_m3, nullptr, nullptr}};
     return table[mm - 1][(W - 1) / 16](W, d_kmers, n, row_base, args, lds, nslabs, waves, st, prepare_only ? 1 : 0, e0, e1);
+}
+
+// Cache policy of a launch's score stores.  Measured on MI355X, W=19 (profiles/r02_lab_variants.txt, same box per
+// line): 2e7 rows (80 MB of scores) nt 85.7-89.2 us, plain 84.4-86.6, sc1 82.4-83.4, sc0 sc1 82.1-83.1;
+// 1.25e8 rows (500 MB) nt 560 us, plain 575-619, sc1 600, sc0 sc1 600.  Write-through stores leave their lines
+// in the 256 MB Infinity Cache, which pays while a launch's scores fit it next to the k-mer stream and costs
+// once they do not.  GRAFIMO_STORE_POLICY=through|stream overrides the choice (measurement aid).
+constexpr long long kStoreThroughMaxBytes = 128ll << 20;
+int score_store_through(long long n, int mm)
+{
+    if (const char *e = std::getenv("GRAFIMO_STORE_POLICY")) {
+        if (!std::strcmp(e, "through")) return 1;
+        if (!std::strcmp(e, "stream")) return 0;
+    }
+    return n * 4ll * mm <= kStoreThroughMaxBytes ? 1 : 0;
 }
 
 // LDS bytes of a launch of mm motifs before the histogram windows: pair tables | strips + hit queues
@@ -216,7 +236,7 @@ int launch_post(gfm_motif *m, const unsigned *partials, int hist_slabs, unsigned
     const int spill_blocks = (d_hist && spill && win_nb < m->nb) ? (m->nb + 255) / 256 : 0;
     const int total = hist_blocks + spill_blocks + hit_slabs;
     if (total == 0) {   // nothing to post, but the rotating hit counter is still handed on zeroed (see post_kernel)
-        if (ctl) HIP_TRY(hipMemsetAsync(&ctl->mid[(ctl_slot + 2) % 3], 0, sizeof(unsigned long long), st));
+        if (ctl) HIP_TRY(hipMemsetAsync(&ctl->mid[(ctl_slot + kCtlAhead) % kCtlSlots], 0, sizeof(unsigned long long), st));
         return GFM_OK;
     }
     hipLaunchKernelGGL(post_kernel, dim3(total), dim3(256), 0, st, partials, hist_slabs, win_nb, win_lo,
@@ -350,7 +370,7 @@ GFM_API void gfm_motif_destroy(gfm_motif_t m)
 {
     if (!m) return;
     if (m->d_slab) (void)hipFree(m->d_slab);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kWorkspaces; ++i) {
         if (m->ev_scored[i]) (void)hipEventDestroy(m->ev_scored[i]);
         if (m->ev_posted[i]) (void)hipEventDestroy(m->ev_posted[i]);
     }
@@ -456,8 +476,8 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     const size_t o_dp = carve(dp_scratch_bytes(W));
     const size_t o_qwork = carve(sizeof(QWork));
     const size_t o_qscratch = carve(sizeof(double) * (size_t)m->L);
-    size_t o_partials[2], o_resid[2], o_resid_n[2], o_spill[2];
-    for (int i = 0; i < 2; ++i) {
+    size_t o_partials[kWorkspaces], o_resid[kWorkspaces], o_resid_n[kWorkspaces], o_spill[kWorkspaces];
+    for (int i = 0; i < kWorkspaces; ++i) {
         o_partials[i] = carve(sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->part_nb + 1));
         o_resid[i] = carve(sizeof(long long) * (size_t)m->max_slabs * kResidPerWG);
         o_resid_n[i] = carve(sizeof(int) * (size_t)m->max_slabs);
@@ -465,8 +485,7 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     const size_t o_sel_resid = carve(sizeof(long long) * (size_t)m->sel_slabs * kResidPerWG);
     const size_t o_sel_resid_n = carve(sizeof(int) * (size_t)m->sel_slabs);
     const size_t o_zero = slab_bytes;                 // what follows starts out zeroed
-    o_spill[0] = carve(sizeof(unsigned) * (size_t)m->nb);
-    o_spill[1] = carve(sizeof(unsigned) * (size_t)m->nb);
+    for (int i = 0; i < kWorkspaces; ++i) o_spill[i] = carve(sizeof(unsigned) * (size_t)m->nb);
     const size_t o_ctl = carve(sizeof(HitCtl));
     const size_t o_sel_ctl = carve(sizeof(HitCtl));
     HIP_TRY_M(hipMalloc(&m->d_slab, slab_bytes));
@@ -476,7 +495,7 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     m->d_ptable = reinterpret_cast<double *>(m->d_slab + o_ptable);
     m->d_qwork = reinterpret_cast<QWork *>(m->d_slab + o_qwork);
     m->d_qscratch = reinterpret_cast<double *>(m->d_slab + o_qscratch);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kWorkspaces; ++i) {
         m->d_partials[i] = reinterpret_cast<unsigned *>(m->d_slab + o_partials[i]);
         m->d_resid[i] = reinterpret_cast<long long *>(m->d_slab + o_resid[i]);
         m->d_resid_n[i] = reinterpret_cast<int *>(m->d_slab + o_resid_n[i]);
@@ -637,24 +656,25 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     }
 
     const unsigned k = m->call_no++;
-    const int ws = (int)(k & 1u), slot = (int)(k % 3u);
+    const int ws = (int)(k % (unsigned)kWorkspaces), slot = (int)(k % (unsigned)kCtlSlots);
+    const int ws_prev = (int)((k + kWorkspaces - 1) % (unsigned)kWorkspaces);
     const bool reset = (flags & GFM_FLAG_RESET_HITS) != 0;
-    // workspace `ws` was last used by call k-2: its post kernel must be done.  Appending to a
+    // workspace `ws` was last used by call k-4: its post kernel must be done.  Appending to a
     // hit list additionally needs the count published by call k-1.
     if (m->posted_valid[ws] && !(flags & GFM_FLAG_CALLER_ORDERS_REUSE))
         HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws], 0));
-    if (split && select && !reset && m->posted_valid[ws ^ 1])
-        HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws ^ 1], 0));
+    if (split && select && !reset && m->posted_valid[ws_prev])
+        HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws_prev], 0));
     ScoreArgs<1> args{};
+    args.store_through = score_store_through(n, 1);
     fill_motif_args(args.m[0], m, ws, slot, use_hist, m->hlo, m->hnb, select_cutoff, d_scores,
                     reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                     reset ? nullptr : reinterpret_cast<unsigned long long *>(d_hit_count));
-    int rc = dispatch_quad(m->W, 1, m, d_kmers, n, row_base, &args, m->lds_bytes, nslabs, m->q_waves, st, false);
+    hipEvent_t scored = split ? m->ev_scored[ws] : nullptr;
+    int rc = dispatch_quad(m->W, 1, m, d_kmers, n, row_base, &args, m->lds_bytes, nslabs, m->q_waves, st, false,
+                           split ? &scored : nullptr);
     if (rc) return rc;
-    if (split) {
-        HIP_TRY(hipEventRecord(m->ev_scored[ws], st));
-        HIP_TRY(hipStreamWaitEvent(tail, m->ev_scored[ws], 0));
-    }
+    if (split) HIP_TRY(hipStreamWaitEvent(tail, scored, 0));
     rc = launch_post(m, m->d_partials[ws], nslabs, reinterpret_cast<unsigned long long *>(d_hist),
                      m->hlo, m->hnb, m->d_spill[ws], m->d_resid[ws], m->d_resid_n[ws], select ? nslabs : 0, m->d_ctl, slot,
                      reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
@@ -777,11 +797,12 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
         ScoreArgs<1> a1{};
         ScoreArgs<2> a2{};
         ScoreArgs<3> a3{};
+        a1.store_through = a2.store_through = a3.store_through = score_store_through(n, mm);
         for (int k = 0; k < mm; ++k) {
             gfm_motif *mo = motifs[i + k];
             const unsigned c = mo->call_no++;
-            ws[k] = (int)(c & 1u);
-            slot[k] = (int)(c % 3u);
+            ws[k] = (int)(c % (unsigned)kWorkspaces);
+            slot[k] = (int)(c % (unsigned)kCtlSlots);
             mo->posted_valid[ws[k]] = false;   // single stream: stream order protects the workspace
             uh[k] = (d_hist && d_hist[i + k]) ? 1 : 0;
             const int cut = select_cutoffs ? select_cutoffs[i + k] : GFM_NO_SELECT;
@@ -890,7 +911,7 @@ GFM_API int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, c
     const long long n4 = (n + 3) >> 2;
     long long blocks = (n4 + kSelThreads - 1) / kSelThreads;
     blocks = std::max<long long>(1, std::min<long long>(blocks, m->sel_slabs));
-    const int slot = (int)(m->sel_call_no++ % 3u);
+    const int slot = (int)(m->sel_call_no++ % (unsigned)kCtlSlots);
     hipLaunchKernelGGL(select_hits_kernel, dim3((unsigned)blocks), dim3(kSelThreads), 0, st, d_scores,
                        (long long)n, d_cutoff, (long long)row_base,
                        reinterpret_cast<long long *>(d_hit_rows), (long long)hit_capacity,

@@ -2,6 +2,7 @@
 // MM, and their launcher; compiled eight times (-DGFM_QUAD_GROUP=0..3 -DGFM_QUAD_MM=1, groups 0 and 1 also with
 // MM = 2 and 3) into libgrafimo_hip.so, side by side.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <atomic>
 #include <cstdint>
@@ -52,10 +53,14 @@ int launch_quad_t(const uint8_t *d_kmers, long long n, long long row_base, const
         done.fetch_or(bit, std::memory_order_release);
         return GFM_OK;
     }
-    if (ev0) Q_TRY(hipEventRecord(ev0, st));
-    hipLaunchKernelGGL(kern, dim3(nslabs), dim3(waves * kWave), lds, st, d_kmers, n, row_base, args);
+    // Events ride ON the dispatch packet (start / completion of this kernel) instead of being recorded around it:
+    // an event recorded behind the kernel is a barrier packet of its own in the queue, and the next score kernel
+    // of the stream starts several microseconds later for each of them (scripts/gap_micro.py).
+    if (ev0 || ev1)
+        hipExtLaunchKernelGGL(kern, dim3(nslabs), dim3(waves * kWave), lds, st, ev0, ev1, 0, d_kmers, n, row_base, args);
+    else
+        hipLaunchKernelGGL(kern, dim3(nslabs), dim3(waves * kWave), lds, st, d_kmers, n, row_base, args);
     Q_TRY(hipGetLastError());
-    if (ev1) Q_TRY(hipEventRecord(ev1, st));
     return GFM_OK;
 }
 

@@ -33,6 +33,7 @@ class ScanSlot:
         self.hits = torch.zeros(self.hit_capacity + 1, dtype=torch.int64, device=device)
         self.done = torch.cuda.Event()
         self.tail_done = torch.cuda.Event()
+        self.used = False
         self.gathered = None
         # raw addresses for the ctypes fast path
         self.p_scores = self.scores.data_ptr()
@@ -54,8 +55,8 @@ class ScanSlot:
 
 class KmerScanner:
     def __init__(self, dm: DeviceMotif, n_rows: int, hit_capacity: Optional[int] = None,
-                 device=None, group=None, n_slots: int = 2, side_stream: bool = True,
-                 always_collective: bool = False, gather_group=None):
+                 device=None, group=None, n_slots: int = 3, side_stream: bool = True,
+                 always_collective: bool = False, gather_group=None, host_paced: Optional[bool] = None):
         torch = _torch()
         self.dm = dm
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -87,9 +88,17 @@ class KmerScanner:
         self._side_p = self.side.cuda_stream if self.side is not None else None
         self._lib = _nv.lib()
         self._cutoffs = {}
-        # with exactly two slots, waiting for slot.done of step k-2 (below) already implies that
-        # the library's workspace of call k-2 is free again: skip its own event wait
-        self._reuse_flag = _nv.GFM_FLAG_CALLER_ORDERS_REUSE if n_slots == 2 else 0
+        # Slot reuse.  Batch k takes slot k % n_slots, whose previous batch (k - n_slots) must have been
+        # consumed by its tail.  With two slots the main stream waits for that on the device (an event wait:
+        # a barrier packet in front of the score kernel, several microseconds of an idle GPU per batch).  With
+        # three or more slots the HOST waits instead (host_paced): the device still holds n_slots - 1 queued
+        # batches meanwhile, and the main stream then carries nothing but score kernels, back to back.
+        self.host_paced = (n_slots >= 3) if host_paced is None else bool(host_paced)
+        if self.host_paced and n_slots < 2:
+            raise ValueError("host-paced slot reuse needs at least two slots")
+        # either way batch k - 4 is done when batch k is enqueued (n_slots <= 4): the library's workspace
+        # ring of four is free again without its own event wait
+        self._reuse_flag = _nv.GFM_FLAG_CALLER_ORDERS_REUSE if n_slots <= 4 else 0
         self._turn = 0
         # entries of a slot's hit buffer ([count | hits...]) that a gather moves: the whole buffer until
         # size_gather() has seen how many hits a batch really holds
@@ -118,7 +127,9 @@ class KmerScanner:
     def enqueue(self, d_kmers, threshold: float, on_qvalue: bool = False, want_qvalues: bool = True,
                 row_base: int = 0, gather_hits: bool = False) -> ScanSlot:
         """Enqueue the whole path for one batch; returns the slot holding its outputs.
-        Nothing here synchronises with the host.  Kept lean on purpose: a step is ~100 us of GPU
+        With two slots nothing here synchronises with the host; with three or more (host_paced) the host
+        waits for the batch n_slots back, which the device finished long ago unless the host runs more than
+        n_slots - 1 batches ahead.  Kept lean on purpose: a step is ~100 us of GPU
         time, so the host side (ctypes calls with cached raw pointers, no torch dispatch unless a
         collective is needed) must stay well below that or the GPU starves."""
         if on_qvalue and not want_qvalues:      # the reference asserts this in ResultTmp.to_df
@@ -132,7 +143,12 @@ class KmerScanner:
         main_p = main.cuda_stream
         tail = self.side if self.side is not None else main
         tail_p = self._side_p if self.side is not None else main_p
-        main.wait_event(slot.done)           # the slot's previous batch has been consumed
+        if slot.used:                        # the slot's previous batch has been consumed
+            if self.host_paced:
+                slot.done.synchronize()
+            else:
+                main.wait_event(slot.done)
+        slot.used = True
         # no zeroing on the critical path: the q-value kernel hands the histogram back cleared
         # (GFM_FLAG_CLEAR_HIST) and the hit list restarts through GFM_FLAG_RESET_HITS
         n = int(d_kmers.shape[0])

@@ -44,9 +44,11 @@ extern "C" {
 /* flags */
 #define GFM_FLAG_RESET_HITS 1u /* start the hit list at 0 instead of appending at *d_hit_count */
 #define GFM_FLAG_CLEAR_HIST 2u /* gfm_qvalue_table: zero the histogram after reading it        */
-/* gfm_score_kmers with a tail stream: the caller guarantees (by its own stream order) that the
- * tail work of the call two before this one has finished, so the library need not make the
- * main stream wait for it (an event wait costs ~5 us of stream time per step). */
+/* gfm_score_kmers with a tail stream: the caller guarantees (by its own stream order, or because the
+ * host has seen it complete) that the tail work of the call FOUR before this one on the same handle has
+ * finished -- the handle's scoring workspace is a ring of four -- so the library need not make the main
+ * stream wait for it (an event wait is a barrier packet in front of the score kernel: several
+ * microseconds of an idle GPU per step). */
 #define GFM_FLAG_CALLER_ORDERS_REUSE 4u
 /* a hit-list entry packs the global row id and the row's scaled score:
  * entry = (row << GFM_HIT_SCORE_BITS) | score   (score <= 1000*64 < 2^20) */

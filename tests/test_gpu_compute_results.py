@@ -357,3 +357,47 @@ def test_two_ranks_on_one_gpu_through_the_scanner():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("two ranks == one process: True") == 2
+
+
+@pytest.mark.parametrize("n_slots", [2, 3, 4])
+def test_scanner_slot_rings_under_pipelining(golden_motifs, n_slots):
+    """Batches enqueued back to back without a host synchronisation in between (two slots: the device orders
+    slot reuse; three or four: the host paces it and the main stream carries score kernels only).  Thirteen
+    batches walk the library's workspace ring (4) and hit-counter ring (8) more than once; thresholds
+    alternate between one that makes every wave flush its hit queue mid-run and selective ones, with and
+    without a q-value threshold.  Every batch must equal the oracle's scores / histogram-derived q-table."""
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.scan import KmerScanner
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    g = flat["ctcf_meme_unif#0"]
+    dev = torch.device("cuda:0")
+    dm = DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"], g["pmf"])
+    ptab = orc.p_table(g["pmf"])
+    rng = np.random.default_rng(5)
+    n = 60_000
+    batches = []
+    for b in range(13):
+        km = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(n - 7 * b, 19))
+        km[rng.integers(0, len(km), 40), rng.integers(0, 19, 40)] = ord("N")
+        batches.append(km)
+    d_batches = [torch.from_numpy(k).to(dev) for k in batches]
+    plan = [(1.0, False), (1e-2, False), (0.3, True), (1e-3, False), (1.0, False), (0.5, True), (1e-2, False)]
+    sc = KmerScanner(dm, n, device=dev, n_slots=n_slots)
+    assert sc.host_paced == (n_slots >= 3)
+    b = 0
+    while b < len(batches):
+        group = list(range(b, min(b + n_slots, len(batches))))
+        slots = [sc.enqueue(d_batches[i], plan[i % len(plan)][0], on_qvalue=plan[i % len(plan)][1]) for i in group]
+        for i, slot in zip(group, slots):
+            thr, on_q = plan[i % len(plan)]
+            res = sc.collect(slot)
+            exp_scores, p = orc.score_kmers_table(batches[i], g["score_matrix"], ptab, g["min_val"])
+            q = orc.fdr_bh(p)
+            keep = np.nonzero((q if on_q else p) < thr)[0]
+            assert res["n_scored"] == len(batches[i])
+            assert np.array_equal(res["rows"], keep), (i, thr, on_q)
+            assert np.array_equal(res["scaled"], exp_scores[keep])
+            assert np.allclose(res["qtable"][exp_scores[keep]], q[keep], rtol=1e-12, atol=0)
+        b += n_slots
+    dm.close()
