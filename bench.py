@@ -240,7 +240,9 @@ def main():
         groups = {w: [j for j, m in enumerate(mots) if m["width"] == w] for w in widths}
         bufs = {w: [synth.make_device_kmers(n, w, mots[groups[w][0]]["probs"], synth.seed_for(50 + w, rank), dev)]
                 for w in widths}
-        scanners = {w: SameWidthScanner([dms[j] for j in groups[w]], n, max(4096, n // 64), dev) for w in widths}
+        scanners = {w: SameWidthScanner([dms[j] for j in groups[w]], n, max(4096, n // 64), dev,
+                                        side_stream=args.overlap == "on")
+                    for w in widths}
         units_per_step = n * len(mots)
         alg_bytes = sum(n * (w + 4 * len(groups[w])) for w in widths)
 
@@ -249,7 +251,8 @@ def main():
                 scanners[w].enqueue(bufs[w][0], args.threshold, on_qvalue=False, want_qvalues=True, row_base=rank * n)
 
         def finish():
-            pass
+            for w in widths:
+                scanners[w].finish()
         rotate = 1
     else:
         m0 = mots[0]

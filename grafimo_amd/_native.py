@@ -61,6 +61,8 @@ PROTOTYPES = {
     "gfm_profile_read": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
     "gfm_qvalue_table": (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                  ctypes.c_uint32, c_void_p]),
+    "gfm_qvalue_table_multi": (c_int, [c_void_p, c_int, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
+                                       ctypes.c_uint32, c_void_p]),
     "gfm_select_hits": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p,
                                 ctypes.c_uint32, c_void_p]),
     "gfm_scan_host": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_int, c_i64, c_void_p,
@@ -153,7 +155,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if L.gfm_abi_version() != 6:
+        if L.gfm_abi_version() != 7:
             raise ImportError("libgrafimo_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -145,9 +145,9 @@ __device__ inline unsigned long long block_sum_u64(unsigned long long v, unsigne
     return t;
 }
 
-__global__ void __launch_bounds__(kQThreads)
-q_count_kernel(const unsigned long long *__restrict__ hist, int L, int lo, int hi, int min_val,
-               QWork *__restrict__ ws, int *__restrict__ cutoff_out)
+__device__ inline void
+q_count_body(const unsigned long long *__restrict__ hist, int L, int lo, int hi, int min_val,
+             QWork *__restrict__ ws, int *__restrict__ cutoff_out)
 {
     __shared__ unsigned long long sh[kQThreads / kWave];
     const int j = lo + blockIdx.x * kQThreads + threadIdx.x;
@@ -163,14 +163,14 @@ q_count_kernel(const unsigned long long *__restrict__ hist, int L, int lo, int h
     }
 }
 
-__global__ void __launch_bounds__(kQThreads)
-q_raw_kernel(const unsigned long long *__restrict__ hist, const double *__restrict__ ptable, int lo,
-             int hi, QWork *__restrict__ ws, double *__restrict__ raw_out)
+__device__ inline void
+q_raw_body(const unsigned long long *__restrict__ hist, const double *__restrict__ ptable, int lo,
+           int hi, QWork *__restrict__ ws, double *__restrict__ raw_out, int nblk)
 {
     __shared__ unsigned long long sh[kQThreads / kWave];
     __shared__ double shm[kQThreads / kWave];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nblk = gridDim.x, blk = blockIdx.x;
+    const int blk = blockIdx.x;
     // totals: all rows, and the rows in blocks above this one
     unsigned long long a = 0, t = 0;
     for (int b = tid; b < nblk; b += kQThreads) {
@@ -212,17 +212,17 @@ q_raw_kernel(const unsigned long long *__restrict__ hist, const double *__restri
     }
 }
 
-__global__ void __launch_bounds__(kQThreads)
-q_final_kernel(const unsigned long long *hist, const double *__restrict__ ptable, int L, int lo,
-               int hi, int min_val, double threshold, int on_qvalue, const QWork *__restrict__ ws,
-               double *qtable, int *__restrict__ cutoff_out, unsigned long long *__restrict__ nrows_out,
-               unsigned long long *__restrict__ clear)
+__device__ inline void
+q_final_body(const unsigned long long *hist, const double *__restrict__ ptable, int L, int lo,
+             int hi, int min_val, double threshold, int on_qvalue, const QWork *__restrict__ ws,
+             double *qtable, int *__restrict__ cutoff_out, unsigned long long *__restrict__ nrows_out,
+             unsigned long long *__restrict__ clear, int nblk)
 {
     __shared__ unsigned long long sh[kQThreads / kWave];
     __shared__ double shm[kQThreads / kWave];
     __shared__ int first_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nblk = gridDim.x, blk = blockIdx.x;
+    const int blk = blockIdx.x;
     if (tid == 0) first_s = L;
     unsigned long long t = 0;
     double below = INFINITY, all = INFINITY;
@@ -285,5 +285,46 @@ q_final_kernel(const unsigned long long *hist, const double *__restrict__ ptable
     }
 }
 
+// The three passes over up to kQJobs motifs in ONE launch each (blockIdx.y = motif): the q-tables of a motif set
+// are 3 launches per kQJobs motifs instead of 3 per motif -- in stream order each of these latency-bound launches
+// costs ~5 us whatever it computes (fifty motifs: 0.8 ms of a 10.6 ms step).
+constexpr int kQJobs = 8;
+struct QJob {
+    const unsigned long long *hist;
+    const double *ptable;
+    QWork *ws;
+    double *qtable;               // raw values between q_raw and q_final, then q(s)
+    int *cutoff;
+    unsigned long long *nrows;
+    unsigned long long *clear;    // == hist when the histogram is handed back zeroed, else nullptr
+    int L, lo, hi, min_val, nblk;
+};
+struct QJobs {
+    QJob j[kQJobs];
+    double threshold;
+    int on_qvalue;
+};
+
+__global__ void __launch_bounds__(kQThreads) q_count_kernel(const QJobs jobs)
+{
+    const QJob &q = jobs.j[blockIdx.y];
+    if ((int)blockIdx.x >= q.nblk) return;
+    q_count_body(q.hist, q.L, q.lo, q.hi, q.min_val, q.ws, q.cutoff);
+}
+
+__global__ void __launch_bounds__(kQThreads) q_raw_kernel(const QJobs jobs)
+{
+    const QJob &q = jobs.j[blockIdx.y];
+    if ((int)blockIdx.x >= q.nblk) return;
+    q_raw_body(q.hist, q.ptable, q.lo, q.hi, q.ws, q.qtable, q.nblk);
+}
+
+__global__ void __launch_bounds__(kQThreads) q_final_kernel(const QJobs jobs)
+{
+    const QJob &q = jobs.j[blockIdx.y];
+    if ((int)blockIdx.x >= q.nblk) return;
+    q_final_body(q.hist, q.ptable, q.L, q.lo, q.hi, q.min_val, jobs.threshold, jobs.on_qvalue, q.ws, q.qtable,
+                 q.cutoff, q.nrows, q.clear, q.nblk);
+}
 
 }  // namespace

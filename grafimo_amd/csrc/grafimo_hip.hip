@@ -192,7 +192,7 @@ int dispatch_quad(int W, int mm, gfm_motif *timer, const uint8_t *d_kmers, long 
 // 1.25e8 rows (500 MB) nt 560 us, plain 575-619, sc1 600, sc0 sc1 600.  Write-through stores leave their lines
 // in the 256 MB Infinity Cache, which pays while a launch's scores fit it next to the k-mer stream and costs
 // once they do not.  GRAFIMO_STORE_POLICY=through|stream overrides the choice (measurement aid).
-constexpr long long kStoreThroughMaxBytes = 128ll << 20;
+constexpr long long kStoreThroughMaxBytes = 96ll << 20;   // crossover between 76 and 114 MiB (scripts/size_sweep.py)
 int score_store_through(long long n, int mm)
 {
     if (const char *e = std::getenv("GRAFIMO_STORE_POLICY")) {
@@ -869,26 +869,66 @@ GFM_API int gfm_profile_read(gfm_motif_t m, float *h_ms, int capacity, int *n_ou
     return GFM_OK;
 }
 
+namespace {
+// q-tables of `count` motifs (<= kQJobs): three launches, blockIdx.y = motif
+int launch_qtables(const gfm_motif_t *motifs, int count, uint64_t *const *d_hist, double threshold, int on_qvalue,
+                   double *const *d_qtable, int32_t *const *d_cutoff, uint64_t *const *d_nrows, uint32_t flags,
+                   hipStream_t st)
+{
+    QJobs jobs{};
+    jobs.threshold = threshold;
+    jobs.on_qvalue = on_qvalue;
+    int max_blk = 0;
+    for (int k = 0; k < count; ++k) {
+        gfm_motif *m = motifs[k];
+        QJob &q = jobs.j[k];
+        q.hist = reinterpret_cast<const unsigned long long *>(d_hist[k]);
+        q.ptable = m->d_ptable;
+        q.ws = m->d_qwork;
+        // q_raw leaves raw(s) in a table of L doubles: the caller's q-table, or ours when none is asked
+        q.qtable = (d_qtable && d_qtable[k]) ? d_qtable[k] : m->d_qscratch;
+        q.cutoff = d_cutoff ? d_cutoff[k] : nullptr;
+        q.nrows = d_nrows ? reinterpret_cast<unsigned long long *>(d_nrows[k]) : nullptr;
+        q.clear = (flags & GFM_FLAG_CLEAR_HIST) ? reinterpret_cast<unsigned long long *>(d_hist[k]) : nullptr;
+        q.L = m->L; q.lo = m->lo; q.hi = m->hi; q.min_val = m->min_val;
+        q.nblk = (m->nb + kQThreads - 1) / kQThreads;   // <= 251 for W <= 64
+        max_blk = std::max(max_blk, q.nblk);
+    }
+    const dim3 grid((unsigned)max_blk, (unsigned)count);
+    hipLaunchKernelGGL(q_count_kernel, grid, dim3(kQThreads), 0, st, jobs);
+    hipLaunchKernelGGL(q_raw_kernel, grid, dim3(kQThreads), 0, st, jobs);
+    hipLaunchKernelGGL(q_final_kernel, grid, dim3(kQThreads), 0, st, jobs);
+    HIP_TRY(hipGetLastError());
+    return GFM_OK;
+}
+}  // namespace
+
 GFM_API int gfm_qvalue_table(gfm_motif_t m, uint64_t *d_hist, double threshold, int on_qvalue,
                              double *d_qtable, int32_t *d_cutoff, uint64_t *d_nrows, uint32_t flags,
                              void *stream)
 {
     if (!m || !d_hist) return fail(GFM_ERR_INVALID, "NULL argument");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const unsigned long long *hc = reinterpret_cast<const unsigned long long *>(d_hist);
-    unsigned long long *clr =
-        (flags & GFM_FLAG_CLEAR_HIST) ? reinterpret_cast<unsigned long long *>(d_hist) : nullptr;
-    unsigned long long *nr = reinterpret_cast<unsigned long long *>(d_nrows);
-    const int nblk = (m->nb + kQThreads - 1) / kQThreads;   // <= 251 for W <= 64
-    hipLaunchKernelGGL(q_count_kernel, dim3(nblk), dim3(kQThreads), 0, st, hc, m->L, m->lo, m->hi,
-                       m->min_val, m->d_qwork, d_cutoff);
-    // q_raw leaves raw(s) in a table of L doubles: the caller's q-table, or ours when none is asked
-    double *qt = d_qtable ? d_qtable : m->d_qscratch;
-    hipLaunchKernelGGL(q_raw_kernel, dim3(nblk), dim3(kQThreads), 0, st, hc, m->d_ptable, m->lo, m->hi,
-                       m->d_qwork, qt);
-    hipLaunchKernelGGL(q_final_kernel, dim3(nblk), dim3(kQThreads), 0, st, hc, m->d_ptable, m->L, m->lo,
-                       m->hi, m->min_val, threshold, on_qvalue, m->d_qwork, qt, d_cutoff, nr, clr);
-    HIP_TRY(hipGetLastError());
+    return launch_qtables(&m, 1, &d_hist, threshold, on_qvalue, &d_qtable, &d_cutoff, &d_nrows, flags,
+                          static_cast<hipStream_t>(stream));
+}
+
+GFM_API int gfm_qvalue_table_multi(const gfm_motif_t *motifs, int n_motifs, uint64_t *const *d_hist,
+                                   double threshold, int on_qvalue, double *const *d_qtable,
+                                   int32_t *const *d_cutoff, uint64_t *const *d_nrows, uint32_t flags, void *stream)
+{
+    if (!motifs || n_motifs < 1 || !d_hist) return fail(GFM_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < n_motifs; ++i) {
+        if (!motifs[i] || !d_hist[i]) return fail(GFM_ERR_INVALID, "motif or histogram %d is NULL", i);
+        for (int j = 0; j < i; ++j)   // the passes of one motif share its scratch (QWork)
+            if (motifs[j] == motifs[i]) return fail(GFM_ERR_INVALID, "motif %d listed twice", i);
+    }
+    for (int i = 0; i < n_motifs; i += kQJobs) {
+        const int count = std::min(kQJobs, n_motifs - i);
+        const int rc = launch_qtables(motifs + i, count, d_hist + i, threshold, on_qvalue,
+                                      d_qtable ? d_qtable + i : nullptr, d_cutoff ? d_cutoff + i : nullptr,
+                                      d_nrows ? d_nrows + i : nullptr, flags, static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+    }
     return GFM_OK;
 }
 

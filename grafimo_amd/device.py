@@ -202,6 +202,25 @@ def score_multi(motifs, kmers, scores, hists=None, cutoffs=None, row_base=0, hit
         nv.GFM_FLAG_RESET_HITS if reset_hits else 0, _stream_ptr(stream)))
 
 
+def qvalue_table_multi(motifs, hists, threshold, on_qvalue, qtables=None, cutoffs=None, nrows=None, stream=None,
+                       clear_hist=False):
+    """gfm_qvalue_table_multi: the q-tables of several DeviceMotifs (any widths) in three launches per eight
+    motifs.  hists / qtables / cutoffs / nrows: lists of torch tensors (the optional ones may be None or hold
+    None entries)."""
+    M = len(motifs)
+    vp = ctypes.c_void_p
+
+    def ptr_array(tensors):
+        if tensors is None:
+            return None
+        return (vp * M)(*[(t.data_ptr() if t is not None else None) for t in tensors])
+
+    handles = (vp * M)(*[m.handle for m in motifs])
+    nv.check(nv.lib().gfm_qvalue_table_multi(
+        handles, M, ptr_array(hists), float(threshold), int(bool(on_qvalue)), ptr_array(qtables),
+        ptr_array(cutoffs), ptr_array(nrows), nv.GFM_FLAG_CLEAR_HIST if clear_hist else 0, _stream_ptr(stream)))
+
+
 def _stream_ptr(stream):
     if stream is None:
         torch = _torch()

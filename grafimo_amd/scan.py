@@ -249,9 +249,20 @@ class SameWidthScanner:
     group the M histograms cross the ranks as ONE all-reduce of an [M, L] tensor; q-tables (and the
     separate selection of --qvalueT) run per motif.  Nothing here synchronises with the host."""
 
-    def __init__(self, dms, n_rows: int, hit_capacity: int, device, group=None, always_collective: bool = False):
+    def __init__(self, dms, n_rows: int, hit_capacity: int, device, group=None, always_collective: bool = False,
+                 side_stream: bool = False):
         torch = _torch()
         self.dms, self.device, self.group = list(dms), device, group
+        # side_stream: the per-motif tail (all-reduce, q-table kernels, the separate selection of --qvalueT) goes
+        # to a side stream behind ONE event per enqueue and runs beside the score kernels of the next enqueue.
+        # Off by default: measured at fifty motifs (BASELINE config 5, one MI355X) the chain of small
+        # latency-bound kernels, 3-4x slower each while a score kernel saturates HBM, became the critical
+        # path (step 13.5 ms against 10.6 ms in stream order) and the score kernels lost 7 % to it.  It pays
+        # Kept as an option for N > 1, where the tail holds a collective (not measured: no multi-GPU box).
+        self.side = torch.cuda.Stream(device=device, priority=-1) if side_stream else None
+        self.scored = torch.cuda.Event()
+        self.done = torch.cuda.Event()
+        self.used = False
         M, L = len(self.dms), self.dms[0].L
         if any(d.L != L for d in self.dms):
             raise ValueError("SameWidthScanner: the motifs must share one width")
@@ -268,32 +279,50 @@ class SameWidthScanner:
 
     def enqueue(self, d_kmers, threshold: float, on_qvalue: bool = False, want_qvalues: bool = True,
                 row_base: int = 0):
-        from .device import score_multi
+        from .device import qvalue_table_multi, score_multi
         torch = _torch()
         if on_qvalue and not want_qvalues:
             raise ValueError("q-value threshold without q-values")
         M = len(self.dms)
         hists = [self.hist[j] for j in range(M)] if want_qvalues else None
+        main = torch.cuda.current_stream(self.device)
+        tail = self.side if self.side is not None else main
+        if self.used and tail is not main:
+            main.wait_event(self.done)           # the previous enqueue's tail has let go of the buffers
+        self.used = True
         if not on_qvalue:
             cuts = self._cuts.get(float(threshold))
             if cuts is None:
                 cuts = self._cuts[float(threshold)] = [d.pvalue_cutoff(threshold) for d in self.dms]
             score_multi(self.dms, d_kmers, self.scores, hists=hists, cutoffs=cuts, row_base=row_base,
                         hit_rows=[self.hits[j, 1:] for j in range(M)], hit_counts=[self.hits[j, :1] for j in range(M)],
-                        reset_hits=True)
+                        reset_hits=True, stream=main)
         else:
-            score_multi(self.dms, d_kmers, self.scores, hists=hists)
+            score_multi(self.dms, d_kmers, self.scores, hists=hists, stream=main)
+        if not (want_qvalues or on_qvalue):
+            return
+        if tail is not main:
+            self.scored.record(main)
+            tail.wait_event(self.scored)
         if want_qvalues:
             if self.collective:
-                torch.distributed.all_reduce(self.hist, group=self.group)   # one exchange for the whole set
-            for j, d in enumerate(self.dms):
-                d.qvalue_table(self.hist[j], threshold, on_qvalue, self.qtable[j], self.cutoff[j:j + 1],
-                               self.nrows[j:j + 1], clear_hist=True)
+                with torch.cuda.stream(tail):
+                    torch.distributed.all_reduce(self.hist, group=self.group)   # one exchange for the whole set
+            qvalue_table_multi(self.dms, [self.hist[j] for j in range(M)], threshold, on_qvalue,
+                               [self.qtable[j] for j in range(M)], [self.cutoff[j:j + 1] for j in range(M)],
+                               [self.nrows[j:j + 1] for j in range(M)], stream=tail, clear_hist=True)
         if on_qvalue:
             n = int(d_kmers.shape[0])
             for j, d in enumerate(self.dms):
                 d.select_hits(self.scores[j][:n], self.cutoff[j:j + 1], self.hits[j, 1:], self.hits[j, :1],
-                              row_base=row_base, reset_hits=True)
+                              row_base=row_base, reset_hits=True, stream=tail)
+        if tail is not main:
+            self.done.record(tail)
+
+    def finish(self):
+        """Make the caller's stream wait for the side-stream work of the last enqueue."""
+        if self.used and self.side is not None:
+            _torch().cuda.current_stream(self.device).wait_event(self.done)
 
 
 def scan_same_width(motifs, d_kmers, threshold: float, on_qvalue: bool = False,
@@ -304,7 +333,7 @@ def scan_same_width(motifs, d_kmers, threshold: float, on_qvalue: bool = False,
     if on_qvalue and not want_qvalues:
         raise ValueError("q-value threshold without q-values")
     torch = _torch()
-    from .device import score_multi
+    from .device import qvalue_table_multi, score_multi
     n = int(d_kmers.shape[0])
     dev = d_kmers.device
     cap = int(hit_capacity) if hit_capacity is not None else n
@@ -321,9 +350,9 @@ def scan_same_width(motifs, d_kmers, threshold: float, on_qvalue: bool = False,
     else:
         score_multi(motifs, d_kmers, scores, hists=hists)
     out = []
+    if want_qvalues:
+        qvalue_table_multi(motifs, hists, threshold, on_qvalue, qtabs, cut_d, nrows)
     for j, m in enumerate(motifs):
-        if want_qvalues:
-            m.qvalue_table(hists[j], threshold, on_qvalue, qtabs[j], cut_d[j], nrows[j])
         if on_qvalue:
             m.select_hits(scores[j], cut_d[j], hits[j][1:], hits[j][:1], row_base=row_base, reset_hits=True)
     torch.cuda.synchronize(dev)

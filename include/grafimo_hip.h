@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFM_ABI_VERSION 6
+#define GFM_ABI_VERSION 7
 
 #define GFM_OK 0
 #define GFM_ERR_INVALID (-1)  /* bad argument (NULL, width out of range, ...)            */
@@ -143,8 +143,8 @@ int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const uint8_t
 
 /* Measurement aid (bench.py): with slots > 0 every `every`-th later gfm_score_kmers call
  * brackets the score kernel ALONE (not the post kernel that follows it) with a hipEvent pair
- * on the launch stream, in a ring of `slots` pairs; slots = 0 turns it off.  (An event pair
- * costs ~7 us of stream time, hence the sampling.)  gfm_profile_read waits for the recorded
+ * on the launch stream, in a ring of `slots` pairs; slots = 0 turns it off.  (The events ride on the
+ * kernel's dispatch packet: start and completion of the kernel itself.)  gfm_profile_read waits for the recorded
  * events and returns the kernel durations in ms, oldest first. */
 int gfm_profile_enable(gfm_motif_t m, int slots, int every);
 int gfm_profile_read(gfm_motif_t m, float *h_ms_out, int capacity, int *n_out);
@@ -157,6 +157,14 @@ int gfm_profile_read(gfm_motif_t m, float *h_ms_out, int capacity, int *n_out);
 int gfm_qvalue_table(gfm_motif_t m, uint64_t *d_hist, double threshold, int on_qvalue,
                      double *d_qtable_out, int32_t *d_cutoff_out, uint64_t *d_nrows_out,
                      uint32_t flags, void *stream);
+/* The same for n_motifs DISTINCT motifs (any widths) in three launches per eight motifs instead of three per
+ * motif: the per-motif compute_qvalues calls of a motif set (score_sequences.py:401-428 once per motif,
+ * grafimo.py:181-195).  Arrays of n_motifs entries; d_qtable_out / d_cutoff_out / d_nrows_out may be NULL or hold
+ * NULL entries.  Results are identical to n_motifs gfm_qvalue_table calls. */
+int gfm_qvalue_table_multi(const gfm_motif_t *motifs, int n_motifs, uint64_t *const *d_hist,
+                           double threshold, int on_qvalue, double *const *d_qtable_out,
+                           int32_t *const *d_cutoff_out, uint64_t *const *d_nrows_out, uint32_t flags,
+                           void *stream);
 
 /* replaces the threshold filter of ResultTmp.to_df (resultsTmp.py:303-307) on device:
  * appends the packed entry of every row with d_scores[row] >= *d_cutoff. */

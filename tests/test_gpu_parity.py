@@ -210,6 +210,51 @@ def test_qvalue_table_vs_sorted_bh(dev, golden_motifs):
         dm.close()
 
 
+def test_qvalue_tables_of_a_motif_set_in_one_call(dev, golden_motifs):
+    """gfm_qvalue_table_multi (three launches per eight motifs) against one gfm_qvalue_table call per motif:
+    eleven motifs of four widths -- more than one group of eight -- with optional outputs left out for some;
+    every table, cutoff and row count must be bit-identical, and the histograms come back cleared."""
+    from grafimo_amd.device import DeviceMotif, qvalue_table_multi
+    _, flat = golden_motifs
+    keys = ["ctcf_meme_unif#0", "atf3_meme_unif#0", "syn30_jaspar_bg0#0", "gata1_meme_bgnt#0", "multi_meme_bg1#0"]
+    keys = [k for k in keys if k in flat] or list(flat)[:4]
+    dms, hists = [], []
+    rng = np.random.default_rng(77)
+    for i in range(11):
+        m = flat[keys[i % len(keys)]]
+        dm = DeviceMotif(m["score_matrix"], m["bg"], m["min_val"], m["scale"], m["offset"], m["pmf"])
+        n = 3000 + 1500 * i
+        d_km = torch.from_numpy(random_kmers(rng, n, m["width"], n_frac=0.01 if i % 3 else 0.0)).to(dev)
+        d_sc = torch.empty(n, dtype=torch.int32, device=dev)
+        h = torch.zeros(dm.L, dtype=torch.int64, device=dev)
+        dm.score(d_km, d_sc, hist=h)
+        dms.append(dm); hists.append(h)
+    for on_q, thr in [(False, 1e-2), (True, 0.5)]:
+        single = []
+        for dm, h in zip(dms, hists):
+            q = torch.empty(dm.L, dtype=torch.float64, device=dev)
+            cut = torch.zeros(1, dtype=torch.int32, device=dev); nr = torch.zeros(1, dtype=torch.int64, device=dev)
+            dm.qvalue_table(h, thr, on_q, q, cut, nr)
+            single.append((q, cut, nr))
+        work = [h.clone() for h in hists]
+        qs = [torch.empty(dm.L, dtype=torch.float64, device=dev) if i != 4 else None for i, dm in enumerate(dms)]
+        cuts = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in dms]
+        nrs = [torch.zeros(1, dtype=torch.int64, device=dev) if i != 9 else None for i in range(len(dms))]
+        qvalue_table_multi(dms, work, thr, on_q, qs, cuts, nrs, clear_hist=True)
+        torch.cuda.synchronize()
+        for i, (q, cut, nr) in enumerate(single):
+            if qs[i] is not None:
+                assert torch.equal(qs[i], q), (i, on_q)
+            assert int(cuts[i].item()) == int(cut.item())
+            if nrs[i] is not None:
+                assert int(nrs[i].item()) == int(nr.item())
+            assert int(work[i].abs().sum().item()) == 0
+    with pytest.raises(Exception):
+        qvalue_table_multi([dms[0], dms[0]], [hists[0], hists[1]], 0.1, False)
+    for dm in dms:
+        dm.close()
+
+
 def test_reference_704_row_fixture_through_scan_host(dev, golden_motifs, golden_json):
     """BASELINE config 1: the reference's own scoring fixture, GPU path end to end
     (numeric core; the DataFrame layer is covered by test_compute_results_gpu)."""
