@@ -26,9 +26,9 @@ struct FileCols {
 // score_seqs' row handling (score_sequences.py:273-293, :305-307) for one file
 void parse_file(const char *path, int W, bool skip_rev, FileCols &out);
 
-// Parse threads worth starting: at most `requested` (<= 0: every hardware thread), one per file and one per
-// MiB of text -- a thread parses ~1.4 GB/s, and starting and joining a thread costs tens of microseconds, so
-// 256 threads for 2e6 rows (180 MB) spent longer being created than parsing.
+// Parse threads worth waking: at most `requested` (<= 0: every hardware thread), one per file, one per MiB of
+// text (a thread parses ~1.4 GB/s) and 96 in all (beyond that the threads' own coordination costs more than
+// they add: tsv_ingest.cpp).
 int pick_threads(const char *const *paths, int n_paths, int requested);
 
 }  // namespace gfm_tsv_detail

@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -25,6 +26,7 @@
 #include <vector>
 
 #include "gfm_tsv_internal.hpp"
+#include "gfm_workers.hpp"
 
 #define GFM_API extern "C" __attribute__((visibility("default")))
 
@@ -251,19 +253,23 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
     sc->table.W = W;
     sc->table.files.resize((size_t)n_paths);
     const double t_begin = now_s();
+    const bool trace = std::getenv("GRAFIMO_SCAN_TRACE") != nullptr;   // development aid: phase times to stderr
+    auto stamp = [&](const char *what) {
+        if (trace) std::fprintf(stderr, "[scan] %8.3f ms  %s\n", (now_s() - t_begin) * 1e3, what);
+    };
 
     // ---- device side
     ScanPool *P = nullptr;
     S_RC(acquire_pool(&P));
     PoolLease lease{P};
+    stamp("pool acquired");
     S_RC(P->reserve_slots((size_t)chunk_rows * (size_t)W + 16));
     S_RC(P->reserve_tables((size_t)L));
     S_RC(P->reserve_hits(std::max<int64_t>(P->hit_cap, 1 << 20)));
     const bool fused = !on_qvalue;     // p-value threshold: the cutoff is known before scoring
     int32_t cutoff = GFM_NO_SELECT;
+    stamp("pool sized");
     if (fused) S_RC(gfm_motif_pvalue_cutoff(m, threshold, &cutoff));
-    if (want_qvalues) S_TRY(hipMemsetAsync(P->d_hist, 0, sizeof(uint64_t) * (size_t)L, P->score));
-    S_TRY(hipMemsetAsync(P->d_count, 0, sizeof(uint64_t), P->score));
 
     // ---- host pipeline.  Worker threads parse the files (taken in path order) AND stage them: as soon as
     // the row counts of all earlier files are known a file's global row offset is fixed, and whichever worker
@@ -346,24 +352,30 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
             cv_work.wait(lk);
         }
     };
-    std::vector<std::thread> pool;
-    for (int k = 0; k < nt; ++k) pool.emplace_back(work);
-    struct Joiner {
-        std::vector<std::thread> &pool;
+    stamp("pipeline set up");
+    // the workers come from the process-wide crew (gfm_workers.hpp): starting threads per call cost more than
+    // the parsing they did
+    struct Crew {
+        gfm_workers::Run run;
         std::mutex &mu;
         std::condition_variable &cv;
         bool &failed;
-        ~Joiner()
+        ~Crew()
         {
             {
                 std::lock_guard<std::mutex> lk(mu);
                 failed = true;          // whoever still waits gives up (after a normal run nobody does)
             }
             cv.notify_all();
-            for (auto &th : pool)
-                if (th.joinable()) th.join();
+            run.wait();
         }
-    } joiner{pool, mu, cv_work, failed};
+    } crew{{}, mu, cv_work, failed};
+    crew.run.start(nt, work);
+    stamp("workers started");
+    // (behind the start of the workers: the two memsets take 0.7 ms of host time to enqueue)
+    if (want_qvalues) S_TRY(hipMemsetAsync(P->d_hist, 0, sizeof(uint64_t) * (size_t)L, P->score));
+    S_TRY(hipMemsetAsync(P->d_count, 0, sizeof(uint64_t), P->score));
+    stamp("buffers cleared");
 
     int64_t total_rows = 0;
     size_t n_chunks = 0;
@@ -399,6 +411,7 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
             rows_k = (int64_t)chunk_staged.size() > k ? chunk_staged[(size_t)k] : 0;
         }
         if (rows_k == 0) break;
+        stamp("chunk staged");
         const int slot = (int)(k % kSlots);
         const size_t bytes = (size_t)rows_k * (size_t)W;
         int32_t *d_sc = nullptr;
@@ -421,13 +434,17 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
     }
     for (int64_t k = std::max<int64_t>(0, (int64_t)n_chunks - (kSlots - 1)); k < (int64_t)n_chunks; ++k)
         S_RC(release_chunk(k));
-    for (auto &th : pool) th.join();
+    stamp("chunks submitted and released");
+    crew.run.wait();
+    stamp("workers done");
     {
         std::lock_guard<std::mutex> lk(mu);
         if (failed) return sfail(GFM_ERR_IO, fail_msg);
     }
     const double t_parsed = t_parse_end;
+    if (trace) std::fprintf(stderr, "[scan] %8.3f ms  (last file parsed)\n", (t_parsed - t_begin) * 1e3);
     sc->table.index_rows();
+    stamp("rows indexed");
     if (sc->table.n != total_rows) return sfail(GFM_ERR_IO, "internal error: row count mismatch");
 
     // ---- tables, selection
@@ -464,6 +481,7 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
             S_TRY(hipMemcpyAsync(q.data(), P->d_q, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, P->score));
         }
         S_TRY(hipStreamSynchronize(P->score));
+        stamp("hits and q-table on the host");
         std::sort(packed.begin(), packed.end());   // (row << 20 | score): ascending by row
         sc->rows.resize((size_t)cnt);
         sc->scaled.resize((size_t)cnt);
@@ -481,6 +499,7 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
     } else {
         S_TRY(hipStreamSynchronize(P->score));
     }
+    stamp("hits annotated");
     const double t_end = now_s();
     sc->stats.n_rows = total_rows;
     sc->stats.n_hits = (int64_t)sc->rows.size();

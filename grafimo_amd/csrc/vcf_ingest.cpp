@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "grafimo_hip.h"
+#include "gfm_workers.hpp"
 
 #define GFM_API extern "C" __attribute__((visibility("default")))
 extern "C" void gfm_set_error_(const char *msg);
@@ -258,16 +259,15 @@ GFM_API int gfm_vcf_open(const char *path, const char *chrom, int with_haplotype
     }
     const int nt = std::max(1, std::min<int>(n_threads, (int)(lines.size() / 256) + 1));
     std::vector<Chunk> chunks((size_t)nt);
-    std::vector<std::thread> pool;
     const size_t per = (lines.size() + (size_t)nt - 1) / (size_t)nt;
-    for (int t = 0; t < nt; ++t)
-        pool.emplace_back([&, t]() {
-            Chunk &c = chunks[(size_t)t];
-            const size_t lo = (size_t)t * per, hi = std::min(lines.size(), lo + per);
-            for (size_t k = lo; k < hi && c.error.empty(); ++k)
-                parse_line(data + lines[k].first, data + lines[k].second, with_haplotypes != 0, c);
-        });
-    for (auto &th : pool) th.join();
+    std::atomic<int> next_part{0};
+    gfm_workers::run(nt, [&]() {
+        const int t = next_part.fetch_add(1);
+        Chunk &c = chunks[(size_t)t];
+        const size_t lo = (size_t)t * per, hi = std::min(lines.size(), lo + per);
+        for (size_t k = lo; k < hi && c.error.empty(); ++k)
+            parse_line(data + lines[k].first, data + lines[k].second, with_haplotypes != 0, c);
+    });
     int H = -1;
     for (auto &c : chunks) {
         if (!c.error.empty()) { gfm_set_error_(c.error.c_str()); return GFM_ERR_IO; }

@@ -18,6 +18,6 @@ done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/lab/libgfm_$tag.so" "$root/lab/gfm_$tag.o" \
     "$root/lab"/gfm_${tag}_g?_m?.o "$src/graph_extract.o" "$src/tsv_ingest.o" "$src/vcf_ingest.o" \
-    "$src/scan_stream.o" -lpthread -lz
+    "$src/scan_stream.o" "$src/gfm_workers.o" -lpthread -lz
 rm -f "$root/lab/gfm_$tag.o" "$root/lab"/gfm_${tag}_g?_m?.o
 echo "built lab/libgfm_$tag.so"

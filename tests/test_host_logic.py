@@ -233,3 +233,47 @@ def test_reference_shaped_motif_is_accepted_by_the_boundary_helpers(golden_motif
     assert np.array_equal(dense_score_matrix(m), rec["score_matrix"])
     assert np.array_equal(dense_bg(m), rec["bg"])
     assert not is_motif_like(object()) and not is_motif_like("MA0139.1")
+
+
+def _read_table(files):
+    t = KmerTable(files, 19, False, 8)
+    return t.n, bytes(t.kmers.tobytes()), list(t.start), list(t.name_id)
+
+
+def _read_in_child(files, q):
+    q.put(_read_table(files)[:2])
+
+
+def test_reader_threads_are_a_kept_crew(tmp_path, golden_motifs):
+    """The TSV reader's host threads come from one process-wide crew (csrc/gfm_workers.cpp).  Calls from several
+    host threads at once (one gets the crew, the others start threads of their own), repeated calls (the crew
+    is reused) and a call in a fork()ed child (which holds none of the parent's threads) must all return what
+    a single-threaded read returns."""
+    import multiprocessing as mp
+    import threading
+    from grafimo_amd import synth
+    _, flat = golden_motifs
+    batch = synth.make_batch(40, 2000, 19, np.asarray(flat["ctcf_meme_unif#0"]["probs"]), 5)
+    synth.write_tsv_dir(batch, str(tmp_path))
+    files = sorted(str(p) for p in (tmp_path / "width_19").glob("*.tsv"))
+    assert sum(os.path.getsize(f) for f in files) > (4 << 20)       # several threads are worth starting
+    t1 = KmerTable(files, 19, False, 1)
+    want = (t1.n, bytes(t1.kmers.tobytes()), list(t1.start), list(t1.name_id))
+    assert want[0] == len(batch)
+    for _ in range(3):
+        assert _read_table(files) == want
+    got = [None] * 4
+    th = [threading.Thread(target=lambda i=i: got.__setitem__(i, _read_table(files))) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert all(g == want for g in got)
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=_read_in_child, args=(files, q))
+    p.start()
+    child = q.get(timeout=120)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and child == want[:2]
+    assert _read_table(files) == want
