@@ -125,13 +125,30 @@ __device__ inline unsigned lds_offset(const void *p)
 //    snap + mid + (counts of slabs < g); the first of them publishes the new *hit_count and
 //    zeroes the mid-run counter two calls ahead.
 constexpr int kSlabsPerGroup = 16;
-__global__ void __launch_bounds__(256)
-post_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, int min_val,
-            unsigned long long *__restrict__ hist64, int bin_blocks, int hist_blocks,
-            unsigned *__restrict__ spill, int spill_lo, int spill_n, int spill_blocks,
-            const long long *__restrict__ resid, const int *__restrict__ resid_n, int hit_slabs,
-            HitCtl *__restrict__ ctl, int par, long long *__restrict__ hit_rows, long long hit_cap,
-            unsigned long long *__restrict__ hit_count)
+// One motif's share of a post launch.  A batched score launch (up to kPostJobs = 3 motifs) posts all of them in ONE
+// launch, blockIdx.y = motif: in stream order a launch costs ~5 us whatever it does.
+constexpr int kPostJobs = 3;
+struct PostJob {
+    const unsigned *partials;
+    unsigned long long *hist64;
+    unsigned *spill;
+    const long long *resid;
+    const int *resid_n;
+    HitCtl *ctl;
+    long long *hit_rows;
+    unsigned long long *hit_count;
+    long long hit_cap;
+    int nslabs, nb, lo, min_val, bin_blocks, hist_blocks, spill_lo, spill_n, spill_blocks, hit_slabs, par, total;
+};
+struct PostJobs { PostJob j[kPostJobs]; };
+
+__device__ inline void
+post_body(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, int min_val,
+          unsigned long long *__restrict__ hist64, int bin_blocks, int hist_blocks,
+          unsigned *__restrict__ spill, int spill_lo, int spill_n, int spill_blocks,
+          const long long *__restrict__ resid, const int *__restrict__ resid_n, int hit_slabs,
+          HitCtl *__restrict__ ctl, int par, long long *__restrict__ hit_rows, long long hit_cap,
+          unsigned long long *__restrict__ hit_count)
 {
     const int tid = threadIdx.x;
     // A call that selects nothing has no hit-slab block to re-zero the mid-run counter two calls ahead
@@ -187,6 +204,15 @@ post_kernel(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, i
         *hit_count = start + (unsigned long long)part_all[0];
         ctl->mid[(par + kCtlAhead) % kCtlSlots] = 0ull;
     }
+}
+
+__global__ void __launch_bounds__(256) post_kernel(const PostJobs jobs)
+{
+    const PostJob &q = jobs.j[blockIdx.y];
+    if ((int)blockIdx.x >= q.total) return;
+    post_body(q.partials, q.nslabs, q.nb, q.lo, q.min_val, q.hist64, q.bin_blocks, q.hist_blocks, q.spill, q.spill_lo,
+              q.spill_n, q.spill_blocks, q.resid, q.resid_n, q.hit_slabs, q.ctl, q.par, q.hit_rows, q.hit_cap,
+              q.hit_count);
 }
 
 // Rows with score >= *cutoff -> hit list (separate pass; used when the cutoff depends on

@@ -225,25 +225,52 @@ gfm_motif::Window best_window(gfm_motif *m, int bins)
     return best;
 }
 
-// one launch after a scoring / selection kernel: histogram slabs -> hist64, hit slabs -> list
+// what follows a scoring / selection kernel: histogram slabs -> hist64, hit slabs -> list.  post_job() describes
+// one motif's share, launch_posts() runs up to kPostJobs of them in one launch.
+PostJob post_job(gfm_motif *m, const unsigned *partials, int hist_slabs, unsigned long long *d_hist,
+                 int win_lo, int win_nb, unsigned *spill, const long long *resid, const int *resid_n, int hit_slabs,
+                 HitCtl *ctl, int ctl_slot, long long *d_hit_rows, long long cap, unsigned long long *d_hit_count)
+{
+    PostJob q{};
+    q.bin_blocks = (win_nb + 1 + 255) / 256;
+    const int groups = (hist_slabs + kSlabsPerGroup - 1) / kSlabsPerGroup;
+    q.hist_blocks = d_hist ? q.bin_blocks * groups : 0;
+    q.spill_blocks = (d_hist && spill && win_nb < m->nb) ? (m->nb + 255) / 256 : 0;
+    q.total = q.hist_blocks + q.spill_blocks + hit_slabs;
+    q.partials = partials; q.hist64 = d_hist; q.spill = spill; q.resid = resid; q.resid_n = resid_n; q.ctl = ctl;
+    q.hit_rows = d_hit_rows; q.hit_count = d_hit_count; q.hit_cap = cap;
+    q.nslabs = hist_slabs; q.nb = win_nb; q.lo = win_lo; q.min_val = m->min_val;
+    q.spill_lo = m->lo; q.spill_n = m->nb; q.hit_slabs = hit_slabs; q.par = ctl_slot;
+    return q;
+}
+
+int launch_posts(const PostJob *jobs, int count, hipStream_t st)
+{
+    PostJobs all{};
+    int live = 0, max_total = 0;
+    for (int k = 0; k < count; ++k) {
+        const PostJob &q = jobs[k];
+        if (q.total == 0) {   // nothing to post, but the rotating hit counter is still handed on zeroed (see post_kernel)
+            if (q.ctl)
+                HIP_TRY(hipMemsetAsync(&q.ctl->mid[(q.par + kCtlAhead) % kCtlSlots], 0, sizeof(unsigned long long), st));
+            continue;
+        }
+        all.j[live++] = q;
+        max_total = std::max(max_total, q.total);
+    }
+    if (live == 0) return GFM_OK;
+    hipLaunchKernelGGL(post_kernel, dim3((unsigned)max_total, (unsigned)live), dim3(256), 0, st, all);
+    HIP_TRY(hipGetLastError());
+    return GFM_OK;
+}
+
 int launch_post(gfm_motif *m, const unsigned *partials, int hist_slabs, unsigned long long *d_hist,
                 int win_lo, int win_nb, unsigned *spill, const long long *resid, const int *resid_n, int hit_slabs, HitCtl *ctl, int ctl_slot,
                 long long *d_hit_rows, long long cap, unsigned long long *d_hit_count, hipStream_t st)
 {
-    const int bin_blocks = (win_nb + 1 + 255) / 256;
-    const int groups = (hist_slabs + kSlabsPerGroup - 1) / kSlabsPerGroup;
-    const int hist_blocks = d_hist ? bin_blocks * groups : 0;
-    const int spill_blocks = (d_hist && spill && win_nb < m->nb) ? (m->nb + 255) / 256 : 0;
-    const int total = hist_blocks + spill_blocks + hit_slabs;
-    if (total == 0) {   // nothing to post, but the rotating hit counter is still handed on zeroed (see post_kernel)
-        if (ctl) HIP_TRY(hipMemsetAsync(&ctl->mid[(ctl_slot + kCtlAhead) % kCtlSlots], 0, sizeof(unsigned long long), st));
-        return GFM_OK;
-    }
-    hipLaunchKernelGGL(post_kernel, dim3(total), dim3(256), 0, st, partials, hist_slabs, win_nb, win_lo,
-                       m->min_val, d_hist, bin_blocks, hist_blocks, spill, m->lo, m->nb, spill_blocks,
-                       resid, resid_n, hit_slabs, ctl, ctl_slot, d_hit_rows, cap, d_hit_count);
-    HIP_TRY(hipGetLastError());
-    return GFM_OK;
+    const PostJob q = post_job(m, partials, hist_slabs, d_hist, win_lo, win_nb, spill, resid, resid_n, hit_slabs, ctl,
+                               ctl_slot, d_hit_rows, cap, d_hit_count);
+    return launch_posts(&q, 1, st);
 }
 
 void fill_motif_args(MotifArgs &a, gfm_motif *m, int ws, int slot, int use_hist, int win_lo, int win_nb,
@@ -817,18 +844,21 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
         const void *args = mm == 1 ? static_cast<const void *>(&a1) : (mm == 2 ? static_cast<const void *>(&a2) : &a3);
         int rc = dispatch_quad(W, mm, motifs[i], d_kmers, n, row_base, args, lds, nslabs, waves, st, false);
         if (rc) return rc;
+        PostJob posts[kPostJobs];
         for (int k = 0; k < mm; ++k) {
             gfm_motif *mo = motifs[i + k];
             const int cut = select_cutoffs ? select_cutoffs[i + k] : GFM_NO_SELECT;
             const bool sel = cut != GFM_NO_SELECT;
-            rc = launch_post(mo, mo->d_partials[ws[k]], nslabs,
-                             uh[k] ? reinterpret_cast<unsigned long long *>(d_hist[i + k]) : nullptr,
-                             win_lo[k], win_nb[k], mo->d_spill[ws[k]], mo->d_resid[ws[k]], mo->d_resid_n[ws[k]], sel ? nslabs : 0, mo->d_ctl, slot[k],
-                             sel ? reinterpret_cast<long long *>(d_hit_rows[i + k]) : nullptr,
-                             sel ? hit_capacity[i + k] : 0,
-                             sel ? reinterpret_cast<unsigned long long *>(d_hit_count[i + k]) : nullptr, st);
-            if (rc) return rc;
+            posts[k] = post_job(mo, mo->d_partials[ws[k]], nslabs,
+                                uh[k] ? reinterpret_cast<unsigned long long *>(d_hist[i + k]) : nullptr,
+                                win_lo[k], win_nb[k], mo->d_spill[ws[k]], mo->d_resid[ws[k]], mo->d_resid_n[ws[k]],
+                                sel ? nslabs : 0, mo->d_ctl, slot[k],
+                                sel ? reinterpret_cast<long long *>(d_hit_rows[i + k]) : nullptr,
+                                sel ? hit_capacity[i + k] : 0,
+                                sel ? reinterpret_cast<unsigned long long *>(d_hit_count[i + k]) : nullptr);
         }
+        rc = launch_posts(posts, mm, st);
+        if (rc) return rc;
         i += mm;
     }
     return GFM_OK;
