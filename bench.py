@@ -177,6 +177,9 @@ def main():
                          "one rank (exercises the N > 1 code path on a 1-GPU box)")
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket the score kernel of every n-th step with a hipEvent pair")
+    ap.add_argument("--no-candidates", action="store_true",
+                    help="config 4: select on the q-value threshold by a pass over every score instead of "
+                         "filtering the p < t candidates the score kernel collects (measurement aid)")
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
                     help="run the per-step tail (post kernel, collective, q-table, gather) on a side "
                          "stream so that it overlaps the next step's score kernel; auto = on")
@@ -267,7 +270,8 @@ def main():
         rotate = len(bufs)
         hit_cap = max(4096, n // 64)
         scanner = KmerScanner(dms[0], n, hit_capacity=hit_cap, device=dev, group=None, side_stream=side,
-                              n_slots=args.slots, always_collective=args.force_dist)
+                              n_slots=args.slots, always_collective=args.force_dist,
+                              candidates=not args.no_candidates)
         units_per_step = n
         alg_bytes = n * (W + 4)
 

@@ -65,6 +65,8 @@ PROTOTYPES = {
                                        ctypes.c_uint32, c_void_p]),
     "gfm_select_hits": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p,
                                 ctypes.c_uint32, c_void_p]),
+    "gfm_select_hits_from": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p,
+                                     c_void_p, c_i64, c_void_p, c_void_p]),
     "gfm_scan_host": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_int, c_i64, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, P(c_i64)]),
     "gfm_tsv_open": (c_int, [P(ctypes.c_char_p), c_int, c_int, c_int, c_int, P(c_void_p), P(c_i64)]),

@@ -218,11 +218,15 @@ __global__ void __launch_bounds__(256) post_kernel(const PostJobs jobs)
 // Rows with score >= *cutoff -> hit list (separate pass; used when the cutoff depends on
 // the global histogram, i.e. --qvalueT).  Same queue / slab scheme as the fused selection.
 constexpr int kSelThreads = 256;
+// `gate` (optional): the pass runs only if the candidate list behind it overflowed (*gate_count > gate_cap); then
+// it restarts the hit list whatever `hit_count` says.  Otherwise it leaves no residual hits and its post kernel
+// republishes the count it found (gfm_select_hits_from: the full pass is the fallback of the candidate filter).
 __global__ void __launch_bounds__(kSelThreads)
 select_hits_kernel(const int *__restrict__ scores, long long n, const int *__restrict__ cutoff_ptr,
                    long long row_base, long long *__restrict__ hit_rows, long long hit_cap,
                    const unsigned long long *__restrict__ hit_count, HitCtl *__restrict__ ctl,
-                   int par, long long *__restrict__ resid, int *__restrict__ resid_n)
+                   int par, long long *__restrict__ resid, int *__restrict__ resid_n,
+                   const unsigned long long *__restrict__ gate_count, long long gate_cap)
 {
     __shared__ long long hq[kSelThreads / kWave][kHitQueue];
     __shared__ int wq_n[kSelThreads / kWave];
@@ -230,6 +234,16 @@ select_hits_kernel(const int *__restrict__ scores, long long n, const int *__res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     long long *hitq = hq[wave];
     int qn = 0;
+    if (gate_count) {
+        if ((long long)*gate_count <= gate_cap) {      // the candidates were complete: nothing to do
+            if (tid == 0) {
+                resid_n[blockIdx.x] = 0;
+                if (blockIdx.x == 0) ctl->snap[par] = hit_count ? *hit_count : 0ull;
+            }
+            return;
+        }
+        hit_count = nullptr;                           // overflow: the list restarts from the scores
+    }
     if (blockIdx.x == 0 && tid == 0) ctl->snap[par] = hit_count ? *hit_count : 0ull;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
     const long long n4 = (n + 3) >> 2;
@@ -254,5 +268,70 @@ select_hits_kernel(const int *__restrict__ scores, long long n, const int *__res
     hitq_finish<kSelThreads / kWave>(hitq, qn, wq_n, wave, lane, tid, resid, resid_n);
 }
 
+// The entries of a candidate list (hit entries of rows with score >= some LOWER cutoff, as the fused selection of
+// the score kernel leaves them) whose score reaches *cutoff -> a new hit list.  A q-value threshold needs the
+// global histogram before its cutoff is known, but q >= p: the rows with q < t are among those with p < t, which
+// the score kernel can select on the fly -- the filter then reads a few MB of entries instead of every score
+// (1e8 rows: 400 MB).  A candidate list that overflowed (count > capacity) is reported through the published
+// count (= the candidates' count) and repaired by the gated select_hits_kernel that follows.
+// Compaction by blocks of kFilterPerBlock entries: every block counts its survivors (block-wide scan), takes its place
+// in the output with ONE returning atomic and writes them there (the order of a hit list does not matter: it is
+// sorted on the host).  The wave queues of the other selection kernels would flush once per 64 survivors -- with
+// nearly every candidate surviving that was 15 600 returning atomics on one word for 1e6 candidates (~180 us).
+// *hit_count must be 0 when the kernel starts.
+constexpr int kFilterPerThread = 16;
+constexpr int kFilterPerBlock = kSelThreads * kFilterPerThread;
+__global__ void __launch_bounds__(kSelThreads)
+filter_hits_kernel(const long long *__restrict__ cand, const unsigned long long *__restrict__ cand_count,
+                   long long cand_cap, const int *__restrict__ cutoff_ptr, long long *__restrict__ hit_rows,
+                   long long hit_cap, unsigned long long *__restrict__ hit_count)
+{
+    __shared__ int wave_tot[kSelThreads / kWave];
+    __shared__ unsigned long long block_base;
+    const int cutoff = *cutoff_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long have = *cand_count;
+    if ((long long)have > cand_cap) {      // overflowed candidates: say so through the count; the gated pass repairs it
+        if (blockIdx.x == 0 && tid == 0) *hit_count = have;
+        return;
+    }
+    const long long n = (long long)have;
+    const long long first = (long long)blockIdx.x * kFilterPerBlock;
+    if (first >= n) return;
+    long long e[kFilterPerThread];
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < kFilterPerThread; ++j) {
+        const long long i = first + (long long)j * kSelThreads + tid;      // coalesced
+        e[j] = i < n ? cand[i] : -1ll;
+        const bool keep = i < n && (int)(e[j] & ((1ll << GFM_HIT_SCORE_BITS) - 1)) >= cutoff;
+        if (!keep) e[j] = -1ll;
+        mine += keep ? 1 : 0;
+    }
+    // exclusive prefix of `mine` over the block
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    if (lane == kWave - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kSelThreads / kWave; ++w) {
+        if (w < wave) before += wave_tot[w];
+        total += wave_tot[w];
+    }
+    if (tid == 0) block_base = total ? atomicAdd(hit_count, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    unsigned long long at = block_base + (unsigned long long)(before + incl - mine);
+#pragma unroll
+    for (int j = 0; j < kFilterPerThread; ++j)
+        if (e[j] >= 0) {
+            if ((long long)at < hit_cap) hit_rows[at] = e[j];
+            ++at;
+        }
+}
 
 }  // namespace

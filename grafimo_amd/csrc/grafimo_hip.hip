@@ -988,7 +988,53 @@ GFM_API int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, c
                        (flags & GFM_FLAG_RESET_HITS)
                            ? nullptr
                            : reinterpret_cast<const unsigned long long *>(d_hit_count),
-                       m->d_sel_ctl, slot, m->d_sel_resid, m->d_sel_resid_n);
+                       m->d_sel_ctl, slot, m->d_sel_resid, m->d_sel_resid_n,
+                       static_cast<const unsigned long long *>(nullptr), 0ll);
+    HIP_TRY(hipGetLastError());
+    return launch_post(m, nullptr, 0, nullptr, 0, 0, nullptr, m->d_sel_resid, m->d_sel_resid_n, (int)blocks,
+                       m->d_sel_ctl, slot, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
+                       reinterpret_cast<unsigned long long *>(d_hit_count), st);
+}
+
+GFM_API int gfm_select_hits_from(gfm_motif_t m, const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
+                                 int64_t row_base, const int64_t *d_cand_rows, int64_t cand_capacity,
+                                 const uint64_t *d_cand_count, int64_t *d_hit_rows, int64_t hit_capacity,
+                                 uint64_t *d_hit_count, void *stream)
+{
+    if (!m) return fail(GFM_ERR_INVALID, "motif is NULL");
+    if (n < 0 || cand_capacity < 0) return fail(GFM_ERR_INVALID, "negative row count or capacity");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        if (d_hit_count) HIP_TRY(hipMemsetAsync(d_hit_count, 0, sizeof(uint64_t), st));
+        return GFM_OK;
+    }
+    if (!d_scores || !d_cutoff || !d_cand_rows || !d_cand_count || !d_hit_rows || !d_hit_count)
+        return fail(GFM_ERR_INVALID, "NULL device buffer");
+    if (d_cand_rows == d_hit_rows || reinterpret_cast<const void *>(d_cand_count) == d_hit_count)
+        return fail(GFM_ERR_INVALID, "the candidate list and the hit list must be different buffers");
+    if ((reinterpret_cast<uintptr_t>(d_scores) & 15u) != 0)
+        return fail(GFM_ERR_INVALID, "d_scores must be 16-byte aligned");
+    // 1. the candidates that reach the cutoff -> hit list (restarted)
+    {
+        const long long blocks = std::max<long long>(1, (cand_capacity + kFilterPerBlock - 1) / kFilterPerBlock);
+        HIP_TRY(hipMemsetAsync(d_hit_count, 0, sizeof(uint64_t), st));
+        hipLaunchKernelGGL(filter_hits_kernel, dim3((unsigned)blocks), dim3(kSelThreads), 0, st,
+                           reinterpret_cast<const long long *>(d_cand_rows),
+                           reinterpret_cast<const unsigned long long *>(d_cand_count), (long long)cand_capacity, d_cutoff,
+                           reinterpret_cast<long long *>(d_hit_rows), (long long)hit_capacity,
+                           reinterpret_cast<unsigned long long *>(d_hit_count));
+        HIP_TRY(hipGetLastError());
+    }
+    // 2. the pass over every score, which runs only if the candidate list had overflowed
+    const long long n4 = (n + 3) >> 2;
+    long long blocks = (n4 + kSelThreads - 1) / kSelThreads;
+    blocks = std::max<long long>(1, std::min<long long>(blocks, m->sel_slabs));
+    const int slot = (int)(m->sel_call_no++ % (unsigned)kCtlSlots);
+    hipLaunchKernelGGL(select_hits_kernel, dim3((unsigned)blocks), dim3(kSelThreads), 0, st, d_scores,
+                       (long long)n, d_cutoff, (long long)row_base, reinterpret_cast<long long *>(d_hit_rows),
+                       (long long)hit_capacity, reinterpret_cast<const unsigned long long *>(d_hit_count),
+                       m->d_sel_ctl, slot, m->d_sel_resid, m->d_sel_resid_n,
+                       reinterpret_cast<const unsigned long long *>(d_cand_count), (long long)cand_capacity);
     HIP_TRY(hipGetLastError());
     return launch_post(m, nullptr, 0, nullptr, 0, 0, nullptr, m->d_sel_resid, m->d_sel_resid_n, (int)blocks,
                        m->d_sel_ctl, slot, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,

@@ -132,6 +132,15 @@ class DeviceMotif:
                                           nv.GFM_FLAG_RESET_HITS if reset_hits else 0,
                                           _stream_ptr(stream)))
 
+    def select_hits_from(self, scores, cutoff, cand_rows, cand_count, hit_rows, hit_count, row_base=0, stream=None):
+        """gfm_select_hits_from: the rows with score >= *cutoff, read from a candidate list (the fused selection
+        at a lower cutoff) when it is complete, else from the scores."""
+        n = int(scores.numel())
+        nv.check(nv.lib().gfm_select_hits_from(self._h, scores.data_ptr() if n else None, n, cutoff.data_ptr(),
+                                               int(row_base), cand_rows.data_ptr(), int(cand_rows.numel()),
+                                               cand_count.data_ptr(), hit_rows.data_ptr(), int(hit_rows.numel()),
+                                               hit_count.data_ptr(), _stream_ptr(stream)))
+
     # ---- measurement aid (bench.py)
     def profile_enable(self, slots: int, every: int = 1):
         nv.check(nv.lib().gfm_profile_enable(self._h, int(slots), int(every)))

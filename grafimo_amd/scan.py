@@ -31,6 +31,8 @@ class ScanSlot:
         self.nrows = torch.zeros(1, dtype=torch.int64, device=device)
         # [0] = hit count, [1:] = hit rows (one buffer so that one gather moves both)
         self.hits = torch.zeros(self.hit_capacity + 1, dtype=torch.int64, device=device)
+        self.cand = None      # [count | candidate entries] of a q-value threshold scan (allocated on first use)
+        self.p_cand_count = self.p_cand_rows = None
         self.done = torch.cuda.Event()
         self.tail_done = torch.cuda.Event()
         self.used = False
@@ -44,6 +46,13 @@ class ScanSlot:
         self.p_hit_count = self.hits.data_ptr()
         self.p_hit_rows = self.hits.data_ptr() + 8
 
+    def candidates(self):
+        if self.cand is None:
+            self.cand = _torch().zeros_like(self.hits)
+            self.p_cand_count = self.cand.data_ptr()
+            self.p_cand_rows = self.cand.data_ptr() + 8
+        return self.cand
+
     @property
     def hit_count(self):
         return self.hits[:1]
@@ -56,7 +65,8 @@ class ScanSlot:
 class KmerScanner:
     def __init__(self, dm: DeviceMotif, n_rows: int, hit_capacity: Optional[int] = None,
                  device=None, group=None, n_slots: int = 3, side_stream: bool = True,
-                 always_collective: bool = False, gather_group=None, host_paced: Optional[bool] = None):
+                 always_collective: bool = False, gather_group=None, host_paced: Optional[bool] = None,
+                 candidates: bool = True):
         torch = _torch()
         self.dm = dm
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -99,6 +109,9 @@ class KmerScanner:
         # either way batch k - 4 is done when batch k is enqueued (n_slots <= 4): the library's workspace
         # ring of four is free again without its own event wait
         self._reuse_flag = _nv.GFM_FLAG_CALLER_ORDERS_REUSE if n_slots <= 4 else 0
+        # q-value threshold: select from the p < t candidates the score kernel collects (enqueue) instead of
+        # reading every score again; False = the separate pass over the scores (measurement aid)
+        self.candidates = bool(candidates)
         self._turn = 0
         # entries of a slot's hit buffer ([count | hits...]) that a gather moves: the whole buffer until
         # size_gather() has seen how many hits a batch really holds
@@ -156,6 +169,7 @@ class KmerScanner:
         h = dm.handle
         # the score kernel goes to the main stream; the library puts its post kernel (histogram
         # slabs -> slot.hist, residual hits -> slot.hits) on the tail stream behind an event
+        use_cand = on_qvalue and self.candidates
         if not on_qvalue:
             key = float(threshold)
             cut = self._cutoffs.get(key)
@@ -164,9 +178,23 @@ class KmerScanner:
             _nv.check(lib.gfm_score_kmers(h, kp, n, slot.p_scores, slot.p_hist if want_qvalues else None,
                                           cut, int(row_base), slot.p_hit_rows, slot.hit_capacity,
                                           slot.p_hit_count, _nv.GFM_FLAG_RESET_HITS | self._reuse_flag, main_p, tail_p))
-        else:
+        elif not use_cand:
             _nv.check(lib.gfm_score_kmers(h, kp, n, slot.p_scores, slot.p_hist, _nv.GFM_NO_SELECT, 0,
                                           None, 0, None, self._reuse_flag, main_p, tail_p))
+        else:
+            # q-value threshold: the cutoff needs the global histogram, but q >= p, so the rows with q < t are
+            # among those with p < t -- the score kernel collects THOSE on the fly (candidates), and the
+            # selection behind the q-table filters the candidate list instead of reading every score again
+            # (1e8 rows: 400 MB on the tail stream, beside the next score kernel).  A candidate list that
+            # overflows is noticed on the device and the scores are read after all (gfm_select_hits_from).
+            key = float(threshold)
+            cut = self._cutoffs.get(key)
+            if cut is None:
+                cut = self._cutoffs[key] = dm.pvalue_cutoff(key)
+            slot.candidates()
+            _nv.check(lib.gfm_score_kmers(h, kp, n, slot.p_scores, slot.p_hist, cut, int(row_base),
+                                          slot.p_cand_rows, slot.hit_capacity, slot.p_cand_count,
+                                          _nv.GFM_FLAG_RESET_HITS | self._reuse_flag, main_p, tail_p))
         if want_qvalues:
             if self.collective:
                 with torch.cuda.stream(tail):
@@ -174,10 +202,14 @@ class KmerScanner:
             _nv.check(lib.gfm_qvalue_table(h, slot.p_hist, float(threshold), int(bool(on_qvalue)),
                                            slot.p_qtable, slot.p_cutoff, slot.p_nrows,
                                            _nv.GFM_FLAG_CLEAR_HIST, tail_p))
-        if on_qvalue:
+        if on_qvalue and not use_cand:
             _nv.check(lib.gfm_select_hits(h, slot.p_scores, n, slot.p_cutoff, int(row_base),
                                           slot.p_hit_rows, slot.hit_capacity, slot.p_hit_count,
                                           _nv.GFM_FLAG_RESET_HITS, tail_p))
+        elif on_qvalue:
+            _nv.check(lib.gfm_select_hits_from(h, slot.p_scores, n, slot.p_cutoff, int(row_base),
+                                               slot.p_cand_rows, slot.hit_capacity, slot.p_cand_count,
+                                               slot.p_hit_rows, slot.hit_capacity, slot.p_hit_count, tail_p))
         if gather_hits and self.collective:
             gs = self._gather_stream
             if gs is not None:                 # gather on its own stream, behind this step's tail

@@ -171,6 +171,18 @@ int gfm_qvalue_table_multi(const gfm_motif_t *motifs, int n_motifs, uint64_t *co
 int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
                     int64_t row_base, int64_t *d_hit_rows, int64_t hit_capacity,
                     uint64_t *d_hit_count, uint32_t flags, void *stream);
+/* The same result -- the hit list restarted, holding the packed entry of every row with d_scores[row] >= *d_cutoff --
+ * taken from a CANDIDATE list instead of the n scores when that list is complete: d_cand_rows / *d_cand_count is a
+ * hit list as the fused selection of gfm_score_kmers left it for a cutoff that is known to be <= *d_cutoff.  With a
+ * q-value threshold t (--qvalueT) the cutoff needs the global histogram, but q >= p (BH), so the rows with q < t
+ * are among those with p < t: score with select_cutoff = gfm_motif_pvalue_cutoff(t) into the candidate list,
+ * build the q-table, then call this -- it reads the few candidates, not every score (1e8 rows: 400 MB).  If the
+ * candidate list overflowed (*d_cand_count > cand_capacity) the rows are taken from d_scores as gfm_select_hits
+ * does (decided on the device, no host synchronisation).  Candidate and hit buffers must differ. */
+int gfm_select_hits_from(gfm_motif_t m, const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
+                         int64_t row_base, const int64_t *d_cand_rows, int64_t cand_capacity,
+                         const uint64_t *d_cand_count, int64_t *d_hit_rows, int64_t hit_capacity,
+                         uint64_t *d_hit_count, void *stream);
 
 /* ------------------------------------------------------------------ one-call host form
  * compute_results' numeric core (score_sequences.py:44-211) for host-resident k-mers:

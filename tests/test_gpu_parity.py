@@ -210,6 +210,58 @@ def test_qvalue_table_vs_sorted_bh(dev, golden_motifs):
         dm.close()
 
 
+def test_selection_from_candidates_equals_selection_from_scores(dev, golden_motifs):
+    """gfm_select_hits_from: with a q-value threshold the score kernel collects the rows with p < t (q >= p) and
+    the selection filters that list instead of reading every score.  Same hit list as gfm_select_hits for a
+    complete candidate list, for one that overflowed (the device falls back to the scores), for a cutoff nothing
+    reaches and for one everything reaches; the scanner's --qvalueT path equals the oracle either way."""
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.scan import KmerScanner
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    m = flat["ctcf_meme_unif#0"]
+    dm = DeviceMotif(m["score_matrix"], m["bg"], m["min_val"], m["scale"], m["offset"], m["pmf"])
+    rng = np.random.default_rng(3)
+    n = 300_001
+    km = random_kmers(rng, n, 19, n_frac=0.01)
+    d_km = torch.from_numpy(km).to(dev)
+    d_sc = torch.empty(n + 3, dtype=torch.int32, device=dev)[:n]
+    low = dm.pvalue_cutoff(0.05)                      # candidates: ~5 % of the rows
+    for cap in (n, 4096):                             # complete / overflowing candidate list
+        cand = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
+        dm.score(d_km, d_sc, select_cutoff=low, hit_rows=cand[1:], hit_count=cand[:1], reset_hits=True)
+        torch.cuda.synchronize()
+        sc = d_sc.cpu().numpy()
+        assert (int(cand[0].item()) > cap) == (cap == 4096)
+        for cut in (low, low + 40, low + 400, int(sc.max()) + 1, low - 1 if cap == 4096 else low):
+            d_cut = torch.tensor([cut], dtype=torch.int32, device=dev)
+            want = torch.full((n + 1,), -1, dtype=torch.int64, device=dev)
+            dm.select_hits(d_sc, d_cut, want[1:], want[:1], row_base=7, reset_hits=True)
+            got = torch.full((n + 1,), 5, dtype=torch.int64, device=dev)     # stale count and entries
+            dm.select_hits_from(d_sc, d_cut, cand[1:], cand[:1], got[1:], got[:1], row_base=7)
+            torch.cuda.synchronize()
+            k = int(want[0].item())
+            assert int(got[0].item()) == k == int((sc >= cut).sum())
+            if cap == n:      # candidates carry row_base 0 (they were collected with it); rows differ by the base
+                a = np.sort(got[1:1 + k].cpu().numpy()); b = np.sort(want[1:1 + k].cpu().numpy())
+                assert np.array_equal(a + (7 << 20), b)
+            else:
+                assert np.array_equal(np.sort(got[1:1 + k].cpu().numpy()), np.sort(want[1:1 + k].cpu().numpy()))
+    # the scanner on a q-value threshold, hit capacity too small for the candidates but enough for the hits
+    ptab = orc.p_table(m["pmf"])
+    exp_sc, p = orc.score_kmers_table(km, m["score_matrix"], ptab, m["min_val"])
+    q = orc.fdr_bh(p)
+    for cap in (n, 2000):
+        scn = KmerScanner(dm, n, hit_capacity=cap, device=dev)
+        for thr in (0.9, 0.05):
+            keep = np.nonzero(q < thr)[0]
+            if len(keep) > cap:
+                continue
+            res = scn.collect(scn.enqueue(d_km, thr, on_qvalue=True))
+            assert np.array_equal(res["rows"], keep) and np.array_equal(res["scaled"], exp_sc[keep]), (cap, thr)
+    dm.close()
+
+
 def test_qvalue_tables_of_a_motif_set_in_one_call(dev, golden_motifs):
     """gfm_qvalue_table_multi (three launches per eight motifs) against one gfm_qvalue_table call per motif:
     eleven motifs of four widths -- more than one group of eight -- with optional outputs left out for some;
