@@ -202,7 +202,10 @@ int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, double thres
  * into columnar arrays.  Two calls: gfm_tsv_open counts, gfm_tsv_read fills. */
 typedef struct gfm_tsv *gfm_tsv_t;
 /* Parses every file (host threads) and reports the number of kept rows.
- * skip_reverse: drop '-' rows before they are counted (--no-reverse, :281-282). */
+ * skip_reverse: drop '-' rows before they are counted (--no-reverse, :281-282).
+ * n_threads: the reference's `cores` (score_sequences.py:123); <= 0 = every hardware thread.  The library uses
+ * at most that many, and never more than one per file, one per MiB of text, or 96; the threads belong to a crew
+ * the library keeps for the life of the process (the VCF reader and the streamed scan share it). */
 int gfm_tsv_open(const char *const *paths, int n_paths, int width, int skip_reverse,
                  int n_threads, gfm_tsv_t *out, int64_t *n_rows);
 /* Copies the parsed columns out (any pointer may be NULL):
