@@ -307,6 +307,7 @@ class SameWidthScanner:
         self.cutoff = torch.zeros(M, dtype=torch.int32, device=device)
         self.nrows = torch.zeros(M, dtype=torch.int64, device=device)
         self.hits = torch.zeros((M, int(hit_capacity) + 1), dtype=torch.int64, device=device)
+        self.cand = None      # candidate lists of a q-value threshold scan (allocated on first use)
         self._cuts = {}
 
     def enqueue(self, d_kmers, threshold: float, on_qvalue: bool = False, want_qvalues: bool = True,
@@ -329,8 +330,15 @@ class SameWidthScanner:
             score_multi(self.dms, d_kmers, self.scores, hists=hists, cutoffs=cuts, row_base=row_base,
                         hit_rows=[self.hits[j, 1:] for j in range(M)], hit_counts=[self.hits[j, :1] for j in range(M)],
                         reset_hits=True, stream=main)
-        else:
-            score_multi(self.dms, d_kmers, self.scores, hists=hists, stream=main)
+        else:       # q-value threshold: collect the p < t candidates while scoring (see KmerScanner.enqueue)
+            cuts = self._cuts.get(float(threshold))
+            if cuts is None:
+                cuts = self._cuts[float(threshold)] = [d.pvalue_cutoff(threshold) for d in self.dms]
+            if self.cand is None:
+                self.cand = torch.zeros_like(self.hits)
+            score_multi(self.dms, d_kmers, self.scores, hists=hists, cutoffs=cuts, row_base=row_base,
+                        hit_rows=[self.cand[j, 1:] for j in range(M)], hit_counts=[self.cand[j, :1] for j in range(M)],
+                        reset_hits=True, stream=main)
         if not (want_qvalues or on_qvalue):
             return
         if tail is not main:
@@ -346,8 +354,8 @@ class SameWidthScanner:
         if on_qvalue:
             n = int(d_kmers.shape[0])
             for j, d in enumerate(self.dms):
-                d.select_hits(self.scores[j][:n], self.cutoff[j:j + 1], self.hits[j, 1:], self.hits[j, :1],
-                              row_base=row_base, reset_hits=True, stream=tail)
+                d.select_hits_from(self.scores[j][:n], self.cutoff[j:j + 1], self.cand[j, 1:], self.cand[j, :1],
+                                   self.hits[j, 1:], self.hits[j, :1], row_base=row_base, stream=tail)
         if tail is not main:
             self.done.record(tail)
 
@@ -379,14 +387,18 @@ def scan_same_width(motifs, d_kmers, threshold: float, on_qvalue: bool = False,
         cuts = [m.pvalue_cutoff(threshold) for m in motifs]
         score_multi(motifs, d_kmers, scores, hists=hists, cutoffs=cuts, row_base=row_base,
                     hit_rows=[h[1:] for h in hits], hit_counts=[h[:1] for h in hits], reset_hits=True)
-    else:
-        score_multi(motifs, d_kmers, scores, hists=hists)
+    else:       # q-value threshold: the p < t candidates are collected while scoring (q >= p)
+        cuts = [m.pvalue_cutoff(threshold) for m in motifs]
+        cand = [torch.zeros(cap + 1, dtype=torch.int64, device=dev) for _ in motifs]
+        score_multi(motifs, d_kmers, scores, hists=hists, cutoffs=cuts, row_base=row_base,
+                    hit_rows=[c[1:] for c in cand], hit_counts=[c[:1] for c in cand], reset_hits=True)
     out = []
     if want_qvalues:
         qvalue_table_multi(motifs, hists, threshold, on_qvalue, qtabs, cut_d, nrows)
     for j, m in enumerate(motifs):
         if on_qvalue:
-            m.select_hits(scores[j], cut_d[j], hits[j][1:], hits[j][:1], row_base=row_base, reset_hits=True)
+            m.select_hits_from(scores[j], cut_d[j], cand[j][1:], cand[j][:1], hits[j][1:], hits[j][:1],
+                               row_base=row_base)
     torch.cuda.synchronize(dev)
     for j, m in enumerate(motifs):
         k = int(hits[j][0].item())

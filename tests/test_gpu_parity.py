@@ -614,6 +614,25 @@ def test_scan_same_width_equals_single_motif_scans(dev, golden_motifs):
             assert np.array_equal(res["rows"], one["rows"]) and np.array_equal(res["scaled"], one["scaled"])
             assert np.array_equal(res["qtable"], one["qtable"]) and res["n_scored"] == one["n_scored"]
         assert sum(len(r["rows"]) for r in multi) > 0
+    # the resident form (one set of buffers, enqueued repeatedly), with and without its side stream; a hit
+    # capacity the p < t candidates of the q-value threshold do not fit makes the device fall back to the scores
+    from grafimo_amd.scan import SameWidthScanner
+    n = len(batch)
+    for side, cap in [(False, n), (True, n), (False, 600)]:
+        sw = SameWidthScanner(dms, n, cap, dev, side_stream=side)
+        for on_q, thr in [(False, 1e-3), (True, 0.3), (True, 0.3), (False, 1e-3)]:
+            sw.enqueue(d_k, thr, on_qvalue=on_q)
+            sw.finish()
+            torch.cuda.synchronize()
+            for j, dm in enumerate(dms):
+                sc = KmerScanner(dm, n, device=dev, side_stream=False)
+                one = sc.collect(sc.enqueue(d_k, thr, on_qvalue=on_q))
+                k = int(sw.hits[j, 0].item())
+                assert k == len(one["rows"])
+                if k <= cap:
+                    packed = np.sort(sw.hits[j, 1:1 + k].cpu().numpy())
+                    assert np.array_equal(packed >> 20, one["rows"]) and np.array_equal(packed & 0xFFFFF, one["scaled"])
+                assert np.array_equal(sw.qtable[j].cpu().numpy(), one["qtable"])
     for dm in dms:
         dm.close()
 
