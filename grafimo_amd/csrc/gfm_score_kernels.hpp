@@ -124,7 +124,7 @@ __device__ inline unsigned lds_offset(const void *p)
 //  the remaining hit_slabs blocks: append residual hit slab g to the dense list at
 //    snap + mid + (counts of slabs < g); the first of them publishes the new *hit_count and
 //    zeroes the mid-run counter two calls ahead.
-constexpr int kSlabsPerGroup = 16;
+constexpr int kSlabsPerGroup = 16;   // 4 / 8 / 16 measure alike; 64 and 256 make the tail the critical path
 // One motif's share of a post launch.  A batched score launch (up to kPostJobs = 3 motifs) posts all of them in ONE
 // launch, blockIdx.y = motif: in stream order a launch costs ~5 us whatever it does.
 constexpr int kPostJobs = 3;
