@@ -405,7 +405,14 @@ def main():
             "cpu_baseline_table": cpu.get("cpu_baseline_table"),
             "e2e": e2e,
         }
-        print(json.dumps(out))
+        # RCCL's version banner sits in the C runtime's stdout buffer until the process ends: push it out first,
+        # so that the JSON line is the last line of the run
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
