@@ -401,3 +401,36 @@ def test_scanner_slot_rings_under_pipelining(golden_motifs, n_slots):
             assert np.allclose(res["qtable"][exp_scores[keep]], q[keep], rtol=1e-12, atol=0)
         b += n_slots
     dm.close()
+
+
+def test_timed_launches_with_a_tail_stream_keep_their_order(golden_motifs):
+    """The timing events of gfm_profile_enable ride on the score kernel's dispatch packet, and on a timed launch
+    the tail stream waits on the timer's stop event instead of the library's own (csrc dispatch_quad).  Every
+    launch timed, tail on a side stream, batches back to back: results unchanged, one plausible duration per
+    launch."""
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.scan import KmerScanner
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    g = flat["ctcf_meme_unif#0"]
+    dev = torch.device("cuda:0")
+    dm = DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"], g["pmf"])
+    ptab = orc.p_table(g["pmf"])
+    rng = np.random.default_rng(8)
+    n = 300_000
+    kms = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(n, 19)) for _ in range(3)]
+    d_kms = [torch.from_numpy(k).to(dev) for k in kms]
+    sc = KmerScanner(dm, n, device=dev, n_slots=3)
+    dm.profile_enable(16, every=1)
+    for rep in range(3):
+        slots = [sc.enqueue(d, 1e-3) for d in d_kms]
+        for km, slot in zip(kms, slots):
+            res = sc.collect(slot)
+            exp_sc, p = orc.score_kmers_table(km, g["score_matrix"], ptab, g["min_val"])
+            keep = np.nonzero(p < 1e-3)[0]
+            assert np.array_equal(res["rows"], keep) and np.array_equal(res["scaled"], exp_sc[keep])
+            assert res["n_scored"] == n
+    ms = dm.profile_read()
+    dm.profile_enable(0)
+    assert len(ms) == 9 and np.all(ms > 0.0005) and np.all(ms < 50.0)
+    dm.close()
