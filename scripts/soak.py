@@ -1,5 +1,8 @@
-"""Soak test of the pipelined scan (score kernel || post + q-table on the tail stream, two slots): every step's
-hit list, q-table and row count must equal the first step's.  Catches rare races between the streams."""
+"""Soak test of the pipelined scan (score kernel || post + q-table on the tail stream): every step's hit list,
+q-table and row count must equal the first step's.  Catches rare races between the streams and in the slot /
+workspace / hit-counter rings.   scripts/soak.py [steps] [n_slots]
+The q-value threshold used (0.2) makes the p < t candidate list overflow its capacity: the device-side fallback
+over the scores runs on every such step."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,7 +17,8 @@ dm = DeviceMotif(m.dense_score_matrix(), m.dense_bg(), m.min_val, m.scale, m.off
 batch = synth.make_batch(2000, 2000, 19, np.asarray(m.count_matrix), synth.seed_for(2))
 d = torch.from_numpy(batch.kmers).cuda()
 n = len(batch)
-sc = KmerScanner(dm, n, hit_capacity=n // 32, device=d.device, side_stream=True)
+n_slots = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+sc = KmerScanner(dm, n, hit_capacity=n // 32, device=d.device, side_stream=True, n_slots=n_slots)
 ref = None
 bad = 0
 t0 = time.time()
