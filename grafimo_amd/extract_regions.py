@@ -116,9 +116,10 @@ class GraphIndex:
     def from_fasta_vcf(cls, fasta: str, vcf: str, chrom: str, with_haplotypes: bool = True,
                        threads: int = 0, allow_skipped: bool = False) -> "GraphIndex":
         """Reference bases of `chrom` + its VCF records through the library's reader (gfm_vcf_*: host
-        threads, plain or gzip/bgzip): SNPs and plain deletions become sites; two haplotypes per sample in
-        file order.  Records the graph does not model (insertions, multi-base substitutions, a deletion that
-        overlaps an earlier one) would make the k-mers differ from vg's: the call FAILS on them unless
+        threads, plain or gzip/bgzip): substitutions (also multi-base ones, a site per position), insertions
+        behind an anchor base and plain deletions become sites; two haplotypes per sample in file order.
+        ALT alleles the graph does not model (complex alleles, a fourth alternate at one position, a deletion
+        that overlaps an earlier one) would make the k-mers differ from vg's: the call FAILS on them unless
         `allow_skipped` is set, in which case they are left out, counted in `.skipped` and reported on stderr."""
         ref = _read_fasta_record(fasta, chrom)
         h = ctypes.c_void_p()
