@@ -77,6 +77,8 @@ struct ScanPool {
     int32_t *d_cutoff = nullptr;
     uint64_t *d_count = nullptr;
     int64_t *d_hits = nullptr;
+    uint64_t *d_cand_count = nullptr;   // q-value threshold: the p < t candidates collected while scoring
+    int64_t *d_cand = nullptr;          // (same capacity as d_hits)
     int64_t hit_cap = 0;
     bool in_use = false;
 
@@ -93,6 +95,7 @@ struct ScanPool {
         }
         S_TRY(hipMalloc(&d_cutoff, sizeof(int32_t)));
         S_TRY(hipMalloc(&d_count, sizeof(uint64_t)));
+        S_TRY(hipMalloc(&d_cand_count, sizeof(uint64_t)));
         return GFM_OK;
     }
     int reserve_slots(size_t bytes)
@@ -129,9 +132,11 @@ struct ScanPool {
     {
         if (cap <= hit_cap) return GFM_OK;
         if (d_hits) (void)hipFree(d_hits);
-        d_hits = nullptr;
+        if (d_cand) (void)hipFree(d_cand);
+        d_hits = d_cand = nullptr;
         hit_cap = 0;
         S_TRY(hipMalloc(&d_hits, sizeof(int64_t) * (size_t)cap));
+        S_TRY(hipMalloc(&d_cand, sizeof(int64_t) * (size_t)cap));
         hit_cap = cap;
         return GFM_OK;
     }
@@ -169,6 +174,8 @@ struct ScanPool {
         if (d_cutoff) (void)hipFree(d_cutoff);
         if (d_count) (void)hipFree(d_count);
         if (d_hits) (void)hipFree(d_hits);
+        if (d_cand_count) (void)hipFree(d_cand_count);
+        if (d_cand) (void)hipFree(d_cand);
         if (copy) (void)hipStreamDestroy(copy);
         if (score) (void)hipStreamDestroy(score);
         *this = ScanPool();
@@ -266,10 +273,15 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
     S_RC(P->reserve_slots((size_t)chunk_rows * (size_t)W + 16));
     S_RC(P->reserve_tables((size_t)L));
     S_RC(P->reserve_hits(std::max<int64_t>(P->hit_cap, 1 << 20)));
-    const bool fused = !on_qvalue;     // p-value threshold: the cutoff is known before scoring
+    // p-value threshold: the cutoff is known before scoring and the score kernel selects the hits.  q-value
+    // threshold: q >= p, so the score kernel collects the p < t CANDIDATES the same way, and the selection behind
+    // the q-table filters those instead of reading every score again (gfm_select_hits_from).
+    const bool fused = !on_qvalue;
     int32_t cutoff = GFM_NO_SELECT;
     stamp("pool sized");
-    if (fused) S_RC(gfm_motif_pvalue_cutoff(m, threshold, &cutoff));
+    S_RC(gfm_motif_pvalue_cutoff(m, threshold, &cutoff));
+    int64_t *d_sel = fused ? P->d_hits : P->d_cand;             // the list the score kernel appends to
+    uint64_t *d_sel_count = fused ? P->d_count : P->d_cand_count;
 
     // ---- host pipeline.  Worker threads parse the files (taken in path order) AND stage them: as soon as
     // the row counts of all earlier files are known a file's global row offset is fixed, and whichever worker
@@ -375,6 +387,7 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
     // (behind the start of the workers: the two memsets take 0.7 ms of host time to enqueue)
     if (want_qvalues) S_TRY(hipMemsetAsync(P->d_hist, 0, sizeof(uint64_t) * (size_t)L, P->score));
     S_TRY(hipMemsetAsync(P->d_count, 0, sizeof(uint64_t), P->score));
+    S_TRY(hipMemsetAsync(P->d_cand_count, 0, sizeof(uint64_t), P->score));
     stamp("buffers cleared");
 
     int64_t total_rows = 0;
@@ -422,8 +435,7 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
         S_TRY(hipEventRecord(P->copied[slot], P->copy));
         S_TRY(hipStreamWaitEvent(P->score, P->copied[slot], 0));
         S_RC(gfm_score_kmers(m, P->d_kmers[slot], rows_k, d_sc, want_qvalues ? P->d_hist : nullptr, cutoff, total_rows,
-                             fused ? P->d_hits : nullptr, fused ? P->hit_cap : 0, fused ? P->d_count : nullptr, 0,
-                             P->score, nullptr));
+                             d_sel, P->hit_cap, d_sel_count, 0, P->score, nullptr));
         S_TRY(hipEventRecord(P->scored[slot], P->score));
         h2d_bytes += (int64_t)bytes;
         chunk_n.push_back(rows_k);
@@ -460,7 +472,16 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
             }
             return GFM_OK;
         };
-        if (on_qvalue) S_RC(select_all());
+        if (on_qvalue) {
+            uint64_t ccnt = 0;
+            S_TRY(hipMemcpyAsync(&ccnt, P->d_cand_count, sizeof ccnt, hipMemcpyDeviceToHost, P->score));
+            S_TRY(hipStreamSynchronize(P->score));
+            if ((int64_t)ccnt <= P->hit_cap)      // the candidates are complete: filter them (the gated pass over
+                S_RC(gfm_select_hits_from(m, P->score_blocks[0], chunk_n[0], P->d_cutoff, 0, P->d_cand, P->hit_cap,   // the scores exits at once)
+                                          P->d_cand_count, P->d_hits, P->hit_cap, P->d_count, P->score));
+            else
+                S_RC(select_all());
+        }
         uint64_t cnt = 0;
         S_TRY(hipMemcpyAsync(&cnt, P->d_count, sizeof cnt, hipMemcpyDeviceToHost, P->score));
         S_TRY(hipStreamSynchronize(P->score));

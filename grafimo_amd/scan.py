@@ -85,7 +85,9 @@ class KmerScanner:
         # still execute in issue order (gather(k) before all-reduce(k+1), the same on every rank), so
         # the communication chain per batch is all-reduce + gather while the tail chain is post +
         # all-reduce + q-table.  A second process group (`gather_group`: its own RCCL communicator) would
-        # also let gather(k) run beside all-reduce(k+1).
+        # also let gather(k) run beside all-reduce(k+1) -- kernels of two communicators overlapping on one
+        # device, which RCCL does not promise to survive: leave it None unless that has been tried on the
+        # target node (a one-rank test with it hung once in about forty runs).
         self.gather_group = gather_group if gather_group is not None else group
         self._gather_stream = None
         self.tail_done = None

@@ -2,6 +2,7 @@
 Written like the reference's own test_scoring (tests/grafimo_run_test.py:119-140)."""
 import contextlib
 import io
+import datetime
 import os
 
 import numpy as np
@@ -255,16 +256,20 @@ def test_scanner_collectives_on_one_gpu_rccl(golden_motifs):
         port = s.getsockname()[1]
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
+    # a short collective timeout: a hung collective fails this test after a minute instead of holding the run
+    # for RCCL's default ten
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                            device_id=dev)
+                            device_id=dev, timeout=datetime.timedelta(seconds=60))
     try:
         dm = DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"], g["pmf"])
         batch = synth.make_batch(50, 500, 19, g["probs"], synth.seed_for(3))
         d_k = torch.from_numpy(batch.kmers).to(dev)
         n = len(batch)
         plain = KmerScanner(dm, n, device=dev, side_stream=False)
-        coll = KmerScanner(dm, n, device=dev, side_stream=True, always_collective=True,
-                           gather_group=dist.new_group(backend="nccl"))
+        # (one communicator, as the product uses it: the gather of batch k and the all-reduce of batch k + 1
+        # then execute in issue order.  A second communicator for the gather lets their kernels overlap on the
+        # device, which RCCL does not promise to survive: one run in about forty hung here until the watchdog.)
+        coll = KmerScanner(dm, n, device=dev, side_stream=True, always_collective=True)
         for on_q, thr in [(False, 1e-3), (True, 0.2)]:
             r0 = plain.collect(plain.enqueue(d_k, thr, on_qvalue=on_q))
             for _ in range(3):   # slots rotate; the side stream hands buffers back cleared

@@ -2,6 +2,7 @@
 oracle, the reference's golden file, and end to end into the scoring path."""
 import contextlib
 import io
+import datetime
 import os
 
 import numpy as np
@@ -352,7 +353,8 @@ def test_graph_pipeline_under_a_process_group(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     dev = torch.device("cuda:0")
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev,
+                            timeout=datetime.timedelta(seconds=60))
     try:
         with contextlib.redirect_stdout(io.StringIO()) as out:
             coll = compute_results_from_graph(motif, g, regions, True, kw, always_collective=True)
