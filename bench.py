@@ -175,8 +175,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostic: initialise torch.distributed and issue the collectives even with "
                          "one rank (exercises the N > 1 code path on a 1-GPU box)")
-    ap.add_argument("--event-every", type=int, default=8,
-                    help="bracket the score kernel of every n-th step with a hipEvent pair")
+    ap.add_argument("--event-every", type=int, default=None,
+                    help="time the score kernel of every n-th step with a hipEvent pair on its dispatch "
+                         "(default: every 8th, more often when the run is short, so that at least ~24 launches are timed)")
     ap.add_argument("--no-candidates", action="store_true",
                     help="config 4: select on the q-value threshold by a pass over every score instead of "
                          "filtering the p < t candidates the score kernel collects (measurement aid)")
@@ -296,7 +297,7 @@ def main():
     fence()
     if cfg != 5 and use_dist:
         scanner.size_gather()          # the per-step gather moves what is hit, not the whole hit buffer
-    every = max(1, args.event_every)
+    every = max(1, args.event_every) if args.event_every else max(1, min(8, args.bursts * args.steps // 24))
     for d in dms:
         d.profile_enable(min(1024, max(16, args.bursts * args.steps // every + 1)), every=every)
     burst_s = []
