@@ -254,9 +254,6 @@ def main():
             for w in widths:
                 scanners[w].enqueue(bufs[w][0], args.threshold, on_qvalue=False, want_qvalues=True, row_base=rank * n)
 
-        def finish():
-            for w in widths:
-                scanners[w].finish()
         rotate = 1
     else:
         m0 = mots[0]
@@ -280,11 +277,8 @@ def main():
             return scanner.enqueue(bufs[i % rotate], args.threshold, on_qvalue=on_q, want_qvalues=True,
                                    row_base=rank * n, gather_hits=use_dist)
 
-        def finish():
-            scanner.finish()
-
     def fence():
-        finish()
+        # the device-wide synchronize covers the side streams too: no stream-to-stream waits (finish()) in front of it
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
