@@ -52,16 +52,6 @@ def load_ctcf():
     return build_motif_meme_host(path, "unfrm_dst", 0.1, False)[0]
 
 
-def synthetic_motif(width, rng, bg):
-    """JASPAR-style synthetic PWM: -> dict(sm, bg, min_val, scale, offset, probs)."""
-    from grafimo_amd import synth
-    from grafimo_amd.device import compute_log_odds_dense, scale_pwm_dense
-    bg = (np.asarray(bg, dtype=np.float64) + 5e-7) / (np.sum(bg) + 2e-6)     # norm_bg (motif_ops.py:1268-1302)
-    probs = synth.jaspar_style_probs(width, rng, 0.1, bg)
-    sm, mn, mx, scale, offset = scale_pwm_dense(compute_log_odds_dense(probs, bg))
-    return dict(sm=sm, bg=bg, min_val=mn, scale=scale, offset=float(offset), probs=probs, width=int(width))
-
-
 # ---------------------------------------------------------------------------- CPU baselines
 def _cpu_worker(args):
     text, W, sm, tab, min_val, scale, offset, table, budget_s = args
@@ -196,15 +186,12 @@ def main():
     cfg = args.config if args.config is not None else (2 if world == 1 else 3)
 
     from grafimo_amd import synth
-    rng = np.random.default_rng(20240139 + cfg)
     ctcf = load_ctcf() if cfg in (2, 3) else None
     if cfg in (2, 3):
         mots = [dict(sm=ctcf.dense_score_matrix(), bg=ctcf.dense_bg(), min_val=ctcf.min_val, scale=ctcf.scale,
                      offset=float(ctcf.offset), probs=np.asarray(ctcf.count_matrix, dtype=np.float64), width=ctcf.width)]
-    elif cfg == 4:
-        mots = [synthetic_motif(30, rng, np.full(4, 0.25))]
     else:
-        mots = [synthetic_motif(8 + (k % 18), rng, rng.dirichlet(50 * synth.BG_NT)) for k in range(50)]
+        mots = synth.config_motifs(cfg)
     on_q = cfg == 4
     rows_default = {2: 20_000_000, 3: 125_000_000, 4: 100_000_000, 5: 100_000_000 // world}[cfg]
     n = int(args.rows) if args.rows else rows_default

@@ -57,6 +57,7 @@ PROTOTYPES = {
                                 c_void_p, c_i64, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
     "gfm_score_kmers_multi": (c_int, [c_void_p, c_int, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i64,
                                       c_void_p, c_void_p, c_void_p, ctypes.c_uint32, c_void_p]),
+    "gfm_score_kmers_multi_plan": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gfm_profile_enable": (c_int, [c_void_p, c_int, c_int]),
     "gfm_profile_read": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
     "gfm_qvalue_table": (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
@@ -157,7 +158,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if L.gfm_abi_version() != 7:
+        if L.gfm_abi_version() != 8:
             raise ImportError("libgrafimo_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -297,6 +297,67 @@ void fill_motif_args(MotifArgs &a, gfm_motif *m, int ws, int slot, int use_hist,
     a.resid_n = m->d_resid_n[ws];
 }
 
+// Grouping of a batched launch: the largest group (<= 3 motifs; 1 beyond kQuadMaxBatchWidth) at the head of
+// `motifs` whose LDS histogram windows still hold kMinWindowMass of each motif's background score distribution,
+// with 16 waves per workgroup if that works and 8 (half the strips) otherwise.  Windows share what the tables and
+// strips leave: a motif whose whole range fits takes it, the others split the rest and spill the rows outside
+// their window.  with_hist[k]: motif k accumulates a histogram.  -> false: not even one motif fits.
+bool plan_group(const gfm_motif_t *motifs, int n_left, const bool *with_hist, int *mm_out, int *waves_out,
+                int *win_lo, int *win_nb)
+{
+    constexpr double kMinWindowMass = 0.999;
+    const int W = motifs[0]->W;
+    int mm = std::min(W <= kQuadMaxBatchWidth ? 3 : 1, n_left);
+    int waves = kWavesPerWG;
+    bool found = false;
+    for (; mm >= 1 && !found; --mm) {
+        for (waves = kWavesPerWG; waves >= kWavesPerWG / 2 && !found; waves /= 2) {
+            long long room = ((long long)kMaxLdsBytes - (long long)quad_fixed_lds(W, waves, mm)) /
+                             (long long)sizeof(unsigned);
+            bool open[3] = {false, false, false};
+            int users = 0;
+            for (int k = 0; k < mm; ++k) {
+                win_nb[k] = 0;
+                win_lo[k] = motifs[k]->lo;
+                open[k] = with_hist[k];
+                users += open[k];
+            }
+            bool ok = room > 0 || users == 0;
+            // water-filling: ranges that fit their equal share are served whole, the rest share again
+            for (bool again = true; ok && again && users > 0;) {
+                again = false;
+                const long long share = room / users - 1;
+                for (int k = 0; k < mm; ++k)
+                    if (open[k] && motifs[k]->nb <= share) {
+                        win_nb[k] = motifs[k]->nb;
+                        room -= win_nb[k] + 1;
+                        open[k] = false;
+                        --users;
+                        again = true;
+                    }
+            }
+            if (ok && users > 0) {
+                const long long share = room / users - 1;
+                if (share < 256) ok = false;
+                for (int k = 0; ok && k < mm; ++k)
+                    if (open[k]) {
+                        const gfm_motif::Window w = best_window(motifs[k], (int)share);
+                        win_nb[k] = w.bins;
+                        win_lo[k] = w.lo;
+                        // a partial window is acceptable for a lone motif at 8 waves (nothing smaller exists)
+                        if ((mm > 1 || waves > kWavesPerWG / 2) && w.mass < kMinWindowMass) ok = false;
+                    }
+            }
+            found = ok;
+            if (found) break;
+        }
+        if (found) break;
+    }
+    *mm_out = mm;
+    *waves_out = waves;
+    return found;
+}
+
 }  // namespace
 
 // --------------------------------------------------------------------------------------- API
@@ -755,61 +816,14 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
     const int W = motifs[0]->W;
     const long long nchunks = (n + kQuadRows - 1) / kQuadRows;
 
-    // grouping: the largest group (<= 3 motifs; 1 beyond kQuadMaxBatchWidth) whose LDS histogram windows still
-    // hold kMinWindowMass of each motif's background score distribution, with 16 waves per workgroup if that
-    // works and 8 (half the strips) otherwise.  Windows share what the tables and strips leave: a motif whose
-    // whole range fits takes it, the others split the rest and spill the rows outside their window.
-    constexpr double kMinWindowMass = 0.999;
     int i = 0;
     while (i < n_motifs) {
-        int mm = std::min(W <= kQuadMaxBatchWidth ? 3 : 1, n_motifs - i), nb_lds[3] = {0, 0, 0};
+        int mm = 0, waves = kWavesPerWG, nb_lds[3] = {0, 0, 0};
         int win_lo[3] = {0, 0, 0}, win_nb[3] = {0, 0, 0};
-        int waves = kWavesPerWG;
-        bool found = false;
-        for (; mm >= 1 && !found; --mm) {
-            for (waves = kWavesPerWG; waves >= kWavesPerWG / 2 && !found; waves /= 2) {
-                long long room = ((long long)kMaxLdsBytes - (long long)quad_fixed_lds(W, waves, mm)) /
-                                 (long long)sizeof(unsigned);
-                bool open[3] = {false, false, false};
-                int users = 0;
-                for (int k = 0; k < mm; ++k) {
-                    win_nb[k] = 0;
-                    win_lo[k] = motifs[i + k]->lo;
-                    open[k] = d_hist && d_hist[i + k];
-                    users += open[k];
-                }
-                bool ok = room > 0 || users == 0;
-                // water-filling: ranges that fit their equal share are served whole, the rest share again
-                for (bool again = true; ok && again && users > 0;) {
-                    again = false;
-                    const long long share = room / users - 1;
-                    for (int k = 0; k < mm; ++k)
-                        if (open[k] && motifs[i + k]->nb <= share) {
-                            win_nb[k] = motifs[i + k]->nb;
-                            room -= win_nb[k] + 1;
-                            open[k] = false;
-                            --users;
-                            again = true;
-                        }
-                }
-                if (ok && users > 0) {
-                    const long long share = room / users - 1;
-                    if (share < 256) ok = false;
-                    for (int k = 0; ok && k < mm; ++k)
-                        if (open[k]) {
-                            const gfm_motif::Window w = best_window(motifs[i + k], (int)share);
-                            win_nb[k] = w.bins;
-                            win_lo[k] = w.lo;
-                            // a partial window is acceptable for a lone motif at 8 waves (nothing smaller exists)
-                            if ((mm > 1 || waves > kWavesPerWG / 2) && w.mass < kMinWindowMass) ok = false;
-                        }
-                }
-                found = ok;
-                if (found) break;
-            }
-            if (found) break;
-        }
-        if (!found) return fail(GFM_ERR_INVALID, "no LDS left for a histogram window at width %d", W);
+        bool with_hist[3];
+        for (int k = 0; k < 3; ++k) with_hist[k] = i + k < n_motifs && d_hist && d_hist[i + k];
+        if (!plan_group(motifs + i, n_motifs - i, with_hist, &mm, &waves, win_lo, win_nb))
+            return fail(GFM_ERR_INVALID, "no LDS left for a histogram window at width %d", W);
         for (int k = 0; k < mm; ++k) {
             if (win_nb[k] > motifs[i + k]->part_nb)
                 return fail(GFM_ERR_INVALID, "internal error: histogram window larger than the workspace");
@@ -859,6 +873,32 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
         }
         rc = launch_posts(posts, mm, st);
         if (rc) return rc;
+        i += mm;
+    }
+    return GFM_OK;
+}
+
+GFM_API int gfm_score_kmers_multi_plan(const gfm_motif_t *motifs, int n_motifs, const int32_t *with_hist,
+                                       int32_t *group_size_out, int32_t *waves_out)
+{
+    if (!motifs || n_motifs < 1) return fail(GFM_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < n_motifs; ++i) {
+        if (!motifs[i]) return fail(GFM_ERR_INVALID, "motif %d is NULL", i);
+        if (motifs[i]->W != motifs[0]->W)
+            return fail(GFM_ERR_INVALID, "motifs of one batched launch must share their width (%d vs %d)",
+                        motifs[i]->W, motifs[0]->W);
+    }
+    int i = 0;
+    while (i < n_motifs) {
+        int mm = 0, waves = 0, win_lo[3], win_nb[3];
+        bool wh[3];
+        for (int k = 0; k < 3; ++k) wh[k] = i + k < n_motifs && (!with_hist || with_hist[i + k]);
+        if (!plan_group(motifs + i, n_motifs - i, wh, &mm, &waves, win_lo, win_nb))
+            return fail(GFM_ERR_INVALID, "no LDS left for a histogram window at width %d", motifs[0]->W);
+        for (int k = 0; k < mm; ++k) {
+            if (group_size_out) group_size_out[i + k] = mm;
+            if (waves_out) waves_out[i + k] = waves;
+        }
         i += mm;
     }
     return GFM_OK;

@@ -211,6 +211,20 @@ def score_multi(motifs, kmers, scores, hists=None, cutoffs=None, row_base=0, hit
         nv.GFM_FLAG_RESET_HITS if reset_hits else 0, _stream_ptr(stream)))
 
 
+def multi_plan(motifs, with_hist=None):
+    """gfm_score_kmers_multi_plan: how score_multi would group these same-width motifs.
+    -> (group sizes int32[M], waves per workgroup int32[M])."""
+    M = len(motifs)
+    handles = (ctypes.c_void_p * M)(*[m.handle for m in motifs])
+    wh = None
+    if with_hist is not None:
+        wh = (ctypes.c_int32 * M)(*[int(bool(x)) for x in with_hist])
+    sizes = np.zeros(M, dtype=np.int32)
+    waves = np.zeros(M, dtype=np.int32)
+    nv.check(nv.lib().gfm_score_kmers_multi_plan(handles, M, wh, nv.ptr(sizes), nv.ptr(waves)))
+    return sizes, waves
+
+
 def qvalue_table_multi(motifs, hists, threshold, on_qvalue, qtables=None, cutoffs=None, nrows=None, stream=None,
                        clear_hist=False):
     """gfm_qvalue_table_multi: the q-tables of several DeviceMotifs (any widths) in three launches per eight

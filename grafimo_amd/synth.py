@@ -189,3 +189,29 @@ def jaspar_style_probs(width: int, rng: np.random.Generator, pseudo: float = 0.1
     tot = counts.sum(0)
     bg = np.full(4, 0.25) if bg is None else np.asarray(bg, dtype=np.float64)
     return (counts / tot * tot.astype(int) + pseudo * bg[:, None]) / (tot.astype(int) + pseudo)
+
+
+def synthetic_motif(width: int, rng: np.random.Generator, bg) -> dict:
+    """JASPAR-style synthetic PWM through the library's own log-odds + scaling (host side of
+    libgrafimo_hip.so, no GPU): -> dict(sm, bg, min_val, scale, offset, probs, width)."""
+    from .device import compute_log_odds_dense, scale_pwm_dense
+    bg = (np.asarray(bg, dtype=np.float64) + 5e-7) / (np.sum(bg) + 2e-6)     # norm_bg (motif_ops.py:1268-1302)
+    probs = jaspar_style_probs(width, rng, 0.1, bg)
+    sm, mn, mx, scale, offset = scale_pwm_dense(compute_log_odds_dense(probs, bg))
+    return dict(sm=sm, bg=bg, min_val=mn, scale=scale, offset=float(offset), probs=probs, width=int(width))
+
+
+def config_motifs(cfg: int):
+    """The synthetic motifs of BASELINE config 4 (one W=30 PWM, uniform background) and config 5 (fifty PWMs,
+    widths cycling 8..25, per-motif background ~ Dirichlet(50 bg_nt)), seeded as SURVEY 8(d) says
+    (PCG64(20240139 + config index)); bench.py and the full-size parity tests share them."""
+    rng = np.random.default_rng(20240139 + int(cfg))
+    if cfg == 4:
+        return [synthetic_motif(30, rng, np.full(4, 0.25))]
+    if cfg == 5:
+        out = []
+        for k in range(50):
+            bg = rng.dirichlet(50 * BG_NT)
+            out.append(synthetic_motif(8 + (k % 18), rng, bg))
+        return out
+    raise ValueError("config_motifs: config 4 or 5")

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFM_ABI_VERSION 7
+#define GFM_ABI_VERSION 8
 
 #define GFM_OK 0
 #define GFM_ERR_INVALID (-1)  /* bad argument (NULL, width out of range, ...)            */
@@ -140,6 +140,13 @@ int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const uint8_t
                           const int32_t *select_cutoffs, int64_t row_base,
                           int64_t *const *d_hit_rows, const int64_t *hit_capacity,
                           uint64_t *const *d_hit_count, uint32_t flags, void *stream);
+
+/* How gfm_score_kmers_multi would group these motifs (no device work): group_size_out[i] = number of motifs of the
+ * launch motif i rides in (1..3), waves_out[i] = waves per workgroup of that launch (16 or 8).  with_hist[i] != 0
+ * (NULL = all): motif i accumulates a histogram, which is what limits a group (LDS windows).  Either output may be
+ * NULL.  Lets a caller (and the parity tests) see which score_quad_kernel<W, MM> instantiation a call uses. */
+int gfm_score_kmers_multi_plan(const gfm_motif_t *motifs, int n_motifs, const int32_t *with_hist,
+                               int32_t *group_size_out, int32_t *waves_out);
 
 /* Measurement aid (bench.py): with slots > 0 every `every`-th later gfm_score_kmers call
  * brackets the score kernel ALONE (not the post kernel that follows it) with a hipEvent pair
