@@ -2,7 +2,11 @@
 """bench.py -- scored haplotype k-mers/s of the MI355X scoring path (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+With N > 1 and no WORLD_SIZE in the environment this process touches no GPU: it starts the N ranks itself
+(python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>),
+passes their output through, prints rank 0's JSON line as its own LAST line and exits with the children's code.
+Launched through torch.distributed.run directly (RANK / LOCAL_RANK / WORLD_SIZE set) it is one of the ranks.
 
 One "step" = one pass of the hot path over one batch of synthetic k-mers resident in HBM:
 score kernel (+ fused p-value selection) -> histogram reduction -> [all-reduce of the score histogram
@@ -22,17 +26,30 @@ units / max-over-ranks time):
 
 Timing: W warm-up steps, then `--bursts` (5) bursts of EXACTLY K steps, each burst bracketed by a barrier +
 torch.cuda.synchronize() on both sides and reduced with MAX over the ranks; the line reports the MEDIAN
-burst.  Rank 0 prints ONE JSON line carrying `roofline` (the score kernel alone: HIP events on its launch
-stream, sampled inside the timed bursts), `cpu_baseline` / `cpu_baseline_table` (the CPU oracle's loop over
-TSV text -- parse + score -- with the reference's two O(1000 W) sums per row, resp. one table lookup; forked
-workers on every host core, bounded sample; N=1 only) and `e2e` (config 2, N=1: a TSV directory through
-compute_results' streamed scan: parse threads -> pinned chunks -> H2D -> kernels -> hits).
+burst.  Rank 0 prints ONE JSON line.  Beside the contract's fields it carries
+  roofline            the score kernel alone: HIP events riding on its dispatch packets, sampled inside the timed
+                      bursts; `peak` = 8 TB/s vendor, `peak_measured` = this device's bare interleaved stream of
+                      the same byte mix (gfm_calibrate_stream), `frac_of_measured`; `traffic` from the committed PMC
+                      passes (`traffic_source` says so);
+  tail_ms             post kernel + [all-reduce] + q-table [+ selection on q] [+ gather], events on the tail stream;
+  rank_ms_per_step    every rank's own median burst; rccl_world = dist.get_world_size();
+  N = 1, default config only (each can be switched off):
+  roofline_config3    >= 10 steps of the config-3 shard (1.25e8 windows generated on the device, `nt` stores: 477 MiB
+                      of scores per launch, beyond any cache) -- also the 1-GPU point of the N > 1 curve;
+  sustained           >= 2 s of back-to-back steps, k-mers/s and min/median/max ms per 100 steps;
+  extract             the k-mer extraction kernels on a synthetic graph at config-2 scale + extraction -> scoring;
+  e2e / e2e_config2   a TSV directory through compute_results' streamed scan (2e6 rows; 2e7 rows in 10 000 files);
+  cpu_baseline / cpu_baseline_table   the CPU oracle's loop over TSV text on every host core (bounded sample).
 """
 import argparse
+import contextlib
+import io
 import json
 import multiprocessing as mp
 import os
 import shutil
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -50,6 +67,72 @@ def load_ctcf():
     from grafimo_amd.motif_ops import build_motif_meme_host
     path = os.path.join(ROOT, "tests", "golden", "ref_data", "MA0139.1.meme")
     return build_motif_meme_host(path, "unfrm_dst", 0.1, False)[0]
+
+
+# ---------------------------------------------------------------------------- N > 1: start the ranks
+def launch_ranks(n: int, argv) -> int:
+    """The driver calls `python bench.py --gpus N ...`; the ranks are children of this process, which has made
+    no GPU call.  Their stdout passes through, except that JSON lines carrying "metric" are held back and the last
+    one is printed at the very end, so that it is this process's last line."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    line_json = None
+    for line in proc.stdout:
+        s = line.strip()
+        if s.startswith("{") and '"metric"' in s:
+            try:
+                json.loads(s)
+                line_json = s
+                continue
+            except ValueError:
+                pass
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if line_json is not None:
+        print(line_json, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def dry_run(args, rank, world):
+    """--dry-run: the launcher and process-group plumbing without a GPU (gloo): rendezvous, one all-reduce, the
+    per-rank list, rank 0's line.  What the CPU test-suite drives; measures nothing."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.dry_run_fail_rank is not None and rank == args.dry_run_fail_rank:
+        sys.exit(3)
+    one = torch.ones(1, dtype=torch.int64)
+    ms = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    per_rank = [ms.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_reduce(one)
+        dist.all_gather(per_rank, ms)
+        assert dist.get_world_size() == args.gpus
+    assert int(one.item()) == world
+    if rank == 0:
+        print(json.dumps({"metric": "scored haplotype k-mers/sec", "value": None, "unit": "k-mers/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+                          "data": "dry run: launcher and process-group plumbing only, no GPU work",
+                          "rccl_world": world, "rank_ms_per_step": [float(t.item()) for t in per_rank],
+                          "config": {"workload": "none (--dry-run)"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 # ---------------------------------------------------------------------------- CPU baselines
@@ -90,7 +173,9 @@ def cpu_baselines(mot, budget_s=8.0):
         total = sum(r[0] for r in res)
         out[name] = {
             "value": total / wall, "unit": "k-mers/s", "cores": cores, "kind": "port",
-            "sample": f"the first {rows} TSV rows of a batch of the same synthetic recipe, passed over again and again "
+            "cache_resident": True,
+            "sample": f"the first {rows} TSV rows ({len(text)} bytes of text: cache resident) of a batch of the same "
+                      f"synthetic recipe, passed over again and again "
                       f"for {budget_s:.0f} s per worker ({min(r[1] for r in res)}..{max(r[1] for r in res)} passes), "
                       f"{cores} forked workers, text parse + "
                       + ("p_table lookup" if table else "per-row O(1000 W) tail sums")
@@ -100,52 +185,127 @@ def cpu_baselines(mot, budget_s=8.0):
 
 
 # ---------------------------------------------------------------------------- end to end (TSV -> hits)
-def e2e_block(motif, dm, rows_regions=1000, rows_per_region=2000, regions_per_file=1):
-    """A TSV directory (synth.write_tsv_dir, 2.0e6 rows) through the pipeline behind compute_results
-    (gfm_scan_tsv): parse threads -> pinned chunks -> hipMemcpyAsync -> score kernel per chunk -> q-table ->
-    hits back; next to the bare ingest (gfm_tsv_open) on the same files and thread count."""
+def _tsv_worker(job):
+    out_dir, r0, count, rows_per_region, W, probs, seed = job
+    from grafimo_amd import synth
+    batch = synth.make_batch(count, rows_per_region, W, probs, seed + r0, region_base=r0)
+    synth.write_tsv_dir(batch, out_dir, regions_per_file=1)
+    return len(batch)
+
+
+def make_tsv_dir(regions, rows_per_region, W, probs, workers):
+    """A synthetic TSV directory (one file per region) written by forked workers -- BEFORE anything
+    touches the GPU.  -> (dir, rows)."""
+    from grafimo_amd import synth
+    need = 3 * regions * rows_per_region * (W + 75)      # ~92 bytes of text per row at W = 19, with headroom
+    base = None
+    for cand in ("/dev/shm", tempfile.gettempdir()):
+        if os.path.isdir(cand) and os.access(cand, os.W_OK) and shutil.disk_usage(cand).free > need:
+            base = cand
+            break
+    if base is None:
+        return None, 0
+    tmp = tempfile.mkdtemp(prefix="grafimo_e2e_", dir=base)
+    per = max(1, min(100, regions // max(1, workers)))
+    jobs = [(tmp, r0, min(per, regions - r0), rows_per_region, W, probs, synth.seed_for(7)) for r0 in range(0, regions, per)]
+    with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+        n = sum(pool.map(_tsv_worker, jobs))
+    return tmp, n
+
+
+def e2e_block(tmp, n_expected, W, dm):
+    """A TSV directory through the pipeline behind compute_results (gfm_scan_tsv): parse threads -> pinned chunks ->
+    hipMemcpyAsync -> score kernel per chunk -> q-table -> hits back; next to the bare ingest (gfm_tsv_open) on the
+    same files and thread count."""
     import ctypes
     import glob
     from grafimo_amd import _native as nv
-    from grafimo_amd import synth
     from grafimo_amd.score_sequences import StreamScan
-    W = motif.width
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-    tmp = tempfile.mkdtemp(prefix="grafimo_e2e_", dir=base)
-    try:
-        batch = synth.make_batch(rows_regions, rows_per_region, W, np.asarray(motif.count_matrix), synth.seed_for(7))
-        synth.write_tsv_dir(batch, tmp, regions_per_file=regions_per_file)
-        files = sorted(glob.glob(os.path.join(tmp, f"width_{W}", "*.tsv")))
-        nbytes = sum(os.path.getsize(f) for f in files)
-        threads = os.cpu_count() or 1
-        arr = (ctypes.c_char_p * len(files))(*[f.encode() for f in files])
-        ingest = []
-        for _ in range(3):
-            h, n = ctypes.c_void_p(), ctypes.c_int64()
+    files = sorted(glob.glob(os.path.join(tmp, f"width_{W}", "*.tsv")))
+    nbytes = sum(os.path.getsize(f) for f in files)
+    threads = os.cpu_count() or 1
+    arr = (ctypes.c_char_p * len(files))(*[f.encode() for f in files])
+    ingest = []
+    for _ in range(3):
+        h, n = ctypes.c_void_p(), ctypes.c_int64()
+        t = time.perf_counter()
+        nv.check(nv.lib().gfm_tsv_open(arr, len(files), W, 0, threads, ctypes.byref(h), ctypes.byref(n)))
+        ingest.append(time.perf_counter() - t)
+        nv.lib().gfm_tsv_close(h)
+    ingest_s = float(np.median(ingest))
+    runs = []
+    for _ in range(4):       # the first call sizes the buffer pool
+        t = time.perf_counter()
+        sc = StreamScan(dm, files, False, threads, 1e-4, False, True)
+        runs.append((time.perf_counter() - t, sc.stats.total_s, sc.stats.parse_s, sc.stats.h2d_s,
+                     sc.stats.h2d_bytes, sc.stats.tail_s, sc.n, sc.n_hits, sc.stats.n_chunks))
+    runs = sorted(runs[1:])
+    wall, total_s, parse_s, h2d_s, h2d_bytes, tail_s, n, n_hits, n_chunks = runs[len(runs) // 2]
+    assert n == n_expected, (n, n_expected)
+    return {
+        "rows": int(n), "tsv_bytes": int(nbytes), "files": len(files), "host_threads": threads, "hits": int(n_hits),
+        "kmers_per_s": n / total_s, "ingest_rows_per_s": n / ingest_s, "h2d_GBps": h2d_bytes / h2d_s / 1e9,
+        "total_ms": total_s * 1e3, "ingest_alone_ms": ingest_s * 1e3, "parse_ms_inside": parse_s * 1e3,
+        "h2d_ms": h2d_s * 1e3, "after_parse_ms": tail_s * 1e3, "chunks": int(n_chunks),
+        "total_over_max_ingest_h2d": total_s / max(ingest_s, h2d_s),
+        "path": "gfm_scan_tsv (grafimo_amd.score_sequences.StreamScan, what compute_results calls)",
+    }
+
+
+# ---------------------------------------------------------------------------- extraction (N = 1)
+def extract_block(ctcf, dev, n_regions=10_000):
+    """The extraction kernels (what replaces `vg find -K`) on a synthetic graph at config-2 scale:
+    10 000 regions x 200 bp, one site per ~32 bp of which 6 % deletions, 5096 haplotypes; W = 19.  emit_ms = the emit
+    kernels of one plan (HIP events around gfm_graph_emit, averaged over 10 calls); extract_plus_score_ms = the
+    product entry point compute_results_from_graph (extraction -> scoring -> table of hits) on the same graph."""
+    import torch
+    from grafimo_amd import _native as nv
+    from grafimo_amd import synth
+    from grafimo_amd.extract_regions import DeviceGraph, compute_results_from_graph
+    from grafimo_amd.workflow import Findmotif
+    W = ctcf.width
+    idx, regions = synth.make_graph_index(n_regions, W)
+    g = DeviceGraph(idx, dev)
+    walls = []
+    rows = None
+    for _ in range(4):
+        t = time.perf_counter()
+        rows = g.extract(regions, W)
+        torch.cuda.synchronize(dev)
+        walls.append(time.perf_counter() - t)
+    n = len(rows)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    ev0.record()
+    for _ in range(reps):
+        nv.check(nv.lib().gfm_graph_emit(g._h, rows.kmers.data_ptr(), rows.start.data_ptr(), rows.stop.data_ptr(),
+                                         rows.strand.data_ptr(), rows.freq.data_ptr(), rows.is_ref.data_ptr(),
+                                         rows.region.data_ptr(), rows.walk.data_ptr(),
+                                         torch.cuda.current_stream(dev).cuda_stream))
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    emit_ms = ev0.elapsed_time(ev1) / reps
+    out_bytes = n * (W + 8 + 8 + 1 + 8 + 1 + 4 + 4)     # k-mer + start, stop, strand, freq, is_ref, region, walk
+    args_obj = Findmotif(cores=1, threshold=1e-4)
+    runs = []
+    hits = 0
+    with contextlib.redirect_stdout(io.StringIO()):
+        for _ in range(4):
             t = time.perf_counter()
-            nv.check(nv.lib().gfm_tsv_open(arr, len(files), W, 0, threads, ctypes.byref(h), ctypes.byref(n)))
-            ingest.append(time.perf_counter() - t)
-            nv.lib().gfm_tsv_close(h)
-        ingest_s = float(np.median(ingest))
-        runs = []
-        for _ in range(4):       # the first call sizes the buffer pool
-            t = time.perf_counter()
-            sc = StreamScan(dm, files, False, threads, 1e-4, False, True)
-            runs.append((time.perf_counter() - t, sc.stats.total_s, sc.stats.parse_s, sc.stats.h2d_s,
-                         sc.stats.h2d_bytes, sc.stats.tail_s, sc.n, sc.n_hits, sc.stats.n_chunks))
-        runs = sorted(runs[1:])
-        wall, total_s, parse_s, h2d_s, h2d_bytes, tail_s, n, n_hits, n_chunks = runs[len(runs) // 2]
-        assert n == len(batch)
-        return {
-            "rows": int(n), "tsv_bytes": int(nbytes), "files": len(files), "host_threads": threads, "hits": int(n_hits),
-            "kmers_per_s": n / total_s, "ingest_rows_per_s": n / ingest_s, "h2d_GBps": h2d_bytes / h2d_s / 1e9,
-            "total_ms": total_s * 1e3, "ingest_alone_ms": ingest_s * 1e3, "parse_ms_inside": parse_s * 1e3,
-            "h2d_ms": h2d_s * 1e3, "after_parse_ms": tail_s * 1e3, "chunks": int(n_chunks),
-            "total_over_max_ingest_h2d": total_s / max(ingest_s, h2d_s),
-            "path": "gfm_scan_tsv (grafimo_amd.score_sequences.StreamScan, what compute_results calls)",
-        }
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+            df = compute_results_from_graph(ctcf, g, regions, False, args_obj)
+            runs.append(time.perf_counter() - t)
+            hits = len(df)
+    g.close()
+    return {
+        "regions": n_regions, "region_bp": 200, "width": W, "sites": int(len(idx.pos)),
+        "deletions": int((idx.del_len > 0).sum()), "haplotypes": idx.n_haplotypes, "rows": int(n),
+        "emit_ms": emit_ms, "rows_per_s_emit": n / (emit_ms * 1e-3),
+        "written_bytes": int(out_bytes), "written_GBps": out_bytes / (emit_ms * 1e-3) / 1e9,
+        "frac": out_bytes / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
+        "plan_plus_emit_wall_ms": 1e3 * float(np.median(walls[1:])),
+        "extract_plus_score_ms": 1e3 * float(np.median(runs[1:])), "hits_p1e-4": int(hits),
+        "path": "gfm_graph_plan + gfm_graph_emit; compute_results_from_graph (extraction -> score kernel -> table)",
+    }
 
 
 def main():
@@ -160,6 +320,10 @@ def main():
     ap.add_argument("--threshold", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-e2e-large", action="store_true", help="skip the 2e7-row / 10 000-file TSV directory")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip roofline_config3, sustained, peak_measured and extract (N=1 default config only)")
+    ap.add_argument("--sustained-s", type=float, default=2.5, help="length of the sustained leg in seconds")
     ap.add_argument("--slots", type=int, default=3,
                     help="buffer slots of the scan pipeline (2: the device waits for slot reuse; >= 3: the host does)")
     ap.add_argument("--force-dist", action="store_true",
@@ -174,19 +338,25 @@ def main():
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
                     help="run the per-step tail (post kernel, collective, q-table, gather) on a side "
                          "stream so that it overlaps the next step's score kernel; auto = on")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / process-group plumbing only (gloo, no GPU, nothing measured): the CPU tests use it")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=None, help="with --dry-run: this rank exits with code 3")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))       # this process never touches a GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run")
         args.gpus = world
+    if args.dry_run:
+        return dry_run(args, rank, world)
     cfg = args.config if args.config is not None else (2 if world == 1 else 3)
 
     from grafimo_amd import synth
-    ctcf = load_ctcf() if cfg in (2, 3) else None
+    ctcf = load_ctcf()
     if cfg in (2, 3):
         mots = [dict(sm=ctcf.dense_score_matrix(), bg=ctcf.dense_bg(), min_val=ctcf.min_val, scale=ctcf.scale,
                      offset=float(ctcf.offset), probs=np.asarray(ctcf.count_matrix, dtype=np.float64), width=ctcf.width)]
@@ -202,13 +372,31 @@ def main():
                                       region_base=rank * 10_000)
         n = len(host_batch)
 
+    # ---- everything that forks workers comes BEFORE the first HIP call
+    default_n1 = rank == 0 and world == 1 and cfg == 2 and not args.rows
     cpu = {}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baselines(mots[0])      # before any HIP initialisation: the workers are forked
+        cpu = cpu_baselines(mots[0])
+    tsv_dirs = {}
+    try:
+        if default_n1 and not args.no_e2e:
+            workers = min(os.cpu_count() or 1, 128)
+            probs = np.asarray(ctcf.count_matrix, dtype=np.float64)
+            tsv_dirs["e2e"] = make_tsv_dir(1000, 2000, ctcf.width, probs, workers)
+            if not args.no_e2e_large:
+                tsv_dirs["e2e_config2"] = make_tsv_dir(10_000, 2000, ctcf.width, probs, workers)
+            tsv_dirs = {k: v for k, v in tsv_dirs.items() if v[0] is not None}     # no room: that block is left out
+        run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q, cpu, tsv_dirs, default_n1)
+    finally:
+        for d, _ in tsv_dirs.values():
+            shutil.rmtree(d, ignore_errors=True)
 
+
+def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q, cpu, tsv_dirs, default_n1):
     import torch
     import torch.distributed as dist
-    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd import synth
+    from grafimo_amd.device import DeviceMotif, calibrate_stream
     from grafimo_amd.scan import KmerScanner, SameWidthScanner
 
     torch.cuda.set_device(local_rank)
@@ -257,6 +445,7 @@ def main():
         scanner = KmerScanner(dms[0], n, hit_capacity=hit_cap, device=dev, group=None, side_stream=side,
                               n_slots=args.slots, always_collective=args.force_dist,
                               candidates=not args.no_candidates)
+        scanner.profile_tail = side
         units_per_step = n
         alg_bytes = n * (W + 4)
 
@@ -281,7 +470,7 @@ def main():
     every = max(1, args.event_every) if args.event_every else max(1, min(8, args.bursts * args.steps // 24))
     for d in dms:
         d.profile_enable(min(1024, max(16, args.bursts * args.steps // every + 1)), every=every)
-    burst_s = []
+    burst_s, own_s = [], []
     for _ in range(max(1, args.bursts)):
         fence()
         t0 = time.perf_counter()
@@ -289,30 +478,117 @@ def main():
             last = step(it)
             it += 1
         fence()
-        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        own_s.append(time.perf_counter() - t0)
+        el = torch.tensor([own_s[-1]], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         burst_s.append(float(el.item()))
     kernel_ms = [d.profile_read() for d in dms]
+    tail_ms = dms[0].profile_read_tail() if cfg != 5 else np.empty(0, np.float32)
     for d in dms:
         d.profile_enable(0)
+    if cfg != 5:
+        scanner.profile_tail = False
+    # every rank's own median burst -> rank 0
+    mine = torch.tensor([1e3 * float(np.median(own_s)) / args.steps], dtype=torch.float64, device=dev)
+    rank_ms = [mine.clone() for _ in range(world)]
+    if use_dist and world > 1:
+        dist.all_gather(rank_ms, mine)
+    rank_ms = [float(t.item()) for t in rank_ms]
 
-    # outputs of the last step stay valid: self-checks outside the timed region
+    # outputs of the last step stay valid: self-checks outside the timed region (the CPU oracle as the checker)
+    from oracle import oracle as orc
+    orc.build()
+    checked_rows = 1_000_000
     if cfg == 5:
         torch.cuda.synchronize(dev)
         for w in widths:
             nr = scanners[w].nrows.cpu().numpy()
             assert (nr == n * world).all(), (w, nr, n, world)
+            km = bufs[w][0][:checked_rows].cpu().numpy()
+            for k, j in enumerate(groups[w]):        # a slice of every motif's scores against the oracle
+                _, pt = dms[j].tables()
+                exp, _ = orc.score_kmers_table(km, mots[j]["sm"], pt, mots[j]["min_val"])
+                got = scanners[w].scores[k][:len(km)].cpu().numpy()
+                assert np.array_equal(got, exp), f"config 5: scores of motif {j} (W={w}) differ from the oracle"
         n_hits = int(sum(int(scanners[w].hits[:, 0].sum().item()) for w in widths))
     else:
         res = scanner.collect(last)
         n_hits = int(len(res["rows"]))
         assert res["n_scored"] == n * world, (res["n_scored"], n, world)
+        km = bufs[(it - 1) % rotate][:checked_rows].cpu().numpy()
+        _, pt = dms[0].tables()
+        exp, _ = orc.score_kmers_table(km, mots[0]["sm"], pt, mots[0]["min_val"])
+        assert np.array_equal(last.scores[:len(km)].cpu().numpy(), exp), "scores differ from the oracle"
     assert n_hits > 0
 
-    e2e = None
-    if rank == 0 and world == 1 and cfg == 2 and not args.no_e2e and not args.rows:
-        e2e = e2e_block(ctcf, dms[0])
+    extras = {}
+    if default_n1 and not args.no_extras:
+        W = mots[0]["width"]
+        # (c) what this device sustains for a bare stream of the kernel's byte mix (76 B in / 16 B out per lane-step)
+        cal = {}
+        for name, through in (("write_through", True), ("nt", False)):
+            us, nbytes = calibrate_stream(5, n * W, through, 20)
+            cal[name] = {"us_per_launch": us, "GBps": nbytes / (us * 1e-6) / 1e9, "bytes_per_launch": nbytes}
+        extras["peak_measured"] = {
+            "kernel": "stream_mix_kernel<5> (gfm_calibrate_stream): 5 x 16 B nt loads + one 16 B store per lane-step, "
+                      "interleaved, one step prefetched; output rotating over three buffers",
+            "in_bytes": n * W, **cal,
+            "GBps": max(c["GBps"] for c in cal.values()), "unit": "GB/s"}
+        # (b) sustained: back-to-back steps for >= sustained_s seconds, one timing event per 100 steps
+        per = 100
+        blocks = max(2, int(args.sustained_s / (np.median(burst_s) / args.steps) / per) + 1)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(blocks + 1)]
+        fence()
+        main_stream = torch.cuda.current_stream(dev)
+        t0 = time.perf_counter()
+        evs[0].record(main_stream)
+        for b in range(blocks):
+            for _ in range(per):
+                step(it)
+                it += 1
+            evs[b + 1].record(main_stream)
+        fence()
+        wall = time.perf_counter() - t0
+        blk = np.array([evs[b].elapsed_time(evs[b + 1]) for b in range(blocks)])
+        extras["sustained"] = {"steps": blocks * per, "seconds": wall, "kmers_per_s": blocks * per * n / wall,
+                               "ms_per_100_steps": {"min": float(blk.min()), "median": float(np.median(blk)),
+                                                    "max": float(blk.max())},
+                               "first_vs_last_block_ms": [float(blk[0]), float(blk[-1])]}
+        # (a) the config-3 shard: scores beyond any cache (477 MiB per launch, nt stores); the 1-GPU point of the curve
+        n3 = 125_000_000
+        d3 = synth.make_device_kmers(n3, W, mots[0]["probs"], synth.seed_for(3, rank), dev)
+        sc3 = KmerScanner(dms[0], n3, hit_capacity=n3 // 64, device=dev, side_stream=side, n_slots=args.slots)
+        for _ in range(3):
+            sc3.enqueue(d3, args.threshold, want_qvalues=True)
+        fence()
+        steps3 = 12
+        dms[0].profile_enable(steps3, every=2)
+        t0 = time.perf_counter()
+        for _ in range(steps3):
+            last3 = sc3.enqueue(d3, args.threshold, want_qvalues=True)
+        fence()
+        el3 = time.perf_counter() - t0
+        k3 = dms[0].profile_read()
+        dms[0].profile_enable(0)
+        r3 = sc3.collect(last3)
+        assert r3["n_scored"] == n3 and len(r3["rows"]) > 0
+        k3_ms = float(np.mean(k3))
+        extras["roofline_config3"] = {
+            "workload": f"BASELINE configs[2], one GPU's shard: CTCF W=19, {n3} windows generated on the device",
+            "steps": steps3, "ms_per_step": 1e3 * el3 / steps3, "kmers_per_s": n3 * steps3 / el3,
+            "kernel": f"score_quad_kernel<{W}, 1>", "kernel_ms_avg": k3_ms, "kernel_launches_timed": int(len(k3)),
+            "algorithmic_bytes_per_launch": n3 * (W + 4), "achieved": n3 * (W + 4) / (k3_ms * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": n3 * (W + 4) / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "score_stores": "nt (477 MiB of scores per launch)"}
+        del sc3, d3, last3
+        torch.cuda.empty_cache()
+        extras["extract"] = extract_block(ctcf, dev)
+
+    e2e = {}
+    if default_n1 and not args.no_e2e:
+        for name, (tmp, rows) in tsv_dirs.items():
+            e2e[name] = e2e_block(tmp, rows, ctcf.width, dms[0])
 
     if rank == 0:
         elapsed = float(np.median(burst_s))
@@ -327,13 +603,15 @@ def main():
             timed = int(len(kernel_ms[0]))
             kname = f"score_quad_kernel<{mots[0]['width']}, 1>"
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and cfg != 5:
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("rows_per_launch") == n and tj.get("width") == mots[0]["width"] and tj.get("kernel") == kname:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/pmc_traffic.json: committed rocprofv3 --pmc passes of this kernel at this "
+                                  "size (" + str(tj.get("source", "scripts/lab_pmc.sh")) + "), NOT counters of this run")
         workload = {
             2: f"BASELINE configs[1] per GPU: CTCF MA0139.1 W=19, 10000 synthetic 200bp regions x 2000 haplotype "
                f"k-mers = {n} windows",
@@ -344,6 +622,22 @@ def main():
             5: f"BASELINE configs[4]: 50 synthetic JASPAR-style PWMs W=8..25 (per-motif background), {n} windows per "
                f"width per GPU, same-width motifs share each k-mer read; unit = (k-mer, motif) pair",
         }[cfg]
+        roofline = {
+            "bound": "hbm",
+            "kernel": kname,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms_avg": k_ms,
+            "kernel_launches_timed": timed,
+        }
+        if "peak_measured" in extras:
+            roofline["peak_measured"] = extras["peak_measured"]["GBps"]
+            roofline["frac_of_measured"] = achieved / extras["peak_measured"]["GBps"]
         out = {
             "metric": "scored haplotype k-mers/sec",
             "value": value,
@@ -357,6 +651,13 @@ def main():
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
+            "rccl_world": dist.get_world_size() if use_dist else 1,
+            "rank_ms_per_step": rank_ms,
+            "tail_ms": ({"avg": float(np.mean(tail_ms)), "max": float(np.max(tail_ms)), "timed": int(len(tail_ms)),
+                         "what": "post kernel" + (" + all-reduce(histogram)" if use_dist else "") + " + q-table"
+                                 + (" + selection on q" if on_q else "") + (" + gather(hits)" if use_dist else "")
+                                 + ", HIP events on the tail / gather stream from 'score kernel done' to the last of it"}
+                        if len(tail_ms) else None),
             "config": {
                 "workload": workload,
                 "baseline_config": cfg,
@@ -364,6 +665,7 @@ def main():
                 "threshold_on": "q-value" if on_q else "p-value",
                 "qvalues": True,
                 "hits_last_step": n_hits,
+                "oracle_checked_rows": checked_rows if cfg != 5 else checked_rows * len(mots),
                 "input_buffers_rotated": rotate,
                 "bursts": len(burst_s),
                 "burst_ms": [round(1e3 * b, 4) for b in burst_s],
@@ -371,21 +673,15 @@ def main():
                 "sharding": (f"regions split over {world} rank(s); all-reduce(score histogram) + gather(hit entries, "
                              f"sized from the observed hit counts) per step") if world > 1 else "single GPU",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kname,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "kernel_ms_avg": k_ms,
-                "kernel_launches_timed": timed,
-            },
+            "roofline": roofline,
+            "roofline_config3": extras.get("roofline_config3"),
+            "sustained": extras.get("sustained"),
+            "peak_measured": extras.get("peak_measured"),
+            "extract": extras.get("extract"),
             "cpu_baseline": cpu.get("cpu_baseline"),
             "cpu_baseline_table": cpu.get("cpu_baseline_table"),
-            "e2e": e2e,
+            "e2e": e2e.get("e2e"),
+            "e2e_config2": e2e.get("e2e_config2"),
         }
         # RCCL's version banner sits in the C runtime's stdout buffer until the process ends: push it out first,
         # so that the JSON line is the last line of the run

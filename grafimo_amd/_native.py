@@ -60,6 +60,9 @@ PROTOTYPES = {
     "gfm_score_kmers_multi_plan": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "gfm_profile_enable": (c_int, [c_void_p, c_int, c_int]),
     "gfm_profile_read": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
+    "gfm_profile_mark_tail": (c_int, [c_void_p, c_void_p]),
+    "gfm_profile_read_tail": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
+    "gfm_calibrate_stream": (c_int, [c_int, c_i64, c_int, c_int, P(c_double), P(c_double)]),
     "gfm_qvalue_table": (c_int, [c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
                                  ctypes.c_uint32, c_void_p]),
     "gfm_qvalue_table_multi": (c_int, [c_void_p, c_int, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,

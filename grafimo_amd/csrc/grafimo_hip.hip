@@ -77,6 +77,13 @@ struct gfm_motif {
     std::vector<hipEvent_t> ev0, ev1;
     int ev_next = 0, ev_used = 0, ev_every = 1;
     unsigned ev_calls = 0;
+    // ... and around the TAIL of a timed call (post kernel and whatever the caller enqueues behind it: collective,
+    // q-table, gather): tev0 is recorded on the tail stream behind its wait for the score kernel, tev1 by
+    // gfm_profile_mark_tail on the stream the caller names
+    std::vector<hipEvent_t> tev0, tev1;
+    int ev_last = -1;               // ring index of the last timed launch (-1: the last launch was not timed)
+    int tail_pending = -1;          // ring index whose tev0 is recorded and whose tev1 is still to come
+    std::vector<int> tail_order;    // ring indices with both tail events recorded, oldest first
 };
 
 namespace {
@@ -175,8 +182,11 @@ int dispatch_quad(int W, int mm, gfm_motif *timer, const uint8_t *d_kmers, long 
         e0 = timer->ev0[timer->ev_next];
         e1 = timer->ev1[timer->ev_next];
         if (done) *done = e1;
+        timer->ev_last = timer->ev_next;
         timer->ev_next = (timer->ev_next + 1) % (int)timer->ev0.size();
         timer->ev_used = std::min(timer->ev_used + 1, (int)timer->ev0.size());
+    } else if (timer) {
+        timer->ev_last = -1;
     }
     typedef int (*launch_fn)(int, const uint8_t *, long long, long long, const void *, size_t, int, int, void *, int,
                              void *, void *);
@@ -464,6 +474,8 @@ GFM_API void gfm_motif_destroy(gfm_motif_t m)
     }
     for (auto e : m->ev0) (void)hipEventDestroy(e);
     for (auto e : m->ev1) (void)hipEventDestroy(e);
+    for (auto e : m->tev0) (void)hipEventDestroy(e);
+    for (auto e : m->tev1) (void)hipEventDestroy(e);
     delete m;
 }
 
@@ -763,6 +775,11 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
                            split ? &scored : nullptr);
     if (rc) return rc;
     if (split) HIP_TRY(hipStreamWaitEvent(tail, scored, 0));
+    m->tail_pending = -1;
+    if (split && m->ev_last >= 0 && !m->tev0.empty()) {   // a timed call: the tail's clock starts when the score kernel is done
+        HIP_TRY(hipEventRecord(m->tev0[m->ev_last], tail));
+        m->tail_pending = m->ev_last;
+    }
     rc = launch_post(m, m->d_partials[ws], nslabs, reinterpret_cast<unsigned long long *>(d_hist),
                      m->hlo, m->hnb, m->d_spill[ws], m->d_resid[ws], m->d_resid_n[ws], select ? nslabs : 0, m->d_ctl, slot,
                      reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
@@ -911,16 +928,50 @@ GFM_API int gfm_profile_enable(gfm_motif_t m, int slots, int every)
     m->ev_calls = 0;
     for (auto e : m->ev0) (void)hipEventDestroy(e);
     for (auto e : m->ev1) (void)hipEventDestroy(e);
+    for (auto e : m->tev0) (void)hipEventDestroy(e);
+    for (auto e : m->tev1) (void)hipEventDestroy(e);
     m->ev0.clear();
     m->ev1.clear();
+    m->tev0.clear();
+    m->tev1.clear();
+    m->tail_order.clear();
     m->ev_next = m->ev_used = 0;
+    m->ev_last = m->tail_pending = -1;
     for (int i = 0; i < slots; ++i) {
-        hipEvent_t a, b;
+        hipEvent_t a, b, c, d;
         HIP_TRY(hipEventCreate(&a));
         HIP_TRY(hipEventCreate(&b));
+        HIP_TRY(hipEventCreate(&c));
+        HIP_TRY(hipEventCreate(&d));
         m->ev0.push_back(a);
         m->ev1.push_back(b);
+        m->tev0.push_back(c);
+        m->tev1.push_back(d);
     }
+    return GFM_OK;
+}
+
+GFM_API int gfm_profile_mark_tail(gfm_motif_t m, void *stream)
+{
+    if (!m) return fail(GFM_ERR_INVALID, "motif is NULL");
+    if (m->tail_pending < 0) return GFM_OK;               // the last call was not a timed one
+    HIP_TRY(hipEventRecord(m->tev1[m->tail_pending], static_cast<hipStream_t>(stream)));
+    if ((int)m->tail_order.size() < (int)m->tev0.size()) m->tail_order.push_back(m->tail_pending);
+    m->tail_pending = -1;
+    return GFM_OK;
+}
+
+GFM_API int gfm_profile_read_tail(gfm_motif_t m, float *h_ms, int capacity, int *n_out)
+{
+    if (!m || !n_out || (!h_ms && capacity)) return fail(GFM_ERR_INVALID, "NULL argument");
+    const int used = std::min((int)m->tail_order.size(), capacity);
+    for (int i = 0; i < used; ++i) {
+        const int slot = m->tail_order[(size_t)i];
+        HIP_TRY(hipEventSynchronize(m->tev1[slot]));
+        HIP_TRY(hipEventElapsedTime(&h_ms[i], m->tev0[slot], m->tev1[slot]));
+    }
+    *n_out = used;
+    m->tail_order.clear();
     return GFM_OK;
 }
 

@@ -151,6 +151,16 @@ class DeviceMotif:
         nv.check(nv.lib().gfm_profile_read(self._h, nv.ptr(ms), capacity, ctypes.byref(n)))
         return ms[: n.value].copy()
 
+    def profile_mark_tail(self, stream=None):
+        """gfm_profile_mark_tail: stop event of the tail of the last call if that call was a timed one."""
+        nv.check(nv.lib().gfm_profile_mark_tail(self._h, _stream_ptr(stream)))
+
+    def profile_read_tail(self, capacity: int = 4096):
+        ms = np.empty(capacity, dtype=np.float32)
+        n = ctypes.c_int(0)
+        nv.check(nv.lib().gfm_profile_read_tail(self._h, nv.ptr(ms), capacity, ctypes.byref(n)))
+        return ms[: n.value].copy()
+
     # ---- host one-call form
     def scan_host(self, kmers: np.ndarray, threshold: float, on_qvalue=False, want_qvalues=True,
                   capacity: Optional[int] = None):
@@ -242,6 +252,15 @@ def qvalue_table_multi(motifs, hists, threshold, on_qvalue, qtables=None, cutoff
     nv.check(nv.lib().gfm_qvalue_table_multi(
         handles, M, ptr_array(hists), float(threshold), int(bool(on_qvalue)), ptr_array(qtables),
         ptr_array(cutoffs), ptr_array(nrows), nv.GFM_FLAG_CLEAR_HIST if clear_hist else 0, _stream_ptr(stream)))
+
+
+def calibrate_stream(loads_per_store: int, in_bytes: int, write_through: bool, launches: int = 20):
+    """gfm_calibrate_stream -> (us per launch, bytes read + written per launch): the bare-stream floor of the score
+    kernel's byte mix on the current device."""
+    us, nbytes = ctypes.c_double(), ctypes.c_double()
+    nv.check(nv.lib().gfm_calibrate_stream(int(loads_per_store), int(in_bytes), int(bool(write_through)),
+                                           int(launches), ctypes.byref(us), ctypes.byref(nbytes)))
+    return us.value, nbytes.value
 
 
 def _stream_ptr(stream):

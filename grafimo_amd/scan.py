@@ -114,6 +114,9 @@ class KmerScanner:
         # q-value threshold: select from the p < t candidates the score kernel collects (enqueue) instead of
         # reading every score again; False = the separate pass over the scores (measurement aid)
         self.candidates = bool(candidates)
+        # measurement aid (bench.py tail_ms): close the tail timing of a timed call (gfm_profile_mark_tail) behind the
+        # last thing the step enqueues -- one more ctypes call per step, so only on request
+        self.profile_tail = False
         self._turn = 0
         # entries of a slot's hit buffer ([count | hits...]) that a gather moves: the whole buffer until
         # size_gather() has seen how many hits a batch really holds
@@ -219,10 +222,14 @@ class KmerScanner:
                 gs.wait_event(slot.tail_done)
                 with torch.cuda.stream(gs):
                     self._gather(slot)
+                if self.profile_tail:
+                    lib.gfm_profile_mark_tail(h, gs.cuda_stream)
                 slot.done.record(gs)
                 return slot
             with torch.cuda.stream(tail):
                 self._gather(slot)
+        if self.profile_tail:
+            lib.gfm_profile_mark_tail(h, tail_p)
         slot.done.record(tail)
         return slot
 

@@ -215,3 +215,56 @@ def config_motifs(cfg: int):
             out.append(synthetic_motif(8 + (k % 18), rng, bg))
         return out
     raise ValueError("config_motifs: config 4 or 5")
+
+
+def make_graph_index(n_regions: int, width: int = 19, n_haplotypes: int = 5096, site_every: int = 32,
+                     del_frac: float = 0.06, seed: int = 20240139, with_counts: bool = True, with_dels: bool = True):
+    """A synthetic chromosome for the extraction kernels at BASELINE config-2 scale: region i = [16 000 + 1000 i,
+    + 200] (SURVEY 8d's layout, shifted to a short contig), variant sites at 1000-Genomes-like density (one per
+    `site_every` bp, 3 % with two alternates, `del_frac` of them deletions of 1..8 bases kept apart from each other),
+    allele frequencies skewed to rare variants (af = u^4), one haplotype bitset per alternate allele.  Sites are
+    drawn only where a window of a region can see them.  -> (GraphIndex, [(S, E)] regions)."""
+    from .extract_regions import GraphIndex
+    rng = np.random.default_rng(seed)
+    L = 16_000 + REGION_STRIDE * n_regions + 4 * REGION_LEN
+    ref = _ACGT[rng.choice(4, size=L, p=BG_NT / BG_NT.sum())]
+    regions = [(16_000 + REGION_STRIDE * i, 16_000 + REGION_STRIDE * i + REGION_LEN) for i in range(n_regions)]
+    span = REGION_LEN + 2 * width + 16
+    per_region = max(1, span // site_every)
+    starts = np.asarray([r[0] for r in regions], dtype=np.int64) - width - 8
+    pos = (starts[:, None] + np.sort(rng.integers(0, span, size=(n_regions, per_region)), axis=1)).ravel()
+    pos = np.unique(pos).astype(np.int32)
+    V = len(pos)
+    n_alts = np.where(rng.random(V) < 0.97, 1, 2).astype(np.uint8)
+    alt_bases = np.zeros((V, 3), np.uint8)
+    code = np.searchsorted(_ACGT, ref[pos])
+    for a in range(2):
+        alt_bases[:, a] = _ACGT[(code + 1 + a) % 4]
+    alt_bases[n_alts < 2, 1] = 0
+    del_len = np.zeros(V, np.int32)
+    if with_dels:
+        last_end = -1
+        for i in np.nonzero(rng.random(V) < del_frac)[0]:
+            ln = int(rng.integers(1, 9))
+            if pos[i] > last_end and pos[i] + ln < L - 1:
+                del_len[i] = ln
+                last_end = int(pos[i]) + ln
+        n_alts[del_len > 0] = 1
+        alt_bases[del_len > 0] = 0
+    bits = None
+    if with_counts:
+        hw = (n_haplotypes + 63) // 64
+        bits = np.zeros((V, 3, hw), np.uint64)
+        af = rng.random(V) ** 4
+        for s in range(0, V, 8192):
+            e = min(V, s + 8192)
+            for a in range(2):
+                carry = rng.random((e - s, hw * 64)) < (af[s:e, None] if a == 0 else 0.5 * af[s:e, None])
+                carry[:, n_haplotypes:] = False
+                if a == 1:      # a haplotype carries one alternate at most
+                    carry &= ~np.unpackbits(bits[s:e, 0, :].view(np.uint8), axis=1, bitorder="little").astype(bool)
+                    carry[n_alts[s:e] < 2] = False
+                bits[s:e, a, :] = np.packbits(carry, axis=1, bitorder="little").view(np.uint64)
+    idx = GraphIndex("22", ref, pos, n_alts, alt_bases, bits, n_haplotypes if with_counts else 0,
+                     del_len=del_len if with_dels else None)
+    return idx, regions

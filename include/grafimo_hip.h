@@ -155,6 +155,22 @@ int gfm_score_kmers_multi_plan(const gfm_motif_t *motifs, int n_motifs, const in
  * events and returns the kernel durations in ms, oldest first. */
 int gfm_profile_enable(gfm_motif_t m, int slots, int every);
 int gfm_profile_read(gfm_motif_t m, float *h_ms_out, int capacity, int *n_out);
+/* The TAIL of a timed gfm_score_kmers call that was given a tail stream: the library records a start event on the
+ * tail stream behind its wait for the score kernel (i.e. when the tail may begin); gfm_profile_mark_tail records the
+ * stop event on `stream` -- call it after everything that belongs to the step's tail has been enqueued (post kernel,
+ * the all-reduce of the histogram, q-table, hit gather) on the stream the last of it runs on; a no-op when the last
+ * call was not a timed one.  gfm_profile_read_tail returns the durations in ms, oldest first. */
+int gfm_profile_mark_tail(gfm_motif_t m, void *stream);
+int gfm_profile_read_tail(gfm_motif_t m, float *h_ms_out, int capacity, int *n_out);
+
+/* Measurement aid (bench.py `peak_measured`): what THIS device sustains for a bare stream with the score kernel's
+ * byte mix -- every lane issues `loads_per_store` 16-byte non-temporal loads per 16-byte store, loads and stores
+ * interleaved in one pass, one step prefetched (the shape score_quad_kernel has; W = 19: 4.75 -> 5 loads per store).
+ * in_bytes are read per launch, in_bytes / loads_per_store written, the output rotating over three buffers;
+ * store_policy 0 = nt, 1 = write-through (sc0 sc1).  Allocates and frees its own buffers; synchronous.
+ * *us_per_launch = average of `launches` launches (HIP events), *bytes_per_launch = bytes read + written. */
+int gfm_calibrate_stream(int loads_per_store, int64_t in_bytes, int store_policy, int launches,
+                         double *us_per_launch, double *bytes_per_launch);
 
 /* replaces compute_qvalues(pvalues, debug) (score_sequences.py:401-428; statsmodels
  * fdr_bh): Benjamini-Hochberg q-value of every scaled score, from the score histogram

@@ -1,0 +1,32 @@
+"""bench.py as the driver calls it for N > 1: `python bench.py --gpus N ...` with no WORLD_SIZE in the environment
+must start its own ranks (torch.distributed.run children of a parent that touches no GPU), print rank 0's JSON line
+as its LAST line and exit with the children's code.  Driven here with --dry-run (gloo, no GPU work)."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _run(extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup",
+                           "1", "--dry-run"] + extra, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_self_launches_its_ranks_and_relays_one_json_line():
+    p = _run([])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    rec = json.loads(lines[-1])                                  # the LAST line is the result line
+    assert rec["n_gpus"] == 2 and rec["rccl_world"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["rank_ms_per_step"] == [1.0, 2.0]                 # one entry per rank, gathered over the group
+    assert sum(1 for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln) == 1
+
+
+def test_bench_launcher_passes_a_failing_rank_on():
+    p = _run(["--dry-run-fail-rank", "1"])
+    assert p.returncode != 0
+    assert not any(ln.lstrip().startswith("{") and '"metric"' in ln for ln in p.stdout.splitlines())
