@@ -9,6 +9,7 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
 #include <unistd.h>
 
 namespace gfm_workers {
@@ -43,19 +44,43 @@ struct Crew {
     }
 };
 
-// The crew is never destroyed: its threads sleep on its condition variable until the process ends.  After a
-// fork() the child holds the object but none of the threads: it starts a crew of its own.
+// The crew is never destroyed: its threads sleep on its condition variable until the process ends (at most one
+// per hardware thread or kMaxCrew, whichever a caller asked for: the TSV reader caps itself at 96, the VCF reader at
+// the `threads` it is given).  fork(): the child holds the object but none of the threads, so it starts a crew of
+// its own; pthread_atfork handlers take both mutexes around the fork so that the child never inherits one that some
+// other thread of the parent held.
+constexpr int kMaxCrew = 512;
+std::mutex g_crew_mu;
+Crew *g_crew = nullptr;
+
+void fork_prepare()
+{
+    g_crew_mu.lock();
+    if (g_crew) g_crew->mu.lock();
+}
+void fork_parent()
+{
+    if (g_crew) g_crew->mu.unlock();
+    g_crew_mu.unlock();
+}
+void fork_child()
+{
+    if (g_crew) g_crew->mu.unlock();
+    g_crew = nullptr;              // the parent's crew object stays behind (its threads do not exist here)
+    g_crew_mu.unlock();
+}
+
 Crew *crew()
 {
-    static std::mutex mu;
-    static Crew *c = nullptr;
-    std::lock_guard<std::mutex> lk(mu);
+    static const int registered = pthread_atfork(fork_prepare, fork_parent, fork_child);
+    (void)registered;
+    std::lock_guard<std::mutex> lk(g_crew_mu);
     const pid_t me = getpid();
-    if (!c || c->pid != me) {
-        c = new (std::nothrow) Crew();
-        if (c) c->pid = me;
+    if (!g_crew || g_crew->pid != me) {
+        g_crew = new (std::nothrow) Crew();
+        if (g_crew) g_crew->pid = me;
     }
-    return c;
+    return g_crew;
 }
 
 }  // namespace
@@ -70,7 +95,7 @@ void Run::start(int n, std::function<void()> fn)
     wait();
     if (n < 1) return;
     impl_ = new Impl();
-    Crew *c = crew();
+    Crew *c = n <= kMaxCrew ? crew() : nullptr;
     if (c) {
         std::unique_lock<std::mutex> lk(c->mu);
         if (!c->busy) {

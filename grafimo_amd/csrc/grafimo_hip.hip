@@ -65,6 +65,12 @@ struct gfm_motif {
     double *d_qscratch = nullptr;    // [L] raw BH values when the caller wants no q-table
     HitCtl *d_ctl = nullptr;
     unsigned call_no = 0;           // score calls: HitCtl slot call_no % kCtlSlots, workspace call_no % kWorkspaces
+    // GFM_FLAG_CALLER_ORDERS_REUSE is a promise about the call four back ON THIS HANDLE, which a pipelined caller can
+    // only keep for its own calls: the flag is honoured when the kWorkspaces calls before this one came from the
+    // same (stream, tail stream) pair, and ignored (the library waits on its own event) when another user of the
+    // handle was in between.
+    hipStream_t last_st = nullptr, last_tail = nullptr;
+    unsigned same_pair_run = 0;     // consecutive calls made with (last_st, last_tail) so far
     hipEvent_t ev_scored[kWorkspaces] = {};   // score kernel of the last call on a workspace done
     hipEvent_t ev_posted[kWorkspaces] = {};   // its post kernel done (workspace free again)
     bool posted_valid[kWorkspaces] = {};
@@ -761,7 +767,12 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     const bool reset = (flags & GFM_FLAG_RESET_HITS) != 0;
     // workspace `ws` was last used by call k-4: its post kernel must be done.  Appending to a
     // hit list additionally needs the count published by call k-1.
-    if (m->posted_valid[ws] && !(flags & GFM_FLAG_CALLER_ORDERS_REUSE))
+    const bool same_owner = st == m->last_st && tail == m->last_tail;
+    const bool caller_orders = (flags & GFM_FLAG_CALLER_ORDERS_REUSE) && same_owner && m->same_pair_run >= (unsigned)kWorkspaces;
+    m->same_pair_run = same_owner ? m->same_pair_run + 1 : 1;
+    m->last_st = st;
+    m->last_tail = tail;
+    if (m->posted_valid[ws] && !caller_orders)
         HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws], 0));
     if (split && select && !reset && m->posted_valid[ws_prev])
         HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws_prev], 0));
@@ -859,6 +870,8 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
         for (int k = 0; k < mm; ++k) {
             gfm_motif *mo = motifs[i + k];
             const unsigned c = mo->call_no++;
+            mo->same_pair_run = 0;             // another user of the handle: see gfm_motif::same_pair_run
+            mo->last_st = mo->last_tail = nullptr;
             ws[k] = (int)(c % (unsigned)kWorkspaces);
             slot[k] = (int)(c % (unsigned)kCtlSlots);
             mo->posted_valid[ws[k]] = false;   // single stream: stream order protects the workspace

@@ -262,23 +262,31 @@ graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ regi
     const int i0 = lower_bound_pos(g.pos, g.n_sites, p);
     long long walks = 1;
     bool touches_del = g.n_dels > 0 && cover_deletion(g, p, i0) >= 0;
+    bool over = false;      // too many walks for a plain window -- reported only if the window is kept as one
     for (int i = i0; i < g.n_sites && g.pos[i] < p + W; ++i) {
         if (g.del_len[i] || g.ins_len[i]) touches_del = true;
-        walks *= 1 + g.n_alts[i];
-        if (walks > kMaxWalksPerWindow) { walks = 0; atomicMax(overflow, 1); break; }
+        if (!over) {
+            walks *= 1 + g.n_alts[i];
+            over = walks > kMaxWalksPerWindow;
+        }
     }
     if (g.n_ins > 0) {
         for (int k = i0 - 1; k >= 0 && g.pos[k] == p - 1; --k)     // walks that start inside an insertion behind p - 1
             if (g.ins_len[k] > 0) touches_del = true;
         // with insertions in the graph the windows run on to the region's last base: beyond E - W only a walk
-        // that reads inserted bases ends inside the region
-        if (!touches_del && p + W > region_stop[r]) walks = 0;
+        // that reads inserted bases ends inside the region -- a plain window there holds no walk, however many
+        // SNPs it spans (no overflow to report for it)
+        if (!touches_del && p + W > region_stop[r]) { walks = 0; over = false; }
     }
     if (touches_del) {
-        // the sites a walk meets depend on the deletions it takes: graph_count_del_kernel enumerates them.
+        // the sites a walk meets depend on the deletions it takes: graph_count_del_kernel enumerates them (and
+        // reports its own overflow).
         // (Done here, the few deletion windows of a wave made all of its lanes wait for their odometers.)
         walks = 0;
         del_list[atomicAdd(del_count, 1)] = (int)w;
+    } else if (over) {
+        walks = 0;
+        atomicMax(overflow, 1);
     }
     first_site[w] = i0;
     n_walks[w] = walks;

@@ -92,6 +92,12 @@ void gfm_tsv_detail::parse_file(const char *path, int W, bool skip_rev, FileCols
     // thousands of region files serialise on the process's address-space lock.  Big files are mapped.
     constexpr size_t kReadLimit = (size_t)32 << 20;
     static thread_local std::vector<char> t_buf;
+    // the parse threads belong to a crew that lives as long as the process: a buffer that grew for one big file is
+    // handed back when this file is done (region files are a few hundred KB: those keep their buffer)
+    struct Shrink {
+        std::vector<char> &b;
+        ~Shrink() { if (b.capacity() > ((size_t)1 << 20)) std::vector<char>().swap(b); }
+    } shrink{t_buf};
     void *map = nullptr;
     const char *p = nullptr;
     if (len <= kReadLimit) {

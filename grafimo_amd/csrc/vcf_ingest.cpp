@@ -58,6 +58,8 @@ struct Chunk {
     std::vector<uint64_t> bits;
     std::vector<uint8_t> ins_pool;
     std::vector<uint8_t> alleles;      // scratch of parse_line, reused from line to line
+    std::vector<int> allele_of_atom;   // scratch of parse_line: ALT index of every atom of the record (any number:
+                                       // a long multi-base substitution yields one atom per mismatching position)
     int n_hap = -1;
     int64_t skipped = 0;
     std::string error;
@@ -106,31 +108,32 @@ void parse_line(const char *b, const char *e, bool want_hap, Chunk &out)
     }
     // what every ALT is
     const size_t first_atom = out.atoms.size();
-    int allele_of_atom[kMaxAlts * 64];
-    int n_new = 0;
+    std::vector<int> &allele_of_atom = out.allele_of_atom;
+    allele_of_atom.clear();
     for (int k = 0; k < na; ++k) {
         bool ok = ref_ok && k < kMaxAlts && k < 16 && al[k] > 0;
         for (long j = 0; ok && j < al[k]; ++j) ok = is_base(up(ab[k][j]));
         if (ok && ref_len == 1 && al[k] == 1) {
             Atom a; a.pos = pos; a.kind = 0; a.base = (uint8_t)up(ab[k][0]);
-            out.atoms.push_back(a); allele_of_atom[n_new++] = k;
+            out.atoms.push_back(a); allele_of_atom.push_back(k);
         } else if (ok && ref_len > 1 && al[k] == 1 && up(ab[k][0]) == up(ref_b[0])) {
             Atom a; a.pos = pos; a.kind = 2; a.del_len = (int32_t)(ref_len - 1);
-            out.atoms.push_back(a); allele_of_atom[n_new++] = k;
+            out.atoms.push_back(a); allele_of_atom.push_back(k);
         } else if (ok && ref_len == 1 && al[k] > 1 && up(ab[k][0]) == up(ref_b[0])) {
             Atom a; a.pos = pos; a.kind = 1; a.ins_len = (int32_t)(al[k] - 1); a.ins_at = out.ins_pool.size();
             for (long j = 1; j < al[k]; ++j) out.ins_pool.push_back((uint8_t)up(ab[k][j]));
-            out.atoms.push_back(a); allele_of_atom[n_new++] = k;
+            out.atoms.push_back(a); allele_of_atom.push_back(k);
         } else if (ok && ref_len == al[k] && ref_len > 1) {
-            for (long j = 0; j < ref_len && n_new < kMaxAlts * 64; ++j)
+            for (long j = 0; j < ref_len; ++j)
                 if (up(ref_b[j]) != up(ab[k][j])) {
                     Atom a; a.pos = pos + j; a.kind = 0; a.base = (uint8_t)up(ab[k][j]);
-                    out.atoms.push_back(a); allele_of_atom[n_new++] = k;
+                    out.atoms.push_back(a); allele_of_atom.push_back(k);
                 }
         } else {
             ++out.skipped;
         }
     }
+    const int n_new = (int)allele_of_atom.size();
     if (n_new == 0) return;
     if (want_hap && nf == 10) {
         // genotype columns start at f[9]; count haplotypes on the first record of the chunk
@@ -169,7 +172,7 @@ void parse_line(const char *b, const char *e, bool want_hap, Chunk &out)
         // one carrier bitset per ALT of the record that yielded atoms; the atoms of one ALT share it
         size_t at_of_allele[kMaxAlts] = {(size_t)-1, (size_t)-1, (size_t)-1};
         for (int t = 0; t < n_new; ++t) {
-            const int k = allele_of_atom[t];
+            const int k = allele_of_atom[(size_t)t];
             if (at_of_allele[k] == (size_t)-1) {
                 at_of_allele[k] = out.bits.size();
                 out.bits.resize(out.bits.size() + (size_t)hw, 0ull);

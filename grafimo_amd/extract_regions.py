@@ -154,6 +154,11 @@ class GraphIndex:
             print(f"WARNING: {int(skipped.value)} ALT allele(s) on {chrom} (complex alleles, a fourth alternate, "
                   f"overlapping deletions) are NOT part of the graph: k-mers through them are missing and their "
                   f"neighbours keep the reference allele.", file=sys.stderr)
+        if V and int(ins_len.max()) > 0:
+            print(f"NOTE: {int((ins_len > 0).sum())} insertion allele(s) on {chrom}: k-mers through inserted bases follow "
+                  f"the rules written down in oracle/extract_oracle.py (coordinates of walks that start or end inside "
+                  f"an insertion, node numbering); they agree with a per-haplotype brute-force enumeration but no "
+                  f"`vg find` output was available to compare them with.", file=sys.stderr)
         if V == 0:
             print(f"WARNING: no usable VCF record for chromosome {chrom!r} in {vcf}: the graph is the bare reference "
                   f"(do the chromosome names of the VCF and the FASTA match?)", file=sys.stderr)

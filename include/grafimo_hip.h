@@ -48,7 +48,9 @@ extern "C" {
  * host has seen it complete) that the tail work of the call FOUR before this one on the same handle has
  * finished -- the handle's scoring workspace is a ring of four -- so the library need not make the main
  * stream wait for it (an event wait is a barrier packet in front of the score kernel: several
- * microseconds of an idle GPU per step). */
+ * microseconds of an idle GPU per step).  The library honours the flag only while the four calls before this one
+ * on the handle were made with the same (stream, tail_stream) pair -- a second user of the handle in between (another
+ * scanner, a batched call) makes it fall back to its own event wait. */
 #define GFM_FLAG_CALLER_ORDERS_REUSE 4u
 /* a hit-list entry packs the global row id and the row's scaled score:
  * entry = (row << GFM_HIT_SCORE_BITS) | score   (score <= 1000*64 < 2^20) */

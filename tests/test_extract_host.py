@@ -389,3 +389,34 @@ def test_host_walk_mirror_follows_the_oracle_through_insertions(tmp_path):
                 seen_ins += any(b[0] == "ins" for b in bases)
                 assert len(idx.nodes_of(bases)) >= 1
         assert seen_ins > 0
+
+
+def test_long_multibase_substitution_keeps_every_mismatch(tmp_path):
+    """a multi-base substitution with more than 192 mismatching positions beside other ALTs of the same
+    record.  Every mismatch becomes a substitution site with the allele's carriers (none dropped, nothing written past
+    a fixed scratch array), the deletion ALT of the record keeps its own carriers, and the C++ reader equals the oracle
+    reader."""
+    from grafimo_amd.extract_regions import GraphIndex
+    from oracle import extract_oracle as xo
+    rng = np.random.default_rng(5)
+    n = 260
+    ref = "".join(rng.choice(list("ACGT"), size=n + 40))
+    comp = {"A": "C", "C": "G", "G": "T", "T": "A"}
+    mnp = "".join(comp[c] for c in ref[10:10 + n])                 # all n positions mismatch
+    head = "##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\tb\tc\n"
+    body = [f"m\t11\t.\t{ref[10:10 + n]}\t{mnp},{ref[10]}\t.\t.\t.\tGT\t1|0\t2|1\t0|0",
+            f"m\t{11 + n + 5}\t.\t{ref[10 + n + 5]}\t{comp[ref[10 + n + 5]]}\t.\t.\t.\tGT\t0|1\t0|0\t1|1"]
+    vcf = tmp_path / "long.vcf"
+    vcf.write_text(head + "\n".join(body) + "\n")
+    fasta = tmp_path / "long.fa"
+    fasta.write_text(">m\n" + ref + "\n")
+    v = xo.read_vcf_variants(str(vcf), "m")
+    assert sum(k == 0 for k in v.kind) == n + 1 and sum(k == 2 for k in v.kind) == 1 and v.skipped == 0
+    for threads in (1, 3):
+        idx = GraphIndex.from_fasta_vcf(str(fasta), str(vcf), "m", threads=threads)      # fail-closed: nothing skipped
+        assert idx.skipped == 0 and int((idx.del_len == 0).sum()) == n + 1
+        _index_equals_variants(idx, v)
+        snp = np.nonzero((idx.del_len == 0) & (idx.pos < 10 + n))[0]
+        assert idx.pos[snp].tolist() == list(range(10, 10 + n))
+        bits = np.unpackbits(idx.alt_bits[snp, 0, :].view(np.uint8), axis=1, bitorder="little")[:, :6]
+        assert (bits == np.array([1, 0, 0, 1, 0, 0], dtype=np.uint8)).all()               # carriers of ALT 1, every site
