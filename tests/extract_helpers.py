@@ -110,3 +110,83 @@ def scoring_fixture_graph():
     sites = xo.Sites([p - S for p, _ in order], [refd[p] for p, _ in order], [[a] for _, a in order], hap)
     dels = xo.Dels([19723467 - S], [2], dhap)
     return rows, refseq, sites, dels, S, E
+
+
+def make_consistent_graph_files(tmpdir, chrom="c", length=600, n_samples=24, seed=1, kinds="sidm", gz=False,
+                                dense=True):
+    """FASTA + phased VCF whose haplotypes are CONFLICT-FREE (what oracle/extract_bruteforce.py needs): records have
+    disjoint REF spans, so a haplotype never carries two alleles over the same reference bases -- except that a
+    single-base substitution record may be followed by an insertion / deletion record anchored on that same base, and a
+    position may get a second substitution record carried only by haplotypes that are reference at the first.
+    Only alleles the extraction graph models (kinds: s substitutions incl. multi-allelic, i insertions, d deletions,
+    m equal-length multi-base substitutions); no deletion touches another.  Returns (fasta, vcf)."""
+    rng = np.random.default_rng(seed)
+    ref = "".join(rng.choice(list("ACGT"), size=length, p=[0.3, 0.2, 0.2, 0.3]))
+    fasta = os.path.join(tmpdir, f"cons{seed}.fa")
+    with open(fasta, "w") as fh:
+        fh.write(f">{chrom}\n")
+        for i in range(0, length, 70):
+            fh.write(ref[i:i + 70] + "\n")
+    H = 2 * n_samples
+    lines = []
+
+    def genotypes(n_alleles, allowed=None):
+        af = rng.random() ** 1.5
+        g = np.where(rng.random(H) < af, rng.integers(1, n_alleles + 1, size=H), 0)
+        if allowed is not None:
+            g = np.where(allowed, g, 0)
+        return g
+
+    def emit(p, r, alts, g):
+        cols = "\t".join(f"{g[2 * s]}|{g[2 * s + 1]}" for s in range(n_samples))
+        lines.append(f"{chrom}\t{p + 1}\t.\t{r}\t{','.join(alts)}\t99\t.\t.\tGT\t{cols}")
+
+    p = int(rng.integers(0, 4))
+    while p < length - 12:
+        r = ref[p]
+        others = [b for b in "ACGT" if b != r]
+        rng.shuffle(others)
+        kind = rng.choice(list(kinds))
+        end = p + 1                                   # first position behind this record's REF span
+        if kind == "s":
+            n_alt = int(rng.choice([1, 1, 1, 2, 3]))
+            g = genotypes(n_alt)
+            emit(p, r, others[:n_alt], g)
+            u = rng.random()
+            if u < 0.12 and n_alt < 3:                # a second record at the position, for the non-carriers
+                g2 = genotypes(1, allowed=g == 0)
+                emit(p, r, [others[n_alt] if rng.random() < 0.6 else others[0]], g2)
+                g = np.where(g2 > 0, 1, g)
+            elif u < 0.24 and "i" in kinds:           # an insertion anchored on the substituted base
+                emit(p, r, [r + "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 5))))], genotypes(1))
+            elif u < 0.36 and "d" in kinds:           # a deletion anchored on it
+                ln = int(rng.integers(1, 5))
+                emit(p, ref[p:p + 1 + ln], [r], genotypes(1))
+                end = p + 1 + ln
+        elif kind == "i":
+            seqs = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 7)))) for _ in range(int(rng.choice([1, 1, 2])))]
+            alts = [r + s for s in dict.fromkeys(seqs)]
+            if rng.random() < 0.2:
+                alts = [others[0]] + alts             # a substitution and insertions in one record
+            emit(p, r, alts[:3], genotypes(len(alts[:3])))
+        elif kind == "d":
+            ln = int(rng.integers(1, 6))
+            emit(p, ref[p:p + 1 + ln], [r], genotypes(1))
+            end = p + 1 + ln
+        else:
+            ln = int(rng.integers(2, 5))
+            span = ref[p:p + ln]
+            sub = "".join(rng.choice([b for b in "ACGT" if b != c]) if rng.random() < 0.7 else c for c in span)
+            if sub == span:
+                sub = others[0] + span[1:]
+            emit(p, span, [sub], genotypes(1))
+            end = p + ln
+        gap = int(rng.integers(0, 6)) if (dense and rng.random() < 0.7) else int(rng.integers(6, 40))
+        p = end + gap
+    vcf = os.path.join(tmpdir, f"cons{seed}.vcf" + (".gz" if gz else ""))
+    op = gzip.open if gz else open
+    with op(vcf, "wt") as fh:
+        fh.write("##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" +
+                 "\t".join(f"s{i}" for i in range(n_samples)) + "\n")
+        fh.write("\n".join(lines) + "\n")
+    return fasta, vcf

@@ -1,0 +1,82 @@
+"""The walk enumerator of the extraction step (oracle/extract_oracle.py) against an independent algorithm: every
+haplotype of the VCF materialised as a sequence, W-windows slid over it (oracle/extract_bruteforce.py).  A row's
+haplotype count must be the number of haplotypes whose sequence holds that k-mer at those coordinates; rows no haplotype
+carries must report 0.  tests/test_gpu_extract.py runs the same check on the HIP kernels' rows."""
+import os
+
+import pytest
+
+from conftest import REF_DATA
+from extract_helpers import make_consistent_graph_files
+
+
+def _rows(tuples):
+    """enumerator rows (label, kmer, 'c:start+', 'c:stop+', count, flag[, path]) -> (kmer, start, stop, strand, count, flag)"""
+    for r in tuples:
+        yield (r[1].encode(), int(r[2].split(":")[1][:-1]), int(r[3].split(":")[1][:-1]), r[2][-1], r[4], r[5])
+
+
+def test_reference_test_graph_counts_from_first_principles():
+    """tests/test_data/input/test.fa + test.vcf.gz (the graph behind the reference's own test_sequence_extraction,
+    tests/grafimo_run_test.py:49-63): the -H counts of both oracles equal the per-haplotype brute force."""
+    from oracle import extract_bruteforce as bf
+    from oracle import extract_oracle as xo
+    ref = xo.read_fasta(os.path.join(REF_DATA, "test.fa"))["x"]
+    vcf = os.path.join(REF_DATA, "test.vcf.gz")
+    recs, H = bf.read_vcf_records(vcf, "x")
+    assert H == 2 and bf.consistent(ref, recs, H)
+    sites = xo.read_vcf_snps(vcf, "x")
+    v = xo.read_vcf_variants(vcf, "x")
+    for S, E, W in [(0, 20, 19), (0, 50, 19), (5, 45, 8), (0, 50, 30), (0, 50, 1)]:
+        freq, flags = bf.window_counts(ref, recs, H, S, E, W)
+        assert len(freq) > 0
+        carried, n = bf.check_rows(_rows(xo.enumerate_region("x", ref, sites, S, E, W, with_counts=True)), freq, flags)
+        assert carried == len(freq) and n > 2 * carried - 1
+        bf.check_rows(_rows(xo.enumerate_region_variants("x", ref, v, S, E, W, with_counts=True)), freq, flags)
+
+
+@pytest.mark.parametrize("kinds", ["s", "sd", "si", "sm", "sidm", "id"])
+def test_enumerator_counts_equal_the_per_haplotype_brute_force(tmp_path, kinds):
+    """Random conflict-free VCFs with every modelled allele kind: substitutions (multi-allelic, second records at a
+    position), insertions (also several at one anchor, behind a substituted anchor), deletions, multi-base
+    substitutions; clustered so that windows hold several sites; regions that touch both chromosome ends."""
+    from oracle import extract_bruteforce as bf
+    from oracle import extract_oracle as xo
+    total = 0
+    for seed in range(3):
+        fasta, vcf = make_consistent_graph_files(str(tmp_path), chrom="c", length=420, n_samples=16,
+                                                 seed=100 * len(kinds) + seed, kinds=kinds)
+        ref = xo.read_fasta(fasta)["c"]
+        recs, H = bf.read_vcf_records(vcf, "c")
+        assert H == 32 and bf.consistent(ref, recs, H)
+        v = xo.read_vcf_variants(vcf, "c")
+        assert v.skipped == 0 and len(v) > 20
+        for (S, E), W in [((0, 90), 19), ((100, 260), 8), ((250, 420), 30), ((30, 200), 3), ((395, 420), 12)]:
+            freq, flags = bf.window_counts(ref, recs, H, S, E, W)
+            rows = xo.enumerate_region_variants("c", ref, v, S, E, W, with_counts=True)
+            carried, n = bf.check_rows(_rows(rows), freq, flags)
+            total += carried
+            if "i" not in kinds and "m" not in kinds:      # the deletion oracle pinned by the 704-row fixture says the same
+                sites, dels, skipped = xo.read_vcf_graph(vcf, "c")
+                if skipped == 0:
+                    bf.check_rows(_rows(xo.enumerate_region_graph("c", ref, sites, dels, S, E, W, with_counts=True)),
+                                  freq, flags)
+    assert total > 1000
+
+
+def test_brute_force_refuses_conflicting_haplotypes(tmp_path):
+    from oracle import extract_bruteforce as bf
+    head = "##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\n"
+    (tmp_path / "x.vcf").write_text(head + "c\t3\t.\tGTA\tG\t.\t.\t.\tGT\t1|0\nc\t4\t.\tT\tC\t.\t.\t.\tGT\t1|1\n")
+    recs, H = bf.read_vcf_records(str(tmp_path / "x.vcf"), "c")
+    ref = b"ACGTACGTAC"
+    assert not bf.consistent(ref, recs, H)          # haplotype 0 carries the deletion AND a base inside it
+    seq, coord, ins, alt = bf.haplotype_sequence(ref, recs, 1)
+    assert bytes(seq) == b"ACGCACGTAC" and coord == list(range(10)) and alt[3] and not any(ins)
+    (tmp_path / "y.vcf").write_text(head + "c\t3\t.\tG\tT\t.\t.\t.\tGT\t1|0\nc\t3\t.\tG\tGAA\t.\t.\t.\tGT\t1|1\n"
+                                    "c\t6\t.\tCGT\tC\t.\t.\t.\tGT\t0|1\n")
+    recs, H = bf.read_vcf_records(str(tmp_path / "y.vcf"), "c")
+    s0 = bf.haplotype_sequence(ref, recs, 0)
+    s1 = bf.haplotype_sequence(ref, recs, 1)
+    assert bytes(s0[0]) == b"ACTAATACGTAC" and s0[1] == [0, 1, 2, 2, 2, 3, 4, 5, 6, 7, 8, 9]
+    assert bytes(s1[0]) == b"ACGAATACAC" and s1[1] == [0, 1, 2, 2, 2, 3, 4, 5, 8, 9] and s1[2][3] and s1[2][4]

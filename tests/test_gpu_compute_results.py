@@ -439,3 +439,41 @@ def test_timed_launches_with_a_tail_stream_keep_their_order(golden_motifs):
     dm.profile_enable(0)
     assert len(ms) == 9 and np.all(ms > 0.0005) and np.all(ms < 50.0)
     dm.close()
+
+
+def test_two_scanners_share_one_handle_interleaved(golden_motifs):
+    """the workspace ring and the hit-counter ring belong to the DeviceMotif, not to a scanner.  Two
+    pipelined scanners (three slots each: both promise 'my batch four back is done' through
+    GFM_FLAG_CALLER_ORDERS_REUSE) that take turns on ONE handle shift each other's ring positions; the library must
+    notice the second user and order the workspace reuse itself.  Large batches (the post kernels are still pending
+    when the next score kernels are enqueued), no host synchronisation inside a round; every batch equals the oracle."""
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.scan import KmerScanner
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    g = flat["ctcf_meme_unif#0"]
+    dev = torch.device("cuda:0")
+    dm = DeviceMotif(g["score_matrix"], g["bg"], g["min_val"], g["scale"], g["offset"], g["pmf"])
+    ptab = orc.p_table(g["pmf"])
+    rng = np.random.default_rng(17)
+    n = 1_500_000
+    batches = [rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(n - 1000 * b, 19)) for b in range(4)]
+    d_batches = [torch.from_numpy(k).to(dev) for k in batches]
+    expect = []
+    for km in batches:
+        sc_exp, p = orc.score_kmers_table(km, g["score_matrix"], ptab, g["min_val"])
+        expect.append((sc_exp, p, np.bincount(sc_exp, minlength=dm.L)))
+    a, b = KmerScanner(dm, n, device=dev, n_slots=3), KmerScanner(dm, n, device=dev, n_slots=3)
+    for rnd in range(6):
+        order = [(a, 0), (b, 1), (a, 2), (b, 3), (a, 1), (b, 0)] if rnd % 2 == 0 else [(a, 3), (a, 2), (b, 1), (a, 0), (b, 2), (b, 3)]
+        slots = [(sc, i, sc.enqueue(d_batches[i], 1e-2 if (i + rnd) % 2 else 1.0)) for sc, i in order[:3]]
+        slots += [(sc, i, sc.enqueue(d_batches[i], 1e-3)) for sc, i in order[3:]]
+        for k, (sc, i, slot) in enumerate(slots):
+            thr = (1e-2 if (i + rnd) % 2 else 1.0) if k < 3 else 1e-3
+            res = sc.collect(slot)
+            sc_exp, p, _ = expect[i]
+            keep = np.nonzero(p < thr)[0]
+            assert res["n_scored"] == len(batches[i]), (rnd, k)
+            assert np.array_equal(res["rows"], keep), (rnd, k, thr)
+            assert np.array_equal(res["scaled"], sc_exp[keep])
+    dm.close()

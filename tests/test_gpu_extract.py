@@ -449,3 +449,46 @@ def test_jumping_walks_must_end_inside_the_region():
     stops = rows.stop.cpu().numpy()[0::2].tolist()
     assert starts.count(18) == 1 and max(stops) <= 32 and 15 in [b - a for a, b in zip(starts, stops)]
     g.close()
+
+
+@pytest.mark.parametrize("kinds", ["s", "sd", "si", "sidm"])
+def test_hip_rows_equal_the_per_haplotype_brute_force(tmp_path, kinds):
+    """the kernels' rows against an algorithm that enumerates no walks at all -- every haplotype of the
+    VCF as a linear sequence, W-windows slid over it (oracle/extract_bruteforce.py): a row's haplotype count is the
+    number of haplotypes that hold this k-mer at these coordinates, rows no haplotype carries report 0, and no
+    window of any haplotype is missing.  Also the reference's own test graph (test.fa + test.vcf.gz)."""
+    from extract_helpers import make_consistent_graph_files
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
+    from oracle import extract_bruteforce as bf
+    from oracle import extract_oracle as xo
+
+    def hip_rows(rows):
+        km = rows.kmers.cpu().numpy()
+        st, sp = rows.start.cpu().numpy(), rows.stop.cpu().numpy()
+        sd, fr, rf = rows.strand.cpu().numpy(), rows.freq.cpu().numpy(), rows.is_ref.cpu().numpy()
+        for i in range(len(rows)):
+            yield (km[i].tobytes(), int(st[i]), int(sp[i]), chr(sd[i]), int(fr[i]), "ref" if rf[i] else "non.ref")
+
+    cases = []
+    for seed in range(2):
+        fasta, vcf = make_consistent_graph_files(str(tmp_path), chrom="c", length=420, n_samples=20,
+                                                 seed=700 + 10 * len(kinds) + seed, kinds=kinds)
+        cases.append((fasta, vcf, "c", [((0, 90), 19), ((100, 260), 8), ((250, 420), 30), ((30, 200), 3), ((395, 420), 12)]))
+    if kinds == "s":
+        cases.append((os.path.join(REF_DATA, "test.fa"), os.path.join(REF_DATA, "test.vcf.gz"), "x",
+                      [((0, 20), 19), ((0, 50), 19), ((5, 45), 8), ((0, 50), 30)]))
+    total = 0
+    for fasta, vcf, chrom, plans in cases:
+        ref = xo.read_fasta(fasta)[chrom]
+        recs, H = bf.read_vcf_records(vcf, chrom)
+        assert bf.consistent(ref, recs, H)
+        idx = GraphIndex.from_fasta_vcf(fasta, vcf, chrom)            # fail-closed: every allele is part of the graph
+        assert idx.skipped == 0 and idx.n_haplotypes == H
+        g = DeviceGraph(idx)
+        for (S, E), W in plans:
+            freq, flags = bf.window_counts(ref, recs, H, S, E, W)
+            carried, n = bf.check_rows(hip_rows(g.extract([(S, E)], W)), freq, flags)
+            assert n >= 2 * carried
+            total += carried
+        g.close()
+    assert total > 500
