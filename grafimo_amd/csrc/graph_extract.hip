@@ -67,6 +67,12 @@ struct GraphDev {
     const int *ins_off;         // [n_sites] offset of the inserted bases in ins_bases
     const uint8_t *ins_bases;
     int n_ins;
+    // haplotype counts of allele combinations over CONSECUTIVE sites, built once per graph (allele 0 = none of the
+    // site's alternates): pair_count[i][a][b] = haplotypes with allele a at site i and b at site i + 1,
+    // triple_count[i][a][b][c] the same over sites i, i + 1, i + 2.  The sites one window holds are consecutive, so
+    // a walk through two or three of them looks its count up instead of ANDing bitsets (nullptr: no haplotypes).
+    const int *pair_count;      // [n_sites][4][4]
+    const int *triple_count;    // [n_sites][4][4][4]
 };
 
 // -------------------------------------------------------------------------------------------
@@ -247,6 +253,17 @@ __device__ inline int region_of(const long long *region_off, int n_regions, long
     return lo;
 }
 
+// What graph_count_del_kernel learns about the first layouts of a listed window, kept for graph_emit_del_kernel: a
+// walk finds its layout by comparing its rank with <= kLayoutCache cumulative counts and replays that layout once,
+// instead of running the odometer from the start (2.5 simulations per walk of a one-deletion window became 1).
+constexpr int kLayoutCache = 8;
+constexpr int kDelMeta = 5;          // staging words per deletion walk: row, start, stop, count, flag
+struct LayoutRec {
+    int cum_end;         // walks of this window up to and including this layout
+    unsigned choice;     // bits 0..23: the jump / insertion decisions, bits 24..31: how many were taken
+    int site, t;         // WalkStart of the layout
+};
+
 // one thread per window: first site inside it and the number of walks (product of allele counts)
 __global__ void __launch_bounds__(kCountThreads)
 graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ region_off,
@@ -308,7 +325,8 @@ __global__ void __launch_bounds__(kCountThreads)
 graph_count_del_kernel(GraphDev g, const int *__restrict__ del_list, const int *__restrict__ del_count,
                        const long long *__restrict__ win_start, const int *__restrict__ win_region,
                        const long long *__restrict__ region_stop, int W, const int *__restrict__ first_site,
-                       long long *__restrict__ n_walks, long long *__restrict__ del_walks, int *__restrict__ overflow)
+                       long long *__restrict__ n_walks, long long *__restrict__ del_walks, int *__restrict__ overflow,
+                       LayoutRec *__restrict__ layouts /* [listed][kLayoutCache] */, int *__restrict__ n_layouts)
 {
     const int m = blockIdx.x * kCountThreads + threadIdx.x;
     if (m >= *del_count) return;
@@ -320,19 +338,29 @@ graph_count_del_kernel(GraphDev g, const int *__restrict__ del_list, const int *
     WalkStart ws;
     long long walks = 0;
     bool bad = false;
+    int nl = 0;
     do {                                             // per start: one pass per layout
         int prefix = 0;
         do {
             long long prod = 0;
             const int rc = simulate(g, p, W, i0, ws, prefix, st, nv, 0, 0, prod, region_stop[win_region[w]]);
-            if (rc == WALK_OK) walks += prod;
+            if (rc == WALK_OK) {
+                walks += prod;
+                if (nl < kLayoutCache && walks <= kMaxWalksPerWindow) {
+                    unsigned bits = (unsigned)st.nd << 24;
+                    for (int d = 0; d < st.nd; ++d) bits |= (unsigned)(st.choice[d] & 1u) << d;
+                    layouts[(size_t)m * kLayoutCache + nl] = LayoutRec{(int)walks, bits, ws.site, ws.t};
+                }
+                ++nl;
+            }
             if (rc == WALK_OVERFLOW || walks > kMaxWalksPerWindow) { bad = true; break; }
             prefix = next_walk(st);
         } while (prefix >= 0);
     } while (!bad && next_start(g, p, i0, ws));
-    if (bad) { walks = 0; atomicMax(overflow, 1); }
+    if (bad) { walks = 0; nl = 0; atomicMax(overflow, 1); }
     n_walks[w] = walks;
     del_walks[m] = walks;
+    n_layouts[m] = nl;
 }
 
 // thread per listed deletion window: walk t of the deletion walks belongs to list entry del_entry[t]
@@ -368,6 +396,48 @@ graph_allele_count_kernel(GraphDev g, int *__restrict__ allele_count /* [n_sites
     for (int a = 0; a < 4; ++a) allele_count[(size_t)i * 4 + a] = c[a];
 }
 
+// word `word` of the haplotype set "allele a at site s" (a = 0: none of its alternates)
+__device__ inline unsigned long long allele_word(const GraphDev &g, int s, int a, int word)
+{
+    const unsigned long long *b = g.alt_bits + ((size_t)s * kMaxAlts) * g.hw + word;
+    const int na = g.n_alts[s];
+    if (a > 0) return a <= na ? b[(size_t)(a - 1) * g.hw] : 0ull;
+    unsigned long long any = b[0];
+    if (na > 1) any |= b[(size_t)g.hw];
+    if (na > 2) any |= b[(size_t)2 * g.hw];
+    unsigned long long valid = ~0ull;
+    if (word == g.hw - 1 && (g.n_hap & 63)) valid = (1ull << (g.n_hap & 63)) - 1ull;
+    return ~any & valid;
+}
+
+// thread per (site i, allele pair): haplotypes with allele a at site i and b at site i + 1
+__global__ void __launch_bounds__(256)
+graph_pair_count_kernel(GraphDev g, int *__restrict__ pair_count /* [n_sites][16] */)
+{
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(id >> 4), a = (int)((id >> 2) & 3), b = (int)(id & 3);
+    if (i >= g.n_sites) return;
+    int c = 0;
+    if (i + 1 < g.n_sites && a <= g.n_alts[i] && b <= g.n_alts[i + 1])
+        for (int word = 0; word < g.hw; ++word)
+            c += __popcll(allele_word(g, i, a, word) & allele_word(g, i + 1, b, word));
+    pair_count[id] = c;
+}
+
+// thread per (site i, allele triple): ... and c at site i + 2
+__global__ void __launch_bounds__(256)
+graph_triple_count_kernel(GraphDev g, int *__restrict__ triple_count /* [n_sites][64] */)
+{
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int i = (int)(id >> 6), a = (int)((id >> 4) & 3), b = (int)((id >> 2) & 3), c3 = (int)(id & 3);
+    if (i >= g.n_sites) return;
+    int c = 0;
+    if (i + 2 < g.n_sites && a <= g.n_alts[i] && b <= g.n_alts[i + 1] && c3 <= g.n_alts[i + 2])
+        for (int word = 0; word < g.hw; ++word)
+            c += __popcll(allele_word(g, i, a, word) & allele_word(g, i + 1, b, word) & allele_word(g, i + 2, c3, word));
+    triple_count[id] = c;
+}
+
 // thread per window: walk t of the plan belongs to window walk_window[t]
 __global__ void __launch_bounds__(kCountThreads)
 graph_map_kernel(long long n_windows, const long long *__restrict__ walk_base, int *__restrict__ walk_window)
@@ -380,7 +450,8 @@ graph_map_kernel(long long n_windows, const long long *__restrict__ walk_base, i
 
 // Haplotypes that carry allele a_k at site s_k for every k < n (allele 0 = none of the alternates; a
 // deletion is a site with one alternate: 1 = carries it).  No constraint: all; one: the popcount table;
-// more: AND of the bitsets, eight words per trip so that their loads are in flight together (one word
+// more: the pair / triple tables for
+// neighbouring sites, else the AND of the bitsets, sixteen words per trip so that their loads are in flight together (one word
 // per trip made every such walk a chain of ~hw dependent L2 latencies).
 template <class F>
 __device__ inline long long count_carriers(const GraphDev &g, const int *__restrict__ allele_count, int n, F at)
@@ -392,7 +463,30 @@ __device__ inline long long count_carriers(const GraphDev &g, const int *__restr
         at(0, site, a);
         return allele_count[(size_t)site * 4 + a];
     }
-    constexpr int kWordsPerTrip = 8;
+    if (n == 2) {               // two neighbouring sites: the pair table
+        int s0, a0, s1, a1;
+        at(0, s0, a0);
+        at(1, s1, a1);
+        if (s1 == s0 + 1) return g.pair_count[(size_t)s0 * 16 + a0 * 4 + a1];
+        if (s0 == s1 + 1) return g.pair_count[(size_t)s1 * 16 + a1 * 4 + a0];
+    } else if (n == 3) {        // three consecutive sites (in any order): the triple table
+        int sv[3], av[3];
+        at(0, sv[0], av[0]);
+        at(1, sv[1], av[1]);
+        at(2, sv[2], av[2]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 2 - r; ++k)
+                if (sv[k] > sv[k + 1]) {
+                    const int ts = sv[k], ta = av[k];
+                    sv[k] = sv[k + 1]; av[k] = av[k + 1];
+                    sv[k + 1] = ts; av[k + 1] = ta;
+                }
+        if (sv[1] == sv[0] + 1 && sv[2] == sv[0] + 2)
+            return g.triple_count[(size_t)sv[0] * 64 + av[0] * 16 + av[1] * 4 + av[2]];
+    }
+    constexpr int kWordsPerTrip = 16;
     long long count = 0;
     for (int w0 = 0; w0 < g.hw; w0 += kWordsPerTrip) {
         unsigned long long acc[kWordsPerTrip];
@@ -433,8 +527,8 @@ __device__ inline long long count_carriers(const GraphDev &g, const int *__restr
 // is written fully coalesced (rows 2t and 2t+1 of thread t).  The walk index is a mixed-radix number
 // over the sites of the window, last site fastest (itertools.product order); the allele digits are
 // kept packed two bits each.
-__global__ void __launch_bounds__(kEmitThreads)
-graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ walk_window,
+__device__ __forceinline__ void
+emit_plain_body(const unsigned bid, const GraphDev &g, const int *__restrict__ allele_count, const int *__restrict__ walk_window,
                   const int *__restrict__ win_region, const long long *__restrict__ win_start, int W,
                   long long n_walks, const int *__restrict__ first_site, const long long *__restrict__ walk_base,
                   uint8_t *__restrict__ kmers, long long *__restrict__ start, long long *__restrict__ stop,
@@ -444,7 +538,7 @@ graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *_
     // the block's 2 x 256 k-mer rows are contiguous in the output: they are assembled in LDS with
     // byte writes and leave with 16-byte coalesced stores (row starts are not even dword aligned)
     extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
-    const long long t0 = (long long)blockIdx.x * kEmitThreads;
+    const long long t0 = (long long)bid * kEmitThreads;
     const long long t = t0 + threadIdx.x;
     const bool valid = t < n_walks;
     const long long tt = valid ? t : n_walks - 1;       // idle threads of the last block shadow a real walk
@@ -455,7 +549,7 @@ graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *_
     const int q0 = q;
     uint8_t *fwd = stage + (size_t)(2 * threadIdx.x) * W, *rev = fwd + W;
     // (windows that touch a deletion are written here as if they did not -- harmless bytes -- and
-    // rewritten by graph_emit_del_kernel, which runs next on the same stream)
+    // rewritten by graph_del_scatter_kernel, which runs next on the same stream)
     long long count = 0;
     const long long end_pos = p + W;
     bool any_alt = false;
@@ -553,20 +647,25 @@ struct DelEmit {
 };
 
 
-// Windows that touch a deletion: one thread per walk of those windows (compacted: a kernel over all
-// walks spent its time in waves with one or two such lanes).  The thread runs its window's odometer up to its own rank, replays that walk writing the bases of its
-// two rows (plain byte stores: these walks are few) and counts the haplotypes.  Runs after
-// graph_emit_kernel on the same stream and overwrites what that kernel wrote for these rows.
-__global__ void __launch_bounds__(kEmitThreads)
-graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ del_list,
-                      const int *__restrict__ del_entry, const long long *__restrict__ del_base,
-                      const long long *__restrict__ win_start, const int *__restrict__ win_region,
-                      const long long *__restrict__ region_stop, int W, long long n_del_walks,
-                      const int *__restrict__ first_site, const long long *__restrict__ walk_base,
-                      uint8_t *__restrict__ kmers, long long *__restrict__ start, long long *__restrict__ stop,
-                      long long *__restrict__ freq, uint8_t *__restrict__ is_ref)
+// Windows that touch a deletion or an insertion: one thread per walk of those windows (compacted: a kernel over all
+// walks spent its time in waves with one or two such lanes).  The thread finds its layout (the ones
+// graph_count_del_kernel kept, else the window's odometer up to its own rank), replays that walk assembling its two
+// rows in LDS, and counts the haplotypes.  These are few, long, latency-bound threads (188 000 walks of 3 million in the
+// bench's graph: less than one resident set of workgroups), so their kernel runs on a side stream BESIDE the kernel of
+// the plain walks and writes to a staging area; graph_del_scatter_kernel then puts the rows in place (the plain kernel
+// has written placeholder bytes there).  Run one after the other on one stream the two kernels took 180 us each; as
+// two bodies of ONE kernel (first workgroups: deletion walks) 436 us -- the plain body then runs with the registers
+// and scratch of the deletion body.
+__device__ __forceinline__ void
+emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ allele_count, const int *__restrict__ del_list,
+              const int *__restrict__ del_entry, const long long *__restrict__ del_base,
+              const long long *__restrict__ win_start, const int *__restrict__ win_region,
+              const long long *__restrict__ region_stop, int W, long long n_del_walks,
+              const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+              const uint8_t *kmers, const LayoutRec *__restrict__ layouts, const int *__restrict__ n_layouts,
+              uint8_t *__restrict__ stg_kmers, long long *__restrict__ stg_meta, int pitch)
 {
-    const long long td = (long long)blockIdx.x * kEmitThreads + threadIdx.x;
+    const long long td = (long long)bid * kEmitThreads + threadIdx.x;
     if (td >= n_del_walks) return;
     const int m = del_entry[td];
     const int w = del_list[m];
@@ -578,9 +677,26 @@ graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const in
     WalkState st;
     WalkStart ws;
     long long q = q0, prod = 0;
-    {
+    bool found = false;
+    {   // the layouts graph_count_del_kernel kept for this window
+        const int nl = min(n_layouts[m], kLayoutCache);
+        int base = 0;
+        for (int k = 0; k < nl && !found; ++k) {
+            const LayoutRec rec = layouts[(size_t)m * kLayoutCache + k];
+            if (q0 < rec.cum_end) {
+                found = true;
+                q = q0 - base;
+                prod = rec.cum_end - base;
+                st.nd = (int)(rec.choice >> 24);
+                for (int d = 0; d < st.nd; ++d) st.choice[d] = (unsigned char)((rec.choice >> d) & 1u);
+                ws.site = rec.site;
+                ws.t = rec.t;
+            }
+            base = rec.cum_end;
+        }
+    }
+    if (!found) {   // beyond the kept layouts: the odometer from the start
         NoVisitor nv;
-        bool found = false;
         while (!found) {                             // starts in order, inside a start the layouts in order
             int prefix = 0;
             for (;;) {                               // skip the layouts that lie before walk q0
@@ -595,20 +711,82 @@ graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const in
             if (!found && !next_start(g, p, i0, ws)) return;   // cannot happen: q0 < walks of the window
         }
     }
-    uint8_t *fwd = kmers + (size_t)(2 * t) * W;
+    // the walk's two rows (2 W contiguous bytes at 2 t W of the k-mer matrix, no alignment) are assembled in this
+    // thread's LDS slot with the byte phase of that place, and go to the staging slot as dwords
+    extern __shared__ __attribute__((aligned(16))) uint8_t del_stage[];
+    const int phase = (int)(reinterpret_cast<uintptr_t>(kmers + (size_t)(2 * t) * W) & 3u);
+    uint8_t *slot = del_stage + (size_t)threadIdx.x * pitch;
+    uint8_t *fwd = slot + phase;
     DelEmit em{g, fwd, fwd + W, W, 0, {}, {}, false};
     long long again = 0;
     simulate(g, p, W, i0, ws, st.nd, st, em, q, prod, again, limit);
+    {
+        unsigned *out = reinterpret_cast<unsigned *>(stg_kmers + (size_t)td * pitch);
+        for (int o = 0; o < pitch / 4; ++o) out[o] = reinterpret_cast<const unsigned *>(slot)[o];
+    }
     // the window starts on deleted bases: carriers lack them (not for a walk that never leaves the insertion it starts in)
     const int cover = (ws.site >= 0 && st.last == p - 1) ? -1 : cover_deletion(g, p, i0);
     if (cover >= 0) em.add(cover, 0);
     const long long count = count_carriers(g, allele_count, em.n_cons,
                                            [&](int k, int &site, int &a) { site = em.csite[k]; a = em.ccode[k]; });
-    const long long row = 2 * t, end_pos = st.last + 1;
+    long long *meta = stg_meta + (size_t)td * kDelMeta;
+    meta[0] = t;
+    meta[1] = p;
+    meta[2] = st.last + 1;
+    meta[3] = count;
+    meta[4] = em.alt ? 0 : 1;
+}
+
+__global__ void __launch_bounds__(kEmitThreads)
+graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ walk_window,
+                  const int *__restrict__ win_region, const long long *__restrict__ win_start, int W,
+                  long long n_walks, const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+                  uint8_t *__restrict__ kmers, long long *__restrict__ start, long long *__restrict__ stop,
+                  uint8_t *__restrict__ strand, long long *__restrict__ freq, uint8_t *__restrict__ is_ref,
+                  int *__restrict__ region, int *__restrict__ walk)
+{
+    emit_plain_body(blockIdx.x, g, allele_count, walk_window, win_region, win_start, W, n_walks, first_site, walk_base,
+                    kmers, start, stop, strand, freq, is_ref, region, walk);
+}
+
+__global__ void __launch_bounds__(kEmitThreads)
+graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ del_list,
+                      const int *__restrict__ del_entry, const long long *__restrict__ del_base,
+                      const long long *__restrict__ win_start, const int *__restrict__ win_region,
+                      const long long *__restrict__ region_stop, int W, long long n_del_walks,
+                      const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+                      const uint8_t *kmers, const LayoutRec *__restrict__ layouts, const int *__restrict__ n_layouts,
+                      uint8_t *__restrict__ stg_kmers, long long *__restrict__ stg_meta, int pitch)
+{
+    emit_del_body(blockIdx.x, g, allele_count, del_list, del_entry, del_base, win_start, win_region, region_stop, W,
+                  n_del_walks, first_site, walk_base, kmers, layouts, n_layouts, stg_kmers, stg_meta, pitch);
+}
+
+// thread per deletion walk: staging -> rows 2 t, 2 t + 1 (k-mer bytes as dwords where the addresses allow)
+__global__ void __launch_bounds__(kEmitThreads)
+graph_del_scatter_kernel(long long n_del_walks, int W, int pitch, const uint8_t *__restrict__ stg_kmers,
+                         const long long *__restrict__ stg_meta, uint8_t *__restrict__ kmers,
+                         long long *__restrict__ start, long long *__restrict__ stop, long long *__restrict__ freq,
+                         uint8_t *__restrict__ is_ref)
+{
+    const long long td = (long long)blockIdx.x * kEmitThreads + threadIdx.x;
+    if (td >= n_del_walks) return;
+    const long long *meta = stg_meta + (size_t)td * kDelMeta;
+    const long long t = meta[0], p = meta[1], end_pos = meta[2], count = meta[3];
+    const uint8_t flag = (uint8_t)meta[4];
+    uint8_t *dst = kmers + (size_t)(2 * t) * W;
+    const int phase = (int)(reinterpret_cast<uintptr_t>(dst) & 3u);
+    const uint8_t *src = stg_kmers + (size_t)td * pitch + phase;
+    const int nbytes = 2 * W;
+    int o = 0;
+    for (; o < nbytes && ((phase + o) & 3); ++o) dst[o] = src[o];
+    for (; o + 4 <= nbytes; o += 4) *reinterpret_cast<unsigned *>(dst + o) = *reinterpret_cast<const unsigned *>(src + o);
+    for (; o < nbytes; ++o) dst[o] = src[o];
+    const long long row = 2 * t;
     start[row] = p;          start[row + 1] = end_pos;
     stop[row] = end_pos;     stop[row + 1] = p;
     freq[row] = count;       freq[row + 1] = count;
-    is_ref[row] = is_ref[row + 1] = em.alt ? 0 : 1;
+    is_ref[row] = is_ref[row + 1] = flag;
 }
 
 template <typename T> hipError_t upload(T **dst, const T *src, size_t count)
@@ -647,6 +825,7 @@ struct gfm_graph {
     uint8_t *d_n_alts = nullptr, *d_alt_bases = nullptr;
     unsigned long long *d_alt_bits = nullptr;
     int *d_allele_count = nullptr;   // [n_sites][4] haplotypes per allele (0 = reference)
+    int *d_pair_count = nullptr, *d_triple_count = nullptr;   // GraphDev::pair_count / triple_count
     int *d_del_len = nullptr, *d_prev_del = nullptr;
     int *d_ins_len = nullptr, *d_ins_off = nullptr;
     uint8_t *d_ins_bases = nullptr;
@@ -658,17 +837,24 @@ struct gfm_graph {
     Buf<unsigned char> scan_tmp;
     Buf<int> del_list, del_entry;
     Buf<long long> del_walks, del_base;
+    Buf<uint8_t> stg_kmers;              // staging of the deletion walks' rows (emit_del_body -> graph_del_scatter_kernel)
+    Buf<long long> stg_meta;
+    Buf<LayoutRec> del_layouts;          // [listed windows][kLayoutCache]
+    Buf<int> del_layout_n;
     long long n_del_walks = 0;
     // plan runs on the NULL stream, emit on the caller's: ordered through these events (a non-blocking
     // caller stream is not ordered against the NULL stream by itself), both ways -- emit waits for the
     // plan's last kernels, the next plan waits for the emit that still reads the plan buffers
     hipEvent_t ev_planned = nullptr, ev_emitted = nullptr;
+    hipStream_t side = nullptr;          // the deletion walks' kernel runs here, beside the plain walks' (gfm_graph_emit)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool emit_pending = false;
     void drop_plan()
     {
         region_off.release(); first_start.release(); region_stop.release(); walk_base.release(); win_start.release(); walks.release();
         first_site.release(); win_region.release(); walk_window.release(); flag.release(); scan_tmp.release();
         del_list.release(); del_entry.release(); del_walks.release(); del_base.release();
+        del_layouts.release(); del_layout_n.release(); stg_kmers.release(); stg_meta.release();
         n_del_walks = 0;
         n_regions = 0;
         n_windows = n_walks = 0;
@@ -751,9 +937,13 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     }
     g->dev = GraphDev{g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
                       bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0,
-                      g->d_del_len, n_dels, g->d_prev_del, g->d_ins_len, g->d_ins_off, g->d_ins_bases, n_ins};
+                      g->d_del_len, n_dels, g->d_prev_del, g->d_ins_len, g->d_ins_off, g->d_ins_bases, n_ins,
+                      nullptr, nullptr};
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_planned, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_emitted, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
     if (e != hipSuccess) {
         gfm_graph_destroy(g);
         return gfail(GFM_ERR_HIP, std::string("event creation failed: ") + hipGetErrorString(e));
@@ -765,11 +955,22 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
                                g->d_allele_count);
             e = hipGetLastError();
         }
+        if (e == hipSuccess) e = hipMalloc(&g->d_pair_count, sizeof(int) * 16 * (size_t)n_sites);
+        if (e == hipSuccess) e = hipMalloc(&g->d_triple_count, sizeof(int) * 64 * (size_t)n_sites);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(graph_pair_count_kernel, dim3((unsigned)(((size_t)n_sites * 16 + 255) / 256)), dim3(256), 0,
+                               nullptr, g->dev, g->d_pair_count);
+            hipLaunchKernelGGL(graph_triple_count_kernel, dim3((unsigned)(((size_t)n_sites * 64 + 255) / 256)), dim3(256), 0,
+                               nullptr, g->dev, g->d_triple_count);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) {
             gfm_graph_destroy(g);
             return gfail(GFM_ERR_HIP, std::string("allele counts failed: ") + hipGetErrorString(e));
         }
+        g->dev.pair_count = g->d_pair_count;
+        g->dev.triple_count = g->d_triple_count;
     }
     *out = g;
     return GFM_OK;
@@ -781,10 +982,14 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     g->drop_plan();
     (void)hipFree(g->d_ref); (void)hipFree(g->d_pos); (void)hipFree(g->d_n_alts);
     (void)hipFree(g->d_alt_bases); (void)hipFree(g->d_alt_bits); (void)hipFree(g->d_allele_count);
+    (void)hipFree(g->d_pair_count); (void)hipFree(g->d_triple_count);
     (void)hipFree(g->d_del_len); (void)hipFree(g->d_prev_del);
     (void)hipFree(g->d_ins_len); (void)hipFree(g->d_ins_off); (void)hipFree(g->d_ins_bases);
     if (g->ev_planned) (void)hipEventDestroy(g->ev_planned);
     if (g->ev_emitted) (void)hipEventDestroy(g->ev_emitted);
+    if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+    if (g->ev_join) (void)hipEventDestroy(g->ev_join);
+    if (g->side) (void)hipStreamDestroy(g->side);
     delete g;
 }
 
@@ -828,28 +1033,34 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     GX_TRY(g->walk_base.reserve(nw + 1));
     const bool dels = g->dev.n_dels > 0 || g->dev.n_ins > 0;   // windows that need the layout enumeration
     GX_TRY(g->del_list.reserve(dels ? nw : 1));
-    GX_TRY(g->del_walks.reserve(dels ? nw : 1));
-    GX_TRY(g->del_base.reserve(dels ? nw + 1 : 1));
     GX_TRY(hipMemcpyAsync(g->region_off.p, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, nullptr));
     GX_TRY(hipMemcpyAsync(g->first_start.p, first.data(), sizeof(long long) * first.size(), hipMemcpyHostToDevice, nullptr));
     GX_TRY(hipMemcpyAsync(g->region_stop.p, rstop.data(), sizeof(long long) * rstop.size(), hipMemcpyHostToDevice, nullptr));
     GX_TRY(hipMemsetAsync(g->flag.p, 0, 2 * sizeof(int), nullptr));
-    if (dels) {
-        GX_TRY(hipMemsetAsync(g->del_walks.p, 0, sizeof(long long) * nw, nullptr));
-        GX_TRY(hipMemsetAsync(g->del_base.p, 0, sizeof(long long), nullptr));
-    }
     GX_TRY(hipMemsetAsync(g->walk_base.p, 0, sizeof(long long), nullptr));
-    // walks per window -> inclusive prefix (row base of every window) on the device: only the total and the
+    // walks per window -> inclusive prefix (row base of every window) on the device: only the totals and the
     // overflow flag come back
     const unsigned blocks = (unsigned)((nw + kCountThreads - 1) / kCountThreads);
     hipLaunchKernelGGL(graph_count_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->dev, n_regions,
                        g->region_off.p, g->first_start.p, g->region_stop.p, width, (long long)nw, g->first_site.p, g->walks.p,
                        g->win_region.p, g->win_start.p, g->flag.p, g->del_list.p, g->flag.p + 1);
     GX_TRY(hipGetLastError());
-    if (dels) {   // the grid covers every window; the kernel reads the real number of listed windows
-        hipLaunchKernelGGL(graph_count_del_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->dev, g->del_list.p,
+    int n_listed = 0;
+    if (dels) {
+        // how many windows need the layout enumeration: sizes their buffers and launches exactly (a grid over ALL
+        // windows whose threads mostly return at once took as long as the counting itself)
+        GX_TRY(hipMemcpy(&n_listed, g->flag.p + 1, sizeof n_listed, hipMemcpyDeviceToHost));
+    }
+    const unsigned lblocks = (unsigned)((n_listed + kCountThreads - 1) / kCountThreads);
+    if (n_listed > 0) {
+        GX_TRY(g->del_walks.reserve((size_t)n_listed));
+        GX_TRY(g->del_base.reserve((size_t)n_listed + 1));
+        GX_TRY(g->del_layouts.reserve((size_t)n_listed * kLayoutCache));
+        GX_TRY(g->del_layout_n.reserve((size_t)n_listed));
+        GX_TRY(hipMemsetAsync(g->del_base.p, 0, sizeof(long long), nullptr));
+        hipLaunchKernelGGL(graph_count_del_kernel, dim3(lblocks), dim3(kCountThreads), 0, nullptr, g->dev, g->del_list.p,
                            g->flag.p + 1, g->win_start.p, g->win_region.p, g->region_stop.p, width, g->first_site.p,
-                           g->walks.p, g->del_walks.p, g->flag.p);
+                           g->walks.p, g->del_walks.p, g->flag.p, g->del_layouts.p, g->del_layout_n.p);
         GX_TRY(hipGetLastError());
     }
     size_t tmp_bytes = 0;
@@ -857,9 +1068,13 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     GX_TRY(g->scan_tmp.reserve(tmp_bytes));
     GX_TRY(hipcub::DeviceScan::InclusiveSum(g->scan_tmp.p, tmp_bytes, g->walks.p, g->walk_base.p + 1, (int)nw, nullptr));
     long long total_del = 0;
-    if (dels) {   // same scan over the listed windows (entries past the list are zero)
-        GX_TRY(hipcub::DeviceScan::InclusiveSum(g->scan_tmp.p, tmp_bytes, g->del_walks.p, g->del_base.p + 1, (int)nw, nullptr));
-        GX_TRY(hipMemcpy(&total_del, g->del_base.p + nw, sizeof total_del, hipMemcpyDeviceToHost));
+    if (n_listed > 0) {   // same scan over the listed windows (the temporary storage of the larger scan is enough)
+        size_t tmp2 = 0;
+        GX_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp2, g->del_walks.p, g->del_base.p + 1, n_listed, nullptr));
+        GX_TRY(g->scan_tmp.reserve(std::max(tmp_bytes, tmp2)));
+        tmp2 = std::max(tmp_bytes, tmp2);
+        GX_TRY(hipcub::DeviceScan::InclusiveSum(g->scan_tmp.p, tmp2, g->del_walks.p, g->del_base.p + 1, n_listed, nullptr));
+        GX_TRY(hipMemcpy(&total_del, g->del_base.p + n_listed, sizeof total_del, hipMemcpyDeviceToHost));
     }
     long long total = 0;
     int overflow = 0;
@@ -875,7 +1090,9 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     }
     if (total_del > 0) {
         GX_TRY(g->del_entry.reserve((size_t)total_del));
-        hipLaunchKernelGGL(graph_del_map_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->flag.p + 1,
+        GX_TRY(g->stg_kmers.reserve((size_t)total_del * (size_t)((2 * width + 6) & ~3)));
+        GX_TRY(g->stg_meta.reserve((size_t)total_del * kDelMeta));
+        hipLaunchKernelGGL(graph_del_map_kernel, dim3(lblocks), dim3(kCountThreads), 0, nullptr, g->flag.p + 1,
                            g->del_base.p, g->del_entry.p);
         GX_TRY(hipGetLastError());
     }
@@ -897,16 +1114,27 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
         return gfail(GFM_ERR_INVALID, "NULL output buffer");
     const unsigned blocks = (unsigned)((g->n_walks + kEmitThreads - 1) / kEmitThreads);
     GX_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), g->ev_planned, 0));
-    hipLaunchKernelGGL(graph_emit_kernel, dim3(blocks), dim3(kEmitThreads), (size_t)2 * kEmitThreads * g->width,
-                       static_cast<hipStream_t>(stream), g->dev, g->d_allele_count, g->walk_window.p,
-                       g->win_region.p, g->win_start.p, g->width, g->n_walks, g->first_site.p, g->walk_base.p, d_kmers, reinterpret_cast<long long *>(d_start),
-                       reinterpret_cast<long long *>(d_stop), d_strand, reinterpret_cast<long long *>(d_freq),
-                       d_is_ref, d_region, d_walk);
-    if (g->n_del_walks > 0) {
-        const unsigned dblocks = (unsigned)((g->n_del_walks + kEmitThreads - 1) / kEmitThreads);
-        hipLaunchKernelGGL(graph_emit_del_kernel, dim3(dblocks), dim3(kEmitThreads), 0, static_cast<hipStream_t>(stream),
+    const unsigned dblocks = (unsigned)((g->n_del_walks + kEmitThreads - 1) / kEmitThreads);
+    const int pitch = (2 * g->width + 6) & ~3;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dblocks) {   // fork: the deletion walks on the side stream, into the staging area
+        GX_TRY(hipEventRecord(g->ev_fork, st));
+        GX_TRY(hipStreamWaitEvent(g->side, g->ev_fork, 0));
+        hipLaunchKernelGGL(graph_emit_del_kernel, dim3(dblocks), dim3(kEmitThreads), (size_t)kEmitThreads * pitch, g->side,
                            g->dev, g->d_allele_count, g->del_list.p, g->del_entry.p, g->del_base.p, g->win_start.p,
-                           g->win_region.p, g->region_stop.p, g->width, g->n_del_walks, g->first_site.p, g->walk_base.p, d_kmers,
+                           g->win_region.p, g->region_stop.p, g->width, g->n_del_walks, g->first_site.p, g->walk_base.p,
+                           d_kmers, g->del_layouts.p, g->del_layout_n.p, g->stg_kmers.p, g->stg_meta.p, pitch);
+        GX_TRY(hipEventRecord(g->ev_join, g->side));
+    }
+    hipLaunchKernelGGL(graph_emit_kernel, dim3(blocks), dim3(kEmitThreads), (size_t)2 * kEmitThreads * g->width, st,
+                       g->dev, g->d_allele_count, g->walk_window.p, g->win_region.p, g->win_start.p, g->width, g->n_walks,
+                       g->first_site.p, g->walk_base.p, d_kmers, reinterpret_cast<long long *>(d_start),
+                       reinterpret_cast<long long *>(d_stop), d_strand, reinterpret_cast<long long *>(d_freq), d_is_ref,
+                       d_region, d_walk);
+    if (dblocks) {   // join: the staged rows over the placeholders
+        GX_TRY(hipStreamWaitEvent(st, g->ev_join, 0));
+        hipLaunchKernelGGL(graph_del_scatter_kernel, dim3(dblocks), dim3(kEmitThreads), 0, st,
+                           g->n_del_walks, g->width, pitch, g->stg_kmers.p, g->stg_meta.p, d_kmers,
                            reinterpret_cast<long long *>(d_start), reinterpret_cast<long long *>(d_stop),
                            reinterpret_cast<long long *>(d_freq), d_is_ref);
     }
