@@ -81,6 +81,10 @@ PROTOTYPES = {
     "gfm_tsv_close": (None, [c_void_p]),
     "gfm_scan_tsv": (c_int, [c_void_p, P(ctypes.c_char_p), c_int, c_int, c_int, c_double, c_int, c_int, c_i64,
                              P(c_void_p), P(c_i64), P(c_i64)]),
+    "gfm_scan_tsv_begin": (c_int, [c_void_p, c_int, P(ctypes.c_char_p), c_int, c_int, c_int, c_double, c_int, c_int,
+                                   c_i64, c_void_p, P(c_void_p), P(c_i64)]),
+    "gfm_scan_tsv_finish": (c_int, [c_void_p, c_void_p]),
+    "gfm_scan_hits_of": (c_int, [c_void_p, c_int] + [c_void_p] * 12),
     "gfm_scan_hits": (c_int, [c_void_p] * 13),
     "gfm_scan_stats": (c_int, [c_void_p, c_void_p]),
     "gfm_scan_table": (c_void_p, [c_void_p]),

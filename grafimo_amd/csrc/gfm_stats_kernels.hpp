@@ -125,6 +125,7 @@ ptable_kernel(const double *__restrict__ pmf, int L, int lo, int hi, double *__r
 //   q_raw_kernel   : C(s) by block-suffix + in-block scan, raw(s) -> qtable (temporary), block minima
 //   q_final_kernel : prefix minimum -> q(s), cutoff, clears
 constexpr int kQThreads = 256;
+constexpr int kQStreams = 8;     // streams per motif handle that may run q-table kernels side by side (one scratch set each)
 struct QWork {
     unsigned long long blk_cnt[256];
     double blk_min[256];

@@ -61,8 +61,19 @@ struct gfm_motif {
     unsigned *d_spill[kWorkspaces] = {};      // [nb] rows outside a partial window
     long long *d_resid[kWorkspaces] = {};     // [max_slabs][kResidPerWG] residual hits
     int *d_resid_n[kWorkspaces] = {};         // [max_slabs]
-    QWork *d_qwork = nullptr;        // q-value kernels' block totals / minima
-    double *d_qscratch = nullptr;    // [L] raw BH values when the caller wants no q-table
+    // q-value kernels' scratch, one set PER STREAM that has called gfm_qvalue_table on this handle (kQStreams of
+    // them): two pipelines on one handle -- two scanners, each with its tail stream -- run their q-table kernels side
+    // by side, and on ONE shared set of block totals each read the other's (a lost-rows count was how it showed).
+    // Calls of one stream are ordered by the stream.
+    QWork *d_qwork = nullptr;        // [kQStreams] block totals / minima
+    double *d_qscratch = nullptr;    // [kQStreams][L] raw BH values when the caller wants no q-table
+    hipStream_t q_stream[kQStreams] = {};
+    int q_streams_used = 0;
+    unsigned long long q_last_use[kQStreams] = {}, q_calls = 0;
+    // the selection workspace (gfm_select_hits*) is one set: users on different streams are ordered by this event
+    hipEvent_t ev_selected = nullptr;
+    hipStream_t sel_last_stream = nullptr;
+    bool sel_valid = false;
     HitCtl *d_ctl = nullptr;
     unsigned call_no = 0;           // score calls: HitCtl slot call_no % kCtlSlots, workspace call_no % kWorkspaces
     // GFM_FLAG_CALLER_ORDERS_REUSE is a promise about the call four back ON THIS HANDLE, which a pipelined caller can
@@ -482,6 +493,7 @@ GFM_API void gfm_motif_destroy(gfm_motif_t m)
     for (auto e : m->ev1) (void)hipEventDestroy(e);
     for (auto e : m->tev0) (void)hipEventDestroy(e);
     for (auto e : m->tev1) (void)hipEventDestroy(e);
+    if (m->ev_selected) (void)hipEventDestroy(m->ev_selected);
     delete m;
 }
 
@@ -580,8 +592,8 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     const size_t o_pmf = carve(sizeof(double) * (size_t)m->L);
     const size_t o_ptable = carve(sizeof(double) * (size_t)m->L);
     const size_t o_dp = carve(dp_scratch_bytes(W));
-    const size_t o_qwork = carve(sizeof(QWork));
-    const size_t o_qscratch = carve(sizeof(double) * (size_t)m->L);
+    const size_t o_qwork = carve(sizeof(QWork) * kQStreams);
+    const size_t o_qscratch = carve(sizeof(double) * (size_t)m->L * kQStreams);
     size_t o_partials[kWorkspaces], o_resid[kWorkspaces], o_resid_n[kWorkspaces], o_spill[kWorkspaces];
     for (int i = 0; i < kWorkspaces; ++i) {
         o_partials[i] = carve(sizeof(unsigned) * (size_t)m->max_slabs * (size_t)(m->part_nb + 1));
@@ -609,6 +621,7 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
         HIP_TRY_M(hipEventCreateWithFlags(&m->ev_scored[i], hipEventDisableTiming | hipEventReleaseToDevice));
         HIP_TRY_M(hipEventCreateWithFlags(&m->ev_posted[i], hipEventDisableTiming | hipEventReleaseToDevice));
     }
+    HIP_TRY_M(hipEventCreateWithFlags(&m->ev_selected, hipEventDisableTiming));
     m->d_sel_resid = reinterpret_cast<long long *>(m->d_slab + o_sel_resid);
     m->d_sel_resid_n = reinterpret_cast<int *>(m->d_slab + o_sel_resid_n);
     m->d_ctl = reinterpret_cast<HitCtl *>(m->d_slab + o_ctl);
@@ -1018,9 +1031,22 @@ int launch_qtables(const gfm_motif_t *motifs, int count, uint64_t *const *d_hist
         QJob &q = jobs.j[k];
         q.hist = reinterpret_cast<const unsigned long long *>(d_hist[k]);
         q.ptable = m->d_ptable;
-        q.ws = m->d_qwork;
+        int qs = 0;                 // this stream's scratch set on this handle
+        while (qs < m->q_streams_used && m->q_stream[qs] != st) ++qs;
+        if (qs == m->q_streams_used) {
+            if (qs < kQStreams) {
+                ++m->q_streams_used;
+            } else {                // every set is taken: the one whose stream called longest ago changes hands
+                qs = 0;
+                for (int c = 1; c < kQStreams; ++c)
+                    if (m->q_last_use[c] < m->q_last_use[qs]) qs = c;
+            }
+            m->q_stream[qs] = st;
+        }
+        m->q_last_use[qs] = ++m->q_calls;
+        q.ws = m->d_qwork + qs;
         // q_raw leaves raw(s) in a table of L doubles: the caller's q-table, or ours when none is asked
-        q.qtable = (d_qtable && d_qtable[k]) ? d_qtable[k] : m->d_qscratch;
+        q.qtable = (d_qtable && d_qtable[k]) ? d_qtable[k] : m->d_qscratch + (size_t)qs * (size_t)m->L;
         q.cutoff = d_cutoff ? d_cutoff[k] : nullptr;
         q.nrows = d_nrows ? reinterpret_cast<unsigned long long *>(d_nrows[k]) : nullptr;
         q.clear = (flags & GFM_FLAG_CLEAR_HIST) ? reinterpret_cast<unsigned long long *>(d_hist[k]) : nullptr;
@@ -1066,6 +1092,25 @@ GFM_API int gfm_qvalue_table_multi(const gfm_motif_t *motifs, int n_motifs, uint
     return GFM_OK;
 }
 
+namespace {
+// The selection workspace of a handle is one set.  A call on another stream than the last one waits for that one's
+// selection (event); inside a stream capture nothing is recorded or waited for (one stream: its order is enough).
+int order_selection(gfm_motif *m, hipStream_t st, bool before)
+{
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) return GFM_OK;
+    if (before) {
+        if (m->sel_valid && m->sel_last_stream != st) HIP_TRY(hipStreamWaitEvent(st, m->ev_selected, 0));
+    } else {
+        HIP_TRY(hipEventRecord(m->ev_selected, st));
+        m->sel_last_stream = st;
+        m->sel_valid = true;
+    }
+    return GFM_OK;
+}
+}  // namespace
+
 GFM_API int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
                             int64_t row_base, int64_t *d_hit_rows, int64_t hit_capacity,
                             uint64_t *d_hit_count, uint32_t flags, void *stream)
@@ -1086,6 +1131,10 @@ GFM_API int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, c
     long long blocks = (n4 + kSelThreads - 1) / kSelThreads;
     blocks = std::max<long long>(1, std::min<long long>(blocks, m->sel_slabs));
     const int slot = (int)(m->sel_call_no++ % (unsigned)kCtlSlots);
+    {
+        const int rc0 = order_selection(m, st, true);
+        if (rc0) return rc0;
+    }
     hipLaunchKernelGGL(select_hits_kernel, dim3((unsigned)blocks), dim3(kSelThreads), 0, st, d_scores,
                        (long long)n, d_cutoff, (long long)row_base,
                        reinterpret_cast<long long *>(d_hit_rows), (long long)hit_capacity,
@@ -1095,9 +1144,10 @@ GFM_API int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, c
                        m->d_sel_ctl, slot, m->d_sel_resid, m->d_sel_resid_n,
                        static_cast<const unsigned long long *>(nullptr), 0ll);
     HIP_TRY(hipGetLastError());
-    return launch_post(m, nullptr, 0, nullptr, 0, 0, nullptr, m->d_sel_resid, m->d_sel_resid_n, (int)blocks,
-                       m->d_sel_ctl, slot, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
-                       reinterpret_cast<unsigned long long *>(d_hit_count), st);
+    const int rc = launch_post(m, nullptr, 0, nullptr, 0, 0, nullptr, m->d_sel_resid, m->d_sel_resid_n, (int)blocks,
+                               m->d_sel_ctl, slot, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
+                               reinterpret_cast<unsigned long long *>(d_hit_count), st);
+    return rc ? rc : order_selection(m, st, false);
 }
 
 GFM_API int gfm_select_hits_from(gfm_motif_t m, const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
@@ -1118,6 +1168,10 @@ GFM_API int gfm_select_hits_from(gfm_motif_t m, const int32_t *d_scores, int64_t
         return fail(GFM_ERR_INVALID, "the candidate list and the hit list must be different buffers");
     if ((reinterpret_cast<uintptr_t>(d_scores) & 15u) != 0)
         return fail(GFM_ERR_INVALID, "d_scores must be 16-byte aligned");
+    {
+        const int rc0 = order_selection(m, st, true);
+        if (rc0) return rc0;
+    }
     // 1. the candidates that reach the cutoff -> hit list (restarted)
     {
         const long long blocks = std::max<long long>(1, (cand_capacity + kFilterPerBlock - 1) / kFilterPerBlock);
@@ -1140,9 +1194,10 @@ GFM_API int gfm_select_hits_from(gfm_motif_t m, const int32_t *d_scores, int64_t
                        m->d_sel_ctl, slot, m->d_sel_resid, m->d_sel_resid_n,
                        reinterpret_cast<const unsigned long long *>(d_cand_count), (long long)cand_capacity);
     HIP_TRY(hipGetLastError());
-    return launch_post(m, nullptr, 0, nullptr, 0, 0, nullptr, m->d_sel_resid, m->d_sel_resid_n, (int)blocks,
-                       m->d_sel_ctl, slot, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
-                       reinterpret_cast<unsigned long long *>(d_hit_count), st);
+    const int rc = launch_post(m, nullptr, 0, nullptr, 0, 0, nullptr, m->d_sel_resid, m->d_sel_resid_n, (int)blocks,
+                               m->d_sel_ctl, slot, reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
+                               reinterpret_cast<unsigned long long *>(d_hit_count), st);
+    return rc ? rc : order_selection(m, st, false);
 }
 
 GFM_API int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, double threshold,

@@ -1,11 +1,18 @@
 // scan_stream.cpp -- compute_results' numeric core as ONE streamed pass (score_sequences.py:113-157,194-205):
 //   TSV parse threads -> pinned chunk buffers -> hipMemcpyAsync on a copy stream -> score kernel per chunk
-//   (one histogram, one hit list, row ids global) -> q-value table + selection once at the end -> the hits,
-//   with the columns of their rows, back to the host.
+//   (one histogram and one hit list per motif, row ids global) -> q-value table + selection once at the end -> the
+//   hits, with the columns of their rows, back to the host.
 // The reference forks `cores` workers that parse and score line by line and then merges pickled lists; here
 // the parse threads run ahead of the GPU and nothing but the hits ever comes back.  Buffers (pinned chunk
-// slots, device slots, score blocks, tables, hit list) live in a per-device pool that only grows: a second
-// call of the same size allocates nothing.
+// slots, device slots, score blocks, tables, hit lists, the host columns of the rows) live in a per-device pool that
+// only grows: a second call of the same size allocates nothing -- and touches no fresh page: at 2e7 rows the page
+// faults of freshly allocated per-file columns (1.4 GB, 96 threads in one address space) were most of the scan.
+//
+// Two phases, so that a sharded scan can put its collective between them (distributed.py): gfm_scan_tsv_begin
+// returns when the last chunk is scored, with every motif's histogram complete on the device; the caller may
+// all-reduce the histograms (its own buffers, if it passed some); gfm_scan_tsv_finish derives q-tables and cutoffs
+// from them, selects and brings the hits back.  gfm_scan_tsv is the two in one call.  Several motifs of ONE width
+// share the pass: each chunk is scored by gfm_score_kmers_multi (one read of the k-mers per group of up to three).
 //
 // Reference lines cited as file:line are relative to /root/reference/src/grafimo/.
 
@@ -19,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -60,18 +68,35 @@ double now_s()
 constexpr int kSlots = 3;                          // chunk slots: one being staged, one in flight, one spare
 constexpr int64_t kDefaultChunkRows = 1 << 20;     // rows per chunk (x W bytes pinned + device, per slot)
 
-// Per-device buffers of the streamed scan; they only grow.
-struct ScanPool {
-    int device = -1;
-    hipStream_t copy = nullptr, score = nullptr;
-    hipEvent_t copied[kSlots] = {}, scored[kSlots] = {};
-    hipEvent_t c0[kSlots] = {}, c1[kSlots] = {};   // H2D timing
-    uint8_t *h_pin[kSlots] = {};
-    uint8_t *d_kmers[kSlots] = {};
-    size_t slot_bytes = 0;
-    int64_t block_rows = 0;                 // rows per score block (== chunk rows they were made for)
-    std::vector<int32_t *> score_blocks;    // one per chunk index
-    uint64_t *d_hist = nullptr;
+// host columns of the rows of one chunk (what the hits are annotated from); one allocation, kept in the pool
+struct MetaChunk {
+    void *block = nullptr;
+    uint8_t *kmers = nullptr;
+    int64_t *start = nullptr, *stop = nullptr, *freq = nullptr;
+    uint8_t *strand = nullptr, *is_ref = nullptr;
+    int32_t *local_name = nullptr;
+    bool alloc(int64_t rows, int W)
+    {
+        const size_t r = (size_t)rows;
+        const size_t bytes = r * (3 * sizeof(int64_t) + sizeof(int32_t) + 2 + (size_t)W) + 64;
+        block = std::malloc(bytes);
+        if (!block) return false;
+        uint8_t *p = static_cast<uint8_t *>(block);
+        start = reinterpret_cast<int64_t *>(p); p += r * sizeof(int64_t);
+        stop = reinterpret_cast<int64_t *>(p); p += r * sizeof(int64_t);
+        freq = reinterpret_cast<int64_t *>(p); p += r * sizeof(int64_t);
+        local_name = reinterpret_cast<int32_t *>(p); p += r * sizeof(int32_t);
+        strand = p; p += r;
+        is_ref = p; p += r;
+        kmers = p;
+        return true;
+    }
+    void release() { std::free(block); *this = MetaChunk(); }
+};
+
+// per-motif device buffers of a scan
+struct MotifBufs {
+    uint64_t *d_hist = nullptr;         // the library's own histogram (a caller may pass its own instead)
     double *d_q = nullptr;
     size_t table_len = 0;
     int32_t *d_cutoff = nullptr;
@@ -80,39 +105,14 @@ struct ScanPool {
     uint64_t *d_cand_count = nullptr;   // q-value threshold: the p < t candidates collected while scoring
     int64_t *d_cand = nullptr;          // (same capacity as d_hits)
     int64_t hit_cap = 0;
-    bool in_use = false;
+    int64_t block_rows = 0;             // rows per score block (== chunk rows they were made for)
+    std::vector<int32_t *> score_blocks;   // one per chunk index
 
-    int init(int dev)
+    int init()
     {
-        device = dev;
-        S_TRY(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
-        S_TRY(hipStreamCreateWithFlags(&score, hipStreamNonBlocking));
-        for (int s = 0; s < kSlots; ++s) {
-            S_TRY(hipEventCreateWithFlags(&copied[s], hipEventDisableTiming));
-            S_TRY(hipEventCreateWithFlags(&scored[s], hipEventDisableTiming));
-            S_TRY(hipEventCreate(&c0[s]));
-            S_TRY(hipEventCreate(&c1[s]));
-        }
         S_TRY(hipMalloc(&d_cutoff, sizeof(int32_t)));
         S_TRY(hipMalloc(&d_count, sizeof(uint64_t)));
         S_TRY(hipMalloc(&d_cand_count, sizeof(uint64_t)));
-        return GFM_OK;
-    }
-    int reserve_slots(size_t bytes)
-    {
-        if (bytes <= slot_bytes) return GFM_OK;
-        for (int s = 0; s < kSlots; ++s) {
-            if (h_pin[s]) (void)hipHostFree(h_pin[s]);
-            if (d_kmers[s]) (void)hipFree(d_kmers[s]);
-            h_pin[s] = nullptr;
-            d_kmers[s] = nullptr;
-        }
-        slot_bytes = 0;
-        for (int s = 0; s < kSlots; ++s) {
-            S_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_pin[s]), bytes, hipHostMallocDefault));
-            S_TRY(hipMalloc(&d_kmers[s], bytes));
-        }
-        slot_bytes = bytes;
         return GFM_OK;
     }
     int reserve_tables(size_t len)
@@ -157,6 +157,88 @@ struct ScanPool {
     }
     void release()
     {
+        for (auto *p : score_blocks) (void)hipFree(p);
+        if (d_hist) (void)hipFree(d_hist);
+        if (d_q) (void)hipFree(d_q);
+        if (d_cutoff) (void)hipFree(d_cutoff);
+        if (d_count) (void)hipFree(d_count);
+        if (d_hits) (void)hipFree(d_hits);
+        if (d_cand_count) (void)hipFree(d_cand_count);
+        if (d_cand) (void)hipFree(d_cand);
+        *this = MotifBufs();
+    }
+};
+
+// Per-device buffers of the streamed scan; they only grow.
+struct ScanPool {
+    int device = -1;
+    hipStream_t copy = nullptr, score = nullptr;
+    hipEvent_t copied[kSlots] = {}, scored[kSlots] = {};
+    hipEvent_t c0[kSlots] = {}, c1[kSlots] = {};   // H2D timing
+    uint8_t *h_pin[kSlots] = {};
+    uint8_t *d_kmers[kSlots] = {};
+    size_t slot_bytes = 0;
+    std::vector<MotifBufs> mb;              // one per motif of the scan
+    std::vector<MetaChunk> meta;            // one per chunk index
+    int64_t meta_rows = 0;                  // rows (and width) the column blocks were made for
+    int meta_W = 0;
+    bool in_use = false;
+
+    int init(int dev)
+    {
+        device = dev;
+        S_TRY(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+        S_TRY(hipStreamCreateWithFlags(&score, hipStreamNonBlocking));
+        for (int s = 0; s < kSlots; ++s) {
+            S_TRY(hipEventCreateWithFlags(&copied[s], hipEventDisableTiming));
+            S_TRY(hipEventCreateWithFlags(&scored[s], hipEventDisableTiming));
+            S_TRY(hipEventCreate(&c0[s]));
+            S_TRY(hipEventCreate(&c1[s]));
+        }
+        return GFM_OK;
+    }
+    int reserve_motifs(size_t n)
+    {
+        while (mb.size() < n) {
+            mb.emplace_back();
+            S_RC(mb.back().init());
+        }
+        return GFM_OK;
+    }
+    int reserve_slots(size_t bytes)
+    {
+        if (bytes <= slot_bytes) return GFM_OK;
+        for (int s = 0; s < kSlots; ++s) {
+            if (h_pin[s]) (void)hipHostFree(h_pin[s]);
+            if (d_kmers[s]) (void)hipFree(d_kmers[s]);
+            h_pin[s] = nullptr;
+            d_kmers[s] = nullptr;
+        }
+        slot_bytes = 0;
+        for (int s = 0; s < kSlots; ++s) {
+            S_TRY(hipHostMalloc(reinterpret_cast<void **>(&h_pin[s]), bytes, hipHostMallocDefault));
+            S_TRY(hipMalloc(&d_kmers[s], bytes));
+        }
+        slot_bytes = bytes;
+        return GFM_OK;
+    }
+    // column block of chunk k (called by the parse threads under the scan's mutex)
+    MetaChunk *meta_chunk(size_t k, int64_t rows, int W)
+    {
+        if (rows > meta_rows || W > meta_W) {
+            for (auto &m : meta) m.release();
+            meta.clear();
+            meta_rows = std::max(rows, meta_rows);
+            meta_W = std::max(W, meta_W);
+        }
+        while (meta.size() <= k) {
+            meta.emplace_back();
+            if (!meta.back().alloc(meta_rows, meta_W)) { meta.pop_back(); return nullptr; }
+        }
+        return &meta[k];
+    }
+    void release()
+    {
         for (int s = 0; s < kSlots; ++s) {
             if (h_pin[s]) (void)hipHostFree(h_pin[s]);
             if (d_kmers[s]) (void)hipFree(d_kmers[s]);
@@ -167,15 +249,10 @@ struct ScanPool {
             h_pin[s] = d_kmers[s] = nullptr;
             copied[s] = scored[s] = c0[s] = c1[s] = nullptr;
         }
-        for (auto *p : score_blocks) (void)hipFree(p);
-        score_blocks.clear();
-        if (d_hist) (void)hipFree(d_hist);
-        if (d_q) (void)hipFree(d_q);
-        if (d_cutoff) (void)hipFree(d_cutoff);
-        if (d_count) (void)hipFree(d_count);
-        if (d_hits) (void)hipFree(d_hits);
-        if (d_cand_count) (void)hipFree(d_cand_count);
-        if (d_cand) (void)hipFree(d_cand);
+        for (auto &m : mb) m.release();
+        mb.clear();
+        for (auto &m : meta) m.release();
+        meta.clear();
         if (copy) (void)hipStreamDestroy(copy);
         if (score) (void)hipStreamDestroy(score);
         *this = ScanPool();
@@ -212,40 +289,60 @@ int acquire_pool(ScanPool **out)
     return GFM_OK;
 }
 
-struct PoolLease {
-    ScanPool *p = nullptr;
-    ~PoolLease()
-    {
-        if (!p) return;
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        p->in_use = false;
-    }
+void release_pool(ScanPool *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    p->in_use = false;
+}
+
+struct MotifHits {
+    std::vector<int64_t> rows;        // hit rows, ascending (global row ids in sorted-file order)
+    std::vector<int32_t> scaled;
+    std::vector<double> logodds, pvalue, qvalue;
 };
 
 }  // namespace
 
 struct gfm_scan {
-    gfm_tsv table;                    // the parsed columns of every file (hits are looked up here)
-    int W = 0;
+    gfm_tsv table;                    // per file: row count and REGION names (the rows' columns live in the pool)
+    int W = 0, L = 0;
     bool have_q = false;
-    std::vector<int64_t> rows;        // hit rows, ascending (global row ids in sorted-file order)
-    std::vector<int32_t> scaled;
-    std::vector<double> logodds, pvalue, qvalue;
+    std::vector<MotifHits> hits;      // one per motif
     gfm_scan_stats_t stats{};
+    // ---- what gfm_scan_tsv_finish needs from gfm_scan_tsv_begin
+    std::vector<gfm_motif_t> motifs;
+    std::vector<uint64_t *> d_hist;   // per motif: the caller's buffer or the pool's
+    std::vector<int32_t> cutoffs;     // p-value cutoffs (known before scoring)
+    ScanPool *pool = nullptr;         // leased from begin to close
+    double threshold = 0.0;
+    bool on_qvalue = false, want_qvalues = false, finished = false;
+    int64_t chunk_rows = 0, total_rows = 0;
+    size_t n_chunks = 0;
+    std::vector<int64_t> chunk_n;     // rows of every submitted chunk
+    double t_begin = 0.0, t_parsed = 0.0, begin_s = 0.0;
+    ~gfm_scan() { release_pool(pool); }
 };
 
-GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, int skip_reverse, int n_threads,
-                         double threshold, int on_qvalue, int want_qvalues, int64_t chunk_rows, gfm_scan_t *out,
-                         int64_t *n_rows, int64_t *n_hits)
+GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const char *const *paths, int n_paths,
+                               int skip_reverse, int n_threads, double threshold, int on_qvalue, int want_qvalues,
+                               int64_t chunk_rows, uint64_t *const *d_hist_ext, gfm_scan_t *out, int64_t *n_rows)
 {
-    if (!m || !out || !n_rows || !n_hits || (n_paths > 0 && !paths)) return sfail(GFM_ERR_INVALID, "NULL argument");
+    if (!motifs || n_motifs < 1 || !out || !n_rows || (n_paths > 0 && !paths)) return sfail(GFM_ERR_INVALID, "NULL argument");
     *out = nullptr;
-    *n_rows = *n_hits = 0;
+    *n_rows = 0;
     if (n_paths < 0) return sfail(GFM_ERR_INVALID, "negative path count");
     if (!(threshold > 0 && threshold <= 1)) return sfail(GFM_ERR_INVALID, "threshold must be in (0, 1]");
     if (on_qvalue && !want_qvalues) return sfail(GFM_ERR_INVALID, "q-value threshold without q-values");
-    const int W = gfm_motif_width(m);
-    const int L = gfm_motif_table_len(m);
+    for (int j = 0; j < n_motifs; ++j) {
+        if (!motifs[j]) return sfail(GFM_ERR_INVALID, "motif is NULL");
+        if (gfm_motif_width(motifs[j]) != gfm_motif_width(motifs[0]))
+            return sfail(GFM_ERR_INVALID, "the motifs of one scan must share their width");
+        if (d_hist_ext && want_qvalues && !d_hist_ext[j]) return sfail(GFM_ERR_INVALID, "a histogram buffer is NULL");
+    }
+    const int W = gfm_motif_width(motifs[0]);
+    const int L = gfm_motif_table_len(motifs[0]);
+    const size_t M = (size_t)n_motifs;
     if (chunk_rows <= 0) chunk_rows = kDefaultChunkRows;
     chunk_rows = (chunk_rows + 255) & ~(int64_t)255;   // whole 256-row score chunks, 16-byte aligned slices
 
@@ -256,10 +353,18 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
         ~Guard() { delete p; }
     } guard{sc};
     sc->W = W;
+    sc->L = L;
     sc->have_q = want_qvalues != 0;
+    sc->want_qvalues = want_qvalues != 0;
+    sc->on_qvalue = on_qvalue != 0;
+    sc->threshold = threshold;
+    sc->chunk_rows = chunk_rows;
+    sc->motifs.assign(motifs, motifs + n_motifs);
+    sc->hits.resize(M);
     sc->table.W = W;
     sc->table.files.resize((size_t)n_paths);
     const double t_begin = now_s();
+    sc->t_begin = t_begin;
     const bool trace = std::getenv("GRAFIMO_SCAN_TRACE") != nullptr;   // development aid: phase times to stderr
     auto stamp = [&](const char *what) {
         if (trace) std::fprintf(stderr, "[scan] %8.3f ms  %s\n", (now_s() - t_begin) * 1e3, what);
@@ -268,100 +373,205 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
     // ---- device side
     ScanPool *P = nullptr;
     S_RC(acquire_pool(&P));
-    PoolLease lease{P};
+    sc->pool = P;                        // released by ~gfm_scan
     stamp("pool acquired");
     S_RC(P->reserve_slots((size_t)chunk_rows * (size_t)W + 16));
-    S_RC(P->reserve_tables((size_t)L));
-    S_RC(P->reserve_hits(std::max<int64_t>(P->hit_cap, 1 << 20)));
-    // p-value threshold: the cutoff is known before scoring and the score kernel selects the hits.  q-value
-    // threshold: q >= p, so the score kernel collects the p < t CANDIDATES the same way, and the selection behind
-    // the q-table filters those instead of reading every score again (gfm_select_hits_from).
+    S_RC(P->reserve_motifs(M));
+    sc->d_hist.assign(M, nullptr);
+    sc->cutoffs.assign(M, GFM_NO_SELECT);
+    for (size_t j = 0; j < M; ++j) {
+        MotifBufs &b = P->mb[j];
+        if (want_qvalues) S_RC(b.reserve_tables((size_t)L));
+        S_RC(b.reserve_hits(std::max<int64_t>(b.hit_cap, 1 << 20)));
+        sc->d_hist[j] = want_qvalues ? (d_hist_ext ? d_hist_ext[j] : b.d_hist) : nullptr;
+        // p-value threshold: the cutoff is known before scoring and the score kernel selects the hits.  q-value
+        // threshold: q >= p, so the score kernel collects the p < t CANDIDATES the same way, and the selection behind
+        // the q-table filters those instead of reading every score again (gfm_select_hits_from).
+        S_RC(gfm_motif_pvalue_cutoff(motifs[j], threshold, &sc->cutoffs[j]));
+    }
     const bool fused = !on_qvalue;
-    int32_t cutoff = GFM_NO_SELECT;
     stamp("pool sized");
-    S_RC(gfm_motif_pvalue_cutoff(m, threshold, &cutoff));
-    int64_t *d_sel = fused ? P->d_hits : P->d_cand;             // the list the score kernel appends to
-    uint64_t *d_sel_count = fused ? P->d_count : P->d_cand_count;
 
-    // ---- host pipeline.  Worker threads parse the files (taken in path order) AND stage them: as soon as
-    // the row counts of all earlier files are known a file's global row offset is fixed, and whichever worker
-    // comes by next copies its k-mers into the pinned slot of the chunk(s) they fall into.  (One thread doing
-    // all staging copies -- 38 MB out of other cores' caches for 2e6 rows -- took longer than 256 threads
-    // needed to parse.)  The calling thread only sequences chunks: chunk k goes to the device once every row
-    // of it has been staged; its slot is handed back to the workers when the score kernel has read it.
+    // ---- host pipeline.  The files are taken in path order.  A worker READS a file into one of its few buffers and
+    // COUNTS its rows at once (a newline scan over bytes that are hot): that fixes the file's global row offset as soon
+    // as every earlier file is counted.  The same worker then PARSES the file from the same bytes, writing each row
+    // where it belongs -- the k-mer into the pinned slot of its chunk, the other columns (and the k-mer again: hits are
+    // annotated from it) into the chunk's column block.  One read() per file (the kernel's copy out of the page cache
+    // is the floor of the whole scan: ~40 GB/s on this host, whatever the thread count), no per-file vectors, no
+    // staging copy, no allocation once the pool has its size.  (Round 2 parsed into per-file columns and copied the
+    // k-mers into the slots afterwards: at 2e7 rows the page faults of 1.4 GB of fresh vectors made it 250 ms; a
+    // count pass and a parse pass that each read the file took 110-200 ms.)  The calling thread only sequences
+    // chunks: chunk k goes to the device once every row of it is in place; its slot is handed back to the workers
+    // when the score kernel has read it.
     const int nt = gfm_tsv_detail::pick_threads(paths, n_paths, n_threads);
-    std::mutex mu;
+    constexpr int kRing = 4;                 // files a worker may hold read-and-counted, waiting for their offsets
+    // Coordination is lock-light on purpose: with one mutex taken ~5 times per file, 96 workers on 10 000 files spent
+    // more time handing the mutex around than parsing (300 ms at 96 threads against 110 ms at 32).  Files are claimed
+    // with an atomic counter; row counts are published through per-file flags and the offsets advanced by whichever
+    // worker gets a try-lock; rows in place are atomic adds per chunk, and only the add that completes a chunk (20 of
+    // them at 2e7 rows) wakes the calling thread.
+    constexpr size_t kMaxChunks = 1 << 16;   // chunk counters (6.9e10 rows at the default chunk size)
+    std::mutex mu;                           // guards the two condition variables and the failure message only
     std::condition_variable cv_work, cv_main;
-    int next_parse = 0;                      // next file to parse
-    int next_assign = 0;                     // files [0, next_assign) have their row offset
-    int next_stage = 0;                      // next file to stage (offsets are assigned in order, so a counter)
-    int staged_files = 0;
-    int64_t assigned_rows = 0;
-    std::vector<char> counted((size_t)n_paths, 0);
+    std::atomic<int> next_count{0};          // next file to read + count
+    std::atomic<int> next_assign{0};         // files [0, next_assign) have their row offset
+    std::mutex assign_mu;                    // try-lock: one worker at a time advances next_assign
+    int64_t assigned_rows = 0;               // under assign_mu; final once next_assign == n_paths
+    std::atomic<int64_t> total_assigned{-1}; // == assigned_rows once every file is counted
+    std::unique_ptr<std::atomic<char>[]> counted(new std::atomic<char>[(size_t)n_paths + 1]);
+    for (int i = 0; i <= n_paths; ++i) counted[(size_t)i].store(0, std::memory_order_relaxed);
     std::vector<int64_t> file_off((size_t)n_paths, 0);
-    std::vector<int64_t> chunk_staged;       // rows staged so far per chunk
-    int64_t released = 0;                    // chunks whose slot may be written again: chunk k needs k < released + kSlots
-    bool failed = false;
+    std::unique_ptr<std::atomic<int64_t>[]> chunk_staged(new std::atomic<int64_t>[kMaxChunks]);
+    for (size_t k = 0; k < kMaxChunks; ++k) chunk_staged[k].store(0, std::memory_order_relaxed);
+    std::atomic<int64_t> released{0};        // chunks whose slot may be written again: chunk k needs k < released + kSlots
+    std::atomic<bool> failed{false};
     std::string fail_msg;
-    double t_parse_end = t_begin;
+    std::atomic<int64_t> parse_end_ns{0};    // steady-clock time of the last finished parse
+    auto fail_with = [&](const std::string &msg) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (!failed.load()) fail_msg = msg;
+            failed.store(true);
+        }
+        cv_work.notify_all();
+        cv_main.notify_all();
+    };
+    auto wake_main = [&]() {
+        { std::lock_guard<std::mutex> g(mu); }
+        cv_main.notify_one();
+    };
+    auto advance_offsets = [&]() {           // any worker, after publishing a count
+        if (!assign_mu.try_lock()) return;   // (whoever holds it sees the flag set before this call, or the next caller does)
+        int na = next_assign.load(std::memory_order_relaxed);
+        bool moved = false;
+        while (na < n_paths && counted[(size_t)na].load(std::memory_order_acquire)) {
+            file_off[(size_t)na] = assigned_rows;
+            assigned_rows += sc->table.files[(size_t)na].n_rows;
+            ++na;
+            moved = true;
+        }
+        if (moved) {
+            if (na == n_paths) total_assigned.store(assigned_rows, std::memory_order_release);
+            next_assign.store(na, std::memory_order_release);
+        }
+        assign_mu.unlock();
+        if (moved && na == n_paths) wake_main();     // the last chunk may be a short one
+    };
     auto work = [&]() {
-        std::unique_lock<std::mutex> lk(mu);
+        // this worker's files between their count and their parse, oldest first (the crew's threads live as long as
+        // the process: so do their buffers)
+        static thread_local gfm_tsv_detail::FileBuf ring[kRing];
+        int held[kRing], n_held = 0, head = 0;         // file index per ring slot, in order from `head`
+        int64_t cached_k = -1;                         // the chunk this worker wrote into last, and its column block
+        MetaChunk cached_mc;
+        struct DropAll {
+            gfm_tsv_detail::FileBuf *r;
+            ~DropAll() { for (int k = 0; k < kRing; ++k) r[k].drop(); }
+        } drop_all{ring};
         for (;;) {
-            if (failed) return;
-            if (next_stage < next_assign) {                     // stage a file whose offset is known
-                const int i = next_stage++;
-                const FileCols &f = sc->table.files[(size_t)i];
-                const int64_t rows = (int64_t)f.start.size();
-                int64_t at = 0;
-                while (at < rows) {
-                    const int64_t g = file_off[(size_t)i] + at;
-                    const int64_t k = g / chunk_rows, in = g % chunk_rows;
-                    const int64_t take = std::min(rows - at, chunk_rows - in);
-                    cv_work.wait(lk, [&] { return failed || k < released + kSlots; });
-                    if (failed) return;
-                    lk.unlock();
-                    std::memcpy(P->h_pin[k % kSlots] + (size_t)in * (size_t)W, f.kmers.data() + (size_t)at * (size_t)W,
-                                (size_t)take * (size_t)W);
-                    lk.lock();
-                    if ((int64_t)chunk_staged.size() <= k) chunk_staged.resize((size_t)k + 1, 0);
-                    chunk_staged[(size_t)k] += take;
-                    at += take;
-                    cv_main.notify_one();
-                }
-                ++staged_files;
-                cv_main.notify_one();
-                continue;
-            }
-            if (next_parse < n_paths) {                          // parse the next file
-                const int i = next_parse++;
+            if (failed.load(std::memory_order_relaxed)) return;
+            if (n_held > 0 && held[head] < next_assign.load(std::memory_order_acquire)) {
+                // my oldest file has its offset: parse it in place
+                const int i = held[head];
+                gfm_tsv_detail::FileBuf &text = ring[head];
                 FileCols &f = sc->table.files[(size_t)i];
-                lk.unlock();
-                try {
-                    gfm_tsv_detail::parse_file(paths[i], W, skip_reverse != 0, f);
-                } catch (const std::bad_alloc &) {
-                    f.error = "out of memory";
+                const int64_t rows = f.n_rows, off = file_off[(size_t)i];
+                std::string err;
+                int64_t done = 0;
+                if (rows > 0) {
+                    gfm_tsv_detail::NameTable names(f.names);
+                    int64_t k = -1, in = 0, left = 0;      // chunk, row inside it, rows until the chunk ends
+                    uint8_t *pin = nullptr;
+                    MetaChunk mc;                          // by value: the pool's vector of blocks may grow meanwhile
+                    int64_t placed = 0;                    // rows written into chunk k and not yet accounted
+                    auto account = [&]() {
+                        if (placed == 0) return;
+                        const int64_t now = chunk_staged[(size_t)k].fetch_add(placed, std::memory_order_acq_rel) + placed;
+                        placed = 0;
+                        // the add that completes a chunk wakes the calling thread (a short last chunk: whoever makes
+                        // it reach the total, or advance_offsets when the total becomes known)
+                        const int64_t tot = total_assigned.load(std::memory_order_acquire);
+                        if (now == chunk_rows || (tot >= 0 && now == tot - k * chunk_rows)) wake_main();
+                    };
+                    bool gave_up = false;
+                    auto sink = [&](const uint8_t *kmer, int64_t st, int64_t sp, int64_t fr, uint8_t strand,
+                                    uint8_t is_ref, int32_t nid) {
+                        if (gave_up || done >= rows) { ++done; return; }   // more rows than counted: reported below
+                        if (left == 0) {
+                            account();
+                            const int64_t g = off + done;
+                            k = g / chunk_rows;
+                            in = g % chunk_rows;
+                            left = chunk_rows - in;
+                            if ((size_t)k >= kMaxChunks) { gave_up = true; err = "too many rows for one scan"; return; }
+                            if (k >= released.load(std::memory_order_acquire) + kSlots) {   // rare: far ahead of the GPU
+                                std::unique_lock<std::mutex> g2(mu);
+                                cv_work.wait(g2, [&] { return failed.load() || k < released.load() + kSlots; });
+                            }
+                            if (failed.load()) { gave_up = true; return; }
+                            if (k != cached_k) {        // consecutive files of a worker mostly stay in one chunk
+                                const MetaChunk *got;
+                                {
+                                    std::lock_guard<std::mutex> g3(assign_mu);      // the pool's block table
+                                    got = P->meta_chunk((size_t)k, chunk_rows, W);
+                                    if (got) cached_mc = *got;
+                                }
+                                if (!got) { gave_up = true; err = "out of memory"; return; }
+                                cached_k = k;
+                            }
+                            mc = cached_mc;
+                            pin = P->h_pin[k % kSlots];
+                        }
+                        std::memcpy(pin + (size_t)in * (size_t)W, kmer, (size_t)W);
+                        std::memcpy(mc.kmers + (size_t)in * (size_t)W, kmer, (size_t)W);
+                        mc.start[in] = st;
+                        mc.stop[in] = sp;
+                        mc.freq[in] = fr;
+                        mc.strand[in] = strand;
+                        mc.is_ref[in] = is_ref;
+                        mc.local_name[in] = nid;
+                        ++in;
+                        --left;
+                        ++placed;
+                        ++done;
+                    };
+                    std::string perr;
+                    const bool ok = gfm_tsv_detail::parse_rows(paths[i], text.begin(), text.end(), W, skip_reverse != 0,
+                                                               names, sink, perr);
+                    account();
+                    if (!ok) err = perr;
+                    else if (err.empty() && !gave_up && done != rows)
+                        err = std::string(paths[i]) + ": internal error: the row count of the first pass does not hold";
                 }
-                lk.lock();
-                if (!f.error.empty()) {
-                    if (!failed) fail_msg = f.error;
-                    failed = true;
-                    cv_work.notify_all();
-                    cv_main.notify_all();
-                    return;
-                }
-                counted[(size_t)i] = 1;
-                t_parse_end = std::max(t_parse_end, now_s());
-                while (next_assign < n_paths && counted[(size_t)next_assign]) {
-                    file_off[(size_t)next_assign] = assigned_rows;
-                    assigned_rows += (int64_t)sc->table.files[(size_t)next_assign].start.size();
-                    ++next_assign;
-                }
-                cv_work.notify_all();
-                cv_main.notify_one();
+                head = (head + 1) % kRing;
+                --n_held;
+                if (!err.empty()) { fail_with(err); return; }
+                const int64_t t_ns = (int64_t)(now_s() * 1e9);
+                int64_t prev = parse_end_ns.load(std::memory_order_relaxed);
+                while (prev < t_ns && !parse_end_ns.compare_exchange_weak(prev, t_ns, std::memory_order_relaxed)) {}
                 continue;
             }
-            if (staged_files >= n_paths || next_stage >= n_paths) return;   // nothing left for this thread to take
-            cv_work.wait(lk);
+            if (n_held < kRing && next_count.load(std::memory_order_relaxed) < n_paths) {
+                const int i = next_count.fetch_add(1, std::memory_order_relaxed);    // read the next file, count its rows
+                if (i < n_paths) {
+                    const int slot_ix = (head + n_held) % kRing;
+                    std::string err;
+                    int64_t rows = 0;
+                    if (ring[slot_ix].load(paths[i], err))
+                        rows = gfm_tsv_detail::count_rows(ring[slot_ix].begin(), ring[slot_ix].end(), skip_reverse != 0);
+                    if (!err.empty()) { fail_with(err); return; }
+                    held[slot_ix] = i;
+                    ++n_held;
+                    sc->table.files[(size_t)i].n_rows = rows;
+                    counted[(size_t)i].store(1, std::memory_order_release);
+                    advance_offsets();
+                    continue;
+                }
+            }
+            if (n_held == 0) return;                             // nothing left for this thread to take
+            // my oldest file waits for earlier counts (they are being made right now): help, then give way
+            advance_offsets();
+            if (held[head] >= next_assign.load(std::memory_order_acquire)) std::this_thread::yield();
         }
     };
     stamp("pipeline set up");
@@ -371,12 +581,12 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
         gfm_workers::Run run;
         std::mutex &mu;
         std::condition_variable &cv;
-        bool &failed;
+        std::atomic<bool> &failed;
         ~Crew()
         {
             {
                 std::lock_guard<std::mutex> lk(mu);
-                failed = true;          // whoever still waits gives up (after a normal run nobody does)
+                failed.store(true);     // whoever still waits gives up (after a normal run nobody does)
             }
             cv.notify_all();
             run.wait();
@@ -384,15 +594,17 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
     } crew{{}, mu, cv_work, failed};
     crew.run.start(nt, work);
     stamp("workers started");
-    // (behind the start of the workers: the two memsets take 0.7 ms of host time to enqueue)
-    if (want_qvalues) S_TRY(hipMemsetAsync(P->d_hist, 0, sizeof(uint64_t) * (size_t)L, P->score));
-    S_TRY(hipMemsetAsync(P->d_count, 0, sizeof(uint64_t), P->score));
-    S_TRY(hipMemsetAsync(P->d_cand_count, 0, sizeof(uint64_t), P->score));
+    // (behind the start of the workers: the memsets take host time to enqueue)
+    for (size_t j = 0; j < M; ++j) {
+        MotifBufs &b = P->mb[j];
+        if (want_qvalues) S_TRY(hipMemsetAsync(sc->d_hist[j], 0, sizeof(uint64_t) * (size_t)L, P->score));
+        S_TRY(hipMemsetAsync(b.d_count, 0, sizeof(uint64_t), P->score));
+        S_TRY(hipMemsetAsync(b.d_cand_count, 0, sizeof(uint64_t), P->score));
+    }
     stamp("buffers cleared");
 
     int64_t total_rows = 0;
     size_t n_chunks = 0;
-    std::vector<int64_t> chunk_n;          // rows of every submitted chunk
     double h2d_ms = 0.0;
     int64_t h2d_bytes = 0;
     auto release_chunk = [&](int64_t k) -> int {   // chunk k has been copied AND scored: its slot is free again
@@ -403,45 +615,63 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
         h2d_ms += ms;
         {
             std::lock_guard<std::mutex> lk(mu);
-            released = k + 1;
+            released.store(k + 1, std::memory_order_release);
         }
         cv_work.notify_all();
         return GFM_OK;
     };
+    std::vector<int32_t *> d_sc(M);
+    std::vector<uint64_t *> v_hist(M), v_count(M);
+    std::vector<int64_t *> v_sel(M);
+    std::vector<int64_t> v_cap(M);
     for (int64_t k = 0;; ++k) {
         int64_t rows_k = 0;
-        {   // wait until chunk k is fully staged (or turns out not to exist)
-            std::unique_lock<std::mutex> lk(mu);
-            cv_main.wait(lk, [&] {
-                if (failed) return true;
-                const int64_t have = (int64_t)chunk_staged.size() > k ? chunk_staged[(size_t)k] : 0;
+        {   // wait until chunk k is fully in place (or turns out not to exist)
+            auto ready = [&]() {
+                if (failed.load()) return true;
+                if ((size_t)k >= kMaxChunks) return true;
+                const int64_t have = chunk_staged[(size_t)k].load(std::memory_order_acquire);
                 if (have == chunk_rows) return true;
-                if (next_assign == n_paths)                 // every row count is known: the last chunk may be short
-                    return have == std::min(chunk_rows, std::max<int64_t>(0, assigned_rows - k * chunk_rows));
+                const int64_t tot = total_assigned.load(std::memory_order_acquire);
+                if (tot >= 0)                               // every row count is known: the last chunk may be short
+                    return have == std::min(chunk_rows, std::max<int64_t>(0, tot - k * chunk_rows));
                 return false;
-            });
-            if (failed) return sfail(GFM_ERR_IO, fail_msg);
-            rows_k = (int64_t)chunk_staged.size() > k ? chunk_staged[(size_t)k] : 0;
+            };
+            std::unique_lock<std::mutex> lk(mu);
+            while (!ready()) cv_main.wait_for(lk, std::chrono::microseconds(500));   // (woken by the completing add)
+            if (failed.load()) return sfail(GFM_ERR_IO, fail_msg);
+            rows_k = (size_t)k < kMaxChunks ? chunk_staged[(size_t)k].load(std::memory_order_acquire) : 0;
         }
         if (rows_k == 0) break;
         stamp("chunk staged");
         const int slot = (int)(k % kSlots);
         const size_t bytes = (size_t)rows_k * (size_t)W;
-        int32_t *d_sc = nullptr;
-        S_RC(P->score_block((size_t)k, chunk_rows, &d_sc));
+        for (size_t j = 0; j < M; ++j) {
+            MotifBufs &b = P->mb[j];
+            S_RC(b.score_block((size_t)k, chunk_rows, &d_sc[j]));
+            v_hist[j] = sc->d_hist[j];
+            v_sel[j] = fused ? b.d_hits : b.d_cand;             // the list the score kernel appends to
+            v_count[j] = fused ? b.d_count : b.d_cand_count;
+            v_cap[j] = b.hit_cap;
+        }
         S_TRY(hipEventRecord(P->c0[slot], P->copy));
         S_TRY(hipMemcpyAsync(P->d_kmers[slot], P->h_pin[slot], bytes, hipMemcpyHostToDevice, P->copy));
         S_TRY(hipEventRecord(P->c1[slot], P->copy));
         S_TRY(hipEventRecord(P->copied[slot], P->copy));
         S_TRY(hipStreamWaitEvent(P->score, P->copied[slot], 0));
-        S_RC(gfm_score_kmers(m, P->d_kmers[slot], rows_k, d_sc, want_qvalues ? P->d_hist : nullptr, cutoff, total_rows,
-                             d_sel, P->hit_cap, d_sel_count, 0, P->score, nullptr));
+        if (M == 1)
+            S_RC(gfm_score_kmers(motifs[0], P->d_kmers[slot], rows_k, d_sc[0], v_hist[0], sc->cutoffs[0], total_rows,
+                                 v_sel[0], v_cap[0], v_count[0], 0, P->score, nullptr));
+        else
+            S_RC(gfm_score_kmers_multi(motifs, n_motifs, P->d_kmers[slot], rows_k, d_sc.data(),
+                                       want_qvalues ? v_hist.data() : nullptr, sc->cutoffs.data(), total_rows, v_sel.data(),
+                                       v_cap.data(), v_count.data(), 0, P->score));
         S_TRY(hipEventRecord(P->scored[slot], P->score));
         h2d_bytes += (int64_t)bytes;
-        chunk_n.push_back(rows_k);
+        sc->chunk_n.push_back(rows_k);
         total_rows += rows_k;
         ++n_chunks;
-        if (k + 1 >= kSlots) S_RC(release_chunk(k + 1 - kSlots));   // the slot chunk k+1 will be staged into
+        if (k + 1 >= kSlots) S_RC(release_chunk(k + 1 - kSlots));   // the slot chunk k+1 will be written into
         if (rows_k < chunk_rows) break;                             // a short chunk is the last one
     }
     for (int64_t k = std::max<int64_t>(0, (int64_t)n_chunks - (kSlots - 1)); k < (int64_t)n_chunks; ++k)
@@ -451,90 +681,183 @@ GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, i
     stamp("workers done");
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (failed) return sfail(GFM_ERR_IO, fail_msg);
+        if (failed.load()) return sfail(GFM_ERR_IO, fail_msg);
     }
-    const double t_parsed = t_parse_end;
-    if (trace) std::fprintf(stderr, "[scan] %8.3f ms  (last file parsed)\n", (t_parsed - t_begin) * 1e3);
+    const double t_parse_end = std::max(t_begin, (double)parse_end_ns.load() * 1e-9);
+    if (trace) std::fprintf(stderr, "[scan] %8.3f ms  (last file parsed)\n", (t_parse_end - t_begin) * 1e3);
     sc->table.index_rows();
     stamp("rows indexed");
     if (sc->table.n != total_rows) return sfail(GFM_ERR_IO, "internal error: row count mismatch");
+    S_TRY(hipStreamSynchronize(P->score));      // the histograms are complete for whoever reads them next
+    sc->total_rows = total_rows;
+    sc->n_chunks = n_chunks;
+    sc->t_parsed = t_parse_end;
+    sc->begin_s = now_s() - t_begin;
+    sc->stats.n_rows = total_rows;
+    sc->stats.n_chunks = (int64_t)n_chunks;
+    sc->stats.h2d_bytes = h2d_bytes;
+    sc->stats.h2d_s = h2d_ms * 1e-3;
+    sc->stats.parse_s = t_parse_end - t_begin;
+    sc->stats.parse_threads = nt;
+    *n_rows = total_rows;
+    guard.p = nullptr;
+    *out = sc;
+    return GFM_OK;
+}
 
-    // ---- tables, selection
-    if (total_rows > 0) {
-        if (want_qvalues)
-            S_RC(gfm_qvalue_table(m, P->d_hist, threshold, on_qvalue, P->d_q, P->d_cutoff, nullptr, 0, P->score));
-        auto select_all = [&]() -> int {   // separate selection pass over every score block
-            int64_t base = 0;
-            for (size_t k = 0; k < n_chunks; ++k) {
-                S_RC(gfm_select_hits(m, P->score_blocks[k], chunk_n[k], P->d_cutoff, base, P->d_hits, P->hit_cap,
-                                     P->d_count, k == 0 ? GFM_FLAG_RESET_HITS : 0, P->score));
-                base += chunk_n[k];
-            }
-            return GFM_OK;
-        };
-        if (on_qvalue) {
-            uint64_t ccnt = 0;
-            S_TRY(hipMemcpyAsync(&ccnt, P->d_cand_count, sizeof ccnt, hipMemcpyDeviceToHost, P->score));
-            S_TRY(hipStreamSynchronize(P->score));
-            if ((int64_t)ccnt <= P->hit_cap)      // the candidates are complete: filter them (the gated pass over
-                S_RC(gfm_select_hits_from(m, P->score_blocks[0], chunk_n[0], P->d_cutoff, 0, P->d_cand, P->hit_cap,   // the scores exits at once)
-                                          P->d_cand_count, P->d_hits, P->hit_cap, P->d_count, P->score));
+GFM_API int gfm_scan_tsv_finish(gfm_scan_t sc, int64_t *n_hits)
+{
+    if (!sc) return sfail(GFM_ERR_INVALID, "NULL handle");
+    if (sc->finished) return sfail(GFM_ERR_INVALID, "gfm_scan_tsv_finish was already called on this scan");
+    ScanPool *P = sc->pool;
+    const size_t M = sc->motifs.size();
+    const int L = sc->L;
+    const double t0 = now_s();
+    const bool fused = !sc->on_qvalue;
+    {
+        int dev = -1;
+        S_TRY(hipGetDevice(&dev));
+        if (dev != P->device) return sfail(GFM_ERR_INVALID, "the scan lives on another device than the current one");
+    }
+    if (sc->total_rows > 0) {
+        // ---- tables
+        if (sc->want_qvalues) {
+            std::vector<double *> v_q(M);
+            std::vector<int32_t *> v_cut(M);
+            for (size_t j = 0; j < M; ++j) { v_q[j] = P->mb[j].d_q; v_cut[j] = P->mb[j].d_cutoff; }
+            if (M == 1)
+                S_RC(gfm_qvalue_table(sc->motifs[0], sc->d_hist[0], sc->threshold, sc->on_qvalue, v_q[0], v_cut[0], nullptr, 0,
+                                      P->score));
             else
-                S_RC(select_all());
+                S_RC(gfm_qvalue_table_multi(sc->motifs.data(), (int)M, sc->d_hist.data(), sc->threshold, sc->on_qvalue,
+                                            v_q.data(), v_cut.data(), nullptr, 0, P->score));
         }
-        uint64_t cnt = 0;
-        S_TRY(hipMemcpyAsync(&cnt, P->d_count, sizeof cnt, hipMemcpyDeviceToHost, P->score));
-        S_TRY(hipStreamSynchronize(P->score));
-        if ((int64_t)cnt > P->hit_cap) {   // the list was too short: size it from the count and select again
-            S_RC(P->reserve_hits((int64_t)cnt + (int64_t)(cnt >> 3) + 1024));
-            if (fused) S_TRY(hipMemcpyAsync(P->d_cutoff, &cutoff, sizeof cutoff, hipMemcpyHostToDevice, P->score));
-            S_RC(select_all());
-            S_TRY(hipMemcpyAsync(&cnt, P->d_count, sizeof cnt, hipMemcpyDeviceToHost, P->score));
+        // ---- selection, hits back: motif by motif
+        for (size_t j = 0; j < M; ++j) {
+            MotifBufs &b = P->mb[j];
+            gfm_motif_t m = sc->motifs[j];
+            auto select_all = [&]() -> int {   // separate selection pass over every score block
+                int64_t base = 0;
+                for (size_t k = 0; k < sc->n_chunks; ++k) {
+                    S_RC(gfm_select_hits(m, b.score_blocks[k], sc->chunk_n[k], b.d_cutoff, base, b.d_hits, b.hit_cap,
+                                         b.d_count, k == 0 ? GFM_FLAG_RESET_HITS : 0, P->score));
+                    base += sc->chunk_n[k];
+                }
+                return GFM_OK;
+            };
+            if (sc->on_qvalue) {
+                uint64_t ccnt = 0;
+                S_TRY(hipMemcpyAsync(&ccnt, b.d_cand_count, sizeof ccnt, hipMemcpyDeviceToHost, P->score));
+                S_TRY(hipStreamSynchronize(P->score));
+                if ((int64_t)ccnt <= b.hit_cap)      // the candidates are complete: filter them (the gated pass over
+                    S_RC(gfm_select_hits_from(m, b.score_blocks[0], sc->chunk_n[0], b.d_cutoff, 0, b.d_cand, b.hit_cap,   // the scores exits at once)
+                                              b.d_cand_count, b.d_hits, b.hit_cap, b.d_count, P->score));
+                else
+                    S_RC(select_all());
+            }
+            uint64_t cnt = 0;
+            S_TRY(hipMemcpyAsync(&cnt, b.d_count, sizeof cnt, hipMemcpyDeviceToHost, P->score));
             S_TRY(hipStreamSynchronize(P->score));
-            if ((int64_t)cnt > P->hit_cap) return sfail(GFM_ERR_OVERFLOW, "hit list overflow");
-        }
-        std::vector<int64_t> packed((size_t)cnt);
-        std::vector<double> q;
-        if (cnt)
-            S_TRY(hipMemcpyAsync(packed.data(), P->d_hits, sizeof(int64_t) * (size_t)cnt, hipMemcpyDeviceToHost, P->score));
-        if (want_qvalues && cnt) {
-            q.resize((size_t)L);
-            S_TRY(hipMemcpyAsync(q.data(), P->d_q, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, P->score));
-        }
-        S_TRY(hipStreamSynchronize(P->score));
-        stamp("hits and q-table on the host");
-        std::sort(packed.begin(), packed.end());   // (row << 20 | score): ascending by row
-        sc->rows.resize((size_t)cnt);
-        sc->scaled.resize((size_t)cnt);
-        sc->logodds.resize((size_t)cnt);
-        sc->pvalue.resize((size_t)cnt);
-        for (size_t i = 0; i < (size_t)cnt; ++i) {
-            sc->rows[i] = packed[i] >> GFM_HIT_SCORE_BITS;
-            sc->scaled[i] = (int32_t)(packed[i] & ((1ll << GFM_HIT_SCORE_BITS) - 1));
-        }
-        if (cnt) S_RC(gfm_motif_annotate(m, sc->scaled.data(), (int64_t)cnt, sc->logodds.data(), sc->pvalue.data()));
-        if (want_qvalues) {
-            sc->qvalue.resize((size_t)cnt);
-            for (size_t i = 0; i < (size_t)cnt; ++i) sc->qvalue[i] = q[(size_t)sc->scaled[i]];
+            if ((int64_t)cnt > b.hit_cap) {   // the list was too short: size it from the count and select again
+                S_RC(b.reserve_hits((int64_t)cnt + (int64_t)(cnt >> 3) + 1024));
+                if (fused)
+                    S_TRY(hipMemcpyAsync(b.d_cutoff, &sc->cutoffs[j], sizeof(int32_t), hipMemcpyHostToDevice, P->score));
+                S_RC(select_all());
+                S_TRY(hipMemcpyAsync(&cnt, b.d_count, sizeof cnt, hipMemcpyDeviceToHost, P->score));
+                S_TRY(hipStreamSynchronize(P->score));
+                if ((int64_t)cnt > b.hit_cap) return sfail(GFM_ERR_OVERFLOW, "hit list overflow");
+            }
+            std::vector<int64_t> packed((size_t)cnt);
+            std::vector<double> q;
+            if (cnt)
+                S_TRY(hipMemcpyAsync(packed.data(), b.d_hits, sizeof(int64_t) * (size_t)cnt, hipMemcpyDeviceToHost, P->score));
+            if (sc->want_qvalues && cnt) {
+                q.resize((size_t)L);
+                S_TRY(hipMemcpyAsync(q.data(), b.d_q, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, P->score));
+            }
+            S_TRY(hipStreamSynchronize(P->score));
+            std::sort(packed.begin(), packed.end());   // (row << 20 | score): ascending by row
+            MotifHits &h = sc->hits[j];
+            h.rows.resize((size_t)cnt);
+            h.scaled.resize((size_t)cnt);
+            h.logodds.resize((size_t)cnt);
+            h.pvalue.resize((size_t)cnt);
+            for (size_t i = 0; i < (size_t)cnt; ++i) {
+                h.rows[i] = packed[i] >> GFM_HIT_SCORE_BITS;
+                h.scaled[i] = (int32_t)(packed[i] & ((1ll << GFM_HIT_SCORE_BITS) - 1));
+            }
+            if (cnt) S_RC(gfm_motif_annotate(m, h.scaled.data(), (int64_t)cnt, h.logodds.data(), h.pvalue.data()));
+            if (sc->want_qvalues) {
+                h.qvalue.resize((size_t)cnt);
+                for (size_t i = 0; i < (size_t)cnt; ++i) h.qvalue[i] = q[(size_t)h.scaled[i]];
+            }
         }
     } else {
         S_TRY(hipStreamSynchronize(P->score));
     }
-    stamp("hits annotated");
+    sc->finished = true;
     const double t_end = now_s();
-    sc->stats.n_rows = total_rows;
-    sc->stats.n_hits = (int64_t)sc->rows.size();
-    sc->stats.n_chunks = (int64_t)n_chunks;
-    sc->stats.h2d_bytes = h2d_bytes;
-    sc->stats.total_s = t_end - t_begin;
-    sc->stats.parse_s = t_parsed - t_begin;
-    sc->stats.h2d_s = h2d_ms * 1e-3;
-    sc->stats.tail_s = t_end - t_parsed;
-    sc->stats.parse_threads = nt;
-    *n_rows = total_rows;
-    *n_hits = (int64_t)sc->rows.size();
-    guard.p = nullptr;
+    sc->stats.n_hits = (int64_t)sc->hits[0].rows.size();
+    sc->stats.total_s = sc->begin_s + (t_end - t0);          // the caller's time between the two phases is not the scan's
+    sc->stats.tail_s = sc->stats.total_s - sc->stats.parse_s;
+    if (n_hits)
+        for (size_t j = 0; j < M; ++j) n_hits[j] = (int64_t)sc->hits[j].rows.size();
+    return GFM_OK;
+}
+
+GFM_API int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, int skip_reverse, int n_threads,
+                         double threshold, int on_qvalue, int want_qvalues, int64_t chunk_rows, gfm_scan_t *out,
+                         int64_t *n_rows, int64_t *n_hits)
+{
+    if (!m || !out || !n_rows || !n_hits) return sfail(GFM_ERR_INVALID, "NULL argument");
+    *n_hits = 0;
+    gfm_scan_t sc = nullptr;
+    S_RC(gfm_scan_tsv_begin(&m, 1, paths, n_paths, skip_reverse, n_threads, threshold, on_qvalue, want_qvalues, chunk_rows,
+                            nullptr, &sc, n_rows));
+    const int rc = gfm_scan_tsv_finish(sc, n_hits);
+    if (rc) {
+        delete sc;
+        *n_rows = 0;
+        return rc;
+    }
     *out = sc;
+    return GFM_OK;
+}
+
+GFM_API int gfm_scan_hits_of(gfm_scan_t s, int motif, int64_t *rows, int32_t *scaled, double *logodds, double *pvalue,
+                             double *qvalue, uint8_t *kmers, int64_t *start, int64_t *stop, uint8_t *strand,
+                             int64_t *freq, uint8_t *is_ref, int32_t *name_id)
+{
+    if (!s) return sfail(GFM_ERR_INVALID, "NULL handle");
+    if (!s->finished) return sfail(GFM_ERR_INVALID, "gfm_scan_tsv_finish has not run on this scan");
+    if (motif < 0 || (size_t)motif >= s->hits.size()) return sfail(GFM_ERR_INVALID, "motif index outside the scan");
+    const MotifHits &h = s->hits[(size_t)motif];
+    const size_t k = h.rows.size();
+    if (rows) std::memcpy(rows, h.rows.data(), k * sizeof(int64_t));
+    if (scaled) std::memcpy(scaled, h.scaled.data(), k * sizeof(int32_t));
+    if (logodds) std::memcpy(logodds, h.logodds.data(), k * sizeof(double));
+    if (pvalue) std::memcpy(pvalue, h.pvalue.data(), k * sizeof(double));
+    if (qvalue) {
+        if (!s->have_q) return sfail(GFM_ERR_INVALID, "the scan computed no q-values");
+        std::memcpy(qvalue, h.qvalue.data(), k * sizeof(double));
+    }
+    const gfm_tsv &t = s->table;
+    const ScanPool *P = s->pool;
+    size_t fi = 0;
+    const size_t W = (size_t)s->W;
+    for (size_t i = 0; i < k; ++i) {          // hits ascend by row: walk the files once
+        const int64_t r = h.rows[i];
+        while (fi + 1 < t.files.size() && t.row_base[fi + 1] <= r) ++fi;
+        const MetaChunk &mc = P->meta[(size_t)(r / s->chunk_rows)];
+        const size_t j = (size_t)(r % s->chunk_rows);
+        if (kmers) std::memcpy(kmers + i * W, mc.kmers + j * W, W);
+        if (start) start[i] = mc.start[j];
+        if (stop) stop[i] = mc.stop[j];
+        if (strand) strand[i] = mc.strand[j];
+        if (freq) freq[i] = mc.freq[j];
+        if (is_ref) is_ref[i] = mc.is_ref[j];
+        if (name_id) name_id[i] = t.remap[fi][(size_t)mc.local_name[j]];
+    }
     return GFM_OK;
 }
 
@@ -542,33 +865,7 @@ GFM_API int gfm_scan_hits(gfm_scan_t s, int64_t *rows, int32_t *scaled, double *
                           double *qvalue, uint8_t *kmers, int64_t *start, int64_t *stop, uint8_t *strand,
                           int64_t *freq, uint8_t *is_ref, int32_t *name_id)
 {
-    if (!s) return sfail(GFM_ERR_INVALID, "NULL handle");
-    const size_t k = s->rows.size();
-    if (rows) std::memcpy(rows, s->rows.data(), k * sizeof(int64_t));
-    if (scaled) std::memcpy(scaled, s->scaled.data(), k * sizeof(int32_t));
-    if (logodds) std::memcpy(logodds, s->logodds.data(), k * sizeof(double));
-    if (pvalue) std::memcpy(pvalue, s->pvalue.data(), k * sizeof(double));
-    if (qvalue) {
-        if (!s->have_q) return sfail(GFM_ERR_INVALID, "the scan computed no q-values");
-        std::memcpy(qvalue, s->qvalue.data(), k * sizeof(double));
-    }
-    const gfm_tsv &t = s->table;
-    size_t fi = 0;
-    const size_t W = (size_t)s->W;
-    for (size_t i = 0; i < k; ++i) {          // hits ascend by row: walk the files once
-        const int64_t r = s->rows[i];
-        while (fi + 1 < t.files.size() && t.row_base[fi + 1] <= r) ++fi;
-        const FileCols &f = t.files[fi];
-        const size_t j = (size_t)(r - t.row_base[fi]);
-        if (kmers) std::memcpy(kmers + i * W, f.kmers.data() + j * W, W);
-        if (start) start[i] = f.start[j];
-        if (stop) stop[i] = f.stop[j];
-        if (strand) strand[i] = f.strand[j];
-        if (freq) freq[i] = f.freq[j];
-        if (is_ref) is_ref[i] = f.is_ref[j];
-        if (name_id) name_id[i] = t.remap[fi][(size_t)f.local_name[j]];
-    }
-    return GFM_OK;
+    return gfm_scan_hits_of(s, 0, rows, scaled, logodds, pvalue, qvalue, kmers, start, stop, strand, freq, is_ref, name_id);
 }
 
 GFM_API int gfm_scan_stats(gfm_scan_t s, gfm_scan_stats_t *out)

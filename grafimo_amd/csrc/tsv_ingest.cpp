@@ -29,6 +29,9 @@
 #define GFM_API extern "C" __attribute__((visibility("default")))
 
 using gfm_tsv_detail::FileCols;
+using gfm_tsv_detail::is_ws;
+using gfm_tsv_detail::NameTable;
+using gfm_tsv_detail::parse_rows;
 
 namespace {
 
@@ -37,163 +40,117 @@ struct ErrSlot {
     ErrSlot &operator=(const char *m) { gfm_set_error_(m); return *this; }
 } t_err;
 
-inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }
-
-// CHR:NUM(+|-) -> NUM and strand; the reference takes split(":")[1] and drops its last char
-bool parse_pos(const char *b, const char *e, int64_t *val, char *strand)
-{
-    if (e - b < 3) return false;
-    const char *colon = static_cast<const char *>(memchr(b, ':', (size_t)(e - b)));
-    if (!colon) return false;
-    const char *p = colon + 1;
-    const char *q = static_cast<const char *>(memchr(p, ':', (size_t)(e - p)));
-    const char *fe = q ? q : e;      // field after the first ':' (up to a second ':', if any)
-    if (fe - p < 2) return false;
-    *strand = e[-1];                 // data[2][-1]: last char of the whole column
-    const char *ne = fe - 1;         // [:-1]
-    bool neg = false;
-    if (p < ne && (*p == '-' || *p == '+')) { neg = *p == '-'; ++p; }
-    if (p >= ne) return false;
-    int64_t v = 0;
-    for (; p < ne; ++p) {
-        if (*p < '0' || *p > '9') return false;
-        v = v * 10 + (*p - '0');
-    }
-    *val = neg ? -v : v;
-    return true;
-}
-
-bool parse_int(const char *b, const char *e, int64_t *val)
-{
-    if (b >= e) return false;
-    bool neg = false;
-    if (*b == '-' || *b == '+') { neg = *b == '-'; ++b; }
-    if (b >= e) return false;
-    int64_t v = 0;
-    for (; b < e; ++b) {
-        if (*b < '0' || *b > '9') return false;
-        v = v * 10 + (*b - '0');
-    }
-    *val = neg ? -v : v;
-    return true;
-}
-
 }  // namespace
 
-void gfm_tsv_detail::parse_file(const char *path, int W, bool skip_rev, FileCols &out)
+// ---------------------------------------------------------------------------------------------- file bytes
+bool gfm_tsv_detail::FileBuf::load(const char *path, std::string &err)
 {
+    drop();
     int fd = open(path, O_RDONLY);
-    if (fd < 0) { out.error = std::string("Unable to open ") + path; return; }
+    if (fd < 0) { err = std::string("Unable to open ") + path; return false; }
     struct stat sb;
-    if (fstat(fd, &sb) != 0) { close(fd); out.error = std::string("Unable to stat ") + path; return; }
+    if (fstat(fd, &sb) != 0) { close(fd); err = std::string("Unable to stat ") + path; return false; }
     const size_t len = (size_t)sb.st_size;
-    if (len == 0) { close(fd); return; }
-    // Small files are read into a per-thread buffer: with hundreds of parse threads, mmap/munmap of
-    // thousands of region files serialise on the process's address-space lock.  Big files are mapped.
+    if (len == 0) { close(fd); return true; }
     constexpr size_t kReadLimit = (size_t)32 << 20;
-    static thread_local std::vector<char> t_buf;
-    // the parse threads belong to a crew that lives as long as the process: a buffer that grew for one big file is
-    // handed back when this file is done (region files are a few hundred KB: those keep their buffer)
-    struct Shrink {
-        std::vector<char> &b;
-        ~Shrink() { if (b.capacity() > ((size_t)1 << 20)) std::vector<char>().swap(b); }
-    } shrink{t_buf};
-    void *map = nullptr;
-    const char *p = nullptr;
     if (len <= kReadLimit) {
-        t_buf.resize(len);
+        if (buf_.size() < len) {
+            buf_.clear();                       // nothing to carry over into a new allocation
+            buf_.resize(len + len / 8);         // (files of one scan are about one size: no growth per file)
+        }
         size_t got = 0;
         while (got < len) {
-            const ssize_t r = read(fd, t_buf.data() + got, len - got);
+            const ssize_t r = read(fd, buf_.data() + got, len - got);
             if (r <= 0) break;
             got += (size_t)r;
         }
         close(fd);
-        if (got != len) { out.error = std::string("Unable to read ") + path; return; }
-        p = t_buf.data();
+        if (got != len) { err = std::string("Unable to read ") + path; return false; }
+        p_ = buf_.data();
+        len_ = len;
     } else {
-        map = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+        void *m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
         close(fd);
-        if (map == MAP_FAILED) { out.error = std::string("Unable to mmap ") + path; return; }
-        madvise(map, len, MADV_SEQUENTIAL);
-        p = static_cast<const char *>(map);
+        if (m == MAP_FAILED) { err = std::string("Unable to mmap ") + path; return false; }
+        madvise(m, len, MADV_SEQUENTIAL);
+        map_ = m;
+        map_len_ = len;
+        p_ = static_cast<const char *>(m);
+        len_ = len;
     }
-    const char *end = p + len;
+    return true;
+}
+
+void gfm_tsv_detail::FileBuf::drop()
+{
+    if (map_) munmap(map_, map_len_);
+    map_ = nullptr;
+    map_len_ = 0;
+    p_ = nullptr;
+    len_ = 0;
+    // the parse threads belong to a crew that lives as long as the process: a buffer that grew for one big file
+    // is handed back (region files are a few hundred KB: those keep theirs)
+    if (buf_.capacity() > ((size_t)4 << 20)) std::vector<char>().swap(buf_);
+}
+
+int64_t gfm_tsv_detail::count_rows(const char *p, const char *end, bool skip_rev)
+{
+    int64_t n = 0;
+    while (p < end) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+        const char *le = nl ? nl : end;
+        const char *c = p;
+        while (c < le && is_ws(*c)) ++c;
+        if (c < le) {
+            if (!skip_rev) {
+                ++n;
+            } else {           // the strand is the last character of the third field
+                for (int f = 0; f < 2 && c < le; ++f) {
+                    while (c < le && !is_ws(*c)) ++c;
+                    while (c < le && is_ws(*c)) ++c;
+                }
+                while (c < le && !is_ws(*c)) ++c;
+                if (c[-1] != '-') ++n;       // (a malformed line is counted: the parse pass reports it)
+            }
+        }
+        p = nl ? nl + 1 : end;
+    }
+    return n;
+}
+
+void gfm_tsv_detail::parse_file(const char *path, int W, bool skip_rev, FileCols &out)
+{
+    static thread_local FileBuf text;
+    struct Drop {
+        FileBuf &b;
+        ~Drop() { b.drop(); }
+    } dropper{text};
+    if (!text.load(path, out.error)) return;
+    const size_t len = (size_t)(text.end() - text.begin());
+    if (len == 0) return;
     const size_t guess = len / (size_t)(2 * W + 60) + 16;
     out.kmers.reserve(guess * (size_t)W);
     out.start.reserve(guess); out.stop.reserve(guess); out.freq.reserve(guess);
     out.strand.reserve(guess); out.is_ref.reserve(guess); out.local_name.reserve(guess);
-    std::unordered_map<std::string, int32_t> name_ix;
-    const char *last_name = nullptr;
-    size_t last_len = 0;
-    int32_t last_id = -1;
-    int64_t lineno = 0;
-    while (p < end) {
-        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
-        const char *le = nl ? nl : end;
-        ++lineno;
-        // split the first six whitespace-separated fields
-        const char *fb[6], *fe[6];
-        int nf = 0;
-        const char *c = p;
-        while (c < le && nf < 6) {
-            while (c < le && is_ws(*c)) ++c;
-            if (c >= le) break;
-            fb[nf] = c;
-            while (c < le && !is_ws(*c)) ++c;
-            fe[nf] = c;
-            ++nf;
-        }
-        const char *next = nl ? nl + 1 : end;
-        if (nf == 0) { p = next; continue; }  // blank line
-        auto bad = [&](const char *what) {
-            char buf[256];
-            snprintf(buf, sizeof buf, "%s:%lld: %s", path, (long long)lineno, what);
-            out.error = buf;
-        };
-        if (nf < 6) { bad("expected at least 6 columns"); break; }
-        int64_t st = 0, sp = 0, fr = 0;
-        char s1 = 0, s2 = 0;
-        if (!parse_pos(fb[2], fe[2], &st, &s1)) { bad("malformed start column"); break; }
-        if (skip_rev && s1 == '-') { p = next; continue; }
-        if (!parse_pos(fb[3], fe[3], &sp, &s2)) { bad("malformed stop column"); break; }
-        if (fe[1] - fb[1] != W) { bad("k-mer length differs from the motif width"); break; }
-        if (!parse_int(fb[4], fe[4], &fr)) { bad("malformed haplotype count"); break; }
-        const size_t nlen = (size_t)(fe[0] - fb[0]);
-        int32_t nid;
-        if (last_name && nlen == last_len && memcmp(last_name, fb[0], nlen) == 0) {
-            nid = last_id;
-        } else {
-            std::string key(fb[0], nlen);
-            auto it = name_ix.find(key);
-            if (it == name_ix.end()) {
-                nid = (int32_t)out.names.size();
-                out.names.push_back(key);
-                name_ix.emplace(std::move(key), nid);
-            } else {
-                nid = it->second;
-            }
-            last_name = fb[0]; last_len = nlen; last_id = nid;
-        }
-        out.kmers.insert(out.kmers.end(), reinterpret_cast<const uint8_t *>(fb[1]),
-                         reinterpret_cast<const uint8_t *>(fe[1]));
-        out.start.push_back(st);
-        out.stop.push_back(sp);
-        out.freq.push_back(fr);
-        out.strand.push_back((uint8_t)s1);
-        const bool is_ref_str = (fe[5] - fb[5] == 3) && memcmp(fb[5], "ref", 3) == 0;
-        const int64_t dist = sp > st ? sp - st : st - sp;
-        out.is_ref.push_back((uint8_t)(is_ref_str && dist == W));  // score_sequences.py:305-307
-        out.local_name.push_back(nid);
-        p = next;
-    }
-    if (map) munmap(map, len);
+    NameTable names(out.names);
+    parse_rows(path, text.begin(), text.end(), W, skip_rev, names,
+               [&](const uint8_t *kmer, int64_t st, int64_t sp, int64_t fr, uint8_t strand, uint8_t is_ref, int32_t nid) {
+                   out.kmers.insert(out.kmers.end(), kmer, kmer + W);
+                   out.start.push_back(st);
+                   out.stop.push_back(sp);
+                   out.freq.push_back(fr);
+                   out.strand.push_back(strand);
+                   out.is_ref.push_back(is_ref);
+                   out.local_name.push_back(nid);
+               },
+               out.error);
 }
 
 // More threads than this lose to their own coordination: 2e6 rows in 1000 files (184 MB) on a 256-thread host
 // through gfm_scan_tsv, median of 7 runs: 32 threads 6.6 ms, 64 5.6, 96 5.0, 128 5.6, 175 8.0 with 80 ms outliers
 // (profiles/r02_scan_trace.txt).
 static constexpr int kMaxParseThreads = 96;
+static constexpr int kMaxParseThreadsBig = 48;
 
 int gfm_tsv_detail::pick_threads(const char *const *paths, int n_paths, int requested)
 {
@@ -213,6 +170,11 @@ int gfm_tsv_detail::pick_threads(const char *const *paths, int n_paths, int requ
     const unsigned long long by_size = bytes >> 20;
     if ((unsigned long long)nt > by_size) nt = (int)(by_size < 1 ? 1 : by_size);
     if (nt > kMaxParseThreads) nt = kMaxParseThreads;
+    // Text that no longer fits the last-level caches (the page cache is then read from DRAM by every thread's
+    // read()): 24..64 threads all take ~80 ms for 1.84 GB in 10 000 files on a 2 x 64-core host, 96 threads 85..170 ms
+    // (scripts/ingest_probe.py, profiles/r03_ingest_probe.txt) -- the kernel's copy out of the page cache saturates
+    // near 40 GB/s whatever the thread count, and more threads only queue up behind it.
+    if (bytes > (1ull << 30) && nt > kMaxParseThreadsBig) nt = kMaxParseThreadsBig;
     return nt;
 }
 
@@ -227,7 +189,7 @@ void gfm_tsv::index_rows()
     for (size_t i = 0; i < n_paths; ++i) {
         FileCols &f = files[i];
         row_base[i] = total;
-        total += (int64_t)f.start.size();
+        total += f.rows();
         auto &rm = remap[i];
         rm.resize(f.names.size());
         for (size_t k = 0; k < f.names.size(); ++k) {

@@ -77,6 +77,15 @@ class ScanBackend:
         """-> (logodds f64, pvalue f64)"""
         raise NotImplementedError
 
+    # ---- the file-level form (compute_results_sharded): one streamed pass over this rank's TSV files
+    def begin(self, motifs, files, width, no_reverse, threads, threshold, on_qvalue, want_qvalues):
+        """Parse + score `files` for `motifs` (one width) -> a shard scan: .n rows scored on this rank, .device,
+        .hist (torch int64 [M, L] on .device: every motif's score histogram, complete), and .finish() -> (list of
+        per-motif hit tables -- rows (ids local to this rank's files, ascending), scaled, logodds, pvalue,
+        qvalue or None, kmers, start, stop, strand, freq, is_ref, name_id -- and the list of REGION names name_id
+        indexes) computed from .hist AS IT IS THEN (the caller all-reduces it in between)."""
+        raise NotImplementedError
+
 
 class HipBackend(ScanBackend):
     """The product backend: DeviceMotif on the current GPU."""
@@ -116,6 +125,41 @@ class HipBackend(ScanBackend):
         score_multi([b.dm for b in backends], d_k, [b._scores for b in backends],
                     hists=[hist[j] for j in range(len(backends))])
         return hist
+
+    @staticmethod
+    def begin(motifs, files, width, no_reverse, threads, threshold, on_qvalue, want_qvalues):
+        """The product's shard scan: gfm_scan_tsv_begin / _finish (score_sequences.StreamScan) over this rank's files,
+        the histograms in a torch tensor so that the all-reduce runs where they live."""
+        import torch
+        from .device import DeviceMotif
+        from .score_sequences import StreamScan
+        dev = torch.device("cuda", torch.cuda.current_device())
+        dms = [DeviceMotif.from_motif(m) for m in motifs]
+
+        class HipShardScan:
+            device = dev
+
+            def __init__(self):
+                self.hist = torch.zeros((len(dms), dms[0].L), dtype=torch.int64, device=dev)
+                try:
+                    self.scan = StreamScan(dms, files, no_reverse, threads, threshold, on_qvalue, want_qvalues,
+                                           hists=[self.hist[j] for j in range(len(dms))], defer=True)
+                except Exception:
+                    for d in dms:
+                        d.close()
+                    raise
+                self.n = self.scan.n
+
+            def finish(self):
+                try:
+                    torch.cuda.synchronize(dev)          # the caller's all-reduce of self.hist is complete
+                    self.scan.finish()
+                    return self.scan.hits, self.scan.names
+                finally:
+                    for d in dms:
+                        d.close()
+
+        return HipShardScan()
 
     def tables(self, hist, threshold, on_qvalue):
         torch = self.torch
@@ -317,75 +361,134 @@ def gather_names(names: Sequence[str], device, group=None):
     return out
 
 
-def compute_results_sharded(motif: Motif, sequence_loc: str, debug: bool, args_obj, group=None,
-                            backend: Optional[ScanBackend] = None) -> Optional[pd.DataFrame]:
-    """compute_results (score_sequences.py:44-211) with the TSV files sharded over the ranks of
-    `group`.  Every rank calls it; rank 0 gets the report table, the others None."""
-    from .score_sequences import KmerTable, print_scoring_msg
+def _parse_threads(cores: int, world: int) -> int:
+    """Parse threads of one rank: the ranks of a node share its cores (eight ranks x 96 threads would fight over
+    256 of them), so every rank takes its share."""
+    share = max(1, (os.cpu_count() or 1) // max(1, world))
+    return max(1, min(int(cores) if cores and cores > 0 else share, share))
+
+
+def _scan_width_sharded(motifs, files, width, args_obj, group, backend, debug):
+    """One streamed pass per rank over its shard of `files` for `motifs` (one width); histogram all-reduce between
+    the scoring phase and the tables; hit rows to rank 0 as packed columns.  -> (per-motif column dicts on rank 0
+    / None elsewhere, the merged REGION names on rank 0, rows scored over all ranks)."""
+    import torch
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     threshold = float(args_obj.threshold)
     no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
-    no_reverse, recomb = bool(args_obj.noreverse), bool(args_obj.recomb)
-    if qval_t and no_qvalue:
-        raise ValueError("q-value threshold without q-values")
-    if rank == 0:
-        print_scoring_msg(motif, no_reverse, debug)
-    width = motif.width
-    files = sorted(glob.glob(os.path.join(sequence_loc, f"width_{width}", "*.tsv")))
+    no_reverse = bool(args_obj.noreverse)
     mine = shard_files(files, world, rank)
-    table = KmerTable(mine, width, no_reverse, max(1, int(args_obj.cores)))
-    own_backend = backend is None
-    if own_backend:
-        backend = HipBackend(motif)
-    try:
-        res = sharded_scan(backend, table.kmers, threshold, qval_t, not no_qvalue, group=group,
-                           select=getattr(backend, "select_host", None))
-    finally:
-        if own_backend:
-            backend.close()
-    if res["n_scored"] == 0:
+    factory = backend if backend is not None else HipBackend
+    scan = factory.begin(motifs, mine, width, no_reverse, _parse_threads(int(args_obj.cores), world), threshold, qval_t,
+                         not no_qvalue)
+    dev = scan.device
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    counts[rank] = scan.n
+    if world > 1:
+        dist.all_reduce(counts, group=group)
+    counts = counts.cpu().numpy()
+    row_base, n_global = int(counts[:rank].sum()), int(counts.sum())
+    if not no_qvalue and world > 1:
+        dist.all_reduce(scan.hist, group=group)          # the one data-path exchange: [M, L] in one collective
+    hits, names = scan.finish()
+    if n_global == 0:
         errmsg = "No result retrieved. Unable to proceed.\n"
         errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
         exception_handler(ValueError, errmsg, debug)
-    # hit rows travel to rank 0 as packed columns (one padded tensor gather); rank 0 derives log-odds, p- and
-    # q-values from the scaled scores -- every rank holds the same tables -- and builds the report table
-    local = res["rows"] - res["row_base"]
-    cols = dict(rows=res["rows"].astype(np.int64), scaled=res["scaled"].astype(np.int32),
-                logodds=np.asarray(res["logodds"], dtype=np.float64), pvalue=np.asarray(res["pvalue"], dtype=np.float64),
-                start=table.start[local], stop=table.stop[local], strand=table.strand[local], freq=table.freq[local],
-                is_ref=table.is_ref[local], name_id=table.name_id[local].astype(np.int32),
-                kmers=table.kmers[local].reshape(len(local), width))
-    if not no_qvalue:
-        cols["qvalue"] = np.asarray(res["qvalue"], dtype=np.float64)
-    got = gather_columns(cols, backend.device, group)
-    name_lists = gather_names(table.names, backend.device, group)
+    bases = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+    name_lists = gather_names(names, dev, group)
+    out = []
+    for h in hits:
+        # hit rows travel to rank 0 as packed columns (one padded tensor gather per motif)
+        cols = dict(rows=np.asarray(h.rows, dtype=np.int64) + row_base, scaled=np.asarray(h.scaled, dtype=np.int32),
+                    logodds=np.asarray(h.logodds, dtype=np.float64), pvalue=np.asarray(h.pvalue, dtype=np.float64),
+                    start=np.asarray(h.start, dtype=np.int64), stop=np.asarray(h.stop, dtype=np.int64),
+                    strand=np.asarray(h.strand, dtype=np.uint8), freq=np.asarray(h.freq, dtype=np.int64),
+                    is_ref=np.asarray(h.is_ref, dtype=np.uint8), name_id=np.asarray(h.name_id, dtype=np.int32),
+                    kmers=np.asarray(h.kmers, dtype=np.uint8).reshape(len(h.rows), width))
+        if not no_qvalue:
+            cols["qvalue"] = np.asarray(h.qvalue, dtype=np.float64)
+        got = gather_columns(cols, dev, group)
+        if rank == 0:
+            if world > 1:
+                # rows ascend with the rank (contiguous shards): rank of a hit = how many shard bases lie at or below it
+                owner = np.searchsorted(bases, got["rows"], side="right") - 1
+                shift = np.cumsum([0] + [len(lst) for lst in name_lists])[:-1]
+                got["name_ix"] = got["name_id"].astype(np.int64) + shift[owner]
+            else:
+                got["name_ix"] = got["name_id"].astype(np.int64)
+        out.append(got if rank == 0 else None)
+    all_names = [n for lst in name_lists for n in lst] if rank == 0 else None
+    return out, all_names, n_global
+
+
+def _frame_from_columns(motif, got, all_names, no_qvalue, recomb):
+    names_arr = np.array(all_names, dtype=object)
+    return build_frame(
+        motif,
+        seqnames=list(names_arr[got["name_ix"]]) if len(got["name_ix"]) else [],
+        starts=got["start"], stops=got["stop"],
+        strands=[chr(c) for c in got["strand"]],
+        scores=got["logodds"], pvalues=got["pvalue"],
+        qvalues=None if no_qvalue else got["qvalue"],
+        seqs=[bytes(k).decode() for k in got["kmers"]],
+        frequencies=got["freq"],
+        references=["ref" if r else "non.ref" for r in got["is_ref"]],
+        threshold=None, recomb=recomb,
+    )
+
+
+def compute_results_sharded(motif: Motif, sequence_loc: str, debug: bool, args_obj, group=None,
+                            backend: Optional[ScanBackend] = None) -> Optional[pd.DataFrame]:
+    """compute_results (score_sequences.py:44-211) with the TSV files sharded over the ranks of `group`: every rank
+    runs the streamed scan (parse threads -> pinned chunks -> score kernel per chunk) over its own files, the score
+    histogram is all-reduced between the scoring phase and the q-table, the hit rows are gathered.  Every rank calls
+    it; rank 0 gets the report table, the others None.  `backend`: the test seam (an object with ScanBackend.begin);
+    None = the HIP path."""
+    from .score_sequences import print_scoring_msg
+    dist = _dist()
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
+    if qval_t and no_qvalue:
+        raise ValueError("q-value threshold without q-values")
+    if rank == 0:
+        print_scoring_msg(motif, bool(args_obj.noreverse), debug)
+    width = motif.width
+    files = sorted(glob.glob(os.path.join(sequence_loc, f"width_{width}", "*.tsv")))
+    got, all_names, n_global = _scan_width_sharded([motif], files, width, args_obj, group, backend, debug)
     out = None
     if rank == 0:
-        all_names = [n for lst in name_lists for n in lst]
-        if world > 1:
-            # rows ascend with the rank (contiguous shards): rank of a hit = how many shard bases lie at or below it
-            bases = np.asarray(res["shard_bases"], dtype=np.int64)
-            owner = np.searchsorted(bases, got["rows"], side="right") - 1
-            shift = np.cumsum([0] + [len(lst) for lst in name_lists])[:-1]
-            name_ix = got["name_id"].astype(np.int64) + shift[owner]
-        else:
-            name_ix = got["name_id"].astype(np.int64)
-        names_arr = np.array(all_names, dtype=object)
-        out = build_frame(
-            motif,
-            seqnames=list(names_arr[name_ix]) if len(name_ix) else [],
-            starts=got["start"], stops=got["stop"],
-            strands=[chr(c) for c in got["strand"]],
-            scores=got["logodds"], pvalues=got["pvalue"],
-            qvalues=None if no_qvalue else got["qvalue"],
-            seqs=[bytes(k).decode() for k in got["kmers"]],
-            frequencies=got["freq"],
-            references=["ref" if r else "non.ref" for r in got["is_ref"]],
-            threshold=None, recomb=recomb,
-        )
-    if rank == 0:
-        print(f"Scanned sequences:\t{res['n_scored']}")
-        print(f"Scanned nucleotides:\t{res['n_scored'] * width}")
+        out = _frame_from_columns(motif, got[0], all_names, no_qvalue, bool(args_obj.recomb))
+        print(f"Scanned sequences:\t{n_global}")
+        print(f"Scanned nucleotides:\t{n_global * width}")
+    return out
+
+
+def compute_results_many_sharded(motifs: Sequence[Motif], sequence_loc: str, debug: bool, args_obj, group=None,
+                                 backend: Optional[ScanBackend] = None):
+    """score_sequences.compute_results_many under torch.distributed: per width ONE streamed pass per rank for all
+    motifs of that width, their M histograms all-reduced as one [M, L] tensor.  Rank 0 gets the tables in the order
+    of `motifs`, the others a list of None."""
+    from .score_sequences import print_scoring_msg
+    dist = _dist()
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    no_qvalue = bool(args_obj.noqvalue)
+    if bool(args_obj.qvalueT) and no_qvalue:
+        raise ValueError("q-value threshold without q-values")
+    out = [None] * len(motifs)
+    by_width = {}
+    for i, m in enumerate(motifs):
+        by_width.setdefault(m.width, []).append(i)
+    for width, idxs in by_width.items():
+        files = sorted(glob.glob(os.path.join(sequence_loc, f"width_{width}", "*.tsv")))
+        got, all_names, n_global = _scan_width_sharded([motifs[i] for i in idxs], files, width, args_obj, group, backend,
+                                                       debug)
+        if rank == 0:
+            for i, g in zip(idxs, got):
+                print_scoring_msg(motifs[i], bool(args_obj.noreverse), debug)
+                print(f"Scanned sequences:\t{n_global}")
+                print(f"Scanned nucleotides:\t{n_global * width}")
+                out[i] = _frame_from_columns(motifs[i], g, all_names, no_qvalue, bool(args_obj.recomb))
     return out

@@ -63,41 +63,77 @@ class KmerTable:
             nv.lib().gfm_tsv_close(h)
 
 
-class StreamScan:
-    """gfm_scan_tsv: the TSV files of one width parsed, uploaded and scored as one pipelined pass (parse
-    threads -> pinned chunks -> copy stream -> score kernel per chunk); only the hit rows -- with the
-    columns of their TSV rows -- come back.  .n rows were scored; .stats holds the timing split."""
+class ScanHits:
+    """The hit rows of one motif of a streamed scan, ascending by row id, each with the columns of its TSV row."""
 
-    def __init__(self, dm: DeviceMotif, paths: List[str], skip_reverse: bool, threads: int, threshold: float,
-                 on_qvalue: bool, want_qvalues: bool, chunk_rows: int = 0):
+    def __init__(self, h, j: int, K: int, width: int, want_qvalues: bool):
+        self.n_hits = K
+        self.rows = np.empty(K, dtype=np.int64)
+        self.scaled = np.empty(K, dtype=np.int32)
+        self.logodds = np.empty(K, dtype=np.float64)
+        self.pvalue = np.empty(K, dtype=np.float64)
+        self.qvalue = np.empty(K, dtype=np.float64) if want_qvalues else None
+        self.kmers = np.empty((K, width), dtype=np.uint8)
+        self.start = np.empty(K, dtype=np.int64)
+        self.stop = np.empty(K, dtype=np.int64)
+        self.strand = np.empty(K, dtype=np.uint8)
+        self.freq = np.empty(K, dtype=np.int64)
+        self.is_ref = np.empty(K, dtype=np.uint8)
+        self.name_id = np.empty(K, dtype=np.int32)
+        nv.check(nv.lib().gfm_scan_hits_of(h, j, nv.ptr(self.rows), nv.ptr(self.scaled), nv.ptr(self.logodds),
+                                           nv.ptr(self.pvalue), nv.ptr(self.qvalue), nv.ptr(self.kmers),
+                                           nv.ptr(self.start), nv.ptr(self.stop), nv.ptr(self.strand),
+                                           nv.ptr(self.freq), nv.ptr(self.is_ref), nv.ptr(self.name_id)))
+
+
+class StreamScan:
+    """gfm_scan_tsv_begin / _finish: the TSV files of one width parsed, uploaded and scored as one pipelined pass
+    (parse threads -> pinned chunks -> copy stream -> score kernel per chunk); only the hit rows -- with the
+    columns of their TSV rows -- come back.  `dm`: one DeviceMotif, or several of ONE width (they share the pass:
+    every chunk is read once per group of up to three motifs).  .n rows were scored; .stats holds the timing split;
+    .hits[j] are motif j's rows (one motif: also as attributes of the scan itself).
+
+    `hists`: torch int64 tensors [L] (one per motif, on the motifs' device) that receive the score histograms
+    instead of the library's own buffers, and `defer=True` stops after the scoring phase: a sharded caller
+    all-reduces the tensors over its process group, synchronises, then calls finish() (distributed.py)."""
+
+    def __init__(self, dm, paths: List[str], skip_reverse: bool, threads: int, threshold: float,
+                 on_qvalue: bool, want_qvalues: bool, chunk_rows: int = 0, hists=None, defer: bool = False):
+        self.dms = list(dm) if isinstance(dm, (list, tuple)) else [dm]
+        M = len(self.dms)
+        self.width = self.dms[0].width
+        self.want_qvalues = bool(want_qvalues)
         arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+        handles = (ctypes.c_void_p * M)(*[d.handle for d in self.dms])
+        hist_ptrs = None
+        if hists is not None:
+            if len(hists) != M:
+                raise ValueError("one histogram tensor per motif")
+            hist_ptrs = (ctypes.c_void_p * M)(*[t.data_ptr() for t in hists])
         h = ctypes.c_void_p()
-        n, k = ctypes.c_int64(), ctypes.c_int64()
-        nv.check(nv.lib().gfm_scan_tsv(dm.handle, arr, len(paths), int(bool(skip_reverse)), int(threads),
-                                       float(threshold), int(bool(on_qvalue)), int(bool(want_qvalues)),
-                                       int(chunk_rows), ctypes.byref(h), ctypes.byref(n), ctypes.byref(k)))
+        n = ctypes.c_int64()
+        nv.check(nv.lib().gfm_scan_tsv_begin(handles, M, arr, len(paths), int(bool(skip_reverse)), int(threads),
+                                             float(threshold), int(bool(on_qvalue)), int(bool(want_qvalues)),
+                                             int(chunk_rows), hist_ptrs, ctypes.byref(h), ctypes.byref(n)))
+        self._h = h
+        self._hists = hists             # kept alive until finish()
+        self.n = int(n.value)
+        self.hits = None
+        if not defer:
+            self.finish()
+
+    def finish(self):
+        """Second phase: q-tables and cutoffs from the histograms as they are now, selection, hits back."""
+        if self._h is None:
+            raise RuntimeError("the scan is closed")
+        M = len(self.dms)
         try:
-            self.n, self.n_hits, self.width = int(n.value), int(k.value), dm.width
-            K = self.n_hits
-            self.rows = np.empty(K, dtype=np.int64)
-            self.scaled = np.empty(K, dtype=np.int32)
-            self.logodds = np.empty(K, dtype=np.float64)
-            self.pvalue = np.empty(K, dtype=np.float64)
-            self.qvalue = np.empty(K, dtype=np.float64) if want_qvalues else None
-            self.kmers = np.empty((K, dm.width), dtype=np.uint8)
-            self.start = np.empty(K, dtype=np.int64)
-            self.stop = np.empty(K, dtype=np.int64)
-            self.strand = np.empty(K, dtype=np.uint8)
-            self.freq = np.empty(K, dtype=np.int64)
-            self.is_ref = np.empty(K, dtype=np.uint8)
-            self.name_id = np.empty(K, dtype=np.int32)
-            nv.check(nv.lib().gfm_scan_hits(h, nv.ptr(self.rows), nv.ptr(self.scaled), nv.ptr(self.logodds),
-                                            nv.ptr(self.pvalue), nv.ptr(self.qvalue), nv.ptr(self.kmers),
-                                            nv.ptr(self.start), nv.ptr(self.stop), nv.ptr(self.strand),
-                                            nv.ptr(self.freq), nv.ptr(self.is_ref), nv.ptr(self.name_id)))
+            counts = (ctypes.c_int64 * M)()
+            nv.check(nv.lib().gfm_scan_tsv_finish(self._h, counts))
+            self.hits = [ScanHits(self._h, j, int(counts[j]), self.width, self.want_qvalues) for j in range(M)]
             self.stats = nv.ScanStats()
-            nv.check(nv.lib().gfm_scan_stats(h, ctypes.byref(self.stats)))
-            t = nv.lib().gfm_scan_table(h)
+            nv.check(nv.lib().gfm_scan_stats(self._h, ctypes.byref(self.stats)))
+            t = nv.lib().gfm_scan_table(self._h)
             cnt = nv.lib().gfm_tsv_name_count(t)
             nbytes = int(nv.lib().gfm_tsv_names_bytes(t))
             off = np.empty(cnt + 1, dtype=np.int64)
@@ -106,7 +142,23 @@ class StreamScan:
             raw = buf.tobytes()
             self.names = [raw[off[i]:off[i + 1]].decode() for i in range(cnt)]
         finally:
-            nv.lib().gfm_scan_close(h)
+            self.close()
+        first = self.hits[0]                # one motif: the hit columns as attributes of the scan, as before
+        for k, v in vars(first).items():
+            setattr(self, k, v)
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            nv.lib().gfm_scan_close(self._h)
+            self._h = None
+            self._hists = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def print_scoring_msg(motif: Motif, noreverse: bool, debug: bool) -> None:
@@ -198,49 +250,35 @@ def compute_results(motif: Motif, sequence_loc: str, debug: bool, args_obj=None,
     print(f"Scanned nucleotides:\t{scan.n * width}")
 
     start_df = time.time()
-    names = np.array(scan.names, dtype=object)
-    df = build_frame(
-        motif,
-        seqnames=list(names[scan.name_id]) if scan.n_hits else [],
-        starts=scan.start,
-        stops=scan.stop,
-        strands=[chr(c) for c in scan.strand],
-        scores=scan.logodds,
-        pvalues=scan.pvalue,
-        qvalues=None if no_qvalue else scan.qvalue,
-        seqs=[bytes(k).decode() for k in scan.kmers],
-        frequencies=scan.freq,
-        references=["ref" if r else "non.ref" for r in scan.is_ref],
-        threshold=None, recomb=bool(recomb),
-    )
+    df = _frame_from_scan(motif, scan.hits[0], np.array(scan.names, dtype=object), no_qvalue, recomb)
     if verbose:
         print("\nResults summary built in %.2fs" % (time.time() - start_df))
     return df
 
 
-def _frame_from_hits(motif: Motif, table: "KmerTable", rows, logodds, pvalue, qvalue, recomb: bool) -> pd.DataFrame:
-    names = np.array(table.names, dtype=object)
+def _frame_from_scan(motif: Motif, hits: "ScanHits", names, no_qvalue: bool, recomb: bool) -> pd.DataFrame:
+    """The report table of one motif from the hit rows of a streamed scan (names: the scan's REGION strings)."""
     return build_frame(
         motif,
-        seqnames=list(names[table.name_id[rows]]),
-        starts=table.start[rows], stops=table.stop[rows],
-        strands=[chr(c) for c in table.strand[rows]],
-        scores=logodds, pvalues=pvalue, qvalues=qvalue,
-        seqs=[bytes(k).decode() for k in table.kmers[rows]],
-        frequencies=table.freq[rows],
-        references=["ref" if r else "non.ref" for r in table.is_ref[rows]],
+        seqnames=list(names[hits.name_id]) if hits.n_hits else [],
+        starts=hits.start, stops=hits.stop,
+        strands=[chr(c) for c in hits.strand],
+        scores=hits.logodds, pvalues=hits.pvalue,
+        qvalues=None if no_qvalue else hits.qvalue,
+        seqs=[bytes(k).decode() for k in hits.kmers],
+        frequencies=hits.freq,
+        references=["ref" if r else "non.ref" for r in hits.is_ref],
         threshold=None, recomb=bool(recomb),
     )
 
 
 def compute_results_many(motifs: List[Motif], sequence_loc: str, debug: bool, args_obj) -> List[pd.DataFrame]:
     """compute_results for a whole motif set (the `for motif in motif_set` loop of grafimo.findmotif,
-    grafimo.py:177-183) without repeating the shared work: the TSV files of a width are parsed and
-    uploaded ONCE for all motifs of that width, and up to three motifs share each read of the k-mers
-    on the device (gfm_score_kmers_multi).  Returns the tables in the order of `motifs`; every table
-    equals compute_results(motif, ...) and the same lines are printed per motif."""
-    import torch
-    from .scan import scan_same_width
+    grafimo.py:177-183) without repeating the shared work: the TSV files of a width go through ONE streamed pass for
+    all motifs of that width (gfm_scan_tsv_begin / _finish: parsed and uploaded once, every chunk scored by
+    gfm_score_kmers_multi -- up to three motifs share each read of the k-mers on the device).  Returns the tables
+    in the order of `motifs`; every table equals compute_results(motif, ...) and the same lines are printed per
+    motif."""
     if not is_findmotif_like(args_obj):
         exception_handler(TypeError, f"Expected Findmotif, got {type(args_obj).__name__}.\n", debug)
     threshold = float(args_obj.threshold)
@@ -255,27 +293,26 @@ def compute_results_many(motifs: List[Motif], sequence_loc: str, debug: bool, ar
         by_width.setdefault(m.width, []).append(i)
     for width, idxs in by_width.items():
         files = sorted(glob.glob(os.path.join(sequence_loc, f"width_{width}", "*.tsv")))
-        try:
-            table = KmerTable(files, width, no_reverse, max(1, int(args_obj.cores)))
-        except nv.NativeError as e:
-            exception_handler(ValueError if e.code == nv.GFM_ERR_IO else RuntimeError, e.msg + "\n", debug)
-        if table.n == 0:
-            errmsg = "No result retrieved. Unable to proceed.\n"
-            errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
-            exception_handler(ValueError, errmsg, debug)
-        d_kmers = torch.from_numpy(table.kmers).cuda()
+        no_rows = "No result retrieved. Unable to proceed.\n"
+        no_rows += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
+        if not files:
+            exception_handler(ValueError, no_rows, debug)
         dms = [DeviceMotif.from_motif(motifs[i]) for i in idxs]
         try:
-            results = scan_same_width(dms, d_kmers, threshold, on_qvalue=qval_t, want_qvalues=not no_qvalue)
-            for i, dm, res in zip(idxs, dms, results):
+            try:
+                scan = StreamScan(dms, files, no_reverse, max(1, int(args_obj.cores)), threshold, qval_t, not no_qvalue)
+            except nv.NativeError as e:
+                exception_handler(ValueError if e.code == nv.GFM_ERR_IO else RuntimeError, e.msg + "\n", debug)
+            if scan.n == 0:
+                exception_handler(ValueError, no_rows, debug)
+            names = np.array(scan.names, dtype=object)
+            for i, hits in zip(idxs, scan.hits):
                 print_scoring_msg(motifs[i], no_reverse, debug)
                 if not no_qvalue:
                     print("\nComputing q-values...\n")
-                lo, pv = dm.annotate(res["scaled"])
-                print(f"Scanned sequences:\t{table.n}")
-                print(f"Scanned nucleotides:\t{table.n * width}")
-                out[i] = _frame_from_hits(motifs[i], table, res["rows"], lo, pv,
-                                          None if no_qvalue else res["qtable"][res["scaled"]], recomb)
+                print(f"Scanned sequences:\t{scan.n}")
+                print(f"Scanned nucleotides:\t{scan.n * width}")
+                out[i] = _frame_from_scan(motifs[i], hits, names, no_qvalue, recomb)
         finally:
             for dm in dms:
                 dm.close()

@@ -266,6 +266,23 @@ typedef struct gfm_scan_stats {
 int gfm_scan_tsv(gfm_motif_t m, const char *const *paths, int n_paths, int skip_reverse, int n_threads,
                  double threshold, int on_qvalue, int want_qvalues, int64_t chunk_rows, gfm_scan_t *out,
                  int64_t *n_rows, int64_t *n_hits);
+/* The same pass in two phases and for several motifs of ONE width (each chunk is scored by gfm_score_kmers_multi: one
+ * read of the k-mers per group of up to three motifs) -- what compute_results_many and the sharded scan
+ * (grafimo_amd/distributed.py) run: the reference's loop over a motif set (grafimo.py:177-183) repeats ingest and
+ * scoring per motif, and its multiprocessing has no second phase because it has no second machine.
+ * gfm_scan_tsv_begin parses, uploads and scores; when it returns every motif's histogram is complete on the device
+ * (d_hist[j]: the caller's buffers of L uint64 each -- zeroed here -- or NULL for the library's own) and *n_rows rows
+ * were scored.  A sharded caller now all-reduces its histogram buffers over the ranks (and synchronises).
+ * gfm_scan_tsv_finish derives the q-tables and cutoffs from the histograms as they are then, selects, and brings the
+ * hits back: n_hits[j] rows for motif j (n_hits may be NULL).  Row ids are local to this call's files. */
+int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const char *const *paths, int n_paths,
+                       int skip_reverse, int n_threads, double threshold, int on_qvalue, int want_qvalues,
+                       int64_t chunk_rows, uint64_t *const *d_hist, gfm_scan_t *out, int64_t *n_rows);
+int gfm_scan_tsv_finish(gfm_scan_t s, int64_t *n_hits);
+/* gfm_scan_hits for motif `motif` of a multi-motif scan */
+int gfm_scan_hits_of(gfm_scan_t s, int motif, int64_t *rows, int32_t *scaled, double *logodds, double *pvalue,
+                     double *qvalue, uint8_t *kmers, int64_t *start, int64_t *stop, uint8_t *strand,
+                     int64_t *freq, uint8_t *is_ref, int32_t *name_id);
 /* The hit rows ascending by row id, each with the columns of its TSV row (any pointer may be NULL;
  * n_hits entries each, kmers n_hits x W bytes; qvalue only if the scan computed q-values). */
 int gfm_scan_hits(gfm_scan_t s, int64_t *rows, int32_t *scaled, double *logodds, double *pvalue,
