@@ -37,7 +37,8 @@ extern "C" void gfm_set_error_(const char *msg);
 
 namespace {
 
-constexpr int kMaxAlts = 3;
+constexpr int kMaxAlts = 3;          // alternates of one substitution site (four bases: there cannot be more)
+constexpr int kMaxRecordAlts = 16;   // ALT alleles taken from one record (insertions and deletions are sites of their own)
 
 // One alternate allele of a record, taken apart (oracle/extract_oracle.py read_vcf_variants states the rules):
 // kind 0 a single-base substitution at `pos`, 1 an insertion behind the anchor `pos`, 2 a deletion behind it.
@@ -95,13 +96,13 @@ void parse_line(const char *b, const char *e, bool want_hap, Chunk &out)
     bool ref_ok = ref_len > 0;
     for (const char *q = ref_b; q < ref_e && ref_ok; ++q) ref_ok = is_base(up(*q)) || up(*q) == 'N';
     // ALT list
-    const char *ab[16];
-    long al[16];
+    const char *ab[kMaxRecordAlts];
+    long al[kMaxRecordAlts];
     int na = 0;
     for (const char *q = alt_b; q <= alt_e;) {
         const char *c = static_cast<const char *>(memchr(q, ',', (size_t)(alt_e - q)));
         const char *qe = c ? c : alt_e;
-        if (na < 16) { ab[na] = q; al[na] = (long)(qe - q); }
+        if (na < kMaxRecordAlts) { ab[na] = q; al[na] = (long)(qe - q); }
         ++na;
         if (!c) break;
         q = c + 1;
@@ -111,7 +112,7 @@ void parse_line(const char *b, const char *e, bool want_hap, Chunk &out)
     std::vector<int> &allele_of_atom = out.allele_of_atom;
     allele_of_atom.clear();
     for (int k = 0; k < na; ++k) {
-        bool ok = ref_ok && k < kMaxAlts && k < 16 && al[k] > 0;
+        bool ok = ref_ok && k < kMaxRecordAlts && al[k] > 0;
         for (long j = 0; ok && j < al[k]; ++j) ok = is_base(up(ab[k][j]));
         if (ok && ref_len == 1 && al[k] == 1) {
             Atom a; a.pos = pos; a.kind = 0; a.base = (uint8_t)up(ab[k][0]);
@@ -170,7 +171,8 @@ void parse_line(const char *b, const char *e, bool want_hap, Chunk &out)
         if (H != out.n_hap) { out.error = "VCF records with different numbers of samples"; return; }
         const int hw = (H + 63) / 64;
         // one carrier bitset per ALT of the record that yielded atoms; the atoms of one ALT share it
-        size_t at_of_allele[kMaxAlts] = {(size_t)-1, (size_t)-1, (size_t)-1};
+        size_t at_of_allele[kMaxRecordAlts];
+        for (int k = 0; k < kMaxRecordAlts; ++k) at_of_allele[k] = (size_t)-1;
         for (int t = 0; t < n_new; ++t) {
             const int k = allele_of_atom[(size_t)t];
             if (at_of_allele[k] == (size_t)-1) {

@@ -365,7 +365,7 @@ def enumerate_region_graph(chrom: str, ref: bytes, sites: Sites, dels: Dels, S: 
 #     deleted bases, ALT = anchor), an insertion (REF = anchor, ALT = anchor + inserted bases), a
 #     multi-base substitution of equal length (one substitution per mismatching position, all carried by
 #     the same haplotypes: `vg construct` aligns ALT to REF and cuts the graph at every edit); anything else
-#     is skipped and counted.  Substitutions at one position become ONE site with up to three alternates
+#     is skipped and counted, like the ALT alleles of a record beyond its sixteenth.  Substitutions at one position become ONE site with up to three alternates
 #     (a fourth is skipped); a deletion that touches one accepted before it is skipped (as before).
 #   * walks start on a reference position p (first base: the reference base or a substitution), or on base
 #     t of an insertion anchored at p - 1 (start coordinate p).  Behind the base at position x, with bases
@@ -421,7 +421,7 @@ def read_vcf_variants(path: str, chrom: Optional[str] = None, ref: Optional[byte
             before = len(atoms)
             for k, a in enumerate(alts):
                 car = gts == k + 1
-                ok = all(c in "ACGT" for c in a) and all(c in "ACGTN" for c in r) and len(a) > 0 and k < 3
+                ok = all(c in "ACGT" for c in a) and all(c in "ACGTN" for c in r) and len(a) > 0 and k < 16
                 if ok and len(r) == 1 and len(a) == 1:
                     atoms.append((p, 0, a, car))
                 elif ok and len(r) > 1 and len(a) == 1 and a[0] == r[0]:

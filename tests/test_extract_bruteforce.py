@@ -80,3 +80,28 @@ def test_brute_force_refuses_conflicting_haplotypes(tmp_path):
     s1 = bf.haplotype_sequence(ref, recs, 1)
     assert bytes(s0[0]) == b"ACTAATACGTAC" and s0[1] == [0, 1, 2, 2, 2, 3, 4, 5, 6, 7, 8, 9]
     assert bytes(s1[0]) == b"ACGAATACAC" and s1[1] == [0, 1, 2, 2, 2, 3, 4, 5, 8, 9] and s1[2][3] and s1[2][4]
+
+
+def test_records_with_more_than_three_alt_alleles(tmp_path):
+    """A substitution site has at most three alternates (four bases), but a RECORD may list more alleles -- an STR
+    site with four insertion lengths beside a substitution.  Every one of them is part of the graph (insertions are
+    sites of their own): the C++ reader equals the oracle reader, nothing is skipped, and the enumerator's counts
+    equal the per-haplotype brute force."""
+    from grafimo_amd.extract_regions import GraphIndex
+    from oracle import extract_bruteforce as bf
+    from oracle import extract_oracle as xo
+    ref = "ACGTTGCAATCGGATCCATGCAAGTCTAGGCTTAACG"
+    head = "##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\tb\tc\n"
+    body = ["s\t9\t.\tA\tG,AT,ATT,ATTT,ATTTT\t.\t.\t.\tGT\t1|2\t3|4\t5|0",
+            "s\t20\t.\tG\tGA,GAC,T,C,A,GACA\t.\t.\t.\tGT\t6|3\t4|5\t1|2"]
+    (tmp_path / "m.vcf").write_text(head + "\n".join(body) + "\n")
+    (tmp_path / "m.fa").write_text(">s\n" + ref + "\n")
+    v = xo.read_vcf_variants(str(tmp_path / "m.vcf"), "s")
+    assert v.skipped == 0 and sum(k == 1 for k in v.kind) == 7 and v.alts[[i for i, k in enumerate(v.kind) if k == 0][1]] == ["T", "C", "A"]
+    idx = GraphIndex.from_fasta_vcf(str(tmp_path / "m.fa"), str(tmp_path / "m.vcf"), "s")
+    assert idx.skipped == 0 and int((idx.ins_len > 0).sum()) == 7
+    recs, H = bf.read_vcf_records(str(tmp_path / "m.vcf"), "s")
+    assert H == 6 and bf.consistent(ref.encode(), recs, H)
+    for W in (3, 8, 19):
+        freq, flags = bf.window_counts(ref.encode(), recs, H, 0, len(ref), W)
+        bf.check_rows(_rows(xo.enumerate_region_variants("s", ref.encode(), v, 0, len(ref), W, with_counts=True)), freq, flags)

@@ -477,6 +477,13 @@ def test_hip_rows_equal_the_per_haplotype_brute_force(tmp_path, kinds):
     if kinds == "s":
         cases.append((os.path.join(REF_DATA, "test.fa"), os.path.join(REF_DATA, "test.vcf.gz"), "x",
                       [((0, 20), 19), ((0, 50), 19), ((5, 45), 8), ((0, 50), 30)]))
+    if kinds == "si":     # records with more than three ALT alleles (an STR site: four insertion lengths and a substitution)
+        ref = "ACGTTGCAATCGGATCCATGCAAGTCTAGGCTTAACG"
+        head = "##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ta\tb\tc\n"
+        (tmp_path / "m.vcf").write_text(head + "s\t9\t.\tA\tG,AT,ATT,ATTT,ATTTT\t.\t.\t.\tGT\t1|2\t3|4\t5|0\n"
+                                               "s\t20\t.\tG\tGA,GAC,T,C,A,GACA\t.\t.\t.\tGT\t6|3\t4|5\t1|2\n")
+        (tmp_path / "m.fa").write_text(">s\n" + ref + "\n")
+        cases.append((str(tmp_path / "m.fa"), str(tmp_path / "m.vcf"), "s", [((0, len(ref)), 3), ((0, len(ref)), 8), ((0, len(ref)), 19)]))
     total = 0
     for fasta, vcf, chrom, plans in cases:
         ref = xo.read_fasta(fasta)[chrom]
