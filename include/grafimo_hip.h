@@ -168,7 +168,8 @@ int gfm_profile_read_tail(gfm_motif_t m, float *h_ms_out, int capacity, int *n_o
 /* Measurement aid (bench.py `peak_measured`): what THIS device sustains for a bare stream with the score kernel's
  * byte mix -- every lane issues `loads_per_store` 16-byte non-temporal loads per 16-byte store, loads and stores
  * interleaved in one pass, one step prefetched (the shape score_quad_kernel has; W = 19: 4.75 -> 5 loads per store).
- * in_bytes are read per launch, in_bytes / loads_per_store written, the output rotating over three buffers;
+ * in_bytes are read per launch (two input buffers used in turn), in_bytes / loads_per_store written, the output
+ * rotating over three buffers;
  * store_policy 0 = nt, 1 = write-through (sc0 sc1).  Allocates and frees its own buffers; synchronous.
  * *us_per_launch = average of `launches` launches (HIP events), *bytes_per_launch = bytes read + written. */
 int gfm_calibrate_stream(int loads_per_store, int64_t in_bytes, int store_policy, int launches,
