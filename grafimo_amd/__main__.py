@@ -49,8 +49,8 @@ def get_parser():
     p.add_argument("--chroms-prefix-find", dest="chroms_prefix", default="", metavar="PREFIX",
                    help="chromosome names in the FASTA / VCF = PREFIX + the BED name without its leading chr")
     p.add_argument("--skip-unmodelled-variants", action="store_true", dest="skip_unmodelled",
-                   help="leave ALT alleles the extraction graph does not model (complex alleles, a fourth alternate "
-                        "at one position, a deletion overlapping an earlier one) out instead of failing on them")
+                   help="leave ALT alleles the extraction graph does not model (complex or symbolic alleles, a fourth "
+                        "alternate base at one position) out instead of failing on them")
     p.add_argument("-k", "--bgfile", default=UNIF)
     p.add_argument("-p", "--pseudo", type=float, default=0.1)
     p.add_argument("-t", "--threshold", type=float, default=1e-4)

@@ -61,6 +61,8 @@ struct GraphDev {
     const int *del_len;         // [n_sites] 0 for a SNP, else the number of deleted bases after the anchor
     int n_dels;
     const int *prev_del;        // [n_sites + 1] index of the last deletion among sites [0, i), or -1
+    const long long *max_reach; // [n_sites + 1] last reference position removed by ANY deletion among sites [0, i), or -1
+                                // (deletions may overlap: several lengths at one anchor, anchors inside another's span)
     // insertions (round 2; semantics unpinned, stated in oracle/extract_oracle.py): a site with ins_len > 0 holds
     // ins_len bases behind its anchor `pos`; several may share an anchor (after the SNP, before the deletion)
     const int *ins_len;         // [n_sites]
@@ -85,6 +87,7 @@ struct GraphDev {
 // a window costs one pass per layout, not per walk, and walk q is found by skipping whole layouts.
 // oracle/extract_oracle.py enumerate_region_graph produces the same order.
 constexpr int kMaxDecisions = 24;      // jumps decided by one walk
+constexpr int kMaxConstraints = 96;    // allele constraints of one walk: <= 64 substitution sites + decisions + skipped / covering deletions
 struct WalkState {
     int nd = 0;
     long long last = 0;                       // reference position of the last base
@@ -167,9 +170,9 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, co
                 continue;
             }
         }
-        int snp = -1, del = -1, ins0 = -1, ins1 = -1;       // insertions anchored here: sites [ins0, ins1)
+        int snp = -1, del0 = -1, del1 = -1, ins0 = -1, ins1 = -1;   // insertions / deletions anchored here: sites [a, b)
         for (int k = i; k < g.n_sites && g.pos[k] == x; ++k) {
-            if (g.del_len[k] > 0) del = k;
+            if (g.del_len[k] > 0) { if (del0 < 0) del0 = k; del1 = k + 1; }
             else if (g.ins_len[k] > 0) { if (ins0 < 0) ins0 = k; ins1 = k + 1; }
             else snp = k;
         }
@@ -202,15 +205,33 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, co
             read_ins = true;
             break;
         }
-        if (del >= 0 && !read_ins) {
-            if (d >= kMaxDecisions) { st.nd = d; return WALK_OVERFLOW; }
-            const int c = d < prefix ? st.choice[d] : 0;
-            st.choice[d] = (unsigned char)c;
-            ++d;
-            if (c) { vis.took(del); x += g.del_len[del] + 1; continue; }
-            vis.passed(del);
+        // the deletions anchored here (site order): jump this one?  (0 before 1; a yes ends the site).  A walk that
+        // goes on behind x uses the bases of every deletion it did not jump as far as that one reaches beyond its
+        // landing place: their carriers lack those bases.
+        int jumped = -1;
+        if (!read_ins)
+            for (int k = del0; k >= 0 && k < del1; ++k) {
+                if (d >= kMaxDecisions) { st.nd = d; return WALK_OVERFLOW; }
+                const int c = d < prefix ? st.choice[d] : 0;
+                st.choice[d] = (unsigned char)c;
+                ++d;
+                if (c) { jumped = k; break; }
+            }
+        if (jumped < 0) {
+            for (int k = del0; k >= 0 && k < del1; ++k) vis.passed(k);     // x + 1 lies inside every one of them
+            ++x;
+        } else {
+            vis.took(jumped);
+            const int len = g.del_len[jumped];
+            for (int k = del0; k < del1; ++k)
+                if (k != jumped && g.del_len[k] > len) vis.passed(k);
+            const long long land = x + len + 1;
+            // sites inside the jumped span are never visited; a deletion anchored there that reaches beyond the
+            // landing place has bases the walk uses
+            for (int k = del1; k < g.n_sites && g.pos[k] < land; ++k)
+                if (g.del_len[k] > 0 && (long long)g.pos[k] + g.del_len[k] >= land) vis.passed(k);
+            x = land;
         }
-        ++x;
     }
 }
 
@@ -224,12 +245,19 @@ __device__ inline int next_walk(WalkState &st)
     return t + 1;
 }
 
-// deletion whose deleted bases contain p (the window starts inside it), or -1.  i0 = first site at or
-// after p: deletions do not overlap, so only the last one anchored before p can reach p.
-__device__ inline int cover_deletion(const GraphDev &g, long long p, int i0)
+// Does a deletion anchored before p remove the base at p (the window starts on deleted bases)?  i0 = first site at
+// or after p.  Deletions may overlap, so this asks how far ANY of the earlier ones reaches.
+__device__ inline bool covered_by_deletion(const GraphDev &g, long long p, int i0)
 {
-    const int d = g.prev_del[i0];
-    return (d >= 0 && p <= (long long)g.pos[d] + g.del_len[d]) ? d : -1;
+    return g.max_reach[i0] >= p;
+}
+// f(site) for every deletion anchored before p that removes the base at p: back along the chain of deletions for as
+// long as one of those further back can still reach p
+template <class F>
+__device__ inline void for_covering_deletions(const GraphDev &g, long long p, int i0, F f)
+{
+    for (int d = g.prev_del[i0]; d >= 0 && g.max_reach[d + 1] >= p; d = g.prev_del[d])
+        if ((long long)g.pos[d] + g.del_len[d] >= p) f(d);
 }
 
 __device__ inline int lower_bound_pos(const int *pos, int n, long long v)
@@ -278,7 +306,7 @@ graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ regi
     const long long p = first_start[r] + (w - region_off[r]);
     const int i0 = lower_bound_pos(g.pos, g.n_sites, p);
     long long walks = 1;
-    bool touches_del = g.n_dels > 0 && cover_deletion(g, p, i0) >= 0;
+    bool touches_del = g.n_dels > 0 && covered_by_deletion(g, p, i0);
     bool over = false;      // too many walks for a plain window -- reported only if the window is kept as one
     for (int i = i0; i < g.n_sites && g.pos[i] < p + W; ++i) {
         if (g.del_len[i] || g.ins_len[i]) touches_del = true;
@@ -617,13 +645,13 @@ struct DelEmit {
     uint8_t *fwd, *rev;
     int W;
     int n_cons;
-    int csite[kMaxDecisions + 1];
-    unsigned char ccode[kMaxDecisions + 1];     // allele: SNP 0..3; deletion 1 = jumped, 0 = its bases are used
+    int csite[kMaxConstraints];
+    unsigned char ccode[kMaxConstraints];       // allele: SNP 0..3; deletion 1 = jumped, 0 = its bases are used
     bool alt;
     static constexpr bool kWantsBases = true;
     __device__ void add(int site, int code)
     {
-        if (n_cons <= kMaxDecisions) { csite[n_cons] = site; ccode[n_cons] = (unsigned char)code; ++n_cons; }
+        if (n_cons < kMaxConstraints) { csite[n_cons] = site; ccode[n_cons] = (unsigned char)code; ++n_cons; }
     }
     __device__ void base(int j, long long x, int snp, int a)
     {
@@ -725,8 +753,7 @@ emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ all
         for (int o = 0; o < pitch / 4; ++o) out[o] = reinterpret_cast<const unsigned *>(slot)[o];
     }
     // the window starts on deleted bases: carriers lack them (not for a walk that never leaves the insertion it starts in)
-    const int cover = (ws.site >= 0 && st.last == p - 1) ? -1 : cover_deletion(g, p, i0);
-    if (cover >= 0) em.add(cover, 0);
+    if (!(ws.site >= 0 && st.last == p - 1)) for_covering_deletions(g, p, i0, [&](int dsite) { em.add(dsite, 0); });
     const long long count = count_carriers(g, allele_count, em.n_cons,
                                            [&](int k, int &site, int &a) { site = em.csite[k]; a = em.ccode[k]; });
     long long *meta = stg_meta + (size_t)td * kDelMeta;
@@ -827,6 +854,7 @@ struct gfm_graph {
     int *d_allele_count = nullptr;   // [n_sites][4] haplotypes per allele (0 = reference)
     int *d_pair_count = nullptr, *d_triple_count = nullptr;   // GraphDev::pair_count / triple_count
     int *d_del_len = nullptr, *d_prev_del = nullptr;
+    long long *d_max_reach = nullptr;
     int *d_ins_len = nullptr, *d_ins_off = nullptr;
     uint8_t *d_ins_bases = nullptr;
     // last plan (buffers are kept between plans)
@@ -873,6 +901,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (n_sites && (!h_pos || !h_n_alts || !h_alt_bases)) return gfail(GFM_ERR_INVALID, "NULL site arrays");
     std::vector<int> del_len((size_t)n_sites, 0), prev_del((size_t)n_sites + 1, -1), ins_len((size_t)n_sites, 0),
         ins_off((size_t)n_sites, 0);
+    std::vector<long long> max_reach((size_t)n_sites + 1, -1);
     int n_dels = 0, n_ins = 0;
     long long deleted_until = -1;        // last reference position removed by an earlier deletion
     auto kind_of = [&](int i) { return del_len[(size_t)i] > 0 ? 2 : (ins_len[(size_t)i] > 0 ? 1 : 0); };
@@ -890,9 +919,9 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
             ins_off[(size_t)i] = (int)off;
             ++n_ins;
         }
-        // same position: the substitution site first, then insertions, then the deletion
+        // same position: the substitution site first, then insertions, then the deletions
         const bool tie_ok = i && h_pos[i] == h_pos[i - 1] &&
-                            (kind_of(i) > kind_of(i - 1) || (kind_of(i) == 1 && kind_of(i - 1) == 1));
+                            (kind_of(i) > kind_of(i - 1) || (kind_of(i) == kind_of(i - 1) && kind_of(i) >= 1));
         if (h_pos[i] < 0 || h_pos[i] >= ref_len || (i && h_pos[i] <= h_pos[i - 1] && !tie_ok))
             return gfail(GFM_ERR_INVALID, "site positions must be ascending inside the reference; at one position the "
                                           "substitution site comes first, then insertions, then the deletion (site " +
@@ -903,12 +932,11 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
             return gfail(GFM_ERR_INVALID, "an insertion / a deletion has one alternate allele (site " +
                                               std::to_string(i) + ")");
         if (dl > 0) {
-            if (h_pos[i] <= deleted_until)
-                return gfail(GFM_ERR_INVALID, "deletions must not overlap (site " + std::to_string(i) + ")");
-            deleted_until = (long long)h_pos[i] + dl;
+            deleted_until = std::max(deleted_until, (long long)h_pos[i] + dl);
             ++n_dels;
         }
         prev_del[(size_t)i + 1] = dl > 0 ? i : prev_del[(size_t)i];
+        max_reach[(size_t)i + 1] = deleted_until;
     }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
@@ -925,6 +953,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = upload(&g->d_alt_bases, h_alt_bases, (size_t)n_sites * kMaxAlts);
     if (e == hipSuccess) e = upload(&g->d_del_len, del_len.data(), del_len.size());
     if (e == hipSuccess) e = upload(&g->d_prev_del, prev_del.data(), prev_del.size());
+    if (e == hipSuccess) e = upload(&g->d_max_reach, max_reach.data(), max_reach.size());
     if (e == hipSuccess) e = upload(&g->d_ins_len, ins_len.data(), ins_len.size());
     if (e == hipSuccess) e = upload(&g->d_ins_off, ins_off.data(), ins_off.size());
     if (e == hipSuccess && n_ins) e = upload(&g->d_ins_bases, h_ins_bases, (size_t)ins_bytes);
@@ -937,8 +966,8 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     }
     g->dev = GraphDev{g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
                       bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0,
-                      g->d_del_len, n_dels, g->d_prev_del, g->d_ins_len, g->d_ins_off, g->d_ins_bases, n_ins,
-                      nullptr, nullptr};
+                      g->d_del_len, n_dels, g->d_prev_del, g->d_max_reach, g->d_ins_len, g->d_ins_off, g->d_ins_bases,
+                      n_ins, nullptr, nullptr};
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_planned, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_emitted, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
@@ -983,7 +1012,7 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     (void)hipFree(g->d_ref); (void)hipFree(g->d_pos); (void)hipFree(g->d_n_alts);
     (void)hipFree(g->d_alt_bases); (void)hipFree(g->d_alt_bits); (void)hipFree(g->d_allele_count);
     (void)hipFree(g->d_pair_count); (void)hipFree(g->d_triple_count);
-    (void)hipFree(g->d_del_len); (void)hipFree(g->d_prev_del);
+    (void)hipFree(g->d_del_len); (void)hipFree(g->d_prev_del); (void)hipFree(g->d_max_reach);
     (void)hipFree(g->d_ins_len); (void)hipFree(g->d_ins_off); (void)hipFree(g->d_ins_bases);
     if (g->ev_planned) (void)hipEventDestroy(g->ev_planned);
     if (g->ev_emitted) (void)hipEventDestroy(g->ev_emitted);

@@ -4,9 +4,9 @@
 // (src/grafimo/constructVG.py:332,394).  For the extraction kernels (graph_extract.hip) the records
 // of one chromosome are taken apart per ALT allele: single-base substitutions (one site per position, up
 // to 3 alternates, also when they come from several records), insertions (REF = anchor, ALT = anchor +
-// inserted bases), deletions (REF = anchor + deleted bases, ALT = anchor; one that touches a deletion
-// accepted before it is skipped), multi-base substitutions of equal length (one substitution per
-// mismatching position); everything else is skipped and counted -- the rules
+// inserted bases), deletions (REF = anchor + deleted bases, ALT = anchor; they may overlap), multi-base
+// substitutions of equal length (one substitution per mismatching position) -- every ALT normalised against REF
+// first (common trailing, then leading bases dropped); everything else is skipped and counted -- the rules
 // oracle/extract_oracle.py read_vcf_variants states.  Genotypes: two haplotypes per sample in
 // file order ("a|b", "a/b" taken as written, a single allele doubled, "." = reference); per
 // alternate allele one bitset over the haplotypes, bit h of word h / 64.
@@ -114,20 +114,32 @@ void parse_line(const char *b, const char *e, bool want_hap, Chunk &out)
     for (int k = 0; k < na; ++k) {
         bool ok = ref_ok && k < kMaxRecordAlts && al[k] > 0;
         for (long j = 0; ok && j < al[k]; ++j) ok = is_base(up(ab[k][j]));
-        if (ok && ref_len == 1 && al[k] == 1) {
-            Atom a; a.pos = pos; a.kind = 0; a.base = (uint8_t)up(ab[k][0]);
+        // per-allele normalisation (oracle/extract_oracle.py read_vcf_variants): common trailing bases go while both
+        // strings keep one base, then common leading bases (the position moves right) -- the alleles of an STR record
+        // (REF=ATTT ALT=A,AT,ATT,ATTTT) become deletions and an insertion anchored on its first base
+        const char *rb = ref_b, *re = ref_e, *qb = ok ? ab[k] : ref_b, *qe = ok ? ab[k] + al[k] : ref_b;
+        int64_t pp = pos;
+        if (ok) {
+            while (re - rb > 1 && qe - qb > 1 && up(re[-1]) == up(qe[-1])) { --re; --qe; }
+            while (re - rb > 1 && qe - qb > 1 && up(rb[0]) == up(qb[0])) { ++rb; ++qb; ++pp; }
+        }
+        const long rl = (long)(re - rb), ql = (long)(qe - qb);
+        if (ok && rl == 1 && ql == 1) {
+            if (up(rb[0]) != up(qb[0])) {
+                Atom a; a.pos = pp; a.kind = 0; a.base = (uint8_t)up(qb[0]);
+                out.atoms.push_back(a); allele_of_atom.push_back(k);
+            }
+        } else if (ok && rl > 1 && ql == 1 && up(qb[0]) == up(rb[0])) {
+            Atom a; a.pos = pp; a.kind = 2; a.del_len = (int32_t)(rl - 1);
             out.atoms.push_back(a); allele_of_atom.push_back(k);
-        } else if (ok && ref_len > 1 && al[k] == 1 && up(ab[k][0]) == up(ref_b[0])) {
-            Atom a; a.pos = pos; a.kind = 2; a.del_len = (int32_t)(ref_len - 1);
+        } else if (ok && rl == 1 && ql > 1 && up(qb[0]) == up(rb[0])) {
+            Atom a; a.pos = pp; a.kind = 1; a.ins_len = (int32_t)(ql - 1); a.ins_at = out.ins_pool.size();
+            for (long j = 1; j < ql; ++j) out.ins_pool.push_back((uint8_t)up(qb[j]));
             out.atoms.push_back(a); allele_of_atom.push_back(k);
-        } else if (ok && ref_len == 1 && al[k] > 1 && up(ab[k][0]) == up(ref_b[0])) {
-            Atom a; a.pos = pos; a.kind = 1; a.ins_len = (int32_t)(al[k] - 1); a.ins_at = out.ins_pool.size();
-            for (long j = 1; j < al[k]; ++j) out.ins_pool.push_back((uint8_t)up(ab[k][j]));
-            out.atoms.push_back(a); allele_of_atom.push_back(k);
-        } else if (ok && ref_len == al[k] && ref_len > 1) {
-            for (long j = 0; j < ref_len; ++j)
-                if (up(ref_b[j]) != up(ab[k][j])) {
-                    Atom a; a.pos = pos + j; a.kind = 0; a.base = (uint8_t)up(ab[k][j]);
+        } else if (ok && rl == ql && rl > 1) {
+            for (long j = 0; j < rl; ++j)
+                if (up(rb[j]) != up(qb[j])) {
+                    Atom a; a.pos = pp + j; a.kind = 0; a.base = (uint8_t)up(qb[j]);
                     out.atoms.push_back(a); allele_of_atom.push_back(k);
                 }
         } else {
@@ -324,7 +336,6 @@ GFM_API int gfm_vcf_open(const char *path, const char *chrom, int with_haplotype
         const uint64_t *src = c.bits.data() + atom(r).bits_at;
         for (int w = 0; w < hw; ++w) dst[w] |= src[w];
     };
-    int64_t busy = -1;
     for (const Ref &r : order) {
         const Atom &a = atom(r);
         const size_t n = v->pos.size();
@@ -362,13 +373,17 @@ GFM_API int gfm_vcf_open(const char *path, const char *chrom, int with_haplotype
                 or_bits(n, 0, r);
             }
         } else {
-            if (a.pos > busy) {
+            // deletions may overlap (several lengths at one anchor: an STR record; an anchor inside another's span):
+            // the graph holds all of them; two records deleting the same bases merge their carriers
+            size_t dup = (size_t)-1;
+            for (size_t s = n; s-- > 0 && v->pos[s] == a.pos;)
+                if (v->del_len[s] == a.del_len) dup = s;
+            if (dup != (size_t)-1) {
+                or_bits(dup, 0, r);
+            } else {
                 add_site(a.pos, a.del_len, 0, 0);
                 v->n_alts[n] = 1;
                 or_bits(n, 0, r);
-                busy = a.pos + a.del_len;
-            } else {
-                ++v->skipped;
             }
         }
     }

@@ -13,7 +13,7 @@ tests/test_data/expected_results/expected_seqs.tsv and the 704 rows of real `vg 
 in its scoring fixture (SNPs, a deletion, haplotype counts, node paths) are reproduced exactly.  The
 graph holds the substitutions (also multi-base ones, one site per mismatching position), insertions and plain
 deletions of the VCF -- what is assumed about insertions is stated in oracle/extract_oracle.py (no vg output pins it);
-complex alleles and a deletion overlapping an earlier one are refused (or, opted in, left out and counted in
+complex and symbolic alleles are refused (or, opted in, left out and counted in
 `GraphIndex.skipped`).  There is no CPU fallback: extraction needs libgrafimo_hip.so and a GPU.
 """
 import ctypes
@@ -118,8 +118,10 @@ class GraphIndex:
         """Reference bases of `chrom` + its VCF records through the library's reader (gfm_vcf_*: host
         threads, plain or gzip/bgzip): substitutions (also multi-base ones, a site per position), insertions
         behind an anchor base and plain deletions become sites; two haplotypes per sample in file order.
-        ALT alleles the graph does not model (complex alleles, a fourth alternate at one position, a deletion
-        that overlaps an earlier one) would make the k-mers differ from vg's: the call FAILS on them unless
+        Every ALT is normalised against REF first (common trailing, then leading bases dropped), so the alleles of
+        an STR record become deletions / insertions behind its first base; deletions may overlap.  ALT alleles the
+        graph does not model (complex alleles -- neither of the above after normalisation --, symbolic alleles, a
+        fourth alternate base at one position) would make the k-mers differ from vg's: the call FAILS on them unless
         `allow_skipped` is set, in which case they are left out, counted in `.skipped` and reported on stderr."""
         ref = _read_fasta_record(fasta, chrom)
         h = ctypes.c_void_p()
@@ -145,14 +147,14 @@ class GraphIndex:
             nv.lib().gfm_vcf_close(h)
         if int(skipped.value) and not allow_skipped:
             raise VGError(
-                f"\n\nERROR: {int(skipped.value)} ALT allele(s) on {chrom} are complex (neither a substitution, an "
-                f"insertion behind an anchor base, a plain deletion nor an equal-length multi-base substitution), a "
-                f"fourth alternate at one position, or a deletion overlapping an earlier one. The extraction graph does "
+                f"\n\nERROR: {int(skipped.value)} ALT allele(s) on {chrom} are complex or symbolic (after normalisation "
+                f"neither a substitution, an insertion behind an anchor base, a deletion nor an equal-length multi-base "
+                f"substitution) or a fourth alternate base at one position. The extraction graph does "
                 f"not model them, so the k-mers would differ from `vg find`'s. Pass allow_skipped=True (CLI: "
                 f"--skip-unmodelled-variants) to leave them out knowingly.\n")
         if int(skipped.value):
-            print(f"WARNING: {int(skipped.value)} ALT allele(s) on {chrom} (complex alleles, a fourth alternate, "
-                  f"overlapping deletions) are NOT part of the graph: k-mers through them are missing and their "
+            print(f"WARNING: {int(skipped.value)} ALT allele(s) on {chrom} (complex or symbolic alleles, a fourth "
+                  f"alternate base) are NOT part of the graph: k-mers through them are missing and their "
                   f"neighbours keep the reference allele.", file=sys.stderr)
         if V and int(ins_len.max()) > 0:
             print(f"NOTE: {int((ins_len > 0).sum())} insertion allele(s) on {chrom}: k-mers through inserted bases follow "
@@ -249,10 +251,12 @@ class GraphIndex:
             k -= 1
         if self._dels is None:
             d = np.nonzero(self.del_len)[0]
-            self._dels = (self.pos[d].astype(np.int64), self.pos[d].astype(np.int64) + self.del_len[d])
-        anchors, ends = self._dels
+            ends = self.pos[d].astype(np.int64) + self.del_len[d]
+            # deletions may overlap: what matters is how far ANY deletion anchored before p reaches
+            self._dels = (self.pos[d].astype(np.int64), np.maximum.accumulate(ends) if len(ends) else ends)
+        anchors, reach = self._dels
         k = int(np.searchsorted(anchors, p, side="left")) - 1          # last deletion anchored before p
-        return k >= 0 and p <= int(ends[k])
+        return k >= 0 and p <= int(reach[k])
 
     def walk_alleles(self, p: int, width: int, walk: int) -> Tuple[int, List[int]]:
         """(first site, allele per site) of walk number `walk` of a window without deletions
@@ -271,7 +275,7 @@ class GraphIndex:
         (reference position, SNP allele) or ("ins", site, offset): mixed radix (last site fastest) for plain
         windows; for windows that touch a deletion or an insertion layout-major: the decision vectors (behind
         the base at x: read insertion k anchored at x? -- a yes ends the site -- then: jump the deletion
-        anchored at x?; 0 before 1) in lexicographic order, on one layout the mixed radix of its SNPs; starts
+        anchored at x? -- for every deletion anchored there, a yes ends the site; 0 before 1) in lexicographic order, on one layout the mixed radix of its SNPs; starts
         inside an insertion anchored at p - 1 follow the plain start (site order, offsets ascending)."""
         if not self.touches_deletion(p, width):
             i0 = int(np.searchsorted(self.pos, p, side="left"))
@@ -307,13 +311,18 @@ class GraphIndex:
                 return
             here = site_at.get(x, ())
             ins = [i for i in here if self.ins_len[i] > 0]
-            dele = next((i for i in here if self.del_len[i] > 0), None)
+            dele = [i for i in here if self.del_len[i] > 0]
+
+            def after_deletions(d):     # jump deletion dele[d] anchored here?  (0 before 1; a yes ends the site)
+                if d == len(dele):
+                    yield from layouts(x + 1, plan)
+                    return
+                yield from after_deletions(d + 1)
+                yield from layouts(x + int(self.del_len[dele[d]]) + 1, plan)
 
             def after(k):
                 if k == len(ins):
-                    yield from layouts(x + 1, plan)
-                    if dele is not None:
-                        yield from layouts(x + int(self.del_len[dele]) + 1, plan)
+                    yield from after_deletions(0)
                     return
                 yield from after(k + 1)
                 i = ins[k]

@@ -307,8 +307,9 @@ void gfm_scan_release_buffers(void);
  *
  * gfm_graph_create: h_ref [ref_len] bases; sites ascending 0-based h_pos [n_sites], h_n_alts [n_sites]
  *   in 1..3, h_alt_bases [n_sites][3]; h_del_len [n_sites] (or NULL): 0 for a SNP, else the site is a
- *   deletion of that many bases after the anchor h_pos (one alternate allele; deletions must not
- *   overlap; a deletion may follow a SNP at the same position); h_alt_bits [n_sites][3][ceil(H/64)] =
+ *   deletion of that many bases after the anchor h_pos (one alternate allele; deletions may overlap -- several
+ *   lengths at one anchor, anchors inside another deletion's span; at one position the substitution site comes
+ *   first, then the insertions, then the deletions); h_alt_bits [n_sites][3][ceil(H/64)] =
  *   haplotypes carrying each alternate allele (bit h of word h/64; deletion carriers in slot 0), or
  *   NULL / H = 0 for no haplotype counts (freq = 0).
  *   Insertions (UNPINNED semantics, stated in oracle/extract_oracle.py): h_ins_len [n_sites] (or NULL): > 0 for a
@@ -343,9 +344,11 @@ int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, int64_t *d
  * threads parse the lines.  The reference hands the VCF to `vg construct` / `vg index -G`
  * (constructVG.py:332,394); here every ALT allele is taken apart: single-base substitutions (one site per
  * position with up to 3 alternates, also across records), insertions, plain deletions, equal-length
- * multi-base substitutions (one substitution per mismatching position); what is left (complex alleles, a
- * fourth alternate, a deletion touching an earlier one) is counted in *n_skipped.  Two haplotypes per
- * sample in file order.
+ * multi-base substitutions (one substitution per mismatching position) -- after normalising the ALT against REF
+ * (common trailing, then leading bases dropped: the alleles of an STR record REF=ATTT ALT=A,AT,ATT become deletions of
+ * 3, 2, 1 bases behind its first base; up to sixteen ALT alleles per record); what is left (complex and symbolic
+ * alleles, a fourth alternate base at one position) is counted in *n_skipped.  Deletions may overlap; two records that
+ * delete the same bases merge their carriers.  Two haplotypes per sample in file order.
  * gfm_vcf_read copies: pos [n], n_alts [n], alt_bases [n][3], del_len [n], alt_bits [n][3][ceil(H/64)]
  * (may be NULL). */
 typedef struct gfm_vcf *gfm_vcf_t;

@@ -79,6 +79,14 @@ def haplotype_sequence(ref: bytes, recs, h: int):
         if a == 0:
             continue
         al = alts[a - 1]
+        # the allele against REF, reduced the way VCF normalisation does it: common trailing bases go while both
+        # strings keep one base, then common leading bases (restated here; the readers under test have their own)
+        while len(r) > 1 and len(al) > 1 and r[-1] == al[-1]:
+            r, al = r[:-1], al[:-1]
+        while len(r) > 1 and len(al) > 1 and r[0] == al[0]:
+            r, al, pos = r[1:], al[1:], pos + 1
+        if r == al:
+            continue
         if len(r) == 1 and len(al) == 1:                         # substitution
             if pos < cur:
                 raise ValueError(f"haplotype {h}: overlapping alleles at {pos}")
@@ -101,7 +109,7 @@ def haplotype_sequence(ref: bytes, recs, h: int):
                 out.append(ord(c)); coord.append(pos); ins.append(True); alt.append(True)
             if len(r) > 1:
                 cur = pos + len(r)                               # the deleted bases are not copied
-                last_sub = -1
+            last_sub = -1                                        # one indel per (possibly substituted) anchor
         else:
             raise ValueError(f"complex allele at {pos}: not part of the modelled graph")
     copy_ref(len(ref))

@@ -365,13 +365,19 @@ def enumerate_region_graph(chrom: str, ref: bytes, sites: Sites, dels: Dels, S: 
 #     deleted bases, ALT = anchor), an insertion (REF = anchor, ALT = anchor + inserted bases), a
 #     multi-base substitution of equal length (one substitution per mismatching position, all carried by
 #     the same haplotypes: `vg construct` aligns ALT to REF and cuts the graph at every edit); anything else
-#     is skipped and counted, like the ALT alleles of a record beyond its sixteenth.  Substitutions at one position become ONE site with up to three alternates
-#     (a fourth is skipped); a deletion that touches one accepted before it is skipped (as before).
+#     is skipped and counted, like the ALT alleles of a record beyond its sixteenth.  Before that every ALT is
+#     NORMALISED against REF the way VCF normalisation does it per allele: common trailing bases are dropped while
+#     both strings keep one base, then common leading bases (the position moves right) -- so the alleles of a
+#     short-tandem-repeat record (REF=ATTT ALT=A,AT,ATT,ATTTT) become deletions of 3, 2, 1 bases and an insertion, all
+#     anchored on the record's first base.  Substitutions at one position become ONE site with up to three
+#     alternates (a fourth is skipped).  Round 3: deletions may OVERLAP -- several at one anchor (different lengths:
+#     the STR case), anchors inside another deletion's span -- the graph simply holds all of them; two records that
+#     delete the same bases merge their carriers.
 #   * walks start on a reference position p (first base: the reference base or a substitution), or on base
 #     t of an insertion anchored at p - 1 (start coordinate p).  Behind the base at position x, with bases
 #     still to go, the walk decides for every insertion anchored at x (in site order) whether to read it
-#     (0 = no, 1 = yes; after a yes nothing else anchored at x is considered), then for the deletion
-#     anchored at x whether to jump it.  Decision vectors in lexicographic order, on one vector the
+#     (0 = no, 1 = yes; after a yes nothing else anchored at x is considered), then for every deletion
+#     anchored at x (site order) whether to jump it (a yes ends the site).  Decision vectors in lexicographic order, on one vector the
 #     substitution alleles like itertools.product; walks without a start inside an insertion first, then
 #     per insertion anchored at p - 1 (site order) the offsets t = 0, 1, ...
 #   * stop = reference coordinate behind the last reference base consumed (the anchor, for a walk that
@@ -422,16 +428,23 @@ def read_vcf_variants(path: str, chrom: Optional[str] = None, ref: Optional[byte
             for k, a in enumerate(alts):
                 car = gts == k + 1
                 ok = all(c in "ACGT" for c in a) and all(c in "ACGTN" for c in r) and len(a) > 0 and k < 16
-                if ok and len(r) == 1 and len(a) == 1:
-                    atoms.append((p, 0, a, car))
-                elif ok and len(r) > 1 and len(a) == 1 and a[0] == r[0]:
-                    atoms.append((p, 2, len(r) - 1, car))
-                elif ok and len(r) == 1 and len(a) > 1 and a[0] == r[0]:
-                    atoms.append((p, 1, a[1:].encode(), car))
-                elif ok and len(r) == len(a) and len(r) > 1:
-                    for j, (x, y) in enumerate(zip(r, a)):
+                rr, aa, pp = r, a, p
+                if ok:                                   # per-allele normalisation: trailing, then leading bases
+                    while len(rr) > 1 and len(aa) > 1 and rr[-1] == aa[-1]:
+                        rr, aa = rr[:-1], aa[:-1]
+                    while len(rr) > 1 and len(aa) > 1 and rr[0] == aa[0]:
+                        rr, aa, pp = rr[1:], aa[1:], pp + 1
+                if ok and len(rr) == 1 and len(aa) == 1:
+                    if rr != aa:
+                        atoms.append((pp, 0, aa, car))
+                elif ok and len(rr) > 1 and len(aa) == 1 and aa[0] == rr[0]:
+                    atoms.append((pp, 2, len(rr) - 1, car))
+                elif ok and len(rr) == 1 and len(aa) > 1 and aa[0] == rr[0]:
+                    atoms.append((pp, 1, aa[1:].encode(), car))
+                elif ok and len(rr) == len(aa) and len(rr) > 1:
+                    for j, (x, y) in enumerate(zip(rr, aa)):
                         if x != y:
-                            atoms.append((p + j, 0, y, car))
+                            atoms.append((pp + j, 0, y, car))
                 else:
                     skipped += 1
             if len(atoms) > before:
@@ -439,7 +452,6 @@ def read_vcf_variants(path: str, chrom: Optional[str] = None, ref: Optional[byte
     order = sorted(range(len(atoms)), key=lambda i: (atoms[i][0], atoms[i][1]))
     v = Variants()
     v.n_haplotypes = H
-    busy = -1
     for i in order:
         p, kind, payload, car = atoms[i]
         car = np.concatenate([car, np.zeros(H - len(car), bool)]) if len(car) < H else car
@@ -461,11 +473,11 @@ def read_vcf_variants(path: str, chrom: Optional[str] = None, ref: Optional[byte
             else:
                 v.add(p, 1, seq=payload, carriers=[car])
         else:
-            if p > busy:
-                v.add(p, 2, length=payload, carriers=[car])
-                busy = p + payload
+            dup = [j for j in range(len(v)) if v.pos[j] == p and v.kind[j] == 2 and v.length[j] == payload]
+            if dup:
+                v.carriers[dup[0]][0] = v.carriers[dup[0]][0] | car
             else:
-                skipped += 1
+                v.add(p, 2, length=payload, carriers=[car])
     v.skipped = skipped
     return v
 
@@ -529,10 +541,15 @@ def enumerate_region_variants(chrom: str, ref: bytes, v: Variants, S: int, E: in
         def after_insertions(k, passed_now):
             # decisions for insertions ins[k:], all answered "no" so far; then the deletion
             if k == len(ins):
-                yield from layouts(x + 1, n, plan, used, took, passed_now)
-                if dele:
-                    j = dele[0]
+                # the deletions anchored here, in site order: jump this one?  (0 before 1; a yes ends the site)
+                def after_deletions(d):
+                    if d == len(dele):
+                        yield from layouts(x + 1, n, plan, used, took, passed_now)
+                        return
+                    yield from after_deletions(d + 1)
+                    j = dele[d]
                     yield from layouts(x + v.length[j] + 1, n, plan, used, took + [j], passed_now)
+                yield from after_deletions(0)
                 return
             i = ins[k]
             yield from after_insertions(k + 1, passed_now + [i])          # 0: do not read insertion i

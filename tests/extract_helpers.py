@@ -119,7 +119,10 @@ def make_consistent_graph_files(tmpdir, chrom="c", length=600, n_samples=24, see
     single-base substitution record may be followed by an insertion / deletion record anchored on that same base, and a
     position may get a second substitution record carried only by haplotypes that are reference at the first.
     Only alleles the extraction graph models (kinds: s substitutions incl. multi-allelic, i insertions, d deletions,
-    m equal-length multi-base substitutions); no deletion touches another.  Returns (fasta, vcf)."""
+    m equal-length multi-base substitutions, D one record whose alleles delete different stretches of its REF --
+    several lengths behind one anchor and nested deletions with anchors further right, what an STR record normalises
+    to -- and O two records whose deletions overlap, the second carried only by haplotypes without the first).
+    Returns (fasta, vcf)."""
     rng = np.random.default_rng(seed)
     ref = "".join(rng.choice(list("ACGT"), size=length, p=[0.3, 0.2, 0.2, 0.3]))
     fasta = os.path.join(tmpdir, f"cons{seed}.fa")
@@ -173,6 +176,24 @@ def make_consistent_graph_files(tmpdir, chrom="c", length=600, n_samples=24, see
             ln = int(rng.integers(1, 6))
             emit(p, ref[p:p + 1 + ln], [r], genotypes(1))
             end = p + 1 + ln
+        elif kind == "D":
+            ln = int(rng.integers(3, 7))                  # REF = anchor + ln bases
+            refa = ref[p:p + 1 + ln]
+            alts = []
+            for j in rng.permutation(np.arange(1, ln + 1))[:3]:
+                j = int(j)
+                # remove j bases right behind the anchor (-> a deletion of j at p) or the last j (-> nested, anchor p + ln - j)
+                alts.append(refa[0] + refa[1 + j:] if rng.random() < 0.5 else refa[:1 + ln - j])
+            alts = [a for a in dict.fromkeys(alts) if a != refa]
+            emit(p, refa, alts, genotypes(len(alts)))
+            end = p + 1 + ln
+        elif kind == "O":
+            l1, shift, l2 = int(rng.integers(2, 6)), int(rng.integers(1, 3)), int(rng.integers(2, 6))
+            g1 = genotypes(1)
+            emit(p, ref[p:p + 1 + l1], [r], g1)
+            p2 = p + min(shift, l1)                       # anchored on a base the first deletion removes
+            emit(p2, ref[p2:p2 + 1 + l2], [ref[p2]], genotypes(1, allowed=g1 == 0))
+            end = max(p + 1 + l1, p2 + 1 + l2)
         else:
             ln = int(rng.integers(2, 5))
             span = ref[p:p + ln]

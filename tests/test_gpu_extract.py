@@ -451,7 +451,7 @@ def test_jumping_walks_must_end_inside_the_region():
     g.close()
 
 
-@pytest.mark.parametrize("kinds", ["s", "sd", "si", "sidm"])
+@pytest.mark.parametrize("kinds", ["s", "sd", "si", "sidm", "sD", "sO", "sidmDO"])
 def test_hip_rows_equal_the_per_haplotype_brute_force(tmp_path, kinds):
     """the kernels' rows against an algorithm that enumerates no walks at all -- every haplotype of the
     VCF as a linear sequence, W-windows slid over it (oracle/extract_bruteforce.py): a row's haplotype count is the
