@@ -162,8 +162,10 @@ post_body(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, int
         const int g1 = min(g0 + kSlabsPerGroup, nslabs);
         unsigned long long s = 0;
         const size_t stride = (size_t)(nb + 1);
+        // non-temporal: the slabs are read once, beside a score kernel that streams through the same L2 -- with plain
+        // loads (lines allocated in L2) this reduction cost that kernel 4 of its 94 us (profiles/r03_tail_cost.txt)
 #pragma unroll 8
-        for (int g = g0; g < g1; ++g) s += partials[g * stride + b];
+        for (int g = g0; g < g1; ++g) s += __builtin_nontemporal_load(&partials[g * stride + b]);
         if (s) atomicAdd(&hist64[b == nb ? min_val : lo + b], s);
         return;
     }
@@ -199,7 +201,7 @@ post_body(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, int
     const int cnt = resid_n[g];
     const long long *slab = resid + (size_t)g * kResidPerWG;
     for (int i = tid; i < cnt; i += 256)
-        if ((long long)(base + i) < hit_cap) hit_rows[base + i] = slab[i];
+        if ((long long)(base + i) < hit_cap) __builtin_nontemporal_store(__builtin_nontemporal_load(&slab[i]), &hit_rows[base + i]);
     if (g == 0 && tid == 0) {
         *hit_count = start + (unsigned long long)part_all[0];
         ctl->mid[(par + kCtlAhead) % kCtlSlots] = 0ull;

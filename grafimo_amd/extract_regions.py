@@ -654,11 +654,18 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
         print_scoring_msg(motif, no_reverse, debug)
     W = motif.width
     parts = [g.extract(r, W) for g, r in zip(graphs, region_lists)]
-    labels: List[str] = []
-    region_ids = []
-    for part in parts:                               # region ids of all chromosomes in one label table
-        region_ids.append(part.region + len(labels))
-        labels += [part.region_label(r) for r in range(len(part.regions))]
+    # region ids of all chromosomes in one table; the label strings are made for the hit rows only (ten thousand
+    # f-strings per call were a quarter of its time) unless they have to travel to rank 0
+    region_ids, label_base = [], [0]
+    for part in parts:
+        region_ids.append(part.region + label_base[-1])
+        label_base.append(label_base[-1] + len(part.regions))
+
+    def label_of(ix: int) -> str:
+        k = int(np.searchsorted(label_base, ix, side="right")) - 1
+        return parts[k].region_label(ix - label_base[k])
+
+    labels: List[str] = [label_of(i) for i in range(label_base[-1])] if world > 1 else []
     cat = lambda name: torch.cat([getattr(p_, name) for p_ in parts]) if len(parts) > 1 else getattr(parts[0], name)
     all_kmers, region = cat("kmers"), (torch.cat(region_ids) if len(parts) > 1 else region_ids[0])
     n_all = int(all_kmers.shape[0])
@@ -683,10 +690,20 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
             print("\nComputing q-values...\n")
         # with a process group the scanner all-reduces the histogram before the q-table; hits stay local
         # (their metadata lives on this rank) and travel as finished table rows below
-        sc = KmerScanner(dm, max(n, 1), device=kmers.device, side_stream=False, group=group,
-                         always_collective=always_collective)
-        res = sc.collect(sc.enqueue(kmers, threshold, on_qvalue=qval_t, want_qvalues=not no_qvalue),
-                         want_qvalues=not no_qvalue)
+        # one batch: one slot; the hit list starts at a sixteenth of the rows (a full-size list is 8 bytes per row of
+        # allocation and zeroing for nothing) and is taken again at full size in the rare case it does not hold
+        cap = max(4096, n // 16)
+        while True:
+            sc = KmerScanner(dm, max(n, 1), hit_capacity=cap, device=kmers.device, side_stream=False, group=group,
+                             always_collective=always_collective, n_slots=1)
+            try:
+                res = sc.collect(sc.enqueue(kmers, threshold, on_qvalue=qval_t, want_qvalues=not no_qvalue),
+                                 want_qvalues=not no_qvalue)
+                break
+            except OverflowError:
+                if cap >= n:
+                    raise
+                cap = n
         lo, pv = dm.annotate(res["scaled"])
     finally:
         dm.close()
@@ -715,7 +732,7 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
         got, name_ix = cols, cols["name_id"].astype(np.int64)
     return build_frame(
         motif,
-        seqnames=[labels[int(r)] for r in name_ix],
+        seqnames=[labels[int(r)] if labels else label_of(int(r)) for r in name_ix],
         starts=got["start"], stops=got["stop"],
         strands=[chr(c) for c in got["strand"]],
         scores=got["logodds"], pvalues=got["pvalue"],

@@ -6,7 +6,8 @@ set -euo pipefail
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 tag="$1"; shift
 W="${LAB_W:-19}"
-src="$root/grafimo_amd/csrc"
+src="${LAB_SRC:-$root/grafimo_amd/csrc}"     # LAB_SRC: another copy of csrc/ (e.g. git archive of HEAD) for A/B runs
+obj="$root/grafimo_amd/csrc"
 mkdir -p "$root/lab"
 CC=(/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fvisibility=hidden
     -I"$root/include" -DGFM_ONLY_W="$W" "$@")
@@ -17,7 +18,7 @@ for gm in 0:1 1:1 2:1 3:1 0:2 1:2 0:3 1:3; do
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/lab/libgfm_$tag.so" "$root/lab/gfm_$tag.o" \
-    "$root/lab"/gfm_${tag}_g?_m?.o "$src/graph_extract.o" "$src/tsv_ingest.o" "$src/vcf_ingest.o" \
-    "$src/scan_stream.o" "$src/gfm_workers.o" -lpthread -lz
+    "$root/lab"/gfm_${tag}_g?_m?.o "$obj/graph_extract.o" "$obj/stream_calib.o" "$obj/tsv_ingest.o" "$obj/vcf_ingest.o" \
+    "$obj/scan_stream.o" "$obj/gfm_workers.o" -lpthread -lz
 rm -f "$root/lab/gfm_$tag.o" "$root/lab"/gfm_${tag}_g?_m?.o
 echo "built lab/libgfm_$tag.so"
