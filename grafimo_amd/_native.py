@@ -74,6 +74,7 @@ PROTOTYPES = {
     "gfm_scan_host": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_int, c_i64, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, P(c_i64)]),
     "gfm_tsv_open": (c_int, [P(ctypes.c_char_p), c_int, c_int, c_int, c_int, P(c_void_p), P(c_i64)]),
+    "gfm_tsv_count_rows": (c_int, [ctypes.c_char_p, c_int, P(c_i64)]),
     "gfm_tsv_read": (c_int, [c_void_p] * 9),
     "gfm_tsv_name_count": (c_int, [c_void_p]),
     "gfm_tsv_names_bytes": (c_i64, [c_void_p]),

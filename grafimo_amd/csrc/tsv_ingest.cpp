@@ -243,6 +243,16 @@ GFM_API int gfm_tsv_open(const char *const *paths, int n_paths, int width, int s
     return GFM_OK;
 }
 
+GFM_API int gfm_tsv_count_rows(const char *path, int skip_reverse, int64_t *n_rows)
+{
+    if (!path || !n_rows) { t_err = "NULL argument"; return GFM_ERR_INVALID; }
+    gfm_tsv_detail::FileBuf text;
+    std::string err;
+    if (!text.load(path, err)) { t_err = err; return GFM_ERR_IO; }
+    *n_rows = gfm_tsv_detail::count_rows(text.begin(), text.end(), skip_reverse != 0);
+    return GFM_OK;
+}
+
 GFM_API int gfm_tsv_read(gfm_tsv_t t, uint8_t *kmers, int64_t *start, int64_t *stop, uint8_t *strand,
                          int64_t *freq, uint8_t *is_ref, int32_t *file_id, int32_t *name_id)
 {

@@ -109,7 +109,9 @@ class KmerScanner:
         if self.host_paced and n_slots < 2:
             raise ValueError("host-paced slot reuse needs at least two slots")
         # either way batch k - 4 is done when batch k is enqueued (n_slots <= 4): the library's workspace
-        # ring of four is free again without its own event wait
+        # ring of four is free again without its own event wait.  (The rings belong to the DeviceMotif, not to this
+        # scanner: the library honours the flag only while the four calls before this one on the handle came from
+        # the same stream pair, and orders the reuse itself when another scanner or a batched call was in between.)
         self._reuse_flag = _nv.GFM_FLAG_CALLER_ORDERS_REUSE if n_slots <= 4 else 0
         # q-value threshold: select from the p < t candidates the score kernel collects (enqueue) instead of
         # reading every score again; False = the separate pass over the scores (measurement aid)
@@ -298,7 +300,7 @@ class SameWidthScanner:
         # to a side stream behind ONE event per enqueue and runs beside the score kernels of the next enqueue.
         # Off by default: measured at fifty motifs (BASELINE config 5, one MI355X) the chain of small
         # latency-bound kernels, 3-4x slower each while a score kernel saturates HBM, became the critical
-        # path (step 13.5 ms against 10.6 ms in stream order) and the score kernels lost 7 % to it.  It pays
+        # path (step 13.5 ms against 10.6 ms in stream order) and the score kernels lost 7 % to it.
         # Kept as an option for N > 1, where the tail holds a collective (not measured: no multi-GPU box).
         self.side = torch.cuda.Stream(device=device, priority=-1) if side_stream else None
         self.scored = torch.cuda.Event()

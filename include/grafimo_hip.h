@@ -234,6 +234,11 @@ typedef struct gfm_tsv *gfm_tsv_t;
  * the library keeps for the life of the process (the VCF reader and the streamed scan share it). */
 int gfm_tsv_open(const char *const *paths, int n_paths, int width, int skip_reverse,
                  int n_threads, gfm_tsv_t *out, int64_t *n_rows);
+/* The first pass of the streamed scan on its own (gfm_scan_tsv_begin reads a file, counts its rows, and parses it in
+ * place once every earlier file is counted): the rows gfm_tsv_open would keep of this file -- lines that hold a field,
+ * minus the '-' rows with skip_reverse -- without parsing them.  Equal to the parsed count for every file the parser
+ * accepts (the CPU tests hold it to that). */
+int gfm_tsv_count_rows(const char *path, int skip_reverse, int64_t *n_rows);
 /* Copies the parsed columns out (any pointer may be NULL):
  * kmers uint8[n][W]; start/stop int64[n]; strand uint8[n] ('+'/'-'); freq int64[n];
  * is_ref uint8[n] (1 = "ref" after the indel fix :305-307, 0 = "non.ref");

@@ -201,14 +201,18 @@ def test_tsv_ingest_property_random_rows(tmp_path):
         d.mkdir(exist_ok=True)
         f = d / "r.tsv"
         with open(f, "w") as fh:
-            for seq, start, delta, strand, freq, ref, sep, region in rows:
+            for k, (seq, start, delta, strand, freq, ref, sep, region) in enumerate(rows):
                 chrom = region.split(":")[0]
                 stop = start + delta
-                fh.write(sep.join([region, seq, f"{chrom}:{start}{strand}", f"{chrom}:{stop}{strand}",
-                                   str(freq), ref, f"1{strand},2{strand},"]) + "\n")
+                lead = ["", " ", "\t"][k % 3] if sep != "\t" else ""          # leading white space (line.strip().split())
+                fh.write(lead + sep.join([region, seq, f"{chrom}:{start}{strand}", f"{chrom}:{stop}{strand}",
+                                          str(freq), ref, f"1{strand},2{strand},"]) + "\n")
         t = KmerTable([str(f)], 7, skip_rev, 1)
         cols = orc.parse_tsv_rows([str(f)], no_reverse=skip_rev)
         assert t.n == len(cols["seq"])
+        counted = ctypes.c_int64(-1)                  # the streamed scan's counting pass says the same
+        assert nv.lib().gfm_tsv_count_rows(str(f).encode(), int(skip_rev), ctypes.byref(counted)) == 0
+        assert counted.value == t.n
         assert [bytes(k).decode() for k in t.kmers] == cols["seq"]
         assert list(t.start) == cols["start"] and list(t.stop) == cols["stop"]
         assert [chr(c) for c in t.strand] == cols["strand"] and list(t.freq) == cols["freq"]
