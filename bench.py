@@ -38,6 +38,7 @@ burst.  Rank 0 prints ONE JSON line.  Beside the contract's fields it carries
                       of scores per launch, beyond any cache) -- also the 1-GPU point of the N > 1 curve;
   sustained           >= 2 s of back-to-back steps, k-mers/s and min/median/max ms per 100 steps;
   extract             the k-mer extraction kernels on a synthetic graph at config-2 scale + extraction -> scoring;
+  pcie_inclusive      the host-buffer form of the boundary (gfm_scan_host) over the same 2e7 k-mers, H2D included;
   e2e / e2e_config2   a TSV directory through compute_results' streamed scan (2e6 rows; 2e7 rows in 10 000 files);
   cpu_baseline / cpu_baseline_table   the CPU oracle's loop over TSV text on every host core (bounded sample).
 """
@@ -584,6 +585,17 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
         del sc3, d3, last3
         torch.cuda.empty_cache()
         extras["extract"] = extract_block(ctcf, dev)
+        # the boundary's host-buffer form (gfm_scan_host: pageable k-mers in, hits out): the PCIe-inclusive rate --
+        # never `value`
+        t_host = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            hres = dms[0].scan_host(host_batch.kmers, args.threshold, capacity=n // 16)
+            t_host.append(time.perf_counter() - t0)
+        extras["pcie_inclusive"] = {
+            "rows": n, "ms": 1e3 * float(np.median(t_host)), "kmers_per_s": n / float(np.median(t_host)),
+            "hits": int(len(hres["rows"])),
+            "path": "gfm_scan_host: hipMalloc + pageable H2D of the k-mer matrix + score + q-table + D2H of the hits, one call"}
 
     e2e = {}
     if default_n1 and not args.no_e2e:
@@ -678,6 +690,7 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
             "sustained": extras.get("sustained"),
             "peak_measured": extras.get("peak_measured"),
             "extract": extras.get("extract"),
+            "pcie_inclusive": extras.get("pcie_inclusive"),
             "cpu_baseline": cpu.get("cpu_baseline"),
             "cpu_baseline_table": cpu.get("cpu_baseline_table"),
             "e2e": e2e.get("e2e"),
