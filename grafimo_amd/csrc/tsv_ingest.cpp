@@ -150,7 +150,7 @@ void gfm_tsv_detail::parse_file(const char *path, int W, bool skip_rev, FileCols
 // through gfm_scan_tsv, median of 7 runs: 32 threads 6.6 ms, 64 5.6, 96 5.0, 128 5.6, 175 8.0 with 80 ms outliers
 // (profiles/r02_scan_trace.txt).
 static constexpr int kMaxParseThreads = 96;
-static constexpr int kMaxParseThreadsBig = 48;
+static constexpr int kMaxParseThreadsBig = 32;
 
 int gfm_tsv_detail::pick_threads(const char *const *paths, int n_paths, int requested)
 {
@@ -171,9 +171,9 @@ int gfm_tsv_detail::pick_threads(const char *const *paths, int n_paths, int requ
     if ((unsigned long long)nt > by_size) nt = (int)(by_size < 1 ? 1 : by_size);
     if (nt > kMaxParseThreads) nt = kMaxParseThreads;
     // Text that no longer fits the last-level caches (the page cache is then read from DRAM by every thread's
-    // read()): 24..64 threads all take ~80 ms for 1.84 GB in 10 000 files on a 2 x 64-core host, 96 threads 85..170 ms
-    // (scripts/ingest_probe.py, profiles/r03_ingest_probe.txt) -- the kernel's copy out of the page cache saturates
-    // near 40 GB/s whatever the thread count, and more threads only queue up behind it.
+    // read()): 1.84 GB in 10 000 files on a 2 x 64-core host take 61-66 ms with 24 or 32 threads, 72-75 ms with 48 and
+    // more, 85..170 ms with 96 (scripts/ingest_probe.py, profiles/r03_ingest_probe.txt) -- the kernel's copy out of
+    // the page cache saturates near 40 GB/s whatever the thread count, and more threads only queue up behind it.
     if (bytes > (1ull << 30) && nt > kMaxParseThreadsBig) nt = kMaxParseThreadsBig;
     return nt;
 }
