@@ -1,0 +1,83 @@
+// ASan/UBSan harness for the host-side readers (no GPU): TSV ingest (table + counting pass) and the VCF reader on the
+// fixtures, on synthetic files and on mutated copies of them.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <string>
+#include <vector>
+#include "grafimo_hip.h"
+static thread_local std::string g_err;
+extern "C" void gfm_set_error_(const char *m) { g_err = m ? m : ""; }
+static std::string slurp(const char *p) { std::ifstream f(p, std::ios::binary); return std::string((std::istreambuf_iterator<char>(f)), {}); }
+int main(int argc, char **argv)
+{
+    const char *tsv = argv[1], *vcf = argv[2], *tmp = argv[3];
+    std::string base = slurp(tsv);
+    std::mt19937 rng(7);
+    long ok = 0, bad = 0;
+    for (int it = 0; it < 400; ++it) {
+        std::string t = base;
+        if (it) {
+            const int muts = 1 + (int)(rng() % 8);
+            for (int k = 0; k < muts; ++k) {
+                const size_t at = rng() % t.size();
+                switch (rng() % 5) {
+                case 0: t[at] = "\t \n:+-0123456789ACGTNx\r"[rng() % 22]; break;
+                case 1: t.erase(at, 1 + rng() % 40); break;
+                case 2: t.insert(at, std::string(1 + rng() % 5, "\t \n"[rng() % 3])); break;
+                case 3: t.resize(at); break;
+                default: t.insert(at, t.substr(rng() % t.size(), rng() % 200)); break;
+                }
+                if (t.empty()) t = "x";
+            }
+        }
+        std::string path = std::string(tmp) + "/m.tsv";
+        { std::ofstream o(path, std::ios::binary); o << t; }
+        const char *paths[1] = {path.c_str()};
+        for (int skip = 0; skip < 2; ++skip) {
+            gfm_tsv_t h = nullptr; int64_t n = 0, c = -1;
+            const int rc = gfm_tsv_open(paths, 1, 19, skip, 1 + it % 3, &h, &n);
+            const int rc2 = gfm_tsv_count_rows(path.c_str(), skip, &c);
+            if (rc == 0) {
+                ++ok;
+                if (rc2 != 0 || c != n) { std::printf("COUNT MISMATCH it=%d skip=%d parsed=%lld counted=%lld\n", it, skip, (long long)n, (long long)c); return 1; }
+                std::vector<uint8_t> km((size_t)n * 19 + 1); std::vector<int64_t> a(n + 1), b(n + 1), f(n + 1); std::vector<uint8_t> s(n + 1), r(n + 1); std::vector<int32_t> fi(n + 1), ni(n + 1);
+                gfm_tsv_read(h, km.data(), a.data(), b.data(), s.data(), f.data(), r.data(), fi.data(), ni.data());
+                gfm_tsv_close(h);
+            } else ++bad;
+        }
+    }
+    std::printf("tsv: %ld parsed, %ld refused\n", ok, bad);
+    // VCF reader on the fixture and mutated copies (plain text)
+    std::string vbase = slurp(vcf);
+    ok = bad = 0;
+    for (int it = 0; it < 300; ++it) {
+        std::string t = vbase;
+        if (it) for (int k = 0; k < 1 + (int)(rng() % 6); ++k) {
+            const size_t at = rng() % t.size();
+            switch (rng() % 4) {
+            case 0: t[at] = "\t,ACGT<>|/.0123456789\n"[rng() % 22]; break;
+            case 1: t.erase(at, 1 + rng() % 30); break;
+            case 2: t.insert(at, std::string(1 + rng() % 300, "ACGT"[rng() % 4])); break;
+            default: t.insert(at, t.substr(rng() % t.size(), rng() % 100)); break;
+            }
+        }
+        std::string path = std::string(tmp) + "/m.vcf";
+        { std::ofstream o(path, std::ios::binary); o << t; }
+        gfm_vcf_t v = nullptr; int64_t ns = 0, sk = 0; int32_t H = 0;
+        const int rc = gfm_vcf_open(path.c_str(), "x", 1, 1 + it % 4, &v, &ns, &H, &sk);
+        if (rc == 0) {
+            ++ok;
+            const int hw = (H + 63) / 64;
+            std::vector<int32_t> pos(ns + 1), dl(ns + 1), il(ns + 1), io(ns + 1); std::vector<uint8_t> na(ns + 1), ab(3 * ns + 3), ib(gfm_vcf_ins_bytes(v) + 1);
+            std::vector<uint64_t> bits((size_t)ns * 3 * hw + 1);
+            gfm_vcf_read(v, pos.data(), na.data(), ab.data(), dl.data(), bits.data());
+            gfm_vcf_read_insertions(v, il.data(), io.data(), ib.data());
+            gfm_vcf_close(v);
+        } else ++bad;
+    }
+    std::printf("vcf: %ld parsed, %ld refused\n", ok, bad);
+    return 0;
+}
