@@ -1,0 +1,69 @@
+"""Two processes on ONE GPU over gloo through the PRODUCT's sharded entry points (compute_results_sharded,
+compute_results_many_sharded: every rank runs the streamed scan over its shard of the TSV files, the histograms are
+all-reduced between gfm_scan_tsv_begin and _finish, the hit rows are gathered): rank 0's tables must equal what one
+process gives over all files.  Exits 1 otherwise.  Not a performance number."""
+import contextlib, io, os, socket, sys, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def table_key(df):
+    key = ["p-value", "start", "stop", "strand", "matched_sequence"]
+    return df.sort_values(key).reset_index(drop=True)
+
+
+def worker(rank, world, port, seqdir, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch, torch.distributed as dist
+    from grafimo_amd.distributed import compute_results_many_sharded, compute_results_sharded
+    from grafimo_amd.motif_ops import build_motif_meme_host
+    from grafimo_amd.score_sequences import compute_results
+    from grafimo_amd.workflow import Findmotif
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    golden = os.path.join(ROOT, "tests", "golden")
+    ctcf = build_motif_meme_host(os.path.join(golden, "ref_data", "MA0139.1.meme"), "unfrm_dst", 0.1, False)[0]
+    ctcf2 = build_motif_meme_host(os.path.join(golden, "ref_data", "MA0139.1.meme"), os.path.join(golden, "synth", "bg_1.txt"), 0.1, False)[0]
+    bad = []
+    for kw in (dict(threshold=1e-3), dict(threshold=0.3, qval_t=True, recomb=True), dict(threshold=1e-2, no_qvalue=True)):
+        wf = Findmotif(cores=4, **kw)
+        with contextlib.redirect_stdout(io.StringIO()):
+            one = compute_results_sharded(ctcf, seqdir, True, wf)
+            many = compute_results_many_sharded([ctcf, ctcf2], seqdir, True, wf)
+        if rank == 0:
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref = [compute_results(m, seqdir, True, wf) for m in (ctcf, ctcf2)]
+            for got, exp, name in ((one, ref[0], "sharded"), (many[0], ref[0], "many[0]"), (many[1], ref[1], "many[1]")):
+                a, b = table_key(got), table_key(exp)
+                same = len(a) == len(b) and all((a[c].astype(str) == b[c].astype(str)).all() for c in b.columns
+                                                 if b[c].dtype.kind != "f") and \
+                    all(np.allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-12, atol=0) for c in b.columns
+                        if b[c].dtype.kind == "f")
+                print(f"{kw} {name}: {len(a)} rows, two ranks == one process: {same}", flush=True)
+                if not same or len(a) == 0:
+                    bad.append((kw, name))
+        else:
+            assert one is None and all(x is None for x in many)
+    if rank == 0 and bad:
+        open(out, "w").write(str(bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    import torch.multiprocessing as mp
+    from grafimo_amd import synth
+    from grafimo_amd.motif_ops import build_motif_meme_host
+    m = build_motif_meme_host(os.path.join(ROOT, "tests/golden/ref_data/MA0139.1.meme"), "unfrm_dst", 0.1, False)[0]
+    seqdir = tempfile.mkdtemp(prefix="gfm_two_rank_")
+    synth.write_tsv_dir(synth.make_batch(9, 1500, 19, np.asarray(m.count_matrix), synth.seed_for(3)), seqdir)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    out = os.path.join(seqdir, "mismatch.flag")
+    try:
+        mp.spawn(worker, args=(2, port, seqdir, out), nprocs=2, join=True)
+        sys.exit(1 if os.path.exists(out) else 0)
+    finally:
+        import shutil
+        shutil.rmtree(seqdir, ignore_errors=True)

@@ -554,3 +554,16 @@ def test_many_motifs_sharded_entry_point_on_one_gpu(tmp_path):
             for m, df in zip(motifs, many):
                 _compare(df, compute_results(m, str(tmp_path), True, wf))
     assert sum(len(df) for df in many) > 0
+
+
+def test_two_ranks_on_one_gpu_through_the_sharded_entry_points():
+    """The N = 2 path of compute_results_sharded / compute_results_many_sharded on the real kernels: two processes share
+    the GPU over gloo, each runs the streamed scan over its shard, the histograms are all-reduced between the two phases
+    of the scan; rank 0's tables equal compute_results over all files (scripts/two_rank_sharded_probe.py exits 1 otherwise)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "two_rank_sharded_probe.py")], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert r.stdout.count("two ranks == one process: True") == 9
