@@ -36,7 +36,7 @@ burst.  Rank 0 prints ONE JSON line.  Beside the contract's fields it carries
   N = 1, default config only (each can be switched off):
   roofline_config3    >= 10 steps of the config-3 shard (1.25e8 windows generated on the device, `nt` stores: 477 MiB
                       of scores per launch, beyond any cache) -- also the 1-GPU point of the N > 1 curve;
-  sustained           >= 2 s of back-to-back steps, k-mers/s and min/median/max ms per 100 steps;
+  sustained           >= 5 s of back-to-back steps, k-mers/s and min/median/max ms per 100 steps;
   extract             the k-mer extraction kernels on a synthetic graph at config-2 scale + extraction -> scoring;
   pcie_inclusive      the host-buffer form of the boundary (gfm_scan_host) over the same 2e7 k-mers, H2D included;
   e2e / e2e_config2   a TSV directory through compute_results' streamed scan (2e6 rows; 2e7 rows in 10 000 files);
@@ -324,7 +324,7 @@ def main():
     ap.add_argument("--no-e2e-large", action="store_true", help="skip the 2e7-row / 10 000-file TSV directory")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip roofline_config3, sustained, peak_measured and extract (N=1 default config only)")
-    ap.add_argument("--sustained-s", type=float, default=2.5, help="length of the sustained leg in seconds")
+    ap.add_argument("--sustained-s", type=float, default=5.0, help="length of the sustained leg in seconds")
     ap.add_argument("--slots", type=int, default=3,
                     help="buffer slots of the scan pipeline (2: the device waits for slot reuse; >= 3: the host does)")
     ap.add_argument("--force-dist", action="store_true",
