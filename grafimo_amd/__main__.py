@@ -48,9 +48,12 @@ def get_parser():
     p.add_argument("-b", "--bedfile", metavar="BED", help="regions to scan (UCSC BED: lines starting with chr)")
     p.add_argument("--chroms-prefix-find", dest="chroms_prefix", default="", metavar="PREFIX",
                    help="chromosome names in the FASTA / VCF = PREFIX + the BED name without its leading chr")
+    p.add_argument("--strict-variants", action="store_true", dest="strict_variants",
+                   help="fail on VCF records with a symbolic ALT (<DEL>, <CN0>, breakends, '*') instead of leaving them "
+                        "out with a warning, which is what vg construct does without --handle-sv")
     p.add_argument("--skip-unmodelled-variants", action="store_true", dest="skip_unmodelled",
-                   help="leave ALT alleles the extraction graph does not model (complex or symbolic alleles, a fourth "
-                        "alternate base at one position) out instead of failing on them")
+                   help="accepted for compatibility (it is the default now: complex alleles are modelled, records with "
+                        "symbolic ALTs are left out with a warning)")
     p.add_argument("-k", "--bgfile", default=UNIF)
     p.add_argument("-p", "--pseudo", type=float, default=0.1)
     p.add_argument("-t", "--threshold", type=float, default=1e-4)
@@ -90,7 +93,7 @@ def main(argv=None):
         from .extract_regions import DeviceGraph, GraphIndex, compute_results_from_graph, read_bed_regions
         for bed_chrom, regs in read_bed_regions(a.bedfile, a.debug).items():
             chrom = a.chroms_prefix + bed_chrom.split("chr")[1]      # extract_regions.py:122,137
-            index = GraphIndex.from_fasta_vcf(a.linear_genome, a.vcf, chrom, allow_skipped=a.skip_unmodelled)
+            index = GraphIndex.from_fasta_vcf(a.linear_genome, a.vcf, chrom, allow_skipped=not a.strict_variants)
             if a.verbose:
                 print(f"{chrom}: {len(index.pos)} variant sites ({int((index.ins_len > 0).sum())} insertions, "
                       f"{int((index.del_len > 0).sum())} deletions), {index.n_haplotypes} haplotypes, "

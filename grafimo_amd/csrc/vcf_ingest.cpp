@@ -6,8 +6,14 @@
 // to 3 alternates, also when they come from several records), insertions (REF = anchor, ALT = anchor +
 // inserted bases), deletions (REF = anchor + deleted bases, ALT = anchor; they may overlap), multi-base
 // substitutions of equal length (one substitution per mismatching position) -- every ALT normalised against REF
-// first (common trailing, then leading bases dropped); everything else is skipped and counted -- the rules
-// oracle/extract_oracle.py read_vcf_variants states.  Genotypes: two haplotypes per sample in
+// first (common trailing, then leading bases dropped).  What is still neither of these is a COMPLEX allele
+// (REF=ACG ALT=TC): it is taken apart into the substitutions of its first min(|REF|, |ALT|) bases and an
+// insertion / deletion of the rest behind the last of them, all carried by the same haplotypes -- `vg construct`
+// (called without --flat-alts, constructVG.py:332) decomposes such alleles too, by alignment; the haplotype
+// sequences, and with them every row a haplotype carries, do not depend on how.  A record with an ALT that is not
+// a string of A, C, G, T (symbolic <DEL> / <CN0> / <INS:ME:ALU>, breakends, '*', IUPAC codes) is left out whole and its alleles are
+// counted in `skipped`: `vg construct` without --handle-sv (the reference's command line) skips such records with
+// a warning.  The rules oracle/extract_oracle.py read_vcf_variants states.  Genotypes: two haplotypes per sample in
 // file order ("a|b", "a/b" taken as written, a single allele doubled, "." = reference); per
 // alternate allele one bitset over the haplotypes, bit h of word h / 64.
 // Plain text is mmap'ed, .gz goes through zlib (any gzip/bgzip stream); lines are parsed by a small
@@ -38,7 +44,7 @@ extern "C" void gfm_set_error_(const char *msg);
 namespace {
 
 constexpr int kMaxAlts = 3;          // alternates of one substitution site (four bases: there cannot be more)
-constexpr int kMaxRecordAlts = 16;   // ALT alleles taken from one record (insertions and deletions are sites of their own)
+constexpr int kMaxRecordAlts = 64;   // ALT alleles taken from one record (insertions and deletions are sites of their own)
 
 // One alternate allele of a record, taken apart (oracle/extract_oracle.py read_vcf_variants states the rules):
 // kind 0 a single-base substitution at `pos`, 1 an insertion behind the anchor `pos`, 2 a deletion behind it.
@@ -107,13 +113,20 @@ void parse_line(const char *b, const char *e, bool want_hap, Chunk &out)
         if (!c) break;
         q = c + 1;
     }
+    // a record with an ALT that is no base string (symbolic, breakend, '*', '.') or with a REF that is none is left
+    // out whole, as vg construct does; so are the ALTs beyond kMaxRecordAlts
+    bool record_ok = ref_ok;
+    for (int k = 0; k < na && k < kMaxRecordAlts && record_ok; ++k) {
+        record_ok = al[k] > 0;
+        for (long j = 0; record_ok && j < al[k]; ++j) record_ok = is_base(up(ab[k][j]));
+    }
+    if (!record_ok) { out.skipped += na; return; }
     // what every ALT is
     const size_t first_atom = out.atoms.size();
     std::vector<int> &allele_of_atom = out.allele_of_atom;
     allele_of_atom.clear();
     for (int k = 0; k < na; ++k) {
-        bool ok = ref_ok && k < kMaxRecordAlts && al[k] > 0;
-        for (long j = 0; ok && j < al[k]; ++j) ok = is_base(up(ab[k][j]));
+        const bool ok = k < kMaxRecordAlts;
         // per-allele normalisation (oracle/extract_oracle.py read_vcf_variants): common trailing bases go while both
         // strings keep one base, then common leading bases (the position moves right) -- the alleles of an STR record
         // (REF=ATTT ALT=A,AT,ATT,ATTTT) become deletions and an insertion anchored on its first base
@@ -142,6 +155,22 @@ void parse_line(const char *b, const char *e, bool want_hap, Chunk &out)
                     Atom a; a.pos = pp + j; a.kind = 0; a.base = (uint8_t)up(qb[j]);
                     out.atoms.push_back(a); allele_of_atom.push_back(k);
                 }
+        } else if (ok) {
+            // complex: substitutions over the common length, the rest an insertion / deletion behind its last base
+            const long common = std::min(rl, ql);
+            for (long j = 0; j < common; ++j)
+                if (up(rb[j]) != up(qb[j])) {
+                    Atom a; a.pos = pp + j; a.kind = 0; a.base = (uint8_t)up(qb[j]);
+                    out.atoms.push_back(a); allele_of_atom.push_back(k);
+                }
+            if (ql > rl) {
+                Atom a; a.pos = pp + common - 1; a.kind = 1; a.ins_len = (int32_t)(ql - common); a.ins_at = out.ins_pool.size();
+                for (long j = common; j < ql; ++j) out.ins_pool.push_back((uint8_t)up(qb[j]));
+                out.atoms.push_back(a); allele_of_atom.push_back(k);
+            } else if (rl > ql) {
+                Atom a; a.pos = pp + common - 1; a.kind = 2; a.del_len = (int32_t)(rl - common);
+                out.atoms.push_back(a); allele_of_atom.push_back(k);
+            }
         } else {
             ++out.skipped;
         }

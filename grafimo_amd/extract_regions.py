@@ -11,10 +11,11 @@ insertions and deletions of a phased VCF (what `grafimo buildvg` feeds `vg const
 Row semantics are those of vg's output as the reference's files pin them: the 32 rows of
 tests/test_data/expected_results/expected_seqs.tsv and the 704 rows of real `vg find -K 19 -E -H` output
 in its scoring fixture (SNPs, a deletion, haplotype counts, node paths) are reproduced exactly.  The
-graph holds the substitutions (also multi-base ones, one site per mismatching position), insertions and plain
+graph holds the substitutions (also multi-base ones, one site per mismatching position), insertions and
 deletions of the VCF -- what is assumed about insertions is stated in oracle/extract_oracle.py (no vg output pins it);
-complex and symbolic alleles are refused (or, opted in, left out and counted in
-`GraphIndex.skipped`).  There is no CPU fallback: extraction needs libgrafimo_hip.so and a GPU.
+complex alleles are taken apart into substitutions and one indel; records with a symbolic ALT are left out and
+counted in `GraphIndex.skipped`, as `vg construct` without --handle-sv (constructVG.py:332) leaves them out.
+There is no CPU fallback: extraction needs libgrafimo_hip.so and a GPU.
 """
 import ctypes
 import gzip
@@ -114,15 +115,19 @@ class GraphIndex:
 
     @classmethod
     def from_fasta_vcf(cls, fasta: str, vcf: str, chrom: str, with_haplotypes: bool = True,
-                       threads: int = 0, allow_skipped: bool = False) -> "GraphIndex":
+                       threads: int = 0, allow_skipped: bool = True) -> "GraphIndex":
         """Reference bases of `chrom` + its VCF records through the library's reader (gfm_vcf_*: host
         threads, plain or gzip/bgzip): substitutions (also multi-base ones, a site per position), insertions
         behind an anchor base and plain deletions become sites; two haplotypes per sample in file order.
         Every ALT is normalised against REF first (common trailing, then leading bases dropped), so the alleles of
-        an STR record become deletions / insertions behind its first base; deletions may overlap.  ALT alleles the
-        graph does not model (complex alleles -- neither of the above after normalisation --, symbolic alleles, a
-        fourth alternate base at one position) would make the k-mers differ from vg's: the call FAILS on them unless
-        `allow_skipped` is set, in which case they are left out, counted in `.skipped` and reported on stderr."""
+        an STR record become deletions / insertions behind its first base; deletions may overlap.  What is then still
+        none of these -- a complex allele, REF=ACG ALT=TC -- becomes the substitutions of its first
+        min(|REF|, |ALT|) bases plus an insertion / deletion of the rest behind the last of them, all with the allele's
+        carriers (`vg construct` decomposes by alignment instead: the same haplotype sequences, hence the same rows
+        with a haplotype count > 0; the recombinant rows of --recomb may differ).  A record with an ALT that is not a
+        string of A, C, G, T (symbolic <DEL> / <CN0> / <INS:ME:ALU>, breakends, '*') is left out whole, counted in
+        `.skipped` (its ALT alleles) and reported on stderr -- what `vg construct` without --handle-sv, the
+        reference's command line (constructVG.py:332), does with it.  `allow_skipped=False` turns that into an error."""
         ref = _read_fasta_record(fasta, chrom)
         h = ctypes.c_void_p()
         n, H, skipped = ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int64()
@@ -147,15 +152,14 @@ class GraphIndex:
             nv.lib().gfm_vcf_close(h)
         if int(skipped.value) and not allow_skipped:
             raise VGError(
-                f"\n\nERROR: {int(skipped.value)} ALT allele(s) on {chrom} are complex or symbolic (after normalisation "
-                f"neither a substitution, an insertion behind an anchor base, a deletion nor an equal-length multi-base "
-                f"substitution) or a fourth alternate base at one position. The extraction graph does "
-                f"not model them, so the k-mers would differ from `vg find`'s. Pass allow_skipped=True (CLI: "
-                f"--skip-unmodelled-variants) to leave them out knowingly.\n")
+                f"\n\nERROR: {int(skipped.value)} ALT allele(s) on {chrom} belong to records with a symbolic or "
+                f"otherwise non-ACGT allele (<DEL>, <CN0>, breakends, '*', more than 64 ALTs). The graph leaves such "
+                f"records out (as `vg construct` does without --handle-sv) and strict variant handling was asked "
+                f"for.\n")
         if int(skipped.value):
-            print(f"WARNING: {int(skipped.value)} ALT allele(s) on {chrom} (complex or symbolic alleles, a fourth "
-                  f"alternate base) are NOT part of the graph: k-mers through them are missing and their "
-                  f"neighbours keep the reference allele.", file=sys.stderr)
+            print(f"WARNING: {int(skipped.value)} ALT allele(s) on {chrom} belong to records with a symbolic or otherwise "
+                  f"non-ACGT allele: those records are NOT part of the graph (`vg construct` without --handle-sv skips "
+                  f"them too); their carriers keep the reference allele there.", file=sys.stderr)
         if V and int(ins_len.max()) > 0:
             print(f"NOTE: {int((ins_len > 0).sum())} insertion allele(s) on {chrom}: k-mers through inserted bases follow "
                   f"the rules written down in oracle/extract_oracle.py (coordinates of walks that start or end inside "

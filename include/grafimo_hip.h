@@ -351,9 +351,13 @@ int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, int64_t *d
  * position with up to 3 alternates, also across records), insertions, plain deletions, equal-length
  * multi-base substitutions (one substitution per mismatching position) -- after normalising the ALT against REF
  * (common trailing, then leading bases dropped: the alleles of an STR record REF=ATTT ALT=A,AT,ATT become deletions of
- * 3, 2, 1 bases behind its first base; up to sixteen ALT alleles per record); what is left (complex and symbolic
- * alleles, a fourth alternate base at one position) is counted in *n_skipped.  Deletions may overlap; two records that
- * delete the same bases merge their carriers.  Two haplotypes per sample in file order.
+ * 3, 2, 1 bases behind its first base; up to 64 ALT alleles per record).  What is then still none of these -- a
+ * complex allele, REF=ACG ALT=TC -- becomes the substitutions of its first min(|REF|, |ALT|) bases plus an insertion /
+ * deletion of the rest behind the last of them, with the allele's carriers (vg construct decomposes by alignment: same
+ * haplotype sequences).  A record with an ALT that is no string of A, C, G, T (symbolic <DEL> / <CN0>, breakends, '*')
+ * is left out whole, as `vg construct` without --handle-sv leaves it out; its ALT alleles are counted in *n_skipped.
+ * Deletions may overlap; two records that delete the same bases merge their carriers.  Two haplotypes per sample in
+ * file order.
  * gfm_vcf_read copies: pos [n], n_alts [n], alt_bases [n][3], del_len [n], alt_bits [n][3][ceil(H/64)]
  * (may be NULL). */
 typedef struct gfm_vcf *gfm_vcf_t;

@@ -49,6 +49,8 @@ def read_vcf_records(path: str, chrom: Optional[str] = None):
             if chrom is not None and f[0] != chrom:
                 continue
             alts = f[4].upper().split(",")
+            if any(not a or set(a) - set("ACGT") for a in alts):
+                continue          # a record with a symbolic ALT is not in the graph (vg construct without --handle-sv)
             gts: List[int] = []
             for s in f[9:]:
                 gt = s.split(":")[0].replace("/", "|").split("|")
@@ -111,7 +113,18 @@ def haplotype_sequence(ref: bytes, recs, h: int):
                 cur = pos + len(r)                               # the deleted bases are not copied
             last_sub = -1                                        # one indel per (possibly substituted) anchor
         else:
-            raise ValueError(f"complex allele at {pos}: not part of the modelled graph")
+            # a complex allele (REF=ACG ALT=TC after trimming): ALT replaces REF; its first min(|REF|, |ALT|) bases are
+            # aligned to the reference bases they replace, bases beyond that are inserted behind the last of them
+            if pos < cur:
+                raise ValueError(f"haplotype {h}: overlapping alleles at {pos}")
+            copy_ref(pos)
+            n = min(len(r), len(al))
+            for j in range(n):
+                out.append(ord(al[j])); coord.append(pos + j); ins.append(False); alt.append(al[j] != r[j])
+            for c in al[n:]:
+                out.append(ord(c)); coord.append(pos + n - 1); ins.append(True); alt.append(True)
+            cur = pos + len(r)
+            last_sub = -1
     copy_ref(len(ref))
     return out, coord, ins, alt
 

@@ -23,8 +23,10 @@ quay.io/vgteam/vg:v1.27.1).  Pinning:
     incl. chopping at 32 bases and the cuts a deletion makes;
   * NOT pinned (no vg binary here): everything about insertions and multi-base substitutions (modelled since
     round 2 by read_vcf_variants / enumerate_region_variants at the end of this file, whose header states
-    what is assumed), complex alleles (skipped and counted), overlapping deletions (the later one is skipped),
-    haplotype counts beyond consistency with the scoring fixture, multi-allelic sites' node order
+    what is assumed; complex alleles are taken apart there into substitutions + one indel, records with a symbolic
+    ALT are left out whole as `vg construct` without --handle-sv does), the rows of overlapping deletions,
+    haplotype counts beyond consistency with the scoring fixture (but see oracle/extract_bruteforce.py, which
+    derives counts and row sets from the haplotype sequences alone), multi-allelic sites' node order
     beyond "alternates first", and the fate of a deletion-crossing walk whose stop lies beyond the
     region end (dropped here: a walk is reported only if both of its ends lie inside the region,
     which is what limits the plain windows to start <= E - W in expected_seqs.tsv).
@@ -425,9 +427,15 @@ def read_vcf_variants(path: str, chrom: Optional[str] = None, ref: Optional[byte
             gts = np.asarray(gts, dtype=np.int64)
             p = int(f[1]) - 1
             before = len(atoms)
+            # a record with an ALT that is no string of A, C, G, T (symbolic, breakend, '*') is left out whole --
+            # vg construct without --handle-sv (constructVG.py:332) skips it with a warning
+            if not (len(r) > 0 and all(c in "ACGTN" for c in r)
+                    and all(len(a) > 0 and all(c in "ACGT" for c in a) for a in alts[:64])):
+                skipped += len(alts)
+                continue
             for k, a in enumerate(alts):
                 car = gts == k + 1
-                ok = all(c in "ACGT" for c in a) and all(c in "ACGTN" for c in r) and len(a) > 0 and k < 16
+                ok = k < 64
                 rr, aa, pp = r, a, p
                 if ok:                                   # per-allele normalisation: trailing, then leading bases
                     while len(rr) > 1 and len(aa) > 1 and rr[-1] == aa[-1]:
@@ -445,6 +453,18 @@ def read_vcf_variants(path: str, chrom: Optional[str] = None, ref: Optional[byte
                     for j, (x, y) in enumerate(zip(rr, aa)):
                         if x != y:
                             atoms.append((pp + j, 0, y, car))
+                elif ok:
+                    # a complex allele: substitutions over the common length, the rest an insertion / a deletion
+                    # behind the last of those bases, all with the allele's carriers (vg decomposes by alignment;
+                    # the haplotype sequences are the same either way)
+                    n = min(len(rr), len(aa))
+                    for j in range(n):
+                        if rr[j] != aa[j]:
+                            atoms.append((pp + j, 0, aa[j], car))
+                    if len(aa) > len(rr):
+                        atoms.append((pp + n - 1, 1, aa[n:].encode(), car))
+                    else:
+                        atoms.append((pp + n - 1, 2, len(rr) - n, car))
                 else:
                     skipped += 1
             if len(atoms) > before:

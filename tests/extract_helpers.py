@@ -8,8 +8,8 @@ REF_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r
 
 
 def make_graph_files(tmpdir, chrom="7", length=3000, n_sites=260, n_samples=65, seed=5, gz=True, rich=False):
-    """FASTA + VCF with: clustered and isolated SNPs, multi-allelic sites, deletions, a few complex records
-    (to be skipped), unphased and missing genotypes.  `rich`: also insertions of 1..6 bases (alone or next to a
+    """FASTA + VCF with: clustered and isolated SNPs, multi-allelic sites, deletions, a few records with a symbolic
+    ALT (to be skipped), unphased and missing genotypes.  `rich`: also insertions of 1..6 bases (alone or next to a
     substitution in one record), equal-length multi-base substitutions and second records at a position
     already used -- what only the round-2 reader / oracle (read_vcf_variants) take apart.  Returns (fasta, vcf)."""
     rng = np.random.default_rng(seed)
@@ -42,8 +42,8 @@ def make_graph_files(tmpdir, chrom="7", length=3000, n_sites=260, n_samples=65, 
             kind = rng.random()
             if kind < 0.06:                      # deletion record
                 alt, refa = r, r + "".join(ref[p + 1:p + 3])
-            elif kind < 0.10 and not rich:       # complex allele (two bases replaced by one other base): skipped
-                alt, refa = others[0], r + "".join(ref[p + 1:p + 2])
+            elif kind < 0.10 and not rich:       # a symbolic allele: the record belongs to no graph (skipped, counted)
+                alt, refa = "<DEL>", r
             elif kind < 0.14 and rich:           # insertion of 1..6 bases behind the anchor
                 alt, refa = r + "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 7)))), r
             elif kind < 0.18 and rich:           # multi-base substitution (at least one base differs)
@@ -52,10 +52,12 @@ def make_graph_files(tmpdir, chrom="7", length=3000, n_sites=260, n_samples=65, 
                 alt, refa = (sub if sub != span else others[0] + span[1:]), span
                 if "N" in span or len(span) < 2:
                     alt, refa = others[0], r
-            elif kind < 0.21 and rich:           # complex allele: skipped
+            elif kind < 0.21 and rich:           # complex allele: a substitution and a deletion behind it
                 alt, refa = others[0], r + "".join(ref[p + 1:p + 2])
                 if len(refa) < 2:
                     alt, refa = others[0], r
+            elif kind < 0.225 and rich:          # a base allele and a symbolic one: the whole record is left out
+                alt, refa = others[0] + ",<CN0>", r
             elif kind < 0.25 and rich:           # a substitution and an insertion in one record
                 alt, refa = others[0] + "," + r + "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 4)))), r
             else:
@@ -121,7 +123,9 @@ def make_consistent_graph_files(tmpdir, chrom="c", length=600, n_samples=24, see
     Only alleles the extraction graph models (kinds: s substitutions incl. multi-allelic, i insertions, d deletions,
     m equal-length multi-base substitutions, D one record whose alleles delete different stretches of its REF --
     several lengths behind one anchor and nested deletions with anchors further right, what an STR record normalises
-    to -- and O two records whose deletions overlap, the second carried only by haplotypes without the first).
+    to --, O two records whose deletions overlap, the second carried only by haplotypes without the first, c complex
+    alleles: REF and ALT of different lengths that share neither their first nor their last base, and S records with a
+    symbolic ALT, which belong to no graph: `vg construct` without --handle-sv leaves them out whole).
     Returns (fasta, vcf)."""
     rng = np.random.default_rng(seed)
     ref = "".join(rng.choice(list("ACGT"), size=length, p=[0.3, 0.2, 0.2, 0.3]))
@@ -194,6 +198,31 @@ def make_consistent_graph_files(tmpdir, chrom="c", length=600, n_samples=24, see
             p2 = p + min(shift, l1)                       # anchored on a base the first deletion removes
             emit(p2, ref[p2:p2 + 1 + l2], [ref[p2]], genotypes(1, allowed=g1 == 0))
             end = max(p + 1 + l1, p2 + 1 + l2)
+        elif kind == "c":
+            lr = int(rng.integers(1, 5))
+            span = ref[p:p + lr]
+            alts = []
+            for _ in range(int(rng.choice([1, 1, 2]))):
+                la = int(rng.choice([x for x in range(1, 7) if x != lr]))
+                a = "".join(rng.choice(list("ACGT"), size=la))
+                # neither end shared with REF: normalisation cannot reduce it to a substitution or a plain indel
+                a = rng.choice([b for b in "ACGT" if b != span[0]]) + a[1:]
+                if la > 1 and lr > 1:
+                    a = a[:-1] + rng.choice([b for b in "ACGT" if b != span[-1]])
+                alts.append(a)
+            alts = list(dict.fromkeys(alts))
+            emit(p, span, alts, genotypes(len(alts)))
+            end = p + lr
+        elif kind == "S":
+            form = int(rng.integers(0, 4))
+            if form == 0:
+                emit(p, r, ["<DEL>"], genotypes(1))
+            elif form == 1:
+                emit(p, r, [others[0], "<CN0>"], genotypes(2))      # the base allele goes with the record
+            elif form == 2:
+                emit(p, ref[p:p + 3], [r, "*"], genotypes(2))
+            else:
+                emit(p, r, [r + "[" + chrom + ":5["], genotypes(1))
         else:
             ln = int(rng.integers(2, 5))
             span = ref[p:p + ln]
@@ -203,6 +232,8 @@ def make_consistent_graph_files(tmpdir, chrom="c", length=600, n_samples=24, see
             emit(p, span, [sub], genotypes(1))
             end = p + ln
         gap = int(rng.integers(0, 6)) if (dense and rng.random() < 0.7) else int(rng.integers(6, 40))
+        if kind == "c":
+            gap += 6              # up to five sites each: keeps the walks of a window enumerable in Python
         p = end + gap
     vcf = os.path.join(tmpdir, f"cons{seed}.vcf" + (".gz" if gz else ""))
     op = gzip.open if gz else open

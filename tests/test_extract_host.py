@@ -283,16 +283,16 @@ def test_bed_reader_follows_the_reference(tmp_path):
         get_regions_bed(7, True)
 
 
-def test_unmodelled_vcf_records_fail_closed(tmp_path, capsys):
-    """insertions / MNPs / overlapping deletions are refused unless the caller opts in; then they
-    are counted and reported on stderr."""
+def test_records_with_symbolic_alleles_are_left_out_and_reported(tmp_path, capsys):
+    """Records with a symbolic ALT are left out like `vg construct` (no --handle-sv) leaves them out: counted and
+    reported on stderr; strict handling turns them into an error."""
     from grafimo_amd.extract_regions import GraphIndex
     from grafimo_amd.grafimo_errors import VGError
     fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=3000, n_sites=260, seed=5)
     with pytest.raises(VGError) as e:
-        GraphIndex.from_fasta_vcf(fasta, vcf, "7")
-    assert "does not model them" in str(e.value)
-    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7", allow_skipped=True)
+        GraphIndex.from_fasta_vcf(fasta, vcf, "7", allow_skipped=False)
+    assert "strict variant handling" in str(e.value)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
     assert idx.skipped > 0 and "NOT part of the graph" in capsys.readouterr().err
     saved = idx.save(str(tmp_path / "chr7"))
     back = GraphIndex.load(saved)
@@ -324,7 +324,7 @@ def _index_equals_variants(idx, v):
 
 def test_reader_takes_insertions_and_multibase_substitutions_apart(tmp_path):
     """Round 2 (UNPINNED semantics, oracle/extract_oracle.py read_vcf_variants): per-ALT decomposition,
-    same-position merge, insertions, MNPs -- the C++ reader against the oracle reader on rich random VCFs,
+    same-position merge, insertions, MNPs, complex alleles, records with symbolic ALTs -- the C++ reader against the oracle reader on rich random VCFs,
     one thread and many."""
     from grafimo_amd.extract_regions import GraphIndex
     from oracle import extract_oracle as xo
@@ -352,14 +352,17 @@ def test_reader_takes_insertions_and_multibase_substitutions_apart(tmp_path):
             "c\t9\t.\tAC\tA\t.\t.\t.\tGT\t1|0\t0|0",
             "c\t10\t.\tCG\tC\t.\t.\t.\tGT\t1|0\t0|0",           # its anchor is a base the deletion before it removes: both are sites
             "c\t12\t.\tG\t<DEL>\t.\t.\t.\tGT\t1|0\t0|0",        # symbolic: skipped
-            "c\t13\t.\tAC\tGT,A\t.\t.\t.\tGT\t1|2\t0|0"]        # an MNP and a deletion in one record
+            "c\t13\t.\tAC\tGT,A\t.\t.\t.\tGT\t1|2\t0|0",        # an MNP and a deletion in one record
+            "c\t16\t.\tTT\tGAC\t.\t.\t.\tGT\t0|1\t0|0"]         # complex: two substitutions and an insertion behind the second
     vcf.write_text(head + "\n".join(body) + "\n")
     fasta = tmp_path / "corner.fa"
     fasta.write_text(">c\nTTTTACGTACGGACTTTT\n")
     v = xo.read_vcf_variants(str(vcf), "c")
-    assert [(p, k) for p, k in zip(v.pos, v.kind)] == [(4, 0), (4, 1), (4, 1), (5, 0), (7, 0), (8, 2), (9, 2), (12, 0), (12, 2), (13, 0)]
+    assert [(p, k) for p, k in zip(v.pos, v.kind)] == [(4, 0), (4, 1), (4, 1), (5, 0), (7, 0), (8, 2), (9, 2), (12, 0), (12, 2), (13, 0),
+                                                      (15, 0), (16, 0), (16, 1)]
     assert v.alts[0] == ["G", "T", "C"] and v.seq[1:3] == [b"GG", b"TT"] and v.alts[3] == ["T"] and v.alts[4] == ["A", "C"]
-    assert v.skipped == 1
+    assert v.skipped == 1 and v.alts[-3:-1] == [["G"], ["A"]] and v.seq[-1] == b"C"
+    assert v.carriers[-1][0].tolist() == v.carriers[-2][0].tolist() == [False, True, False, False]
     assert v.carriers[0][0].tolist() == [True, False, True, False] and v.carriers[1][0].tolist() == [True, False, True, False]
     idx = GraphIndex.from_fasta_vcf(str(fasta), str(vcf), "c", threads=2, allow_skipped=True)
     _index_equals_variants(idx, v)

@@ -268,12 +268,12 @@ def test_several_graphs_share_one_scoring_pass_and_cli_mode(tmp_path, capsys):
     assert len(one) > 0 and one.equals(two)
     g.close()
     out = tmp_path / "cli_out"
-    with pytest.raises(Exception) as e:                 # fail closed on records the graph does not model
+    with pytest.raises(Exception) as e:                 # strict: records with symbolic ALTs are an error
         main(["-m", os.path.join(REF_DATA, "MA0139.1.meme"), "-l", fasta, "-v", vcf, "-b", str(bed), "-t", "0.05",
-              "--recomb", "-o", str(out), "--debug"])
-    assert "does not model them" in str(e.value)
+              "--recomb", "-o", str(out), "--debug", "--strict-variants"])
+    assert "strict variant handling" in str(e.value)
     main(["-m", os.path.join(REF_DATA, "MA0139.1.meme"), "-l", fasta, "-v", vcf, "-b", str(bed), "-t", "0.05",
-          "--recomb", "-o", str(out), "--verbose", "--skip-unmodelled-variants"])
+          "--recomb", "-o", str(out), "--verbose"])         # default: left out with a warning, as vg construct does
     assert "deletions), 130 haplotypes" in capsys.readouterr().out
     tsv = pd.read_csv(out / "grafimo_out.tsv", sep="\t", index_col=0)
     assert len(tsv) == len(one) and list(tsv["matched_sequence"]) == list(one["matched_sequence"])
@@ -451,7 +451,7 @@ def test_jumping_walks_must_end_inside_the_region():
     g.close()
 
 
-@pytest.mark.parametrize("kinds", ["s", "sd", "si", "sidm", "sD", "sO", "sidmDO"])
+@pytest.mark.parametrize("kinds", ["s", "sd", "si", "sidm", "sD", "sO", "sidmDO", "sc", "sidmDOcS"])
 def test_hip_rows_equal_the_per_haplotype_brute_force(tmp_path, kinds):
     """the kernels' rows against an algorithm that enumerates no walks at all -- every haplotype of the
     VCF as a linear sequence, W-windows slid over it (oracle/extract_bruteforce.py): a row's haplotype count is the
@@ -489,8 +489,9 @@ def test_hip_rows_equal_the_per_haplotype_brute_force(tmp_path, kinds):
         ref = xo.read_fasta(fasta)[chrom]
         recs, H = bf.read_vcf_records(vcf, chrom)
         assert bf.consistent(ref, recs, H)
-        idx = GraphIndex.from_fasta_vcf(fasta, vcf, chrom)            # fail-closed: every allele is part of the graph
-        assert idx.skipped == 0 and idx.n_haplotypes == H
+        idx = GraphIndex.from_fasta_vcf(fasta, vcf, chrom)
+        # every allele is part of the graph, except those of records with a symbolic ALT (kind S: in no graph)
+        assert (idx.skipped > 0) == ("S" in kinds) and idx.n_haplotypes == H
         g = DeviceGraph(idx)
         for (S, E), W in plans:
             freq, flags = bf.window_counts(ref, recs, H, S, E, W)
