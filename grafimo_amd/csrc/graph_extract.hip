@@ -15,6 +15,8 @@
 // (sites-in-window x ceil(H/64) x 8 B per walk, re-used across the W overlapping windows of a site).
 
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -49,7 +51,15 @@ constexpr int kCountThreads = 256;
 constexpr int kEmitThreads = 256;                    // walks (threads) per workgroup of the emit kernel
 constexpr long long kMaxWalksPerWindow = 1ll << 20;  // refuse pathological windows (2^20 walks)
 
+// One site as the walk simulation reads it: one 16-byte load instead of four loads from four arrays.  The array holds
+// kSitePad records behind the last site whose pos is kNoSitePos, so a scan for "the sites at x" ends by itself.
+struct SiteRec { int pos, del_len, ins_len, n_alts; };
+constexpr int kNoSitePos = 0x7fffffff;
+constexpr int kSiteCache = 8;        // records of the window's first sites an emit thread keeps in LDS
+constexpr int kSitePad = kSiteCache + 1;
+
 struct GraphDev {
+    const SiteRec *site_rec;    // [n_sites + kSitePad]
     const uint8_t *ref;         // [ref_len]
     long long ref_len;
     int n_sites;
@@ -91,13 +101,14 @@ constexpr int kMaxConstraints = 96;    // allele constraints of one walk: <= 64 
 struct WalkState {
     int nd = 0;
     long long last = 0;                       // reference position of the last base
-    unsigned char choice[kMaxDecisions];      // 0 / 1 per deletion met
+    unsigned choice = 0;                      // bit d: 0 / 1 at the d-th decision (a register: as a byte array it lived in
+                                              // scratch memory, and every read waited for the scratch stores before it)
 };
 enum { WALK_OK = 0, WALK_DEAD = 1, WALK_OVERFLOW = 2 };
 
 struct NoVisitor {
     static constexpr bool kWantsBases = false;     // stretches without a site are skipped in one step
-    __device__ void base(int, long long, int, int) {}
+    __device__ void base(int, long long, int, int, int) {}
     __device__ void ins_base(int, int, int) {}
     __device__ void took(int) {}
     __device__ void passed(int) {}
@@ -129,14 +140,31 @@ __device__ inline bool next_start(const GraphDev &g, long long p, int i0, WalkSt
 // chromosome: vg reports a walk only if both of its ends map into the region.  `prod` returns
 // the number of allele combinations of the layout.  When the visitor wants bases, walk `q` of the
 // layout is decoded on the way: rem starts as the layout's product and is divided at every SNP.
-template <class V>
-__device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, const WalkStart &ws, int prefix,
+// Where simulate() reads site records: straight from the array, or from the copy of the window's first kSiteCache
+// records an emit thread made in LDS (one batch of loads) -- a walk is a chain of "what is at x" questions, and as
+// global loads each answer was an L2 round trip.
+struct GlobalSites {
+    const SiteRec *rec;
+    __device__ SiteRec at(int k) const { return rec[k]; }
+};
+struct CachedSites {
+    const SiteRec *rec;
+    const SiteRec *lds;      // [kSiteCache] records of sites first .. first + kSiteCache - 1
+    int first;
+    __device__ SiteRec at(int k) const
+    {
+        const unsigned d = (unsigned)(k - first);
+        return d < (unsigned)kSiteCache ? lds[d] : rec[k];
+    }
+};
+
+template <class V, class S>
+__device__ inline int simulate(const GraphDev &g, const S &sites, long long p, int W, int i0, const WalkStart &ws, int prefix,
                                WalkState &st, V &vis, long long q, long long rem, long long &prod, long long limit)
 {
-    constexpr long long kNoSite = 0x7fffffffffffffffll;
     long long x = p;
     int n = 0, d = 0, i = i0;
-    long long next_pos = i < g.n_sites ? (long long)g.pos[i] : kNoSite;   // position of site i, kept in a register
+    long long next_pos = sites.at(i).pos;               // position of site i (kNoSitePos behind the last), kept in a register
     prod = 1;
     if (ws.site >= 0) {                                // the walk starts on base ws.t of an insertion behind p - 1
         int take = g.ins_len[ws.site] - ws.t;
@@ -151,7 +179,7 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, co
         if (x >= g.ref_len) { st.nd = d; return WALK_DEAD; }
         while (next_pos < x) {                         // only after a jump over deleted bases
             ++i;
-            next_pos = i < g.n_sites ? (long long)g.pos[i] : kNoSite;
+            next_pos = sites.at(i).pos;
         }
         if (next_pos > x) {                            // no site here
             if constexpr (!V::kWantsBases) {
@@ -164,21 +192,24 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, co
                 if (n == W) { st.nd = d; st.last = x - 1; return x <= limit ? WALK_OK : WALK_DEAD; }
                 continue;
             } else {
-                vis.base(n, x, -1, 0);
+                vis.base(n, x, -1, 0, 1);
                 if (++n == W) { st.nd = d; st.last = x; return x + 1 <= limit ? WALK_OK : WALK_DEAD; }
                 ++x;
                 continue;
             }
         }
         int snp = -1, del0 = -1, del1 = -1, ins0 = -1, ins1 = -1;   // insertions / deletions anchored here: sites [a, b)
-        for (int k = i; k < g.n_sites && g.pos[k] == x; ++k) {
-            if (g.del_len[k] > 0) { if (del0 < 0) del0 = k; del1 = k + 1; }
-            else if (g.ins_len[k] > 0) { if (ins0 < 0) ins0 = k; ins1 = k + 1; }
-            else snp = k;
+        int snp_alts = 0;
+        for (int k = i; k < g.n_sites; ++k) {
+            const SiteRec r = sites.at(k);
+            if (r.pos != x) break;
+            if (r.del_len > 0) { if (del0 < 0) del0 = k; del1 = k + 1; }
+            else if (r.ins_len > 0) { if (ins0 < 0) ins0 = k; ins1 = k + 1; }
+            else { snp = k; snp_alts = r.n_alts; }
         }
-        int a = 0;
+        int a = 0, nall = 1;
         if (snp >= 0) {
-            const int nall = 1 + g.n_alts[snp];
+            nall = 1 + snp_alts;
             prod *= nall;
             if (prod > kMaxWalksPerWindow) { st.nd = d; return WALK_OVERFLOW; }
             if constexpr (V::kWantsBases) {
@@ -186,16 +217,16 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, co
                 a = (int)((q / rem) % nall);
             }
         }
-        vis.base(n, x, snp, a);
+        vis.base(n, x, snp, a, nall);
         if (++n == W) { st.nd = d; st.last = x; return x + 1 <= limit ? WALK_OK : WALK_DEAD; }
         bool read_ins = false;
         for (int k = ins0; k >= 0 && k < ins1; ++k) {   // read insertion k?  (0 = no, 1 = yes; a yes ends the site)
             if (d >= kMaxDecisions) { st.nd = d; return WALK_OVERFLOW; }
-            const int c = d < prefix ? st.choice[d] : 0;
-            st.choice[d] = (unsigned char)c;
+            const int c = d < prefix ? (int)((st.choice >> d) & 1u) : 0;
+            st.choice = (st.choice & ~(1u << d)) | ((unsigned)c << d);
             ++d;
             if (!c) { vis.passed(k); continue; }
-            int take = g.ins_len[k];
+            int take = sites.at(k).ins_len;
             if (take > W - n) take = W - n;
             if constexpr (V::kWantsBases)
                 for (int j = 0; j < take; ++j) vis.ins_base(n + j, k, j);
@@ -212,8 +243,8 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, co
         if (!read_ins)
             for (int k = del0; k >= 0 && k < del1; ++k) {
                 if (d >= kMaxDecisions) { st.nd = d; return WALK_OVERFLOW; }
-                const int c = d < prefix ? st.choice[d] : 0;
-                st.choice[d] = (unsigned char)c;
+                const int c = d < prefix ? (int)((st.choice >> d) & 1u) : 0;
+                st.choice = (st.choice & ~(1u << d)) | ((unsigned)c << d);
                 ++d;
                 if (c) { jumped = k; break; }
             }
@@ -222,14 +253,17 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, co
             ++x;
         } else {
             vis.took(jumped);
-            const int len = g.del_len[jumped];
+            const int len = sites.at(jumped).del_len;
             for (int k = del0; k < del1; ++k)
-                if (k != jumped && g.del_len[k] > len) vis.passed(k);
+                if (k != jumped && sites.at(k).del_len > len) vis.passed(k);
             const long long land = x + len + 1;
             // sites inside the jumped span are never visited; a deletion anchored there that reaches beyond the
             // landing place has bases the walk uses
-            for (int k = del1; k < g.n_sites && g.pos[k] < land; ++k)
-                if (g.del_len[k] > 0 && (long long)g.pos[k] + g.del_len[k] >= land) vis.passed(k);
+            for (int k = del1; k < g.n_sites; ++k) {
+                const SiteRec r = sites.at(k);
+                if (r.pos >= land) break;
+                if (r.del_len > 0 && (long long)r.pos + r.del_len >= land) vis.passed(k);
+            }
             x = land;
         }
     }
@@ -239,9 +273,9 @@ __device__ inline int simulate(const GraphDev &g, long long p, int W, int i0, co
 __device__ inline int next_walk(WalkState &st)
 {
     int t = st.nd - 1;
-    while (t >= 0 && st.choice[t]) --t;
+    while (t >= 0 && ((st.choice >> t) & 1u)) --t;
     if (t < 0) return -1;
-    st.choice[t] = 1;
+    st.choice |= 1u << t;
     return t + 1;
 }
 
@@ -291,6 +325,13 @@ struct LayoutRec {
     unsigned choice;     // bits 0..23: the jump / insertion decisions, bits 24..31: how many were taken
     int site, t;         // WalkStart of the layout
 };
+// a listed window as its walks' threads need it (one 32-byte record instead of a chain of lookups by window index)
+struct DelRec {
+    long long p, limit;  // window start, end of its region
+    int w, i0;           // window index, first site at or behind p
+    int pad[2];
+};
+constexpr int kDelThreads = 128;     // walks (threads) per workgroup of graph_emit_del_kernel
 
 // one thread per window: first site inside it and the number of walks (product of allele counts)
 __global__ void __launch_bounds__(kCountThreads)
@@ -298,7 +339,8 @@ graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ regi
                    const long long *__restrict__ first_start, const long long *__restrict__ region_stop, int W,
                    long long n_windows, int *__restrict__ first_site, long long *__restrict__ n_walks,
                    int *__restrict__ win_region, long long *__restrict__ win_start, int *__restrict__ overflow,
-                   int *__restrict__ del_list, int *__restrict__ del_count)
+                   int *__restrict__ del_list, int *__restrict__ del_count, int *__restrict__ win_sites,
+                   unsigned long long *__restrict__ slow_totals)
 {
     const long long w = (long long)blockIdx.x * kCountThreads + threadIdx.x;
     if (w >= n_windows) return;
@@ -308,7 +350,8 @@ graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ regi
     long long walks = 1;
     bool touches_del = g.n_dels > 0 && covered_by_deletion(g, p, i0);
     bool over = false;      // too many walks for a plain window -- reported only if the window is kept as one
-    for (int i = i0; i < g.n_sites && g.pos[i] < p + W; ++i) {
+    int ns = 0;
+    for (int i = i0; i < g.n_sites && g.pos[i] < p + W; ++i, ++ns) {
         if (g.del_len[i] || g.ins_len[i]) touches_del = true;
         if (!over) {
             walks *= 1 + g.n_alts[i];
@@ -332,21 +375,39 @@ graph_count_kernel(GraphDev g, int n_regions, const long long *__restrict__ regi
     } else if (over) {
         walks = 0;
         atomicMax(overflow, 1);
+    } else if (ns > 3 && walks > 0 && g.alt_bits) {
+        // its walks' haplotype counts need the bitsets: room for their count jobs (exact; see CountJobs)
+        atomicAdd(&slow_totals[0], (unsigned long long)walks);
+        atomicAdd(&slow_totals[1], (unsigned long long)walks * (unsigned long long)ns);
     }
     first_site[w] = i0;
     n_walks[w] = walks;
     win_region[w] = r;      // the emit kernel reads these instead of repeating the search: its waves
     win_start[w] = p;       // are latency-bound, and a binary search is a chain of dependent loads
+    win_sites[w] = touches_del ? 0 : ns;   // the sites a plain window's walks choose alleles at (a listed window's rows are
+                                           // placeholders in the plain kernel: no work for them there)
 }
 
-__device__ inline uint8_t complement(uint8_t c)
+// A <-> T, C <-> G in either case, everything else (N) stays.  Without branches: the emit kernels call it per base,
+// and as a switch it was four to eight divergent branches each time.  Letters differ in their low five bits
+// (A 1, C 3, G 7, T 20); A ^ T = 0x15, C ^ G = 0x04.
+__device__ __forceinline__ uint8_t complement(uint8_t c)
 {
-    switch (c) {
-    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
-    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
-    default: return c;   // N stays N
-    }
+    const unsigned t = c & 31u;
+    const unsigned letter = ((c & 0xC0u) == 0x40u) ? 1u : 0u;
+    const unsigned at = (((1u << 1) | (1u << 20)) >> t) & letter;
+    const unsigned cg = (((1u << 3) | (1u << 7)) >> t) & letter;
+    return (uint8_t)(c ^ (at * 0x15u) ^ (cg * 0x04u));
 }
+
+// unaligned loads (gfx950 under HSA handles them in hardware; the arrays read this way are padded behind their end)
+__device__ __forceinline__ unsigned long long load_u64(const void *p)
+{
+    unsigned long long v;
+    __builtin_memcpy(&v, p, sizeof v);
+    return v;
+}
+constexpr size_t kReadPad = 16;     // bytes behind d_ref, d_n_alts, d_pos that such a load may touch
 
 // thread per listed deletion window: number of walks by running the odometer
 __global__ void __launch_bounds__(kCountThreads)
@@ -354,13 +415,15 @@ graph_count_del_kernel(GraphDev g, const int *__restrict__ del_list, const int *
                        const long long *__restrict__ win_start, const int *__restrict__ win_region,
                        const long long *__restrict__ region_stop, int W, const int *__restrict__ first_site,
                        long long *__restrict__ n_walks, long long *__restrict__ del_walks, int *__restrict__ overflow,
-                       LayoutRec *__restrict__ layouts /* [listed][kLayoutCache] */, int *__restrict__ n_layouts)
+                       LayoutRec *__restrict__ layouts /* [listed][kLayoutCache] */, int *__restrict__ n_layouts,
+                       DelRec *__restrict__ del_rec)
 {
     const int m = blockIdx.x * kCountThreads + threadIdx.x;
     if (m >= *del_count) return;
     const int w = del_list[m];
     const long long p = win_start[w];
     const int i0 = first_site[w];
+    del_rec[m] = DelRec{p, region_stop[win_region[w]], w, i0, {0, 0}};
     WalkState st;
     NoVisitor nv;
     WalkStart ws;
@@ -371,12 +434,11 @@ graph_count_del_kernel(GraphDev g, const int *__restrict__ del_list, const int *
         int prefix = 0;
         do {
             long long prod = 0;
-            const int rc = simulate(g, p, W, i0, ws, prefix, st, nv, 0, 0, prod, region_stop[win_region[w]]);
+            const int rc = simulate(g, GlobalSites{g.site_rec}, p, W, i0, ws, prefix, st, nv, 0, 0, prod, region_stop[win_region[w]]);
             if (rc == WALK_OK) {
                 walks += prod;
                 if (nl < kLayoutCache && walks <= kMaxWalksPerWindow) {
-                    unsigned bits = (unsigned)st.nd << 24;
-                    for (int d = 0; d < st.nd; ++d) bits |= (unsigned)(st.choice[d] & 1u) << d;
+                    const unsigned bits = ((unsigned)st.nd << 24) | (st.choice & ((1u << st.nd) - 1u));
                     layouts[(size_t)m * kLayoutCache + nl] = LayoutRec{(int)walks, bits, ws.site, ws.t};
                 }
                 ++nl;
@@ -478,12 +540,13 @@ graph_map_kernel(long long n_windows, const long long *__restrict__ walk_base, i
 
 // Haplotypes that carry allele a_k at site s_k for every k < n (allele 0 = none of the alternates; a
 // deletion is a site with one alternate: 1 = carries it).  No constraint: all; one: the popcount table;
-// more: the pair / triple tables for
-// neighbouring sites, else the AND of the bitsets, sixteen words per trip so that their loads are in flight together (one word
-// per trip made every such walk a chain of ~hw dependent L2 latencies).
+// two or three neighbouring sites: the pair / triple tables; else the AND of the bitsets.
+// `done` = false: the walk needs the bitsets (count_by_bitsets, or a deferred job: CountJobs).
 template <class F>
-__device__ inline long long count_carriers(const GraphDev &g, const int *__restrict__ allele_count, int n, F at)
+__device__ __forceinline__ long long count_by_tables(const GraphDev &g, const int *__restrict__ allele_count, int n, F at,
+                                                     bool &done)
 {
+    done = true;
     if (!g.alt_bits) return 0;
     if (n == 0) return g.n_hap;
     if (n == 1) {
@@ -514,6 +577,15 @@ __device__ inline long long count_carriers(const GraphDev &g, const int *__restr
         if (sv[1] == sv[0] + 1 && sv[2] == sv[0] + 2)
             return g.triple_count[(size_t)sv[0] * 64 + av[0] * 16 + av[1] * 4 + av[2]];
     }
+    done = false;
+    return 0;
+}
+
+// the AND of the bitsets, sixteen words per trip so that their loads are in flight together (one word per trip made
+// every such walk a chain of ~hw dependent L2 latencies)
+template <class F>
+__device__ inline long long count_by_bitsets(const GraphDev &g, int n, F at)
+{
     constexpr int kWordsPerTrip = 16;
     long long count = 0;
     for (int w0 = 0; w0 < g.hw; w0 += kWordsPerTrip) {
@@ -550,6 +622,86 @@ __device__ inline long long count_carriers(const GraphDev &g, const int *__restr
     return count;
 }
 
+// Walks whose count needs the bitsets are rare among the plain walks (four or more sites in one window: 0.5 % of the
+// walks of the bench's graph) and a third of the deletion walks -- but one such lane kept its whole wave in
+// count_by_bitsets (a quarter of the plain kernel's waves held one: 169 us with them, 99 us without; the deletion kernel
+// 173 against 118 us).  The emit kernels therefore only NOTE such a walk -- a job: where its count goes and its
+// constraints, each as site * 16 + (alternates of the site) * 4 + allele -- and graph_count_jobs_kernel, sixteen lanes per
+// job, counts them afterwards.  The plain walks' share of the lists is exact (graph_count_kernel adds it up per plan), so
+// the plain kernel holds no bitset code at all; a deletion walk that finds its share full is counted in place as before.
+struct JobHead {
+    long long dst;            // t >= 0: rows 2 t, 2 t + 1 of the freq column;  ~td < 0: the staged deletion walk td
+    int off, n;               // its constraints: pool[off .. off + n);  n <= 0: no job (its walk was counted in place)
+};
+struct CountJobs {
+    int *counters;            // [0] plain jobs, [1] plain pool entries, [2] deletion jobs, [3] deletion pool entries
+    JobHead *head;            // [plain_jobs + del_jobs]: the plain kernel's jobs first
+    int *pool;                // [plain_pool + del_pool]
+    int plain_jobs, plain_pool, del_jobs, del_pool;     // capacities
+};
+__device__ __forceinline__ int job_constraint(int site, int n_alts, int allele) { return site * 16 + n_alts * 4 + allele; }
+
+constexpr int kJobLanes = 16;
+constexpr int kJobWords = 5;     // bitset words per lane and pass: 80 words (5 120 haplotypes) in one
+__global__ void __launch_bounds__(256)
+graph_count_jobs_kernel(GraphDev g, CountJobs jobs, int which /* 0: the plain kernel's jobs, 1: the deletion kernel's */,
+                        long long *__restrict__ freq, long long *__restrict__ stg_meta, int meta_pitch)
+{
+    const int lane = threadIdx.x & (kJobLanes - 1);
+    const int group = (int)((blockIdx.x * blockDim.x + threadIdx.x) / kJobLanes);
+    const int n_groups = (int)((gridDim.x * blockDim.x) / kJobLanes);
+    const int n_jobs = which == 0 ? min(jobs.counters[0], jobs.plain_jobs) : min(jobs.counters[2], jobs.del_jobs);
+    const JobHead *heads = jobs.head + (which == 0 ? 0 : jobs.plain_jobs);
+    for (int jj = group; jj < n_jobs; jj += n_groups) {
+        const JobHead h = heads[jj];
+        if (h.n <= 0) continue;
+        const int *cons = jobs.pool + h.off;
+        long long count = 0;
+        for (int w0 = 0; w0 < g.hw; w0 += kJobLanes * kJobWords) {
+            unsigned long long acc[kJobWords];
+#pragma unroll
+            for (int i = 0; i < kJobWords; ++i) {
+                const int word = w0 + i * kJobLanes + lane;
+                acc[i] = word < g.hw ? ~0ull : 0ull;
+                if (word == g.hw - 1 && (g.n_hap & 63)) acc[i] = (1ull << (g.n_hap & 63)) - 1ull;
+            }
+            for (int k0 = 0; k0 < h.n; k0 += 4) {
+                int c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) c[u] = k0 + u < h.n ? cons[k0 + u] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (c[u] < 0) continue;
+                    const int a = c[u] & 3, na = (c[u] >> 2) & 3;
+                    const unsigned long long *b = g.alt_bits + ((size_t)(c[u] >> 4) * kMaxAlts) * g.hw + w0 + lane;
+#pragma unroll
+                    for (int i = 0; i < kJobWords; ++i) {
+                        if (w0 + i * kJobLanes + lane >= g.hw) continue;
+                        unsigned long long bits;
+                        if (a > 0) {
+                            bits = b[(size_t)(a - 1) * g.hw + i * kJobLanes];
+                        } else {
+                            bits = b[i * kJobLanes];
+                            if (na > 1) bits |= b[(size_t)g.hw + i * kJobLanes];
+                            if (na > 2) bits |= b[(size_t)2 * g.hw + i * kJobLanes];
+                            bits = ~bits;
+                        }
+                        acc[i] &= bits;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kJobWords; ++i) count += __popcll(acc[i]);
+        }
+#pragma unroll
+        for (int off = kJobLanes / 2; off > 0; off >>= 1) count += __shfl_xor(count, off, kJobLanes);
+        if (lane == 0) {
+            if (h.dst >= 0) { freq[2 * h.dst] = count; freq[2 * h.dst + 1] = count; }
+            else stg_meta[(size_t)(~h.dst) * meta_pitch + 3] = count;
+        }
+    }
+}
+
 // Thread per walk.  Neighbouring threads are walks of one window or of overlapping windows: their
 // reference bytes, site records and bitset words are the same cache lines, and every per-row column
 // is written fully coalesced (rows 2t and 2t+1 of thread t).  The walk index is a mixed-radix number
@@ -559,9 +711,10 @@ __device__ __forceinline__ void
 emit_plain_body(const unsigned bid, const GraphDev &g, const int *__restrict__ allele_count, const int *__restrict__ walk_window,
                   const int *__restrict__ win_region, const long long *__restrict__ win_start, int W,
                   long long n_walks, const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+                  const int *__restrict__ win_sites,
                   uint8_t *__restrict__ kmers, long long *__restrict__ start, long long *__restrict__ stop,
                   uint8_t *__restrict__ strand, long long *__restrict__ freq, uint8_t *__restrict__ is_ref,
-                  int *__restrict__ region, int *__restrict__ walk)
+                  int *__restrict__ region, int *__restrict__ walk, const bool wide_rows, const CountJobs &jobs)
 {
     // the block's 2 x 256 k-mer rows are contiguous in the output: they are assembled in LDS with
     // byte writes and leave with 16-byte coalesced stores (row starts are not even dword aligned)
@@ -573,6 +726,8 @@ emit_plain_body(const unsigned bid, const GraphDev &g, const int *__restrict__ a
     const int w = walk_window[tt];
     const long long p = win_start[w];
     const int i0 = first_site[w];
+    const int ns = win_sites[w];
+    const int r = win_region[w];
     int q = (int)(tt - walk_base[w]);
     const int q0 = q;
     uint8_t *fwd = stage + (size_t)(2 * threadIdx.x) * W, *rev = fwd + W;
@@ -582,12 +737,24 @@ emit_plain_body(const unsigned bid, const GraphDev &g, const int *__restrict__ a
     const long long end_pos = p + W;
     bool any_alt = false;
     {
-    int ns = 0;
-    while (i0 + ns < g.n_sites && g.pos[i0 + ns] < p + W) ++ns;
+    // Everything the walk reads is requested before anything is used: the reference window as up to eight unaligned
+    // 8-byte loads, the allele counts of its first eight sites as one, the positions of its first four as two.  (As
+    // loops of byte loads -- W of them for the bases, one per site for the rest, each waited for -- the kernel was a
+    // chain of ~25 dependent L2 latencies per wave: 180 us for 3 million walks.)
+    unsigned long long rw[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) rw[c] = 8 * c < W ? load_u64(g.ref + p + 8 * c) : 0ull;
+    const unsigned long long nal8 = ns > 0 ? load_u64(g.n_alts + i0) : 0ull;
+    unsigned long long pos01 = 0ull, pos23 = 0ull;
+    if (ns > 0) { pos01 = load_u64(g.pos + i0); pos23 = load_u64(g.pos + i0 + 2); }
+    auto n_alts_of = [&](int k) { return k < 8 ? (int)((nal8 >> (8 * k)) & 0xffull) : (int)g.n_alts[i0 + k]; };
+    auto pos_of = [&](int k) {
+        return k < 2 ? (int)(pos01 >> (32 * k)) : (k < 4 ? (int)(pos23 >> (32 * (k - 2))) : g.pos[i0 + k]);
+    };
     // allele digits, last site first
     unsigned long long dig[2] = {0ull, 0ull};     // 2 bits per site, up to 64 sites
     for (int k = ns - 1; k >= 0; --k) {
-        const int nall = 1 + g.n_alts[i0 + k];
+        const int nall = 1 + n_alts_of(k);
         const unsigned long long a = (unsigned long long)(q % nall);
         q /= nall;
         dig[k >> 5] |= a << (2 * (k & 31));
@@ -596,8 +763,10 @@ emit_plain_body(const unsigned bid, const GraphDev &g, const int *__restrict__ a
     any_alt = (dig[0] | dig[1]) != 0ull;
 
     // rows 2t (forward) and 2t+1 (reverse complement): reference window first, then the alternates
-    for (int j = 0; j < W; ++j) {
-        const uint8_t c = g.ref[p + j];
+#pragma unroll
+    for (int j = 0; j < GFM_MAX_WIDTH; ++j) {
+        if (j >= W) break;
+        const uint8_t c = (uint8_t)(rw[j >> 3] >> (8 * (j & 7)));
         fwd[j] = c;
         rev[W - 1 - j] = complement(c);
     }
@@ -605,14 +774,26 @@ emit_plain_body(const unsigned bid, const GraphDev &g, const int *__restrict__ a
         const int a = allele(k);
         if (a) {
             const uint8_t c = g.alt_bases[(size_t)(i0 + k) * kMaxAlts + (a - 1)];
-            const int j = (int)(g.pos[i0 + k] - p);
+            const int j = (int)(pos_of(k) - p);
             fwd[j] = c;                      // same thread, same address: ordered after the reference byte
             rev[W - 1 - j] = complement(c);
         }
     }
 
     // haplotypes that carry every allele of the walk
-    count = count_carriers(g, allele_count, ns, [&](int k, int &site, int &a) { site = i0 + k; a = allele(k); });
+    {
+        auto at = [&](int k, int &site, int &a) { site = i0 + k; a = allele(k); };
+        bool done;
+        count = count_by_tables(g, allele_count, ns, at, done);
+        if (!done && valid) {    // four or more sites: a job for graph_count_jobs_kernel (room for all of them: exact)
+            const int j = atomicAdd(&jobs.counters[0], 1);
+            const int off = atomicAdd(&jobs.counters[1], ns);
+            if (j < jobs.plain_jobs && off + ns <= jobs.plain_pool) {
+                for (int k = 0; k < ns; ++k) jobs.pool[off + k] = job_constraint(i0 + k, n_alts_of(k), allele(k));
+                jobs.head[j] = JobHead{t, off, ns};
+            }
+        }
+    }
     }   // plain window
     __syncthreads();
     {
@@ -628,46 +809,74 @@ emit_plain_body(const unsigned bid, const GraphDev &g, const int *__restrict__ a
         }
     }
     if (!valid) return;
-    const int r = win_region[w];
     const long long row = 2 * t;
-    start[row] = p;          start[row + 1] = end_pos;
-    stop[row] = end_pos;     stop[row + 1] = p;
-    strand[row] = '+';       strand[row + 1] = '-';
-    freq[row] = count;       freq[row + 1] = count;
-    is_ref[row] = is_ref[row + 1] = any_alt ? 0 : 1;
-    region[row] = region[row + 1] = r;
-    walk[row] = walk[row + 1] = q0;
+    const uint8_t flag = any_alt ? 0 : 1;
+    if (wide_rows) {   // the two rows of the walk as ONE store per column (gfm_graph_emit checked the alignment)
+        *reinterpret_cast<longlong2 *>(start + row) = longlong2{p, end_pos};
+        *reinterpret_cast<longlong2 *>(stop + row) = longlong2{end_pos, p};
+        *reinterpret_cast<longlong2 *>(freq + row) = longlong2{count, count};
+        *reinterpret_cast<int2 *>(region + row) = int2{r, r};
+        *reinterpret_cast<int2 *>(walk + row) = int2{q0, q0};
+        *reinterpret_cast<unsigned short *>(strand + row) = (unsigned short)('+' | ('-' << 8));
+        *reinterpret_cast<unsigned short *>(is_ref + row) = (unsigned short)(flag | (flag << 8));
+    } else {
+        start[row] = p;          start[row + 1] = end_pos;
+        stop[row] = end_pos;     stop[row + 1] = p;
+        strand[row] = '+';       strand[row + 1] = '-';
+        freq[row] = count;       freq[row + 1] = count;
+        is_ref[row] = is_ref[row + 1] = flag;
+        region[row] = region[row + 1] = r;
+        walk[row] = walk[row + 1] = q0;
+    }
 }
 
 // visitor of simulate() that writes the bases of a walk and collects what its haplotypes must carry
 struct DelEmit {
     const GraphDev &g;
     uint8_t *fwd, *rev;
+    int *src;                 // [W] reference position of base j, fetched after the walk (-1: written already)
     int W;
+    // constraints as job_constraint() packs them (allele: SNP 0..3; deletion / insertion 1 = taken, 0 = passed by).  The
+    // first four in registers -- the tables need no more --, the rest in scratch memory, which nothing reads before the
+    // walk is over (with all of them there, every load inside the walk waited for the scratch stores before it).
     int n_cons;
-    int csite[kMaxConstraints];
-    unsigned char ccode[kMaxConstraints];       // allele: SNP 0..3; deletion 1 = jumped, 0 = its bases are used
+    int c0, c1, c2, c3;
+    int more[kMaxConstraints - 4];
     bool alt;
     static constexpr bool kWantsBases = true;
-    __device__ void add(int site, int code)
+    __device__ void add(int site, int code, int n_alts = 1)
     {
-        if (n_cons < kMaxConstraints) { csite[n_cons] = site; ccode[n_cons] = (unsigned char)code; ++n_cons; }
+        const int v = job_constraint(site, n_alts, code);
+        if (n_cons == 0) c0 = v;
+        else if (n_cons == 1) c1 = v;
+        else if (n_cons == 2) c2 = v;
+        else if (n_cons == 3) c3 = v;
+        else if (n_cons < kMaxConstraints) more[n_cons - 4] = v;
+        if (n_cons < kMaxConstraints) ++n_cons;
     }
-    __device__ void base(int j, long long x, int snp, int a)
+    __device__ int get(int k) const { return k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : (k == 3 ? c3 : more[k - 4]))); }
+    // A reference base is only NOTED here and fetched once the walk is known (emit_del_body: eight loads in flight at a
+    // time); fetched here, every base was an L2 round trip in the middle of the walk.
+    __device__ void base(int j, long long x, int snp, int a, int nall)
     {
-        uint8_t c = g.ref[x];
+        src[j] = (int)x;
         if (snp >= 0) {
-            if (a) { c = g.alt_bases[(size_t)snp * kMaxAlts + (a - 1)]; alt = true; }
-            add(snp, a);
+            if (a) {
+                const uint8_t c = g.alt_bases[(size_t)snp * kMaxAlts + (a - 1)];
+                fwd[j] = c;
+                rev[W - 1 - j] = complement(c);
+                src[j] = -1;
+                alt = true;
+            }
+            add(snp, a, nall - 1);
         }
-        fwd[j] = c;
-        rev[W - 1 - j] = complement(c);
     }
     __device__ void ins_base(int j, int site, int t)
     {
         const uint8_t c = g.ins_bases[g.ins_off[site] + t];
         fwd[j] = c;
         rev[W - 1 - j] = complement(c);
+        src[j] = -1;
         alt = true;
     }
     __device__ void took(int site) { add(site, 1); }
@@ -685,42 +894,56 @@ struct DelEmit {
 // two bodies of ONE kernel (first workgroups: deletion walks) 436 us -- the plain body then runs with the registers
 // and scratch of the deletion body.
 __device__ __forceinline__ void
-emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ allele_count, const int *__restrict__ del_list,
+emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ allele_count,
               const int *__restrict__ del_entry, const long long *__restrict__ del_base,
-              const long long *__restrict__ win_start, const int *__restrict__ win_region,
-              const long long *__restrict__ region_stop, int W, long long n_del_walks,
-              const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+              const DelRec *__restrict__ del_rec, int W, long long n_del_walks,
+              const long long *__restrict__ walk_base,
               const uint8_t *kmers, const LayoutRec *__restrict__ layouts, const int *__restrict__ n_layouts,
-              uint8_t *__restrict__ stg_kmers, long long *__restrict__ stg_meta, int pitch)
+              uint8_t *__restrict__ stg_kmers, long long *__restrict__ stg_meta, int pitch, const CountJobs &jobs)
 {
-    const long long td = (long long)bid * kEmitThreads + threadIdx.x;
+    const long long td = (long long)bid * kDelThreads + threadIdx.x;
     if (td >= n_del_walks) return;
+    // LDS of the workgroup: [threads][kSiteCache] site records | [threads][W] source positions | [threads][pitch] rows
+    extern __shared__ __attribute__((aligned(16))) uint8_t del_stage[];
+    SiteRec *cache = reinterpret_cast<SiteRec *>(del_stage) + (size_t)threadIdx.x * kSiteCache;
+    int *src = reinterpret_cast<int *>(del_stage + (size_t)kDelThreads * kSiteCache * sizeof(SiteRec)) + (size_t)threadIdx.x * W;
+    uint8_t *slot = del_stage + (size_t)kDelThreads * (kSiteCache * sizeof(SiteRec) + (size_t)W * sizeof(int)) +
+                    (size_t)threadIdx.x * pitch;
+    // everything the walk is found from, requested together: the window, its kept layouts, its first site records
     const int m = del_entry[td];
-    const int w = del_list[m];
-    const long long p = win_start[w];
-    const int i0 = first_site[w];
+    const DelRec dr = del_rec[m];
     const int q0 = (int)(td - del_base[m]);
-    const long long t = walk_base[w] + q0;          // its place among all walks
-    const long long limit = region_stop[win_region[w]];
+    const int nl = min(n_layouts[m], kLayoutCache);
+    LayoutRec kept[kLayoutCache];
+#pragma unroll
+    for (int k = 0; k < kLayoutCache; ++k) kept[k] = layouts[(size_t)m * kLayoutCache + k];
+    const long long p = dr.p, limit = dr.limit;
+    const int i0 = dr.i0;
+#pragma unroll
+    for (int k = 0; k < kSiteCache; ++k) cache[k] = g.site_rec[i0 + k];
+    const CachedSites sites{g.site_rec, cache, i0};
+    const long long t = walk_base[dr.w] + q0;          // its place among all walks
     WalkState st;
     WalkStart ws;
     long long q = q0, prod = 0;
     bool found = false;
     {   // the layouts graph_count_del_kernel kept for this window
-        const int nl = min(n_layouts[m], kLayoutCache);
         int base = 0;
-        for (int k = 0; k < nl && !found; ++k) {
-            const LayoutRec rec = layouts[(size_t)m * kLayoutCache + k];
-            if (q0 < rec.cum_end) {
-                found = true;
-                q = q0 - base;
-                prod = rec.cum_end - base;
-                st.nd = (int)(rec.choice >> 24);
-                for (int d = 0; d < st.nd; ++d) st.choice[d] = (unsigned char)((rec.choice >> d) & 1u);
-                ws.site = rec.site;
-                ws.t = rec.t;
+#pragma unroll
+        for (int k = 0; k < kLayoutCache; ++k) {
+            if (k < nl && !found) {
+                const LayoutRec rec = kept[k];
+                if (q0 < rec.cum_end) {
+                    found = true;
+                    q = q0 - base;
+                    prod = rec.cum_end - base;
+                    st.nd = (int)(rec.choice >> 24);
+                    st.choice = rec.choice & 0xffffffu;
+                    ws.site = rec.site;
+                    ws.t = rec.t;
+                }
+                base = rec.cum_end;
             }
-            base = rec.cum_end;
         }
     }
     if (!found) {   // beyond the kept layouts: the odometer from the start
@@ -728,7 +951,7 @@ emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ all
         while (!found) {                             // starts in order, inside a start the layouts in order
             int prefix = 0;
             for (;;) {                               // skip the layouts that lie before walk q0
-                const int rc = simulate(g, p, W, i0, ws, prefix, st, nv, 0, 0, prod, limit);
+                const int rc = simulate(g, sites, p, W, i0, ws, prefix, st, nv, 0, 0, prod, limit);
                 if (rc == WALK_OK) {
                     if (q < prod) { found = true; break; }
                     q -= prod;
@@ -741,26 +964,51 @@ emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ all
     }
     // the walk's two rows (2 W contiguous bytes at 2 t W of the k-mer matrix, no alignment) are assembled in this
     // thread's LDS slot with the byte phase of that place, and go to the staging slot as dwords
-    extern __shared__ __attribute__((aligned(16))) uint8_t del_stage[];
     const int phase = (int)(reinterpret_cast<uintptr_t>(kmers + (size_t)(2 * t) * W) & 3u);
-    uint8_t *slot = del_stage + (size_t)threadIdx.x * pitch;
     uint8_t *fwd = slot + phase;
-    DelEmit em{g, fwd, fwd + W, W, 0, {}, {}, false};
+    DelEmit em{g, fwd, fwd + W, src, W, 0, 0, 0, 0, 0, {}, false};
     long long again = 0;
-    simulate(g, p, W, i0, ws, st.nd, st, em, q, prod, again, limit);
+    simulate(g, sites, p, W, i0, ws, st.nd, st, em, q, prod, again, limit);
+    for (int j0 = 0; j0 < W; j0 += 8) {              // the reference bases it noted, eight loads in flight
+        int sx[8];
+        uint8_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sx[u] = j0 + u < W ? src[j0 + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = sx[u] >= 0 ? g.ref[sx[u]] : (uint8_t)0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (sx[u] >= 0) {
+                fwd[j0 + u] = c[u];
+                fwd[2 * W - 1 - (j0 + u)] = complement(c[u]);
+            }
+    }
     {
         unsigned *out = reinterpret_cast<unsigned *>(stg_kmers + (size_t)td * pitch);
         for (int o = 0; o < pitch / 4; ++o) out[o] = reinterpret_cast<const unsigned *>(slot)[o];
     }
     // the window starts on deleted bases: carriers lack them (not for a walk that never leaves the insertion it starts in)
     if (!(ws.site >= 0 && st.last == p - 1)) for_covering_deletions(g, p, i0, [&](int dsite) { em.add(dsite, 0); });
-    const long long count = count_carriers(g, allele_count, em.n_cons,
-                                           [&](int k, int &site, int &a) { site = em.csite[k]; a = em.ccode[k]; });
+    auto at = [&](int k, int &site, int &a) { const int v = em.get(k); site = v >> 4; a = v & 3; };
+    bool done;
+    long long count = count_by_tables(g, allele_count, em.n_cons, at, done);
+    bool deferred = false;
+    if (!done && jobs.counters) {       // a job for graph_count_jobs_kernel, which writes meta[3]
+        const int j = atomicAdd(&jobs.counters[2], 1);
+        if (j < jobs.del_jobs) {
+            const int off = atomicAdd(&jobs.counters[3], em.n_cons);
+            deferred = off + em.n_cons <= jobs.del_pool;
+            if (deferred)
+                for (int k = 0; k < em.n_cons; ++k) jobs.pool[jobs.plain_pool + off + k] = em.get(k);
+            jobs.head[jobs.plain_jobs + j] = JobHead{~td, jobs.plain_pool + off, deferred ? em.n_cons : 0};
+        }
+    }
+    if (!done && !deferred) count = count_by_bitsets(g, em.n_cons, at);
     long long *meta = stg_meta + (size_t)td * kDelMeta;
     meta[0] = t;
     meta[1] = p;
     meta[2] = st.last + 1;
-    meta[3] = count;
+    if (!deferred) meta[3] = count;
     meta[4] = em.alt ? 0 : 1;
 }
 
@@ -768,25 +1016,25 @@ __global__ void __launch_bounds__(kEmitThreads)
 graph_emit_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ walk_window,
                   const int *__restrict__ win_region, const long long *__restrict__ win_start, int W,
                   long long n_walks, const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+                  const int *__restrict__ win_sites,
                   uint8_t *__restrict__ kmers, long long *__restrict__ start, long long *__restrict__ stop,
                   uint8_t *__restrict__ strand, long long *__restrict__ freq, uint8_t *__restrict__ is_ref,
-                  int *__restrict__ region, int *__restrict__ walk)
+                  int *__restrict__ region, int *__restrict__ walk, int wide_rows, CountJobs jobs)
 {
     emit_plain_body(blockIdx.x, g, allele_count, walk_window, win_region, win_start, W, n_walks, first_site, walk_base,
-                    kmers, start, stop, strand, freq, is_ref, region, walk);
+                    win_sites, kmers, start, stop, strand, freq, is_ref, region, walk, wide_rows != 0, jobs);
 }
 
-__global__ void __launch_bounds__(kEmitThreads)
-graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count, const int *__restrict__ del_list,
+__global__ void __launch_bounds__(kDelThreads)
+graph_emit_del_kernel(GraphDev g, const int *__restrict__ allele_count,
                       const int *__restrict__ del_entry, const long long *__restrict__ del_base,
-                      const long long *__restrict__ win_start, const int *__restrict__ win_region,
-                      const long long *__restrict__ region_stop, int W, long long n_del_walks,
-                      const int *__restrict__ first_site, const long long *__restrict__ walk_base,
+                      const DelRec *__restrict__ del_rec, int W, long long n_del_walks,
+                      const long long *__restrict__ walk_base,
                       const uint8_t *kmers, const LayoutRec *__restrict__ layouts, const int *__restrict__ n_layouts,
-                      uint8_t *__restrict__ stg_kmers, long long *__restrict__ stg_meta, int pitch)
+                      uint8_t *__restrict__ stg_kmers, long long *__restrict__ stg_meta, int pitch, CountJobs jobs)
 {
-    emit_del_body(blockIdx.x, g, allele_count, del_list, del_entry, del_base, win_start, win_region, region_stop, W,
-                  n_del_walks, first_site, walk_base, kmers, layouts, n_layouts, stg_kmers, stg_meta, pitch);
+    emit_del_body(blockIdx.x, g, allele_count, del_entry, del_base, del_rec, W, n_del_walks, walk_base, kmers, layouts,
+                  n_layouts, stg_kmers, stg_meta, pitch, jobs);
 }
 
 // thread per deletion walk: staging -> rows 2 t, 2 t + 1 (k-mer bytes as dwords where the addresses allow)
@@ -816,12 +1064,18 @@ graph_del_scatter_kernel(long long n_del_walks, int W, int pitch, const uint8_t 
     is_ref[row] = is_ref[row + 1] = flag;
 }
 
-template <typename T> hipError_t upload(T **dst, const T *src, size_t count)
+// `pad` bytes are allocated (and zeroed) behind the array: see load_u64
+template <typename T> hipError_t upload(T **dst, const T *src, size_t count, size_t pad = 0)
 {
     *dst = nullptr;
-    if (count == 0) return hipSuccess;
-    hipError_t e = hipMalloc(dst, sizeof(T) * count);
+    if (count == 0 && pad == 0) return hipSuccess;
+    hipError_t e = hipMalloc(dst, sizeof(T) * count + pad);
     if (e != hipSuccess) return e;
+    if (pad) {
+        e = hipMemset(reinterpret_cast<uint8_t *>(*dst) + sizeof(T) * count, 0, pad);
+        if (e != hipSuccess) return e;
+    }
+    if (count == 0) return hipSuccess;
     return hipMemcpy(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice);
 }
 
@@ -849,6 +1103,7 @@ struct gfm_graph {
     GraphDev dev{};
     uint8_t *d_ref = nullptr;
     int *d_pos = nullptr;
+    SiteRec *d_site_rec = nullptr;
     uint8_t *d_n_alts = nullptr, *d_alt_bases = nullptr;
     unsigned long long *d_alt_bits = nullptr;
     int *d_allele_count = nullptr;   // [n_sites][4] haplotypes per allele (0 = reference)
@@ -861,14 +1116,18 @@ struct gfm_graph {
     int n_regions = 0, width = 0;
     long long n_windows = 0, n_walks = 0;
     Buf<long long> region_off, first_start, region_stop, walk_base, win_start, walks;
-    Buf<int> first_site, win_region, walk_window, flag;
+    Buf<int> first_site, win_region, walk_window, flag, win_sites;
     Buf<unsigned char> scan_tmp;
     Buf<int> del_list, del_entry;
     Buf<long long> del_walks, del_base;
     Buf<uint8_t> stg_kmers;              // staging of the deletion walks' rows (emit_del_body -> graph_del_scatter_kernel)
     Buf<long long> stg_meta;
     Buf<LayoutRec> del_layouts;          // [listed windows][kLayoutCache]
+    Buf<DelRec> del_rec;                 // [listed windows]
     Buf<int> del_layout_n;
+    Buf<JobHead> job_head;               // CountJobs of the last plan's emits
+    Buf<int> job_pool;
+    CountJobs jobs{};
     long long n_del_walks = 0;
     // plan runs on the NULL stream, emit on the caller's: ordered through these events (a non-blocking
     // caller stream is not ordered against the NULL stream by itself), both ways -- emit waits for the
@@ -880,9 +1139,11 @@ struct gfm_graph {
     void drop_plan()
     {
         region_off.release(); first_start.release(); region_stop.release(); walk_base.release(); win_start.release(); walks.release();
-        first_site.release(); win_region.release(); walk_window.release(); flag.release(); scan_tmp.release();
+        first_site.release(); win_region.release(); walk_window.release(); flag.release(); scan_tmp.release(); win_sites.release();
         del_list.release(); del_entry.release(); del_walks.release(); del_base.release();
-        del_layouts.release(); del_layout_n.release(); stg_kmers.release(); stg_meta.release();
+        del_layouts.release(); del_layout_n.release(); del_rec.release(); stg_kmers.release(); stg_meta.release();
+        job_head.release(); job_pool.release();
+        jobs = CountJobs{};
         n_del_walks = 0;
         n_regions = 0;
         n_windows = n_walks = 0;
@@ -947,9 +1208,9 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (!g) return gfail(GFM_ERR_NOMEM, "out of host memory");
     const int hw = (n_haplotypes + 63) / 64;
     const bool bits = h_alt_bits && n_haplotypes > 0 && n_sites > 0;
-    hipError_t e = upload(&g->d_ref, h_ref, (size_t)ref_len);
-    if (e == hipSuccess) e = upload(&g->d_pos, h_pos, (size_t)n_sites);
-    if (e == hipSuccess) e = upload(&g->d_n_alts, h_n_alts, (size_t)n_sites);
+    hipError_t e = upload(&g->d_ref, h_ref, (size_t)ref_len, kReadPad);
+    if (e == hipSuccess) e = upload(&g->d_pos, h_pos, (size_t)n_sites, kReadPad);
+    if (e == hipSuccess) e = upload(&g->d_n_alts, h_n_alts, (size_t)n_sites, kReadPad);
     if (e == hipSuccess) e = upload(&g->d_alt_bases, h_alt_bases, (size_t)n_sites * kMaxAlts);
     if (e == hipSuccess) e = upload(&g->d_del_len, del_len.data(), del_len.size());
     if (e == hipSuccess) e = upload(&g->d_prev_del, prev_del.data(), prev_del.size());
@@ -957,6 +1218,11 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = upload(&g->d_ins_len, ins_len.data(), ins_len.size());
     if (e == hipSuccess) e = upload(&g->d_ins_off, ins_off.data(), ins_off.size());
     if (e == hipSuccess && n_ins) e = upload(&g->d_ins_bases, h_ins_bases, (size_t)ins_bytes);
+    if (e == hipSuccess) {
+        std::vector<SiteRec> recs((size_t)n_sites + kSitePad, SiteRec{kNoSitePos, 0, 0, 0});
+        for (int i = 0; i < n_sites; ++i) recs[(size_t)i] = SiteRec{h_pos[i], del_len[(size_t)i], ins_len[(size_t)i], h_n_alts[i]};
+        e = upload(&g->d_site_rec, recs.data(), recs.size());
+    }
     if (e == hipSuccess && bits)
         e = upload(&g->d_alt_bits, reinterpret_cast<const unsigned long long *>(h_alt_bits),
                    (size_t)n_sites * kMaxAlts * hw);
@@ -964,7 +1230,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
         gfm_graph_destroy(g);
         return gfail(GFM_ERR_HIP, std::string("graph upload failed: ") + hipGetErrorString(e));
     }
-    g->dev = GraphDev{g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
+    g->dev = GraphDev{g->d_site_rec, g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
                       bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0,
                       g->d_del_len, n_dels, g->d_prev_del, g->d_max_reach, g->d_ins_len, g->d_ins_off, g->d_ins_bases,
                       n_ins, nullptr, nullptr};
@@ -972,7 +1238,13 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_emitted, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        // high priority: the deletion walks are few and long -- their workgroups must get the first wave slots that come
+        // free while the plain kernel fills the chip, not the last
+        int lo = 0, hi = 0;
+        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&g->side, hipStreamNonBlocking, hi);
+    }
     if (e != hipSuccess) {
         gfm_graph_destroy(g);
         return gfail(GFM_ERR_HIP, std::string("event creation failed: ") + hipGetErrorString(e));
@@ -1009,7 +1281,7 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
 {
     if (!g) return;
     g->drop_plan();
-    (void)hipFree(g->d_ref); (void)hipFree(g->d_pos); (void)hipFree(g->d_n_alts);
+    (void)hipFree(g->d_ref); (void)hipFree(g->d_pos); (void)hipFree(g->d_n_alts); (void)hipFree(g->d_site_rec);
     (void)hipFree(g->d_alt_bases); (void)hipFree(g->d_alt_bits); (void)hipFree(g->d_allele_count);
     (void)hipFree(g->d_pair_count); (void)hipFree(g->d_triple_count);
     (void)hipFree(g->d_del_len); (void)hipFree(g->d_prev_del); (void)hipFree(g->d_max_reach);
@@ -1056,23 +1328,27 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     GX_TRY(g->region_stop.reserve(rstop.size()));
     GX_TRY(g->first_site.reserve(nw));
     GX_TRY(g->walks.reserve(nw));
-    GX_TRY(g->flag.reserve(2));          // [0] overflow flag, [1] number of windows that touch a deletion
+    // [0] overflow flag, [1] number of windows that touch a deletion, [2..5] two 64-bit totals (plain walks that need the
+    // bitsets, their constraints), [6..9] CountJobs::counters of an emit
+    GX_TRY(g->flag.reserve(10));
     GX_TRY(g->win_region.reserve(nw));
     GX_TRY(g->win_start.reserve(nw));
+    GX_TRY(g->win_sites.reserve(nw));
     GX_TRY(g->walk_base.reserve(nw + 1));
     const bool dels = g->dev.n_dels > 0 || g->dev.n_ins > 0;   // windows that need the layout enumeration
     GX_TRY(g->del_list.reserve(dels ? nw : 1));
     GX_TRY(hipMemcpyAsync(g->region_off.p, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, nullptr));
     GX_TRY(hipMemcpyAsync(g->first_start.p, first.data(), sizeof(long long) * first.size(), hipMemcpyHostToDevice, nullptr));
     GX_TRY(hipMemcpyAsync(g->region_stop.p, rstop.data(), sizeof(long long) * rstop.size(), hipMemcpyHostToDevice, nullptr));
-    GX_TRY(hipMemsetAsync(g->flag.p, 0, 2 * sizeof(int), nullptr));
+    GX_TRY(hipMemsetAsync(g->flag.p, 0, 10 * sizeof(int), nullptr));
     GX_TRY(hipMemsetAsync(g->walk_base.p, 0, sizeof(long long), nullptr));
     // walks per window -> inclusive prefix (row base of every window) on the device: only the totals and the
     // overflow flag come back
     const unsigned blocks = (unsigned)((nw + kCountThreads - 1) / kCountThreads);
     hipLaunchKernelGGL(graph_count_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, g->dev, n_regions,
                        g->region_off.p, g->first_start.p, g->region_stop.p, width, (long long)nw, g->first_site.p, g->walks.p,
-                       g->win_region.p, g->win_start.p, g->flag.p, g->del_list.p, g->flag.p + 1);
+                       g->win_region.p, g->win_start.p, g->flag.p, g->del_list.p, g->flag.p + 1, g->win_sites.p,
+                       reinterpret_cast<unsigned long long *>(g->flag.p + 2));
     GX_TRY(hipGetLastError());
     int n_listed = 0;
     if (dels) {
@@ -1086,10 +1362,11 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
         GX_TRY(g->del_base.reserve((size_t)n_listed + 1));
         GX_TRY(g->del_layouts.reserve((size_t)n_listed * kLayoutCache));
         GX_TRY(g->del_layout_n.reserve((size_t)n_listed));
+        GX_TRY(g->del_rec.reserve((size_t)n_listed));
         GX_TRY(hipMemsetAsync(g->del_base.p, 0, sizeof(long long), nullptr));
         hipLaunchKernelGGL(graph_count_del_kernel, dim3(lblocks), dim3(kCountThreads), 0, nullptr, g->dev, g->del_list.p,
                            g->flag.p + 1, g->win_start.p, g->win_region.p, g->region_stop.p, width, g->first_site.p,
-                           g->walks.p, g->del_walks.p, g->flag.p, g->del_layouts.p, g->del_layout_n.p);
+                           g->walks.p, g->del_walks.p, g->flag.p, g->del_layouts.p, g->del_layout_n.p, g->del_rec.p);
         GX_TRY(hipGetLastError());
     }
     size_t tmp_bytes = 0;
@@ -1125,6 +1402,17 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
                            g->del_base.p, g->del_entry.p);
         GX_TRY(hipGetLastError());
     }
+    g->jobs = CountJobs{};
+    if (g->dev.alt_bits && total > 0) {   // room for the walks whose haplotype count is deferred (see CountJobs)
+        unsigned long long slow[2] = {0, 0};
+        GX_TRY(hipMemcpy(slow, g->flag.p + 2, sizeof slow, hipMemcpyDeviceToHost));
+        const unsigned long long del_pool = 8ull * (unsigned long long)total_del + (total_del ? 4096ull : 0ull);
+        if (slow[0] + (unsigned long long)total_del > 0x7fffffffull || slow[1] + del_pool > 0x7fffffffull)
+            return gfail(GFM_ERR_INVALID, "too many multi-site walks in one plan (split the regions)");
+        GX_TRY(g->job_head.reserve((size_t)(slow[0] + (unsigned long long)total_del) + 1));
+        GX_TRY(g->job_pool.reserve((size_t)(slow[1] + del_pool) + 1));
+        g->jobs = CountJobs{g->flag.p + 6, g->job_head.p, g->job_pool.p, (int)slow[0], (int)slow[1], (int)total_del, (int)del_pool};
+    }
     GX_TRY(hipEventRecord(g->ev_planned, nullptr));   // behind the map kernels
     g->n_windows = (long long)nw;
     g->n_walks = total;
@@ -1143,26 +1431,47 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
         return gfail(GFM_ERR_INVALID, "NULL output buffer");
     const unsigned blocks = (unsigned)((g->n_walks + kEmitThreads - 1) / kEmitThreads);
     GX_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), g->ev_planned, 0));
-    const unsigned dblocks = (unsigned)((g->n_del_walks + kEmitThreads - 1) / kEmitThreads);
+    const unsigned dblocks = (unsigned)((g->n_del_walks + kDelThreads - 1) / kDelThreads);
+    const unsigned sblocks = (unsigned)((g->n_del_walks + kEmitThreads - 1) / kEmitThreads);
     const int pitch = (2 * g->width + 6) & ~3;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // rows 2t, 2t+1 of a walk leave as one store per column where the columns' addresses allow it
+    const int wide_rows = ((reinterpret_cast<uintptr_t>(d_start) | reinterpret_cast<uintptr_t>(d_stop) |
+                            reinterpret_cast<uintptr_t>(d_freq)) & 15u) == 0 &&
+                          ((reinterpret_cast<uintptr_t>(d_region) | reinterpret_cast<uintptr_t>(d_walk)) & 7u) == 0 &&
+                          ((reinterpret_cast<uintptr_t>(d_strand) | reinterpret_cast<uintptr_t>(d_is_ref)) & 1u) == 0;
+    // measurement aid: GRAFIMO_EXTRACT_SERIAL=1 runs the two emit kernels one after the other on the caller's stream,
+    // so that a kernel trace shows what each takes alone
+    static const bool serial = [] { const char *e = std::getenv("GRAFIMO_EXTRACT_SERIAL"); return e && *e == '1'; }();
+    hipStream_t del_st = serial ? st : g->side;
+    const CountJobs jobs = g->jobs;
+    if (jobs.counters) GX_TRY(hipMemsetAsync(jobs.counters, 0, 4 * sizeof(int), st));
     if (dblocks) {   // fork: the deletion walks on the side stream, into the staging area
-        GX_TRY(hipEventRecord(g->ev_fork, st));
-        GX_TRY(hipStreamWaitEvent(g->side, g->ev_fork, 0));
-        hipLaunchKernelGGL(graph_emit_del_kernel, dim3(dblocks), dim3(kEmitThreads), (size_t)kEmitThreads * pitch, g->side,
-                           g->dev, g->d_allele_count, g->del_list.p, g->del_entry.p, g->del_base.p, g->win_start.p,
-                           g->win_region.p, g->region_stop.p, g->width, g->n_del_walks, g->first_site.p, g->walk_base.p,
-                           d_kmers, g->del_layouts.p, g->del_layout_n.p, g->stg_kmers.p, g->stg_meta.p, pitch);
-        GX_TRY(hipEventRecord(g->ev_join, g->side));
+        if (!serial) {
+            GX_TRY(hipEventRecord(g->ev_fork, st));
+            GX_TRY(hipStreamWaitEvent(g->side, g->ev_fork, 0));
+        }
+        const size_t del_lds = (size_t)kDelThreads * (kSiteCache * sizeof(SiteRec) + (size_t)g->width * sizeof(int) + (size_t)pitch);
+        hipLaunchKernelGGL(graph_emit_del_kernel, dim3(dblocks), dim3(kDelThreads), del_lds, del_st,
+                           g->dev, g->d_allele_count, g->del_entry.p, g->del_base.p, g->del_rec.p, g->width, g->n_del_walks,
+                           g->walk_base.p, d_kmers, g->del_layouts.p, g->del_layout_n.p, g->stg_kmers.p, g->stg_meta.p,
+                           pitch, jobs);
+        if (jobs.counters && jobs.del_jobs > 0)      // the counts it left to graph_count_jobs_kernel, also beside the plain walks
+            hipLaunchKernelGGL(graph_count_jobs_kernel, dim3(1024), dim3(256), 0, del_st, g->dev, jobs, 1,
+                               reinterpret_cast<long long *>(d_freq), g->stg_meta.p, kDelMeta);
+        if (!serial) GX_TRY(hipEventRecord(g->ev_join, g->side));
     }
     hipLaunchKernelGGL(graph_emit_kernel, dim3(blocks), dim3(kEmitThreads), (size_t)2 * kEmitThreads * g->width, st,
                        g->dev, g->d_allele_count, g->walk_window.p, g->win_region.p, g->win_start.p, g->width, g->n_walks,
-                       g->first_site.p, g->walk_base.p, d_kmers, reinterpret_cast<long long *>(d_start),
+                       g->first_site.p, g->walk_base.p, g->win_sites.p, d_kmers, reinterpret_cast<long long *>(d_start),
                        reinterpret_cast<long long *>(d_stop), d_strand, reinterpret_cast<long long *>(d_freq), d_is_ref,
-                       d_region, d_walk);
+                       d_region, d_walk, wide_rows, jobs);
+    if (jobs.counters && jobs.plain_jobs > 0)    // the counts the plain kernel left to it
+        hipLaunchKernelGGL(graph_count_jobs_kernel, dim3(256), dim3(256), 0, st, g->dev, jobs, 0,
+                           reinterpret_cast<long long *>(d_freq), g->stg_meta.p, kDelMeta);
     if (dblocks) {   // join: the staged rows over the placeholders
-        GX_TRY(hipStreamWaitEvent(st, g->ev_join, 0));
-        hipLaunchKernelGGL(graph_del_scatter_kernel, dim3(dblocks), dim3(kEmitThreads), 0, st,
+        if (!serial) GX_TRY(hipStreamWaitEvent(st, g->ev_join, 0));
+        hipLaunchKernelGGL(graph_del_scatter_kernel, dim3(sblocks), dim3(kEmitThreads), 0, st,
                            g->n_del_walks, g->width, pitch, g->stg_kmers.p, g->stg_meta.p, d_kmers,
                            reinterpret_cast<long long *>(d_start), reinterpret_cast<long long *>(d_stop),
                            reinterpret_cast<long long *>(d_freq), d_is_ref);
