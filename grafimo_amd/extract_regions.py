@@ -716,11 +716,14 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
         print(f"Scanned nucleotides:\t{n_global * W}")
     hit = torch.from_numpy(res["rows"]).to(kmers.device)
     src = keep[hit] if keep is not None else hit
-    take = lambda t: t[src].cpu().numpy()
-    cols = dict(name_id=take(region).astype(np.int32), start=take(cat("start")), stop=take(cat("stop")),
-                strand=take(cat("strand")), logodds=np.asarray(lo, dtype=np.float64), pvalue=np.asarray(pv, dtype=np.float64),
-                kmers=take(all_kmers).reshape(len(res["rows"]), W), freq=take(cat("freq")), is_ref=take(cat("is_ref")),
-                owner=np.full(len(res["rows"]), rank, dtype=np.int32))
+    # the hit rows' columns come back as TWO copies (an int64 matrix and the k-mer bytes), not one per column: every
+    # device -> host copy is a synchronisation of its own
+    meta = torch.stack([cat(name)[src].to(torch.int64) for name in ("start", "stop", "freq", "strand", "is_ref")] +
+                       [region[src].to(torch.int64)], dim=1).cpu().numpy()
+    cols = dict(name_id=meta[:, 5].astype(np.int32), start=np.ascontiguousarray(meta[:, 0]), stop=np.ascontiguousarray(meta[:, 1]),
+                strand=meta[:, 3].astype(np.uint8), logodds=np.asarray(lo, dtype=np.float64), pvalue=np.asarray(pv, dtype=np.float64),
+                kmers=all_kmers[src].cpu().numpy().reshape(len(res["rows"]), W), freq=np.ascontiguousarray(meta[:, 2]),
+                is_ref=meta[:, 4].astype(np.uint8), owner=np.full(len(res["rows"]), rank, dtype=np.int32))
     if not no_qvalue:
         cols["qvalue"] = np.asarray(res["qtable"][res["scaled"]], dtype=np.float64)
     if world > 1:      # packed columns to rank 0 (one tensor gather), the region labels of every rank beside them

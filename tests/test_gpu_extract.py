@@ -500,3 +500,34 @@ def test_hip_rows_equal_the_per_haplotype_brute_force(tmp_path, kinds):
             total += carried
         g.close()
     assert total > 500
+
+
+@pytest.mark.gpu
+def test_deferred_and_in_place_haplotype_counts_agree(tmp_path, monkeypatch):
+    """The emit kernels leave the haplotype counts that need the bitsets (four or more sites in a window, constraints on
+    sites that are no neighbours) to graph_count_jobs_kernel; a deletion walk that finds the job lists full counts in
+    place.  Both ways against the oracle on a dense graph, and against each other (GRAFIMO_EXTRACT_DEL_POOL=0 leaves
+    no room for deletion jobs)."""
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
+    from oracle import extract_oracle as xo
+    W = 24
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=1500, n_sites=200, n_samples=65, seed=91, rich=True)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
+    ref = xo.read_fasta(fasta)["7"]
+    v = xo.read_vcf_variants(vcf, "7")
+    regions = [(0, 110), (420, 520), (1400, 1500)]       # (sized for the Python enumerator: a fraction of a second)
+    exp = []
+    for s, e in regions:
+        exp += xo.enumerate_region_variants("7", ref, v, s, e, W, with_counts=True)
+    want = [r[4] for r in exp]
+    assert len(want) > 3000 and sum(1 for c in want if c > 0) > 500           # windows of four and more sites among them
+    g = DeviceGraph(idx)
+    got = {}
+    for pool in ("", "0", "37"):
+        if pool:
+            monkeypatch.setenv("GRAFIMO_EXTRACT_DEL_POOL", pool)
+        rows = g.extract(regions, W)
+        got[pool] = rows.freq.cpu().numpy().tolist()
+        assert [k.tobytes().decode() for k in rows.kmers.cpu().numpy()] == [r[1] for r in exp]
+    g.close()
+    assert got[""] == want and got["0"] == want and got["37"] == want
