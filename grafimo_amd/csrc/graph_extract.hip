@@ -1235,6 +1235,9 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
                       bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0,
                       g->d_del_len, n_dels, g->d_prev_del, g->d_max_reach, g->d_ins_len, g->d_ins_off, g->d_ins_bases,
                       n_ins, nullptr, nullptr};
+    if (e == hipSuccess)     // the widest windows need a little more than 64 KB of LDS per workgroup of deletion walks
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_emit_del_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(kDelThreads * (kSiteCache * sizeof(SiteRec) + GFM_MAX_WIDTH * sizeof(int) + 2 * GFM_MAX_WIDTH + 8)));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&g->h_back), 8 * sizeof(long long), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_planned, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_emitted, hipEventDisableTiming);
