@@ -339,8 +339,8 @@ bool plan_group(const gfm_motif_t *motifs, int n_left, const bool *with_hist, in
     bool found = false;
     for (; mm >= 1 && !found; --mm) {
         for (waves = kWavesPerWG; waves >= kWavesPerWG / 2 && !found; waves /= 2) {
-            long long room = ((long long)kMaxLdsBytes - (long long)quad_fixed_lds(W, waves, mm)) /
-                             (long long)sizeof(unsigned);
+            const long long spare = (long long)kMaxLdsBytes - (long long)quad_fixed_lds(W, waves, mm);   // bytes
+            long long room = spare / (long long)sizeof(unsigned);
             bool open[3] = {false, false, false};
             int users = 0;
             for (int k = 0; k < mm; ++k) {
@@ -349,7 +349,8 @@ bool plan_group(const gfm_motif_t *motifs, int n_left, const bool *with_hist, in
                 open[k] = with_hist[k];
                 users += open[k];
             }
-            bool ok = room > 0 || users == 0;
+            // (tables, strips and queues must fit even when no motif wants a window: wide motifs get 8 waves)
+            bool ok = spare >= 0 && (room > 0 || users == 0);
             // water-filling: ranges that fit their equal share are served whole, the rest share again
             for (bool again = true; ok && again && users > 0;) {
                 again = false;

@@ -280,3 +280,30 @@ def test_config5_full_size_batched_equals_single_and_oracle(dev, W):
         assert torch.equal(got >> 20, exp_rows)
     for d in dms:
         d.close()
+
+
+@pytest.mark.parametrize("W", [40, 44, 57, 64])
+def test_wide_motif_without_histogram_through_the_batched_entry_point(dev, W):
+    """A motif too wide for 16 waves' strips, scored through gfm_score_kmers_multi WITHOUT a histogram: the launch plan
+    must still step down to 8 waves (found by scripts/score_fuzz.py: with no window to place the plan kept 16 waves and
+    asked for more LDS than a CU has)."""
+    from grafimo_amd.device import DeviceMotif, multi_plan, score_multi
+    rng = np.random.default_rng(4400 + W)
+    sm = band_matrix(rng, W, 4200 // W)
+    bg = rng.dirichlet([30, 20, 20, 30])
+    m = DeviceMotif(sm, bg, int(sm.min()), 40, -9.0)
+    sizes, waves = multi_plan([m], [False])
+    assert list(sizes) == [1] and list(waves) == [8]
+    n = 264_825
+    km = random_kmers(rng, n, W)
+    d_k = torch.from_numpy(km).to(dev)
+    for with_hist in (False, True):
+        scores = [torch.full((n,), -7, dtype=torch.int32, device=dev)]
+        hists = [torch.zeros(m.L, dtype=torch.int64, device=dev) if with_hist else None]
+        hits = [torch.zeros(n + 1, dtype=torch.int64, device=dev)]
+        cuts = [m.pvalue_cutoff(0.03)]
+        score_multi([m], d_k, scores, hists=hists, cutoffs=cuts, row_base=0,
+                    hit_rows=[h[1:] for h in hits], hit_counts=[h[:1] for h in hits], reset_hits=True)
+        torch.cuda.synchronize()
+        check_against_oracle(dev, [m], [(sm, bg)], km, scores, hists, hits, cuts, 0, (W, with_hist))
+    m.close()
