@@ -148,6 +148,26 @@ def _cpu_worker(args):
     return n, passes
 
 
+def cpu_quota_cores():
+    """CPU time the container may use per second of wall time, in cores (cgroup v2 cpu.max / v1 cfs quota); None: no
+    quota.  The GPU boxes of round 3 show 256 hardware threads and a quota of 16: more runnable threads than that only
+    burst until the period's allowance is used up and are then frozen to its end (cpu.stat nr_throttled)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+            quota = float(fh.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+            period = float(fh.read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baselines(mot, budget_s=8.0):
     """The reference's scoring loop restated (oracle/, the checker -- kind 'port'), timed on the host
     cores of this box: per TSV line the text handling of score_seqs (score_sequences.py:273-321) and
@@ -162,7 +182,11 @@ def cpu_baselines(mot, budget_s=8.0):
     pmf = orc.comp_pval_mat(mot["sm"], mot["bg"])
     ptab = orc.p_table(pmf)
     sample = synth.make_batch(10, 2000, W, mot["probs"], synth.seed_for(0))
-    cores = os.cpu_count() or 1
+    threads = os.cpu_count() or 1
+    quota = cpu_quota_cores()
+    # one worker per core the container may actually use (a quota of 16 on a 256-thread host: 256 workers would share
+    # the same 16 cores' worth of time and only add throttling stalls)
+    cores = threads if quota is None else max(1, min(threads, int(np.ceil(quota))))
     out = {}
     for name, tab, table, rows in (("cpu_baseline", pmf, False, 1000), ("cpu_baseline_table", ptab, True, 20000)):
         text = synth.tsv_text(sample, np.arange(rows))
@@ -174,6 +198,7 @@ def cpu_baselines(mot, budget_s=8.0):
         total = sum(r[0] for r in res)
         out[name] = {
             "value": total / wall, "unit": "k-mers/s", "cores": cores, "kind": "port",
+            "host_threads": threads, "cpu_quota_cores": quota,
             "cache_resident": True,
             "sample": f"the first {rows} TSV rows ({len(text)} bytes of text: cache resident) of a batch of the same "
                       f"synthetic recipe, passed over again and again "
@@ -200,7 +225,10 @@ def make_tsv_dir(regions, rows_per_region, W, probs, workers):
     from grafimo_amd import synth
     need = 3 * regions * rows_per_region * (W + 75)      # ~92 bytes of text per row at W = 19, with headroom
     base = None
-    for cand in ("/dev/shm", tempfile.gettempdir()):
+    cands = ("/dev/shm", tempfile.gettempdir())
+    if os.environ.get("GRAFIMO_BENCH_TSV_BASE"):                  # measurement aid: where the TSV directories go
+        cands = (os.environ["GRAFIMO_BENCH_TSV_BASE"],)
+    for cand in cands:
         if os.path.isdir(cand) and os.access(cand, os.W_OK) and shutil.disk_usage(cand).free > need:
             base = cand
             break
@@ -244,7 +272,8 @@ def e2e_block(tmp, n_expected, W, dm):
     wall, total_s, parse_s, h2d_s, h2d_bytes, tail_s, n, n_hits, n_chunks = runs[len(runs) // 2]
     assert n == n_expected, (n, n_expected)
     return {
-        "rows": int(n), "tsv_bytes": int(nbytes), "files": len(files), "host_threads": threads, "hits": int(n_hits),
+        "rows": int(n), "tsv_bytes": int(nbytes), "files": len(files), "host_threads": threads,
+        "cpu_quota_cores": cpu_quota_cores(), "parse_threads": int(sc.stats.parse_threads), "hits": int(n_hits),
         "kmers_per_s": n / total_s, "ingest_rows_per_s": n / ingest_s, "h2d_GBps": h2d_bytes / h2d_s / 1e9,
         "total_ms": total_s * 1e3, "ingest_alone_ms": ingest_s * 1e3, "parse_ms_inside": parse_s * 1e3,
         "h2d_ms": h2d_s * 1e3, "after_parse_ms": tail_s * 1e3, "chunks": int(n_chunks),

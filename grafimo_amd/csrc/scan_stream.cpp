@@ -427,6 +427,12 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     std::atomic<bool> failed{false};
     std::string fail_msg;
     std::atomic<int64_t> parse_end_ns{0};    // steady-clock time of the last finished parse
+    // development aid (GRAFIMO_SCAN_TRACE): the longest single wait of each kind, in ns
+    std::atomic<int64_t> tr_read{0}, tr_slot{0}, tr_offset{0}, tr_parse{0}, tr_block{0};
+    auto tr_max = [](std::atomic<int64_t> &a, int64_t v) {
+        int64_t prev = a.load(std::memory_order_relaxed);
+        while (prev < v && !a.compare_exchange_weak(prev, v, std::memory_order_relaxed)) {}
+    };
     auto fail_with = [&](const std::string &msg) {
         {
             std::lock_guard<std::mutex> g(mu);
@@ -457,7 +463,15 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
         assign_mu.unlock();
         if (moved && na == n_paths) wake_main();     // the last chunk may be a short one
     };
+    // trace only: what every worker is doing (state * 2^32 + file index); states 1 read, 2 parse, 3 slot wait, 4 yield
+    std::unique_ptr<std::atomic<long long>[]> w_state(new std::atomic<long long>[(size_t)nt + 1]);
+    for (int i = 0; i <= nt; ++i) w_state[(size_t)i].store(0);
+    std::atomic<int> w_next{0};
     auto work = [&]() {
+        const int me = w_next.fetch_add(1);
+        auto set_state = [&](int st, long long file) {
+            if (trace && me < nt) w_state[(size_t)me].store(((long long)st << 32) | (file & 0xffffffffll), std::memory_order_relaxed);
+        };
         // this worker's files between their count and their parse, oldest first (the crew's threads live as long as
         // the process: so do their buffers)
         static thread_local gfm_tsv_detail::FileBuf ring[kRing];
@@ -473,6 +487,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
             if (n_held > 0 && held[head] < next_assign.load(std::memory_order_acquire)) {
                 // my oldest file has its offset: parse it in place
                 const int i = held[head];
+                set_state(2, i);
                 gfm_tsv_detail::FileBuf &text = ring[head];
                 FileCols &f = sc->table.files[(size_t)i];
                 const int64_t rows = f.n_rows, off = file_off[(size_t)i];
@@ -505,17 +520,25 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                             left = chunk_rows - in;
                             if ((size_t)k >= kMaxChunks) { gave_up = true; err = "too many rows for one scan"; return; }
                             if (k >= released.load(std::memory_order_acquire) + kSlots) {   // rare: far ahead of the GPU
-                                std::unique_lock<std::mutex> g2(mu);
-                                cv_work.wait(g2, [&] { return failed.load() || k < released.load() + kSlots; });
+                                const double w0 = trace ? now_s() : 0.0;
+                                set_state(3, (long long)i | ((long long)k << 20));
+                                {
+                                    std::unique_lock<std::mutex> g2(mu);
+                                    cv_work.wait(g2, [&] { return failed.load() || k < released.load() + kSlots; });
+                                }
+                                if (trace) tr_max(tr_slot, (int64_t)((now_s() - w0) * 1e9));
+                                set_state(2, i);
                             }
                             if (failed.load()) { gave_up = true; return; }
                             if (k != cached_k) {        // consecutive files of a worker mostly stay in one chunk
                                 const MetaChunk *got;
+                                const double b0 = trace ? now_s() : 0.0;
                                 {
                                     std::lock_guard<std::mutex> g3(assign_mu);      // the pool's block table
                                     got = P->meta_chunk((size_t)k, chunk_rows, W);
                                     if (got) cached_mc = *got;
                                 }
+                                if (trace) tr_max(tr_block, (int64_t)((now_s() - b0) * 1e9));
                                 if (!got) { gave_up = true; err = "out of memory"; return; }
                                 cached_k = k;
                             }
@@ -536,8 +559,10 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                         ++done;
                     };
                     std::string perr;
+                    const double p0 = trace ? now_s() : 0.0;
                     const bool ok = gfm_tsv_detail::parse_rows(paths[i], text.begin(), text.end(), W, skip_reverse != 0,
                                                                names, sink, perr);
+                    if (trace) tr_max(tr_parse, (int64_t)((now_s() - p0) * 1e9));
                     account();
                     if (!ok) err = perr;
                     else if (err.empty() && !gave_up && done != rows)
@@ -557,8 +582,11 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                     const int slot_ix = (head + n_held) % kRing;
                     std::string err;
                     int64_t rows = 0;
+                    const double r0 = trace ? now_s() : 0.0;
+                    set_state(1, i);
                     if (ring[slot_ix].load(paths[i], err))
                         rows = gfm_tsv_detail::count_rows(ring[slot_ix].begin(), ring[slot_ix].end(), skip_reverse != 0);
+                    if (trace) tr_max(tr_read, (int64_t)((now_s() - r0) * 1e9));
                     if (!err.empty()) { fail_with(err); return; }
                     held[slot_ix] = i;
                     ++n_held;
@@ -568,10 +596,15 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                     continue;
                 }
             }
-            if (n_held == 0) return;                             // nothing left for this thread to take
+            if (n_held == 0) { set_state(0, 0); return; }        // nothing left for this thread to take
             // my oldest file waits for earlier counts (they are being made right now): help, then give way
             advance_offsets();
-            if (held[head] >= next_assign.load(std::memory_order_acquire)) std::this_thread::yield();
+            if (held[head] >= next_assign.load(std::memory_order_acquire)) {
+                const double y0 = trace ? now_s() : 0.0;
+                set_state(4, held[head]);
+                std::this_thread::yield();
+                if (trace) tr_max(tr_offset, (int64_t)((now_s() - y0) * 1e9));
+            }
         }
     };
     stamp("pipeline set up");
@@ -624,8 +657,10 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     std::vector<uint64_t *> v_hist(M), v_count(M);
     std::vector<int64_t *> v_sel(M);
     std::vector<int64_t> v_cap(M);
+    double m_wait = 0, m_submit = 0, m_release = 0;     // trace: the main thread's longest wait / submit / release
     for (int64_t k = 0;; ++k) {
         int64_t rows_k = 0;
+        const double t_w0 = trace ? now_s() : 0.0;
         {   // wait until chunk k is fully in place (or turns out not to exist)
             auto ready = [&]() {
                 if (failed.load()) return true;
@@ -638,12 +673,43 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                 return false;
             };
             std::unique_lock<std::mutex> lk(mu);
-            while (!ready()) cv_main.wait_for(lk, std::chrono::microseconds(500));   // (woken by the completing add)
+            bool dumped = false;
+            while (!ready()) {
+                cv_main.wait_for(lk, std::chrono::microseconds(500));   // (woken by the completing add)
+                // stuck for 10 ms: who holds what.  (What this showed on the GPU boxes of round 3: every worker asleep in its
+                // slot wait or in the middle of a parse, for 20-80 ms at a time, with nothing in the pipeline to wait for --
+                // the container's CPU quota, 16 CPUs' worth of time per 100 ms on a 256-thread host, was used up and the
+                // kernel had frozen all threads until the next period: /sys/fs/cgroup/cpu.stat nr_throttled.)
+                if (trace && !dumped && now_s() - t_w0 > 0.010) {
+                    dumped = true;
+                    int cnt[5] = {0, 0, 0, 0, 0};
+                    long long lo_file[5] = {1ll << 40, 1ll << 40, 1ll << 40, 1ll << 40, 1ll << 40};
+                    for (int i = 0; i < nt; ++i) {
+                        const long long v = w_state[(size_t)i].load();
+                        const int st = (int)(v >> 32);
+                        if (st >= 0 && st < 5) { ++cnt[st]; lo_file[st] = std::min(lo_file[st], v & 0xffffffffll); }
+                    }
+                    for (int i = 0; i < nt; ++i) {
+                        const long long v = w_state[(size_t)i].load();
+                        if ((int)(v >> 32) == 3 && ((v >> 20) & 0xfff) <= k)
+                            std::fprintf(stderr, "[scan]   worker %d waits for a slot with file %lld, chunk %lld\n", i, v & 0xfffff,
+                                         (v >> 20) & 0xfff);
+                    }
+                    std::fprintf(stderr, "[scan] STUCK at chunk %lld: have %lld of %lld rows; next_count %d next_assign %d released %lld; "
+                                         "workers idle %d, reading %d (lowest file %lld), parsing %d (lowest %lld), slot wait %d (lowest %lld), "
+                                         "yield %d (lowest %lld)\n",
+                                 (long long)k, (long long)chunk_staged[(size_t)k].load(), (long long)chunk_rows, next_count.load(),
+                                 next_assign.load(), (long long)released.load(), cnt[0], cnt[1], lo_file[1], cnt[2], lo_file[2], cnt[3],
+                                 lo_file[3], cnt[4], lo_file[4]);
+                }
+            }
             if (failed.load()) return sfail(GFM_ERR_IO, fail_msg);
             rows_k = (size_t)k < kMaxChunks ? chunk_staged[(size_t)k].load(std::memory_order_acquire) : 0;
         }
         if (rows_k == 0) break;
         stamp("chunk staged");
+        const double t_s0 = trace ? now_s() : 0.0;
+        if (trace) m_wait = std::max(m_wait, t_s0 - t_w0);
         const int slot = (int)(k % kSlots);
         const size_t bytes = (size_t)rows_k * (size_t)W;
         for (size_t j = 0; j < M; ++j) {
@@ -671,7 +737,10 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
         sc->chunk_n.push_back(rows_k);
         total_rows += rows_k;
         ++n_chunks;
+        const double t_r0 = trace ? now_s() : 0.0;
+        if (trace) m_submit = std::max(m_submit, t_r0 - t_s0);
         if (k + 1 >= kSlots) S_RC(release_chunk(k + 1 - kSlots));   // the slot chunk k+1 will be written into
+        if (trace) m_release = std::max(m_release, now_s() - t_r0);
         if (rows_k < chunk_rows) break;                             // a short chunk is the last one
     }
     for (int64_t k = std::max<int64_t>(0, (int64_t)n_chunks - (kSlots - 1)); k < (int64_t)n_chunks; ++k)
@@ -684,7 +753,14 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
         if (failed.load()) return sfail(GFM_ERR_IO, fail_msg);
     }
     const double t_parse_end = std::max(t_begin, (double)parse_end_ns.load() * 1e-9);
-    if (trace) std::fprintf(stderr, "[scan] %8.3f ms  (last file parsed)\n", (t_parse_end - t_begin) * 1e3);
+    if (trace) {
+        std::fprintf(stderr, "[scan] %8.3f ms  (last file parsed)\n", (t_parse_end - t_begin) * 1e3);
+        std::fprintf(stderr, "[scan] main thread, longest: wait for a chunk %.3f ms, submit %.3f ms, release %.3f ms\n",
+                     m_wait * 1e3, m_submit * 1e3, m_release * 1e3);
+        std::fprintf(stderr, "[scan] longest single: read+count %.3f ms, parse of a file %.3f ms, wait for a slot %.3f ms, "
+                             "column block lookup %.3f ms, yield %.3f ms\n", tr_read.load() * 1e-6, tr_parse.load() * 1e-6,
+                     tr_slot.load() * 1e-6, tr_block.load() * 1e-6, tr_offset.load() * 1e-6);
+    }
     sc->table.index_rows();
     stamp("rows indexed");
     if (sc->table.n != total_rows) return sfail(GFM_ERR_IO, "internal error: row count mismatch");

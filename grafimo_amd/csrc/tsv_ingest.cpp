@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -150,7 +151,35 @@ void gfm_tsv_detail::parse_file(const char *path, int W, bool skip_rev, FileCols
 // through gfm_scan_tsv, median of 7 runs: 32 threads 6.6 ms, 64 5.6, 96 5.0, 128 5.6, 175 8.0 with 80 ms outliers
 // (profiles/r02_scan_trace.txt).
 static constexpr int kMaxParseThreads = 96;
-static constexpr int kMaxParseThreadsBig = 32;
+
+// CPU time the container may use per second of wall time, in cores (cgroup v2 cpu.max, v1 cfs quota); 0: no quota.
+// Read once.  A container that shows 256 hardware threads under a quota of 16 lets 64 threads burst for a few
+// milliseconds, but work that needs more CPU time than one period's allowance (100 ms x the quota) is frozen as a whole
+// once the allowance is used up, until the period ends (cpu.stat nr_throttled).
+static double cpu_quota_cores()
+{
+    static const double cached = [] {
+        double quota = 0, period = 0;
+        if (FILE *fh = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            const int got = std::fscanf(fh, "%63s %lf", q, &period);
+            std::fclose(fh);
+            if (got == 2 && std::strcmp(q, "max") != 0 && period > 0) return std::atof(q) / period;
+            if (got >= 1) return 0.0;
+        }
+        FILE *fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+        FILE *fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (fq && fp && std::fscanf(fq, "%lf", &quota) == 1 && std::fscanf(fp, "%lf", &period) == 1 && quota > 0 && period > 0) {
+            std::fclose(fq);
+            std::fclose(fp);
+            return quota / period;
+        }
+        if (fq) std::fclose(fq);
+        if (fp) std::fclose(fp);
+        return 0.0;
+    }();
+    return cached;
+}
 
 int gfm_tsv_detail::pick_threads(const char *const *paths, int n_paths, int requested)
 {
@@ -169,12 +198,22 @@ int gfm_tsv_detail::pick_threads(const char *const *paths, int n_paths, int requ
     bytes = bytes / (unsigned long long)sampled * (unsigned long long)n_paths;
     const unsigned long long by_size = bytes >> 20;
     if ((unsigned long long)nt > by_size) nt = (int)(by_size < 1 ? 1 : by_size);
+    if (const char *e = std::getenv("GRAFIMO_PARSE_THREADS_EXACT")) {   // measurement aid: no caps at all
+        if (*e == '1') return nt;
+    }
     if (nt > kMaxParseThreads) nt = kMaxParseThreads;
-    // Text that no longer fits the last-level caches (the page cache is then read from DRAM by every thread's
-    // read()): 1.84 GB in 10 000 files on a 2 x 64-core host take 61-66 ms with 24 or 32 threads, 72-75 ms with 48 and
-    // more, 85..170 ms with 96 (scripts/ingest_probe.py, profiles/r03_ingest_probe.txt) -- the kernel's copy out of
-    // the page cache saturates near 40 GB/s whatever the thread count, and more threads only queue up behind it.
-    if (bytes > (1ull << 30) && nt > kMaxParseThreadsBig) nt = kMaxParseThreadsBig;
+    // Big inputs under a CPU quota: 1.84 GB in 10 000 files need about two CPU-seconds of reading and parsing.  On the
+    // round-3 GPU boxes (256 hardware threads, quota 16 = 1.6 CPU-seconds per 100 ms) they take 61-66 ms with 24 or 32
+    // threads, 72-75 ms with 48 and more, 85..170 ms with 96 (scripts/ingest_probe.py, profiles/r03_ingest_probe.txt):
+    // the more threads, the earlier the period's allowance is gone and the longer every thread of the process is frozen
+    // (a trace of the scan shows all workers asleep for 20-80 ms with nothing to wait for; profiles/r03_cpu_quota.txt).
+    // Twice the quota keeps the burst short of that; without a quota the cap above stands (the bare read + parse of
+    // those files scales to 96 threads: 28 ms, profiles/r03_file_read_scaling.txt).
+    const double quota = cpu_quota_cores();
+    if (quota > 0 && bytes > (1ull << 30)) {
+        const int cap = std::max(16, std::min(kMaxParseThreads, (int)(2.0 * quota + 0.5)));
+        if (nt > cap) nt = cap;
+    }
     return nt;
 }
 
