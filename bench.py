@@ -168,6 +168,17 @@ def cpu_quota_cores():
         return None
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baselines(mot, budget_s=8.0):
     """The reference's scoring loop restated (oracle/, the checker -- kind 'port'), timed on the host
     cores of this box: per TSV line the text handling of score_seqs (score_sequences.py:273-321) and
@@ -198,7 +209,7 @@ def cpu_baselines(mot, budget_s=8.0):
         total = sum(r[0] for r in res)
         out[name] = {
             "value": total / wall, "unit": "k-mers/s", "cores": cores, "kind": "port",
-            "host_threads": threads, "cpu_quota_cores": quota,
+            "host_threads": threads, "cpu_quota_cores": quota, "cpu_model": cpu_model(),
             "cache_resident": True,
             "sample": f"the first {rows} TSV rows ({len(text)} bytes of text: cache resident) of a batch of the same "
                       f"synthetic recipe, passed over again and again "
