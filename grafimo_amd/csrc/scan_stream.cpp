@@ -743,15 +743,24 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
         if (trace) m_release = std::max(m_release, now_s() - t_r0);
         if (rows_k < chunk_rows) break;                             // a short chunk is the last one
     }
-    for (int64_t k = std::max<int64_t>(0, (int64_t)n_chunks - (kSlots - 1)); k < (int64_t)n_chunks; ++k)
-        S_RC(release_chunk(k));
-    stamp("chunks submitted and released");
+    stamp("chunks submitted");
+    // every row is parsed by now (the last chunk was complete): the workers are done or about to be.  The host-side
+    // index of the rows is made while the GPU still copies and scores the last chunks; their slots are waited for after it
     crew.run.wait();
     stamp("workers done");
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (failed.load()) return sfail(GFM_ERR_IO, fail_msg);
+        if (failed.load()) {
+            (void)hipStreamSynchronize(P->copy);         // nothing of this scan may still use the pool's slots
+            (void)hipStreamSynchronize(P->score);
+            return sfail(GFM_ERR_IO, fail_msg);
+        }
     }
+    sc->table.index_rows();
+    stamp("rows indexed");
+    for (int64_t k = std::max<int64_t>(0, (int64_t)n_chunks - (kSlots - 1)); k < (int64_t)n_chunks; ++k)
+        S_RC(release_chunk(k));
+    stamp("chunks released");
     const double t_parse_end = std::max(t_begin, (double)parse_end_ns.load() * 1e-9);
     if (trace) {
         std::fprintf(stderr, "[scan] %8.3f ms  (last file parsed)\n", (t_parse_end - t_begin) * 1e3);
@@ -761,8 +770,6 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                              "column block lookup %.3f ms, yield %.3f ms\n", tr_read.load() * 1e-6, tr_parse.load() * 1e-6,
                      tr_slot.load() * 1e-6, tr_block.load() * 1e-6, tr_offset.load() * 1e-6);
     }
-    sc->table.index_rows();
-    stamp("rows indexed");
     if (sc->table.n != total_rows) return sfail(GFM_ERR_IO, "internal error: row count mismatch");
     S_TRY(hipStreamSynchronize(P->score));      // the histograms are complete for whoever reads them next
     sc->total_rows = total_rows;
