@@ -255,8 +255,51 @@ __attribute__((target("avx2,bmi"))) inline int split_fields_avx2(const char *p, 
 // Line end AND fields from the same 64-byte blocks (no separate memchr pass over the line): the newline's bit ends the
 // line, everything behind it counts as white space.  -> number of fields (<= 6), *line_end = the '\n' (or `end`);
 // -1: a block would reach beyond `end` -- the caller takes the scalar way for this line (the file's last lines).
+__attribute__((target("avx2,bmi"))) inline int split_line_avx2_blocks(const char *p, const char *end, const char **fb,
+                                                                       const char **fe, const char **line_end);
+// The common case first -- the six fields end inside the first 128 bytes of the line: both blocks' masks at once, field
+// starts and ends as the 0 -> 1 / 1 -> 0 steps of the 128-bit white-space mask, picked off lowest first.  Anything
+// else (a longer k-mer, a field across byte 128) goes to the block loop.
 __attribute__((target("avx2,bmi"))) inline int split_line_avx2(const char *p, const char *end, const char **fb, const char **fe,
                                                                 const char **line_end)
+{
+    if (end - p < 128) return split_line_avx2_blocks(p, end, fb, fe, line_end);
+    const __m256i nlv = _mm256_set1_epi8('\n');
+    const __m256i v0 = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p));
+    const __m256i v1 = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + 32));
+    const __m256i v2 = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + 64));
+    const __m256i v3 = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p + 96));
+    const unsigned long long nl0 = (unsigned long long)(unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v0, nlv)) |
+                                   ((unsigned long long)(unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v1, nlv)) << 32);
+    const unsigned long long nl1 = (unsigned long long)(unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v2, nlv)) |
+                                   ((unsigned long long)(unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v3, nlv)) << 32);
+    unsigned long long ws0 = (unsigned long long)ws_mask32_avx2(v0) | ((unsigned long long)ws_mask32_avx2(v1) << 32);
+    unsigned long long ws1 = (unsigned long long)ws_mask32_avx2(v2) | ((unsigned long long)ws_mask32_avx2(v3) << 32);
+    int L = -1;                                          // the newline's offset, if it lies in these 128 bytes
+    if (nl0) { L = __builtin_ctzll(nl0); ws0 |= ~0ull << L; ws1 = ~0ull; }
+    else if (nl1) { const int t = __builtin_ctzll(nl1); L = 64 + t; ws1 |= ~0ull << t; }
+    const unsigned long long prev0 = (ws0 << 1) | 1ull, prev1 = (ws1 << 1) | (ws0 >> 63);
+    unsigned long long s0 = ~ws0 & prev0, s1 = ~ws1 & prev1, e0 = ws0 & ~prev0, e1 = ws1 & ~prev1;
+    int nf = 0, ne = 0;
+    for (; nf < 6; ++nf) {
+        if (s0) { fb[nf] = p + __builtin_ctzll(s0); s0 &= s0 - 1; }
+        else if (s1) { fb[nf] = p + 64 + __builtin_ctzll(s1); s1 &= s1 - 1; }
+        else break;
+    }
+    for (; ne < nf; ++ne) {
+        if (e0) { fe[ne] = p + __builtin_ctzll(e0); e0 &= e0 - 1; }
+        else if (e1) { fe[ne] = p + 64 + __builtin_ctzll(e1); e1 &= e1 - 1; }
+        else break;
+    }
+    if (ne < nf) return split_line_avx2_blocks(p, end, fb, fe, line_end);     // a field runs on beyond byte 128
+    if (L >= 0) { *line_end = p + L; return nf; }
+    if (nf < 6) return split_line_avx2_blocks(p, end, fb, fe, line_end);      // a long line with fields still to come
+    const char *q = static_cast<const char *>(memchr(p + 128, '\n', (size_t)(end - (p + 128))));
+    *line_end = q ? q : end;
+    return nf;
+}
+__attribute__((target("avx2,bmi"))) inline int split_line_avx2_blocks(const char *p, const char *end, const char **fb,
+                                                                       const char **fe, const char **line_end)
 {
     int nf = 0;
     bool in_field = false;
@@ -334,7 +377,18 @@ struct NameTable {
     explicit NameTable(std::vector<std::string> &n) : names(n) {}
     int32_t id(const char *b, size_t len)
     {
-        if (last && len == last_len && memcmp(last, b, len) == 0) return last_id;
+        if (last && len == last_len) {                 // consecutive rows repeat the name: eight bytes at a time, no call
+            size_t i = 0;
+            bool same = true;
+            for (; same && i + 8 <= len; i += 8) {
+                uint64_t x, y;
+                memcpy(&x, last + i, 8);
+                memcpy(&y, b + i, 8);
+                same = x == y;
+            }
+            for (; same && i < len; ++i) same = last[i] == b[i];
+            if (same) return last_id;
+        }
         std::string key(b, len);
         auto it = ix.find(key);
         int32_t nid;

@@ -49,11 +49,26 @@ int main(int argc, char **argv)
     const char *tsv = argv[1], *vcf = argv[2], *tmp = argv[3];
     std::string base = slurp(tsv);
     std::mt19937 rng(7);
+    // a second base text: region names of 1..150 characters, so that every field boundary falls on either side of bytes
+    // 64 and 128 of its line (the splitter works on 64-byte blocks and has a fast path for lines that fit two of them)
+    std::string base2;
+    for (int i = 0; i < 400; ++i) {
+        std::string name(1 + rng() % 150, 'r');
+        for (auto &c : name) c = "chr0123456789:-_"[rng() % 16];
+        std::string kmer(19, 'A');
+        for (auto &c : kmer) c = "ACGTN"[rng() % 5];
+        const long a = (long)(rng() % 100000000), b = a + 19;
+        const bool minus = rng() % 2;
+        base2 += name + "\t" + kmer + "\tchr22:" + std::to_string(minus ? b : a) + (minus ? "-" : "+") + "\tchr22:" +
+                 std::to_string(minus ? a : b) + (minus ? "-" : "+") + "\t" + std::to_string(rng() % 5097) + "\t" +
+                 (rng() % 2 ? "ref" : "non.ref") + "\t" + std::string(rng() % 90, '7') + ",\n";
+    }
     long ok = 0, bad = 0;
-    for (int it = 0; it < 1500; ++it) {
-        std::string t = base;
+    for (int it = 0; it < 2000; ++it) {
+        std::string t = it < 1500 ? base : base2;
+        if (it == 1500) { /* unmutated */ } else
         if (it) {
-            const int muts = 1 + (int)(rng() % 8);
+            const int muts = 1 + (int)(rng() % (it < 1500 ? 8 : 3));
             for (int k = 0; k < muts; ++k) {
                 const size_t at = rng() % t.size();
                 switch (rng() % 6) {
