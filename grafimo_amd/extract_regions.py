@@ -436,8 +436,13 @@ class DeviceGraph:
     def extract(self, regions: Sequence[Tuple[int, int]], width: int, stream=None) -> ExtractedKmers:
         """All rows of `vg find -p chrom:S-E -K width -E -H` for the given (S, E) regions."""
         torch = _torch()
-        starts = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
-        stops = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+        if isinstance(regions, np.ndarray):              # [n, 2]: no Python loop over the regions
+            se = np.asarray(regions, dtype=np.int64).reshape(-1, 2)
+            starts, stops = np.ascontiguousarray(se[:, 0]), np.ascontiguousarray(se[:, 1])
+            regions = [(int(a), int(b)) for a, b in se] if len(se) < 64 else se
+        else:                                            # (two list comprehensions beat np.asarray on a list of tuples)
+            starts = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
+            stops = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
         nw, nr = ctypes.c_int64(), ctypes.c_int64()
         with torch.cuda.device(self.device):
             nv.check(nv.lib().gfm_graph_plan(self._h, len(regions), nv.ptr(starts), nv.ptr(stops), int(width),
@@ -737,9 +742,14 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
         labels = [x for lst in label_lists for x in lst]
     else:
         got, name_ix = cols, cols["name_id"].astype(np.int64)
+    if labels:
+        seqnames = [labels[int(r)] for r in name_ix]
+    else:                                            # the hit rows' labels: one search for all of them
+        part_of = np.searchsorted(np.asarray(label_base), name_ix, side="right") - 1
+        seqnames = [parts[int(k)].region_label(int(r) - label_base[int(k)]) for k, r in zip(part_of, name_ix)]
     return build_frame(
         motif,
-        seqnames=[labels[int(r)] if labels else label_of(int(r)) for r in name_ix],
+        seqnames=seqnames,
         starts=got["start"], stops=got["stop"],
         strands=[chr(c) for c in got["strand"]],
         scores=got["logodds"], pvalues=got["pvalue"],
