@@ -439,7 +439,6 @@ class DeviceGraph:
         if isinstance(regions, np.ndarray):              # [n, 2]: no Python loop over the regions
             se = np.asarray(regions, dtype=np.int64).reshape(-1, 2)
             starts, stops = np.ascontiguousarray(se[:, 0]), np.ascontiguousarray(se[:, 1])
-            regions = [(int(a), int(b)) for a, b in se] if len(se) < 64 else se
         else:                                            # (two list comprehensions beat np.asarray on a list of tuples)
             starts = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
             stops = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
