@@ -4,6 +4,7 @@ Everything numeric is done by libgrafimo_hip.so; torch is used only for device
 buffers, streams and (in distributed.py) torch.distributed over RCCL.
 """
 import ctypes
+from collections import OrderedDict
 from typing import Optional
 
 import numpy as np
@@ -64,6 +65,47 @@ class DeviceMotif:
         if getattr(self, "_h", None):
             nv.lib().gfm_motif_destroy(self._h)
             self._h = None
+
+    # ---- kept handles for the entry points that are called once per motif AND once more per chromosome / region set
+    # (compute_results, compute_results_from_graph): creating the handle -- one device allocation, the pair tables, the
+    # DP or the upload of its result, the tail table -- and destroying it again was 0.65 ms of a 3 ms call
+    _kept = OrderedDict()          # key -> [DeviceMotif, leases]
+    _KEEP = 8
+
+    @classmethod
+    def lease(cls, motif, use_motif_pmf=True) -> "DeviceMotif":
+        """A handle for `motif` on the current device, a kept one if the same numbers were leased before.  Give it
+        back with `release()`, not `close()`."""
+        from .motif import dense_bg, dense_score_matrix
+        pmf = getattr(motif, "pval_matrix", None) if use_motif_pmf else None
+        sm, bg = dense_score_matrix(motif), dense_bg(motif)
+        key = (_torch().cuda.current_device(), np.ascontiguousarray(sm, dtype=np.int64).tobytes(),
+               np.ascontiguousarray(bg, dtype=np.float64).tobytes(), int(motif.min_val), int(motif.scale), float(motif.offset),
+               None if pmf is None else hash(np.ascontiguousarray(pmf, dtype=np.float64).tobytes()))
+        slot = cls._kept.get(key)
+        if slot is not None and slot[0]._h:
+            slot[1] += 1
+            cls._kept.move_to_end(key)
+            return slot[0]
+        dm = cls(sm, bg, int(motif.min_val), int(motif.scale), float(motif.offset), pmf)
+        dm._lease_key = key
+        cls._kept[key] = [dm, 1]
+        for old in [k for k, v in cls._kept.items() if v[1] == 0][:max(0, len(cls._kept) - cls._KEEP)]:
+            cls._kept.pop(old)[0].close()
+        return dm
+
+    def release(self):
+        slot = DeviceMotif._kept.get(getattr(self, "_lease_key", None))
+        if slot is None or slot[0] is not self:
+            self.close()
+        else:
+            slot[1] = max(0, slot[1] - 1)
+
+    @classmethod
+    def drop_kept(cls):
+        """Destroy every kept handle nobody holds (tests; before a fork that will use the GPU itself)."""
+        for k in [k for k, v in cls._kept.items() if v[1] == 0]:
+            cls._kept.pop(k)[0].close()
 
     def __del__(self):
         try:

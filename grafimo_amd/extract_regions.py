@@ -692,7 +692,7 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
         errmsg = "No result retrieved. Unable to proceed.\n"
         errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
         exception_handler(ValueError, errmsg, debug)
-    dm = DeviceMotif.from_motif(motif)
+    dm = DeviceMotif.lease(motif)            # a kept handle when this motif was scored before (device.py)
     try:
         if not no_qvalue and rank == 0:
             print("\nComputing q-values...\n")
@@ -714,7 +714,7 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
                 cap = n
         lo, pv = dm.annotate(res["scaled"])
     finally:
-        dm.close()
+        dm.release()
     if rank == 0:
         print(f"Scanned sequences:\t{n_global}")
         print(f"Scanned nucleotides:\t{n_global * W}")

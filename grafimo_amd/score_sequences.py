@@ -225,7 +225,7 @@ def compute_results(motif: Motif, sequence_loc: str, debug: bool, args_obj=None,
         errmsg = "No result retrieved. Unable to proceed.\n"
         errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
         exception_handler(ValueError, errmsg, debug)
-    dm = DeviceMotif.from_motif(motif)
+    dm = DeviceMotif.lease(motif)            # a kept handle when this motif was scored before (device.py)
     try:
         scan = StreamScan(dm, files, no_reverse, cores, float(threshold), bool(qval_t), not no_qvalue)
     except nv.NativeError as e:
@@ -234,7 +234,7 @@ def compute_results(motif: Motif, sequence_loc: str, debug: bool, args_obj=None,
         print("\nCaught SIGINT. GRAFIMO will exit")
         die(2)
     finally:
-        dm.close()
+        dm.release()
     if scan.n == 0:
         errmsg = "No result retrieved. Unable to proceed.\n"
         errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"

@@ -567,3 +567,30 @@ def test_two_ranks_on_one_gpu_through_the_sharded_entry_points():
                        text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     assert r.stdout.count("two ranks == one process: True") == 9
+
+
+def test_kept_motif_handles(golden_motifs):
+    """DeviceMotif.lease / release: the entry points that run once per motif and once more per chromosome keep their
+    handle -- same numbers, same handle; other numbers, another; a plain handle is untouched by it; drop_kept() destroys
+    what nobody holds."""
+    from grafimo_amd.device import DeviceMotif
+    DeviceMotif.drop_kept()
+    motif = _ctcf(True)
+    a = DeviceMotif.lease(motif)
+    b = DeviceMotif.lease(motif)
+    assert a is b and a.handle
+    plain = DeviceMotif.from_motif(motif)
+    assert plain is not a
+    other = DeviceMotif.lease(_ctcf(False))              # no score distribution on the host: the DP runs on the device
+    assert other is not a and other.handle
+    pa, pb = a.tables()[1], other.tables()[1]
+    np.testing.assert_allclose(pa, pb, rtol=1e-12)
+    a.release(); b.release()
+    DeviceMotif.drop_kept()                              # `other` is still held: only a / b go
+    assert a.handle is None and other.handle
+    again = DeviceMotif.lease(motif)
+    assert again is not a and again.handle
+    again.release(); other.release(); plain.release()    # release() of a plain handle closes it
+    assert plain.handle is None
+    DeviceMotif.drop_kept()
+    assert again.handle is None and other.handle is None and not DeviceMotif._kept
