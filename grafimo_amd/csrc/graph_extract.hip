@@ -1446,6 +1446,8 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
         return gfail(GFM_ERR_INVALID, "NULL output buffer");
     const unsigned blocks = (unsigned)((g->n_walks + kEmitThreads - 1) / kEmitThreads);
     GX_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), g->ev_planned, 0));
+    // an earlier emit of this handle (possibly on another stream) still owns the staging area and the job lists
+    if (g->emit_pending) GX_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), g->ev_emitted, 0));
     const unsigned dblocks = (unsigned)((g->n_del_walks + kDelThreads - 1) / kDelThreads);
     const unsigned sblocks = (unsigned)((g->n_del_walks + kEmitThreads - 1) / kEmitThreads);
     const int pitch = (2 * g->width + 6) & ~3;
