@@ -832,18 +832,25 @@ emit_plain_body(const unsigned bid, const GraphDev &g, const int *__restrict__ a
 
 // visitor of simulate() that writes the bases of a walk and collects what its haplotypes must carry
 struct DelEmit {
-    const GraphDev &g;
+    // the graph's arrays it reads, BY VALUE: a reference to the GraphDev kernel argument, held by an object that lives in
+    // scratch memory, made every thread copy the whole argument struct (144 bytes) into scratch and read its fields
+    // back from there
+    const uint8_t *alt_bases, *ins_bases;
+    const int *ins_off;
     uint8_t *fwd, *rev;
     int *src;                 // [W] reference position of base j, fetched after the walk (-1: written already)
     int W;
     // constraints as job_constraint() packs them (allele: SNP 0..3; deletion / insertion 1 = taken, 0 = passed by).  The
     // first four in registers -- the tables need no more --, the rest in scratch memory, which nothing reads before the
     // walk is over (with all of them there, every load inside the walk waited for the scratch stores before it).
-    int n_cons;
-    int c0, c1, c2, c3;
-    int more[kMaxConstraints - 4];
-    bool alt;
+    int n_cons = 0;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    int *more;                                  // [kMaxConstraints - 4], an array of the caller's: inside this object it
+                                                // kept ALL of the object in scratch memory, the four "registers" too
+    bool alt = false;
     static constexpr bool kWantsBases = true;
+    __device__ DelEmit(const GraphDev &g, uint8_t *fwd_, uint8_t *rev_, int *src_, int W_, int *more_)
+        : alt_bases(g.alt_bases), ins_bases(g.ins_bases), ins_off(g.ins_off), fwd(fwd_), rev(rev_), src(src_), W(W_), more(more_) {}
     __device__ void add(int site, int code, int n_alts = 1)
     {
         const int v = job_constraint(site, n_alts, code);
@@ -862,7 +869,7 @@ struct DelEmit {
         src[j] = (int)x;
         if (snp >= 0) {
             if (a) {
-                const uint8_t c = g.alt_bases[(size_t)snp * kMaxAlts + (a - 1)];
+                const uint8_t c = alt_bases[(size_t)snp * kMaxAlts + (a - 1)];
                 fwd[j] = c;
                 rev[W - 1 - j] = complement(c);
                 src[j] = -1;
@@ -873,7 +880,7 @@ struct DelEmit {
     }
     __device__ void ins_base(int j, int site, int t)
     {
-        const uint8_t c = g.ins_bases[g.ins_off[site] + t];
+        const uint8_t c = ins_bases[ins_off[site] + t];
         fwd[j] = c;
         rev[W - 1 - j] = complement(c);
         src[j] = -1;
@@ -914,9 +921,6 @@ emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ all
     const DelRec dr = del_rec[m];
     const int q0 = (int)(td - del_base[m]);
     const int nl = min(n_layouts[m], kLayoutCache);
-    LayoutRec kept[kLayoutCache];
-#pragma unroll
-    for (int k = 0; k < kLayoutCache; ++k) kept[k] = layouts[(size_t)m * kLayoutCache + k];
     const long long p = dr.p, limit = dr.limit;
     const int i0 = dr.i0;
 #pragma unroll
@@ -927,12 +931,14 @@ emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ all
     WalkStart ws;
     long long q = q0, prod = 0;
     bool found = false;
-    {   // the layouts graph_count_del_kernel kept for this window
+    {   // the layouts graph_count_del_kernel kept for this window: all eight records requested at once (slots behind
+        // nl hold stale bytes and are not looked at), the first whose cumulative count exceeds q0 is the walk's.  (Kept in
+        // a local array they went through scratch memory: 128 bytes stored and read back by every thread.)
         int base = 0;
 #pragma unroll
         for (int k = 0; k < kLayoutCache; ++k) {
+            const LayoutRec rec = layouts[(size_t)m * kLayoutCache + k];
             if (k < nl && !found) {
-                const LayoutRec rec = kept[k];
                 if (q0 < rec.cum_end) {
                     found = true;
                     q = q0 - base;
@@ -966,7 +972,8 @@ emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ all
     // thread's LDS slot with the byte phase of that place, and go to the staging slot as dwords
     const int phase = (int)(reinterpret_cast<uintptr_t>(kmers + (size_t)(2 * t) * W) & 3u);
     uint8_t *fwd = slot + phase;
-    DelEmit em{g, fwd, fwd + W, src, W, 0, 0, 0, 0, 0, {}, false};
+    int more_cons[kMaxConstraints - 4];          // NOT initialised (368 bytes of scratch stores per thread otherwise)
+    DelEmit em(g, fwd, fwd + W, src, W, more_cons);
     long long again = 0;
     simulate(g, sites, p, W, i0, ws, st.nd, st, em, q, prod, again, limit);
     for (int j0 = 0; j0 < W; j0 += 8) {              // the reference bases it noted, eight loads in flight
