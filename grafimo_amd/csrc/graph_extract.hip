@@ -632,6 +632,8 @@ __device__ inline long long count_by_bitsets(const GraphDev &g, int n, F at)
 struct JobHead {
     long long dst;            // t >= 0: rows 2 t, 2 t + 1 of the freq column;  ~td < 0: the staged deletion walk td
     int off, n;               // its constraints: pool[off .. off + n);  n <= 0: no job (its walk was counted in place)
+    int first[4];             // the first four of them once more: most jobs have no others, and read here they cost the
+                              // job kernel one dependent load less
 };
 struct CountJobs {
     int *counters;            // [0] plain jobs, [1] plain pool entries, [2] deletion jobs, [3] deletion pool entries
@@ -668,7 +670,7 @@ graph_count_jobs_kernel(GraphDev g, CountJobs jobs, int which /* 0: the plain ke
             for (int k0 = 0; k0 < h.n; k0 += 4) {
                 int c[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) c[u] = k0 + u < h.n ? cons[k0 + u] : -1;
+                for (int u = 0; u < 4; ++u) c[u] = k0 + u < h.n ? (k0 == 0 ? h.first[u] : cons[k0 + u]) : -1;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (c[u] < 0) continue;
@@ -789,8 +791,13 @@ emit_plain_body(const unsigned bid, const GraphDev &g, const int *__restrict__ a
             const int j = atomicAdd(&jobs.counters[0], 1);
             const int off = atomicAdd(&jobs.counters[1], ns);
             if (j < jobs.plain_jobs && off + ns <= jobs.plain_pool) {
-                for (int k = 0; k < ns; ++k) jobs.pool[off + k] = job_constraint(i0 + k, n_alts_of(k), allele(k));
-                jobs.head[j] = JobHead{t, off, ns};
+                JobHead h{t, off, ns, {0, 0, 0, 0}};
+                for (int k = 0; k < ns; ++k) {
+                    const int v = job_constraint(i0 + k, n_alts_of(k), allele(k));
+                    jobs.pool[off + k] = v;
+                    if (k < 4) h.first[k] = v;
+                }
+                jobs.head[j] = h;
             }
         }
     }
@@ -1007,7 +1014,7 @@ emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ all
             deferred = off + em.n_cons <= jobs.del_pool;
             if (deferred)
                 for (int k = 0; k < em.n_cons; ++k) jobs.pool[jobs.plain_pool + off + k] = em.get(k);
-            jobs.head[jobs.plain_jobs + j] = JobHead{~td, jobs.plain_pool + off, deferred ? em.n_cons : 0};
+            jobs.head[jobs.plain_jobs + j] = JobHead{~td, jobs.plain_pool + off, deferred ? em.n_cons : 0, {em.c0, em.c1, em.c2, em.c3}};
         }
     }
     if (!done && !deferred) count = count_by_bitsets(g, em.n_cons, at);
@@ -1141,7 +1148,7 @@ struct gfm_graph {
     // plan's last kernels, the next plan waits for the emit that still reads the plan buffers
     hipEvent_t ev_planned = nullptr, ev_emitted = nullptr;
     long long *h_back = nullptr;         // pinned: what a plan reads back (gfm_graph_plan)
-    hipStream_t side = nullptr;          // the deletion walks' kernel runs here, beside the plain walks' (gfm_graph_emit)
+    hipStream_t side = nullptr;          // the plain walks' kernels run here when there are deletion walks, beside the plain walks' (gfm_graph_emit)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool emit_pending = false;
     void drop_plan()
@@ -1250,13 +1257,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_emitted, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming);
-    if (e == hipSuccess) {
-        // high priority: the deletion walks are few and long -- their workgroups must get the first wave slots that come
-        // free while the plain kernel fills the chip, not the last
-        int lo = 0, hi = 0;
-        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&g->side, hipStreamNonBlocking, hi);
-    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
     if (e != hipSuccess) {
         gfm_graph_destroy(g);
         return gfail(GFM_ERR_HIP, std::string("event creation failed: ") + hipGetErrorString(e));
@@ -1467,34 +1468,42 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
     // measurement aid: GRAFIMO_EXTRACT_SERIAL=1 runs the two emit kernels one after the other on the caller's stream,
     // so that a kernel trace shows what each takes alone
     static const bool serial = [] { const char *e = std::getenv("GRAFIMO_EXTRACT_SERIAL"); return e && *e == '1'; }();
-    hipStream_t del_st = serial ? st : g->side;
     const CountJobs jobs = g->jobs;
     if (jobs.counters) GX_TRY(hipMemsetAsync(jobs.counters, 0, 4 * sizeof(int), st));
-    if (dblocks) {   // fork: the deletion walks on the side stream, into the staging area
+    // The deletion walks' chain -- kernel, its count jobs, the scatter of its staged rows -- stays on the caller's stream;
+    // the plain walks and their count jobs go to the side stream and are done before the scatter needs their placeholder
+    // rows.  Which of the two gets the side stream does not matter for the total (scripts/extract_timeline.sh: 175 us from
+    // the first kernel's start to the scatter's end either way): the kernels share the chip's wave slots -- whichever starts
+    // first runs near its stand-alone time (deletions 55 -> 84 us, plain 95 -> 105 us), the other one stretches (130 us) --
+    // and what counts is the sum of their work.
+    hipStream_t plain_st = (dblocks && !serial) ? g->side : st;
+    if (dblocks) {
         if (!serial) {
             GX_TRY(hipEventRecord(g->ev_fork, st));
             GX_TRY(hipStreamWaitEvent(g->side, g->ev_fork, 0));
         }
         const size_t del_lds = (size_t)kDelThreads * (kSiteCache * sizeof(SiteRec) + (size_t)g->width * sizeof(int) + (size_t)pitch);
-        hipLaunchKernelGGL(graph_emit_del_kernel, dim3(dblocks), dim3(kDelThreads), del_lds, del_st,
+        hipLaunchKernelGGL(graph_emit_del_kernel, dim3(dblocks), dim3(kDelThreads), del_lds, st,
                            g->dev, g->d_allele_count, g->del_entry.p, g->del_base.p, g->del_rec.p, g->width, g->n_del_walks,
                            g->walk_base.p, d_kmers, g->del_layouts.p, g->del_layout_n.p, g->stg_kmers.p, g->stg_meta.p,
                            pitch, jobs);
-        if (jobs.counters && jobs.del_jobs > 0)      // the counts it left to graph_count_jobs_kernel, also beside the plain walks
-            hipLaunchKernelGGL(graph_count_jobs_kernel, dim3(1024), dim3(256), 0, del_st, g->dev, jobs, 1,
+        if (jobs.counters && jobs.del_jobs > 0)      // the counts it left to graph_count_jobs_kernel
+            hipLaunchKernelGGL(graph_count_jobs_kernel, dim3(4096), dim3(256), 0, st, g->dev, jobs, 1,
                                reinterpret_cast<long long *>(d_freq), g->stg_meta.p, kDelMeta);
-        if (!serial) GX_TRY(hipEventRecord(g->ev_join, g->side));
     }
-    hipLaunchKernelGGL(graph_emit_kernel, dim3(blocks), dim3(kEmitThreads), (size_t)2 * kEmitThreads * g->width, st,
+    hipLaunchKernelGGL(graph_emit_kernel, dim3(blocks), dim3(kEmitThreads), (size_t)2 * kEmitThreads * g->width, plain_st,
                        g->dev, g->d_allele_count, g->walk_window.p, g->win_region.p, g->win_start.p, g->width, g->n_walks,
                        g->first_site.p, g->walk_base.p, g->win_sites.p, d_kmers, reinterpret_cast<long long *>(d_start),
                        reinterpret_cast<long long *>(d_stop), d_strand, reinterpret_cast<long long *>(d_freq), d_is_ref,
                        d_region, d_walk, wide_rows, jobs);
     if (jobs.counters && jobs.plain_jobs > 0)    // the counts the plain kernel left to it
-        hipLaunchKernelGGL(graph_count_jobs_kernel, dim3(256), dim3(256), 0, st, g->dev, jobs, 0,
+        hipLaunchKernelGGL(graph_count_jobs_kernel, dim3(2048), dim3(256), 0, plain_st, g->dev, jobs, 0,
                            reinterpret_cast<long long *>(d_freq), g->stg_meta.p, kDelMeta);
-    if (dblocks) {   // join: the staged rows over the placeholders
-        if (!serial) GX_TRY(hipStreamWaitEvent(st, g->ev_join, 0));
+    if (dblocks) {   // join: the staged rows over the placeholders the plain kernel wrote
+        if (!serial) {
+            GX_TRY(hipEventRecord(g->ev_join, g->side));
+            GX_TRY(hipStreamWaitEvent(st, g->ev_join, 0));
+        }
         hipLaunchKernelGGL(graph_del_scatter_kernel, dim3(sblocks), dim3(kEmitThreads), 0, st,
                            g->n_del_walks, g->width, pitch, g->stg_kmers.p, g->stg_meta.p, d_kmers,
                            reinterpret_cast<long long *>(d_start), reinterpret_cast<long long *>(d_stop),
