@@ -1,3 +1,6 @@
+#!/usr/bin/env bash
+# Development aid (GPU box): durations of the extraction kernels by grid size (the two kinds of count-job launches apart),
+# emit kernels one after the other (GRAFIMO_EXTRACT_SERIAL=1).
 cd /tmp && export TMPDIR=/tmp
 export GRAFIMO_EXTRACT_SERIAL=1
 rocprofv3 --kernel-trace --output-format csv -d /tmp/jt -- python3 $GRAFT_REPO_ROOT/scripts/extract_bench.py > /dev/null 2>&1
