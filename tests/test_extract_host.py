@@ -430,3 +430,19 @@ def test_long_multibase_substitution_keeps_every_mismatch(tmp_path):
         assert idx.pos[snp].tolist() == list(range(10, 10 + n))
         bits = np.unpackbits(idx.alt_bits[snp, 0, :].view(np.uint8), axis=1, bitorder="little")[:, :6]
         assert (bits == np.array([1, 0, 0, 1, 0, 0], dtype=np.uint8)).all()               # carriers of ALT 1, every site
+
+
+def test_window_table_equals_the_per_window_lookups(tmp_path):
+    """GraphIndex.window_table (one vectorised pass per region, used by the TSV writer) against touches_deletion and the
+    per-window site searches, on a rich graph (insertions, deletions incl. overlapping ones, complex alleles)."""
+    from grafimo_amd.extract_regions import GraphIndex
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=1800, n_sites=220, n_samples=9, seed=31, rich=True)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7", with_haplotypes=False)
+    for W in (1, 8, 19, 40):
+        for lo, hi in ((0, 300), (700, 1799), (1795, 1799), (5, 5)):
+            i0, i1, touches = idx.window_table(lo, hi, W)
+            assert len(i0) == hi - lo + 1
+            for k, p in enumerate(range(lo, hi + 1)):
+                assert bool(touches[k]) == idx.touches_deletion(p, W), (W, p)
+                assert int(i0[k]) == int(np.searchsorted(idx.pos, p, side="left"))
+                assert int(i1[k]) == int(np.searchsorted(idx.pos, p + W, side="left"))
