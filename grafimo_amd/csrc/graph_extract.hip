@@ -149,12 +149,14 @@ struct GlobalSites {
 };
 struct CachedSites {
     const SiteRec *rec;
-    const SiteRec *lds;      // [kSiteCache] records of sites first .. first + kSiteCache - 1
-    int first;
+    const SiteRec *lds;      // records of sites first .. first + kSiteCache - 1, record d at lds[d * stride]
+    int first, stride;       // stride = threads of the workgroup: record d of all threads lies side by side, so that the
+                             // 16-byte reads of a wave fall on all banks (thread-major -- 128 bytes per thread -- every
+                             // read was a 32-way bank conflict: SQ_LDS_BANK_CONFLICT 89 % of the kernel's LDS cycles)
     __device__ SiteRec at(int k) const
     {
         const unsigned d = (unsigned)(k - first);
-        return d < (unsigned)kSiteCache ? lds[d] : rec[k];
+        return d < (unsigned)kSiteCache ? lds[d * stride] : rec[k];
     }
 };
 
@@ -919,7 +921,7 @@ emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ all
     if (td >= n_del_walks) return;
     // LDS of the workgroup: [threads][kSiteCache] site records | [threads][W] source positions | [threads][pitch] rows
     extern __shared__ __attribute__((aligned(16))) uint8_t del_stage[];
-    SiteRec *cache = reinterpret_cast<SiteRec *>(del_stage) + (size_t)threadIdx.x * kSiteCache;
+    SiteRec *cache = reinterpret_cast<SiteRec *>(del_stage) + threadIdx.x;      // [kSiteCache][threads]: see CachedSites
     int *src = reinterpret_cast<int *>(del_stage + (size_t)kDelThreads * kSiteCache * sizeof(SiteRec)) + (size_t)threadIdx.x * W;
     uint8_t *slot = del_stage + (size_t)kDelThreads * (kSiteCache * sizeof(SiteRec) + (size_t)W * sizeof(int)) +
                     (size_t)threadIdx.x * pitch;
@@ -931,8 +933,8 @@ emit_del_body(const unsigned bid, const GraphDev &g, const int *__restrict__ all
     const long long p = dr.p, limit = dr.limit;
     const int i0 = dr.i0;
 #pragma unroll
-    for (int k = 0; k < kSiteCache; ++k) cache[k] = g.site_rec[i0 + k];
-    const CachedSites sites{g.site_rec, cache, i0};
+    for (int k = 0; k < kSiteCache; ++k) cache[k * kDelThreads] = g.site_rec[i0 + k];
+    const CachedSites sites{g.site_rec, cache, i0, kDelThreads};
     const long long t = walk_base[dr.w] + q0;          // its place among all walks
     WalkState st;
     WalkStart ws;
