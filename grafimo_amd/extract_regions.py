@@ -462,8 +462,22 @@ class DeviceGraph:
             stops = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
         nw, nr = ctypes.c_int64(), ctypes.c_int64()
         with torch.cuda.device(self.device):
-            nv.check(nv.lib().gfm_graph_plan(self._h, len(regions), nv.ptr(starts), nv.ptr(stops), int(width),
-                                             ctypes.byref(nw), ctypes.byref(nr)))
+            rc = nv.lib().gfm_graph_plan(self._h, len(regions), nv.ptr(starts), nv.ptr(stops), int(width),
+                                         ctypes.byref(nw), ctypes.byref(nr))
+            if rc == nv.GFM_ERR_OVERFLOW and len(regions) > 1:
+                # a window with more than 2^20 walks (twenty and more variant sites inside one k-mer): name the regions, the
+                # way a user can act on it -- `vg find -K W -E` would list every one of those walks
+                bad = []
+                for k in range(len(regions)):
+                    if nv.lib().gfm_graph_plan(self._h, 1, nv.ptr(starts[k:k + 1]), nv.ptr(stops[k:k + 1]), int(width),
+                                               ctypes.byref(nw), ctypes.byref(nr)) == nv.GFM_ERR_OVERFLOW:
+                        bad.append(f"{self.index.chrom}:{int(starts[k])}-{int(stops[k])}")
+                        if len(bad) == 8:
+                            break
+                raise nv.NativeError(rc, f"a window of width {int(width)} holds more than 2^20 walks through its variant sites in "
+                                         f"region(s) {', '.join(bad)}{' ...' if len(bad) == 8 else ''}: leave them out of the BED "
+                                         f"file or scan them with a shorter motif")
+            nv.check(rc)
             n = int(nr.value)
             dev = self.device
             kmers = torch.empty((n, width), dtype=torch.uint8, device=dev)

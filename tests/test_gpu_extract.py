@@ -531,3 +531,25 @@ def test_deferred_and_in_place_haplotype_counts_agree(tmp_path, monkeypatch):
         assert [k.tobytes().decode() for k in rows.kmers.cpu().numpy()] == [r[1] for r in exp]
     g.close()
     assert got[""] == want and got["0"] == want and got["37"] == want
+
+
+@pytest.mark.gpu
+def test_a_window_of_too_many_walks_names_its_region():
+    """Twenty-two neighbouring biallelic sites inside one 30-mer are 2^22 walks: the plan is refused (vg find -E would list
+    them all), and the message names the region that holds the window, not the others."""
+    from grafimo_amd import _native as nv
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
+    rng = np.random.default_rng(3)
+    ref = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 600)]
+    pos = np.arange(300, 322, dtype=np.int32)
+    alt = np.zeros((len(pos), 3), np.uint8)
+    alt[:, 0] = np.where(ref[pos] == ord("A"), ord("C"), ord("A"))
+    idx = GraphIndex("c", ref, pos, np.ones(len(pos), np.uint8), alt, None, 0)
+    g = DeviceGraph(idx)
+    ok = g.extract([(0, 200), (400, 600)], 30)
+    assert len(ok) == 2 * (171 + 171)
+    with pytest.raises(nv.NativeError) as e:
+        g.extract([(0, 200), (250, 400), (400, 600)], 30)
+    assert e.value.code == nv.GFM_ERR_OVERFLOW and "c:250-400" in str(e.value) and "c:0-200" not in str(e.value)
+    assert len(g.extract([(0, 200), (250, 400)], 8)) > 0        # a shorter motif fits: at most eight sites per window
+    g.close()
