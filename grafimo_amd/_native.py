@@ -26,6 +26,8 @@ GFM_FLAG_RESET_HITS = 1
 GFM_FLAG_CLEAR_HIST = 2
 GFM_FLAG_CALLER_ORDERS_REUSE = 4
 GFM_MAX_WIDTH = 64
+GFM_BEST_ROW_BITS = 44
+ABI_VERSION = 9
 RANGE = 1000
 
 c_int = ctypes.c_int
@@ -71,6 +73,11 @@ PROTOTYPES = {
                                 ctypes.c_uint32, c_void_p]),
     "gfm_select_hits_from": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p,
                                      c_void_p, c_i64, c_void_p, c_void_p]),
+    "gfm_region_ids": (c_int, [c_void_p, c_i32, c_i64, c_void_p, c_void_p]),
+    "gfm_region_best": (c_int, [c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p]),
+    "gfm_locus_max_workspace": (c_i64, [c_i64]),
+    "gfm_locus_max": (c_int, [c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p,
+                              c_i64, c_void_p, c_void_p]),
     "gfm_scan_host": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_int, c_int, c_i64, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, P(c_i64)]),
     "gfm_tsv_open": (c_int, [P(ctypes.c_char_p), c_int, c_int, c_int, c_int, P(c_void_p), P(c_i64)]),
@@ -166,7 +173,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if L.gfm_abi_version() != 8:
+        if L.gfm_abi_version() != ABI_VERSION:
             raise ImportError("libgrafimo_hip.so ABI version mismatch")
         _lib = L
     return _lib

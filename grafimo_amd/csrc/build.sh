@@ -19,12 +19,13 @@ for gm in 0:1 1:1 2:1 3:1 0:2 1:2 0:3 1:3; do
 done
 cc -c "$here/graph_extract.hip" -o "$here/graph_extract.o"
 cc -c "$here/stream_calib.hip" -o "$here/stream_calib.o"
+cc -c "$here/region_reduce.hip" -o "$here/region_reduce.o"
 cc -c "$here/tsv_ingest.cpp" -o "$here/tsv_ingest.o"
 cc -c "$here/vcf_ingest.cpp" -o "$here/vcf_ingest.o"
 cc -c "$here/scan_stream.cpp" -o "$here/scan_stream.o"
 cc -c "$here/gfm_workers.cpp" -o "$here/gfm_workers.o"
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$here/libgrafimo_hip.so" \
-    "$here/grafimo_hip.o" "${quad[@]}" "$here/graph_extract.o" "$here/stream_calib.o" "$here/tsv_ingest.o" \
+    "$here/grafimo_hip.o" "${quad[@]}" "$here/graph_extract.o" "$here/stream_calib.o" "$here/region_reduce.o" "$here/tsv_ingest.o" \
     "$here/vcf_ingest.o" "$here/scan_stream.o" "$here/gfm_workers.o" -lpthread -lz
 echo "built $here/libgrafimo_hip.so"

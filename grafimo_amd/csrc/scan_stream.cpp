@@ -237,6 +237,28 @@ struct ScanPool {
         }
         return &meta[k];
     }
+    // What a scan leaves behind is O(rows of the largest scan so far): one score block per chunk and motif on the device,
+    // one column block per chunk on the host.  Kept, they make the next scan of that size allocation-free; beyond these
+    // budgets the blocks of the highest chunk indices are given back when a scan closes (nothing of it is in flight then).
+    static constexpr size_t kKeepHostBytes = (size_t)1 << 30, kKeepDeviceBytes = (size_t)4 << 30;
+    void trim()
+    {
+        const size_t per_meta = (size_t)meta_rows * (3 * sizeof(int64_t) + sizeof(int32_t) + 2 + (size_t)meta_W) + 64;
+        while (!meta.empty() && meta.size() * per_meta > kKeepHostBytes) {
+            meta.back().release();
+            meta.pop_back();
+        }
+        size_t dev_bytes = 0;
+        for (auto &m : mb) dev_bytes += m.score_blocks.size() * (size_t)m.block_rows * sizeof(int32_t);
+        for (size_t j = mb.size(); j-- > 0 && dev_bytes > kKeepDeviceBytes;) {
+            MotifBufs &m = mb[j];
+            while (!m.score_blocks.empty() && dev_bytes > kKeepDeviceBytes) {
+                (void)hipFree(m.score_blocks.back());
+                m.score_blocks.pop_back();
+                dev_bytes -= (size_t)m.block_rows * sizeof(int32_t);
+            }
+        }
+    }
     void release()
     {
         for (int s = 0; s < kSlots; ++s) {
@@ -293,6 +315,7 @@ void release_pool(ScanPool *p)
 {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pool_mu);
+    p->trim();
     p->in_use = false;
 }
 
@@ -374,6 +397,20 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     ScanPool *P = nullptr;
     S_RC(acquire_pool(&P));
     sc->pool = P;                        // released by ~gfm_scan
+    // Any exit that is not the successful one leaves copies and score kernels of earlier chunks in flight: they still read
+    // the pool's pinned slots and add into the histograms (the caller's own buffers, possibly freed on the exception).
+    // Declared behind `guard` and before the crew: on the way out the workers are joined first, then the streams
+    // drained, then the pool goes back.
+    struct DrainOnFail {
+        ScanPool *p;
+        bool armed = true;
+        ~DrainOnFail()
+        {
+            if (!armed || !p) return;
+            (void)hipStreamSynchronize(p->copy);
+            (void)hipStreamSynchronize(p->score);
+        }
+    } drain{P};
     stamp("pool acquired");
     S_RC(P->reserve_slots((size_t)chunk_rows * (size_t)W + 16));
     S_RC(P->reserve_motifs(M));
@@ -417,7 +454,9 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     std::atomic<int> next_assign{0};         // files [0, next_assign) have their row offset
     std::mutex assign_mu;                    // try-lock: one worker at a time advances next_assign
     int64_t assigned_rows = 0;               // under assign_mu; final once next_assign == n_paths
-    std::atomic<int64_t> total_assigned{-1}; // == assigned_rows once every file is counted
+    // == assigned_rows once every file is counted; with no file at all that is now (a rank of a sharded scan whose
+    // shard is empty: nobody would ever set it, and the calling thread would poll for chunk 0 forever)
+    std::atomic<int64_t> total_assigned{n_paths == 0 ? 0 : -1};
     std::unique_ptr<std::atomic<char>[]> counted(new std::atomic<char>[(size_t)n_paths + 1]);
     for (int i = 0; i <= n_paths; ++i) counted[(size_t)i].store(0, std::memory_order_relaxed);
     std::vector<int64_t> file_off((size_t)n_paths, 0);
@@ -783,6 +822,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     sc->stats.parse_s = t_parse_end - t_begin;
     sc->stats.parse_threads = nt;
     *n_rows = total_rows;
+    drain.armed = false;
     guard.p = nullptr;
     *out = sc;
     return GFM_OK;

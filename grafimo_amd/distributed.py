@@ -140,7 +140,10 @@ class HipBackend(ScanBackend):
             device = dev
 
             def __init__(self):
-                self.hist = torch.zeros((len(dms), dms[0].L), dtype=torch.int64, device=dev)
+                # empty, not zeros: the library zeroes the buffers on ITS score stream before it adds into them; a fill
+                # on torch's current stream is ordered against neither and could land behind the first atomics
+                self.hist = torch.empty((len(dms), dms[0].L), dtype=torch.int64, device=dev)
+                torch.cuda.current_stream(dev).synchronize()     # (the allocator may hand out memory with work pending)
                 try:
                     self.scan = StreamScan(dms, files, no_reverse, threads, threshold, on_qvalue, want_qvalues,
                                            hists=[self.hist[j] for j in range(len(dms))], defer=True)
@@ -368,10 +371,11 @@ def _parse_threads(cores: int, world: int) -> int:
     return max(1, min(int(cores) if cores and cores > 0 else share, share))
 
 
-def _scan_width_sharded(motifs, files, width, args_obj, group, backend, debug):
+def _scan_width_sharded(motifs, files, width, args_obj, group, backend, debug, reduce=None):
     """One streamed pass per rank over its shard of `files` for `motifs` (one width); histogram all-reduce between
     the scoring phase and the tables; hit rows to rank 0 as packed columns.  -> (per-motif column dicts on rank 0
-    / None elsewhere, the merged REGION names on rank 0, rows scored over all ranks)."""
+    / None elsewhere, the merged REGION names on rank 0, rows scored over all ranks).  `reduce`: applied to every rank's
+    column dict before it travels (top_hits.compute_top_regions_sharded keeps one hit per region there)."""
     import torch
     dist = _dist()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -410,6 +414,8 @@ def _scan_width_sharded(motifs, files, width, args_obj, group, backend, debug):
                     kmers=np.asarray(h.kmers, dtype=np.uint8).reshape(len(h.rows), width))
         if not no_qvalue:
             cols["qvalue"] = np.asarray(h.qvalue, dtype=np.float64)
+        if reduce is not None:
+            cols = reduce(cols)
         got = gather_columns(cols, dev, group)
         if rank == 0:
             if world > 1:

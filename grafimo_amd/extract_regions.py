@@ -233,6 +233,66 @@ class GraphIndex:
             self._nodes = (cuts, first, site_of, ins_first)
         return self._nodes
 
+    def graph_nodes(self):
+        """The whole graph as `vg construct` lays it out: ({node id: sequence}, sorted [(from, to)] edges, [node ids of
+        the reference path]).  Pinned by vg's own files in the reference repository -- tests/test_data/expected_results/
+        expected.vg (SNPs) and the tutorial's x.xg / y.xg (one-base insertions and deletions) -- through
+        tests/test_vg_pins.py; used by nothing on the scoring path (node ids are column 7 of the TSV, which GRAFIMO's
+        scoring does not read)."""
+        cuts, first, site_of, ins_first = self._node_table()
+        ref = self.ref.tobytes().decode()
+        nodes: Dict[int, str] = {}
+        edges = set()
+        ref_path: List[int] = []
+        ins_behind: Dict[int, List[int]] = {}
+        for i in np.nonzero(self.ins_len > 0)[0].tolist():
+            ins_behind.setdefault(int(self.pos[i]) + 1, []).append(i)
+        heads: List[List[int]] = []          # per interval: the nodes a walk may enter it through / leave it through
+        tails: List[List[int]] = []
+        for j in range(len(cuts) - 1):
+            b, e = int(cuts[j]), int(cuts[j + 1])
+            i = int(site_of[j])
+            if i >= 0:
+                na = int(self.n_alts[i])
+                for a in range(na):
+                    nodes[int(first[j]) + a] = chr(int(self.alt_bases[i, a]))
+                nodes[int(first[j]) + na] = ref[b]
+                both = [int(first[j]) + a for a in range(na + 1)]
+                heads.append(both)
+                tails.append(both)
+                ref_path.append(int(first[j]) + na)
+            else:
+                k = -(-(e - b) // NODE_MAX)
+                ids = [int(first[j]) + t for t in range(k)]
+                for t, nid in enumerate(ids):
+                    nodes[nid] = ref[b + NODE_MAX * t:min(e, b + NODE_MAX * (t + 1))]
+                edges.update(zip(ids[:-1], ids[1:]))
+                heads.append(ids[:1])
+                tails.append(ids[-1:])
+                ref_path.extend(ids)
+        start_of = {int(c): j for j, c in enumerate(cuts[:-1])}
+        for j in range(len(cuts) - 2):
+            edges.update((u, v) for u in tails[j] for v in heads[j + 1])
+        for e, sites in ins_behind.items():
+            j = start_of.get(e)
+            for i in sites:
+                k = -(-int(self.ins_len[i]) // NODE_MAX)
+                seq = self.ins_bases[int(self.ins_off[i]):int(self.ins_off[i]) + int(self.ins_len[i])].tobytes().decode()
+                ids = [ins_first[i] + t for t in range(k)]
+                for t, nid in enumerate(ids):
+                    nodes[nid] = seq[NODE_MAX * t:NODE_MAX * (t + 1)]
+                edges.update(zip(ids[:-1], ids[1:]))
+                if j is not None and j > 0:
+                    edges.update((u, ids[0]) for u in tails[j - 1])
+                if j is not None:
+                    edges.update((ids[-1], v) for v in heads[j])
+        for i in np.nonzero(self.del_len > 0)[0].tolist():
+            a, ln = int(self.pos[i]), int(self.del_len[i])
+            ja, jb = start_of.get(a + 1), start_of.get(a + ln + 1)
+            if ja is not None and jb is not None and ja > 0:
+                edges.update((u, v) for u in tails[ja - 1] for v in heads[jb])
+        return nodes, sorted(edges), ref_path
+
     def _node_at(self, x: int, allele: int = 0) -> int:
         cuts, first, site_of, _ = self._node_table()
         j = int(np.searchsorted(cuts, x, side="right")) - 1

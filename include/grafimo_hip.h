@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFM_ABI_VERSION 8
+#define GFM_ABI_VERSION 9
 
 #define GFM_OK 0
 #define GFM_ERR_INVALID (-1)  /* bad argument (NULL, width out of range, ...)            */
@@ -209,6 +209,40 @@ int gfm_select_hits_from(gfm_motif_t m, const int32_t *d_scores, int64_t n, cons
                          int64_t row_base, const int64_t *d_cand_rows, int64_t cand_capacity,
                          const uint64_t *d_cand_count, int64_t *d_hit_rows, int64_t hit_capacity,
                          uint64_t *d_hit_count, void *stream);
+
+/* ------------------------------------------------------------------ strand-max and per-region best hit
+ * BASELINE.json north_star: "wavefront-level reductions for forward/reverse-strand max ... RCCL only for the final
+ * top-hit gather".  The reference has neither: every strand is a row of its own (score_sequences.py:279-321) and the
+ * report lists rows.  Its one consumer of "the best hit of a region" is --top-graphs, which takes the first N
+ * distinct sequence_names of the table sorted by p-value (res_writer.py:153-157) -- the regions ranked by their best
+ * reported hit.  These entry points compute that key on the device and NEVER change the reported rows;
+ * grafimo_amd/top_hits.py builds the top-regions table from them and, under torch.distributed, gathers
+ * n_regions entries per rank instead of every hit.
+ *
+ * Rows taking part: score >= max(min_score, *d_cutoff) (d_cutoff may be NULL; the q-value cutoff of gfm_qvalue_table
+ * lives on the device), a region id in [0, n_regions), and -- if d_freq is given -- d_freq[row] > 0 (the rows
+ * ResultTmp.to_df keeps without --recomb, resultsTmp.py:309-310).
+ *
+ * gfm_region_best: d_best[r] = max over the rows of region r of  (score << GFM_BEST_ROW_BITS) | (2^44 - 1 - row),
+ *   row = row_base + index: the best score, the lowest row among equals; 0 = no such row.  d_best is in/out
+ *   (atomic max: batches and chunks accumulate; the caller zeroes it).  d_region int32 [n], any order -- rows of one
+ *   region that are contiguous (TSV files, extraction rows) cost one atomic per wavefront instead of one per row.
+ * gfm_region_ids: the d_region array of rows laid out region after region, from d_region_off int64 [n_regions + 1]
+ *   (rows [off[r], off[r+1]) belong to region r): the TSV scan's files, row_base per file.
+ * gfm_locus_max: d_locus_max[i] = the best score among the rows of i's locus -- same region, same
+ *   {start, stop} as a set: the reference span of the k-mer whatever its strand ('-' rows carry start > stop,
+ *   score_sequences.py:288-291) -- i.e. the forward/reverse-strand maximum at that span; -1 for rows that take no part.
+ *   d_work: gfm_locus_max_workspace(n) bytes of scratch, 8-byte aligned; its first 8 bytes hold, afterwards, the number
+ *   of rows that found no table slot (0 unless the workspace was smaller than asked for).  Enqueue only. */
+#define GFM_BEST_ROW_BITS 44
+int gfm_region_ids(const int64_t *d_region_off, int32_t n_regions, int64_t n, int32_t *d_region_out, void *stream);
+int gfm_region_best(const int32_t *d_scores, int64_t n, const int32_t *d_region, int32_t n_regions,
+                    const int64_t *d_freq, int32_t min_score, const int32_t *d_cutoff, int64_t row_base,
+                    uint64_t *d_best, void *stream);
+int64_t gfm_locus_max_workspace(int64_t n_rows);
+int gfm_locus_max(const int32_t *d_scores, int64_t n, const int32_t *d_region, int32_t n_regions,
+                  const int64_t *d_start, const int64_t *d_stop, const int64_t *d_freq, int32_t min_score,
+                  const int32_t *d_cutoff, void *d_work, int64_t work_bytes, int32_t *d_locus_max, void *stream);
 
 /* ------------------------------------------------------------------ one-call host form
  * compute_results' numeric core (score_sequences.py:44-211) for host-resident k-mers:

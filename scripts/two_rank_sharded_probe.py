@@ -57,7 +57,11 @@ if __name__ == "__main__":
     from grafimo_amd.motif_ops import build_motif_meme_host
     m = build_motif_meme_host(os.path.join(ROOT, "tests/golden/ref_data/MA0139.1.meme"), "unfrm_dst", 0.1, False)[0]
     seqdir = tempfile.mkdtemp(prefix="gfm_two_rank_")
-    synth.write_tsv_dir(synth.make_batch(9, 1500, 19, np.asarray(m.count_matrix), synth.seed_for(3)), seqdir)
+    # `--files K`: K regions = K files (default 9); K = 1 leaves rank 1 with an EMPTY shard: its scan has no file at all
+    # (gfm_scan_tsv_begin with n_paths == 0 once polled for a chunk that never came) and its histogram still joins the
+    # all-reduce
+    n_files = int(sys.argv[sys.argv.index("--files") + 1]) if "--files" in sys.argv else 9
+    synth.write_tsv_dir(synth.make_batch(n_files, 1500, 19, np.asarray(m.count_matrix), synth.seed_for(3)), seqdir)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     out = os.path.join(seqdir, "mismatch.flag")

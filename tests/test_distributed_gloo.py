@@ -346,3 +346,65 @@ def test_same_width_set_shares_one_histogram_exchange(tmp_path):
         qs = np.concatenate([bucket[r][j][1] for r in range(2)])
         assert np.array_equal(rows, exp_rows) and len(rows) > 0
         np.testing.assert_allclose(qs, q[exp_rows], rtol=1e-12, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the top-hit-only gather (north_star: "RCCL ... only for the final top-hit gather"; grafimo_amd/top_hits.py)
+def _top_worker(rank, world, port, seqdir, kw, top_n, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import pickle
+    import torch.distributed as dist
+    from grafimo_amd import distributed as D
+    from grafimo_amd.motif import Motif
+    from grafimo_amd.top_hits import compute_top_regions_sharded
+    from grafimo_amd.workflow import Findmotif
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = _golden_ctcf()
+        m = Motif(np.array(g["probs"]), 19, ["A", "C", "G", "T"], g["motif_id"], g["motif_name"],
+                  {n: i for i, n in enumerate("ACGT")})
+        stats, moved = {}, []
+        real = D.gather_columns
+
+        def counting(cols, device, group=None):
+            if "rows" in cols:
+                moved.append(len(cols["rows"]))
+            return real(cols, device, group)
+        D.gather_columns = counting
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                top = compute_top_regions_sharded(m, seqdir, True, Findmotif(**kw), top_graphs=top_n,
+                                                  backend=_make_backend(g), stats=stats)
+                full = D.compute_results_sharded(m, seqdir, True, Findmotif(**kw), backend=_make_backend(g))
+        finally:
+            D.gather_columns = real
+        with open(os.path.join(outdir, f"top{rank}.pkl"), "wb") as fh:
+            pickle.dump(dict(top=top, full=full, stats=stats, moved=moved), fh)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kw", [dict(threshold=5e-2), dict(threshold=0.5, qval_t=True, recomb=True)])
+def test_two_ranks_gather_one_hit_per_region_for_the_top_regions(tsv_dir, tmp_path, kw):
+    """Every rank keeps the best reported hit of each of its regions and only those travel: the table rank 0 builds
+    equals the first-row-per-region of the full sharded report (what --top-graphs walks, res_writer.py:153-157), and
+    the rows gathered are at most one per region per rank instead of every hit."""
+    import pickle
+    import torch.multiprocessing as mp
+    from grafimo_amd.top_hits import top_regions, top_regions_table
+    top_n = 4
+    mp.spawn(_top_worker, args=(2, _free_port(), tsv_dir, kw, top_n, str(tmp_path)), nprocs=2, join=True)
+    parts = [pickle.load(open(tmp_path / f"top{r}.pkl", "rb")) for r in range(2)]
+    top, full = parts[0]["top"], parts[0]["full"]
+    assert parts[1]["top"] is None and parts[1]["full"] is None
+    want = top_regions_table(full, top_n)
+    assert len(top) == len(want) == top_n and list(top.columns) == list(full.columns)
+    for c in full.columns:       # ties in p-value can only come from equal scores: compare as sets of rows per column
+        assert (top[c].astype(str) == want[c].astype(str)).all(), c
+    assert list(top["sequence_name"]) == top_regions(full, top_n)
+    for p in parts:
+        # first gather = the reduced one (one row per region of this rank), second = the full report's
+        assert p["moved"][0] == p["stats"]["sent"] <= 7 and p["moved"][1] == p["stats"]["hits"]
+        assert p["stats"]["sent"] < p["stats"]["hits"]
+    assert sum(p["stats"]["sent"] for p in parts) == full["sequence_name"].nunique()

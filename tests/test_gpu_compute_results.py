@@ -569,6 +569,35 @@ def test_two_ranks_on_one_gpu_through_the_sharded_entry_points():
     assert r.stdout.count("two ranks == one process: True") == 9
 
 
+@pytest.mark.timeout(120)
+def test_streamed_scan_without_any_file_returns_an_empty_scan(golden_motifs):
+    """gfm_scan_tsv_begin with n_paths == 0 -- the shard of a rank when there are more ranks than files -- returns an
+    empty scan instead of waiting for a first chunk that never comes."""
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.score_sequences import StreamScan
+    dm = DeviceMotif.from_motif(_ctcf(True))
+    for on_q, want_q in ((False, True), (True, True), (False, False)):
+        hist = torch.full((dm.L,), 7, dtype=torch.int64, device="cuda:0") if want_q else None
+        scan = StreamScan(dm, [], False, 4, 1e-3, on_q, want_q, hists=[hist] if want_q else None)
+        assert scan.n == 0 and scan.hits[0].n_hits == 0 and scan.names == []
+        if want_q:
+            assert int(hist.abs().sum().item()) == 0        # the caller's histogram was zeroed: it joins an all-reduce
+    dm.close()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_one_file_leaves_a_rank_without_files():
+    """two processes, ONE TSV file: rank 1 runs the streamed scan over nothing and still takes part in the histogram
+    all-reduce and the gathers (scripts/two_rank_sharded_probe.py --files 1)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "two_rank_sharded_probe.py"), "--files", "1"],
+                       capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert r.stdout.count("two ranks == one process: True") == 9
+
+
 def test_kept_motif_handles(golden_motifs):
     """DeviceMotif.lease / release: the entry points that run once per motif and once more per chromosome keep their
     handle -- same numbers, same handle; other numbers, another; a plain handle is untouched by it; drop_kept() destroys
