@@ -305,9 +305,11 @@ def e2e_block(tmp, n_expected, W, dm):
 # ---------------------------------------------------------------------------- extraction (N = 1)
 def extract_block(ctcf, dev, n_regions=10_000):
     """The extraction kernels (what replaces `vg find -K`) on a synthetic graph at config-2 scale:
-    10 000 regions x 200 bp, one site per ~32 bp of which 6 % deletions, 5096 haplotypes; W = 19.  emit_ms = the emit
-    kernels of one plan (HIP events around gfm_graph_emit, averaged over 10 calls); extract_plus_score_ms = the
-    product entry point compute_results_from_graph (extraction -> scoring -> table of hits) on the same graph."""
+    10 000 regions x 200 bp, one site per ~32 bp of which 6 % deletions, 5096 haplotypes; W = 19.  fused_ms = the
+    kernels of gfm_graph_score (every walk scored on both strands where it is enumerated; HIP events, 10 calls);
+    extract_plus_score_ms = the product entry point compute_results_from_graph (fused extraction + scoring -> q-table ->
+    columns of the hit rows -> table) on the same graph; emit_ms = the materialising emit kernels of one plan, kept for
+    write_region_tsvs."""
     import torch
     from grafimo_amd import _native as nv
     from grafimo_amd import synth
@@ -337,24 +339,57 @@ def extract_block(ctcf, dev, n_regions=10_000):
     emit_ms = ev0.elapsed_time(ev1) / reps
     out_bytes = n * (W + 8 + 8 + 1 + 8 + 1 + 4 + 4)     # k-mer + start, stop, strand, freq, is_ref, region, walk
     args_obj = Findmotif(cores=1, threshold=1e-4)
-    runs = []
+    # ---- the fused path (the product's default): gfm_graph_score alone (HIP events: tile ticket reset, the two score
+    # kernels, the slab reduction), then the entry point as a caller sees it -- regions as an [n, 2] array, the way a caller
+    # that scans motif after motif over one BED file holds them
+    from grafimo_amd.device import DeviceMotif
+    dm = DeviceMotif.lease(ctcf)
+    reg = np.asarray(regions, dtype=np.int64)
+    starts, stops = np.ascontiguousarray(reg[:, 0]), np.ascontiguousarray(reg[:, 1])
+    hist = torch.zeros(dm.L, dtype=torch.int64, device=dev)
+    cut = dm.pvalue_cutoff(1e-4)
+    for _ in range(3):
+        g.score(dm, starts, stops, cut, hist=hist)
+    torch.cuda.synchronize(dev)
+    ev0.record()
+    for _ in range(reps):
+        g.score(dm, starts, stops, cut, hist=hist)
+    ev1.record()
+    torch.cuda.synchronize(dev)
+    fused_ms = ev0.elapsed_time(ev1) / reps
+    fused_rows = int(g.fused_results()[1])
+    dm.release()
+    runs, runs_rows = [], []
     hits = 0
     with contextlib.redirect_stdout(io.StringIO()):
-        for _ in range(4):
+        for _ in range(12):
             t = time.perf_counter()
-            df = compute_results_from_graph(ctcf, g, regions, False, args_obj)
+            df = compute_results_from_graph(ctcf, g, reg, False, args_obj)
             runs.append(time.perf_counter() - t)
             hits = len(df)
+        for _ in range(4):
+            t = time.perf_counter()
+            df_m = compute_results_from_graph(ctcf, g, regions, False, args_obj, fused=False)
+            runs_rows.append(time.perf_counter() - t)
+    same = len(df_m) == len(df) and bool((df_m["matched_sequence"].to_numpy() == df["matched_sequence"].to_numpy()).all()) \
+        and bool((df_m["start"].to_numpy() == df["start"].to_numpy()).all()) \
+        and bool((df_m["haplotype_frequency"].to_numpy() == df["haplotype_frequency"].to_numpy()).all())
     g.close()
+    e2e = 1e3 * float(np.median(runs[2:]))
     return {
         "regions": n_regions, "region_bp": 200, "width": W, "sites": int(len(idx.pos)),
         "deletions": int((idx.del_len > 0).sum()), "haplotypes": idx.n_haplotypes, "rows": int(n),
+        "fused_ms": fused_ms, "rows_per_s_fused": fused_rows / (fused_ms * 1e-3),
+        "extract_plus_score_ms": e2e, "rows_per_s_extract_plus_score": n / (e2e * 1e-3), "hits_p1e-4": int(hits),
+        "fused_equals_materialised": same,
         "emit_ms": emit_ms, "rows_per_s_emit": n / (emit_ms * 1e-3),
         "written_bytes": int(out_bytes), "written_GBps": out_bytes / (emit_ms * 1e-3) / 1e9,
         "frac": out_bytes / (emit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
         "plan_plus_emit_wall_ms": 1e3 * float(np.median(walls[1:])),
-        "extract_plus_score_ms": 1e3 * float(np.median(runs[1:])), "hits_p1e-4": int(hits),
-        "path": "gfm_graph_plan + gfm_graph_emit; compute_results_from_graph (extraction -> score kernel -> table)",
+        "extract_plus_score_materialised_ms": 1e3 * float(np.median(runs_rows[1:])),
+        "path": "compute_results_from_graph = gfm_graph_score (walks scored where they are enumerated: no row reaches HBM) + "
+                "q-table + gfm_graph_annotate (columns of the hit rows only) -> table; fused_ms = gfm_graph_score alone; "
+                "emit_ms / written_GBps / frac = the materialising gfm_graph_emit kept for write_region_tsvs",
     }
 
 

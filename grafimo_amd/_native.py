@@ -27,6 +27,7 @@ GFM_FLAG_CLEAR_HIST = 2
 GFM_FLAG_CALLER_ORDERS_REUSE = 4
 GFM_MAX_WIDTH = 64
 GFM_BEST_ROW_BITS = 44
+GFM_GRAPH_FORWARD_ONLY = 1
 ABI_VERSION = 9
 RANGE = 1000
 
@@ -103,6 +104,9 @@ PROTOTYPES = {
     "gfm_graph_destroy": (None, [c_void_p]),
     "gfm_graph_plan": (c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_i32, P(c_i64), P(c_i64)]),
     "gfm_graph_emit": (c_int, [c_void_p] * 10),
+    "gfm_graph_score": (c_int, [c_void_p, c_void_p, c_i32, c_void_p, c_void_p, ctypes.c_uint32, c_i32, c_void_p, c_void_p, c_i64,
+                                c_void_p, c_void_p, c_void_p, P(c_i64), c_void_p]),
+    "gfm_graph_annotate": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfm_vcf_open": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_int, c_int, P(c_void_p), P(c_i64), P(c_i32),
                              P(c_i64)]),
     "gfm_vcf_read": (c_int, [c_void_p] * 6),

@@ -391,6 +391,26 @@ bool plan_group(const gfm_motif_t *motifs, int n_left, const bool *with_hist, in
 // --------------------------------------------------------------------------------------- API
 extern "C" __attribute__((visibility("hidden"))) void gfm_set_error_(const char *msg) { g_err = msg ? msg : ""; }
 
+// What the fused extraction -> scoring kernels of graph_extract.hip need of a motif (inside the library only): the score
+// matrix as the caller gave it (rows A, C, G, T), the score a k-mer holding N gets, the reachable range, and the
+// `max_bins` consecutive scores that hold the most background probability (where an LDS histogram window goes).
+extern "C" __attribute__((visibility("hidden"))) int gfm_motif_view_(gfm_motif_t m, int max_bins, const int64_t **sm, int *W,
+                                                                     int *min_val, int *L, int *win_lo, int *win_nb,
+                                                                     int *device, int *n_cu)
+{
+    if (!m) return fail(GFM_ERR_INVALID, "motif is NULL");
+    const gfm_motif::Window w = best_window(m, std::max(1, std::min(max_bins, m->nb)));
+    *sm = m->sm.data();
+    *W = m->W;
+    *min_val = m->min_val;
+    *L = m->L;
+    *win_lo = w.lo;
+    *win_nb = w.bins;
+    *device = m->device;
+    *n_cu = m->n_cu;
+    return GFM_OK;
+}
+
 GFM_API int gfm_abi_version(void) { return GFM_ABI_VERSION; }
 GFM_API const char *gfm_last_error(void) { return g_err.c_str(); }
 

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <new>
 #include <string>
 #include <vector>
@@ -160,7 +161,7 @@ struct CachedSites {
     }
 };
 
-template <class V, class S>
+template <class V, class S, long long MaxWalks = kMaxWalksPerWindow>
 __device__ inline int simulate(const GraphDev &g, const S &sites, long long p, int W, int i0, const WalkStart &ws, int prefix,
                                WalkState &st, V &vis, long long q, long long rem, long long &prod, long long limit)
 {
@@ -213,7 +214,7 @@ __device__ inline int simulate(const GraphDev &g, const S &sites, long long p, i
         if (snp >= 0) {
             nall = 1 + snp_alts;
             prod *= nall;
-            if (prod > kMaxWalksPerWindow) { st.nd = d; return WALK_OVERFLOW; }
+            if (prod > MaxWalks) { st.nd = d; return WALK_OVERFLOW; }
             if constexpr (V::kWantsBases) {
                 rem /= nall;
                 a = (int)((q / rem) % nall);
@@ -1080,6 +1081,8 @@ graph_del_scatter_kernel(long long n_del_walks, int W, int pitch, const uint8_t 
     is_ref[row] = is_ref[row + 1] = flag;
 }
 
+#include "gfm_graph_fused.hpp"
+
 // `pad` bytes are allocated (and zeroed) behind the array: see load_u64
 template <typename T> hipError_t upload(T **dst, const T *src, size_t count, size_t pad = 0)
 {
@@ -1153,6 +1156,19 @@ struct gfm_graph {
     hipStream_t side = nullptr;          // the plain walks' kernels run here when there are deletion walks, beside the plain walks' (gfm_graph_emit)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool emit_pending = false;
+    // ---- fused extraction -> scoring (gfm_graph_score / gfm_graph_annotate)
+    std::vector<int> h_pos;              // host copy of the site positions: the tiles' first sites are found here
+    std::vector<long long> f_starts, f_stops;   // the regions the device tile table was built for (reused while they repeat)
+    int f_width = 0, f_n_tiles = 0;
+    long long f_n_windows = 0;
+    Buf<Tile> f_tiles;
+    Tile *h_tiles = nullptr;             // pinned staging of the tile table
+    size_t h_tiles_cap = 0;
+    hipEvent_t ev_tiles = nullptr;       // the staging has been copied
+    bool tiles_pending = false;
+    Buf<DelWin> f_del_wins;
+    Buf<unsigned> f_slabs;
+    Buf<int> f_flags;                    // [0] tile ticket, [1] listed windows, [2] overflow
     void drop_plan()
     {
         region_off.release(); first_start.release(); region_stop.release(); walk_base.release(); win_start.release(); walks.release();
@@ -1247,6 +1263,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
         gfm_graph_destroy(g);
         return gfail(GFM_ERR_HIP, std::string("graph upload failed: ") + hipGetErrorString(e));
     }
+    g->h_pos.assign(h_pos, h_pos + n_sites);
     g->dev = GraphDev{g->d_site_rec, g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
                       bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0,
                       g->d_del_len, n_dels, g->d_prev_del, g->d_max_reach, g->d_ins_len, g->d_ins_off, g->d_ins_bases,
@@ -1260,6 +1277,11 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_tiles, hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_score_del_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
         gfm_graph_destroy(g);
         return gfail(GFM_ERR_HIP, std::string("event creation failed: ") + hipGetErrorString(e));
@@ -1307,6 +1329,9 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     if (g->ev_join) (void)hipEventDestroy(g->ev_join);
     if (g->side) (void)hipStreamDestroy(g->side);
     if (g->h_back) (void)hipHostFree(g->h_back);
+    if (g->ev_tiles) (void)hipEventDestroy(g->ev_tiles);
+    if (g->h_tiles) (void)hipHostFree(g->h_tiles);
+    g->f_tiles.release(); g->f_del_wins.release(); g->f_slabs.release(); g->f_flags.release();
     delete g;
 }
 
@@ -1514,5 +1539,177 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
     GX_TRY(hipGetLastError());
     GX_TRY(hipEventRecord(g->ev_emitted, static_cast<hipStream_t>(stream)));
     g->emit_pending = true;
+    return GFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------- fused path
+extern "C" int gfm_motif_view_(gfm_motif_t m, int max_bins, const int64_t **sm, int *W, int *min_val, int *L, int *win_lo,
+                               int *win_nb, int *device, int *n_cu);
+
+namespace {
+constexpr int kFusedMaxBins = 16384;     // LDS histogram window of the fused kernels (64 KiB); scores outside it spill
+
+// first site at or behind `target`, searched from a hint (tiles come in ascending order: a step or two)
+int site_lower_bound(const std::vector<int> &pos, int hint, long long target)
+{
+    const int n = (int)pos.size();
+    if (hint > n) hint = n;
+    if (hint > 0 && (long long)pos[(size_t)hint - 1] >= target) hint = 0;        // the hint lies behind: start over
+    int step = 1, lo = hint, hi = hint;
+    while (hi < n && (long long)pos[(size_t)hi] < target) { lo = hi + 1; hi += step; step <<= 1; }
+    if (hi > n) hi = n;
+    return (int)(std::lower_bound(pos.begin() + lo, pos.begin() + hi, target, [](int a, long long b) { return (long long)a < b; }) -
+                 pos.begin());
+}
+}  // namespace
+
+GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, const int64_t *h_starts, const int64_t *h_stops,
+                            uint32_t flags, int32_t select_cutoff, uint64_t *d_hist, void *d_hits, int64_t hit_capacity,
+                            uint64_t *d_hit_count, uint64_t *d_n_rows, int32_t *d_overflow, int64_t *n_windows, void *stream)
+{
+    if (!g || !m || n_regions < 0 || (n_regions && (!h_starts || !h_stops))) return gfail(GFM_ERR_INVALID, "bad argument");
+    if (!d_hit_count || !d_n_rows || hit_capacity < 0 || (hit_capacity && !d_hits))
+        return gfail(GFM_ERR_INVALID, "NULL device buffer");
+    const int64_t *sm = nullptr;
+    int W = 0, min_val = 0, L = 0, hlo = 0, hnb = 0, mdev = 0, n_cu = 256;
+    {
+        const int rc = gfm_motif_view_(m, kFusedMaxBins, &sm, &W, &min_val, &L, &hlo, &hnb, &mdev, &n_cu);
+        if (rc) return rc;
+    }
+    {
+        int dev = -1;
+        GX_TRY(hipGetDevice(&dev));
+        if (dev != mdev) return gfail(GFM_ERR_INVALID, "the motif lives on another device than the current one");
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // ---- the tile table: rebuilt only when the regions or the width change (GRAFIMO scans the same BED regions motif after
+    // motif, grafimo.py:177-183)
+    const size_t nr = (size_t)n_regions;
+    const bool same = g->f_width == W && g->f_starts.size() == nr &&
+                      (nr == 0 || (std::memcmp(g->f_starts.data(), h_starts, nr * sizeof(long long)) == 0 &&
+                                   std::memcmp(g->f_stops.data(), h_stops, nr * sizeof(long long)) == 0));
+    if (!same) {
+        if (g->tiles_pending) {          // the staging buffer may still be read by the last copy
+            GX_TRY(hipEventSynchronize(g->ev_tiles));
+            g->tiles_pending = false;
+        }
+        const long long tail = g->dev.n_ins > 0 ? 1 : W;
+        size_t n_tiles = 0;
+        for (int r = 0; r < n_regions; ++r) {
+            const long long s = std::max<long long>(h_starts[r], 0), e = std::min<long long>(h_stops[r], g->dev.ref_len);
+            const long long nw = std::max<long long>(0, e - tail - s + 1);
+            n_tiles += (size_t)((nw + kFusedThreads - 1) / kFusedThreads);
+        }
+        if (n_tiles > 0x7fffffffull) return gfail(GFM_ERR_INVALID, "too many windows in one call (split the regions)");
+        if (n_tiles > g->h_tiles_cap) {
+            if (g->h_tiles) (void)hipHostFree(g->h_tiles);
+            g->h_tiles = nullptr;
+            g->h_tiles_cap = 0;
+            GX_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_tiles), sizeof(Tile) * (n_tiles + 1), hipHostMallocDefault));
+            g->h_tiles_cap = n_tiles;
+        }
+        long long w_base = 0;
+        size_t ti = 0;
+        int hint_lo = 0, hint_hi = 0;
+        for (int r = 0; r < n_regions; ++r) {
+            const long long s = std::max<long long>(h_starts[r], 0), e = std::min<long long>(h_stops[r], g->dev.ref_len);
+            const long long nw = std::max<long long>(0, e - tail - s + 1);
+            for (long long off = 0; off < nw; off += kFusedThreads) {
+                Tile &t = g->h_tiles[ti++];
+                t.p0 = s + off;
+                t.limit = e;
+                t.n_win = (int)std::min<long long>(kFusedThreads, nw - off);
+                t.region = r;
+                t.i_lo = hint_lo = site_lower_bound(g->h_pos, hint_lo, t.p0 - 1);
+                t.i_hi = hint_hi = site_lower_bound(g->h_pos, std::max(hint_hi, hint_lo), t.p0 + t.n_win - 1 + W);
+                t.w_base = (int)w_base;
+                t.pad = 0;
+                w_base += t.n_win;
+                if (w_base > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "too many windows in one call (split the regions)");
+            }
+        }
+        GX_TRY(g->f_tiles.reserve(n_tiles + 1));
+        if (n_tiles) {
+            GX_TRY(hipMemcpyAsync(g->f_tiles.p, g->h_tiles, sizeof(Tile) * n_tiles, hipMemcpyHostToDevice, st));
+            GX_TRY(hipEventRecord(g->ev_tiles, st));
+            g->tiles_pending = true;
+        }
+        g->f_starts.assign(h_starts, h_starts + nr);
+        g->f_stops.assign(h_stops, h_stops + nr);
+        g->f_width = W;
+        g->f_n_tiles = (int)n_tiles;
+        g->f_n_windows = w_base;
+    }
+    if (n_windows) *n_windows = g->f_n_windows;
+    if (g->f_n_tiles == 0) return GFM_OK;
+    const int g1 = std::min(g->f_n_tiles, 2 * n_cu), g2 = n_cu;
+    const bool with_hist = d_hist != nullptr;
+    if (!with_hist) hnb = 0;
+    GX_TRY(g->f_del_wins.reserve((size_t)g->f_n_windows + 1));
+    GX_TRY(g->f_slabs.reserve((size_t)(g1 + g2) * (size_t)(hnb + 1) + 1));
+    GX_TRY(g->f_flags.reserve(4));
+    GX_TRY(hipMemsetAsync(g->f_flags.p, 0, 4 * sizeof(int), st));
+    FusedTab tab{};
+    {
+        static const int row_of_code[4] = {0, 1, 3, 2};       // code 2 = T (row 3), code 3 = G (row 2)
+        for (int j = 0; j < W; ++j)
+            for (int c = 0; c < 4; ++c) {
+                const unsigned fwd = (unsigned)sm[(size_t)row_of_code[c] * W + j];
+                const unsigned rc = (unsigned)sm[(size_t)row_of_code[c ^ 2] * W + (W - 1 - j)];   // comp: A <-> T, C <-> G
+                tab.v[j * 8 + c] = fwd | (rc << 16);
+            }
+    }
+    FusedArgs a{};
+    a.W = W;
+    a.forward_only = (flags & GFM_GRAPH_FORWARD_ONLY) ? 1 : 0;
+    a.min_val = min_val;
+    a.cutoff = select_cutoff;
+    a.hlo = hlo;
+    a.hnb = hnb;
+    a.hist = reinterpret_cast<unsigned long long *>(d_hist);
+    a.slabs = g->f_slabs.p;
+    a.hits = static_cast<GraphHit *>(d_hits);
+    a.hit_cap = hit_capacity;
+    a.hit_count = reinterpret_cast<unsigned long long *>(d_hit_count);
+    a.n_rows = reinterpret_cast<unsigned long long *>(d_n_rows);
+    a.ticket = reinterpret_cast<unsigned *>(g->f_flags.p);
+    const size_t hist_bytes = with_hist ? sizeof(unsigned) * (size_t)(hnb + 1) : 0;
+    const size_t lds1 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(SiteRec) * kFusedSites + kFusedRefBytes +
+                        kFusedThreads * (sizeof(long long) + 4 * sizeof(int)) + 4 * sizeof(long long) + 4 * sizeof(int) + hist_bytes;
+    hipLaunchKernelGGL(graph_score_kernel, dim3((unsigned)g1), dim3(kFusedThreads), lds1, st, g->dev, a, tab, g->f_tiles.p,
+                       g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2);
+    int pitch = ((W + 3) / 4) * 4;
+    if ((pitch / 4) % 2 == 0) pitch += 4;             // an odd dword pitch: the threads' slots fall on all LDS banks
+    const size_t lds2 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(SiteRec) * kSiteCache * kFusedDelThreads +
+                        sizeof(FusedLayout) * kFusedDelThreads * kFusedLayouts + sizeof(long long) * (kFusedDelThreads + 2) +
+                        sizeof(int) * kFusedDelThreads + sizeof(int) * (size_t)kFusedDelThreads * W +
+                        (size_t)kFusedDelThreads * pitch + hist_bytes;
+    FusedArgs a2 = a;
+    a2.slabs = g->f_slabs.p + (size_t)g1 * (size_t)(hnb + 1);
+    if (g->dev.n_dels > 0 || g->dev.n_ins > 0)
+        hipLaunchKernelGGL(graph_score_del_kernel, dim3((unsigned)g2), dim3(kFusedDelThreads), lds2, st, g->dev, a2, tab,
+                           g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, pitch);
+    if (with_hist)
+        hipLaunchKernelGGL(graph_hist_reduce_kernel, dim3((unsigned)((hnb + 1 + 255) / 256)), dim3(256), 0, st, g->f_slabs.p,
+                           (g->dev.n_dels > 0 || g->dev.n_ins > 0) ? g1 + g2 : g1, hlo, hnb, min_val,
+                           reinterpret_cast<unsigned long long *>(d_hist));
+    GX_TRY(hipGetLastError());
+    if (d_overflow) GX_TRY(hipMemcpyAsync(d_overflow, g->f_flags.p + 2, sizeof(int), hipMemcpyDeviceToDevice, st));
+    return GFM_OK;
+}
+
+GFM_API int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t *d_hit_count, int64_t hit_capacity,
+                               const int32_t *d_cutoff, const double *d_qtable, void *d_records, void *stream)
+{
+    if (!g) return gfail(GFM_ERR_INVALID, "graph is NULL");
+    if (hit_capacity <= 0 || g->f_n_tiles == 0) return GFM_OK;
+    if (!d_hits || !d_hit_count || !d_records) return gfail(GFM_ERR_INVALID, "NULL device buffer");
+    static_assert(sizeof(HitRec) == sizeof(gfm_graph_hit_t) && sizeof(GraphHit) == 16, "record layouts of the C ABI");
+    const unsigned blocks = (unsigned)((hit_capacity + 63) / 64);
+    hipLaunchKernelGGL(graph_annotate_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), g->dev,
+                       g->d_allele_count, g->f_width, g->f_tiles.p, g->f_n_tiles, static_cast<const GraphHit *>(d_hits),
+                       reinterpret_cast<const unsigned long long *>(d_hit_count), (long long)hit_capacity, d_cutoff, d_qtable,
+                       static_cast<HitRec *>(d_records));
+    GX_TRY(hipGetLastError());
     return GFM_OK;
 }

@@ -138,6 +138,14 @@ class DeviceMotif:
         nv.check(nv.lib().gfm_motif_annotate(self._h, nv.ptr(s), len(s), nv.ptr(lo), nv.ptr(pv)))
         return lo, pv
 
+    def fused_workspace(self, device):
+        """int64 [2 L + 2] on `device`, kept with the handle: score histogram | q-table (viewed as f64) | cutoff, row count
+        -- what one compute_results_from_graph call needs beside the graphs' own buffers (no allocation per call)."""
+        w = getattr(self, "_fused_ws", None)
+        if w is None or w.device != device:
+            w = self._fused_ws = _torch().zeros(2 * self.L + 2, dtype=_torch().int64, device=device)
+        return w
+
     # ---- device-pointer entry points (torch tensors as buffers)
     def score(self, kmers, scores, hist=None, select_cutoff=None, row_base=0, hit_rows=None,
               hit_count=None, stream=None, reset_hits=False, tail_stream=None):

@@ -467,6 +467,26 @@ class GraphIndex:
         return self.nodes_of(self.walk_bases(p, width, walk))
 
 
+# most hit rows one call brings back to the host (120 bytes each, and a report row each)
+MAX_HITS = int(os.environ.get("GRAFIMO_MAX_HITS", 1 << 23))
+
+# gfm_graph_hit_t (include/grafimo_hip.h): one record per hit row of the fused path
+HIT_DTYPE = np.dtype([("start", "<i8"), ("stop", "<i8"), ("freq", "<i8"), ("q2", "<i8"), ("qvalue", "<f8"), ("w", "<i4"),
+                      ("score", "<i4"), ("region", "<i4"), ("strand", "u1"), ("is_ref", "u1"), ("keep", "u1"), ("pad", "u1"),
+                      ("kmer", "u1", (nv.GFM_MAX_WIDTH,))])
+assert HIT_DTYPE.itemsize == 120
+
+
+def _region_arrays(regions):
+    """[(S, E)] or an [n, 2] array -> (starts int64[n], stops int64[n])"""
+    if isinstance(regions, np.ndarray):              # [n, 2]: no Python loop over the regions
+        se = np.asarray(regions, dtype=np.int64).reshape(-1, 2)
+        return np.ascontiguousarray(se[:, 0]), np.ascontiguousarray(se[:, 1])
+    # (two list comprehensions beat np.asarray on a list of tuples)
+    return (np.ascontiguousarray([r[0] for r in regions], dtype=np.int64),
+            np.ascontiguousarray([r[1] for r in regions], dtype=np.int64))
+
+
 class ExtractedKmers:
     """Device-resident rows of one extraction (torch tensors on the graph's device)."""
 
@@ -511,15 +531,54 @@ class DeviceGraph:
         except Exception:
             pass
 
+    # ---- extraction fused into scoring (gfm_graph_score / gfm_graph_annotate)
+    def fused_buffers(self, cap: int):
+        """One int64 tensor per graph, kept between calls: [16 control words | cap entries of 2 words | cap records of 15
+        words].  Control: [0] hit count, [1] rows scored, [2] overflow flag (int32)."""
+        torch = _torch()
+        buf = getattr(self, "_fused_buf", None)
+        if buf is None or self._fused_cap < cap:
+            self._fused_cap = int(cap)
+            self._fused_buf = buf = torch.empty(16 + 17 * self._fused_cap, dtype=torch.int64, device=self.device)
+        return buf, self._fused_cap
+
+    def score(self, dm, starts: np.ndarray, stops: np.ndarray, cutoff: int, hist=None, forward_only: bool = False,
+              cap: int = 1 << 14, stream=None):
+        """gfm_graph_score over the regions: every walk of every window scored on both strands against `dm`; the rows'
+        score histogram added to `hist` (torch int64 [L] or None), the rows with score >= cutoff left as entries in
+        this graph's buffer (fused_buffers).  Enqueue only.  -> number of windows."""
+        buf, cap = self.fused_buffers(cap)
+        buf[:16].zero_()
+        base = buf.data_ptr()
+        nw = ctypes.c_int64()
+        nv.check(nv.lib().gfm_graph_score(self._h, dm.handle, len(starts), nv.ptr(starts), nv.ptr(stops),
+                                          nv.GFM_GRAPH_FORWARD_ONLY if forward_only else 0, int(cutoff),
+                                          hist.data_ptr() if hist is not None else None, base + 128, cap, base, base + 8,
+                                          base + 16, ctypes.byref(nw), _stream_ptr(stream)))
+        return int(nw.value)
+
+    def annotate(self, cutoff=None, qtable=None, stream=None):
+        """gfm_graph_annotate: the records of the entries the last score() left (cutoff: device int32 [1] or None)."""
+        buf, cap = self.fused_buffers(0)
+        base = buf.data_ptr()
+        nv.check(nv.lib().gfm_graph_annotate(self._h, base + 128, base, cap, cutoff.data_ptr() if cutoff is not None else None,
+                                             qtable.data_ptr() if qtable is not None else None, base + 128 + 16 * cap,
+                                             _stream_ptr(stream)))
+
+    def fused_results(self, guess: int = 1024):
+        """(hit count, rows scored, overflow flag, records as a numpy structured array) of the last score() + annotate();
+        synchronises.  One copy when the hits fit `guess` entries' worth of a prefix, two otherwise."""
+        buf, cap = self.fused_buffers(0)
+        ctl = buf[:16].cpu().numpy()
+        count, n_rows, over = int(ctl[0]), int(ctl[1]), int(ctl[2] & 0xffffffff)
+        k = min(count, cap)
+        recs = buf[16 + 2 * cap:16 + 2 * cap + 15 * k].cpu().numpy().view(HIT_DTYPE) if k else np.empty(0, dtype=HIT_DTYPE)
+        return count, n_rows, over, recs
+
     def extract(self, regions: Sequence[Tuple[int, int]], width: int, stream=None) -> ExtractedKmers:
         """All rows of `vg find -p chrom:S-E -K width -E -H` for the given (S, E) regions."""
         torch = _torch()
-        if isinstance(regions, np.ndarray):              # [n, 2]: no Python loop over the regions
-            se = np.asarray(regions, dtype=np.int64).reshape(-1, 2)
-            starts, stops = np.ascontiguousarray(se[:, 0]), np.ascontiguousarray(se[:, 1])
-        else:                                            # (two list comprehensions beat np.asarray on a list of tuples)
-            starts = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
-            stops = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+        starts, stops = _region_arrays(regions)
         nw, nr = ctypes.c_int64(), ctypes.c_int64()
         with torch.cuda.device(self.device):
             rc = nv.lib().gfm_graph_plan(self._h, len(regions), nv.ptr(starts), nv.ptr(stops), int(width),
@@ -759,9 +818,150 @@ def scan_graph(widths: Set[int], args_obj, debug: bool) -> str:
 
 
 def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_obj, group=None,
-                               always_collective: bool = False) -> Optional[pd.DataFrame]:
-    """extract_regions.scan_graph + score_sequences.compute_results in one device pipeline: the rows go
-    from the extraction kernel to the score kernel in HBM; only the hits and their metadata come back.
+                               always_collective: bool = False, fused: bool = True) -> Optional[pd.DataFrame]:
+    """extract_regions.scan_graph + score_sequences.compute_results as ONE device pass: every walk of every window of
+    the regions is scored on both strands where it is enumerated (gfm_graph_score) -- no row of `vg find -K` is ever
+    written, neither as TSV (extract_regions.py:180,225) nor as a device matrix; what leaves the kernels is the score
+    histogram of all rows (the q-values are computed over all of them, score_sequences.py:194-198) and one entry per row
+    under the threshold, whose columns -- coordinates, haplotype count, vg's ref flag, the bases -- gfm_graph_annotate
+    then derives for those rows only.  The table equals the one of the materialising path (`fused=False`:
+    gfm_graph_plan + gfm_graph_emit + the score kernel over the rows), row for row.
+    `graph` / `regions`: one DeviceGraph with its [(S, E)] list (or an [n, 2] array), or lists of both (one entry per
+    chromosome) -- the q-values are computed over the rows of all of them, like the reference does over all TSV files of
+    a motif.
+    Under torch.distributed (one process per GPU, every rank calls this with the same arguments and its own replica of
+    the graphs) the regions are split over the ranks, the score histogram is all-reduced so that q-values stay global,
+    and rank 0 returns the merged table (the others None)."""
+    if not fused:
+        return compute_results_from_graph_rows(motif, graph, regions, debug, args_obj, group, always_collective)
+    from .resultsTmp import build_frame_sorted
+    from .score_sequences import print_scoring_msg
+    torch = _torch()
+    many = isinstance(graph, (list, tuple))
+    graphs = list(graph) if many else [graph]
+    spans = [_region_arrays(r) for r in (regions if many else [regions])]
+    dist = torch.distributed
+    live = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if live else 1
+    rank = dist.get_rank(group) if live else 0
+    collective = world > 1 or (always_collective and live)
+    if world > 1:                                    # contiguous shard of the flattened (graph, region) list
+        from .distributed import shard_bounds
+        sizes = [len(s_) for s_, _ in spans]
+        lo_, hi_ = shard_bounds(sum(sizes), world, rank)
+        at = 0
+        for gi, n_ in enumerate(sizes):
+            a_, b_ = min(max(lo_ - at, 0), n_), min(max(hi_ - at, 0), n_)
+            spans[gi] = (spans[gi][0][a_:b_], spans[gi][1][a_:b_])
+            at += n_
+    threshold = float(args_obj.threshold)
+    no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
+    no_reverse, recomb = bool(args_obj.noreverse), bool(args_obj.recomb)
+    if rank == 0:
+        print_scoring_msg(motif, no_reverse, debug)
+    W = motif.width
+    dev = graphs[0].device
+    dm = DeviceMotif.lease(motif)            # a kept handle when this motif was scored before (device.py)
+    try:
+        cut_p = dm.pvalue_cutoff(threshold)
+        work = dm.fused_workspace(dev) if not no_qvalue else None     # [L hist | L q-table | cutoff, nrows]: kept per handle
+        L = dm.L
+        cap = max(getattr(g, "_fused_cap", 0) for g in graphs) or (1 << 14)
+        while True:
+            hist = qtable = d_cut = None
+            if work is not None:
+                hist, qtable, d_cut = work[:L], work[L:2 * L].view(torch.float64), work[2 * L:2 * L + 1].view(torch.int32)[:1]
+                hist.zero_()
+            for g, (s_, e_) in zip(graphs, spans):
+                g.score(dm, s_, e_, cut_p, hist=hist, forward_only=no_reverse, cap=cap)
+            if collective and hist is not None:
+                dist.all_reduce(hist, group=group)           # the one data-path exchange: BH ranks are global
+            if hist is not None:
+                dm.qvalue_table(hist, threshold, qval_t, qtable, d_cut, None)
+            for g in graphs:
+                g.annotate(cutoff=d_cut if qval_t else None, qtable=qtable)
+            got = [g.fused_results() for g in graphs]
+            # a hit list that turned out too short is taken again at the size the counters ask for -- on EVERY rank or
+            # on none: the scoring pass holds a collective (ADVICE r3: a rank-local retry would leave the ranks' all-reduce
+            # sequences out of step)
+            need = max([c for c, _, _, _ in got] + [0])
+            if collective:
+                t_need = torch.tensor([need], dtype=torch.int64, device=dev)
+                dist.all_reduce(t_need, op=dist.ReduceOp.MAX, group=group)
+                need = int(t_need.item())
+            if need <= cap:
+                break
+            if need > MAX_HITS:
+                # every hit becomes a 120-byte record on the host and a row of the report: refuse before the host's memory
+                # does (a threshold near 1 over windows with many variant sites reports every allele combination)
+                raise nv.NativeError(nv.GFM_ERR_OVERFLOW,
+                                     f"{need} rows pass the threshold {threshold}: more than GRAFIMO_MAX_HITS = {MAX_HITS}; "
+                                     f"use a stricter threshold or raise the limit")
+            cap = need + need // 4 + 1024
+    finally:
+        dm.release()
+    if any(o for _, _, o, _ in got):
+        raise nv.NativeError(nv.GFM_ERR_OVERFLOW, f"a window of width {W} holds more than 2^40 walks through its variant sites")
+    n_rows = sum(n for _, n, _, _ in got)
+    n_global = n_rows
+    if collective:
+        tot = torch.tensor([n_rows], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, group=group)
+        n_global = int(tot.item())
+    if n_global == 0:
+        errmsg = "No result retrieved. Unable to proceed.\n"
+        errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
+        exception_handler(ValueError, errmsg, debug)
+    if not no_qvalue and rank == 0:
+        print("\nComputing q-values...\n")
+    if rank == 0:
+        print(f"Scanned sequences:\t{n_global}")
+        print(f"Scanned nucleotides:\t{n_global * W}")
+    # ---- the hit rows in the row order of the materialising path: graph, window, walk, strand
+    parts = []
+    for gi, (_, _, _, recs) in enumerate(got):
+        recs = recs[recs["keep"] != 0]
+        order = np.lexsort((recs["q2"], recs["w"]))
+        parts.append((gi, recs[order]))
+    seqnames: List[str] = []
+    for gi, recs in parts:
+        c, (s_, e_) = graphs[gi].index.chrom, spans[gi]
+        reg = recs["region"]
+        seqnames.extend([f"{c}:{a}-{b}" for a, b in zip(s_[reg].tolist(), e_[reg].tolist())])
+    recs = np.concatenate([r for _, r in parts]) if len(parts) > 1 else parts[0][1]
+    lo, pv = dm_annotate_host(motif, dm, recs["score"])
+    cols = dict(start=recs["start"], stop=recs["stop"], strand=recs["strand"], logodds=lo, pvalue=pv,
+                kmers=np.ascontiguousarray(recs["kmer"][:, :W]), freq=recs["freq"], is_ref=recs["is_ref"])
+    if not no_qvalue:
+        cols["qvalue"] = recs["qvalue"]
+    if world > 1:      # packed columns to rank 0 (one tensor gather), the hit rows' region labels beside them
+        from .distributed import gather_columns, gather_names
+        got_c = gather_columns(cols, dev, group)
+        label_lists = gather_names(seqnames, dev, group)
+        if rank != 0:
+            return None
+        cols = got_c
+        seqnames = [x for lst in label_lists for x in lst]
+    k = cols["kmers"]
+    return build_frame_sorted(
+        motif, seqnames=np.array(seqnames, dtype=object), starts=cols["start"], stops=cols["stop"],
+        strands=np.where(cols["strand"] == ord("+"), "+", "-").astype(object),
+        scores=cols["logodds"], pvalues=cols["pvalue"], qvalues=None if no_qvalue else cols["qvalue"],
+        seqs=np.ascontiguousarray(k).view(f"S{W}").ravel().astype("U").astype(object) if len(k) else np.empty(0, dtype=object),
+        frequencies=cols["freq"],
+        # vg flags a walk over a deletion `ref`; GRAFIMO repairs that on ingest (score_sequences.py:305-307)
+        references=np.where((cols["is_ref"] != 0) & (np.abs(cols["stop"] - cols["start"]) == W), "ref", "non.ref").astype(object),
+        recomb=recomb)
+
+
+def dm_annotate_host(motif, dm, scaled):
+    return dm.annotate(np.ascontiguousarray(scaled, dtype=np.int32))
+
+
+def compute_results_from_graph_rows(motif: Motif, graph, regions, debug: bool, args_obj, group=None,
+                                    always_collective: bool = False) -> Optional[pd.DataFrame]:
+    """The MATERIALISING form of compute_results_from_graph (its `fused=False`): the rows go from the extraction kernels
+    to the score kernel as a device matrix with their columns beside them; only the hits and their metadata come back.
     `graph` / `regions`: one DeviceGraph with its [(S, E)] list, or lists of both (one entry per
     chromosome) -- the q-values are computed over the rows of all of them, like the reference does over
     all TSV files of a motif.
@@ -826,7 +1026,9 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
         # (their metadata lives on this rank) and travel as finished table rows below
         # one batch: one slot; the hit list starts at a sixteenth of the rows (a full-size list is 8 bytes per row of
         # allocation and zeroing for nothing) and is taken again at full size in the rare case it does not hold
-        cap = max(4096, n // 16)
+        # (with a process group the scanner's enqueue holds an all-reduce: a retry that only SOME ranks make would leave
+        # their collective sequences out of step -- there the list is full-size from the start)
+        cap = max(n, 1) if (world > 1 or always_collective) else max(4096, n // 16)
         while True:
             sc = KmerScanner(dm, max(n, 1), hit_capacity=cap, device=kmers.device, side_stream=False, group=group,
                              always_collective=always_collective, n_slots=1)

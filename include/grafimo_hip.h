@@ -338,11 +338,12 @@ void gfm_scan_release_buffers(void);
 /* ------------------------------------------------------------------ k-mer extraction
  * Replaces the rows of `vg find -p CHR:S-E -x XG -H GBWT -K W -E` (extract_regions.py:180,225,326;
  * consumed by score_sequences.py:273-307) for graphs made of a linear reference plus SNP sites
- * and deletions (the inputs of `vg construct -r REF -v VCF`, constructVG.py:332).  Rows are written on the device
+ * insertions and deletions (the inputs of `vg construct -r REF -v VCF`, constructVG.py:332).  Rows are written on the device
  * in the layout gfm_score_kmers reads, so extraction -> scoring needs no TSV.  Pinned by the
  * reference's expected_seqs.tsv and by the 704 rows of real vg output in its scoring fixture
- * (oracle/extract_oracle.py lists what is not pinned: insertions and other records -- they are not part
- * of the graph).
+ * (SNPs, deletions, node ids and cuts also by vg's own node tables: tests/test_vg_pins.py).  Insertions, multi-base
+ * substitutions and complex alleles are part of the graph too; oracle/extract_oracle.py states what no vg output pins
+ * about them (coordinates of k-mers that start or end inside inserted bases, row order).
  *
  * gfm_graph_create: h_ref [ref_len] bases; sites ascending 0-based h_pos [n_sites], h_n_alts [n_sites]
  *   in 1..3, h_alt_bases [n_sites][3]; h_del_len [n_sites] (or NULL): 0 for a SNP, else the site is a
@@ -378,6 +379,47 @@ int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_starts, co
                    int32_t width, int64_t *n_windows, int64_t *n_rows);
 int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, int64_t *d_stop, uint8_t *d_strand,
                    int64_t *d_freq, uint8_t *d_is_ref, int32_t *d_region, int32_t *d_walk, void *stream);
+
+/* ------------------------------------------------------------------ extraction fused into scoring
+ * The join `extract_seqs -> score_seq` of the hot path without its intermediate: the reference writes every row of
+ * `vg find -K W -E` to a TSV (extract_regions.py:180,225) and score_seqs reads them all back (score_sequences.py:273-321),
+ * although only the rows under the threshold are ever reported (resultsTmp.py:303-310).  gfm_graph_score walks the
+ * windows of the regions, scores both strands of every walk against the motif and keeps: the score histogram of ALL rows
+ * (q-values are computed over all of them, score_sequences.py:194-198), the number of rows, and one 16-byte entry per row
+ * with score >= select_cutoff.  gfm_graph_annotate then produces, for those entries only, the columns a TSV row would
+ * have carried -- k-mer, start, stop, strand, haplotype count, vg's ref flag, region -- identical to what
+ * gfm_graph_plan + gfm_graph_emit + gfm_score_kmers give for the same rows.
+ *
+ * gfm_graph_score: regions as gfm_graph_plan takes them; the motif's width is the k-mer width.
+ *   flags: GFM_GRAPH_FORWARD_ONLY = skip the '-' rows before they are scored or counted (--no-reverse, :281-282).
+ *   d_hist uint64 [L] in/out or NULL (+= rows per score); select_cutoff as gfm_score_kmers (GFM_NO_SELECT: no hits);
+ *   d_hits gfm_graph_entry_t [hit_capacity], appended from *d_hit_count on (entries beyond the capacity are counted,
+ *   not stored; the caller zeroes the counter); *d_n_rows += rows scored; *d_overflow (optional) = 1 if a window holds
+ *   more than 2^40 walks (its rows are left out); *n_windows (host, optional) = windows of the call.  Entry order is
+ *   arbitrary; sorted by (w, q2) it is the row order of gfm_graph_emit.  Enqueue only (the first call for a set of
+ *   regions builds and uploads their tile table; later calls with the same regions and width reuse it).
+ * gfm_graph_annotate: for entry i < min(*d_hit_count, hit_capacity) the record d_records[i] of the LAST gfm_graph_score
+ *   call on this handle; d_cutoff (device, optional): entries with score < *d_cutoff get keep = 0 and no columns (the
+ *   p < t candidates of a --qvalueT scan that the q-value cutoff drops: q >= p); d_qtable (device, optional): the
+ *   q-value of the entry's score.  Enqueue only. */
+#define GFM_GRAPH_FORWARD_ONLY 1u
+typedef struct gfm_graph_entry {
+    int32_t w;          /* window of the call: regions in order, window starts ascending */
+    int32_t score;      /* scaled score */
+    int64_t q2;         /* walk of the window * 2 + strand (0 '+', 1 '-') */
+} gfm_graph_entry_t;
+typedef struct gfm_graph_hit {
+    int64_t start, stop, freq, q2;
+    double qvalue;
+    int32_t w, score, region;
+    uint8_t strand, is_ref, keep, pad;
+    uint8_t kmer[GFM_MAX_WIDTH];
+} gfm_graph_hit_t;
+int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, const int64_t *h_starts, const int64_t *h_stops,
+                    uint32_t flags, int32_t select_cutoff, uint64_t *d_hist, void *d_hits, int64_t hit_capacity,
+                    uint64_t *d_hit_count, uint64_t *d_n_rows, int32_t *d_overflow, int64_t *n_windows, void *stream);
+int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t *d_hit_count, int64_t hit_capacity,
+                       const int32_t *d_cutoff, const double *d_qtable, void *d_records, void *stream);
 
 /* Phased VCF (plain or gzip/bgzip) -> the site arrays of gfm_graph_create for one chromosome; host
  * threads parse the lines.  The reference hands the VCF to `vg construct` / `vg index -G`

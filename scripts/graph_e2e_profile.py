@@ -11,6 +11,7 @@ idx, regions = synth.make_graph_index(10_000, 19)
 g = DeviceGraph(idx, dev)
 wf = Findmotif(cores=1, threshold=1e-4)
 with contextlib.redirect_stdout(io.StringIO()):
+    regions = np.asarray(regions, dtype=np.int64)
     for _ in range(3): compute_results_from_graph(ctcf, g, regions, False, wf)
     pr = cProfile.Profile(); pr.enable()
     for _ in range(20): compute_results_from_graph(ctcf, g, regions, False, wf)
