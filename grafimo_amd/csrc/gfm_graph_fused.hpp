@@ -9,13 +9,13 @@
 // the reference computes over ALL rows) and one 16-byte entry per hit.  graph_annotate_kernel then re-derives the
 // columns -- coordinates, vg's ref flag, the bases, the haplotype count -- for the hit rows only.
 //
-// Work decomposition: the host cuts the regions into TILES of <= 256 consecutive window starts (one region each) and
-// finds each tile's first site; a persistent grid of workgroups takes tiles by ticket.  Per tile everything the
-// windows read -- site records (with their alternate bases packed in), the reference bases -- is staged in LDS by
+// Work decomposition: the host cuts the regions into TILES of <= 64 consecutive window starts (one region each) and
+// finds each tile's first site; a persistent grid deals the tiles round-robin, one WAVEFRONT per tile.  Per tile everything
+// the windows read -- site records (with their alternate bases packed in), the reference bases -- is staged in LDS by
 // coalesced loads ONCE; the materialising kernels found the same things through a chain of four dependent global round
-// trips per wave.  Phase 1, thread per window: first site, number of walks, the reference window's score on both
+// trips per wave.  Phase 1, lane per window: first site, number of walks, the reference window's score on both
 // strands (a walk differs from it at its alternate alleles only); windows that touch an insertion / deletion are
-// listed for graph_score_del_kernel.  Block scan of the walk counts.  Phase 2, thread per walk: the mixed-radix
+// listed for graph_score_del_kernel.  Wave scan of the walk counts.  Phase 2, lane per walk: the mixed-radix
 // digits of its rank, the score adjusted per alternate allele, histogram in an LDS window, hits appended.
 //
 // Scores: one LDS table of packed entries tab[j][code] = sm[code][j] | sm[comp(code)][W-1-j] << 16 (code =
@@ -25,14 +25,18 @@
 // exact modulo 2^32 as long as the final halves are, which they are: they are scores.
 
 struct FusedTab { unsigned v[GFM_MAX_WIDTH * 8]; };
-struct GraphHit { int w, score; long long q2; };      // window of the call, scaled score, walk * 2 + strand (0 '+', 1 '-')
+// an entry of the hit list (gfm_graph_entry_t, opaque to the caller): where the walk is -- tile of the call, window of
+// the tile (bits 56..63 of q2k), walk * 2 + strand (bits 0..55) -- and its scaled score
+struct GraphHit { int tile, score; long long q2k; };
+constexpr int kHitWinShift = 56;
+constexpr long long kHitWalkMask = (1ll << kHitWinShift) - 1;
 struct Tile {
     long long p0, limit;      // first window start, end of the region (a walk must end inside it)
     int n_win, region;        // windows p0 .. p0 + n_win - 1
     int i_lo, i_hi;           // sites [i_lo, i_hi): pos >= p0 - 1 ... pos < p0 + n_win - 1 + W
     int w_base, pad;          // index of the tile's first window among the call's windows
 };
-struct DelWin { long long p, limit; int w, i0, region, pad; };   // a listed window for graph_score_del_kernel
+struct DelWin { int tile, k, i0, pad; };   // a listed window for graph_score_del_kernel: window k of the tile, its first site
 struct HitRec {               // what graph_annotate_kernel writes per hit (120 bytes; numpy dtype in extract_regions.py)
     long long start, stop, freq, q2;
     double qvalue;
@@ -42,17 +46,19 @@ struct HitRec {               // what graph_annotate_kernel writes per hit (120 
 };
 
 constexpr long long kFusedMaxWalks = 1ll << 40;      // per window; beyond it the product of allele counts is refused
-constexpr int kFusedThreads = 256;                   // = windows per tile
-constexpr int kFusedSites = 448;                     // site records staged per tile (more: read from global memory)
-constexpr int kFusedRefBytes = kFusedThreads + GFM_MAX_WIDTH + 8;
-constexpr int kFusedDelThreads = 128;
-constexpr int kFusedLayouts = 8;
+constexpr int kTileWin = 64;                         // windows per tile = lanes of the wavefront that works on it
+constexpr int kFusedWaves = 8;                       // wavefronts per workgroup of graph_score_kernel (they share the histogram)
+constexpr int kFusedThreads = kTileWin * kFusedWaves;
+constexpr int kWaveSites = 96;                       // site records staged per tile (more: read from global memory)
+constexpr int kWaveRefBytes = 144;                   // kTileWin + GFM_MAX_WIDTH - 1 reference bytes, in 8-byte loads
+constexpr int kFusedDelThreads = 64;
+constexpr int kFusedLayouts = 4;
 
 struct FusedArgs {
     int W, forward_only;
     int min_val, cutoff;          // cutoff: rows with score >= cutoff are hits (INT32_MAX: none)
     int hlo, hnb;                 // LDS histogram window [hlo, hlo + hnb) + one bin for min_val; hnb = 0: no histogram
-    unsigned long long *hist;     // [L] spill target (scores outside the window) or nullptr
+    unsigned long long *hist;     // [L]: spill target of the window / where graph_score_del_kernel books; or nullptr
     unsigned *slabs;              // [gridDim.x][hnb + 1]
     GraphHit *hits;
     long long hit_cap;
@@ -84,18 +90,18 @@ struct TileSites {
 };
 
 // hits of one wave: one returning atomic per wave that holds any (a p < 1e-4 scan: a few hundred per plan)
-__device__ __forceinline__ void push_hits(const FusedArgs &a, bool hit, int w, long long q2, int score)
+__device__ __forceinline__ void push_hits(const FusedArgs &a, bool hit, int tile, int k, long long q2, int score)
 {
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
     if (mask == 0ull) return;
     const int lane = threadIdx.x & 63;
+    const int leader = __builtin_ctzll(mask);
     unsigned long long base = 0;
-    if (lane == __builtin_ctzll(mask)) base = atomicAdd(a.hit_count, (unsigned long long)__popcll(mask));
-    base = ((unsigned long long)__shfl((int)(base >> 32), __builtin_ctzll(mask)) << 32) |
-           (unsigned)__shfl((int)(base & 0xffffffffull), __builtin_ctzll(mask));
+    if (lane == leader) base = atomicAdd(a.hit_count, (unsigned long long)__popcll(mask));
+    base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader) << 32) | (unsigned)__shfl((int)(base & 0xffffffffull), leader);
     if (hit) {
         const unsigned long long at = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-        if (at < (unsigned long long)a.hit_cap) a.hits[at] = GraphHit{w, score, q2};
+        if (at < (unsigned long long)a.hit_cap) a.hits[at] = GraphHit{tile, score, q2 | ((long long)k << kHitWinShift)};
     }
 }
 
@@ -144,50 +150,65 @@ __device__ __forceinline__ WinInfo classify_window(const GraphDev &g, const S &s
     return w;
 }
 
+// what one wavefront keeps in LDS: of the tile it works on, and the listed windows it has found and not yet handed on
+constexpr int kWaveQueue = 128;
+struct WaveLds {
+    SiteRec rec[kWaveSites];
+    long long incl[kTileWin];
+    int i0[kTileWin], ns[kTileWin], bad[kTileWin];
+    unsigned score[kTileWin];
+    DelWin queue[kWaveQueue];
+    unsigned char ref[kWaveRefBytes];
+};
+
+// Persistent grid; every WAVEFRONT works on tiles (64 consecutive window starts of one region) on its own -- no workgroup
+// barrier inside the loop, so the sixteen wavefronts of a CU are at sixteen different points of their tiles and cover
+// each other's latencies (a first version with a 256-window tile per workgroup and five barriers per tile took 163 us
+// for the bench's 3 million walks: every tile was a serial chain of ticket -> tile record -> staging loads -> phase 1 ->
+// scan -> phase 2).  Tiles are dealt round-robin over the wavefronts of the grid -- and NOTHING in the loop is an atomic
+// on one global word per tile: one word sustains ~88 atomics per microsecond, so a ticket per tile (34 000 of them) made
+// this kernel 469 us, and one append per tile to the list of listed windows would cost 110 us more.  Listed windows
+// are queued per wavefront in LDS and handed on 64 and more at a time; what is left at the end, and the row counts,
+// leave once per workgroup.  What the wavefronts of a workgroup share is the LDS table and the histogram window.
 __global__ void __launch_bounds__(kFusedThreads)
 graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__restrict__ tiles, int n_tiles,
                    DelWin *__restrict__ del_wins, int *__restrict__ del_count, int *__restrict__ overflow)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
-    // LDS: table | site records | reference bytes | per-window arrays | block scalars | histogram window
     unsigned *tab = reinterpret_cast<unsigned *>(fused_lds);
-    SiteRec *s_rec = reinterpret_cast<SiteRec *>(tab + GFM_MAX_WIDTH * 8);
-    unsigned char *s_ref = reinterpret_cast<unsigned char *>(s_rec + kFusedSites);
-    long long *w_incl = reinterpret_cast<long long *>(s_ref + kFusedRefBytes);
-    int *w_i0 = reinterpret_cast<int *>(w_incl + kFusedThreads);
-    int *w_ns = w_i0 + kFusedThreads;
-    unsigned *w_score = reinterpret_cast<unsigned *>(w_ns + kFusedThreads);
-    int *w_bad = reinterpret_cast<int *>(w_score + kFusedThreads);
-    long long *wave_tot = reinterpret_cast<long long *>(w_bad + kFusedThreads);     // [4]
-    int *blk = reinterpret_cast<int *>(wave_tot + 4);                               // [0] tile, [1] del base, [2] del count
-    unsigned *h = reinterpret_cast<unsigned *>(blk + 4);
+    WaveLds *wl = reinterpret_cast<WaveLds *>(tab + GFM_MAX_WIDTH * 8) + (threadIdx.x >> 6);
+    unsigned long long *blk_rows = reinterpret_cast<unsigned long long *>(reinterpret_cast<WaveLds *>(tab + GFM_MAX_WIDTH * 8) + kFusedWaves);
+    int *blk_q = reinterpret_cast<int *>(blk_rows + kFusedWaves);         // [kFusedWaves] queue lengths, [kFusedWaves] = base
+    unsigned *h = reinterpret_cast<unsigned *>(blk_q + kFusedWaves + 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int W = a.W;
     for (int i = tid; i < W * 8; i += kFusedThreads) tab[i] = tab_arg.v[i];
     for (int i = tid; i <= a.hnb && a.hnb > 0; i += kFusedThreads) h[i] = 0u;
+    __syncthreads();
     unsigned long long rows_done = 0;
-    for (;;) {
-        __syncthreads();                       // everybody is done with the previous tile's LDS
-        if (tid == 0) { blk[0] = (int)atomicAdd(a.ticket, 1u); blk[2] = 0; }
-        __syncthreads();
-        const int ti = blk[0];
-        if (ti >= n_tiles) break;
+    int q_n = 0;                                                   // listed windows in this wavefront's queue (uniform)
+    const int stride = (int)gridDim.x * kFusedWaves;
+    for (int ti = (int)blockIdx.x * kFusedWaves + wave; ti < n_tiles; ti += stride) {
         const Tile t = tiles[ti];
-        const int staged = min(t.i_hi - t.i_lo + 1, kFusedSites);      // (+1: the record that ends a window's site scan)
-        for (int i = tid; i < staged; i += kFusedThreads) s_rec[i] = packed_site(g, t.i_lo + i);
-        {
-            const long long span = min((long long)t.n_win + W - 1, g.ref_len - t.p0);
-            for (int i = tid; i < kFusedRefBytes; i += kFusedThreads)
-                s_ref[i] = i < span ? g.ref[t.p0 + i] : (unsigned char)'N';
+        const int staged = min(t.i_hi - t.i_lo + 1, kWaveSites);      // (+1: the record that ends a window's site scan)
+        for (int i = lane; i < staged; i += 64) wl->rec[i] = packed_site(g, t.i_lo + i);
+        if (lane < kWaveRefBytes / 8) {
+            const long long at = t.p0 + 8 * lane;
+            unsigned long long v = 0x4e4e4e4e4e4e4e4eull;                      // 'N's behind the reference's end
+            if (at + 8 <= g.ref_len + (long long)kReadPad) v = load_u64(g.ref + at);
+            if (at + 8 > g.ref_len)
+                for (int b = 0; b < 8; ++b)
+                    if (at + b >= g.ref_len) v = (v & ~(0xffull << (8 * b))) | (0x4eull << (8 * b));
+            *reinterpret_cast<unsigned long long *>(wl->ref + 8 * lane) = v;
         }
-        __syncthreads();
-        const TileSites sites{g, s_rec, t.i_lo, staged};
-        // ---- phase 1: thread per window
+        __builtin_amdgcn_wave_barrier();
+        const TileSites sites{g, wl->rec, t.i_lo, staged};
+        // ---- phase 1: lane per window
         long long walks = 0;
         bool listed = false;
         WinInfo wi{0, 0, 0, false};
-        const long long p = t.p0 + tid;
-        if (tid < t.n_win) {
+        const long long p = t.p0 + lane;
+        if (lane < t.n_win) {
             wi = classify_window(g, sites, p, W, t.limit, t.i_lo, t.i_hi);
             listed = wi.listed;
             if (wi.walks < 0) { atomicMax(overflow, 1); wi.walks = 0; }
@@ -196,72 +217,69 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 unsigned sum = 0;
                 int bad = 0;
                 for (int j = 0; j < W; ++j) {
-                    const unsigned c = base_code(s_ref[tid + j]);
+                    const unsigned c = base_code(wl->ref[lane + j]);
                     sum += tab[j * 8 + c];
                     bad += (int)(c >> 2);
                 }
-                w_score[tid] = sum;
-                w_bad[tid] = bad;
+                wl->score[lane] = sum;
+                wl->bad[lane] = bad;
             }
-            w_i0[tid] = wi.i0;
-            w_ns[tid] = wi.ns;
+            wl->i0[lane] = wi.i0;
+            wl->ns[lane] = wi.ns;
         }
-        // listed windows -> graph_score_del_kernel (one global atomic per tile)
+        // listed windows -> this wavefront's queue; 64 and more of them go to graph_score_del_kernel's list at once
         {
             const unsigned long long lm = __builtin_amdgcn_ballot_w64(listed);
-            int at = 0;
             if (lm) {
-                if (lane == 0) at = atomicAdd(&blk[2], __popcll(lm));
-                at = __shfl(at, 0) + __popcll(lm & ((1ull << lane) - 1ull));
+                if (listed) wl->queue[q_n + __popcll(lm & ((1ull << lane) - 1ull))] = DelWin{ti, lane, wi.i0, 0};
+                q_n += __popcll(lm);
+                if (q_n >= kTileWin) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(del_count, q_n);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    __builtin_amdgcn_wave_barrier();
+                    for (int i = lane; i < q_n; i += 64) del_wins[base + i] = wl->queue[i];
+                    q_n = 0;
+                }
             }
-            __syncthreads();
-            if (tid == 0 && blk[2] > 0) blk[1] = atomicAdd(del_count, blk[2]);
-            __syncthreads();
-            if (listed) del_wins[blk[1] + at] = DelWin{p, t.limit, t.w_base + tid, wi.i0, t.region, 0};
         }
-        // inclusive scan of the walk counts over the block
+        // inclusive scan of the walk counts over the wave
         long long incl = walks;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int lo_ = __shfl_up((int)(incl & 0xffffffffll), d), hi_ = __shfl_up((int)(incl >> 32), d);
             if (lane >= d) incl += ((long long)hi_ << 32) | (unsigned)lo_;
         }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        long long before = 0, total = 0;
-        for (int k = 0; k < kFusedThreads / 64; ++k) {
-            if (k < wave) before += wave_tot[k];
-            total += wave_tot[k];
-        }
-        w_incl[tid] = incl + before;
-        __syncthreads();
-        // ---- phase 2: thread per walk
-        for (long long base = 0; base < total; base += kFusedThreads) {
-            const long long wt = base + tid;
+        wl->incl[lane] = incl;
+        const long long total = ((long long)__shfl((int)(incl >> 32), 63) << 32) | (unsigned)__shfl((int)(incl & 0xffffffffll), 63);
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 2: lane per walk
+        for (long long base = 0; base < total; base += 64) {
+            const long long wt = base + lane;
             const bool live = wt < total;
             int k = 0;
             long long q = 0;
             int s_f = 0, s_r = 0;
             if (live) {
-                int lo = 0, hi = t.n_win - 1;                  // first window whose inclusive count exceeds wt
+                int lo = 0, hi = kTileWin - 1;                 // first window whose inclusive count exceeds wt
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    if (w_incl[mid] > wt) hi = mid; else lo = mid + 1;
+                    if (wl->incl[mid] > wt) hi = mid; else lo = mid + 1;
                 }
                 k = lo;
-                q = wt - (k ? w_incl[k - 1] : 0ll);
-                unsigned sum = w_score[k];
-                int bad = w_bad[k];
+                q = wt - (k ? wl->incl[k - 1] : 0ll);
+                unsigned sum = wl->score[k];
+                int bad = wl->bad[k];
                 long long rest = q;
-                const int i0 = w_i0[k];
-                for (int s = w_ns[k] - 1; s >= 0 && rest; --s) {          // digits, last site first
+                const int i0 = wl->i0[k];
+                for (int s = wl->ns[k] - 1; s >= 0 && rest; --s) {        // digits, last site first
                     const SiteRec r = sites.at(i0 + s);
                     const int nall = 1 + (r.n_alts & 3);
                     const int al = (int)(rest % nall);
                     rest /= nall;
                     if (al) {
                         const int j = r.pos - (int)(t.p0 + k);
-                        const unsigned cr = base_code(s_ref[k + j]), ca = base_code((unsigned)r.n_alts >> (8 * al));
+                        const unsigned cr = base_code(wl->ref[k + j]), ca = base_code((unsigned)r.n_alts >> (8 * al));
                         sum += tab[j * 8 + ca] - tab[j * 8 + cr];
                         bad += (int)(ca >> 2) - (int)(cr >> 2);
                     }
@@ -273,15 +291,30 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                     if (!a.forward_only) book_score(a, h, s_r);
                 }
             }
-            push_hits(a, live && s_f >= a.cutoff, t.w_base + k, 2 * q, s_f);
-            if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, t.w_base + k, 2 * q + 1, s_r);
+            push_hits(a, live && s_f >= a.cutoff, ti, k, 2 * q, s_f);
+            if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, ti, k, 2 * q + 1, s_r);
         }
-        if (tid == 0) rows_done += (unsigned long long)total * (a.forward_only ? 1ull : 2ull);
+        rows_done += (unsigned long long)total * (a.forward_only ? 1ull : 2ull);
+        __builtin_amdgcn_wave_barrier();       // the tile's LDS is free again
+    }
+    // once per workgroup: the rows scored, what is left in the wavefronts' queues, the histogram slab
+    if (lane == 0) { blk_rows[wave] = rows_done; blk_q[wave] = q_n; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long rows = 0;
+        int left = 0;
+        for (int k = 0; k < kFusedWaves; ++k) { rows += blk_rows[k]; left += blk_q[k]; }
+        if (rows) atomicAdd(a.n_rows, rows);
+        blk_q[kFusedWaves] = left ? atomicAdd(del_count, left) : 0;
     }
     __syncthreads();
+    {
+        int at = blk_q[kFusedWaves];
+        for (int k = 0; k < wave; ++k) at += blk_q[k];
+        for (int i = lane; i < q_n; i += 64) del_wins[at + i] = wl->queue[i];
+    }
     if (a.hnb > 0)
         for (int i = tid; i <= a.hnb; i += kFusedThreads) a.slabs[(size_t)blockIdx.x * (a.hnb + 1) + i] = h[i];
-    if (tid == 0 && rows_done) atomicAdd(a.n_rows, rows_done);
 }
 
 // visitor of simulate(): the bases of a walk into a k-mer slot (alternate / inserted bases at once, reference bases
@@ -302,47 +335,51 @@ struct ScoreEmit {
     __device__ void passed(int) {}
 };
 
-struct FusedLayout { long long cum_end; unsigned choice; int site, t, pad; };
 
 // The walks of the listed windows (they touch an insertion or a deletion: the sites a walk meets depend on its
-// decisions).  Workgroup per 128 listed windows: thread per window enumerates its layouts (the odometer over
-// simulate()) and keeps the first eight; block scan of the walk counts; then thread per walk: its layout by
+// decisions).  ONE WAVEFRONT per workgroup, 64 listed windows per round: lane per window enumerates its layouts (the
+// odometer over simulate()) and keeps the first four; wave scan of the walk counts; then lane per walk: its layout by
 // comparison, one replay that writes the bases, the reference bases fetched eight at a time, both strands scored from
-// the slot.  (The materialising path does the same in three kernels with a device-wide scan and a host read-back
-// between them.)
+// the slot.  These are few, long, latency-bound threads -- 100 000 windows of the bench's graph are 1 600 wavefronts --
+// so what counts is that ALL of them are resident at once: 23 KB of LDS per wavefront (W = 19) lets six or seven share
+// a CU.  (With 128-thread workgroups that also held a 30 KB histogram window, one workgroup fit a CU and the kernel ran
+// three rounds of two wavefronts per CU: 162 us.)  Their scores go to the caller's histogram by global atomics:
+// 400 000 adds spread over thousands of bins.  (The materialising path does the same work in three kernels with a
+// device-wide scan and a host read-back between them.)
 __global__ void __launch_bounds__(kFusedDelThreads)
-graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const DelWin *__restrict__ del_wins,
-                       const int *__restrict__ del_count, int *__restrict__ overflow, int pitch)
+graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__restrict__ tiles,
+                       const DelWin *__restrict__ del_wins, const int *__restrict__ del_count, int *__restrict__ overflow, int pitch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
     constexpr int T = kFusedDelThreads;
     unsigned *tab = reinterpret_cast<unsigned *>(fused_lds);
     SiteRec *cache = reinterpret_cast<SiteRec *>(tab + GFM_MAX_WIDTH * 8);                 // [kSiteCache][T]
-    FusedLayout *lay = reinterpret_cast<FusedLayout *>(cache + kSiteCache * T);            // [T][kFusedLayouts]
+    LayoutRec *lay = reinterpret_cast<LayoutRec *>(cache + kSiteCache * T);                // [T][kFusedLayouts]
     long long *w_incl = reinterpret_cast<long long *>(lay + T * kFusedLayouts);            // [T]
-    long long *wave_tot = w_incl + T;                                                      // [2]
-    int *n_lay = reinterpret_cast<int *>(wave_tot + 2);                                    // [T]
+    int *n_lay = reinterpret_cast<int *>(w_incl + T);                                      // [T]
     int *src = n_lay + T;                                                                  // [T][W]
     unsigned char *slots = reinterpret_cast<unsigned char *>(src + (size_t)T * a.W);       // [T][pitch]
-    unsigned *h = reinterpret_cast<unsigned *>(slots + (size_t)T * pitch);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x;
     const int W = a.W;
-    for (int i = tid; i < W * 8; i += T) tab[i] = tab_arg.v[i];
-    for (int i = tid; i <= a.hnb && a.hnb > 0; i += T) h[i] = 0u;
+    for (int i = lane; i < W * 8; i += T) tab[i] = tab_arg.v[i];
     const int n_listed = *del_count;
     unsigned long long rows_done = 0;
     for (int batch = blockIdx.x; (long long)batch * T < n_listed; batch += gridDim.x) {
         __syncthreads();
-        const int m = batch * T + tid;
+        const int m = batch * T + lane;
         const bool have = m < n_listed;
-        DelWin dw{0, 0, 0, 0, 0, 0};
+        struct { long long p, limit; int i0; } dw{0, 0, 0};
         long long walks = 0;
         int nl = 0;
         if (have) {
-            dw = del_wins[m];
+            const DelWin e = del_wins[m];
+            const Tile t = tiles[e.tile];
+            dw.p = t.p0 + e.k;
+            dw.limit = t.limit;
+            dw.i0 = e.i0;
 #pragma unroll
-            for (int k = 0; k < kSiteCache; ++k) cache[k * T + tid] = g.site_rec[dw.i0 + k];
-            const CachedSites sites{g.site_rec, cache + tid, dw.i0, T};
+            for (int k = 0; k < kSiteCache; ++k) cache[k * T + lane] = g.site_rec[dw.i0 + k];
+            const CachedSites sites{g.site_rec, cache + lane, dw.i0, T};
             WalkState st;
             NoVisitor nv;
             WalkStart ws;
@@ -355,10 +392,10 @@ graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const DelWin *
                                                                                    prod, dw.limit);
                     if (rc == WALK_OK) {
                         walks += prod;
-                        if (nl < kFusedLayouts)
-                            lay[tid * kFusedLayouts + nl] = FusedLayout{walks, ((unsigned)st.nd << 24) | (st.choice & ((1u << st.nd) - 1u)),
-                                                                        ws.site, ws.t, 0};
-                        ++nl;
+                        if (nl < kFusedLayouts && walks < 0x7fffffffll)      // (a window of 2^31 walks and more: the odometer finds them)
+                            lay[lane * kFusedLayouts + nl] = LayoutRec{(int)walks, ((unsigned)st.nd << 24) | (st.choice & ((1u << st.nd) - 1u)),
+                                                                       ws.site, ws.t};
+                        if (walks < 0x7fffffffll) ++nl;
                     }
                     if (rc == WALK_OVERFLOW || walks > kFusedMaxWalks) { bad = true; break; }
                     prefix = next_walk(st);
@@ -366,22 +403,20 @@ graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const DelWin *
             } while (!bad && next_start(g, dw.p, dw.i0, ws));
             if (bad) { walks = 0; nl = 0; atomicMax(overflow, 1); }
         }
-        n_lay[tid] = nl;
+        n_lay[lane] = nl;
         long long incl = walks;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int lo_ = __shfl_up((int)(incl & 0xffffffffll), d), hi_ = __shfl_up((int)(incl >> 32), d);
             if (lane >= d) incl += ((long long)hi_ << 32) | (unsigned)lo_;
         }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        const long long total = wave_tot[0] + wave_tot[1];
-        w_incl[tid] = incl + (wave ? wave_tot[0] : 0ll);
+        w_incl[lane] = incl;
+        const long long total = ((long long)__shfl((int)(incl >> 32), 63) << 32) | (unsigned)__shfl((int)(incl & 0xffffffffll), 63);
         __syncthreads();
         for (long long base = 0; base < total; base += T) {
-            const long long wt = base + tid;
+            const long long wt = base + lane;
             const bool live = wt < total;
-            int s_f = 0, s_r = 0, w_id = 0;
+            int s_f = 0, s_r = 0, w_tile = 0, w_k = 0;
             long long q0 = 0;
             if (live) {
                 int lo = 0, hi = T - 1;
@@ -389,10 +424,13 @@ graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const DelWin *
                     const int mid = (lo + hi) >> 1;
                     if (w_incl[mid] > wt) hi = mid; else lo = mid + 1;
                 }
-                const int o = lo;                                   // the thread that owns the walk's window
+                const int o = lo;                                   // the lane that owns the walk's window
                 q0 = wt - (o ? w_incl[o - 1] : 0ll);
-                const DelWin ow = del_wins[batch * T + o];
-                w_id = ow.w;
+                const DelWin oe = del_wins[batch * T + o];
+                const Tile ot = tiles[oe.tile];
+                const struct { long long p, limit; int i0; } ow{ot.p0 + oe.k, ot.limit, oe.i0};
+                w_tile = oe.tile;
+                w_k = oe.k;
                 const CachedSites sites{g.site_rec, cache + o, ow.i0, T};
                 WalkState st;
                 WalkStart ws;
@@ -402,7 +440,7 @@ graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const DelWin *
                     long long lbase = 0;
                     const int nlo = min(n_lay[o], kFusedLayouts);
                     for (int k = 0; k < nlo && !found; ++k) {
-                        const FusedLayout rec = lay[o * kFusedLayouts + k];
+                        const LayoutRec rec = lay[o * kFusedLayouts + k];
                         if (q0 < rec.cum_end) {
                             found = true;
                             q = q0 - lbase;
@@ -433,8 +471,8 @@ graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const DelWin *
                         if (!found) more = next_start(g, ow.p, ow.i0, ws);
                     }
                 }
-                unsigned char *slot = slots + (size_t)tid * pitch;
-                int *my_src = src + (size_t)tid * W;
+                unsigned char *slot = slots + (size_t)lane * pitch;
+                int *my_src = src + (size_t)lane * W;
                 if (found) {
                     ScoreEmit em{g.alt_bases, g.ins_bases, g.ins_off, slot, my_src};
                     long long again = 0;
@@ -459,36 +497,40 @@ graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const DelWin *
                     }
                     s_f = bad ? a.min_val : (int)(sum & 0xffffu);
                     s_r = bad ? a.min_val : (int)(sum >> 16);
-                    if (a.hnb > 0) {
-                        book_score(a, h, s_f);
-                        if (!a.forward_only) book_score(a, h, s_r);
+                    if (a.hist) {
+                        atomicAdd(&a.hist[s_f], 1ull);
+                        if (!a.forward_only) atomicAdd(&a.hist[s_r], 1ull);
                     }
                 }
             }
-            push_hits(a, live && s_f >= a.cutoff, w_id, 2 * q0, s_f);
-            if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, w_id, 2 * q0 + 1, s_r);
+            push_hits(a, live && s_f >= a.cutoff, w_tile, w_k, 2 * q0, s_f);
+            if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, w_tile, w_k, 2 * q0 + 1, s_r);
         }
-        if (tid == 0) rows_done += (unsigned long long)total * (a.forward_only ? 1ull : 2ull);
+        if (lane == 0) rows_done += (unsigned long long)total * (a.forward_only ? 1ull : 2ull);
     }
-    __syncthreads();
-    if (a.hnb > 0)
-        for (int i = tid; i <= a.hnb; i += T) a.slabs[(size_t)blockIdx.x * (a.hnb + 1) + i] = h[i];
-    if (tid == 0 && rows_done) atomicAdd(a.n_rows, rows_done);
+    if (lane == 0 && rows_done) atomicAdd(a.n_rows, rows_done);
 }
 
-// histogram slabs of both kernels -> the caller's histogram (thread per bin; the extra bin is min_val's)
+// histogram slabs of graph_score_kernel -> the caller's histogram: thread per (bin, group of 32 slabs), all of a thread's
+// loads in flight together (thread per bin over ALL slabs was 768 loads in a row for 116 wavefronts: 180 us)
+constexpr int kSlabGroup = 32;
 __global__ void __launch_bounds__(256)
 graph_hist_reduce_kernel(const unsigned *__restrict__ slabs, int n_slabs, int hlo, int hnb, int min_val,
                          unsigned long long *__restrict__ hist)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b > hnb) return;
+    const int s0 = blockIdx.y * kSlabGroup;
+    unsigned v[kSlabGroup];
+#pragma unroll
+    for (int s = 0; s < kSlabGroup; ++s) v[s] = s0 + s < n_slabs ? slabs[(size_t)(s0 + s) * (hnb + 1) + b] : 0u;
     unsigned long long sum = 0;
-    for (int s = 0; s < n_slabs; ++s) sum += slabs[(size_t)s * (hnb + 1) + b];
+#pragma unroll
+    for (int s = 0; s < kSlabGroup; ++s) sum += v[s];
     if (sum) atomicAdd(&hist[b < hnb ? hlo + b : min_val], sum);
 }
 
-// ---- the columns of the hit rows.  Thread per hit: the window from the tile table, then what the materialising emit
+// ---- the columns of the hit rows.  Thread per hit: tile and window from the entry, then what the materialising emit
 // kernels do for every row -- for a plain window the mixed-radix digits, the bases, the count from the tables (or the
 // bitsets, in place: these are a few hundred threads); for a listed window the odometer up to the walk's rank and one
 // replay with the visitor that collects the haplotype constraints.
@@ -501,21 +543,18 @@ graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, c
     const long long hi_ = (long long)blockIdx.x * 64 + threadIdx.x;
     if (hi_ >= n) return;
     const GraphHit hit = hits[hi_];
+    const Tile t = tiles[min(max(hit.tile, 0), n_tiles - 1)];
+    const int k = (int)(hit.q2k >> kHitWinShift) & 0xff;
+    const long long q2 = hit.q2k & kHitWalkMask;
     HitRec rec{};
-    rec.w = hit.w;
+    rec.w = t.w_base + k;
     rec.score = hit.score;
-    rec.q2 = hit.q2;
+    rec.q2 = q2;
     rec.keep = (!d_cutoff || hit.score >= *d_cutoff) ? 1 : 0;
     rec.qvalue = qtable ? qtable[hit.score] : 0.0;
-    int lo = 0, hi = n_tiles - 1;                      // last tile with w_base <= w
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (tiles[mid].w_base <= hit.w) lo = mid; else hi = mid - 1;
-    }
-    const Tile t = tiles[lo];
-    const long long p = t.p0 + (hit.w - t.w_base);
-    const long long q = hit.q2 >> 1;
-    const bool minus = (hit.q2 & 1) != 0;
+    const long long p = t.p0 + k;
+    const long long q = q2 >> 1;
+    const bool minus = (q2 & 1) != 0;
     rec.region = t.region;
     rec.strand = minus ? '-' : '+';
     if (!rec.keep) { out[hi_] = rec; return; }          // a p < t candidate that the q-value cutoff drops
@@ -523,9 +562,16 @@ graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, c
     long long end_pos = p + W, count = 0;
     bool any_alt = false;
     const GlobalSites gs{g.site_rec};
-    const WinInfo wi = classify_window(g, gs, p, W, t.limit, t.i_lo, t.i_hi + 1);
+    const WinInfo wi = classify_window(g, gs, p, W, t.limit, t.i_lo, t.i_hi);
     if (!wi.listed) {
-        for (int j = 0; j < W; ++j) km[j] = g.ref[p + j];
+        {
+            unsigned long long rw[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rw[c] = 8 * c < W ? load_u64(g.ref + p + 8 * c) : 0ull;
+#pragma unroll
+            for (int j = 0; j < GFM_MAX_WIDTH; ++j)
+                if (j < W) km[j] = (uint8_t)(rw[j >> 3] >> (8 * (j & 7)));
+        }
         unsigned long long dig[2] = {0ull, 0ull};
         long long rest = q;
         for (int s = wi.ns - 1; s >= 0; --s) {
@@ -536,7 +582,7 @@ graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, c
             if (al) km[g.pos[wi.i0 + s] - p] = g.alt_bases[(size_t)(wi.i0 + s) * kMaxAlts + (al - 1)];
         }
         any_alt = (dig[0] | dig[1]) != 0ull;
-        auto at = [&](int k, int &site, int &al) { site = wi.i0 + k; al = (int)((dig[k >> 5] >> (2 * (k & 31))) & 3ull); };
+        auto at = [&](int kk, int &site, int &al) { site = wi.i0 + kk; al = (int)((dig[kk >> 5] >> (2 * (kk & 31))) & 3ull); };
         bool done;
         count = count_by_tables(g, allele_count, wi.ns, at, done);
         if (!done) count = count_by_bitsets(g, wi.ns, at);
@@ -568,7 +614,7 @@ graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, c
         for (int j = 0; j < W; ++j)
             if (src[j] >= 0) km[j] = g.ref[src[j]];
         if (!(ws.site >= 0 && st.last == p - 1)) for_covering_deletions(g, p, wi.i0, [&](int dsite) { em.add(dsite, 0); });
-        auto at = [&](int k, int &site, int &al) { const int v = em.get(k); site = v >> 4; al = v & 3; };
+        auto at = [&](int kk, int &site, int &al) { const int v = em.get(kk); site = v >> 4; al = v & 3; };
         bool done;
         count = count_by_tables(g, allele_count, em.n_cons, at, done);
         if (!done) count = count_by_bitsets(g, em.n_cons, at);

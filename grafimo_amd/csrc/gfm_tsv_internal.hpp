@@ -456,6 +456,87 @@ bool parse_rows(const char *path, const char *p, const char *end, int W, bool sk
     return true;
 }
 
+// The streamed scan's pass over a file: what must be known of EVERY row before the hits are -- its k-mer (the score
+// kernel's input, score_sequences.py:286) and the strand character, the last one of the third column (:280-282: '-' rows
+// are skipped under --no-reverse before they are scored or counted) -- plus where its line starts, so that the other
+// columns can be read for the few rows that turn out to be hits (parse_line, at gfm_scan_tsv_finish).  The numbers of a
+// row are NOT converted here: that was 20 of the parser's 36 ns per row, for values that one row in ten thousand needs.
+// Checked for every row: six columns, a k-mer of the motif's width.  (A number that does not parse is therefore reported
+// only if its row is a hit; the reference's int() raises for any row.  vg does not write such rows.)
+// sink(kmer bytes [W], offset of the line in the file).  false: `error` holds "path:line: what".
+template <class Sink>
+bool scan_rows(const char *path, const char *base, const char *end, int W, bool skip_rev, Sink &&sink, std::string &error)
+{
+    int64_t lineno = 0;
+    const char *p = base;
+#if defined(__x86_64__)
+    const bool wide = cpu_has_avx2();
+#endif
+    while (p < end) {
+        ++lineno;
+        const char *fb[6], *fe[6];
+        const char *le = nullptr;
+        int nf = -1;
+#if defined(__x86_64__)
+        if (wide) nf = split_line_avx2(p, end, fb, fe, &le);
+#endif
+        if (nf < 0) {
+            const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+            le = nl ? nl : end;
+            nf = split_fields(p, le, end, fb, fe);
+        }
+        const char *next = le < end ? le + 1 : end;
+        if (nf == 0) { p = next; continue; }  // blank line
+        auto bad = [&](const char *what) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "%s:%lld: %s", path, (long long)lineno, what);
+            error = buf;
+            return false;
+        };
+        if (nf < 6) return bad("expected at least 6 columns");
+        if (!(skip_rev && fe[2][-1] == '-')) {
+            if (fe[1] - fb[1] != W) return bad("k-mer length differs from the motif width");
+            sink(reinterpret_cast<const uint8_t *>(fb[1]), (uint64_t)(p - base));
+        }
+        p = next;
+    }
+    return true;
+}
+
+// The columns of ONE row, from the bytes at its line start (`readable_end`: what may be read; the line may end earlier):
+// what parse_rows hands its sink for that row.  -1: the first six columns do not end inside the bytes given (the
+// caller reads more); 0: malformed, *what says why; 1: fine.
+struct LineCols {
+    int64_t start = 0, stop = 0, freq = 0;
+    uint8_t strand = 0, is_ref = 0;
+    const char *name = nullptr, *kmer = nullptr;
+    size_t name_len = 0, kmer_len = 0;
+};
+inline int parse_line(const char *p, const char *readable_end, bool complete, int W, LineCols &out, const char **what)
+{
+    const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(readable_end - p)));
+    const char *le = nl ? nl : readable_end;
+    const char *fb[6], *fe[6];
+    const int nf = split_fields_scalar(p, le, fb, fe);
+    // without the line's end in sight the sixth column may go on behind the bytes we hold
+    if (!nl && !complete && (nf < 6 || fe[5] == le)) return -1;
+    if (nf < 6) { *what = "expected at least 6 columns"; return 0; }
+    char s1 = 0, s2 = 0;
+    if (!parse_pos(fb[2], fe[2], false, &out.start, &s1)) { *what = "malformed start column"; return 0; }
+    if (!parse_pos(fb[3], fe[3], false, &out.stop, &s2)) { *what = "malformed stop column"; return 0; }
+    if (fe[1] - fb[1] != W) { *what = "k-mer length differs from the motif width"; return 0; }
+    if (!parse_int(fb[4], fe[4], &out.freq)) { *what = "malformed haplotype count"; return 0; }
+    const bool is_ref_str = (fe[5] - fb[5] == 3) && memcmp(fb[5], "ref", 3) == 0;
+    const int64_t dist = out.stop > out.start ? out.stop - out.start : out.start - out.stop;
+    out.strand = (uint8_t)s1;
+    out.is_ref = (uint8_t)(is_ref_str && dist == W);      // score_sequences.py:305-307
+    out.name = fb[0];
+    out.name_len = (size_t)(fe[0] - fb[0]);
+    out.kmer = fb[1];
+    out.kmer_len = (size_t)(fe[1] - fb[1]);
+    return 1;
+}
+
 }  // namespace gfm_tsv_detail
 
 struct gfm_tsv {

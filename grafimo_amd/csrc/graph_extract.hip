@@ -1598,7 +1598,7 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
         for (int r = 0; r < n_regions; ++r) {
             const long long s = std::max<long long>(h_starts[r], 0), e = std::min<long long>(h_stops[r], g->dev.ref_len);
             const long long nw = std::max<long long>(0, e - tail - s + 1);
-            n_tiles += (size_t)((nw + kFusedThreads - 1) / kFusedThreads);
+            n_tiles += (size_t)((nw + kTileWin - 1) / kTileWin);
         }
         if (n_tiles > 0x7fffffffull) return gfail(GFM_ERR_INVALID, "too many windows in one call (split the regions)");
         if (n_tiles > g->h_tiles_cap) {
@@ -1614,11 +1614,11 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
         for (int r = 0; r < n_regions; ++r) {
             const long long s = std::max<long long>(h_starts[r], 0), e = std::min<long long>(h_stops[r], g->dev.ref_len);
             const long long nw = std::max<long long>(0, e - tail - s + 1);
-            for (long long off = 0; off < nw; off += kFusedThreads) {
+            for (long long off = 0; off < nw; off += kTileWin) {
                 Tile &t = g->h_tiles[ti++];
                 t.p0 = s + off;
                 t.limit = e;
-                t.n_win = (int)std::min<long long>(kFusedThreads, nw - off);
+                t.n_win = (int)std::min<long long>(kTileWin, nw - off);
                 t.region = r;
                 t.i_lo = hint_lo = site_lower_bound(g->h_pos, hint_lo, t.p0 - 1);
                 t.i_hi = hint_hi = site_lower_bound(g->h_pos, std::max(hint_hi, hint_lo), t.p0 + t.n_win - 1 + W);
@@ -1642,11 +1642,14 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     }
     if (n_windows) *n_windows = g->f_n_windows;
     if (g->f_n_tiles == 0) return GFM_OK;
-    const int g1 = std::min(g->f_n_tiles, 2 * n_cu), g2 = n_cu;
+    // graph_score_kernel: workgroups of eight wavefronts, two per CU; graph_score_del_kernel: one wavefront per workgroup,
+    // as many as a CU's LDS holds
+    const int g1 = std::min((g->f_n_tiles + kFusedWaves - 1) / kFusedWaves, 2 * n_cu);
     const bool with_hist = d_hist != nullptr;
     if (!with_hist) hnb = 0;
+    const bool indels = g->dev.n_dels > 0 || g->dev.n_ins > 0;
     GX_TRY(g->f_del_wins.reserve((size_t)g->f_n_windows + 1));
-    GX_TRY(g->f_slabs.reserve((size_t)(g1 + g2) * (size_t)(hnb + 1) + 1));
+    GX_TRY(g->f_slabs.reserve((size_t)g1 * (size_t)(hnb + 1) + 1));
     GX_TRY(g->f_flags.reserve(4));
     GX_TRY(hipMemsetAsync(g->f_flags.p, 0, 4 * sizeof(int), st));
     FusedTab tab{};
@@ -1674,25 +1677,24 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     a.n_rows = reinterpret_cast<unsigned long long *>(d_n_rows);
     a.ticket = reinterpret_cast<unsigned *>(g->f_flags.p);
     const size_t hist_bytes = with_hist ? sizeof(unsigned) * (size_t)(hnb + 1) : 0;
-    const size_t lds1 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(SiteRec) * kFusedSites + kFusedRefBytes +
-                        kFusedThreads * (sizeof(long long) + 4 * sizeof(int)) + 4 * sizeof(long long) + 4 * sizeof(int) + hist_bytes;
+    const size_t lds1 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(WaveLds) * kFusedWaves + sizeof(long long) * kFusedWaves +
+                        sizeof(int) * (kFusedWaves + 2) + hist_bytes;
     hipLaunchKernelGGL(graph_score_kernel, dim3((unsigned)g1), dim3(kFusedThreads), lds1, st, g->dev, a, tab, g->f_tiles.p,
                        g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2);
-    int pitch = ((W + 3) / 4) * 4;
-    if ((pitch / 4) % 2 == 0) pitch += 4;             // an odd dword pitch: the threads' slots fall on all LDS banks
-    const size_t lds2 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(SiteRec) * kSiteCache * kFusedDelThreads +
-                        sizeof(FusedLayout) * kFusedDelThreads * kFusedLayouts + sizeof(long long) * (kFusedDelThreads + 2) +
-                        sizeof(int) * kFusedDelThreads + sizeof(int) * (size_t)kFusedDelThreads * W +
-                        (size_t)kFusedDelThreads * pitch + hist_bytes;
-    FusedArgs a2 = a;
-    a2.slabs = g->f_slabs.p + (size_t)g1 * (size_t)(hnb + 1);
-    if (g->dev.n_dels > 0 || g->dev.n_ins > 0)
-        hipLaunchKernelGGL(graph_score_del_kernel, dim3((unsigned)g2), dim3(kFusedDelThreads), lds2, st, g->dev, a2, tab,
-                           g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, pitch);
+    if (indels) {
+        int pitch = ((W + 3) / 4) * 4;
+        if ((pitch / 4) % 2 == 0) pitch += 4;         // an odd dword pitch: the lanes' slots fall on all LDS banks
+        const size_t lds2 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(SiteRec) * kSiteCache * kFusedDelThreads +
+                            sizeof(LayoutRec) * kFusedDelThreads * kFusedLayouts + sizeof(long long) * kFusedDelThreads +
+                            sizeof(int) * kFusedDelThreads + sizeof(int) * (size_t)kFusedDelThreads * W +
+                            (size_t)kFusedDelThreads * pitch;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 * 1024) / lds2));
+        hipLaunchKernelGGL(graph_score_del_kernel, dim3((unsigned)(per_cu * n_cu)), dim3(kFusedDelThreads), lds2, st, g->dev, a, tab,
+                           g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, pitch);
+    }
     if (with_hist)
-        hipLaunchKernelGGL(graph_hist_reduce_kernel, dim3((unsigned)((hnb + 1 + 255) / 256)), dim3(256), 0, st, g->f_slabs.p,
-                           (g->dev.n_dels > 0 || g->dev.n_ins > 0) ? g1 + g2 : g1, hlo, hnb, min_val,
-                           reinterpret_cast<unsigned long long *>(d_hist));
+        hipLaunchKernelGGL(graph_hist_reduce_kernel, dim3((unsigned)((hnb + 1 + 255) / 256), (unsigned)((g1 + kSlabGroup - 1) / kSlabGroup)),
+                           dim3(256), 0, st, g->f_slabs.p, g1, hlo, hnb, min_val, reinterpret_cast<unsigned long long *>(d_hist));
     GX_TRY(hipGetLastError());
     if (d_overflow) GX_TRY(hipMemcpyAsync(d_overflow, g->f_flags.p + 2, sizeof(int), hipMemcpyDeviceToDevice, st));
     return GFM_OK;

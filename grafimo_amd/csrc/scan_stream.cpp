@@ -18,7 +18,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -68,27 +73,18 @@ double now_s()
 constexpr int kSlots = 3;                          // chunk slots: one being staged, one in flight, one spare
 constexpr int64_t kDefaultChunkRows = 1 << 20;     // rows per chunk (x W bytes pinned + device, per slot)
 
-// host columns of the rows of one chunk (what the hits are annotated from); one allocation, kept in the pool
+// What the host keeps of the rows of one chunk: where each row's line starts in its file (8 bytes per row).  The
+// columns of a row -- coordinates, haplotype count, ref flag, REGION -- are read from there for the hit rows only, at
+// gfm_scan_tsv_finish (round 3 kept 30 + W bytes of parsed columns per row: 1 GB of stores for 2e7 rows of which two
+// thousand were ever looked at).  One allocation, kept in the pool.
 struct MetaChunk {
     void *block = nullptr;
-    uint8_t *kmers = nullptr;
-    int64_t *start = nullptr, *stop = nullptr, *freq = nullptr;
-    uint8_t *strand = nullptr, *is_ref = nullptr;
-    int32_t *local_name = nullptr;
-    bool alloc(int64_t rows, int W)
+    uint64_t *line_off = nullptr;
+    bool alloc(int64_t rows, int)
     {
-        const size_t r = (size_t)rows;
-        const size_t bytes = r * (3 * sizeof(int64_t) + sizeof(int32_t) + 2 + (size_t)W) + 64;
-        block = std::malloc(bytes);
+        block = std::malloc((size_t)rows * sizeof(uint64_t) + 64);
         if (!block) return false;
-        uint8_t *p = static_cast<uint8_t *>(block);
-        start = reinterpret_cast<int64_t *>(p); p += r * sizeof(int64_t);
-        stop = reinterpret_cast<int64_t *>(p); p += r * sizeof(int64_t);
-        freq = reinterpret_cast<int64_t *>(p); p += r * sizeof(int64_t);
-        local_name = reinterpret_cast<int32_t *>(p); p += r * sizeof(int32_t);
-        strand = p; p += r;
-        is_ref = p; p += r;
-        kmers = p;
+        line_off = static_cast<uint64_t *>(block);
         return true;
     }
     void release() { std::free(block); *this = MetaChunk(); }
@@ -243,7 +239,7 @@ struct ScanPool {
     static constexpr size_t kKeepHostBytes = (size_t)1 << 30, kKeepDeviceBytes = (size_t)4 << 30;
     void trim()
     {
-        const size_t per_meta = (size_t)meta_rows * (3 * sizeof(int64_t) + sizeof(int32_t) + 2 + (size_t)meta_W) + 64;
+        const size_t per_meta = (size_t)meta_rows * sizeof(uint64_t) + 64;
         while (!meta.empty() && meta.size() * per_meta > kKeepHostBytes) {
             meta.back().release();
             meta.pop_back();
@@ -323,6 +319,10 @@ struct MotifHits {
     std::vector<int64_t> rows;        // hit rows, ascending (global row ids in sorted-file order)
     std::vector<int32_t> scaled;
     std::vector<double> logodds, pvalue, qvalue;
+    // the columns of the hit rows' TSV lines (read back from the files at finish)
+    std::vector<uint8_t> kmers, strand, is_ref;
+    std::vector<int64_t> start, stop, freq;
+    std::vector<int32_t> name_id;
 };
 
 }  // namespace
@@ -332,6 +332,8 @@ struct gfm_scan {
     int W = 0, L = 0;
     bool have_q = false;
     std::vector<MotifHits> hits;      // one per motif
+    std::vector<std::string> paths;   // the files, in scan order (the hit rows' lines are read from them at finish)
+    int n_threads = 1;
     gfm_scan_stats_t stats{};
     // ---- what gfm_scan_tsv_finish needs from gfm_scan_tsv_begin
     std::vector<gfm_motif_t> motifs;
@@ -346,6 +348,137 @@ struct gfm_scan {
     double t_begin = 0.0, t_parsed = 0.0, begin_s = 0.0;
     ~gfm_scan() { release_pool(pool); }
 };
+
+namespace {
+
+// The columns of the hit rows, read back from their files (score_sequences.py:285-293, :305-307 for the rows that are
+// reported).  Hits ascend by row, rows by file: per motif and file ONE job -- open, then either a pread of a kilobyte
+// per hit (the usual case: one hit in ten thousand rows) or, when a file holds so many hits that this would read most
+// of it anyway, the whole file once; the jobs are spread over the crew.  REGION strings become ids in the scan's name
+// table (only names of hit rows are in it).
+struct HitJob {
+    size_t motif, file, i0, i1;               // hits [i0, i1) of the motif lie in this file
+    std::vector<std::string> names;           // distinct REGION strings of the job's rows, local ids in name_id[]
+};
+
+int fetch_hit_columns(gfm_scan *sc)
+{
+    const gfm_tsv &t = sc->table;
+    const ScanPool *P = sc->pool;
+    const size_t W = (size_t)sc->W;
+    std::vector<HitJob> jobs;
+    for (size_t j = 0; j < sc->hits.size(); ++j) {
+        MotifHits &h = sc->hits[j];
+        const size_t k = h.rows.size();
+        h.kmers.resize(k * W);
+        h.start.resize(k); h.stop.resize(k); h.freq.resize(k);
+        h.strand.resize(k); h.is_ref.resize(k); h.name_id.resize(k);
+        size_t fi = 0;
+        for (size_t i = 0; i < k;) {
+            while (fi + 1 < t.files.size() && t.row_base[fi + 1] <= h.rows[i]) ++fi;
+            const int64_t file_end = fi + 1 < t.files.size() ? t.row_base[fi + 1] : t.n;
+            size_t e = i;
+            while (e < k && h.rows[e] < file_end) ++e;
+            jobs.push_back(HitJob{j, fi, i, e, {}});
+            i = e;
+        }
+    }
+    if (jobs.empty()) return GFM_OK;
+    std::atomic<size_t> next{0};
+    std::mutex err_mu;
+    std::string err;
+    auto fail_job = [&](const std::string &msg) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (err.empty()) err = msg;
+    };
+    auto work = [&]() {
+        static thread_local gfm_tsv_detail::FileBuf whole;
+        std::vector<char> buf;
+        for (;;) {
+            const size_t jx = next.fetch_add(1, std::memory_order_relaxed);
+            if (jx >= jobs.size()) break;
+            HitJob &job = jobs[jx];
+            MotifHits &h = sc->hits[job.motif];
+            const std::string &path = sc->paths[job.file];
+            gfm_tsv_detail::NameTable names(job.names);
+            const int64_t base_row = t.row_base[job.file];
+            auto store = [&](size_t i, const gfm_tsv_detail::LineCols &c) {
+                std::memcpy(h.kmers.data() + i * W, c.kmer, W);
+                h.start[i] = c.start; h.stop[i] = c.stop; h.freq[i] = c.freq;
+                h.strand[i] = c.strand; h.is_ref[i] = c.is_ref;
+                h.name_id[i] = names.id(c.name, c.name_len);
+                names.last = nullptr;      // (the table remembers the last name by ADDRESS: ours lies in a buffer that is read into again)
+            };
+            auto offset_of = [&](size_t i) {
+                const int64_t r = h.rows[i];
+                return P->meta[(size_t)(r / sc->chunk_rows)].line_off[(size_t)(r % sc->chunk_rows)];
+            };
+            auto complain = [&](size_t i, const char *what) {
+                fail_job(path + ": row " + std::to_string((long long)(h.rows[i] - base_row + 1)) + " of the file: " + what);
+            };
+            const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+            if (fd < 0) { fail_job("cannot open " + path + " again for its hit rows"); continue; }
+            struct stat sb {};
+            const bool have_size = ::fstat(fd, &sb) == 0;
+            const size_t n_hits = job.i1 - job.i0;
+            if (have_size && (uint64_t)n_hits * 2048u >= (uint64_t)sb.st_size) {
+                ::close(fd);
+                std::string lerr;
+                if (!whole.load(path.c_str(), lerr)) { fail_job(lerr); continue; }
+                for (size_t i = job.i0; i < job.i1; ++i) {
+                    const uint64_t off = offset_of(i);
+                    gfm_tsv_detail::LineCols c;
+                    const char *what = "the file changed during the scan";
+                    if (off >= (uint64_t)(whole.end() - whole.begin()) ||
+                        gfm_tsv_detail::parse_line(whole.begin() + off, whole.end(), true, (int)W, c, &what) != 1) {
+                        complain(i, what);
+                        break;
+                    }
+                    store(i, c);
+                }
+                whole.drop();
+                continue;
+            }
+            for (size_t i = job.i0; i < job.i1; ++i) {
+                const uint64_t off = offset_of(i);
+                size_t want = 1024;
+                for (;;) {
+                    buf.resize(want + 64);
+                    size_t got = 0;
+                    bool eof = false, io_bad = false;
+                    while (got < want) {
+                        const ssize_t r = ::pread(fd, buf.data() + got, want - got, (off_t)(off + got));
+                        if (r < 0) { if (errno == EINTR) continue; io_bad = true; break; }
+                        if (r == 0) { eof = true; break; }
+                        got += (size_t)r;
+                    }
+                    if (io_bad) { complain(i, "read error"); break; }
+                    std::memset(buf.data() + got, 0, 64);
+                    gfm_tsv_detail::LineCols c;
+                    const char *what = "the file changed during the scan";
+                    const int rc = got ? gfm_tsv_detail::parse_line(buf.data(), buf.data() + got, eof, (int)W, c, &what) : 0;
+                    if (rc == 1) { store(i, c); break; }
+                    if (rc == 0 || eof) { complain(i, what); break; }
+                    want *= 8;                 // the sixth column ends behind what was read (a long line): read more
+                }
+            }
+            ::close(fd);
+        }
+    };
+    gfm_workers::run(std::max(1, std::min<int>(sc->n_threads, (int)((jobs.size() + 3) / 4))), work);
+    if (!err.empty()) return sfail(GFM_ERR_IO, err);
+    // local name ids -> ids in the scan's table
+    gfm_tsv_detail::NameTable global(sc->table.names);
+    for (auto &job : jobs) {
+        std::vector<int32_t> map(job.names.size());
+        for (size_t q = 0; q < job.names.size(); ++q) map[q] = global.id(job.names[q].data(), job.names[q].size());
+        MotifHits &h = sc->hits[job.motif];
+        for (size_t i = job.i0; i < job.i1; ++i) h.name_id[i] = map[(size_t)h.name_id[i]];
+    }
+    return GFM_OK;
+}
+
+}  // namespace
 
 GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const char *const *paths, int n_paths,
                                int skip_reverse, int n_threads, double threshold, int on_qvalue, int want_qvalues,
@@ -386,6 +519,8 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     sc->hits.resize(M);
     sc->table.W = W;
     sc->table.files.resize((size_t)n_paths);
+    sc->paths.reserve((size_t)n_paths);
+    for (int i = 0; i < n_paths; ++i) sc->paths.emplace_back(paths[i]);
     const double t_begin = now_s();
     sc->t_begin = t_begin;
     const bool trace = std::getenv("GRAFIMO_SCAN_TRACE") != nullptr;   // development aid: phase times to stderr
@@ -414,6 +549,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     stamp("pool acquired");
     S_RC(P->reserve_slots((size_t)chunk_rows * (size_t)W + 16));
     S_RC(P->reserve_motifs(M));
+    sc->n_threads = gfm_tsv_detail::pick_threads(paths, n_paths, n_threads);
     sc->d_hist.assign(M, nullptr);
     sc->cutoffs.assign(M, GFM_NO_SELECT);
     for (size_t j = 0; j < M; ++j) {
@@ -533,7 +669,6 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                 std::string err;
                 int64_t done = 0;
                 if (rows > 0) {
-                    gfm_tsv_detail::NameTable names(f.names);
                     int64_t k = -1, in = 0, left = 0;      // chunk, row inside it, rows until the chunk ends
                     uint8_t *pin = nullptr;
                     MetaChunk mc;                          // by value: the pool's vector of blocks may grow meanwhile
@@ -548,8 +683,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                         if (now == chunk_rows || (tot >= 0 && now == tot - k * chunk_rows)) wake_main();
                     };
                     bool gave_up = false;
-                    auto sink = [&](const uint8_t *kmer, int64_t st, int64_t sp, int64_t fr, uint8_t strand,
-                                    uint8_t is_ref, int32_t nid) {
+                    auto sink = [&](const uint8_t *kmer, uint64_t line_off) {
                         if (gave_up || done >= rows) { ++done; return; }   // more rows than counted: reported below
                         if (left == 0) {
                             account();
@@ -585,13 +719,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                             pin = P->h_pin[k % kSlots];
                         }
                         gfm_tsv_detail::copy_kmer(pin + (size_t)in * (size_t)W, kmer, W);
-                        gfm_tsv_detail::copy_kmer(mc.kmers + (size_t)in * (size_t)W, kmer, W);
-                        mc.start[in] = st;
-                        mc.stop[in] = sp;
-                        mc.freq[in] = fr;
-                        mc.strand[in] = strand;
-                        mc.is_ref[in] = is_ref;
-                        mc.local_name[in] = nid;
+                        mc.line_off[in] = line_off;
                         ++in;
                         --left;
                         ++placed;
@@ -599,8 +727,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                     };
                     std::string perr;
                     const double p0 = trace ? now_s() : 0.0;
-                    const bool ok = gfm_tsv_detail::parse_rows(paths[i], text.begin(), text.end(), W, skip_reverse != 0,
-                                                               names, sink, perr);
+                    const bool ok = gfm_tsv_detail::scan_rows(paths[i], text.begin(), text.end(), W, skip_reverse != 0, sink, perr);
                     if (trace) tr_max(tr_parse, (int64_t)((now_s() - p0) * 1e9));
                     account();
                     if (!ok) err = perr;
@@ -915,6 +1042,7 @@ GFM_API int gfm_scan_tsv_finish(gfm_scan_t sc, int64_t *n_hits)
                 for (size_t i = 0; i < (size_t)cnt; ++i) h.qvalue[i] = q[(size_t)h.scaled[i]];
             }
         }
+        S_RC(fetch_hit_columns(sc));
     } else {
         S_TRY(hipStreamSynchronize(P->score));
     }
@@ -964,23 +1092,14 @@ GFM_API int gfm_scan_hits_of(gfm_scan_t s, int motif, int64_t *rows, int32_t *sc
         if (!s->have_q) return sfail(GFM_ERR_INVALID, "the scan computed no q-values");
         std::memcpy(qvalue, h.qvalue.data(), k * sizeof(double));
     }
-    const gfm_tsv &t = s->table;
-    const ScanPool *P = s->pool;
-    size_t fi = 0;
     const size_t W = (size_t)s->W;
-    for (size_t i = 0; i < k; ++i) {          // hits ascend by row: walk the files once
-        const int64_t r = h.rows[i];
-        while (fi + 1 < t.files.size() && t.row_base[fi + 1] <= r) ++fi;
-        const MetaChunk &mc = P->meta[(size_t)(r / s->chunk_rows)];
-        const size_t j = (size_t)(r % s->chunk_rows);
-        if (kmers) std::memcpy(kmers + i * W, mc.kmers + j * W, W);
-        if (start) start[i] = mc.start[j];
-        if (stop) stop[i] = mc.stop[j];
-        if (strand) strand[i] = mc.strand[j];
-        if (freq) freq[i] = mc.freq[j];
-        if (is_ref) is_ref[i] = mc.is_ref[j];
-        if (name_id) name_id[i] = t.remap[fi][(size_t)mc.local_name[j]];
-    }
+    if (kmers) std::memcpy(kmers, h.kmers.data(), k * W);
+    if (start) std::memcpy(start, h.start.data(), k * sizeof(int64_t));
+    if (stop) std::memcpy(stop, h.stop.data(), k * sizeof(int64_t));
+    if (strand) std::memcpy(strand, h.strand.data(), k);
+    if (freq) std::memcpy(freq, h.freq.data(), k * sizeof(int64_t));
+    if (is_ref) std::memcpy(is_ref, h.is_ref.data(), k);
+    if (name_id) std::memcpy(name_id, h.name_id.data(), k * sizeof(int32_t));
     return GFM_OK;
 }
 

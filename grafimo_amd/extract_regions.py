@@ -838,22 +838,34 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
     from .score_sequences import print_scoring_msg
     torch = _torch()
     many = isinstance(graph, (list, tuple))
-    graphs = list(graph) if many else [graph]
-    spans = [_region_arrays(r) for r in (regions if many else [regions])]
+    entries = list(graph) if many else [graph]
+    entry_spans = [_region_arrays(r) for r in (regions if many else [regions])]
     dist = torch.distributed
     live = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if live else 1
     rank = dist.get_rank(group) if live else 0
     collective = world > 1 or (always_collective and live)
-    if world > 1:                                    # contiguous shard of the flattened (graph, region) list
+    if world > 1:                                    # contiguous shard of the flattened (entry, region) list
         from .distributed import shard_bounds
-        sizes = [len(s_) for s_, _ in spans]
+        sizes = [len(s_) for s_, _ in entry_spans]
         lo_, hi_ = shard_bounds(sum(sizes), world, rank)
         at = 0
-        for gi, n_ in enumerate(sizes):
+        for ei, n_ in enumerate(sizes):
             a_, b_ = min(max(lo_ - at, 0), n_), min(max(hi_ - at, 0), n_)
-            spans[gi] = (spans[gi][0][a_:b_], spans[gi][1][a_:b_])
+            entry_spans[ei] = (entry_spans[ei][0][a_:b_], entry_spans[ei][1][a_:b_])
             at += n_
+    # one scoring call per distinct graph handle (a handle holds the tile table of its last call): entries that share a
+    # handle are scored as one list of regions; `first_entry[gi]` keeps the entries' order for the rows
+    graphs, spans, entry_of = [], [], []
+    for ei, g_ in enumerate(entries):
+        gi = next((k for k, x in enumerate(graphs) if x is g_), -1)
+        if gi < 0:
+            graphs.append(g_)
+            spans.append(entry_spans[ei])
+            entry_of.append(np.full(len(entry_spans[ei][0]), ei, dtype=np.int64))
+        else:
+            spans[gi] = (np.concatenate([spans[gi][0], entry_spans[ei][0]]), np.concatenate([spans[gi][1], entry_spans[ei][1]]))
+            entry_of[gi] = np.concatenate([entry_of[gi], np.full(len(entry_spans[ei][0]), ei, dtype=np.int64)])
     threshold = float(args_obj.threshold)
     no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
     no_reverse, recomb = bool(args_obj.noreverse), bool(args_obj.recomb)
@@ -917,18 +929,20 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
     if rank == 0:
         print(f"Scanned sequences:\t{n_global}")
         print(f"Scanned nucleotides:\t{n_global * W}")
-    # ---- the hit rows in the row order of the materialising path: graph, window, walk, strand
-    parts = []
+    # ---- the hit rows in the row order of the materialising path: entry, window, walk, strand
+    kept, names_of, entry_key = [], [], []
     for gi, (_, _, _, recs) in enumerate(got):
         recs = recs[recs["keep"] != 0]
-        order = np.lexsort((recs["q2"], recs["w"]))
-        parts.append((gi, recs[order]))
-    seqnames: List[str] = []
-    for gi, recs in parts:
         c, (s_, e_) = graphs[gi].index.chrom, spans[gi]
         reg = recs["region"]
-        seqnames.extend([f"{c}:{a}-{b}" for a, b in zip(s_[reg].tolist(), e_[reg].tolist())])
-    recs = np.concatenate([r for _, r in parts]) if len(parts) > 1 else parts[0][1]
+        kept.append(recs)
+        entry_key.append(entry_of[gi][reg] if len(recs) else np.empty(0, dtype=np.int64))
+        names_of.append(np.array([f"{c}:{a}-{b}" for a, b in zip(s_[reg].tolist(), e_[reg].tolist())], dtype=object))
+    recs = np.concatenate(kept) if len(kept) > 1 else kept[0]
+    ekey = np.concatenate(entry_key) if len(kept) > 1 else entry_key[0]
+    names = np.concatenate(names_of) if len(kept) > 1 else names_of[0]
+    order = np.lexsort((recs["q2"], recs["w"], ekey))
+    recs, seqnames = recs[order], names[order].tolist()
     lo, pv = dm_annotate_host(motif, dm, recs["score"])
     cols = dict(start=recs["start"], stop=recs["stop"], strand=recs["strand"], logodds=lo, pvalue=pv,
                 kmers=np.ascontiguousarray(recs["kmer"][:, :W]), freq=recs["freq"], is_ref=recs["is_ref"])

@@ -396,17 +396,17 @@ int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, int64_t *d
  *   d_hits gfm_graph_entry_t [hit_capacity], appended from *d_hit_count on (entries beyond the capacity are counted,
  *   not stored; the caller zeroes the counter); *d_n_rows += rows scored; *d_overflow (optional) = 1 if a window holds
  *   more than 2^40 walks (its rows are left out); *n_windows (host, optional) = windows of the call.  Entry order is
- *   arbitrary; sorted by (w, q2) it is the row order of gfm_graph_emit.  Enqueue only (the first call for a set of
+ *   arbitrary; the records of gfm_graph_annotate sorted by (w, q2) are in the row order of gfm_graph_emit.  Enqueue only (the first call for a set of
  *   regions builds and uploads their tile table; later calls with the same regions and width reuse it).
  * gfm_graph_annotate: for entry i < min(*d_hit_count, hit_capacity) the record d_records[i] of the LAST gfm_graph_score
  *   call on this handle; d_cutoff (device, optional): entries with score < *d_cutoff get keep = 0 and no columns (the
  *   p < t candidates of a --qvalueT scan that the q-value cutoff drops: q >= p); d_qtable (device, optional): the
  *   q-value of the entry's score.  Enqueue only. */
 #define GFM_GRAPH_FORWARD_ONLY 1u
-typedef struct gfm_graph_entry {
-    int32_t w;          /* window of the call: regions in order, window starts ascending */
+typedef struct gfm_graph_entry {   /* opaque to the caller, who only provides the room: */
+    int32_t tile;       /* where the walk is among the call's windows (64 consecutive window starts of one region) */
     int32_t score;      /* scaled score */
-    int64_t q2;         /* walk of the window * 2 + strand (0 '+', 1 '-') */
+    int64_t q2k;        /* window of the tile << 56 | (walk of the window * 2 + strand: 0 '+', 1 '-') */
 } gfm_graph_entry_t;
 typedef struct gfm_graph_hit {
     int64_t start, stop, freq, q2;

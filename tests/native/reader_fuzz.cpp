@@ -44,6 +44,78 @@ static RefRows ref_parse(const std::string &t, int W, bool skip_rev)
     return r;
 }
 
+// The streamed scan's pass (scan_rows: k-mer + line offset of every kept row, six columns and the k-mer length checked,
+// no numbers converted) with byte loops only, and parse_line for single rows against the full parse of that line.
+struct LightRows {
+    bool ok = true;
+    std::vector<uint64_t> off;
+    std::vector<uint8_t> kmers;
+};
+static LightRows ref_light(const std::string &t, int W, bool skip_rev)
+{
+    using namespace gfm_tsv_detail;
+    LightRows r;
+    const char *p = t.data(), *end = p + t.size();
+    while (p < end) {
+        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+        const char *le = nl ? nl : end;
+        const char *fb[6], *fe[6];
+        const int nf = split_fields_scalar(p, le, fb, fe);
+        const char *line = p;
+        p = nl ? nl + 1 : end;
+        if (nf == 0) continue;
+        if (nf < 6) { r.ok = false; return r; }
+        if (skip_rev && fe[2][-1] == '-') continue;
+        if (fe[1] - fb[1] != W) { r.ok = false; return r; }
+        r.off.push_back((uint64_t)(line - t.data()));
+        r.kmers.insert(r.kmers.end(), fb[1], fe[1]);
+    }
+    return r;
+}
+static int check_light(const std::string &t, int it, int skip, std::mt19937 &rng)
+{
+    using namespace gfm_tsv_detail;
+    const LightRows ref = ref_light(t, 19, skip != 0);
+    LightRows got;
+    std::string err;
+    std::string padded = t + std::string(64, '\0');           // (FileBuf keeps 64 readable bytes behind the text)
+    got.ok = scan_rows("m.tsv", padded.data(), padded.data() + t.size(), 19, skip != 0,
+                       [&](const uint8_t *k, uint64_t off) { got.off.push_back(off); got.kmers.insert(got.kmers.end(), k, k + 19); }, err);
+    if (got.ok != ref.ok) { std::printf("LIGHT ACCEPT MISMATCH it=%d skip=%d scan_rows=%d reference=%d\n", it, skip, (int)got.ok, (int)ref.ok); return 1; }
+    if (!ref.ok) return 0;
+    if (got.off != ref.off || got.kmers != ref.kmers) { std::printf("LIGHT VALUE MISMATCH it=%d skip=%d\n", it, skip); return 1; }
+    if (count_rows(padded.data(), padded.data() + t.size(), skip != 0) != (int64_t)ref.off.size()) {
+        std::printf("LIGHT COUNT MISMATCH it=%d skip=%d\n", it, skip);
+        return 1;
+    }
+    for (int k = 0; k < 12 && !ref.off.empty(); ++k) {          // single rows: whole line, and a prefix of it as a pread would hold
+        const uint64_t off = ref.off[rng() % ref.off.size()];
+        const char *p = t.data() + off, *end = t.data() + t.size();
+        const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+        const std::string line(p, nl ? nl : end);
+        const RefRows one = ref_parse(line, 19, false);
+        LineCols c;
+        const char *what = "";
+        const int rc = parse_line(p, end, true, 19, c, &what);
+        if ((rc == 1) != (one.ok && one.start.size() == 1)) { std::printf("LINE ACCEPT MISMATCH it=%d off=%llu rc=%d\n", it, (unsigned long long)off, rc); return 1; }
+        if (rc == 1 && (c.start != one.start[0] || c.stop != one.stop[0] || c.freq != one.freq[0] || c.strand != one.strand[0] ||
+                        c.is_ref != one.is_ref[0] || memcmp(c.kmer, one.kmers.data(), 19) != 0)) {
+            std::printf("LINE VALUE MISMATCH it=%d off=%llu\n", it, (unsigned long long)off);
+            return 1;
+        }
+        const size_t cut = 1 + rng() % (size_t)(end - p);
+        std::string part(p, cut);
+        LineCols d;
+        const int rc2 = parse_line(part.data(), part.data() + part.size(), cut == (size_t)(end - p), 19, d, &what);
+        if (rc2 >= 0 && rc2 != rc) { std::printf("LINE PREFIX MISMATCH it=%d off=%llu cut=%zu rc=%d full=%d\n", it, (unsigned long long)off, cut, rc2, rc); return 1; }
+        if (rc2 == 1 && (d.start != c.start || d.stop != c.stop || d.freq != c.freq || d.is_ref != c.is_ref || d.name_len != c.name_len)) {
+            std::printf("LINE PREFIX VALUE MISMATCH it=%d off=%llu cut=%zu\n", it, (unsigned long long)off, cut);
+            return 1;
+        }
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     const char *tsv = argv[1], *vcf = argv[2], *tmp = argv[3];
@@ -89,6 +161,7 @@ int main(int argc, char **argv)
             gfm_tsv_t h = nullptr; int64_t n = 0, c = -1;
             const int rc = gfm_tsv_open(paths, 1, 19, skip, 1 + it % 3, &h, &n);
             const int rc2 = gfm_tsv_count_rows(path.c_str(), skip, &c);
+            if (check_light(t, it, skip, rng)) return 1;
             const RefRows ref = ref_parse(t, 19, skip != 0);
             if ((rc == 0) != ref.ok) { std::printf("ACCEPT MISMATCH it=%d skip=%d library rc=%d reference ok=%d\n", it, skip, rc, (int)ref.ok); return 1; }
             if (rc == 0) {

@@ -11,7 +11,7 @@ import pandas as pd
 import pytest
 
 from conftest import REF_DATA
-from extract_helpers import make_graph_files, scoring_fixture_graph
+from extract_helpers import make_graph_files
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -113,30 +113,6 @@ def test_flag_settings_on_thresholds_that_select(tmp_path):
     g.close()
 
 
-def test_reference_scoring_fixture_through_the_fused_path(tmp_path):
-    """The 704 rows of real `vg find -K 19 -E -H` output behind the reference's test_scoring (a region with five SNPs and
-    a deletion, rebuilt from the fixture itself): the fused path reports all of them at threshold 1 and its table is
-    the reference's expected scoring_results.tsv."""
-    from grafimo_amd.extract_regions import DeviceGraph, compute_results_from_graph
-    from grafimo_amd.workflow import Findmotif
-    idx, S, E = scoring_fixture_graph()
-    g = DeviceGraph(idx)
-    motif = _ctcf()
-    with contextlib.redirect_stdout(io.StringIO()) as out:
-        df = compute_results_from_graph(motif, g, [(0, E - S)], True, Findmotif(threshold=1.0, recomb=True))
-    assert "Scanned sequences:\t704" in out.getvalue() and len(df) == 704
-    ref = pd.read_csv(os.path.join(REF_DATA, "scoring_results.tsv"), sep="\t", index_col=0)
-    key = ["p-value", "start", "stop"]
-    df = df.assign(start=df["start"] + S, stop=df["stop"] + S)
-    a = df.sort_values(key + ["matched_sequence"]).reset_index(drop=True)
-    b = ref.sort_values(key + ["matched_sequence"]).reset_index(drop=True)
-    for c in ("start", "stop", "strand", "matched_sequence", "haplotype_frequency", "reference"):
-        assert (a[c].astype(str) == b[c].astype(str)).all(), c
-    for c in ("score", "p-value", "q-value"):
-        np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-9, atol=0)
-    g.close()
-
-
 def test_tiles_with_more_sites_than_the_lds_stage_and_heavy_windows():
     """A hand-made chromosome with a SNP at EVERY position and, every eight bases over a stretch, twenty one-base
     insertions behind one anchor: a tile's site table (262 SNPs + 240 insertions) overflows the 448 records staged in
@@ -224,4 +200,9 @@ def test_config2_scale_graph_and_repeated_calls():
     m8 = _motif_of_width(8)
     a5, b5 = _both(m8, g, regions, threshold=1e-3)                  # another width over the same regions
     _assert_same(a5, b5)
+    # one graph listed several times (chromosome entries of one call may share a handle), entries without regions
+    parts = [regions[:300], regions[300:300], regions[300:]]
+    a6, b6 = _both(motif, [g, g, g], parts, threshold=1e-2)
+    _assert_same(a6, b6)
+    _assert_same(a6, a)
     g.close()
