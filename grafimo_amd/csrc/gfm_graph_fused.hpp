@@ -36,7 +36,11 @@ struct Tile {
     int i_lo, i_hi;           // sites [i_lo, i_hi): pos >= p0 - 1 ... pos < p0 + n_win - 1 + W
     int w_base, pad;          // index of the tile's first window among the call's windows
 };
-struct DelWin { int tile, k, i0, pad; };   // a listed window for graph_score_del_kernel: window k of the tile, its first site
+// a listed window for the deletion kernels: tile and window of the tile (k << 25 | tile: tiles < 2^25), its first site
+struct DelWin { int tile_k, i0; };
+constexpr int kDelTileBits = 25;
+__device__ __forceinline__ int del_tile(const DelWin &d) { return d.tile_k & ((1 << kDelTileBits) - 1); }
+__device__ __forceinline__ int del_k(const DelWin &d) { return (int)((unsigned)d.tile_k >> kDelTileBits); }
 struct HitRec {               // what graph_annotate_kernel writes per hit (120 bytes; numpy dtype in extract_regions.py)
     long long start, stop, freq, q2;
     double qvalue;
@@ -49,10 +53,10 @@ constexpr long long kFusedMaxWalks = 1ll << 40;      // per window; beyond it th
 constexpr int kTileWin = 64;                         // windows per tile = lanes of the wavefront that works on it
 constexpr int kFusedWaves = 8;                       // wavefronts per workgroup of graph_score_kernel (they share the histogram)
 constexpr int kFusedThreads = kTileWin * kFusedWaves;
-constexpr int kWaveSites = 96;                       // site records staged per tile (more: read from global memory)
+constexpr int kWaveSites = 80;                       // site records staged per tile (more: read from global memory)
 constexpr int kWaveRefBytes = 144;                   // kTileWin + GFM_MAX_WIDTH - 1 reference bytes, in 8-byte loads
 constexpr int kFusedDelThreads = 64;
-constexpr int kFusedLayouts = 4;
+constexpr int kFusedLayouts = 8;
 
 struct FusedArgs {
     int W, forward_only;
@@ -63,8 +67,21 @@ struct FusedArgs {
     GraphHit *hits;
     long long hit_cap;
     unsigned long long *hit_count, *n_rows;
-    unsigned *ticket;
+    int listing;                  // 1: listed windows are queued for the deletion kernels (first call of a plan); 0: that list exists
+    const int *plan_overflow;     // a window of the plan's deletion list was refused (read when listing == 0)
+    unsigned long long *dbg;      // measurement aid (GRAFIMO_FUSED_TIMERS=1): [k] sum, [16 + k] max of phase k's 10-ns ticks, [32 + k] count
 };
+__device__ __forceinline__ void dbg_tick(const FusedArgs &a, int slot, unsigned long long &t0)
+{
+    if (!a.dbg) return;
+    const unsigned long long t1 = wall_clock64();
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&a.dbg[slot], t1 - t0);
+        atomicMax(&a.dbg[16 + slot], t1 - t0);
+        atomicAdd(&a.dbg[32 + slot], 1ull);
+    }
+    t0 = wall_clock64();
+}
 
 __device__ __forceinline__ unsigned base_code(unsigned c) { return (c >> 1) & 7u; }
 
@@ -81,12 +98,25 @@ __device__ __forceinline__ SiteRec packed_site(const GraphDev &g, int i)
 struct TileSites {
     const GraphDev &g;
     const SiteRec *lds;
+    const int *reach;         // per staged site index i: max_reach[i] - p0 (how far the deletions BEFORE site i reach), clamped
+    long long p0;
     int i_lo, staged;
     __device__ __forceinline__ SiteRec at(int i) const
     {
         const unsigned d = (unsigned)(i - i_lo);
         return d < (unsigned)staged ? lds[d] : packed_site(g, i);
     }
+    // does a deletion anchored before p remove the base at p?  (i = first site at or behind p)
+    __device__ __forceinline__ bool covered(long long p, int i) const
+    {
+        const unsigned d = (unsigned)(i - i_lo);
+        return d < (unsigned)staged ? (long long)reach[d] >= p - p0 : covered_by_deletion(g, p, i);
+    }
+};
+struct GlobalTileSites {      // the same interface straight from global memory (graph_annotate_kernel)
+    const GraphDev &g;
+    __device__ __forceinline__ SiteRec at(int i) const { return g.site_rec[i]; }
+    __device__ __forceinline__ bool covered(long long p, int i) const { return covered_by_deletion(g, p, i); }
 };
 
 // hits of one wave: one returning atomic per wave that holds any (a p < 1e-4 scan: a few hundred per plan)
@@ -113,8 +143,20 @@ __device__ __forceinline__ void book_score(const FusedArgs &a, unsigned *h, int 
     else atomicAdd(&a.hist[s], 1ull);
 }
 
-// one window as phase 1 / the annotate kernel see it
-struct WinInfo { int i0, ns; long long walks; bool listed; };
+// one window as phase 1 / the annotate kernel see it.  `listed`: the window touches an insertion or a deletion (the
+// sites a walk meets depend on its decisions).  `simple`: ... and all it touches is ONE deletion anchored inside it --
+// nineteen of twenty listed windows of a 1000-Genomes-like graph -- whose walks are then two plain products: layout A
+// along the reference (walks of the sites in [p, p + W)), layout B jumping the deleted bases (sites up to the anchor
+// and from behind the deleted stretch on, W + len positions in all), in that order: the odometer's order
+// (graph_extract.hip: "no jump" before "jump").  graph_score_kernel scores those itself; the rest goes to
+// graph_score_del_kernel.
+struct WinInfo {
+    int i0, ns;                // first site at or behind p; sites in [p, p + W)
+    long long walks;           // plain window: its walks; simple: layout A's; else 0 (-1: refused, more than 2^40)
+    bool listed, simple;
+    long long walks_b;         // simple: layout B's walks
+    int ns_b, jx, del_len;     // simple: sites in [p, p + W + len); the anchor's index in the window; deleted bases
+};
 template <class S>
 __device__ __forceinline__ WinInfo classify_window(const GraphDev &g, const S &sites, long long p, int W, long long limit,
                                                    int i_lo, int i_hi)
@@ -124,39 +166,72 @@ __device__ __forceinline__ WinInfo classify_window(const GraphDev &g, const S &s
         const int mid = (lo + hi) >> 1;
         if (sites.at(mid).pos < p) lo = mid + 1; else hi = mid;
     }
-    WinInfo w{lo, 0, 1, false};
+    WinInfo w{lo, 0, 1, false, false, 0, 0, 0, 0};
     bool over = false;
-    w.listed = g.n_dels > 0 && covered_by_deletion(g, p, lo);
+    const bool covered = g.n_dels > 0 && sites.covered(p, lo);
+    w.listed = covered;
+    int n_indel = 0, first_indel = -1;
     for (int i = lo;; ++i, ++w.ns) {
         const SiteRec r = sites.at(i);
         if (r.pos >= p + W) break;
-        if (r.del_len || r.ins_len) w.listed = true;
-        if (!over) {
+        if (r.del_len || r.ins_len) {
+            w.listed = true;
+            if (n_indel++ == 0) first_indel = i;
+        } else if (!over) {
             w.walks *= 1 + (r.n_alts & 3);
             over = w.walks > kFusedMaxWalks;
         }
     }
+    bool ins_before = false;
     if (g.n_ins > 0) {
         for (int k = lo - 1; k >= i_lo; --k) {
             const SiteRec r = sites.at(k);
             if (r.pos != p - 1) break;
-            if (r.ins_len > 0) w.listed = true;
+            if (r.ins_len > 0) { w.listed = true; ins_before = true; }
         }
         if (!w.listed && p + W > limit) { w.walks = 0; over = false; }
     }
     if (p + W > g.ref_len && !w.listed) w.walks = 0;
+    if (w.listed && !covered && !ins_before && n_indel == 1 && !over) {
+        const SiteRec d = sites.at(first_indel);
+        if (d.del_len > 0) {
+            const long long x = d.pos, len = d.del_len;
+            bool ok = true, over_b = false;
+            long long wb = 1;
+            int nsb = 0;
+            for (int i = lo;; ++i, ++nsb) {                       // layout B's positions: [p, x] and [x + len + 1, p + W + len)
+                const SiteRec r = sites.at(i);
+                if (r.pos >= p + W + len) break;
+                if (r.del_len || r.ins_len) { if (i != first_indel) { ok = false; break; } continue; }
+                if (r.pos > x && r.pos <= x + len) continue;      // inside the deleted stretch: jumped
+                if (!over_b) { wb *= 1 + (r.n_alts & 3); over_b = wb > kFusedMaxWalks; }
+            }
+            if (ok && !over_b) {
+                w.simple = true;
+                w.ns_b = nsb;
+                w.jx = (int)(x - p);
+                w.del_len = (int)len;
+                const bool a_lives = p + W <= limit && p + W <= g.ref_len;
+                const bool b_lives = a_lives && w.jx < W - 1 && p + W + len <= limit && p + W + len <= g.ref_len;
+                if (!a_lives) w.walks = 0;
+                w.walks_b = b_lives ? wb : 0;
+                return w;
+            }
+        }
+    }
     if (w.listed) w.walks = 0;
     else if (over) w.walks = -1;          // refused: more than 2^40 walks
     return w;
 }
 
 // what one wavefront keeps in LDS: of the tile it works on, and the listed windows it has found and not yet handed on
-constexpr int kWaveQueue = 128;
+constexpr int kWaveQueue = 96;
 struct WaveLds {
     SiteRec rec[kWaveSites];
-    long long incl[kTileWin];
-    int i0[kTileWin], ns[kTileWin], bad[kTileWin];
-    unsigned score[kTileWin];
+    long long incl[kTileWin], walks_a[kTileWin];
+    int i0[kTileWin], ns[kTileWin], bad[kTileWin], bad_b[kTileWin], jx[kTileWin], del_len[kTileWin];
+    unsigned score[kTileWin], score_b[kTileWin];
+    int reach[kWaveSites];
     DelWin queue[kWaveQueue];
     unsigned char ref[kWaveRefBytes];
 };
@@ -180,7 +255,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
     unsigned long long *blk_rows = reinterpret_cast<unsigned long long *>(reinterpret_cast<WaveLds *>(tab + GFM_MAX_WIDTH * 8) + kFusedWaves);
     int *blk_q = reinterpret_cast<int *>(blk_rows + kFusedWaves);         // [kFusedWaves] queue lengths, [kFusedWaves] = base
     unsigned *h = reinterpret_cast<unsigned *>(blk_q + kFusedWaves + 2);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W = a.W;
     for (int i = tid; i < W * 8; i += kFusedThreads) tab[i] = tab_arg.v[i];
     for (int i = tid; i <= a.hnb && a.hnb > 0; i += kFusedThreads) h[i] = 0u;
@@ -188,10 +263,26 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
     unsigned long long rows_done = 0;
     int q_n = 0;                                                   // listed windows in this wavefront's queue (uniform)
     const int stride = (int)gridDim.x * kFusedWaves;
-    for (int ti = (int)blockIdx.x * kFusedWaves + wave; ti < n_tiles; ti += stride) {
-        const Tile t = tiles[ti];
+    unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, acc_n = 0;   // measurement aid: this wavefront's ticks per phase
+    auto lap = [&](int slot, unsigned long long &t0) {
+        if (!a.dbg) return;
+        const unsigned long long t1 = wall_clock64();
+        acc_t[slot] += t1 - t0;
+        t0 = t1;
+    };
+    // what the NEXT tile needs from global memory is requested before the current one is worked on and sits in
+    // registers meanwhile: the two dependent round trips per tile (its record; its sites and bases) were 60 % of a
+    // tile's time when every tile began with them
+    struct TilePf { SiteRec r0, r1; int reach0, reach1; unsigned long long refw; };
+    auto reach_of = [&](const Tile &t, int i) -> int {
+        const long long r = (i <= g.n_sites ? g.max_reach[i] : -1ll) - t.p0;
+        return (int)max(-1ll, min(r, 0x7fffffffll));
+    };
+    auto issue = [&](const Tile &t) {
+        TilePf f{};
         const int staged = min(t.i_hi - t.i_lo + 1, kWaveSites);      // (+1: the record that ends a window's site scan)
-        for (int i = lane; i < staged; i += 64) wl->rec[i] = packed_site(g, t.i_lo + i);
+        if (lane < staged) { f.r0 = packed_site(g, t.i_lo + lane); f.reach0 = reach_of(t, t.i_lo + lane); }
+        if (lane + 64 < staged) { f.r1 = packed_site(g, t.i_lo + lane + 64); f.reach1 = reach_of(t, t.i_lo + lane + 64); }
         if (lane < kWaveRefBytes / 8) {
             const long long at = t.p0 + 8 * lane;
             unsigned long long v = 0x4e4e4e4e4e4e4e4eull;                      // 'N's behind the reference's end
@@ -199,21 +290,56 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
             if (at + 8 > g.ref_len)
                 for (int b = 0; b < 8; ++b)
                     if (at + b >= g.ref_len) v = (v & ~(0xffull << (8 * b))) | (0x4eull << (8 * b));
-            *reinterpret_cast<unsigned long long *>(wl->ref + 8 * lane) = v;
+            f.refw = v;
         }
+        return f;
+    };
+    auto commit = [&](const Tile &t, const TilePf &f) {
+        const int staged = min(t.i_hi - t.i_lo + 1, kWaveSites);
+        if (lane < staged) { wl->rec[lane] = f.r0; wl->reach[lane] = f.reach0; }
+        if (lane + 64 < staged) { wl->rec[lane + 64] = f.r1; wl->reach[lane + 64] = f.reach1; }
+        if (lane < kWaveRefBytes / 8) *reinterpret_cast<unsigned long long *>(wl->ref + 8 * lane) = f.refw;
+    };
+    int ti = (int)blockIdx.x * kFusedWaves + wave;
+    Tile t_cur{}, t_nxt{};
+    TilePf pf{};
+    if (ti < n_tiles) {
+        t_cur = tiles[ti];
+        pf = issue(t_cur);
+        if (ti + stride < n_tiles) t_nxt = tiles[ti + stride];
+    }
+    for (; ti < n_tiles; ti += stride) {
+        unsigned long long tk0 = a.dbg ? wall_clock64() : 0ull, tk_tile = tk0;
+        const Tile t = t_cur;
+        commit(t, pf);
         __builtin_amdgcn_wave_barrier();
-        const TileSites sites{g, wl->rec, t.i_lo, staged};
+        if (ti + stride < n_tiles) {
+            pf = issue(t_nxt);
+            t_cur = t_nxt;
+            if (ti + 2 * stride < n_tiles) t_nxt = tiles[ti + 2 * stride];
+        }
+        const int staged = min(t.i_hi - t.i_lo + 1, kWaveSites);
+        const TileSites sites{g, wl->rec, wl->reach, t.p0, t.i_lo, staged};
+        lap(0, tk0);                   // 8: the staged data into LDS, the next tile's loads issued
         // ---- phase 1: lane per window
+        auto ref_at = [&](long long x) -> unsigned {             // a reference base: from the staged bytes if it lies there
+            const long long d = x - t.p0;
+            return (unsigned long long)d < (unsigned long long)kWaveRefBytes ? (unsigned)wl->ref[d]
+                                                                            : (x < g.ref_len ? (unsigned)g.ref[x] : (unsigned)'N');
+        };
         long long walks = 0;
         bool listed = false;
-        WinInfo wi{0, 0, 0, false};
+        WinInfo wi{0, 0, 0, false, false, 0, 0, 0, 0};
         const long long p = t.p0 + lane;
         if (lane < t.n_win) {
             wi = classify_window(g, sites, p, W, t.limit, t.i_lo, t.i_hi);
-            listed = wi.listed;
+            listed = wi.listed && !wi.simple;
             if (wi.walks < 0) { atomicMax(overflow, 1); wi.walks = 0; }
-            walks = wi.walks;
-            if (walks > 0) {                   // the reference window's score on both strands
+            walks = wi.walks + wi.walks_b;
+        }
+        lap(1, tk0);                   // 9: classify
+        if (lane < t.n_win) {
+            if (wi.walks > 0) {                // the reference window's score on both strands
                 unsigned sum = 0;
                 int bad = 0;
                 for (int j = 0; j < W; ++j) {
@@ -224,16 +350,31 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 wl->score[lane] = sum;
                 wl->bad[lane] = bad;
             }
+            if (wi.walks_b > 0) {              // ... and the one of the walk that jumps the deletion
+                unsigned sum = 0;
+                int bad = 0;
+                for (int j = 0; j < W; ++j) {
+                    const unsigned c = base_code(ref_at(p + j + (j > wi.jx ? wi.del_len : 0)));
+                    sum += tab[j * 8 + c];
+                    bad += (int)(c >> 2);
+                }
+                wl->score_b[lane] = sum;
+                wl->bad_b[lane] = bad;
+            }
             wl->i0[lane] = wi.i0;
-            wl->ns[lane] = wi.ns;
+            wl->ns[lane] = wi.ns | (wi.ns_b << 16);
+            wl->walks_a[lane] = wi.walks;
+            wl->jx[lane] = wi.jx;
+            wl->del_len[lane] = wi.del_len;
         }
+        lap(2, tk0);                  // 10: base scores
         // listed windows -> this wavefront's queue; 64 and more of them go to graph_score_del_kernel's list at once
         {
-            const unsigned long long lm = __builtin_amdgcn_ballot_w64(listed);
+            const unsigned long long lm = a.listing ? __builtin_amdgcn_ballot_w64(listed) : 0ull;
             if (lm) {
-                if (listed) wl->queue[q_n + __popcll(lm & ((1ull << lane) - 1ull))] = DelWin{ti, lane, wi.i0, 0};
+                if (listed) wl->queue[q_n + __popcll(lm & ((1ull << lane) - 1ull))] = DelWin{ti | (lane << kDelTileBits), wi.i0};
                 q_n += __popcll(lm);
-                if (q_n >= kTileWin) {
+                if (q_n >= kWaveQueue - kTileWin) {
                     int base = 0;
                     if (lane == 0) base = atomicAdd(del_count, q_n);
                     base = __builtin_amdgcn_readfirstlane(base);
@@ -253,6 +394,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         wl->incl[lane] = incl;
         const long long total = ((long long)__shfl((int)(incl >> 32), 63) << 32) | (unsigned)__shfl((int)(incl & 0xffffffffll), 63);
         __builtin_amdgcn_wave_barrier();
+        lap(3, tk0);                  // 11: listing + scan
         // ---- phase 2: lane per walk
         for (long long base = 0; base < total; base += 64) {
             const long long wt = base + lane;
@@ -268,20 +410,47 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 }
                 k = lo;
                 q = wt - (k ? wl->incl[k - 1] : 0ll);
-                unsigned sum = wl->score[k];
-                int bad = wl->bad[k];
-                long long rest = q;
-                const int i0 = wl->i0[k];
-                for (int s = wl->ns[k] - 1; s >= 0 && rest; --s) {        // digits, last site first
-                    const SiteRec r = sites.at(i0 + s);
-                    const int nall = 1 + (r.n_alts & 3);
-                    const int al = (int)(rest % nall);
-                    rest /= nall;
-                    if (al) {
-                        const int j = r.pos - (int)(t.p0 + k);
-                        const unsigned cr = base_code(wl->ref[k + j]), ca = base_code((unsigned)r.n_alts >> (8 * al));
-                        sum += tab[j * 8 + ca] - tab[j * 8 + cr];
-                        bad += (int)(ca >> 2) - (int)(cr >> 2);
+                const long long wa = wl->walks_a[k];
+                const bool jump = q >= wa;                        // layout B of a one-deletion window
+                const int i0 = wl->i0[k], nsx = wl->ns[k];
+                unsigned sum;
+                int bad;
+                if (!jump) {                                      // the common case: positions p .. p + W - 1
+                    sum = wl->score[k];
+                    bad = wl->bad[k];
+                    long long rest = q;
+                    const int pk = (int)(t.p0 + k);
+                    for (int s = (nsx & 0xffff) - 1; s >= 0 && rest; --s) {        // digits, last site first
+                        const SiteRec r = sites.at(i0 + s);
+                        const int nall = (r.del_len | r.ins_len) ? 1 : 1 + (r.n_alts & 3);     // (a one-deletion window's own record)
+                        const int al = (int)(rest % nall);
+                        rest /= nall;
+                        if (al) {
+                            const int j = r.pos - pk;
+                            const unsigned cr = base_code(wl->ref[k + j]), ca = base_code((unsigned)r.n_alts >> (8 * al));
+                            sum += tab[j * 8 + ca] - tab[j * 8 + cr];
+                            bad += (int)(ca >> 2) - (int)(cr >> 2);
+                        }
+                    }
+                } else {
+                    sum = wl->score_b[k];
+                    bad = wl->bad_b[k];
+                    long long rest = q - wa;
+                    const long long pk = t.p0 + k;
+                    const long long x = pk + wl->jx[k], len = wl->del_len[k];
+                    for (int s = (nsx >> 16) - 1; s >= 0 && rest; --s) {
+                        const SiteRec r = sites.at(i0 + s);
+                        if (r.del_len | r.ins_len) continue;      // (the deletion's own record)
+                        if (r.pos > x && r.pos <= x + len) continue;
+                        const int nall = 1 + (r.n_alts & 3);
+                        const int al = (int)(rest % nall);
+                        rest /= nall;
+                        if (al) {
+                            const int j = (int)(r.pos - pk) - (r.pos > x ? (int)len : 0);
+                            const unsigned cr = base_code(ref_at(r.pos)), ca = base_code((unsigned)r.n_alts >> (8 * al));
+                            sum += tab[j * 8 + ca] - tab[j * 8 + cr];
+                            bad += (int)(ca >> 2) - (int)(cr >> 2);
+                        }
                     }
                 }
                 s_f = bad ? a.min_val : (int)(sum & 0xffffu);
@@ -296,11 +465,21 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         }
         rows_done += (unsigned long long)total * (a.forward_only ? 1ull : 2ull);
         __builtin_amdgcn_wave_barrier();       // the tile's LDS is free again
+        lap(4, tk0);                  // 12: phase 2
+        lap(5, tk_tile);                       // 13: the whole tile
+        ++acc_n;
     }
+    if (a.dbg && lane == 0 && acc_n)
+        for (int k = 0; k < 6; ++k) {
+            atomicAdd(&a.dbg[8 + k], acc_t[k]);
+            atomicMax(&a.dbg[24 + k], acc_t[k]);         // (max over the wavefronts of their SUMS)
+            atomicAdd(&a.dbg[40 + k], acc_n);
+        }
     // once per workgroup: the rows scored, what is left in the wavefronts' queues, the histogram slab
     if (lane == 0) { blk_rows[wave] = rows_done; blk_q[wave] = q_n; }
     __syncthreads();
     if (tid == 0) {
+        if (!a.listing && blockIdx.x == 0 && *a.plan_overflow) atomicMax(overflow, 1);
         unsigned long long rows = 0;
         int left = 0;
         for (int k = 0; k < kFusedWaves; ++k) { rows += blk_rows[k]; left += blk_q[k]; }
@@ -336,19 +515,97 @@ struct ScoreEmit {
 };
 
 
-// The walks of the listed windows (they touch an insertion or a deletion: the sites a walk meets depend on its
-// decisions).  ONE WAVEFRONT per workgroup, 64 listed windows per round: lane per window enumerates its layouts (the
-// odometer over simulate()) and keeps the first four; wave scan of the walk counts; then lane per walk: its layout by
-// comparison, one replay that writes the bases, the reference bases fetched eight at a time, both strands scored from
-// the slot.  These are few, long, latency-bound threads -- 100 000 windows of the bench's graph are 1 600 wavefronts --
-// so what counts is that ALL of them are resident at once: 23 KB of LDS per wavefront (W = 19) lets six or seven share
-// a CU.  (With 128-thread workgroups that also held a 30 KB histogram window, one workgroup fit a CU and the kernel ran
-// three rounds of two wavefronts per CU: 162 us.)  Their scores go to the caller's histogram by global atomics:
-// 400 000 adds spread over thousands of bins.  (The materialising path does the same work in three kernels with a
-// device-wide scan and a host read-back between them.)
+// ---- the walks of the listed windows (they touch an insertion or a deletion: the sites a walk meets depend on its
+// decisions), in two kernels of ONE wavefront per workgroup -- these are few, long, latency-bound threads (the bench's
+// graph: 25 000 windows, 50 000 walks), so what counts is that all of them are resident at once and that no wavefront
+// holds more work than the others:
+//   graph_del_count_kernel  64 listed windows per wavefront: lane per window enumerates its layouts (the odometer over
+//                           simulate()), keeps the first four and the walk count; wave scan; the batch's record goes to
+//                           global memory and its walks are cut into WORK ITEMS of two rounds of 64 walks (at most 64
+//                           items per batch: a batch of a billion walks becomes 64 long items, not a list of millions);
+//   graph_del_score_kernel  one work item per wavefront: lane per walk -- its window by search in the batch's counts, its
+//                           layout by comparison, one replay that writes the bases, the reference bases fetched eight
+//                           at a time, both strands scored from the slot.
+// (One kernel that did both per batch ran as long as its unluckiest wavefront: 130 us for batches of two to eight
+// rounds, all resident at once.  The materialising path does this work in three kernels with a device-wide scan and a host
+// read-back between them.)  Scores go to the caller's histogram by global atomics: a few hundred thousand adds spread
+// over thousands of bins.
+struct DelBatchRec {                       // what graph_del_count_kernel leaves per listed window
+    long long incl;                        // walks of the batch's windows up to and including this one
+    int n_lay, pad;
+    LayoutRec lay[kFusedLayouts];
+};
+struct DelItem { int batch, chunk, n_chunks, pad; };
+constexpr int kDelItemRounds = 1, kDelMaxItems = 64;
+
 __global__ void __launch_bounds__(kFusedDelThreads)
-graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__restrict__ tiles,
-                       const DelWin *__restrict__ del_wins, const int *__restrict__ del_count, int *__restrict__ overflow, int pitch)
+graph_del_count_kernel(GraphDev g, int W, const Tile *__restrict__ tiles, const DelWin *__restrict__ del_wins,
+                       const int *__restrict__ del_count, int *__restrict__ overflow, int *__restrict__ plan_overflow,
+                       DelBatchRec *__restrict__ recs, DelItem *__restrict__ items, int *__restrict__ item_count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+    constexpr int T = kFusedDelThreads;
+    SiteRec *cache = reinterpret_cast<SiteRec *>(fused_lds);                               // [kSiteCache][T]
+    const int lane = threadIdx.x;
+    const int n_listed = *del_count;
+    for (int batch = blockIdx.x; (long long)batch * T < n_listed; batch += gridDim.x) {
+        __syncthreads();
+        const int m = batch * T + lane;
+        long long walks = 0;
+        DelBatchRec rec{};
+        if (m < n_listed) {
+            const DelWin e = del_wins[m];
+            const Tile t = tiles[del_tile(e)];
+            const long long p = t.p0 + del_k(e);
+#pragma unroll
+            for (int k = 0; k < kSiteCache; ++k) cache[k * T + lane] = g.site_rec[e.i0 + k];
+            const CachedSites sites{g.site_rec, cache + lane, e.i0, T};
+            WalkState st;
+            NoVisitor nv;
+            WalkStart ws;
+            bool bad = false;
+            int nl = 0;
+            do {
+                int prefix = 0;
+                do {
+                    long long prod = 0;
+                    const int rc = simulate<NoVisitor, CachedSites, kFusedMaxWalks>(g, sites, p, W, e.i0, ws, prefix, st, nv, 0, 0, prod, t.limit);
+                    if (rc == WALK_OK) {
+                        walks += prod;
+                        if (nl < kFusedLayouts && walks < 0x7fffffffll)      // (a window of 2^31 walks and more: the odometer finds them)
+                            rec.lay[nl] = LayoutRec{(int)walks, ((unsigned)st.nd << 24) | (st.choice & ((1u << st.nd) - 1u)), ws.site, ws.t};
+                        if (walks < 0x7fffffffll) ++nl;
+                    }
+                    if (rc == WALK_OVERFLOW || walks > kFusedMaxWalks) { bad = true; break; }
+                    prefix = next_walk(st);
+                } while (prefix >= 0);
+            } while (!bad && next_start(g, p, e.i0, ws));
+            if (bad) { walks = 0; nl = 0; atomicMax(overflow, 1); atomicMax(plan_overflow, 1); }
+            rec.n_lay = nl;
+        }
+        long long incl = walks;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int lo_ = __shfl_up((int)(incl & 0xffffffffll), d), hi_ = __shfl_up((int)(incl >> 32), d);
+            if (lane >= d) incl += ((long long)hi_ << 32) | (unsigned)lo_;
+        }
+        rec.incl = incl;
+        recs[(size_t)batch * T + lane] = rec;
+        const long long total = ((long long)__shfl((int)(incl >> 32), 63) << 32) | (unsigned)__shfl((int)(incl & 0xffffffffll), 63);
+        const long long rounds = (total + T - 1) / T;
+        const int n_chunks = (int)min((long long)kDelMaxItems, (rounds + kDelItemRounds - 1) / kDelItemRounds);
+        int at = 0;
+        if (lane == 0 && n_chunks) at = atomicAdd(item_count, n_chunks);
+        at = __builtin_amdgcn_readfirstlane(at);
+        if (lane < n_chunks) items[at + lane] = DelItem{batch, lane, n_chunks, 0};
+    }
+}
+
+__global__ void __launch_bounds__(kFusedDelThreads)
+graph_del_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__restrict__ tiles,
+                       const DelWin *__restrict__ del_wins, const int *__restrict__ del_count,
+                       const DelBatchRec *__restrict__ recs, const DelItem *__restrict__ items,
+                       const int *__restrict__ item_count, int pitch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
     constexpr int T = kFusedDelThreads;
@@ -356,67 +613,50 @@ graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__
     SiteRec *cache = reinterpret_cast<SiteRec *>(tab + GFM_MAX_WIDTH * 8);                 // [kSiteCache][T]
     LayoutRec *lay = reinterpret_cast<LayoutRec *>(cache + kSiteCache * T);                // [T][kFusedLayouts]
     long long *w_incl = reinterpret_cast<long long *>(lay + T * kFusedLayouts);            // [T]
-    int *n_lay = reinterpret_cast<int *>(w_incl + T);                                      // [T]
-    int *src = n_lay + T;                                                                  // [T][W]
+    long long *w_p = w_incl + T;                                                           // [T] window starts
+    long long *w_limit = w_p + T;                                                          // [T]
+    int *n_lay = reinterpret_cast<int *>(w_limit + T);                                     // [T]
+    int *w_i0 = n_lay + T, *w_tk = w_i0 + T;                                               // [T] first sites, tile | k
+    int *src = w_tk + T;                                                                   // [T][W]
     unsigned char *slots = reinterpret_cast<unsigned char *>(src + (size_t)T * a.W);       // [T][pitch]
     const int lane = threadIdx.x;
     const int W = a.W;
     for (int i = lane; i < W * 8; i += T) tab[i] = tab_arg.v[i];
-    const int n_listed = *del_count;
+    const int n_items = *item_count, n_listed = *del_count;
     unsigned long long rows_done = 0;
-    for (int batch = blockIdx.x; (long long)batch * T < n_listed; batch += gridDim.x) {
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
         __syncthreads();
-        const int m = batch * T + lane;
-        const bool have = m < n_listed;
-        struct { long long p, limit; int i0; } dw{0, 0, 0};
-        long long walks = 0;
-        int nl = 0;
-        if (have) {
-            const DelWin e = del_wins[m];
-            const Tile t = tiles[e.tile];
-            dw.p = t.p0 + e.k;
-            dw.limit = t.limit;
-            dw.i0 = e.i0;
+        unsigned long long tk0 = a.dbg ? wall_clock64() : 0ull, tk_item = tk0;
+        const DelItem item = items[it];
+        const int m = item.batch * T + lane;
+        {   // the batch's state: what graph_del_count_kernel found, and each window's first site records
+            const DelBatchRec rec = recs[m];       // (written for all 64 lanes of a batch: lanes behind the last listed
+            DelWin e{0, 0};                        // window hold the batch's total and no layout)
+            if (m < n_listed) e = del_wins[m];
+            const Tile t = tiles[del_tile(e)];
+            w_incl[lane] = rec.incl;
+            n_lay[lane] = rec.n_lay;
 #pragma unroll
-            for (int k = 0; k < kSiteCache; ++k) cache[k * T + lane] = g.site_rec[dw.i0 + k];
-            const CachedSites sites{g.site_rec, cache + lane, dw.i0, T};
-            WalkState st;
-            NoVisitor nv;
-            WalkStart ws;
-            bool bad = false;
-            do {
-                int prefix = 0;
-                do {
-                    long long prod = 0;
-                    const int rc = simulate<NoVisitor, CachedSites, kFusedMaxWalks>(g, sites, dw.p, W, dw.i0, ws, prefix, st, nv, 0, 0,
-                                                                                   prod, dw.limit);
-                    if (rc == WALK_OK) {
-                        walks += prod;
-                        if (nl < kFusedLayouts && walks < 0x7fffffffll)      // (a window of 2^31 walks and more: the odometer finds them)
-                            lay[lane * kFusedLayouts + nl] = LayoutRec{(int)walks, ((unsigned)st.nd << 24) | (st.choice & ((1u << st.nd) - 1u)),
-                                                                       ws.site, ws.t};
-                        if (walks < 0x7fffffffll) ++nl;
-                    }
-                    if (rc == WALK_OVERFLOW || walks > kFusedMaxWalks) { bad = true; break; }
-                    prefix = next_walk(st);
-                } while (prefix >= 0);
-            } while (!bad && next_start(g, dw.p, dw.i0, ws));
-            if (bad) { walks = 0; nl = 0; atomicMax(overflow, 1); }
-        }
-        n_lay[lane] = nl;
-        long long incl = walks;
+            for (int k = 0; k < kFusedLayouts; ++k) lay[lane * kFusedLayouts + k] = rec.lay[k];
+            w_p[lane] = t.p0 + del_k(e);
+            w_limit[lane] = t.limit;
+            w_i0[lane] = e.i0;
+            w_tk[lane] = e.tile_k;
+            if (m < n_listed) {
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int lo_ = __shfl_up((int)(incl & 0xffffffffll), d), hi_ = __shfl_up((int)(incl >> 32), d);
-            if (lane >= d) incl += ((long long)hi_ << 32) | (unsigned)lo_;
+                for (int k = 0; k < kSiteCache; ++k) cache[k * T + lane] = g.site_rec[e.i0 + k];
+            }
         }
-        w_incl[lane] = incl;
-        const long long total = ((long long)__shfl((int)(incl >> 32), 63) << 32) | (unsigned)__shfl((int)(incl & 0xffffffffll), 63);
         __syncthreads();
-        for (long long base = 0; base < total; base += T) {
-            const long long wt = base + lane;
+        dbg_tick(a, 0, tk0);                   // 0: staging of the batch's state
+        const long long total = w_incl[T - 1];
+        const long long rounds = (total + T - 1) / T;
+        const long long per = (rounds + item.n_chunks - 1) / item.n_chunks;           // rounds of this item
+        const long long r0 = per * item.chunk, r1 = min(rounds, r0 + per);
+        for (long long round = r0; round < r1; ++round) {
+            const long long wt = round * T + lane;
             const bool live = wt < total;
-            int s_f = 0, s_r = 0, w_tile = 0, w_k = 0;
+            int s_f = 0, s_r = 0, tk = 0;
             long long q0 = 0;
             if (live) {
                 int lo = 0, hi = T - 1;
@@ -424,14 +664,12 @@ graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__
                     const int mid = (lo + hi) >> 1;
                     if (w_incl[mid] > wt) hi = mid; else lo = mid + 1;
                 }
-                const int o = lo;                                   // the lane that owns the walk's window
+                const int o = lo;                                   // the lane that holds the walk's window
                 q0 = wt - (o ? w_incl[o - 1] : 0ll);
-                const DelWin oe = del_wins[batch * T + o];
-                const Tile ot = tiles[oe.tile];
-                const struct { long long p, limit; int i0; } ow{ot.p0 + oe.k, ot.limit, oe.i0};
-                w_tile = oe.tile;
-                w_k = oe.k;
-                const CachedSites sites{g.site_rec, cache + o, ow.i0, T};
+                const long long p = w_p[o], limit = w_limit[o];
+                const int i0 = w_i0[o];
+                tk = w_tk[o];
+                const CachedSites sites{g.site_rec, cache + o, i0, T};
                 WalkState st;
                 WalkStart ws;
                 long long q = q0, prod = 0;
@@ -459,8 +697,7 @@ graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__
                     while (!found && more) {
                         int prefix = 0;
                         for (;;) {
-                            const int rc = simulate<NoVisitor, CachedSites, kFusedMaxWalks>(g, sites, ow.p, W, ow.i0, ws, prefix, st, nv,
-                                                                                           0, 0, prod, ow.limit);
+                            const int rc = simulate<NoVisitor, CachedSites, kFusedMaxWalks>(g, sites, p, W, i0, ws, prefix, st, nv, 0, 0, prod, limit);
                             if (rc == WALK_OK) {
                                 if (q < prod) { found = true; break; }
                                 q -= prod;
@@ -468,15 +705,17 @@ graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__
                             prefix = next_walk(st);
                             if (prefix < 0) break;
                         }
-                        if (!found) more = next_start(g, ow.p, ow.i0, ws);
+                        if (!found) more = next_start(g, p, i0, ws);
                     }
                 }
                 unsigned char *slot = slots + (size_t)lane * pitch;
                 int *my_src = src + (size_t)lane * W;
+                dbg_tick(a, 1, tk0);           // 1: window search + layout (lanes that are live)
                 if (found) {
                     ScoreEmit em{g.alt_bases, g.ins_bases, g.ins_off, slot, my_src};
                     long long again = 0;
-                    simulate<ScoreEmit, CachedSites, kFusedMaxWalks>(g, sites, ow.p, W, ow.i0, ws, st.nd, st, em, q, prod, again, ow.limit);
+                    simulate<ScoreEmit, CachedSites, kFusedMaxWalks>(g, sites, p, W, i0, ws, st.nd, st, em, q, prod, again, limit);
+                    dbg_tick(a, 2, tk0);       // 2: the replay
                     for (int j0 = 0; j0 < W; j0 += 8) {
                         int sx[8];
                         uint8_t c[8];
@@ -497,16 +736,21 @@ graph_score_del_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__
                     }
                     s_f = bad ? a.min_val : (int)(sum & 0xffffu);
                     s_r = bad ? a.min_val : (int)(sum >> 16);
+                    dbg_tick(a, 3, tk0);       // 3: reference bytes + scoring
                     if (a.hist) {
                         atomicAdd(&a.hist[s_f], 1ull);
                         if (!a.forward_only) atomicAdd(&a.hist[s_r], 1ull);
                     }
                 }
             }
+            dbg_tick(a, 4, tk0);               // 4: histogram atomics, reconvergence
+            const int w_tile = tk & ((1 << kDelTileBits) - 1), w_k = (int)((unsigned)tk >> kDelTileBits);
             push_hits(a, live && s_f >= a.cutoff, w_tile, w_k, 2 * q0, s_f);
             if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, w_tile, w_k, 2 * q0 + 1, s_r);
         }
-        if (lane == 0) rows_done += (unsigned long long)total * (a.forward_only ? 1ull : 2ull);
+        if (lane == 0 && r1 > r0) rows_done += (unsigned long long)(min(total, r1 * T) - r0 * T) * (a.forward_only ? 1ull : 2ull);
+        dbg_tick(a, 5, tk0);                   // 5: hits
+        dbg_tick(a, 6, tk_item);               // 6: the whole item
     }
     if (lane == 0 && rows_done) atomicAdd(a.n_rows, rows_done);
 }
@@ -530,18 +774,46 @@ graph_hist_reduce_kernel(const unsigned *__restrict__ slabs, int n_slabs, int hl
     if (sum) atomicAdd(&hist[b < hnb ? hlo + b : min_val], sum);
 }
 
-// ---- the columns of the hit rows.  Thread per hit: tile and window from the entry, then what the materialising emit
-// kernels do for every row -- for a plain window the mixed-radix digits, the bases, the count from the tables (or the
-// bitsets, in place: these are a few hundred threads); for a listed window the odometer up to the walk's rank and one
-// replay with the visitor that collects the haplotype constraints.
+// the AND of the bitsets by a whole wavefront: lane per word (80 words for 5 096 haplotypes), all of a lane's loads in
+// flight together, wave sum -- every lane returns the count.  (One thread per hit walked the words sixteen at a time:
+// tens of microseconds for a walk through six constraint sites, and the kernel is as slow as its slowest hit.)
+template <class F>
+__device__ inline long long count_by_bitsets_wave(const GraphDev &g, int n, F at)
+{
+    const int lane = threadIdx.x & 63;
+    long long count = 0;
+    for (int word = lane; word < g.hw; word += 64) {
+        unsigned long long acc = ~0ull;
+        if (word == g.hw - 1 && (g.n_hap & 63)) acc = (1ull << (g.n_hap & 63)) - 1ull;
+        for (int k = 0; k < n; ++k) {
+            int site, al;
+            at(k, site, al);
+            acc &= allele_word(g, site, al, word);
+        }
+        count += __popcll(acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int lo_ = __shfl_xor((int)(count & 0xffffffffll), off), hi_ = __shfl_xor((int)(count >> 32), off);
+        count += ((long long)hi_ << 32) | (unsigned)lo_;
+    }
+    return count;
+}
+
+// ---- the columns of the hit rows.  WAVEFRONT per hit: every lane follows the same path -- tile and window from the
+// entry, then what the materialising emit kernels do for every row: for a plain window the mixed-radix digits, the
+// bases, the count from the tables; for a listed window the odometer up to the walk's rank and one replay with the
+// visitor that collects the haplotype constraints -- so the chain of loads is one wavefront's, not sixty-four divergent
+// threads', and where the count needs the bitsets the lanes share the words.  Lane 0 writes the record.
 __global__ void __launch_bounds__(64)
 graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, const Tile *__restrict__ tiles, int n_tiles,
                       const GraphHit *__restrict__ hits, const unsigned long long *__restrict__ hit_count, long long hit_cap,
                       const int *__restrict__ d_cutoff, const double *__restrict__ qtable, HitRec *__restrict__ out)
 {
     const long long n = min((long long)*hit_count, hit_cap);
-    const long long hi_ = (long long)blockIdx.x * 64 + threadIdx.x;
+    const long long hi_ = (long long)blockIdx.x;
     if (hi_ >= n) return;
+    const bool writer = threadIdx.x == 0;
     const GraphHit hit = hits[hi_];
     const Tile t = tiles[min(max(hit.tile, 0), n_tiles - 1)];
     const int k = (int)(hit.q2k >> kHitWinShift) & 0xff;
@@ -557,12 +829,11 @@ graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, c
     const bool minus = (q2 & 1) != 0;
     rec.region = t.region;
     rec.strand = minus ? '-' : '+';
-    if (!rec.keep) { out[hi_] = rec; return; }          // a p < t candidate that the q-value cutoff drops
+    if (!rec.keep) { if (writer) out[hi_] = rec; return; }          // a p < t candidate that the q-value cutoff drops
     uint8_t km[2 * GFM_MAX_WIDTH];
     long long end_pos = p + W, count = 0;
     bool any_alt = false;
-    const GlobalSites gs{g.site_rec};
-    const WinInfo wi = classify_window(g, gs, p, W, t.limit, t.i_lo, t.i_hi);
+    const WinInfo wi = classify_window(g, GlobalTileSites{g}, p, W, t.limit, t.i_lo, t.i_hi);
     if (!wi.listed) {
         {
             unsigned long long rw[8];
@@ -574,19 +845,24 @@ graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, c
         }
         unsigned long long dig[2] = {0ull, 0ull};
         long long rest = q;
-        for (int s = wi.ns - 1; s >= 0; --s) {
-            const int nall = 1 + g.n_alts[wi.i0 + s];
+        for (int s_ = wi.ns - 1; s_ >= 0; --s_) {
+            const int nall = 1 + g.n_alts[wi.i0 + s_];
             const unsigned long long al = (unsigned long long)(rest % nall);
             rest /= nall;
-            dig[s >> 5] |= al << (2 * (s & 31));
-            if (al) km[g.pos[wi.i0 + s] - p] = g.alt_bases[(size_t)(wi.i0 + s) * kMaxAlts + (al - 1)];
+            dig[s_ >> 5] |= al << (2 * (s_ & 31));
+            if (al) km[g.pos[wi.i0 + s_] - p] = g.alt_bases[(size_t)(wi.i0 + s_) * kMaxAlts + (al - 1)];
         }
         any_alt = (dig[0] | dig[1]) != 0ull;
         auto at = [&](int kk, int &site, int &al) { site = wi.i0 + kk; al = (int)((dig[kk >> 5] >> (2 * (kk & 31))) & 3ull); };
         bool done;
         count = count_by_tables(g, allele_count, wi.ns, at, done);
-        if (!done) count = count_by_bitsets(g, wi.ns, at);
+        if (!done) count = count_by_bitsets_wave(g, wi.ns, at);
     } else {
+        // the window's first site records in LDS, in one batch: the odometer below is a chain of "what is at x" questions
+        __shared__ SiteRec ann_cache[kSiteCache];
+        if (threadIdx.x < kSiteCache) ann_cache[threadIdx.x] = g.site_rec[wi.i0 + threadIdx.x];
+        __syncthreads();
+        const CachedSites cs{g.site_rec, ann_cache, wi.i0, 1};
         WalkState st;
         WalkStart ws;
         NoVisitor nv;
@@ -595,7 +871,7 @@ graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, c
         while (!found && more) {
             int prefix = 0;
             for (;;) {
-                const int rc = simulate<NoVisitor, GlobalSites, kFusedMaxWalks>(g, gs, p, W, wi.i0, ws, prefix, st, nv, 0, 0, prod, t.limit);
+                const int rc = simulate<NoVisitor, CachedSites, kFusedMaxWalks>(g, cs, p, W, wi.i0, ws, prefix, st, nv, 0, 0, prod, t.limit);
                 if (rc == WALK_OK) {
                     if (rest < prod) { found = true; break; }
                     rest -= prod;
@@ -605,22 +881,23 @@ graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, c
             }
             if (!found) more = next_start(g, p, wi.i0, ws);
         }
-        if (!found) { rec.keep = 0; out[hi_] = rec; return; }      // cannot happen: the score kernel found this walk
+        if (!found) { rec.keep = 0; if (writer) out[hi_] = rec; return; }      // cannot happen: the score kernel found this walk
         int src[GFM_MAX_WIDTH];
         int more_cons[kMaxConstraints - 4];
         DelEmit em(g, km, km + W, src, W, more_cons);
         long long again = 0;
-        simulate<DelEmit, GlobalSites, kFusedMaxWalks>(g, gs, p, W, wi.i0, ws, st.nd, st, em, rest, prod, again, t.limit);
+        simulate<DelEmit, CachedSites, kFusedMaxWalks>(g, cs, p, W, wi.i0, ws, st.nd, st, em, rest, prod, again, t.limit);
         for (int j = 0; j < W; ++j)
             if (src[j] >= 0) km[j] = g.ref[src[j]];
         if (!(ws.site >= 0 && st.last == p - 1)) for_covering_deletions(g, p, wi.i0, [&](int dsite) { em.add(dsite, 0); });
         auto at = [&](int kk, int &site, int &al) { const int v = em.get(kk); site = v >> 4; al = v & 3; };
         bool done;
         count = count_by_tables(g, allele_count, em.n_cons, at, done);
-        if (!done) count = count_by_bitsets(g, em.n_cons, at);
+        if (!done) count = count_by_bitsets_wave(g, em.n_cons, at);
         end_pos = st.last + 1;
         any_alt = em.alt;
     }
+    if (!writer) return;
     rec.freq = count;
     rec.is_ref = any_alt ? 0 : 1;
     rec.start = minus ? end_pos : p;

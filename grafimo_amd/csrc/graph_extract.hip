@@ -1167,8 +1167,18 @@ struct gfm_graph {
     hipEvent_t ev_tiles = nullptr;       // the staging has been copied
     bool tiles_pending = false;
     Buf<DelWin> f_del_wins;
+    Buf<DelBatchRec> f_del_recs;         // per listed window: what graph_del_count_kernel found
+    Buf<DelItem> f_del_items;            // work items of graph_del_score_kernel
     Buf<unsigned> f_slabs;
-    Buf<int> f_flags;                    // [0] tile ticket, [1] listed windows, [2] overflow
+    Buf<unsigned long long> f_dbg;
+    // [0] unused, [1] listed windows, [2] overflow of the call, [3] work items of the deletion kernels, [4] overflow among the
+    // listed windows.  [1], [3], [4] belong to the PLAN -- the list of windows that touch an indel, their layouts and the
+    // work items cut from them depend on the graph, the regions and the width, not on the motif: they are made by the first
+    // call for a tile table and reused by the calls that follow (GRAFIMO scans motif after motif over one BED file)
+    Buf<int> f_flags;
+    bool f_plan_ready = false;
+    hipStream_t f_plan_stream = nullptr;   // the stream the plan was made on; a call on another one waits for ev_plan
+    hipEvent_t ev_plan = nullptr;
     void drop_plan()
     {
         region_off.release(); first_start.release(); region_stop.release(); walk_base.release(); win_start.release(); walks.release();
@@ -1278,10 +1288,11 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_tiles, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_plan, hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_score_del_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_del_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
         gfm_graph_destroy(g);
         return gfail(GFM_ERR_HIP, std::string("event creation failed: ") + hipGetErrorString(e));
@@ -1330,8 +1341,10 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     if (g->side) (void)hipStreamDestroy(g->side);
     if (g->h_back) (void)hipHostFree(g->h_back);
     if (g->ev_tiles) (void)hipEventDestroy(g->ev_tiles);
+    if (g->ev_plan) (void)hipEventDestroy(g->ev_plan);
     if (g->h_tiles) (void)hipHostFree(g->h_tiles);
-    g->f_tiles.release(); g->f_del_wins.release(); g->f_slabs.release(); g->f_flags.release();
+    g->f_tiles.release(); g->f_del_wins.release(); g->f_del_recs.release(); g->f_del_items.release(); g->f_slabs.release();
+    g->f_flags.release();
     delete g;
 }
 
@@ -1589,6 +1602,7 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
                       (nr == 0 || (std::memcmp(g->f_starts.data(), h_starts, nr * sizeof(long long)) == 0 &&
                                    std::memcmp(g->f_stops.data(), h_stops, nr * sizeof(long long)) == 0));
     if (!same) {
+        g->f_plan_ready = false;
         if (g->tiles_pending) {          // the staging buffer may still be read by the last copy
             GX_TRY(hipEventSynchronize(g->ev_tiles));
             g->tiles_pending = false;
@@ -1650,8 +1664,11 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     const bool indels = g->dev.n_dels > 0 || g->dev.n_ins > 0;
     GX_TRY(g->f_del_wins.reserve((size_t)g->f_n_windows + 1));
     GX_TRY(g->f_slabs.reserve((size_t)g1 * (size_t)(hnb + 1) + 1));
-    GX_TRY(g->f_flags.reserve(4));
-    GX_TRY(hipMemsetAsync(g->f_flags.p, 0, 4 * sizeof(int), st));
+    GX_TRY(g->f_flags.reserve(8));
+    const bool listing = indels && !g->f_plan_ready;
+    if (indels && !listing && st != g->f_plan_stream) GX_TRY(hipStreamWaitEvent(st, g->ev_plan, 0));
+    if (listing || !indels) GX_TRY(hipMemsetAsync(g->f_flags.p, 0, 8 * sizeof(int), st));
+    else GX_TRY(hipMemsetAsync(g->f_flags.p + 2, 0, sizeof(int), st));
     FusedTab tab{};
     {
         static const int row_of_code[4] = {0, 1, 3, 2};       // code 2 = T (row 3), code 3 = G (row 2)
@@ -1675,27 +1692,58 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     a.hit_cap = hit_capacity;
     a.hit_count = reinterpret_cast<unsigned long long *>(d_hit_count);
     a.n_rows = reinterpret_cast<unsigned long long *>(d_n_rows);
-    a.ticket = reinterpret_cast<unsigned *>(g->f_flags.p);
+    a.listing = listing ? 1 : 0;
+    a.plan_overflow = g->f_flags.p + 4;
+    static const bool timers = [] { const char *e = std::getenv("GRAFIMO_FUSED_TIMERS"); return e && *e == '1'; }();
+    if (timers) {
+        GX_TRY(g->f_dbg.reserve(48));
+        GX_TRY(hipMemsetAsync(g->f_dbg.p, 0, 48 * sizeof(unsigned long long), st));
+        a.dbg = g->f_dbg.p;
+    }
     const size_t hist_bytes = with_hist ? sizeof(unsigned) * (size_t)(hnb + 1) : 0;
     const size_t lds1 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(WaveLds) * kFusedWaves + sizeof(long long) * kFusedWaves +
                         sizeof(int) * (kFusedWaves + 2) + hist_bytes;
     hipLaunchKernelGGL(graph_score_kernel, dim3((unsigned)g1), dim3(kFusedThreads), lds1, st, g->dev, a, tab, g->f_tiles.p,
                        g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2);
     if (indels) {
+        // the listed windows' walks: count + cut into work items, then one wavefront per item (gfm_graph_fused.hpp)
+        const size_t n_batches = ((size_t)g->f_n_windows + kFusedDelThreads - 1) / kFusedDelThreads;
+        GX_TRY(g->f_del_recs.reserve(n_batches * kFusedDelThreads + 1));
+        GX_TRY(g->f_del_items.reserve(n_batches * kDelMaxItems + 1));
+        if (listing) {
+            const size_t lds_a = sizeof(SiteRec) * kSiteCache * kFusedDelThreads;
+            hipLaunchKernelGGL(graph_del_count_kernel, dim3((unsigned)(12 * n_cu)), dim3(kFusedDelThreads), lds_a, st, g->dev, W,
+                               g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_flags.p + 4, g->f_del_recs.p,
+                               g->f_del_items.p, g->f_flags.p + 3);
+            g->f_plan_ready = true;       // (stream order: the calls that follow on this stream find the plan complete)
+            g->f_plan_stream = st;
+            GX_TRY(hipEventRecord(g->ev_plan, st));
+        }
         int pitch = ((W + 3) / 4) * 4;
         if ((pitch / 4) % 2 == 0) pitch += 4;         // an odd dword pitch: the lanes' slots fall on all LDS banks
-        const size_t lds2 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(SiteRec) * kSiteCache * kFusedDelThreads +
-                            sizeof(LayoutRec) * kFusedDelThreads * kFusedLayouts + sizeof(long long) * kFusedDelThreads +
-                            sizeof(int) * kFusedDelThreads + sizeof(int) * (size_t)kFusedDelThreads * W +
-                            (size_t)kFusedDelThreads * pitch;
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 * 1024) / lds2));
-        hipLaunchKernelGGL(graph_score_del_kernel, dim3((unsigned)(per_cu * n_cu)), dim3(kFusedDelThreads), lds2, st, g->dev, a, tab,
-                           g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, pitch);
+        const size_t lds_b = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(SiteRec) * kSiteCache * kFusedDelThreads +
+                             sizeof(LayoutRec) * kFusedDelThreads * kFusedLayouts + 3 * sizeof(long long) * kFusedDelThreads +
+                             3 * sizeof(int) * kFusedDelThreads + sizeof(int) * (size_t)kFusedDelThreads * W +
+                             (size_t)kFusedDelThreads * pitch;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 * 1024) / lds_b));
+        hipLaunchKernelGGL(graph_del_score_kernel, dim3((unsigned)(per_cu * n_cu)), dim3(kFusedDelThreads), lds_b, st, g->dev, a, tab,
+                           g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_del_recs.p, g->f_del_items.p, g->f_flags.p + 3,
+                           pitch);
     }
     if (with_hist)
         hipLaunchKernelGGL(graph_hist_reduce_kernel, dim3((unsigned)((hnb + 1 + 255) / 256), (unsigned)((g1 + kSlabGroup - 1) / kSlabGroup)),
                            dim3(256), 0, st, g->f_slabs.p, g1, hlo, hnb, min_val, reinterpret_cast<unsigned long long *>(d_hist));
     GX_TRY(hipGetLastError());
+    if (timers) {      // measurement aid: what the wavefronts of graph_del_score_kernel spent where (10-ns ticks)
+        unsigned long long h[48];
+        int fl[4];
+        GX_TRY(hipStreamSynchronize(st));
+        GX_TRY(hipMemcpy(h, g->f_dbg.p, sizeof h, hipMemcpyDeviceToHost));
+        GX_TRY(hipMemcpy(fl, g->f_flags.p, sizeof fl, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[fused] listed windows %d, work items %d\n", fl[1], fl[3]);
+        for (int k = 0; k < 16; ++k)
+            if (h[32 + k]) std::fprintf(stderr, "[fused] phase %d: n %llu, mean %.2f us, max %.2f us\n", k, h[32 + k], 0.01 * (double)h[k] / (double)h[32 + k], 0.01 * (double)h[16 + k]);
+    }
     if (d_overflow) GX_TRY(hipMemcpyAsync(d_overflow, g->f_flags.p + 2, sizeof(int), hipMemcpyDeviceToDevice, st));
     return GFM_OK;
 }
@@ -1707,7 +1755,8 @@ GFM_API int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t
     if (hit_capacity <= 0 || g->f_n_tiles == 0) return GFM_OK;
     if (!d_hits || !d_hit_count || !d_records) return gfail(GFM_ERR_INVALID, "NULL device buffer");
     static_assert(sizeof(HitRec) == sizeof(gfm_graph_hit_t) && sizeof(GraphHit) == 16, "record layouts of the C ABI");
-    const unsigned blocks = (unsigned)((hit_capacity + 63) / 64);
+    if (hit_capacity > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "hit capacity beyond 2^31");
+    const unsigned blocks = (unsigned)hit_capacity;            // a wavefront per entry; those behind the count exit at once
     hipLaunchKernelGGL(graph_annotate_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), g->dev,
                        g->d_allele_count, g->f_width, g->f_tiles.p, g->f_n_tiles, static_cast<const GraphHit *>(d_hits),
                        reinterpret_cast<const unsigned long long *>(d_hit_count), (long long)hit_capacity, d_cutoff, d_qtable,
