@@ -103,6 +103,7 @@ PROTOTYPES = {
                                  c_void_p, c_i64, c_void_p, c_i32, P(c_void_p)]),
     "gfm_graph_destroy": (None, [c_void_p]),
     "gfm_graph_plan": (c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_i32, P(c_i64), P(c_i64)]),
+    "gfm_graph_plan_windows": (c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32, P(c_i64), P(c_i64)]),
     "gfm_graph_emit": (c_int, [c_void_p] * 10),
     "gfm_graph_score": (c_int, [c_void_p, c_void_p, c_i32, c_void_p, c_void_p, ctypes.c_uint32, c_i32, c_void_p, c_void_p, c_i64,
                                 c_void_p, c_void_p, c_void_p, P(c_i64), c_void_p]),

@@ -50,7 +50,10 @@ int gfail(int code, const std::string &msg)
 constexpr int kMaxAlts = 3;
 constexpr int kCountThreads = 256;
 constexpr int kEmitThreads = 256;                    // walks (threads) per workgroup of the emit kernel
-constexpr long long kMaxWalksPerWindow = 1ll << 20;  // refuse pathological windows (2^20 walks)
+// walks of one window that the MATERIALISING path can hold: what one plan can (2^30 walks = 2^31 rows: the row indices of
+// its kernels are 32-bit, and 2^31 rows of W + 34 bytes are what one MI355X's HBM holds at W = 64).  A window beyond it
+// has no rows to give -- the fused path (gfm_graph_score) scores up to 2^40 walks per window without writing any.
+constexpr long long kMaxWalksPerWindow = 1ll << 30;
 
 // One site as the walk simulation reads it: one 16-byte load instead of four loads from four arrays.  The array holds
 // kSitePad records behind the last site whose pos is kNoSitePos, so a scan for "the sites at x" ends by itself.
@@ -1354,6 +1357,27 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     if (!g || n_regions < 0 || (n_regions && (!h_starts || !h_stops)))
         return gfail(GFM_ERR_INVALID, "bad argument");
     if (width < 1 || width > GFM_MAX_WIDTH) return gfail(GFM_ERR_INVALID, "width outside [1, 64]");
+    // windows of region r: starts p in [max(S,0), min(E, ref_len) - W]  (vg find -p S-E -K W, pinned by
+    // expected_seqs.tsv: x:0-20, W=19 -> p in {0, 1}); with insertions in the graph a walk that reads inserted bases
+    // may start later: p up to E - 1
+    std::vector<int64_t> first((size_t)n_regions), last((size_t)n_regions), limit((size_t)n_regions);
+    for (int r = 0; r < n_regions; ++r) {
+        const long long s = std::max<long long>(h_starts[r], 0);
+        const long long e = std::min<long long>(h_stops[r], g->dev.ref_len);
+        first[(size_t)r] = s;
+        limit[(size_t)r] = e;
+        last[(size_t)r] = e - (g->dev.n_ins > 0 ? 1 : width);
+    }
+    return gfm_graph_plan_windows(g, n_regions, first.data(), last.data(), limit.data(), width, n_windows, n_rows);
+}
+
+GFM_API int gfm_graph_plan_windows(gfm_graph_t g, int32_t n_ranges, const int64_t *h_first, const int64_t *h_last,
+                                   const int64_t *h_limit, int32_t width, int64_t *n_windows, int64_t *n_rows)
+{
+    const int32_t n_regions = n_ranges;
+    if (!g || n_regions < 0 || (n_regions && (!h_first || !h_last || !h_limit)))
+        return gfail(GFM_ERR_INVALID, "bad argument");
+    if (width < 1 || width > GFM_MAX_WIDTH) return gfail(GFM_ERR_INVALID, "width outside [1, 64]");
     if (g->emit_pending) {   // the last emit may still read the plan buffers this call rewrites / frees
         GX_TRY(hipEventSynchronize(g->ev_emitted));
         g->emit_pending = false;
@@ -1361,16 +1385,14 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     g->n_windows = g->n_walks = 0;
     g->width = width;
     g->n_regions = n_regions;
-    // windows of region r: starts p in [max(S,0), min(E, ref_len) - W]  (vg find -p S-E -K W, pinned by
-    // expected_seqs.tsv: x:0-20, W=19 -> p in {0, 1})
     std::vector<long long> off(n_regions + 1, 0), first(n_regions, 0), rstop(n_regions, 0);
     for (int r = 0; r < n_regions; ++r) {
-        const long long s = std::max<long long>(h_starts[r], 0);
-        const long long e = std::min<long long>(h_stops[r], g->dev.ref_len);
+        const long long s = std::max<long long>(h_first[r], 0);
+        const long long e = std::min<long long>(h_limit[r], g->dev.ref_len);
         first[r] = s;
         rstop[r] = e;
-        // without insertions the last start is E - W; with them a walk that reads inserted bases may start later
-        off[r + 1] = off[r] + std::max<long long>(0, e - (g->dev.n_ins > 0 ? 1 : width) - s + 1);
+        // (a plain window must end inside its region; with insertions in the graph the kernels check that per walk)
+        off[r + 1] = off[r] + std::max<long long>(0, std::min<long long>(h_last[r], e - (g->dev.n_ins > 0 ? 1 : width)) - s + 1);
     }
     if (n_windows) *n_windows = off[n_regions];
     if (n_rows) *n_rows = 0;
@@ -1448,8 +1470,10 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
     const long long total = back[0];
     total_del = back[1];
     const int overflow = (int)back[4];
-    if (overflow) return gfail(GFM_ERR_OVERFLOW, "a window holds more than 2^20 walks through its sites");
-    if (total > 0x3fffffffll) return gfail(GFM_ERR_INVALID, "too many rows in one plan (split the regions)");
+    if (overflow) return gfail(GFM_ERR_OVERFLOW, "a window holds more than 2^30 walks through its sites: its rows do not fit one plan");
+    // (GRAFIMO_PLAN_MAX_WALKS: test aid -- a small cap makes callers cut their regions into several plans)
+    static const long long plan_cap = [] { const char *e = std::getenv("GRAFIMO_PLAN_MAX_WALKS"); return e ? std::min(atoll(e), 0x3fffffffll) : 0x3fffffffll; }();
+    if (total > plan_cap) return gfail(GFM_ERR_OVERFLOW, "more than 2^31 rows in one plan (split the regions)");
     if (total > 0) {
         GX_TRY(g->walk_window.reserve((size_t)total));
         hipLaunchKernelGGL(graph_map_kernel, dim3(blocks), dim3(kCountThreads), 0, nullptr, (long long)nw,
@@ -1471,7 +1495,7 @@ GFM_API int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_st
         if (const char *e = std::getenv("GRAFIMO_EXTRACT_DEL_POOL"))   // test aid: a small pool makes deletion walks count in place
             del_pool = std::min<unsigned long long>(del_pool, strtoull(e, nullptr, 10));
         if (slow[0] + (unsigned long long)total_del > 0x7fffffffull || slow[1] + del_pool > 0x7fffffffull)
-            return gfail(GFM_ERR_INVALID, "too many multi-site walks in one plan (split the regions)");
+            return gfail(GFM_ERR_OVERFLOW, "too many multi-site walks in one plan (split the regions)");
         GX_TRY(g->job_head.reserve((size_t)(slow[0] + (unsigned long long)total_del) + 1));
         GX_TRY(g->job_pool.reserve((size_t)(slow[1] + del_pool) + 1));
         g->jobs = CountJobs{g->flag.p + 6, g->job_head.p, g->job_pool.p, (int)slow[0], (int)slow[1], (int)total_del, (int)del_pool};

@@ -576,43 +576,76 @@ class DeviceGraph:
         return count, n_rows, over, recs
 
     def extract(self, regions: Sequence[Tuple[int, int]], width: int, stream=None) -> ExtractedKmers:
-        """All rows of `vg find -p chrom:S-E -K width -E -H` for the given (S, E) regions."""
+        """All rows of `vg find -p chrom:S-E -K width -E -H` for the given (S, E) regions, on the device.  One plan holds
+        at most 2^31 rows; regions whose rows are more are planned piece by piece (extract_chunks) and the pieces joined
+        here -- `for part in graph.extract_chunks(...)` avoids the joined copy."""
+        torch = _torch()
+        parts = list(self.extract_chunks(regions, width, stream))
+        if len(parts) == 1:
+            return parts[0]
+        cat = lambda name: torch.cat([getattr(p_, name) for p_ in parts])     # noqa: E731
+        return ExtractedKmers(self.index.chrom, parts[0].regions, width, cat("kmers"), cat("start"), cat("stop"),
+                              cat("strand"), cat("freq"), cat("is_ref"), cat("region"), cat("walk"))
+
+    def extract_chunks(self, regions: Sequence[Tuple[int, int]], width: int, stream=None):
+        """The rows of extract() as a sequence of ExtractedKmers pieces in row order, each the output of ONE plan
+        (gfm_graph_plan_windows + gfm_graph_emit).  A set of regions that does not fit one plan (GFM_ERR_OVERFLOW: more
+        than 2^31 rows) is cut in halves -- region list first, then a region's range of window starts -- until every
+        piece fits; `region` of every piece indexes the caller's regions.  Only a SINGLE window of more than 2^30 walks
+        (thirty and more biallelic sites inside one k-mer) has no rows to give: `vg find -K` would print them, here they
+        would not fit the device -- compute_results_from_graph scores such windows without writing their rows."""
         torch = _torch()
         starts, stops = _region_arrays(regions)
+        regions = list(regions) if not isinstance(regions, np.ndarray) else [tuple(r) for r in np.asarray(regions).reshape(-1, 2).tolist()]
+        L = len(self.index.ref)
+        tail = 1 if bool((self.index.ins_len > 0).any()) else int(width)
+        first = np.maximum(starts, 0)
+        limit = np.minimum(stops, L)
+        last = limit - tail
+        dev = self.device
         nw, nr = ctypes.c_int64(), ctypes.c_int64()
-        with torch.cuda.device(self.device):
-            rc = nv.lib().gfm_graph_plan(self._h, len(regions), nv.ptr(starts), nv.ptr(stops), int(width),
-                                         ctypes.byref(nw), ctypes.byref(nr))
-            if rc == nv.GFM_ERR_OVERFLOW and len(regions) > 1:
-                # a window with more than 2^20 walks (twenty and more variant sites inside one k-mer): name the regions, the
-                # way a user can act on it -- `vg find -K W -E` would list every one of those walks
-                bad = []
-                for k in range(len(regions)):
-                    if nv.lib().gfm_graph_plan(self._h, 1, nv.ptr(starts[k:k + 1]), nv.ptr(stops[k:k + 1]), int(width),
-                                               ctypes.byref(nw), ctypes.byref(nr)) == nv.GFM_ERR_OVERFLOW:
-                        bad.append(f"{self.index.chrom}:{int(starts[k])}-{int(stops[k])}")
-                        if len(bad) == 8:
-                            break
-                raise nv.NativeError(rc, f"a window of width {int(width)} holds more than 2^20 walks through its variant sites in "
-                                         f"region(s) {', '.join(bad)}{' ...' if len(bad) == 8 else ''}: leave them out of the BED "
-                                         f"file or scan them with a shorter motif")
+        # pieces still to plan, in row order: (region ids, first window starts, last window starts)
+        todo = [(np.arange(len(starts), dtype=np.int64), first, last)]
+        if len(starts) == 0:
+            todo = [(np.zeros(0, np.int64), first, last)]
+        while todo:
+            ids, f_, l_ = todo.pop(0)
+            lim_ = np.ascontiguousarray(limit[ids])
+            f_, l_ = np.ascontiguousarray(f_, dtype=np.int64), np.ascontiguousarray(l_, dtype=np.int64)
+            with torch.cuda.device(dev):
+                rc = nv.lib().gfm_graph_plan_windows(self._h, len(ids), nv.ptr(f_), nv.ptr(l_), nv.ptr(lim_), int(width),
+                                                     ctypes.byref(nw), ctypes.byref(nr))
+            if rc == nv.GFM_ERR_OVERFLOW:
+                if len(ids) > 1:                         # halve the list of ranges
+                    h = len(ids) // 2
+                    todo[:0] = [(ids[:h], f_[:h], l_[:h]), (ids[h:], f_[h:], l_[h:])]
+                    continue
+                if int(l_[0]) > int(f_[0]):              # halve the range of window starts
+                    m = (int(f_[0]) + int(l_[0])) // 2
+                    todo[:0] = [(ids, np.array([f_[0]]), np.array([m])), (ids, np.array([m + 1]), np.array([l_[0]]))]
+                    continue
+                s_, e_ = regions[int(ids[0])]
+                raise nv.NativeError(rc, f"the window of width {int(width)} that starts at {self.index.chrom}:{int(f_[0])} (region "
+                                         f"{self.index.chrom}:{s_}-{e_}) holds more than 2^30 walks through its variant sites: its rows "
+                                         f"do not fit the device; compute_results_from_graph scores them without writing them")
             nv.check(rc)
             n = int(nr.value)
-            dev = self.device
-            kmers = torch.empty((n, width), dtype=torch.uint8, device=dev)
-            start = torch.empty(n, dtype=torch.int64, device=dev)
-            stop = torch.empty(n, dtype=torch.int64, device=dev)
-            strand = torch.empty(n, dtype=torch.uint8, device=dev)
-            freq = torch.empty(n, dtype=torch.int64, device=dev)
-            is_ref = torch.empty(n, dtype=torch.uint8, device=dev)
-            region = torch.empty(n, dtype=torch.int32, device=dev)
-            walk = torch.empty(n, dtype=torch.int32, device=dev)
-            if n:
-                nv.check(nv.lib().gfm_graph_emit(self._h, kmers.data_ptr(), start.data_ptr(), stop.data_ptr(),
-                                                 strand.data_ptr(), freq.data_ptr(), is_ref.data_ptr(),
-                                                 region.data_ptr(), walk.data_ptr(), _stream_ptr(stream)))
-        return ExtractedKmers(self.index.chrom, regions, width, kmers, start, stop, strand, freq, is_ref,
-                              region, walk)
+            with torch.cuda.device(dev):
+                kmers = torch.empty((n, width), dtype=torch.uint8, device=dev)
+                start = torch.empty(n, dtype=torch.int64, device=dev)
+                stop = torch.empty(n, dtype=torch.int64, device=dev)
+                strand = torch.empty(n, dtype=torch.uint8, device=dev)
+                freq = torch.empty(n, dtype=torch.int64, device=dev)
+                is_ref = torch.empty(n, dtype=torch.uint8, device=dev)
+                region = torch.empty(n, dtype=torch.int32, device=dev)
+                walk = torch.empty(n, dtype=torch.int32, device=dev)
+                if n:
+                    nv.check(nv.lib().gfm_graph_emit(self._h, kmers.data_ptr(), start.data_ptr(), stop.data_ptr(),
+                                                     strand.data_ptr(), freq.data_ptr(), is_ref.data_ptr(),
+                                                     region.data_ptr(), walk.data_ptr(), _stream_ptr(stream)))
+                    if not np.array_equal(ids, np.arange(len(ids))):
+                        region = torch.from_numpy(ids.astype(np.int32)).to(dev)[region.long()]     # piece -> caller's regions
+            yield ExtractedKmers(self.index.chrom, regions, width, kmers, start, stop, strand, freq, is_ref, region, walk)
 
 
 def write_region_tsvs(index: GraphIndex, rows: ExtractedKmers, out_dir: str, labels: Optional[Sequence[str]] = None,

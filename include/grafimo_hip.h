@@ -360,7 +360,9 @@ void gfm_scan_release_buffers(void);
  *   p - 1 (start = p); with insertions in the graph windows start at p in [S, E - 1] and a walk is kept if its
  *   stop lies inside the region.
  * gfm_graph_plan: regions [S, E] as vg takes them (windows start at p in [S, E - W]); returns the
- *   number of windows and of rows (2 per walk: forward, reverse complement).  Synchronous.
+ *   number of windows and of rows (2 per walk: forward, reverse complement).  Synchronous.  GFM_ERR_OVERFLOW: the rows do not
+ *   fit one plan (more than 2^31 of them; a single window of more than 2^30 walks) -- plan fewer windows at a time
+ *   (gfm_graph_plan_windows), or use gfm_graph_score, which writes no rows.
  * gfm_graph_emit: rows of the last plan, window-major, walks in mixed-radix order with the LAST site
  *   of the window varying fastest (windows that touch a deletion: layout-major -- the vectors of
  *   jumps over deletions in lexicographic order, "no jump" first, and on one such layout the mixed
@@ -377,6 +379,11 @@ int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_sites, con
 void gfm_graph_destroy(gfm_graph_t g);
 int gfm_graph_plan(gfm_graph_t g, int32_t n_regions, const int64_t *h_starts, const int64_t *h_stops,
                    int32_t width, int64_t *n_windows, int64_t *n_rows);
+/* gfm_graph_plan for RANGES OF WINDOW STARTS: range r holds the windows p in [h_first[r], h_last[r]] of a region that ends at
+ * h_limit[r] (a walk is kept if it ends inside its region) -- what a caller uses to cut a region whose rows do not fit one
+ * plan (GFM_ERR_OVERFLOW: more than 2^31 rows) into several; d_region of gfm_graph_emit then indexes the ranges. */
+int gfm_graph_plan_windows(gfm_graph_t g, int32_t n_ranges, const int64_t *h_first, const int64_t *h_last,
+                           const int64_t *h_limit, int32_t width, int64_t *n_windows, int64_t *n_rows);
 int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, int64_t *d_stop, uint8_t *d_strand,
                    int64_t *d_freq, uint8_t *d_is_ref, int32_t *d_region, int32_t *d_walk, void *stream);
 

@@ -534,22 +534,82 @@ def test_deferred_and_in_place_haplotype_counts_agree(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_a_window_of_too_many_walks_names_its_region():
-    """Twenty-two neighbouring biallelic sites inside one 30-mer are 2^22 walks: the plan is refused (vg find -E would list
-    them all), and the message names the region that holds the window, not the others."""
-    from grafimo_amd import _native as nv
+def test_windows_of_millions_of_walks_are_planned_not_refused():
+    """Twenty-four neighbouring biallelic sites inside one 30-mer are 2^24 walks per window: `vg find -K 30 -E` lists them
+    all, so the plan is NOT refused (round 3 refused windows beyond 2^20 walks).  Three such windows: the row
+    count is the allele product, the k-mers of a window are all different, sampled rows are the reference with the walk's
+    mixed-radix alleles put in, and the FUSED path's score histogram equals the bincount of the scores of these rows."""
+    from grafimo_amd.device import DeviceMotif
     from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
     rng = np.random.default_rng(3)
-    ref = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 600)]
-    pos = np.arange(300, 322, dtype=np.int32)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = acgt[rng.integers(0, 4, 600)]
+    pos = np.arange(300, 324, dtype=np.int32)
     alt = np.zeros((len(pos), 3), np.uint8)
     alt[:, 0] = np.where(ref[pos] == ord("A"), ord("C"), ord("A"))
     idx = GraphIndex("c", ref, pos, np.ones(len(pos), np.uint8), alt, None, 0)
     g = DeviceGraph(idx)
-    ok = g.extract([(0, 200), (400, 600)], 30)
-    assert len(ok) == 2 * (171 + 171)
-    with pytest.raises(nv.NativeError) as e:
-        g.extract([(0, 200), (250, 400), (400, 600)], 30)
-    assert e.value.code == nv.GFM_ERR_OVERFLOW and "c:250-400" in str(e.value) and "c:0-200" not in str(e.value)
-    assert len(g.extract([(0, 200), (250, 400)], 8)) > 0        # a shorter motif fits: at most eight sites per window
+    W, S = 30, 294                                    # windows 294, 295, 296 hold all 24 sites
+    rows = g.extract([(0, 200), (S, S + 2 + W)], W)
+    n_plain = 2 * 171
+    assert len(rows) == n_plain + 2 * 3 * (1 << 24)
+    first = rows.kmers[n_plain:n_plain + 2 * (1 << 24):2]                      # forward rows of window 294
+    code = (first >> 1) & 3
+    key = torch.zeros(first.shape[0], dtype=torch.int64, device=first.device)
+    for j in range(W):
+        key = key * 4 + code[:, j].to(torch.int64)
+    assert int(torch.unique(key).numel()) == 1 << 24
+    take = rng.integers(n_plain, len(rows), 300)
+    km, st, sp = rows.kmers[take].cpu().numpy(), rows.start[take].cpu().numpy(), rows.stop[take].cpu().numpy()
+    sd, wk, rg = rows.strand[take].cpu().numpy(), rows.walk[take].cpu().numpy(), rows.region[take].cpu().numpy()
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    for i in range(len(take)):
+        p = int(st[i]) if sd[i] == ord("+") else int(sp[i])
+        _, alleles = idx.walk_alleles(p, W, int(wk[i]))
+        want = ref[p:p + W].copy()
+        for k, a in enumerate(alleles):
+            if a:
+                want[pos[k] - p] = alt[k, a - 1]
+        if sd[i] == ord("-"):
+            want = np.array([comp[c] for c in want[::-1]], np.uint8)
+        assert km[i].tobytes() == want.tobytes() and rg[i] == 1 and abs(int(sp[i]) - int(st[i])) == W
+    # the fused path walks the same windows (heavy tiles: 2^24 walks per window) and books the same scores
+    rec = __import__("grafimo_amd.synth", fromlist=["x"]).synthetic_motif(W, np.random.default_rng(5), np.full(4, 0.25))
+    dm = DeviceMotif(rec["sm"], rec["bg"], rec["min_val"], rec["scale"], rec["offset"])
+    sc = torch.empty(len(rows), dtype=torch.int32, device=rows.kmers.device)
+    dm.score(rows.kmers, sc)
+    hist = torch.zeros(dm.L, dtype=torch.int64, device=sc.device)
+    reg = np.array([(0, 200), (S, S + 2 + W)], dtype=np.int64)
+    g.score(dm, np.ascontiguousarray(reg[:, 0]), np.ascontiguousarray(reg[:, 1]), dm.pvalue_cutoff(1e-7), hist=hist)
+    count, n_rows, over, recs = g.fused_results()
+    assert n_rows == len(rows) and not over
+    assert torch.equal(hist, torch.bincount(sc.long(), minlength=dm.L))
+    dm.close()
     g.close()
+
+
+@pytest.mark.gpu
+def test_regions_beyond_one_plan_are_cut_into_pieces(tmp_path):
+    """A plan holds at most 2^31 rows (GRAFIMO_PLAN_MAX_WALKS lowers that for this test; tests/plan_pieces_probe.py runs in
+    its own process): extract() then plans the regions in pieces -- the region list halved, then a region's range of window
+    starts -- and joins them: the same rows, the same region indices, as one plan gives.  Only a single window beyond the
+    cap has no rows to give; the message names it."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    probe = os.path.join(ROOT, "tests", "plan_pieces_probe.py")
+    outs, pieces = [], []
+    for cap in (1 << 17, 0x3fffffff):
+        out = str(tmp_path / f"rows_{cap}.npz")
+        r = subprocess.run([sys.executable, probe, "rows", out], capture_output=True, text=True,
+                           env=dict(os.environ, GRAFIMO_PLAN_MAX_WALKS=str(cap)), timeout=600)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        pieces.append(int(r.stdout.split("pieces")[1].split()[0]))
+        outs.append(np.load(out))
+    assert pieces[0] > 3 and pieces[1] == 1
+    assert len(outs[0]["st"]) > 1_500_000 and (np.diff(outs[0]["rg"]) >= 0).all() and set(outs[0]["rg"].tolist()) == {0, 1, 2, 3, 4}
+    for k in ("km", "st", "sp", "rg", "wk", "fr", "sd", "rf"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    r = subprocess.run([sys.executable, probe, "single"], capture_output=True, text=True,
+                       env=dict(os.environ, GRAFIMO_PLAN_MAX_WALKS=str(1 << 15)), timeout=600)
+    assert "REFUSED -7" in r.stdout and "c:280-340" in r.stdout and "starts at c:" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
