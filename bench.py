@@ -35,7 +35,9 @@ burst.  Rank 0 prints ONE JSON line.  Beside the contract's fields it carries
   rank_ms_per_step    every rank's own median burst; rccl_world = dist.get_world_size();
   N = 1, default config only (each can be switched off):
   roofline_config3    >= 10 steps of the config-3 shard (1.25e8 windows generated on the device, `nt` stores: 477 MiB
-                      of scores per launch, beyond any cache) -- also the 1-GPU point of the N > 1 curve;
+                      of scores per launch, beyond any cache) -- also the 1-GPU point of the N > 1 curve
+                      (`scaling_curve_point` names the curve's workload and this N's value on it at every N);
+  roofline_config4/5  12 steps each of BASELINE configs[3] (W=30, --qvalueT) and configs[4] (50 PWMs, batched launches);
   sustained           >= 5 s of back-to-back steps, k-mers/s and min/median/max ms per 100 steps;
   extract             the k-mer extraction kernels on a synthetic graph at config-2 scale + extraction -> scoring;
   pcie_inclusive      the host-buffer form of the boundary (gfm_scan_host) over the same 2e7 k-mers, H2D included;
@@ -254,9 +256,12 @@ def make_tsv_dir(regions, rows_per_region, W, probs, workers):
 
 
 def e2e_block(tmp, n_expected, W, dm):
-    """A TSV directory through the pipeline behind compute_results (gfm_scan_tsv): parse threads -> pinned chunks ->
-    hipMemcpyAsync -> score kernel per chunk -> q-table -> hits back; next to the bare ingest (gfm_tsv_open) on the
-    same files and thread count."""
+    """A TSV directory through the pipeline behind compute_results (gfm_scan_tsv): parse threads (k-mer + line offset per
+    row) -> pinned chunks -> hipMemcpyAsync -> score kernel per chunk -> q-table -> hits back, their columns read from
+    the files.  `total_ms` is the median of BACK-TO-BACK scans -- what a caller that scans motif after motif gets; on a
+    host with a CPU quota a scan that has a quota period to itself is given beside it, labelled.  `full_parse_ms`: the
+    table form of the ingest (gfm_tsv_open: every column of every row converted) on the same files with the same thread
+    request -- what the scan no longer does for rows that are not hits."""
     import ctypes
     import glob
     from grafimo_amd import _native as nv
@@ -264,42 +269,48 @@ def e2e_block(tmp, n_expected, W, dm):
     files = sorted(glob.glob(os.path.join(tmp, f"width_{W}", "*.tsv")))
     nbytes = sum(os.path.getsize(f) for f in files)
     threads = os.cpu_count() or 1
+    quota = cpu_quota_cores()
+
+    def scans(count, idle):
+        runs = []
+        for _ in range(count):
+            if idle:
+                time.sleep(idle)
+            t = time.perf_counter()
+            sc = StreamScan(dm, files, False, threads, 1e-4, False, True)
+            runs.append((sc.stats.total_s, time.perf_counter() - t, sc.stats.parse_s, sc.stats.h2d_s, sc.stats.h2d_bytes,
+                         sc.stats.tail_s, sc.n, sc.n_hits, sc.stats.n_chunks, sc.stats.parse_threads))
+        return runs
+
+    scans(1, 0.0)                            # the first call sizes the buffer pool
+    back = sorted(scans(5, 0.0))
+    total_s, wall, parse_s, h2d_s, h2d_bytes, tail_s, n, n_hits, n_chunks, pthreads = back[len(back) // 2]
+    assert n == n_expected, (n, n_expected)
+    out = {
+        "rows": int(n), "tsv_bytes": int(nbytes), "files": len(files), "host_threads": threads,
+        "cpu_quota_cores": quota, "parse_threads": int(pthreads), "hits": int(n_hits),
+        "kmers_per_s": n / total_s, "h2d_GBps": h2d_bytes / h2d_s / 1e9,
+        "total_ms": total_s * 1e3, "total_ms_runs": [round(r[0] * 1e3, 3) for r in back],
+        "parse_ms_inside": parse_s * 1e3, "parse_cpu_ns_per_row": parse_s * pthreads / max(n, 1) * 1e9,
+        "h2d_ms": h2d_s * 1e3, "after_parse_ms": tail_s * 1e3, "chunks": int(n_chunks),
+        "path": "gfm_scan_tsv (grafimo_amd.score_sequences.StreamScan, what compute_results calls); total_ms = median of "
+                "five back-to-back scans",
+    }
+    if quota is not None and nbytes > (1 << 30):
+        # a container with a CPU quota freezes every thread once a 100 ms period's allowance is used up, and a scan of
+        # this size needs a good part of one: with 0.15 s of idle before it a scan is charged for its own CPU time only
+        fresh = sorted(scans(3, 0.15))
+        out["total_ms_with_a_quota_period_to_itself"] = fresh[len(fresh) // 2][0] * 1e3
     arr = (ctypes.c_char_p * len(files))(*[f.encode() for f in files])
     ingest = []
     for _ in range(3):
-        h, n = ctypes.c_void_p(), ctypes.c_int64()
+        h, n_ = ctypes.c_void_p(), ctypes.c_int64()
         t = time.perf_counter()
-        nv.check(nv.lib().gfm_tsv_open(arr, len(files), W, 0, threads, ctypes.byref(h), ctypes.byref(n)))
+        nv.check(nv.lib().gfm_tsv_open(arr, len(files), W, 0, threads, ctypes.byref(h), ctypes.byref(n_)))
         ingest.append(time.perf_counter() - t)
         nv.lib().gfm_tsv_close(h)
-    ingest_s = float(np.median(ingest))
-    runs = []
-    quota = cpu_quota_cores()
-    for _ in range(4):       # the first call sizes the buffer pool
-        if quota is not None and nbytes > (1 << 30):
-            # a container with a CPU quota freezes every thread once a 100 ms period's allowance is used up, and a scan
-            # of this size needs most of one: let the previous run's period pass, so that a run is charged for its own
-            # CPU time only.  (Not for the small directory: it needs a tenth of an allowance, and crew
-            # threads that slept 150 ms wake up slower than the whole scan takes.)
-            time.sleep(0.15)
-        t = time.perf_counter()
-        sc = StreamScan(dm, files, False, threads, 1e-4, False, True)
-        runs.append((time.perf_counter() - t, sc.stats.total_s, sc.stats.parse_s, sc.stats.h2d_s,
-                     sc.stats.h2d_bytes, sc.stats.tail_s, sc.n, sc.n_hits, sc.stats.n_chunks))
-    runs = sorted(runs[1:])
-    wall, total_s, parse_s, h2d_s, h2d_bytes, tail_s, n, n_hits, n_chunks = runs[len(runs) // 2]
-    assert n == n_expected, (n, n_expected)
-    return {
-        "rows": int(n), "tsv_bytes": int(nbytes), "files": len(files), "host_threads": threads,
-        "cpu_quota_cores": cpu_quota_cores(), "parse_threads": int(sc.stats.parse_threads), "hits": int(n_hits),
-        "kmers_per_s": n / total_s, "ingest_rows_per_s": n / ingest_s, "h2d_GBps": h2d_bytes / h2d_s / 1e9,
-        "total_ms": total_s * 1e3, "ingest_alone_ms": ingest_s * 1e3, "parse_ms_inside": parse_s * 1e3,
-        "h2d_ms": h2d_s * 1e3, "after_parse_ms": tail_s * 1e3, "chunks": int(n_chunks),
-        "total_over_max_ingest_h2d": total_s / max(ingest_s, h2d_s),
-        "path": "gfm_scan_tsv (grafimo_amd.score_sequences.StreamScan, what compute_results calls)"
-                + ("; 0.15 s of idle before every run: the container's CPU quota period"
-                   if quota is not None and nbytes > (1 << 30) else ""),
-    }
+    out["full_parse_ms"] = float(np.median(ingest)) * 1e3
+    return out
 
 
 # ---------------------------------------------------------------------------- extraction (N = 1)
@@ -393,6 +404,90 @@ def extract_block(ctcf, dev, n_regions=10_000):
     }
 
 
+def extra_config_block(cfg, dev, rank, args, side, steps=12):
+    """BASELINE configs[3] / configs[4] inside the default N = 1 line (like roofline_config3): `steps` timed steps after
+    two warm-up steps, the score kernels timed by HIP events on their dispatch packets, a slice of the last step's scores
+    against the CPU oracle.  -> the block (roofline_config4 / roofline_config5)."""
+    import torch
+    from grafimo_amd import synth
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.scan import KmerScanner, SameWidthScanner
+    from oracle import oracle as orc
+    mots = synth.config_motifs(cfg)
+    dms = [DeviceMotif(m["sm"], m["bg"], m["min_val"], m["scale"], m["offset"]) for m in mots]
+    n = 100_000_000
+
+    def fence():
+        torch.cuda.synchronize(dev)
+
+    if cfg == 4:
+        W = mots[0]["width"]
+        d = synth.make_device_kmers(n, W, mots[0]["probs"], synth.seed_for(4, rank), dev)
+        sc = KmerScanner(dms[0], n, hit_capacity=n // 64, device=dev, side_stream=side, n_slots=args.slots)
+        step = lambda: sc.enqueue(d, args.threshold, on_qvalue=True, want_qvalues=True)      # noqa: E731
+        units, alg = n, n * (W + 4)
+        kname = f"score_quad_kernel<{W}, 1>"
+        what = f"BASELINE configs[3]: synthetic JASPAR-style PWM W=30, {n} windows generated on the device, both strands, --qvalueT"
+    else:
+        widths = sorted({m["width"] for m in mots})
+        groups = {w: [j for j, m in enumerate(mots) if m["width"] == w] for w in widths}
+        bufs = {w: synth.make_device_kmers(n, w, mots[groups[w][0]]["probs"], synth.seed_for(50 + w, rank), dev) for w in widths}
+        scs = {w: SameWidthScanner([dms[j] for j in groups[w]], n, max(4096, n // 64), dev) for w in widths}
+
+        def step():
+            for w in widths:
+                scs[w].enqueue(bufs[w], args.threshold, on_qvalue=False, want_qvalues=True)
+
+        units, alg = n * len(mots), sum(n * (w + 4 * len(groups[w])) for w in widths)
+        kname = "score_quad_kernel<W, MM> (batched, one launch per group of <= 3 same-width motifs; summed per step)"
+        what = (f"BASELINE configs[4]: 50 synthetic JASPAR-style PWMs W=8..25 (per-motif background), {n} windows per width, "
+                f"same-width motifs share each k-mer read; unit = (k-mer, motif) pair")
+    last = None
+    for _ in range(2):
+        last = step()
+    fence()
+    for dmx in dms:
+        dmx.profile_enable(steps + 2, every=1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    fence()
+    el = time.perf_counter() - t0
+    per_motif = [dmx.profile_read() for dmx in dms]
+    for dmx in dms:
+        dmx.profile_enable(0)
+    orc.build()
+    if cfg == 4:
+        k_ms = float(np.mean(per_motif[0]))
+        timed = int(len(per_motif[0]))
+        res = sc.collect(last)
+        assert res["n_scored"] == n
+        km = d[:1_000_000].cpu().numpy()
+        _, pt = dms[0].tables()
+        exp, _ = orc.score_kmers_table(km, mots[0]["sm"], pt, mots[0]["min_val"])
+        assert np.array_equal(last.scores[:len(km)].cpu().numpy(), exp), "config 4: scores differ from the oracle"
+        hits = int(len(res["rows"]))
+    else:
+        k_ms = float(sum(float(np.mean(k)) for k in per_motif if len(k)))
+        timed = int(sum(len(k) for k in per_motif))
+        hits = 0
+        for w in widths:
+            km = bufs[w][:200_000].cpu().numpy()
+            for k_, j in enumerate(groups[w]):
+                _, pt = dms[j].tables()
+                exp, _ = orc.score_kmers_table(km, mots[j]["sm"], pt, mots[j]["min_val"])
+                assert np.array_equal(scs[w].scores[k_][:len(km)].cpu().numpy(), exp), f"config 5: motif {j} (W={w}) differs from the oracle"
+            hits += int(scs[w].hits[:, 0].sum().item())
+    block = {"workload": what, "steps": steps, "ms_per_step": 1e3 * el / steps, "units_per_s": units * steps / el,
+             "unit": "k-mers/s" if cfg == 4 else "(k-mer, motif) pairs/s", "kernel": kname, "kernel_ms_avg": k_ms,
+             "kernel_launches_timed": timed, "algorithmic_bytes_per_launch": alg, "achieved": alg / (k_ms * 1e-3) / 1e9,
+             "peak": HBM_PEAK_GBS, "unit_bw": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "hits_last_step": hits, "oracle_checked": True}
+    for dmx in dms:
+        dmx.close()
+    return block
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -409,6 +504,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip roofline_config3, sustained, peak_measured and extract (N=1 default config only)")
     ap.add_argument("--sustained-s", type=float, default=5.0, help="length of the sustained leg in seconds")
+    ap.add_argument("--no-config45", action="store_true", help="skip the roofline_config4 / roofline_config5 blocks of the default line")
     ap.add_argument("--slots", type=int, default=3,
                     help="buffer slots of the scan pipeline (2: the device waits for slot reuse; >= 3: the host does)")
     ap.add_argument("--force-dist", action="store_true",
@@ -668,6 +764,12 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
             "score_stores": "nt (477 MiB of scores per launch)"}
         del sc3, d3, last3
         torch.cuda.empty_cache()
+        if not args.no_config45:
+            # BASELINE configs[3] and configs[4], driver-timed inside the default line (their own runs: --config 4 / 5)
+            extras["roofline_config4"] = extra_config_block(4, dev, rank, args, side)
+            torch.cuda.empty_cache()
+            extras["roofline_config5"] = extra_config_block(5, dev, rank, args, side)
+            torch.cuda.empty_cache()
         extras["extract"] = extract_block(ctcf, dev)
         # the boundary's host-buffer form (gfm_scan_host: pageable k-mers in, hits out): the PCIe-inclusive rate --
         # never `value`
@@ -705,9 +807,16 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("rows_per_launch") == n and tj.get("width") == mots[0]["width"] and tj.get("kernel") == kname:
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_source = ("profiles/pmc_traffic.json: committed rocprofv3 --pmc passes of this kernel at this "
-                                  "size (" + str(tj.get("source", "scripts/lab_pmc.sh")) + "), NOT counters of this run")
+                import hashlib
+                src = b"".join(open(os.path.join(ROOT, f), "rb").read() for f in tj.get("kernel_source_files", []))
+                if src and hashlib.sha256(src).hexdigest()[:16] == tj.get("kernel_source_sha16"):
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/pmc_traffic.json: committed rocprofv3 --pmc passes of this kernel at this "
+                                      "size (" + str(tj.get("source", "scripts/lab_pmc.sh")) + "), NOT counters of this run; "
+                                      "the kernel's sources still hash to what the counters were taken from")
+                else:
+                    traffic_source = ("profiles/pmc_traffic.json is STALE: the score kernel's sources changed since its counters "
+                                      "were collected (scripts/lab_pmc.sh collects them again)")
         workload = {
             2: f"BASELINE configs[1] per GPU: CTCF MA0139.1 W=19, 10000 synthetic 200bp regions x 2000 haplotype "
                f"k-mers = {n} windows",
@@ -743,10 +852,19 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
             "warmup": max(args.warmup, rotate),
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            # every rank scores its own shard of fixed size (weak) -- except config 5, whose 1e8 windows per width are SPLIT
+            # over the ranks (strong)
+            "scaling": "strong" if cfg == 5 else "weak",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
+            # the workload a 1 -> N curve is made of: N = 1 defaults to configs[1] (the config the metric is quoted on), N > 1
+            # to configs[2]'s per-GPU shard -- the curve's point for THIS N on that one workload is given here at every N
+            "scaling_curve_point": (
+                {"workload": "BASELINE configs[2] per-GPU shard: CTCF W=19, 1.25e8 windows per GPU", "n_gpus": world,
+                 "kmers_per_s": value if cfg == 3 else (extras.get("roofline_config3") or {}).get("kmers_per_s"),
+                 "source": "value" if cfg == 3 else "roofline_config3"}
+                if cfg in (2, 3) else None),
             "rccl_world": dist.get_world_size() if use_dist else 1,
             "rank_ms_per_step": rank_ms,
             "tail_ms": ({"avg": float(np.mean(tail_ms)), "max": float(np.max(tail_ms)), "timed": int(len(tail_ms)),
@@ -771,6 +889,8 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
             },
             "roofline": roofline,
             "roofline_config3": extras.get("roofline_config3"),
+            "roofline_config4": extras.get("roofline_config4"),
+            "roofline_config5": extras.get("roofline_config5"),
             "sustained": extras.get("sustained"),
             "peak_measured": extras.get("peak_measured"),
             "extract": extras.get("extract"),

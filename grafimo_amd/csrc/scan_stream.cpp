@@ -176,6 +176,14 @@ struct ScanPool {
     size_t slot_bytes = 0;
     std::vector<MotifBufs> mb;              // one per motif of the scan
     std::vector<MetaChunk> meta;            // one per chunk index
+    // The TEXT of the scanned files, kept until the scan closes: the files are read straight into this arena (no per-thread
+    // buffer, no copy), and the hit rows' columns are parsed from it at finish -- at the bench's hit density (1 % of the
+    // rows are planted motif instances) reading the lines back from the files was 193 000 pread()s and 10 000 open()s for
+    // a 2e7-row scan: 22 ms of a 73 ms scan, under a CPU quota that the scan's own work already exhausts.  Grow-only like
+    // the slots; files that do not fit (or directories beyond kTextMax) go through the threads' own buffers and their
+    // hit rows are read back from the files.
+    char *text = nullptr;
+    size_t text_cap = 0;
     int64_t meta_rows = 0;                  // rows (and width) the column blocks were made for
     int meta_W = 0;
     bool in_use = false;
@@ -236,11 +244,23 @@ struct ScanPool {
     // What a scan leaves behind is O(rows of the largest scan so far): one score block per chunk and motif on the device,
     // one column block per chunk on the host.  Kept, they make the next scan of that size allocation-free; beyond these
     // budgets the blocks of the highest chunk indices are given back when a scan closes (nothing of it is in flight then).
-    static constexpr size_t kKeepHostBytes = (size_t)1 << 30, kKeepDeviceBytes = (size_t)4 << 30;
+    static constexpr size_t kKeepHostBytes = (size_t)3 << 30, kKeepDeviceBytes = (size_t)4 << 30, kTextMax = (size_t)8 << 30;
+    int reserve_text(size_t bytes)
+    {
+        if (bytes <= text_cap) return GFM_OK;
+        std::free(text);
+        text = nullptr;
+        text_cap = 0;
+        text = static_cast<char *>(std::malloc(bytes));
+        if (!text) return sfail(GFM_ERR_NOMEM, "out of host memory");
+        text_cap = bytes;
+        return GFM_OK;
+    }
     void trim()
     {
+        if (text_cap > kKeepHostBytes) { std::free(text); text = nullptr; text_cap = 0; }
         const size_t per_meta = (size_t)meta_rows * sizeof(uint64_t) + 64;
-        while (!meta.empty() && meta.size() * per_meta > kKeepHostBytes) {
+        while (!meta.empty() && meta.size() * per_meta + text_cap > kKeepHostBytes) {
             meta.back().release();
             meta.pop_back();
         }
@@ -271,6 +291,7 @@ struct ScanPool {
         mb.clear();
         for (auto &m : meta) m.release();
         meta.clear();
+        std::free(text);
         if (copy) (void)hipStreamDestroy(copy);
         if (score) (void)hipStreamDestroy(score);
         *this = ScanPool();
@@ -333,6 +354,8 @@ struct gfm_scan {
     bool have_q = false;
     std::vector<MotifHits> hits;      // one per motif
     std::vector<std::string> paths;   // the files, in scan order (the hit rows' lines are read from them at finish)
+    struct Kept { const char *p = nullptr; size_t len = 0; };
+    std::vector<Kept> kept;           // per file: its text in the pool's arena (nullptr: not kept, read it back from the file)
     int n_threads = 1;
     gfm_scan_stats_t stats{};
     // ---- what gfm_scan_tsv_finish needs from gfm_scan_tsv_begin
@@ -416,6 +439,20 @@ int fetch_hit_columns(gfm_scan *sc)
             auto complain = [&](size_t i, const char *what) {
                 fail_job(path + ": row " + std::to_string((long long)(h.rows[i] - base_row + 1)) + " of the file: " + what);
             };
+            if (const char *text = sc->kept[job.file].p) {       // the file's text is still in the scan's arena
+                const char *tend = text + sc->kept[job.file].len;
+                for (size_t i = job.i0; i < job.i1; ++i) {
+                    const uint64_t off = offset_of(i);
+                    gfm_tsv_detail::LineCols c;
+                    const char *what = "internal error: line offset outside the file";
+                    if (off >= (uint64_t)(tend - text) || gfm_tsv_detail::parse_line(text + off, tend, true, (int)W, c, &what) != 1) {
+                        complain(i, what);
+                        break;
+                    }
+                    store(i, c);
+                }
+                continue;
+            }
             const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
             if (fd < 0) { fail_job("cannot open " + path + " again for its hit rows"); continue; }
             struct stat sb {};
@@ -521,6 +558,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     sc->table.files.resize((size_t)n_paths);
     sc->paths.reserve((size_t)n_paths);
     for (int i = 0; i < n_paths; ++i) sc->paths.emplace_back(paths[i]);
+    sc->kept.assign((size_t)n_paths, gfm_scan::Kept());
     const double t_begin = now_s();
     sc->t_begin = t_begin;
     const bool trace = std::getenv("GRAFIMO_SCAN_TRACE") != nullptr;   // development aid: phase times to stderr
@@ -548,6 +586,21 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     } drain{P};
     stamp("pool acquired");
     S_RC(P->reserve_slots((size_t)chunk_rows * (size_t)W + 16));
+    {   // the text arena: the directory's size estimated from a sample of its files (a stat per file was 0.8 ms per thousand)
+        unsigned long long bytes = 0;
+        const int step = (n_paths + 63) / 64;
+        int sampled = 0;
+        for (int i = 0; i < n_paths; i += std::max(1, step), ++sampled) {
+            struct stat sb {};
+            if (::stat(paths[i], &sb) == 0) bytes += (unsigned long long)sb.st_size;
+        }
+        if (sampled) bytes = bytes / (unsigned long long)sampled * (unsigned long long)n_paths;
+        size_t want = (size_t)(bytes + bytes / 16) + (size_t)n_paths * 64 + (1u << 20);
+        if (const char *e = std::getenv("GRAFIMO_SCAN_TEXT_BYTES")) want = (size_t)strtoull(e, nullptr, 10);   // test aid (0: keep nothing)
+        if (want > ScanPool::kTextMax) want = ScanPool::kTextMax;
+        if (want && P->reserve_text(want) != GFM_OK) (void)P->reserve_text(0);      // no memory for it: the files are read back instead
+    }
+    std::atomic<size_t> text_used{0};
     S_RC(P->reserve_motifs(M));
     sc->n_threads = gfm_tsv_detail::pick_threads(paths, n_paths, n_threads);
     sc->d_hist.assign(M, nullptr);
@@ -650,6 +703,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
         // this worker's files between their count and their parse, oldest first (the crew's threads live as long as
         // the process: so do their buffers)
         static thread_local gfm_tsv_detail::FileBuf ring[kRing];
+        const char *h_begin[kRing] = {}, *h_end[kRing] = {};   // the held files' bytes: in the pool's text arena, or in ring[]
         int held[kRing], n_held = 0, head = 0;         // file index per ring slot, in order from `head`
         int64_t cached_k = -1;                         // the chunk this worker wrote into last, and its column block
         MetaChunk cached_mc;
@@ -663,7 +717,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                 // my oldest file has its offset: parse it in place
                 const int i = held[head];
                 set_state(2, i);
-                gfm_tsv_detail::FileBuf &text = ring[head];
+                struct { const char *b, *e; const char *begin() const { return b; } const char *end() const { return e; } } text{h_begin[head], h_end[head]};
                 FileCols &f = sc->table.files[(size_t)i];
                 const int64_t rows = f.n_rows, off = file_off[(size_t)i];
                 std::string err;
@@ -750,10 +804,49 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                     int64_t rows = 0;
                     const double r0 = trace ? now_s() : 0.0;
                     set_state(1, i);
-                    if (ring[slot_ix].load(paths[i], err))
-                        rows = gfm_tsv_detail::count_rows(ring[slot_ix].begin(), ring[slot_ix].end(), skip_reverse != 0);
+                    // straight into the scan's text arena when the file fits what is left of it (kept until the scan closes:
+                    // the hit rows' columns are parsed from there); else into this thread's own buffer
+                    bool in_arena = false;
+                    if (P->text_cap) {
+                        const int fd = ::open(paths[i], O_RDONLY | O_CLOEXEC);
+                        struct stat sb {};
+                        if (fd >= 0 && ::fstat(fd, &sb) == 0 && sb.st_size > 0 && (size_t)sb.st_size <= ((size_t)32 << 20)) {
+                            const size_t len = (size_t)sb.st_size;
+                            const size_t at = text_used.fetch_add(len + 64, std::memory_order_relaxed);
+                            if (at + len + 64 <= P->text_cap) {
+                                char *dst = P->text + at;
+                                size_t got = 0;
+                                while (got < len) {
+                                    const ssize_t r = ::read(fd, dst + got, len - got);
+                                    if (r < 0 && errno == EINTR) continue;
+                                    if (r <= 0) break;
+                                    got += (size_t)r;
+                                }
+                                if (got == len) {
+                                    std::memset(dst + len, 0, 64);
+                                    h_begin[slot_ix] = dst;
+                                    h_end[slot_ix] = dst + len;
+                                    sc->kept[(size_t)i].p = dst;
+                                    sc->kept[(size_t)i].len = len;
+                                    in_arena = true;
+                                } else {
+                                    err = std::string("Unable to read ") + paths[i];
+                                }
+                            }
+                        }
+                        if (fd >= 0) ::close(fd);
+                    }
+                    if (!in_arena && err.empty()) {
+                        if (ring[slot_ix].load(paths[i], err)) {
+                            h_begin[slot_ix] = ring[slot_ix].begin();
+                            h_end[slot_ix] = ring[slot_ix].end();
+                        }
+                    }
+                    if (err.empty() && h_begin[slot_ix])
+                        rows = gfm_tsv_detail::count_rows(h_begin[slot_ix], h_end[slot_ix], skip_reverse != 0);
                     if (trace) tr_max(tr_read, (int64_t)((now_s() - r0) * 1e9));
                     if (!err.empty()) { fail_with(err); return; }
+                    if (!h_begin[slot_ix]) h_begin[slot_ix] = h_end[slot_ix] = "";      // an empty file
                     held[slot_ix] = i;
                     ++n_held;
                     sc->table.files[(size_t)i].n_rows = rows;

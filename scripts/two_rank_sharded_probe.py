@@ -66,7 +66,8 @@ if __name__ == "__main__":
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     out = os.path.join(seqdir, "mismatch.flag")
     try:
-        mp.spawn(worker, args=(2, port, seqdir, out), nprocs=2, join=True)
+        n_ranks = int(sys.argv[sys.argv.index("--ranks") + 1]) if "--ranks" in sys.argv else 2
+        mp.spawn(worker, args=(n_ranks, port, seqdir, out), nprocs=n_ranks, join=True)
         sys.exit(1 if os.path.exists(out) else 0)
     finally:
         import shutil

@@ -9,11 +9,12 @@ import sys
 from conftest import ROOT
 
 
-def _run(extra):
+def _run(extra, gpus=2):
     env = {k: v for k, v in os.environ.items()
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup",
-                           "1", "--dry-run"] + extra, env=env, capture_output=True, text=True, timeout=300)
+    env["OMP_NUM_THREADS"] = "1"
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup",
+                           "1", "--dry-run"] + extra, env=env, capture_output=True, text=True, timeout=600)
 
 
 def test_bench_self_launches_its_ranks_and_relays_one_json_line():
@@ -28,5 +29,17 @@ def test_bench_self_launches_its_ranks_and_relays_one_json_line():
 
 def test_bench_launcher_passes_a_failing_rank_on():
     p = _run(["--dry-run-fail-rank", "1"])
+    assert p.returncode != 0
+    assert not any(ln.lstrip().startswith("{") and '"metric"' in ln for ln in p.stdout.splitlines())
+
+
+def test_eight_ranks_as_the_driver_launches_them():
+    """--gpus 8, the driver's largest run: eight children, one JSON line with eight per-rank entries; and a rank that
+    dies (rank 5) takes the run's exit code with it instead of leaving seven ranks in a collective."""
+    p = _run([], gpus=8)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert rec["n_gpus"] == 8 and rec["rccl_world"] == 8 and rec["rank_ms_per_step"] == [float(r + 1) for r in range(8)]
+    p = _run(["--dry-run-fail-rank", "5"], gpus=8)
     assert p.returncode != 0
     assert not any(ln.lstrip().startswith("{") and '"metric"' in ln for ln in p.stdout.splitlines())

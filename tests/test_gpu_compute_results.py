@@ -28,8 +28,8 @@ def _ctcf(pvalue_matrix):
 def _compare(df, exp):
     assert list(df.columns) == list(exp.columns)
     key = ["p-value", "start", "stop", "strand"]
-    a = df.sort_values(key).reset_index(drop=True)
-    b = exp.sort_values(key).reset_index(drop=True)
+    a = df.sort_values(key, kind="stable").reset_index(drop=True)
+    b = exp.sort_values(key, kind="stable").reset_index(drop=True)
     assert len(a) == len(b)
     for c in exp.columns:
         if c in ("p-value", "q-value"):
@@ -571,6 +571,36 @@ def test_two_ranks_on_one_gpu_through_the_sharded_entry_points():
     assert r.stdout.count("two ranks == one process: True") == 9
 
 
+def test_hit_columns_from_the_kept_text_and_from_the_files_agree(tmp_path, monkeypatch):
+    """The streamed scan keeps k-mer + line offset per row and reads the OTHER columns for the hit rows only: from the
+    files' text kept in the pool's arena, or -- for what does not fit it -- back from the files (pread per hit, or the
+    whole file when it holds many).  All three ways (arena for everything, for nothing, for a part) give the table the
+    oracle gives, at a hit density of a few rows and of every row."""
+    from grafimo_amd import synth
+    from grafimo_amd.score_sequences import compute_results
+    from grafimo_amd.workflow import Findmotif
+    from oracle import oracle as orc
+    motif = _ctcf(True)
+    batch = synth.make_batch(23, 700, 19, np.asarray(motif.count_matrix, dtype=np.float64), synth.seed_for(12))
+    synth.write_tsv_dir(batch, str(tmp_path))
+    md = dict(score_matrix=motif.dense_score_matrix(), pmf=np.asarray(motif.pval_matrix), min_val=motif.min_val, scale=motif.scale,
+              offset=float(motif.offset), width=19, motif_id=motif.motif_id, motif_name=motif.motif_name)
+    for kw in (dict(threshold=1e-4), dict(threshold=1.0, recomb=True), dict(threshold=0.2, qval_t=True, no_reverse=True)):
+        ref = orc.compute_results(md, str(tmp_path), threshold=kw["threshold"], qval_t=kw.get("qval_t", False), no_qvalue=False,
+                                  no_reverse=kw.get("no_reverse", False), recomb=kw.get("recomb", False))
+        exp = pd.DataFrame({c: ref[c] for c in ref if not c.startswith("_")})
+        for text_bytes in (None, "0", "200000"):
+            if text_bytes is None:
+                monkeypatch.delenv("GRAFIMO_SCAN_TEXT_BYTES", raising=False)
+            else:
+                monkeypatch.setenv("GRAFIMO_SCAN_TEXT_BYTES", text_bytes)
+            with contextlib.redirect_stdout(io.StringIO()):
+                df = compute_results(motif, str(tmp_path), True, Findmotif(cores=3, **kw))
+            key = ["p-value", "sequence_name", "start", "stop", "strand", "matched_sequence", "haplotype_frequency"]
+            _compare(df.sort_values(key).reset_index(drop=True), exp.sort_values(key).reset_index(drop=True))
+    assert len(exp) > 10
+
+
 @pytest.mark.timeout(120)
 def test_streamed_scan_without_any_file_returns_an_empty_scan(golden_motifs):
     """gfm_scan_tsv_begin with n_paths == 0 -- the shard of a rank when there are more ranks than files -- returns an
@@ -598,6 +628,43 @@ def test_two_ranks_one_file_leaves_a_rank_without_files():
                        capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     assert r.stdout.count("two ranks == one process: True") == 9
+
+
+@pytest.mark.timeout(900)
+def test_four_ranks_on_one_gpu_through_the_sharded_entry_points():
+    """scripts/two_rank_sharded_probe.py with FOUR processes sharing the test GPU (nine files over four ranks: ragged
+    shards): rank 0's tables equal compute_results over all files."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "two_rank_sharded_probe.py"), "--ranks", "4"],
+                       capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert r.stdout.count("ranks == one process: True") == 9
+
+
+@pytest.mark.timeout(900)
+def test_bench_distributed_path_on_one_gpu_with_reserved_cus():
+    """The N > 1 bench path on the one GPU the test box has: --force-dist initialises RCCL with a one-rank group, every
+    step issues the histogram all-reduce and the sized hit gather on the tail / gather streams beside a persistent score
+    grid that leaves 16 CUs free (GRAFIMO_RESERVE_CUS=16, what bench.py sets for N > 1); the line must carry the group's
+    size, the tail timing with the collectives in it, and have passed its own oracle slice."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, GRAFIMO_RESERVE_CUS="16", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--config", "3", "--rows", "8000000",
+                        "--steps", "12", "--warmup", "3", "--bursts", "2", "--no-cpu-baseline", "--no-e2e", "--no-extras"],
+                       capture_output=True, text=True, env=env, timeout=800)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    assert rec["rccl_world"] == 1 and rec["n_gpus"] == 1 and rec["scaling"] == "weak"
+    assert rec["tail_ms"] and rec["tail_ms"]["timed"] > 0 and "all-reduce" in rec["tail_ms"]["what"] and "gather" in rec["tail_ms"]["what"]
+    assert rec["config"]["oracle_checked_rows"] == 1_000_000 and rec["config"]["hits_last_step"] > 0
+    assert rec["scaling_curve_point"]["source"] == "value" and rec["scaling_curve_point"]["kmers_per_s"] == rec["value"]
 
 
 def test_kept_motif_handles(golden_motifs):
