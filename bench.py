@@ -771,6 +771,37 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
             extras["roofline_config5"] = extra_config_block(5, dev, rank, args, side)
             torch.cuda.empty_cache()
         extras["extract"] = extract_block(ctcf, dev)
+        # the strand-max / per-region best-hit reductions (north_star; csrc/region_reduce.hip) over this batch's scores:
+        # 10 000 regions, rows under the p-value cutoff and carried by a haplotype
+        from grafimo_amd import top_hits as th
+        d_region = torch.from_numpy(host_batch.region).to(dev)
+        d_freq = torch.from_numpy(host_batch.freq).to(dev)
+        d_start, d_stop = torch.from_numpy(host_batch.start).to(dev), torch.from_numpy(host_batch.stop).to(dev)
+        cut = dms[0].pvalue_cutoff(args.threshold)
+        sc_last = last.scores
+        best = th.region_best(sc_last, d_region, 10_000, freq=d_freq, min_score=cut)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(10):
+            th.region_best(sc_last, d_region, 10_000, freq=d_freq, min_score=cut, out=best)
+        e1.record()
+        for _ in range(3):
+            lm = th.locus_max(sc_last, d_region, 10_000, d_start, d_stop, freq=d_freq, min_score=cut)
+        e2.record()
+        torch.cuda.synchronize(dev)
+        s_np = sc_last.cpu().numpy()
+        ok_rows = (s_np >= cut) & (host_batch.freq > 0)
+        want = np.full(10_000, -1, np.int64)
+        np.maximum.at(want, host_batch.region[ok_rows], s_np[ok_rows])
+        got_s, _, _ = th.decode_best(best)
+        extras["strand_max"] = {
+            "rows": n, "regions": 10_000, "region_best_ms": e0.elapsed_time(e1) / 10,
+            "region_best_read_GBps": n * 16 / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9,      # score + region id + frequency
+            "locus_max_ms_all_rows_filtered": e1.elapsed_time(e2) / 3, "regions_with_a_hit": int((want >= 0).sum()),
+            "equals_numpy_groupby": bool(np.array_equal(got_s, want)) and int((lm.cpu().numpy() >= 0).sum()) == int(ok_rows.sum()),
+            "what": "gfm_region_best / gfm_locus_max over the last step's scores: per region the best reported hit, per "
+                    "locus the both-strand maximum (rows with p < threshold and haplotype_frequency > 0)"}
         # the boundary's host-buffer form (gfm_scan_host: pageable k-mers in, hits out): the PCIe-inclusive rate --
         # never `value`
         t_host = []
@@ -894,6 +925,7 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
             "sustained": extras.get("sustained"),
             "peak_measured": extras.get("peak_measured"),
             "extract": extras.get("extract"),
+            "strand_max": extras.get("strand_max"),
             "pcie_inclusive": extras.get("pcie_inclusive"),
             "cpu_baseline": cpu.get("cpu_baseline"),
             "cpu_baseline_table": cpu.get("cpu_baseline_table"),

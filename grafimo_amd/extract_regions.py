@@ -851,7 +851,8 @@ def scan_graph(widths: Set[int], args_obj, debug: bool) -> str:
 
 
 def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_obj, group=None,
-                               always_collective: bool = False, fused: bool = True) -> Optional[pd.DataFrame]:
+                               always_collective: bool = False, fused: bool = True,
+                               top_graphs: Optional[int] = None) -> Optional[pd.DataFrame]:
     """extract_regions.scan_graph + score_sequences.compute_results as ONE device pass: every walk of every window of
     the regions is scored on both strands where it is enumerated (gfm_graph_score) -- no row of `vg find -K` is ever
     written, neither as TSV (extract_regions.py:180,225) nor as a device matrix; what leaves the kernels is the score
@@ -864,9 +865,17 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
     a motif.
     Under torch.distributed (one process per GPU, every rank calls this with the same arguments and its own replica of
     the graphs) the regions are split over the ranks, the score histogram is all-reduced so that q-values stay global,
-    and rank 0 returns the merged table (the others None)."""
+    and rank 0 returns the merged table (the others None).
+    `top_graphs` = N: only the N best regions are asked for (what --top-graphs draws, res_writer.py:153-157: the first N
+    distinct sequence_names of the report) -- every rank keeps ONE hit per region, the best of the rows it would report,
+    before the gather (n_regions entries per rank travel instead of every hit), and the table is
+    top_hits.top_regions_table(full report, N): one row per region, best regions first."""
     if not fused:
-        return compute_results_from_graph_rows(motif, graph, regions, debug, args_obj, group, always_collective)
+        df_ = compute_results_from_graph_rows(motif, graph, regions, debug, args_obj, group, always_collective)
+        if top_graphs is not None and df_ is not None:
+            from .top_hits import top_regions_table
+            df_ = top_regions_table(df_, top_graphs)
+        return df_
     from .resultsTmp import build_frame_sorted
     from .score_sequences import print_scoring_msg
     torch = _torch()
@@ -976,6 +985,12 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
     names = np.concatenate(names_of) if len(kept) > 1 else names_of[0]
     order = np.lexsort((recs["q2"], recs["w"], ekey))
     recs, seqnames = recs[order], names[order].tolist()
+    if top_graphs is not None and len(recs):     # the top-hit-only gather: one row per region leaves this rank
+        from .top_hits import best_rows_per_region
+        _, region_key = np.unique(np.asarray(seqnames, dtype=object), return_inverse=True)
+        keep = None if recomb else (recs["freq"] > 0)
+        sel = np.sort(best_rows_per_region(region_key, recs["score"], np.arange(len(recs)), keep))
+        recs, seqnames = recs[sel], [seqnames[i] for i in sel.tolist()]
     lo, pv = dm_annotate_host(motif, dm, recs["score"])
     cols = dict(start=recs["start"], stop=recs["stop"], strand=recs["strand"], logodds=lo, pvalue=pv,
                 kmers=np.ascontiguousarray(recs["kmer"][:, :W]), freq=recs["freq"], is_ref=recs["is_ref"])
@@ -990,7 +1005,7 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
         cols = got_c
         seqnames = [x for lst in label_lists for x in lst]
     k = cols["kmers"]
-    return build_frame_sorted(
+    df = build_frame_sorted(
         motif, seqnames=np.array(seqnames, dtype=object), starts=cols["start"], stops=cols["stop"],
         strands=np.where(cols["strand"] == ord("+"), "+", "-").astype(object),
         scores=cols["logodds"], pvalues=cols["pvalue"], qvalues=None if no_qvalue else cols["qvalue"],
@@ -999,6 +1014,10 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
         # vg flags a walk over a deletion `ref`; GRAFIMO repairs that on ingest (score_sequences.py:305-307)
         references=np.where((cols["is_ref"] != 0) & (np.abs(cols["stop"] - cols["start"]) == W), "ref", "non.ref").astype(object),
         recomb=recomb)
+    if top_graphs is not None:
+        from .top_hits import top_regions_table
+        df = top_regions_table(df, top_graphs)
+    return df
 
 
 def dm_annotate_host(motif, dm, scaled):

@@ -31,6 +31,7 @@ class ScanSlot:
         self.nrows = torch.zeros(1, dtype=torch.int64, device=device)
         # [0] = hit count, [1:] = hit rows (one buffer so that one gather moves both)
         self.hits = torch.zeros(self.hit_capacity + 1, dtype=torch.int64, device=device)
+        self.best = None      # per-region best (score, row) keys of gfm_region_best (allocated by KmerScanner.set_regions)
         self.cand = None      # [count | candidate entries] of a q-value threshold scan (allocated on first use)
         self.p_cand_count = self.p_cand_rows = None
         self.done = torch.cuda.Event()
@@ -123,6 +124,25 @@ class KmerScanner:
         # entries of a slot's hit buffer ([count | hits...]) that a gather moves: the whole buffer until
         # size_gather() has seen how many hits a batch really holds
         self.gather_len = cap + 1
+        # per-region best hit (set_regions): region ids of a batch's rows, optional haplotype counts, and whether the
+        # per-step gather moves the n_regions keys INSTEAD of the hit entries (top_only)
+        self._regions = None
+        self.top_only = False
+
+    def set_regions(self, region, n_regions: int, freq=None, top_only: bool = False):
+        """Per-region best hit beside the hit list (north_star: the top-hit reduction; top_hits.py): every enqueue() then
+        also leaves, in slot.best, for each of `n_regions` regions the key of its best row among those that pass the
+        batch's threshold (and have freq > 0 if `freq` is given: the rows reported without --recomb).  `region`: int32
+        [n_rows] on the device, region id per row of the batches to come (the same layout for every batch).
+        top_only: with a process group the per-step gather moves these n_regions keys per rank INSTEAD of every hit
+        entry -- what a caller that asks for the top regions only needs (res_writer.py:153-157)."""
+        torch = _torch()
+        assert region.dtype == torch.int32 and region.is_cuda
+        self._regions = (region, int(n_regions), freq)
+        self.top_only = bool(top_only)
+        for s in self.slots:
+            s.best = torch.zeros(int(n_regions), dtype=torch.int64, device=self.device)
+            s.gathered = None
 
     def size_gather(self, margin: float = 1.25, granule: int = 512) -> int:
         """Cut the per-step hit gather down to what is hit: the largest hit count of the finished batches
@@ -217,6 +237,15 @@ class KmerScanner:
             _nv.check(lib.gfm_select_hits_from(h, slot.p_scores, n, slot.p_cutoff, int(row_base),
                                                slot.p_cand_rows, slot.hit_capacity, slot.p_cand_count,
                                                slot.p_hit_rows, slot.hit_capacity, slot.p_hit_count, tail_p))
+        if self._regions is not None:
+            region, n_regions, freq = self._regions
+            with torch.cuda.stream(tail):
+                slot.best.zero_()
+            # rows under the batch's threshold: the p-value cutoff is known on the host, the q-value cutoff lives in slot.cutoff
+            _nv.check(lib.gfm_region_best(slot.p_scores, n, region.data_ptr(), n_regions,
+                                          freq.data_ptr() if freq is not None else None,
+                                          0 if on_qvalue else self._cutoffs[float(threshold)],
+                                          slot.p_cutoff if on_qvalue else None, int(row_base), slot.best.data_ptr(), tail_p))
         if gather_hits and self.collective:
             gs = self._gather_stream
             if gs is not None:                 # gather on its own stream, behind this step's tail
@@ -240,7 +269,9 @@ class KmerScanner:
         (world-1) buffers into rank 0 only; if the backend lacks it, all_gather is the fallback."""
         torch = _torch()
         dist = torch.distributed
-        part = slot.hits[:self.gather_len]      # [count | the first gather_len - 1 hit entries]
+        # [count | the first gather_len - 1 hit entries] -- or, for a caller that wants the top regions only, the n_regions
+        # best-hit keys: the top-hit-only gather
+        part = slot.best if (self.top_only and slot.best is not None) else slot.hits[:self.gather_len]
         if slot.gathered is None and (self.rank == 0 or not self._gather_ok):
             slot.gathered = [torch.empty_like(part) for _ in range(self.world)]
         if self._gather_ok:
@@ -268,6 +299,14 @@ class KmerScanner:
         are merged (rows are global ids through row_base)."""
         torch = _torch()
         slot.done.synchronize()
+        if self.top_only and slot.best is not None:      # per-region keys: the ranks' tables merged by maximum (regions are sharded,
+            keys = slot.best                             # so at most one rank holds a key for a region)
+            if slot.gathered is not None and self.rank == 0:
+                keys = torch.stack(slot.gathered).max(dim=0).values
+            out = {"best": keys.cpu().numpy(), "n_scored": int(slot.nrows.item()) if want_qvalues else None}
+            if want_qvalues:
+                out["qtable"] = slot.qtable.cpu().numpy()
+            return out
         bufs = [slot.hits]
         if slot.gathered is not None and self.rank == 0:
             bufs = slot.gathered
@@ -283,6 +322,8 @@ class KmerScanner:
         out = {"rows": rows, "scaled": scaled, "n_scored": int(slot.nrows.item()) if want_qvalues else None}
         if want_qvalues:
             out["qtable"] = slot.qtable.cpu().numpy()
+        if slot.best is not None:
+            out["best"] = slot.best.cpu().numpy()
         return out
 
 

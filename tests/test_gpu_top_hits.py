@@ -174,3 +174,74 @@ def test_any_row_order_ragged_sizes_and_accumulation(dev):
     ids = th.region_ids(off, 1000, device=dev).cpu().numpy()
     assert np.array_equal(ids, np.searchsorted(off, np.arange(1000), side="right") - 1)
     assert len(th.region_best(torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev), 3)) == 3
+
+
+def test_scanner_keeps_the_best_hit_per_region_and_gathers_only_that(ctcf):
+    """KmerScanner.set_regions: every step leaves per region the key of its best reported row (threshold on p and on q,
+    haplotype-frequency filter) == a numpy group-by over oracle scores; with a process group (RCCL, one rank here) and
+    top_only the per-step gather moves the n_regions keys instead of the hit entries."""
+    import torch.distributed as dist
+    from grafimo_amd import synth, top_hits as th
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.scan import KmerScanner
+    from oracle import oracle as orc
+    dev = torch.device("cuda:0")
+    n_reg = 400
+    batch = synth.make_batch(n_reg, 600, 19, ctcf["probs"], synth.seed_for(21))
+    exp = _oracle_scores(ctcf, batch.kmers)
+    ptab = orc.p_table(ctcf["pmf"])
+    q = orc.fdr_bh(ptab[exp])
+    dm = DeviceMotif(ctcf["score_matrix"], ctcf["bg"], ctcf["min_val"], ctcf["scale"], ctcf["offset"], ctcf["pmf"])
+    d_k, region = torch.from_numpy(batch.kmers).to(dev), torch.from_numpy(batch.region).to(dev)
+    freq = torch.from_numpy(batch.freq).to(dev)
+    started = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29588")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        started = True
+    try:
+        for on_q, thr, use_freq, coll in [(False, 1e-3, False, False), (False, 1e-3, True, True), (True, 0.5, True, True)]:
+            sc = KmerScanner(dm, len(batch), device=dev, always_collective=coll)
+            sc.set_regions(region, n_reg, freq=freq if use_freq else None, top_only=coll)
+            slot = sc.enqueue(d_k, thr, on_qvalue=on_q, want_qvalues=True, gather_hits=coll)
+            res = sc.collect(slot)
+            keep = ((q < thr) if on_q else (ptab[exp] < thr)) & ((batch.freq > 0) if use_freq else True)
+            es, er = _np_region_best(exp, batch.region, n_reg, keep=keep)
+            s_, r_, ok = th.decode_best(res["best"])
+            assert np.array_equal(s_, es) and np.array_equal(r_, er), (on_q, thr, use_freq, coll)
+            assert ok.sum() > 5
+            if coll:
+                assert "rows" not in res and slot.gathered is not None and slot.gathered[0].numel() == n_reg
+    finally:
+        if started:
+            dist.destroy_process_group()
+        dm.close()
+
+
+def test_graph_path_top_graphs_is_the_first_row_per_region_of_the_report(tmp_path):
+    """compute_results_from_graph(top_graphs=N) == top_regions_table(full report, N), fused and materialising."""
+    import contextlib
+    import io
+    from extract_helpers import make_graph_files
+    from grafimo_amd import top_hits as th
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, compute_results_from_graph
+    from grafimo_amd.motif_ops import build_motif_meme_host
+    from grafimo_amd.workflow import Findmotif
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=6000, n_sites=400, seed=31)
+    with contextlib.redirect_stderr(io.StringIO()):
+        g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7"))
+    motif = build_motif_meme_host(os.path.join(REF_DATA, "MA0139.1.meme"), "unfrm_dst", 0.1, False)[0]
+    regions = [(i, i + 300) for i in range(0, 5700, 300)]
+    for kw in (dict(threshold=0.02), dict(threshold=0.02, recomb=True)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            full = compute_results_from_graph(motif, g, regions, True, Findmotif(**kw))
+            top = compute_results_from_graph(motif, g, regions, True, Findmotif(**kw), top_graphs=5)
+            top_m = compute_results_from_graph(motif, g, regions, True, Findmotif(**kw), top_graphs=5, fused=False)
+        want = th.top_regions_table(full, 5)
+        assert len(want) == 5 and full["sequence_name"].nunique() > 5
+        for c in full.columns:
+            assert (top[c].astype(str) == want[c].astype(str)).all(), c
+            assert (top_m[c].astype(str) == want[c].astype(str)).all(), c
+        assert list(top["sequence_name"]) == th.top_regions(full, 5)
+    g.close()
