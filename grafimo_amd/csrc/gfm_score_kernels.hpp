@@ -80,13 +80,20 @@ __device__ inline void hitq_finish(const long long *hitq, int qn, int *wq_n /* s
 }
 
 // ---------------------------------------------------------------------------------------
+// Rows outside a partial LDS window are counted by no-return global atomics.  Their scores are the few bins next to the
+// window's edges, and ONE address takes ~88 atomics per microsecond on this chip: 1e5 such rows per launch (0.1 % of
+// 1e8) on a handful of bins cost a three-motif launch 100-170 us of its 430 (profiles/r04_config5_shapes.txt).  So the
+// counters exist kSpillCopies times and a workgroup uses the copy of its index; post_kernel adds the copies up.
+constexpr int kSpillCopies = 16;
+
 // Argument block of one motif in a score launch (score_quad_kernel<W, MM> takes MM of them).
 struct MotifArgs {
     const uint16_t *tab;      // [2*NDW][64] pair tables (global)
     int lo, nb, min_val;      // LDS histogram window [lo, lo+nb) (+ the N bin at nb)
     int use_hist;             // 0 none, 1 LDS window -> slab (+ spill outside the window)
     int spill_lo;             // first score of the motif's full range
-    unsigned *spill;          // [full range] counters of rows outside the window (post re-zeroes)
+    int spill_n;              // bins of the full range
+    unsigned *spill;          // [kSpillCopies][full range] counters of rows outside the window (post re-zeroes)
     int cutoff;               // rows with score >= cutoff are hits; GFM_NO_SELECT: none
     int slot;                 // HitCtl slot of this call
     int *scores;
@@ -172,11 +179,16 @@ post_body(const unsigned *__restrict__ partials, int nslabs, int nb, int lo, int
     if ((int)blockIdx.x < hist_blocks + spill_blocks) {
         const int b = ((int)blockIdx.x - hist_blocks) * 256 + tid;
         if (b < spill_n) {
-            const unsigned v = spill[b];
-            if (v) {
-                atomicAdd(&hist64[spill_lo + b], (unsigned long long)v);
-                spill[b] = 0u;
+            unsigned long long v = 0;
+#pragma unroll
+            for (int c = 0; c < kSpillCopies; ++c) {
+                const unsigned x = spill[(size_t)c * (size_t)spill_n + b];
+                if (x) {
+                    v += x;
+                    spill[(size_t)c * (size_t)spill_n + b] = 0u;
+                }
             }
+            if (v) atomicAdd(&hist64[spill_lo + b], v);
         }
         return;
     }

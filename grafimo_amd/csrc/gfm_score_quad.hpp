@@ -130,7 +130,7 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
                     else if (p_score[m][j] == ma.min_val)   // a row holding N scores min_val, below every reachable
                         atomicAdd(&hist[m][ma.nb], 1u);     // sum unless the window holds min_val itself
                     else
-                        atomicAdd(&ma.spill[p_score[m][j] - ma.spill_lo], 1u);   // outside the window: rare
+                        atomicAdd(&ma.spill[(size_t)(blockIdx.x & (kSpillCopies - 1)) * (size_t)ma.spill_n + (size_t)(p_score[m][j] - ma.spill_lo)], 1u);   // outside the window: rare
                 }
             }
             if (select[m]) {
@@ -339,7 +339,7 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
                         else if (sc == ma.min_val)
                             atomicAdd(&hist[m][ma.nb], 1u);
                         else
-                            atomicAdd(&ma.spill[sc - ma.spill_lo], 1u);
+                            atomicAdd(&ma.spill[(size_t)(blockIdx.x & (kSpillCopies - 1)) * (size_t)ma.spill_n + (size_t)(sc - ma.spill_lo)], 1u);
                     }
                 }
                 if (select[m])

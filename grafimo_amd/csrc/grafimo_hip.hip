@@ -26,6 +26,7 @@
 
 #define GFM_API extern "C" __attribute__((visibility("default")))
 
+#include "gfm_hit_sort.hpp"
 #include "gfm_common.hpp"
 #include "gfm_score_kernels.hpp"
 #include "gfm_quad_launch.hpp"
@@ -58,7 +59,7 @@ struct gfm_motif {
     // Scoring workspace, a ring of kWorkspaces sets taken in call order, so that the post kernel of call k
     // (on a tail stream) may run while the score kernels of calls k+1.. fill the other sets.
     unsigned *d_partials[kWorkspaces] = {};   // [max_slabs][hnb+1] histogram slabs
-    unsigned *d_spill[kWorkspaces] = {};      // [nb] rows outside a partial window
+    unsigned *d_spill[kWorkspaces] = {};      // [kSpillCopies][nb] rows outside a partial window
     long long *d_resid[kWorkspaces] = {};     // [max_slabs][kResidPerWG] residual hits
     int *d_resid_n[kWorkspaces] = {};         // [max_slabs]
     // q-value kernels' scratch, one set PER STREAM that has called gfm_qvalue_table on this handle (kQStreams of
@@ -311,6 +312,7 @@ void fill_motif_args(MotifArgs &a, gfm_motif *m, int ws, int slot, int use_hist,
     a.min_val = m->min_val;
     a.use_hist = use_hist;
     a.spill_lo = m->lo;
+    a.spill_n = m->nb;
     a.spill = m->d_spill[ws];
     a.cutoff = cutoff;
     a.slot = slot;
@@ -325,10 +327,14 @@ void fill_motif_args(MotifArgs &a, gfm_motif *m, int ws, int slot, int use_hist,
 }
 
 // Grouping of a batched launch: the largest group (<= 3 motifs; 1 beyond kQuadMaxBatchWidth) at the head of
-// `motifs` whose LDS histogram windows still hold kMinWindowMass of each motif's background score distribution,
-// with 16 waves per workgroup if that works and 8 (half the strips) otherwise.  Windows share what the tables and
-// strips leave: a motif whose whole range fits takes it, the others split the rest and spill the rows outside
-// their window.  with_hist[k]: motif k accumulates a histogram.  -> false: not even one motif fits.
+// `motifs` whose LDS histogram windows still hold kMinWindowMass of each motif's background score distribution.
+// Per group size the shapes are tried in this order: 16 waves per workgroup with every window WHOLE, 8 waves (half the
+// strips) with every window whole, then 16 and 8 waves with partial windows.  Windows share what the tables and strips
+// leave: a motif whose whole range fits takes it, the others split the rest and spill the rows outside their window
+// through global atomics -- which is why whole windows at 8 waves go first: on config 5 (1e8 rows per width) the
+// three-motif launches with 8 waves and whole windows run at 0.66-0.75 of the HBM peak, the two widths (12, 14) that
+// got 16 waves with 99.9 % windows at 0.51 and 0.62 (profiles/r04_kernel_stats_config5.csv): 1e5 spilled rows per
+// motif cost more than half the waves.  with_hist[k]: motif k accumulates a histogram.  -> false: not even one motif fits.
 bool plan_group(const gfm_motif_t *motifs, int n_left, const bool *with_hist, int *mm_out, int *waves_out,
                 int *win_lo, int *win_nb)
 {
@@ -338,45 +344,49 @@ bool plan_group(const gfm_motif_t *motifs, int n_left, const bool *with_hist, in
     int waves = kWavesPerWG;
     bool found = false;
     for (; mm >= 1 && !found; --mm) {
-        for (waves = kWavesPerWG; waves >= kWavesPerWG / 2 && !found; waves /= 2) {
-            const long long spare = (long long)kMaxLdsBytes - (long long)quad_fixed_lds(W, waves, mm);   // bytes
-            long long room = spare / (long long)sizeof(unsigned);
-            bool open[3] = {false, false, false};
-            int users = 0;
-            for (int k = 0; k < mm; ++k) {
-                win_nb[k] = 0;
-                win_lo[k] = motifs[k]->lo;
-                open[k] = with_hist[k];
-                users += open[k];
+        // (a lone motif keeps the single-motif launch's order: 16 waves, partial window if need be, before 8 waves)
+        for (int pass = mm > 1 ? 0 : 1; pass < 2 && !found; ++pass) {       // 0: whole windows only, 1: partial windows allowed
+            for (waves = kWavesPerWG; waves >= kWavesPerWG / 2 && !found; waves /= 2) {
+                const long long spare = (long long)kMaxLdsBytes - (long long)quad_fixed_lds(W, waves, mm);   // bytes
+                long long room = spare / (long long)sizeof(unsigned);
+                bool open[3] = {false, false, false};
+                int users = 0;
+                for (int k = 0; k < mm; ++k) {
+                    win_nb[k] = 0;
+                    win_lo[k] = motifs[k]->lo;
+                    open[k] = with_hist[k];
+                    users += open[k];
+                }
+                // (tables, strips and queues must fit even when no motif wants a window: wide motifs get 8 waves)
+                bool ok = spare >= 0 && (room > 0 || users == 0);
+                // water-filling: ranges that fit their equal share are served whole, the rest share again
+                for (bool again = true; ok && again && users > 0;) {
+                    again = false;
+                    const long long share = room / users - 1;
+                    for (int k = 0; k < mm; ++k)
+                        if (open[k] && motifs[k]->nb <= share) {
+                            win_nb[k] = motifs[k]->nb;
+                            room -= win_nb[k] + 1;
+                            open[k] = false;
+                            --users;
+                            again = true;
+                        }
+                }
+                if (ok && users > 0) {
+                    const long long share = room / users - 1;
+                    if (pass == 0 || share < 256) ok = false;
+                    for (int k = 0; ok && k < mm; ++k)
+                        if (open[k]) {
+                            const gfm_motif::Window w = best_window(motifs[k], (int)share);
+                            win_nb[k] = w.bins;
+                            win_lo[k] = w.lo;
+                            // a partial window is acceptable for a lone motif at 8 waves (nothing smaller exists)
+                            if ((mm > 1 || waves > kWavesPerWG / 2) && w.mass < kMinWindowMass) ok = false;
+                        }
+                }
+                found = ok;
+                if (found) break;
             }
-            // (tables, strips and queues must fit even when no motif wants a window: wide motifs get 8 waves)
-            bool ok = spare >= 0 && (room > 0 || users == 0);
-            // water-filling: ranges that fit their equal share are served whole, the rest share again
-            for (bool again = true; ok && again && users > 0;) {
-                again = false;
-                const long long share = room / users - 1;
-                for (int k = 0; k < mm; ++k)
-                    if (open[k] && motifs[k]->nb <= share) {
-                        win_nb[k] = motifs[k]->nb;
-                        room -= win_nb[k] + 1;
-                        open[k] = false;
-                        --users;
-                        again = true;
-                    }
-            }
-            if (ok && users > 0) {
-                const long long share = room / users - 1;
-                if (share < 256) ok = false;
-                for (int k = 0; ok && k < mm; ++k)
-                    if (open[k]) {
-                        const gfm_motif::Window w = best_window(motifs[k], (int)share);
-                        win_nb[k] = w.bins;
-                        win_lo[k] = w.lo;
-                        // a partial window is acceptable for a lone motif at 8 waves (nothing smaller exists)
-                        if ((mm > 1 || waves > kWavesPerWG / 2) && w.mass < kMinWindowMass) ok = false;
-                    }
-            }
-            found = ok;
             if (found) break;
         }
         if (found) break;
@@ -624,7 +634,7 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     const size_t o_sel_resid = carve(sizeof(long long) * (size_t)m->sel_slabs * kResidPerWG);
     const size_t o_sel_resid_n = carve(sizeof(int) * (size_t)m->sel_slabs);
     const size_t o_zero = slab_bytes;                 // what follows starts out zeroed
-    for (int i = 0; i < kWorkspaces; ++i) o_spill[i] = carve(sizeof(unsigned) * (size_t)m->nb);
+    for (int i = 0; i < kWorkspaces; ++i) o_spill[i] = carve(sizeof(unsigned) * (size_t)m->nb * (size_t)kSpillCopies);
     const size_t o_ctl = carve(sizeof(HitCtl));
     const size_t o_sel_ctl = carve(sizeof(HitCtl));
     HIP_TRY_M(hipMalloc(&m->d_slab, slab_bytes));
@@ -1311,7 +1321,7 @@ GFM_API int gfm_scan_host(gfm_motif_t m, const uint8_t *h_kmers, int64_t n, doub
             SCAN_TRY(hipMemcpyAsync(q.data(), d_q, sizeof(double) * (size_t)m->L, hipMemcpyDeviceToHost, st));
         }
         SCAN_TRY(hipStreamSynchronize(st));
-        std::sort(rows.begin(), rows.end());  // packed (row << 20 | score): ascending by row
+        gfm_hit_sort::sort_packed(reinterpret_cast<int64_t *>(rows.data()), rows.size(), GFM_HIT_SCORE_BITS);  // ascending by row
         for (size_t i = 0; i < cnt; ++i) {
             const int s = (int)(rows[i] & ((1ll << GFM_HIT_SCORE_BITS) - 1));
             if (h_rows) h_rows[i] = rows[i] >> GFM_HIT_SCORE_BITS;

@@ -38,6 +38,7 @@
 #include <thread>
 #include <vector>
 
+#include "gfm_hit_sort.hpp"
 #include "gfm_tsv_internal.hpp"
 #include "gfm_workers.hpp"
 
@@ -1119,7 +1120,7 @@ GFM_API int gfm_scan_tsv_finish(gfm_scan_t sc, int64_t *n_hits)
                 S_TRY(hipMemcpyAsync(q.data(), b.d_q, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, P->score));
             }
             S_TRY(hipStreamSynchronize(P->score));
-            std::sort(packed.begin(), packed.end());   // (row << 20 | score): ascending by row
+            gfm_hit_sort::sort_packed(packed.data(), packed.size(), GFM_HIT_SCORE_BITS);   // ascending by row
             MotifHits &h = sc->hits[j];
             h.rows.resize((size_t)cnt);
             h.scaled.resize((size_t)cnt);

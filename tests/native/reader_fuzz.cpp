@@ -9,6 +9,8 @@
 #include <vector>
 #include "grafimo_hip.h"
 #include "gfm_tsv_internal.hpp"
+#include "gfm_hit_sort.hpp"
+#include <algorithm>
 static thread_local std::string g_err;
 extern "C" void gfm_set_error_(const char *m) { g_err = m ? m : ""; }
 static std::string slurp(const char *p) { std::ifstream f(p, std::ios::binary); return std::string((std::istreambuf_iterator<char>(f)), {}); }
@@ -209,5 +211,22 @@ int main(int argc, char **argv)
         } else ++bad;
     }
     std::printf("vcf: %ld parsed, %ld refused\n", ok, bad);
+    // the hit entries' order (gfm_hit_sort.hpp): distinct rows << 20 | score, every size class of the radix passes
+    for (int it = 0; it < 60; ++it) {
+        const size_t n = it < 6 ? (size_t)it : (size_t)(rng() % (it < 30 ? 2000 : 300000));
+        const int row_bits = 1 + (int)(rng() % 40);
+        std::vector<int64_t> v(n);
+        int64_t row = 0;
+        for (size_t i = 0; i < n; ++i) {
+            row += 1 + (int64_t)(rng() % (uint64_t)std::max<int64_t>(1, (1ll << row_bits) / (int64_t)(n + 1)));   // distinct, < 2^43
+            v[i] = (row << 20) | (int64_t)(rng() % (1 << 20));
+        }
+        std::shuffle(v.begin(), v.end(), rng);
+        std::vector<int64_t> want = v;
+        std::stable_sort(want.begin(), want.end(), [](int64_t a, int64_t b) { return (a >> 20) < (b >> 20); });
+        gfm_hit_sort::sort_packed(v.data(), v.size(), 20);
+        if (v != want) { std::printf("SORT MISMATCH it=%d n=%zu\n", it, n); return 1; }
+    }
+    std::printf("sort: ok\n");
     return 0;
 }
