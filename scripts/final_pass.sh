@@ -53,3 +53,11 @@ rm -rf "$root/gpurun_out/pmc_$tag"/*/
 cd "$root"
 python scripts/ingest_probe.py > "$out/ingest_probe.txt" 2>&1
 GRAFIMO_FUSED_TIMERS=1 python scripts/fused_prof.py 2>&1 | grep "\[fused\]" | tail -16 > "$out/fused_timers.txt"
+# the four fuzz drivers on fresh seeds (bounded: FUZZ_S seconds each), the round's last code
+{
+  s0=$(( $(date +%s) % 100000 ))
+  for f in score_fuzz scan_fuzz results_fuzz extract_fuzz; do
+    echo "== scripts/$f.py ${FUZZ_S:-100} $s0"
+    timeout $(( ${FUZZ_S:-100} + 200 )) python scripts/$f.py ${FUZZ_S:-100} $s0 2>&1 | grep -v "amdgpu.ids" | tail -4
+  done
+} > "$out/fuzz_final.txt" 2>&1
