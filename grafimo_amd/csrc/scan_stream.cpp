@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -31,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -184,7 +186,7 @@ struct ScanPool {
     // the slots; files that do not fit (or directories beyond kTextMax) go through the threads' own buffers and their
     // hit rows are read back from the files.
     char *text = nullptr;
-    size_t text_cap = 0;
+    size_t text_cap = 0, text_map = 0;
     int64_t meta_rows = 0;                  // rows (and width) the column blocks were made for
     int meta_W = 0;
     bool in_use = false;
@@ -246,20 +248,35 @@ struct ScanPool {
     // one column block per chunk on the host.  Kept, they make the next scan of that size allocation-free; beyond these
     // budgets the blocks of the highest chunk indices are given back when a scan closes (nothing of it is in flight then).
     static constexpr size_t kKeepHostBytes = (size_t)3 << 30, kKeepDeviceBytes = (size_t)4 << 30, kTextMax = (size_t)8 << 30;
+    // The text arena is its own mapping, advised to use huge pages: 1.8 GB of 4 KiB pages is 450 000 TLB entries'
+    // worth of text that is written once by read(), read once by the scan and then picked at by the hit rows -- each
+    // of those a page walk (the hit rows' columns: 208 -> 130 ms of CPU at 193 000 hits once the walks were gone).
+    void free_text()
+    {
+        if (text) (void)::munmap(text, text_map);
+        text = nullptr;
+        text_cap = text_map = 0;
+    }
     int reserve_text(size_t bytes)
     {
         if (bytes <= text_cap) return GFM_OK;
-        std::free(text);
-        text = nullptr;
-        text_cap = 0;
-        text = static_cast<char *>(std::malloc(bytes));
-        if (!text) return sfail(GFM_ERR_NOMEM, "out of host memory");
+        free_text();
+        if (bytes == 0) return GFM_OK;
+        const size_t huge = (size_t)2 << 20;
+        const size_t len = (bytes + huge - 1) / huge * huge;
+        void *p = ::mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) return sfail(GFM_ERR_NOMEM, "out of host memory");
+#ifdef MADV_HUGEPAGE
+        (void)::madvise(p, len, MADV_HUGEPAGE);      // (refused where the kernel has none: small pages then, as before)
+#endif
+        text = static_cast<char *>(p);
+        text_map = len;
         text_cap = bytes;
         return GFM_OK;
     }
     void trim()
     {
-        if (text_cap > kKeepHostBytes) { std::free(text); text = nullptr; text_cap = 0; }
+        if (text_cap > kKeepHostBytes) free_text();
         const size_t per_meta = (size_t)meta_rows * sizeof(uint64_t) + 64;
         while (!meta.empty() && meta.size() * per_meta + text_cap > kKeepHostBytes) {
             meta.back().release();
@@ -292,7 +309,7 @@ struct ScanPool {
         mb.clear();
         for (auto &m : meta) m.release();
         meta.clear();
-        std::free(text);
+        free_text();
         if (copy) (void)hipStreamDestroy(copy);
         if (score) (void)hipStreamDestroy(score);
         *this = ScanPool();
@@ -408,7 +425,17 @@ int fetch_hit_columns(gfm_scan *sc)
         }
     }
     if (jobs.empty()) return GFM_OK;
+    const bool trace = std::getenv("GRAFIMO_SCAN_TRACE") != nullptr;
+    const double t_jobs = trace ? now_s() : 0.0;
+    std::atomic<int64_t> cpu_offsets{0}, cpu_lines{0};
+    auto tcpu = []() -> int64_t {
+        timespec ts{};
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+        return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+    };
     std::atomic<size_t> next{0};
+    const int n_workers = std::max(1, std::min<int>(sc->n_threads, (int)((jobs.size() + 3) / 4)));
+    const size_t job_run = std::max<size_t>(1, std::min<size_t>(64, jobs.size() / ((size_t)n_workers * 4)));
     std::mutex err_mu;
     std::string err;
     auto fail_job = [&](const std::string &msg) {
@@ -418,9 +445,16 @@ int fetch_hit_columns(gfm_scan *sc)
     auto work = [&]() {
         static thread_local gfm_tsv_detail::FileBuf whole;
         std::vector<char> buf;
+        size_t jx_at = 0, jx_end = 0;
         for (;;) {
-            const size_t jx = next.fetch_add(1, std::memory_order_relaxed);
-            if (jx >= jobs.size()) break;
+            // Jobs are taken a run at a time: neighbouring jobs write neighbouring entries of the hit columns, and handed out
+            // one by one they made 24 threads share every cache line of the one-byte columns (660 ns of CPU per hit row).
+            if (jx_at == jx_end) {
+                jx_at = next.fetch_add(job_run, std::memory_order_relaxed);
+                if (jx_at >= jobs.size()) break;
+                jx_end = std::min(jobs.size(), jx_at + job_run);
+            }
+            const size_t jx = jx_at++;
             HitJob &job = jobs[jx];
             MotifHits &h = sc->hits[job.motif];
             const std::string &path = sc->paths[job.file];
@@ -431,7 +465,6 @@ int fetch_hit_columns(gfm_scan *sc)
                 h.start[i] = c.start; h.stop[i] = c.stop; h.freq[i] = c.freq;
                 h.strand[i] = c.strand; h.is_ref[i] = c.is_ref;
                 h.name_id[i] = names.id(c.name, c.name_len);
-                names.last = nullptr;      // (the table remembers the last name by ADDRESS: ours lies in a buffer that is read into again)
             };
             auto offset_of = [&](size_t i) {
                 const int64_t r = h.rows[i];
@@ -442,6 +475,20 @@ int fetch_hit_columns(gfm_scan *sc)
             };
             if (const char *text = sc->kept[job.file].p) {       // the file's text is still in the scan's arena
                 const char *tend = text + sc->kept[job.file].len;
+                const int64_t jc0 = trace ? tcpu() : 0;
+                // (the lines lie anywhere in 1.8 GB of text that has left every cache: ask for them all before the first is parsed)
+                for (size_t i = job.i0; i < job.i1; ++i) {
+                    const uint64_t off = offset_of(i);
+                    if (off < (uint64_t)(tend - text)) {
+                        __builtin_prefetch(text + off);
+                        __builtin_prefetch(text + off + 64);
+                    }
+                }
+                const int64_t jc1 = trace ? tcpu() : 0;
+                struct Acc {
+                    std::atomic<int64_t> &a, &b; int64_t t0, t1; bool on; int64_t (*clk)();
+                    ~Acc() { if (on) { a.fetch_add(t1 - t0, std::memory_order_relaxed); b.fetch_add(clk() - t1, std::memory_order_relaxed); } }
+                } acc{cpu_offsets, cpu_lines, jc0, jc1, trace, +tcpu};
                 for (size_t i = job.i0; i < job.i1; ++i) {
                     const uint64_t off = offset_of(i);
                     gfm_tsv_detail::LineCols c;
@@ -503,7 +550,9 @@ int fetch_hit_columns(gfm_scan *sc)
             ::close(fd);
         }
     };
-    gfm_workers::run(std::max(1, std::min<int>(sc->n_threads, (int)((jobs.size() + 3) / 4))), work);
+    const double t_run = trace ? now_s() : 0.0;
+    gfm_workers::run(n_workers, work);
+    const double t_merge = trace ? now_s() : 0.0;
     if (!err.empty()) return sfail(GFM_ERR_IO, err);
     // local name ids -> ids in the scan's table
     gfm_tsv_detail::NameTable global(sc->table.names);
@@ -513,6 +562,10 @@ int fetch_hit_columns(gfm_scan *sc)
         MotifHits &h = sc->hits[job.motif];
         for (size_t i = job.i0; i < job.i1; ++i) h.name_id[i] = map[(size_t)h.name_id[i]];
     }
+    if (trace)
+        std::fprintf(stderr, "[scan] hit columns: %zu jobs listed in %.3f ms, run %.3f ms (worker CPU: offsets + prefetch %.1f ms, lines %.1f ms), "
+                             "names merged in %.3f ms\n", jobs.size(), (t_run - t_jobs) * 1e3, (t_merge - t_run) * 1e3,
+                     cpu_offsets.load() * 1e-6, cpu_lines.load() * 1e-6, (now_s() - t_merge) * 1e3);
     return GFM_OK;
 }
 
@@ -619,19 +672,19 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     const bool fused = !on_qvalue;
     stamp("pool sized");
 
-    // ---- host pipeline.  The files are taken in path order.  A worker READS a file into one of its few buffers and
-    // COUNTS its rows at once (a newline scan over bytes that are hot): that fixes the file's global row offset as soon
-    // as every earlier file is counted.  The same worker then PARSES the file from the same bytes, writing each row
-    // where it belongs -- the k-mer into the pinned slot of its chunk, the other columns (and the k-mer again: hits are
-    // annotated from it) into the chunk's column block.  One read() per file (the kernel's copy out of the page cache
-    // is the floor of the whole scan: ~40 GB/s on this host, whatever the thread count), no per-file vectors, no
-    // staging copy, no allocation once the pool has its size.  (Round 2 parsed into per-file columns and copied the
-    // k-mers into the slots afterwards: at 2e7 rows the page faults of 1.4 GB of fresh vectors made it 250 ms; a
-    // count pass and a parse pass that each read the file took 110-200 ms.)  The calling thread only sequences
-    // chunks: chunk k goes to the device once every row of it is in place; its slot is handed back to the workers
-    // when the score kernel has read it.
+    // ---- host pipeline.  The files are taken in path order.  A worker READS a file into its own small text buffer and
+    // SCANS it at once (k-mer + line offset per row into a stage of the worker): that fixes the file's global row offset
+    // as soon as every earlier file is scanned.  The text goes to the scan's arena (non-temporal copy) for the hit rows'
+    // columns later; the stage's rows are COPIED to where they belong -- the k-mers into the pinned slot of their chunk,
+    // the line offsets into the chunk's block -- once the offset is known.  One read() per file, no allocation once the
+    // buffers have their size.  What was measured on the way (CPU seconds per 2e7 rows in 10 000 files, 16-CPU quota):
+    // round 2 parsed into per-file columns (page faults of 1.4 GB of fresh vectors: 250 ms wall); round 3 read into ring
+    // buffers, counted, parsed every column in place (1.1 s); round 4 first read straight into the arena, counted, and
+    // scanned k-mers only (0.86 s: the read() into cold memory alone 0.46 s, profiles/r04_ingest_cpu.txt), then this.
+    // The calling thread only sequences chunks: chunk k goes to the device once every row of it is in place; its slot is
+    // handed back to the workers when the score kernel has read it.
     const int nt = gfm_tsv_detail::pick_threads(paths, n_paths, n_threads);
-    constexpr int kRing = 4;                 // files a worker may hold read-and-counted, waiting for their offsets
+    constexpr int kRing = 4;                 // files a worker may hold scanned, waiting for their offsets
     // Coordination is lock-light on purpose: with one mutex taken ~5 times per file, 96 workers on 10 000 files spent
     // more time handing the mutex around than parsing (300 ms at 96 threads against 110 ms at 32).  Files are claimed
     // with an atomic counter; row counts are published through per-file flags and the offsets advanced by whichever
@@ -658,6 +711,13 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     std::atomic<int64_t> parse_end_ns{0};    // steady-clock time of the last finished parse
     // development aid (GRAFIMO_SCAN_TRACE): the longest single wait of each kind, in ns
     std::atomic<int64_t> tr_read{0}, tr_slot{0}, tr_offset{0}, tr_parse{0}, tr_block{0};
+    // ... and the CPU time (this thread's clock) the workers spent per phase, summed over the workers, in ns
+    std::atomic<int64_t> cpu_read{0}, cpu_count{0}, cpu_parse{0}, cpu_keep{0}, cpu_yield{0}, cpu_all{0};
+    auto tcpu = []() -> int64_t {
+        timespec ts{};
+        clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+        return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+    };
     auto tr_max = [](std::atomic<int64_t> &a, int64_t v) {
         int64_t prev = a.load(std::memory_order_relaxed);
         while (prev < v && !a.compare_exchange_weak(prev, v, std::memory_order_relaxed)) {}
@@ -698,97 +758,88 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     std::atomic<int> w_next{0};
     auto work = [&]() {
         const int me = w_next.fetch_add(1);
+        const int64_t cpu_in = trace ? tcpu() : 0;
+        struct CpuAll {
+            std::atomic<int64_t> &a; int64_t t0; bool on; int64_t (*clk)();
+            ~CpuAll() { if (on) a.fetch_add(clk() - t0, std::memory_order_relaxed); }
+        } cpu_total{cpu_all, cpu_in, trace, +tcpu};
         auto set_state = [&](int st, long long file) {
             if (trace && me < nt) w_state[(size_t)me].store(((long long)st << 32) | (file & 0xffffffffll), std::memory_order_relaxed);
         };
-        // this worker's files between their count and their parse, oldest first (the crew's threads live as long as
-        // the process: so do their buffers)
-        static thread_local gfm_tsv_detail::FileBuf ring[kRing];
-        const char *h_begin[kRing] = {}, *h_end[kRing] = {};   // the held files' bytes: in the pool's text arena, or in ring[]
-        int held[kRing], n_held = 0, head = 0;         // file index per ring slot, in order from `head`
+        // A file is read into this thread's one text buffer (the same few hundred KB for every file: the kernel's copy out of
+        // the page cache lands in L2, 24 us a file against 35 into the arena's cold memory), scanned there at once -- k-mers and
+        // line offsets into a STAGE, which also gives the row count that fixes the file's global row offset -- and its text
+        // goes to the arena with non-temporal stores (kept until the scan closes: the hit rows' columns are parsed from it).
+        // Stages wait, oldest first, until every earlier file is counted; then their rows are copied to where they belong.
+        // (The crew's threads live as long as the process: so do these buffers.)
+        struct Stage {
+            std::vector<uint8_t> kmers;
+            std::vector<uint64_t> offs;
+            int64_t rows = 0;
+        };
+        static thread_local gfm_tsv_detail::FileBuf hot;
+        static thread_local Stage stage[kRing];
+        int held[kRing], n_held = 0, head = 0;         // file index per stage, in order from `head`
         int64_t cached_k = -1;                         // the chunk this worker wrote into last, and its column block
         MetaChunk cached_mc;
         struct DropAll {
-            gfm_tsv_detail::FileBuf *r;
-            ~DropAll() { for (int k = 0; k < kRing; ++k) r[k].drop(); }
-        } drop_all{ring};
+            gfm_tsv_detail::FileBuf &h;
+            Stage *st;
+            ~DropAll()
+            {
+                h.drop();
+                for (int k = 0; k < kRing; ++k)        // (a stage that grew for one big file is handed back)
+                    if (st[k].kmers.capacity() > ((size_t)8 << 20)) { std::vector<uint8_t>().swap(st[k].kmers); std::vector<uint64_t>().swap(st[k].offs); }
+            }
+        } drop_all{hot, stage};
         for (;;) {
             if (failed.load(std::memory_order_relaxed)) return;
             if (n_held > 0 && held[head] < next_assign.load(std::memory_order_acquire)) {
-                // my oldest file has its offset: parse it in place
+                // my oldest file has its offset: its rows go into their chunk(s)
                 const int i = held[head];
                 set_state(2, i);
-                struct { const char *b, *e; const char *begin() const { return b; } const char *end() const { return e; } } text{h_begin[head], h_end[head]};
-                FileCols &f = sc->table.files[(size_t)i];
-                const int64_t rows = f.n_rows, off = file_off[(size_t)i];
+                const Stage &st = stage[head];
+                const int64_t rows = st.rows, off = file_off[(size_t)i];
                 std::string err;
-                int64_t done = 0;
-                if (rows > 0) {
-                    int64_t k = -1, in = 0, left = 0;      // chunk, row inside it, rows until the chunk ends
-                    uint8_t *pin = nullptr;
-                    MetaChunk mc;                          // by value: the pool's vector of blocks may grow meanwhile
-                    int64_t placed = 0;                    // rows written into chunk k and not yet accounted
-                    auto account = [&]() {
-                        if (placed == 0) return;
-                        const int64_t now = chunk_staged[(size_t)k].fetch_add(placed, std::memory_order_acq_rel) + placed;
-                        placed = 0;
-                        // the add that completes a chunk wakes the calling thread (a short last chunk: whoever makes
-                        // it reach the total, or advance_offsets when the total becomes known)
-                        const int64_t tot = total_assigned.load(std::memory_order_acquire);
-                        if (now == chunk_rows || (tot >= 0 && now == tot - k * chunk_rows)) wake_main();
-                    };
-                    bool gave_up = false;
-                    auto sink = [&](const uint8_t *kmer, uint64_t line_off) {
-                        if (gave_up || done >= rows) { ++done; return; }   // more rows than counted: reported below
-                        if (left == 0) {
-                            account();
-                            const int64_t g = off + done;
-                            k = g / chunk_rows;
-                            in = g % chunk_rows;
-                            left = chunk_rows - in;
-                            if ((size_t)k >= kMaxChunks) { gave_up = true; err = "too many rows for one scan"; return; }
-                            if (k >= released.load(std::memory_order_acquire) + kSlots) {   // rare: far ahead of the GPU
-                                const double w0 = trace ? now_s() : 0.0;
-                                set_state(3, (long long)i | ((long long)k << 20));
-                                {
-                                    std::unique_lock<std::mutex> g2(mu);
-                                    cv_work.wait(g2, [&] { return failed.load() || k < released.load() + kSlots; });
-                                }
-                                if (trace) tr_max(tr_slot, (int64_t)((now_s() - w0) * 1e9));
-                                set_state(2, i);
-                            }
-                            if (failed.load()) { gave_up = true; return; }
-                            if (k != cached_k) {        // consecutive files of a worker mostly stay in one chunk
-                                const MetaChunk *got;
-                                const double b0 = trace ? now_s() : 0.0;
-                                {
-                                    std::lock_guard<std::mutex> g3(assign_mu);      // the pool's block table
-                                    got = P->meta_chunk((size_t)k, chunk_rows, W);
-                                    if (got) cached_mc = *got;
-                                }
-                                if (trace) tr_max(tr_block, (int64_t)((now_s() - b0) * 1e9));
-                                if (!got) { gave_up = true; err = "out of memory"; return; }
-                                cached_k = k;
-                            }
-                            mc = cached_mc;
-                            pin = P->h_pin[k % kSlots];
+                const int64_t pc0 = trace ? tcpu() : 0;
+                for (int64_t done = 0; done < rows && err.empty();) {
+                    const int64_t g = off + done, k = g / chunk_rows, in = g % chunk_rows;
+                    const int64_t cnt = std::min(rows - done, chunk_rows - in);
+                    if ((size_t)k >= kMaxChunks) { err = "too many rows for one scan"; break; }
+                    if (k >= released.load(std::memory_order_acquire) + kSlots) {   // rare: far ahead of the GPU
+                        const double w0 = trace ? now_s() : 0.0;
+                        set_state(3, (long long)i | ((long long)k << 20));
+                        {
+                            std::unique_lock<std::mutex> g2(mu);
+                            cv_work.wait(g2, [&] { return failed.load() || k < released.load() + kSlots; });
                         }
-                        gfm_tsv_detail::copy_kmer(pin + (size_t)in * (size_t)W, kmer, W);
-                        mc.line_off[in] = line_off;
-                        ++in;
-                        --left;
-                        ++placed;
-                        ++done;
-                    };
-                    std::string perr;
-                    const double p0 = trace ? now_s() : 0.0;
-                    const bool ok = gfm_tsv_detail::scan_rows(paths[i], text.begin(), text.end(), W, skip_reverse != 0, sink, perr);
-                    if (trace) tr_max(tr_parse, (int64_t)((now_s() - p0) * 1e9));
-                    account();
-                    if (!ok) err = perr;
-                    else if (err.empty() && !gave_up && done != rows)
-                        err = std::string(paths[i]) + ": internal error: the row count of the first pass does not hold";
+                        if (trace) tr_max(tr_slot, (int64_t)((now_s() - w0) * 1e9));
+                        set_state(2, i);
+                    }
+                    if (failed.load()) return;
+                    if (k != cached_k) {        // consecutive files of a worker mostly stay in one chunk
+                        const MetaChunk *got;
+                        const double b0 = trace ? now_s() : 0.0;
+                        {
+                            std::lock_guard<std::mutex> g3(assign_mu);      // the pool's block table
+                            got = P->meta_chunk((size_t)k, chunk_rows, W);
+                            if (got) cached_mc = *got;      // by value: the pool's vector of blocks may grow meanwhile
+                        }
+                        if (trace) tr_max(tr_block, (int64_t)((now_s() - b0) * 1e9));
+                        if (!got) { err = "out of memory"; break; }
+                        cached_k = k;
+                    }
+                    std::memcpy(P->h_pin[k % kSlots] + (size_t)in * (size_t)W, st.kmers.data() + (size_t)done * (size_t)W,
+                                (size_t)cnt * (size_t)W);
+                    std::memcpy(cached_mc.line_off + in, st.offs.data() + done, (size_t)cnt * sizeof(uint64_t));
+                    const int64_t now = chunk_staged[(size_t)k].fetch_add(cnt, std::memory_order_acq_rel) + cnt;
+                    // the add that completes a chunk wakes the calling thread (a short last chunk: whoever makes
+                    // it reach the total, or advance_offsets when the total becomes known)
+                    const int64_t tot = total_assigned.load(std::memory_order_acquire);
+                    if (now == chunk_rows || (tot >= 0 && now == tot - k * chunk_rows)) wake_main();
+                    done += cnt;
                 }
+                if (trace) cpu_count.fetch_add(tcpu() - pc0, std::memory_order_relaxed);
                 head = (head + 1) % kRing;
                 --n_held;
                 if (!err.empty()) { fail_with(err); return; }
@@ -798,61 +849,63 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
                 continue;
             }
             if (n_held < kRing && next_count.load(std::memory_order_relaxed) < n_paths) {
-                const int i = next_count.fetch_add(1, std::memory_order_relaxed);    // read the next file, count its rows
+                const int i = next_count.fetch_add(1, std::memory_order_relaxed);    // read and scan the next file
                 if (i < n_paths) {
                     const int slot_ix = (head + n_held) % kRing;
+                    Stage &st = stage[slot_ix];
                     std::string err;
-                    int64_t rows = 0;
                     const double r0 = trace ? now_s() : 0.0;
+                    const int64_t rc0 = trace ? tcpu() : 0;
                     set_state(1, i);
-                    // straight into the scan's text arena when the file fits what is left of it (kept until the scan closes:
-                    // the hit rows' columns are parsed from there); else into this thread's own buffer
-                    bool in_arena = false;
-                    if (P->text_cap) {
-                        const int fd = ::open(paths[i], O_RDONLY | O_CLOEXEC);
-                        struct stat sb {};
-                        if (fd >= 0 && ::fstat(fd, &sb) == 0 && sb.st_size > 0 && (size_t)sb.st_size <= ((size_t)32 << 20)) {
-                            const size_t len = (size_t)sb.st_size;
-                            const size_t at = text_used.fetch_add(len + 64, std::memory_order_relaxed);
-                            if (at + len + 64 <= P->text_cap) {
-                                char *dst = P->text + at;
-                                size_t got = 0;
-                                while (got < len) {
-                                    const ssize_t r = ::read(fd, dst + got, len - got);
-                                    if (r < 0 && errno == EINTR) continue;
-                                    if (r <= 0) break;
-                                    got += (size_t)r;
-                                }
-                                if (got == len) {
-                                    std::memset(dst + len, 0, 64);
-                                    h_begin[slot_ix] = dst;
-                                    h_end[slot_ix] = dst + len;
-                                    sc->kept[(size_t)i].p = dst;
-                                    sc->kept[(size_t)i].len = len;
-                                    in_arena = true;
-                                } else {
-                                    err = std::string("Unable to read ") + paths[i];
-                                }
-                            }
-                        }
-                        if (fd >= 0) ::close(fd);
-                    }
-                    if (!in_arena && err.empty()) {
-                        if (ring[slot_ix].load(paths[i], err)) {
-                            h_begin[slot_ix] = ring[slot_ix].begin();
-                            h_end[slot_ix] = ring[slot_ix].end();
-                        }
-                    }
-                    if (err.empty() && h_begin[slot_ix])
-                        rows = gfm_tsv_detail::count_rows(h_begin[slot_ix], h_end[slot_ix], skip_reverse != 0);
+                    st.rows = 0;
+                    if (!hot.load(paths[i], err)) { fail_with(err); return; }
+                    const int64_t rc1 = trace ? tcpu() : 0;
                     if (trace) tr_max(tr_read, (int64_t)((now_s() - r0) * 1e9));
-                    if (!err.empty()) { fail_with(err); return; }
-                    if (!h_begin[slot_ix]) h_begin[slot_ix] = h_end[slot_ix] = "";      // an empty file
+                    const size_t len = (size_t)(hot.end() - hot.begin());
+                    if (len > 0) {
+                        // room for the rows this text can hold at most (a row is a k-mer, five more columns and six separators)
+                        const size_t most = len / ((size_t)W + 11) + 1;
+                        if (st.offs.size() < most || st.kmers.size() < most * (size_t)W + 64) {      // (the stage outlives the scan: W may have changed)
+                            st.offs.resize(most + most / 8);
+                            st.kmers.resize((most + most / 8) * (size_t)W + 64);
+                        }
+                        uint8_t *kd = st.kmers.data();
+                        uint64_t *od = st.offs.data();
+                        int64_t n = 0;
+                        auto sink = [&](const uint8_t *kmer, uint64_t line_off) {
+                            gfm_tsv_detail::copy_kmer(kd + (size_t)n * (size_t)W, kmer, W);
+                            od[n] = line_off;
+                            ++n;
+                        };
+                        const double p0 = trace ? now_s() : 0.0;
+                        const bool ok = gfm_tsv_detail::scan_rows(paths[i], hot.begin(), hot.end(), W, skip_reverse != 0, sink, err);
+                        if (trace) tr_max(tr_parse, (int64_t)((now_s() - p0) * 1e9));
+                        if (!ok) { fail_with(err); return; }
+                        st.rows = n;
+                    }
+                    const int64_t rc2 = trace ? tcpu() : 0;
                     held[slot_ix] = i;
                     ++n_held;
-                    sc->table.files[(size_t)i].n_rows = rows;
+                    sc->table.files[(size_t)i].n_rows = st.rows;
                     counted[(size_t)i].store(1, std::memory_order_release);
                     advance_offsets();
+                    // the text into the scan's arena while the file fits what is left of it
+                    if (P->text_cap && len > 0 && len <= ((size_t)32 << 20)) {
+                        const size_t at = text_used.fetch_add(len + 64, std::memory_order_relaxed);
+                        if (at + len + 64 <= P->text_cap) {
+                            char *dst = P->text + at;
+                            gfm_tsv_detail::copy_streaming(dst, hot.begin(), len);
+                            std::memset(dst + len, 0, 64);
+                            sc->kept[(size_t)i].p = dst;
+                            sc->kept[(size_t)i].len = len;
+                        }
+                    }
+                    if (trace) {
+                        const int64_t rc3 = tcpu();
+                        cpu_read.fetch_add(rc1 - rc0, std::memory_order_relaxed);
+                        cpu_parse.fetch_add(rc2 - rc1, std::memory_order_relaxed);
+                        cpu_keep.fetch_add(rc3 - rc2, std::memory_order_relaxed);
+                    }
                     continue;
                 }
             }
@@ -861,9 +914,11 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
             advance_offsets();
             if (held[head] >= next_assign.load(std::memory_order_acquire)) {
                 const double y0 = trace ? now_s() : 0.0;
+                const int64_t yc0 = trace ? tcpu() : 0;
                 set_state(4, held[head]);
                 std::this_thread::yield();
                 if (trace) tr_max(tr_offset, (int64_t)((now_s() - y0) * 1e9));
+                if (trace) cpu_yield.fetch_add(tcpu() - yc0, std::memory_order_relaxed);
             }
         }
     };
@@ -1029,6 +1084,13 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
         std::fprintf(stderr, "[scan] longest single: read+count %.3f ms, parse of a file %.3f ms, wait for a slot %.3f ms, "
                              "column block lookup %.3f ms, yield %.3f ms\n", tr_read.load() * 1e-6, tr_parse.load() * 1e-6,
                      tr_slot.load() * 1e-6, tr_block.load() * 1e-6, tr_offset.load() * 1e-6);
+        const double rows_d = (double)std::max<int64_t>(total_rows, 1);
+        std::fprintf(stderr, "[scan] worker CPU (thread clocks, summed): read %.1f ms (%.1f ns/row), scan %.1f ms (%.1f), text to the arena "
+                             "%.1f ms (%.1f), rows into their chunks %.1f ms (%.1f), yield %.1f ms (%.1f), all %.1f ms (%.1f ns/row)\n",
+                     cpu_read.load() * 1e-6, cpu_read.load() / rows_d, cpu_parse.load() * 1e-6, cpu_parse.load() / rows_d,
+                     cpu_keep.load() * 1e-6, cpu_keep.load() / rows_d, cpu_count.load() * 1e-6, cpu_count.load() / rows_d,
+                     cpu_yield.load() * 1e-6, cpu_yield.load() / rows_d,
+                     cpu_all.load() * 1e-6, cpu_all.load() / rows_d);
     }
     if (sc->table.n != total_rows) return sfail(GFM_ERR_IO, "internal error: row count mismatch");
     S_TRY(hipStreamSynchronize(P->score));      // the histograms are complete for whoever reads them next
@@ -1058,6 +1120,14 @@ GFM_API int gfm_scan_tsv_finish(gfm_scan_t sc, int64_t *n_hits)
     const int L = sc->L;
     const double t0 = now_s();
     const bool fused = !sc->on_qvalue;
+    const bool trace = std::getenv("GRAFIMO_SCAN_TRACE") != nullptr;
+    auto proc_cpu = []() {
+        timespec ts{};
+        clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+        return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    };
+    const double c0 = trace ? proc_cpu() : 0.0;
+    double c_sorted = c0, t_sorted = t0;
     {
         int dev = -1;
         S_TRY(hipGetDevice(&dev));
@@ -1136,12 +1206,17 @@ GFM_API int gfm_scan_tsv_finish(gfm_scan_t sc, int64_t *n_hits)
                 for (size_t i = 0; i < (size_t)cnt; ++i) h.qvalue[i] = q[(size_t)h.scaled[i]];
             }
         }
+        if (trace) { c_sorted = proc_cpu(); t_sorted = now_s(); }
         S_RC(fetch_hit_columns(sc));
     } else {
         S_TRY(hipStreamSynchronize(P->score));
     }
     sc->finished = true;
     const double t_end = now_s();
+    if (trace)
+        std::fprintf(stderr, "[scan] finish: tables + selection + hits back + order %.3f ms (process CPU %.1f ms), columns of the hit rows "
+                             "%.3f ms (process CPU %.1f ms)\n", (t_sorted - t0) * 1e3, (c_sorted - c0) * 1e3, (t_end - t_sorted) * 1e3,
+                     (proc_cpu() - c_sorted) * 1e3);
     sc->stats.n_hits = (int64_t)sc->hits[0].rows.size();
     sc->stats.total_s = sc->begin_s + (t_end - t0);          // the caller's time between the two phases is not the scan's
     sc->stats.tail_s = sc->stats.total_s - sc->stats.parse_s;

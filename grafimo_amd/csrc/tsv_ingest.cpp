@@ -127,15 +127,56 @@ __attribute__((target("avx2,bmi"))) static int64_t count_rows_avx2(const char *p
     }
     return n + (seen ? 1 : 0);
 }
+
+// The same with one 64-byte load and mask-register compares per block (3 -> 2 ns per row).
+__attribute__((target("avx512f,avx512bw,bmi"))) static int64_t count_rows_avx512(const char *p, const char *end)
+{
+    using namespace gfm_tsv_detail;
+    int64_t n = 0;
+    bool seen = false;                                   // the current line has shown a field byte
+    for (; end - p >= 64; p += 64) {
+        unsigned long long nl, ws;
+        masks64_avx512(p, &nl, &ws);
+        unsigned long long field = ~(ws | nl);
+        while (nl) {
+            const int t = __builtin_ctzll(nl);
+            nl &= nl - 1;
+            const unsigned long long upto = (1ull << t) - 1ull;
+            if (seen || (field & upto)) ++n;
+            seen = false;
+            field &= ~upto;
+        }
+        if (field) seen = true;
+    }
+    for (; p < end; ++p) {
+        if (*p == '\n') { if (seen) ++n; seen = false; }
+        else if (!is_ws(*p)) seen = true;
+    }
+    return n + (seen ? 1 : 0);
+}
 #endif
 
 int64_t gfm_tsv_detail::count_rows(const char *p, const char *end, bool skip_rev)
 {
 #if defined(__x86_64__)
+    if (!skip_rev && cpu_has_avx512()) return count_rows_avx512(p, end);
     if (!skip_rev && cpu_has_avx2()) return count_rows_avx2(p, end);
+    const bool wide512 = cpu_has_avx512();
 #endif
     int64_t n = 0;
     while (p < end) {
+#if defined(__x86_64__)
+        if (wide512 && end - p >= 128) {    // --no-reverse: the strand of a well-formed line from its white-space mask (76 -> 9 ns per kept row)
+            const char *kb, *ke, *le;
+            char sd = 0;
+            const int r = light_line_avx512(p, end, &kb, &ke, &sd, &le);
+            if (r >= 0) {
+                if (r == 1 && sd != '-') ++n;
+                p = le < end ? le + 1 : end;
+                continue;
+            }
+        }
+#endif
         const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
         const char *le = nl ? nl : end;
         const char *c = p;

@@ -182,6 +182,49 @@ int main(int argc, char **argv)
         }
     }
     std::printf("tsv: %ld parsed, %ld refused\n", ok, bad);
+    // the block-wise scanner's edges (scan_rows_avx512, where the CPU has AVX-512; the line-wise form elsewhere): a text whose
+    // size is a multiple of 64, one byte more, one byte less; no newline at the end; blank stretches longer than the 128-byte
+    // slice; a line longer than one round of blocks; a buffer with NO readable byte behind its end
+    {
+        using namespace gfm_tsv_detail;
+        const std::string row = "chr22:16000000-16000200\tGAAAATTATTGATATGTAT\tchr22:16000000+\tchr22:16000019+\t984\tref\t1+,\n";
+        std::vector<std::string> cases;
+        for (int pad = 0; pad < 130; ++pad) {
+            std::string t;
+            for (int r = 0; r < 40; ++r) t += row;
+            t += std::string((size_t)pad, ' ');
+            cases.push_back(t);
+            cases.push_back(t + row.substr(0, row.size() - 1));          // no closing newline
+            cases.push_back(std::string((size_t)pad, '\n') + t);
+        }
+        cases.push_back(row + std::string(300, ' ') + "\n" + row + std::string(200, '\t') + row);
+        cases.push_back(row.substr(0, row.size() - 1) + std::string(20000, '7') + "\n" + row + row);     // a 20 KB node path
+        cases.push_back(std::string(40000, 'A') + "\n" + row);                                             // a 40 KB first field: refused
+        cases.push_back(std::string(17000, ' ') + row + row);
+        cases.push_back("");
+        cases.push_back("\n");
+        cases.push_back(row.substr(0, 60));
+        for (size_t ci = 0; ci < cases.size(); ++ci) {
+            const std::string &t = cases[ci];
+            for (int skip = 0; skip < 2; ++skip) {
+                const LightRows ref = ref_light(t, 19, skip != 0);
+                std::vector<char> exact(t.begin(), t.end());           // heap block of exactly the text's size
+                LightRows got;
+                std::string err;
+                got.ok = scan_rows("m.tsv", exact.data(), exact.data() + exact.size(), 19, skip != 0,
+                                   [&](const uint8_t *k, uint64_t off) { got.off.push_back(off); got.kmers.insert(got.kmers.end(), k, k + 19); }, err);
+                if (got.ok != ref.ok || (ref.ok && (got.off != ref.off || got.kmers != ref.kmers))) {
+                    std::printf("EDGE MISMATCH case=%zu skip=%d ok %d/%d rows %zu/%zu\n", ci, skip, (int)got.ok, (int)ref.ok, got.off.size(), ref.off.size());
+                    return 1;
+                }
+                if (ref.ok && count_rows(exact.data(), exact.data() + exact.size(), skip != 0) != (int64_t)ref.off.size()) {
+                    std::printf("EDGE COUNT MISMATCH case=%zu skip=%d\n", ci, skip);
+                    return 1;
+                }
+            }
+        }
+        std::printf("edges: %zu texts\n", cases.size());
+    }
     // VCF reader on the fixture and mutated copies (plain text)
     std::string vbase = slurp(vcf);
     ok = bad = 0;

@@ -30,10 +30,12 @@ def test_readers_under_asan_and_ubsan(tmp_path):
         dst.write(src.read())
     work = tmp_path / "work"
     work.mkdir()
-    run = subprocess.run([exe, os.path.join(REF_DATA, "width_19", "scoring_test_input.tsv"), str(vcf), str(work)],
-                         capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
-    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
-    assert "tsv:" in run.stdout and "vcf:" in run.stdout and "MISMATCH" not in run.stdout
-    parsed = int(run.stdout.split("tsv:")[1].split("parsed")[0])
-    assert parsed > 20                                  # some mutated files are still well-formed
+    for env_extra in ({}, {"GRAFIMO_SCAN_NO_AVX512": "1"}):        # the AVX-512 forms where the CPU has them, then the AVX2 / scalar ones
+        run = subprocess.run([exe, os.path.join(REF_DATA, "width_19", "scoring_test_input.tsv"), str(vcf), str(work)],
+                             capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", **env_extra))
+        assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-4000:])
+        assert "tsv:" in run.stdout and "vcf:" in run.stdout and "MISMATCH" not in run.stdout
+        assert "edges:" in run.stdout and "sort: ok" in run.stdout
+        parsed = int(run.stdout.split("tsv:")[1].split("parsed")[0])
+        assert parsed > 20                                  # some mutated files are still well-formed
