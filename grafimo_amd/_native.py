@@ -202,3 +202,22 @@ def device_count():
     n = c_int(0)
     check(lib().gfm_device_count(ctypes.byref(n)))
     return n.value
+
+
+def c_paths(paths):
+    """A list of str paths as `const char *const *` for the library: ONE encoded blob and a numpy array of addresses into
+    it (10 000 paths: 1.5 ms; a ctypes array of c_char_p built from 10 000 bytes objects: 6 ms -- a fifth of the scan that
+    follows).  -> (pointer, keepalive): keep `keepalive` referenced until the call returns."""
+    import numpy as np
+    if len(paths) == 0:
+        return ctypes.cast(None, P(ctypes.c_char_p)), None
+    blob = ("\0".join(paths) + "\0").encode()
+    buf = np.frombuffer(blob, dtype=np.uint8)
+    ends = np.flatnonzero(buf == 0)
+    if len(ends) != len(paths):
+        raise ValueError("a path holds a NUL character")
+    starts = np.empty(len(ends), dtype=np.uint64)
+    starts[0] = 0
+    starts[1:] = ends[:-1] + 1
+    ptrs = starts + np.uint64(buf.ctypes.data)
+    return ctypes.cast(ptrs.ctypes.data, P(ctypes.c_char_p)), (blob, buf, ptrs)

@@ -103,7 +103,7 @@ class StreamScan:
         M = len(self.dms)
         self.width = self.dms[0].width
         self.want_qvalues = bool(want_qvalues)
-        arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+        arr, _keep = nv.c_paths(paths)
         handles = (ctypes.c_void_p * M)(*[d.handle for d in self.dms])
         hist_ptrs = None
         if hists is not None:
@@ -140,7 +140,11 @@ class StreamScan:
             buf = np.empty(max(nbytes, 1), dtype=np.uint8)
             nv.check(nv.lib().gfm_tsv_names(t, nv.ptr(off), nv.ptr(buf)))
             raw = buf.tobytes()
-            self.names = [raw[off[i]:off[i + 1]].decode() for i in range(cnt)]
+            if raw.isascii():               # (byte offsets are character offsets: one decode, then slices of the str)
+                txt, o = raw.decode("ascii"), off.tolist()
+                self.names = [txt[o[i]:o[i + 1]] for i in range(cnt)]
+            else:
+                self.names = [raw[off[i]:off[i + 1]].decode() for i in range(cnt)]
         finally:
             self.close()
         first = self.hits[0]                # one motif: the hit columns as attributes of the scan, as before
