@@ -70,6 +70,8 @@ struct FusedArgs {
     int listing;                  // 1: listed windows are queued for the deletion kernels (first call of a plan); 0: that list exists
     const int *plan_overflow;     // a window of the plan's deletion list was refused (read when listing == 0)
     unsigned long long *dbg;      // measurement aid (GRAFIMO_FUSED_TIMERS=1): [k] sum, [16 + k] max of phase k's 10-ns ticks, [32 + k] count
+    int lab;                      // measurement aid (GRAFIMO_FUSED_LAB=bits, results WRONG): parts of graph_score_kernel switched off --
+                                  // 1 no phase 2, 2 no base scores, 4 no window classification, 8 no booking, 16 no staging of the next tile
 };
 __device__ __forceinline__ void dbg_tick(const FusedArgs &a, int slot, unsigned long long &t0)
 {
@@ -314,7 +316,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         commit(t, pf);
         __builtin_amdgcn_wave_barrier();
         if (ti + stride < n_tiles) {
-            pf = issue(t_nxt);
+            if (!(a.lab & 16)) pf = issue(t_nxt);
             t_cur = t_nxt;
             if (ti + 2 * stride < n_tiles) t_nxt = tiles[ti + 2 * stride];
         }
@@ -331,15 +333,17 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         bool listed = false;
         WinInfo wi{0, 0, 0, false, false, 0, 0, 0, 0};
         const long long p = t.p0 + lane;
-        if (lane < t.n_win) {
+        if (lane < t.n_win && (a.lab & 4)) wi.walks = 1;
+        if (lane < t.n_win && !(a.lab & 4)) {
             wi = classify_window(g, sites, p, W, t.limit, t.i_lo, t.i_hi);
             listed = wi.listed && !wi.simple;
             if (wi.walks < 0) { atomicMax(overflow, 1); wi.walks = 0; }
             walks = wi.walks + wi.walks_b;
         }
         lap(1, tk0);                   // 9: classify
+        if (lane < t.n_win && (a.lab & 4)) walks = 1;
         if (lane < t.n_win) {
-            if (wi.walks > 0) {                // the reference window's score on both strands
+            if (wi.walks > 0 && !(a.lab & 2)) {                // the reference window's score on both strands
                 unsigned sum = 0;
                 int bad = 0;
                 for (int j = 0; j < W; ++j) {
@@ -392,7 +396,8 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
             if (lane >= d) incl += ((long long)hi_ << 32) | (unsigned)lo_;
         }
         wl->incl[lane] = incl;
-        const long long total = ((long long)__shfl((int)(incl >> 32), 63) << 32) | (unsigned)__shfl((int)(incl & 0xffffffffll), 63);
+        long long total = ((long long)__shfl((int)(incl >> 32), 63) << 32) | (unsigned)__shfl((int)(incl & 0xffffffffll), 63);
+        if (a.lab & 1) total = 0;
         __builtin_amdgcn_wave_barrier();
         lap(3, tk0);                  // 11: listing + scan
         // ---- phase 2: lane per walk
@@ -418,13 +423,12 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 if (!jump) {                                      // the common case: positions p .. p + W - 1
                     sum = wl->score[k];
                     bad = wl->bad[k];
-                    long long rest = q;
+                    unsigned long long rest = (unsigned long long)q;
                     const int pk = (int)(t.p0 + k);
                     for (int s = (nsx & 0xffff) - 1; s >= 0 && rest; --s) {        // digits, last site first
                         const SiteRec r = sites.at(i0 + s);
                         const int nall = (r.del_len | r.ins_len) ? 1 : 1 + (r.n_alts & 3);     // (a one-deletion window's own record)
-                        const int al = (int)(rest % nall);
-                        rest /= nall;
+                        const int al = take_digit(rest, nall);
                         if (al) {
                             const int j = r.pos - pk;
                             const unsigned cr = base_code(wl->ref[k + j]), ca = base_code((unsigned)r.n_alts >> (8 * al));
@@ -435,7 +439,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 } else {
                     sum = wl->score_b[k];
                     bad = wl->bad_b[k];
-                    long long rest = q - wa;
+                    unsigned long long rest = (unsigned long long)(q - wa);
                     const long long pk = t.p0 + k;
                     const long long x = pk + wl->jx[k], len = wl->del_len[k];
                     for (int s = (nsx >> 16) - 1; s >= 0 && rest; --s) {
@@ -443,8 +447,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                         if (r.del_len | r.ins_len) continue;      // (the deletion's own record)
                         if (r.pos > x && r.pos <= x + len) continue;
                         const int nall = 1 + (r.n_alts & 3);
-                        const int al = (int)(rest % nall);
-                        rest /= nall;
+                        const int al = take_digit(rest, nall);
                         if (al) {
                             const int j = (int)(r.pos - pk) - (r.pos > x ? (int)len : 0);
                             const unsigned cr = base_code(ref_at(r.pos)), ca = base_code((unsigned)r.n_alts >> (8 * al));
@@ -455,11 +458,12 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 }
                 s_f = bad ? a.min_val : (int)(sum & 0xffffu);
                 s_r = bad ? a.min_val : (int)(sum >> 16);
-                if (a.hnb > 0) {
+                if (a.hnb > 0 && !(a.lab & 8)) {
                     book_score(a, h, s_f);
                     if (!a.forward_only) book_score(a, h, s_r);
                 }
             }
+            if (a.lab & 8) continue;
             push_hits(a, live && s_f >= a.cutoff, ti, k, 2 * q, s_f);
             if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, ti, k, 2 * q + 1, s_r);
         }
@@ -844,11 +848,10 @@ graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, c
                 if (j < W) km[j] = (uint8_t)(rw[j >> 3] >> (8 * (j & 7)));
         }
         unsigned long long dig[2] = {0ull, 0ull};
-        long long rest = q;
+        unsigned long long rest = (unsigned long long)q;
         for (int s_ = wi.ns - 1; s_ >= 0; --s_) {
             const int nall = 1 + g.n_alts[wi.i0 + s_];
-            const unsigned long long al = (unsigned long long)(rest % nall);
-            rest /= nall;
+            const unsigned long long al = (unsigned long long)take_digit(rest, nall);
             dig[s_ >> 5] |= al << (2 * (s_ & 31));
             if (al) km[g.pos[wi.i0 + s_] - p] = g.alt_bases[(size_t)(wi.i0 + s_) * kMaxAlts + (al - 1)];
         }

@@ -118,6 +118,23 @@ struct NoVisitor {
     __device__ void passed(int) {}
 };
 
+// One mixed-radix digit (radix 1..4: the alleles of a site) off a walk number, last site first.  The compiler's 64-bit
+// division is a hundred instructions; walk numbers nearly always fit 32 bits, and a radix of 2 or 4 is a shift, 3 a multiply.
+// (graph_score_kernel spent about half of its vector instructions in `rest % nall; rest /= nall`.)
+__device__ inline int take_digit(unsigned long long &rest, int nall)
+{
+    if (rest <= 0xffffffffull) {
+        const unsigned r = (unsigned)rest;
+        const unsigned q3 = __umulhi(r, 0xAAAAAAABu) >> 1;
+        const unsigned q = nall == 1 ? r : (nall == 2 ? r >> 1 : (nall == 3 ? q3 : r >> 2));
+        rest = q;
+        return (int)(r - q * (unsigned)nall);
+    }
+    const int d = (int)(rest % (unsigned long long)nall);
+    rest /= (unsigned long long)nall;
+    return d;
+}
+
 // A walk may start inside an insertion anchored at p - 1 (start coordinate p): `pre_site` = that site (or -1),
 // `pre_t` = offset of its first base inside the inserted string.  next_start() steps through the starts of
 // window p in enumeration order: the plain start, then per insertion anchored at p - 1 (site order) t = 0, 1, ...
@@ -761,10 +778,10 @@ emit_plain_body(const unsigned bid, const GraphDev &g, const int *__restrict__ a
     };
     // allele digits, last site first
     unsigned long long dig[2] = {0ull, 0ull};     // 2 bits per site, up to 64 sites
+    unsigned long long qd = (unsigned long long)(unsigned)q;
     for (int k = ns - 1; k >= 0; --k) {
         const int nall = 1 + n_alts_of(k);
-        const unsigned long long a = (unsigned long long)(q % nall);
-        q /= nall;
+        const unsigned long long a = (unsigned long long)take_digit(qd, nall);
         dig[k >> 5] |= a << (2 * (k & 31));
     }
     auto allele = [&](int k) { return (int)((dig[k >> 5] >> (2 * (k & 31))) & 3ull); };
@@ -1724,6 +1741,8 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
         GX_TRY(hipMemsetAsync(g->f_dbg.p, 0, 48 * sizeof(unsigned long long), st));
         a.dbg = g->f_dbg.p;
     }
+    static const int lab = [] { const char *e = std::getenv("GRAFIMO_FUSED_LAB"); return e ? atoi(e) : 0; }();
+    a.lab = lab;
     const size_t hist_bytes = with_hist ? sizeof(unsigned) * (size_t)(hnb + 1) : 0;
     const size_t lds1 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(WaveLds) * kFusedWaves + sizeof(long long) * kFusedWaves +
                         sizeof(int) * (kFusedWaves + 2) + hist_bytes;

@@ -1,15 +1,17 @@
 #!/usr/bin/env bash
-# what the deletion kernel of the fused path spends its time on: the same profile with parts switched off
+# Development aid (GPU box): what graph_score_kernel spends its time on -- the same profile with parts switched off
+# (GRAFIMO_FUSED_LAB bits: 1 no phase 2, 2 no base scores, 4 no window classification, 8 no booking, 16 no staging of the next
+# tile; results are wrong in those runs, only the kernel times count).   scripts/fused_lab.sh <tag>
 root="$GRAFT_REPO_ROOT"; out="$root/gpurun_out/${1:-r04lab}"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-for dbg in ${FUSED_LAB_MODES:-0 1 2 4}; do
-  export GRAFIMO_FUSED_DEBUG=$dbg
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/p$dbg" -- python3 "$root/scripts/fused_prof.py" > "$out/log$dbg.txt" 2>&1
-  f=$(ls -t "$out"/p$dbg/*/*kernel_stats.csv 2>/dev/null | head -1)
-  python3 - "$f" "$dbg" <<'PY'
+for lab in ${FUSED_LAB_MODES:-0 1 2 4 8 16 3 7 15 31}; do
+  export GRAFIMO_FUSED_LAB=$lab
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/p$lab" -- python3 "$root/scripts/fused_prof.py" > "$out/log$lab.txt" 2>&1
+  f=$(ls -t "$out"/p$lab/*/*kernel_stats.csv 2>/dev/null | head -1)
+  python3 - "$f" "$lab" <<'PY'
 import csv, sys
 rows = {r["Name"].split("::")[1].split("(")[0]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(sys.argv[1])) if "graph_" in r["Name"]}
-print(f"debug={sys.argv[2]}: " + ", ".join(f"{k} {v:.1f} us" for k, v in rows.items() if k.startswith("graph_") and "count_kernel" != k[-12:] or k.startswith("graph_del")))
+print(f"lab={sys.argv[2]:>2s}: " + ", ".join(f"{k} {v:.1f} us" for k, v in rows.items() if k in ("graph_score_kernel", "graph_del_score_kernel", "graph_hist_reduce_kernel")))
 PY
-  rm -rf "$out/p$dbg"
+  rm -rf "$out/p$lab"
 done
