@@ -41,6 +41,19 @@ struct DelWin { int tile_k, i0; };
 constexpr int kDelTileBits = 25;
 __device__ __forceinline__ int del_tile(const DelWin &d) { return d.tile_k & ((1 << kDelTileBits) - 1); }
 __device__ __forceinline__ int del_k(const DelWin &d) { return (int)((unsigned)d.tile_k >> kDelTileBits); }
+// a HEAVY window: no insertion or deletion in reach, more than kHeavyWalks walks (seven and more biallelic SNPs in one
+// window).  graph_score_kernel leaves those to graph_heavy_kernel, whose wavefronts share a window's walks by ITEMS of up to
+// kHeavyItemRounds rounds of 64 (a window of 2^24 walks: 4 096 items), found through `item_base` (ascending along the list).
+struct HeavyWin {
+    int tile_k, i0;           // as DelWin
+    int ns;                   // sites in [p, p + W)
+    unsigned item_base, n_chunks, rounds_per_chunk;
+    long long walks;
+};
+constexpr long long kHeavyWalks = 64;
+constexpr int kHeavyItemRounds = 64;
+constexpr unsigned kHeavyMaxChunks = 1u << 16;
+constexpr int kHeavyCap = 1 << 20;       // windows of one plan's heavy list (beyond it the plan is refused)
 struct HitRec {               // what graph_annotate_kernel writes per hit (120 bytes; numpy dtype in extract_regions.py)
     long long start, stop, freq, q2;
     double qvalue;
@@ -249,7 +262,8 @@ struct WaveLds {
 // leave once per workgroup.  What the wavefronts of a workgroup share is the LDS table and the histogram window.
 __global__ void __launch_bounds__(kFusedThreads)
 graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__restrict__ tiles, int n_tiles,
-                   DelWin *__restrict__ del_wins, int *__restrict__ del_count, int *__restrict__ overflow)
+                   DelWin *__restrict__ del_wins, int *__restrict__ del_count, int *__restrict__ overflow,
+                   HeavyWin *__restrict__ heavy_wins, unsigned long long *__restrict__ heavy_ctl, int *__restrict__ plan_overflow_w)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
     unsigned *tab = reinterpret_cast<unsigned *>(fused_lds);
@@ -336,8 +350,28 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         if (lane < t.n_win && (a.lab & 4)) wi.walks = 1;
         if (lane < t.n_win && !(a.lab & 4)) {
             wi = classify_window(g, sites, p, W, t.limit, t.i_lo, t.i_hi);
-            listed = wi.listed && !wi.simple;
             if (wi.walks < 0) { atomicMax(overflow, 1); wi.walks = 0; }
+            // more walks than a round or so: not this wavefront's business.  A plain window goes to graph_heavy_kernel (its
+            // walks shared out over the grid, a table of per-site score differences instead of this kernel's chain of LDS
+            // reads per site); a one-deletion window goes the way of the other listed windows.
+            if (wi.simple && wi.walks + wi.walks_b > kHeavyWalks) { wi.simple = false; wi.walks = 0; wi.walks_b = 0; }
+            listed = wi.listed && !wi.simple;
+            if (!wi.listed && wi.walks > kHeavyWalks && wi.ns <= 64) {      // (a lane per site there)
+                if (a.listing) {
+                    const long long rounds = (wi.walks + 63) >> 6;
+                    const unsigned n_chunks = (unsigned)min((long long)kHeavyMaxChunks, (rounds + kHeavyItemRounds - 1) / kHeavyItemRounds);
+                    const unsigned long long got = atomicAdd(heavy_ctl, (1ull << 32) | (unsigned long long)n_chunks);
+                    const unsigned slot = (unsigned)(got >> 32), base = (unsigned)(got & 0xffffffffull);
+                    if (slot < (unsigned)kHeavyCap && (unsigned long long)base + n_chunks < 0xffffffffull) {
+                        heavy_wins[slot] = HeavyWin{ti | (lane << kDelTileBits), wi.i0, wi.ns, base, n_chunks,
+                                                    (unsigned)((rounds + n_chunks - 1) / n_chunks), wi.walks};
+                    } else {
+                        atomicMax(overflow, 1);
+                        atomicMax(plan_overflow_w, 1);
+                    }
+                }
+                wi.walks = 0;
+            }
             walks = wi.walks + wi.walks_b;
         }
         lap(1, tk0);                   // 9: classify
@@ -757,6 +791,137 @@ graph_del_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__
         dbg_tick(a, 6, tk_item);               // 6: the whole item
     }
     if (lane == 0 && rows_done) atomicAdd(a.n_rows, rows_done);
+}
+
+// ---- the heavy windows (plain windows of more than kHeavyWalks walks; listed by graph_score_kernel on a plan's first call).
+// Same workgroup shape as graph_score_kernel -- the LDS table, the histogram window and the slab of workgroup b are the same
+// objects; the grid always fills the chip, whatever the number of tiles -- but a wavefront takes ITEMS: (window, chunk of rounds).  Per item: the window's reference score by a lane
+// per position and a wave sum; a lane per site writes delta[site][allele] = the packed score difference of putting that
+// allele in (and what it does to the count of invalid bases); then a round is 64 consecutive walk numbers, a lane each:
+// mixed-radix digits, last site first, one LDS read per site.  A window of 2^24 walks took one wavefront of
+// graph_score_kernel 5 s (12 us a round: per site a chain of four dependent LDS reads); here its 262 144 rounds are 4 096
+// items over the whole grid.
+struct HeavyLds {
+    unsigned delta[64 * 4];
+    signed char dbad[64 * 4];
+    unsigned char nall[64];
+};
+static_assert(sizeof(HeavyLds) <= sizeof(WaveLds), "graph_heavy_kernel reuses graph_score_kernel's per-wave LDS");
+
+__global__ void __launch_bounds__(kFusedThreads)
+graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__restrict__ tiles,
+                   const HeavyWin *__restrict__ wins, const unsigned long long *__restrict__ ctl, int main_blocks)
+{
+    const unsigned long long c = *ctl;
+    const unsigned n_wins = (unsigned)min((unsigned long long)kHeavyCap, c >> 32), n_items = (unsigned)(c & 0xffffffffull);
+    if (n_items == 0u || n_wins == 0u) {
+        // nothing heavy in this plan (the host launches this kernel until it has learnt that).  The slab rows behind
+        // graph_score_kernel's own must still read as zeros to the reduction that follows.
+        if ((int)blockIdx.x >= main_blocks && a.hnb > 0)
+            for (int i = threadIdx.x; i <= a.hnb; i += kFusedThreads) a.slabs[(size_t)blockIdx.x * (a.hnb + 1) + i] = 0u;
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+    unsigned *tab = reinterpret_cast<unsigned *>(fused_lds);
+    HeavyLds *hl = reinterpret_cast<HeavyLds *>(reinterpret_cast<WaveLds *>(tab + GFM_MAX_WIDTH * 8) + (threadIdx.x >> 6));
+    unsigned long long *blk_rows = reinterpret_cast<unsigned long long *>(reinterpret_cast<WaveLds *>(tab + GFM_MAX_WIDTH * 8) + kFusedWaves);
+    int *blk_q = reinterpret_cast<int *>(blk_rows + kFusedWaves);
+    unsigned *h = reinterpret_cast<unsigned *>(blk_q + kFusedWaves + 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = a.W;
+    for (int i = tid; i < W * 8; i += kFusedThreads) tab[i] = tab_arg.v[i];
+    for (int i = tid; i <= a.hnb && a.hnb > 0; i += kFusedThreads) h[i] = 0u;
+    __syncthreads();
+    unsigned long long rows_done = 0;
+    const unsigned stride = gridDim.x * kFusedWaves;
+    unsigned cur = 0xffffffffu;                 // the window this wavefront's tables describe
+    HeavyWin hw{};
+    long long p = 0;
+    unsigned base_sum = 0;
+    int base_bad = 0, tile_id = 0, win_k = 0;
+    for (unsigned it = blockIdx.x * kFusedWaves + (unsigned)wave; it < n_items; it += stride) {
+        unsigned lo = 0, hi = n_wins - 1;       // the last window whose item_base <= it
+        while (lo < hi) {
+            const unsigned mid = (lo + hi + 1) >> 1;
+            if (wins[mid].item_base <= it) lo = mid; else hi = mid - 1;
+        }
+        if (lo != cur) {
+            cur = lo;
+            hw = wins[lo];
+            tile_id = del_tile(DelWin{hw.tile_k, 0});
+            win_k = del_k(DelWin{hw.tile_k, 0});
+            const Tile t = tiles[tile_id];
+            p = t.p0 + win_k;
+            __builtin_amdgcn_wave_barrier();    // (the last item's rounds have read the tables)
+            unsigned v = 0;
+            int bad = 0;
+            if (lane < W) {
+                const unsigned cr = base_code((unsigned)g.ref[p + lane]);
+                v = tab[lane * 8 + cr];
+                bad = (int)(cr >> 2);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { v += (unsigned)__shfl_xor((int)v, d); bad += __shfl_xor(bad, d); }
+            base_sum = v;
+            base_bad = bad;
+            if (lane < hw.ns) {
+                const SiteRec r = packed_site(g, hw.i0 + lane);
+                const int j = (int)(r.pos - p);
+                const unsigned cr = base_code((unsigned)g.ref[r.pos]);
+                const int na = r.n_alts & 3;
+                hl->nall[lane] = (unsigned char)(1 + na);
+                hl->delta[lane * 4] = 0u;
+                hl->dbad[lane * 4] = 0;
+                for (int al = 1; al <= 3; ++al) {
+                    const unsigned ca = al <= na ? base_code((unsigned)r.n_alts >> (8 * al)) : cr;
+                    hl->delta[lane * 4 + al] = tab[j * 8 + ca] - tab[j * 8 + cr];
+                    hl->dbad[lane * 4 + al] = (signed char)((int)(ca >> 2) - (int)(cr >> 2));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const unsigned chunk = it - hw.item_base;
+        const long long rounds = (hw.walks + 63) >> 6;
+        const long long r0 = (long long)chunk * hw.rounds_per_chunk, r1 = min(rounds, r0 + (long long)hw.rounds_per_chunk);
+        for (long long r = r0; r < r1; ++r) {
+            const long long wt = (r << 6) + lane;
+            const bool live = wt < hw.walks;
+            unsigned long long rest = live ? (unsigned long long)wt : 0ull;
+            unsigned sum = base_sum;
+            int bad = base_bad;
+            for (int s = hw.ns - 1; s >= 0; --s) {
+                if (__builtin_amdgcn_ballot_w64(rest != 0ull) == 0ull) break;
+                const int d = take_digit(rest, (int)hl->nall[s]);
+                sum += hl->delta[s * 4 + d];
+                bad += (int)hl->dbad[s * 4 + d];
+            }
+            const int s_f = bad ? a.min_val : (int)(sum & 0xffffu);
+            const int s_r = bad ? a.min_val : (int)(sum >> 16);
+            if (live && a.hnb > 0) {
+                book_score(a, h, s_f);
+                if (!a.forward_only) book_score(a, h, s_r);
+            }
+            push_hits(a, live && s_f >= a.cutoff, tile_id, win_k, 2 * wt, s_f);
+            if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, tile_id, win_k, 2 * wt + 1, s_r);
+            const long long n_live = min(64ll, hw.walks - (r << 6));
+            rows_done += (unsigned long long)n_live * (a.forward_only ? 1ull : 2ull);
+        }
+    }
+    if (lane == 0) blk_rows[wave] = rows_done;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long rows = 0;
+        for (int k = 0; k < kFusedWaves; ++k) rows += blk_rows[k];
+        if (rows) atomicAdd(a.n_rows, rows);
+    }
+    if (a.hnb > 0) {        // on top of what graph_score_kernel's workgroup of this index left there, if there was one
+        const bool fresh = (int)blockIdx.x >= main_blocks;
+        for (int i = tid; i <= a.hnb; i += kFusedThreads) {
+            unsigned *dst = &a.slabs[(size_t)blockIdx.x * (a.hnb + 1) + i];
+            if (fresh) *dst = h[i];
+            else if (h[i]) *dst += h[i];
+        }
+    }
 }
 
 // histogram slabs of graph_score_kernel -> the caller's histogram: thread per (bin, group of 32 slabs), all of a thread's

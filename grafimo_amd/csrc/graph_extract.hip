@@ -1187,6 +1187,10 @@ struct gfm_graph {
     hipEvent_t ev_tiles = nullptr;       // the staging has been copied
     bool tiles_pending = false;
     Buf<DelWin> f_del_wins;
+    Buf<HeavyWin> f_heavy;                 // the plan's heavy windows (graph_heavy_kernel); f_flags[8..9]: their count << 32 | items
+    unsigned long long *h_heavy_ctl = nullptr;   // pinned: that word, copied back once per plan (no heavy window: no launch)
+    hipEvent_t ev_heavy = nullptr;
+    bool heavy_known = false, heavy_asked = false;
     Buf<DelBatchRec> f_del_recs;         // per listed window: what graph_del_count_kernel found
     Buf<DelItem> f_del_items;            // work items of graph_del_score_kernel
     Buf<unsigned> f_slabs;
@@ -1309,6 +1313,8 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_tiles, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_plan, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_heavy, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&g->h_heavy_ctl), sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
@@ -1362,9 +1368,12 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     if (g->h_back) (void)hipHostFree(g->h_back);
     if (g->ev_tiles) (void)hipEventDestroy(g->ev_tiles);
     if (g->ev_plan) (void)hipEventDestroy(g->ev_plan);
+    if (g->ev_heavy) (void)hipEventDestroy(g->ev_heavy);
+    if (g->h_heavy_ctl) (void)hipHostFree(g->h_heavy_ctl);
     if (g->h_tiles) (void)hipHostFree(g->h_tiles);
     g->f_tiles.release(); g->f_del_wins.release(); g->f_del_recs.release(); g->f_del_items.release(); g->f_slabs.release();
     g->f_flags.release();
+    g->f_heavy.release();
     delete g;
 }
 
@@ -1704,12 +1713,21 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     if (!with_hist) hnb = 0;
     const bool indels = g->dev.n_dels > 0 || g->dev.n_ins > 0;
     GX_TRY(g->f_del_wins.reserve((size_t)g->f_n_windows + 1));
-    GX_TRY(g->f_slabs.reserve((size_t)g1 * (size_t)(hnb + 1) + 1));
-    GX_TRY(g->f_flags.reserve(8));
-    const bool listing = indels && !g->f_plan_ready;
-    if (indels && !listing && st != g->f_plan_stream) GX_TRY(hipStreamWaitEvent(st, g->ev_plan, 0));
-    if (listing || !indels) GX_TRY(hipMemsetAsync(g->f_flags.p, 0, 8 * sizeof(int), st));
-    else GX_TRY(hipMemsetAsync(g->f_flags.p + 2, 0, sizeof(int), st));
+    const int g_heavy = 2 * n_cu;           // graph_heavy_kernel fills the chip whatever the number of tiles
+    GX_TRY(g->f_slabs.reserve((size_t)std::max(g1, g_heavy) * (size_t)(hnb + 1) + 1));
+    GX_TRY(g->f_flags.reserve(16));
+    GX_TRY(g->f_heavy.reserve((size_t)std::min<long long>(g->f_n_windows, kHeavyCap) + 1));
+    // What depends on (graph, regions, width) only is made by the first call of a tile table and kept: the list of the windows
+    // that touch an insertion / deletion with their layouts and work items, and the list of the heavy windows.
+    const bool listing = !g->f_plan_ready;
+    if (!listing && st != g->f_plan_stream) GX_TRY(hipStreamWaitEvent(st, g->ev_plan, 0));
+    if (listing) {
+        GX_TRY(hipMemsetAsync(g->f_flags.p, 0, 16 * sizeof(int), st));
+        g->heavy_known = g->heavy_asked = false;
+    } else {
+        GX_TRY(hipMemsetAsync(g->f_flags.p + 2, 0, sizeof(int), st));
+    }
+    unsigned long long *heavy_ctl = reinterpret_cast<unsigned long long *>(g->f_flags.p + 8);
     FusedTab tab{};
     {
         static const int row_of_code[4] = {0, 1, 3, 2};       // code 2 = T (row 3), code 3 = G (row 2)
@@ -1747,7 +1765,27 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     const size_t lds1 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(WaveLds) * kFusedWaves + sizeof(long long) * kFusedWaves +
                         sizeof(int) * (kFusedWaves + 2) + hist_bytes;
     hipLaunchKernelGGL(graph_score_kernel, dim3((unsigned)g1), dim3(kFusedThreads), lds1, st, g->dev, a, tab, g->f_tiles.p,
-                       g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2);
+                       g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_heavy.p, heavy_ctl, g->f_flags.p + 4);
+    int n_slabs = g1;
+    {
+        // the heavy windows: launched until the plan's count has come back and says there is none
+        if (!g->heavy_known && g->heavy_asked && hipEventQuery(g->ev_heavy) == hipSuccess) g->heavy_known = true;
+        if (!g->heavy_known || (*g->h_heavy_ctl & 0xffffffffull) != 0ull) {
+            hipLaunchKernelGGL(graph_heavy_kernel, dim3((unsigned)g_heavy), dim3(kFusedThreads), lds1, st, g->dev, a, tab, g->f_tiles.p,
+                               g->f_heavy.p, heavy_ctl, g1);
+            n_slabs = std::max(g1, g_heavy);
+        }
+        if (listing) {
+            GX_TRY(hipMemcpyAsync(g->h_heavy_ctl, heavy_ctl, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            GX_TRY(hipEventRecord(g->ev_heavy, st));
+            g->heavy_asked = true;
+        }
+    }
+    if (listing && !indels) {
+        g->f_plan_ready = true;
+        g->f_plan_stream = st;
+        GX_TRY(hipEventRecord(g->ev_plan, st));
+    }
     if (indels) {
         // the listed windows' walks: count + cut into work items, then one wavefront per item (gfm_graph_fused.hpp)
         const size_t n_batches = ((size_t)g->f_n_windows + kFusedDelThreads - 1) / kFusedDelThreads;
@@ -1774,8 +1812,8 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
                            pitch);
     }
     if (with_hist)
-        hipLaunchKernelGGL(graph_hist_reduce_kernel, dim3((unsigned)((hnb + 1 + 255) / 256), (unsigned)((g1 + kSlabGroup - 1) / kSlabGroup)),
-                           dim3(256), 0, st, g->f_slabs.p, g1, hlo, hnb, min_val, reinterpret_cast<unsigned long long *>(d_hist));
+        hipLaunchKernelGGL(graph_hist_reduce_kernel, dim3((unsigned)((hnb + 1 + 255) / 256), (unsigned)((n_slabs + kSlabGroup - 1) / kSlabGroup)),
+                           dim3(256), 0, st, g->f_slabs.p, n_slabs, hlo, hnb, min_val, reinterpret_cast<unsigned long long *>(d_hist));
     GX_TRY(hipGetLastError());
     if (timers) {      // measurement aid: what the wavefronts of graph_del_score_kernel spent where (10-ns ticks)
         unsigned long long h[48];

@@ -152,6 +152,44 @@ def test_tiles_with_more_sites_than_the_lds_stage_and_heavy_windows():
     g.close()
 
 
+def test_heavy_windows_go_to_their_own_kernel_and_the_list_is_kept_with_the_plan():
+    """Windows of more than 64 walks leave graph_score_kernel for graph_heavy_kernel (plain windows: their walks shared out
+    over the grid) or for the deletion kernels (a one-deletion window of that many walks).  A stretch of twelve neighbouring
+    sites, some tri- and tetra-allelic, a two-base deletion in its middle and quiet stretches around it: every row equals the
+    materialised one -- on the first call of a plan (the heavy list is made), on the next call with ANOTHER motif of the
+    width (the list is reused), after the regions changed (made again), forward strand only, and with a threshold that
+    selects."""
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = acgt[rng.integers(0, 4, 900)]
+    pos, n_alts, alt, del_len = [], [], [], []
+    for x in list(range(200, 212)) + [320, 322, 324, 326, 328, 330, 332, 500, 640]:
+        others = [c for c in acgt if c != ref[x]]
+        k = 1 + (x % 3 if x < 212 else 0)
+        pos.append(x); n_alts.append(k); alt.append(others[:k] + [0] * (3 - k)); del_len.append(0)
+    pos.append(327); n_alts.append(1); alt.append([0, 0, 0]); del_len.append(2)         # a deletion inside the second stretch
+    order = np.argsort(np.array(pos), kind="stable")
+    H = 20
+    bits = rng.integers(0, 2 ** 20, size=(len(pos), 3, 1), dtype=np.uint64)
+    idx = GraphIndex("c", ref, np.array(pos, np.int32)[order], np.array(n_alts, np.uint8)[order], np.array(alt, np.uint8)[order],
+                     bits[order], H, del_len=np.array(del_len, np.int32)[order])
+    g = DeviceGraph(idx)
+    regions = [(150, 400), (480, 700)]
+    assert _approx_walks(idx, regions, 16) < 3e6
+    a, b = _both(_motif_of_width(16), g, regions, threshold=1.0, recomb=True)
+    assert len(b) > 100_000
+    _assert_same(a, b, "first call of the plan")
+    a, b = _both(_motif_of_width(16, seed=3), g, regions, threshold=1.0, recomb=True)
+    _assert_same(a, b, "another motif, the plan's lists reused")
+    a, b = _both(_motif_of_width(16), g, [(190, 260)], threshold=1.0, recomb=True, no_reverse=True)
+    _assert_same(a, b, "other regions, forward only")
+    a, b = _both(_motif_of_width(16), g, regions, threshold=0.01)
+    assert 0 < len(a) < 100_000
+    _assert_same(a, b, "a threshold that selects")
+    g.close()
+
+
 def test_a_hit_list_beyond_the_host_limit_is_refused(monkeypatch):
     """A threshold of 1 over windows of many variant sites would bring every allele combination back as a report row: the
     call is refused from the device's COUNT (nothing of that size is allocated or copied), naming the limit."""
