@@ -575,11 +575,15 @@ struct DelBatchRec {                       // what graph_del_count_kernel leaves
 };
 struct DelItem { int batch, chunk, n_chunks, pad; };
 constexpr int kDelItemRounds = 1, kDelMaxItems = 64;
+// ... and a pool of this many MORE items for the batches that hold more than 64 rounds (a listed window of a million walks: a
+// wavefront per round of it instead of 64 long items); a batch that finds the pool used up keeps its 64.
+constexpr int kDelExtraItems = 1 << 20, kDelMaxChunks = 1 << 18;
 
 __global__ void __launch_bounds__(kFusedDelThreads)
 graph_del_count_kernel(GraphDev g, int W, const Tile *__restrict__ tiles, const DelWin *__restrict__ del_wins,
                        const int *__restrict__ del_count, int *__restrict__ overflow, int *__restrict__ plan_overflow,
-                       DelBatchRec *__restrict__ recs, DelItem *__restrict__ items, int *__restrict__ item_count)
+                       DelBatchRec *__restrict__ recs, DelItem *__restrict__ items, int *__restrict__ item_count,
+                       int *__restrict__ extra_used)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
     constexpr int T = kFusedDelThreads;
@@ -631,11 +635,20 @@ graph_del_count_kernel(GraphDev g, int W, const Tile *__restrict__ tiles, const 
         recs[(size_t)batch * T + lane] = rec;
         const long long total = ((long long)__shfl((int)(incl >> 32), 63) << 32) | (unsigned)__shfl((int)(incl & 0xffffffffll), 63);
         const long long rounds = (total + T - 1) / T;
-        const int n_chunks = (int)min((long long)kDelMaxItems, (rounds + kDelItemRounds - 1) / kDelItemRounds);
+        const long long want = (rounds + kDelItemRounds - 1) / kDelItemRounds;
+        int n_chunks = (int)min((long long)kDelMaxItems, want);
         int at = 0;
-        if (lane == 0 && n_chunks) at = atomicAdd(item_count, n_chunks);
+        if (lane == 0 && n_chunks) {
+            if (want > kDelMaxItems) {          // more from the pool, if it still has them
+                const int extra = (int)min((long long)kDelMaxChunks, want) - kDelMaxItems;
+                if (atomicAdd(extra_used, extra) + extra <= kDelExtraItems) n_chunks += extra;
+                else atomicSub(extra_used, extra);
+            }
+            at = atomicAdd(item_count, n_chunks);
+        }
         at = __builtin_amdgcn_readfirstlane(at);
-        if (lane < n_chunks) items[at + lane] = DelItem{batch, lane, n_chunks, 0};
+        n_chunks = __builtin_amdgcn_readfirstlane(n_chunks);
+        for (int c = lane; c < n_chunks; c += 64) items[at + c] = DelItem{batch, c, n_chunks, 0};
     }
 }
 

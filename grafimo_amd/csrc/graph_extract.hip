@@ -1790,12 +1790,12 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
         // the listed windows' walks: count + cut into work items, then one wavefront per item (gfm_graph_fused.hpp)
         const size_t n_batches = ((size_t)g->f_n_windows + kFusedDelThreads - 1) / kFusedDelThreads;
         GX_TRY(g->f_del_recs.reserve(n_batches * kFusedDelThreads + 1));
-        GX_TRY(g->f_del_items.reserve(n_batches * kDelMaxItems + 1));
+        GX_TRY(g->f_del_items.reserve(n_batches * kDelMaxItems + (size_t)kDelExtraItems + 1));
         if (listing) {
             const size_t lds_a = sizeof(SiteRec) * kSiteCache * kFusedDelThreads;
             hipLaunchKernelGGL(graph_del_count_kernel, dim3((unsigned)(12 * n_cu)), dim3(kFusedDelThreads), lds_a, st, g->dev, W,
                                g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_flags.p + 4, g->f_del_recs.p,
-                               g->f_del_items.p, g->f_flags.p + 3);
+                               g->f_del_items.p, g->f_flags.p + 3, g->f_flags.p + 5);
             g->f_plan_ready = true;       // (stream order: the calls that follow on this stream find the plan complete)
             g->f_plan_stream = st;
             GX_TRY(hipEventRecord(g->ev_plan, st));

@@ -8,17 +8,23 @@ from grafimo_amd import synth
 from grafimo_amd.device import DeviceMotif
 from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
 
-W = 30
+W = 30 if not (len(sys.argv) > 1 and sys.argv[1] == "del") else 60
 rec = synth.synthetic_motif(W, np.random.default_rng(5), np.full(4, 0.25))
 dm = DeviceMotif(rec["sm"], rec["bg"], rec["min_val"], rec["scale"], rec["offset"])
 rng = np.random.default_rng(3)
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 ref = acgt[rng.integers(0, 4, 600)]
-for n in (8, 12, 16, 20, 24):
-    pos = np.arange(300, 300 + n, dtype=np.int32)
-    alt = np.zeros((n, 3), np.uint8)
+with_del = len(sys.argv) > 1 and sys.argv[1] == "del"        # ... and a two-base deletion anchored behind the SNPs' middle
+for n in (8, 12, 16, 20, 24)[:4 if with_del else 5]:
+    pos = np.arange(300, 300 + 2 * n, 2, dtype=np.int32) if with_del else np.arange(300, 300 + n, dtype=np.int32)
+    alt = np.zeros((len(pos), 3), np.uint8)
     alt[:, 0] = np.where(ref[pos] == ord("A"), ord("C"), ord("A"))
-    g = DeviceGraph(GraphIndex("c", ref, pos, np.ones(n, np.uint8), alt, None, 0))
+    n_alts, del_len = np.ones(len(pos), np.uint8), np.zeros(len(pos), np.int32)
+    if with_del:
+        at = int(pos[len(pos) // 2]) + 1
+        pos, alt = np.insert(pos, len(pos) // 2 + 1, at), np.insert(alt, len(alt) // 2 + 1, 0, axis=0)
+        n_alts, del_len = np.insert(n_alts, len(n_alts) // 2 + 1, 1), np.insert(del_len, len(del_len) // 2 + 1, 2)
+    g = DeviceGraph(GraphIndex("c", ref, pos, n_alts, alt, None, 0, del_len=del_len))
     reg = np.array([(0, 200), (270, 360)], dtype=np.int64)
     s0, s1 = np.ascontiguousarray(reg[:, 0]), np.ascontiguousarray(reg[:, 1])
     hist = torch.zeros(dm.L, dtype=torch.int64, device="cuda")
