@@ -387,7 +387,39 @@ def extract_block(ctcf, dev, n_regions=10_000):
         and bool((df_m["haplotype_frequency"].to_numpy() == df["haplotype_frequency"].to_numpy()).all())
     g.close()
     e2e = 1e3 * float(np.median(runs[2:]))
+    # ---- windows of very many walks (16 neighbouring biallelic SNPs inside one 30-mer: 2^16 walks per window): they leave
+    # graph_score_kernel for graph_heavy_kernel, whose wavefronts share a window's walks (one wavefront had them all: 78 ms)
+    heavy = None
+    try:
+        from grafimo_amd.extract_regions import GraphIndex
+        rng = np.random.default_rng(3)
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        href = acgt[rng.integers(0, 4, 600)]
+        hpos = np.arange(300, 316, dtype=np.int32)
+        halt = np.zeros((16, 3), np.uint8)
+        halt[:, 0] = np.where(href[hpos] == ord("A"), ord("C"), ord("A"))
+        hg = DeviceGraph(GraphIndex("c", href, hpos, np.ones(16, np.uint8), halt, None, 0), dev)
+        rec = synth.synthetic_motif(30, np.random.default_rng(5), np.full(4, 0.25))
+        hdm = DeviceMotif(rec["sm"], rec["bg"], rec["min_val"], rec["scale"], rec["offset"])
+        hs, he = np.array([0, 270], dtype=np.int64), np.array([200, 360], dtype=np.int64)
+        hh = torch.zeros(hdm.L, dtype=torch.int64, device=dev)
+        for _ in range(3):
+            hg.score(hdm, hs, he, hdm.pvalue_cutoff(1e-9), hist=hh)
+        torch.cuda.synchronize(dev)
+        ev0.record()
+        for _ in range(reps):
+            hg.score(hdm, hs, he, hdm.pvalue_cutoff(1e-9), hist=hh)
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        hrows = int(hg.fused_results()[1])
+        heavy = {"what": "16 neighbouring SNPs inside one 30-mer (windows of up to 2^16 walks)", "rows": hrows,
+                 "fused_ms": ev0.elapsed_time(ev1) / reps, "rows_per_s": hrows / (ev0.elapsed_time(ev1) / reps * 1e-3)}
+        hdm.close()
+        hg.close()
+    except Exception as e:                       # (a side measurement: it must not take the bench line with it)
+        heavy = {"error": f"{type(e).__name__}: {e}"}
     return {
+        "heavy_windows": heavy,
         "regions": n_regions, "region_bp": 200, "width": W, "sites": int(len(idx.pos)),
         "deletions": int((idx.del_len > 0).sum()), "haplotypes": idx.n_haplotypes, "rows": int(n),
         "fused_ms": fused_ms, "rows_per_s_fused": fused_rows / (fused_ms * 1e-3),
