@@ -556,11 +556,19 @@ int fetch_hit_columns(gfm_scan *sc)
     if (!err.empty()) return sfail(GFM_ERR_IO, err);
     // local name ids -> ids in the scan's table
     gfm_tsv_detail::NameTable global(sc->table.names);
+    global.ix.reserve(jobs.size() + jobs.size() / 4);          // (a file is mostly one region: about a name per job)
+    sc->table.names.reserve(jobs.size() + jobs.size() / 4);
+    std::vector<int32_t> map;
     for (auto &job : jobs) {
-        std::vector<int32_t> map(job.names.size());
+        map.resize(job.names.size());
         for (size_t q = 0; q < job.names.size(); ++q) map[q] = global.id(job.names[q].data(), job.names[q].size());
         MotifHits &h = sc->hits[job.motif];
-        for (size_t i = job.i0; i < job.i1; ++i) h.name_id[i] = map[(size_t)h.name_id[i]];
+        if (job.names.size() == 1) {
+            const int32_t only = map[0];
+            for (size_t i = job.i0; i < job.i1; ++i) h.name_id[i] = only;
+        } else {
+            for (size_t i = job.i0; i < job.i1; ++i) h.name_id[i] = map[(size_t)h.name_id[i]];
+        }
     }
     if (trace)
         std::fprintf(stderr, "[scan] hit columns: %zu jobs listed in %.3f ms, run %.3f ms (worker CPU: offsets + prefetch %.1f ms, lines %.1f ms), "
