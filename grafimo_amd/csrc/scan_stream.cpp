@@ -691,7 +691,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     // scanned k-mers only (0.86 s: the read() into cold memory alone 0.46 s, profiles/r04_ingest_cpu.txt), then this.
     // The calling thread only sequences chunks: chunk k goes to the device once every row of it is in place; its slot is
     // handed back to the workers when the score kernel has read it.
-    const int nt = gfm_tsv_detail::pick_threads(paths, n_paths, n_threads);
+    const int nt = sc->n_threads;            // (pick_threads() once per scan: it notes when it was last asked)
     constexpr int kRing = 4;                 // files a worker may hold scanned, waiting for their offsets
     // Coordination is lock-light on purpose: with one mutex taken ~5 times per file, 96 workers on 10 000 files spent
     // more time handing the mutex around than parsing (300 ms at 96 threads against 110 ms at 32).  Files are claimed

@@ -281,25 +281,24 @@ int gfm_tsv_detail::pick_threads(const char *const *paths, int n_paths, int requ
         if (*e == '1') return nt;
     }
     if (nt > kMaxParseThreads) nt = kMaxParseThreads;
-    // Big inputs under a CPU quota.  On the round-3 GPU boxes (256 hardware threads, quota 16 = 1.6 CPU-seconds per
-    // 100 ms) a scan whose CPU time exceeds one period's allowance is frozen as a whole until the period ends, the
-    // sooner the more threads it runs (a trace of the scan shows all workers asleep for 20-80 ms with nothing to wait
-    // for; profiles/r03_cpu_quota.txt).  1.84 GB in 10 000 files needed ~1.9 CPU-seconds with the round's first parser
-    // (61-66 ms with 24 or 32 threads, 72-75 ms with 48 and more, 85..170 ms with 96) and needs ~1.1 with its last one,
-    // which fits one allowance: 47 ms with 32 threads, 37 with 48, 33 with 64, 31 with 96 but 111 ms now and then
-    // (scripts/ingest_probe4.py: every run behind 0.15 s of idle).  Four times the quota; without a quota the cap above
-    // stands (the bare read + parse of those files scales to 96 threads: 28 ms, profiles/r03_file_read_scaling.txt).
-    // ... unless big scans follow each other: then it is the allowance per period that bounds the throughput (three
-    // 33 ms scans of 64 threads want more than one period gives: 72 ms per scan, against 45 ms with 32 threads), so a big
-    // scan that starts within 150 ms of the one before it gets twice the quota only.
+    // Big inputs under a CPU quota.  On the GPU boxes (256 hardware threads, quota 16 = 1.6 CPU-seconds per 100 ms) a
+    // scan whose CPU time exceeds one period's allowance is frozen as a whole until the period ends, the sooner the more
+    // threads it runs (a trace shows all workers asleep for 20-80 ms with nothing to wait for; profiles/r03_cpu_quota.txt),
+    // and every thread beyond the quota makes the same work dearer (SMT siblings, cache sharing: 1.84 GB in 10 000 files cost
+    // 0.58 CPU-s with 16 threads, 0.65 with 24, 0.75 with 32, 1.0 with 48, 1.37 with 64; profiles/r04_ingest_cpu.txt: wall
+    // 44 / 38 / 34 / 32 / 36 ms rested, 44 / 46 / 34-61 / 75 / 95 ms back to back).  So: twice the quota for a scan that
+    // finds the allowance untouched, one and a half times for one that starts within 150 ms of the one before it -- then
+    // it is the allowance per period that bounds the throughput.  Without a quota the cap above stands (the bare read +
+    // parse of those files scales to 96 threads: 28 ms, profiles/r03_file_read_scaling.txt).
     const double quota = cpu_quota_cores();
+    if (quota > 0 && nt > (int)(4.0 * quota + 0.5)) nt = std::max(16, (int)(4.0 * quota + 0.5));   // (2e6 rows in 1000 files: 4.6 ms with 64 threads, 4.9 with 96)
     if (quota > 0 && bytes > (1ull << 30)) {
         static std::atomic<long long> last_big_ns{0};
         const long long now_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(
                                      std::chrono::steady_clock::now().time_since_epoch()).count();
         const long long prev = last_big_ns.exchange(now_ns);
         const bool sustained = prev != 0 && now_ns - prev < 150000000ll;
-        const int cap = std::max(16, std::min(kMaxParseThreads, (int)((sustained ? 2.0 : 4.0) * quota + 0.5)));
+        const int cap = std::max(16, std::min(kMaxParseThreads, (int)((sustained ? 1.5 : 2.0) * quota + 0.5)));
         if (nt > cap) nt = cap;
     }
     return nt;

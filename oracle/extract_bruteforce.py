@@ -140,7 +140,7 @@ def consistent(ref: bytes, recs, H: int) -> bool:
 
 def window_counts(ref: bytes, recs, H: int, S: int, E: int, W: int):
     """-> (freq, flags): freq[(kmer bytes, start, stop)] = number of (haplotype, window) pairs inside the region
-    [S, E] (start >= S, stop <= E) that spell it; flags[key] = set of vg-style flags seen ('ref' iff no base of
+    [S, E) (S <= start < E, stop <= E) that spell it; flags[key] = set of vg-style flags seen ('ref' iff no base of
     the window is substituted or inserted).  Forward strand; the '-' row of a walk is its mirror."""
     freq: Dict[Tuple[bytes, int, int], int] = defaultdict(int)
     flags: Dict[Tuple[bytes, int, int], set] = defaultdict(set)
@@ -154,8 +154,8 @@ def window_counts(ref: bytes, recs, H: int, S: int, E: int, W: int):
             start = coord[o] + (1 if ins[o] else 0)
             if start < S:
                 continue
-            if start > E:
-                break
+            if start >= E:            # (a k-mer made of nothing but the bases inserted behind the region's LAST base would start
+                break                 # at E with an empty extent: not a window start of [S, E) -- the enumerator's rule, and the kernels')
             stop = coord[o + W - 1] + 1
             if stop > E:
                 continue

@@ -114,7 +114,11 @@ with tempfile.TemporaryDirectory() as tmp:
                 n_carried += carried
                 continue
             freq, flags = bf.window_counts(ref, recs, H, S, E, W)
-            carried, n = bf.check_rows(got, freq, flags)
+            try:
+                carried, n = bf.check_rows(got, freq, flags)
+            except AssertionError:
+                print(f"FAILED at seed {seed} kinds {kinds} samples {n_samples} region {S}-{E} W {W}", flush=True)
+                raise
             exp = xo.enumerate_region_variants("c", ref, v, S, E, W, with_counts=True)
             want = [(r[1].encode(), int(r[2].split(":")[1][:-1]), int(r[3].split(":")[1][:-1]), r[2][-1], r[4], r[5]) for r in exp]
             assert got == want, (seed, kinds, S, E, W, len(got), len(want),
