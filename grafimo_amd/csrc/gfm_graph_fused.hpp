@@ -46,9 +46,11 @@ __device__ __forceinline__ int del_k(const DelWin &d) { return (int)((unsigned)d
 // kHeavyItemRounds rounds of 64 (a window of 2^24 walks: 4 096 items), found through `item_base` (ascending along the list).
 struct HeavyWin {
     int tile_k, i0;           // as DelWin
-    int ns;                   // sites in [p, p + W)
+    int ns;                   // site records the layout looks at, from i0 on
     unsigned item_base, n_chunks, rounds_per_chunk;
-    long long walks;
+    long long walks;          // of this layout
+    long long q_base;         // walk number of its first walk inside the window (layout B of a one-deletion window: layout A's walks)
+    int jx, del_len;          // layout B: the anchor's index in the window and the deleted bases behind it; del_len = 0: a plain layout
 };
 constexpr long long kHeavyWalks = 64;
 constexpr int kHeavyItemRounds = 64;
@@ -351,25 +353,38 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         if (lane < t.n_win && !(a.lab & 4)) {
             wi = classify_window(g, sites, p, W, t.limit, t.i_lo, t.i_hi);
             if (wi.walks < 0) { atomicMax(overflow, 1); wi.walks = 0; }
-            // more walks than a round or so: not this wavefront's business.  A plain window goes to graph_heavy_kernel (its
-            // walks shared out over the grid, a table of per-site score differences instead of this kernel's chain of LDS
-            // reads per site); a one-deletion window goes the way of the other listed windows.
-            if (wi.simple && wi.walks + wi.walks_b > kHeavyWalks) { wi.simple = false; wi.walks = 0; wi.walks_b = 0; }
-            listed = wi.listed && !wi.simple;
-            if (!wi.listed && wi.walks > kHeavyWalks && wi.ns <= 64) {      // (a lane per site there)
-                if (a.listing) {
-                    const long long rounds = (wi.walks + 63) >> 6;
-                    const unsigned n_chunks = (unsigned)min((long long)kHeavyMaxChunks, (rounds + kHeavyItemRounds - 1) / kHeavyItemRounds);
-                    const unsigned long long got = atomicAdd(heavy_ctl, (1ull << 32) | (unsigned long long)n_chunks);
-                    const unsigned slot = (unsigned)(got >> 32), base = (unsigned)(got & 0xffffffffull);
-                    if (slot < (unsigned)kHeavyCap && (unsigned long long)base + n_chunks < 0xffffffffull) {
-                        heavy_wins[slot] = HeavyWin{ti | (lane << kDelTileBits), wi.i0, wi.ns, base, n_chunks,
-                                                    (unsigned)((rounds + n_chunks - 1) / n_chunks), wi.walks};
-                    } else {
-                        atomicMax(overflow, 1);
-                        atomicMax(plan_overflow_w, 1);
-                    }
+            // more walks than a round or so: not this wavefront's business.  The window's layouts -- the one of a plain window,
+            // the two of a one-deletion window -- go to graph_heavy_kernel (walks shared out over the grid, a table of per-site
+            // score differences instead of this kernel's chain of LDS reads per site).
+            auto to_heavy = [&](long long n_walks, long long q_base, int ns, int jx, int del_len) {
+                if (!a.listing) return;
+                const long long rounds = (n_walks + 63) >> 6;
+                const unsigned n_chunks = (unsigned)min((long long)kHeavyMaxChunks, (rounds + kHeavyItemRounds - 1) / kHeavyItemRounds);
+                const unsigned long long got = atomicAdd(heavy_ctl, (1ull << 32) | (unsigned long long)n_chunks);
+                const unsigned slot = (unsigned)(got >> 32), base = (unsigned)(got & 0xffffffffull);
+                if (slot < (unsigned)kHeavyCap && (unsigned long long)base + n_chunks < 0xffffffffull) {
+                    heavy_wins[slot] = HeavyWin{ti | (lane << kDelTileBits), wi.i0, ns, base, n_chunks,
+                                                (unsigned)((rounds + n_chunks - 1) / n_chunks), n_walks, q_base, jx, del_len};
+                } else {
+                    atomicMax(overflow, 1);
+                    atomicMax(plan_overflow_w, 1);
                 }
+            };
+            const bool many = wi.walks + wi.walks_b > kHeavyWalks;
+            if (wi.simple && many) {
+                if (wi.ns <= 64 && wi.ns_b <= 64) {          // both layouts to graph_heavy_kernel (a lane per site record there)
+                    if (wi.walks > 0) to_heavy(wi.walks, 0, wi.ns, 0, 0);
+                    if (wi.walks_b > 0) to_heavy(wi.walks_b, wi.walks, wi.ns_b, wi.jx, wi.del_len);
+                    wi.listed = false;
+                } else {
+                    wi.simple = false;                       // ... or the way of the other listed windows
+                }
+                wi.walks = 0;
+                wi.walks_b = 0;
+            }
+            listed = wi.listed && !wi.simple;
+            if (!wi.listed && !wi.simple && many && wi.ns <= 64) {
+                to_heavy(wi.walks, 0, wi.ns, 0, 0);
                 wi.walks = 0;
             }
             walks = wi.walks + wi.walks_b;
@@ -866,10 +881,12 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
             const Tile t = tiles[tile_id];
             p = t.p0 + win_k;
             __builtin_amdgcn_wave_barrier();    // (the last item's rounds have read the tables)
+            // the layout's positions: p .. p + W - 1, or -- layout B of a one-deletion window -- with the deleted bases jumped
+            const long long dx = p + hw.jx, dlen = hw.del_len;
             unsigned v = 0;
             int bad = 0;
             if (lane < W) {
-                const unsigned cr = base_code((unsigned)g.ref[p + lane]);
+                const unsigned cr = base_code((unsigned)g.ref[p + lane + (dlen && lane > hw.jx ? dlen : 0)]);
                 v = tab[lane * 8 + cr];
                 bad = (int)(cr >> 2);
             }
@@ -879,16 +896,19 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
             base_bad = bad;
             if (lane < hw.ns) {
                 const SiteRec r = packed_site(g, hw.i0 + lane);
-                const int j = (int)(r.pos - p);
+                // the deletion's own record and -- layout B -- the sites inside the deleted stretch take no digit (radix 1), as
+                // in graph_score_kernel's phase 2
+                const bool none = (r.del_len | r.ins_len) != 0 || (dlen && r.pos > dx && r.pos <= dx + dlen);
+                const int j = (int)(r.pos - p) - (dlen && r.pos > dx ? (int)dlen : 0);
                 const unsigned cr = base_code((unsigned)g.ref[r.pos]);
-                const int na = r.n_alts & 3;
+                const int na = none ? 0 : (r.n_alts & 3);
                 hl->nall[lane] = (unsigned char)(1 + na);
                 hl->delta[lane * 4] = 0u;
                 hl->dbad[lane * 4] = 0;
                 for (int al = 1; al <= 3; ++al) {
                     const unsigned ca = al <= na ? base_code((unsigned)r.n_alts >> (8 * al)) : cr;
-                    hl->delta[lane * 4 + al] = tab[j * 8 + ca] - tab[j * 8 + cr];
-                    hl->dbad[lane * 4 + al] = (signed char)((int)(ca >> 2) - (int)(cr >> 2));
+                    hl->delta[lane * 4 + al] = none ? 0u : tab[j * 8 + ca] - tab[j * 8 + cr];
+                    hl->dbad[lane * 4 + al] = none ? (signed char)0 : (signed char)((int)(ca >> 2) - (int)(cr >> 2));
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -914,8 +934,8 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 book_score(a, h, s_f);
                 if (!a.forward_only) book_score(a, h, s_r);
             }
-            push_hits(a, live && s_f >= a.cutoff, tile_id, win_k, 2 * wt, s_f);
-            if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, tile_id, win_k, 2 * wt + 1, s_r);
+            push_hits(a, live && s_f >= a.cutoff, tile_id, win_k, 2 * (hw.q_base + wt), s_f);
+            if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, tile_id, win_k, 2 * (hw.q_base + wt) + 1, s_r);
             const long long n_live = min(64ll, hw.walks - (r << 6));
             rows_done += (unsigned long long)n_live * (a.forward_only ? 1ull : 2ull);
         }
