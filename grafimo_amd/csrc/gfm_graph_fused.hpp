@@ -243,14 +243,20 @@ __device__ __forceinline__ WinInfo classify_window(const GraphDev &g, const S &s
 
 // what one wavefront keeps in LDS: of the tile it works on, and the listed windows it has found and not yet handed on
 constexpr int kWaveQueue = 96;
+constexpr int kOwnerSlots = 256;
 struct WaveLds {
     SiteRec rec[kWaveSites];
     long long incl[kTileWin], walks_a[kTileWin];
-    int i0[kTileWin], ns[kTileWin], bad[kTileWin], bad_b[kTileWin], jx[kTileWin], del_len[kTileWin];
-    unsigned score[kTileWin], score_b[kTileWin];
+    // per window, ONE 16-byte read in phase 2: .x the reference score (both strands packed), .y its first site, .z sites of
+    // layout A | layout B << 16, .w invalid bases of the reference window | layout A's walks << 8 | its first walk number
+    // << 16 (the last two only where the tile holds at most kOwnerSlots walks: else incl[] / walks_a[])
+    uint4 pack[kTileWin];
+    int bad_b[kTileWin], jx[kTileWin], del_len[kTileWin];
+    unsigned score_b[kTileWin];
     int reach[kWaveSites];
     DelWin queue[kWaveQueue];
     unsigned char ref[kWaveRefBytes];
+    unsigned char owner[kOwnerSlots];     // tiles of up to that many walks: the window of walk number x (else: a search over incl[])
 };
 
 // Persistent grid; every WAVEFRONT works on tiles (64 consecutive window starts of one region) on its own -- no workgroup
@@ -391,6 +397,8 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         }
         lap(1, tk0);                   // 9: classify
         if (lane < t.n_win && (a.lab & 4)) walks = 1;
+        unsigned sc_a = 0;
+        int bad_a = 0;
         if (lane < t.n_win) {
             if (wi.walks > 0 && !(a.lab & 2)) {                // the reference window's score on both strands
                 unsigned sum = 0;
@@ -400,8 +408,8 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                     sum += tab[j * 8 + c];
                     bad += (int)(c >> 2);
                 }
-                wl->score[lane] = sum;
-                wl->bad[lane] = bad;
+                sc_a = sum;
+                bad_a = bad;
             }
             if (wi.walks_b > 0) {              // ... and the one of the walk that jumps the deletion
                 unsigned sum = 0;
@@ -414,8 +422,6 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 wl->score_b[lane] = sum;
                 wl->bad_b[lane] = bad;
             }
-            wl->i0[lane] = wi.i0;
-            wl->ns[lane] = wi.ns | (wi.ns_b << 16);
             wl->walks_a[lane] = wi.walks;
             wl->jx[lane] = wi.jx;
             wl->del_len[lane] = wi.del_len;
@@ -447,6 +453,13 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         wl->incl[lane] = incl;
         long long total = ((long long)__shfl((int)(incl >> 32), 63) << 32) | (unsigned)__shfl((int)(incl & 0xffffffffll), 63);
         if (a.lab & 1) total = 0;
+        // the usual tile holds a hundred walks: every window writes its index over its walks' slots, and phase 2 reads a
+        // walk's window with ONE LDS access instead of a six-step search through incl[]
+        const bool owners = total < kOwnerSlots;          // (below it: a window's walks fit the record's eight bits)
+        if (owners)
+            for (int x = (int)(incl - walks); x < (int)incl; ++x) wl->owner[x] = (unsigned char)lane;
+        wl->pack[lane] = uint4{sc_a, (unsigned)wi.i0, (unsigned)(wi.ns | (wi.ns_b << 16)),
+                               (unsigned)bad_a | ((unsigned)min(wi.walks, 255ll) << 8) | (((unsigned)(incl - walks) & 0xffffu) << 16)};
         __builtin_amdgcn_wave_barrier();
         lap(3, tk0);                  // 11: listing + scan
         // ---- phase 2: lane per walk
@@ -457,21 +470,32 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
             long long q = 0;
             int s_f = 0, s_r = 0;
             if (live) {
-                int lo = 0, hi = kTileWin - 1;                 // first window whose inclusive count exceeds wt
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (wl->incl[mid] > wt) hi = mid; else lo = mid + 1;
+                if (owners) {
+                    k = wl->owner[wt];
+                } else {
+                    int lo = 0, hi = kTileWin - 1;             // first window whose inclusive count exceeds wt
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (wl->incl[mid] > wt) hi = mid; else lo = mid + 1;
+                    }
+                    k = lo;
                 }
-                k = lo;
-                q = wt - (k ? wl->incl[k - 1] : 0ll);
-                const long long wa = wl->walks_a[k];
+                const uint4 pw = wl->pack[k];
+                long long wa;
+                if (owners) {
+                    q = wt - (long long)(pw.w >> 16);
+                    wa = (long long)((pw.w >> 8) & 0xffu);
+                } else {
+                    q = wt - (k ? wl->incl[k - 1] : 0ll);
+                    wa = wl->walks_a[k];
+                }
                 const bool jump = q >= wa;                        // layout B of a one-deletion window
-                const int i0 = wl->i0[k], nsx = wl->ns[k];
+                const int i0 = (int)pw.y, nsx = (int)pw.z;
                 unsigned sum;
                 int bad;
                 if (!jump) {                                      // the common case: positions p .. p + W - 1
-                    sum = wl->score[k];
-                    bad = wl->bad[k];
+                    sum = pw.x;
+                    bad = (int)(pw.w & 0xffu);
                     unsigned long long rest = (unsigned long long)q;
                     const int pk = (int)(t.p0 + k);
                     for (int s = (nsx & 0xffff) - 1; s >= 0 && rest; --s) {        // digits, last site first
