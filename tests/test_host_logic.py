@@ -281,3 +281,16 @@ def test_reader_threads_are_a_kept_crew(tmp_path, golden_motifs):
     p.join(timeout=120)
     assert p.exitcode == 0 and child == want[:2]
     assert _read_table(files) == want
+
+
+def test_paths_are_handed_over_as_one_blob():
+    """nv.c_paths: the `const char *const *` of a path list as one encoded blob + an array of addresses into it (what
+    StreamScan passes to gfm_scan_tsv_begin): every entry reads back as its path, non-ASCII included, none for no paths."""
+    from grafimo_amd import _native as nv
+    paths = [f"/tmp/dir/width_19/region_{i:05d}.tsv" for i in range(1000)] + ["/tmp/ü/β.tsv", "x"]
+    arr, keep = nv.c_paths(paths)
+    assert keep is not None
+    for i in (0, 1, 499, 999, 1000, 1001):
+        assert arr[i] == paths[i].encode()
+    arr0, keep0 = nv.c_paths([])
+    assert keep0 is None and not arr0
