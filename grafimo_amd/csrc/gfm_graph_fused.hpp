@@ -34,7 +34,8 @@ struct Tile {
     long long p0, limit;      // first window start, end of the region (a walk must end inside it)
     int n_win, region;        // windows p0 .. p0 + n_win - 1
     int i_lo, i_hi;           // sites [i_lo, i_hi): pos >= p0 - 1 ... pos < p0 + n_win - 1 + W
-    int w_base, pad;          // index of the tile's first window among the call's windows
+    int w_base, i_far;        // index of the tile's first window among the call's windows; first site at or behind
+                              // p0 + n_win - 1 + W + (the graph's longest deletion): what a one-deletion window's scan can reach
 };
 // a listed window for the deletion kernels: tile and window of the tile (k << 25 | tile: tiles < 2^25), its first site
 struct DelWin { int tile_k, i0; };
@@ -86,7 +87,7 @@ struct FusedArgs {
     const int *plan_overflow;     // a window of the plan's deletion list was refused (read when listing == 0)
     unsigned long long *dbg;      // measurement aid (GRAFIMO_FUSED_TIMERS=1): [k] sum, [16 + k] max of phase k's 10-ns ticks, [32 + k] count
     int lab;                      // measurement aid (GRAFIMO_FUSED_LAB=bits, results WRONG): parts of graph_score_kernel switched off --
-                                  // 1 no phase 2, 2 no base scores, 4 no window classification, 8 no booking, 16 no staging of the next tile
+                                  // 1 no phase 2, 2 no base scores, 4 no window classification, 8 no booking
 };
 __device__ __forceinline__ void dbg_tick(const FusedArgs &a, int slot, unsigned long long &t0)
 {
@@ -103,15 +104,7 @@ __device__ __forceinline__ void dbg_tick(const FusedArgs &a, int slot, unsigned 
 __device__ __forceinline__ unsigned base_code(unsigned c) { return (c >> 1) & 7u; }
 
 // site record with the alternate bases packed into n_alts' upper bytes (one LDS read instead of two global ones)
-__device__ __forceinline__ SiteRec packed_site(const GraphDev &g, int i)
-{
-    SiteRec r = g.site_rec[i];
-    if (i < g.n_sites) {
-        const uint8_t *a = g.alt_bases + (size_t)i * kMaxAlts;
-        r.n_alts |= ((int)a[0] << 8) | ((int)a[1] << 16) | ((int)a[2] << 24);
-    }
-    return r;
-}
+__device__ __forceinline__ SiteRec packed_site(const GraphDev &g, int i) { return g.site_pk[i]; }
 struct TileSites {
     const GraphDev &g;
     const SiteRec *lds;
@@ -129,6 +122,14 @@ struct TileSites {
         const unsigned d = (unsigned)(i - i_lo);
         return d < (unsigned)staged ? (long long)reach[d] >= p - p0 : covered_by_deletion(g, p, i);
     }
+};
+struct LdsTileSites {         // a tile whose site records up to i_far (the one that ends every scan) are ALL staged: LDS only
+    const SiteRec *lds;
+    const int *reach;
+    long long p0;
+    int i_lo;
+    __device__ __forceinline__ SiteRec at(int i) const { return lds[i - i_lo]; }
+    __device__ __forceinline__ bool covered(long long p, int i) const { return (long long)reach[i - i_lo] >= p - p0; }
 };
 struct GlobalTileSites {      // the same interface straight from global memory (graph_annotate_kernel)
     const GraphDev &g;
@@ -304,7 +305,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
     };
     auto issue = [&](const Tile &t) {
         TilePf f{};
-        const int staged = min(t.i_hi - t.i_lo + 1, kWaveSites);      // (+1: the record that ends a window's site scan)
+        const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);     // (+1: the record that ends a window's site scan)
         if (lane < staged) { f.r0 = packed_site(g, t.i_lo + lane); f.reach0 = reach_of(t, t.i_lo + lane); }
         if (lane + 64 < staged) { f.r1 = packed_site(g, t.i_lo + lane + 64); f.reach1 = reach_of(t, t.i_lo + lane + 64); }
         if (lane < kWaveRefBytes / 8) {
@@ -319,18 +320,36 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         return f;
     };
     auto commit = [&](const Tile &t, const TilePf &f) {
-        const int staged = min(t.i_hi - t.i_lo + 1, kWaveSites);
+        const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);
         if (lane < staged) { wl->rec[lane] = f.r0; wl->reach[lane] = f.reach0; }
         if (lane + 64 < staged) { wl->rec[lane + 64] = f.r1; wl->reach[lane + 64] = f.reach1; }
         if (lane < kWaveRefBytes / 8) *reinterpret_cast<unsigned long long *>(wl->ref + 8 * lane) = f.refw;
     };
     int ti = (int)blockIdx.x * kFusedWaves + wave;
+    // The record of the tile after next travels as a VECTOR load, a dword per lane, and is put together from the lanes when
+    // it is needed: as the scalar load the compiler makes of `tiles[uniform index]` it shares its counter with the LDS
+    // reads, and the first LDS read of a tile waited for it (scalar loads return out of order: lgkmcnt(0)).
+    static_assert(sizeof(Tile) == 40, "ten dwords");
+    auto tile_ask = [&](int idx) -> unsigned {
+        return lane < 10 ? reinterpret_cast<const unsigned *>(tiles + idx)[lane] : 0u;
+    };
+    auto tile_take = [&](unsigned dw) -> Tile {
+        unsigned v[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) v[k] = (unsigned)__builtin_amdgcn_readlane((int)dw, k);
+        Tile t;
+        t.p0 = (long long)(((unsigned long long)v[1] << 32) | v[0]);
+        t.limit = (long long)(((unsigned long long)v[3] << 32) | v[2]);
+        t.n_win = (int)v[4]; t.region = (int)v[5]; t.i_lo = (int)v[6]; t.i_hi = (int)v[7]; t.w_base = (int)v[8]; t.i_far = (int)v[9];
+        return t;
+    };
     Tile t_cur{}, t_nxt{};
+    unsigned nxt_dw = 0;
     TilePf pf{};
     if (ti < n_tiles) {
         t_cur = tiles[ti];
         pf = issue(t_cur);
-        if (ti + stride < n_tiles) t_nxt = tiles[ti + stride];
+        if (ti + stride < n_tiles) nxt_dw = tile_ask(ti + stride);
     }
     for (; ti < n_tiles; ti += stride) {
         unsigned long long tk0 = a.dbg ? wall_clock64() : 0ull, tk_tile = tk0;
@@ -338,13 +357,19 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         commit(t, pf);
         __builtin_amdgcn_wave_barrier();
         if (ti + stride < n_tiles) {
-            if (!(a.lab & 16)) pf = issue(t_nxt);
+            t_nxt = tile_take(nxt_dw);
+            pf = issue(t_nxt);
             t_cur = t_nxt;
-            if (ti + 2 * stride < n_tiles) t_nxt = tiles[ti + 2 * stride];
+            if (ti + 2 * stride < n_tiles) nxt_dw = tile_ask(ti + 2 * stride);
         }
-        const int staged = min(t.i_hi - t.i_lo + 1, kWaveSites);
-        const TileSites sites{g, wl->rec, wl->reach, t.p0, t.i_lo, staged};
+        const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);
         lap(0, tk0);                   // 8: the staged data into LDS, the next tile's loads issued
+        // The tile's work exists TWICE: for tiles whose sites are all staged (nearly every tile) with a site accessor that
+        // cannot read global memory, and for the others with the one that can.  With one body the value of `sites.at(i)` is a
+        // merge of an LDS read and a global load, and where it is used the compiler must wait for "the load" -- vmcnt(0),
+        // in order: for the NEXT tile's staging loads issued a moment ago, every tile, whichever branch ran.  That wait was
+        // 14 of the kernel's 77 us.
+        auto work = [&](const auto &sites) {
         // ---- phase 1: lane per window
         auto ref_at = [&](long long x) -> unsigned {             // a reference base: from the staged bytes if it lies there
             const long long d = x - t.p0;
@@ -541,6 +566,9 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
             if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, ti, k, 2 * q + 1, s_r);
         }
         rows_done += (unsigned long long)total * (a.forward_only ? 1ull : 2ull);
+        };
+        if (t.i_far - t.i_lo + 1 <= kWaveSites) work(LdsTileSites{wl->rec, wl->reach, t.p0, t.i_lo});
+        else work(TileSites{g, wl->rec, wl->reach, t.p0, t.i_lo, staged});
         __builtin_amdgcn_wave_barrier();       // the tile's LDS is free again
         lap(4, tk0);                  // 12: phase 2
         lap(5, tk_tile);                       // 13: the whole tile

@@ -89,6 +89,9 @@ struct GraphDev {
     // a walk through two or three of them looks its count up instead of ANDing bitsets (nullptr: no haplotypes).
     const int *pair_count;      // [n_sites][4][4]
     const int *triple_count;    // [n_sites][4][4][4]
+    // site_rec again with the alternate bases in the upper bytes of n_alts (count | a0 << 8 | a1 << 16 | a2 << 24): what the
+    // fused kernels stage per tile, one 16-byte load per site instead of that plus three byte loads
+    const SiteRec *site_pk;     // [n_sites + kSitePad]
 };
 
 // -------------------------------------------------------------------------------------------
@@ -1142,7 +1145,7 @@ struct gfm_graph {
     GraphDev dev{};
     uint8_t *d_ref = nullptr;
     int *d_pos = nullptr;
-    SiteRec *d_site_rec = nullptr;
+    SiteRec *d_site_rec = nullptr, *d_site_pk = nullptr;
     uint8_t *d_n_alts = nullptr, *d_alt_bases = nullptr;
     unsigned long long *d_alt_bits = nullptr;
     int *d_allele_count = nullptr;   // [n_sites][4] haplotypes per allele (0 = reference)
@@ -1186,6 +1189,7 @@ struct gfm_graph {
     size_t h_tiles_cap = 0;
     hipEvent_t ev_tiles = nullptr;       // the staging has been copied
     bool tiles_pending = false;
+    long long max_del_len = 0;             // the graph's longest deletion (how far behind a window a one-deletion scan looks)
     Buf<DelWin> f_del_wins;
     Buf<HeavyWin> f_heavy;                 // the plan's heavy windows (graph_heavy_kernel); f_flags[8..9]: their count << 32 | items
     unsigned long long *h_heavy_ctl = nullptr;   // pinned: that word, copied back once per plan (no heavy window: no launch)
@@ -1231,6 +1235,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
         ins_off((size_t)n_sites, 0);
     std::vector<long long> max_reach((size_t)n_sites + 1, -1);
     int n_dels = 0, n_ins = 0;
+    long long max_del_len = 0;
     long long deleted_until = -1;        // last reference position removed by an earlier deletion
     auto kind_of = [&](int i) { return del_len[(size_t)i] > 0 ? 2 : (ins_len[(size_t)i] > 0 ? 1 : 0); };
     for (int i = 0; i < n_sites; ++i) {
@@ -1262,6 +1267,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
         if (dl > 0) {
             deleted_until = std::max(deleted_until, (long long)h_pos[i] + dl);
             ++n_dels;
+            max_del_len = std::max(max_del_len, (long long)dl);
         }
         prev_del[(size_t)i + 1] = dl > 0 ? i : prev_del[(size_t)i];
         max_reach[(size_t)i + 1] = deleted_until;
@@ -1289,6 +1295,11 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
         std::vector<SiteRec> recs((size_t)n_sites + kSitePad, SiteRec{kNoSitePos, 0, 0, 0});
         for (int i = 0; i < n_sites; ++i) recs[(size_t)i] = SiteRec{h_pos[i], del_len[(size_t)i], ins_len[(size_t)i], h_n_alts[i]};
         e = upload(&g->d_site_rec, recs.data(), recs.size());
+        for (int i = 0; i < n_sites && e == hipSuccess; ++i) {
+            const uint8_t *ab = h_alt_bases + (size_t)i * kMaxAlts;
+            recs[(size_t)i].n_alts |= ((int)ab[0] << 8) | ((int)ab[1] << 16) | ((int)ab[2] << 24);
+        }
+        if (e == hipSuccess) e = upload(&g->d_site_pk, recs.data(), recs.size());
     }
     if (e == hipSuccess && bits)
         e = upload(&g->d_alt_bits, reinterpret_cast<const unsigned long long *>(h_alt_bits),
@@ -1298,10 +1309,11 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
         return gfail(GFM_ERR_HIP, std::string("graph upload failed: ") + hipGetErrorString(e));
     }
     g->h_pos.assign(h_pos, h_pos + n_sites);
+    g->max_del_len = max_del_len;
     g->dev = GraphDev{g->d_site_rec, g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
                       bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0,
                       g->d_del_len, n_dels, g->d_prev_del, g->d_max_reach, g->d_ins_len, g->d_ins_off, g->d_ins_bases,
-                      n_ins, nullptr, nullptr};
+                      n_ins, nullptr, nullptr, g->d_site_pk};
     if (e == hipSuccess)     // the widest windows need a little more than 64 KB of LDS per workgroup of deletion walks
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_emit_del_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(kDelThreads * (kSiteCache * sizeof(SiteRec) + GFM_MAX_WIDTH * sizeof(int) + 2 * GFM_MAX_WIDTH + 8)));
@@ -1355,7 +1367,7 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
 {
     if (!g) return;
     g->drop_plan();
-    (void)hipFree(g->d_ref); (void)hipFree(g->d_pos); (void)hipFree(g->d_n_alts); (void)hipFree(g->d_site_rec);
+    (void)hipFree(g->d_ref); (void)hipFree(g->d_pos); (void)hipFree(g->d_n_alts); (void)hipFree(g->d_site_rec); (void)hipFree(g->d_site_pk);
     (void)hipFree(g->d_alt_bases); (void)hipFree(g->d_alt_bits); (void)hipFree(g->d_allele_count);
     (void)hipFree(g->d_pair_count); (void)hipFree(g->d_triple_count);
     (void)hipFree(g->d_del_len); (void)hipFree(g->d_prev_del); (void)hipFree(g->d_max_reach);
@@ -1674,7 +1686,7 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
         }
         long long w_base = 0;
         size_t ti = 0;
-        int hint_lo = 0, hint_hi = 0;
+        int hint_lo = 0, hint_hi = 0, hint_far = 0;
         for (int r = 0; r < n_regions; ++r) {
             const long long s = std::max<long long>(h_starts[r], 0), e = std::min<long long>(h_stops[r], g->dev.ref_len);
             const long long nw = std::max<long long>(0, e - tail - s + 1);
@@ -1687,7 +1699,7 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
                 t.i_lo = hint_lo = site_lower_bound(g->h_pos, hint_lo, t.p0 - 1);
                 t.i_hi = hint_hi = site_lower_bound(g->h_pos, std::max(hint_hi, hint_lo), t.p0 + t.n_win - 1 + W);
                 t.w_base = (int)w_base;
-                t.pad = 0;
+                t.i_far = hint_far = site_lower_bound(g->h_pos, std::max(hint_far, hint_hi), t.p0 + t.n_win - 1 + W + g->max_del_len);
                 w_base += t.n_win;
                 if (w_base > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "too many windows in one call (split the regions)");
             }

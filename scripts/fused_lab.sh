@@ -1,12 +1,13 @@
 #!/usr/bin/env bash
 # Development aid (GPU box): what graph_score_kernel spends its time on -- the same profile with parts switched off
-# (GRAFIMO_FUSED_LAB bits: 1 no phase 2, 2 no base scores, 4 no window classification, 8 no booking, 16 no staging of the next
-# tile; results are wrong in those runs, only the kernel times count).   scripts/fused_lab.sh <tag>
+# (GRAFIMO_FUSED_LAB bits: 1 no phase 2, 2 no base scores, 4 no window classification, 8 no booking; results are wrong in
+# those runs, only the kernel times count; every run under `timeout`: a switched-off part must never leave a wavefront
+# without the data its loops end on -- a bit that skipped the staging of the next tile did, and hung the box for 25 minutes).   scripts/fused_lab.sh <tag>
 root="$GRAFT_REPO_ROOT"; out="$root/gpurun_out/${1:-r04lab}"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-for lab in ${FUSED_LAB_MODES:-0 1 2 4 8 16 3 7 15 31}; do
+for lab in ${FUSED_LAB_MODES:-0 1 4 8 3 7 15}; do
   export GRAFIMO_FUSED_LAB=$lab
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$out/p$lab" -- python3 "$root/scripts/fused_prof.py" > "$out/log$lab.txt" 2>&1
+  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/p$lab" -- python3 "$root/scripts/fused_prof.py" > "$out/log$lab.txt" 2>&1
   f=$(ls -t "$out"/p$lab/*/*kernel_stats.csv 2>/dev/null | head -1)
   python3 - "$f" "$lab" <<'PY'
 import csv, sys
