@@ -1059,14 +1059,11 @@ __device__ inline long long count_by_bitsets_wave(const GraphDev &g, int n, F at
 // bases, the count from the tables; for a listed window the odometer up to the walk's rank and one replay with the
 // visitor that collects the haplotype constraints -- so the chain of loads is one wavefront's, not sixty-four divergent
 // threads', and where the count needs the bitsets the lanes share the words.  Lane 0 writes the record.
-__global__ void __launch_bounds__(64)
-graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, const Tile *__restrict__ tiles, int n_tiles,
-                      const GraphHit *__restrict__ hits, const unsigned long long *__restrict__ hit_count, long long hit_cap,
-                      const int *__restrict__ d_cutoff, const double *__restrict__ qtable, HitRec *__restrict__ out)
+__device__ __forceinline__ void annotate_hit(const GraphDev &g, const int *__restrict__ allele_count, int W,
+                                             const Tile *__restrict__ tiles, int n_tiles, const GraphHit *__restrict__ hits,
+                                             const int *__restrict__ d_cutoff, const double *__restrict__ qtable,
+                                             HitRec *__restrict__ out, long long hi_)
 {
-    const long long n = min((long long)*hit_count, hit_cap);
-    const long long hi_ = (long long)blockIdx.x;
-    if (hi_ >= n) return;
     const bool writer = threadIdx.x == 0;
     const GraphHit hit = hits[hi_];
     const Tile t = tiles[min(max(hit.tile, 0), n_tiles - 1)];
@@ -1087,7 +1084,19 @@ graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, c
     uint8_t km[2 * GFM_MAX_WIDTH];
     long long end_pos = p + W, count = 0;
     bool any_alt = false;
-    const WinInfo wi = classify_window(g, GlobalTileSites{g}, p, W, t.limit, t.i_lo, t.i_hi);
+    // the tile's site records into LDS in one go, as graph_score_kernel stages them: the window's first site is a search, and
+    // through global memory that was seven dependent round trips before anything else could start
+    __shared__ SiteRec a_rec[kWaveSites];
+    __shared__ int a_reach[kWaveSites];
+    const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);
+    for (int s_ = threadIdx.x; s_ < staged; s_ += 64) {
+        const int i = t.i_lo + s_;
+        a_rec[s_] = packed_site(g, i);
+        const long long r = (i <= g.n_sites ? g.max_reach[i] : -1ll) - t.p0;
+        a_reach[s_] = (int)max(-1ll, min(r, 0x7fffffffll));
+    }
+    __syncthreads();
+    const WinInfo wi = classify_window(g, TileSites{g, a_rec, a_reach, t.p0, t.i_lo, staged}, p, W, t.limit, t.i_lo, t.i_hi);
     if (!wi.listed) {
         {
             unsigned long long rw[8];
@@ -1157,4 +1166,18 @@ graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, c
     rec.stop = minus ? p : end_pos;
     for (int j = 0; j < W; ++j) rec.kmer[j] = minus ? complement(km[W - 1 - j]) : km[j];
     out[hi_] = rec;
+}
+
+// A wavefront per hit entry, the entries dealt over a grid of at most a few thousand workgroups: a workgroup per SLOT of the
+// hit list (2^20 and more, nearly all of them behind the count) spent 20 us launching workgroups that had nothing to do.
+__global__ void __launch_bounds__(64)
+graph_annotate_kernel(GraphDev g, const int *__restrict__ allele_count, int W, const Tile *__restrict__ tiles, int n_tiles,
+                      const GraphHit *__restrict__ hits, const unsigned long long *__restrict__ hit_count, long long hit_cap,
+                      const int *__restrict__ d_cutoff, const double *__restrict__ qtable, HitRec *__restrict__ out)
+{
+    const long long n = min((long long)*hit_count, hit_cap);
+    for (long long hi_ = (long long)blockIdx.x; hi_ < n; hi_ += (long long)gridDim.x) {
+        __syncthreads();                    // (the last entry's LDS caches are no longer read)
+        annotate_hit(g, allele_count, W, tiles, n_tiles, hits, d_cutoff, qtable, out, hi_);
+    }
 }

@@ -1849,7 +1849,7 @@ GFM_API int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t
     if (!d_hits || !d_hit_count || !d_records) return gfail(GFM_ERR_INVALID, "NULL device buffer");
     static_assert(sizeof(HitRec) == sizeof(gfm_graph_hit_t) && sizeof(GraphHit) == 16, "record layouts of the C ABI");
     if (hit_capacity > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "hit capacity beyond 2^31");
-    const unsigned blocks = (unsigned)hit_capacity;            // a wavefront per entry; those behind the count exit at once
+    const unsigned blocks = (unsigned)std::min<int64_t>(hit_capacity, 8192);   // a wavefront per entry, entries dealt over the grid
     hipLaunchKernelGGL(graph_annotate_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), g->dev,
                        g->d_allele_count, g->f_width, g->f_tiles.p, g->f_n_tiles, static_cast<const GraphHit *>(d_hits),
                        reinterpret_cast<const unsigned long long *>(d_hit_count), (long long)hit_capacity, d_cutoff, d_qtable,
