@@ -38,6 +38,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "gfm_hit_sort.hpp"
@@ -447,10 +448,26 @@ int fetch_hit_columns(gfm_scan *sc)
         std::lock_guard<std::mutex> lk(err_mu);
         if (err.empty()) err = msg;
     };
+    std::atomic<int64_t> w_first{INT64_MAX}, w_last_start{0}, w_last_end{0};      // trace: when the workers got going (ns after t_run)
+    std::atomic<int> w_with_work{0};
     auto work = [&]() {
         static thread_local gfm_tsv_detail::FileBuf whole;
         std::vector<char> buf;
         size_t jx_at = 0, jx_end = 0;
+        const int64_t w_t0 = trace ? (int64_t)((now_s() - t_jobs) * 1e9) : 0;
+        bool w_any = false;
+        struct Stamp {
+            std::atomic<int64_t> &first, &last_start, &last_end; std::atomic<int> &n; int64_t t0; const bool &any; bool on; double base;
+            ~Stamp()
+            {
+                if (!on || !any) return;
+                const int64_t t1 = (int64_t)((now_s() - base) * 1e9);
+                int64_t v = first.load(); while (t0 < v && !first.compare_exchange_weak(v, t0)) {}
+                v = last_start.load(); while (t0 > v && !last_start.compare_exchange_weak(v, t0)) {}
+                v = last_end.load(); while (t1 > v && !last_end.compare_exchange_weak(v, t1)) {}
+                n.fetch_add(1);
+            }
+        } stamp_{w_first, w_last_start, w_last_end, w_with_work, w_t0, w_any, trace, t_jobs};
         for (;;) {
             // Jobs are taken a run at a time: neighbouring jobs write neighbouring entries of the hit columns, and handed out
             // one by one they made 24 threads share every cache line of the one-byte columns (660 ns of CPU per hit row).
@@ -460,6 +477,7 @@ int fetch_hit_columns(gfm_scan *sc)
                 jx_end = std::min(jobs.size(), jx_at + job_run);
             }
             const size_t jx = jx_at++;
+            w_any = true;
             HitJob &job = jobs[jx];
             MotifHits &h = sc->hits[job.motif];
             const std::string &path = sc->paths[job.file];
@@ -487,6 +505,7 @@ int fetch_hit_columns(gfm_scan *sc)
                     if (off < (uint64_t)(tend - text)) {
                         __builtin_prefetch(text + off);
                         __builtin_prefetch(text + off + 64);
+                        __builtin_prefetch(text + off + 127);     // (the splitter looks at 128 bytes from wherever the line starts)
                     }
                 }
                 const int64_t jc1 = trace ? tcpu() : 0;
@@ -577,8 +596,10 @@ int fetch_hit_columns(gfm_scan *sc)
     }
     if (trace)
         std::fprintf(stderr, "[scan] hit columns: %zu jobs listed in %.3f ms, run %.3f ms (worker CPU: offsets + prefetch %.1f ms, lines %.1f ms), "
-                             "names merged in %.3f ms\n", jobs.size(), (t_run - t_jobs) * 1e3, (t_merge - t_run) * 1e3,
-                     cpu_offsets.load() * 1e-6, cpu_lines.load() * 1e-6, (now_s() - t_merge) * 1e3);
+                             "names merged in %.3f ms; %d of %d workers had jobs, the first started at %.3f ms, the last at %.3f ms, the "
+                             "last finished at %.3f ms\n", jobs.size(), (t_run - t_jobs) * 1e3, (t_merge - t_run) * 1e3,
+                     cpu_offsets.load() * 1e-6, cpu_lines.load() * 1e-6, (now_s() - t_merge) * 1e3, w_with_work.load(), n_workers,
+                     w_first.load() * 1e-6, w_last_start.load() * 1e-6, w_last_end.load() * 1e-6);
     return GFM_OK;
 }
 
