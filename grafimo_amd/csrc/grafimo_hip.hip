@@ -404,12 +404,20 @@ extern "C" __attribute__((visibility("hidden"))) void gfm_set_error_(const char 
 // What the fused extraction -> scoring kernels of graph_extract.hip need of a motif (inside the library only): the score
 // matrix as the caller gave it (rows A, C, G, T), the score a k-mer holding N gets, the reachable range, and the
 // `max_bins` consecutive scores that hold the most background probability (where an LDS histogram window goes).
-extern "C" __attribute__((visibility("hidden"))) int gfm_motif_view_(gfm_motif_t m, int max_bins, const int64_t **sm, int *W,
-                                                                     int *min_val, int *L, int *win_lo, int *win_nb,
+extern "C" __attribute__((visibility("hidden"))) int gfm_motif_view_(gfm_motif_t m, int max_bins, int small_bins, const int64_t **sm,
+                                                                     int *W, int *min_val, int *L, int *win_lo, int *win_nb,
                                                                      int *device, int *n_cu)
 {
     if (!m) return fail(GFM_ERR_INVALID, "motif is NULL");
-    const gfm_motif::Window w = best_window(m, std::max(1, std::min(max_bins, m->nb)));
+    // `small_bins` consecutive scores if they hold 90 % of the background mass (a window that leaves room for two workgroups
+    // of the fused kernels per CU; the rows outside it are booked by global atomics, spread over thousands of bins: W = 40,
+    // 10^7 rows, 0.36 ms with the wide window and one workgroup per CU, 0.25 ms with this one), else up to `max_bins`
+    gfm_motif::Window w = best_window(m, std::max(1, std::min(max_bins, m->nb)));
+    if (small_bins > 0 && small_bins < w.bins) {
+        const gfm_motif::Window ws = best_window(m, small_bins);
+        static const double need = [] { const char *e = std::getenv("GRAFIMO_FUSED_SMALL_MASS"); return e ? atof(e) : 0.9; }();   // (measurement aid)
+        if (ws.mass >= need) w = ws;
+    }
     *sm = m->sm.data();
     *W = m->W;
     *min_val = m->min_val;

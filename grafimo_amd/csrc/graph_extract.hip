@@ -1618,11 +1618,16 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
 }
 
 // ------------------------------------------------------------------------------------------- fused path
-extern "C" int gfm_motif_view_(gfm_motif_t m, int max_bins, const int64_t **sm, int *W, int *min_val, int *L, int *win_lo,
-                               int *win_nb, int *device, int *n_cu);
+extern "C" int gfm_motif_view_(gfm_motif_t m, int max_bins, int small_bins, const int64_t **sm, int *W, int *min_val, int *L,
+                               int *win_lo, int *win_nb, int *device, int *n_cu);
 
 namespace {
 constexpr int kFusedMaxBins = 16384;     // LDS histogram window of the fused kernels (64 KiB); scores outside it spill
+// ... but a window of this many bins lets TWO workgroups of graph_score_kernel share a CU (160 KiB: 2 x (2 KiB table + 8 waves'
+// tiles + this window)), and is taken whenever it holds 90 % of the motif's background mass (synthetic W = 19..64 motifs with
+// 12 000+ reachable scores: gfm_graph_score 0.15 / 0.25 / 0.36 / 0.57 ms at W = 19 / 30 / 40 / 64 with the wide window and one
+// workgroup per CU, 0.105 / 0.18 / 0.25 / 0.44 ms with this one)
+constexpr int kFusedSmallBins = 8000;
 
 // first site at or behind `target`, searched from a hint (tiles come in ascending order: a step or two)
 int site_lower_bound(const std::vector<int> &pos, int hint, long long target)
@@ -1648,7 +1653,7 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     const int64_t *sm = nullptr;
     int W = 0, min_val = 0, L = 0, hlo = 0, hnb = 0, mdev = 0, n_cu = 256;
     {
-        const int rc = gfm_motif_view_(m, kFusedMaxBins, &sm, &W, &min_val, &L, &hlo, &hnb, &mdev, &n_cu);
+        const int rc = gfm_motif_view_(m, kFusedMaxBins, kFusedSmallBins, &sm, &W, &min_val, &L, &hlo, &hnb, &mdev, &n_cu);
         if (rc) return rc;
     }
     {
