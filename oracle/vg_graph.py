@@ -20,8 +20,16 @@ extraction's node numbering although no `vg` binary exists in this image:
                  (zigzag of the other node's record offset relative to this one, << 1 | reversing bit) -- and, further on, the SEQUENCE
                  VECTOR (codes A 0, T 1, C 2, G 3, N 4).  Decoded: node ids, node sequences, edges.  NOT decoded (the
                  decode stops there): the rank / select supports, the path structures (XGPath: sdsl enc_vectors and
-                 wavelet trees) and the GBWT haplotype index beside it (x.gbwt) -- so the reference path is recovered
-                 by matching node sequences against the FASTA, and haplotype counts stay unpinned by these files.
+                 wavelet trees) -- so the reference path is recovered by matching node sequences against the FASTA.
+  * read_gbwt -- the GBWT haplotype index beside an xg (x.gbwt; `vg index -G`, constructVG.py:343-402; what `vg find -H`
+                 counts haplotypes with, extract_regions.py:180,225).  Tagged container (tag "GBWT"), payload = gbwt's
+                 sdsl serialisation, version 4: header (tag 0x6B376B37, version, sequences, size, offset, alphabet
+                 size, flags), the record array (record count; an sdsl sd_vector of the records' start bytes with its two
+                 select supports; then the bytes), further on the document-array samples and the metadata (not read).
+                 A record belongs to one oriented node (GBWT node = 2 * id + is_reverse; record r = node r + offset, record 0
+                 the endmarker): ByteCode outdegree, (node delta, offset) per edge, then the run-length coded body: per
+                 visit of the node, in order, the rank of the edge the visiting sequence leaves by.  Sequences are followed
+                 from the endmarker by LF-mapping; sequence 2k is haplotype k forward, 2k + 1 its reverse.
 """
 import gzip
 import struct
@@ -223,3 +231,122 @@ def _spells(nodes, succ, n, ref, at, depth) -> bool:
     if at >= len(ref) or depth == 0:
         return True
     return any(_spells(nodes, succ, m, ref, at, depth - 1) for m in succ.get(n, []))
+
+
+def _sdsl_int_vector0(b: bytes, pos: int):
+    """sdsl int_vector<0>: uint64 bit count, uint8 width, 64-bit words -> (values, next position)"""
+    bits, = struct.unpack_from("<Q", b, pos)
+    width = b[pos + 8]
+    n_bytes = (bits + 63) // 64 * 8
+    big = int.from_bytes(b[pos + 9:pos + 9 + n_bytes], "little")
+    vals = [(big >> (i * width)) & ((1 << width) - 1) for i in range(bits // width)] if width else []
+    return vals, pos + 9 + n_bytes
+
+
+def _sdsl_bit_vector(b: bytes, pos: int):
+    bits, = struct.unpack_from("<Q", b, pos)
+    n_bytes = (bits + 63) // 64 * 8
+    return bits, int.from_bytes(b[pos + 8:pos + 8 + n_bytes], "little"), pos + 8 + n_bytes
+
+
+def _sdsl_select_mcl(b: bytes, pos: int) -> int:
+    """skips an sdsl select_support_mcl: count, superblock vector, mini_or_long bits, one block vector per 4096 arguments"""
+    arg_cnt, = struct.unpack_from("<Q", b, pos)
+    pos += 8
+    if arg_cnt:
+        _, pos = _sdsl_int_vector0(b, pos)
+        _, _, pos = _sdsl_bit_vector(b, pos)
+        for _ in range((arg_cnt + 4095) >> 12):
+            _, pos = _sdsl_int_vector0(b, pos)
+    return pos
+
+
+def _bytecode(buf: bytes, i: int) -> Tuple[int, int]:
+    v = shift = 0
+    while True:
+        c = buf[i]
+        i += 1
+        v |= (c & 0x7F) << shift
+        shift += 7
+        if not c & 0x80:
+            return v, i
+
+
+def read_gbwt(path: str) -> dict:
+    """-> dict(version, sequences, offset, alphabet_size, bidirectional, paths): paths[j] = the oriented nodes
+    [(node id, is_reverse), ...] sequence j visits, in order."""
+    raw = open(path, "rb").read()
+    groups = _groups(raw)
+    if not groups or groups[0][0] != b"GBWT":
+        raise ValueError(f"{path}: not a type-tagged GBWT stream")
+    b = b"".join(groups[0][1:])
+    tag, version = struct.unpack_from("<II", b, 0)
+    if tag != 0x6B376B37:
+        raise ValueError(f"{path}: GBWT header tag {tag:#x}")
+    sequences, size, offset, alphabet_size, flags = struct.unpack_from("<5Q", b, 8)
+    if version != 4:
+        raise ValueError(f"{path}: GBWT version {version}: only version 4 is decoded")
+    pos = 48
+    records, = struct.unpack_from("<Q", b, pos)
+    pos += 8
+    data_len, = struct.unpack_from("<Q", b, pos)                      # sd_vector: size, wl, low, high, two select supports
+    wl = b[pos + 8]
+    low, pos = _sdsl_int_vector0(b, pos + 9)
+    hbits, high, pos = _sdsl_bit_vector(b, pos)
+    pos = _sdsl_select_mcl(b, pos)
+    pos = _sdsl_select_mcl(b, pos)
+    data = b[pos:pos + data_len]
+    starts, k = [], 0
+    for p in range(hbits):
+        if (high >> p) & 1:
+            starts.append(((p - k) << wl) | low[k])
+            k += 1
+    if len(starts) != records or len(data) != data_len:
+        raise ValueError(f"{path}: record index does not add up")
+    recs = []
+    for r in range(records):
+        buf = data[starts[r]:starts[r + 1] if r + 1 < records else data_len]
+        sigma, i = _bytecode(buf, 0)
+        edges, node = [], 0
+        for _ in range(sigma):
+            d, i = _bytecode(buf, i)
+            o, i = _bytecode(buf, i)
+            node += d
+            edges.append((node, o))
+        body = []                                                     # rank of the outgoing edge per visit
+        while i < len(buf):
+            if sigma >= 255:
+                rank, i = _bytecode(buf, i)
+                extra, i = _bytecode(buf, i)
+                run = extra + 1
+            else:
+                per_byte = 256 // sigma                               # run lengths one byte can hold
+                c = buf[i]
+                i += 1
+                rank, run = c % sigma, c // sigma + 1
+                if run == per_byte:                                   # the longest: more follows
+                    extra, i = _bytecode(buf, i)
+                    run += extra
+            body.extend([rank] * run)
+        recs.append((edges, body))
+
+    def record_of(node):
+        return 0 if node == 0 else node - offset
+
+    paths = []
+    for j in range(sequences):
+        node, at, path = 0, j, []
+        while True:
+            edges, body = recs[record_of(node)]
+            rank = body[at]
+            nxt, first = edges[rank]
+            at = first + sum(1 for x in body[:at] if x == rank)
+            node = nxt
+            if node == 0:
+                break
+            path.append((node >> 1, node & 1))
+            if len(path) > size:
+                raise ValueError(f"{path}: a sequence does not end")
+        paths.append(path)
+    return dict(version=version, sequences=sequences, offset=offset, alphabet_size=alphabet_size,
+                bidirectional=bool(flags & 1), paths=paths)

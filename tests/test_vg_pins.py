@@ -1,7 +1,8 @@
 """vg's OWN node tables pin the extraction's graph layout.  The reference repository holds three vg artefacts -- the
 `.vg` its test_vg_construct compares (tests/grafimo_run_test.py:15-30; built by constructVG.py:296-338) and the
 tutorial's x.xg / y.xg (constructVG.py:343-402 on xy.fa + xy2.vcf.gz: one-base insertions and deletions).
-tests/golden/make_golden.py decoded them (oracle/vg_graph.py) into tests/golden/vg_graphs.json; here the GraphIndex
+tests/golden/make_golden.py decoded them (oracle/vg_graph.py) into tests/golden/vg_graphs.json -- and the x.gbwt / y.gbwt beside
+the xg files into the node ids every haplotype threads; here the GraphIndex
 built from the same FASTA + VCF must reproduce vg's node ids, node sequences, edges and reference path for the WHOLE
 chromosome -- SNP sites (alternates numbered before the reference allele), the 32-base chopping, the cuts around a
 deleted stretch, and the node of an insertion numbered right behind the reference node that ends with its anchor."""
@@ -76,6 +77,43 @@ def _site_at(idx, x):
         i += 1
     assert idx.pos[i] == x
     return i
+
+
+@pytest.mark.parametrize("name", ["tutorial_x_xg", "tutorial_y_xg"])
+def test_haplotypes_thread_the_nodes_vgs_gbwt_says(vg_graphs, name):
+    """The GBWT beside the tutorial's xg (x.gbwt / y.gbwt: what `vg find -H` counts haplotypes with, extract_regions.py:
+    180,225) holds, per haplotype, the nodes it threads.  The product's GraphIndex -- its haplotype bitsets per alternate
+    allele, its node table -- must put every haplotype of xy2.vcf.gz on exactly those nodes: substitutions, the one-base
+    insertions (their own node behind the anchor's) and the deletions (the deleted nodes left out) included."""
+    g = vg_graphs[name]
+    idx = _index(g)
+    want = g["haplotype_paths"]
+    assert len(want) == idx.n_haplotypes == g["gbwt_sequences"] // 2
+    carries = lambda site, a, h: bool((int(idx.alt_bits[site, a, h // 64]) >> (h % 64)) & 1)       # noqa: E731
+    for h in range(idx.n_haplotypes):
+        bases, gone_until = [], -1
+        site = 0
+        for x in range(len(idx.ref)):
+            here = []
+            while site < len(idx.pos) and idx.pos[site] == x:
+                here.append(site)
+                site += 1
+            if x <= gone_until:                         # inside a deletion this haplotype carries
+                assert not any(carries(s_, a, h) for s_ in here for a in range(int(idx.n_alts[s_])))
+                continue
+            allele = 0
+            for s_ in here:                             # the substitution site first, then insertions, then the deletion
+                if idx.del_len[s_] == 0 and idx.ins_len[s_] == 0:
+                    allele = next((a + 1 for a in range(int(idx.n_alts[s_])) if carries(s_, a, h)), 0)
+            bases.append((x, allele))
+            for s_ in here:
+                if idx.ins_len[s_] > 0 and carries(s_, 0, h):
+                    bases.extend(("ins", s_, t) for t in range(int(idx.ins_len[s_])))
+            for s_ in here:
+                if idx.del_len[s_] > 0 and carries(s_, 0, h):
+                    gone_until = max(gone_until, x + int(idx.del_len[s_]))
+        assert idx.nodes_of(bases) == want[h], (name, h)
+    assert any(len(p) != len(want[0]) for p in want) or name == "tutorial_x_xg"      # (y's second haplotype carries a deletion)
 
 
 def test_decoders_on_hand_made_streams(tmp_path):
