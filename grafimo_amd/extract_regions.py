@@ -955,7 +955,8 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
     finally:
         dm.release()
     if any(o for _, _, o, _ in got):
-        raise nv.NativeError(nv.GFM_ERR_OVERFLOW, f"a window of width {W} holds more than 2^40 walks through its variant sites")
+        raise nv.NativeError(nv.GFM_ERR_OVERFLOW, f"a window of width {W} holds more than 2^40 walks through its variant sites, or the "
+                                                  f"regions hold more than 2^20 windows of more than 64 walks each (scan fewer regions at a time)")
     n_rows = sum(n for _, n, _, _ in got)
     n_global = n_rows
     if collective:
