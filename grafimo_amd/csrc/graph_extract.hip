@@ -1786,7 +1786,10 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     int n_slabs = g1;
     {
         // the heavy windows: launched until the plan's count has come back and says there is none
-        if (!g->heavy_known && g->heavy_asked && hipEventQuery(g->ev_heavy) == hipSuccess) g->heavy_known = true;
+        if (!g->heavy_known && g->heavy_asked) {
+            if (hipEventQuery(g->ev_heavy) == hipSuccess) g->heavy_known = true;
+            else (void)hipGetLastError();          // ("not ready" is no error of this call: it must not surface in the check below)
+        }
         if (!g->heavy_known || (*g->h_heavy_ctl & 0xffffffffull) != 0ull) {
             hipLaunchKernelGGL(graph_heavy_kernel, dim3((unsigned)g_heavy), dim3(kFusedThreads), lds1, st, g->dev, a, tab, g->f_tiles.p,
                                g->f_heavy.p, heavy_ctl, g1);
