@@ -1331,6 +1331,8 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_del_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_heavy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
         gfm_graph_destroy(g);
         return gfail(GFM_ERR_HIP, std::string("event creation failed: ") + hipGetErrorString(e));
