@@ -85,18 +85,30 @@ struct FusedArgs {
     unsigned long long *hit_count, *n_rows;
     int listing;                  // 1: listed windows are queued for the deletion kernels (first call of a plan); 0: that list exists
     const int *plan_overflow;     // a window of the plan's deletion list was refused (read when listing == 0)
-    unsigned long long *dbg;      // measurement aid (GRAFIMO_FUSED_TIMERS=1): [k] sum, [16 + k] max of phase k's 10-ns ticks, [32 + k] count
-    int lab;                      // measurement aid (GRAFIMO_FUSED_LAB=bits, results WRONG): parts of graph_score_kernel switched off --
-                                  // 1 no phase 2, 2 no base scores, 4 no window classification, 8 no booking
+#ifdef GFM_LAB
+    // LAB BUILDS ONLY (scripts/lab_build.sh -DGFM_LAB; never in libgrafimo_hip.so): per-phase timers and switches that turn
+    // parts of graph_score_kernel off -- with a switch set the results are WRONG, only the kernel times count
+    unsigned long long *dbg;      // GRAFIMO_FUSED_TIMERS=1: [k] sum, [16 + k] max of phase k's 10-ns ticks, [32 + k] count
+    int lab;                      // GRAFIMO_FUSED_LAB=bits: 1 no phase 2, 2 no base scores, 4 no window classification, 8 no booking
+#endif
 };
+#ifdef GFM_LAB
+#define GFM_LAB_BIT(a, bit) ((a).lab & (bit))
+#define GFM_DBG(a) ((a).dbg)
+#else
+// the product: constants, so that every branch on them is compiled out
+#define GFM_LAB_BIT(a, bit) 0
+#define GFM_DBG(a) (static_cast<unsigned long long *>(nullptr))
+#endif
 __device__ __forceinline__ void dbg_tick(const FusedArgs &a, int slot, unsigned long long &t0)
 {
-    if (!a.dbg) return;
+    unsigned long long *dbg = GFM_DBG(a);
+    if (!dbg) return;
     const unsigned long long t1 = wall_clock64();
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&a.dbg[slot], t1 - t0);
-        atomicMax(&a.dbg[16 + slot], t1 - t0);
-        atomicAdd(&a.dbg[32 + slot], 1ull);
+        atomicAdd(&dbg[slot], t1 - t0);
+        atomicMax(&dbg[16 + slot], t1 - t0);
+        atomicAdd(&dbg[32 + slot], 1ull);
     }
     t0 = wall_clock64();
 }
@@ -290,7 +302,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
     const int stride = (int)gridDim.x * kFusedWaves;
     unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, acc_n = 0;   // measurement aid: this wavefront's ticks per phase
     auto lap = [&](int slot, unsigned long long &t0) {
-        if (!a.dbg) return;
+        if (!GFM_DBG(a)) return;
         const unsigned long long t1 = wall_clock64();
         acc_t[slot] += t1 - t0;
         t0 = t1;
@@ -352,7 +364,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         if (ti + stride < n_tiles) nxt_dw = tile_ask(ti + stride);
     }
     for (; ti < n_tiles; ti += stride) {
-        unsigned long long tk0 = a.dbg ? wall_clock64() : 0ull, tk_tile = tk0;
+        unsigned long long tk0 = GFM_DBG(a) ? wall_clock64() : 0ull, tk_tile = tk0;
         const Tile t = t_cur;
         commit(t, pf);
         __builtin_amdgcn_wave_barrier();
@@ -380,8 +392,8 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         bool listed = false;
         WinInfo wi{0, 0, 0, false, false, 0, 0, 0, 0};
         const long long p = t.p0 + lane;
-        if (lane < t.n_win && (a.lab & 4)) wi.walks = 1;
-        if (lane < t.n_win && !(a.lab & 4)) {
+        if (lane < t.n_win && GFM_LAB_BIT(a, 4)) wi.walks = 1;
+        if (lane < t.n_win && !GFM_LAB_BIT(a, 4)) {
             wi = classify_window(g, sites, p, W, t.limit, t.i_lo, t.i_hi);
             if (wi.walks < 0) { atomicMax(overflow, 1); wi.walks = 0; }
             // more walks than a round or so: not this wavefront's business.  The window's layouts -- the one of a plain window,
@@ -421,11 +433,11 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
             walks = wi.walks + wi.walks_b;
         }
         lap(1, tk0);                   // 9: classify
-        if (lane < t.n_win && (a.lab & 4)) walks = 1;
+        if (lane < t.n_win && GFM_LAB_BIT(a, 4)) walks = 1;
         unsigned sc_a = 0;
         int bad_a = 0;
         if (lane < t.n_win) {
-            if (wi.walks > 0 && !(a.lab & 2)) {                // the reference window's score on both strands
+            if (wi.walks > 0 && !GFM_LAB_BIT(a, 2)) {                // the reference window's score on both strands
                 unsigned sum = 0;
                 int bad = 0;
                 for (int j = 0; j < W; ++j) {
@@ -477,7 +489,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         }
         wl->incl[lane] = incl;
         long long total = ((long long)__shfl((int)(incl >> 32), 63) << 32) | (unsigned)__shfl((int)(incl & 0xffffffffll), 63);
-        if (a.lab & 1) total = 0;
+        if (GFM_LAB_BIT(a, 1)) total = 0;
         // the usual tile holds a hundred walks: every window writes its index over its walks' slots, and phase 2 reads a
         // walk's window with ONE LDS access instead of a six-step search through incl[]
         const bool owners = total < kOwnerSlots;          // (below it: a window's walks fit the record's eight bits)
@@ -556,12 +568,12 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 }
                 s_f = bad ? a.min_val : (int)(sum & 0xffffu);
                 s_r = bad ? a.min_val : (int)(sum >> 16);
-                if (a.hnb > 0 && !(a.lab & 8)) {
+                if (a.hnb > 0 && !GFM_LAB_BIT(a, 8)) {
                     book_score(a, h, s_f);
                     if (!a.forward_only) book_score(a, h, s_r);
                 }
             }
-            if (a.lab & 8) continue;
+            if (GFM_LAB_BIT(a, 8)) continue;
             push_hits(a, live && s_f >= a.cutoff, ti, k, 2 * q, s_f);
             if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, ti, k, 2 * q + 1, s_r);
         }
@@ -574,11 +586,11 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         lap(5, tk_tile);                       // 13: the whole tile
         ++acc_n;
     }
-    if (a.dbg && lane == 0 && acc_n)
+    if (unsigned long long *dbg = GFM_DBG(a); dbg && lane == 0 && acc_n)
         for (int k = 0; k < 6; ++k) {
-            atomicAdd(&a.dbg[8 + k], acc_t[k]);
-            atomicMax(&a.dbg[24 + k], acc_t[k]);         // (max over the wavefronts of their SUMS)
-            atomicAdd(&a.dbg[40 + k], acc_n);
+            atomicAdd(&dbg[8 + k], acc_t[k]);
+            atomicMax(&dbg[24 + k], acc_t[k]);         // (max over the wavefronts of their SUMS)
+            atomicAdd(&dbg[40 + k], acc_n);
         }
     // once per workgroup: the rows scored, what is left in the wavefronts' queues, the histogram slab
     if (lane == 0) { blk_rows[wave] = rows_done; blk_q[wave] = q_n; }
@@ -744,7 +756,7 @@ graph_del_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__
     unsigned long long rows_done = 0;
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
         __syncthreads();
-        unsigned long long tk0 = a.dbg ? wall_clock64() : 0ull, tk_item = tk0;
+        unsigned long long tk0 = GFM_DBG(a) ? wall_clock64() : 0ull, tk_item = tk0;
         const DelItem item = items[it];
         const int m = item.batch * T + lane;
         {   // the batch's state: what graph_del_count_kernel found, and each window's first site records
@@ -912,7 +924,7 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
     for (int i = tid; i < W * 8; i += kFusedThreads) tab[i] = tab_arg.v[i];
     for (int i = tid; i <= a.hnb && a.hnb > 0; i += kFusedThreads) h[i] = 0u;
     __syncthreads();
-    unsigned long long rows_done = 0;
+    unsigned long long rows_done = 0, booked = 0;
     const unsigned stride = gridDim.x * kFusedWaves;
     unsigned cur = 0xffffffffu;                 // the window this wavefront's tables describe
     HeavyWin hw{};
@@ -990,6 +1002,18 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
             if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, tile_id, win_k, 2 * (hw.q_base + wt) + 1, s_r);
             const long long n_live = min(64ll, hw.walks - (r << 6));
             rows_done += (unsigned long long)n_live * (a.forward_only ? 1ull : 2ull);
+        }
+        // The window's counters are 32 bits wide and a heavy window may hold 2^40 walks that all land in ONE bin (a reference
+        // 'N' inside it: every walk scores min_val).  A wavefront that has booked 2^28 scores since it last did so empties the
+        // whole window into the caller's 64-bit histogram -- by exchange, so the other wavefronts' adds fall on either side of
+        // it -- which keeps every bin below 8 x 2^28 whatever the others do.
+        booked += (unsigned long long)(r1 > r0 ? r1 - r0 : 0) * 128ull;
+        if (booked >= (1ull << 28) && a.hnb > 0) {
+            for (int i = lane; i <= a.hnb; i += 64) {
+                const unsigned v = atomicExch(&h[i], 0u);
+                if (v) atomicAdd(&a.hist[i < a.hnb ? a.hlo + i : a.min_val], (unsigned long long)v);
+            }
+            booked = 0;
         }
     }
     if (lane == 0) blk_rows[wave] = rows_done;

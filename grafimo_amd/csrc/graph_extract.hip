@@ -1198,7 +1198,9 @@ struct gfm_graph {
     Buf<DelBatchRec> f_del_recs;         // per listed window: what graph_del_count_kernel found
     Buf<DelItem> f_del_items;            // work items of graph_del_score_kernel
     Buf<unsigned> f_slabs;
+#ifdef GFM_LAB
     Buf<unsigned long long> f_dbg;
+#endif
     // [0] unused, [1] listed windows, [2] overflow of the call, [3] work items of the deletion kernels, [4] overflow among the
     // listed windows.  [1], [3], [4] belong to the PLAN -- the list of windows that touch an indel, their layouts and the
     // work items cut from them depend on the graph, the regions and the width, not on the motif: they are made by the first
@@ -1207,6 +1209,27 @@ struct gfm_graph {
     bool f_plan_ready = false;
     hipStream_t f_plan_stream = nullptr;   // the stream the plan was made on; a call on another one waits for ev_plan
     hipEvent_t ev_plan = nullptr;
+    // The fused calls of ONE handle share its scratch (overflow word, slabs, heavy list, tile table): they are serialised --
+    // a gfm_graph_score / gfm_graph_annotate on another stream than the handle's last call waits for that call's work.
+    hipStream_t f_last_stream = nullptr;
+    hipEvent_t ev_call = nullptr;
+    bool call_pending = false;
+    int serialise(hipStream_t st)
+    {
+        if (call_pending && st != f_last_stream) {
+            const hipError_t e = hipStreamWaitEvent(st, ev_call, 0);
+            if (e != hipSuccess) return gfail(GFM_ERR_HIP, std::string("hipStreamWaitEvent failed: ") + hipGetErrorString(e));
+        }
+        return GFM_OK;
+    }
+    int called(hipStream_t st)
+    {
+        const hipError_t e = hipEventRecord(ev_call, st);
+        if (e != hipSuccess) return gfail(GFM_ERR_HIP, std::string("hipEventRecord failed: ") + hipGetErrorString(e));
+        f_last_stream = st;
+        call_pending = true;
+        return GFM_OK;
+    }
     void drop_plan()
     {
         region_off.release(); first_start.release(); region_stop.release(); walk_base.release(); win_start.release(); walks.release();
@@ -1325,6 +1348,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_tiles, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_plan, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_call, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_heavy, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&g->h_heavy_ctl), sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess)
@@ -1382,6 +1406,7 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     if (g->h_back) (void)hipHostFree(g->h_back);
     if (g->ev_tiles) (void)hipEventDestroy(g->ev_tiles);
     if (g->ev_plan) (void)hipEventDestroy(g->ev_plan);
+    if (g->ev_call) (void)hipEventDestroy(g->ev_call);
     if (g->ev_heavy) (void)hipEventDestroy(g->ev_heavy);
     if (g->h_heavy_ctl) (void)hipHostFree(g->h_heavy_ctl);
     if (g->h_tiles) (void)hipHostFree(g->h_tiles);
@@ -1664,6 +1689,7 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
         if (dev != mdev) return gfail(GFM_ERR_INVALID, "the motif lives on another device than the current one");
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (const int rc = g->serialise(st)) return rc;
     // ---- the tile table: rebuilt only when the regions or the width change (GRAFIMO scans the same BED regions motif after
     // motif, grafimo.py:177-183)
     const size_t nr = (size_t)n_regions;
@@ -1683,7 +1709,11 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
             const long long nw = std::max<long long>(0, e - tail - s + 1);
             n_tiles += (size_t)((nw + kTileWin - 1) / kTileWin);
         }
-        if (n_tiles > 0x7fffffffull) return gfail(GFM_ERR_INVALID, "too many windows in one call (split the regions)");
+        // DelWin / HeavyWin / the hit entries pack (tile | window of the tile << kDelTileBits) into 32 bits: many short regions
+        // give partly filled tiles, so the tile count is the limit that binds first
+        static_assert(kDelTileBits + 6 <= 31 && kTileWin == 64, "tile index and window of the tile share one int");
+        if (n_tiles >= (1ull << kDelTileBits))
+            return gfail(GFM_ERR_INVALID, "more than 2^25 tiles of 64 window starts in one call (split the regions)");
         if (n_tiles > g->h_tiles_cap) {
             if (g->h_tiles) (void)hipHostFree(g->h_tiles);
             g->h_tiles = nullptr;
@@ -1772,6 +1802,7 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     a.n_rows = reinterpret_cast<unsigned long long *>(d_n_rows);
     a.listing = listing ? 1 : 0;
     a.plan_overflow = g->f_flags.p + 4;
+#ifdef GFM_LAB      // lab builds only (scripts/lab_build.sh -DGFM_LAB): the product reads neither variable
     static const bool timers = [] { const char *e = std::getenv("GRAFIMO_FUSED_TIMERS"); return e && *e == '1'; }();
     if (timers) {
         GX_TRY(g->f_dbg.reserve(48));
@@ -1780,11 +1811,13 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     }
     static const int lab = [] { const char *e = std::getenv("GRAFIMO_FUSED_LAB"); return e ? atoi(e) : 0; }();
     a.lab = lab;
+#endif
     const size_t hist_bytes = with_hist ? sizeof(unsigned) * (size_t)(hnb + 1) : 0;
     const size_t lds1 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(WaveLds) * kFusedWaves + sizeof(long long) * kFusedWaves +
                         sizeof(int) * (kFusedWaves + 2) + hist_bytes;
     hipLaunchKernelGGL(graph_score_kernel, dim3((unsigned)g1), dim3(kFusedThreads), lds1, st, g->dev, a, tab, g->f_tiles.p,
                        g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_heavy.p, heavy_ctl, g->f_flags.p + 4);
+    GX_TRY(hipGetLastError());      // (before the event query below, whose "not ready" answer is cleared: a launch failure must not go with it)
     int n_slabs = g1;
     {
         // the heavy windows: launched until the plan's count has come back and says there is none
@@ -1837,6 +1870,7 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
         hipLaunchKernelGGL(graph_hist_reduce_kernel, dim3((unsigned)((hnb + 1 + 255) / 256), (unsigned)((n_slabs + kSlabGroup - 1) / kSlabGroup)),
                            dim3(256), 0, st, g->f_slabs.p, n_slabs, hlo, hnb, min_val, reinterpret_cast<unsigned long long *>(d_hist));
     GX_TRY(hipGetLastError());
+#ifdef GFM_LAB
     if (timers) {      // measurement aid: what the wavefronts of graph_del_score_kernel spent where (10-ns ticks)
         unsigned long long h[48];
         int fl[4];
@@ -1847,8 +1881,9 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
         for (int k = 0; k < 16; ++k)
             if (h[32 + k]) std::fprintf(stderr, "[fused] phase %d: n %llu, mean %.2f us, max %.2f us\n", k, h[32 + k], 0.01 * (double)h[k] / (double)h[32 + k], 0.01 * (double)h[16 + k]);
     }
+#endif
     if (d_overflow) GX_TRY(hipMemcpyAsync(d_overflow, g->f_flags.p + 2, sizeof(int), hipMemcpyDeviceToDevice, st));
-    return GFM_OK;
+    return g->called(st);
 }
 
 GFM_API int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t *d_hit_count, int64_t hit_capacity,
@@ -1860,10 +1895,11 @@ GFM_API int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t
     static_assert(sizeof(HitRec) == sizeof(gfm_graph_hit_t) && sizeof(GraphHit) == 16, "record layouts of the C ABI");
     if (hit_capacity > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "hit capacity beyond 2^31");
     const unsigned blocks = (unsigned)std::min<int64_t>(hit_capacity, 8192);   // a wavefront per entry, entries dealt over the grid
+    if (const int rc = g->serialise(static_cast<hipStream_t>(stream))) return rc;
     hipLaunchKernelGGL(graph_annotate_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), g->dev,
                        g->d_allele_count, g->f_width, g->f_tiles.p, g->f_n_tiles, static_cast<const GraphHit *>(d_hits),
                        reinterpret_cast<const unsigned long long *>(d_hit_count), (long long)hit_capacity, d_cutoff, d_qtable,
                        static_cast<HitRec *>(d_records));
     GX_TRY(hipGetLastError());
-    return GFM_OK;
+    return g->called(static_cast<hipStream_t>(stream));
 }

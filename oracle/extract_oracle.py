@@ -511,6 +511,7 @@ def enumerate_region_variants(chrom: str, ref: bytes, v: Variants, S: int, E: in
     for i, p in enumerate(v.pos):
         at.setdefault(p, []).append(i)
     has_ins = any(k == 1 for k in v.kind)
+    del_sites = [i for i in range(len(v)) if v.kind[i] == 2]
     H = v.n_haplotypes
     L = len(ref)
     rows = []
@@ -533,8 +534,8 @@ def enumerate_region_variants(chrom: str, ref: bytes, v: Variants, S: int, E: in
                 ok &= v.carriers[i][0]
             for i in passed:
                 ok &= ~v.carriers[i][0]
-            for i in range(len(v)):
-                if v.kind[i] == 2 and i not in took:
+            for i in del_sites:
+                if i not in took:
                     lo, hi = v.pos[i] + 1, v.pos[i] + v.length[i]
                     if any(lo <= x <= hi for x in used):
                         ok &= ~v.carriers[i][0]

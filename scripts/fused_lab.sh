@@ -3,7 +3,10 @@
 # (GRAFIMO_FUSED_LAB bits: 1 no phase 2, 2 no base scores, 4 no window classification, 8 no booking; results are wrong in
 # those runs, only the kernel times count; every run under `timeout`: a switched-off part must never leave a wavefront
 # without the data its loops end on -- a bit that skipped the staging of the next tile did, and hung the box for 25 minutes).   scripts/fused_lab.sh <tag>
-root="$GRAFT_REPO_ROOT"; out="$root/gpurun_out/${1:-r04lab}"; mkdir -p "$out"
+# Needs a LAB BUILD (the product library has neither the switches nor the timers): scripts/lab_build.sh fusedlab -DGFM_LAB
+root="$GRAFT_REPO_ROOT"; out="$root/gpurun_out/${1:-r05lab}"; mkdir -p "$out"
+export GRAFIMO_HIP_LIB="$root/lab/libgfm_fusedlab.so"
+[ -f "$GRAFIMO_HIP_LIB" ] || { echo "build lab/libgfm_fusedlab.so first (scripts/lab_build.sh fusedlab -DGFM_LAB)"; exit 1; }
 cd /tmp && export TMPDIR=/tmp
 for lab in ${FUSED_LAB_MODES:-0 1 4 8 3 7 15}; do
   export GRAFIMO_FUSED_LAB=$lab

@@ -242,3 +242,88 @@ def make_consistent_graph_files(tmpdir, chrom="c", length=600, n_samples=24, see
                  "\t".join(f"s{i}" for i in range(n_samples)) + "\n")
         fh.write("\n".join(lines) + "\n")
     return fasta, vcf
+
+
+# ------------------------------------------------------------------------------------------------ the oracle's side
+# (TEST INFRASTRUCTURE: everything below imports oracle/ and is used by the GPU tests as the EXPECTED side -- rows and
+# tables that no HIP kernel produced.)
+def variants_from_index(idx):
+    """A GraphIndex's arrays as the oracle's Variants (oracle/extract_oracle.py) -- for hand-made graphs that never were
+    a VCF.  Carriers come from the bitsets (none: no haplotypes)."""
+    from oracle import extract_oracle as xo
+    v = xo.Variants()
+    H = int(idx.n_haplotypes) if idx.alt_bits is not None else 0
+    v.n_haplotypes = H
+
+    def carriers(i, k):
+        if not H:
+            return np.zeros(0, bool)
+        words = np.ascontiguousarray(idx.alt_bits[i, k]).view(np.uint8)
+        return np.unpackbits(words, bitorder="little")[:H].astype(bool)
+
+    for i in range(len(idx.pos)):
+        p = int(idx.pos[i])
+        if idx.del_len[i] > 0:
+            v.add(p, 2, length=int(idx.del_len[i]), carriers=[carriers(i, 0)])
+        elif idx.ins_len[i] > 0:
+            o = int(idx.ins_off[i])
+            v.add(p, 1, seq=idx.ins_bases[o:o + int(idx.ins_len[i])].tobytes(), carriers=[carriers(i, 0)])
+        else:
+            na = int(idx.n_alts[i])
+            v.add(p, 0, alts=[chr(int(c)) for c in idx.alt_bases[i, :na]], carriers=[carriers(i, k) for k in range(na)])
+    return v
+
+
+def motif_as_oracle_dict(motif):
+    """the members oracle.compute_results reads, from a product Motif or a stand-in with the reference's members"""
+    from oracle import oracle as orc
+    W = int(motif.width)
+    if hasattr(motif, "dense_score_matrix"):
+        sm, bg = motif.dense_score_matrix(), motif.dense_bg()
+    else:
+        sm = np.ascontiguousarray(np.asarray(motif.score_matrix, dtype=np.int64).reshape(4, W))
+        bg = np.array([float(motif.bg[n]) for n in "ACGT"], dtype=np.float64)
+    return dict(score_matrix=sm, pmf=orc.comp_pval_mat(sm, bg), min_val=int(motif.min_val), scale=int(motif.scale),
+                offset=float(motif.offset), width=W, motif_id=motif.motif_id, motif_name=motif.motif_name)
+
+
+def oracle_table(tmpdir, chrom, ref, v, regions, motif, reuse_rows=False, **kw):
+    """The report table the REFERENCE's pipeline gives for these regions, restated by the oracle end to end: the rows of
+    `vg find -K W -E -H` from the walk enumerator (oracle/extract_oracle.py), written as the TSV files scan_graph leaves,
+    read back, scored and filtered by oracle.compute_results (score_sequences.py:44-211, resultsTmp.py:241-314).
+    kw: threshold, qval_t, no_qvalue, no_reverse, recomb.  `reuse_rows`: the files of the last call with these regions and
+    this width are still in tmpdir (the enumeration is the slow part).  -> (DataFrame, rows scanned)"""
+    import pandas as pd
+    from oracle import extract_oracle as xo
+    from oracle import oracle as orc
+    W = int(motif.width)
+    d = os.path.join(str(tmpdir), "width_%d" % W)
+    want = sorted(f"{chrom}_{int(s)}-{int(e)}.tsv" for s, e in regions)
+    if not (reuse_rows and os.path.isdir(d) and sorted(os.listdir(d)) == want):
+        os.makedirs(d, exist_ok=True)
+        for f in os.listdir(d):
+            os.remove(os.path.join(d, f))
+        for s, e in regions:
+            rows = xo.enumerate_region_variants(chrom, ref, v, int(s), int(e), W, with_counts=True)
+            with open(os.path.join(d, f"{chrom}_{int(s)}-{int(e)}.tsv"), "w") as fh:
+                for r in rows:
+                    fh.write("\t".join(str(x) for x in r) + "\t1+,\n")
+    res = orc.compute_results(motif_as_oracle_dict(motif), str(tmpdir), threshold=kw.get("threshold", 1.0),
+                              qval_t=kw.get("qval_t", False), no_qvalue=kw.get("no_qvalue", False),
+                              no_reverse=kw.get("no_reverse", False), recomb=kw.get("recomb", False))
+    return pd.DataFrame({c: res[c] for c in res if not c.startswith("_")}), int(res["_scanned"])
+
+
+def assert_table_equals_oracle(df, exp, what=""):
+    """every column of every reported row; rows compared as a set keyed on everything that identifies one (pandas' sort
+    on p-value leaves ties in no particular order, resultsTmp.py:312)"""
+    assert list(df.columns) == list(exp.columns), (what, list(df.columns), list(exp.columns))
+    assert len(df) == len(exp), (what, len(df), len(exp))
+    key = ["p-value", "sequence_name", "start", "stop", "strand", "matched_sequence", "haplotype_frequency"]
+    a = df.sort_values(key).reset_index(drop=True)
+    b = exp.sort_values(key).reset_index(drop=True)
+    for c in exp.columns:
+        if b[c].dtype.kind == "f":
+            np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-9, atol=0, err_msg=str((what, c)))
+        else:
+            assert (a[c].astype(str) == b[c].astype(str)).all(), (what, c)

@@ -1,7 +1,11 @@
-"""Extraction fused into scoring (gfm_graph_score + gfm_graph_annotate: csrc/gfm_graph_fused.hpp) against the
-materialising path (gfm_graph_plan + gfm_graph_emit + the score kernel over the rows) -- the same table, row for row and
-column for column -- and against the CPU oracle.  What the fused path replaces in the reference: the TSV between
-`vg find -K` (extract_regions.py:180,225) and score_seqs (score_sequences.py:273-321)."""
+"""Extraction fused into scoring (gfm_graph_score + gfm_graph_annotate: csrc/gfm_graph_fused.hpp).  Two expected sides:
+(1) the CPU ORACLE end to end -- the walk enumerator's rows (oracle/extract_oracle.py) written as the TSV files of
+`vg find -K` (extract_regions.py:180,225), read back, scored and filtered by oracle.compute_results
+(score_sequences.py:44-211) -- for every fused kernel: graph_score_kernel (plain and one-deletion windows, tiles whose sites
+overflow the LDS stage), graph_del_count/score_kernel (listed windows), graph_heavy_kernel (plain and one-deletion layouts),
+graph_annotate_kernel, under every flag setting that changes the row set (`*_equal_the_oracle` tests: regions the Python
+enumerator finishes in seconds); (2) the materialising HIP path (gfm_graph_plan + gfm_graph_emit + the score kernel over
+the rows) row for row at sizes the enumerator cannot reach -- itself held to the oracle in tests/test_gpu_extract.py."""
 import contextlib
 import io
 import os
@@ -11,7 +15,8 @@ import pandas as pd
 import pytest
 
 from conftest import REF_DATA
-from extract_helpers import make_graph_files
+from extract_helpers import (assert_table_equals_oracle, make_consistent_graph_files, make_graph_files, oracle_table,
+                             variants_from_index)
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -95,8 +100,8 @@ def test_every_row_of_a_rich_graph(tmp_path, W):
 
 
 def test_flag_settings_on_thresholds_that_select(tmp_path):
-    """p- and q-value thresholds, --no-qvalue, --no-reverse, the --recomb filter: fused == materialised == the oracle's
-    compute_results over the oracle's own rows."""
+    """p- and q-value thresholds, --no-qvalue, --no-reverse, the --recomb filter: fused == materialised (the oracle's
+    table for a graph like this one: test_flag_settings_equal_the_oracle below)."""
     from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
     fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=6000, n_sites=500, seed=78, rich=True)
     g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7"))
@@ -244,3 +249,173 @@ def test_config2_scale_graph_and_repeated_calls():
     _assert_same(a6, b6)
     _assert_same(a6, a)
     g.close()
+
+
+# ------------------------------------------------------------------------------------------------ against the oracle
+def _fused(motif, g, regions, **kw):
+    from grafimo_amd.extract_regions import compute_results_from_graph
+    from grafimo_amd.workflow import Findmotif
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        df = compute_results_from_graph(motif, g, regions, True, Findmotif(**kw))
+    return df, out.getvalue()
+
+
+_FLAG_SETTINGS = [dict(threshold=1.0, recomb=True), dict(threshold=1.0, recomb=True, no_reverse=True), dict(threshold=0.05),
+                  dict(threshold=0.5, qval_t=True, recomb=True), dict(threshold=0.3, qval_t=True),
+                  dict(threshold=0.02, no_reverse=True), dict(threshold=0.05, no_qvalue=True, recomb=True)]
+
+
+def _check_against_oracle(tmp_path, motif, g, chrom, ref, v, regions, settings, what, min_rows=1):
+    n_checked = 0
+    for i, kw in enumerate(settings):
+        exp, scanned = oracle_table(tmp_path / "oracle", chrom, ref, v, regions, motif, reuse_rows=i > 0, **kw)
+        df, out = _fused(motif, g, regions, **kw)
+        assert f"Scanned sequences:\t{scanned}" in out, (what, kw)
+        assert_table_equals_oracle(df, exp, (what, kw))
+        n_checked += len(exp)
+    assert n_checked >= min_rows, (what, n_checked)
+
+
+@pytest.mark.parametrize("W", [5, 19, 30])
+def test_flag_settings_equal_the_oracle(tmp_path, W):
+    """A rich graph read from a VCF (SNPs, multi-allelic sites, insertions, deletions, multi-base substitutions, complex
+    alleles): the fused path's table == the oracle's, for every flag setting -- all rows (threshold 1, --recomb), forward
+    strand only, p- and q-value thresholds, --no-qvalue, the haplotype filter."""
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
+    from oracle import extract_oracle as xo
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=2400, n_sites=260, n_samples=40, seed=300 + W, rich=True)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
+    ref, v = xo.read_fasta(fasta)["7"], xo.read_vcf_variants(vcf, "7")
+    regions = [(0, 260), (700, 700 + W - 1), (900, 1200), (2200, 2400)]
+    assert _approx_walks(idx, regions, W) < 3e5
+    g = DeviceGraph(idx)
+    _check_against_oracle(tmp_path, _ctcf() if W == 19 else _motif_of_width(W), g, "7", ref, v, regions, _FLAG_SETTINGS,
+                          f"rich graph W={W}", min_rows=3000)
+    g.close()
+
+
+def _dense_graph():
+    """test_tiles_with_more_sites_than_the_lds_stage_and_heavy_windows' chromosome: a SNP at EVERY position of [20, 560) and,
+    every eight bases over a stretch, twenty one-base insertions behind one anchor"""
+    from grafimo_amd.extract_regions import GraphIndex
+    rng = np.random.default_rng(9)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = acgt[rng.integers(0, 4, 700)]
+    pos, n_alts, alt, ins_len, ins_off, ins_bases = [], [], [], [], [], []
+    anchors = {100 + 8 * k for k in range(12)}
+    for x in range(20, 560):
+        other = acgt[(np.searchsorted(acgt, ref[x]) + 1) % 4]
+        pos.append(x); n_alts.append(1); alt.append([other, 0, 0]); ins_len.append(0); ins_off.append(0)
+        if x in anchors:
+            for _ in range(20):
+                pos.append(x); n_alts.append(1); alt.append([0, 0, 0]); ins_len.append(1)
+                ins_off.append(len(ins_bases)); ins_bases.append(int(acgt[rng.integers(0, 4)]))
+    H = 70
+    bits = rng.integers(0, 2 ** 63, size=(len(pos), 3, 2), dtype=np.uint64)
+    bits[:, 1:, :] = 0
+    bits[:, :, 1] &= np.uint64((1 << (H - 64)) - 1)
+    return GraphIndex("c", ref, np.array(pos, np.int32), np.array(n_alts, np.uint8), np.array(alt, np.uint8), bits, H,
+                      ins_len=np.array(ins_len, np.int32), ins_off=np.array(ins_off, np.int32),
+                      ins_bases=np.array(ins_bases, np.uint8))
+
+
+def test_dense_tiles_and_heavy_windows_equal_the_oracle(tmp_path):
+    """graph_score_kernel on tiles whose site records overflow the LDS stage (a SNP at every base + twenty insertions per
+    anchor: the later windows of a tile read their sites from global memory), graph_del_count / graph_del_score_kernel on
+    windows of twenty-one layouts, graph_heavy_kernel on windows of 1 024 walks (W = 10 over ten SNPs): the table of every
+    row == the oracle's, k-mers, coordinates, strands, haplotype counts, ref flags, scores, p- and q-values."""
+    from grafimo_amd.extract_regions import DeviceGraph
+    idx = _dense_graph()
+    ref, v = idx.ref.tobytes(), variants_from_index(idx)
+    g = DeviceGraph(idx)
+    every = [dict(threshold=1.0, recomb=True), dict(threshold=1.0, recomb=True, no_reverse=True)]
+    # one full tile of 64 windows + the next one, 250 site records under them
+    _check_against_oracle(tmp_path, _motif_of_width(6), g, "c", ref, v, [(99, 180)], every + [dict(threshold=0.05)],
+                          "dense tile", min_rows=100_000)
+    # SNPs only, ten per window: every window is heavy; and a quiet stretch in the same call
+    _check_against_oracle(tmp_path, _motif_of_width(10), g, "c", ref, v, [(300, 330), (0, 60)],
+                          every + [dict(threshold=0.01), dict(threshold=0.2, qval_t=True)], "heavy windows", min_rows=60_000)
+    g.close()
+
+
+def _heavy_deletion_graph():
+    """test_heavy_windows_go_to_their_own_kernel...'s chromosome: twelve neighbouring sites, some tri- and tetra-allelic; seven
+    biallelic sites two bases apart with a two-base deletion in their middle; quiet stretches around"""
+    from grafimo_amd.extract_regions import GraphIndex
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = acgt[rng.integers(0, 4, 900)]
+    pos, n_alts, alt, del_len = [], [], [], []
+    for x in list(range(200, 212)) + [320, 322, 324, 326, 328, 330, 332, 500, 640]:
+        others = [c for c in acgt if c != ref[x]]
+        k = 1 + (x % 3 if x < 212 else 0)
+        pos.append(x); n_alts.append(k); alt.append(others[:k] + [0] * (3 - k)); del_len.append(0)
+    pos.append(327); n_alts.append(1); alt.append([0, 0, 0]); del_len.append(2)         # a deletion inside the second stretch
+    order = np.argsort(np.array(pos), kind="stable")
+    H = 20
+    bits = rng.integers(0, 2 ** 20, size=(len(pos), 3, 1), dtype=np.uint64)
+    return GraphIndex("c", ref, np.array(pos, np.int32)[order], np.array(n_alts, np.uint8)[order], np.array(alt, np.uint8)[order],
+                      bits[order], H, del_len=np.array(del_len, np.int32)[order])
+
+
+def test_heavy_windows_and_heavy_one_deletion_windows_equal_the_oracle(tmp_path):
+    """graph_heavy_kernel's two kinds of entries against the oracle: plain windows of up to 27 648 walks (ten neighbouring
+    sites with two to four alleles) and the two layouts of a one-deletion window of more than 64 walks (seven biallelic sites
+    around a two-base deletion) -- on the first call of a plan (the heavy list is made), with another motif of the width (the
+    list is reused), forward strand only, with thresholds that select."""
+    from grafimo_amd.extract_regions import DeviceGraph
+    idx = _heavy_deletion_graph()
+    ref, v = idx.ref.tobytes(), variants_from_index(idx)
+    g = DeviceGraph(idx)
+    regions = [(186, 210), (310, 345), (630, 660)]
+    assert 2e4 < _approx_walks(idx, regions, 16) < 3e5
+    every = [dict(threshold=1.0, recomb=True)]
+    _check_against_oracle(tmp_path, _motif_of_width(16), g, "c", ref, v, regions, every, "first call of the plan", min_rows=40_000)
+    _check_against_oracle(tmp_path, _motif_of_width(16, seed=3), g, "c", ref, v, regions,
+                          every + [dict(threshold=1.0, recomb=True, no_reverse=True), dict(threshold=0.01),
+                                   dict(threshold=0.3, qval_t=True), dict(threshold=0.05, no_qvalue=True)],
+                          "another motif, the plan's lists reused", min_rows=80_000)
+    g.close()
+
+
+def test_fuzz_seeds_fused_and_materialised_equal_enumerator_and_brute_force(tmp_path):
+    """A bounded seed set of scripts/extract_fuzz.py inside the suite: random conflict-free graphs of every allele kind
+    (one seed per kind mix: substitutions, insertions, deletions, multi-base substitutions, nested / overlapping deletions,
+    complex alleles, symbolic records), the extraction kernels' rows == the walk enumerator's == the per-haplotype brute
+    force (oracle/extract_bruteforce.py: counts from first principles, no walks enumerated), and the same rows through the
+    FUSED path (threshold 1, --recomb) with the score of every k-mer from the motif's integer matrix."""
+    from extract_fuzz_core import KINDS, fuzz_seed
+    stats = dict(graphs=0, rows=0, carried=0, heavy=0, fused=0)
+    for seed in range(91001, 91001 + len(KINDS)):
+        fuzz_seed(seed, str(tmp_path), stats)
+    assert stats["graphs"] == len(KINDS) and stats["fused"] >= 3 * len(KINDS) and stats["rows"] > 100_000, stats
+
+
+def test_lab_switches_are_not_in_the_product(tmp_path, monkeypatch):
+    """GRAFIMO_FUSED_LAB turned parts of graph_score_kernel off at run time (results wrong).  It now exists only
+    in lab builds (scripts/lab_build.sh -DGFM_LAB): the product library does not contain the variable's name, and setting
+    it changes no table.  (The library reads its switches once per process: set before the first fused call.)"""
+    import subprocess
+    import sys
+    from grafimo_amd import _native as nv
+    blob = open(nv.LIB_PATH, "rb").read()
+    assert b"GRAFIMO_FUSED_LAB" not in blob and b"GRAFIMO_FUSED_TIMERS" not in blob
+    code = (
+        "import sys, contextlib, io; sys.path[:0] = [%r, %r]\n"
+        "from test_gpu_fused import _ctcf, _fused\n"
+        "from grafimo_amd import synth\n"
+        "from grafimo_amd.extract_regions import DeviceGraph\n"
+        "idx, regions = synth.make_graph_index(300, 19)\n"
+        "df, _ = _fused(_ctcf(), DeviceGraph(idx), regions, threshold=1e-2)\n"
+        "df.to_csv(sys.argv[1], sep='\\t')\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                 os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for lab in (None, "15"):
+        env = dict(os.environ)
+        env.pop("GRAFIMO_FUSED_LAB", None)
+        if lab:
+            env["GRAFIMO_FUSED_LAB"] = lab
+        out = tmp_path / f"table_{lab}.tsv"
+        subprocess.run([sys.executable, "-c", code, str(out)], check=True, env=env, timeout=600)
+        outs.append(out.read_bytes())
+    assert outs[0] == outs[1] and outs[0].count(b"\n") > 100

@@ -34,6 +34,17 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert nv.device_count() >= 0
 
 
+def test_product_library_holds_no_lab_switch():
+    """the switches that turn parts of graph_score_kernel off (results wrong) and the kernels' phase timers
+    exist in lab builds only (scripts/lab_build.sh -DGFM_LAB): the product library does not even contain their names."""
+    blob = open(nv.LIB_PATH, "rb").read()
+    for name in (b"GRAFIMO_FUSED_LAB", b"GRAFIMO_FUSED_TIMERS"):
+        assert name not in blob, name
+    src = open(os.path.join(ROOT, "grafimo_amd", "csrc", "graph_extract.hip")).read()
+    at = src.index('getenv("GRAFIMO_FUSED_LAB")')
+    assert "#ifdef GFM_LAB" in src[max(0, at - 1200):at] and "#endif" in src[at:at + 400]
+
+
 def test_no_cpu_fallback_without_gpu(golden_motifs):
     import torch
     if torch.cuda.is_available():
