@@ -385,6 +385,14 @@ def extract_block(ctcf, dev, n_regions=10_000):
     same = len(df_m) == len(df) and bool((df_m["matched_sequence"].to_numpy() == df["matched_sequence"].to_numpy()).all()) \
         and bool((df_m["start"].to_numpy() == df["start"].to_numpy()).all()) \
         and bool((df_m["haplotype_frequency"].to_numpy() == df["haplotype_frequency"].to_numpy()).all())
+    # ---- the reference's unchanged call sequence (grafimo.py:176-183): scan_graph, then compute_results per motif.
+    # (a) our compute_results as the consumer: scan_graph leaves a manifest, no row exists anywhere; (b) GRAFIMO's own
+    # compute_results as the consumer: the TSV files, written by the library's host threads (gfm_graph_write_tsvs)
+    scan_e2e = None
+    try:
+        scan_e2e = scan_graph_block(ctcf, idx, regions, rows, g)
+    except Exception as e:                       # (a side measurement: it must not take the bench line with it)
+        scan_e2e = {"error": f"{type(e).__name__}: {e}"}
     g.close()
     e2e = 1e3 * float(np.median(runs[2:]))
     # ---- windows of very many walks (16 neighbouring biallelic SNPs inside one 30-mer: 2^16 walks per window): they leave
@@ -419,7 +427,7 @@ def extract_block(ctcf, dev, n_regions=10_000):
     except Exception as e:                       # (a side measurement: it must not take the bench line with it)
         heavy = {"error": f"{type(e).__name__}: {e}"}
     return {
-        "heavy_windows": heavy,
+        "heavy_windows": heavy, "scan_graph_e2e": scan_e2e,
         "regions": n_regions, "region_bp": 200, "width": W, "sites": int(len(idx.pos)),
         "deletions": int((idx.del_len > 0).sum()), "haplotypes": idx.n_haplotypes, "rows": int(n),
         "fused_ms": fused_ms, "rows_per_s_fused": fused_rows / (fused_ms * 1e-3),
@@ -434,6 +442,75 @@ def extract_block(ctcf, dev, n_regions=10_000):
                 "q-table + gfm_graph_annotate (columns of the hit rows only) -> table; fused_ms = gfm_graph_score alone; "
                 "emit_ms / written_GBps / frac = the materialising gfm_graph_emit kept for write_region_tsvs",
     }
+
+
+def scan_graph_block(ctcf, idx, regions, rows, g):
+    """scan_graph(widths, workflow, debug) + compute_results(motif, loc, debug, workflow), the two calls of
+    grafimo.findmotif (grafimo.py:176-179) with their reference signatures, on the extract block's graph."""
+    import shutil
+    import tempfile
+    from grafimo_amd import extract_regions as xr
+    from grafimo_amd.score_sequences import compute_results
+    from grafimo_amd.workflow import Findmotif
+    W = ctcf.width
+    tmp = tempfile.mkdtemp(prefix="gfm_bench_scan_")
+    out = {}
+    old_mode = os.environ.get("GRAFIMO_SCAN_OUTPUT")
+    try:
+        idx.save(os.path.join(tmp, "chr22"))
+        bed = os.path.join(tmp, "regions.bed")
+        with open(bed, "w") as fh:
+            fh.write("".join(f"chr22\t{s}\t{e}\n" for s, e in regions))
+        wf = Findmotif(cores=min(32, os.cpu_count() or 1), threshold=1e-4, graph_genome_dir=tmp, bedfile=bed, chroms_prefix="chr")
+        sink = io.StringIO()
+        # (a) manifest: scan_graph does not touch the GPU; the first compute_results loads and uploads the graph
+        os.environ["GRAFIMO_SCAN_OUTPUT"] = "manifest"
+        with contextlib.redirect_stdout(sink):
+            t = time.perf_counter()
+            loc = xr.scan_graph({W}, wf, False)
+            t_scan = time.perf_counter() - t
+            calls = []
+            for _ in range(8):                               # "motif after motif" over one scan_graph result
+                t = time.perf_counter()
+                df = compute_results(ctcf, loc, False, wf)
+                calls.append(time.perf_counter() - t)
+        shutil.rmtree(loc)
+        xr.drop_graph_cache()
+        out["manifest"] = {"scan_graph_ms": 1e3 * t_scan, "first_compute_results_ms": 1e3 * calls[0],
+                           "compute_results_ms": 1e3 * float(np.median(calls[2:])), "hits": int(len(df)), "rows_written": 0,
+                           "what": "scan_graph leaves a manifest (graph index, regions, widths); compute_results runs "
+                                   "compute_results_from_graph; first call = + GraphIndex.load + upload of the graph"}
+        # (b) TSV files for GRAFIMO's own compute_results: extraction + native writer
+        os.environ["GRAFIMO_SCAN_OUTPUT"] = "tsv"
+        with contextlib.redirect_stdout(sink):
+            t = time.perf_counter()
+            loc = xr.scan_graph({W}, wf, False)
+            t_tsv = time.perf_counter() - t
+        n_files = len(os.listdir(os.path.join(loc, f"width_{W}")))
+        shutil.rmtree(loc)
+        # the writer alone on the extract block's rows (round 4: a Python row loop, 4 us a row)
+        wr = {}
+        for name, node_paths in (("with_node_paths", True), ("without_node_paths", False)):
+            ts = []
+            for _ in range(2):
+                d = os.path.join(tmp, "w_" + name)
+                t = time.perf_counter()
+                xr.write_region_tsvs(idx, rows, d, node_paths=node_paths, threads=wf.cores)
+                ts.append(time.perf_counter() - t)
+                st = rows.write_stats
+                shutil.rmtree(d)
+            wr[name] = {"ms": 1e3 * min(ts), "rows_per_s": len(rows) / min(ts), "bytes": int(st.bytes), "threads": int(st.threads),
+                        "format_s": float(st.format_s), "copy_wait_s": float(st.copy_s)}
+        out["tsv"] = {"scan_graph_ms": 1e3 * t_tsv, "files": n_files, "rows": int(len(rows)), "rows_per_s": len(rows) / t_tsv,
+                      "writer": wr, "what": "scan_graph = GraphIndex.load + upload + plan + emit + gfm_graph_write_tsvs (host "
+                                            "threads format the rows from pinned chunks; node paths from the node table)"}
+    finally:
+        if old_mode is None:
+            os.environ.pop("GRAFIMO_SCAN_OUTPUT", None)
+        else:
+            os.environ["GRAFIMO_SCAN_OUTPUT"] = old_mode
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def extra_config_block(cfg, dev, rank, args, side, steps=12):

@@ -28,7 +28,8 @@ GFM_FLAG_CALLER_ORDERS_REUSE = 4
 GFM_MAX_WIDTH = 64
 GFM_BEST_ROW_BITS = 44
 GFM_GRAPH_FORWARD_ONLY = 1
-ABI_VERSION = 9
+GFM_TSV_NO_NODEPATH = 1
+ABI_VERSION = 10
 RANGE = 1000
 
 c_int = ctypes.c_int
@@ -105,6 +106,8 @@ PROTOTYPES = {
     "gfm_graph_plan": (c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_i32, P(c_i64), P(c_i64)]),
     "gfm_graph_plan_windows": (c_int, [c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i32, P(c_i64), P(c_i64)]),
     "gfm_graph_emit": (c_int, [c_void_p] * 10),
+    "gfm_graph_write_tsvs": (c_int, [c_void_p] * 9 + [c_i64, c_i32, c_i32, c_void_p, P(ctypes.c_char_p), P(ctypes.c_char_p),
+                                     ctypes.c_char_p, ctypes.c_uint32, c_int, c_void_p, c_void_p, c_void_p]),
     "gfm_graph_score": (c_int, [c_void_p, c_void_p, c_i32, c_void_p, c_void_p, ctypes.c_uint32, c_i32, c_void_p, c_void_p, c_i64,
                                 c_void_p, c_void_p, c_void_p, P(c_i64), c_void_p]),
     "gfm_graph_annotate": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -122,6 +125,12 @@ class ScanStats(ctypes.Structure):
     _fields_ = [("n_rows", c_i64), ("n_hits", c_i64), ("n_chunks", c_i64), ("h2d_bytes", c_i64),
                 ("total_s", c_double), ("parse_s", c_double), ("h2d_s", c_double), ("tail_s", c_double),
                 ("parse_threads", c_i32), ("reserved", c_i32)]
+
+
+class TsvWriteStats(ctypes.Structure):
+    """gfm_tsv_write_stats_t"""
+    _fields_ = [("n_rows", c_i64), ("n_files", c_i64), ("bytes", c_i64), ("total_s", c_double), ("copy_s", c_double),
+                ("format_s", c_double), ("threads", c_i32), ("reserved", c_i32)]
 
 
 class NativeError(RuntimeError):

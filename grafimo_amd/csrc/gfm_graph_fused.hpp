@@ -57,6 +57,10 @@ constexpr long long kHeavyWalks = 64;
 constexpr int kHeavyItemRounds = 64;
 constexpr unsigned kHeavyMaxChunks = 1u << 16;
 constexpr int kHeavyCap = 1 << 20;       // windows of one plan's heavy list (beyond it the plan is refused)
+#ifndef GFM_GRAPH_HEAVY_FLUSH_AT         // (a lab build with a small value exercises the flush without 2^41 walks)
+#define GFM_GRAPH_HEAVY_FLUSH_AT (1ull << 28)
+#endif
+constexpr unsigned long long kHeavyFlushAt = GFM_GRAPH_HEAVY_FLUSH_AT;   // scores a wavefront books between two flushes of the LDS window
 struct HitRec {               // what graph_annotate_kernel writes per hit (120 bytes; numpy dtype in extract_regions.py)
     long long start, stop, freq, q2;
     double qvalue;
@@ -1008,7 +1012,7 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         // whole window into the caller's 64-bit histogram -- by exchange, so the other wavefronts' adds fall on either side of
         // it -- which keeps every bin below 8 x 2^28 whatever the others do.
         booked += (unsigned long long)(r1 > r0 ? r1 - r0 : 0) * 128ull;
-        if (booked >= (1ull << 28) && a.hnb > 0) {
+        if (booked >= kHeavyFlushAt && a.hnb > 0) {
             for (int i = lane; i <= a.hnb; i += 64) {
                 const unsigned v = atomicExch(&h[i], 0u);
                 if (v) atomicAdd(&a.hist[i < a.hnb ? a.hlo + i : a.min_val], (unsigned long long)v);

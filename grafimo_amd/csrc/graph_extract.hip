@@ -20,14 +20,17 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "grafimo_hip.h"
+#include "gfm_graph_host.hpp"
 
 #define GFM_API extern "C" __attribute__((visibility("default")))
 extern "C" void gfm_set_error_(const char *msg);   // thread-local slot of grafimo_hip.hip
@@ -1179,6 +1182,12 @@ struct gfm_graph {
     hipStream_t side = nullptr;          // the plain walks' kernels run here when there are deletion walks, beside the plain walks' (gfm_graph_emit)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool emit_pending = false;
+    // ---- the TSV writer (gfm_graph_write_tsvs): the site arrays on the host, two pinned staging buffers, a copy stream
+    gfm_host::HostGraph host;
+    void *h_stage[2] = {nullptr, nullptr};
+    size_t h_stage_cap = 0;
+    hipStream_t copy_st = nullptr;
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};
     // ---- fused extraction -> scoring (gfm_graph_score / gfm_graph_annotate)
     std::vector<int> h_pos;              // host copy of the site positions: the tiles' first sites are found here
     std::vector<long long> f_starts, f_stops;   // the regions the device tile table was built for (reused while they repeat)
@@ -1333,6 +1342,13 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     }
     g->h_pos.assign(h_pos, h_pos + n_sites);
     g->max_del_len = max_del_len;
+    g->host.ref_len = ref_len;
+    g->host.pos.assign(h_pos, h_pos + n_sites);
+    g->host.del_len = del_len;
+    g->host.ins_len = ins_len;
+    g->host.n_alts.assign(h_n_alts, h_n_alts + n_sites);
+    g->host.max_reach = max_reach;
+    g->host.has_ins = n_ins > 0;
     g->dev = GraphDev{g->d_site_rec, g->d_ref, (long long)ref_len, n_sites, g->d_pos, g->d_n_alts, g->d_alt_bases,
                       bits ? g->d_alt_bits : nullptr, bits ? n_haplotypes : 0, bits ? hw : 0,
                       g->d_del_len, n_dels, g->d_prev_del, g->d_max_reach, g->d_ins_len, g->d_ins_off, g->d_ins_bases,
@@ -1410,6 +1426,11 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     if (g->ev_heavy) (void)hipEventDestroy(g->ev_heavy);
     if (g->h_heavy_ctl) (void)hipHostFree(g->h_heavy_ctl);
     if (g->h_tiles) (void)hipHostFree(g->h_tiles);
+    for (int k = 0; k < 2; ++k) {
+        if (g->h_stage[k]) (void)hipHostFree(g->h_stage[k]);
+        if (g->ev_copy[k]) (void)hipEventDestroy(g->ev_copy[k]);
+    }
+    if (g->copy_st) (void)hipStreamDestroy(g->copy_st);
     g->f_tiles.release(); g->f_del_wins.release(); g->f_del_recs.release(); g->f_del_items.release(); g->f_slabs.release();
     g->f_flags.release();
     g->f_heavy.release();
@@ -1641,6 +1662,108 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
     GX_TRY(hipGetLastError());
     GX_TRY(hipEventRecord(g->ev_emitted, static_cast<hipStream_t>(stream)));
     g->emit_pending = true;
+    return GFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------- the TSV files of scan_graph
+// Rows travel in chunks: device -> one of two pinned staging buffers (copy stream) while host threads format the chunk before
+// (graph_tsv_writer.cpp); a chunk is [kmers | start | stop | freq | region | walk | strand | is_ref] of <= kTsvChunkRows rows.
+namespace {
+constexpr long long kTsvChunkRows = 1ll << 21;
+struct StageView { unsigned char *kmers; long long *start, *stop, *freq; int *region, *walk; unsigned char *strand, *is_ref; };
+size_t stage_bytes(long long n, int W) { return (((size_t)n * (size_t)W + 15) & ~(size_t)15) + (size_t)n * (3 * 8 + 2 * 4 + 2) + 64; }
+StageView stage_view(void *base, long long n, int W)
+{
+    StageView v{};
+    unsigned char *p = static_cast<unsigned char *>(base);
+    v.kmers = p; p += ((size_t)n * (size_t)W + 15) & ~(size_t)15;
+    v.start = reinterpret_cast<long long *>(p); p += (size_t)n * 8;
+    v.stop = reinterpret_cast<long long *>(p); p += (size_t)n * 8;
+    v.freq = reinterpret_cast<long long *>(p); p += (size_t)n * 8;
+    v.region = reinterpret_cast<int *>(p); p += (size_t)n * 4;
+    v.walk = reinterpret_cast<int *>(p); p += (size_t)n * 4;
+    v.strand = p; p += (size_t)n;
+    v.is_ref = p;
+    return v;
+}
+}  // namespace
+
+GFM_API int gfm_graph_write_tsvs(gfm_graph_t g, const uint8_t *d_kmers, const int64_t *d_start, const int64_t *d_stop,
+                                 const uint8_t *d_strand, const int64_t *d_freq, const uint8_t *d_is_ref, const int32_t *d_region,
+                                 const int32_t *d_walk, int64_t n_rows, int32_t width, int32_t n_regions,
+                                 const int64_t *h_region_stops, const char *const *h_labels, const char *const *h_paths,
+                                 const char *chrom_name, uint32_t flags, int n_threads, uint8_t *h_seen, void *stream,
+                                 gfm_tsv_write_stats_t *stats)
+{
+    if (!g || n_rows < 0 || n_regions < 0 || width < 1 || width > GFM_MAX_WIDTH) return gfail(GFM_ERR_INVALID, "bad argument");
+    if (n_regions && (!h_region_stops || !h_labels || !h_paths || !h_seen)) return gfail(GFM_ERR_INVALID, "NULL region arrays");
+    if (!chrom_name) return gfail(GFM_ERR_INVALID, "NULL chromosome name");
+    if (n_rows && (!d_kmers || !d_start || !d_stop || !d_strand || !d_freq || !d_is_ref || !d_region || !d_walk))
+        return gfail(GFM_ERR_INVALID, "NULL row buffer");
+    static_assert(sizeof(gfm_tsv_write_stats_t) == sizeof(gfm_host::WriteStats), "stats layout of the C ABI");
+    gfm_host::WriteStats ws{};
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n_threads <= 0) n_threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    gfm_host::WriteJob job{};
+    job.W = width;
+    job.n_regions = n_regions;
+    job.region_stop = reinterpret_cast<const long long *>(h_region_stops);
+    job.labels = h_labels;
+    job.paths = h_paths;
+    job.chrom = chrom_name;
+    job.node_paths = !(flags & GFM_TSV_NO_NODEPATH);
+    job.seen = h_seen;
+    job.threads = n_threads;
+    if (n_rows > 0) {
+        const long long chunk = std::min<long long>(n_rows, kTsvChunkRows);
+        const size_t need = stage_bytes(chunk, width);
+        if (need > g->h_stage_cap) {
+            for (int k = 0; k < 2; ++k) {
+                if (g->h_stage[k]) (void)hipHostFree(g->h_stage[k]);
+                g->h_stage[k] = nullptr;
+            }
+            g->h_stage_cap = 0;
+            for (int k = 0; k < 2; ++k) GX_TRY(hipHostMalloc(&g->h_stage[k], need, hipHostMallocDefault));
+            g->h_stage_cap = need;
+        }
+        if (!g->copy_st) GX_TRY(hipStreamCreateWithFlags(&g->copy_st, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k)
+            if (!g->ev_copy[k]) GX_TRY(hipEventCreateWithFlags(&g->ev_copy[k], hipEventDisableTiming));
+        GX_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));       // the rows are complete
+        const long long n_chunks = (n_rows + chunk - 1) / chunk;
+        auto issue = [&](long long c) -> hipError_t {
+            const long long r0 = c * chunk, n = std::min(chunk, n_rows - r0);
+            const StageView v = stage_view(g->h_stage[c & 1], chunk, width);
+            hipError_t e = hipMemcpyAsync(v.kmers, d_kmers + (size_t)r0 * (size_t)width, (size_t)n * (size_t)width, hipMemcpyDeviceToHost, g->copy_st);
+            if (e == hipSuccess) e = hipMemcpyAsync(v.start, d_start + r0, (size_t)n * 8, hipMemcpyDeviceToHost, g->copy_st);
+            if (e == hipSuccess) e = hipMemcpyAsync(v.stop, d_stop + r0, (size_t)n * 8, hipMemcpyDeviceToHost, g->copy_st);
+            if (e == hipSuccess) e = hipMemcpyAsync(v.freq, d_freq + r0, (size_t)n * 8, hipMemcpyDeviceToHost, g->copy_st);
+            if (e == hipSuccess) e = hipMemcpyAsync(v.region, d_region + r0, (size_t)n * 4, hipMemcpyDeviceToHost, g->copy_st);
+            if (e == hipSuccess) e = hipMemcpyAsync(v.walk, d_walk + r0, (size_t)n * 4, hipMemcpyDeviceToHost, g->copy_st);
+            if (e == hipSuccess) e = hipMemcpyAsync(v.strand, d_strand + r0, (size_t)n, hipMemcpyDeviceToHost, g->copy_st);
+            if (e == hipSuccess) e = hipMemcpyAsync(v.is_ref, d_is_ref + r0, (size_t)n, hipMemcpyDeviceToHost, g->copy_st);
+            if (e == hipSuccess) e = hipEventRecord(g->ev_copy[c & 1], g->copy_st);
+            return e;
+        };
+        GX_TRY(issue(0));
+        for (long long c = 0; c < n_chunks; ++c) {
+            const auto tc = std::chrono::steady_clock::now();
+            GX_TRY(hipEventSynchronize(g->ev_copy[c & 1]));
+            ws.copy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
+            if (c + 1 < n_chunks) GX_TRY(issue(c + 1));         // (its buffer's last chunk, c - 1, has been written)
+            const long long r0 = c * chunk, n = std::min(chunk, n_rows - r0);
+            const StageView v = stage_view(g->h_stage[c & 1], chunk, width);
+            const gfm_host::RowChunk rc{v.kmers, v.start, v.stop, v.freq, v.strand, v.is_ref, v.region, v.walk, n};
+            std::string err;
+            const int rc_ = gfm_host::write_chunk(g->host, job, rc, ws, err);
+            if (rc_) {
+                (void)hipStreamSynchronize(g->copy_st);
+                return gfail(rc_, err);
+            }
+        }
+    }
+    ws.total_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) std::memcpy(stats, &ws, sizeof ws);
     return GFM_OK;
 }
 

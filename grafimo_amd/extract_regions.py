@@ -490,10 +490,11 @@ def _region_arrays(regions):
 class ExtractedKmers:
     """Device-resident rows of one extraction (torch tensors on the graph's device)."""
 
-    def __init__(self, chrom, regions, width, kmers, start, stop, strand, freq, is_ref, region, walk):
+    def __init__(self, chrom, regions, width, kmers, start, stop, strand, freq, is_ref, region, walk, graph=None):
         self.chrom, self.regions, self.width = chrom, list(regions), int(width)
         self.kmers, self.start, self.stop, self.strand = kmers, start, stop, strand
         self.freq, self.is_ref, self.region, self.walk = freq, is_ref, region, walk
+        self.graph = graph            # the DeviceGraph the rows came from (write_region_tsvs needs its node table)
 
     def __len__(self):
         return int(self.kmers.shape[0])
@@ -585,7 +586,7 @@ class DeviceGraph:
             return parts[0]
         cat = lambda name: torch.cat([getattr(p_, name) for p_ in parts])     # noqa: E731
         return ExtractedKmers(self.index.chrom, parts[0].regions, width, cat("kmers"), cat("start"), cat("stop"),
-                              cat("strand"), cat("freq"), cat("is_ref"), cat("region"), cat("walk"))
+                              cat("strand"), cat("freq"), cat("is_ref"), cat("region"), cat("walk"), graph=self)
 
     def extract_chunks(self, regions: Sequence[Tuple[int, int]], width: int, stream=None):
         """The rows of extract() as a sequence of ExtractedKmers pieces in row order, each the output of ONE plan
@@ -645,77 +646,62 @@ class DeviceGraph:
                                                      region.data_ptr(), walk.data_ptr(), _stream_ptr(stream)))
                     if not np.array_equal(ids, np.arange(len(ids))):
                         region = torch.from_numpy(ids.astype(np.int32)).to(dev)[region.long()]     # piece -> caller's regions
-            yield ExtractedKmers(self.index.chrom, regions, width, kmers, start, stop, strand, freq, is_ref, region, walk)
+            yield ExtractedKmers(self.index.chrom, regions, width, kmers, start, stop, strand, freq, is_ref, region, walk,
+                                 graph=self)
+
+
+def region_file_names(labels: Sequence[str]) -> List[str]:
+    """CHR:S-E -> CHR_S-E.tsv (extract_regions.py:165-170: the redirect target of `vg find`)"""
+    return [lb.replace(":", "_") + ".tsv" for lb in labels]
 
 
 def write_region_tsvs(index: GraphIndex, rows: ExtractedKmers, out_dir: str, labels: Optional[Sequence[str]] = None,
-                      chrom: Optional[str] = None) -> List[str]:
-    """The files scan_graph leaves for compute_results: out_dir/width_W/CHR_S-E.tsv
-    (extract_regions.py:165-170,180), seven tab-separated columns per row like vg's.  `labels` / `chrom`:
-    the region strings and the chromosome name to print (default: the graph's own)."""
+                      chrom: Optional[str] = None, node_paths: bool = True, seen: Optional[np.ndarray] = None,
+                      threads: int = 0) -> List[str]:
+    """The files scan_graph leaves for compute_results: out_dir/width_W/CHR_S-E.tsv (extract_regions.py:165-170,180),
+    seven tab-separated columns per row like vg's -- written by gfm_graph_write_tsvs (csrc/graph_tsv_writer.cpp: host threads
+    of the library format the rows of the extraction straight from pinned copies of its buffers; no Python touches a row).
+    `labels` / `chrom`: the region strings and the chromosome name to print (default: the graph's own).
+    `node_paths=False` leaves column 7 empty -- GRAFIMO's scoring never reads it (score_sequences.py:279-293).
+    `seen`: uint8 [n_regions], zeroed by the caller, when the rows of one directory arrive in several pieces
+    (DeviceGraph.extract_chunks: a region cut into plans is appended to); the caller then also creates the files of the
+    regions that never had a row (finish_region_tsvs).  -> the paths, one per region."""
     W = rows.width
+    g = rows.graph
+    if g is None or g.index is not index:
+        raise ValueError("the rows do not come from a DeviceGraph of this index")
     cname = index.chrom if chrom is None else chrom
     d = os.path.join(out_dir, f"width_{W}")
     os.makedirs(d, exist_ok=True)
-    km = rows.kmers.cpu().numpy()
-    start, stop = rows.start.cpu().numpy(), rows.stop.cpu().numpy()
-    strand, freq = rows.strand.cpu().numpy(), rows.freq.cpu().numpy()
-    is_ref, region, walk = rows.is_ref.cpu().numpy(), rows.region.cpu().numpy(), rows.walk.cpu().numpy()
-    paths = []
-    bounds = np.searchsorted(region, np.arange(len(rows.regions) + 1), side="left")
-    cuts, first, site_of, _ = index._node_table()
-    L = len(index.ref)
-    for r in range(len(rows.regions)):
-        label = rows.region_label(r) if labels is None else labels[r]
-        path = os.path.join(d, label.replace(":", "_") + ".tsv")
-        S, E = int(rows.regions[r][0]), int(rows.regions[r][1])
-        # node of every reference base of the region, reference alleles at the SNP sites: ONE search for the region
-        # (per base and walk it was 17 us per row: two and a half minutes for the rows of ten thousand regions)
-        x0, x1 = max(S, 0), min(max(E, S) + W + 1, L)
-        xs = np.arange(x0, max(x1, x0), dtype=np.int64)
-        jj = np.searchsorted(cuts, xs, side="right") - 1
-        st_ = site_of[jj]
-        node_ref = np.where(st_ >= 0, first[jj] + index.n_alts[np.maximum(st_, 0)], first[jj] + (xs - cuts[jj]) // NODE_MAX)
-        lines = []
-        cur_p, node_paths, plain = None, [], False
-        i0 = i1 = 0
-        w_i0, w_i1, w_touch = index.window_table(x0, max(x0, min(E, L)), W)
-        for i in range(bounds[r], bounds[r + 1]):
-            sg = chr(strand[i])
-            p = int(start[i]) if sg == "+" else int(stop[i])
-            if p != cur_p:                        # rows are window-major: a window's walks are prepared once
-                cur_p = p
-                plain = 0 <= p - x0 < len(w_touch) and not w_touch[p - x0]
-                if plain:
-                    i0, i1 = int(w_i0[p - x0]), int(w_i1[p - x0])
-                    node_paths = {}
-                else:
-                    node_paths = [index.nodes_of(b_) for b_ in index.window_walks(p, W, rows.regions[r][1])]
-            q = int(walk[i])
-            if plain:
-                nodes = node_paths.get(q)
-                if nodes is None:                 # the reference path with the walk's alternate nodes put in
-                    nd = node_ref[p - x0:p - x0 + W].copy()
-                    qq = q
-                    for k in range(i1 - i0 - 1, -1, -1):
-                        n_all = 1 + int(index.n_alts[i0 + k])
-                        a_ = qq % n_all
-                        qq //= n_all
-                        if a_:
-                            xk = int(index.pos[i0 + k])
-                            nd[xk - p] = first[int(np.searchsorted(cuts, xk, side="right")) - 1] + a_ - 1
-                    nodes = nd[np.concatenate(([True], nd[1:] != nd[:-1]))].tolist()
-                    node_paths[q] = nodes
-            else:
-                nodes = node_paths[q]
-            if sg == "-":
-                nodes = nodes[::-1]
-            lines.append(f"{label}\t{km[i].tobytes().decode()}\t{cname}:{int(start[i])}{sg}\t{cname}:{int(stop[i])}{sg}\t"
-                         f"{int(freq[i])}\t{'ref' if is_ref[i] else 'non.ref'}\t" + "".join(f"{n}{sg}," for n in nodes) + "\n")
-        with open(path, "w") as fh:
-            fh.writelines(lines)
-        paths.append(path)
+    n_reg = len(rows.regions)
+    labels = [rows.region_label(r) for r in range(n_reg)] if labels is None else list(labels)
+    paths = [os.path.join(d, f) for f in region_file_names(labels)]
+    own_seen = seen is None
+    if own_seen:
+        seen = np.zeros(n_reg, dtype=np.uint8)
+    stops = np.ascontiguousarray([r[1] for r in rows.regions], dtype=np.int64)
+    c_labels, keep1 = nv.c_paths(labels)
+    c_files, keep2 = nv.c_paths(paths)
+    st = nv.TsvWriteStats()
+    n = len(rows)
+    with _torch().cuda.device(g.device):
+        nv.check(nv.lib().gfm_graph_write_tsvs(
+            g._h, rows.kmers.data_ptr() if n else None, rows.start.data_ptr() if n else None,
+            rows.stop.data_ptr() if n else None, rows.strand.data_ptr() if n else None, rows.freq.data_ptr() if n else None,
+            rows.is_ref.data_ptr() if n else None, rows.region.data_ptr() if n else None,
+            rows.walk.data_ptr() if n else None, n, W, n_reg, nv.ptr(stops), c_labels, c_files, cname.encode(),
+            0 if node_paths else nv.GFM_TSV_NO_NODEPATH, int(threads), nv.ptr(seen), None, ctypes.byref(st)))
+    del keep1, keep2
+    rows.write_stats = st
+    if own_seen:
+        finish_region_tsvs(paths, seen)
     return paths
+
+
+def finish_region_tsvs(paths: Sequence[str], seen: np.ndarray) -> None:
+    """the regions that had no row: an empty file each, as `vg find ... > file` leaves one"""
+    for r in np.flatnonzero(np.asarray(seen) == 0).tolist():
+        open(paths[r], "w").close()
 
 
 def isbed(bedfile: str, debug: bool) -> bool:
@@ -769,12 +755,36 @@ def _index_path(xg: str) -> str:
     return xg[:-3] + INDEX_SUFFIX if xg.endswith(".xg") else xg + INDEX_SUFFIX
 
 
+MANIFEST_NAME = "grafimo_amd_manifest.json"   # what scan_graph leaves instead of rows when compute_results is ours
+
+
+def _scan_output_mode(caller_globals) -> str:
+    """'manifest' or 'tsv'.  GRAFIMO_SCAN_OUTPUT=manifest|tsv decides; otherwise ("auto") the CALLER's own `compute_results`
+    does: grafimo.findmotif calls scan_graph and then the compute_results its module imported (grafimo.py:176-179) -- if that
+    one is grafimo_amd's, rows would only be written to be parsed again, and a manifest is left instead; any other consumer
+    (GRAFIMO's own compute_results, a user who wants the files) gets the TSV files."""
+    mode = os.environ.get("GRAFIMO_SCAN_OUTPUT", "auto").strip().lower()
+    if mode in ("manifest", "tsv"):
+        return mode
+    if mode not in ("", "auto"):
+        raise ValueError(f"GRAFIMO_SCAN_OUTPUT must be auto, manifest or tsv, not {mode!r}")
+    consumer = (caller_globals or {}).get("compute_results")
+    return "manifest" if getattr(consumer, "__module__", "").startswith("grafimo_amd.") else "tsv"
+
+
 def scan_graph(widths: Set[int], args_obj, debug: bool) -> str:
-    """extract_regions.scan_graph (extract_regions.py:55-239) with the extraction kernel in place of the
+    """extract_regions.scan_graph (extract_regions.py:55-239) with the extraction kernels in place of the
     `vg find -p REGION -x XG -H GBWT -K W -E` subprocesses: same arguments (the widths of the motif set and
     the reference's Findmotif -- .graph_genome / .graph_genome_dir, .bedfile, .chroms, .chroms_prefix,
-    .namemap, .cores, .verbose), same result: a fresh `grafimo_XXXX` directory holding
-    width_W/CHR_START-STOP.tsv, one seven-column file per region and width, for compute_results.
+    .namemap, .cores, .verbose), same result: a fresh `grafimo_XXXX` directory for compute_results.
+
+    What the directory holds depends on who reads it (_scan_output_mode):
+      * GRAFIMO's own compute_results (or GRAFIMO_SCAN_OUTPUT=tsv): width_W/CHR_START-STOP.tsv, one seven-column file per
+        region and width, written by the library's host threads (gfm_graph_write_tsvs);
+      * grafimo_amd.score_sequences.compute_results (the caller's module imported ours, or GRAFIMO_SCAN_OUTPUT=manifest):
+        a MANIFEST -- which graph index, which regions, which widths -- and no row at all: compute_results then scores the
+        walks where they are enumerated (compute_results_from_graph).  grafimo.py:176-183 runs unchanged either way; in
+        manifest mode this function does not touch the GPU (no fork hazard for a caller that forks afterwards).
 
     vg's XG / GBWT files cannot be read here; the graph of a chromosome comes from the GraphIndex written by
     `GraphIndex.from_fasta_vcf(...).save(...)` NEXT TO the XG the reference would open, under the same name
@@ -783,6 +793,7 @@ def scan_graph(widths: Set[int], args_obj, debug: bool) -> str:
         exception_handler(TypeError, f"Expected set, got {type(widths).__name__}.", debug)
     if not is_scan_args_like(args_obj):
         exception_handler(TypeError, f"Expected Findmotif, got {type(args_obj).__name__}.", debug)
+    mode = _scan_output_mode(sys._getframe(1).f_globals)
     if args_obj.has_graphgenome():
         vg = args_obj.graph_genome
     elif args_obj.has_graphgenome_dir():
@@ -801,6 +812,7 @@ def scan_graph(widths: Set[int], args_obj, debug: bool) -> str:
     tmpwd = tempfile.mkdtemp(prefix="grafimo_")
     start_sq = time.time()
     graphs: Dict[str, DeviceGraph] = {}
+    entries = []                         # manifest mode: one per chromosome
     try:
         for chrom in chroms:
             # chromosome -> graph file and the name used in the region strings (extract_regions.py:136-226)
@@ -828,14 +840,28 @@ def scan_graph(widths: Set[int], args_obj, debug: bool) -> str:
                 exception_handler(VGError, f"Unable to locate {ipath} (the GPU extraction's index beside {xg}). "
                                            "Are your VGs named with \"chr\"? Consider using --chroms-prefix-find or "
                                            "chroms-namemap-find.\n", debug)
+            spans = [(int(s), int(e)) for s, e in regions[key]]
+            if mode == "manifest":
+                entries.append({"index": os.path.abspath(ipath), "chrom": c, "regions": spans})
+                continue
             if ipath not in graphs:
                 graphs[ipath] = DeviceGraph(GraphIndex.load(ipath))
             graph = graphs[ipath]
-            spans = [(int(s), int(e)) for s, e in regions[key]]
             labels = ["-".join([":".join([c, str(s)]), str(e)]) for s, e in regions[key]]
             for width in widths:
-                rows = graph.extract(spans, int(width))
-                write_region_tsvs(graph.index, rows, tmpwd, labels=labels, chrom=c)
+                d = os.path.join(tmpwd, f"width_{int(width)}")
+                seen = np.zeros(len(spans), dtype=np.uint8)
+                for piece in graph.extract_chunks(spans, int(width)):     # one plan's rows at a time
+                    write_region_tsvs(graph.index, piece, tmpwd, labels=labels, chrom=c, seen=seen,
+                                      threads=max(1, int(args_obj.cores)))
+                os.makedirs(d, exist_ok=True)
+                finish_region_tsvs([os.path.join(d, f) for f in region_file_names(labels)], seen)
+        if mode == "manifest":
+            import json
+            for width in widths:           # the directories compute_results looks into (score_sequences.py:113)
+                os.makedirs(os.path.join(tmpwd, f"width_{int(width)}"), exist_ok=True)
+            with open(os.path.join(tmpwd, MANIFEST_NAME), "w") as fh:
+                json.dump({"format": 1, "widths": sorted(int(w) for w in widths), "entries": entries}, fh)
     except (VGError, KeyError):
         raise
     except Exception as e:   # the reference funnels everything into a VGError (extract_regions.py:228-234)
@@ -850,9 +876,66 @@ def scan_graph(widths: Set[int], args_obj, debug: bool) -> str:
     return tmpwd
 
 
+# ---- the manifest's consumer (score_sequences.compute_results calls this when sequence_loc holds a manifest)
+_GRAPH_CACHE: Dict[Tuple, "DeviceGraph"] = {}
+_GRAPH_CACHE_MAX = int(os.environ.get("GRAFIMO_GRAPH_CACHE", 32))
+
+
+def cached_device_graph(ipath: str) -> "DeviceGraph":
+    """The DeviceGraph of a saved index on the current device, kept between calls: grafimo.findmotif scores motif after
+    motif over one scan_graph result (grafimo.py:177-183), and loading + uploading a chromosome per motif would cost more
+    than scoring it.  Keyed on path, modification time and device; drop_graph_cache() frees them."""
+    torch = _torch()
+    st = os.stat(ipath)
+    key = (os.path.abspath(ipath), st.st_mtime_ns, st.st_size, torch.cuda.current_device())
+    g = _GRAPH_CACHE.get(key)
+    if g is None or g._h is None:
+        while len(_GRAPH_CACHE) >= max(1, _GRAPH_CACHE_MAX):
+            _GRAPH_CACHE.pop(next(iter(_GRAPH_CACHE))).close()
+        g = _GRAPH_CACHE[key] = DeviceGraph(GraphIndex.load(ipath))
+    return g
+
+
+def drop_graph_cache() -> None:
+    for g in _GRAPH_CACHE.values():
+        g.close()
+    _GRAPH_CACHE.clear()
+
+
+def read_manifest(sequence_loc: str):
+    """the manifest scan_graph left in `sequence_loc`, or None (the directory holds TSV files)"""
+    path = os.path.join(sequence_loc, MANIFEST_NAME)
+    if not os.path.isfile(path):
+        return None
+    import json
+    with open(path) as fh:
+        man = json.load(fh)
+    if man.get("format") != 1:
+        raise ValueError(f"{path}: unknown manifest format {man.get('format')!r}")
+    return man
+
+
+def compute_results_from_manifest(motif: Motif, manifest: dict, debug: bool, args_obj, group=None,
+                                  top_graphs: Optional[int] = None) -> Optional[pd.DataFrame]:
+    """compute_results over what scan_graph described instead of wrote: every entry's graph (kept on the device between
+    motifs) and regions through compute_results_from_graph -- the table GRAFIMO's compute_results would build from the TSV
+    files of the same regions, without any of their rows existing anywhere."""
+    if int(motif.width) not in set(int(w) for w in manifest["widths"]):
+        errmsg = "No result retrieved. Unable to proceed.\n"
+        errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
+        exception_handler(ValueError, errmsg, debug)
+    graphs, regions, names = [], [], []
+    for e in manifest["entries"]:
+        graphs.append(cached_device_graph(e["index"]))
+        regions.append(np.asarray(e["regions"], dtype=np.int64).reshape(-1, 2))
+        names.append(e["chrom"])
+    return compute_results_from_graph(motif, graphs, regions, debug, args_obj, group=group, top_graphs=top_graphs,
+                                      chrom_names=names)
+
+
 def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_obj, group=None,
                                always_collective: bool = False, fused: bool = True,
-                               top_graphs: Optional[int] = None) -> Optional[pd.DataFrame]:
+                               top_graphs: Optional[int] = None, chrom_names=None) -> Optional[pd.DataFrame]:
     """extract_regions.scan_graph + score_sequences.compute_results as ONE device pass: every walk of every window of
     the regions is scored on both strands where it is enumerated (gfm_graph_score) -- no row of `vg find -K` is ever
     written, neither as TSV (extract_regions.py:180,225) nor as a device matrix; what leaves the kernels is the score
@@ -869,8 +952,12 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
     `top_graphs` = N: only the N best regions are asked for (what --top-graphs draws, res_writer.py:153-157: the first N
     distinct sequence_names of the report) -- every rank keeps ONE hit per region, the best of the rows it would report,
     before the gather (n_regions entries per rank travel instead of every hit), and the table is
-    top_hits.top_regions_table(full report, N): one row per region, best regions first."""
+    top_hits.top_regions_table(full report, N): one row per region, best regions first.
+    `chrom_names`: the chromosome name to print in sequence_name, one per entry (default: the graph's own) -- scan_graph's
+    --chroms-prefix-find / --chroms-namemap-find rules (extract_regions.py:136-226)."""
     if not fused:
+        if chrom_names is not None:
+            raise ValueError("chrom_names is a parameter of the fused path")
         df_ = compute_results_from_graph_rows(motif, graph, regions, debug, args_obj, group, always_collective)
         if top_graphs is not None and df_ is not None:
             from .top_hits import top_regions_table
@@ -882,6 +969,10 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
     many = isinstance(graph, (list, tuple))
     entries = list(graph) if many else [graph]
     entry_spans = [_region_arrays(r) for r in (regions if many else [regions])]
+    entry_names = ([chrom_names] if isinstance(chrom_names, str) else list(chrom_names)) if chrom_names is not None \
+        else [g_.index.chrom for g_ in entries]
+    if len(entry_names) != len(entries):
+        raise ValueError("one chromosome name per (graph, regions) entry")
     dist = torch.distributed
     live = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if live else 1
@@ -976,11 +1067,13 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
     kept, names_of, entry_key = [], [], []
     for gi, (_, _, _, recs) in enumerate(got):
         recs = recs[recs["keep"] != 0]
-        c, (s_, e_) = graphs[gi].index.chrom, spans[gi]
+        s_, e_ = spans[gi]
         reg = recs["region"]
         kept.append(recs)
-        entry_key.append(entry_of[gi][reg] if len(recs) else np.empty(0, dtype=np.int64))
-        names_of.append(np.array([f"{c}:{a}-{b}" for a, b in zip(s_[reg].tolist(), e_[reg].tolist())], dtype=object))
+        ek = entry_of[gi][reg] if len(recs) else np.empty(0, dtype=np.int64)
+        entry_key.append(ek)
+        names_of.append(np.array([f"{entry_names[k]}:{a}-{b}" for k, a, b in zip(ek.tolist(), s_[reg].tolist(), e_[reg].tolist())],
+                                 dtype=object))
     recs = np.concatenate(kept) if len(kept) > 1 else kept[0]
     ekey = np.concatenate(entry_key) if len(kept) > 1 else entry_key[0]
     names = np.concatenate(names_of) if len(kept) > 1 else names_of[0]

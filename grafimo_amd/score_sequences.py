@@ -219,6 +219,24 @@ def compute_results(motif: Motif, sequence_loc: str, debug: bool, args_obj=None,
         no_qvalue = qval_t = no_reverse = verbose = False
     assert threshold > 0 and threshold <= 1
     assert cores >= 1
+    # What grafimo_amd's scan_graph leaves when THIS function is its consumer (extract_regions.scan_graph): a manifest of
+    # graphs and regions instead of rows -- scored where they are enumerated, the same table as from the files.
+    from .extract_regions import compute_results_from_manifest, read_manifest
+    manifest = read_manifest(sequence_loc)
+    if manifest is not None:
+        if testmode:
+            from .workflow import Findmotif
+            args_obj = Findmotif(cores=1, threshold=1.0, recomb=True)
+        print_progress_bar(0, 1, prefix="Progress:", suffix="Complete", length=50)
+        try:
+            df = compute_results_from_manifest(motif, manifest, debug, args_obj)
+        except nv.NativeError as e:
+            exception_handler(RuntimeError, e.msg + "\n", debug)
+        except KeyboardInterrupt:
+            print("\nCaught SIGINT. GRAFIMO will exit")
+            die(2)
+        print_progress_bar(1, 1, prefix="Progress:", suffix="Complete", length=50)
+        return df
     print_scoring_msg(motif, no_reverse, debug)
 
     width = motif.width

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFM_ABI_VERSION 9
+#define GFM_ABI_VERSION 10
 
 #define GFM_OK 0
 #define GFM_ERR_INVALID (-1)  /* bad argument (NULL, width out of range, ...)            */
@@ -387,6 +387,33 @@ int gfm_graph_plan_windows(gfm_graph_t g, int32_t n_ranges, const int64_t *h_fir
 int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, int64_t *d_stop, uint8_t *d_strand,
                    int64_t *d_freq, uint8_t *d_is_ref, int32_t *d_region, int32_t *d_walk, void *stream);
 
+/* The files scan_graph leaves for GRAFIMO's own compute_results (extract_regions.py:165-170,180,225: one
+ * `vg find ... > width_W/CHR_S-E.tsv` per region), written from the rows of gfm_graph_emit by host threads of the
+ * library's crew: seven tab-separated columns per row as vg prints them --
+ *     REGION  KMER  CHR:START(+|-)  CHR:STOP(+|-)  COUNT  ref|non.ref  NODE(+|-),NODE(+|-),...
+ * -- d_* are the buffers gfm_graph_emit filled for this handle (n_rows rows, region-major), `width` the plan's;
+ * h_region_stops [n_regions] the regions' E (a walk ends inside its region: the layouts of a window near the end depend on
+ * it), h_labels [n_regions] column 1, h_paths [n_regions] the file of every region, chrom_name the name printed in columns 3
+ * and 4.  Column 7 (vg's node ids along the walk, '-' rows reversed; the node numbering of `vg construct -m 32` on this graph,
+ * pinned by vg's own .vg / .xg files) is left EMPTY with GFM_TSV_NO_NODEPATH: GRAFIMO's scoring never reads it
+ * (score_sequences.py:279-293 uses columns 1-6).  h_seen [n_regions] in/out, zeroed by the caller before the first call of a
+ * directory: a region whose file this sequence of calls already wrote is appended to (plans that cut one region into several
+ * pieces, gfm_graph_plan_windows); regions that never get a row are left to the caller (vg's redirect leaves an empty file).
+ * Synchronous: waits for `stream` (the emit), copies the rows to the host in chunks, returns when the files are closed.
+ * n_threads <= 0: as many as the machine has, at most 32. */
+#define GFM_TSV_NO_NODEPATH 1u
+typedef struct gfm_tsv_write_stats {
+    int64_t n_rows, n_files, bytes;
+    double total_s, copy_s, format_s;   /* wall time; waiting for device->host copies; formatting + writing */
+    int32_t threads, reserved;
+} gfm_tsv_write_stats_t;
+int gfm_graph_write_tsvs(gfm_graph_t g, const uint8_t *d_kmers, const int64_t *d_start, const int64_t *d_stop,
+                         const uint8_t *d_strand, const int64_t *d_freq, const uint8_t *d_is_ref, const int32_t *d_region,
+                         const int32_t *d_walk, int64_t n_rows, int32_t width, int32_t n_regions,
+                         const int64_t *h_region_stops, const char *const *h_labels, const char *const *h_paths,
+                         const char *chrom_name, uint32_t flags, int n_threads, uint8_t *h_seen, void *stream,
+                         gfm_tsv_write_stats_t *stats);
+
 /* ------------------------------------------------------------------ extraction fused into scoring
  * The join `extract_seqs -> score_seq` of the hot path without its intermediate: the reference writes every row of
  * `vg find -K W -E` to a TSV (extract_regions.py:180,225) and score_seqs reads them all back (score_sequences.py:273-321),
@@ -409,7 +436,10 @@ int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, int64_t *d
  * gfm_graph_annotate: for entry i < min(*d_hit_count, hit_capacity) the record d_records[i] of the LAST gfm_graph_score
  *   call on this handle; d_cutoff (device, optional): entries with score < *d_cutoff get keep = 0 and no columns (the
  *   p < t candidates of a --qvalueT scan that the q-value cutoff drops: q >= p); d_qtable (device, optional): the
- *   q-value of the entry's score.  Enqueue only. */
+ *   q-value of the entry's score.  Enqueue only.
+ * One call at a time per graph handle: the fused calls of a handle share its scratch (overflow word, histogram slabs, the
+ * plan's lists, the tile table), so a gfm_graph_score / gfm_graph_annotate on another stream than the handle's previous
+ * call waits (an event, on the device) for that call's work; use one handle per stream for calls that should overlap. */
 #define GFM_GRAPH_FORWARD_ONLY 1u
 typedef struct gfm_graph_entry {   /* opaque to the caller, who only provides the room: */
     int32_t tile;       /* where the walk is among the call's windows (64 consecutive window starts of one region) */

@@ -327,3 +327,74 @@ def assert_table_equals_oracle(df, exp, what=""):
             np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-9, atol=0, err_msg=str((what, c)))
         else:
             assert (a[c].astype(str) == b[c].astype(str)).all(), (what, c)
+
+
+def write_region_tsvs_reference(index, rows, out_dir, labels=None, chrom=None):
+    """TEST INFRASTRUCTURE: the Python row loop that wrote scan_graph's files in rounds 1-4 (4 us a row), kept as the
+    expected side of the native writer (gfm_graph_write_tsvs, csrc/graph_tsv_writer.cpp): the two must agree byte for byte.
+    out_dir/width_W/CHR_S-E.tsv (extract_regions.py:165-170,180), seven tab-separated columns per row like vg's; node
+    paths through GraphIndex's node table and its Python walk enumerator (window_walks)."""
+    from grafimo_amd.extract_regions import NODE_MAX
+    W = rows.width
+    cname = index.chrom if chrom is None else chrom
+    d = os.path.join(out_dir, f"width_{W}")
+    os.makedirs(d, exist_ok=True)
+    km = rows.kmers.cpu().numpy()
+    start, stop = rows.start.cpu().numpy(), rows.stop.cpu().numpy()
+    strand, freq = rows.strand.cpu().numpy(), rows.freq.cpu().numpy()
+    is_ref, region, walk = rows.is_ref.cpu().numpy(), rows.region.cpu().numpy(), rows.walk.cpu().numpy()
+    paths = []
+    bounds = np.searchsorted(region, np.arange(len(rows.regions) + 1), side="left")
+    cuts, first, site_of, _ = index._node_table()
+    L = len(index.ref)
+    for r in range(len(rows.regions)):
+        label = rows.region_label(r) if labels is None else labels[r]
+        path = os.path.join(d, label.replace(":", "_") + ".tsv")
+        S, E = int(rows.regions[r][0]), int(rows.regions[r][1])
+        # node of every reference base of the region, reference alleles at the SNP sites: ONE search for the region
+        # (per base and walk it was 17 us per row: two and a half minutes for the rows of ten thousand regions)
+        x0, x1 = max(S, 0), min(max(E, S) + W + 1, L)
+        xs = np.arange(x0, max(x1, x0), dtype=np.int64)
+        jj = np.searchsorted(cuts, xs, side="right") - 1
+        st_ = site_of[jj]
+        node_ref = np.where(st_ >= 0, first[jj] + index.n_alts[np.maximum(st_, 0)], first[jj] + (xs - cuts[jj]) // NODE_MAX)
+        lines = []
+        cur_p, node_paths, plain = None, [], False
+        i0 = i1 = 0
+        w_i0, w_i1, w_touch = index.window_table(x0, max(x0, min(E, L)), W)
+        for i in range(bounds[r], bounds[r + 1]):
+            sg = chr(strand[i])
+            p = int(start[i]) if sg == "+" else int(stop[i])
+            if p != cur_p:                        # rows are window-major: a window's walks are prepared once
+                cur_p = p
+                plain = 0 <= p - x0 < len(w_touch) and not w_touch[p - x0]
+                if plain:
+                    i0, i1 = int(w_i0[p - x0]), int(w_i1[p - x0])
+                    node_paths = {}
+                else:
+                    node_paths = [index.nodes_of(b_) for b_ in index.window_walks(p, W, rows.regions[r][1])]
+            q = int(walk[i])
+            if plain:
+                nodes = node_paths.get(q)
+                if nodes is None:                 # the reference path with the walk's alternate nodes put in
+                    nd = node_ref[p - x0:p - x0 + W].copy()
+                    qq = q
+                    for k in range(i1 - i0 - 1, -1, -1):
+                        n_all = 1 + int(index.n_alts[i0 + k])
+                        a_ = qq % n_all
+                        qq //= n_all
+                        if a_:
+                            xk = int(index.pos[i0 + k])
+                            nd[xk - p] = first[int(np.searchsorted(cuts, xk, side="right")) - 1] + a_ - 1
+                    nodes = nd[np.concatenate(([True], nd[1:] != nd[:-1]))].tolist()
+                    node_paths[q] = nodes
+            else:
+                nodes = node_paths[q]
+            if sg == "-":
+                nodes = nodes[::-1]
+            lines.append(f"{label}\t{km[i].tobytes().decode()}\t{cname}:{int(start[i])}{sg}\t{cname}:{int(stop[i])}{sg}\t"
+                         f"{int(freq[i])}\t{'ref' if is_ref[i] else 'non.ref'}\t" + "".join(f"{n}{sg}," for n in nodes) + "\n")
+        with open(path, "w") as fh:
+            fh.writelines(lines)
+        paths.append(path)
+    return paths

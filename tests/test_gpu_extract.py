@@ -601,7 +601,7 @@ def test_regions_beyond_one_plan_are_cut_into_pieces(tmp_path):
     outs, pieces = [], []
     for cap in (1 << 17, 0x3fffffff):
         out = str(tmp_path / f"rows_{cap}.npz")
-        r = subprocess.run([sys.executable, probe, "rows", out], capture_output=True, text=True,
+        r = subprocess.run([sys.executable, probe, "rows", out, str(tmp_path / f"tsv_{cap}")], capture_output=True, text=True,
                            env=dict(os.environ, GRAFIMO_PLAN_MAX_WALKS=str(cap)), timeout=600)
         assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
         pieces.append(int(r.stdout.split("pieces")[1].split()[0]))
@@ -610,6 +610,13 @@ def test_regions_beyond_one_plan_are_cut_into_pieces(tmp_path):
     assert len(outs[0]["st"]) > 1_500_000 and (np.diff(outs[0]["rg"]) >= 0).all() and set(outs[0]["rg"].tolist()) == {0, 1, 2, 3, 4}
     for k in ("km", "st", "sp", "rg", "wk", "fr", "sd", "rf"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+    # the TSV files written piece by piece (a region cut into several plans is appended to) == written from one plan
+    da, db = tmp_path / f"tsv_{1 << 17}" / "width_24", tmp_path / f"tsv_{0x3fffffff}" / "width_24"
+    names = sorted(os.listdir(db))
+    assert names == sorted(os.listdir(da)) == ["c_0-120.tsv", "c_100-130.tsv", "c_280-340.tsv", "c_590-640.tsv", "c_700-900.tsv"]
+    for f in names:
+        assert open(da / f, "rb").read() == open(db / f, "rb").read(), f
+    assert sum(open(db / f, "rb").read().count(b"\n") for f in names) == len(outs[1]["st"])
     r = subprocess.run([sys.executable, probe, "single"], capture_output=True, text=True,
                        env=dict(os.environ, GRAFIMO_PLAN_MAX_WALKS=str(1 << 15)), timeout=600)
     assert "REFUSED -7" in r.stdout and "c:280-340" in r.stdout and "starts at c:" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

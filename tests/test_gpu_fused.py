@@ -378,6 +378,37 @@ def test_heavy_windows_and_heavy_one_deletion_windows_equal_the_oracle(tmp_path)
     g.close()
 
 
+def test_a_heavy_window_whose_2_32_rows_all_fall_into_one_bin():
+    """the fused kernels' LDS histogram counters are 32 bits wide.  One window of 2^31 walks (31 biallelic sites
+    inside a 64-mer) whose reference holds an 'N': every walk scores min_val on both strands (score_sequences.py:376-378) --
+    2^32 rows in ONE bin.  The histogram holds exactly that (known answer: no kernel needed to say it), the row count too."""
+    from grafimo_amd import _native as nv
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref = acgt[rng.integers(0, 4, 300)].copy()
+    ref[100 + 50] = ord("N")
+    pos = np.arange(100, 131, dtype=np.int32)
+    alt = np.zeros((len(pos), 3), np.uint8)
+    alt[:, 0] = np.where(ref[pos] == ord("A"), ord("C"), ord("A"))
+    g = DeviceGraph(GraphIndex("c", ref, pos, np.ones(len(pos), np.uint8), alt, None, 0))
+    motif = _motif_of_width(64)
+    dm = DeviceMotif.lease(motif)
+    hist = torch.zeros(dm.L, dtype=torch.int64, device=g.device)
+    starts, stops = np.array([100], np.int64), np.array([164], np.int64)
+    assert g.score(dm, starts, stops, nv.GFM_NO_SELECT, hist=hist) == 1
+    count, n_rows, over, _ = g.fused_results()
+    h = hist.cpu().numpy()
+    assert (count, n_rows, over) == (0, 1 << 32, 0)
+    assert int(h[motif.min_val]) == 1 << 32 and int(h.sum()) == 1 << 32
+    hist.zero_()                    # the plan's heavy list is reused by the second call; forward strand only: half of it
+    g.score(dm, starts, stops, nv.GFM_NO_SELECT, hist=hist, forward_only=True)
+    assert int(hist[motif.min_val].item()) == 1 << 31 and int(hist.sum().item()) == 1 << 31
+    dm.release()
+    g.close()
+
+
 def test_fuzz_seeds_fused_and_materialised_equal_enumerator_and_brute_force(tmp_path):
     """A bounded seed set of scripts/extract_fuzz.py inside the suite: random conflict-free graphs of every allele kind
     (one seed per kind mix: substitutions, insertions, deletions, multi-base substitutions, nested / overlapping deletions,

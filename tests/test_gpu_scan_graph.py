@@ -1,0 +1,187 @@
+"""grafimo.findmotif's own call sequence (grafimo.py:176-183), UNCHANGED, on the GPU:
+
+    sequences_loc = scan_graph(motif_set.widths, workflow, debug)
+    for motif in motif_set:
+        res = compute_results(motif, sequences_loc, debug, workflow)
+    ... rm -rf sequences_loc
+
+with the two names imported from grafimo_amd at module level, exactly as grafimo.py imports GRAFIMO's own.  scan_graph sees
+that its caller's compute_results is grafimo_amd's and leaves a MANIFEST instead of rows; compute_results recognises it and
+scores the walks where they are enumerated (compute_results_from_graph).  With GRAFIMO's own compute_results as the consumer
+(GRAFIMO_SCAN_OUTPUT=tsv here) the same call leaves the TSV files, written natively.  Both give the same tables."""
+import contextlib
+import io
+import os
+import subprocess
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import REF_DATA
+from extract_helpers import make_graph_files, write_region_tsvs_reference
+from grafimo_amd.extract_regions import scan_graph                    # <- grafimo.py:25 `from grafimo.extract_regions import scan_graph`
+from grafimo_amd.score_sequences import compute_results              # <- grafimo.py:26 `from grafimo.score_sequences import compute_results`
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _findmotif_body(motif_set, workflow, debug):
+    """grafimo.py:176-183 and :184-190, word for word as far as the two calls go"""
+    widths = {m.width for m in motif_set}
+    sequences_loc = scan_graph(widths, workflow, debug)
+    tables = []
+    for motif in motif_set:
+        res = compute_results(motif, sequences_loc, debug, workflow)
+        tables.append(res)
+    listing = sorted(os.path.relpath(os.path.join(d, f), sequences_loc) for d, _, fs in os.walk(sequences_loc) for f in fs)
+    cmd = f"rm -rf {sequences_loc}"
+    assert subprocess.call(cmd, shell=True) == 0
+    return tables, listing
+
+
+def _motifs():
+    from grafimo_amd.motif_ops import build_motif_meme_host
+    from test_gpu_fused import _motif_of_width
+    return [build_motif_meme_host(os.path.join(REF_DATA, "MA0139.1.meme"), "unfrm_dst", 0.1, False)[0], _motif_of_width(12),
+            _motif_of_width(19, seed=2)]
+
+
+def _same(a: pd.DataFrame, b: pd.DataFrame, what):
+    assert list(a.columns) == list(b.columns) and len(a) == len(b), (what, len(a), len(b))
+    key = ["p-value", "sequence_name", "start", "stop", "strand", "matched_sequence"]
+    a, b = a.sort_values(key).reset_index(drop=True), b.sort_values(key).reset_index(drop=True)
+    for c in b.columns:
+        if b[c].dtype.kind == "f":
+            assert np.array_equal(a[c].to_numpy(float), b[c].to_numpy(float)), (what, c)
+        else:
+            assert (a[c].astype(str) == b[c].astype(str)).all(), (what, c)
+
+
+@pytest.mark.parametrize("flags", [dict(threshold=0.05, recomb=True), dict(threshold=0.3, qval_t=True), dict(threshold=0.02, no_reverse=True)])
+def test_unchanged_call_sequence_reaches_the_fused_path(tmp_path, monkeypatch, flags):
+    from grafimo_amd import extract_regions as xr
+    from grafimo_amd.workflow import Findmotif
+    gdir = tmp_path / "vgs"
+    gdir.mkdir()
+    regions = {}
+    for chrom, seed in (("7", 21), ("9", 22)):               # two chromosomes: q-values are computed over the rows of both
+        fasta, vcf = make_graph_files(str(tmp_path), chrom=chrom, length=5000, n_sites=380, n_samples=30, seed=seed, rich=True)
+        xr.GraphIndex.from_fasta_vcf(fasta, vcf, chrom).save(str(gdir / f"chr{chrom}"))
+        regions[chrom] = [(0, 700), (650, 1500), (2000, 2000 + 5), (3000, 4990)]
+    bed = tmp_path / "r.bed"
+    bed.write_text("".join(f"chr{c}\t{s}\t{e}\n" for c in regions for s, e in regions[c]))
+    wf = Findmotif(graph_genome_dir=str(gdir), bedfile=str(bed), chroms_prefix="chr", cores=3, **flags)
+    motifs = _motifs()
+    monkeypatch.delenv("GRAFIMO_SCAN_OUTPUT", raising=False)
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        fused, listing = _findmotif_body(motifs, wf, True)
+    assert listing == [xr.MANIFEST_NAME], listing                         # no row was written
+    text = out.getvalue()
+    assert text.count("Scanned sequences:") == 3 and "Scoring hits for motif +MA0139.1." in text
+    # the table of every motif == compute_results_from_graph called by hand on the same graphs and regions
+    graphs = [xr.cached_device_graph(str(gdir / f"chr{c}.gfmidx.npz")) for c in regions]
+    for m, got in zip(motifs, fused):
+        with contextlib.redirect_stdout(io.StringIO()):
+            want = xr.compute_results_from_graph(m, graphs, [regions[c] for c in regions], True, wf)
+        _same(got, want, ("direct", m.motif_id))
+        assert len(got) > 0 or flags.get("qval_t")
+        assert set(got["sequence_name"]) <= {f"{c}:{s}-{e}" for c in regions for s, e in regions[c]}
+    # ... == what the same call sequence gives through real TSV files (GRAFIMO's own compute_results as the consumer)
+    monkeypatch.setenv("GRAFIMO_SCAN_OUTPUT", "tsv")
+    with contextlib.redirect_stdout(io.StringIO()):
+        via_files, listing = _findmotif_body(motifs, wf, True)
+    assert xr.MANIFEST_NAME not in listing and len(listing) == 2 * 8 and "width_19/7_0-700.tsv" in listing
+    for m, a, b in zip(motifs, fused, via_files):
+        _same(a, b, ("files", m.motif_id))
+    xr.drop_graph_cache()
+
+
+def test_a_consumer_that_is_not_ours_gets_files(tmp_path, monkeypatch):
+    """auto mode looks at the CALLER's compute_results: a module whose compute_results is not grafimo_amd's (GRAFIMO's own
+    grafimo.py with only scan_graph swapped) gets the TSV files."""
+    import types
+    from grafimo_amd import extract_regions as xr
+    from grafimo_amd.workflow import Findmotif
+    fasta, vcf = os.path.join(REF_DATA, "test.fa"), os.path.join(REF_DATA, "test.vcf.gz")
+    xr.GraphIndex.from_fasta_vcf(fasta, vcf, "x").save(str(tmp_path / "x"))
+    bed = tmp_path / "r.bed"
+    bed.write_text("chrx\t0\t300\n")
+    wf = Findmotif(graph_genome=str(tmp_path / "x.xg"), bedfile=str(bed), chroms=["x"])
+    monkeypatch.delenv("GRAFIMO_SCAN_OUTPUT", raising=False)
+    other = types.ModuleType("grafimo_like")
+    other.scan_graph = xr.scan_graph
+    other.compute_results = lambda *a, **k: None                 # (its __module__ is this test's, not grafimo_amd's)
+    exec("def run(w, wf):\n    return scan_graph(w, wf, True)\n", other.__dict__)
+    with contextlib.redirect_stdout(io.StringIO()):
+        loc = other.run({19}, wf)
+    assert os.listdir(os.path.join(loc, "width_19")) == ["x_0-300.tsv"] and not os.path.exists(os.path.join(loc, xr.MANIFEST_NAME))
+    subprocess.call(f"rm -rf {loc}", shell=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        loc = scan_graph({19}, wf, True)                          # this module's compute_results IS ours: a manifest
+    assert os.path.exists(os.path.join(loc, xr.MANIFEST_NAME)) and os.listdir(os.path.join(loc, "width_19")) == []
+    with contextlib.redirect_stdout(io.StringIO()):
+        df = compute_results(_motifs()[0], loc, True, None, testmode=True)      # the reference's test mode: threshold 1, --recomb
+    assert len(df) > 500
+    with pytest.raises(ValueError) as e:
+        with contextlib.redirect_stdout(io.StringIO()):
+            compute_results(_motifs()[1], loc, True, wf)          # width 12 was not scanned
+    assert "No result retrieved" in str(e.value)
+    subprocess.call(f"rm -rf {loc}", shell=True)
+    xr.drop_graph_cache()
+
+
+@pytest.mark.parametrize("W", [8, 19, 30])
+def test_native_writer_equals_the_python_writer_on_gpu_rows(tmp_path, W):
+    """gfm_graph_write_tsvs on the rows of gfm_graph_emit == the Python row loop of rounds 1-4 over the same rows, byte for
+    byte, node paths included: a rich graph (insertions, deletions, multi-allelic sites), regions without a window, chromosome
+    names and labels as scan_graph passes them; and with column 7 switched off."""
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, write_region_tsvs
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=2600, n_sites=260, n_samples=40, seed=70 + W, rich=True)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
+    regions = [(0, 130), (400, 400 + W - 1), (500, 1300), (1290, 1500), (2300, 2600), (2590, 2600)]
+    g = DeviceGraph(idx)
+    rows = g.extract(regions, W)
+    assert len(rows) > 5000
+    labels = [f"chr7:{s}-{e}" for s, e in regions]
+    exp = write_region_tsvs_reference(idx, rows, str(tmp_path / "py"), labels=labels, chrom="chr7")
+    got = write_region_tsvs(idx, rows, str(tmp_path / "native"), labels=labels, chrom="chr7", threads=4)
+    assert [os.path.basename(p) for p in got] == [os.path.basename(p) for p in exp]
+    for a, b in zip(exp, got):
+        assert open(a, "rb").read() == open(b, "rb").read(), os.path.basename(a)
+    st = rows.write_stats
+    assert st.n_rows == len(rows) and st.n_files == sum(os.path.getsize(p) > 0 for p in got) and st.bytes == sum(os.path.getsize(p) for p in got)
+    bare = write_region_tsvs(idx, rows, str(tmp_path / "bare"), labels=labels, chrom="chr7", node_paths=False)
+    for a, b in zip(exp, bare):
+        la, lb = open(a).read().splitlines(), open(b).read().splitlines()
+        assert [x.rsplit("\t", 1)[0] for x in la] == [x.rsplit("\t", 1)[0] for x in lb] and all(x.endswith("\t") for x in lb)
+    g.close()
+
+
+def test_native_writer_on_the_reference_fixtures_rows(tmp_path):
+    """the 704 rows of the reference's scoring fixture, regenerated by the extraction kernels from the fixture's local graph:
+    the native writer's file == the Python writer's, byte for byte (a deletion, 5 096 haplotypes, node paths)."""
+    from extract_helpers import scoring_fixture_graph
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex, write_region_tsvs
+    rows, refseq, sites, dels, S, E = scoring_fixture_graph()
+    H = sites.n_haplotypes
+    recs = sorted([(int(p), 0, i) for i, p in enumerate(sites.pos)] + [(int(a), 1, j) for j, a in enumerate(dels.anchor)])
+    hw = (H + 63) // 64
+    bits = np.zeros((len(recs), 3, hw), dtype=np.uint64)
+    alt = np.zeros((len(recs), 3), dtype=np.uint8)
+    for k, (_, kind, j) in enumerate(recs):
+        carry = np.zeros(hw * 64, dtype=bool)
+        carry[:H] = dels.hap[j] if kind else sites.hap[j] == 1
+        bits[k, 0] = np.packbits(carry, bitorder="little").view(np.uint64)
+        if not kind:
+            alt[k, 0] = ord(sites.alts[j][0])
+    idx = GraphIndex("22", np.frombuffer(refseq, dtype=np.uint8), [r[0] for r in recs], [1] * len(recs), alt, bits, H,
+                     del_len=[int(dels.length[j]) if kind else 0 for _, kind, j in recs])
+    g = DeviceGraph(idx)
+    ext = g.extract([(0, E - S)], 19)
+    assert len(ext) == 704
+    a = write_region_tsvs_reference(idx, ext, str(tmp_path / "py"))[0]
+    b = write_region_tsvs(idx, ext, str(tmp_path / "native"))[0]
+    assert open(a, "rb").read() == open(b, "rb").read() and open(b).read().count("\n") == 704
+    g.close()
