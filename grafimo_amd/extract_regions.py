@@ -902,16 +902,32 @@ def drop_graph_cache() -> None:
     _GRAPH_CACHE.clear()
 
 
+_MANIFEST_CACHE: Dict[Tuple, dict] = {}
+
+
 def read_manifest(sequence_loc: str):
-    """the manifest scan_graph left in `sequence_loc`, or None (the directory holds TSV files)"""
+    """the manifest scan_graph left in `sequence_loc`, or None (the directory holds TSV files).  Parsed once per file
+    (grafimo.findmotif calls compute_results motif after motif over one directory, grafimo.py:177-183: ten thousand regions
+    of JSON cost more to parse than to score); the regions come back as [n, 2] int64 arrays."""
     path = os.path.join(sequence_loc, MANIFEST_NAME)
-    if not os.path.isfile(path):
+    try:
+        st = os.stat(path)
+    except OSError:
         return None
-    import json
-    with open(path) as fh:
-        man = json.load(fh)
-    if man.get("format") != 1:
-        raise ValueError(f"{path}: unknown manifest format {man.get('format')!r}")
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+    man = _MANIFEST_CACHE.get(key)
+    if man is None:
+        import json
+        with open(path) as fh:
+            man = json.load(fh)
+        if man.get("format") != 1:
+            raise ValueError(f"{path}: unknown manifest format {man.get('format')!r}")
+        for e in man["entries"]:
+            e["regions"] = np.ascontiguousarray(np.asarray(e["regions"], dtype=np.int64).reshape(-1, 2))
+        man["widths"] = set(int(w) for w in man["widths"])
+        if len(_MANIFEST_CACHE) >= 8:
+            _MANIFEST_CACHE.pop(next(iter(_MANIFEST_CACHE)))
+        _MANIFEST_CACHE[key] = man
     return man
 
 
@@ -920,14 +936,14 @@ def compute_results_from_manifest(motif: Motif, manifest: dict, debug: bool, arg
     """compute_results over what scan_graph described instead of wrote: every entry's graph (kept on the device between
     motifs) and regions through compute_results_from_graph -- the table GRAFIMO's compute_results would build from the TSV
     files of the same regions, without any of their rows existing anywhere."""
-    if int(motif.width) not in set(int(w) for w in manifest["widths"]):
+    if int(motif.width) not in manifest["widths"]:
         errmsg = "No result retrieved. Unable to proceed.\n"
         errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
         exception_handler(ValueError, errmsg, debug)
     graphs, regions, names = [], [], []
     for e in manifest["entries"]:
         graphs.append(cached_device_graph(e["index"]))
-        regions.append(np.asarray(e["regions"], dtype=np.int64).reshape(-1, 2))
+        regions.append(e["regions"])
         names.append(e["chrom"])
     return compute_results_from_graph(motif, graphs, regions, debug, args_obj, group=group, top_graphs=top_graphs,
                                       chrom_names=names)

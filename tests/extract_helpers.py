@@ -292,7 +292,11 @@ def oracle_table(tmpdir, chrom, ref, v, regions, motif, reuse_rows=False, **kw):
     `vg find -K W -E -H` from the walk enumerator (oracle/extract_oracle.py), written as the TSV files scan_graph leaves,
     read back, scored and filtered by oracle.compute_results (score_sequences.py:44-211, resultsTmp.py:241-314).
     kw: threshold, qval_t, no_qvalue, no_reverse, recomb.  `reuse_rows`: the files of the last call with these regions and
-    this width are still in tmpdir (the enumeration is the slow part).  -> (DataFrame, rows scanned)"""
+    this width are still in tmpdir (the enumeration is the slow part).  -> (DataFrame, rows scanned)
+    The two sums of compute_score_seq (score_sequences.py:390-391) are taken the way GRAFIMO as shipped takes them -- numba's
+    np.sum, a sequential loop (the oracle's sum_mode 1) -- not numpy's pairwise sums of the un-jitted function: the two differ
+    in the last bit, which decides one thing only: at the LOWEST reachable score the sequential tail sum equals the total
+    exactly (p = 1.0: not reported by `p < 1`, resultsTmp.py:303-307), the pairwise one gives 0.9999999999999999."""
     import pandas as pd
     from oracle import extract_oracle as xo
     from oracle import oracle as orc
@@ -310,7 +314,7 @@ def oracle_table(tmpdir, chrom, ref, v, regions, motif, reuse_rows=False, **kw):
                     fh.write("\t".join(str(x) for x in r) + "\t1+,\n")
     res = orc.compute_results(motif_as_oracle_dict(motif), str(tmpdir), threshold=kw.get("threshold", 1.0),
                               qval_t=kw.get("qval_t", False), no_qvalue=kw.get("no_qvalue", False),
-                              no_reverse=kw.get("no_reverse", False), recomb=kw.get("recomb", False))
+                              no_reverse=kw.get("no_reverse", False), recomb=kw.get("recomb", False), sum_mode=1)
     return pd.DataFrame({c: res[c] for c in res if not c.startswith("_")}), int(res["_scanned"])
 
 
