@@ -110,6 +110,8 @@ PROTOTYPES = {
                                      ctypes.c_char_p, ctypes.c_uint32, c_int, c_void_p, c_void_p, c_void_p]),
     "gfm_graph_score": (c_int, [c_void_p, c_void_p, c_i32, c_void_p, c_void_p, ctypes.c_uint32, c_i32, c_void_p, c_void_p, c_i64,
                                 c_void_p, c_void_p, c_void_p, P(c_i64), c_void_p]),
+    "gfm_graph_score_multi": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, ctypes.c_uint32, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, P(c_i64), c_void_p]),
     "gfm_graph_annotate": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfm_vcf_open": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_int, c_int, P(c_void_p), P(c_i64), P(c_i32),
                              P(c_i64)]),

@@ -24,7 +24,7 @@
 // strands (score_sequences.py:376-378).  Sums stay below 2^16 per half (<= 64 x 1000), and packed adds / subtracts are
 // exact modulo 2^32 as long as the final halves are, which they are: they are scores.
 
-struct FusedTab { unsigned v[GFM_MAX_WIDTH * 8]; };
+constexpr int kMaxMM = 3;     // motifs of ONE width that share an enumeration (gfm_graph_score_multi): tables, windows, hit lists x MM
 // an entry of the hit list (gfm_graph_entry_t, opaque to the caller): where the walk is -- tile of the call, window of
 // the tile (bits 56..63 of q2k), walk * 2 + strand (bits 0..55) -- and its scaled score
 struct GraphHit { int tile, score; long long q2k; };
@@ -32,11 +32,16 @@ constexpr int kHitWinShift = 56;
 constexpr long long kHitWalkMask = (1ll << kHitWinShift) - 1;
 struct Tile {
     long long p0, limit;      // first window start, end of the region (a walk must end inside it)
-    int n_win, region;        // windows p0 .. p0 + n_win - 1
+    int n_win, region;        // windows p0 .. p0 + (n_win & 0xff) - 1; n_win & kTilePure: see below
     int i_lo, i_hi;           // sites [i_lo, i_hi): pos >= p0 - 1 ... pos < p0 + n_win - 1 + W
     int w_base, i_far;        // index of the tile's first window among the call's windows; first site at or behind
                               // p0 + n_win - 1 + W + (the graph's longest deletion): what a one-deletion window's scan can reach
 };
+// The host marks the tiles whose windows can only meet substitution sites -- no insertion or deletion record in [i_lo, i_hi), no
+// deletion anchored before the tile that reaches into it, all of those records staged: four tiles in five of a 1000-Genomes-like
+// graph.  graph_score_kernel classifies their windows by ONE uniform loop over the tile's few sites (every lane counts the
+// sites before its window and multiplies the alleles of those inside) instead of a binary search and a site scan per lane.
+constexpr int kTilePure = 1 << 8;
 // a listed window for the deletion kernels: tile and window of the tile (k << 25 | tile: tiles < 2^25), its first site
 struct DelWin { int tile_k, i0; };
 constexpr int kDelTileBits = 25;
@@ -58,7 +63,7 @@ constexpr int kHeavyItemRounds = 64;
 constexpr unsigned kHeavyMaxChunks = 1u << 16;
 constexpr int kHeavyCap = 1 << 20;       // windows of one plan's heavy list (beyond it the plan is refused)
 #ifndef GFM_GRAPH_HEAVY_FLUSH_AT         // (a lab build with a small value exercises the flush without 2^41 walks)
-#define GFM_GRAPH_HEAVY_FLUSH_AT (1ull << 28)
+#define GFM_GRAPH_HEAVY_FLUSH_AT (1ull << 27)
 #endif
 constexpr unsigned long long kHeavyFlushAt = GFM_GRAPH_HEAVY_FLUSH_AT;   // scores a wavefront books between two flushes of the LDS window
 struct HitRec {               // what graph_annotate_kernel writes per hit (120 bytes; numpy dtype in extract_regions.py)
@@ -71,23 +76,27 @@ struct HitRec {               // what graph_annotate_kernel writes per hit (120 
 
 constexpr long long kFusedMaxWalks = 1ll << 40;      // per window; beyond it the product of allele counts is refused
 constexpr int kTileWin = 64;                         // windows per tile = lanes of the wavefront that works on it
-constexpr int kFusedWaves = 8;                       // wavefronts per workgroup of graph_score_kernel (they share the histogram)
-constexpr int kFusedThreads = kTileWin * kFusedWaves;
-constexpr int kWaveSites = 80;                       // site records staged per tile (more: read from global memory)
+constexpr int kFusedMaxWaves = 16;                   // wavefronts per workgroup of graph_score_kernel / graph_heavy_kernel (they share the histogram windows)
+constexpr int kWaveSites = 48;                       // site records staged per tile (more: read from global memory)
 constexpr int kWaveRefBytes = 144;                   // kTileWin + GFM_MAX_WIDTH - 1 reference bytes, in 8-byte loads
 constexpr int kFusedDelThreads = 64;
 constexpr int kFusedLayouts = 8;
 
 struct FusedArgs {
-    int W, forward_only;
-    int min_val, cutoff;          // cutoff: rows with score >= cutoff are hits (INT32_MAX: none)
-    int hlo, hnb;                 // LDS histogram window [hlo, hlo + hnb) + one bin for min_val; hnb = 0: no histogram
-    unsigned long long *hist;     // [L]: spill target of the window / where graph_score_del_kernel books; or nullptr
-    unsigned *slabs;              // [gridDim.x][hnb + 1]
-    GraphHit *hits;
-    long long hit_cap;
-    unsigned long long *hit_count, *n_rows;
+    int W, forward_only, n_motifs;
     int listing;                  // 1: listed windows are queued for the deletion kernels (first call of a plan); 0: that list exists
+    int min_val[kMaxMM], cutoff[kMaxMM];     // cutoff: rows with score >= cutoff are hits (INT32_MAX: none)
+    // per motif an LDS histogram window [hlo, hlo + hnb) + one bin for min_val, at counter `hoff` of the workgroup's windows
+    // (and of its slab row); hnb = 0: no histogram for that motif
+    int hlo[kMaxMM], hnb[kMaxMM], hoff[kMaxMM];
+    int slab_stride;              // counters per workgroup: sum over the motifs of hnb + 1 (0: no histogram at all)
+    unsigned long long *hist[kMaxMM];        // [L]: spill target of the window / where graph_del_score_kernel books; or nullptr
+    const unsigned *tab[kMaxMM];  // device: the motif's packed table [W][8] (gfm_motif_view_)
+    unsigned *slabs;              // [workgroups][slab_stride]
+    GraphHit *hits[kMaxMM];
+    long long hit_cap[kMaxMM];
+    unsigned long long *hit_count[kMaxMM];
+    unsigned long long *n_rows;   // rows scored PER MOTIF (every motif scores the same walks)
     const int *plan_overflow;     // a window of the plan's deletion list was refused (read when listing == 0)
 #ifdef GFM_LAB
     // LAB BUILDS ONLY (scripts/lab_build.sh -DGFM_LAB; never in libgrafimo_hip.so): per-phase timers and switches that turn
@@ -154,27 +163,28 @@ struct GlobalTileSites {      // the same interface straight from global memory 
 };
 
 // hits of one wave: one returning atomic per wave that holds any (a p < 1e-4 scan: a few hundred per plan)
-__device__ __forceinline__ void push_hits(const FusedArgs &a, bool hit, int tile, int k, long long q2, int score)
+__device__ __forceinline__ void push_hits(const FusedArgs &a, int m, bool hit, int tile, int k, long long q2, int score)
 {
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
     if (mask == 0ull) return;
     const int lane = threadIdx.x & 63;
     const int leader = __builtin_ctzll(mask);
     unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(a.hit_count, (unsigned long long)__popcll(mask));
+    if (lane == leader) base = atomicAdd(a.hit_count[m], (unsigned long long)__popcll(mask));
     base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader) << 32) | (unsigned)__shfl((int)(base & 0xffffffffull), leader);
     if (hit) {
         const unsigned long long at = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-        if (at < (unsigned long long)a.hit_cap) a.hits[at] = GraphHit{tile, score, q2 | ((long long)k << kHitWinShift)};
+        if (at < (unsigned long long)a.hit_cap[m]) a.hits[m][at] = GraphHit{tile, score, q2 | ((long long)k << kHitWinShift)};
     }
 }
 
-__device__ __forceinline__ void book_score(const FusedArgs &a, unsigned *h, int s)
+// h: the workgroup's LDS windows (all motifs); motif m's window starts at a.hoff[m], its min_val bin sits behind the window
+__device__ __forceinline__ void book_score(const FusedArgs &a, int m, unsigned *h, int s)
 {
-    const int d = s - a.hlo;
-    if ((unsigned)d < (unsigned)a.hnb) atomicAdd(&h[d], 1u);
-    else if (s == a.min_val) atomicAdd(&h[a.hnb], 1u);
-    else atomicAdd(&a.hist[s], 1ull);
+    const int d = s - a.hlo[m];
+    const bool inside = (unsigned)d < (unsigned)a.hnb[m];
+    if (inside || s == a.min_val[m]) atomicAdd(&h[a.hoff[m] + (inside ? d : a.hnb[m])], 1u);
+    else atomicAdd(&a.hist[m][s], 1ull);
 }
 
 // one window as phase 1 / the annotate kernel see it.  `listed`: the window touches an insertion or a deletion (the
@@ -258,52 +268,64 @@ __device__ __forceinline__ WinInfo classify_window(const GraphDev &g, const S &s
     return w;
 }
 
-// what one wavefront keeps in LDS: of the tile it works on, and the listed windows it has found and not yet handed on
+// what one wavefront keeps in LDS: of the tile it works on, and (first call of a plan) the listed windows it has found and
+// not yet handed on.  2.8 KB for one motif (round 4: 5.8 KB): with the 32 KB histogram window two workgroups of twelve or
+// sixteen wavefronts share a CU where two of eight did.
 constexpr int kWaveQueue = 96;
 constexpr int kOwnerSlots = 256;
-struct WaveLds {
+template <int MM, bool LISTING> struct WaveLdsT {
     SiteRec rec[kWaveSites];
-    long long incl[kTileWin], walks_a[kTileWin];
-    // per window, ONE 16-byte read in phase 2: .x the reference score (both strands packed), .y its first site, .z sites of
-    // layout A | layout B << 16, .w invalid bases of the reference window | layout A's walks << 8 | its first walk number
-    // << 16 (the last two only where the tile holds at most kOwnerSlots walks: else incl[] / walks_a[])
-    uint4 pack[kTileWin];
-    int bad_b[kTileWin], jx[kTileWin], del_len[kTileWin];
-    unsigned score_b[kTileWin];
     int reach[kWaveSites];
-    DelWin queue[kWaveQueue];
+    // per window, ONE 8-byte read in phase 2: .x = first site - i_lo | sites of layout A << 16 | of layout B << 24;
+    // .y = invalid bases of the reference window | layout A's walks << 7 | number of the window's first phase-2 walk << 14
+    uint2 winfo[kTileWin];
+    unsigned wsc[MM][kTileWin];           // the reference window's score per motif (both strands packed)
+    unsigned score_b[MM][kTileWin];       // one-deletion windows: the score of the walk that jumps, all else reference
+    unsigned sinfo[kTileWin];             // ... its invalid bases | the anchor's index in the window << 8 | deleted bases << 16
+    unsigned short incl[kTileWin];        // inclusive scan of the windows' phase-2 walks (<= 64 x 127)
+    unsigned char owner[kOwnerSlots];     // tiles of up to that many phase-2 walks: the window of walk number x (else: a search over incl[])
     unsigned char ref[kWaveRefBytes];
-    unsigned char owner[kOwnerSlots];     // tiles of up to that many walks: the window of walk number x (else: a search over incl[])
+    DelWin queue[LISTING ? kWaveQueue : 1];
 };
+__host__ __device__ constexpr int fused_tab_dwords(int MM, int W) { return (MM * W * 8 + 3) & ~3; }
 
 // Persistent grid; every WAVEFRONT works on tiles (64 consecutive window starts of one region) on its own -- no workgroup
-// barrier inside the loop, so the sixteen wavefronts of a CU are at sixteen different points of their tiles and cover
-// each other's latencies (a first version with a 256-window tile per workgroup and five barriers per tile took 163 us
-// for the bench's 3 million walks: every tile was a serial chain of ticket -> tile record -> staging loads -> phase 1 ->
-// scan -> phase 2).  Tiles are dealt round-robin over the wavefronts of the grid -- and NOTHING in the loop is an atomic
-// on one global word per tile: one word sustains ~88 atomics per microsecond, so a ticket per tile (34 000 of them) made
-// this kernel 469 us, and one append per tile to the list of listed windows would cost 110 us more.  Listed windows
-// are queued per wavefront in LDS and handed on 64 and more at a time; what is left at the end, and the row counts,
-// leave once per workgroup.  What the wavefronts of a workgroup share is the LDS table and the histogram window.
-__global__ void __launch_bounds__(kFusedThreads)
-graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__restrict__ tiles, int n_tiles,
+// barrier inside the loop, so the wavefronts of a CU are at different points of their tiles and cover each other's latencies
+// (a first version with a 256-window tile per workgroup and five barriers per tile took 163 us for the bench's 3 million
+// walks).  Tiles are dealt round-robin over the wavefronts of the grid -- and NOTHING in the loop is an atomic on one global
+// word per tile: one word sustains ~88 atomics per microsecond, so a ticket per tile (34 000 of them) made this kernel
+// 469 us.  Listed windows are queued per wavefront in LDS and handed on 64 and more at a time; what is left at the end, and
+// the row counts, leave once per workgroup.  What the wavefronts of a workgroup share is the LDS tables and the histogram
+// windows.  MM motifs of one width are scored over ONE enumeration: tables, windows and hit lists per motif, everything else --
+// staging, classification, the walks' digits -- once.
+// Per tile: phase 1, lane per window: first site, walks, the reference window's score; the reference walk (no alternate
+// allele: walk 0 of every window, two walks in three at 1000-Genomes density) is booked right there.  Phase 2, lane per walk
+// with an alternate allele: digits, the score adjusted per allele.
+template <int MM, bool LISTING>
+__global__ void __launch_bounds__(kFusedMaxWaves * 64)
+graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int n_tiles,
                    DelWin *__restrict__ del_wins, int *__restrict__ del_count, int *__restrict__ overflow,
                    HeavyWin *__restrict__ heavy_wins, unsigned long long *__restrict__ heavy_ctl, int *__restrict__ plan_overflow_w)
 {
+    using WL = WaveLdsT<MM, LISTING>;
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
-    unsigned *tab = reinterpret_cast<unsigned *>(fused_lds);
-    WaveLds *wl = reinterpret_cast<WaveLds *>(tab + GFM_MAX_WIDTH * 8) + (threadIdx.x >> 6);
-    unsigned long long *blk_rows = reinterpret_cast<unsigned long long *>(reinterpret_cast<WaveLds *>(tab + GFM_MAX_WIDTH * 8) + kFusedWaves);
-    int *blk_q = reinterpret_cast<int *>(blk_rows + kFusedWaves);         // [kFusedWaves] queue lengths, [kFusedWaves] = base
-    unsigned *h = reinterpret_cast<unsigned *>(blk_q + kFusedWaves + 2);
+    const int W = a.W, W8 = W * 8;
+    const int nw = (int)(blockDim.x >> 6), n_thr = (int)blockDim.x;
+    unsigned *tab = reinterpret_cast<unsigned *>(fused_lds);                  // [MM][W8]
+    WL *wl0 = reinterpret_cast<WL *>(tab + fused_tab_dwords(MM, W));
+    WL *wl = wl0 + (threadIdx.x >> 6);
+    unsigned long long *blk_rows = reinterpret_cast<unsigned long long *>(wl0 + nw);
+    int *blk_q = reinterpret_cast<int *>(blk_rows + nw);                      // [nw] queue lengths, [nw] = base
+    unsigned *h = reinterpret_cast<unsigned *>(blk_q + nw + 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = a.W;
-    for (int i = tid; i < W * 8; i += kFusedThreads) tab[i] = tab_arg.v[i];
-    for (int i = tid; i <= a.hnb && a.hnb > 0; i += kFusedThreads) h[i] = 0u;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+        for (int i = tid; i < W8; i += n_thr) tab[m * W8 + i] = a.tab[m][i];
+    for (int i = tid; i < a.slab_stride; i += n_thr) h[i] = 0u;
     __syncthreads();
     unsigned long long rows_done = 0;
     int q_n = 0;                                                   // listed windows in this wavefront's queue (uniform)
-    const int stride = (int)gridDim.x * kFusedWaves;
+    const int stride = (int)gridDim.x * nw;
     unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, acc_n = 0;   // measurement aid: this wavefront's ticks per phase
     auto lap = [&](int slot, unsigned long long &t0) {
         if (!GFM_DBG(a)) return;
@@ -314,16 +336,19 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
     // what the NEXT tile needs from global memory is requested before the current one is worked on and sits in
     // registers meanwhile: the two dependent round trips per tile (its record; its sites and bases) were 60 % of a
     // tile's time when every tile began with them
-    struct TilePf { SiteRec r0, r1; int reach0, reach1; unsigned long long refw; };
-    auto reach_of = [&](const Tile &t, int i) -> int {
-        const long long r = (i <= g.n_sites ? g.max_reach[i] : -1ll) - t.p0;
-        return (int)max(-1ll, min(r, 0x7fffffffll));
-    };
+    static_assert(kWaveSites <= 64, "one staged record per lane");
+    struct TilePf { SiteRec r0; int reach0; unsigned long long refw; };
     auto issue = [&](const Tile &t) {
         TilePf f{};
         const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);     // (+1: the record that ends a window's site scan)
-        if (lane < staged) { f.r0 = packed_site(g, t.i_lo + lane); f.reach0 = reach_of(t, t.i_lo + lane); }
-        if (lane + 64 < staged) { f.r1 = packed_site(g, t.i_lo + lane + 64); f.reach1 = reach_of(t, t.i_lo + lane + 64); }
+        if (lane < staged) {
+            f.r0 = packed_site(g, t.i_lo + lane);
+            if (g.n_dels > 0 && !(t.n_win & kTilePure)) {
+                const int i = t.i_lo + lane;
+                const long long r = (i <= g.n_sites ? g.max_reach[i] : -1ll) - t.p0;
+                f.reach0 = (int)max(-1ll, min(r, 0x7fffffffll));
+            }
+        }
         if (lane < kWaveRefBytes / 8) {
             const long long at = t.p0 + 8 * lane;
             unsigned long long v = 0x4e4e4e4e4e4e4e4eull;                      // 'N's behind the reference's end
@@ -338,10 +363,9 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
     auto commit = [&](const Tile &t, const TilePf &f) {
         const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);
         if (lane < staged) { wl->rec[lane] = f.r0; wl->reach[lane] = f.reach0; }
-        if (lane + 64 < staged) { wl->rec[lane + 64] = f.r1; wl->reach[lane + 64] = f.reach1; }
         if (lane < kWaveRefBytes / 8) *reinterpret_cast<unsigned long long *>(wl->ref + 8 * lane) = f.refw;
     };
-    int ti = (int)blockIdx.x * kFusedWaves + wave;
+    int ti = (int)blockIdx.x * nw + wave;
     // The record of the tile after next travels as a VECTOR load, a dword per lane, and is put together from the lanes when
     // it is needed: as the scalar load the compiler makes of `tiles[uniform index]` it shares its counter with the LDS
     // reads, and the first LDS read of a tile waited for it (scalar loads return out of order: lgkmcnt(0)).
@@ -379,44 +403,73 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
             if (ti + 2 * stride < n_tiles) nxt_dw = tile_ask(ti + 2 * stride);
         }
         const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);
+        const int n_win = t.n_win & 0xff;
         lap(0, tk0);                   // 8: the staged data into LDS, the next tile's loads issued
-        // The tile's work exists TWICE: for tiles whose sites are all staged (nearly every tile) with a site accessor that
-        // cannot read global memory, and for the others with the one that can.  With one body the value of `sites.at(i)` is a
-        // merge of an LDS read and a global load, and where it is used the compiler must wait for "the load" -- vmcnt(0),
-        // in order: for the NEXT tile's staging loads issued a moment ago, every tile, whichever branch ran.  That wait was
-        // 14 of the kernel's 77 us.
-        auto work = [&](const auto &sites) {
+        // The tile's work exists THREE times: for pure tiles (substitution sites only: the uniform site loop), for the other
+        // tiles whose sites are all staged, with a site accessor that cannot read global memory, and for the rest with the one
+        // that can.  With one body the value of `sites.at(i)` is a merge of an LDS read and a global load, and where it is used
+        // the compiler must wait for "the load" -- vmcnt(0), in order: for the NEXT tile's staging loads issued a moment ago,
+        // every tile, whichever branch ran.  That wait was 14 of the kernel's 77 us.
+        auto work = [&](const auto &sites, auto pure_tag) {
+        constexpr bool PURE = decltype(pure_tag)::value;
         // ---- phase 1: lane per window
         auto ref_at = [&](long long x) -> unsigned {             // a reference base: from the staged bytes if it lies there
             const long long d = x - t.p0;
             return (unsigned long long)d < (unsigned long long)kWaveRefBytes ? (unsigned)wl->ref[d]
                                                                             : (x < g.ref_len ? (unsigned)g.ref[x] : (unsigned)'N');
         };
-        long long walks = 0;
-        bool listed = false;
-        WinInfo wi{0, 0, 0, false, false, 0, 0, 0, 0};
         const long long p = t.p0 + lane;
-        if (lane < t.n_win && GFM_LAB_BIT(a, 4)) wi.walks = 1;
-        if (lane < t.n_win && !GFM_LAB_BIT(a, 4)) {
-            wi = classify_window(g, sites, p, W, t.limit, t.i_lo, t.i_hi);
+        bool listed = false;
+        int i0 = t.i_lo, ns = 0, ns_b = 0, jx = 0, dlen = 0;
+        int walks_a = 0, walks_b = 0;          // walks of this window that this kernel scores (<= 64 in all)
+        // more walks than a round or so: not this wavefront's business.  The window's layouts -- the one of a plain window,
+        // the two of a one-deletion window -- go to graph_heavy_kernel (walks shared out over the grid, a table of per-site
+        // score differences instead of this kernel's chain of LDS reads per site).
+        auto to_heavy = [&](long long n_walks, long long q_base, int ns_, int jx_, int del_len_) {
+            if (!a.listing) return;
+            const long long rounds = (n_walks + 63) >> 6;
+            const unsigned n_chunks = (unsigned)min((long long)kHeavyMaxChunks, (rounds + kHeavyItemRounds - 1) / kHeavyItemRounds);
+            const unsigned long long got = atomicAdd(heavy_ctl, (1ull << 32) | (unsigned long long)n_chunks);
+            const unsigned slot = (unsigned)(got >> 32), base = (unsigned)(got & 0xffffffffull);
+            if (slot < (unsigned)kHeavyCap && (unsigned long long)base + n_chunks < 0xffffffffull) {
+                heavy_wins[slot] = HeavyWin{ti | (lane << kDelTileBits), i0, ns_, base, n_chunks,
+                                            (unsigned)((rounds + n_chunks - 1) / n_chunks), n_walks, q_base, jx_, del_len_};
+            } else {
+                atomicMax(overflow, 1);
+                atomicMax(plan_overflow_w, 1);
+            }
+        };
+        if constexpr (PURE) {
+            // every site of the tile is a substitution site and sits in LDS: one uniform loop, the records read as broadcasts
+            const int pi = (int)p, n_t = t.i_hi - t.i_lo;
+            int before = 0, inside = 0;
+            unsigned long long prod = 1;
+            for (int s = 0; s < n_t; ++s) {
+                const int spos = __builtin_amdgcn_readfirstlane(wl->rec[s].pos);
+                const int na = __builtin_amdgcn_readfirstlane(wl->rec[s].n_alts) & 3;
+                const bool bef = spos < pi, in = !bef && spos < pi + W;
+                before += bef ? 1 : 0;
+                inside += in ? 1 : 0;
+                if (in && prod <= (unsigned long long)kFusedMaxWalks) prod *= (unsigned long long)(1 + na);   // (saturates above 2^40)
+            }
+            if (lane < n_win && !GFM_LAB_BIT(a, 4)) {
+                i0 = t.i_lo + before;
+                ns = inside;
+                long long wlk = (p + W <= t.limit && p + W <= g.ref_len) ? (long long)prod : 0ll;
+                if (wlk > kFusedMaxWalks) { atomicMax(overflow, 1); wlk = 0; }       // refused: more than 2^40 walks
+                else if (wlk > kHeavyWalks) { to_heavy(wlk, 0, ns, 0, 0); wlk = 0; }  // (ns <= W <= 64: one substitution site per position)
+                walks_a = (int)wlk;
+            }
+        } else if (lane < n_win && !GFM_LAB_BIT(a, 4)) {
+            WinInfo wi = classify_window(g, sites, p, W, t.limit, t.i_lo, t.i_hi);
             if (wi.walks < 0) { atomicMax(overflow, 1); wi.walks = 0; }
-            // more walks than a round or so: not this wavefront's business.  The window's layouts -- the one of a plain window,
-            // the two of a one-deletion window -- go to graph_heavy_kernel (walks shared out over the grid, a table of per-site
-            // score differences instead of this kernel's chain of LDS reads per site).
-            auto to_heavy = [&](long long n_walks, long long q_base, int ns, int jx, int del_len) {
-                if (!a.listing) return;
-                const long long rounds = (n_walks + 63) >> 6;
-                const unsigned n_chunks = (unsigned)min((long long)kHeavyMaxChunks, (rounds + kHeavyItemRounds - 1) / kHeavyItemRounds);
-                const unsigned long long got = atomicAdd(heavy_ctl, (1ull << 32) | (unsigned long long)n_chunks);
-                const unsigned slot = (unsigned)(got >> 32), base = (unsigned)(got & 0xffffffffull);
-                if (slot < (unsigned)kHeavyCap && (unsigned long long)base + n_chunks < 0xffffffffull) {
-                    heavy_wins[slot] = HeavyWin{ti | (lane << kDelTileBits), wi.i0, ns, base, n_chunks,
-                                                (unsigned)((rounds + n_chunks - 1) / n_chunks), n_walks, q_base, jx, del_len};
-                } else {
-                    atomicMax(overflow, 1);
-                    atomicMax(plan_overflow_w, 1);
-                }
-            };
+            i0 = wi.i0;
+            if (wi.simple && (wi.ns_b > 255 || wi.del_len > 0xffff)) {     // (what the window's LDS record cannot hold:
+                wi.simple = false;                                           //  the way of the other listed windows)
+                wi.walks = 0;
+                wi.walks_b = 0;
+            }
+            if (wi.i0 - t.i_lo > 0xffff) { atomicMax(overflow, 1); wi.walks = 0; wi.walks_b = 0; wi.listed = wi.simple = false; }
             const bool many = wi.walks + wi.walks_b > kHeavyWalks;
             if (wi.simple && many) {
                 if (wi.ns <= 64 && wi.ns_b <= 64) {          // both layouts to graph_heavy_kernel (a lane per site record there)
@@ -434,45 +487,67 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 to_heavy(wi.walks, 0, wi.ns, 0, 0);
                 wi.walks = 0;
             }
-            walks = wi.walks + wi.walks_b;
+            ns = wi.ns; ns_b = wi.ns_b; jx = wi.jx; dlen = wi.del_len;
+            walks_a = (int)wi.walks;
+            walks_b = (int)wi.walks_b;
         }
+        if (GFM_LAB_BIT(a, 4) && lane < n_win) walks_a = 1;
         lap(1, tk0);                   // 9: classify
-        if (lane < t.n_win && GFM_LAB_BIT(a, 4)) walks = 1;
-        unsigned sc_a = 0;
+        unsigned sc_a[MM];
+#pragma unroll
+        for (int m = 0; m < MM; ++m) sc_a[m] = 0u;
         int bad_a = 0;
-        if (lane < t.n_win) {
-            if (wi.walks > 0 && !GFM_LAB_BIT(a, 2)) {                // the reference window's score on both strands
-                unsigned sum = 0;
+        if (lane < n_win) {
+            if (walks_a > 0 && !GFM_LAB_BIT(a, 2)) {           // the reference window's score on both strands
                 int bad = 0;
                 for (int j = 0; j < W; ++j) {
                     const unsigned c = base_code(wl->ref[lane + j]);
-                    sum += tab[j * 8 + c];
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) sc_a[m] += tab[m * W8 + j * 8 + c];
                     bad += (int)(c >> 2);
                 }
-                sc_a = sum;
                 bad_a = bad;
             }
-            if (wi.walks_b > 0) {              // ... and the one of the walk that jumps the deletion
-                unsigned sum = 0;
+            if (walks_b > 0) {              // ... and the one of the walk that jumps the deletion
+                unsigned sum[MM];
+#pragma unroll
+                for (int m = 0; m < MM; ++m) sum[m] = 0u;
                 int bad = 0;
                 for (int j = 0; j < W; ++j) {
-                    const unsigned c = base_code(ref_at(p + j + (j > wi.jx ? wi.del_len : 0)));
-                    sum += tab[j * 8 + c];
+                    const unsigned c = base_code(ref_at(p + j + (j > jx ? dlen : 0)));
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) sum[m] += tab[m * W8 + j * 8 + c];
                     bad += (int)(c >> 2);
                 }
-                wl->score_b[lane] = sum;
-                wl->bad_b[lane] = bad;
+#pragma unroll
+                for (int m = 0; m < MM; ++m) wl->score_b[m][lane] = sum[m];
+                wl->sinfo[lane] = (unsigned)bad | ((unsigned)jx << 8) | ((unsigned)dlen << 16);
             }
-            wl->walks_a[lane] = wi.walks;
-            wl->jx[lane] = wi.jx;
-            wl->del_len[lane] = wi.del_len;
         }
         lap(2, tk0);                  // 10: base scores
-        // listed windows -> this wavefront's queue; 64 and more of them go to graph_score_del_kernel's list at once
+        // the reference walk of every window that has one: booked here, a lane per window
         {
-            const unsigned long long lm = a.listing ? __builtin_amdgcn_ballot_w64(listed) : 0ull;
+            const bool has_ref = walks_a > 0;
+            if (!GFM_LAB_BIT(a, 8)) {
+#pragma unroll
+                for (int m = 0; m < MM; ++m) {
+                    const int s_f = bad_a ? a.min_val[m] : (int)(sc_a[m] & 0xffffu);
+                    const int s_r = bad_a ? a.min_val[m] : (int)(sc_a[m] >> 16);
+                    if (has_ref && a.hnb[m] > 0) {
+                        book_score(a, m, h, s_f);
+                        if (!a.forward_only) book_score(a, m, h, s_r);
+                    }
+                    push_hits(a, m, has_ref && s_f >= a.cutoff[m], ti, lane, 0, s_f);
+                    if (!a.forward_only) push_hits(a, m, has_ref && s_r >= a.cutoff[m], ti, lane, 1, s_r);
+                }
+            }
+            rows_done += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(has_ref)) * (a.forward_only ? 1ull : 2ull);
+        }
+        // listed windows -> this wavefront's queue; 64 and more of them go to graph_score_del_kernel's list at once
+        if constexpr (LISTING) {
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(listed);
             if (lm) {
-                if (listed) wl->queue[q_n + __popcll(lm & ((1ull << lane) - 1ull))] = DelWin{ti | (lane << kDelTileBits), wi.i0};
+                if (listed) wl->queue[q_n + __popcll(lm & ((1ull << lane) - 1ull))] = DelWin{ti | (lane << kDelTileBits), i0};
                 q_n += __popcll(lm);
                 if (q_n >= kWaveQueue - kTileWin) {
                     int base = 0;
@@ -484,32 +559,41 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 }
             }
         }
-        // inclusive scan of the walk counts over the wave
-        long long incl = walks;
+        // the walks left for phase 2: layout A's with an alternate allele somewhere, all of layout B's.  Inclusive scan.
+        const int nA = walks_a > 0 ? walks_a - 1 : 0;
+        const int v_w = nA + walks_b;
+        int incl = v_w;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const int lo_ = __shfl_up((int)(incl & 0xffffffffll), d), hi_ = __shfl_up((int)(incl >> 32), d);
-            if (lane >= d) incl += ((long long)hi_ << 32) | (unsigned)lo_;
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
         }
-        wl->incl[lane] = incl;
-        long long total = ((long long)__shfl((int)(incl >> 32), 63) << 32) | (unsigned)__shfl((int)(incl & 0xffffffffll), 63);
+        int total = __shfl(incl, 63);
         if (GFM_LAB_BIT(a, 1)) total = 0;
-        // the usual tile holds a hundred walks: every window writes its index over its walks' slots, and phase 2 reads a
-        // walk's window with ONE LDS access instead of a six-step search through incl[]
-        const bool owners = total < kOwnerSlots;          // (below it: a window's walks fit the record's eight bits)
-        if (owners)
-            for (int x = (int)(incl - walks); x < (int)incl; ++x) wl->owner[x] = (unsigned char)lane;
-        wl->pack[lane] = uint4{sc_a, (unsigned)wi.i0, (unsigned)(wi.ns | (wi.ns_b << 16)),
-                               (unsigned)bad_a | ((unsigned)min(wi.walks, 255ll) << 8) | (((unsigned)(incl - walks) & 0xffffu) << 16)};
+        // the usual tile holds a few dozen such walks: every window writes its index over its walks' slots, and phase 2
+        // reads a walk's window with ONE LDS access instead of a six-step search through incl[]
+        const bool owners = total < kOwnerSlots;
+        if (total > 0) {
+            wl->incl[lane] = (unsigned short)incl;
+            if (owners)
+                for (int x = incl - v_w; x < incl; ++x) wl->owner[x] = (unsigned char)lane;
+            wl->winfo[lane] = uint2{(unsigned)(i0 - t.i_lo) | ((unsigned)ns << 16) | ((unsigned)ns_b << 24),
+                                    (unsigned)bad_a | ((unsigned)walks_a << 7) | ((unsigned)(incl - v_w) << 14)};
+#pragma unroll
+            for (int m = 0; m < MM; ++m) wl->wsc[m][lane] = sc_a[m];
+        }
         __builtin_amdgcn_wave_barrier();
-        lap(3, tk0);                  // 11: listing + scan
+        lap(3, tk0);                  // 11: reference walks + listing + scan
         // ---- phase 2: lane per walk
-        for (long long base = 0; base < total; base += 64) {
-            const long long wt = base + lane;
+        for (int base = 0; base < total; base += 64) {
+            const int wt = base + lane;
             const bool live = wt < total;
             int k = 0;
             long long q = 0;
-            int s_f = 0, s_r = 0;
+            unsigned sum[MM];
+#pragma unroll
+            for (int m = 0; m < MM; ++m) sum[m] = 0u;
+            int bad = 0;
             if (live) {
                 if (owners) {
                     k = wl->owner[wt];
@@ -517,47 +601,46 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                     int lo = 0, hi = kTileWin - 1;             // first window whose inclusive count exceeds wt
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
-                        if (wl->incl[mid] > wt) hi = mid; else lo = mid + 1;
+                        if ((int)wl->incl[mid] > wt) hi = mid; else lo = mid + 1;
                     }
                     k = lo;
                 }
-                const uint4 pw = wl->pack[k];
-                long long wa;
-                if (owners) {
-                    q = wt - (long long)(pw.w >> 16);
-                    wa = (long long)((pw.w >> 8) & 0xffu);
-                } else {
-                    q = wt - (k ? wl->incl[k - 1] : 0ll);
-                    wa = wl->walks_a[k];
-                }
-                const bool jump = q >= wa;                        // layout B of a one-deletion window
-                const int i0 = (int)pw.y, nsx = (int)pw.z;
-                unsigned sum;
-                int bad;
+                const uint2 pw = wl->winfo[k];
+                const int qq = wt - (int)(pw.y >> 14);            // number among the window's phase-2 walks
+                const int wa = (int)((pw.y >> 7) & 0x7fu);
+                const int nA_k = wa > 0 ? wa - 1 : 0;
+                const bool jump = qq >= nA_k;                     // layout B of a one-deletion window
+                const int i0k = t.i_lo + (int)(pw.x & 0xffffu);
                 if (!jump) {                                      // the common case: positions p .. p + W - 1
-                    sum = pw.x;
-                    bad = (int)(pw.w & 0xffu);
+                    q = qq + 1;
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) sum[m] = wl->wsc[m][k];
+                    bad = (int)(pw.y & 0x7fu);
                     unsigned long long rest = (unsigned long long)q;
                     const int pk = (int)(t.p0 + k);
-                    for (int s = (nsx & 0xffff) - 1; s >= 0 && rest; --s) {        // digits, last site first
-                        const SiteRec r = sites.at(i0 + s);
+                    for (int s = (int)((pw.x >> 16) & 0xffu) - 1; s >= 0 && rest; --s) {        // digits, last site first
+                        const SiteRec r = sites.at(i0k + s);
                         const int nall = (r.del_len | r.ins_len) ? 1 : 1 + (r.n_alts & 3);     // (a one-deletion window's own record)
                         const int al = take_digit(rest, nall);
                         if (al) {
                             const int j = r.pos - pk;
                             const unsigned cr = base_code(wl->ref[k + j]), ca = base_code((unsigned)r.n_alts >> (8 * al));
-                            sum += tab[j * 8 + ca] - tab[j * 8 + cr];
+#pragma unroll
+                            for (int m = 0; m < MM; ++m) sum[m] += tab[m * W8 + j * 8 + ca] - tab[m * W8 + j * 8 + cr];
                             bad += (int)(ca >> 2) - (int)(cr >> 2);
                         }
                     }
                 } else {
-                    sum = wl->score_b[k];
-                    bad = wl->bad_b[k];
-                    unsigned long long rest = (unsigned long long)(q - wa);
+                    q = (long long)wa + (qq - nA_k);
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) sum[m] = wl->score_b[m][k];
+                    const unsigned si = wl->sinfo[k];
+                    bad = (int)(si & 0xffu);
+                    unsigned long long rest = (unsigned long long)(qq - nA_k);
                     const long long pk = t.p0 + k;
-                    const long long x = pk + wl->jx[k], len = wl->del_len[k];
-                    for (int s = (nsx >> 16) - 1; s >= 0 && rest; --s) {
-                        const SiteRec r = sites.at(i0 + s);
+                    const long long x = pk + (long long)((si >> 8) & 0xffu), len = (long long)(si >> 16);
+                    for (int s = (int)(pw.x >> 24) - 1; s >= 0 && rest; --s) {
+                        const SiteRec r = sites.at(i0k + s);
                         if (r.del_len | r.ins_len) continue;      // (the deletion's own record)
                         if (r.pos > x && r.pos <= x + len) continue;
                         const int nall = 1 + (r.n_alts & 3);
@@ -565,26 +648,31 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                         if (al) {
                             const int j = (int)(r.pos - pk) - (r.pos > x ? (int)len : 0);
                             const unsigned cr = base_code(ref_at(r.pos)), ca = base_code((unsigned)r.n_alts >> (8 * al));
-                            sum += tab[j * 8 + ca] - tab[j * 8 + cr];
+#pragma unroll
+                            for (int m = 0; m < MM; ++m) sum[m] += tab[m * W8 + j * 8 + ca] - tab[m * W8 + j * 8 + cr];
                             bad += (int)(ca >> 2) - (int)(cr >> 2);
                         }
                     }
                 }
-                s_f = bad ? a.min_val : (int)(sum & 0xffffu);
-                s_r = bad ? a.min_val : (int)(sum >> 16);
-                if (a.hnb > 0 && !GFM_LAB_BIT(a, 8)) {
-                    book_score(a, h, s_f);
-                    if (!a.forward_only) book_score(a, h, s_r);
-                }
             }
             if (GFM_LAB_BIT(a, 8)) continue;
-            push_hits(a, live && s_f >= a.cutoff, ti, k, 2 * q, s_f);
-            if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, ti, k, 2 * q + 1, s_r);
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                const int s_f = bad ? a.min_val[m] : (int)(sum[m] & 0xffffu);
+                const int s_r = bad ? a.min_val[m] : (int)(sum[m] >> 16);
+                if (live && a.hnb[m] > 0) {
+                    book_score(a, m, h, s_f);
+                    if (!a.forward_only) book_score(a, m, h, s_r);
+                }
+                push_hits(a, m, live && s_f >= a.cutoff[m], ti, k, 2 * q, s_f);
+                if (!a.forward_only) push_hits(a, m, live && s_r >= a.cutoff[m], ti, k, 2 * q + 1, s_r);
+            }
         }
         rows_done += (unsigned long long)total * (a.forward_only ? 1ull : 2ull);
         };
-        if (t.i_far - t.i_lo + 1 <= kWaveSites) work(LdsTileSites{wl->rec, wl->reach, t.p0, t.i_lo});
-        else work(TileSites{g, wl->rec, wl->reach, t.p0, t.i_lo, staged});
+        if (t.n_win & kTilePure) work(LdsTileSites{wl->rec, wl->reach, t.p0, t.i_lo}, std::true_type{});
+        else if (t.i_far - t.i_lo + 1 <= kWaveSites) work(LdsTileSites{wl->rec, wl->reach, t.p0, t.i_lo}, std::false_type{});
+        else work(TileSites{g, wl->rec, wl->reach, t.p0, t.i_lo, staged}, std::false_type{});
         __builtin_amdgcn_wave_barrier();       // the tile's LDS is free again
         lap(4, tk0);                  // 12: phase 2
         lap(5, tk_tile);                       // 13: the whole tile
@@ -603,18 +691,17 @@ graph_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
         if (!a.listing && blockIdx.x == 0 && *a.plan_overflow) atomicMax(overflow, 1);
         unsigned long long rows = 0;
         int left = 0;
-        for (int k = 0; k < kFusedWaves; ++k) { rows += blk_rows[k]; left += blk_q[k]; }
+        for (int k = 0; k < nw; ++k) { rows += blk_rows[k]; left += blk_q[k]; }
         if (rows) atomicAdd(a.n_rows, rows);
-        blk_q[kFusedWaves] = left ? atomicAdd(del_count, left) : 0;
+        blk_q[nw] = left ? atomicAdd(del_count, left) : 0;
     }
     __syncthreads();
-    {
-        int at = blk_q[kFusedWaves];
+    if constexpr (LISTING) {
+        int at = blk_q[nw];
         for (int k = 0; k < wave; ++k) at += blk_q[k];
         for (int i = lane; i < q_n; i += 64) del_wins[at + i] = wl->queue[i];
     }
-    if (a.hnb > 0)
-        for (int i = tid; i <= a.hnb; i += kFusedThreads) a.slabs[(size_t)blockIdx.x * (a.hnb + 1) + i] = h[i];
+    for (int i = tid; i < a.slab_stride; i += n_thr) a.slabs[(size_t)blockIdx.x * a.slab_stride + i] = h[i];
 }
 
 // visitor of simulate(): the bases of a walk into a k-mer slot (alternate / inserted bases at once, reference bases
@@ -735,16 +822,17 @@ graph_del_count_kernel(GraphDev g, int W, const Tile *__restrict__ tiles, const 
     }
 }
 
+template <int MM>
 __global__ void __launch_bounds__(kFusedDelThreads)
-graph_del_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__restrict__ tiles,
+graph_del_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles,
                        const DelWin *__restrict__ del_wins, const int *__restrict__ del_count,
                        const DelBatchRec *__restrict__ recs, const DelItem *__restrict__ items,
                        const int *__restrict__ item_count, int pitch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
     constexpr int T = kFusedDelThreads;
-    unsigned *tab = reinterpret_cast<unsigned *>(fused_lds);
-    SiteRec *cache = reinterpret_cast<SiteRec *>(tab + GFM_MAX_WIDTH * 8);                 // [kSiteCache][T]
+    unsigned *tab = reinterpret_cast<unsigned *>(fused_lds);                               // [MM][W * 8]
+    SiteRec *cache = reinterpret_cast<SiteRec *>(tab + fused_tab_dwords(MM, a.W));         // [kSiteCache][T]
     LayoutRec *lay = reinterpret_cast<LayoutRec *>(cache + kSiteCache * T);                // [T][kFusedLayouts]
     long long *w_incl = reinterpret_cast<long long *>(lay + T * kFusedLayouts);            // [T]
     long long *w_p = w_incl + T;                                                           // [T] window starts
@@ -754,8 +842,10 @@ graph_del_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__
     int *src = w_tk + T;                                                                   // [T][W]
     unsigned char *slots = reinterpret_cast<unsigned char *>(src + (size_t)T * a.W);       // [T][pitch]
     const int lane = threadIdx.x;
-    const int W = a.W;
-    for (int i = lane; i < W * 8; i += T) tab[i] = tab_arg.v[i];
+    const int W = a.W, W8 = W * 8;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+        for (int i = lane; i < W8; i += T) tab[m * W8 + i] = a.tab[m][i];
     const int n_items = *item_count, n_listed = *del_count;
     unsigned long long rows_done = 0;
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
@@ -790,7 +880,9 @@ graph_del_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__
         for (long long round = r0; round < r1; ++round) {
             const long long wt = round * T + lane;
             const bool live = wt < total;
-            int s_f = 0, s_r = 0, tk = 0;
+            int s_f[MM], s_r[MM], tk = 0;
+#pragma unroll
+            for (int m = 0; m < MM; ++m) s_f[m] = s_r[m] = 0;
             long long q0 = 0;
             if (live) {
                 int lo = 0, hi = T - 1;
@@ -861,26 +953,35 @@ graph_del_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__
                         for (int u = 0; u < 8; ++u)
                             if (sx[u] >= 0) slot[j0 + u] = c[u];
                     }
-                    unsigned sum = 0;
+                    unsigned sum[MM];
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) sum[m] = 0u;
                     int bad = 0;
                     for (int j = 0; j < W; ++j) {
                         const unsigned c = base_code(slot[j]);
-                        sum += tab[j * 8 + c];
+#pragma unroll
+                        for (int m = 0; m < MM; ++m) sum[m] += tab[m * W8 + j * 8 + c];
                         bad += (int)(c >> 2);
                     }
-                    s_f = bad ? a.min_val : (int)(sum & 0xffffu);
-                    s_r = bad ? a.min_val : (int)(sum >> 16);
                     dbg_tick(a, 3, tk0);       // 3: reference bytes + scoring
-                    if (a.hist) {
-                        atomicAdd(&a.hist[s_f], 1ull);
-                        if (!a.forward_only) atomicAdd(&a.hist[s_r], 1ull);
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) {
+                        s_f[m] = bad ? a.min_val[m] : (int)(sum[m] & 0xffffu);
+                        s_r[m] = bad ? a.min_val[m] : (int)(sum[m] >> 16);
+                        if (a.hist[m]) {
+                            atomicAdd(&a.hist[m][s_f[m]], 1ull);
+                            if (!a.forward_only) atomicAdd(&a.hist[m][s_r[m]], 1ull);
+                        }
                     }
                 }
             }
             dbg_tick(a, 4, tk0);               // 4: histogram atomics, reconvergence
             const int w_tile = tk & ((1 << kDelTileBits) - 1), w_k = (int)((unsigned)tk >> kDelTileBits);
-            push_hits(a, live && s_f >= a.cutoff, w_tile, w_k, 2 * q0, s_f);
-            if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, w_tile, w_k, 2 * q0 + 1, s_r);
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                push_hits(a, m, live && s_f[m] >= a.cutoff[m], w_tile, w_k, 2 * q0, s_f[m]);
+                if (!a.forward_only) push_hits(a, m, live && s_r[m] >= a.cutoff[m], w_tile, w_k, 2 * q0 + 1, s_r[m]);
+            }
         }
         if (lane == 0 && r1 > r0) rows_done += (unsigned long long)(min(total, r1 * T) - r0 * T) * (a.forward_only ? 1ull : 2ull);
         dbg_tick(a, 5, tk0);                   // 5: hits
@@ -897,45 +998,51 @@ graph_del_score_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__
 // mixed-radix digits, last site first, one LDS read per site.  A window of 2^24 walks took one wavefront of
 // graph_score_kernel 5 s (12 us a round: per site a chain of four dependent LDS reads); here its 262 144 rounds are 4 096
 // items over the whole grid.
-struct HeavyLds {
-    unsigned delta[64 * 4];
+template <int MM> struct HeavyLdsT {
+    unsigned delta[MM][64 * 4];
     signed char dbad[64 * 4];
     unsigned char nall[64];
 };
-static_assert(sizeof(HeavyLds) <= sizeof(WaveLds), "graph_heavy_kernel reuses graph_score_kernel's per-wave LDS");
 
-__global__ void __launch_bounds__(kFusedThreads)
-graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__restrict__ tiles,
+template <int MM>
+__global__ void __launch_bounds__(kFusedMaxWaves * 64)
+graph_heavy_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles,
                    const HeavyWin *__restrict__ wins, const unsigned long long *__restrict__ ctl, int main_blocks)
 {
     const unsigned long long c = *ctl;
     const unsigned n_wins = (unsigned)min((unsigned long long)kHeavyCap, c >> 32), n_items = (unsigned)(c & 0xffffffffull);
+    const int n_thr = (int)blockDim.x, nw = n_thr >> 6;
     if (n_items == 0u || n_wins == 0u) {
         // nothing heavy in this plan (the host launches this kernel until it has learnt that).  The slab rows behind
         // graph_score_kernel's own must still read as zeros to the reduction that follows.
-        if ((int)blockIdx.x >= main_blocks && a.hnb > 0)
-            for (int i = threadIdx.x; i <= a.hnb; i += kFusedThreads) a.slabs[(size_t)blockIdx.x * (a.hnb + 1) + i] = 0u;
+        if ((int)blockIdx.x >= main_blocks)
+            for (int i = threadIdx.x; i < a.slab_stride; i += n_thr) a.slabs[(size_t)blockIdx.x * a.slab_stride + i] = 0u;
         return;
     }
+    using HL = HeavyLdsT<MM>;
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+    const int W = a.W, W8 = W * 8;
     unsigned *tab = reinterpret_cast<unsigned *>(fused_lds);
-    HeavyLds *hl = reinterpret_cast<HeavyLds *>(reinterpret_cast<WaveLds *>(tab + GFM_MAX_WIDTH * 8) + (threadIdx.x >> 6));
-    unsigned long long *blk_rows = reinterpret_cast<unsigned long long *>(reinterpret_cast<WaveLds *>(tab + GFM_MAX_WIDTH * 8) + kFusedWaves);
-    int *blk_q = reinterpret_cast<int *>(blk_rows + kFusedWaves);
-    unsigned *h = reinterpret_cast<unsigned *>(blk_q + kFusedWaves + 2);
+    HL *hl0 = reinterpret_cast<HL *>(tab + fused_tab_dwords(MM, W));
+    HL *hl = hl0 + (threadIdx.x >> 6);
+    unsigned long long *blk_rows = reinterpret_cast<unsigned long long *>(hl0 + nw);
+    unsigned *h = reinterpret_cast<unsigned *>(blk_rows + nw);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int W = a.W;
-    for (int i = tid; i < W * 8; i += kFusedThreads) tab[i] = tab_arg.v[i];
-    for (int i = tid; i <= a.hnb && a.hnb > 0; i += kFusedThreads) h[i] = 0u;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+        for (int i = tid; i < W8; i += n_thr) tab[m * W8 + i] = a.tab[m][i];
+    for (int i = tid; i < a.slab_stride; i += n_thr) h[i] = 0u;
     __syncthreads();
     unsigned long long rows_done = 0, booked = 0;
-    const unsigned stride = gridDim.x * kFusedWaves;
+    const unsigned stride = gridDim.x * (unsigned)nw;
     unsigned cur = 0xffffffffu;                 // the window this wavefront's tables describe
     HeavyWin hw{};
     long long p = 0;
-    unsigned base_sum = 0;
+    unsigned base_sum[MM];
+#pragma unroll
+    for (int m = 0; m < MM; ++m) base_sum[m] = 0u;
     int base_bad = 0, tile_id = 0, win_k = 0;
-    for (unsigned it = blockIdx.x * kFusedWaves + (unsigned)wave; it < n_items; it += stride) {
+    for (unsigned it = blockIdx.x * (unsigned)nw + (unsigned)wave; it < n_items; it += stride) {
         unsigned lo = 0, hi = n_wins - 1;       // the last window whose item_base <= it
         while (lo < hi) {
             const unsigned mid = (lo + hi + 1) >> 1;
@@ -951,16 +1058,24 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
             __builtin_amdgcn_wave_barrier();    // (the last item's rounds have read the tables)
             // the layout's positions: p .. p + W - 1, or -- layout B of a one-deletion window -- with the deleted bases jumped
             const long long dx = p + hw.jx, dlen = hw.del_len;
-            unsigned v = 0;
+            unsigned v[MM];
+#pragma unroll
+            for (int m = 0; m < MM; ++m) v[m] = 0u;
             int bad = 0;
             if (lane < W) {
                 const unsigned cr = base_code((unsigned)g.ref[p + lane + (dlen && lane > hw.jx ? dlen : 0)]);
-                v = tab[lane * 8 + cr];
+#pragma unroll
+                for (int m = 0; m < MM; ++m) v[m] = tab[m * W8 + lane * 8 + cr];
                 bad = (int)(cr >> 2);
             }
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { v += (unsigned)__shfl_xor((int)v, d); bad += __shfl_xor(bad, d); }
-            base_sum = v;
+            for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+                for (int m = 0; m < MM; ++m) v[m] += (unsigned)__shfl_xor((int)v[m], d);
+                bad += __shfl_xor(bad, d);
+            }
+#pragma unroll
+            for (int m = 0; m < MM; ++m) base_sum[m] = v[m];
             base_bad = bad;
             if (lane < hw.ns) {
                 const SiteRec r = packed_site(g, hw.i0 + lane);
@@ -971,11 +1086,13 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
                 const unsigned cr = base_code((unsigned)g.ref[r.pos]);
                 const int na = none ? 0 : (r.n_alts & 3);
                 hl->nall[lane] = (unsigned char)(1 + na);
-                hl->delta[lane * 4] = 0u;
                 hl->dbad[lane * 4] = 0;
+#pragma unroll
+                for (int m = 0; m < MM; ++m) hl->delta[m][lane * 4] = 0u;
                 for (int al = 1; al <= 3; ++al) {
                     const unsigned ca = al <= na ? base_code((unsigned)r.n_alts >> (8 * al)) : cr;
-                    hl->delta[lane * 4 + al] = none ? 0u : tab[j * 8 + ca] - tab[j * 8 + cr];
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) hl->delta[m][lane * 4 + al] = none ? 0u : tab[m * W8 + j * 8 + ca] - tab[m * W8 + j * 8 + cr];
                     hl->dbad[lane * 4 + al] = none ? (signed char)0 : (signed char)((int)(ca >> 2) - (int)(cr >> 2));
                 }
             }
@@ -988,35 +1105,43 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
             const long long wt = (r << 6) + lane;
             const bool live = wt < hw.walks;
             unsigned long long rest = live ? (unsigned long long)wt : 0ull;
-            unsigned sum = base_sum;
+            unsigned sum[MM];
+#pragma unroll
+            for (int m = 0; m < MM; ++m) sum[m] = base_sum[m];
             int bad = base_bad;
             for (int s = hw.ns - 1; s >= 0; --s) {
                 if (__builtin_amdgcn_ballot_w64(rest != 0ull) == 0ull) break;
                 const int d = take_digit(rest, (int)hl->nall[s]);
-                sum += hl->delta[s * 4 + d];
+#pragma unroll
+                for (int m = 0; m < MM; ++m) sum[m] += hl->delta[m][s * 4 + d];
                 bad += (int)hl->dbad[s * 4 + d];
             }
-            const int s_f = bad ? a.min_val : (int)(sum & 0xffffu);
-            const int s_r = bad ? a.min_val : (int)(sum >> 16);
-            if (live && a.hnb > 0) {
-                book_score(a, h, s_f);
-                if (!a.forward_only) book_score(a, h, s_r);
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                const int s_f = bad ? a.min_val[m] : (int)(sum[m] & 0xffffu);
+                const int s_r = bad ? a.min_val[m] : (int)(sum[m] >> 16);
+                if (live && a.hnb[m] > 0) {
+                    book_score(a, m, h, s_f);
+                    if (!a.forward_only) book_score(a, m, h, s_r);
+                }
+                push_hits(a, m, live && s_f >= a.cutoff[m], tile_id, win_k, 2 * (hw.q_base + wt), s_f);
+                if (!a.forward_only) push_hits(a, m, live && s_r >= a.cutoff[m], tile_id, win_k, 2 * (hw.q_base + wt) + 1, s_r);
             }
-            push_hits(a, live && s_f >= a.cutoff, tile_id, win_k, 2 * (hw.q_base + wt), s_f);
-            if (!a.forward_only) push_hits(a, live && s_r >= a.cutoff, tile_id, win_k, 2 * (hw.q_base + wt) + 1, s_r);
             const long long n_live = min(64ll, hw.walks - (r << 6));
             rows_done += (unsigned long long)n_live * (a.forward_only ? 1ull : 2ull);
         }
-        // The window's counters are 32 bits wide and a heavy window may hold 2^40 walks that all land in ONE bin (a reference
-        // 'N' inside it: every walk scores min_val).  A wavefront that has booked 2^28 scores since it last did so empties the
-        // whole window into the caller's 64-bit histogram -- by exchange, so the other wavefronts' adds fall on either side of
-        // it -- which keeps every bin below 8 x 2^28 whatever the others do.
+        // The windows' counters are 32 bits wide and a heavy window may hold 2^40 walks that all land in ONE bin (a reference
+        // 'N' inside it: every walk scores min_val).  A wavefront that has booked 2^27 scores per motif since it last did so
+        // empties the windows into the caller's 64-bit histograms -- by exchange, so the other wavefronts' adds fall on either
+        // side of it -- which keeps every bin below 16 x 2^27 whatever the others do.
         booked += (unsigned long long)(r1 > r0 ? r1 - r0 : 0) * 128ull;
-        if (booked >= kHeavyFlushAt && a.hnb > 0) {
-            for (int i = lane; i <= a.hnb; i += 64) {
-                const unsigned v = atomicExch(&h[i], 0u);
-                if (v) atomicAdd(&a.hist[i < a.hnb ? a.hlo + i : a.min_val], (unsigned long long)v);
-            }
+        if (booked >= kHeavyFlushAt && a.slab_stride > 0) {
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+                for (int i = lane; i <= a.hnb[m] && a.hnb[m] > 0; i += 64) {
+                    const unsigned v = atomicExch(&h[a.hoff[m] + i], 0u);
+                    if (v) atomicAdd(&a.hist[m][i < a.hnb[m] ? a.hlo[m] + i : a.min_val[m]], (unsigned long long)v);
+                }
             booked = 0;
         }
     }
@@ -1024,13 +1149,13 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
     __syncthreads();
     if (tid == 0) {
         unsigned long long rows = 0;
-        for (int k = 0; k < kFusedWaves; ++k) rows += blk_rows[k];
+        for (int k = 0; k < nw; ++k) rows += blk_rows[k];
         if (rows) atomicAdd(a.n_rows, rows);
     }
-    if (a.hnb > 0) {        // on top of what graph_score_kernel's workgroup of this index left there, if there was one
+    {       // on top of what graph_score_kernel's workgroup of this index left there, if there was one
         const bool fresh = (int)blockIdx.x >= main_blocks;
-        for (int i = tid; i <= a.hnb; i += kFusedThreads) {
-            unsigned *dst = &a.slabs[(size_t)blockIdx.x * (a.hnb + 1) + i];
+        for (int i = tid; i < a.slab_stride; i += n_thr) {
+            unsigned *dst = &a.slabs[(size_t)blockIdx.x * a.slab_stride + i];
             if (fresh) *dst = h[i];
             else if (h[i]) *dst += h[i];
         }
@@ -1041,7 +1166,7 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, FusedTab tab_arg, const Tile *__rest
 // loads in flight together (thread per bin over ALL slabs was 768 loads in a row for 116 wavefronts: 180 us)
 constexpr int kSlabGroup = 32;
 __global__ void __launch_bounds__(256)
-graph_hist_reduce_kernel(const unsigned *__restrict__ slabs, int n_slabs, int hlo, int hnb, int min_val,
+graph_hist_reduce_kernel(const unsigned *__restrict__ slabs, int n_slabs, int slab_stride, int hoff, int hlo, int hnb, int min_val,
                          unsigned long long *__restrict__ hist)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
@@ -1049,7 +1174,7 @@ graph_hist_reduce_kernel(const unsigned *__restrict__ slabs, int n_slabs, int hl
     const int s0 = blockIdx.y * kSlabGroup;
     unsigned v[kSlabGroup];
 #pragma unroll
-    for (int s = 0; s < kSlabGroup; ++s) v[s] = s0 + s < n_slabs ? slabs[(size_t)(s0 + s) * (hnb + 1) + b] : 0u;
+    for (int s = 0; s < kSlabGroup; ++s) v[s] = s0 + s < n_slabs ? slabs[(size_t)(s0 + s) * slab_stride + hoff + b] : 0u;
     unsigned long long sum = 0;
 #pragma unroll
     for (int s = 0; s < kSlabGroup; ++s) sum += v[s];

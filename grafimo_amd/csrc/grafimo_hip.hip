@@ -54,6 +54,7 @@ struct gfm_motif {
     std::vector<double> h_ptable;
     unsigned char *d_slab = nullptr;   // one allocation behind every device pointer below
     uint16_t *d_tab = nullptr;
+    unsigned *d_ftab = nullptr;        // the fused graph kernels' table [W][8]: sm[code][j] | sm[comp(code)][W-1-j] << 16
     double *d_pmf = nullptr;
     double *d_ptable = nullptr;
     // Scoring workspace, a ring of kWorkspaces sets taken in call order, so that the post kernel of call k
@@ -406,7 +407,7 @@ extern "C" __attribute__((visibility("hidden"))) void gfm_set_error_(const char 
 // `max_bins` consecutive scores that hold the most background probability (where an LDS histogram window goes).
 extern "C" __attribute__((visibility("hidden"))) int gfm_motif_view_(gfm_motif_t m, int max_bins, int small_bins, const int64_t **sm,
                                                                      int *W, int *min_val, int *L, int *win_lo, int *win_nb,
-                                                                     int *device, int *n_cu)
+                                                                     int *device, int *n_cu, const unsigned **d_ftab)
 {
     if (!m) return fail(GFM_ERR_INVALID, "motif is NULL");
     // `small_bins` consecutive scores if they hold 90 % of the background mass (a window that leaves room for two workgroups
@@ -426,6 +427,7 @@ extern "C" __attribute__((visibility("hidden"))) int gfm_motif_view_(gfm_motif_t
     *win_nb = w.bins;
     *device = m->device;
     *n_cu = m->n_cu;
+    if (d_ftab) *d_ftab = m->d_ftab;
     return GFM_OK;
 }
 
@@ -628,6 +630,19 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     size_t slab_bytes = 0;
     auto carve = [&](size_t bytes) { const size_t at = slab_bytes; slab_bytes += (bytes + 255) & ~(size_t)255; return at; };
     const size_t o_tab = carve(tab.size() * sizeof(uint16_t));
+    // the fused extraction -> scoring kernels' table (gfm_graph_fused.hpp): ONE lookup per base serves both strands -- the
+    // reverse complement holds comp(base j) at position W-1-j; code 2 = T (row 3), code 3 = G (row 2); codes 4..7 hold 0
+    std::vector<unsigned> ftab((size_t)W * 8, 0u);
+    {
+        static const int row_of_code[4] = {0, 1, 3, 2};
+        for (int j = 0; j < W; ++j)
+            for (int c = 0; c < 4; ++c) {
+                const unsigned fwd = (unsigned)sm[(size_t)row_of_code[c] * W + j];
+                const unsigned rc_ = (unsigned)sm[(size_t)row_of_code[c ^ 2] * W + (W - 1 - j)];   // comp: A <-> T, C <-> G
+                ftab[(size_t)j * 8 + c] = fwd | (rc_ << 16);
+            }
+    }
+    const size_t o_ftab = carve(ftab.size() * sizeof(unsigned));
     const size_t o_pmf = carve(sizeof(double) * (size_t)m->L);
     const size_t o_ptable = carve(sizeof(double) * (size_t)m->L);
     const size_t o_dp = carve(dp_scratch_bytes(W));
@@ -648,6 +663,7 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     HIP_TRY_M(hipMalloc(&m->d_slab, slab_bytes));
     HIP_TRY_M(hipMemsetAsync(m->d_slab + o_zero, 0, slab_bytes - o_zero, nullptr));
     m->d_tab = reinterpret_cast<uint16_t *>(m->d_slab + o_tab);
+    m->d_ftab = reinterpret_cast<unsigned *>(m->d_slab + o_ftab);
     m->d_pmf = reinterpret_cast<double *>(m->d_slab + o_pmf);
     m->d_ptable = reinterpret_cast<double *>(m->d_slab + o_ptable);
     m->d_qwork = reinterpret_cast<QWork *>(m->d_slab + o_qwork);
@@ -667,6 +683,7 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
     m->d_sel_ctl = reinterpret_cast<HitCtl *>(m->d_slab + o_sel_ctl);
 
     HIP_TRY_M(hipMemcpyAsync(m->d_tab, tab.data(), tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY_M(hipMemcpyAsync(m->d_ftab, ftab.data(), ftab.size() * sizeof(unsigned), hipMemcpyHostToDevice, nullptr));
     if (h_pmf) {
         HIP_TRY_M(hipMemcpyAsync(m->d_pmf, h_pmf, sizeof(double) * (size_t)m->L, hipMemcpyHostToDevice, nullptr));
     } else {

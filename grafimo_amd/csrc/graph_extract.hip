@@ -1190,6 +1190,7 @@ struct gfm_graph {
     hipEvent_t ev_copy[2] = {nullptr, nullptr};
     // ---- fused extraction -> scoring (gfm_graph_score / gfm_graph_annotate)
     std::vector<int> h_pos;              // host copy of the site positions: the tiles' first sites are found here
+    std::vector<int> h_indel_prefix;     // [n_sites + 1] insertion / deletion records among sites [0, i) (pure tiles; made on first use)
     std::vector<long long> f_starts, f_stops;   // the regions the device tile table was built for (reused while they repeat)
     int f_width = 0, f_n_tiles = 0;
     long long f_n_windows = 0;
@@ -1367,12 +1368,6 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_call, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_heavy, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&g->h_heavy_ctl), sizeof(unsigned long long), hipHostMallocDefault);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_del_score_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(graph_heavy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
         gfm_graph_destroy(g);
         return gfail(GFM_ERR_HIP, std::string("event creation failed: ") + hipGetErrorString(e));
@@ -1769,15 +1764,18 @@ GFM_API int gfm_graph_write_tsvs(gfm_graph_t g, const uint8_t *d_kmers, const in
 
 // ------------------------------------------------------------------------------------------- fused path
 extern "C" int gfm_motif_view_(gfm_motif_t m, int max_bins, int small_bins, const int64_t **sm, int *W, int *min_val, int *L,
-                               int *win_lo, int *win_nb, int *device, int *n_cu);
+                               int *win_lo, int *win_nb, int *device, int *n_cu, const unsigned **d_ftab);
 
 namespace {
-constexpr int kFusedMaxBins = 16384;     // LDS histogram window of the fused kernels (64 KiB); scores outside it spill
-// ... but a window of this many bins lets TWO workgroups of graph_score_kernel share a CU (160 KiB: 2 x (2 KiB table + 8 waves'
-// tiles + this window)), and is taken whenever it holds 90 % of the motif's background mass (synthetic W = 19..64 motifs with
+// LDS histogram windows of the fused kernels, per number of motifs that share the enumeration: at most `kFusedMaxBins` bins
+// (scores outside a window spill to global atomics) -- but `kFusedSmallBins` whenever that many hold 90 % of a motif's
+// background mass: a window of 8 000 bins lets TWO workgroups of graph_score_kernel share a CU (synthetic W = 19..64 motifs with
 // 12 000+ reachable scores: gfm_graph_score 0.15 / 0.25 / 0.36 / 0.57 ms at W = 19 / 30 / 40 / 64 with the wide window and one
-// workgroup per CU, 0.105 / 0.18 / 0.25 / 0.44 ms with this one)
-constexpr int kFusedSmallBins = 8000;
+// workgroup per CU, 0.105 / 0.18 / 0.25 / 0.44 ms with the small one, round 4).  Two and three motifs: windows that leave
+// the workgroup its wavefronts.
+constexpr int kFusedMaxBins[kMaxMM] = {16384, 8000, 5400};
+constexpr int kFusedSmallBins[kMaxMM] = {8000, 6000, 5000};
+constexpr size_t kCuLdsBytes = 160 * 1024;
 
 // first site at or behind `target`, searched from a hint (tiles come in ascending order: a step or two)
 int site_lower_bound(const std::vector<int> &pos, int hint, long long target)
@@ -1791,20 +1789,180 @@ int site_lower_bound(const std::vector<int> &pos, int hint, long long target)
     return (int)(std::lower_bound(pos.begin() + lo, pos.begin() + hi, target, [](int a, long long b) { return (long long)a < b; }) -
                  pos.begin());
 }
+
+// One instantiation of a fused kernel: its register count (asked once) and the dynamic-LDS attribute (set once).
+struct KernelInfo { const void *fn = nullptr; int vgprs = 128; bool ready = false; };
+int kernel_prepare(KernelInfo &k, const void *fn)
+{
+    if (k.ready) return GFM_OK;
+    hipFuncAttributes at{};
+    GX_TRY(hipFuncGetAttributes(&at, fn));
+    GX_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCuLdsBytes));
+    k.fn = fn;
+    k.vgprs = std::max(8, at.numRegs);
+    k.ready = true;
+    return GFM_OK;
+}
+// wavefronts per workgroup and workgroups per CU: as many wavefronts on a CU as its LDS and the kernel's registers allow
+// (512 VGPRs per SIMD lane, four SIMDs; two workgroups rather than one where both give the same)
+struct Shape { int waves = 8, per_cu = 1; };
+Shape pick_shape(int vgprs, size_t lds_fixed, size_t lds_per_wave)
+{
+    const int alloc = (vgprs + 7) & ~7;
+    const int by_regs = std::max(1, std::min(8, 512 / std::max(8, alloc))) * 4;      // wavefronts per CU the registers allow
+    Shape best{};
+    int best_waves = 0;
+    static const int force = [] { const char *e = std::getenv("GRAFIMO_FUSED_WAVES"); return e ? atoi(e) : 0; }();   // measurement aid
+    for (int per_cu = 2; per_cu >= 1; --per_cu)
+        for (int waves = kFusedMaxWaves; waves >= 4; waves -= 4) {
+            if (force && waves != force) continue;
+            if ((size_t)per_cu * (lds_fixed + (size_t)waves * lds_per_wave) > kCuLdsBytes) continue;
+            if (per_cu * waves > by_regs) continue;
+            if (per_cu * waves > best_waves) { best_waves = per_cu * waves; best = Shape{waves, per_cu}; }
+        }
+    if (best_waves == 0) best = Shape{4, 1};
+    return best;
+}
+
+template <int MM> struct FusedKernels {
+    static KernelInfo score[2], heavy, del_score;
+};
+template <int MM> KernelInfo FusedKernels<MM>::score[2];
+template <int MM> KernelInfo FusedKernels<MM>::heavy;
+template <int MM> KernelInfo FusedKernels<MM>::del_score;
+
+struct FusedLaunch {
+    gfm_graph *g;
+    FusedArgs a;
+    hipStream_t st;
+    int n_cu, n_motifs;
+    bool listing, indels, with_hist;
+    unsigned long long *heavy_ctl;
+};
+
+// the launches of one gfm_graph_score[_multi] call for MM motifs
+template <int MM> int launch_fused(FusedLaunch &L)
+{
+    gfm_graph *g = L.g;
+    FusedArgs &a = L.a;
+    hipStream_t st = L.st;
+    const int W = a.W, n_cu = L.n_cu;
+    const size_t tab_bytes = sizeof(unsigned) * (size_t)fused_tab_dwords(MM, W), hist_bytes = sizeof(unsigned) * (size_t)a.slab_stride;
+    using FK = FusedKernels<MM>;
+    // ---- graph_score_kernel
+    KernelInfo &ks = FK::score[L.listing ? 1 : 0];
+    const void *fn_score = L.listing ? reinterpret_cast<const void *>(graph_score_kernel<MM, true>)
+                                     : reinterpret_cast<const void *>(graph_score_kernel<MM, false>);
+    if (const int rc = kernel_prepare(ks, fn_score)) return rc;
+    const size_t wave_bytes = L.listing ? sizeof(WaveLdsT<MM, true>) : sizeof(WaveLdsT<MM, false>);
+    const Shape sh = pick_shape(ks.vgprs, tab_bytes + hist_bytes + 16, wave_bytes + sizeof(long long) + sizeof(int));
+    const int g1 = std::max(1, std::min((g->f_n_tiles + sh.waves - 1) / sh.waves, sh.per_cu * n_cu));
+    const size_t lds1 = tab_bytes + (size_t)sh.waves * wave_bytes + sizeof(long long) * (size_t)sh.waves + sizeof(int) * (size_t)(sh.waves + 2) + hist_bytes;
+    // ---- graph_heavy_kernel: a grid that fills the chip whatever the number of tiles
+    if (const int rc = kernel_prepare(FK::heavy, reinterpret_cast<const void *>(graph_heavy_kernel<MM>))) return rc;
+    const Shape shh = pick_shape(FK::heavy.vgprs, tab_bytes + hist_bytes + 16, sizeof(HeavyLdsT<MM>) + sizeof(long long));
+    const int g_heavy = shh.per_cu * n_cu;
+    const size_t lds_h = tab_bytes + (size_t)shh.waves * sizeof(HeavyLdsT<MM>) + sizeof(long long) * (size_t)shh.waves + hist_bytes;
+    GX_TRY(g->f_slabs.reserve((size_t)std::max(g1, g_heavy) * (size_t)std::max(1, a.slab_stride) + 1));
+    a.slabs = g->f_slabs.p;
+    if (L.listing) {
+        hipLaunchKernelGGL((graph_score_kernel<MM, true>), dim3((unsigned)g1), dim3((unsigned)sh.waves * 64), lds1, st, g->dev, a, g->f_tiles.p,
+                           g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_heavy.p, L.heavy_ctl, g->f_flags.p + 4);
+    } else {
+        hipLaunchKernelGGL((graph_score_kernel<MM, false>), dim3((unsigned)g1), dim3((unsigned)sh.waves * 64), lds1, st, g->dev, a, g->f_tiles.p,
+                           g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_heavy.p, L.heavy_ctl, g->f_flags.p + 4);
+    }
+    GX_TRY(hipGetLastError());      // (before the event query below, whose "not ready" answer is cleared: a launch failure must not go with it)
+    int n_slabs = g1;
+    {
+        // the heavy windows: launched until the plan's count has come back and says there is none
+        if (!g->heavy_known && g->heavy_asked) {
+            if (hipEventQuery(g->ev_heavy) == hipSuccess) g->heavy_known = true;
+            else (void)hipGetLastError();          // ("not ready" is no error of this call: it must not surface in the check below)
+        }
+        if (!g->heavy_known || (*g->h_heavy_ctl & 0xffffffffull) != 0ull) {
+            hipLaunchKernelGGL((graph_heavy_kernel<MM>), dim3((unsigned)g_heavy), dim3((unsigned)shh.waves * 64), lds_h, st, g->dev, a,
+                               g->f_tiles.p, g->f_heavy.p, L.heavy_ctl, g1);
+            n_slabs = std::max(g1, g_heavy);
+        }
+        if (L.listing) {
+            GX_TRY(hipMemcpyAsync(g->h_heavy_ctl, L.heavy_ctl, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            GX_TRY(hipEventRecord(g->ev_heavy, st));
+            g->heavy_asked = true;
+        }
+    }
+    if (L.listing && !L.indels) {
+        g->f_plan_ready = true;
+        g->f_plan_stream = st;
+        GX_TRY(hipEventRecord(g->ev_plan, st));
+    }
+    if (L.indels) {
+        // the listed windows' walks: count + cut into work items, then one wavefront per item (gfm_graph_fused.hpp)
+        const size_t n_batches = ((size_t)g->f_n_windows + kFusedDelThreads - 1) / kFusedDelThreads;
+        GX_TRY(g->f_del_recs.reserve(n_batches * kFusedDelThreads + 1));
+        GX_TRY(g->f_del_items.reserve(n_batches * kDelMaxItems + (size_t)kDelExtraItems + 1));
+        if (L.listing) {
+            const size_t lds_a = sizeof(SiteRec) * kSiteCache * kFusedDelThreads;
+            hipLaunchKernelGGL(graph_del_count_kernel, dim3((unsigned)(12 * n_cu)), dim3(kFusedDelThreads), lds_a, st, g->dev, W,
+                               g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_flags.p + 4, g->f_del_recs.p,
+                               g->f_del_items.p, g->f_flags.p + 3, g->f_flags.p + 5);
+            g->f_plan_ready = true;       // (stream order: the calls that follow on this stream find the plan complete)
+            g->f_plan_stream = st;
+            GX_TRY(hipEventRecord(g->ev_plan, st));
+        }
+        if (const int rc = kernel_prepare(FK::del_score, reinterpret_cast<const void *>(graph_del_score_kernel<MM>))) return rc;
+        int pitch = ((W + 3) / 4) * 4;
+        if ((pitch / 4) % 2 == 0) pitch += 4;         // an odd dword pitch: the lanes' slots fall on all LDS banks
+        const size_t lds_b = tab_bytes + sizeof(SiteRec) * kSiteCache * kFusedDelThreads +
+                             sizeof(LayoutRec) * kFusedDelThreads * kFusedLayouts + 3 * sizeof(long long) * kFusedDelThreads +
+                             3 * sizeof(int) * kFusedDelThreads + sizeof(int) * (size_t)kFusedDelThreads * W +
+                             (size_t)kFusedDelThreads * pitch;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 * 1024) / lds_b));
+        hipLaunchKernelGGL((graph_del_score_kernel<MM>), dim3((unsigned)(per_cu * n_cu)), dim3(kFusedDelThreads), lds_b, st, g->dev, a,
+                           g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_del_recs.p, g->f_del_items.p, g->f_flags.p + 3,
+                           pitch);
+    }
+    for (int m = 0; m < MM; ++m)
+        if (a.hnb[m] > 0)
+            hipLaunchKernelGGL(graph_hist_reduce_kernel, dim3((unsigned)((a.hnb[m] + 1 + 255) / 256), (unsigned)((n_slabs + kSlabGroup - 1) / kSlabGroup)),
+                               dim3(256), 0, st, g->f_slabs.p, n_slabs, a.slab_stride, a.hoff[m], a.hlo[m], a.hnb[m], a.min_val[m], a.hist[m]);
+    GX_TRY(hipGetLastError());
+    return GFM_OK;
+}
 }  // namespace
 
-GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, const int64_t *h_starts, const int64_t *h_stops,
-                            uint32_t flags, int32_t select_cutoff, uint64_t *d_hist, void *d_hits, int64_t hit_capacity,
-                            uint64_t *d_hit_count, uint64_t *d_n_rows, int32_t *d_overflow, int64_t *n_windows, void *stream)
+GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int32_t n_motifs, int32_t n_regions,
+                                  const int64_t *h_starts, const int64_t *h_stops, uint32_t flags, const int32_t *select_cutoffs,
+                                  uint64_t *const *d_hist, void *const *d_hits, const int64_t *hit_capacity,
+                                  uint64_t *const *d_hit_count, uint64_t *d_n_rows, int32_t *d_overflow, int64_t *n_windows,
+                                  void *stream)
 {
-    if (!g || !m || n_regions < 0 || (n_regions && (!h_starts || !h_stops))) return gfail(GFM_ERR_INVALID, "bad argument");
-    if (!d_hit_count || !d_n_rows || hit_capacity < 0 || (hit_capacity && !d_hits))
-        return gfail(GFM_ERR_INVALID, "NULL device buffer");
-    const int64_t *sm = nullptr;
-    int W = 0, min_val = 0, L = 0, hlo = 0, hnb = 0, mdev = 0, n_cu = 256;
-    {
-        const int rc = gfm_motif_view_(m, kFusedMaxBins, kFusedSmallBins, &sm, &W, &min_val, &L, &hlo, &hnb, &mdev, &n_cu);
+    if (!g || !motifs || n_motifs < 1 || n_motifs > kMaxMM || n_regions < 0 || (n_regions && (!h_starts || !h_stops)))
+        return gfail(GFM_ERR_INVALID, n_motifs > kMaxMM ? "at most three motifs share one enumeration" : "bad argument");
+    if (!d_hit_count || !d_n_rows || !hit_capacity || !select_cutoffs) return gfail(GFM_ERR_INVALID, "NULL argument array");
+    FusedArgs a{};
+    int W = 0, n_cu = 256, mdev = -1;
+    bool with_hist = false;
+    for (int m = 0; m < n_motifs; ++m) {
+        if (!motifs[m] || !d_hit_count[m] || hit_capacity[m] < 0 || (hit_capacity[m] && (!d_hits || !d_hits[m])))
+            return gfail(GFM_ERR_INVALID, "NULL motif / device buffer");
+        const int64_t *sm = nullptr;
+        int Wm = 0, L = 0, dev_m = 0;
+        const bool hist_m = d_hist && d_hist[m];
+        const int rc = gfm_motif_view_(motifs[m], kFusedMaxBins[n_motifs - 1], kFusedSmallBins[n_motifs - 1], &sm, &Wm, &a.min_val[m], &L,
+                                       &a.hlo[m], &a.hnb[m], &dev_m, &n_cu, &a.tab[m]);
         if (rc) return rc;
+        if (m == 0) { W = Wm; mdev = dev_m; }
+        else if (Wm != W || dev_m != mdev) return gfail(GFM_ERR_INVALID, "the motifs of one call have one width and live on one device");
+        if (!hist_m) a.hnb[m] = 0;
+        with_hist = with_hist || hist_m;
+        a.hist[m] = hist_m ? reinterpret_cast<unsigned long long *>(d_hist[m]) : nullptr;
+        a.cutoff[m] = select_cutoffs[m];
+        a.hits[m] = static_cast<GraphHit *>(d_hits ? d_hits[m] : nullptr);
+        a.hit_cap[m] = hit_capacity[m];
+        a.hit_count[m] = reinterpret_cast<unsigned long long *>(d_hit_count[m]);
+        a.hoff[m] = a.slab_stride;
+        if (a.hnb[m] > 0) a.slab_stride += a.hnb[m] + 1;
     }
     {
         int dev = -1;
@@ -1844,6 +2002,12 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
             GX_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_tiles), sizeof(Tile) * (n_tiles + 1), hipHostMallocDefault));
             g->h_tiles_cap = n_tiles;
         }
+        // sites that are an insertion or a deletion, counted from the left: a tile is PURE (kTilePure) when none lies under it
+        if (g->h_indel_prefix.empty()) {
+            g->h_indel_prefix.assign(g->host.pos.size() + 1, 0);
+            for (size_t i = 0; i < g->host.pos.size(); ++i)
+                g->h_indel_prefix[i + 1] = g->h_indel_prefix[i] + ((g->host.del_len[i] > 0 || g->host.ins_len[i] > 0) ? 1 : 0);
+        }
         long long w_base = 0;
         size_t ti = 0;
         int hint_lo = 0, hint_hi = 0, hint_far = 0;
@@ -1852,15 +2016,18 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
             const long long nw = std::max<long long>(0, e - tail - s + 1);
             for (long long off = 0; off < nw; off += kTileWin) {
                 Tile &t = g->h_tiles[ti++];
+                const int n_win = (int)std::min<long long>(kTileWin, nw - off);
                 t.p0 = s + off;
                 t.limit = e;
-                t.n_win = (int)std::min<long long>(kTileWin, nw - off);
                 t.region = r;
                 t.i_lo = hint_lo = site_lower_bound(g->h_pos, hint_lo, t.p0 - 1);
-                t.i_hi = hint_hi = site_lower_bound(g->h_pos, std::max(hint_hi, hint_lo), t.p0 + t.n_win - 1 + W);
+                t.i_hi = hint_hi = site_lower_bound(g->h_pos, std::max(hint_hi, hint_lo), t.p0 + n_win - 1 + W);
                 t.w_base = (int)w_base;
-                t.i_far = hint_far = site_lower_bound(g->h_pos, std::max(hint_far, hint_hi), t.p0 + t.n_win - 1 + W + g->max_del_len);
-                w_base += t.n_win;
+                t.i_far = hint_far = site_lower_bound(g->h_pos, std::max(hint_far, hint_hi), t.p0 + n_win - 1 + W + g->max_del_len);
+                const bool pure = t.i_hi - t.i_lo + 1 <= kWaveSites && g->h_indel_prefix[(size_t)t.i_hi] == g->h_indel_prefix[(size_t)t.i_lo] &&
+                                  g->host.max_reach[(size_t)t.i_lo] < t.p0;
+                t.n_win = n_win | (pure ? kTilePure : 0);
+                w_base += n_win;
                 if (w_base > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "too many windows in one call (split the regions)");
             }
         }
@@ -1878,15 +2045,8 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     }
     if (n_windows) *n_windows = g->f_n_windows;
     if (g->f_n_tiles == 0) return GFM_OK;
-    // graph_score_kernel: workgroups of eight wavefronts, two per CU; graph_score_del_kernel: one wavefront per workgroup,
-    // as many as a CU's LDS holds
-    const int g1 = std::min((g->f_n_tiles + kFusedWaves - 1) / kFusedWaves, 2 * n_cu);
-    const bool with_hist = d_hist != nullptr;
-    if (!with_hist) hnb = 0;
     const bool indels = g->dev.n_dels > 0 || g->dev.n_ins > 0;
     GX_TRY(g->f_del_wins.reserve((size_t)g->f_n_windows + 1));
-    const int g_heavy = 2 * n_cu;           // graph_heavy_kernel fills the chip whatever the number of tiles
-    GX_TRY(g->f_slabs.reserve((size_t)std::max(g1, g_heavy) * (size_t)(hnb + 1) + 1));
     GX_TRY(g->f_flags.reserve(16));
     GX_TRY(g->f_heavy.reserve((size_t)std::min<long long>(g->f_n_windows, kHeavyCap) + 1));
     // What depends on (graph, regions, width) only is made by the first call of a tile table and kept: the list of the windows
@@ -1899,29 +2059,9 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     } else {
         GX_TRY(hipMemsetAsync(g->f_flags.p + 2, 0, sizeof(int), st));
     }
-    unsigned long long *heavy_ctl = reinterpret_cast<unsigned long long *>(g->f_flags.p + 8);
-    FusedTab tab{};
-    {
-        static const int row_of_code[4] = {0, 1, 3, 2};       // code 2 = T (row 3), code 3 = G (row 2)
-        for (int j = 0; j < W; ++j)
-            for (int c = 0; c < 4; ++c) {
-                const unsigned fwd = (unsigned)sm[(size_t)row_of_code[c] * W + j];
-                const unsigned rc = (unsigned)sm[(size_t)row_of_code[c ^ 2] * W + (W - 1 - j)];   // comp: A <-> T, C <-> G
-                tab.v[j * 8 + c] = fwd | (rc << 16);
-            }
-    }
-    FusedArgs a{};
     a.W = W;
+    a.n_motifs = n_motifs;
     a.forward_only = (flags & GFM_GRAPH_FORWARD_ONLY) ? 1 : 0;
-    a.min_val = min_val;
-    a.cutoff = select_cutoff;
-    a.hlo = hlo;
-    a.hnb = hnb;
-    a.hist = reinterpret_cast<unsigned long long *>(d_hist);
-    a.slabs = g->f_slabs.p;
-    a.hits = static_cast<GraphHit *>(d_hits);
-    a.hit_cap = hit_capacity;
-    a.hit_count = reinterpret_cast<unsigned long long *>(d_hit_count);
     a.n_rows = reinterpret_cast<unsigned long long *>(d_n_rows);
     a.listing = listing ? 1 : 0;
     a.plan_overflow = g->f_flags.p + 4;
@@ -1935,64 +2075,12 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
     static const int lab = [] { const char *e = std::getenv("GRAFIMO_FUSED_LAB"); return e ? atoi(e) : 0; }();
     a.lab = lab;
 #endif
-    const size_t hist_bytes = with_hist ? sizeof(unsigned) * (size_t)(hnb + 1) : 0;
-    const size_t lds1 = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(WaveLds) * kFusedWaves + sizeof(long long) * kFusedWaves +
-                        sizeof(int) * (kFusedWaves + 2) + hist_bytes;
-    hipLaunchKernelGGL(graph_score_kernel, dim3((unsigned)g1), dim3(kFusedThreads), lds1, st, g->dev, a, tab, g->f_tiles.p,
-                       g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_heavy.p, heavy_ctl, g->f_flags.p + 4);
-    GX_TRY(hipGetLastError());      // (before the event query below, whose "not ready" answer is cleared: a launch failure must not go with it)
-    int n_slabs = g1;
-    {
-        // the heavy windows: launched until the plan's count has come back and says there is none
-        if (!g->heavy_known && g->heavy_asked) {
-            if (hipEventQuery(g->ev_heavy) == hipSuccess) g->heavy_known = true;
-            else (void)hipGetLastError();          // ("not ready" is no error of this call: it must not surface in the check below)
-        }
-        if (!g->heavy_known || (*g->h_heavy_ctl & 0xffffffffull) != 0ull) {
-            hipLaunchKernelGGL(graph_heavy_kernel, dim3((unsigned)g_heavy), dim3(kFusedThreads), lds1, st, g->dev, a, tab, g->f_tiles.p,
-                               g->f_heavy.p, heavy_ctl, g1);
-            n_slabs = std::max(g1, g_heavy);
-        }
-        if (listing) {
-            GX_TRY(hipMemcpyAsync(g->h_heavy_ctl, heavy_ctl, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-            GX_TRY(hipEventRecord(g->ev_heavy, st));
-            g->heavy_asked = true;
-        }
-    }
-    if (listing && !indels) {
-        g->f_plan_ready = true;
-        g->f_plan_stream = st;
-        GX_TRY(hipEventRecord(g->ev_plan, st));
-    }
-    if (indels) {
-        // the listed windows' walks: count + cut into work items, then one wavefront per item (gfm_graph_fused.hpp)
-        const size_t n_batches = ((size_t)g->f_n_windows + kFusedDelThreads - 1) / kFusedDelThreads;
-        GX_TRY(g->f_del_recs.reserve(n_batches * kFusedDelThreads + 1));
-        GX_TRY(g->f_del_items.reserve(n_batches * kDelMaxItems + (size_t)kDelExtraItems + 1));
-        if (listing) {
-            const size_t lds_a = sizeof(SiteRec) * kSiteCache * kFusedDelThreads;
-            hipLaunchKernelGGL(graph_del_count_kernel, dim3((unsigned)(12 * n_cu)), dim3(kFusedDelThreads), lds_a, st, g->dev, W,
-                               g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_flags.p + 4, g->f_del_recs.p,
-                               g->f_del_items.p, g->f_flags.p + 3, g->f_flags.p + 5);
-            g->f_plan_ready = true;       // (stream order: the calls that follow on this stream find the plan complete)
-            g->f_plan_stream = st;
-            GX_TRY(hipEventRecord(g->ev_plan, st));
-        }
-        int pitch = ((W + 3) / 4) * 4;
-        if ((pitch / 4) % 2 == 0) pitch += 4;         // an odd dword pitch: the lanes' slots fall on all LDS banks
-        const size_t lds_b = sizeof(unsigned) * GFM_MAX_WIDTH * 8 + sizeof(SiteRec) * kSiteCache * kFusedDelThreads +
-                             sizeof(LayoutRec) * kFusedDelThreads * kFusedLayouts + 3 * sizeof(long long) * kFusedDelThreads +
-                             3 * sizeof(int) * kFusedDelThreads + sizeof(int) * (size_t)kFusedDelThreads * W +
-                             (size_t)kFusedDelThreads * pitch;
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 * 1024) / lds_b));
-        hipLaunchKernelGGL(graph_del_score_kernel, dim3((unsigned)(per_cu * n_cu)), dim3(kFusedDelThreads), lds_b, st, g->dev, a, tab,
-                           g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_del_recs.p, g->f_del_items.p, g->f_flags.p + 3,
-                           pitch);
-    }
-    if (with_hist)
-        hipLaunchKernelGGL(graph_hist_reduce_kernel, dim3((unsigned)((hnb + 1 + 255) / 256), (unsigned)((n_slabs + kSlabGroup - 1) / kSlabGroup)),
-                           dim3(256), 0, st, g->f_slabs.p, n_slabs, hlo, hnb, min_val, reinterpret_cast<unsigned long long *>(d_hist));
-    GX_TRY(hipGetLastError());
+    FusedLaunch L{g, a, st, n_cu, n_motifs, listing, indels, with_hist, reinterpret_cast<unsigned long long *>(g->f_flags.p + 8)};
+    int rc = GFM_OK;
+    if (n_motifs == 1) rc = launch_fused<1>(L);
+    else if (n_motifs == 2) rc = launch_fused<2>(L);
+    else rc = launch_fused<3>(L);
+    if (rc) return rc;
 #ifdef GFM_LAB
     if (timers) {      // measurement aid: what the wavefronts of graph_del_score_kernel spent where (10-ns ticks)
         unsigned long long h[48];
@@ -2007,6 +2095,15 @@ GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, con
 #endif
     if (d_overflow) GX_TRY(hipMemcpyAsync(d_overflow, g->f_flags.p + 2, sizeof(int), hipMemcpyDeviceToDevice, st));
     return g->called(st);
+}
+
+GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, const int64_t *h_starts, const int64_t *h_stops,
+                            uint32_t flags, int32_t select_cutoff, uint64_t *d_hist, void *d_hits, int64_t hit_capacity,
+                            uint64_t *d_hit_count, uint64_t *d_n_rows, int32_t *d_overflow, int64_t *n_windows, void *stream)
+{
+    if (!m) return gfail(GFM_ERR_INVALID, "bad argument");
+    return gfm_graph_score_multi(g, &m, 1, n_regions, h_starts, h_stops, flags, &select_cutoff, &d_hist, &d_hits, &hit_capacity,
+                                 &d_hit_count, d_n_rows, d_overflow, n_windows, stream);
 }
 
 GFM_API int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t *d_hit_count, int64_t hit_capacity,

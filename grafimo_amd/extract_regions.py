@@ -313,14 +313,18 @@ class GraphIndex:
             if self.ins_len[k] > 0:
                 return True
             k -= 1
+        anchors, reach = self._reach_table()
+        k = int(np.searchsorted(anchors, p, side="left")) - 1          # last deletion anchored before p
+        return k >= 0 and p <= int(reach[k])
+
+    def _reach_table(self):
+        """(anchors of the deletions, how far the deletions up to and including each one reach)"""
         if self._dels is None:
             d = np.nonzero(self.del_len)[0]
             ends = self.pos[d].astype(np.int64) + self.del_len[d]
             # deletions may overlap: what matters is how far ANY deletion anchored before p reaches
             self._dels = (self.pos[d].astype(np.int64), np.maximum.accumulate(ends) if len(ends) else ends)
-        anchors, reach = self._dels
-        k = int(np.searchsorted(anchors, p, side="left")) - 1          # last deletion anchored before p
-        return k >= 0 and p <= int(reach[k])
+        return self._dels
 
     def window_table(self, lo: int, hi: int, width: int):
         """touches_deletion and the site range [i0, i1) for every window start in [lo, hi], in one go
@@ -333,8 +337,7 @@ class GraphIndex:
         ins_pos = self.pos[self.ins_len > 0].astype(np.int64)
         if len(ins_pos):
             touches |= np.isin(ps - 1, ins_pos)
-        self.touches_deletion(0, 1)                    # (builds the reach table)
-        anchors, reach = self._dels
+        anchors, reach = self._reach_table()
         if len(anchors):
             k = np.searchsorted(anchors, ps, side="left") - 1
             touches |= (k >= 0) & (ps <= reach[np.maximum(k, 0)])
@@ -532,46 +535,75 @@ class DeviceGraph:
         except Exception:
             pass
 
-    # ---- extraction fused into scoring (gfm_graph_score / gfm_graph_annotate)
-    def fused_buffers(self, cap: int):
-        """One int64 tensor per graph, kept between calls: [16 control words | cap entries of 2 words | cap records of 15
-        words].  Control: [0] hit count, [1] rows scored, [2] overflow flag (int32)."""
+    # ---- extraction fused into scoring (gfm_graph_score[_multi] / gfm_graph_annotate)
+    def fused_buffers(self, cap: int, slot: int = 0):
+        """One int64 tensor per graph and SLOT (a slot per motif that shares a scoring pass), kept between calls:
+        [16 control words | cap entries of 2 words | cap records of 15 words].  Control: [0] hit count; in the first slot of a
+        call also [1] rows scored (per motif), [2] overflow flag (int32).  All slots have one capacity."""
         torch = _torch()
-        buf = getattr(self, "_fused_buf", None)
-        if buf is None or self._fused_cap < cap:
+        bufs = self.__dict__.setdefault("_fused_bufs", {})
+        if getattr(self, "_fused_cap", 0) < cap:
             self._fused_cap = int(cap)
-            self._fused_buf = buf = torch.empty(16 + 17 * self._fused_cap, dtype=torch.int64, device=self.device)
+            bufs.clear()
+        buf = bufs.get(slot)
+        if buf is None:
+            buf = bufs[slot] = torch.empty(16 + 17 * self._fused_cap, dtype=torch.int64, device=self.device)
         return buf, self._fused_cap
+
+    def score_many(self, dms, starts: np.ndarray, stops: np.ndarray, cutoffs, hists=None, forward_only: bool = False,
+                   cap: int = 1 << 14, slots=None, stream=None):
+        """gfm_graph_score_multi over the regions: every walk of every window scored on both strands against up to THREE
+        motifs of one width in ONE enumeration; per motif the rows' score histogram added to hists[m] (torch int64 [L] or
+        None) and the rows with score >= cutoffs[m] left as entries in this graph's buffer of slot slots[m].  Enqueue only.
+        -> number of windows."""
+        M = len(dms)
+        slots = list(range(M)) if slots is None else list(slots)
+        bufs = [self.fused_buffers(cap, s_)[0] for s_ in slots]
+        cap = self._fused_cap
+        bufs = [self.fused_buffers(cap, s_)[0] for s_ in slots]         # (a capacity that grew replaced the earlier slots)
+        for b_ in bufs:
+            b_[:16].zero_()
+        ctl = self.__dict__.setdefault("_fused_ctl", {})
+        for s_ in slots:
+            ctl[s_] = slots[0]
+        vp = ctypes.c_void_p
+        handles = (vp * M)(*[d.handle for d in dms])
+        cuts = (ctypes.c_int32 * M)(*[int(c) for c in cutoffs])
+        hist_p = (vp * M)(*[(h.data_ptr() if h is not None else None) for h in (hists if hists is not None else [None] * M)])
+        hits_p = (vp * M)(*[b_.data_ptr() + 128 for b_ in bufs])
+        caps = (ctypes.c_int64 * M)(*([cap] * M))
+        cnt_p = (vp * M)(*[b_.data_ptr() for b_ in bufs])
+        base0 = bufs[0].data_ptr()
+        nw = ctypes.c_int64()
+        nv.check(nv.lib().gfm_graph_score_multi(self._h, handles, M, len(starts), nv.ptr(starts), nv.ptr(stops),
+                                                nv.GFM_GRAPH_FORWARD_ONLY if forward_only else 0, cuts, hist_p, hits_p, caps, cnt_p,
+                                                base0 + 8, base0 + 16, ctypes.byref(nw), _stream_ptr(stream)))
+        return int(nw.value)
 
     def score(self, dm, starts: np.ndarray, stops: np.ndarray, cutoff: int, hist=None, forward_only: bool = False,
               cap: int = 1 << 14, stream=None):
         """gfm_graph_score over the regions: every walk of every window scored on both strands against `dm`; the rows'
         score histogram added to `hist` (torch int64 [L] or None), the rows with score >= cutoff left as entries in
         this graph's buffer (fused_buffers).  Enqueue only.  -> number of windows."""
-        buf, cap = self.fused_buffers(cap)
-        buf[:16].zero_()
-        base = buf.data_ptr()
-        nw = ctypes.c_int64()
-        nv.check(nv.lib().gfm_graph_score(self._h, dm.handle, len(starts), nv.ptr(starts), nv.ptr(stops),
-                                          nv.GFM_GRAPH_FORWARD_ONLY if forward_only else 0, int(cutoff),
-                                          hist.data_ptr() if hist is not None else None, base + 128, cap, base, base + 8,
-                                          base + 16, ctypes.byref(nw), _stream_ptr(stream)))
-        return int(nw.value)
+        return self.score_many([dm], starts, stops, [cutoff], [hist], forward_only, cap, [0], stream)
 
-    def annotate(self, cutoff=None, qtable=None, stream=None):
-        """gfm_graph_annotate: the records of the entries the last score() left (cutoff: device int32 [1] or None)."""
-        buf, cap = self.fused_buffers(0)
+    def annotate(self, cutoff=None, qtable=None, stream=None, slot: int = 0):
+        """gfm_graph_annotate: the records of the entries the last score() / score_many() left in `slot` (cutoff: device
+        int32 [1] or None)."""
+        buf, cap = self.fused_buffers(0, slot)
         base = buf.data_ptr()
         nv.check(nv.lib().gfm_graph_annotate(self._h, base + 128, base, cap, cutoff.data_ptr() if cutoff is not None else None,
                                              qtable.data_ptr() if qtable is not None else None, base + 128 + 16 * cap,
                                              _stream_ptr(stream)))
 
-    def fused_results(self, guess: int = 1024):
-        """(hit count, rows scored, overflow flag, records as a numpy structured array) of the last score() + annotate();
-        synchronises.  One copy when the hits fit `guess` entries' worth of a prefix, two otherwise."""
-        buf, cap = self.fused_buffers(0)
+    def fused_results(self, guess: int = 1024, slot: int = 0):
+        """(hit count, rows scored, overflow flag, records as a numpy structured array) of the last score() + annotate() of
+        `slot`; synchronises."""
+        buf, cap = self.fused_buffers(0, slot)
         ctl = buf[:16].cpu().numpy()
-        count, n_rows, over = int(ctl[0]), int(ctl[1]), int(ctl[2] & 0xffffffff)
+        first = self.__dict__.get("_fused_ctl", {}).get(slot, slot)
+        ctl0 = ctl if first == slot else self.fused_buffers(0, first)[0][:16].cpu().numpy()
+        count, n_rows, over = int(ctl[0]), int(ctl0[1]), int(ctl0[2] & 0xffffffff)
         k = min(count, cap)
         recs = buf[16 + 2 * cap:16 + 2 * cap + 15 * k].cpu().numpy().view(HIT_DTYPE) if k else np.empty(0, dtype=HIT_DTYPE)
         return count, n_rows, over, recs
@@ -979,9 +1011,38 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
             from .top_hits import top_regions_table
             df_ = top_regions_table(df_, top_graphs)
         return df_
+    return _fused_tables([motif], graph, regions, debug, args_obj, group, always_collective, top_graphs, chrom_names)[0]
+
+
+def compute_results_from_graph_many(motifs: Sequence[Motif], graph, regions, debug: bool, args_obj, group=None,
+                                    always_collective: bool = False, chrom_names=None) -> List[Optional[pd.DataFrame]]:
+    """compute_results_from_graph for a whole motif set -- the `for motif in motif_set` loop of grafimo.findmotif
+    (grafimo.py:177-183) over one extraction -- without repeating the shared work: the motifs of one width are scored in
+    groups of up to three over ONE enumeration of the walks (gfm_graph_score_multi: tiles, site records, window
+    classification and the walks' digits once; per motif an LDS table, a histogram window, a hit list), their histograms
+    cross the ranks as ONE [M, L] all-reduce per width, and every motif gets its own q-table, cutoff and table.  Returns the
+    tables in the order of `motifs` (rank 0; None elsewhere); each equals compute_results_from_graph(motif, ...) and the same
+    lines are printed per motif."""
+    out: List[Optional[pd.DataFrame]] = [None] * len(motifs)
+    by_width: Dict[int, List[int]] = {}
+    for i, m in enumerate(motifs):
+        by_width.setdefault(int(m.width), []).append(i)
+    for _, idxs in by_width.items():
+        tabs = _fused_tables([motifs[i] for i in idxs], graph, regions, debug, args_obj, group, always_collective, None, chrom_names)
+        for i, t_ in zip(idxs, tabs):
+            out[i] = t_
+    return out
+
+
+FUSED_GROUP = 3        # motifs of one width that share an enumeration (kMaxMM of csrc/gfm_graph_fused.hpp)
+
+
+def _fused_tables(motifs, graph, regions, debug, args_obj, group, always_collective, top_graphs, chrom_names):
+    """The fused pass for motifs of ONE width -> their tables (see compute_results_from_graph[_many])."""
     from .resultsTmp import build_frame_sorted
     from .score_sequences import print_scoring_msg
     torch = _torch()
+    M = len(motifs)
     many = isinstance(graph, (list, tuple))
     entries = list(graph) if many else [graph]
     entry_spans = [_region_arrays(r) for r in (regions if many else [regions])]
@@ -1018,34 +1079,58 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
     threshold = float(args_obj.threshold)
     no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
     no_reverse, recomb = bool(args_obj.noreverse), bool(args_obj.recomb)
-    if rank == 0:
-        print_scoring_msg(motif, no_reverse, debug)
-    W = motif.width
+    W = int(motifs[0].width)
     dev = graphs[0].device
-    dm = DeviceMotif.lease(motif)            # a kept handle when this motif was scored before (device.py)
+    dms = []
+    for m in motifs:                 # kept handles when these motifs were scored before (device.py); the same numbers twice in
+        dm = DeviceMotif.lease(m)    # one set: a handle of its own (a handle's workspace holds ONE histogram)
+        if any(dm is d for d in dms):
+            dm.release()
+            dm = DeviceMotif.from_motif(m)
+        dms.append(dm)
     try:
-        cut_p = dm.pvalue_cutoff(threshold)
-        work = dm.fused_workspace(dev) if not no_qvalue else None     # [L hist | L q-table | cutoff, nrows]: kept per handle
-        L = dm.L
+        L = dms[0].L
+        cuts_p = [dm.pvalue_cutoff(threshold) for dm in dms]
+        # per motif [L hist | L q-table | cutoff, nrows]: kept per handle; the histograms of several motifs cross the ranks
+        # as ONE [M, L] tensor
+        works = [dm.fused_workspace(dev) for dm in dms] if not no_qvalue else None
+        hist_all = None
+        if works is not None and M > 1 and collective:
+            hist_all = torch.zeros((M, L), dtype=torch.int64, device=dev)
         cap = max(getattr(g, "_fused_cap", 0) for g in graphs) or (1 << 14)
         while True:
-            hist = qtable = d_cut = None
-            if work is not None:
-                hist, qtable, d_cut = work[:L], work[L:2 * L].view(torch.float64), work[2 * L:2 * L + 1].view(torch.int32)[:1]
-                hist.zero_()
-            for g, (s_, e_) in zip(graphs, spans):
-                g.score(dm, s_, e_, cut_p, hist=hist, forward_only=no_reverse, cap=cap)
-            if collective and hist is not None:
-                dist.all_reduce(hist, group=group)           # the one data-path exchange: BH ranks are global
-            if hist is not None:
-                dm.qvalue_table(hist, threshold, qval_t, qtable, d_cut, None)
+            hists = qtables = d_cuts = [None] * M
+            if works is not None:
+                hists = [hist_all[m] for m in range(M)] if hist_all is not None else [w_[:L] for w_ in works]
+                qtables = [w_[L:2 * L].view(torch.float64) for w_ in works]
+                d_cuts = [w_[2 * L:2 * L + 1].view(torch.int32)[:1] for w_ in works]
+                if hist_all is not None:
+                    hist_all.zero_()
+                else:
+                    for h_ in hists:
+                        h_.zero_()
+            for c0 in range(0, M, FUSED_GROUP):
+                sl = list(range(c0, min(M, c0 + FUSED_GROUP)))
+                for g, (s_, e_) in zip(graphs, spans):
+                    g.score_many([dms[m] for m in sl], s_, e_, [cuts_p[m] for m in sl], [hists[m] for m in sl],
+                                 forward_only=no_reverse, cap=cap, slots=sl)
+            if collective and works is not None:
+                # the one data-path exchange: BH ranks are global
+                dist.all_reduce(hist_all if hist_all is not None else hists[0], group=group)
+            if works is not None:
+                if M == 1:
+                    dms[0].qvalue_table(hists[0], threshold, qval_t, qtables[0], d_cuts[0], None)
+                else:
+                    from .device import qvalue_table_multi
+                    qvalue_table_multi(dms, hists, threshold, qval_t, qtables, d_cuts)
             for g in graphs:
-                g.annotate(cutoff=d_cut if qval_t else None, qtable=qtable)
-            got = [g.fused_results() for g in graphs]
+                for m in range(M):
+                    g.annotate(cutoff=d_cuts[m] if qval_t else None, qtable=qtables[m], slot=m)
+            got = [[g.fused_results(slot=m) for g in graphs] for m in range(M)]
             # a hit list that turned out too short is taken again at the size the counters ask for -- on EVERY rank or
             # on none: the scoring pass holds a collective (a rank-local retry would leave the ranks' all-reduce
             # sequences out of step)
-            need = max([c for c, _, _, _ in got] + [0])
+            need = max([c for per in got for c, _, _, _ in per] + [0])
             if collective:
                 t_need = torch.tensor([need], dtype=torch.int64, device=dev)
                 dist.all_reduce(t_need, op=dist.ReduceOp.MAX, group=group)
@@ -1059,75 +1144,82 @@ def compute_results_from_graph(motif: Motif, graph, regions, debug: bool, args_o
                                      f"{need} rows pass the threshold {threshold}: more than GRAFIMO_MAX_HITS = {MAX_HITS}; "
                                      f"use a stricter threshold or raise the limit")
             cap = need + need // 4 + 1024
+        if any(o for per in got for _, _, o, _ in per):
+            raise nv.NativeError(nv.GFM_ERR_OVERFLOW, f"a window of width {W} holds more than 2^40 walks through its variant sites, or the "
+                                                      f"regions hold more than 2^20 windows of more than 64 walks each (scan fewer regions at a time)")
+        n_rows = sum(n for _, n, _, _ in got[0])
+        n_global = n_rows
+        if collective:
+            tot = torch.tensor([n_rows], dtype=torch.int64, device=dev)
+            dist.all_reduce(tot, group=group)
+            n_global = int(tot.item())
+        tables = []
+        for mi, motif in enumerate(motifs):
+            if rank == 0:
+                print_scoring_msg(motif, no_reverse, debug)
+            if n_global == 0:
+                errmsg = "No result retrieved. Unable to proceed.\n"
+                errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
+                exception_handler(ValueError, errmsg, debug)
+            if not no_qvalue and rank == 0:
+                print("\nComputing q-values...\n")
+            if rank == 0:
+                print(f"Scanned sequences:\t{n_global}")
+                print(f"Scanned nucleotides:\t{n_global * W}")
+            # ---- the hit rows in the row order of the materialising path: entry, window, walk, strand
+            kept, names_of, entry_key = [], [], []
+            for gi, (_, _, _, recs) in enumerate(got[mi]):
+                recs = recs[recs["keep"] != 0]
+                s_, e_ = spans[gi]
+                reg = recs["region"]
+                kept.append(recs)
+                ek = entry_of[gi][reg] if len(recs) else np.empty(0, dtype=np.int64)
+                entry_key.append(ek)
+                names_of.append(np.array([f"{entry_names[k]}:{a}-{b}" for k, a, b in zip(ek.tolist(), s_[reg].tolist(), e_[reg].tolist())],
+                                         dtype=object))
+            recs = np.concatenate(kept) if len(kept) > 1 else kept[0]
+            ekey = np.concatenate(entry_key) if len(kept) > 1 else entry_key[0]
+            names = np.concatenate(names_of) if len(kept) > 1 else names_of[0]
+            order = np.lexsort((recs["q2"], recs["w"], ekey))
+            recs, seqnames = recs[order], names[order].tolist()
+            if top_graphs is not None and len(recs):     # the top-hit-only gather: one row per region leaves this rank
+                from .top_hits import best_rows_per_region
+                _, region_key = np.unique(np.asarray(seqnames, dtype=object), return_inverse=True)
+                keep = None if recomb else (recs["freq"] > 0)
+                sel = np.sort(best_rows_per_region(region_key, recs["score"], np.arange(len(recs)), keep))
+                recs, seqnames = recs[sel], [seqnames[i] for i in sel.tolist()]
+            lo, pv = dm_annotate_host(motif, dms[mi], recs["score"])
+            cols = dict(start=recs["start"], stop=recs["stop"], strand=recs["strand"], logodds=lo, pvalue=pv,
+                        kmers=np.ascontiguousarray(recs["kmer"][:, :W]), freq=recs["freq"], is_ref=recs["is_ref"])
+            if not no_qvalue:
+                cols["qvalue"] = recs["qvalue"]
+            if world > 1:      # packed columns to rank 0 (one tensor gather), the hit rows' region labels beside them
+                from .distributed import gather_columns, gather_names
+                got_c = gather_columns(cols, dev, group)
+                label_lists = gather_names(seqnames, dev, group)
+                if rank != 0:
+                    tables.append(None)
+                    continue
+                cols = got_c
+                seqnames = [x for lst in label_lists for x in lst]
+            k = cols["kmers"]
+            df = build_frame_sorted(
+                motif, seqnames=np.array(seqnames, dtype=object), starts=cols["start"], stops=cols["stop"],
+                strands=np.where(cols["strand"] == ord("+"), "+", "-").astype(object),
+                scores=cols["logodds"], pvalues=cols["pvalue"], qvalues=None if no_qvalue else cols["qvalue"],
+                seqs=np.ascontiguousarray(k).view(f"S{W}").ravel().astype("U").astype(object) if len(k) else np.empty(0, dtype=object),
+                frequencies=cols["freq"],
+                # vg flags a walk over a deletion `ref`; GRAFIMO repairs that on ingest (score_sequences.py:305-307)
+                references=np.where((cols["is_ref"] != 0) & (np.abs(cols["stop"] - cols["start"]) == W), "ref", "non.ref").astype(object),
+                recomb=recomb)
+            if top_graphs is not None:
+                from .top_hits import top_regions_table
+                df = top_regions_table(df, top_graphs)
+            tables.append(df)
+        return tables
     finally:
-        dm.release()
-    if any(o for _, _, o, _ in got):
-        raise nv.NativeError(nv.GFM_ERR_OVERFLOW, f"a window of width {W} holds more than 2^40 walks through its variant sites, or the "
-                                                  f"regions hold more than 2^20 windows of more than 64 walks each (scan fewer regions at a time)")
-    n_rows = sum(n for _, n, _, _ in got)
-    n_global = n_rows
-    if collective:
-        tot = torch.tensor([n_rows], dtype=torch.int64, device=dev)
-        dist.all_reduce(tot, group=group)
-        n_global = int(tot.item())
-    if n_global == 0:
-        errmsg = "No result retrieved. Unable to proceed.\n"
-        errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
-        exception_handler(ValueError, errmsg, debug)
-    if not no_qvalue and rank == 0:
-        print("\nComputing q-values...\n")
-    if rank == 0:
-        print(f"Scanned sequences:\t{n_global}")
-        print(f"Scanned nucleotides:\t{n_global * W}")
-    # ---- the hit rows in the row order of the materialising path: entry, window, walk, strand
-    kept, names_of, entry_key = [], [], []
-    for gi, (_, _, _, recs) in enumerate(got):
-        recs = recs[recs["keep"] != 0]
-        s_, e_ = spans[gi]
-        reg = recs["region"]
-        kept.append(recs)
-        ek = entry_of[gi][reg] if len(recs) else np.empty(0, dtype=np.int64)
-        entry_key.append(ek)
-        names_of.append(np.array([f"{entry_names[k]}:{a}-{b}" for k, a, b in zip(ek.tolist(), s_[reg].tolist(), e_[reg].tolist())],
-                                 dtype=object))
-    recs = np.concatenate(kept) if len(kept) > 1 else kept[0]
-    ekey = np.concatenate(entry_key) if len(kept) > 1 else entry_key[0]
-    names = np.concatenate(names_of) if len(kept) > 1 else names_of[0]
-    order = np.lexsort((recs["q2"], recs["w"], ekey))
-    recs, seqnames = recs[order], names[order].tolist()
-    if top_graphs is not None and len(recs):     # the top-hit-only gather: one row per region leaves this rank
-        from .top_hits import best_rows_per_region
-        _, region_key = np.unique(np.asarray(seqnames, dtype=object), return_inverse=True)
-        keep = None if recomb else (recs["freq"] > 0)
-        sel = np.sort(best_rows_per_region(region_key, recs["score"], np.arange(len(recs)), keep))
-        recs, seqnames = recs[sel], [seqnames[i] for i in sel.tolist()]
-    lo, pv = dm_annotate_host(motif, dm, recs["score"])
-    cols = dict(start=recs["start"], stop=recs["stop"], strand=recs["strand"], logodds=lo, pvalue=pv,
-                kmers=np.ascontiguousarray(recs["kmer"][:, :W]), freq=recs["freq"], is_ref=recs["is_ref"])
-    if not no_qvalue:
-        cols["qvalue"] = recs["qvalue"]
-    if world > 1:      # packed columns to rank 0 (one tensor gather), the hit rows' region labels beside them
-        from .distributed import gather_columns, gather_names
-        got_c = gather_columns(cols, dev, group)
-        label_lists = gather_names(seqnames, dev, group)
-        if rank != 0:
-            return None
-        cols = got_c
-        seqnames = [x for lst in label_lists for x in lst]
-    k = cols["kmers"]
-    df = build_frame_sorted(
-        motif, seqnames=np.array(seqnames, dtype=object), starts=cols["start"], stops=cols["stop"],
-        strands=np.where(cols["strand"] == ord("+"), "+", "-").astype(object),
-        scores=cols["logodds"], pvalues=cols["pvalue"], qvalues=None if no_qvalue else cols["qvalue"],
-        seqs=np.ascontiguousarray(k).view(f"S{W}").ravel().astype("U").astype(object) if len(k) else np.empty(0, dtype=object),
-        frequencies=cols["freq"],
-        # vg flags a walk over a deletion `ref`; GRAFIMO repairs that on ingest (score_sequences.py:305-307)
-        references=np.where((cols["is_ref"] != 0) & (np.abs(cols["stop"] - cols["start"]) == W), "ref", "non.ref").astype(object),
-        recomb=recomb)
-    if top_graphs is not None:
-        from .top_hits import top_regions_table
-        df = top_regions_table(df, top_graphs)
-    return df
+        for dm in dms:
+            dm.release()
 
 
 def dm_annotate_host(motif, dm, scaled):

@@ -456,6 +456,18 @@ typedef struct gfm_graph_hit {
 int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, const int64_t *h_starts, const int64_t *h_stops,
                     uint32_t flags, int32_t select_cutoff, uint64_t *d_hist, void *d_hits, int64_t hit_capacity,
                     uint64_t *d_hit_count, uint64_t *d_n_rows, int32_t *d_overflow, int64_t *n_windows, void *stream);
+/* gfm_graph_score for up to THREE motifs of one width over ONE enumeration of the walks -- the `for motif in motif_set`
+ * loop of grafimo.findmotif (grafimo.py:177-183; motifs are processed per width, motif_ops.py:303-311) for the motifs of a
+ * width: tiles, site records, window classification and the walks' digits are shared, every motif has its own LDS score table,
+ * histogram window, hit list and cutoff.  Arrays of n_motifs entries: select_cutoffs, d_hist (NULL or NULL entries: no
+ * histogram for that motif), d_hits / hit_capacity / d_hit_count (one list per motif; the caller zeroes the counters).
+ * *d_n_rows += rows scored PER MOTIF (every motif scores the same walks).  Results are identical to n_motifs gfm_graph_score
+ * calls.  gfm_graph_annotate serves every motif's list in turn (the entries do not depend on the motif). */
+int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int32_t n_motifs, int32_t n_regions,
+                          const int64_t *h_starts, const int64_t *h_stops, uint32_t flags, const int32_t *select_cutoffs,
+                          uint64_t *const *d_hist, void *const *d_hits, const int64_t *hit_capacity,
+                          uint64_t *const *d_hit_count, uint64_t *d_n_rows, int32_t *d_overflow, int64_t *n_windows,
+                          void *stream);
 int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t *d_hit_count, int64_t hit_capacity,
                        const int32_t *d_cutoff, const double *d_qtable, void *d_records, void *stream);
 
