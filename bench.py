@@ -369,6 +369,20 @@ def extract_block(ctcf, dev, n_regions=10_000):
     torch.cuda.synchronize(dev)
     fused_ms = ev0.elapsed_time(ev1) / reps
     fused_rows = int(g.fused_results()[1])
+    # graph_score_kernel alone (HIP events on its launch stream, inside the library) against its instruction-issue floor
+    fused_roofline = None
+    try:
+        nv.check(nv.lib().gfm_graph_profile_enable(g._h, 1))
+        for _ in range(20):
+            g.score(dm, starts, stops, cut, hist=hist)
+        torch.cuda.synchronize(dev)
+        ms = np.empty(64, dtype=np.float32)
+        k_ = ctypes.c_int(0)
+        nv.check(nv.lib().gfm_graph_profile_read(g._h, nv.ptr(ms), 64, ctypes.byref(k_)))
+        nv.check(nv.lib().gfm_graph_profile_enable(g._h, 0))
+        fused_roofline = fused_issue_roofline(float(np.median(ms[:k_.value])) * 1e3)
+    except Exception as e:                       # (a side measurement: it must not take the bench line with it)
+        fused_roofline = {"error": f"{type(e).__name__}: {e}"}
     dm.release()
     runs, runs_rows = [], []
     hits = 0
@@ -430,7 +444,7 @@ def extract_block(ctcf, dev, n_regions=10_000):
         "heavy_windows": heavy, "scan_graph_e2e": scan_e2e,
         "regions": n_regions, "region_bp": 200, "width": W, "sites": int(len(idx.pos)),
         "deletions": int((idx.del_len > 0).sum()), "haplotypes": idx.n_haplotypes, "rows": int(n),
-        "fused_ms": fused_ms, "rows_per_s_fused": fused_rows / (fused_ms * 1e-3),
+        "fused_ms": fused_ms, "rows_per_s_fused": fused_rows / (fused_ms * 1e-3), "roofline": fused_roofline,
         "extract_plus_score_ms": e2e, "rows_per_s_extract_plus_score": n / (e2e * 1e-3), "hits_p1e-4": int(hits),
         "fused_equals_materialised": same,
         "emit_ms": emit_ms, "rows_per_s_emit": n / (emit_ms * 1e-3),
@@ -442,6 +456,87 @@ def extract_block(ctcf, dev, n_regions=10_000):
                 "q-table + gfm_graph_annotate (columns of the hit rows only) -> table; fused_ms = gfm_graph_score alone; "
                 "emit_ms / written_GBps / frac = the materialising gfm_graph_emit kept for write_region_tsvs",
     }
+
+
+def fused_issue_roofline(kernel_us):
+    """graph_score_kernel is integer / LDS work that moves ~40 MB per launch: its bound is instruction ISSUE, not HBM.  A
+    wave64 vector instruction occupies a SIMD for two cycles (MI355X_MICROARCH.md: SIMD-32 lanes), a CU has four SIMDs and ONE
+    scalar unit: floor = max(VALU x 2 / (4 x CUs), SALU / CUs) / clock, with the instruction counts of the committed
+    rocprofv3 --pmc passes (profiles/pmc_fused.json, valid while the kernel's sources hash as they did)."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "pmc_fused.json")
+    out = {"bound": "valu_issue", "kernel": "graph_score_kernel", "kernel_us": kernel_us, "clock_ghz": 2.4, "cus": 256}
+    try:
+        rec = json.load(open(path))
+        src = b"".join(open(os.path.join(ROOT, f), "rb").read() for f in rec["kernel_source_files"])
+        fresh = hashlib.sha256(src).hexdigest()[:16] == rec["kernel_source_sha16"]
+        valu_us = rec["insts_valu"] * 2.0 / (4 * 256) / 2.4e3
+        salu_us = rec["insts_salu"] / 256.0 / 2.4e3
+        out.update({"insts": {"valu": rec["insts_valu"], "salu": rec["insts_salu"], "lds": rec["insts_lds"]},
+                    "floor_us": max(valu_us, salu_us), "valu_floor_us": valu_us, "salu_floor_us": salu_us,
+                    "frac": max(valu_us, salu_us) / kernel_us if kernel_us > 0 else None,
+                    "counters": rec["source"] if fresh else "profiles/pmc_fused.json is STALE: the fused kernels' sources changed "
+                                                              "since its counters were taken (the floor is that of the older kernel)",
+                    "counters_fresh": fresh})
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def extract_config_block(cfg, dev):
+    """BASELINE configs[3] / configs[4] THROUGH THE GRAPH (the fused path): 50 000 regions x 200 bp of the synthetic
+    chromosome.  cfg 4: one W = 30 motif, both strands, --qvalueT 1e-4.  cfg 5: 50 PWMs of widths 8..25 -- in ONE
+    compute_results_from_graph_many call (up to three motifs of a width per enumeration) against 50 single calls."""
+    import torch
+    from grafimo_amd import synth
+    from grafimo_amd.extract_regions import DeviceGraph, compute_results_from_graph, compute_results_from_graph_many
+    from grafimo_amd.workflow import Findmotif
+    mots = synth.config_motifs(cfg)
+    motifs = [synth.motif_object(m, f"M{i}") for i, m in enumerate(mots)]
+    n_regions = 50_000
+    idx, regions = synth.make_graph_index(n_regions, max(m.width for m in motifs))
+    g = DeviceGraph(idx, dev)
+    reg = np.asarray(regions, dtype=np.int64)
+    sink = io.StringIO()
+    out = {"regions": n_regions, "region_bp": 200, "sites": int(len(idx.pos)), "motifs": len(motifs)}
+    with contextlib.redirect_stdout(sink):
+        if cfg == 4:
+            wf = Findmotif(threshold=1e-4, qval_t=True)
+            ts = []
+            for _ in range(8):
+                t = time.perf_counter()
+                df = compute_results_from_graph(motifs[0], g, reg, False, wf)
+                ts.append(time.perf_counter() - t)
+            n_rows = int(g.fused_results()[1])
+            ms = 1e3 * float(np.median(ts[2:]))
+            out.update({"width": motifs[0].width, "rows": n_rows, "compute_results_from_graph_ms": ms,
+                        "rows_per_s": n_rows / (ms * 1e-3), "hits_q1e-4": int(len(df)),
+                        "what": "BASELINE configs[3] through the graph: W = 30, 50 000 regions, both strands, --qvalueT 1e-4"})
+        else:
+            wf = Findmotif(threshold=1e-4)
+            ts_many, ts_single = [], []
+            for _ in range(4):
+                t = time.perf_counter()
+                tabs = compute_results_from_graph_many(motifs, g, reg, False, wf)
+                ts_many.append(time.perf_counter() - t)
+            for _ in range(2):
+                t = time.perf_counter()
+                singles = [compute_results_from_graph(m, g, reg, False, wf) for m in motifs]
+                ts_single.append(time.perf_counter() - t)
+            same = all(len(a) == len(b) and bool((a["matched_sequence"].to_numpy() == b["matched_sequence"].to_numpy()).all())
+                       and bool(np.array_equal(a["q-value"].to_numpy(), b["q-value"].to_numpy())) for a, b in zip(tabs, singles))
+            pairs = 0
+            for m in motifs:
+                pairs += 2 * sum(max(0, min(int(e), len(idx.ref)) - m.width - max(int(s), 0) + 1) for s, e in regions)   # (reference walks only: a lower bound)
+            many_ms, single_ms = 1e3 * float(np.median(ts_many[1:])), 1e3 * float(min(ts_single))
+            out.update({"widths": sorted({m.width for m in motifs}), "many_ms": many_ms, "fifty_single_calls_ms": single_ms,
+                        "speedup_vs_single_calls": single_ms / many_ms, "tables_equal": same, "hits": int(sum(len(t_) for t_ in tabs)),
+                        "reference_walk_pairs_lower_bound": int(pairs),
+                        "what": "BASELINE configs[4] through the graph: 50 PWMs (W = 8..25), 50 000 regions; many = one "
+                                "compute_results_from_graph_many call (<= 3 motifs of a width per enumeration, gfm_graph_score_multi), "
+                                "against one compute_results_from_graph call per motif"})
+    g.close()
+    return out
 
 
 def scan_graph_block(ctcf, idx, regions, rows, g):
@@ -880,6 +975,13 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
             extras["roofline_config5"] = extra_config_block(5, dev, rank, args, side)
             torch.cuda.empty_cache()
         extras["extract"] = extract_block(ctcf, dev)
+        if not args.no_config45:
+            for cfg_ in (4, 5):                  # the same two configs through the GRAPH (the fused path; motif sets in one pass)
+                try:
+                    extras[f"extract_config{cfg_}"] = extract_config_block(cfg_, dev)
+                except Exception as e:           # (a side measurement: it must not take the bench line with it)
+                    extras[f"extract_config{cfg_}"] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
         # the strand-max / per-region best-hit reductions (north_star; csrc/region_reduce.hip) over this batch's scores:
         # 10 000 regions, rows under the p-value cutoff and carried by a haplotype
         from grafimo_amd import top_hits as th

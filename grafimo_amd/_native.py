@@ -112,6 +112,8 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_void_p, P(c_i64), c_void_p]),
     "gfm_graph_score_multi": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, ctypes.c_uint32, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, P(c_i64), c_void_p]),
+    "gfm_graph_profile_enable": (c_int, [c_void_p, c_int]),
+    "gfm_graph_profile_read": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
     "gfm_graph_annotate": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfm_vcf_open": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_int, c_int, P(c_void_p), P(c_i64), P(c_i32),
                              P(c_i64)]),

@@ -178,13 +178,20 @@ __device__ __forceinline__ void push_hits(const FusedArgs &a, int m, bool hit, i
     }
 }
 
-// h: the workgroup's LDS windows (all motifs); motif m's window starts at a.hoff[m], its min_val bin sits behind the window
-__device__ __forceinline__ void book_score(const FusedArgs &a, int m, unsigned *h, int s)
+// h: the workgroup's LDS windows (all motifs); motif m's window starts at a.hoff[m], its min_val bin sits behind the window.
+// `live`: the lane holds a score.  Scores outside a partial window (rare: a window holds >= 90 % of the background mass) go to
+// the caller's histogram by global atomics -- decided for the whole wavefront first, so that the common case is one
+// unconditional LDS add instead of a three-way divergent branch.
+__device__ __forceinline__ void book_score(const FusedArgs &a, int m, unsigned *h, bool live, int s)
 {
     const int d = s - a.hlo[m];
     const bool inside = (unsigned)d < (unsigned)a.hnb[m];
-    if (inside || s == a.min_val[m]) atomicAdd(&h[a.hoff[m] + (inside ? d : a.hnb[m])], 1u);
-    else atomicAdd(&a.hist[m][s], 1ull);
+    const bool spill = live && !inside && s != a.min_val[m];
+    if (__builtin_amdgcn_ballot_w64(spill) != 0ull) {
+        if (spill) atomicAdd(&a.hist[m][s], 1ull);
+        live = live && !spill;
+    }
+    if (live) atomicAdd(&h[a.hoff[m] + (inside ? d : a.hnb[m])], 1u);
 }
 
 // one window as phase 1 / the annotate kernel see it.  `listed`: the window touches an insertion or a deletion (the
@@ -301,8 +308,11 @@ __host__ __device__ constexpr int fused_tab_dwords(int MM, int W) { return (MM *
 // Per tile: phase 1, lane per window: first site, walks, the reference window's score; the reference walk (no alternate
 // allele: walk 0 of every window, two walks in three at 1000-Genomes density) is booked right there.  Phase 2, lane per walk
 // with an alternate allele: digits, the score adjusted per allele.
+#ifndef GFM_GRAPH_SCORE_MIN_WAVES        // wavefronts per SIMD the compiler must leave room for (registers); lab builds vary it
+#define GFM_GRAPH_SCORE_MIN_WAVES 1
+#endif
 template <int MM, bool LISTING>
-__global__ void __launch_bounds__(kFusedMaxWaves * 64)
+__global__ void __launch_bounds__(kFusedMaxWaves * 64, GFM_GRAPH_SCORE_MIN_WAVES)
 graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int n_tiles,
                    DelWin *__restrict__ del_wins, int *__restrict__ del_count, int *__restrict__ overflow,
                    HeavyWin *__restrict__ heavy_wins, unsigned long long *__restrict__ heavy_ctl, int *__restrict__ plan_overflow_w)
@@ -395,6 +405,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         unsigned long long tk0 = GFM_DBG(a) ? wall_clock64() : 0ull, tk_tile = tk0;
         const Tile t = t_cur;
         commit(t, pf);
+        const int my_pos = pf.r0.pos, my_alts = pf.r0.n_alts;      // lane s: the tile's site s (pure tiles read them by readlane)
         __builtin_amdgcn_wave_barrier();
         if (ti + stride < n_tiles) {
             t_nxt = tile_take(nxt_dw);
@@ -445,8 +456,8 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
             int before = 0, inside = 0;
             unsigned long long prod = 1;
             for (int s = 0; s < n_t; ++s) {
-                const int spos = __builtin_amdgcn_readfirstlane(wl->rec[s].pos);
-                const int na = __builtin_amdgcn_readfirstlane(wl->rec[s].n_alts) & 3;
+                const int spos = __builtin_amdgcn_readlane(my_pos, s);
+                const int na = __builtin_amdgcn_readlane(my_alts, s) & 3;
                 const bool bef = spos < pi, in = !bef && spos < pi + W;
                 before += bef ? 1 : 0;
                 inside += in ? 1 : 0;
@@ -500,7 +511,21 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         if (lane < n_win) {
             if (walks_a > 0 && !GFM_LAB_BIT(a, 2)) {           // the reference window's score on both strands
                 int bad = 0;
-                for (int j = 0; j < W; ++j) {
+                int j = 0;
+                for (; j + 4 <= W; j += 4) {                  // four bases a step: their LDS reads are in flight together
+                    unsigned c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) c[u] = base_code(wl->ref[lane + j + u]);
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) {
+                        unsigned v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = tab[m * W8 + (j + u) * 8 + c[u]];
+                        sc_a[m] += (v[0] + v[1]) + (v[2] + v[3]);
+                    }
+                    bad += (int)((c[0] >> 2) + (c[1] >> 2) + (c[2] >> 2) + (c[3] >> 2));      // (a COUNT: an alternate allele may replace an 'N')
+                }
+                for (; j < W; ++j) {
                     const unsigned c = base_code(wl->ref[lane + j]);
 #pragma unroll
                     for (int m = 0; m < MM; ++m) sc_a[m] += tab[m * W8 + j * 8 + c];
@@ -533,9 +558,9 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
                 for (int m = 0; m < MM; ++m) {
                     const int s_f = bad_a ? a.min_val[m] : (int)(sc_a[m] & 0xffffu);
                     const int s_r = bad_a ? a.min_val[m] : (int)(sc_a[m] >> 16);
-                    if (has_ref && a.hnb[m] > 0) {
-                        book_score(a, m, h, s_f);
-                        if (!a.forward_only) book_score(a, m, h, s_r);
+                    if (a.hnb[m] > 0) {
+                        book_score(a, m, h, has_ref, s_f);
+                        if (!a.forward_only) book_score(a, m, h, has_ref, s_r);
                     }
                     push_hits(a, m, has_ref && s_f >= a.cutoff[m], ti, lane, 0, s_f);
                     if (!a.forward_only) push_hits(a, m, has_ref && s_r >= a.cutoff[m], ti, lane, 1, s_r);
@@ -660,9 +685,9 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
             for (int m = 0; m < MM; ++m) {
                 const int s_f = bad ? a.min_val[m] : (int)(sum[m] & 0xffffu);
                 const int s_r = bad ? a.min_val[m] : (int)(sum[m] >> 16);
-                if (live && a.hnb[m] > 0) {
-                    book_score(a, m, h, s_f);
-                    if (!a.forward_only) book_score(a, m, h, s_r);
+                if (a.hnb[m] > 0) {
+                    book_score(a, m, h, live, s_f);
+                    if (!a.forward_only) book_score(a, m, h, live, s_r);
                 }
                 push_hits(a, m, live && s_f >= a.cutoff[m], ti, k, 2 * q, s_f);
                 if (!a.forward_only) push_hits(a, m, live && s_r >= a.cutoff[m], ti, k, 2 * q + 1, s_r);
@@ -1120,9 +1145,9 @@ graph_heavy_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles,
             for (int m = 0; m < MM; ++m) {
                 const int s_f = bad ? a.min_val[m] : (int)(sum[m] & 0xffffu);
                 const int s_r = bad ? a.min_val[m] : (int)(sum[m] >> 16);
-                if (live && a.hnb[m] > 0) {
-                    book_score(a, m, h, s_f);
-                    if (!a.forward_only) book_score(a, m, h, s_r);
+                if (a.hnb[m] > 0) {
+                    book_score(a, m, h, live, s_f);
+                    if (!a.forward_only) book_score(a, m, h, live, s_r);
                 }
                 push_hits(a, m, live && s_f >= a.cutoff[m], tile_id, win_k, 2 * (hw.q_base + wt), s_f);
                 if (!a.forward_only) push_hits(a, m, live && s_r >= a.cutoff[m], tile_id, win_k, 2 * (hw.q_base + wt) + 1, s_r);

@@ -80,7 +80,8 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
     const long long nfull = n / kQuadRows;
     const long long cstride = (long long)gridDim.x * n_waves;
     bool vec_store = true;                            // uniform: every score buffer 16-byte aligned
-    const bool through = a.store_through != 0;        // uniform: cache policy of the score stores
+    const bool through = a.store_through == 1;        // uniform: cache policy of the score stores
+    const bool no_store = a.store_through == 2;       // uniform: the caller asked for no scores at all (histogram + hits only)
 #pragma unroll
     for (int m = 0; m < MM; ++m) vec_store = vec_store && (reinterpret_cast<uintptr_t>(a.m[m].scores) & 15u) == 0;
 
@@ -273,7 +274,10 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
                 // launch's scores fit the Infinity Cache, streaming (nt) beyond.
                 const __amdgpu_buffer_rsrc_t rs =
                     __builtin_amdgcn_make_buffer_rsrc(a.m[m].scores + crow, 0, kQuadRows * 4, 0x00020000);
-                if (vec_store) {   // one 16-byte store per lane and motif: the wave writes 1 KiB contiguous
+                if (no_store) {
+                    // d_scores == NULL: what the product's scans ask for -- hits and histogram come out of this kernel, and
+                    // the int32 [N] array (80 MB of the 460 MB a 2e7-row launch moves) would never be read
+                } else if (vec_store) {   // one 16-byte store per lane and motif: the wave writes 1 KiB contiguous
                     const u32x4_t out = {(unsigned)score[m][0], (unsigned)score[m][1], (unsigned)score[m][2],
                                          (unsigned)score[m][3]};
                     if (through)
@@ -331,7 +335,7 @@ score_quad_kernel(const uint8_t *__restrict__ kmers, long long n, long long row_
                 const MotifArgs &ma = a.m[m];
                 const int sc = bad ? ma.min_val : (int)((MM == 1 ? s64 : (s64 >> (19 * m))) & 0x7FFFFull);
                 if (live) {
-                    ma.scores[first + k] = sc;
+                    if (!no_store) ma.scores[first + k] = sc;
                     if (ma.use_hist) {
                         const unsigned off = (unsigned)(sc - ma.lo);
                         if (off < (unsigned)ma.nb)

@@ -794,7 +794,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         }
         return GFM_OK;
     }
-    if (!d_kmers || !d_scores) return fail(GFM_ERR_INVALID, "NULL device buffer");
+    if (!d_kmers) return fail(GFM_ERR_INVALID, "NULL device buffer");
     {
         int dev = -1;
         HIP_TRY(hipGetDevice(&dev));
@@ -805,6 +805,8 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
         return fail(GFM_ERR_INVALID, "d_kmers must be 16-byte aligned");
     if ((reinterpret_cast<uintptr_t>(d_scores) & 3u) != 0)
         return fail(GFM_ERR_INVALID, "d_scores must be 4-byte aligned");
+    if (!d_scores && !d_hist && select_cutoff == GFM_NO_SELECT)
+        return fail(GFM_ERR_INVALID, "nothing to do: no scores, no histogram, no selection");
     if (n > (int64_t)kQuadRows * 0x7fffff00ll)
         return fail(GFM_ERR_INVALID, "too many rows for one launch (split the batch)");
     const bool select = select_cutoff != GFM_NO_SELECT;
@@ -850,7 +852,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     if (split && select && !reset && m->posted_valid[ws_prev])
         HIP_TRY(hipStreamWaitEvent(st, m->ev_posted[ws_prev], 0));
     ScoreArgs<1> args{};
-    args.store_through = score_store_through(n, 1);
+    args.store_through = d_scores ? score_store_through(n, 1) : 2;      // 2: no score store at all
     fill_motif_args(args.m[0], m, ws, slot, use_hist, m->hlo, m->hnb, select_cutoff, d_scores,
                     reinterpret_cast<long long *>(d_hit_rows), hit_capacity,
                     reset ? nullptr : reinterpret_cast<unsigned long long *>(d_hit_count));
@@ -884,10 +886,18 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
                                   int64_t *const *d_hit_rows, const int64_t *hit_capacity,
                                   uint64_t *const *d_hit_count, uint32_t flags, void *stream)
 {
-    if (!motifs || n_motifs < 1 || !d_scores) return fail(GFM_ERR_INVALID, "NULL argument");
+    if (!motifs || n_motifs < 1) return fail(GFM_ERR_INVALID, "NULL argument");
     if (n < 0) return fail(GFM_ERR_INVALID, "negative row count");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool reset = (flags & GFM_FLAG_RESET_HITS) != 0;
+    // d_scores == NULL (or every entry NULL): no score is stored -- histograms and hit lists only
+    bool no_scores = d_scores == nullptr;
+    if (d_scores) {
+        int n_null = 0;
+        for (int i = 0; i < n_motifs; ++i) n_null += d_scores[i] ? 0 : 1;
+        if (n_null != 0 && n_null != n_motifs) return fail(GFM_ERR_INVALID, "d_scores: every entry or none (scores are stored for all motifs of a call or for none)");
+        no_scores = n_null == n_motifs;
+    }
     for (int i = 0; i < n_motifs; ++i) {
         if (!motifs[i]) return fail(GFM_ERR_INVALID, "motif %d is NULL", i);
         if (motifs[i]->W != motifs[0]->W)
@@ -898,7 +908,6 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
         const bool sel = select_cutoffs && select_cutoffs[i] != GFM_NO_SELECT;
         if (sel && (!d_hit_rows || !d_hit_rows[i] || !d_hit_count || !d_hit_count[i] || !hit_capacity))
             return fail(GFM_ERR_INVALID, "selection requested for motif %d without hit buffers", i);
-        if (!d_scores[i]) return fail(GFM_ERR_INVALID, "d_scores[%d] is NULL", i);
     }
     if (n == 0) {
         if (reset && d_hit_count)
@@ -911,7 +920,7 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
         return fail(GFM_ERR_INVALID, "d_kmers must be 16-byte aligned");
     if (n > (int64_t)kQuadRows * 0x7fffff00ll)
         return fail(GFM_ERR_INVALID, "too many rows for one launch (split the batch)");
-    for (int i = 0; i < n_motifs; ++i)
+    for (int i = 0; i < n_motifs && !no_scores; ++i)
         if ((reinterpret_cast<uintptr_t>(d_scores[i]) & 3u) != 0)
             return fail(GFM_ERR_INVALID, "d_scores[%d] must be 4-byte aligned", i);
     const int W = motifs[0]->W;
@@ -939,7 +948,7 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
         ScoreArgs<1> a1{};
         ScoreArgs<2> a2{};
         ScoreArgs<3> a3{};
-        a1.store_through = a2.store_through = a3.store_through = score_store_through(n, mm);
+        a1.store_through = a2.store_through = a3.store_through = no_scores ? 2 : score_store_through(n, mm);
         for (int k = 0; k < mm; ++k) {
             gfm_motif *mo = motifs[i + k];
             const unsigned c = mo->call_no++;
@@ -952,7 +961,7 @@ GFM_API int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const
             const int cut = select_cutoffs ? select_cutoffs[i + k] : GFM_NO_SELECT;
             const bool sel = cut != GFM_NO_SELECT;
             MotifArgs &dst = mm == 1 ? a1.m[k] : (mm == 2 ? a2.m[k] : a3.m[k]);
-            fill_motif_args(dst, mo, ws[k], slot[k], uh[k], win_lo[k], win_nb[k], cut, d_scores[i + k],
+            fill_motif_args(dst, mo, ws[k], slot[k], uh[k], win_lo[k], win_nb[k], cut, no_scores ? nullptr : d_scores[i + k],
                             sel ? reinterpret_cast<long long *>(d_hit_rows[i + k]) : nullptr,
                             sel ? hit_capacity[i + k] : 0,
                             (sel && !reset) ? reinterpret_cast<const unsigned long long *>(d_hit_count[i + k])
@@ -1222,7 +1231,7 @@ GFM_API int gfm_select_hits_from(gfm_motif_t m, const int32_t *d_scores, int64_t
         if (d_hit_count) HIP_TRY(hipMemsetAsync(d_hit_count, 0, sizeof(uint64_t), st));
         return GFM_OK;
     }
-    if (!d_scores || !d_cutoff || !d_cand_rows || !d_cand_count || !d_hit_rows || !d_hit_count)
+    if (!d_cutoff || !d_cand_rows || !d_cand_count || !d_hit_rows || !d_hit_count)
         return fail(GFM_ERR_INVALID, "NULL device buffer");
     if (d_cand_rows == d_hit_rows || reinterpret_cast<const void *>(d_cand_count) == d_hit_count)
         return fail(GFM_ERR_INVALID, "the candidate list and the hit list must be different buffers");
@@ -1243,7 +1252,9 @@ GFM_API int gfm_select_hits_from(gfm_motif_t m, const int32_t *d_scores, int64_t
                            reinterpret_cast<unsigned long long *>(d_hit_count));
         HIP_TRY(hipGetLastError());
     }
-    // 2. the pass over every score, which runs only if the candidate list had overflowed
+    // 2. the pass over every score, which runs only if the candidate list had overflowed -- and only for a caller that kept
+    // the scores (d_scores == NULL: the caller has read *d_cand_count and knows the list is complete)
+    if (!d_scores) return order_selection(m, st, false);
     const long long n4 = (n + 3) >> 2;
     long long blocks = (n4 + kSelThreads - 1) / kSelThreads;
     blocks = std::max<long long>(1, std::min<long long>(blocks, m->sel_slabs));

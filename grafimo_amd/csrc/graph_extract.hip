@@ -1190,6 +1190,10 @@ struct gfm_graph {
     hipEvent_t ev_copy[2] = {nullptr, nullptr};
     // ---- fused extraction -> scoring (gfm_graph_score / gfm_graph_annotate)
     std::vector<int> h_pos;              // host copy of the site positions: the tiles' first sites are found here
+    // measurement aid (gfm_graph_profile_enable): event pairs around graph_score_kernel's launches
+    static constexpr int kProfSlots = 64;
+    hipEvent_t prof_ev[2 * kProfSlots] = {};
+    int prof_on = 0, prof_n = 0;
     std::vector<int> h_indel_prefix;     // [n_sites + 1] insertion / deletion records among sites [0, i) (pure tiles; made on first use)
     std::vector<long long> f_starts, f_stops;   // the regions the device tile table was built for (reused while they repeat)
     int f_width = 0, f_n_tiles = 0;
@@ -1426,6 +1430,8 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
         if (g->ev_copy[k]) (void)hipEventDestroy(g->ev_copy[k]);
     }
     if (g->copy_st) (void)hipStreamDestroy(g->copy_st);
+    for (hipEvent_t e : g->prof_ev)
+        if (e) (void)hipEventDestroy(e);
     g->f_tiles.release(); g->f_del_wins.release(); g->f_del_recs.release(); g->f_del_items.release(); g->f_slabs.release();
     g->f_flags.release();
     g->f_heavy.release();
@@ -1814,7 +1820,8 @@ Shape pick_shape(int vgprs, size_t lds_fixed, size_t lds_per_wave)
     int best_waves = 0;
     static const int force = [] { const char *e = std::getenv("GRAFIMO_FUSED_WAVES"); return e ? atoi(e) : 0; }();   // measurement aid
     for (int per_cu = 2; per_cu >= 1; --per_cu)
-        for (int waves = kFusedMaxWaves; waves >= 4; waves -= 4) {
+        for (int waves = kFusedMaxWaves; waves >= 4; waves -= 4) {     // whole rounds of the four SIMDs: a workgroup of ten wavefronts
+                                                                        // loads them 3, 3, 2, 2 and two such do not fit where 2 x 10 / 4 would (82.9 against 60.8 us)
             if (force && waves != force) continue;
             if ((size_t)per_cu * (lds_fixed + (size_t)waves * lds_per_wave) > kCuLdsBytes) continue;
             if (per_cu * waves > by_regs) continue;
@@ -1865,6 +1872,8 @@ template <int MM> int launch_fused(FusedLaunch &L)
     const size_t lds_h = tab_bytes + (size_t)shh.waves * sizeof(HeavyLdsT<MM>) + sizeof(long long) * (size_t)shh.waves + hist_bytes;
     GX_TRY(g->f_slabs.reserve((size_t)std::max(g1, g_heavy) * (size_t)std::max(1, a.slab_stride) + 1));
     a.slabs = g->f_slabs.p;
+    const bool timed = g->prof_on && g->prof_n < gfm_graph::kProfSlots;
+    if (timed) GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n], st));
     if (L.listing) {
         hipLaunchKernelGGL((graph_score_kernel<MM, true>), dim3((unsigned)g1), dim3((unsigned)sh.waves * 64), lds1, st, g->dev, a, g->f_tiles.p,
                            g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_heavy.p, L.heavy_ctl, g->f_flags.p + 4);
@@ -1873,6 +1882,7 @@ template <int MM> int launch_fused(FusedLaunch &L)
                            g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_heavy.p, L.heavy_ctl, g->f_flags.p + 4);
     }
     GX_TRY(hipGetLastError());      // (before the event query below, whose "not ready" answer is cleared: a launch failure must not go with it)
+    if (timed) { GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n + 1], st)); ++g->prof_n; }
     int n_slabs = g1;
     {
         // the heavy windows: launched until the plan's count has come back and says there is none
@@ -2095,6 +2105,30 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
 #endif
     if (d_overflow) GX_TRY(hipMemcpyAsync(d_overflow, g->f_flags.p + 2, sizeof(int), hipMemcpyDeviceToDevice, st));
     return g->called(st);
+}
+
+GFM_API int gfm_graph_profile_enable(gfm_graph_t g, int on)
+{
+    if (!g) return gfail(GFM_ERR_INVALID, "graph is NULL");
+    if (on)
+        for (hipEvent_t &e : g->prof_ev)
+            if (!e) GX_TRY(hipEventCreate(&e));
+    g->prof_on = on ? 1 : 0;
+    g->prof_n = 0;
+    return GFM_OK;
+}
+
+GFM_API int gfm_graph_profile_read(gfm_graph_t g, float *h_ms_out, int capacity, int *n_out)
+{
+    if (!g || !h_ms_out || !n_out || capacity < 0) return gfail(GFM_ERR_INVALID, "bad argument");
+    const int n = std::min(capacity, g->prof_n);
+    for (int k = 0; k < n; ++k) {
+        GX_TRY(hipEventSynchronize(g->prof_ev[2 * k + 1]));
+        GX_TRY(hipEventElapsedTime(&h_ms_out[k], g->prof_ev[2 * k], g->prof_ev[2 * k + 1]));
+    }
+    *n_out = n;
+    g->prof_n = 0;
+    return GFM_OK;
 }
 
 GFM_API int gfm_graph_score(gfm_graph_t g, gfm_motif_t m, int32_t n_regions, const int64_t *h_starts, const int64_t *h_stops,

@@ -110,9 +110,6 @@ struct MotifBufs {
     uint64_t *d_cand_count = nullptr;   // q-value threshold: the p < t candidates collected while scoring
     int64_t *d_cand = nullptr;          // (same capacity as d_hits)
     int64_t hit_cap = 0;
-    int64_t block_rows = 0;             // rows per score block (== chunk rows they were made for)
-    std::vector<int32_t *> score_blocks;   // one per chunk index
-
     int init()
     {
         S_TRY(hipMalloc(&d_cutoff, sizeof(int32_t)));
@@ -133,6 +130,13 @@ struct MotifBufs {
         table_len = len;
         return GFM_OK;
     }
+    void release_hits()
+    {
+        if (d_hits) (void)hipFree(d_hits);
+        if (d_cand) (void)hipFree(d_cand);
+        d_hits = d_cand = nullptr;
+        hit_cap = 0;
+    }
     int reserve_hits(int64_t cap)
     {
         if (cap <= hit_cap) return GFM_OK;
@@ -145,24 +149,8 @@ struct MotifBufs {
         hit_cap = cap;
         return GFM_OK;
     }
-    int score_block(size_t k, int64_t rows, int32_t **out)
-    {
-        if (rows > block_rows) {   // chunk size grew: the old blocks are too small
-            for (auto *p : score_blocks) (void)hipFree(p);
-            score_blocks.clear();
-            block_rows = rows;
-        }
-        while (score_blocks.size() <= k) {
-            int32_t *p = nullptr;
-            S_TRY(hipMalloc(&p, sizeof(int32_t) * (size_t)block_rows));
-            score_blocks.push_back(p);
-        }
-        *out = score_blocks[k];
-        return GFM_OK;
-    }
     void release()
     {
-        for (auto *p : score_blocks) (void)hipFree(p);
         if (d_hist) (void)hipFree(d_hist);
         if (d_q) (void)hipFree(d_q);
         if (d_cutoff) (void)hipFree(d_cutoff);
@@ -250,10 +238,21 @@ struct ScanPool {
         }
         return &meta[k];
     }
-    // What a scan leaves behind is O(rows of the largest scan so far): one score block per chunk and motif on the device,
-    // one column block per chunk on the host.  Kept, they make the next scan of that size allocation-free; beyond these
-    // budgets the blocks of the highest chunk indices are given back when a scan closes (nothing of it is in flight then).
-    static constexpr size_t kKeepHostBytes = (size_t)3 << 30, kKeepDeviceBytes = (size_t)4 << 30, kTextMax = (size_t)8 << 30;
+    // What a scan holds while it runs: three chunk slots on each side, hit lists, per row 8 bytes of host memory (line
+    // offsets) and -- up to kTextMax -- the files' text (the hit rows' columns are parsed from it at finish; files beyond it are
+    // read back with pread).  NO score is stored (round 5: the cutoff is known before scoring, hits and histogram come out of
+    // the score kernel; rounds 1-4 kept one int32 block per chunk and motif, 80 MB per 2e7 rows, read only by a fallback).
+    // What a CLOSED scan leaves behind is bounded by keep_bytes() per side (GRAFIMO_SCAN_KEEP_BYTES, default 256 MiB): a
+    // next scan of that size is allocation-free, a bigger one maps its arena again (huge pages, touched by all workers).
+    static constexpr size_t kTextMax = (size_t)4 << 30;
+    static size_t keep_bytes()
+    {
+        static const size_t v = [] {
+            const char *e = std::getenv("GRAFIMO_SCAN_KEEP_BYTES");
+            return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)256 << 20;
+        }();
+        return v;
+    }
     // The text arena is its own mapping, advised to use huge pages: 1.8 GB of 4 KiB pages is 450 000 TLB entries'
     // worth of text that is written once by read(), read once by the scan and then picked at by the hit rows -- each
     // of those a page walk (the hit rows' columns: 208 -> 130 ms of CPU at 193 000 hits once the walks were gone).
@@ -282,22 +281,15 @@ struct ScanPool {
     }
     void trim()
     {
-        if (text_cap > kKeepHostBytes) free_text();
+        const size_t keep = keep_bytes();
+        if (text_cap > keep) free_text();
         const size_t per_meta = (size_t)meta_rows * sizeof(uint64_t) + 64;
-        while (!meta.empty() && meta.size() * per_meta + text_cap > kKeepHostBytes) {
+        while (!meta.empty() && meta.size() * per_meta + text_cap > keep) {
             meta.back().release();
             meta.pop_back();
         }
-        size_t dev_bytes = 0;
-        for (auto &m : mb) dev_bytes += m.score_blocks.size() * (size_t)m.block_rows * sizeof(int32_t);
-        for (size_t j = mb.size(); j-- > 0 && dev_bytes > kKeepDeviceBytes;) {
-            MotifBufs &m = mb[j];
-            while (!m.score_blocks.empty() && dev_bytes > kKeepDeviceBytes) {
-                (void)hipFree(m.score_blocks.back());
-                m.score_blocks.pop_back();
-                dev_bytes -= (size_t)m.block_rows * sizeof(int32_t);
-            }
-        }
+        for (auto &m : mb)          // hit lists that an overflow made large: back to the default next time
+            if ((size_t)m.hit_cap * 2 * sizeof(int64_t) > keep) m.release_hits();
     }
     void release()
     {
@@ -674,6 +666,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     } drain{P};
     stamp("pool acquired");
     S_RC(P->reserve_slots((size_t)chunk_rows * (size_t)W + 16));
+    int64_t est_rows = 0;
     {   // the text arena: the directory's size estimated from a sample of its files (a stat per file was 0.8 ms per thousand)
         unsigned long long bytes = 0;
         const int step = (n_paths + 63) / 64;
@@ -683,6 +676,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
             if (::stat(paths[i], &sb) == 0) bytes += (unsigned long long)sb.st_size;
         }
         if (sampled) bytes = bytes / (unsigned long long)sampled * (unsigned long long)n_paths;
+        est_rows = (int64_t)(bytes / (unsigned long long)(2 * W + 56));      // a row: two W-mers' worth of text and change
         size_t want = (size_t)(bytes + bytes / 16) + (size_t)n_paths * 64 + (1u << 20);
         if (const char *e = std::getenv("GRAFIMO_SCAN_TEXT_BYTES")) want = (size_t)strtoull(e, nullptr, 10);   // test aid (0: keep nothing)
         if (want > ScanPool::kTextMax) want = ScanPool::kTextMax;
@@ -696,7 +690,9 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     for (size_t j = 0; j < M; ++j) {
         MotifBufs &b = P->mb[j];
         if (want_qvalues) S_RC(b.reserve_tables((size_t)L));
-        S_RC(b.reserve_hits(std::max<int64_t>(b.hit_cap, 1 << 20)));
+        // room for one row in sixteen (a p < 1e-4 scan reports one in ten thousand; the bench plants one in a hundred); a
+        // list that turns out too short is grown at finish and the scan asked for again (GFM_ERR_OVERFLOW)
+        S_RC(b.reserve_hits(std::max<int64_t>(std::max<int64_t>(b.hit_cap, 1 << 20), est_rows / 16)));
         sc->d_hist[j] = want_qvalues ? (d_hist_ext ? d_hist_ext[j] : b.d_hist) : nullptr;
         // p-value threshold: the cutoff is known before scoring and the score kernel selects the hits.  q-value
         // threshold: q >= p, so the score kernel collects the p < t CANDIDATES the same way, and the selection behind
@@ -1002,7 +998,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
         cv_work.notify_all();
         return GFM_OK;
     };
-    std::vector<int32_t *> d_sc(M);
+    std::vector<int32_t *> d_sc(M, nullptr);          // no score is stored: hits and histograms are all a scan needs
     std::vector<uint64_t *> v_hist(M), v_count(M);
     std::vector<int64_t *> v_sel(M);
     std::vector<int64_t> v_cap(M);
@@ -1063,7 +1059,6 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
         const size_t bytes = (size_t)rows_k * (size_t)W;
         for (size_t j = 0; j < M; ++j) {
             MotifBufs &b = P->mb[j];
-            S_RC(b.score_block((size_t)k, chunk_rows, &d_sc[j]));
             v_hist[j] = sc->d_hist[j];
             v_sel[j] = fused ? b.d_hits : b.d_cand;             // the list the score kernel appends to
             v_count[j] = fused ? b.d_count : b.d_cand_count;
@@ -1078,7 +1073,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
             S_RC(gfm_score_kmers(motifs[0], P->d_kmers[slot], rows_k, d_sc[0], v_hist[0], sc->cutoffs[0], total_rows,
                                  v_sel[0], v_cap[0], v_count[0], 0, P->score, nullptr));
         else
-            S_RC(gfm_score_kmers_multi(motifs, n_motifs, P->d_kmers[slot], rows_k, d_sc.data(),
+            S_RC(gfm_score_kmers_multi(motifs, n_motifs, P->d_kmers[slot], rows_k, nullptr,
                                        want_qvalues ? v_hist.data() : nullptr, sc->cutoffs.data(), total_rows, v_sel.data(),
                                        v_cap.data(), v_count.data(), 0, P->score));
         S_TRY(hipEventRecord(P->scored[slot], P->score));
@@ -1153,7 +1148,6 @@ GFM_API int gfm_scan_tsv_finish(gfm_scan_t sc, int64_t *n_hits)
     const size_t M = sc->motifs.size();
     const int L = sc->L;
     const double t0 = now_s();
-    const bool fused = !sc->on_qvalue;
     const bool trace = std::getenv("GRAFIMO_SCAN_TRACE") != nullptr;
     auto proc_cpu = []() {
         timespec ts{};
@@ -1184,37 +1178,26 @@ GFM_API int gfm_scan_tsv_finish(gfm_scan_t sc, int64_t *n_hits)
         for (size_t j = 0; j < M; ++j) {
             MotifBufs &b = P->mb[j];
             gfm_motif_t m = sc->motifs[j];
-            auto select_all = [&]() -> int {   // separate selection pass over every score block
-                int64_t base = 0;
-                for (size_t k = 0; k < sc->n_chunks; ++k) {
-                    S_RC(gfm_select_hits(m, b.score_blocks[k], sc->chunk_n[k], b.d_cutoff, base, b.d_hits, b.hit_cap,
-                                         b.d_count, k == 0 ? GFM_FLAG_RESET_HITS : 0, P->score));
-                    base += sc->chunk_n[k];
-                }
-                return GFM_OK;
+            // A list that was too short (the score kernel counts what it could not store): no score was kept to select from
+            // again, so the list is grown to what the count asks for and the caller runs the scan once more.
+            auto too_short = [&](uint64_t need) -> int {
+                S_RC(b.reserve_hits((int64_t)need + (int64_t)(need >> 3) + 1024));
+                return sfail(GFM_ERR_OVERFLOW, "the hit list of this scan was too short (" + std::to_string(need) + " rows pass the threshold); it "
+                                               "has been grown: run the scan again");
             };
             if (sc->on_qvalue) {
                 uint64_t ccnt = 0;
                 S_TRY(hipMemcpyAsync(&ccnt, b.d_cand_count, sizeof ccnt, hipMemcpyDeviceToHost, P->score));
                 S_TRY(hipStreamSynchronize(P->score));
-                if ((int64_t)ccnt <= b.hit_cap)      // the candidates are complete: filter them (the gated pass over
-                    S_RC(gfm_select_hits_from(m, b.score_blocks[0], sc->chunk_n[0], b.d_cutoff, 0, b.d_cand, b.hit_cap,   // the scores exits at once)
-                                              b.d_cand_count, b.d_hits, b.hit_cap, b.d_count, P->score));
-                else
-                    S_RC(select_all());
+                if ((int64_t)ccnt > b.hit_cap) return too_short(ccnt);
+                // the p < t candidates are complete: those that reach the q-value cutoff are the hits
+                S_RC(gfm_select_hits_from(m, nullptr, sc->total_rows, b.d_cutoff, 0, b.d_cand, b.hit_cap, b.d_cand_count, b.d_hits,
+                                          b.hit_cap, b.d_count, P->score));
             }
             uint64_t cnt = 0;
             S_TRY(hipMemcpyAsync(&cnt, b.d_count, sizeof cnt, hipMemcpyDeviceToHost, P->score));
             S_TRY(hipStreamSynchronize(P->score));
-            if ((int64_t)cnt > b.hit_cap) {   // the list was too short: size it from the count and select again
-                S_RC(b.reserve_hits((int64_t)cnt + (int64_t)(cnt >> 3) + 1024));
-                if (fused)
-                    S_TRY(hipMemcpyAsync(b.d_cutoff, &sc->cutoffs[j], sizeof(int32_t), hipMemcpyHostToDevice, P->score));
-                S_RC(select_all());
-                S_TRY(hipMemcpyAsync(&cnt, b.d_count, sizeof cnt, hipMemcpyDeviceToHost, P->score));
-                S_TRY(hipStreamSynchronize(P->score));
-                if ((int64_t)cnt > b.hit_cap) return sfail(GFM_ERR_OVERFLOW, "hit list overflow");
-            }
+            if ((int64_t)cnt > b.hit_cap) return too_short(cnt);
             std::vector<int64_t> packed((size_t)cnt);
             std::vector<double> q;
             if (cnt)

@@ -201,6 +201,24 @@ def synthetic_motif(width: int, rng: np.random.Generator, bg) -> dict:
     return dict(sm=sm, bg=bg, min_val=mn, scale=scale, offset=float(offset), probs=probs, width=int(width))
 
 
+class SyntheticMotif:
+    """A synthetic_motif() record with the members of the reference's Motif that the scoring entry points read
+    (grafimo_amd.motif.MOTIF_FIELDS): what bench.py hands to compute_results_from_graph[_many].  No pval_matrix: the score
+    distribution is computed on the device."""
+
+    def __init__(self, rec: dict, name: str):
+        self.score_matrix = rec["sm"]
+        self.nucsmap = {n: i for i, n in enumerate("ACGT")}
+        self.bg = {n: float(rec["bg"][i]) for i, n in enumerate("ACGT")}
+        self.min_val, self.scale, self.offset = int(rec["min_val"]), int(rec["scale"]), np.double(rec["offset"])
+        self.width = int(rec["width"])
+        self.motif_id, self.motif_name = name, name.lower()
+
+
+def motif_object(rec: dict, name: str) -> SyntheticMotif:
+    return SyntheticMotif(rec, name)
+
+
 def config_motifs(cfg: int):
     """The synthetic motifs of BASELINE config 4 (one W=30 PWM, uniform background) and config 5 (fifty PWMs,
     widths cycling 8..25, per-motif background ~ Dirichlet(50 bg_nt)), seeded as SURVEY 8(d) says

@@ -115,7 +115,10 @@ int gfm_motif_annotate(gfm_motif_t m, const int32_t *h_scores, int64_t n,
  *              the vg TSV rows.  A/a C/c G/g T/t score; a row holding 'N' (or any other
  *              byte whose bits 1-3 do not name A,C,G,T) scores min_val (:376-378).
  *   d_scores   int32 [n] out: scaled integer scores (16-byte aligned for the fastest stores;
- *              4-byte alignment is accepted).
+ *              4-byte alignment is accepted); NULL: no score is stored -- the histogram and the hit
+ *              list are all the caller wants (what the product's scans ask for: with a threshold the
+ *              cutoff is known before scoring, so the array would never be read; 4 of the W + 4
+ *              bytes a k-mer moves).
  *   d_hist     uint64 [L] in/out or NULL: d_hist[s] += #rows scored s.
  *   select_cutoff / d_hit_*: if select_cutoff != GFM_NO_SELECT, rows with
  *              score >= select_cutoff get the entry ((row_base + row) << 20 | score)
@@ -135,7 +138,8 @@ int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, int32_t *d
  * group of up to three motifs (as many as fit the LDS: tables, per-motif histogram windows and hit
  * queues), so per (k-mer, motif) pair the bytes moved drop from W + 4 to W/M + 4.  Arrays of
  * n_motifs entries; d_hist / select_cutoffs / d_hit_* may be NULL (or hold NULL / GFM_NO_SELECT
- * entries) exactly like the scalar arguments of gfm_score_kmers.  Results are identical to
+ * entries) exactly like the scalar arguments of gfm_score_kmers; d_scores may be NULL or hold only NULL
+ * entries (no scores stored for any motif of the call).  Results are identical to
  * n_motifs separate gfm_score_kmers calls.  Single stream. */
 int gfm_score_kmers_multi(const gfm_motif_t *motifs, int n_motifs, const uint8_t *d_kmers,
                           int64_t n, int32_t *const *d_scores, uint64_t *const *d_hist,
@@ -204,7 +208,8 @@ int gfm_select_hits(gfm_motif_t m, const int32_t *d_scores, int64_t n, const int
  * are among those with p < t: score with select_cutoff = gfm_motif_pvalue_cutoff(t) into the candidate list,
  * build the q-table, then call this -- it reads the few candidates, not every score (1e8 rows: 400 MB).  If the
  * candidate list overflowed (*d_cand_count > cand_capacity) the rows are taken from d_scores as gfm_select_hits
- * does (decided on the device, no host synchronisation).  Candidate and hit buffers must differ. */
+ * does (decided on the device, no host synchronisation).  Candidate and hit buffers must differ.  d_scores may be NULL for a
+ * caller that stored no scores (gfm_score_kmers with d_scores == NULL) and has read *d_cand_count <= cand_capacity itself. */
 int gfm_select_hits_from(gfm_motif_t m, const int32_t *d_scores, int64_t n, const int32_t *d_cutoff,
                          int64_t row_base, const int64_t *d_cand_rows, int64_t cand_capacity,
                          const uint64_t *d_cand_count, int64_t *d_hit_rows, int64_t hit_capacity,
@@ -468,6 +473,11 @@ int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int32_t n_mo
                           uint64_t *const *d_hist, void *const *d_hits, const int64_t *hit_capacity,
                           uint64_t *const *d_hit_count, uint64_t *d_n_rows, int32_t *d_overflow, int64_t *n_windows,
                           void *stream);
+/* Measurement aid (bench.py `extract.roofline`): with on != 0 the next (up to 64) gfm_graph_score[_multi] calls bracket
+ * graph_score_kernel ALONE -- the kernel of the plain and one-deletion windows, the one the fused path's time is in -- with
+ * a hipEvent pair on the launch stream; gfm_graph_profile_read waits for them and returns the durations in ms, oldest first. */
+int gfm_graph_profile_enable(gfm_graph_t g, int on);
+int gfm_graph_profile_read(gfm_graph_t g, float *h_ms_out, int capacity, int *n_out);
 int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t *d_hit_count, int64_t hit_capacity,
                        const int32_t *d_cutoff, const double *d_qtable, void *d_records, void *stream);
 
