@@ -2041,6 +2041,25 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
                 if (w_base > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "too many windows in one call (split the regions)");
             }
         }
+        // The persistent grid deals tiles round-robin (no ticket: one global word sustains 88 atomics a microsecond), so a
+        // wavefront's share is fixed before the kernel starts -- and in genome order it is luck: the SQ counters showed
+        // wavefronts busy 42 us on average in a kernel of 61 us, the rest is waiting for the unluckiest one.  Tiles are
+        // therefore dealt in order of DESCENDING estimated cost (longest processing time first): every wavefront gets one tile
+        // of every cost stratum, the cheap ones last.  Cost: the site records under the tile (each costs every window that
+        // holds it a phase-2 walk), doubled for tiles that may hold insertions / deletions (the general classification).
+        // Nothing refers to a tile's place in the table but through its index: entries, listed and heavy windows carry it.
+        if (n_tiles > 1) {
+            std::vector<std::pair<int, unsigned>> order(n_tiles);
+            for (size_t i = 0; i < n_tiles; ++i) {
+                const Tile &t = g->h_tiles[i];
+                const int sites = t.i_hi - t.i_lo;
+                order[i] = {-(((t.n_win & kTilePure) ? sites : 2 * sites + 8) * 64 + (t.n_win & 0xff)), (unsigned)i};
+            }
+            std::sort(order.begin(), order.end());
+            std::vector<Tile> sorted(n_tiles);
+            for (size_t i = 0; i < n_tiles; ++i) sorted[i] = g->h_tiles[order[i].second];
+            std::memcpy(g->h_tiles, sorted.data(), sizeof(Tile) * n_tiles);
+        }
         GX_TRY(g->f_tiles.reserve(n_tiles + 1));
         if (n_tiles) {
             GX_TRY(hipMemcpyAsync(g->f_tiles.p, g->h_tiles, sizeof(Tile) * n_tiles, hipMemcpyHostToDevice, st));

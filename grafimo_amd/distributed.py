@@ -385,18 +385,34 @@ def _scan_width_sharded(motifs, files, width, args_obj, group, backend, debug, r
     no_reverse = bool(args_obj.noreverse)
     mine = shard_files(files, world, rank)
     factory = backend if backend is not None else HipBackend
-    scan = factory.begin(motifs, mine, width, no_reverse, _parse_threads(int(args_obj.cores), world), threshold, qval_t,
-                         not no_qvalue)
-    dev = scan.device
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    counts[rank] = scan.n
-    if world > 1:
-        dist.all_reduce(counts, group=group)
-    counts = counts.cpu().numpy()
-    row_base, n_global = int(counts[:rank].sum()), int(counts.sum())
-    if not no_qvalue and world > 1:
-        dist.all_reduce(scan.hist, group=group)          # the one data-path exchange: [M, L] in one collective
-    hits, names = scan.finish()
+    from .score_sequences import ScanRetry
+    for attempt in range(3):
+        scan = factory.begin(motifs, mine, width, no_reverse, _parse_threads(int(args_obj.cores), world), threshold, qval_t,
+                             not no_qvalue)
+        dev = scan.device
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        counts[rank] = scan.n
+        if world > 1:
+            dist.all_reduce(counts, group=group)
+        counts = counts.cpu().numpy()
+        row_base, n_global = int(counts[:rank].sum()), int(counts.sum())
+        if not no_qvalue and world > 1:
+            dist.all_reduce(scan.hist, group=group)          # the one data-path exchange: [M, L] in one collective
+        # The scan stores no scores: a rank whose hit list was too short has had it grown and must run both phases again --
+        # and because the first phase ends in a collective, every rank repeats it or none does.
+        again, err = 0, None
+        try:
+            hits, names = scan.finish()
+        except ScanRetry as e:
+            again, err = 1, e
+        if world > 1:
+            flag = torch.tensor([again], dtype=torch.int64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            again = int(flag.item())
+        if not again:
+            break
+        if attempt == 2:
+            raise err if err is not None else RuntimeError("another rank's hit list kept overflowing")
     if n_global == 0:
         errmsg = "No result retrieved. Unable to proceed.\n"
         errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"

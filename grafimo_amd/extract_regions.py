@@ -470,6 +470,44 @@ class GraphIndex:
         return self.nodes_of(self.walk_bases(p, width, walk))
 
 
+def shard_index(index: GraphIndex, starts, stops, max_width: int = nv.GFM_MAX_WIDTH) -> GraphIndex:
+    """The part of a chromosome's graph that the windows of the given regions can meet: a GraphIndex with the SAME
+    coordinates (the reference array is shared, not sliced) that holds only the site records -- and their haplotype
+    bitsets, the bulk of a graph: sites x 3 x ceil(H / 64) words, 12 GB for a 1000-Genomes chr1 -- within reach of a
+    region: [start - margin, stop + margin], margin = the graph's longest deletion + two k-mer widths.  What a rank of a
+    sharded scan uploads instead of a replica of the whole graph (compute_results_from_graph given a GraphIndex under a
+    process group).  A window inside a kept region meets exactly the sites it meets in the whole graph: the sites it can
+    read lie in [p - 1, p + W + longest deletion), the deletions that can remove its first base are anchored behind
+    p - longest deletion.  Node ids (column 7 of the TSV rows) count the sites LEFT of a node: the TSV writer needs the
+    whole index, the fused path never looks at them."""
+    starts = np.asarray(starts, dtype=np.int64).ravel()
+    stops = np.asarray(stops, dtype=np.int64).ravel()
+    n = len(index.pos)
+    margin = (int(index.del_len.max()) if n else 0) + 2 * int(max_width) + 2
+    pos64 = index.pos.astype(np.int64)
+    lo = np.searchsorted(pos64, starts - margin, side="left")
+    hi = np.searchsorted(pos64, stops + margin, side="right")
+    mark = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(mark, lo, 1)
+    np.add.at(mark, hi, -1)
+    keep = np.cumsum(mark)[:n] > 0
+    ins_len = index.ins_len[keep]
+    ins_off = np.zeros(int(keep.sum()), dtype=np.int32)
+    pieces = []
+    at = 0
+    for k in np.flatnonzero(ins_len > 0).tolist():
+        o = int(index.ins_off[keep][k])
+        pieces.append(index.ins_bases[o:o + int(ins_len[k])])
+        ins_off[k] = at
+        at += int(ins_len[k])
+    sub = GraphIndex(index.chrom, index.ref, index.pos[keep], index.n_alts[keep], index.alt_bases[keep],
+                     index.alt_bits[keep] if index.alt_bits is not None else None, index.n_haplotypes, index.skipped,
+                     del_len=index.del_len[keep], ins_len=ins_len, ins_off=ins_off,
+                     ins_bases=np.concatenate(pieces) if pieces else np.zeros(0, dtype=np.uint8))
+    sub.shard_of = (n, int(keep.sum()))
+    return sub
+
+
 # most hit rows one call brings back to the host (120 bytes each, and a report row each)
 MAX_HITS = int(os.environ.get("GRAFIMO_MAX_HITS", 1 << 23))
 
@@ -928,10 +966,27 @@ def cached_device_graph(ipath: str) -> "DeviceGraph":
     return g
 
 
+_INDEX_CACHE: Dict[Tuple, GraphIndex] = {}
+
+
+def cached_host_index(ipath: str) -> GraphIndex:
+    """The GraphIndex of a saved index file, loaded once (sharded scans: every rank cuts its own part out of it)."""
+    st = os.stat(ipath)
+    key = (os.path.abspath(ipath), st.st_mtime_ns, st.st_size)
+    idx = _INDEX_CACHE.get(key)
+    if idx is None:
+        while len(_INDEX_CACHE) >= max(1, _GRAPH_CACHE_MAX):
+            _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))
+        idx = _INDEX_CACHE[key] = GraphIndex.load(ipath)
+    return idx
+
+
 def drop_graph_cache() -> None:
-    for g in _GRAPH_CACHE.values():
+    for g in list(_GRAPH_CACHE.values()) + list(_SHARD_GRAPHS.values()):
         g.close()
     _GRAPH_CACHE.clear()
+    _SHARD_GRAPHS.clear()
+    _INDEX_CACHE.clear()
 
 
 _MANIFEST_CACHE: Dict[Tuple, dict] = {}
@@ -972,9 +1027,12 @@ def compute_results_from_manifest(motif: Motif, manifest: dict, debug: bool, arg
         errmsg = "No result retrieved. Unable to proceed.\n"
         errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
         exception_handler(ValueError, errmsg, debug)
+    torch = _torch()
+    sharded = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1
     graphs, regions, names = [], [], []
     for e in manifest["entries"]:
-        graphs.append(cached_device_graph(e["index"]))
+        # under a process group the index stays on the host: every rank uploads the shard of the graph its regions touch
+        graphs.append(cached_host_index(e["index"]) if sharded else cached_device_graph(e["index"]))
         regions.append(e["regions"])
         names.append(e["chrom"])
     return compute_results_from_graph(motif, graphs, regions, debug, args_obj, group=group, top_graphs=top_graphs,
@@ -1037,6 +1095,27 @@ def compute_results_from_graph_many(motifs: Sequence[Motif], graph, regions, deb
 FUSED_GROUP = 3        # motifs of one width that share an enumeration (kMaxMM of csrc/gfm_graph_fused.hpp)
 
 
+_SHARD_GRAPHS: Dict[Tuple, "DeviceGraph"] = {}
+
+
+def _device_graph_for(index: GraphIndex, span, world: int, rank: int) -> "DeviceGraph":
+    """DeviceGraph of `index` for the regions `span` = (starts, stops) of this rank: the whole graph when there is one rank,
+    else its shard (shard_index).  Kept while the same index object is scanned with the same regions (motif after motif)."""
+    import hashlib
+    torch = _torch()
+    s_, e_ = span
+    key = (id(index), world, rank, torch.cuda.current_device(),
+           hashlib.sha1(np.ascontiguousarray(s_).tobytes() + np.ascontiguousarray(e_).tobytes()).hexdigest() if world > 1 else "")
+    g = _SHARD_GRAPHS.get(key)
+    if g is None or g._h is None or g._source is not index:
+        for k in [k for k, v in _SHARD_GRAPHS.items() if v._source is index or v._h is None]:      # one shard per index at a time
+            _SHARD_GRAPHS.pop(k).close()
+        g = DeviceGraph(shard_index(index, s_, e_) if world > 1 else index)
+        g._source = index
+        _SHARD_GRAPHS[key] = g
+    return g
+
+
 def _fused_tables(motifs, graph, regions, debug, args_obj, group, always_collective, top_graphs, chrom_names):
     """The fused pass for motifs of ONE width -> their tables (see compute_results_from_graph[_many])."""
     from .resultsTmp import build_frame_sorted
@@ -1047,7 +1126,7 @@ def _fused_tables(motifs, graph, regions, debug, args_obj, group, always_collect
     entries = list(graph) if many else [graph]
     entry_spans = [_region_arrays(r) for r in (regions if many else [regions])]
     entry_names = ([chrom_names] if isinstance(chrom_names, str) else list(chrom_names)) if chrom_names is not None \
-        else [g_.index.chrom for g_ in entries]
+        else [(g_.chrom if isinstance(g_, GraphIndex) else g_.index.chrom) for g_ in entries]
     if len(entry_names) != len(entries):
         raise ValueError("one chromosome name per (graph, regions) entry")
     dist = torch.distributed
@@ -1064,6 +1143,18 @@ def _fused_tables(motifs, graph, regions, debug, args_obj, group, always_collect
             a_, b_ = min(max(lo_ - at, 0), n_), min(max(hi_ - at, 0), n_)
             entry_spans[ei] = (entry_spans[ei][0][a_:b_], entry_spans[ei][1][a_:b_])
             at += n_
+    # An entry given as a GraphIndex (host side) is uploaded here: all of it in a single process; under a process group only
+    # what THIS rank's regions can meet (shard_index: the site records and haplotype bitsets within reach of them) -- a rank
+    # touches an n-th of the regions and holds an n-th of the graph, not a replica.  Kept per (index, regions).
+    host_entries: Dict[int, List[int]] = {}
+    for ei, g_ in enumerate(entries):
+        if isinstance(g_, GraphIndex):
+            host_entries.setdefault(id(g_), []).append(ei)
+    for eis in host_entries.values():               # (entries that name one index share one device graph: one shard for all their regions)
+        span_all = (np.concatenate([entry_spans[ei][0] for ei in eis]), np.concatenate([entry_spans[ei][1] for ei in eis]))
+        dg = _device_graph_for(entries[eis[0]], span_all, world, rank)
+        for ei in eis:
+            entries[ei] = dg
     # one scoring call per distinct graph handle (a handle holds the tile table of its last call): entries that share a
     # handle are scored as one list of regions; `first_entry[gi]` keeps the entries' order for the rows
     graphs, spans, entry_of = [], [], []

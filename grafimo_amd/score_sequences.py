@@ -86,6 +86,10 @@ class ScanHits:
                                            nv.ptr(self.freq), nv.ptr(self.is_ref), nv.ptr(self.name_id)))
 
 
+class ScanRetry(nv.NativeError):
+    """a deferred scan's hit list was too short; the library has grown it: run both phases again (on every rank)"""
+
+
 class StreamScan:
     """gfm_scan_tsv_begin / _finish: the TSV files of one width parsed, uploaded and scored as one pipelined pass
     (parse threads -> pinned chunks -> copy stream -> score kernel per chunk); only the hit rows -- with the
@@ -100,36 +104,55 @@ class StreamScan:
     def __init__(self, dm, paths: List[str], skip_reverse: bool, threads: int, threshold: float,
                  on_qvalue: bool, want_qvalues: bool, chunk_rows: int = 0, hists=None, defer: bool = False):
         self.dms = list(dm) if isinstance(dm, (list, tuple)) else [dm]
-        M = len(self.dms)
         self.width = self.dms[0].width
         self.want_qvalues = bool(want_qvalues)
-        arr, _keep = nv.c_paths(paths)
-        handles = (ctypes.c_void_p * M)(*[d.handle for d in self.dms])
-        hist_ptrs = None
-        if hists is not None:
-            if len(hists) != M:
-                raise ValueError("one histogram tensor per motif")
-            hist_ptrs = (ctypes.c_void_p * M)(*[t.data_ptr() for t in hists])
-        h = ctypes.c_void_p()
-        n = ctypes.c_int64()
-        nv.check(nv.lib().gfm_scan_tsv_begin(handles, M, arr, len(paths), int(bool(skip_reverse)), int(threads),
-                                             float(threshold), int(bool(on_qvalue)), int(bool(want_qvalues)),
-                                             int(chunk_rows), hist_ptrs, ctypes.byref(h), ctypes.byref(n)))
-        self._h = h
+        if hists is not None and len(hists) != len(self.dms):
+            raise ValueError("one histogram tensor per motif")
+        self._args = (list(paths), int(bool(skip_reverse)), int(threads), float(threshold), int(bool(on_qvalue)),
+                      int(bool(want_qvalues)), int(chunk_rows))
         self._hists = hists             # kept alive until finish()
-        self.n = int(n.value)
+        self._defer = bool(defer)
+        self._h = None
         self.hits = None
+        self._begin()
         if not defer:
             self.finish()
 
+    def _begin(self):
+        paths, skip_reverse, threads, threshold, on_qvalue, want_qvalues, chunk_rows = self._args
+        M = len(self.dms)
+        arr, _keep = nv.c_paths(paths)
+        handles = (ctypes.c_void_p * M)(*[d.handle for d in self.dms])
+        hist_ptrs = None
+        if self._hists is not None:
+            hist_ptrs = (ctypes.c_void_p * M)(*[t.data_ptr() for t in self._hists])
+        h = ctypes.c_void_p()
+        n = ctypes.c_int64()
+        nv.check(nv.lib().gfm_scan_tsv_begin(handles, M, arr, len(paths), skip_reverse, threads, threshold, on_qvalue,
+                                             want_qvalues, chunk_rows, hist_ptrs, ctypes.byref(h), ctypes.byref(n)))
+        self._h = h
+        self.n = int(n.value)
+
     def finish(self):
-        """Second phase: q-tables and cutoffs from the histograms as they are now, selection, hits back."""
+        """Second phase: q-tables and cutoffs from the histograms as they are now, selection, hits back.
+        The scan stores no scores: a hit list that turns out too short (more than one row in sixteen passes the threshold)
+        is grown by the library, which then asks for the scan again (GFM_ERR_OVERFLOW) -- done here, once, for a scan that
+        runs both phases itself; a deferred scan (a sharded caller all-reduces the histograms between the phases) gets
+        ScanRetry and repeats both phases on every rank together."""
         if self._h is None:
             raise RuntimeError("the scan is closed")
         M = len(self.dms)
         try:
             counts = (ctypes.c_int64 * M)()
-            nv.check(nv.lib().gfm_scan_tsv_finish(self._h, counts))
+            rc = nv.lib().gfm_scan_tsv_finish(self._h, counts)
+            if rc == nv.GFM_ERR_OVERFLOW:
+                msg = nv.lib().gfm_last_error().decode("utf-8", "replace")
+                if self._defer:
+                    raise ScanRetry(rc, msg)
+                self.close_handle()
+                self._begin()
+                rc = nv.lib().gfm_scan_tsv_finish(self._h, counts)
+            nv.check(rc)
             self.hits = [ScanHits(self._h, j, int(counts[j]), self.width, self.want_qvalues) for j in range(M)]
             self.stats = nv.ScanStats()
             nv.check(nv.lib().gfm_scan_stats(self._h, ctypes.byref(self.stats)))
@@ -151,6 +174,11 @@ class StreamScan:
         for k, v in vars(first).items():
             setattr(self, k, v)
         return self
+
+    def close_handle(self):
+        if getattr(self, "_h", None) is not None:
+            nv.lib().gfm_scan_close(self._h)
+            self._h = None
 
     def close(self):
         if getattr(self, "_h", None) is not None:

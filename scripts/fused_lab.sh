@@ -14,8 +14,8 @@ for lab in ${FUSED_LAB_MODES:-0 1 4 8 3 7 15}; do
   f=$(ls -t "$out"/p$lab/*/*kernel_stats.csv 2>/dev/null | head -1)
   python3 - "$f" "$lab" <<'PY'
 import csv, sys
-rows = {r["Name"].split("::")[1].split("(")[0]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(sys.argv[1])) if "graph_" in r["Name"]}
-print(f"lab={sys.argv[2]:>2s}: " + ", ".join(f"{k} {v:.1f} us" for k, v in rows.items() if k in ("graph_score_kernel", "graph_del_score_kernel", "graph_hist_reduce_kernel")))
+rows = {r["Name"].split("namespace)::")[1].split("(")[0]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(sys.argv[1])) if "graph_" in r["Name"]}
+print(f"lab={sys.argv[2]:>2s}: " + ", ".join(f"{k} {v:.1f} us" for k, v in rows.items() if k.startswith(("graph_score_kernel<1, false", "graph_del_score_kernel", "graph_hist_reduce_kernel"))))
 PY
   rm -rf "$out/p$lab"
 done

@@ -45,6 +45,38 @@ def worker(rank, world, port, seqdir, out):
                     bad.append((kw, name))
         else:
             assert one is None and all(x is None for x in many)
+    # ---- the graph path: every rank is given the HOST index and uploads only the shard of the graph its regions touch
+    from grafimo_amd import synth
+    from grafimo_amd.extract_regions import DeviceGraph, compute_results_from_graph, compute_results_from_graph_many
+    idx, regions = synth.make_graph_index(600, 19)
+    reg = np.asarray(regions, dtype=np.int64)
+    syn = synth.motif_object(synth.synthetic_motif(19, np.random.default_rng(7), np.full(4, 0.25)), "SYN19")
+    solo = dist.new_group([0])                      # (a group of rank 0 alone: the one-process reference inside this job)
+    for kw in (dict(threshold=1e-3), dict(threshold=0.5, qval_t=True, recomb=True)):
+        wf = Findmotif(cores=2, **kw)
+        with contextlib.redirect_stdout(io.StringIO()):
+            one = compute_results_from_graph(ctcf, idx, reg, True, wf)
+            many = compute_results_from_graph_many([ctcf, ctcf2, syn], idx, reg, True, wf)
+        from grafimo_amd.extract_regions import _SHARD_GRAPHS
+        mine = [g for g in _SHARD_GRAPHS.values() if g._source is idx]
+        assert len(mine) == 1 and 0 < len(mine[0].index.pos) < len(idx.pos), "this rank holds a shard of the graph, not a replica"
+        if rank == 0:
+            full = DeviceGraph(idx)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref = [compute_results_from_graph(m, full, reg, True, wf, group=solo) for m in (ctcf, ctcf2, syn)]
+            full.close()
+            for got, exp, name in ((one, ref[0], "graph"), (many[0], ref[0], "graph many[0]"), (many[1], ref[1], "graph many[1]"),
+                                   (many[2], ref[2], "graph many[2]")):
+                a, b = table_key(got), table_key(exp)
+                same = len(a) == len(b) and all((a[c].astype(str) == b[c].astype(str)).all() for c in b.columns
+                                                 if b[c].dtype.kind != "f") and \
+                    all(np.allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-12, atol=0) for c in b.columns
+                        if b[c].dtype.kind == "f")
+                print(f"{kw} {name}: {len(a)} rows, ranks holding shards of the graph == one process with all of it: {same}", flush=True)
+                if not same or (len(a) == 0 and not kw.get("qval_t")):
+                    bad.append((kw, name))
+        else:
+            assert one is None and all(x is None for x in many)
     if rank == 0 and bad:
         open(out, "w").write(str(bad))
     dist.barrier()

@@ -446,3 +446,42 @@ def test_window_table_equals_the_per_window_lookups(tmp_path):
                 assert bool(touches[k]) == idx.touches_deletion(p, W), (W, p)
                 assert int(i0[k]) == int(np.searchsorted(idx.pos, p, side="left"))
                 assert int(i1[k]) == int(np.searchsorted(idx.pos, p + W, side="left"))
+
+
+def test_a_ranks_shard_of_the_graph_gives_the_rows_of_the_whole_graph(tmp_path):
+    """under a process group every rank held a replica of every graph.  shard_index() keeps the site records
+    (and haplotype bitsets) within reach of a rank's regions only; the oracle's walk enumerator gives, for every region of
+    the rank, exactly the rows it gives on the whole graph -- rich graph, deletions longer than a window, regions at both
+    ends of the chromosome, two ranks whose site sets are disjoint."""
+    from extract_helpers import make_graph_files, variants_from_index
+    from grafimo_amd.distributed import shard_bounds
+    from grafimo_amd.extract_regions import GraphIndex, shard_index
+    from oracle import extract_oracle as xo
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=6000, n_sites=520, n_samples=20, seed=31, rich=True)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
+    ref = idx.ref.tobytes()
+    regions = [(0, 150), (400, 600), (1000, 1100), (2900, 3200), (4100, 4300), (5850, 6000)]
+    v_full = variants_from_index(idx)
+    world = 2
+    kept = []
+    for rank in range(world):
+        lo, hi = shard_bounds(len(regions), world, rank)
+        mine = regions[lo:hi]
+        sub = shard_index(idx, [s for s, _ in mine], [e for _, e in mine])
+        assert sub.ref is idx.ref or np.shares_memory(sub.ref, idx.ref)          # same coordinates, the reference is not copied
+        assert 0 < len(sub.pos) < len(idx.pos) and sub.shard_of == (len(idx.pos), len(sub.pos))
+        kept.append(set(zip(sub.pos.tolist(), sub.del_len.tolist(), sub.ins_len.tolist())))
+        v_sub = variants_from_index(sub)
+        for W in (8, 19, 30):
+            for s, e in mine:
+                a = xo.enumerate_region_variants("7", ref, v_sub, s, e, W, with_counts=True)
+                b = xo.enumerate_region_variants("7", ref, v_full, s, e, W, with_counts=True)
+                assert a == b and len(b) > 0, (rank, W, s, e)
+    assert not (kept[0] & kept[1])                   # the two ranks hold disjoint parts of the graph
+    # insertions' bases are re-based into the shard's own pool
+    sub = shard_index(idx, [2900], [3200])
+    for i in np.flatnonzero(sub.ins_len > 0).tolist():
+        j = int(np.flatnonzero((idx.pos == sub.pos[i]) & (idx.ins_len == sub.ins_len[i]))[0])
+        got = sub.ins_bases[sub.ins_off[i]:sub.ins_off[i] + sub.ins_len[i]].tobytes()
+        assert any(got == idx.ins_bases[idx.ins_off[k]:idx.ins_off[k] + idx.ins_len[k]].tobytes()
+                   for k in np.flatnonzero((idx.pos == sub.pos[i]) & (idx.ins_len > 0)).tolist()), (i, j)

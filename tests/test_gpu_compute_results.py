@@ -177,8 +177,10 @@ def test_streamed_scan_chunks_do_not_change_the_result(tmp_path, golden_motifs):
 
 
 def test_streamed_scan_grows_its_hit_list(tmp_path, golden_motifs):
-    """More hits than the pooled hit list holds (threshold 1: every one of 1.2e6 rows): the scan sizes
-    the list from the count and selects again from the kept scores."""
+    """More hits than the pooled hit list holds (threshold 1: every one of 1.2e6 rows).  The scan stores no scores (round 5):
+    the score kernel counts what its list could not hold, the library grows the list from that count and asks for the scan
+    again (GFM_ERR_OVERFLOW), StreamScan runs both phases once more -- the same rows as the oracle's.  Also with a q-value
+    threshold, where the list that overflows is the one of the p < t candidates."""
     from grafimo_amd import synth
     from grafimo_amd.device import DeviceMotif
     from grafimo_amd.score_sequences import StreamScan
@@ -200,7 +202,58 @@ def test_streamed_scan_grows_its_hit_list(tmp_path, golden_motifs):
     assert sc.n == 1_200_000 and len(exp) > (1 << 20)
     assert np.array_equal(sc.rows, exp) and np.array_equal(sc.scaled, exp_sc[exp])
     assert np.array_equal(sc.kmers, batch.kmers[order][exp])
+    nv_lib.gfm_scan_release_buffers()                   # the default capacity again
+    sq = StreamScan(dm, files, False, 4, 1.0, True, True, chunk_rows=256 * 1024)      # q < 1: the candidates are all p < 1 rows
+    q = orc.fdr_bh(exp_p)
+    exp_q = np.nonzero(q < 1.0)[0]
+    assert len(exp_q) > (1 << 20) and np.array_equal(sq.rows, exp_q) and np.allclose(sq.qvalue, q[exp_q], rtol=1e-12, atol=0)
     dm.close()
+
+
+def test_a_closed_scan_leaves_o_chunk_memory_behind(tmp_path):
+    """host text arena, 8 bytes of host memory per row and device score blocks stayed O(dataset) for the
+    life of the process.  Now no score is stored at all, and what a closed scan keeps is bounded (GRAFIMO_SCAN_KEEP_BYTES;
+    here 8 MiB): after compute_results over 3e6 rows (270 MB of text) the process holds neither the text nor per-row host
+    memory nor per-row device memory -- resident set and free HBM are back to within a chunk's worth of where they were."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = """
+import contextlib, io, os, sys, resource
+sys.path.insert(0, %r)
+import numpy as np, torch
+from grafimo_amd import synth
+from grafimo_amd.motif_ops import build_motif_meme_host
+from grafimo_amd.score_sequences import compute_results
+from grafimo_amd.workflow import Findmotif
+def rss():
+    return int(open('/proc/self/statm').read().split()[1]) * os.sysconf('SC_PAGE_SIZE')
+motif = build_motif_meme_host(os.path.join(%r, 'MA0139.1.meme'), 'unfrm_dst', 0.1, False)[0]
+d = sys.argv[1]
+batch = synth.make_batch(1500, 2000, 19, np.asarray(motif.count_matrix, dtype=np.float64), synth.seed_for(2))
+synth.write_tsv_dir(batch, d, regions_per_file=10)
+del batch
+text_bytes = sum(os.path.getsize(os.path.join(d, 'width_19', f)) for f in os.listdir(os.path.join(d, 'width_19')))
+wf = Findmotif(cores=8, threshold=1e-3)
+with contextlib.redirect_stdout(io.StringIO()):
+    small = compute_results(motif, d, False, Findmotif(cores=8, threshold=1e-9))      # warm: runtime, streams, slots
+torch.cuda.synchronize()
+free0, rss0 = torch.cuda.mem_get_info()[0], rss()
+with contextlib.redirect_stdout(io.StringIO()):
+    df = compute_results(motif, d, False, wf)
+torch.cuda.synchronize()
+free1, rss1 = torch.cuda.mem_get_info()[0], rss()
+print('ROWS', 3000000, 'HITS', len(df), 'TEXT', text_bytes, 'RSS_DELTA', rss1 - rss0, 'HBM_DELTA', free0 - free1)
+"""
+    from conftest import REF_DATA
+    r = subprocess.run([sys.executable, "-c", code % (ROOT, REF_DATA), str(tmp_path)], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, GRAFIMO_SCAN_KEEP_BYTES=str(8 << 20)))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    f = r.stdout.split()
+    val = {f[i]: int(f[i + 1]) for i in range(0, len(f), 2)}
+    assert val["TEXT"] > 250_000_000 and val["HITS"] > 1000
+    assert val["RSS_DELTA"] < 96 << 20, val            # (the text alone is 270 MB, the line offsets 24 MB)
+    assert val["HBM_DELTA"] < 64 << 20, val            # (3e6 int32 scores would be 12 MB per motif -- and are not there)
 
 
 def test_sharded_entry_point_on_one_gpu(golden_json):
@@ -569,6 +622,7 @@ def test_two_ranks_on_one_gpu_through_the_sharded_entry_points():
                        text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     assert r.stdout.count("two ranks == one process: True") == 9
+    assert r.stdout.count("ranks holding shards of the graph == one process with all of it: True") == 8
 
 
 def test_hit_columns_from_the_kept_text_and_from_the_files_agree(tmp_path, monkeypatch):
@@ -628,6 +682,7 @@ def test_two_ranks_one_file_leaves_a_rank_without_files():
                        capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     assert r.stdout.count("two ranks == one process: True") == 9
+    assert r.stdout.count("ranks holding shards of the graph == one process with all of it: True") == 8
 
 
 @pytest.mark.timeout(900)
@@ -641,6 +696,7 @@ def test_four_ranks_on_one_gpu_through_the_sharded_entry_points():
                        capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     assert r.stdout.count("ranks == one process: True") == 9
+    assert r.stdout.count("ranks holding shards of the graph == one process with all of it: True") == 8
 
 
 @pytest.mark.timeout(900)

@@ -678,3 +678,59 @@ def test_single_stream_path_is_graph_capturable(dev, golden_motifs):
     assert torch.equal(sc, ref[0]) and torch.equal(hits.sort().values, ref[1])
     assert torch.equal(q, ref[2]) and int(nr) == ref[3] == n
     dm.close()
+
+
+def test_no_score_store_leaves_histogram_and_hits_unchanged(golden_motifs):
+    """gfm_score_kmers / gfm_score_kmers_multi with d_scores == NULL (what the product's scans pass: with a threshold the
+    cutoff is known before scoring, nothing ever reads the int32 [N] array): histograms and hit lists equal the ones of the
+    call that stores the scores -- and the oracle's -- for 1, 2 and 3 motifs per launch, ragged row counts included."""
+    import ctypes
+    from grafimo_amd import _native as nv
+    from grafimo_amd import synth
+    from grafimo_amd.device import DeviceMotif
+    from oracle import oracle as orc
+    _, flat = golden_motifs
+    g = flat["ctcf_meme_unif#0"]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    recs = [synth.synthetic_motif(19, rng, np.full(4, 0.25)) for _ in range(3)]
+    dms = [DeviceMotif(r["sm"], r["bg"], r["min_val"], r["scale"], r["offset"]) for r in recs]
+    for n in (1_000_003, 777, 256 * 50):
+        batch = synth.make_batch(max(1, n // 2000 + 1), 2000, 19, g["probs"], synth.seed_for(3))
+        km = np.ascontiguousarray(batch.kmers[:n])
+        d_k = torch.from_numpy(km).to(dev)
+        for M in (1, 2, 3):
+            outs = []
+            for store in (True, False):
+                scores = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(M)] if store else None
+                hists = [torch.zeros(dms[j].L, dtype=torch.int64, device=dev) for j in range(M)]
+                hits = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(M)]
+                counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(M)]
+                cuts = [dms[j].pvalue_cutoff(1e-2) for j in range(M)]
+                vp = ctypes.c_void_p
+                arr = lambda ts: (vp * M)(*[t.data_ptr() for t in ts])      # noqa: E731
+                if M == 1:
+                    nv.check(nv.lib().gfm_score_kmers(dms[0].handle, d_k.data_ptr(), n, scores[0].data_ptr() if store else None,
+                                                      hists[0].data_ptr(), cuts[0], 0, hits[0].data_ptr(), n, counts[0].data_ptr(),
+                                                      nv.GFM_FLAG_RESET_HITS, None, None))
+                else:
+                    nv.check(nv.lib().gfm_score_kmers_multi((vp * M)(*[d.handle for d in dms[:M]]), M, d_k.data_ptr(), n,
+                                                            arr(scores) if store else None, arr(hists), (ctypes.c_int32 * M)(*cuts), 0,
+                                                            arr(hits), (ctypes.c_int64 * M)(*([n] * M)), arr(counts),
+                                                            nv.GFM_FLAG_RESET_HITS, None))
+                torch.cuda.synchronize()
+                outs.append(([h.cpu().numpy() for h in hists],
+                             [np.sort(hits[j][:int(counts[j].item())].cpu().numpy()) for j in range(M)]))
+            for j in range(M):
+                assert np.array_equal(outs[0][0][j], outs[1][0][j]), (n, M, j)
+                assert np.array_equal(outs[0][1][j], outs[1][1][j]) and len(outs[1][1][j]) > 0, (n, M, j)
+                ptab = orc.p_table(orc.comp_pval_mat(recs[j]["sm"], recs[j]["bg"]))
+                exp_sc, _ = orc.score_kmers_table(km, recs[j]["sm"], ptab, recs[j]["min_val"])
+                assert np.array_equal(outs[1][0][j], np.bincount(exp_sc, minlength=dms[j].L)), (n, M, j)
+    for d in dms:
+        d.close()
+    # nothing to do at all is refused
+    dm = DeviceMotif(recs[0]["sm"], recs[0]["bg"], recs[0]["min_val"], recs[0]["scale"], recs[0]["offset"])
+    d_k = torch.zeros((256, 19), dtype=torch.uint8, device=dev)
+    assert nv.lib().gfm_score_kmers(dm.handle, d_k.data_ptr(), 256, None, None, nv.GFM_NO_SELECT, 0, None, 0, None, 0, None, None) == nv.GFM_ERR_INVALID
+    dm.close()
