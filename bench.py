@@ -132,6 +132,8 @@ def dry_run(args, rank, world):
                           "scaling": "weak", "vs_baseline": None, "dtype": "int32",
                           "data": "dry run: launcher and process-group plumbing only, no GPU work",
                           "rccl_world": world, "rank_ms_per_step": [float(t.item()) for t in per_rank],
+                          # what every rank would hold of the sharded product paths (product_paths at N > 1): host-side plan
+                          "product_paths": shard_plan(world),
                           "config": {"workload": "none (--dry-run)"}}), flush=True)
     if world > 1:
         dist.barrier()
@@ -456,6 +458,104 @@ def extract_block(ctcf, dev, n_regions=10_000):
                 "q-table + gfm_graph_annotate (columns of the hit rows only) -> table; fused_ms = gfm_graph_score alone; "
                 "emit_ms / written_GBps / frac = the materialising gfm_graph_emit kept for write_region_tsvs",
     }
+
+
+GRAPH_REGIONS_PER_RANK = 4000      # product_paths: regions of the synthetic chromosome per rank (weak scaling)
+SCAN_REGIONS_PER_RANK = 400        # ... and TSV files (2 000 rows each) per rank
+
+
+def shard_plan(world, cores_flag=0):
+    """What every rank of an N-rank run holds of the two sharded product paths -- computable without a GPU (bench.py
+    --dry-run prints it; tests/test_bench_launcher.py checks it): regions and site records of the graph per rank
+    (extract_regions.shard_index), TSV files and parse threads per rank (distributed.shard_files / _parse_threads)."""
+    from grafimo_amd import synth
+    from grafimo_amd.distributed import _parse_threads, shard_bounds
+    from grafimo_amd.extract_regions import shard_index
+    idx, regions = synth.make_graph_index(min(GRAPH_REGIONS_PER_RANK, 500) * world, 19, with_counts=False)
+    reg = np.asarray(regions, dtype=np.int64)
+    sites, n_reg = [], []
+    for r in range(world):
+        lo, hi = shard_bounds(len(reg), world, r)
+        n_reg.append(int(hi - lo))
+        sites.append(int(len(shard_index(idx, reg[lo:hi, 0], reg[lo:hi, 1]).pos)) if world > 1 else int(len(idx.pos)))
+    return {"graph_path": {"regions_per_rank": n_reg, "sites_per_rank": sites, "sites_total": int(len(idx.pos))},
+            "streamed_scan": {"files_per_rank": [int(shard_bounds(SCAN_REGIONS_PER_RANK * world, world, r)[1] -
+                                                     shard_bounds(SCAN_REGIONS_PER_RANK * world, world, r)[0]) for r in range(world)],
+                              "parse_threads_per_rank": [_parse_threads(cores_flag, world)] * world,
+                              "host_cores": os.cpu_count() or 1}}
+
+
+def product_paths_block(ctcf, dev, rank, world):
+    """N > 1: the fused graph path and the streamed scan under the run's process group (weak scaling: every rank brings
+    GRAPH_REGIONS_PER_RANK regions / SCAN_REGIONS_PER_RANK files).  Rank 0 reports; every rank takes part."""
+    import shutil
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from grafimo_amd import synth
+    from grafimo_amd.distributed import compute_results_sharded
+    from grafimo_amd.extract_regions import _SHARD_GRAPHS, compute_results_from_graph, drop_graph_cache
+    from grafimo_amd.workflow import Findmotif
+    W = ctcf.width
+    out = {}
+    sink = io.StringIO()
+    # ---- graph path: the HOST index is handed over; a rank uploads the part of the graph its regions can meet
+    idx, regions = synth.make_graph_index(GRAPH_REGIONS_PER_RANK * world, W)
+    reg = np.asarray(regions, dtype=np.int64)
+    wf = Findmotif(cores=1, threshold=1e-4)
+    ts = []
+    with contextlib.redirect_stdout(sink):
+        for _ in range(8):
+            dist.barrier()
+            t = time.perf_counter()
+            df = compute_results_from_graph(ctcf, idx, reg, False, wf)
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t)
+    mine = [g for g in _SHARD_GRAPHS.values() if g._source is idx]
+    n_rows = torch.tensor([int(mine[0].fused_results()[1]) if mine else 0], dtype=torch.int64, device=dev)
+    sites = torch.tensor([len(mine[0].index.pos) if mine else 0], dtype=torch.int64, device=dev)
+    t_max = torch.tensor([float(np.median(ts[2:]))], dtype=torch.float64, device=dev)
+    dist.all_reduce(n_rows)
+    dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    per_rank_sites = [torch.zeros_like(sites) for _ in range(world)]
+    dist.all_gather(per_rank_sites, sites)
+    out["graph_path"] = {"regions": int(len(reg)), "rows": int(n_rows.item()), "compute_results_from_graph_ms": 1e3 * float(t_max.item()),
+                         "rows_per_s": int(n_rows.item()) / float(t_max.item()), "hits": int(len(df)) if df is not None else None,
+                         "sites_total": int(len(idx.pos)), "sites_per_rank": [int(x.item()) for x in per_rank_sites],
+                         "what": "compute_results_from_graph(motif, GraphIndex, regions) on every rank: regions sharded, each rank "
+                                 "uploads its shard of the graph (shard_index), one all-reduce of the histogram, hit rows gathered; "
+                                 "median of 6 calls, MAX over ranks"}
+    drop_graph_cache()
+    # ---- streamed scan: every rank writes its own files, then compute_results_sharded over the whole directory
+    tmp = tempfile.mkdtemp(prefix="gfm_bench_scan_") if rank == 0 else None
+    box = [tmp]
+    dist.broadcast_object_list(box, src=0)
+    tmp = box[0]
+    try:
+        batch = synth.make_batch(SCAN_REGIONS_PER_RANK, 2000, W, np.asarray(ctcf.count_matrix, dtype=np.float64), synth.seed_for(2, rank),
+                                 region_base=rank * SCAN_REGIONS_PER_RANK)       # (file names are made from the region numbers)
+        synth.write_tsv_dir(batch, tmp)
+        dist.barrier()
+        wf = Findmotif(cores=0, threshold=1e-4)
+        ts = []
+        with contextlib.redirect_stdout(sink):
+            for _ in range(5):
+                dist.barrier()
+                t = time.perf_counter()
+                df = compute_results_sharded(ctcf, tmp, False, wf)
+                ts.append(time.perf_counter() - t)
+        t_max = torch.tensor([float(np.median(ts[1:]))], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        n = SCAN_REGIONS_PER_RANK * 2000 * world
+        out["streamed_scan"] = {"files": SCAN_REGIONS_PER_RANK * world, "rows": n, "compute_results_sharded_ms": 1e3 * float(t_max.item()),
+                                "rows_per_s": n / float(t_max.item()), "hits": int(len(df)) if df is not None else None,
+                                "what": "compute_results_sharded over one directory: files split over the ranks, gfm_scan_tsv_begin per "
+                                        "rank, all-reduce of the histogram, gfm_scan_tsv_finish, hit rows gathered; median of 4, MAX over ranks"}
+    finally:
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def fused_issue_roofline(kernel_us):
@@ -908,6 +1008,13 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
     assert n_hits > 0
 
     extras = {}
+    if use_dist and cfg in (2, 3) and not args.no_extras:
+        # the two other PRODUCT paths under the same process group, so that a scaling run says something about all three: the
+        # fused graph path (every rank uploads its shard of the graph) and the streamed TSV scan (every rank its files)
+        try:
+            extras["product_paths"] = product_paths_block(ctcf, dev, rank, world)
+        except Exception as e:                   # (side measurements: they must not take the bench line with them)
+            extras["product_paths"] = {"error": f"{type(e).__name__}: {e}"}
     if default_n1 and not args.no_extras:
         W = mots[0]["width"]
         # (c) what this device sustains for a bare stream of the kernel's byte mix (76 B in / 16 B out per lane-step)
@@ -920,6 +1027,35 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
                       "interleaved, one step prefetched; output rotating over three buffers",
             "in_bytes": n * W, **cal,
             "GBps": max(c["GBps"] for c in cal.values()), "unit": "GB/s"}
+        # (c') the same launch WITHOUT the score store (d_scores == NULL: what the product's scans run -- with a threshold the
+        # cutoff is known before scoring and nothing ever reads the int32 [N] array): N x W bytes instead of N x (W + 4).
+        # A side block: the contract's metric counts the score store, `value` keeps it.
+        try:
+            hist0 = torch.zeros(dms[0].L, dtype=torch.int64, device=dev)
+            rows0 = torch.empty(max(4096, n // 64), dtype=torch.int64, device=dev)
+            cnt0 = torch.zeros(1, dtype=torch.int64, device=dev)
+            cut0 = dms[0].pvalue_cutoff(args.threshold)
+            for i_ in range(3):
+                dms[0].score(bufs[i_ % rotate], None, hist=hist0, select_cutoff=cut0, hit_rows=rows0, hit_count=cnt0, reset_hits=True)
+            fence()
+            dms[0].profile_enable(20, every=1)
+            t0 = time.perf_counter()
+            for i_ in range(20):                 # (input buffers rotated like the main loop's)
+                dms[0].score(bufs[i_ % rotate], None, hist=hist0, select_cutoff=cut0, hit_rows=rows0, hit_count=cnt0, reset_hits=True)
+            fence()
+            el0 = time.perf_counter() - t0
+            k0 = dms[0].profile_read()
+            dms[0].profile_enable(0)
+            k0_ms = float(np.mean(k0))
+            extras["roofline_noscore"] = {
+                "what": "gfm_score_kmers with d_scores == NULL on the same 2e7 k-mers: histogram + hit list, no score array",
+                "kernel": f"score_quad_kernel<{W}, 1>", "kernel_ms_avg": k0_ms, "ms_per_step": 1e3 * el0 / 20,
+                "kmers_per_s": n * 20 / el0, "algorithmic_bytes_per_launch": n * W,
+                "achieved": n * W / (k0_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": n * W / (k0_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "hits": int(cnt0.item())}
+            del hist0, rows0, cnt0
+        except Exception as e:                   # (a side measurement: it must not take the bench line with it)
+            extras["roofline_noscore"] = {"error": f"{type(e).__name__}: {e}"}
         # (b) sustained: back-to-back steps for >= sustained_s seconds, one timing event per 100 steps
         per = 100
         blocks = max(2, int(args.sustained_s / (np.median(burst_s) / args.steps) / per) + 1)
@@ -1130,12 +1266,16 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
                              f"sized from the observed hit counts) per step") if world > 1 else "single GPU",
             },
             "roofline": roofline,
+            "roofline_noscore": extras.get("roofline_noscore"),
             "roofline_config3": extras.get("roofline_config3"),
             "roofline_config4": extras.get("roofline_config4"),
             "roofline_config5": extras.get("roofline_config5"),
             "sustained": extras.get("sustained"),
             "peak_measured": extras.get("peak_measured"),
             "extract": extras.get("extract"),
+            "extract_config4": extras.get("extract_config4"),
+            "extract_config5": extras.get("extract_config5"),
+            "product_paths": extras.get("product_paths"),
             "strand_max": extras.get("strand_max"),
             "pcie_inclusive": extras.get("pcie_inclusive"),
             "cpu_baseline": cpu.get("cpu_baseline"),

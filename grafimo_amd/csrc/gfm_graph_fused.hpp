@@ -280,19 +280,20 @@ __device__ __forceinline__ WinInfo classify_window(const GraphDev &g, const S &s
 // sixteen wavefronts share a CU where two of eight did.
 constexpr int kWaveQueue = 96;
 constexpr int kOwnerSlots = 256;
-template <int MM, bool LISTING> struct WaveLdsT {
+template <int MM, bool LISTING, bool GENERAL> struct WaveLdsT {
     SiteRec rec[kWaveSites];
-    int reach[kWaveSites];
     // per window, ONE 8-byte read in phase 2: .x = first site - i_lo | sites of layout A << 16 | of layout B << 24;
     // .y = invalid bases of the reference window | layout A's walks << 7 | number of the window's first phase-2 walk << 14
     uint2 winfo[kTileWin];
     unsigned wsc[MM][kTileWin];           // the reference window's score per motif (both strands packed)
-    unsigned score_b[MM][kTileWin];       // one-deletion windows: the score of the walk that jumps, all else reference
-    unsigned sinfo[kTileWin];             // ... its invalid bases | the anchor's index in the window << 8 | deleted bases << 16
     unsigned short incl[kTileWin];        // inclusive scan of the windows' phase-2 walks (<= 64 x 127)
     unsigned char owner[kOwnerSlots];     // tiles of up to that many phase-2 walks: the window of walk number x (else: a search over incl[])
     unsigned char ref[kWaveRefBytes];
-    DelWin queue[LISTING ? kWaveQueue : 1];
+    // only the kernel of the tiles that may hold insertions / deletions (GENERAL) needs what follows:
+    int reach[GENERAL ? kWaveSites : 1];
+    unsigned score_b[MM][GENERAL ? kTileWin : 1];       // one-deletion windows: the score of the walk that jumps, all else reference
+    unsigned sinfo[GENERAL ? kTileWin : 1];             // ... its invalid bases | the anchor's index in the window << 8 | deleted bases << 16
+    DelWin queue[(LISTING && GENERAL) ? kWaveQueue : 1];
 };
 __host__ __device__ constexpr int fused_tab_dwords(int MM, int W) { return (MM * W * 8 + 3) & ~3; }
 
@@ -309,15 +310,18 @@ __host__ __device__ constexpr int fused_tab_dwords(int MM, int W) { return (MM *
 // allele: walk 0 of every window, two walks in three at 1000-Genomes density) is booked right there.  Phase 2, lane per walk
 // with an alternate allele: digits, the score adjusted per allele.
 #ifndef GFM_GRAPH_SCORE_MIN_WAVES        // wavefronts per SIMD the compiler must leave room for (registers); lab builds vary it
-#define GFM_GRAPH_SCORE_MIN_WAVES 1
+#define GFM_GRAPH_SCORE_MIN_WAVES 6
 #endif
-template <int MM, bool LISTING>
-__global__ void __launch_bounds__(kFusedMaxWaves * 64, GFM_GRAPH_SCORE_MIN_WAVES)
-graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int n_tiles,
+// Two instantiations share the tiles of a call: GENERAL = false takes the PURE tiles (substitution sites only: four in five) with
+// none of the insertion / deletion machinery compiled in -- fewer registers, more wavefronts per SIMD -- and GENERAL = true the
+// rest; the host sorts the tile table into the two ranges [tile_begin, n_tiles).
+template <int MM, bool LISTING, bool GENERAL>
+__global__ void __launch_bounds__(kFusedMaxWaves * 64, (GENERAL || LISTING) ? 1 : GFM_GRAPH_SCORE_MIN_WAVES)
+graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int tile_begin, int n_tiles,
                    DelWin *__restrict__ del_wins, int *__restrict__ del_count, int *__restrict__ overflow,
                    HeavyWin *__restrict__ heavy_wins, unsigned long long *__restrict__ heavy_ctl, int *__restrict__ plan_overflow_w)
 {
-    using WL = WaveLdsT<MM, LISTING>;
+    using WL = WaveLdsT<MM, LISTING, GENERAL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
     const int W = a.W, W8 = W * 8;
     const int nw = (int)(blockDim.x >> 6), n_thr = (int)blockDim.x;
@@ -353,10 +357,12 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);     // (+1: the record that ends a window's site scan)
         if (lane < staged) {
             f.r0 = packed_site(g, t.i_lo + lane);
-            if (g.n_dels > 0 && !(t.n_win & kTilePure)) {
-                const int i = t.i_lo + lane;
-                const long long r = (i <= g.n_sites ? g.max_reach[i] : -1ll) - t.p0;
-                f.reach0 = (int)max(-1ll, min(r, 0x7fffffffll));
+            if constexpr (GENERAL) {
+                if (g.n_dels > 0 && !(t.n_win & kTilePure)) {
+                    const int i = t.i_lo + lane;
+                    const long long r = (i <= g.n_sites ? g.max_reach[i] : -1ll) - t.p0;
+                    f.reach0 = (int)max(-1ll, min(r, 0x7fffffffll));
+                }
             }
         }
         if (lane < kWaveRefBytes / 8) {
@@ -372,10 +378,13 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
     };
     auto commit = [&](const Tile &t, const TilePf &f) {
         const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);
-        if (lane < staged) { wl->rec[lane] = f.r0; wl->reach[lane] = f.reach0; }
+        if (lane < staged) {
+            wl->rec[lane] = f.r0;
+            if constexpr (GENERAL) wl->reach[lane] = f.reach0;
+        }
         if (lane < kWaveRefBytes / 8) *reinterpret_cast<unsigned long long *>(wl->ref + 8 * lane) = f.refw;
     };
-    int ti = (int)blockIdx.x * nw + wave;
+    int ti = tile_begin + (int)blockIdx.x * nw + wave;
     // The record of the tile after next travels as a VECTOR load, a dword per lane, and is put together from the lanes when
     // it is needed: as the scalar load the compiler makes of `tiles[uniform index]` it shares its counter with the LDS
     // reads, and the first LDS read of a tile waited for it (scalar loads return out of order: lgkmcnt(0)).
@@ -533,7 +542,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
                 }
                 bad_a = bad;
             }
-            if (walks_b > 0) {              // ... and the one of the walk that jumps the deletion
+            if constexpr (!PURE) if (walks_b > 0) {              // ... and the one of the walk that jumps the deletion
                 unsigned sum[MM];
 #pragma unroll
                 for (int m = 0; m < MM; ++m) sum[m] = 0u;
@@ -569,7 +578,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
             rows_done += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(has_ref)) * (a.forward_only ? 1ull : 2ull);
         }
         // listed windows -> this wavefront's queue; 64 and more of them go to graph_score_del_kernel's list at once
-        if constexpr (LISTING) {
+        if constexpr (LISTING && !PURE) {
             const unsigned long long lm = __builtin_amdgcn_ballot_w64(listed);
             if (lm) {
                 if (listed) wl->queue[q_n + __popcll(lm & ((1ull << lane) - 1ull))] = DelWin{ti | (lane << kDelTileBits), i0};
@@ -655,7 +664,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
                             bad += (int)(ca >> 2) - (int)(cr >> 2);
                         }
                     }
-                } else {
+                } else if constexpr (!PURE) {
                     q = (long long)wa + (qq - nA_k);
 #pragma unroll
                     for (int m = 0; m < MM; ++m) sum[m] = wl->score_b[m][k];
@@ -695,9 +704,13 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         }
         rows_done += (unsigned long long)total * (a.forward_only ? 1ull : 2ull);
         };
-        if (t.n_win & kTilePure) work(LdsTileSites{wl->rec, wl->reach, t.p0, t.i_lo}, std::true_type{});
-        else if (t.i_far - t.i_lo + 1 <= kWaveSites) work(LdsTileSites{wl->rec, wl->reach, t.p0, t.i_lo}, std::false_type{});
-        else work(TileSites{g, wl->rec, wl->reach, t.p0, t.i_lo, staged}, std::false_type{});
+        if constexpr (!GENERAL) {
+            work(LdsTileSites{wl->rec, nullptr, t.p0, t.i_lo}, std::true_type{});          // (the host hands this kernel pure tiles only)
+        } else {
+            if (t.n_win & kTilePure) work(LdsTileSites{wl->rec, wl->reach, t.p0, t.i_lo}, std::true_type{});
+            else if (t.i_far - t.i_lo + 1 <= kWaveSites) work(LdsTileSites{wl->rec, wl->reach, t.p0, t.i_lo}, std::false_type{});
+            else work(TileSites{g, wl->rec, wl->reach, t.p0, t.i_lo, staged}, std::false_type{});
+        }
         __builtin_amdgcn_wave_barrier();       // the tile's LDS is free again
         lap(4, tk0);                  // 12: phase 2
         lap(5, tk_tile);                       // 13: the whole tile
@@ -721,7 +734,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         blk_q[nw] = left ? atomicAdd(del_count, left) : 0;
     }
     __syncthreads();
-    if constexpr (LISTING) {
+    if constexpr (LISTING && GENERAL) {
         int at = blk_q[nw];
         for (int k = 0; k < wave; ++k) at += blk_q[k];
         for (int i = lane; i < q_n; i += 64) del_wins[at + i] = wl->queue[i];

@@ -1196,7 +1196,7 @@ struct gfm_graph {
     int prof_on = 0, prof_n = 0;
     std::vector<int> h_indel_prefix;     // [n_sites + 1] insertion / deletion records among sites [0, i) (pure tiles; made on first use)
     std::vector<long long> f_starts, f_stops;   // the regions the device tile table was built for (reused while they repeat)
-    int f_width = 0, f_n_tiles = 0;
+    int f_width = 0, f_n_tiles = 0, f_n_general = 0;     // tiles [0, f_n_general): may hold insertions / deletions; the rest: pure
     long long f_n_windows = 0;
     Buf<Tile> f_tiles;
     Tile *h_tiles = nullptr;             // pinned staging of the tile table
@@ -1832,9 +1832,9 @@ Shape pick_shape(int vgprs, size_t lds_fixed, size_t lds_per_wave)
 }
 
 template <int MM> struct FusedKernels {
-    static KernelInfo score[2], heavy, del_score;
+    static KernelInfo score[2][2], heavy, del_score;       // [listing][general]
 };
-template <int MM> KernelInfo FusedKernels<MM>::score[2];
+template <int MM> KernelInfo FusedKernels<MM>::score[2][2];
 template <int MM> KernelInfo FusedKernels<MM>::heavy;
 template <int MM> KernelInfo FusedKernels<MM>::del_score;
 
@@ -1856,15 +1856,27 @@ template <int MM> int launch_fused(FusedLaunch &L)
     const int W = a.W, n_cu = L.n_cu;
     const size_t tab_bytes = sizeof(unsigned) * (size_t)fused_tab_dwords(MM, W), hist_bytes = sizeof(unsigned) * (size_t)a.slab_stride;
     using FK = FusedKernels<MM>;
-    // ---- graph_score_kernel
-    KernelInfo &ks = FK::score[L.listing ? 1 : 0];
-    const void *fn_score = L.listing ? reinterpret_cast<const void *>(graph_score_kernel<MM, true>)
-                                     : reinterpret_cast<const void *>(graph_score_kernel<MM, false>);
-    if (const int rc = kernel_prepare(ks, fn_score)) return rc;
-    const size_t wave_bytes = L.listing ? sizeof(WaveLdsT<MM, true>) : sizeof(WaveLdsT<MM, false>);
-    const Shape sh = pick_shape(ks.vgprs, tab_bytes + hist_bytes + 16, wave_bytes + sizeof(long long) + sizeof(int));
-    const int g1 = std::max(1, std::min((g->f_n_tiles + sh.waves - 1) / sh.waves, sh.per_cu * n_cu));
-    const size_t lds1 = tab_bytes + (size_t)sh.waves * wave_bytes + sizeof(long long) * (size_t)sh.waves + sizeof(int) * (size_t)(sh.waves + 2) + hist_bytes;
+    // ---- graph_score_kernel, twice: over the tiles that may hold insertions / deletions, then -- its lean instantiation -- over
+    // the pure ones (the host sorted the table into the two ranges)
+    struct Part { int begin, end, grid; Shape sh; size_t lds; } part[2];
+    for (int general = 1; general >= 0; --general) {
+        KernelInfo &ks = FK::score[L.listing ? 1 : 0][general];
+        const void *fn = L.listing ? (general ? reinterpret_cast<const void *>(graph_score_kernel<MM, true, true>)
+                                              : reinterpret_cast<const void *>(graph_score_kernel<MM, true, false>))
+                                   : (general ? reinterpret_cast<const void *>(graph_score_kernel<MM, false, true>)
+                                              : reinterpret_cast<const void *>(graph_score_kernel<MM, false, false>));
+        if (const int rc = kernel_prepare(ks, fn)) return rc;
+        const size_t wave_bytes = L.listing ? (general ? sizeof(WaveLdsT<MM, true, true>) : sizeof(WaveLdsT<MM, true, false>))
+                                            : (general ? sizeof(WaveLdsT<MM, false, true>) : sizeof(WaveLdsT<MM, false, false>));
+        Part &pt = part[general];
+        pt.begin = general ? 0 : g->f_n_general;
+        pt.end = general ? g->f_n_general : g->f_n_tiles;
+        pt.sh = pick_shape(ks.vgprs, tab_bytes + hist_bytes + 16, wave_bytes + sizeof(long long) + sizeof(int));
+        const int n_t = pt.end - pt.begin;
+        pt.grid = n_t > 0 ? std::max(1, std::min((n_t + pt.sh.waves - 1) / pt.sh.waves, pt.sh.per_cu * n_cu)) : 0;
+        pt.lds = tab_bytes + (size_t)pt.sh.waves * wave_bytes + sizeof(long long) * (size_t)pt.sh.waves + sizeof(int) * (size_t)(pt.sh.waves + 2) + hist_bytes;
+    }
+    const int g1 = part[0].grid + part[1].grid;          // slab rows of the two launches: the general one's first
     // ---- graph_heavy_kernel: a grid that fills the chip whatever the number of tiles
     if (const int rc = kernel_prepare(FK::heavy, reinterpret_cast<const void *>(graph_heavy_kernel<MM>))) return rc;
     const Shape shh = pick_shape(FK::heavy.vgprs, tab_bytes + hist_bytes + 16, sizeof(HeavyLdsT<MM>) + sizeof(long long));
@@ -1874,12 +1886,18 @@ template <int MM> int launch_fused(FusedLaunch &L)
     a.slabs = g->f_slabs.p;
     const bool timed = g->prof_on && g->prof_n < gfm_graph::kProfSlots;
     if (timed) GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n], st));
-    if (L.listing) {
-        hipLaunchKernelGGL((graph_score_kernel<MM, true>), dim3((unsigned)g1), dim3((unsigned)sh.waves * 64), lds1, st, g->dev, a, g->f_tiles.p,
-                           g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_heavy.p, L.heavy_ctl, g->f_flags.p + 4);
-    } else {
-        hipLaunchKernelGGL((graph_score_kernel<MM, false>), dim3((unsigned)g1), dim3((unsigned)sh.waves * 64), lds1, st, g->dev, a, g->f_tiles.p,
-                           g->f_n_tiles, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_heavy.p, L.heavy_ctl, g->f_flags.p + 4);
+    for (int general = 1; general >= 0; --general) {
+        const Part &pt = part[general];
+        if (pt.grid == 0) continue;
+        FusedArgs ap = a;
+        ap.slabs = a.slabs + (general ? (size_t)0 : (size_t)part[1].grid * (size_t)a.slab_stride);
+        const dim3 grid((unsigned)pt.grid), block((unsigned)pt.sh.waves * 64);
+#define GFM_LAUNCH_SCORE(LST, GEN)                                                                                              \
+        hipLaunchKernelGGL((graph_score_kernel<MM, LST, GEN>), grid, block, pt.lds, st, g->dev, ap, g->f_tiles.p, pt.begin, pt.end, \
+                           g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_heavy.p, L.heavy_ctl, g->f_flags.p + 4)
+        if (L.listing) { if (general) GFM_LAUNCH_SCORE(true, true); else GFM_LAUNCH_SCORE(true, false); }
+        else { if (general) GFM_LAUNCH_SCORE(false, true); else GFM_LAUNCH_SCORE(false, false); }
+#undef GFM_LAUNCH_SCORE
     }
     GX_TRY(hipGetLastError());      // (before the event query below, whose "not ready" answer is cleared: a launch failure must not go with it)
     if (timed) { GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n + 1], st)); ++g->prof_n; }
@@ -2053,13 +2071,16 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
             for (size_t i = 0; i < n_tiles; ++i) {
                 const Tile &t = g->h_tiles[i];
                 const int sites = t.i_hi - t.i_lo;
-                order[i] = {-(((t.n_win & kTilePure) ? sites : 2 * sites + 8) * 64 + (t.n_win & 0xff)), (unsigned)i};
+                // (the tiles that may hold insertions / deletions first -- they are graph_score_kernel<.., GENERAL>'s -- then the pure ones)
+                order[i] = {((t.n_win & kTilePure) ? 0 : -(1 << 28)) - (sites * 64 + (t.n_win & 0xff)), (unsigned)i};
             }
             std::sort(order.begin(), order.end());
             std::vector<Tile> sorted(n_tiles);
             for (size_t i = 0; i < n_tiles; ++i) sorted[i] = g->h_tiles[order[i].second];
             std::memcpy(g->h_tiles, sorted.data(), sizeof(Tile) * n_tiles);
         }
+        g->f_n_general = 0;
+        for (size_t i = 0; i < n_tiles; ++i) g->f_n_general += (g->h_tiles[i].n_win & kTilePure) ? 0 : 1;
         GX_TRY(g->f_tiles.reserve(n_tiles + 1));
         if (n_tiles) {
             GX_TRY(hipMemcpyAsync(g->f_tiles.p, g->h_tiles, sizeof(Tile) * n_tiles, hipMemcpyHostToDevice, st));

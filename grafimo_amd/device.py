@@ -149,14 +149,14 @@ class DeviceMotif:
     # ---- device-pointer entry points (torch tensors as buffers)
     def score(self, kmers, scores, hist=None, select_cutoff=None, row_base=0, hit_rows=None,
               hit_count=None, stream=None, reset_hits=False, tail_stream=None):
-        """Enqueue gfm_score_kmers.  kmers uint8 [n,W] (cuda), scores int32 [n],
-        hist int64 [L] (accumulated), hit_rows int64 [cap], hit_count int64 [1]."""
+        """Enqueue gfm_score_kmers.  kmers uint8 [n,W] (cuda), scores int32 [n] or None (no score is stored: histogram
+        and hits only), hist int64 [L] (accumulated), hit_rows int64 [cap], hit_count int64 [1]."""
         n = int(kmers.shape[0])
         assert kmers.is_contiguous() and kmers.dtype == _torch().uint8
         assert n == 0 or kmers.shape[1] == self.width
         cut = nv.GFM_NO_SELECT if select_cutoff is None else int(select_cutoff)
         nv.check(nv.lib().gfm_score_kmers(
-            self._h, kmers.data_ptr() if n else None, n, scores.data_ptr() if n else None,
+            self._h, kmers.data_ptr() if n else None, n, scores.data_ptr() if (n and scores is not None) else None,
             hist.data_ptr() if hist is not None else None, cut, int(row_base),
             hit_rows.data_ptr() if hit_rows is not None else None,
             int(hit_rows.numel()) if hit_rows is not None else 0,

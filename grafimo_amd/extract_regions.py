@@ -1384,21 +1384,32 @@ def compute_results_from_graph_rows(motif: Motif, graph, regions, debug: bool, a
         # with a process group the scanner all-reduces the histogram before the q-table; hits stay local
         # (their metadata lives on this rank) and travel as finished table rows below
         # one batch: one slot; the hit list starts at a sixteenth of the rows (a full-size list is 8 bytes per row of
-        # allocation and zeroing for nothing) and is taken again at full size in the rare case it does not hold
-        # (with a process group the scanner's enqueue holds an all-reduce: a retry that only SOME ranks make would leave
-        # their collective sequences out of step -- there the list is full-size from the start)
-        cap = max(n, 1) if (world > 1 or always_collective) else max(4096, n // 16)
+        # allocation and zeroing for nothing -- many GB beside the materialised rows of a 2^31-row plan) and is taken again
+        # at full size in the rare case it does not hold.  With a process group the scanner's enqueue holds an all-reduce, so
+        # a retry is decided by ALL ranks together (the list used to be full-size from the start there): the
+        # ranks exchange "mine was too short" and repeat the pass on every rank or on none.
+        collective = world > 1 or always_collective
+        cap = max(4096, n // 16)
         while True:
             sc = KmerScanner(dm, max(n, 1), hit_capacity=cap, device=kmers.device, side_stream=False, group=group,
                              always_collective=always_collective, n_slots=1)
+            short = 0
             try:
                 res = sc.collect(sc.enqueue(kmers, threshold, on_qvalue=qval_t, want_qvalues=not no_qvalue),
                                  want_qvalues=not no_qvalue)
-                break
             except OverflowError:
-                if cap >= n:
+                if cap >= n and not collective:
                     raise
-                cap = n
+                short = 1
+            if collective:
+                flag = torch.tensor([short], dtype=torch.int64, device=kmers.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+                short = int(flag.item())
+            if not short:
+                break
+            if cap >= max(n, 1):
+                raise OverflowError("the hit list of a rank holds every row and still overflowed")
+            cap = max(n, 1)
         lo, pv = dm.annotate(res["scaled"])
     finally:
         dm.release()
