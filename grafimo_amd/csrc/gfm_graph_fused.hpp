@@ -316,7 +316,7 @@ __host__ __device__ constexpr int fused_tab_dwords(int MM, int W) { return (MM *
 // none of the insertion / deletion machinery compiled in -- fewer registers, more wavefronts per SIMD -- and GENERAL = true the
 // rest; the host sorts the tile table into the two ranges [tile_begin, n_tiles).
 template <int MM, bool LISTING, bool GENERAL>
-__global__ void __launch_bounds__(kFusedMaxWaves * 64, (GENERAL || LISTING) ? 1 : GFM_GRAPH_SCORE_MIN_WAVES)
+__global__ void __launch_bounds__(kFusedMaxWaves * 64, LISTING ? 1 : GFM_GRAPH_SCORE_MIN_WAVES)
 graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int tile_begin, int n_tiles,
                    DelWin *__restrict__ del_wins, int *__restrict__ del_count, int *__restrict__ overflow,
                    HeavyWin *__restrict__ heavy_wins, unsigned long long *__restrict__ heavy_ctl, int *__restrict__ plan_overflow_w)

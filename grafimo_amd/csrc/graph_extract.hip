@@ -1859,6 +1859,7 @@ template <int MM> int launch_fused(FusedLaunch &L)
     // ---- graph_score_kernel, twice: over the tiles that may hold insertions / deletions, then -- its lean instantiation -- over
     // the pure ones (the host sorted the table into the two ranges)
     struct Part { int begin, end, grid; Shape sh; size_t lds; } part[2];
+    static const int split = [] { const char *e = std::getenv("GRAFIMO_FUSED_SPLIT"); return e ? atoi(e) : 0; }();
     for (int general = 1; general >= 0; --general) {
         KernelInfo &ks = FK::score[L.listing ? 1 : 0][general];
         const void *fn = L.listing ? (general ? reinterpret_cast<const void *>(graph_score_kernel<MM, true, true>)
@@ -1869,8 +1870,12 @@ template <int MM> int launch_fused(FusedLaunch &L)
         const size_t wave_bytes = L.listing ? (general ? sizeof(WaveLdsT<MM, true, true>) : sizeof(WaveLdsT<MM, true, false>))
                                             : (general ? sizeof(WaveLdsT<MM, false, true>) : sizeof(WaveLdsT<MM, false, false>));
         Part &pt = part[general];
-        pt.begin = general ? 0 : g->f_n_general;
-        pt.end = general ? g->f_n_general : g->f_n_tiles;
+        // One launch of the GENERAL instantiation over all tiles is the default: it classifies pure tiles with the same lean
+        // code path, and the tiles that may hold insertions / deletions (a fifth of them, two to three times the cost each)
+        // fill a chip badly on their own -- split: 36.5 + 25.8 us against 49.7 us for the one launch (profiles/r05_fused_ab.txt).
+        // GRAFIMO_FUSED_SPLIT=1 (measurement aid) runs the two instantiations one after the other, =2 side by side on two streams.
+        pt.begin = general ? 0 : (split ? g->f_n_general : g->f_n_tiles);
+        pt.end = general ? (split ? g->f_n_general : g->f_n_tiles) : g->f_n_tiles;
         pt.sh = pick_shape(ks.vgprs, tab_bytes + hist_bytes + 16, wave_bytes + sizeof(long long) + sizeof(int));
         const int n_t = pt.end - pt.begin;
         pt.grid = n_t > 0 ? std::max(1, std::min((n_t + pt.sh.waves - 1) / pt.sh.waves, pt.sh.per_cu * n_cu)) : 0;
@@ -1886,9 +1891,15 @@ template <int MM> int launch_fused(FusedLaunch &L)
     a.slabs = g->f_slabs.p;
     const bool timed = g->prof_on && g->prof_n < gfm_graph::kProfSlots;
     if (timed) GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n], st));
+    const bool beside = split == 2 && part[0].grid > 0 && part[1].grid > 0;
+    if (beside) {
+        GX_TRY(hipEventRecord(g->ev_fork, st));
+        GX_TRY(hipStreamWaitEvent(g->side, g->ev_fork, 0));
+    }
     for (int general = 1; general >= 0; --general) {
         const Part &pt = part[general];
         if (pt.grid == 0) continue;
+        hipStream_t st = (beside && general) ? g->side : L.st;      // (shadows: the general tiles' launch goes to the side stream)
         FusedArgs ap = a;
         ap.slabs = a.slabs + (general ? (size_t)0 : (size_t)part[1].grid * (size_t)a.slab_stride);
         const dim3 grid((unsigned)pt.grid), block((unsigned)pt.sh.waves * 64);
@@ -1898,6 +1909,10 @@ template <int MM> int launch_fused(FusedLaunch &L)
         if (L.listing) { if (general) GFM_LAUNCH_SCORE(true, true); else GFM_LAUNCH_SCORE(true, false); }
         else { if (general) GFM_LAUNCH_SCORE(false, true); else GFM_LAUNCH_SCORE(false, false); }
 #undef GFM_LAUNCH_SCORE
+    }
+    if (beside) {
+        GX_TRY(hipEventRecord(g->ev_join, g->side));
+        GX_TRY(hipStreamWaitEvent(st, g->ev_join, 0));
     }
     GX_TRY(hipGetLastError());      // (before the event query below, whose "not ready" answer is cleared: a launch failure must not go with it)
     if (timed) { GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n + 1], st)); ++g->prof_n; }
