@@ -46,6 +46,7 @@ burst.  Rank 0 prints ONE JSON line.  Beside the contract's fields it carries
 """
 import argparse
 import contextlib
+import ctypes
 import io
 import json
 import multiprocessing as mp
@@ -630,16 +631,51 @@ def extract_config_block(cfg, dev):
                 ts_single.append(time.perf_counter() - t)
             same = all(len(a) == len(b) and bool((a["matched_sequence"].to_numpy() == b["matched_sequence"].to_numpy()).all())
                        and bool(np.array_equal(a["q-value"].to_numpy(), b["q-value"].to_numpy())) for a, b in zip(tabs, singles))
-            pairs = 0
-            for m in motifs:
-                pairs += 2 * sum(max(0, min(int(e), len(idx.ref)) - m.width - max(int(s), 0) + 1) for s, e in regions)   # (reference walks only: a lower bound)
             many_ms, single_ms = 1e3 * float(np.median(ts_many[1:])), 1e3 * float(min(ts_single))
+            # the DEVICE passes alone (the tables above are dominated by what the host does with 440 000 hit rows: records back,
+            # 50 DataFrames): gfm_graph_score_multi per group of <= 3 motifs of a width against gfm_graph_score per motif, HIP
+            # events around the enqueued calls, histograms and hit lists as in the product
+            from grafimo_amd.device import DeviceMotif
+            by_w = {}
+            for i, m in enumerate(motifs):
+                by_w.setdefault(m.width, []).append(i)
+            dms = [DeviceMotif.from_motif(m) for m in motifs]
+            hists = [torch.zeros(d.L, dtype=torch.int64, device=dev) for d in dms]
+            cuts = [d.pvalue_cutoff(1e-4) for d in dms]
+            starts, stops = np.ascontiguousarray(reg[:, 0]), np.ascontiguousarray(reg[:, 1])
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+            def pass_many():
+                for w, idxs in by_w.items():
+                    for c0 in range(0, len(idxs), 3):
+                        sl = idxs[c0:c0 + 3]
+                        g.score_many([dms[i] for i in sl], starts, stops, [cuts[i] for i in sl], [hists[i] for i in sl],
+                                     slots=list(range(len(sl))))
+
+            def pass_single():
+                for w, idxs in by_w.items():
+                    for i in idxs:
+                        g.score(dms[i], starts, stops, cuts[i], hist=hists[i])
+
+            for fn in (pass_many, pass_single):          # warm: plans of every width, kernels loaded
+                fn()
+            torch.cuda.synchronize(dev)
+            ev[0].record(); pass_many(); ev[1].record()
+            ev[2].record(); pass_single(); ev[3].record()
+            torch.cuda.synchronize(dev)
+            dev_many, dev_single = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])
+            rows_per_motif = int(g.fused_results()[1])
+            for d in dms:
+                d.close()
             out.update({"widths": sorted({m.width for m in motifs}), "many_ms": many_ms, "fifty_single_calls_ms": single_ms,
                         "speedup_vs_single_calls": single_ms / many_ms, "tables_equal": same, "hits": int(sum(len(t_) for t_ in tabs)),
-                        "reference_walk_pairs_lower_bound": int(pairs),
+                        "device_pass_many_ms": dev_many, "device_pass_fifty_single_ms": dev_single,
+                        "device_speedup_vs_single_passes": dev_single / dev_many, "rows_last_width": rows_per_motif,
                         "what": "BASELINE configs[4] through the graph: 50 PWMs (W = 8..25), 50 000 regions; many = one "
                                 "compute_results_from_graph_many call (<= 3 motifs of a width per enumeration, gfm_graph_score_multi), "
-                                "against one compute_results_from_graph call per motif"})
+                                "against one compute_results_from_graph call per motif; device_pass_* = the scoring passes alone "
+                                "(HIP events: the tile-table switches between widths included), many_ms / fifty_single_calls_ms = "
+                                "whole calls with their tables (host work on ~9 000 hit rows per motif dominates both)"})
     g.close()
     return out
 

@@ -1889,13 +1889,40 @@ template <int MM> int launch_fused(FusedLaunch &L)
     const size_t lds_h = tab_bytes + (size_t)shh.waves * sizeof(HeavyLdsT<MM>) + sizeof(long long) * (size_t)shh.waves + hist_bytes;
     GX_TRY(g->f_slabs.reserve((size_t)std::max(g1, g_heavy) * (size_t)std::max(1, a.slab_stride) + 1));
     a.slabs = g->f_slabs.p;
-    const bool timed = g->prof_on && g->prof_n < gfm_graph::kProfSlots;
-    if (timed) GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n], st));
+    // the listed windows' walks (graph_del_score_kernel: one wavefront per work item of the plan).  On every call but a plan's
+    // first the list, the layouts and the work items exist already: the kernel depends on nothing graph_score_kernel does and
+    // runs BESIDE it on the handle's side stream (20 us of a 90 us call, r05: latency-bound wavefronts that leave most of the
+    // chip idle on their own).  It books into the caller's histogram by global atomics and appends to the same hit lists.
+    auto launch_del_score = [&](hipStream_t on) -> int {
+        if (const int rc = kernel_prepare(FK::del_score, reinterpret_cast<const void *>(graph_del_score_kernel<MM>))) return rc;
+        int pitch = ((W + 3) / 4) * 4;
+        if ((pitch / 4) % 2 == 0) pitch += 4;         // an odd dword pitch: the lanes' slots fall on all LDS banks
+        const size_t lds_b = tab_bytes + sizeof(SiteRec) * kSiteCache * kFusedDelThreads +
+                             sizeof(LayoutRec) * kFusedDelThreads * kFusedLayouts + 3 * sizeof(long long) * kFusedDelThreads +
+                             3 * sizeof(int) * kFusedDelThreads + sizeof(int) * (size_t)kFusedDelThreads * W +
+                             (size_t)kFusedDelThreads * pitch;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 * 1024) / lds_b));
+        hipLaunchKernelGGL((graph_del_score_kernel<MM>), dim3((unsigned)(per_cu * n_cu)), dim3(kFusedDelThreads), lds_b, on, g->dev, a,
+                           g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_del_recs.p, g->f_del_items.p, g->f_flags.p + 3,
+                           pitch);
+        return GFM_OK;
+    };
+    static const bool serial = [] { const char *e = std::getenv("GRAFIMO_FUSED_SERIAL"); return e && *e == '1'; }();   // measurement aid
     const bool beside = split == 2 && part[0].grid > 0 && part[1].grid > 0;
-    if (beside) {
+    const bool del_beside = !L.listing && L.indels && !serial;
+    if (L.indels) {
+        const size_t n_batches = ((size_t)g->f_n_windows + kFusedDelThreads - 1) / kFusedDelThreads;
+        GX_TRY(g->f_del_recs.reserve(n_batches * kFusedDelThreads + 1));
+        GX_TRY(g->f_del_items.reserve(n_batches * kDelMaxItems + (size_t)kDelExtraItems + 1));
+    }
+    if (beside || del_beside) {
         GX_TRY(hipEventRecord(g->ev_fork, st));
         GX_TRY(hipStreamWaitEvent(g->side, g->ev_fork, 0));
     }
+    if (del_beside)
+        if (const int rc = launch_del_score(g->side)) return rc;
+    const bool timed = g->prof_on && g->prof_n < gfm_graph::kProfSlots;
+    if (timed) GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n], st));
     for (int general = 1; general >= 0; --general) {
         const Part &pt = part[general];
         if (pt.grid == 0) continue;
@@ -1909,10 +1936,6 @@ template <int MM> int launch_fused(FusedLaunch &L)
         if (L.listing) { if (general) GFM_LAUNCH_SCORE(true, true); else GFM_LAUNCH_SCORE(true, false); }
         else { if (general) GFM_LAUNCH_SCORE(false, true); else GFM_LAUNCH_SCORE(false, false); }
 #undef GFM_LAUNCH_SCORE
-    }
-    if (beside) {
-        GX_TRY(hipEventRecord(g->ev_join, g->side));
-        GX_TRY(hipStreamWaitEvent(st, g->ev_join, 0));
     }
     GX_TRY(hipGetLastError());      // (before the event query below, whose "not ready" answer is cleared: a launch failure must not go with it)
     if (timed) { GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n + 1], st)); ++g->prof_n; }
@@ -1939,31 +1962,22 @@ template <int MM> int launch_fused(FusedLaunch &L)
         g->f_plan_stream = st;
         GX_TRY(hipEventRecord(g->ev_plan, st));
     }
-    if (L.indels) {
-        // the listed windows' walks: count + cut into work items, then one wavefront per item (gfm_graph_fused.hpp)
-        const size_t n_batches = ((size_t)g->f_n_windows + kFusedDelThreads - 1) / kFusedDelThreads;
-        GX_TRY(g->f_del_recs.reserve(n_batches * kFusedDelThreads + 1));
-        GX_TRY(g->f_del_items.reserve(n_batches * kDelMaxItems + (size_t)kDelExtraItems + 1));
-        if (L.listing) {
-            const size_t lds_a = sizeof(SiteRec) * kSiteCache * kFusedDelThreads;
-            hipLaunchKernelGGL(graph_del_count_kernel, dim3((unsigned)(12 * n_cu)), dim3(kFusedDelThreads), lds_a, st, g->dev, W,
-                               g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_flags.p + 4, g->f_del_recs.p,
-                               g->f_del_items.p, g->f_flags.p + 3, g->f_flags.p + 5);
-            g->f_plan_ready = true;       // (stream order: the calls that follow on this stream find the plan complete)
-            g->f_plan_stream = st;
-            GX_TRY(hipEventRecord(g->ev_plan, st));
-        }
-        if (const int rc = kernel_prepare(FK::del_score, reinterpret_cast<const void *>(graph_del_score_kernel<MM>))) return rc;
-        int pitch = ((W + 3) / 4) * 4;
-        if ((pitch / 4) % 2 == 0) pitch += 4;         // an odd dword pitch: the lanes' slots fall on all LDS banks
-        const size_t lds_b = tab_bytes + sizeof(SiteRec) * kSiteCache * kFusedDelThreads +
-                             sizeof(LayoutRec) * kFusedDelThreads * kFusedLayouts + 3 * sizeof(long long) * kFusedDelThreads +
-                             3 * sizeof(int) * kFusedDelThreads + sizeof(int) * (size_t)kFusedDelThreads * W +
-                             (size_t)kFusedDelThreads * pitch;
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 * 1024) / lds_b));
-        hipLaunchKernelGGL((graph_del_score_kernel<MM>), dim3((unsigned)(per_cu * n_cu)), dim3(kFusedDelThreads), lds_b, st, g->dev, a,
-                           g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_del_recs.p, g->f_del_items.p, g->f_flags.p + 3,
-                           pitch);
+    if (L.indels && L.listing) {
+        // a plan's first call: the listed windows' layouts are counted and cut into work items (gfm_graph_fused.hpp), behind the
+        // score kernel that lists them
+        const size_t lds_a = sizeof(SiteRec) * kSiteCache * kFusedDelThreads;
+        hipLaunchKernelGGL(graph_del_count_kernel, dim3((unsigned)(12 * n_cu)), dim3(kFusedDelThreads), lds_a, st, g->dev, W,
+                           g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_flags.p + 4, g->f_del_recs.p,
+                           g->f_del_items.p, g->f_flags.p + 3, g->f_flags.p + 5);
+        g->f_plan_ready = true;       // (stream order: the calls that follow on this stream find the plan complete)
+        g->f_plan_stream = st;
+        GX_TRY(hipEventRecord(g->ev_plan, st));
+    }
+    if (L.indels && !del_beside)
+        if (const int rc = launch_del_score(st)) return rc;
+    if (beside || del_beside) {       // join: the histogram reduction and everything the caller enqueues next see the side stream's work
+        GX_TRY(hipEventRecord(g->ev_join, g->side));
+        GX_TRY(hipStreamWaitEvent(st, g->ev_join, 0));
     }
     for (int m = 0; m < MM; ++m)
         if (a.hnb[m] > 0)
