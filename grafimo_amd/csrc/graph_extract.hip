@@ -1890,9 +1890,10 @@ template <int MM> int launch_fused(FusedLaunch &L)
     GX_TRY(g->f_slabs.reserve((size_t)std::max(g1, g_heavy) * (size_t)std::max(1, a.slab_stride) + 1));
     a.slabs = g->f_slabs.p;
     // the listed windows' walks (graph_del_score_kernel: one wavefront per work item of the plan).  On every call but a plan's
-    // first the list, the layouts and the work items exist already: the kernel depends on nothing graph_score_kernel does and
-    // runs BESIDE it on the handle's side stream (20 us of a 90 us call, r05: latency-bound wavefronts that leave most of the
-    // chip idle on their own).  It books into the caller's histogram by global atomics and appends to the same hit lists.
+    // first the list, the layouts and the work items exist already and the kernel depends on nothing graph_score_kernel does:
+    // it COULD run beside it on the handle's side stream -- measured (GRAFIMO_FUSED_BESIDE=1, profiles/r05_fused_ab.txt): the
+    // call gets slower, 0.094 against 0.088 ms -- its one-wavefront workgroups take LDS the score kernel's second workgroup
+    // per CU then waits for, and graph_score_kernel stretches from 53.5 to 73.2 us.  One after the other it is.
     auto launch_del_score = [&](hipStream_t on) -> int {
         if (const int rc = kernel_prepare(FK::del_score, reinterpret_cast<const void *>(graph_del_score_kernel<MM>))) return rc;
         int pitch = ((W + 3) / 4) * 4;
@@ -1907,7 +1908,7 @@ template <int MM> int launch_fused(FusedLaunch &L)
                            pitch);
         return GFM_OK;
     };
-    static const bool serial = [] { const char *e = std::getenv("GRAFIMO_FUSED_SERIAL"); return e && *e == '1'; }();   // measurement aid
+    static const bool serial = [] { const char *e = std::getenv("GRAFIMO_FUSED_BESIDE"); return !(e && *e == '1'); }();   // measurement aid
     const bool beside = split == 2 && part[0].grid > 0 && part[1].grid > 0;
     const bool del_beside = !L.listing && L.indels && !serial;
     if (L.indels) {
