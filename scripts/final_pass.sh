@@ -3,7 +3,7 @@
 # fused extraction -> scoring kernels), PMC passes (score kernel; FETCH / WRITE of the fused kernels), the ingest probe.
 #   scripts/final_pass.sh <tag>      (outputs under gpurun_out/final_<tag>/)
 set -u
-tag="${1:-r04}"
+tag="${1:-r05}"
 root="$GRAFT_REPO_ROOT"
 out="$root/gpurun_out/final_$tag"
 mkdir -p "$out"
@@ -52,7 +52,11 @@ cp "$root/gpurun_out/pmc_$tag/summary.txt" "$out/pmc_summary.txt" 2>/dev/null
 rm -rf "$root/gpurun_out/pmc_$tag"/*/
 cd "$root"
 python scripts/ingest_probe.py > "$out/ingest_probe.txt" 2>&1
-GRAFIMO_FUSED_TIMERS=1 python scripts/fused_prof.py 2>&1 | grep "\[fused\]" | tail -16 > "$out/fused_timers.txt"
+# SQ counters of the fused kernels (the bench's extract.roofline prices graph_score_kernel against them)
+bash "$root/scripts/pmc_fused_sq.sh" > /dev/null 2>&1
+cp "$root/gpurun_out/pmc_fused_sq/summary.txt" "$out/pmc_fused_sq.txt" 2>/dev/null
+# per-phase timers exist in lab builds only (scripts/lab_build.sh fusedlab -DGFM_LAB)
+[ -f "$root/lab/libgfm_fusedlab.so" ] && GRAFIMO_HIP_LIB="$root/lab/libgfm_fusedlab.so" GRAFIMO_FUSED_TIMERS=1 python scripts/fused_prof.py 2>&1 | grep "\[fused\]" | tail -16 > "$out/fused_timers.txt"
 # the four fuzz drivers on fresh seeds (bounded: FUZZ_S seconds each), the round's last code
 {
   s0=$(( $(date +%s) % 100000 ))
