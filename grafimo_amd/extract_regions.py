@@ -1266,8 +1266,15 @@ def _fused_tables(motifs, graph, regions, debug, args_obj, group, always_collect
                 kept.append(recs)
                 ek = entry_of[gi][reg] if len(recs) else np.empty(0, dtype=np.int64)
                 entry_key.append(ek)
-                names_of.append(np.array([f"{entry_names[k]}:{a}-{b}" for k, a, b in zip(ek.tolist(), s_[reg].tolist(), e_[reg].tolist())],
-                                         dtype=object))
+                # one label per distinct REGION among the hit rows, not per row (a p < 1e-4 scan of short motifs reports
+                # thousands of rows from a few hundred regions)
+                if len(recs):
+                    ureg, inv = np.unique(reg, return_inverse=True)
+                    ulab = np.array([f"{entry_names[int(entry_of[gi][r_])]}:{int(s_[r_])}-{int(e_[r_])}" for r_ in ureg.tolist()],
+                                    dtype=object)
+                    names_of.append(ulab[inv])
+                else:
+                    names_of.append(np.empty(0, dtype=object))
             recs = np.concatenate(kept) if len(kept) > 1 else kept[0]
             ekey = np.concatenate(entry_key) if len(kept) > 1 else entry_key[0]
             names = np.concatenate(names_of) if len(kept) > 1 else names_of[0]
