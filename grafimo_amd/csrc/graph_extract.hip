@@ -1144,6 +1144,42 @@ template <typename T> struct Buf {
 
 }  // namespace
 
+// one PLAN of the fused path (see gfm_graph::plans)
+struct FusedPlan {
+    std::vector<long long> f_starts, f_stops;   // the regions the tile table was built for
+    int f_width = 0, f_n_tiles = 0, f_n_general = 0;     // tiles [0, f_n_general): may hold insertions / deletions; the rest: pure
+    long long f_n_windows = 0, f_general_windows = 0;
+    Buf<Tile> f_tiles;
+    Buf<DelWin> f_del_wins;
+    Buf<HeavyWin> f_heavy;                 // the plan's heavy windows (graph_heavy_kernel); f_flags[8..9]: their count << 32 | items
+    unsigned long long *h_heavy_ctl = nullptr;   // pinned: that word, copied back once per plan (no heavy window: no launch)
+    hipEvent_t ev_heavy = nullptr;
+    bool heavy_known = false, heavy_asked = false;
+    Buf<DelBatchRec> f_del_recs;         // per listed window: what graph_del_count_kernel found
+    Buf<DelItem> f_del_items;            // work items of graph_del_score_kernel
+    // [0] unused, [1] listed windows, [2] overflow of the call, [3] work items of the deletion kernels, [4] overflow among the
+    // listed windows.  [1], [3], [4] belong to the PLAN -- the list of windows that touch an indel, their layouts and the
+    // work items cut from them depend on the graph, the regions and the width, not on the motif
+    Buf<int> f_flags;
+    bool f_plan_ready = false;
+    hipStream_t f_plan_stream = nullptr;   // the stream the plan was made on; a call on another one waits for ev_plan
+    hipEvent_t ev_plan = nullptr;
+    hipError_t init()
+    {
+        hipError_t e = hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_heavy, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h_heavy_ctl), sizeof(unsigned long long), hipHostMallocDefault);
+        return e;
+    }
+    ~FusedPlan()
+    {
+        if (ev_plan) (void)hipEventDestroy(ev_plan);
+        if (ev_heavy) (void)hipEventDestroy(ev_heavy);
+        if (h_heavy_ctl) (void)hipHostFree(h_heavy_ctl);
+        f_tiles.release(); f_del_wins.release(); f_heavy.release(); f_del_recs.release(); f_del_items.release(); f_flags.release();
+    }
+};
+
 struct gfm_graph {
     GraphDev dev{};
     uint8_t *d_ref = nullptr;
@@ -1195,34 +1231,23 @@ struct gfm_graph {
     hipEvent_t prof_ev[2 * kProfSlots] = {};
     int prof_on = 0, prof_n = 0;
     std::vector<int> h_indel_prefix;     // [n_sites + 1] insertion / deletion records among sites [0, i) (pure tiles; made on first use)
-    std::vector<long long> f_starts, f_stops;   // the regions the device tile table was built for (reused while they repeat)
-    int f_width = 0, f_n_tiles = 0, f_n_general = 0;     // tiles [0, f_n_general): may hold insertions / deletions; the rest: pure
-    long long f_n_windows = 0;
-    Buf<Tile> f_tiles;
-    Tile *h_tiles = nullptr;             // pinned staging of the tile table
+    // ---- the fused path's PLANS: what depends on (graph, regions, width) only -- the tile table, the list of the windows that
+    // touch an insertion / deletion with their layouts and work items, the list of the heavy windows -- is made by the first call
+    // for a (regions, width) and kept; a handle keeps several (kMaxPlans, least recently used goes): GRAFIMO scans motif after
+    // motif over one BED file (grafimo.py:177-183) and the widths of a motif set alternate (building one for 50 000 regions
+    // took 12 ms of host time a call when only the last was kept)
+    static constexpr int kMaxPlans = 32;
+    std::vector<FusedPlan *> plans;      // most recently used first
+    FusedPlan *plan = nullptr;           // of the last gfm_graph_score[_multi] call (what gfm_graph_annotate refers to)
+    Tile *h_tiles = nullptr;             // pinned staging of a tile table on its way to the device
     size_t h_tiles_cap = 0;
     hipEvent_t ev_tiles = nullptr;       // the staging has been copied
     bool tiles_pending = false;
     long long max_del_len = 0;             // the graph's longest deletion (how far behind a window a one-deletion scan looks)
-    Buf<DelWin> f_del_wins;
-    Buf<HeavyWin> f_heavy;                 // the plan's heavy windows (graph_heavy_kernel); f_flags[8..9]: their count << 32 | items
-    unsigned long long *h_heavy_ctl = nullptr;   // pinned: that word, copied back once per plan (no heavy window: no launch)
-    hipEvent_t ev_heavy = nullptr;
-    bool heavy_known = false, heavy_asked = false;
-    Buf<DelBatchRec> f_del_recs;         // per listed window: what graph_del_count_kernel found
-    Buf<DelItem> f_del_items;            // work items of graph_del_score_kernel
     Buf<unsigned> f_slabs;
 #ifdef GFM_LAB
     Buf<unsigned long long> f_dbg;
 #endif
-    // [0] unused, [1] listed windows, [2] overflow of the call, [3] work items of the deletion kernels, [4] overflow among the
-    // listed windows.  [1], [3], [4] belong to the PLAN -- the list of windows that touch an indel, their layouts and the
-    // work items cut from them depend on the graph, the regions and the width, not on the motif: they are made by the first
-    // call for a tile table and reused by the calls that follow (GRAFIMO scans motif after motif over one BED file)
-    Buf<int> f_flags;
-    bool f_plan_ready = false;
-    hipStream_t f_plan_stream = nullptr;   // the stream the plan was made on; a call on another one waits for ev_plan
-    hipEvent_t ev_plan = nullptr;
     // The fused calls of ONE handle share its scratch (overflow word, slabs, heavy list, tile table): they are serialised --
     // a gfm_graph_score / gfm_graph_annotate on another stream than the handle's last call waits for that call's work.
     hipStream_t f_last_stream = nullptr;
@@ -1368,10 +1393,7 @@ GFM_API int gfm_graph_create(const uint8_t *h_ref, int64_t ref_len, int32_t n_si
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_tiles, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_plan, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_call, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_heavy, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&g->h_heavy_ctl), sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) {
         gfm_graph_destroy(g);
         return gfail(GFM_ERR_HIP, std::string("event creation failed: ") + hipGetErrorString(e));
@@ -1420,10 +1442,7 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     if (g->side) (void)hipStreamDestroy(g->side);
     if (g->h_back) (void)hipHostFree(g->h_back);
     if (g->ev_tiles) (void)hipEventDestroy(g->ev_tiles);
-    if (g->ev_plan) (void)hipEventDestroy(g->ev_plan);
     if (g->ev_call) (void)hipEventDestroy(g->ev_call);
-    if (g->ev_heavy) (void)hipEventDestroy(g->ev_heavy);
-    if (g->h_heavy_ctl) (void)hipHostFree(g->h_heavy_ctl);
     if (g->h_tiles) (void)hipHostFree(g->h_tiles);
     for (int k = 0; k < 2; ++k) {
         if (g->h_stage[k]) (void)hipHostFree(g->h_stage[k]);
@@ -1432,9 +1451,10 @@ GFM_API void gfm_graph_destroy(gfm_graph_t g)
     if (g->copy_st) (void)hipStreamDestroy(g->copy_st);
     for (hipEvent_t e : g->prof_ev)
         if (e) (void)hipEventDestroy(e);
-    g->f_tiles.release(); g->f_del_wins.release(); g->f_del_recs.release(); g->f_del_items.release(); g->f_slabs.release();
-    g->f_flags.release();
-    g->f_heavy.release();
+    for (FusedPlan *pl : g->plans) delete pl;
+    g->plans.clear();
+    g->plan = nullptr;
+    g->f_slabs.release();
     delete g;
 }
 
@@ -1840,6 +1860,7 @@ template <int MM> KernelInfo FusedKernels<MM>::del_score;
 
 struct FusedLaunch {
     gfm_graph *g;
+    FusedPlan *P;
     FusedArgs a;
     hipStream_t st;
     int n_cu, n_motifs;
@@ -1851,6 +1872,7 @@ struct FusedLaunch {
 template <int MM> int launch_fused(FusedLaunch &L)
 {
     gfm_graph *g = L.g;
+    FusedPlan *P = L.P;
     FusedArgs &a = L.a;
     hipStream_t st = L.st;
     const int W = a.W, n_cu = L.n_cu;
@@ -1874,8 +1896,8 @@ template <int MM> int launch_fused(FusedLaunch &L)
         // code path, and the tiles that may hold insertions / deletions (a fifth of them, two to three times the cost each)
         // fill a chip badly on their own -- split: 36.5 + 25.8 us against 49.7 us for the one launch (profiles/r05_fused_ab.txt).
         // GRAFIMO_FUSED_SPLIT=1 (measurement aid) runs the two instantiations one after the other, =2 side by side on two streams.
-        pt.begin = general ? 0 : (split ? g->f_n_general : g->f_n_tiles);
-        pt.end = general ? (split ? g->f_n_general : g->f_n_tiles) : g->f_n_tiles;
+        pt.begin = general ? 0 : (split ? P->f_n_general : P->f_n_tiles);
+        pt.end = general ? (split ? P->f_n_general : P->f_n_tiles) : P->f_n_tiles;
         pt.sh = pick_shape(ks.vgprs, tab_bytes + hist_bytes + 16, wave_bytes + sizeof(long long) + sizeof(int));
         const int n_t = pt.end - pt.begin;
         pt.grid = n_t > 0 ? std::max(1, std::min((n_t + pt.sh.waves - 1) / pt.sh.waves, pt.sh.per_cu * n_cu)) : 0;
@@ -1904,7 +1926,7 @@ template <int MM> int launch_fused(FusedLaunch &L)
                              (size_t)kFusedDelThreads * pitch;
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 * 1024) / lds_b));
         hipLaunchKernelGGL((graph_del_score_kernel<MM>), dim3((unsigned)(per_cu * n_cu)), dim3(kFusedDelThreads), lds_b, on, g->dev, a,
-                           g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_del_recs.p, g->f_del_items.p, g->f_flags.p + 3,
+                           P->f_tiles.p, P->f_del_wins.p, P->f_flags.p + 1, P->f_del_recs.p, P->f_del_items.p, P->f_flags.p + 3,
                            pitch);
         return GFM_OK;
     };
@@ -1912,9 +1934,9 @@ template <int MM> int launch_fused(FusedLaunch &L)
     const bool beside = split == 2 && part[0].grid > 0 && part[1].grid > 0;
     const bool del_beside = !L.listing && L.indels && !serial;
     if (L.indels) {
-        const size_t n_batches = ((size_t)g->f_n_windows + kFusedDelThreads - 1) / kFusedDelThreads;
-        GX_TRY(g->f_del_recs.reserve(n_batches * kFusedDelThreads + 1));
-        GX_TRY(g->f_del_items.reserve(n_batches * kDelMaxItems + (size_t)kDelExtraItems + 1));
+        const size_t n_batches = ((size_t)P->f_general_windows + kFusedDelThreads - 1) / kFusedDelThreads;      // (listed windows live in the general tiles)
+        GX_TRY(P->f_del_recs.reserve(n_batches * kFusedDelThreads + 1));
+        GX_TRY(P->f_del_items.reserve(n_batches * kDelMaxItems + (size_t)kDelExtraItems + 1));
     }
     if (beside || del_beside) {
         GX_TRY(hipEventRecord(g->ev_fork, st));
@@ -1932,8 +1954,8 @@ template <int MM> int launch_fused(FusedLaunch &L)
         ap.slabs = a.slabs + (general ? (size_t)0 : (size_t)part[1].grid * (size_t)a.slab_stride);
         const dim3 grid((unsigned)pt.grid), block((unsigned)pt.sh.waves * 64);
 #define GFM_LAUNCH_SCORE(LST, GEN)                                                                                              \
-        hipLaunchKernelGGL((graph_score_kernel<MM, LST, GEN>), grid, block, pt.lds, st, g->dev, ap, g->f_tiles.p, pt.begin, pt.end, \
-                           g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_heavy.p, L.heavy_ctl, g->f_flags.p + 4)
+        hipLaunchKernelGGL((graph_score_kernel<MM, LST, GEN>), grid, block, pt.lds, st, g->dev, ap, P->f_tiles.p, pt.begin, pt.end, \
+                           P->f_del_wins.p, P->f_flags.p + 1, P->f_flags.p + 2, P->f_heavy.p, L.heavy_ctl, P->f_flags.p + 4)
         if (L.listing) { if (general) GFM_LAUNCH_SCORE(true, true); else GFM_LAUNCH_SCORE(true, false); }
         else { if (general) GFM_LAUNCH_SCORE(false, true); else GFM_LAUNCH_SCORE(false, false); }
 #undef GFM_LAUNCH_SCORE
@@ -1943,36 +1965,36 @@ template <int MM> int launch_fused(FusedLaunch &L)
     int n_slabs = g1;
     {
         // the heavy windows: launched until the plan's count has come back and says there is none
-        if (!g->heavy_known && g->heavy_asked) {
-            if (hipEventQuery(g->ev_heavy) == hipSuccess) g->heavy_known = true;
+        if (!P->heavy_known && P->heavy_asked) {
+            if (hipEventQuery(P->ev_heavy) == hipSuccess) P->heavy_known = true;
             else (void)hipGetLastError();          // ("not ready" is no error of this call: it must not surface in the check below)
         }
-        if (!g->heavy_known || (*g->h_heavy_ctl & 0xffffffffull) != 0ull) {
+        if (!P->heavy_known || (*P->h_heavy_ctl & 0xffffffffull) != 0ull) {
             hipLaunchKernelGGL((graph_heavy_kernel<MM>), dim3((unsigned)g_heavy), dim3((unsigned)shh.waves * 64), lds_h, st, g->dev, a,
-                               g->f_tiles.p, g->f_heavy.p, L.heavy_ctl, g1);
+                               P->f_tiles.p, P->f_heavy.p, L.heavy_ctl, g1);
             n_slabs = std::max(g1, g_heavy);
         }
         if (L.listing) {
-            GX_TRY(hipMemcpyAsync(g->h_heavy_ctl, L.heavy_ctl, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-            GX_TRY(hipEventRecord(g->ev_heavy, st));
-            g->heavy_asked = true;
+            GX_TRY(hipMemcpyAsync(P->h_heavy_ctl, L.heavy_ctl, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            GX_TRY(hipEventRecord(P->ev_heavy, st));
+            P->heavy_asked = true;
         }
     }
     if (L.listing && !L.indels) {
-        g->f_plan_ready = true;
-        g->f_plan_stream = st;
-        GX_TRY(hipEventRecord(g->ev_plan, st));
+        P->f_plan_ready = true;
+        P->f_plan_stream = st;
+        GX_TRY(hipEventRecord(P->ev_plan, st));
     }
     if (L.indels && L.listing) {
         // a plan's first call: the listed windows' layouts are counted and cut into work items (gfm_graph_fused.hpp), behind the
         // score kernel that lists them
         const size_t lds_a = sizeof(SiteRec) * kSiteCache * kFusedDelThreads;
         hipLaunchKernelGGL(graph_del_count_kernel, dim3((unsigned)(12 * n_cu)), dim3(kFusedDelThreads), lds_a, st, g->dev, W,
-                           g->f_tiles.p, g->f_del_wins.p, g->f_flags.p + 1, g->f_flags.p + 2, g->f_flags.p + 4, g->f_del_recs.p,
-                           g->f_del_items.p, g->f_flags.p + 3, g->f_flags.p + 5);
-        g->f_plan_ready = true;       // (stream order: the calls that follow on this stream find the plan complete)
-        g->f_plan_stream = st;
-        GX_TRY(hipEventRecord(g->ev_plan, st));
+                           P->f_tiles.p, P->f_del_wins.p, P->f_flags.p + 1, P->f_flags.p + 2, P->f_flags.p + 4, P->f_del_recs.p,
+                           P->f_del_items.p, P->f_flags.p + 3, P->f_flags.p + 5);
+        P->f_plan_ready = true;       // (stream order: the calls that follow on this stream find the plan complete)
+        P->f_plan_stream = st;
+        GX_TRY(hipEventRecord(P->ev_plan, st));
     }
     if (L.indels && !del_beside)
         if (const int rc = launch_del_score(st)) return rc;
@@ -2029,14 +2051,31 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (const int rc = g->serialise(st)) return rc;
-    // ---- the tile table: rebuilt only when the regions or the width change (GRAFIMO scans the same BED regions motif after
-    // motif, grafimo.py:177-183)
+    // ---- the plan: looked up among the handle's (GRAFIMO scans the same BED regions motif after motif, grafimo.py:177-183;
+    // the widths of a motif set alternate), built and uploaded when this (regions, width) is new
     const size_t nr = (size_t)n_regions;
-    const bool same = g->f_width == W && g->f_starts.size() == nr &&
-                      (nr == 0 || (std::memcmp(g->f_starts.data(), h_starts, nr * sizeof(long long)) == 0 &&
-                                   std::memcmp(g->f_stops.data(), h_stops, nr * sizeof(long long)) == 0));
-    if (!same) {
-        g->f_plan_ready = false;
+    FusedPlan *P = nullptr;
+    for (size_t k = 0; k < g->plans.size(); ++k) {
+        FusedPlan *c = g->plans[k];
+        if (c->f_width == W && c->f_starts.size() == nr &&
+            (nr == 0 || (std::memcmp(c->f_starts.data(), h_starts, nr * sizeof(long long)) == 0 &&
+                         std::memcmp(c->f_stops.data(), h_stops, nr * sizeof(long long)) == 0))) {
+            P = c;
+            g->plans.erase(g->plans.begin() + (long)k);
+            g->plans.insert(g->plans.begin(), P);          // most recently used first
+            break;
+        }
+    }
+    if (!P) {
+        if ((int)g->plans.size() >= gfm_graph::kMaxPlans) {
+            // the least recently used plan goes; kernels of earlier calls may still read its buffers: hipFree waits for the device
+            delete g->plans.back();
+            g->plans.pop_back();
+        }
+        P = new (std::nothrow) FusedPlan();
+        if (!P) return gfail(GFM_ERR_NOMEM, "out of host memory");
+        g->plans.insert(g->plans.begin(), P);
+        GX_TRY(P->init());
         if (g->tiles_pending) {          // the staging buffer may still be read by the last copy
             GX_TRY(hipEventSynchronize(g->ev_tiles));
             g->tiles_pending = false;
@@ -2066,14 +2105,18 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
             for (size_t i = 0; i < g->host.pos.size(); ++i)
                 g->h_indel_prefix[i + 1] = g->h_indel_prefix[i] + ((g->host.del_len[i] > 0 || g->host.ins_len[i] > 0) ? 1 : 0);
         }
-        long long w_base = 0;
-        size_t ti = 0;
+        // The tiles in genome order first (a host vector), with their cost keys ...
+        std::vector<Tile> built(n_tiles);
+        std::vector<unsigned> key(n_tiles);
+        constexpr unsigned kKeyMax = 1u << 14;
+        long long w_base = 0, general_windows = 0;
+        size_t ti = 0, n_general = 0;
         int hint_lo = 0, hint_hi = 0, hint_far = 0;
         for (int r = 0; r < n_regions; ++r) {
             const long long s = std::max<long long>(h_starts[r], 0), e = std::min<long long>(h_stops[r], g->dev.ref_len);
             const long long nw = std::max<long long>(0, e - tail - s + 1);
             for (long long off = 0; off < nw; off += kTileWin) {
-                Tile &t = g->h_tiles[ti++];
+                Tile &t = built[ti];
                 const int n_win = (int)std::min<long long>(kTileWin, nw - off);
                 t.p0 = s + off;
                 t.limit = e;
@@ -2085,66 +2128,67 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
                 const bool pure = t.i_hi - t.i_lo + 1 <= kWaveSites && g->h_indel_prefix[(size_t)t.i_hi] == g->h_indel_prefix[(size_t)t.i_lo] &&
                                   g->host.max_reach[(size_t)t.i_lo] < t.p0;
                 t.n_win = n_win | (pure ? kTilePure : 0);
+                // cost: the site records under the tile (each costs every window that holds it a phase-2 walk), then its windows;
+                // the tiles that may hold insertions / deletions count as the dearest (they are the general code path's)
+                const unsigned cost = (unsigned)std::min(t.i_hi - t.i_lo, 120) * 64u + (unsigned)n_win;
+                key[ti] = pure ? cost : (kKeyMax / 2 + cost);
+                if (!pure) { ++n_general; general_windows += n_win; }
+                ++ti;
                 w_base += n_win;
                 if (w_base > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "too many windows in one call (split the regions)");
             }
         }
-        // The persistent grid deals tiles round-robin (no ticket: one global word sustains 88 atomics a microsecond), so a
-        // wavefront's share is fixed before the kernel starts -- and in genome order it is luck: the SQ counters showed
-        // wavefronts busy 42 us on average in a kernel of 61 us, the rest is waiting for the unluckiest one.  Tiles are
-        // therefore dealt in order of DESCENDING estimated cost (longest processing time first): every wavefront gets one tile
-        // of every cost stratum, the cheap ones last.  Cost: the site records under the tile (each costs every window that
-        // holds it a phase-2 walk), doubled for tiles that may hold insertions / deletions (the general classification).
-        // Nothing refers to a tile's place in the table but through its index: entries, listed and heavy windows carry it.
-        if (n_tiles > 1) {
-            std::vector<std::pair<int, unsigned>> order(n_tiles);
-            for (size_t i = 0; i < n_tiles; ++i) {
-                const Tile &t = g->h_tiles[i];
-                const int sites = t.i_hi - t.i_lo;
-                // (the tiles that may hold insertions / deletions first -- they are graph_score_kernel<.., GENERAL>'s -- then the pure ones)
-                order[i] = {((t.n_win & kTilePure) ? 0 : -(1 << 28)) - (sites * 64 + (t.n_win & 0xff)), (unsigned)i};
-            }
-            std::sort(order.begin(), order.end());
-            std::vector<Tile> sorted(n_tiles);
-            for (size_t i = 0; i < n_tiles; ++i) sorted[i] = g->h_tiles[order[i].second];
-            std::memcpy(g->h_tiles, sorted.data(), sizeof(Tile) * n_tiles);
+        // ... then into the pinned staging in order of DESCENDING cost (a counting sort: the keys are small; std::sort of
+        // 150 000 tiles was 25 ms of the 35 ms a plan for 50 000 regions took to build).  The persistent grid deals tiles
+        // round-robin (no ticket: one global word sustains 88 atomics a microsecond), so a wavefront's share is fixed before
+        // the kernel starts -- and in genome order it is luck: the SQ counters showed wavefronts busy 42 us on average in a
+        // kernel of 61 us, the rest is waiting for the unluckiest one.  Longest first, every wavefront gets one tile of every
+        // cost stratum, the cheap ones last.  Nothing refers to a tile's place in the table but through its index: entries,
+        // listed and heavy windows carry it.
+        {
+            std::vector<unsigned> first(kKeyMax + 1, 0);
+            for (size_t i = 0; i < n_tiles; ++i) ++first[kKeyMax - 1 - key[i]];              // bucket 0 = the dearest
+            unsigned run = 0;
+            for (unsigned b = 0; b <= kKeyMax; ++b) { const unsigned c = first[b]; first[b] = run; run += c; }
+            for (size_t i = 0; i < n_tiles; ++i) g->h_tiles[first[kKeyMax - 1 - key[i]]++] = built[i];
         }
-        g->f_n_general = 0;
-        for (size_t i = 0; i < n_tiles; ++i) g->f_n_general += (g->h_tiles[i].n_win & kTilePure) ? 0 : 1;
-        GX_TRY(g->f_tiles.reserve(n_tiles + 1));
+        P->f_n_general = (int)n_general;
+        P->f_general_windows = general_windows;
+        GX_TRY(P->f_tiles.reserve(n_tiles + 1));
         if (n_tiles) {
-            GX_TRY(hipMemcpyAsync(g->f_tiles.p, g->h_tiles, sizeof(Tile) * n_tiles, hipMemcpyHostToDevice, st));
+            GX_TRY(hipMemcpyAsync(P->f_tiles.p, g->h_tiles, sizeof(Tile) * n_tiles, hipMemcpyHostToDevice, st));
             GX_TRY(hipEventRecord(g->ev_tiles, st));
             g->tiles_pending = true;
         }
-        g->f_starts.assign(h_starts, h_starts + nr);
-        g->f_stops.assign(h_stops, h_stops + nr);
-        g->f_width = W;
-        g->f_n_tiles = (int)n_tiles;
-        g->f_n_windows = w_base;
+        P->f_starts.assign(h_starts, h_starts + nr);
+        P->f_stops.assign(h_stops, h_stops + nr);
+        P->f_width = W;
+        P->f_n_tiles = (int)n_tiles;
+        P->f_n_windows = w_base;
     }
-    if (n_windows) *n_windows = g->f_n_windows;
-    if (g->f_n_tiles == 0) return GFM_OK;
+    g->plan = P;
+    if (n_windows) *n_windows = P->f_n_windows;
+    if (P->f_n_tiles == 0) return GFM_OK;
     const bool indels = g->dev.n_dels > 0 || g->dev.n_ins > 0;
-    GX_TRY(g->f_del_wins.reserve((size_t)g->f_n_windows + 1));
-    GX_TRY(g->f_flags.reserve(16));
-    GX_TRY(g->f_heavy.reserve((size_t)std::min<long long>(g->f_n_windows, kHeavyCap) + 1));
+    GX_TRY(P->f_del_wins.reserve((size_t)P->f_general_windows + 1));      // (listed windows live in the general tiles)
+    GX_TRY(P->f_flags.reserve(16));
+    GX_TRY(P->f_heavy.reserve((size_t)std::min<long long>(P->f_n_windows, kHeavyCap) + 1));
     // What depends on (graph, regions, width) only is made by the first call of a tile table and kept: the list of the windows
     // that touch an insertion / deletion with their layouts and work items, and the list of the heavy windows.
-    const bool listing = !g->f_plan_ready;
-    if (!listing && st != g->f_plan_stream) GX_TRY(hipStreamWaitEvent(st, g->ev_plan, 0));
+    const bool listing = !P->f_plan_ready;
+    if (!listing && st != P->f_plan_stream) GX_TRY(hipStreamWaitEvent(st, P->ev_plan, 0));
     if (listing) {
-        GX_TRY(hipMemsetAsync(g->f_flags.p, 0, 16 * sizeof(int), st));
-        g->heavy_known = g->heavy_asked = false;
+        GX_TRY(hipMemsetAsync(P->f_flags.p, 0, 16 * sizeof(int), st));
+        P->heavy_known = P->heavy_asked = false;
     } else {
-        GX_TRY(hipMemsetAsync(g->f_flags.p + 2, 0, sizeof(int), st));
+        GX_TRY(hipMemsetAsync(P->f_flags.p + 2, 0, sizeof(int), st));
     }
     a.W = W;
     a.n_motifs = n_motifs;
     a.forward_only = (flags & GFM_GRAPH_FORWARD_ONLY) ? 1 : 0;
     a.n_rows = reinterpret_cast<unsigned long long *>(d_n_rows);
     a.listing = listing ? 1 : 0;
-    a.plan_overflow = g->f_flags.p + 4;
+    a.plan_overflow = P->f_flags.p + 4;
 #ifdef GFM_LAB      // lab builds only (scripts/lab_build.sh -DGFM_LAB): the product reads neither variable
     static const bool timers = [] { const char *e = std::getenv("GRAFIMO_FUSED_TIMERS"); return e && *e == '1'; }();
     if (timers) {
@@ -2155,7 +2199,7 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
     static const int lab = [] { const char *e = std::getenv("GRAFIMO_FUSED_LAB"); return e ? atoi(e) : 0; }();
     a.lab = lab;
 #endif
-    FusedLaunch L{g, a, st, n_cu, n_motifs, listing, indels, with_hist, reinterpret_cast<unsigned long long *>(g->f_flags.p + 8)};
+    FusedLaunch L{g, P, a, st, n_cu, n_motifs, listing, indels, with_hist, reinterpret_cast<unsigned long long *>(P->f_flags.p + 8)};
     int rc = GFM_OK;
     if (n_motifs == 1) rc = launch_fused<1>(L);
     else if (n_motifs == 2) rc = launch_fused<2>(L);
@@ -2167,13 +2211,13 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
         int fl[4];
         GX_TRY(hipStreamSynchronize(st));
         GX_TRY(hipMemcpy(h, g->f_dbg.p, sizeof h, hipMemcpyDeviceToHost));
-        GX_TRY(hipMemcpy(fl, g->f_flags.p, sizeof fl, hipMemcpyDeviceToHost));
+        GX_TRY(hipMemcpy(fl, P->f_flags.p, sizeof fl, hipMemcpyDeviceToHost));
         std::fprintf(stderr, "[fused] listed windows %d, work items %d\n", fl[1], fl[3]);
         for (int k = 0; k < 16; ++k)
             if (h[32 + k]) std::fprintf(stderr, "[fused] phase %d: n %llu, mean %.2f us, max %.2f us\n", k, h[32 + k], 0.01 * (double)h[k] / (double)h[32 + k], 0.01 * (double)h[16 + k]);
     }
 #endif
-    if (d_overflow) GX_TRY(hipMemcpyAsync(d_overflow, g->f_flags.p + 2, sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (d_overflow) GX_TRY(hipMemcpyAsync(d_overflow, P->f_flags.p + 2, sizeof(int), hipMemcpyDeviceToDevice, st));
     return g->called(st);
 }
 
@@ -2214,14 +2258,15 @@ GFM_API int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t
                                const int32_t *d_cutoff, const double *d_qtable, void *d_records, void *stream)
 {
     if (!g) return gfail(GFM_ERR_INVALID, "graph is NULL");
-    if (hit_capacity <= 0 || g->f_n_tiles == 0) return GFM_OK;
+    FusedPlan *P = g->plan;
+    if (hit_capacity <= 0 || !P || P->f_n_tiles == 0) return GFM_OK;
     if (!d_hits || !d_hit_count || !d_records) return gfail(GFM_ERR_INVALID, "NULL device buffer");
     static_assert(sizeof(HitRec) == sizeof(gfm_graph_hit_t) && sizeof(GraphHit) == 16, "record layouts of the C ABI");
     if (hit_capacity > 0x7fffffffll) return gfail(GFM_ERR_INVALID, "hit capacity beyond 2^31");
     const unsigned blocks = (unsigned)std::min<int64_t>(hit_capacity, 8192);   // a wavefront per entry, entries dealt over the grid
     if (const int rc = g->serialise(static_cast<hipStream_t>(stream))) return rc;
     hipLaunchKernelGGL(graph_annotate_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), g->dev,
-                       g->d_allele_count, g->f_width, g->f_tiles.p, g->f_n_tiles, static_cast<const GraphHit *>(d_hits),
+                       g->d_allele_count, P->f_width, P->f_tiles.p, P->f_n_tiles, static_cast<const GraphHit *>(d_hits),
                        reinterpret_cast<const unsigned long long *>(d_hit_count), (long long)hit_capacity, d_cutoff, d_qtable,
                        static_cast<HitRec *>(d_records));
     GX_TRY(hipGetLastError());

@@ -436,8 +436,10 @@ int gfm_graph_write_tsvs(gfm_graph_t g, const uint8_t *d_kmers, const int64_t *d
  *   not stored; the caller zeroes the counter); *d_n_rows += rows scored; *d_overflow (optional) = 1 if a window holds
  *   more than 2^40 walks, or the regions hold more than 2^20 windows of more than 64 walks each (those windows' rows are
  *   left out: score fewer regions at a time); *n_windows (host, optional) = windows of the call.  Entry order is
- *   arbitrary; the records of gfm_graph_annotate sorted by (w, q2) are in the row order of gfm_graph_emit.  Enqueue only (the first call for a set of
- *   regions builds and uploads their tile table; later calls with the same regions and width reuse it).
+ *   arbitrary; the records of gfm_graph_annotate sorted by (w, q2) are in the row order of gfm_graph_emit.  Enqueue only (the first call for a
+ *   (regions, width) pair builds and uploads its PLAN -- the tile table; the lists of the windows that touch an insertion /
+ *   deletion and of the heavy windows follow on the device -- and later calls with the same regions and width reuse it; a handle
+ *   keeps the plans of its 32 most recently used pairs: the widths of a motif set alternate, grafimo.py:177-183).
  * gfm_graph_annotate: for entry i < min(*d_hit_count, hit_capacity) the record d_records[i] of the LAST gfm_graph_score
  *   call on this handle; d_cutoff (device, optional): entries with score < *d_cutoff get keep = 0 and no columns (the
  *   p < t candidates of a --qvalueT scan that the q-value cutoff drops: q >= p); d_qtable (device, optional): the

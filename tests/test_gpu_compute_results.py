@@ -723,6 +723,30 @@ def test_bench_distributed_path_on_one_gpu_with_reserved_cus():
     assert rec["scaling_curve_point"]["source"] == "value" and rec["scaling_curve_point"]["kmers_per_s"] == rec["value"]
 
 
+@pytest.mark.timeout(900)
+def test_bench_product_paths_block_under_a_process_group():
+    """What `bench.py --gpus N` adds at N > 1 -- the fused graph path (a rank uploads its shard of the graph) and the streamed
+    scan under the run's process group -- driven with a one-rank RCCL group on the test box's one GPU: both blocks report rows
+    and rates, no error string."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, GRAFIMO_RESERVE_CUS="16", MASTER_ADDR="127.0.0.1", MASTER_PORT="29579")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--config", "3", "--rows", "4000000",
+                        "--steps", "6", "--warmup", "2", "--bursts", "2", "--no-cpu-baseline", "--no-e2e"],
+                       capture_output=True, text=True, env=env, timeout=800)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][-1])
+    pp = rec["product_paths"]
+    assert "error" not in pp, pp
+    gp, ss = pp["graph_path"], pp["streamed_scan"]
+    assert gp["regions"] == 4000 and gp["rows"] > 2_000_000 and gp["rows_per_s"] > 1e8 and gp["sites_per_rank"] == [gp["sites_total"]]
+    assert ss["rows"] == 800_000 and ss["files"] == 400 and ss["rows_per_s"] > 1e6 and ss["hits"] > 0
+
+
 def test_kept_motif_handles(golden_motifs):
     """DeviceMotif.lease / release: the entry points that run once per motif and once more per chromosome keep their
     handle -- same numbers, same handle; other numbers, another; a plain handle is untouched by it; drop_kept() destroys
