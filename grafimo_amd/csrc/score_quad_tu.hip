@@ -33,11 +33,11 @@ int qfail(int code, const std::string &msg)
         if (e_ != hipSuccess) return qfail(GFM_ERR_HIP, std::string(#expr " failed: ") + hipGetErrorString(e_)); \
     } while (0)
 
-template <int W, int MM>
-int launch_quad_t(const uint8_t *d_kmers, long long n, long long row_base, const ScoreArgs<MM> &args, size_t lds,
+template <int W, int MM, bool STORE>
+int launch_quad_k(const uint8_t *d_kmers, long long n, long long row_base, const ScoreArgs<MM> &args, size_t lds,
                   int nslabs, int waves, hipStream_t st, bool prepare, hipEvent_t ev0, hipEvent_t ev1)
 {
-    auto kern = score_quad_kernel<W, MM>;
+    auto kern = score_quad_kernel<W, MM, STORE>;
     if (prepare) {  // from gfm_motif_create (never inside a stream capture); once per process and device
         static std::atomic<unsigned long long> done{0ull};       // one bit per device for this instantiation
         int dev = 0;
@@ -62,6 +62,19 @@ int launch_quad_t(const uint8_t *d_kmers, long long n, long long row_base, const
         hipLaunchKernelGGL(kern, dim3(nslabs), dim3(waves * kWave), lds, st, d_kmers, n, row_base, args);
     Q_TRY(hipGetLastError());
     return GFM_OK;
+}
+
+// the storing instantiation, or -- args.store_through == 2: the caller passed d_scores == NULL -- the one without score stores
+template <int W, int MM>
+int launch_quad_t(const uint8_t *d_kmers, long long n, long long row_base, const ScoreArgs<MM> &args, size_t lds,
+                  int nslabs, int waves, hipStream_t st, bool prepare, hipEvent_t ev0, hipEvent_t ev1)
+{
+    if (prepare) {
+        const int rc = launch_quad_k<W, MM, true>(d_kmers, n, row_base, args, lds, nslabs, waves, st, true, ev0, ev1);
+        return rc ? rc : launch_quad_k<W, MM, false>(d_kmers, n, row_base, args, lds, nslabs, waves, st, true, ev0, ev1);
+    }
+    if (args.store_through == 2) return launch_quad_k<W, MM, false>(d_kmers, n, row_base, args, lds, nslabs, waves, st, false, ev0, ev1);
+    return launch_quad_k<W, MM, true>(d_kmers, n, row_base, args, lds, nslabs, waves, st, false, ev0, ev1);
 }
 
 }  // namespace
