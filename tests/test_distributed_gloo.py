@@ -408,3 +408,77 @@ def test_two_ranks_gather_one_hit_per_region_for_the_top_regions(tsv_dir, tmp_pa
         assert p["moved"][0] == p["stats"]["sent"] <= 7 and p["moved"][1] == p["stats"]["hits"]
         assert p["stats"]["sent"] < p["stats"]["hits"]
     assert sum(p["stats"]["sent"] for p in parts) == full["sequence_name"].nunique()
+
+
+# ------------------------------------------------------------------------------------------------ sharded GRAPH
+def _graph_shard_worker(rank, world, port, workdir):
+    """every rank: its contiguous share of the regions, the SHARD of the graph those regions can meet (shard_index), the
+    oracle's rows over that shard, their score histogram -> all-reduce; rank 0 compares with one process over the whole graph"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from extract_helpers import variants_from_index
+    from grafimo_amd.distributed import shard_bounds
+    from grafimo_amd.extract_regions import GraphIndex, shard_index
+    from oracle import extract_oracle as xo
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = _golden_ctcf()
+    sm, ptab = np.array(g["score_matrix"], dtype=np.int64), orc.p_table(g["pmf"])
+    idx = GraphIndex.load(os.path.join(workdir, "g.gfmidx.npz"))
+    regions = np.load(os.path.join(workdir, "regions.npy"))
+    lo, hi = shard_bounds(len(regions), world, rank)
+    mine = regions[lo:hi]
+    sub = shard_index(idx, mine[:, 0], mine[:, 1]) if len(mine) else None
+    ref = idx.ref.tobytes()
+
+    def rows_of(index, regs):
+        v = variants_from_index(index)
+        out = []
+        for s, e in regs.tolist():
+            out += xo.enumerate_region_variants("7", ref, v, s, e, 19, with_counts=True)
+        return out
+
+    rows = rows_of(sub, mine) if sub is not None else []
+    km = np.frombuffer("".join(r[1] for r in rows).encode(), dtype=np.uint8).reshape(-1, 19)
+    sc = orc.score_kmers_table(km, sm, ptab, g["min_val"])[0] if len(km) else np.empty(0, np.int64)
+    hist = torch.from_numpy(np.bincount(sc, minlength=19001).astype(np.int64))
+    n_sites = torch.tensor([len(sub.pos) if sub is not None else 0], dtype=torch.int64)
+    dist.all_reduce(hist)                                   # the one data-path exchange of the sharded graph path
+    per_rank = [torch.zeros_like(n_sites) for _ in range(world)]
+    dist.all_gather(per_rank, n_sites)
+    counts = [None] * world
+    dist.all_gather_object(counts, [(r[0], r[1], r[2], r[3], r[4], r[5]) for r in rows])
+    if rank == 0:
+        full = rows_of(idx, regions)
+        km_f = np.frombuffer("".join(r[1] for r in full).encode(), dtype=np.uint8).reshape(-1, 19)
+        exp = np.bincount(orc.score_kmers_table(km_f, sm, ptab, g["min_val"])[0], minlength=19001)
+        ok = bool(np.array_equal(hist.numpy(), exp)) and [tuple(r) for part in counts for r in part] == [tuple(r[:6]) for r in full]
+        sites = [int(x.item()) for x in per_rank]
+        with open(os.path.join(workdir, f"result_{world}.txt"), "w") as fh:
+            fh.write(f"{ok} {len(full)} {len(idx.pos)} {' '.join(map(str, sites))}\n")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_hold_shards_of_the_graph_and_agree_with_one_process(tmp_path, world):
+    """the graph shards with the regions.  gloo world 2 / 4: every rank cuts the part of the graph its regions
+    can meet out of the host index (shard_index), enumerates and scores its rows there, the histograms are all-reduced: the
+    global histogram and the concatenated rows equal one process over the whole graph, and no rank holds more than its share
+    (plus margins) of the site records."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from extract_helpers import make_graph_files
+    from grafimo_amd.extract_regions import GraphIndex
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=9000, n_sites=700, n_samples=16, seed=55, rich=True)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
+    idx.save(str(tmp_path / "g"))
+    regions = np.array([(200 + 1000 * i, 420 + 1000 * i) for i in range(8)] + [(8800, 9000)], dtype=np.int64)
+    np.save(str(tmp_path / "regions.npy"), regions)
+    mp.spawn(_graph_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ok, n_rows, n_sites, *per_rank = open(tmp_path / f"result_{world}.txt").read().split()
+    assert ok == "True" and int(n_rows) > 3000
+    per_rank = [int(x) for x in per_rank]
+    assert len(per_rank) == world and all(0 < x < int(n_sites) * 0.75 for x in per_rank) and sum(per_rank) < 1.3 * int(n_sites)
