@@ -7,7 +7,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 summary, note = sys.argv[1], sys.argv[2]
 vals = {}
 for line in open(summary):
-    m = re.match(r"score_quad_kernel<19, 1>\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=([0-9.e+]+)", line)
+    m = re.match(r"score_quad_kernel<19, 1(?:, true)?>\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=([0-9.e+]+)", line)
     if m:
         vals[m.group(1)] = float(m.group(2))
 files = ["grafimo_amd/csrc/gfm_score_quad.hpp", "grafimo_amd/csrc/score_quad_tu.hip"]
