@@ -1152,9 +1152,10 @@ struct FusedPlan {
     Buf<Tile> f_tiles;
     Buf<DelWin> f_del_wins;
     Buf<HeavyWin> f_heavy;                 // the plan's heavy windows (graph_heavy_kernel); f_flags[8..9]: their count << 32 | items
-    unsigned long long *h_heavy_ctl = nullptr;   // pinned: that word, copied back once per plan (no heavy window: no launch)
-    hipEvent_t ev_heavy = nullptr;
-    bool heavy_known = false, heavy_asked = false;
+    unsigned long long *h_heavy_ctl = nullptr;   // pinned [2]: that word, copied back once per plan (no heavy window: no launch); [1]: the
+                                                 // number of work items of graph_del_score_kernel (its grid, once the host knows it)
+    hipEvent_t ev_heavy = nullptr, ev_items = nullptr;
+    bool heavy_known = false, heavy_asked = false, items_known = false, items_asked = false;
     Buf<DelBatchRec> f_del_recs;         // per listed window: what graph_del_count_kernel found
     Buf<DelItem> f_del_items;            // work items of graph_del_score_kernel
     // [0] unused, [1] listed windows, [2] overflow of the call, [3] work items of the deletion kernels, [4] overflow among the
@@ -1168,13 +1169,16 @@ struct FusedPlan {
     {
         hipError_t e = hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_heavy, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h_heavy_ctl), sizeof(unsigned long long), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_items, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h_heavy_ctl), 2 * sizeof(unsigned long long), hipHostMallocDefault);
+        if (e == hipSuccess) h_heavy_ctl[0] = h_heavy_ctl[1] = 0ull;
         return e;
     }
     ~FusedPlan()
     {
         if (ev_plan) (void)hipEventDestroy(ev_plan);
         if (ev_heavy) (void)hipEventDestroy(ev_heavy);
+        if (ev_items) (void)hipEventDestroy(ev_items);
         if (h_heavy_ctl) (void)hipHostFree(h_heavy_ctl);
         f_tiles.release(); f_del_wins.release(); f_heavy.release(); f_del_recs.release(); f_del_items.release(); f_flags.release();
     }
@@ -1913,10 +1917,13 @@ template <int MM> int launch_fused(FusedLaunch &L)
     a.slabs = g->f_slabs.p;
     // the listed windows' walks (graph_del_score_kernel: one wavefront per work item of the plan).  On every call but a plan's
     // first the list, the layouts and the work items exist already and the kernel depends on nothing graph_score_kernel does:
-    // it COULD run beside it on the handle's side stream -- measured (GRAFIMO_FUSED_BESIDE=1, profiles/r05_fused_ab.txt): the
-    // call gets slower, 0.094 against 0.088 ms -- its one-wavefront workgroups take LDS the score kernel's second workgroup
-    // per CU then waits for, and graph_score_kernel stretches from 53.5 to 73.2 us.  One after the other it is.
-    auto launch_del_score = [&](hipStream_t on) -> int {
+    // it COULD run beside it on the handle's side stream.  Measured twice (GRAFIMO_FUSED_BESIDE=1, profiles/r05_fused_ab.txt):
+    // with the grid that fills every CU's LDS whatever the number of items the call was 0.094 against 0.088 ms; with the grid
+    // sized to the plan's items (the host learns their number on the plan's first call: at most one workgroup per CU, launched
+    // behind the score kernel) 0.106 against 0.089 ms -- graph_score_kernel stretches by more than graph_del_score_kernel
+    // takes alone (its share of the tiles per wavefront is fixed before it starts: whatever delays some of its wavefronts
+    // delays its end).  One after the other it is; the item count still sizes the grid.
+    auto launch_del_score = [&](hipStream_t on, int grid_cap) -> int {
         if (const int rc = kernel_prepare(FK::del_score, reinterpret_cast<const void *>(graph_del_score_kernel<MM>))) return rc;
         int pitch = ((W + 3) / 4) * 4;
         if ((pitch / 4) % 2 == 0) pitch += 4;         // an odd dword pitch: the lanes' slots fall on all LDS banks
@@ -1925,14 +1932,21 @@ template <int MM> int launch_fused(FusedLaunch &L)
                              3 * sizeof(int) * kFusedDelThreads + sizeof(int) * (size_t)kFusedDelThreads * W +
                              (size_t)kFusedDelThreads * pitch;
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(150 * 1024) / lds_b));
-        hipLaunchKernelGGL((graph_del_score_kernel<MM>), dim3((unsigned)(per_cu * n_cu)), dim3(kFusedDelThreads), lds_b, on, g->dev, a,
+        const int grid = grid_cap > 0 ? std::min(grid_cap, per_cu * n_cu) : per_cu * n_cu;
+        hipLaunchKernelGGL((graph_del_score_kernel<MM>), dim3((unsigned)grid), dim3(kFusedDelThreads), lds_b, on, g->dev, a,
                            P->f_tiles.p, P->f_del_wins.p, P->f_flags.p + 1, P->f_del_recs.p, P->f_del_items.p, P->f_flags.p + 3,
                            pitch);
         return GFM_OK;
     };
-    static const bool serial = [] { const char *e = std::getenv("GRAFIMO_FUSED_BESIDE"); return !(e && *e == '1'); }();   // measurement aid
+    static const bool serial = [] { const char *e = std::getenv("GRAFIMO_FUSED_BESIDE"); return !(e && *e == '1'); }();   // measurement aid: '1' = beside
+    if (!P->items_known && P->items_asked) {
+        if (hipEventQuery(P->ev_items) == hipSuccess) P->items_known = true;
+        else (void)hipGetLastError();          // ("not ready" is no error of this call)
+    }
+    const int n_items = P->items_known ? (int)P->h_heavy_ctl[1] : -1;
     const bool beside = split == 2 && part[0].grid > 0 && part[1].grid > 0;
-    const bool del_beside = !L.listing && L.indels && !serial;
+    const bool del_beside = !L.listing && L.indels && !serial && n_items > 0;
+    const bool del_none = !L.listing && n_items == 0;          // the plan lists no window: nothing to launch
     if (L.indels) {
         const size_t n_batches = ((size_t)P->f_general_windows + kFusedDelThreads - 1) / kFusedDelThreads;      // (listed windows live in the general tiles)
         GX_TRY(P->f_del_recs.reserve(n_batches * kFusedDelThreads + 1));
@@ -1942,8 +1956,6 @@ template <int MM> int launch_fused(FusedLaunch &L)
         GX_TRY(hipEventRecord(g->ev_fork, st));
         GX_TRY(hipStreamWaitEvent(g->side, g->ev_fork, 0));
     }
-    if (del_beside)
-        if (const int rc = launch_del_score(g->side)) return rc;
     const bool timed = g->prof_on && g->prof_n < gfm_graph::kProfSlots;
     if (timed) GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n], st));
     for (int general = 1; general >= 0; --general) {
@@ -1962,6 +1974,8 @@ template <int MM> int launch_fused(FusedLaunch &L)
     }
     GX_TRY(hipGetLastError());      // (before the event query below, whose "not ready" answer is cleared: a launch failure must not go with it)
     if (timed) { GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n + 1], st)); ++g->prof_n; }
+    if (del_beside)                 // behind the score kernel's launch: its workgroups have the CUs' LDS first
+        if (const int rc = launch_del_score(g->side, std::min(n_items, n_cu))) return rc;
     int n_slabs = g1;
     {
         // the heavy windows: launched until the plan's count has come back and says there is none
@@ -1995,9 +2009,13 @@ template <int MM> int launch_fused(FusedLaunch &L)
         P->f_plan_ready = true;       // (stream order: the calls that follow on this stream find the plan complete)
         P->f_plan_stream = st;
         GX_TRY(hipEventRecord(P->ev_plan, st));
+        // how many work items the plan holds: the grid of graph_del_score_kernel on the calls that follow
+        GX_TRY(hipMemcpyAsync(&P->h_heavy_ctl[1], P->f_flags.p + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+        GX_TRY(hipEventRecord(P->ev_items, st));
+        P->items_asked = true;
     }
-    if (L.indels && !del_beside)
-        if (const int rc = launch_del_score(st)) return rc;
+    if (L.indels && !del_beside && !del_none)
+        if (const int rc = launch_del_score(st, n_items)) return rc;
     if (beside || del_beside) {       // join: the histogram reduction and everything the caller enqueues next see the side stream's work
         GX_TRY(hipEventRecord(g->ev_join, g->side));
         GX_TRY(hipStreamWaitEvent(st, g->ev_join, 0));
@@ -2180,6 +2198,7 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
     if (listing) {
         GX_TRY(hipMemsetAsync(P->f_flags.p, 0, 16 * sizeof(int), st));
         P->heavy_known = P->heavy_asked = false;
+        P->items_known = P->items_asked = false;
     } else {
         GX_TRY(hipMemsetAsync(P->f_flags.p + 2, 0, sizeof(int), st));
     }
