@@ -485,3 +485,53 @@ def test_a_ranks_shard_of_the_graph_gives_the_rows_of_the_whole_graph(tmp_path):
         got = sub.ins_bases[sub.ins_off[i]:sub.ins_off[i] + sub.ins_len[i]].tobytes()
         assert any(got == idx.ins_bases[idx.ins_off[k]:idx.ins_off[k] + idx.ins_len[k]].tobytes()
                    for k in np.flatnonzero((idx.pos == sub.pos[i]) & (idx.ins_len > 0)).tolist()), (i, j)
+
+
+def test_scan_graph_manifest_mode_needs_no_gpu(tmp_path, monkeypatch, capsys):
+    """scan_graph in manifest mode (its consumer is grafimo_amd's compute_results) reads the BED file, resolves the graph
+    files by the reference's naming rules (--chroms-prefix-find / --chroms-namemap-find, extract_regions.py:136-226) and
+    writes a manifest -- no GPU call, no row.  Which mode: the caller's own `compute_results` decides (or GRAFIMO_SCAN_OUTPUT)."""
+    import json
+    import shutil
+    from grafimo_amd import extract_regions as xr
+    from grafimo_amd.workflow import Findmotif
+    ref = np.frombuffer(b"ACGT" * 100, dtype=np.uint8)
+    idx = xr.GraphIndex("1", ref, [10, 50], [1, 1], np.array([[67, 0, 0], [71, 0, 0]], np.uint8), None, 0)
+    gdir = tmp_path / "vgs"
+    gdir.mkdir()
+    idx.save(str(gdir / "chr1"))
+    idx.save(str(gdir / "scaffoldX"))
+    bed = tmp_path / "r.bed"
+    bed.write_text("track name=t\nchr1\t0\t100\tpeak1\nchr1\t200\t390\nchrX\t5\t60\n1\t0\t10\n")
+    # (1) the mode
+    assert xr._scan_output_mode({"compute_results": xr.compute_results_from_graph}) == "manifest"      # a grafimo_amd function
+    assert xr._scan_output_mode({"compute_results": json.dumps}) == "tsv" and xr._scan_output_mode({}) == "tsv"
+    monkeypatch.setenv("GRAFIMO_SCAN_OUTPUT", "tsv")
+    assert xr._scan_output_mode({"compute_results": xr.compute_results_from_graph}) == "tsv"
+    monkeypatch.setenv("GRAFIMO_SCAN_OUTPUT", "nonsense")
+    with pytest.raises(ValueError):
+        xr._scan_output_mode({})
+    monkeypatch.setenv("GRAFIMO_SCAN_OUTPUT", "manifest")
+    # (2) --chroms-prefix-find chr: chromosome 1 only asked for
+    loc = xr.scan_graph({19, 8}, Findmotif(graph_genome_dir=str(gdir), bedfile=str(bed), chroms=["1"], chroms_prefix="chr"), True)
+    man = json.load(open(os.path.join(loc, xr.MANIFEST_NAME)))
+    assert man["format"] == 1 and man["widths"] == [8, 19] and sorted(os.listdir(loc)) == sorted([xr.MANIFEST_NAME, "width_19", "width_8"])
+    assert man["entries"] == [{"index": str(gdir / "chr1.gfmidx.npz"), "chrom": "1", "regions": [[0, 100], [200, 390]]}]
+    got = xr.read_manifest(loc)
+    assert got["widths"] == {8, 19} and got["entries"][0]["regions"].dtype == np.int64 and got["entries"][0]["regions"].shape == (2, 2)
+    assert xr.read_manifest(loc) is got                         # parsed once per file
+    shutil.rmtree(loc)
+    assert xr.read_manifest(str(tmp_path)) is None
+    # (3) a name map: BED chromosome X -> graph file scaffoldX; every chromosome of the BED file (the default)
+    loc = xr.scan_graph({19}, Findmotif(graph_genome_dir=str(gdir), bedfile=str(bed), namemap={"1": "chr1", "X": "scaffoldX"}), True)
+    man = json.load(open(os.path.join(loc, xr.MANIFEST_NAME)))
+    assert [(os.path.basename(e["index"]), e["chrom"], e["regions"]) for e in man["entries"]] == \
+        [("chr1.gfmidx.npz", "1", [[0, 100], [200, 390]]), ("scaffoldX.gfmidx.npz", "X", [[5, 60]])]      # the path name of the
+    # query stays the chromosome's (reference :155-159: `c = chrom` under a name map); only the FILE is the mapped name
+    shutil.rmtree(loc)
+    # (4) a missing index is the reference's VGError
+    with pytest.raises(Exception) as e:
+        xr.scan_graph({19}, Findmotif(graph_genome_dir=str(tmp_path), bedfile=str(bed), chroms=["1"], chroms_prefix="chr"), True)
+    assert "Unable to locate" in str(e.value)
+    out = capsys.readouterr().out
+    assert "Extracting regions defined in" in out
