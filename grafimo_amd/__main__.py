@@ -1,11 +1,18 @@
-"""Scoring stage of ``grafimo findmotif`` on the GPU, for k-mers that were already extracted.
+"""``grafimo findmotif`` on the GPU.
 
 The reference's ``findmotif`` runs ``get_motif_pwm`` -> ``scan_graph`` (external ``vg find``) ->
-``compute_results`` -> ``write_results`` (grafimo.py:80-190).  ``vg`` is not part of this build, so
-this entry point starts after ``scan_graph``: ``--sequences`` is the directory it would have
-produced (``width_W/REGION.tsv``).  Flags keep the names, defaults and meaning of the reference CLI
-(__main__.py:119-415): -m/--motif, -k/--bgfile, -p/--pseudo, -t/--threshold, -q/--no-qvalue,
+``compute_results`` -> ``write_results`` (grafimo.py:80-190).  Flags keep the names, defaults and meaning of the
+reference CLI (__main__.py:119-415): -g/--genome-graph, -d/--genome-graph-dir, -b/--bedfile, --chroms-find,
+--chroms-prefix-find, --chroms-namemap-find, -m/--motif, -k/--bgfile, -p/--pseudo, -t/--threshold, -q/--no-qvalue,
 -r/--no-reverse, -f/--text-only, --recomb, --qvalueT, -j/--cores, -o/--out, --verbose, --debug.
+
+With -g XG or -d DIR (+ -b BED) the run is the reference's: scan_graph over the chromosomes' graphs -- vg's own
+chrN.xg + chrN.gbwt, read by grafimo_amd/vg_files.py, or the .gfmidx.npz saved beside them -- then compute_results per
+motif.  The reference's tutorial runs as written (tutorials/findmotif_tutorial):
+
+    python -m grafimo_amd -d data/mygenome/ -m data/example.meme -b data/regions.bed
+
+``--sequences`` starts after ``scan_graph``: the directory it would have produced (``width_W/REGION.tsv``).
 
     python -m grafimo_amd -m MA0139.1.meme -s /tmp/grafimo_XXXX -t 1e-4 -o out_dir
 
@@ -30,24 +37,53 @@ class _Workflow(Findmotif):
     def __init__(self, a):
         super().__init__(cores=a.cores, threshold=a.threshold, no_qvalue=a.no_qvalue, qval_t=a.qval_t,
                          no_reverse=a.no_reverse, recomb=a.recomb, verbose=a.verbose, bgfile=a.bgfile,
-                         pseudo=a.pseudo)
+                         pseudo=a.pseudo, graph_genome=a.genome_graph or "", graph_genome_dir=a.genome_graph_dir or "",
+                         bedfile=a.bedfile or "", chroms=a.chroms_find, chroms_prefix=a.chroms_prefix or "",
+                         namemap=_parse_namemap(a.chroms_namemap_find))
         self.outdir = a.out
         self.top_graphs = 0
         self.text_only = a.text_only
+
+
+NOMAP = "NOMAP"
+
+
+def _parse_namemap(fn):
+    """utils.parse_namemap (utils.py:83-120): original chromosome name, the name its graph is stored under"""
+    if not fn or fn == NOMAP:
+        return {}
+    import os
+    if not os.path.isfile(fn):
+        sys.exit(f"ERROR: Unable to find {fn}.")
+    out = {}
+    with open(fn) as fh:
+        for line in fh:
+            f = line.split()
+            if len(f) >= 2:
+                out[f[0]] = f[1]
+    return out
 
 
 def get_parser():
     p = argparse.ArgumentParser(prog="python -m grafimo_amd", description=__doc__,
                                 formatter_class=argparse.RawDescriptionHelpFormatter)
     p.add_argument("-m", "--motif", nargs="+", required=True, metavar="MOTIF-FILE")
+    p.add_argument("-g", "--genome-graph", dest="genome_graph", metavar="XG",
+                   help="whole-genome graph: vg's XG (the GBWT beside it), or the .gfmidx.npz saved under its name")
+    p.add_argument("-d", "--genome-graph-dir", dest="genome_graph_dir", metavar="DIR",
+                   help="directory of per-chromosome graphs (chrN.xg + chrN.gbwt, or chrN.gfmidx.npz)")
+    p.add_argument("--chroms-find", dest="chroms_find", nargs="*", default=[], metavar="CHR",
+                   help="scan only these chromosomes (default: every chromosome of the BED file)")
+    p.add_argument("--chroms-namemap-find", dest="chroms_namemap_find", nargs="?", default=NOMAP, metavar="NAME-MAP-FILE",
+                   help="two columns: chromosome name, name its graph is stored under")
     p.add_argument("-s", "--sequences", metavar="DIR",
                    help="directory holding width_W/*.tsv as written by vg find -K W -E")
     p.add_argument("-l", "--linear-genome", dest="linear_genome", metavar="FASTA",
                    help="reference FASTA (with -v and -b: extract the k-mers on the GPU instead of -s)")
     p.add_argument("-v", "--vcf", metavar="VCF", help="phased VCF (.vcf or .vcf.gz): substitutions, insertions, deletions")
     p.add_argument("-b", "--bedfile", metavar="BED", help="regions to scan (UCSC BED: lines starting with chr)")
-    p.add_argument("--chroms-prefix-find", dest="chroms_prefix", default="", metavar="PREFIX",
-                   help="chromosome names in the FASTA / VCF = PREFIX + the BED name without its leading chr")
+    p.add_argument("--chroms-prefix-find", dest="chroms_prefix", nargs="?", default="", metavar="PREFIX",
+                   help="graph files / chromosome names in the FASTA and VCF = PREFIX + the BED name without its leading chr")
     p.add_argument("--strict-variants", action="store_true", dest="strict_variants",
                    help="fail on VCF records with a symbolic ALT (<DEL>, <CN0>, breakends, '*') instead of leaving them "
                         "out with a warning, which is what vg construct does without --handle-sv")
@@ -75,9 +111,19 @@ def main(argv=None):
         sys.exit("ERROR: the threshold must be in (0, 1]")
     if a.qval_t and a.no_qvalue:
         sys.exit("ERROR: --qvalueT needs q-values (drop -q)")
-    from_graph = bool(a.linear_genome or a.vcf or a.bedfile)
-    if from_graph == bool(a.sequences) or (from_graph and not (a.linear_genome and a.vcf and a.bedfile)):
-        sys.exit("ERROR: give either -s DIR or all of -l FASTA -v VCF -b BED")
+    from_vg = bool(a.genome_graph or a.genome_graph_dir)
+    if from_vg:
+        if a.genome_graph and a.genome_graph_dir:
+            sys.exit("ERROR: give -g XG or -d DIR, not both")
+        if not a.bedfile or a.sequences or a.linear_genome or a.vcf:
+            sys.exit("ERROR: -g / -d go with -b BED (and without -s, -l, -v)")
+        if a.chroms_prefix and a.chroms_namemap_find != NOMAP:
+            sys.exit('ERROR: "--chroms-prefix-find" and "chroms-namemap-find" cannot be used together')
+        if len(set(a.chroms_find)) != len(a.chroms_find):
+            sys.exit('ERROR: Duplicated chromosome names given to "--chroms-find"')
+    from_graph = not from_vg and bool(a.linear_genome or a.vcf or a.bedfile)
+    if not from_vg and (from_graph == bool(a.sequences) or (from_graph and not (a.linear_genome and a.vcf and a.bedfile))):
+        sys.exit("ERROR: give -g XG / -d DIR with -b BED, or -s DIR, or all of -l FASTA -v VCF -b BED")
     if a.cores <= 0:
         import os
         a.cores = os.cpu_count() or 1
@@ -100,9 +146,17 @@ def main(argv=None):
                       f"{index.skipped} ALT alleles left out")
             graphs.append(DeviceGraph(index))
             region_lists.append(regs)
-    shared = None if from_graph or len(motifs) < 2 else compute_results_many(motifs, a.sequences, a.debug, wf)
+    sequences_loc = None
+    if from_vg:
+        # the reference's own sequence (grafimo.py:176-183); `compute_results` above is ours, so scan_graph leaves a manifest
+        # and every motif is scored where its walks are enumerated
+        from .extract_regions import scan_graph
+        sequences_loc = scan_graph({int(m.width) for m in motifs}, wf, a.debug)
+    shared = None if from_graph or from_vg or len(motifs) < 2 else compute_results_many(motifs, a.sequences, a.debug, wf)
     for k, motif in enumerate(motifs):
-        if from_graph:
+        if from_vg:
+            res = compute_results(motif, sequences_loc, a.debug, wf)
+        elif from_graph:
             res = compute_results_from_graph(motif, graphs, region_lists, a.debug, wf)
         elif shared is not None:
             res = shared[k]              # one ingest / upload per width, batched launches
@@ -112,6 +166,9 @@ def main(argv=None):
             print_results(res, a.debug)
         else:
             write_results(res, motif, len(motifs), wf, a.debug)
+    if sequences_loc:
+        import shutil
+        shutil.rmtree(sequences_loc, ignore_errors=True)
     print("Elapsed time %.2fs" % (time.time() - start))
 
 

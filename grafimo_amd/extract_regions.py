@@ -825,6 +825,60 @@ def _index_path(xg: str) -> str:
     return xg[:-3] + INDEX_SUFFIX if xg.endswith(".xg") else xg + INDEX_SUFFIX
 
 
+def _index_cache_dir() -> str:
+    d = os.environ.get("GRAFIMO_INDEX_CACHE") or os.path.join(tempfile.gettempdir(), f"grafimo_amd_index_{os.getuid()}")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def graph_index_file(xg: str, chrom: str, whole_genome: bool, debug: bool = False, verbose: bool = False) -> str:
+    """The saved GraphIndex that stands for the graph file `xg` the reference would hand to `vg find -x XG -H GBWT`
+    (extract_regions.py:172-180, 217-225), made on the spot from vg's own files where it does not exist yet:
+      1. `<xg without .xg>.gfmidx.npz` (what `GraphIndex.from_fasta_vcf(...).save(...)` left there) if it exists;
+         for a whole-genome XG also `<...>.<chrom>.gfmidx.npz`;
+      2. otherwise the XG and the GBWT beside it (same name, as the reference requires) are read (grafimo_amd.vg_files:
+         the path named `chrom` -- or the only path of a one-chromosome XG) and the index is saved under the name of 1.,
+         or, where that directory cannot be written, in $GRAFIMO_INDEX_CACHE / the temporary directory, keyed on the
+         files' path, size and modification time;
+      3. neither: the reference's own error (`Unable to locate ...`)."""
+    from . import vg_files
+    beside = [_index_path(xg)]
+    if whole_genome:
+        beside.insert(0, _index_path(xg)[:-len(INDEX_SUFFIX)] + f".{chrom}" + INDEX_SUFFIX)
+    for f in beside:
+        if os.path.isfile(f):
+            return f
+    gbwt = xg.replace("xg", "gbwt")                    # (the reference's own rule, extract_regions.py:174,219)
+    for f in (xg, gbwt):
+        if not os.path.isfile(f):
+            exception_handler(VGError, f"Unable to locate {f}. Are your VGs named with \"chr\"? Consider using "
+                                       "--chroms-prefix-find or chroms-namemap-find.\n", debug)
+    st = [os.stat(f) for f in (xg, gbwt)]
+    tag = "_".join(f"{s.st_size:x}.{s.st_mtime_ns:x}" for s in st)
+    import hashlib
+    cached = os.path.join(_index_cache_dir(), hashlib.sha1(f"{os.path.abspath(xg)}|{chrom if whole_genome else ''}|{tag}"
+                                                             .encode()).hexdigest()[:24] + INDEX_SUFFIX)
+    if os.path.isfile(cached):
+        return cached
+    t0 = time.time()
+    try:
+        index = vg_files.index_from_vg(xg, gbwt, chrom=chrom, path_name=chrom if whole_genome else None)
+    except vg_files.VGFormatError as e:
+        exception_handler(VGError, f"{e}\n", debug)
+    if verbose:
+        print(f"Read {xg} + {os.path.basename(gbwt)}: {len(index.ref)} bases, {len(index.pos)} sites, "
+              f"{index.n_haplotypes} haplotypes in %.2fs.\n" % (time.time() - t0))
+    for target in (beside[0], cached):
+        try:
+            tmp = target + f".{os.getpid()}.tmp" + INDEX_SUFFIX
+            index.save(tmp)
+            os.replace(tmp, target)
+            return target
+        except OSError:
+            continue
+    exception_handler(VGError, f"Unable to save the graph index of {xg} (tried {beside[0]} and {cached}).\n", debug)
+
+
 MANIFEST_NAME = "grafimo_amd_manifest.json"   # what scan_graph leaves instead of rows when compute_results is ours
 
 
@@ -856,9 +910,9 @@ def scan_graph(widths: Set[int], args_obj, debug: bool) -> str:
         walks where they are enumerated (compute_results_from_graph).  grafimo.py:176-183 runs unchanged either way; in
         manifest mode this function does not touch the GPU (no fork hazard for a caller that forks afterwards).
 
-    vg's XG / GBWT files cannot be read here; the graph of a chromosome comes from the GraphIndex written by
-    `GraphIndex.from_fasta_vcf(...).save(...)` NEXT TO the XG the reference would open, under the same name
-    with the extension .gfmidx.npz (chr22.xg -> chr22.gfmidx.npz)."""
+    The graph of a chromosome: the GraphIndex saved NEXT TO the XG the reference would open, under the same name with the
+    extension .gfmidx.npz (chr22.xg -> chr22.gfmidx.npz; `GraphIndex.from_fasta_vcf(...).save(...)` writes one) -- or, where
+    there is none, vg's own chr22.xg + chr22.gbwt, read once and saved as that index (graph_index_file, vg_files.py)."""
     if not isinstance(widths, set):
         exception_handler(TypeError, f"Expected set, got {type(widths).__name__}.", debug)
     if not is_scan_args_like(args_obj):
@@ -905,11 +959,7 @@ def scan_graph(widths: Set[int], args_obj, debug: bool) -> str:
             else:
                 c = chrname
             xg = os.path.join(vg, ".".join([chrname, "xg"])) if args_obj.has_graphgenome_dir() else vg
-            ipath = _index_path(xg)
-            if not os.path.isfile(ipath):
-                exception_handler(VGError, f"Unable to locate {ipath} (the GPU extraction's index beside {xg}). "
-                                           "Are your VGs named with \"chr\"? Consider using --chroms-prefix-find or "
-                                           "chroms-namemap-find.\n", debug)
+            ipath = graph_index_file(xg, c, not args_obj.has_graphgenome_dir(), debug, verbose)
             spans = [(int(s), int(e)) for s, e in regions[key]]
             if mode == "manifest":
                 entries.append({"index": os.path.abspath(ipath), "chrom": c, "regions": spans})

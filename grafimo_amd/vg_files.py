@@ -1,0 +1,699 @@
+"""vg's own index files as the graph input of scan_graph: the XG (`vg index -x`: nodes, edges, the reference path) and the GBWT
+beside it (`vg index -G`: the haplotype threads) -- what a GRAFIMO user HAS, and what the reference hands to
+`vg find -p REGION -x XG -H GBWT -K W -E` (extract_regions.py:172-180, 217-225; built by constructVG.py:343-402).  Read here on
+the host, once per chromosome, and turned into the GraphIndex the extraction kernels work on (index_from_vg); scan_graph does
+that by itself when it finds `chrN.xg` + `chrN.gbwt` and no `chrN.gfmidx.npz`, and saves the index for the next run.
+
+What is decoded, and what it is pinned by.  The formats are vg's (sdsl-lite serialisations inside vg's type-tagged message
+stream); no vg binary and no vg source exist in this image, so the layouts below were read off the files the reference
+repository ships (tutorials/findmotif_tutorial/data/mygenome/{x,y}.xg + .gbwt: XG version 15, GBWT version 4, built from
+tutorials/buildvg_tutorial/data/xy.fa + xy2.vcf.gz) and every decode is CHECKED rather than trusted: a path must be a walk
+along the graph's edges from record start to record start, the edge and node counts must equal the header's, the GBWT's
+record index must add up.  tests/test_vg_files.py holds the pin: the GraphIndex from x.xg + x.gbwt equals, array by array,
+the one from xy.fa + xy2.vcf.gz (the route pinned against vg's own `vg find` rows), for both tutorial chromosomes.  Other
+versions of the two formats are refused by name, not guessed at.
+
+  XG (version 15), payload after the tag "XG":
+    u32 magic 0xF6F596A1, u32 version (both big-endian); u64 x 6: sequence length, nodes, edges, paths, min id, max id;
+    r_iv   int_vector<0>   node ids by rank
+    g_iv   int_vector<0>   per node the record [id, start in s_iv, length, #edges to, #edges from] and one entry per edge
+                           side: zigzag(offset of the other node's record relative to this one) << 1 | reversing bit
+    g_bv   bit_vector      1 at every record start of g_iv;  + rank_support_v, select_support_mcl
+    s_iv   int_vector<0>   the bases (A 0, T 1, C 2, G 3, N 4);  s_bv bit_vector (node starts) + rank + select
+    pn_iv  int_vector<0>   the path names, "#name$" each;  pn_csa (a compressed suffix array: NOT parsed -- skipped by
+                           looking for the first byte offset behind it at which the path block below decodes and validates)
+    u64 path count, then per path:  u64 min_handle;  enc_vector<elias_delta, 128> handles (handle = record offset << 1 |
+                           is_reverse, stored minus min_handle);  rrr_vector<63> offsets (skipped structurally);  u8 is_circular
+  GBWT (version 4), payload after the tag "GBWT":
+    u32 tag 0x6B376B37, u32 version, u64 x 5: sequences, size, offset, alphabet size, flags (bit 0 = bidirectional);
+    u64 records;  sd_vector of the records' first bytes (u64 size, u8 low width, low int_vector<0>, high bit_vector, two
+    select supports);  the records' bytes.  Record r belongs to GBWT node r + offset (record 0: the endmarker), GBWT node =
+    2 * id + is_reverse: ByteCode outdegree, (node delta, offset) per outgoing edge, then runs (edge rank, length) -- one
+    entry per visit, in the order of the BWT.  In a bidirectional index sequence 2k is haplotype k forward.
+
+Haplotypes per node WITHOUT following the threads one by one: the visits of a node are sorted by the node they came from, so
+the sequence ids at node w are the concatenation, over its predecessors in node order, of the ids that left the predecessor
+by the edge to w -- and the record says where each predecessor's block starts (the edge's offset).  One pass over the forward
+nodes in id order (`vg construct` numbers nodes along the reference: every edge goes up) moves every id once per node it
+visits, as array slices.
+"""
+import os
+import struct
+import sys
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+XG_MAGIC = 0xF6F596A1
+XG_VERSIONS = (15,)                 # what the reference repository's files pin
+GBWT_TAG = 0x6B376B37
+GBWT_VERSIONS = (4,)
+_XG_BASES = np.frombuffer(b"ATCGNNNN", dtype=np.uint8)
+ENC_DENS = 128                      # sdsl::enc_vector<>'s sample density
+
+
+class VGFormatError(ValueError):
+    """the file is not what this reader decodes (wrong container, another version, a structure that does not add up)"""
+
+
+def _varint(b, i: int) -> Tuple[int, int]:
+    v = s = 0
+    while True:
+        c = b[i]
+        i += 1
+        v |= (c & 0x7F) << s
+        s += 7
+        if not c & 0x80:
+            return v, i
+
+
+def tagged_payload(raw: bytes, tag: bytes, path: str = "") -> bytes:
+    """vg's type-tagged stream: groups `[varint count][varint length, bytes] * count`, the first message of a group its
+    tag, the others the payload in order.  -> the payload of all groups with that tag, joined."""
+    out, i, n = [], 0, len(raw)
+    mv = memoryview(raw)
+    try:
+        while i < n:
+            cnt, i = _varint(raw, i)
+            for k in range(cnt):
+                ln, i = _varint(raw, i)
+                if i + ln > n:
+                    raise IndexError
+                if k == 0:
+                    if bytes(mv[i:i + ln]) != tag:
+                        raise VGFormatError(f"{path}: a group tagged {bytes(mv[i:i + ln])[:16]!r}, not {tag!r}")
+                else:
+                    out.append(mv[i:i + ln])
+                i += ln
+    except IndexError:
+        raise VGFormatError(f"{path}: not a type-tagged vg stream (truncated, or another container)") from None
+    if not out:
+        raise VGFormatError(f"{path}: no {tag.decode()} payload")
+    return b"".join(out)
+
+
+def _unpack(words: np.ndarray, width: int, n: int) -> np.ndarray:
+    """n entries of `width` bits from little-endian 64-bit words (sdsl::int_vector's layout) -> uint64 [n]"""
+    if n == 0 or width == 0:
+        return np.zeros(n, dtype=np.uint64)
+    if width == 64:
+        return words[:n].astype(np.uint64)
+    pos = np.arange(n, dtype=np.uint64) * np.uint64(width)
+    wi = (pos >> np.uint64(6)).astype(np.int64)
+    sh = pos & np.uint64(63)
+    w = np.concatenate([words.astype(np.uint64), np.zeros(1, dtype=np.uint64)])
+    lo = w[wi] >> sh
+    hi = np.where(sh > 0, w[wi + 1] << ((np.uint64(64) - sh) & np.uint64(63)), np.uint64(0))
+    return (lo | hi) & np.uint64((1 << width) - 1)
+
+
+def _ones(words: np.ndarray, bits: int) -> np.ndarray:
+    """positions of the set bits of an sdsl::bit_vector"""
+    if bits == 0:
+        return np.zeros(0, dtype=np.int64)
+    b = np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:bits]
+    return np.flatnonzero(b).astype(np.int64)
+
+
+class _Reader:
+    """a cursor over an sdsl serialisation"""
+
+    def __init__(self, buf: bytes, path: str, at: int = 0):
+        self.b, self.path, self.o = buf, path, at
+
+    def _need(self, n: int):
+        if n < 0 or self.o + n > len(self.b):
+            raise VGFormatError(f"{self.path}: a structure runs past the end of the file (offset {self.o}, {n} bytes)")
+
+    def u64(self) -> int:
+        self._need(8)
+        v, = struct.unpack_from("<Q", self.b, self.o)
+        self.o += 8
+        return v
+
+    def u8(self) -> int:
+        self._need(1)
+        v = self.b[self.o]
+        self.o += 1
+        return v
+
+    def words(self, bits: int) -> np.ndarray:
+        n = (bits + 63) >> 6
+        self._need(8 * n)
+        a = np.frombuffer(self.b, dtype="<u8", count=n, offset=self.o)
+        self.o += 8 * n
+        return a
+
+    def int_vector0(self) -> Tuple[np.ndarray, int, int]:
+        """sdsl::int_vector<0>: u64 bits, u8 width, words -> (words, width, entries)"""
+        bits, width = self.u64(), self.u8()
+        if width > 64:
+            raise VGFormatError(f"{self.path}: int_vector of width {width} at offset {self.o - 9}")
+        return self.words(bits), width, (bits // width if width else 0)
+
+    def values0(self) -> np.ndarray:
+        w, width, n = self.int_vector0()
+        return _unpack(w, width, n)
+
+    def bit_vector(self) -> Tuple[np.ndarray, int]:
+        bits = self.u64()
+        return self.words(bits), bits
+
+    def skip_rank_v(self):
+        self.words(self.u64())                                     # int_vector<64> of the basic blocks
+
+    def skip_select_mcl(self):
+        """sdsl::select_support_mcl: u64 arguments; if any: the superblock vector, the mini-or-long bits, one vector per
+        4 096 arguments"""
+        args = self.u64()
+        if args:
+            self.int_vector0()
+            self.bit_vector()
+            for _ in range((args + 4095) >> 12):
+                self.int_vector0()
+
+    def skip_rrr63(self):
+        """sdsl::rrr_vector<63>: u64 size, block types, block numbers (a bit_vector), their pointers, rank samples, the
+        inversion bits; its rank / select supports serialise nothing"""
+        self.u64()
+        self.int_vector0()
+        self.bit_vector()
+        self.int_vector0()
+        self.int_vector0()
+        self.bit_vector()
+
+
+def _elias_delta_all(zwords: np.ndarray, zbits: int, samples: np.ndarray, size: int) -> np.ndarray:
+    """sdsl::enc_vector<coder::elias_delta, 128>: entry i = sample value of its block + the sum of the deltas since.
+    samples = [value, bit pointer] per block (+ a closing pair).  A delta x >= 1 is written, least significant bit first, as:
+    k zeros and a one (k = bits of (bits of x)) - 1... i.e. unary k; the low k bits of len = bits(x); the low len - 1 bits of x."""
+    z = int.from_bytes(np.ascontiguousarray(zwords).tobytes(), "little")
+    out = np.empty(size, dtype=np.uint64)
+    mask64 = (1 << 64) - 1
+    v = pos = 0
+    for i in range(size):
+        if i % ENC_DENS == 0:
+            v, pos = int(samples[2 * (i // ENC_DENS)]), int(samples[2 * (i // ENC_DENS) + 1])
+        else:
+            k = 0
+            while not (z >> pos) & 1:
+                pos += 1
+                k += 1
+                if pos > zbits:
+                    raise VGFormatError("Elias-delta stream runs out")
+            pos += 1
+            if k == 0:
+                d = 1
+            else:
+                ln = ((z >> pos) & ((1 << k) - 1)) + (1 << k)
+                pos += k
+                d = ((z >> pos) & ((1 << (ln - 1)) - 1)) + ((1 << (ln - 1)) if ln - 1 < 64 else 0)
+                pos += ln - 1
+            v = (v + d) & mask64
+        out[i] = v
+    return out
+
+
+class XG:
+    """nodes (ids, sequences), edges (indices into the node arrays, all end -> start) and the embedded paths of one XG"""
+
+    def __init__(self, path: str):
+        self.path = path
+        raw = open(path, "rb").read()
+        p = raw if raw[:4] == struct.pack(">I", XG_MAGIC) else tagged_payload(raw, b"XG", path)
+        if len(p) < 56:
+            raise VGFormatError(f"{path}: too short for an XG")
+        magic, self.version = struct.unpack_from(">II", p, 0)
+        if magic != XG_MAGIC:
+            raise VGFormatError(f"{path}: bad XG magic {magic:#x}")
+        if self.version not in XG_VERSIONS:
+            raise VGFormatError(f"{path}: XG version {self.version}; this reader decodes version(s) "
+                                f"{', '.join(map(str, XG_VERSIONS))} (build the index from FASTA + VCF instead: "
+                                f"GraphIndex.from_fasta_vcf)")
+        r = _Reader(p, path, 8)
+        self.seq_length, n_nodes, n_edges, n_paths, self.min_id, self.max_id = (r.u64() for _ in range(6))
+        rank_ids = r.values0()
+        if len(rank_ids) != n_nodes:
+            raise VGFormatError(f"{path}: id vector holds {len(rank_ids)} entries for {n_nodes} nodes")
+        g = r.values0().astype(np.int64)
+        gbv, gbits = r.bit_vector()
+        if gbits != len(g):
+            raise VGFormatError(f"{path}: graph bit vector of {gbits} bits beside a graph vector of {len(g)} entries")
+        r.skip_rank_v()
+        r.skip_select_mcl()
+        sw, swidth, sn = r.int_vector0()
+        if sn != self.seq_length or swidth > 3:
+            raise VGFormatError(f"{path}: sequence vector of {sn} x {swidth} bits for {self.seq_length} bases")
+        self.bases = _XG_BASES[_unpack(sw, swidth, sn).astype(np.int64)]
+        r.bit_vector()                                            # s_bv: node starts (the records say the same)
+        r.skip_rank_v()
+        r.skip_select_mcl()
+        names = bytes(r.values0().astype(np.uint8))
+        # ---- the node records
+        rec = _ones(gbv, gbits)
+        if len(rec) != n_nodes or (n_nodes and (rec[0] != 0 or rec[-1] + 5 > len(g))):
+            raise VGFormatError(f"{path}: {len(rec)} node records for {n_nodes} nodes")
+        self.rec_off = rec
+        self.ids = g[rec]
+        self.start = g[rec + 1]
+        self.length = g[rec + 2]
+        n_to, n_from = g[rec + 3], g[rec + 4]
+        ends = rec + 5 + n_to + n_from
+        if n_nodes and (not np.array_equal(ends[:-1], rec[1:]) or ends[-1] != len(g)):
+            raise VGFormatError(f"{path}: the node records do not tile the graph vector")
+        if n_nodes and ((self.start + self.length).max() > self.seq_length or self.length.min() < 1):
+            raise VGFormatError(f"{path}: a node's sequence lies outside the sequence vector")
+        src = np.repeat(np.arange(n_nodes, dtype=np.int64), n_from)
+        inner = np.arange(len(src), dtype=np.int64) - np.repeat(np.cumsum(n_from) - n_from, n_from)
+        ent = g[np.repeat(rec + 5 + n_to, n_from) + inner]
+        if (ent & 1).any():
+            raise VGFormatError(f"{path}: a reversing edge -- not a graph `vg construct` writes")
+        zz = ent >> 1
+        delta = np.where(zz & 1, -((zz + 1) >> 1), zz >> 1)
+        tgt = np.repeat(rec, n_from) + delta
+        dst = np.searchsorted(rec, tgt)
+        if len(dst) and ((dst >= n_nodes).any() or not np.array_equal(rec[np.minimum(dst, n_nodes - 1)], tgt)):
+            raise VGFormatError(f"{path}: an edge does not lead to a node record")
+        if len(src) != n_edges:
+            raise VGFormatError(f"{path}: {len(src)} edges decoded, the header says {n_edges}")
+        self.edge_from, self.edge_to = src, dst
+        # ---- the paths: behind the names' suffix array, which is skipped by finding where the block decodes
+        self.path_names = [s.decode() for s in names.replace(b"#", b"").split(b"$") if s]
+        if len(self.path_names) != n_paths:
+            raise VGFormatError(f"{path}: {len(self.path_names)} path names for {n_paths} paths")
+        self.paths: Dict[str, np.ndarray] = {}
+        if n_paths:
+            self._read_paths(p, r.o, n_paths)
+
+    def _path_at(self, p: bytes, at: int) -> Tuple[np.ndarray, int]:
+        """the XGPath serialised at `at` -> (node indices of its steps, offset behind it); VGFormatError if there is none"""
+        r = _Reader(p, self.path, at)
+        min_handle = r.u64()
+        size = r.u64()
+        if size == 0 or size > 64 * len(self.ids) + 64 or (min_handle >> 1) > int(self.rec_off[-1]):
+            raise VGFormatError("no path here")
+        zw, zwidth, _ = r.int_vector0()
+        zbits = len(zw) * 64
+        samples = r.values0()
+        if len(samples) != 2 * ((size + ENC_DENS - 1) // ENC_DENS + 1):
+            raise VGFormatError("no path here")
+        handles = _elias_delta_all(zw, zbits, samples, size) + np.uint64(min_handle)
+        if (handles & np.uint64(1)).any():
+            raise VGFormatError(f"{self.path}: a path visits a node in reverse -- not a graph `vg construct` writes")
+        off = (handles >> np.uint64(1)).astype(np.int64)
+        idx = np.searchsorted(self.rec_off, off)
+        if (idx >= len(self.rec_off)).any() or not np.array_equal(self.rec_off[idx], off):
+            raise VGFormatError("no path here")
+        have = set(zip(self.edge_from.tolist(), self.edge_to.tolist())) if len(idx) < 4096 else None
+        if have is not None:
+            if any((a, b) not in have for a, b in zip(idx[:-1].tolist(), idx[1:].tolist())):
+                raise VGFormatError("no path here")
+        else:
+            key = self.edge_from * len(self.ids) + self.edge_to
+            key.sort()
+            want = idx[:-1] * len(self.ids) + idx[1:]
+            at_ = np.searchsorted(key, want)
+            if (at_ >= len(key)).any() or not np.array_equal(key[np.minimum(at_, len(key) - 1)], want):
+                raise VGFormatError("no path here")
+        r.skip_rrr63()
+        r.u8()                                                    # is_circular
+        return idx, r.o
+
+    def _read_paths(self, p: bytes, lo: int, n_paths: int):
+        pat = struct.pack("<Q", n_paths)
+        at = lo
+        while True:
+            at = p.find(pat, at)
+            if at < 0:
+                raise VGFormatError(f"{self.path}: the path block was not found (the reference path is what region "
+                                    f"coordinates are counted along: nothing can be extracted without it)")
+            try:
+                o = at + 8
+                got = []
+                for _ in range(n_paths):
+                    idx, o = self._path_at(p, o)
+                    got.append(idx)
+                break
+            except (VGFormatError, struct.error, IndexError):
+                at += 1
+        for name, idx in zip(self.path_names, got):
+            self.paths[name] = idx
+
+    def sequence_of(self, node: int) -> bytes:
+        return self.bases[int(self.start[node]):int(self.start[node] + self.length[node])].tobytes()
+
+
+def _bytecode(buf, i: int) -> Tuple[int, int]:
+    v = shift = 0
+    while True:
+        c = buf[i]
+        i += 1
+        v |= (c & 0x7F) << shift
+        shift += 7
+        if not c & 0x80:
+            return v, i
+
+
+class GBWT:
+    """the records of a GBWT (version 4, as `vg index -G` writes it): per oriented node its outgoing edges and, per visit
+    in BWT order, the edge the visiting sequence leaves by"""
+
+    def __init__(self, path: str):
+        self.path = path
+        raw = open(path, "rb").read()
+        b = raw if raw[:4] == struct.pack("<I", GBWT_TAG) else tagged_payload(raw, b"GBWT", path)
+        if len(b) < 56:
+            raise VGFormatError(f"{path}: too short for a GBWT")
+        tag, self.version = struct.unpack_from("<II", b, 0)
+        if tag != GBWT_TAG:
+            raise VGFormatError(f"{path}: GBWT header tag {tag:#x}")
+        if self.version not in GBWT_VERSIONS:
+            raise VGFormatError(f"{path}: GBWT version {self.version}; this reader decodes version(s) "
+                                f"{', '.join(map(str, GBWT_VERSIONS))} (build the index from FASTA + VCF instead: "
+                                f"GraphIndex.from_fasta_vcf)")
+        self.sequences, self.size, self.offset, self.alphabet_size, flags = struct.unpack_from("<5Q", b, 8)
+        self.bidirectional = bool(flags & 1)
+        r = _Reader(b, path, 48)
+        self.records = r.u64()
+        data_len, wl = r.u64(), r.u8()
+        low = r.values0().astype(np.int64)
+        hw, hbits = r.bit_vector()
+        r.skip_select_mcl()
+        r.skip_select_mcl()
+        ones = _ones(hw, hbits)
+        if len(ones) != self.records or len(low) != self.records:
+            raise VGFormatError(f"{path}: the record index holds {len(ones)} starts for {self.records} records")
+        self.starts = ((ones - np.arange(len(ones), dtype=np.int64)) << wl) | low
+        r._need(data_len)
+        self.data = memoryview(b)[r.o:r.o + data_len]
+        self.data_len = data_len
+        if len(self.starts) and (np.diff(self.starts) < 0).any() or (len(self.starts) and self.starts[-1] > data_len):
+            raise VGFormatError(f"{path}: the record index does not add up")
+
+    def record(self, node: int) -> Tuple[List[Tuple[int, int]], np.ndarray, np.ndarray]:
+        """GBWT node (0 = endmarker) -> ([(successor node, offset in its record)], edge rank per run, run lengths)"""
+        rix = 0 if node == 0 else node - self.offset
+        if not 0 <= rix < self.records:
+            return [], np.zeros(0, np.int64), np.zeros(0, np.int64)
+        lo = int(self.starts[rix])
+        hi = int(self.starts[rix + 1]) if rix + 1 < self.records else self.data_len
+        buf = self.data[lo:hi]
+        n = len(buf)
+        sigma, i = _bytecode(buf, 0) if n else (0, 0)
+        edges, to = [], 0
+        for _ in range(sigma):
+            d, i = _bytecode(buf, i)
+            o, i = _bytecode(buf, i)
+            to += d
+            edges.append((to, o))
+        ranks, runs = [], []
+        if sigma >= 255:
+            while i < n:
+                rk, i = _bytecode(buf, i)
+                ex, i = _bytecode(buf, i)
+                ranks.append(rk)
+                runs.append(ex + 1)
+        elif sigma:
+            per_byte = 256 // sigma                                # run lengths one byte can hold
+            while i < n:
+                c = buf[i]
+                i += 1
+                rk, run = c % sigma, c // sigma + 1
+                if run >= per_byte:                                # the longest: more follows
+                    ex, i = _bytecode(buf, i)
+                    run += ex
+                ranks.append(rk)
+                runs.append(run)
+        return edges, np.asarray(ranks, dtype=np.int64), np.asarray(runs, dtype=np.int64)
+
+    def haplotype_sets(self, nodes: Sequence[int], edges: Sequence[Tuple[int, int]]):
+        """-> ({node id: sequence ids that visit it forward}, {(from id, to id): sequence ids that take that edge}) for the
+        node ids / edges asked for, by one pass over the forward nodes in id order (see the module's head)."""
+        want_n = set(int(x) for x in nodes)
+        want_e: Dict[int, set] = {}
+        for u, w in edges:
+            want_e.setdefault(int(u), set()).add(int(w))
+        got_n: Dict[int, np.ndarray] = {}
+        got_e: Dict[Tuple[int, int], np.ndarray] = {}
+        ids: Dict[int, np.ndarray] = {}              # GBWT node -> sequence ids of its visits (filled by its predecessors)
+        recs: Dict[int, tuple] = {}
+
+        def rec_of(v):
+            if v not in recs:
+                recs[v] = self.record(v)
+            return recs[v]
+
+        def hand_on(v, mine):
+            e, ranks, runs = rec_of(v)
+            recs.pop(v, None)
+            if not e:
+                return
+            body = np.repeat(ranks, runs)
+            if len(body) != len(mine):
+                raise VGFormatError(f"{self.path}: node {v >> 1}: {len(body)} visits in its record, {len(mine)} arrive")
+            for k, (w, off) in enumerate(e):
+                part = mine[body == k]
+                if v and (v >> 1) in want_e and (w >> 1) in want_e[v >> 1] and not (w & 1) and not (v & 1):
+                    got_e[(v >> 1, w >> 1)] = part
+                if w == 0 or (w & 1):                            # the sequence ends / a reverse node: not followed
+                    continue
+                if v and w <= v:
+                    raise VGFormatError(f"{self.path}: an edge from node {v >> 1} back to node {w >> 1}: not a graph "
+                                        f"whose ids go up along every walk (`vg construct` numbers them so)")
+                if w not in ids:
+                    _, rk, rn = rec_of(w)
+                    ids[w] = np.full(int(rn.sum()), -1, dtype=np.int64)
+                if off + len(part) > len(ids[w]):
+                    raise VGFormatError(f"{self.path}: edge {v >> 1} -> {w >> 1} overruns the record of node {w >> 1}")
+                ids[w][off:off + len(part)] = part
+
+        hand_on(0, np.arange(self.sequences, dtype=np.int64))
+        while ids:
+            v = min(ids)                                         # (few nodes are open at a time: a bubble's)
+            mine = ids.pop(v)
+            if (mine < 0).any():
+                raise VGFormatError(f"{self.path}: node {v >> 1} has visits no predecessor accounts for")
+            if (v >> 1) in want_n:
+                got_n[v >> 1] = mine
+            hand_on(v, mine)
+        return got_n, got_e
+
+
+MAX_ALTS = 3
+
+
+def graph_to_index(chrom: str, node_ids: np.ndarray, node_seqs: Sequence[bytes], edge_from: np.ndarray, edge_to: np.ndarray,
+                   ref_steps: np.ndarray, carriers, n_hap: int, where: str = "graph"):
+    """Nodes (ids, sequences), edges (indices into the node arrays) and the reference path (node indices) of a graph as
+    `vg construct` makes it of a reference and a VCF -> GraphIndex.  `carriers(alt_node_ids, gap_edges)` -> ({node id:
+    haplotypes that visit it}, {(from id, to id): haplotypes that take the edge}) (None: no haplotypes).
+
+    The path's nodes spell the reference.  Every other node -- or chain of nodes: a long allele chopped up -- is an alternate
+    allele that replaces the reference bases between the reference positions it hangs on: a substitution where it replaces
+    as many bases as it has (one site per mismatching position), an insertion where it replaces none, otherwise the
+    substitutions of the common length and an insertion / deletion of the rest behind them; an edge that skips reference
+    bases is a deletion (also one that leaves or enters an alternate allele: its carriers have both).  Sites are put
+    together by the rules of the VCF reader (csrc/vcf_ingest.cpp: one substitution site per position with up to three
+    alternates, insertions and deletions sites of their own behind their anchor, order substitution < insertion <
+    deletion; equal alleles merge their carriers), so that both routes give the same index for the same data."""
+    from .extract_regions import GraphIndex
+    n = len(node_ids)
+    ref_steps = np.asarray(ref_steps, dtype=np.int64)
+    step_of = np.full(n, -1, dtype=np.int64)
+    step_of[ref_steps] = np.arange(len(ref_steps))
+    if (step_of[ref_steps] != np.arange(len(ref_steps))).any():
+        raise VGFormatError(f"{where}: path {chrom} visits a node twice")
+    length = np.array([len(s) for s in node_seqs], dtype=np.int64)
+    lens = length[ref_steps]
+    r_start = np.zeros(n, dtype=np.int64)
+    r_start[ref_steps] = np.cumsum(lens) - lens
+    ref = np.frombuffer(b"".join(node_seqs[s] for s in ref_steps.tolist()), dtype=np.uint8)
+    ref_len = len(ref)
+    on_ref = step_of >= 0
+    order = np.argsort(edge_from, kind="stable")
+    et = edge_to[order]
+    succ_at = np.searchsorted(edge_from[order], np.arange(n + 1))
+    order_p = np.argsort(edge_to, kind="stable")
+    pf = edge_from[order_p]
+    pred_at = np.searchsorted(edge_to[order_p], np.arange(n + 1))
+    succs = lambda v: et[succ_at[v]:succ_at[v + 1]]                # noqa: E731
+    preds = lambda v: pf[pred_at[v]:pred_at[v + 1]]                # noqa: E731
+    # ---- coordinates: start[v] = the reference offset a walk stands at when it enters v, end[v] = when it leaves v
+    start = np.where(on_ref, r_start, -1)
+    end = np.where(on_ref, r_start + length, -1)
+    alt_nodes = np.flatnonzero(~on_ref).tolist()
+    chain_head = np.arange(n, dtype=np.int64)                     # an allele longer than a node: its nodes in a row
+    for v in alt_nodes:                                           # (ids go up along every walk: a head comes before its tail)
+        p = preds(v)
+        if len(p) == 1 and not on_ref[p[0]] and len(succs(int(p[0]))) == 1:
+            chain_head[v] = chain_head[int(p[0])]
+    members: Dict[int, List[int]] = {}
+    for v in alt_nodes:
+        members.setdefault(int(chain_head[v]), []).append(v)
+    a_start: Dict[int, int] = {}
+    a_end: Dict[int, int] = {}
+    for h, mem in members.items():
+        # a deletion that ends where this allele starts adds the node in front of it to the predecessors (and likewise
+        # behind): the allele starts behind the LAST reference predecessor and ends at the FIRST reference successor
+        p = preds(h)
+        rp = p[on_ref[p]]
+        if len(rp):
+            a_start[h] = int(end[rp].max())
+        elif len(p) == 0:
+            a_start[h] = 0
+        s = succs(mem[-1])
+        rs = s[on_ref[s]]
+        if len(rs):
+            a_end[h] = int(start[rs].min())
+        elif len(s) == 0:
+            a_end[h] = ref_len
+    for _ in range(8):          # an allele that hangs on alternate alleles only takes its ends from them
+        missing = [h for h in members if h not in a_start or h not in a_end]
+        if not missing:
+            break
+        for h in missing:
+            if h not in a_start:
+                known = [a_end[int(chain_head[q])] for q in preds(h).tolist() if int(chain_head[q]) in a_end and not on_ref[q]]
+                if known:
+                    a_start[h] = max(known)
+            if h not in a_end:
+                known = [a_start[int(chain_head[q])] for q in succs(members[h][-1]).tolist()
+                         if int(chain_head[q]) in a_start and not on_ref[q]]
+                if known:
+                    a_end[h] = min(known)
+    for h, mem in members.items():
+        if h not in a_start or h not in a_end or a_end[h] < a_start[h]:
+            raise VGFormatError(f"{where}: node {int(node_ids[h])} is no allele between two reference positions -- not a "
+                                f"graph `vg construct` writes")
+        for v in mem:                       # entered at the allele's start, left at its end; an edge inside the chain skips nothing
+            start[v] = a_start[h] if v == h else a_end[h]
+            end[v] = a_end[h]
+    ef_l, et_l = edge_from.tolist(), edge_to.tolist()
+    gap = []
+    for u, w in zip(ef_l, et_l):
+        if not on_ref[u] and not on_ref[w] and chain_head[u] == chain_head[w]:
+            continue
+        if end[u] > start[w]:
+            raise VGFormatError(f"{where}: the edge {int(node_ids[u])} -> {int(node_ids[w])} goes backwards along the reference")
+        if end[u] < start[w]:
+            gap.append((u, w))
+    # ---- carriers
+    hw = (n_hap + 63) // 64
+    node_sets, edge_sets = ({}, {})
+    if carriers is not None and n_hap:
+        node_sets, edge_sets = carriers([int(node_ids[h]) for h in members],
+                                        [(int(node_ids[u]), int(node_ids[w])) for u, w in gap])
+
+    def bits_of(haps) -> np.ndarray:
+        b = np.zeros(hw, dtype=np.uint64)
+        if haps is not None and len(haps) and hw:
+            h = np.unique(np.asarray(haps, dtype=np.int64))
+            np.bitwise_or.at(b, h >> 6, np.uint64(1) << (h & 63).astype(np.uint64))
+        return b
+
+    # ---- atoms: (position, kind 0 substitution / 1 insertion / 2 deletion, payload, carriers, node id: file order in a tie)
+    atoms = []
+    skipped = 0
+    for h, mem in members.items():
+        s, e = a_start[h], a_end[h]
+        seq = b"".join(node_seqs[v] for v in mem)
+        who = bits_of(node_sets.get(int(node_ids[h])))
+        lr, la = e - s, len(seq)
+        m = min(lr, la)
+        key = int(node_ids[h])
+        if any(c not in b"ACGT" for c in seq) or (la > m and s + m - 1 < 0) or (lr > m and s + m - 1 < 0):
+            skipped += 1            # not a base string / an insertion or deletion in front of the first base: no anchor
+            continue
+        for j in range(m):
+            if seq[j] != ref[s + j]:
+                atoms.append((s + j, 0, seq[j], who, key))
+        if la > m:
+            atoms.append((s + m - 1, 1, seq[m:], who, key))
+        elif lr > m:
+            atoms.append((s + m - 1, 2, lr - m, who, key))
+    for (u, w) in gap:
+        s, e = int(end[u]), int(start[w])
+        if s - 1 < 0:
+            skipped += 1
+            continue
+        atoms.append((s - 1, 2, e - s, bits_of(edge_sets.get((int(node_ids[u]), int(node_ids[w])))), int(node_ids[w])))
+    atoms.sort(key=lambda a: (a[0], a[1], a[4]))
+    pos, dl, il, io, na, ab, bits, ins = [], [], [], [], [], [], [], bytearray()
+
+    def add_site(p, d, i_len, i_off):
+        pos.append(p)
+        dl.append(d)
+        il.append(i_len)
+        io.append(i_off)
+        na.append(1)
+        ab.append([0] * MAX_ALTS)
+        bits.append(np.zeros((MAX_ALTS, hw), dtype=np.uint64))
+
+    def same_anchor(p):                      # the sites already made at this anchor, latest first
+        for x in range(len(pos) - 1, -1, -1):
+            if pos[x] != p:
+                return
+            yield x
+
+    for (p, kind, payload, who, _) in atoms:
+        if kind == 0:
+            if pos and pos[-1] == p and dl[-1] == 0 and il[-1] == 0:
+                slot = next((x for x in range(na[-1]) if ab[-1][x] == payload), -1)
+                if slot < 0:
+                    if na[-1] >= MAX_ALTS:
+                        skipped += 1
+                        continue
+                    slot = na[-1]
+                    na[-1] += 1
+                    ab[-1][slot] = payload
+                bits[-1][slot] |= who
+            else:
+                add_site(p, 0, 0, 0)
+                ab[-1][0] = payload
+                bits[-1][0] |= who
+        elif kind == 1:
+            dup = next((x for x in same_anchor(p) if il[x] == len(payload) and bytes(ins[io[x]:io[x] + il[x]]) == payload), -1)
+            if dup < 0:
+                add_site(p, 0, len(payload), len(ins))
+                ins.extend(payload)
+                dup = len(pos) - 1
+            bits[dup][0] |= who
+        else:
+            dup = next((x for x in same_anchor(p) if dl[x] == payload), -1)
+            if dup < 0:
+                add_site(p, payload, 0, 0)
+                dup = len(pos) - 1
+            bits[dup][0] |= who
+    V = len(pos)
+    alt_bits = np.stack(bits).reshape(V, MAX_ALTS, hw) if (V and hw) else None
+    return GraphIndex(chrom, ref, np.asarray(pos, np.int32), np.asarray(na, np.uint8),
+                      np.asarray(ab, np.uint8).reshape(V, MAX_ALTS), alt_bits, n_hap, skipped,
+                      del_len=np.asarray(dl, np.int32), ins_len=np.asarray(il, np.int32), ins_off=np.asarray(io, np.int32),
+                      ins_bases=np.frombuffer(bytes(ins), dtype=np.uint8))
+
+
+def index_from_vg(xg_path: str, gbwt_path: Optional[str] = None, chrom: Optional[str] = None, path_name: Optional[str] = None):
+    """XG (+ the GBWT beside it) -> GraphIndex of the embedded path `path_name` (default: the path named `chrom`, or the
+    only path there is).  Without a GBWT the index carries no haplotypes.  Raises VGFormatError for what is not decoded."""
+    xg = XG(xg_path)
+    if not xg.paths:
+        raise VGFormatError(f"{xg_path}: no embedded path: region coordinates have nothing to refer to")
+    name = path_name if path_name is not None else chrom
+    if name is None or name not in xg.paths:
+        if len(xg.paths) == 1 and path_name is None:
+            name = next(iter(xg.paths))     # one chromosome per XG (constructVG.py:296-402): its path, whatever the file is called
+        else:
+            raise VGFormatError(f"{xg_path}: no path named {name!r} (paths: {', '.join(xg.paths)})")
+    n_hap, carriers = 0, None
+    if gbwt_path:
+        gb = GBWT(gbwt_path)
+        shift = 1 if gb.bidirectional else 0
+        n_hap = gb.sequences >> shift
+
+        def carriers(nodes, edges):
+            ns, es = gb.haplotype_sets(nodes, edges)
+            return {k: v >> shift for k, v in ns.items()}, {k: v >> shift for k, v in es.items()}
+
+    seqs = [xg.sequence_of(v) for v in range(len(xg.ids))]
+    return graph_to_index(chrom if chrom is not None else name, xg.ids, seqs, xg.edge_from, xg.edge_to, xg.paths[name],
+                          carriers, n_hap, where=xg_path)
