@@ -426,6 +426,14 @@ class GBWT:
                 runs.append(run)
         return edges, np.asarray(ranks, dtype=np.int64), np.asarray(runs, dtype=np.int64)
 
+    def first_nodes(self) -> np.ndarray:
+        """per sequence the GBWT node it starts with (the endmarker's record: one visit per sequence, in order)"""
+        e, ranks, runs = self.record(0)
+        body = np.repeat(ranks, runs)
+        if len(body) != self.sequences:
+            raise VGFormatError(f"{self.path}: the endmarker holds {len(body)} visits for {self.sequences} sequences")
+        return np.array([w for w, _ in e], dtype=np.int64)[body] if len(e) else np.zeros(0, np.int64)
+
     def haplotype_sets(self, nodes: Sequence[int], edges: Sequence[Tuple[int, int]]):
         """-> ({node id: sequence ids that visit it forward}, {(from id, to id): sequence ids that take that edge}) for the
         node ids / edges asked for, by one pass over the forward nodes in id order (see the module's head)."""
@@ -455,6 +463,8 @@ class GBWT:
                 part = mine[body == k]
                 if v and (v >> 1) in want_e and (w >> 1) in want_e[v >> 1] and not (w & 1) and not (v & 1):
                     got_e[(v >> 1, w >> 1)] = part
+                if w == 0 and v and not (v & 1) and len(part):
+                    self.last_nodes.add(v >> 1)                  # (forward sequences end here)
                 if w == 0 or (w & 1):                            # the sequence ends / a reverse node: not followed
                     continue
                 if v and w <= v:
@@ -467,6 +477,7 @@ class GBWT:
                     raise VGFormatError(f"{self.path}: edge {v >> 1} -> {w >> 1} overruns the record of node {w >> 1}")
                 ids[w][off:off + len(part)] = part
 
+        self.last_nodes = set()
         hand_on(0, np.arange(self.sequences, dtype=np.int64))
         while ids:
             v = min(ids)                                         # (few nodes are open at a time: a bubble's)
@@ -684,16 +695,54 @@ def index_from_vg(xg_path: str, gbwt_path: Optional[str] = None, chrom: Optional
             name = next(iter(xg.paths))     # one chromosome per XG (constructVG.py:296-402): its path, whatever the file is called
         else:
             raise VGFormatError(f"{xg_path}: no path named {name!r} (paths: {', '.join(xg.paths)})")
+    ids, ef, et, steps = xg.ids, xg.edge_from, xg.edge_to, xg.paths[name]
+    keep = np.arange(len(ids))
+    if len(xg.paths) > 1:
+        # a whole-genome XG: the chromosome is the connected component its path lies in
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import connected_components
+        n = len(ids)
+        _, label = connected_components(coo_matrix((np.ones(len(ef), np.int8), (ef, et)), shape=(n, n)), directed=False)
+        keep = np.flatnonzero(label == label[steps[0]])
+        new_at = np.full(n, -1, dtype=np.int64)
+        new_at[keep] = np.arange(len(keep))
+        if (new_at[steps] < 0).any():
+            raise VGFormatError(f"{xg_path}: path {name} is not connected")
+        sel = new_at[ef] >= 0
+        ids, ef, et, steps = ids[keep], new_at[ef[sel]], new_at[et[sel]], new_at[steps]
     n_hap, carriers = 0, None
     if gbwt_path:
+        # The haplotypes of this chromosome: the forward sequences that start in its component (a whole-genome GBWT holds
+        # one sequence per haplotype and chromosome), numbered in their order.  `vg find -H` counts the sequences a k-mer
+        # lies on, and so do the kernels -- with "carries no alternate allele of the site" standing for the reference
+        # allele, which is only right for sequences that run through the WHOLE chromosome: one that starts or ends inside
+        # it (a haplotype broken at a phase break) is refused rather than counted where it does not go.
         gb = GBWT(gbwt_path)
-        shift = 1 if gb.bidirectional else 0
-        n_hap = gb.sequences >> shift
+        firsts = gb.first_nodes()
+        fwd = np.flatnonzero((firsts & 1) == 0)
+        fwd = fwd[np.isin(firsts[fwd] >> 1, ids)]
+        n_hap = len(fwd)
+        sources = set(ids[np.setdiff1d(np.arange(len(ids)), et)].tolist())
+        sinks = set(ids[np.setdiff1d(np.arange(len(ids)), ef)].tolist())
+        inside = sorted(set((firsts[fwd] >> 1).tolist()) - sources)
+        if inside:
+            raise VGFormatError(f"{gbwt_path}: a haplotype starts at node {inside[0]}, inside the chromosome: haplotypes in "
+                                f"pieces (phase breaks) are not modelled")
 
         def carriers(nodes, edges):
             ns, es = gb.haplotype_sets(nodes, edges)
-            return {k: v >> shift for k, v in ns.items()}, {k: v >> shift for k, v in es.items()}
+            inside = sorted(gb.last_nodes & set(ids.tolist()) - sinks)
+            if inside:
+                raise VGFormatError(f"{gbwt_path}: a haplotype ends at node {inside[0]}, inside the chromosome: haplotypes "
+                                    f"in pieces (phase breaks) are not modelled")
 
-    seqs = [xg.sequence_of(v) for v in range(len(xg.ids))]
-    return graph_to_index(chrom if chrom is not None else name, xg.ids, seqs, xg.edge_from, xg.edge_to, xg.paths[name],
-                          carriers, n_hap, where=xg_path)
+            def dense(v):
+                k = np.searchsorted(fwd, v)
+                if len(v) and ((k >= len(fwd)).any() or not np.array_equal(fwd[np.minimum(k, len(fwd) - 1)], v)):
+                    raise VGFormatError(f"{gbwt_path}: a sequence that starts on another chromosome visits this one")
+                return k
+
+            return {k: dense(v) for k, v in ns.items()}, {k: dense(v) for k, v in es.items()}
+
+    seqs = [xg.sequence_of(int(v)) for v in keep.tolist()]
+    return graph_to_index(chrom if chrom is not None else name, ids, seqs, ef, et, steps, carriers, n_hap, where=xg_path)

@@ -280,3 +280,129 @@ def test_scan_graph_reads_vgs_files_and_saves_the_index(tmp_path, monkeypatch, c
     os.remove(gdir / "y.gfmidx.npz")
     with pytest.raises(Exception, match="Unable to locate .*y.gbwt"):
         xr.scan_graph({19}, Findmotif(graph_genome_dir=str(gdir), bedfile=os.path.join(REF_DATA, "regions.bed"), chroms=["y"]), True)
+
+
+# ---- the byte-level readers on streams written here (tests/vg_encode.py: what this can and cannot show is said there)
+def _write_pair(tmp_path, name, idx, **xg_kw):
+    import vg_encode
+    ids, seqs, ef, et, steps, walks = graph_of_index(idx)
+    nodes = {int(i): s for i, s in zip(ids.tolist(), seqs)}
+    edges = [(int(ids[a]), int(ids[b])) for a, b in zip(ef.tolist(), et.tolist())]
+    (tmp_path / f"{name}.xg").write_bytes(vg_encode.xg_bytes(nodes, edges, {name: ids[steps].tolist()}, **xg_kw))
+    (tmp_path / f"{name}.gbwt").write_bytes(vg_encode.gbwt_bytes(walks))
+    return str(tmp_path / f"{name}.xg"), str(tmp_path / f"{name}.gbwt")
+
+
+def test_writers_reproduce_what_the_readers_take_from_vgs_own_files(tmp_path):
+    """the tutorial graph written by tests/vg_encode.py reads back as the tutorial graph read from vg's file -- and the
+    structures both hold (the node records, the bases, the path's coded handles, the GBWT's records) are the SAME BYTES
+    in vg's file and in the written one"""
+    import vg_encode
+    from grafimo_amd import vg_files
+    xg = vg_files.XG(os.path.join(MYGENOME, "x.xg"))
+    nodes = {int(i): xg.sequence_of(k) for k, i in enumerate(xg.ids.tolist())}
+    edges = [(int(xg.ids[a]), int(xg.ids[b])) for a, b in zip(xg.edge_from.tolist(), xg.edge_to.tolist())]
+    path = xg.ids[xg.paths["x"]].tolist()
+    mine = vg_encode.xg_bytes(nodes, edges, {"x": path})
+    theirs = open(os.path.join(MYGENOME, "x.xg"), "rb").read()
+    (tmp_path / "w.xg").write_bytes(mine)
+    back = vg_files.XG(str(tmp_path / "w.xg"))
+    assert np.array_equal(back.ids, xg.ids) and np.array_equal(back.bases, xg.bases) and back.path_names == ["x"]
+    assert sorted(zip(back.edge_from.tolist(), back.edge_to.tolist())) == sorted(zip(xg.edge_from.tolist(), xg.edge_to.tolist()))
+    assert np.array_equal(back.paths["x"], xg.paths["x"])
+    ids_iv = vg_encode.int_vector0(sorted(nodes))
+    assert ids_iv in theirs and ids_iv in mine                         # r_iv
+    handles = [int(xg.rec_off[k]) << 1 for k in xg.paths["x"].tolist()]
+    coded = vg_encode.enc_vector(handles)
+    assert coded in theirs and coded in mine                           # the path: vg's Elias-delta bytes, bit for bit
+    s_iv = vg_encode.int_vector0([vg_encode.XG_CODE[c] for c in b"".join(nodes[i] for i in sorted(nodes))], 2)
+    assert s_iv in theirs and s_iv in mine                             # the bases
+    # (the graph vector: vg lists a node's edges in its own order -- same entries, compared as sets by the reader test above)
+    with open(os.path.join(GOLDEN, "vg_graphs.json")) as fh:
+        walks = json.load(fh)["tutorial_x_xg"]["haplotype_paths"]
+    gmine = vg_encode.gbwt_bytes(walks)
+    gtheirs = open(os.path.join(MYGENOME, "x.gbwt"), "rb").read()
+    (tmp_path / "w.gbwt").write_bytes(gmine)
+    a, b = vg_files.GBWT(os.path.join(MYGENOME, "x.gbwt")), vg_files.GBWT(str(tmp_path / "w.gbwt"))
+    assert (a.sequences, a.offset, a.alphabet_size, a.records, a.bidirectional) == \
+        (b.sequences, b.offset, b.alphabet_size, b.records, b.bidirectional)
+    assert bytes(a.data) == bytes(b.data) and bytes(a.data) in gtheirs     # every record, byte for byte
+    assert np.array_equal(a.starts, b.starts)
+
+
+@pytest.mark.parametrize("seed,kinds,samples", [(11, "sidmDOc", 12), (12, "sid", 150), (13, "sidm", 40)])
+def test_readers_on_written_streams(tmp_path, seed, kinds, samples):
+    """a rich graph with up to 300 haplotypes -> XG + GBWT bytes -> index_from_vg -> the index it was written from.
+    300 haplotypes: runs longer than a byte holds (128 at two outgoing edges), records of several hundred bytes."""
+    from grafimo_amd import vg_files
+    from grafimo_amd.extract_regions import GraphIndex
+    fasta, vcf = make_consistent_graph_files(str(tmp_path), chrom="c", length=500, n_samples=samples, seed=seed, kinds=kinds)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "c")
+    rng = np.random.default_rng(seed)
+    xg, gbwt = _write_pair(tmp_path, "c", idx, junk=rng.integers(0, 256, size=3000, dtype=np.uint8).tobytes(),
+                           msg_size=1500, msgs_per_group=3)
+    got = vg_files.index_from_vg(xg, gbwt, "c")
+    assert np.array_equal(got.ref, idx.ref) and got.n_haplotypes == idx.n_haplotypes == 2 * samples
+    assert _sites(got) == _sites(idx)
+    if samples >= 150:
+        gb = vg_files.GBWT(gbwt)
+        longest = max(int(gb.record(v)[2].max(initial=0)) for v in range(gb.offset + 1, gb.alphabet_size, 2))
+        assert longest > 128, longest
+
+
+def test_several_paths_and_n_bases_in_one_xg(tmp_path):
+    """a whole-genome XG (`-g`): two chromosomes, node ids of the second behind the first's; an N stretch in one (3-bit bases)"""
+    import vg_encode
+    from grafimo_amd import vg_files
+    from grafimo_amd.extract_regions import GraphIndex
+    parts, nodes, edges, paths, walks_all, shift = {}, {}, [], {}, [], 0
+    for name, seed in (("chrA", 21), ("chrB", 22)):
+        fasta, vcf = make_consistent_graph_files(str(tmp_path), chrom=name, length=400, n_samples=10, seed=seed, kinds="sid")
+        if name == "chrB":                                             # an assembly gap
+            txt = open(fasta).read().split("\n", 1)
+            body = txt[1].replace("\n", "")
+            body = body[:300] + "N" * 40 + body[340:]
+            open(fasta, "w").write(txt[0] + "\n" + body + "\n")
+            lines = [ln for ln in open(vcf) if ln.startswith("#") or not 290 <= int(ln.split("\t")[1]) <= 350]
+            open(vcf, "w").write("".join(lines))
+        idx = GraphIndex.from_fasta_vcf(fasta, vcf, name)
+        parts[name] = idx
+        ids, seqs, ef, et, steps, walks = graph_of_index(idx)
+        nodes.update({int(i) + shift: s for i, s in zip(ids.tolist(), seqs)})
+        edges += [(int(ids[a]) + shift, int(ids[b]) + shift) for a, b in zip(ef.tolist(), et.tolist())]
+        paths[name] = [int(i) + shift for i in ids[steps].tolist()]
+        walks_all.append([[n + shift for n in w] for w in walks])
+        shift += int(ids.max())
+    (tmp_path / "genome.xg").write_bytes(vg_encode.xg_bytes(nodes, edges, paths, junk=b"\x01" + bytes(500)))
+    # one GBWT over both chromosomes: haplotype h of the genome = its walk through chrA, then (another sequence) through chrB
+    (tmp_path / "genome.gbwt").write_bytes(vg_encode.gbwt_bytes(walks_all[0] + walks_all[1]))
+    xg = vg_files.XG(str(tmp_path / "genome.xg"))
+    assert xg.path_names == ["chrA", "chrB"] and b"N" in xg.bases.tobytes()
+    for k, name in enumerate(("chrA", "chrB")):
+        got = vg_files.index_from_vg(str(tmp_path / "genome.xg"), None, chrom=name, path_name=name)
+        assert np.array_equal(got.ref, parts[name].ref) and np.array_equal(got.pos, parts[name].pos), name
+        # with the genome's GBWT: 40 sequences forward, 20 of them on this chromosome -- ITS haplotypes, numbered 0..19
+        got = vg_files.index_from_vg(str(tmp_path / "genome.xg"), str(tmp_path / "genome.gbwt"), chrom=name, path_name=name)
+        assert got.n_haplotypes == parts[name].n_haplotypes == 20 and _sites(got) == _sites(parts[name]), name
+    with pytest.raises(vg_files.VGFormatError, match="no path named"):
+        vg_files.index_from_vg(str(tmp_path / "genome.xg"), None, chrom="chrC")
+
+
+def test_haplotypes_in_pieces_are_refused(tmp_path):
+    """a thread that starts or ends inside the chromosome (vg breaks haplotypes at phase breaks) would be counted as a
+    reference carrier where it does not go: refused by name"""
+    import vg_encode
+    from grafimo_amd import vg_files
+    from grafimo_amd.extract_regions import GraphIndex
+    fasta, vcf = make_consistent_graph_files(str(tmp_path), chrom="c", length=300, n_samples=4, seed=31, kinds="sd")
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "c")
+    ids, seqs, ef, et, steps, walks = graph_of_index(idx)
+    nodes = {int(i): s for i, s in zip(ids.tolist(), seqs)}
+    edges = [(int(ids[a]), int(ids[b])) for a, b in zip(ef.tolist(), et.tolist())]
+    (tmp_path / "c.xg").write_bytes(vg_encode.xg_bytes(nodes, edges, {"c": ids[steps].tolist()}))
+    whole = vg_files.index_from_vg(str(tmp_path / "c.xg"), None, "c")
+    assert len(whole.pos) == len(idx.pos)
+    for what, broken in (("starts", [walks[0][:], walks[1][7:]]), ("ends", [walks[0][:], walks[1][:-5]])):
+        (tmp_path / "c.gbwt").write_bytes(vg_encode.gbwt_bytes(broken + walks[2:]))
+        with pytest.raises(vg_files.VGFormatError, match=f"a haplotype {what} at node .* inside the chromosome"):
+            vg_files.index_from_vg(str(tmp_path / "c.xg"), str(tmp_path / "c.gbwt"), "c")
