@@ -183,35 +183,53 @@ class _Reader:
         self.bit_vector()
 
 
+def _window(w: np.ndarray, pos: np.ndarray) -> np.ndarray:
+    """the 64 bits that start at bit `pos` of the little-endian words w (w padded by one word)"""
+    wi = (pos >> np.uint64(6)).astype(np.int64)
+    sh = pos & np.uint64(63)
+    lo = w[wi] >> sh
+    hi = np.where(sh > 0, w[wi + 1] << ((np.uint64(64) - sh) & np.uint64(63)), np.uint64(0))
+    return lo | hi
+
+
 def _elias_delta_all(zwords: np.ndarray, zbits: int, samples: np.ndarray, size: int) -> np.ndarray:
-    """sdsl::enc_vector<coder::elias_delta, 128>: entry i = sample value of its block + the sum of the deltas since.
-    samples = [value, bit pointer] per block (+ a closing pair).  A delta x >= 1 is written, least significant bit first, as:
-    k zeros and a one (k = bits of (bits of x)) - 1... i.e. unary k; the low k bits of len = bits(x); the low len - 1 bits of x."""
-    z = int.from_bytes(np.ascontiguousarray(zwords).tobytes(), "little")
-    out = np.empty(size, dtype=np.uint64)
-    mask64 = (1 << 64) - 1
-    v = pos = 0
-    for i in range(size):
-        if i % ENC_DENS == 0:
-            v, pos = int(samples[2 * (i // ENC_DENS)]), int(samples[2 * (i // ENC_DENS) + 1])
-        else:
-            k = 0
-            while not (z >> pos) & 1:
-                pos += 1
-                k += 1
-                if pos > zbits:
-                    raise VGFormatError("Elias-delta stream runs out")
-            pos += 1
-            if k == 0:
-                d = 1
-            else:
-                ln = ((z >> pos) & ((1 << k) - 1)) + (1 << k)
-                pos += k
-                d = ((z >> pos) & ((1 << (ln - 1)) - 1)) + ((1 << (ln - 1)) if ln - 1 < 64 else 0)
-                pos += ln - 1
-            v = (v + d) & mask64
-        out[i] = v
-    return out
+    """sdsl::enc_vector<coder::elias_delta, 128>: entry i = the sample value of its block + the sum of the deltas since.
+    samples = [value, bit pointer] per block (+ a closing pair).  A delta x >= 1 is written, least significant bit first, as
+    k zeros and a one (k = bits(bits(x)) - 1), the low k bits of bits(x), the low bits(x) - 1 bits of x (x = 2^64 stands
+    for 0).  All blocks are decoded in step: entry j of every block at once."""
+    n_blocks = (size + ENC_DENS - 1) // ENC_DENS
+    w = np.concatenate([zwords.astype(np.uint64), np.zeros(2, dtype=np.uint64)])
+    val = samples[0:2 * n_blocks:2].astype(np.uint64).copy()
+    pos = samples[1:2 * n_blocks:2].astype(np.uint64).copy()
+    if len(pos) and int(pos.max()) > zbits:
+        raise VGFormatError("Elias-delta stream: a block starts behind its end")
+    out = np.empty((ENC_DENS, n_blocks), dtype=np.uint64)
+    out[0] = val
+    one = np.uint64(1)
+    limit = np.uint64(zbits + 64)
+    for j in range(1, min(ENC_DENS, size)):
+        live = np.arange(n_blocks) * ENC_DENS + j < size
+        pos = np.where(live, pos, np.uint64(0))
+        win = _window(w, pos)
+        low = win & (~win + one)                                  # the lowest set bit: 2^k
+        if ((low == 0) | (low > np.uint64(64)))[live].any():
+            raise VGFormatError("Elias-delta stream: no code here")
+        k = np.zeros(n_blocks, dtype=np.uint64)
+        for b in range(1, 7):
+            k[low == np.uint64(1 << b)] = b
+        pos = pos + k + one
+        ln = (_window(w, pos) & ((one << k) - one)) + (one << k)   # bits(x); k == 0: 1
+        pos = pos + k
+        body = ln - one                                            # 0 .. 64
+        full = body >= np.uint64(64)
+        sh = np.where(full, np.uint64(0), body)
+        d = np.where(full, _window(w, pos), (_window(w, pos) & ((one << sh) - one)) + (one << sh))
+        pos = pos + body
+        if (pos[live] > limit).any():
+            raise VGFormatError("Elias-delta stream runs out")
+        val = val + np.where(live, d, np.uint64(0))               # (wraps: the differences are taken modulo 2^64)
+        out[j] = val
+    return out.T.reshape(-1)[:size].copy()
 
 
 class XG:
@@ -493,7 +511,7 @@ class GBWT:
 MAX_ALTS = 3
 
 
-def graph_to_index(chrom: str, node_ids: np.ndarray, node_seqs: Sequence[bytes], edge_from: np.ndarray, edge_to: np.ndarray,
+def graph_to_index(chrom: str, node_ids: np.ndarray, node_seqs, edge_from: np.ndarray, edge_to: np.ndarray,
                    ref_steps: np.ndarray, carriers, n_hap: int, where: str = "graph"):
     """Nodes (ids, sequences), edges (indices into the node arrays) and the reference path (node indices) of a graph as
     `vg construct` makes it of a reference and a VCF -> GraphIndex.  `carriers(alt_node_ids, gap_edges)` -> ({node id:
@@ -514,12 +532,20 @@ def graph_to_index(chrom: str, node_ids: np.ndarray, node_seqs: Sequence[bytes],
     step_of[ref_steps] = np.arange(len(ref_steps))
     if (step_of[ref_steps] != np.arange(len(ref_steps))).any():
         raise VGFormatError(f"{where}: path {chrom} visits a node twice")
-    length = np.array([len(s) for s in node_seqs], dtype=np.int64)
+    if isinstance(node_seqs, tuple):                              # (bases, start, length): a node's bases = bases[start:start+length]
+        bases, s_at, length = (np.asarray(a) for a in node_seqs)
+        length = length.astype(np.int64)
+    else:
+        length = np.array([len(q) for q in node_seqs], dtype=np.int64)
+        s_at = np.cumsum(length) - length
+        bases = np.frombuffer(b"".join(node_seqs), dtype=np.uint8)
+    seq_of = lambda v: bases[int(s_at[v]):int(s_at[v] + length[v])].tobytes()      # noqa: E731
     lens = length[ref_steps]
     r_start = np.zeros(n, dtype=np.int64)
     r_start[ref_steps] = np.cumsum(lens) - lens
-    ref = np.frombuffer(b"".join(node_seqs[s] for s in ref_steps.tolist()), dtype=np.uint8)
-    ref_len = len(ref)
+    ref_len = int(lens.sum())
+    ref = bases[np.repeat(s_at[ref_steps] - r_start[ref_steps], lens) + np.arange(ref_len)] if ref_len else np.zeros(0, np.uint8)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
     on_ref = step_of >= 0
     order = np.argsort(edge_from, kind="stable")
     et = edge_to[order]
@@ -607,7 +633,7 @@ def graph_to_index(chrom: str, node_ids: np.ndarray, node_seqs: Sequence[bytes],
     skipped = 0
     for h, mem in members.items():
         s, e = a_start[h], a_end[h]
-        seq = b"".join(node_seqs[v] for v in mem)
+        seq = b"".join(seq_of(v) for v in mem)
         who = bits_of(node_sets.get(int(node_ids[h])))
         lr, la = e - s, len(seq)
         m = min(lr, la)
@@ -744,5 +770,5 @@ def index_from_vg(xg_path: str, gbwt_path: Optional[str] = None, chrom: Optional
 
             return {k: dense(v) for k, v in ns.items()}, {k: dense(v) for k, v in es.items()}
 
-    seqs = [xg.sequence_of(int(v)) for v in keep.tolist()]
-    return graph_to_index(chrom if chrom is not None else name, ids, seqs, ef, et, steps, carriers, n_hap, where=xg_path)
+    return graph_to_index(chrom if chrom is not None else name, ids, (xg.bases, xg.start[keep], xg.length[keep]), ef, et, steps,
+                          carriers, n_hap, where=xg_path)
