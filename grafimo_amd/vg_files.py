@@ -408,11 +408,11 @@ class GBWT:
         if len(self.starts) and (np.diff(self.starts) < 0).any() or (len(self.starts) and self.starts[-1] > data_len):
             raise VGFormatError(f"{path}: the record index does not add up")
 
-    def record(self, node: int) -> Tuple[List[Tuple[int, int]], np.ndarray, np.ndarray]:
-        """GBWT node (0 = endmarker) -> ([(successor node, offset in its record)], edge rank per run, run lengths)"""
+    def record(self, node: int) -> Tuple[List[Tuple[int, int]], List[int], List[int], int]:
+        """GBWT node (0 = endmarker) -> ([(successor node, offset in its record)], edge rank per run, run lengths, visits)"""
         rix = 0 if node == 0 else node - self.offset
         if not 0 <= rix < self.records:
-            return [], np.zeros(0, np.int64), np.zeros(0, np.int64)
+            return [], [], [], 0
         lo = int(self.starts[rix])
         hi = int(self.starts[rix + 1]) if rix + 1 < self.records else self.data_len
         buf = self.data[lo:hi]
@@ -424,15 +424,21 @@ class GBWT:
             o, i = _bytecode(buf, i)
             to += d
             edges.append((to, o))
-        ranks, runs = [], []
+        ranks, runs, visits = [], [], 0
         if sigma >= 255:
             while i < n:
                 rk, i = _bytecode(buf, i)
                 ex, i = _bytecode(buf, i)
                 ranks.append(rk)
                 runs.append(ex + 1)
+                visits += ex + 1
         elif sigma:
             per_byte = 256 // sigma                                # run lengths one byte can hold
+            if n - i > 24:                                         # many runs: all of them at once if none is continued
+                c = np.frombuffer(buf, dtype=np.uint8, offset=i).astype(np.int64)
+                rn = c // sigma + 1
+                if int(rn.max()) < per_byte:
+                    return edges, (c % sigma).tolist(), rn.tolist(), int(rn.sum())
             while i < n:
                 c = buf[i]
                 i += 1
@@ -442,12 +448,13 @@ class GBWT:
                     run += ex
                 ranks.append(rk)
                 runs.append(run)
-        return edges, np.asarray(ranks, dtype=np.int64), np.asarray(runs, dtype=np.int64)
+                visits += run
+        return edges, ranks, runs, visits
 
     def first_nodes(self) -> np.ndarray:
         """per sequence the GBWT node it starts with (the endmarker's record: one visit per sequence, in order)"""
-        e, ranks, runs = self.record(0)
-        body = np.repeat(ranks, runs)
+        e, ranks, runs, _ = self.record(0)
+        body = np.repeat(np.asarray(ranks, dtype=np.int64), np.asarray(runs, dtype=np.int64))
         if len(body) != self.sequences:
             raise VGFormatError(f"{self.path}: the endmarker holds {len(body)} visits for {self.sequences} sequences")
         return np.array([w for w, _ in e], dtype=np.int64)[body] if len(e) else np.zeros(0, np.int64)
@@ -470,38 +477,47 @@ class GBWT:
             return recs[v]
 
         def hand_on(v, mine):
-            e, ranks, runs = rec_of(v)
+            e, ranks, runs, visits = rec_of(v)
             recs.pop(v, None)
             if not e:
                 return
-            body = np.repeat(ranks, runs)
-            if len(body) != len(mine):
-                raise VGFormatError(f"{self.path}: node {v >> 1}: {len(body)} visits in its record, {len(mine)} arrive")
+            if visits != len(mine):
+                raise VGFormatError(f"{self.path}: node {v >> 1}: {visits} visits in its record, {len(mine)} arrive")
+            body = None if len(e) == 1 else np.repeat(np.asarray(ranks, dtype=np.int64), np.asarray(runs, dtype=np.int64))
+            fwd = v and not (v & 1)
             for k, (w, off) in enumerate(e):
-                part = mine[body == k]
-                if v and (v >> 1) in want_e and (w >> 1) in want_e[v >> 1] and not (w & 1) and not (v & 1):
+                part = mine if body is None else mine[body == k]
+                if fwd and not (w & 1) and (v >> 1) in want_e and (w >> 1) in want_e[v >> 1]:
                     got_e[(v >> 1, w >> 1)] = part
-                if w == 0 and v and not (v & 1) and len(part):
+                if w == 0 and fwd and len(part):
                     self.last_nodes.add(v >> 1)                  # (forward sequences end here)
                 if w == 0 or (w & 1):                            # the sequence ends / a reverse node: not followed
                     continue
                 if v and w <= v:
                     raise VGFormatError(f"{self.path}: an edge from node {v >> 1} back to node {w >> 1}: not a graph "
                                         f"whose ids go up along every walk (`vg construct` numbers them so)")
-                if w not in ids:
-                    _, rk, rn = rec_of(w)
-                    ids[w] = np.full(int(rn.sum()), -1, dtype=np.int64)
-                if off + len(part) > len(ids[w]):
+                have = ids.get(w)
+                if have is None:
+                    total = rec_of(w)[3]
+                    if off == 0 and len(part) == total:          # the only predecessor: its block IS the node's visits
+                        ids[w] = part
+                        continue
+                    have = ids[w] = np.full(total, -1, dtype=np.int64)
+                    patched.add(w)
+                if off + len(part) > len(have) or w not in patched:
                     raise VGFormatError(f"{self.path}: edge {v >> 1} -> {w >> 1} overruns the record of node {w >> 1}")
-                ids[w][off:off + len(part)] = part
+                have[off:off + len(part)] = part
 
+        patched = set()                                          # nodes whose visits are put together from several blocks
         self.last_nodes = set()
         hand_on(0, np.arange(self.sequences, dtype=np.int64))
         while ids:
             v = min(ids)                                         # (few nodes are open at a time: a bubble's)
             mine = ids.pop(v)
-            if (mine < 0).any():
-                raise VGFormatError(f"{self.path}: node {v >> 1} has visits no predecessor accounts for")
+            if v in patched:
+                patched.discard(v)
+                if (mine < 0).any():
+                    raise VGFormatError(f"{self.path}: node {v >> 1} has visits no predecessor accounts for")
             if (v >> 1) in want_n:
                 got_n[v >> 1] = mine
             hand_on(v, mine)
@@ -621,20 +637,13 @@ def graph_to_index(chrom: str, node_ids: np.ndarray, node_seqs, edge_from: np.nd
         node_sets, edge_sets = carriers([int(node_ids[h]) for h in members],
                                         [(int(node_ids[u]), int(node_ids[w])) for u, w in gap])
 
-    def bits_of(haps) -> np.ndarray:
-        b = np.zeros(hw, dtype=np.uint64)
-        if haps is not None and len(haps) and hw:
-            h = np.unique(np.asarray(haps, dtype=np.int64))
-            np.bitwise_or.at(b, h >> 6, np.uint64(1) << (h & 63).astype(np.uint64))
-        return b
-
     # ---- atoms: (position, kind 0 substitution / 1 insertion / 2 deletion, payload, carriers, node id: file order in a tie)
     atoms = []
     skipped = 0
     for h, mem in members.items():
         s, e = a_start[h], a_end[h]
         seq = b"".join(seq_of(v) for v in mem)
-        who = bits_of(node_sets.get(int(node_ids[h])))
+        who = node_sets.get(int(node_ids[h]))
         lr, la = e - s, len(seq)
         m = min(lr, la)
         key = int(node_ids[h])
@@ -653,9 +662,10 @@ def graph_to_index(chrom: str, node_ids: np.ndarray, node_seqs, edge_from: np.nd
         if s - 1 < 0:
             skipped += 1
             continue
-        atoms.append((s - 1, 2, e - s, bits_of(edge_sets.get((int(node_ids[u]), int(node_ids[w])))), int(node_ids[w])))
+        atoms.append((s - 1, 2, e - s, edge_sets.get((int(node_ids[u]), int(node_ids[w]))), int(node_ids[w])))
     atoms.sort(key=lambda a: (a[0], a[1], a[4]))
-    pos, dl, il, io, na, ab, bits, ins = [], [], [], [], [], [], [], bytearray()
+    pos, dl, il, io, na, ab, ins = [], [], [], [], [], [], bytearray()
+    placed = []                              # (site, slot, carriers): ORed into ONE bit array once the sites are counted
 
     def add_site(p, d, i_len, i_off):
         pos.append(p)
@@ -664,7 +674,6 @@ def graph_to_index(chrom: str, node_ids: np.ndarray, node_seqs, edge_from: np.nd
         io.append(i_off)
         na.append(1)
         ab.append([0] * MAX_ALTS)
-        bits.append(np.zeros((MAX_ALTS, hw), dtype=np.uint64))
 
     def same_anchor(p):                      # the sites already made at this anchor, latest first
         for x in range(len(pos) - 1, -1, -1):
@@ -683,26 +692,32 @@ def graph_to_index(chrom: str, node_ids: np.ndarray, node_seqs, edge_from: np.nd
                     slot = na[-1]
                     na[-1] += 1
                     ab[-1][slot] = payload
-                bits[-1][slot] |= who
+                placed.append((len(pos) - 1, slot, who))
             else:
                 add_site(p, 0, 0, 0)
                 ab[-1][0] = payload
-                bits[-1][0] |= who
+                placed.append((len(pos) - 1, 0, who))
         elif kind == 1:
             dup = next((x for x in same_anchor(p) if il[x] == len(payload) and bytes(ins[io[x]:io[x] + il[x]]) == payload), -1)
             if dup < 0:
                 add_site(p, 0, len(payload), len(ins))
                 ins.extend(payload)
                 dup = len(pos) - 1
-            bits[dup][0] |= who
+            placed.append((dup, 0, who))
         else:
             dup = next((x for x in same_anchor(p) if dl[x] == payload), -1)
             if dup < 0:
                 add_site(p, payload, 0, 0)
                 dup = len(pos) - 1
-            bits[dup][0] |= who
+            placed.append((dup, 0, who))
     V = len(pos)
-    alt_bits = np.stack(bits).reshape(V, MAX_ALTS, hw) if (V and hw) else None
+    alt_bits = None
+    if V and hw:
+        alt_bits = np.zeros((V, MAX_ALTS, hw), dtype=np.uint64)
+        for site, slot, who in placed:
+            if who is not None and len(who):
+                h = np.unique(np.asarray(who, dtype=np.int64))
+                np.bitwise_or.at(alt_bits[site, slot], h >> 6, np.uint64(1) << (h & 63).astype(np.uint64))
     return GraphIndex(chrom, ref, np.asarray(pos, np.int32), np.asarray(na, np.uint8),
                       np.asarray(ab, np.uint8).reshape(V, MAX_ALTS), alt_bits, n_hap, skipped,
                       del_len=np.asarray(dl, np.int32), ins_len=np.asarray(il, np.int32), ins_off=np.asarray(io, np.int32),

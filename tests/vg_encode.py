@@ -24,27 +24,33 @@ def varint(v: int) -> bytes:
             return out
 
 
-def _pack_bits(big: int, bits: int) -> bytes:
-    return big.to_bytes(((bits + 63) // 64) * 8, "little")
+def pack_fields(values, widths) -> bytes:
+    """fields of widths[i] <= 64 bits, one behind the other, least significant bit first -> whole 64-bit words"""
+    values = np.asarray(values, dtype=np.uint64)
+    widths = np.asarray(widths, dtype=np.uint64)
+    total = int(widths.sum())
+    words = np.zeros((total + 63) // 64 + 1, dtype=np.uint64)
+    if len(values):
+        pos = np.cumsum(widths) - widths
+        wi = (pos >> np.uint64(6)).astype(np.int64)
+        sh = pos & np.uint64(63)
+        np.bitwise_or.at(words, wi, values << sh)
+        spill = sh + widths > np.uint64(64)
+        np.bitwise_or.at(words, wi[spill] + 1, values[spill] >> (np.uint64(64) - sh[spill]))
+    return words[:(total + 63) // 64].tobytes()
 
 
 def int_vector0(values: Sequence[int], width: int = 0) -> bytes:
-    values = [int(v) for v in values]
-    width = width or max(1, max(values, default=0).bit_length())
-    big = 0
-    for i, v in enumerate(values):
-        assert 0 <= v < (1 << width)
-        big |= v << (i * width)
-    bits = len(values) * width
-    return u64(bits) + bytes([width]) + _pack_bits(big, bits)
+    values = np.asarray([int(v) for v in values] if not isinstance(values, np.ndarray) else values, dtype=np.uint64)
+    width = width or max(1, int(values.max(initial=0)).bit_length())
+    assert width == 64 or not len(values) or int(values.max()) < (1 << width)
+    return u64(len(values) * width) + bytes([width]) + pack_fields(values, np.full(len(values), width))
 
 
 def bit_vector(bits: Sequence[int]) -> bytes:
-    big = 0
-    for i, b in enumerate(bits):
-        if b:
-            big |= 1 << i
-    return u64(len(bits)) + _pack_bits(big, len(bits))
+    b = np.asarray(bits, dtype=bool).astype(np.uint8)
+    packed = np.packbits(b, bitorder="little")
+    return u64(len(b)) + packed.tobytes() + bytes((-len(packed)) % 8)
 
 
 def rank_v(n_bits: int) -> bytes:
@@ -62,29 +68,26 @@ def select_mcl(n_ones: int) -> bytes:
     return out
 
 
-def _delta(big: int, pos: int, d: int) -> Tuple[int, int]:
-    """append the Elias-delta code of d >= 1 at bit `pos` (least significant bit first)"""
-    len_1 = d.bit_length() - 1
-    k = (len_1 + 1).bit_length() - 1
-    big |= 1 << (pos + k)
-    pos += k + 1
-    if k:
-        big |= ((len_1 + 1) & ((1 << k) - 1)) << pos
-        pos += k
-        big |= (d & ((1 << len_1) - 1)) << pos
-        pos += len_1
-    return big, pos
-
-
 def enc_vector(values: Sequence[int], dens: int = 128) -> bytes:
-    big, pos, samples = 0, 0, []
+    """sdsl::enc_vector<coder::elias_delta, dens>: per entry that is no sample the Elias-delta code of its difference to the
+    entry before (modulo 2^64; 2^64 for 0): k zeros and a one (k = bits(bits(d)) - 1), the low k bits of bits(d), the low
+    bits(d) - 1 bits of d -- least significant bit first"""
+    fields_v, fields_w, samples, pos = [], [], [], 0
     for i, v in enumerate(values):
         if i % dens == 0:
             samples += [v, pos]
-        else:
-            big, pos = _delta(big, pos, (v - values[i - 1]) & ((1 << 64) - 1) or (1 << 64))
+            continue
+        d = (v - values[i - 1]) & ((1 << 64) - 1) or (1 << 64)
+        len_1 = d.bit_length() - 1
+        k = (len_1 + 1).bit_length() - 1
+        fields_v.append(1 << k)
+        fields_w.append(k + 1)
+        if k:
+            fields_v += [(len_1 + 1) & ((1 << k) - 1), d & ((1 << len_1) - 1)]
+            fields_w += [k, len_1]
+        pos += 2 * k + 1 + (len_1 if k else 0)
     samples += [0, pos + 1]
-    return u64(len(values)) + u64(pos) + bytes([1]) + _pack_bits(big, pos) + int_vector0(samples)
+    return u64(len(values)) + u64(pos) + bytes([1]) + pack_fields(fields_v, fields_w) + int_vector0(samples)
 
 
 def rrr63(n_bits: int) -> bytes:
