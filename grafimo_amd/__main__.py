@@ -105,7 +105,61 @@ def get_parser():
     return p
 
 
+def buildvg(argv):
+    """`grafimo buildvg -l FASTA -v VCF [--chroms-build 1 X] [--chroms-prefix-build P | --chroms-namemap-build FILE] [-o DIR]`
+    (__main__.py:200-260, constructVG.py:137-300): one graph per chromosome, named as the reference names its chrN.xg --
+    here the .gfmidx.npz scan_graph takes in the XG's place (GraphIndex.from_fasta_vcf: the library's VCF reader, host only)."""
+    import os
+    from .extract_regions import GraphIndex, INDEX_SUFFIX
+    p = argparse.ArgumentParser(prog="python -m grafimo_amd buildvg", description=buildvg.__doc__)
+    p.add_argument("-l", "--linear-genome", dest="linear_genome", required=True, metavar="FASTA")
+    p.add_argument("-v", "--vcf", required=True, metavar="VCF")
+    p.add_argument("--chroms-build", dest="chroms_build", nargs="*", default=[], metavar="CHR")
+    p.add_argument("--chroms-prefix-build", dest="chroms_prefix_build", nargs="?", default="", metavar="PREFIX")
+    p.add_argument("--chroms-namemap-build", dest="chroms_namemap_build", nargs="?", default=NOMAP, metavar="NAME-MAP-FILE")
+    p.add_argument("--strict-variants", action="store_true", dest="strict_variants")
+    p.add_argument("-j", "--cores", type=int, default=0)
+    p.add_argument("-o", "--out", default="")
+    p.add_argument("--verbose", action="store_true")
+    p.add_argument("--debug", action="store_true")
+    a = p.parse_args(argv)
+    for f in (a.linear_genome, a.vcf):
+        if not os.path.isfile(f):
+            sys.exit(f"ERROR: Unable to locate {f}")
+    if a.chroms_prefix_build and a.chroms_namemap_build != NOMAP:
+        sys.exit('ERROR: "--chroms-prefix-build" and "chroms-namemap-build" cannot be used together')
+    namemap = _parse_namemap(a.chroms_namemap_build)
+    available = []
+    with open(a.linear_genome) as fh:                 # get_chromlist (constructVG.py:407-470): the FASTA's sequence names
+        for line in fh:
+            if line.startswith(">"):
+                available.append(line.rstrip().split()[0][1:])
+    chroms = a.chroms_build or available
+    for c in chroms:
+        if c not in available:
+            sys.exit(f'ERROR: Chromosome "{c}" not found among names in {a.linear_genome}.')
+    out = a.out or os.getcwd()
+    os.makedirs(out, exist_ok=True)
+    start = time.time()
+    for c in chroms:
+        if namemap and c not in namemap:
+            sys.exit(f'ERROR: Missing out name map for chromosome "{c}".')
+        name = namemap[c] if namemap else a.chroms_prefix_build + c
+        t0 = time.time()
+        index = GraphIndex.from_fasta_vcf(a.linear_genome, a.vcf, c, threads=a.cores, allow_skipped=not a.strict_variants)
+        path = index.save(os.path.join(out, name))
+        if a.verbose:
+            print(f"{c}: {len(index.ref)} bases, {len(index.pos)} variant sites, {index.n_haplotypes} haplotypes -> {path} "
+                  "in %.2fs" % (time.time() - t0))
+    print("Elapsed time %.2fs" % (time.time() - start))
+
+
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if argv and argv[0] == "buildvg":                  # the reference's two workflows (__main__.py:119-415); findmotif is the default
+        return buildvg(argv[1:])
+    if argv and argv[0] == "findmotif":
+        argv = argv[1:]
     a = get_parser().parse_args(argv)
     if a.threshold <= 0 or a.threshold > 1:
         sys.exit("ERROR: the threshold must be in (0, 1]")

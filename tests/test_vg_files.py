@@ -406,3 +406,23 @@ def test_haplotypes_in_pieces_are_refused(tmp_path):
         (tmp_path / "c.gbwt").write_bytes(vg_encode.gbwt_bytes(broken + walks[2:]))
         with pytest.raises(vg_files.VGFormatError, match=f"a haplotype {what} at node .* inside the chromosome"):
             vg_files.index_from_vg(str(tmp_path / "c.xg"), str(tmp_path / "c.gbwt"), "c")
+
+
+def test_buildvg_subcommand_leaves_the_same_index(tmp_path, capsys):
+    """`python -m grafimo_amd buildvg -l xy.fa -v xy2.vcf.gz -o DIR` (the reference's buildvg flags, __main__.py:200-260):
+    one index per chromosome under the name the reference gives its chrN.xg; the same index vg's own files give"""
+    from grafimo_amd import vg_files
+    from grafimo_amd.__main__ import main
+    from grafimo_amd.extract_regions import GraphIndex
+    main(["buildvg", "-l", os.path.join(REF_DATA, "xy.fa"), "-v", os.path.join(REF_DATA, "xy2.vcf.gz"), "-o", str(tmp_path / "g"),
+          "--chroms-prefix-build", "chr", "--verbose"])
+    assert sorted(os.listdir(tmp_path / "g")) == ["chrx.gfmidx.npz", "chry.gfmidx.npz"]
+    for c in "xy":
+        _same_index(GraphIndex.load(str(tmp_path / "g" / f"chr{c}.gfmidx.npz")),
+                    vg_files.index_from_vg(os.path.join(MYGENOME, f"{c}.xg"), os.path.join(MYGENOME, f"{c}.gbwt"), c), c)
+    (tmp_path / "map.txt").write_text("x\tscaffold_1\n")
+    main(["buildvg", "-l", os.path.join(REF_DATA, "xy.fa"), "-v", os.path.join(REF_DATA, "xy2.vcf.gz"), "-o", str(tmp_path / "m"),
+          "--chroms-build", "x", "--chroms-namemap-build", str(tmp_path / "map.txt")])
+    assert os.listdir(tmp_path / "m") == ["scaffold_1.gfmidx.npz"]
+    with pytest.raises(SystemExit, match="not found among names"):
+        main(["buildvg", "-l", os.path.join(REF_DATA, "xy.fa"), "-v", os.path.join(REF_DATA, "xy2.vcf.gz"), "--chroms-build", "z"])
