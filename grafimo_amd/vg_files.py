@@ -281,6 +281,8 @@ class XG:
             raise VGFormatError(f"{path}: the node records do not tile the graph vector")
         if n_nodes and ((self.start + self.length).max() > self.seq_length or self.length.min() < 1):
             raise VGFormatError(f"{path}: a node's sequence lies outside the sequence vector")
+        if int(n_from.sum()) != n_edges or int(n_to.sum()) != n_edges:
+            raise VGFormatError(f"{path}: {int(n_from.sum())} / {int(n_to.sum())} edge entries, the header says {n_edges} edges")
         src = np.repeat(np.arange(n_nodes, dtype=np.int64), n_from)
         inner = np.arange(len(src), dtype=np.int64) - np.repeat(np.cumsum(n_from) - n_from, n_from)
         ent = g[np.repeat(rec + 5 + n_to, n_from) + inner]
@@ -499,6 +501,8 @@ class GBWT:
                 have = ids.get(w)
                 if have is None:
                     total = rec_of(w)[3]
+                    if total > self.sequences:
+                        raise VGFormatError(f"{self.path}: node {w >> 1}: {total} visits by {self.sequences} sequences")
                     if off == 0 and len(part) == total:          # the only predecessor: its block IS the node's visits
                         ids[w] = part
                         continue
@@ -727,6 +731,16 @@ def graph_to_index(chrom: str, node_ids: np.ndarray, node_seqs, edge_from: np.nd
 def index_from_vg(xg_path: str, gbwt_path: Optional[str] = None, chrom: Optional[str] = None, path_name: Optional[str] = None):
     """XG (+ the GBWT beside it) -> GraphIndex of the embedded path `path_name` (default: the path named `chrom`, or the
     only path there is).  Without a GBWT the index carries no haplotypes.  Raises VGFormatError for what is not decoded."""
+    try:
+        return _index_from_vg(xg_path, gbwt_path, chrom, path_name)
+    except VGFormatError:
+        raise
+    except (IndexError, KeyError, struct.error, OverflowError, MemoryError, ValueError, ZeroDivisionError) as e:
+        # a damaged file that got past the structural checks: still the reader's error, not a stray exception
+        raise VGFormatError(f"{xg_path}{' / ' + gbwt_path if gbwt_path else ''}: not decodable ({type(e).__name__}: {e})") from e
+
+
+def _index_from_vg(xg_path, gbwt_path, chrom, path_name):
     xg = XG(xg_path)
     if not xg.paths:
         raise VGFormatError(f"{xg_path}: no embedded path: region coordinates have nothing to refer to")

@@ -426,3 +426,38 @@ def test_buildvg_subcommand_leaves_the_same_index(tmp_path, capsys):
     assert os.listdir(tmp_path / "m") == ["scaffold_1.gfmidx.npz"]
     with pytest.raises(SystemExit, match="not found among names"):
         main(["buildvg", "-l", os.path.join(REF_DATA, "xy.fa"), "-v", os.path.join(REF_DATA, "xy2.vcf.gz"), "--chroms-build", "z"])
+
+
+def test_damaged_files_are_refused_or_read_never_anything_else(tmp_path):
+    """single flipped bytes and truncations of the tutorial's files: either the reader's own error or an index (a flip in a
+    structure that is skipped changes nothing) -- no stray exception, no hang, no allocation by a corrupted count"""
+    import time
+    from grafimo_amd import vg_files
+    rng = np.random.default_rng(5)
+    xg_raw = open(os.path.join(MYGENOME, "x.xg"), "rb").read()
+    gb_raw = open(os.path.join(MYGENOME, "x.gbwt"), "rb").read()
+    good = vg_files.index_from_vg(os.path.join(MYGENOME, "x.xg"), os.path.join(MYGENOME, "x.gbwt"), "x")
+    outcomes = {"refused": 0, "same": 0, "other index": 0}
+    t0 = time.time()
+    for trial in range(400):
+        which = trial % 2
+        raw = bytearray(xg_raw if which == 0 else gb_raw)
+        if trial % 10 == 9:
+            raw = raw[:int(rng.integers(1, len(raw)))]
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                raw[int(rng.integers(0, len(raw)))] = int(rng.integers(0, 256))
+        xp, gp = tmp_path / "d.xg", tmp_path / "d.gbwt"
+        xp.write_bytes(bytes(raw) if which == 0 else xg_raw)
+        gp.write_bytes(bytes(raw) if which == 1 else gb_raw)
+        try:
+            got = vg_files.index_from_vg(str(xp), str(gp), "x")
+        except vg_files.VGFormatError:
+            outcomes["refused"] += 1
+            continue
+        same = all(np.array_equal(getattr(got, f), getattr(good, f)) for f in FIELDS)
+        outcomes["same" if same else "other index"] += 1
+    assert time.time() - t0 < 120
+    assert outcomes["refused"] > 100 and outcomes["same"] > 20, outcomes
+    # (an "other index" is a flip inside the data itself -- a base, a haplotype's edge -- that leaves a well-formed file)
+    assert outcomes["other index"] < outcomes["refused"], outcomes
