@@ -329,17 +329,20 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
     WL *wl0 = reinterpret_cast<WL *>(tab + fused_tab_dwords(MM, W));
     WL *wl = wl0 + (threadIdx.x >> 6);
     unsigned long long *blk_rows = reinterpret_cast<unsigned long long *>(wl0 + nw);
-    int *blk_q = reinterpret_cast<int *>(blk_rows + nw);                      // [nw] queue lengths, [nw] = base
+    int *blk_q = reinterpret_cast<int *>(blk_rows + nw);                      // [nw] queue lengths, [nw] = base, [nw + 1] = tile ticket
     unsigned *h = reinterpret_cast<unsigned *>(blk_q + nw + 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
     for (int m = 0; m < MM; ++m)
         for (int i = tid; i < W8; i += n_thr) tab[m * W8 + i] = a.tab[m][i];
     for (int i = tid; i < a.slab_stride; i += n_thr) h[i] = 0u;
+#ifndef GFM_GRAPH_STATIC_TILES
+    int *next_tile = blk_q + nw + 1;                               // the workgroup's ticket: see `claim` below
+    if (tid == 0) *next_tile = 0;
+#endif
     __syncthreads();
     unsigned long long rows_done = 0;
     int q_n = 0;                                                   // listed windows in this wavefront's queue (uniform)
-    const int stride = (int)gridDim.x * nw;
     unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, acc_n = 0;   // measurement aid: this wavefront's ticks per phase
     auto lap = [&](int slot, unsigned long long &t0) {
         if (!GFM_DBG(a)) return;
@@ -384,7 +387,26 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         }
         if (lane < kWaveRefBytes / 8) *reinterpret_cast<unsigned long long *>(wl->ref + 8 * lane) = f.refw;
     };
+    // Which tile next.  The host deals the tiles (sorted by cost, dearest first) to the WORKGROUPS round-robin: workgroup b
+    // owns tiles b, b + G, b + 2G, ... -- some dozens of them, dear and cheap ones alike, so the workgroups' shares even
+    // out -- and inside the workgroup a wavefront that is done takes the next one by an LDS ticket.  Dealt to the WAVEFRONTS
+    // instead (five tiles each, round 4 and the first half of round 5) a wavefront's share was left to luck: the
+    // wavefronts were busy 32 us on average in a 50 us kernel.  (A ticket in global memory -- one word sustains ~88 atomics
+    // per microsecond -- made this kernel 469 us in round 4; an LDS ticket costs an LDS round trip.)  A wavefront holds two
+    // tiles ahead of the one it works on (record asked / staging loads issued): the last, cheapest tiles wait for it.
+#ifndef GFM_GRAPH_STATIC_TILES
+    auto claim = [&]() -> int {
+        int j = 0;
+        if (lane == 0) j = atomicAdd(next_tile, 1);
+        j = __builtin_amdgcn_readfirstlane(j);
+        const long long at = (long long)tile_begin + (long long)blockIdx.x + (long long)j * (long long)gridDim.x;
+        return at < (long long)n_tiles ? (int)at : n_tiles;
+    };
+    int ti = claim(), ti1 = n_tiles, ti2 = n_tiles;
+#else
+    const int stride = (int)gridDim.x * nw;
     int ti = tile_begin + (int)blockIdx.x * nw + wave;
+#endif
     // The record of the tile after next travels as a VECTOR load, a dword per lane, and is put together from the lanes when
     // it is needed: as the scalar load the compiler makes of `tiles[uniform index]` it shares its counter with the LDS
     // reads, and the first LDS read of a tile waited for it (scalar loads return out of order: lgkmcnt(0)).
@@ -405,23 +427,44 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
     Tile t_cur{}, t_nxt{};
     unsigned nxt_dw = 0;
     TilePf pf{};
+#ifndef GFM_GRAPH_STATIC_TILES
+    if (ti < n_tiles) {
+        t_cur = tiles[ti];
+        pf = issue(t_cur);
+        ti1 = claim();
+        if (ti1 < n_tiles) nxt_dw = tile_ask(ti1);
+    }
+    for (; ti < n_tiles; ti = ti1, ti1 = ti2) {
+#else
     if (ti < n_tiles) {
         t_cur = tiles[ti];
         pf = issue(t_cur);
         if (ti + stride < n_tiles) nxt_dw = tile_ask(ti + stride);
     }
     for (; ti < n_tiles; ti += stride) {
+#endif
         unsigned long long tk0 = GFM_DBG(a) ? wall_clock64() : 0ull, tk_tile = tk0;
         const Tile t = t_cur;
         commit(t, pf);
         const int my_pos = pf.r0.pos, my_alts = pf.r0.n_alts;      // lane s: the tile's site s (pure tiles read them by readlane)
         __builtin_amdgcn_wave_barrier();
+#ifndef GFM_GRAPH_STATIC_TILES
+        ti2 = n_tiles;
+        if (ti1 < n_tiles) {
+            t_nxt = tile_take(nxt_dw);
+            pf = issue(t_nxt);
+            t_cur = t_nxt;
+            ti2 = claim();
+            if (ti2 < n_tiles) nxt_dw = tile_ask(ti2);
+        }
+#else
         if (ti + stride < n_tiles) {
             t_nxt = tile_take(nxt_dw);
             pf = issue(t_nxt);
             t_cur = t_nxt;
             if (ti + 2 * stride < n_tiles) nxt_dw = tile_ask(ti + 2 * stride);
         }
+#endif
         const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);
         const int n_win = t.n_win & 0xff;
         lap(0, tk0);                   // 8: the staged data into LDS, the next tile's loads issued
