@@ -332,15 +332,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
     int *blk_q = reinterpret_cast<int *>(blk_rows + nw);                      // [nw] queue lengths, [nw] = base, [nw + 1] = tile ticket
     unsigned *h = reinterpret_cast<unsigned *>(blk_q + nw + 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#pragma unroll
-    for (int m = 0; m < MM; ++m)
-        for (int i = tid; i < W8; i += n_thr) tab[m * W8 + i] = a.tab[m][i];
-    for (int i = tid; i < a.slab_stride; i += n_thr) h[i] = 0u;
-#ifndef GFM_GRAPH_STATIC_TILES
     int *next_tile = blk_q + nw + 1;                               // the workgroup's ticket: see `claim` below
-    if (tid == 0) *next_tile = 0;
-#endif
-    __syncthreads();
     unsigned long long rows_done = 0;
     int q_n = 0;                                                   // listed windows in this wavefront's queue (uniform)
     unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, acc_n = 0;   // measurement aid: this wavefront's ticks per phase
@@ -394,19 +386,15 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
     // wavefronts were busy 32 us on average in a 50 us kernel.  (A ticket in global memory -- one word sustains ~88 atomics
     // per microsecond -- made this kernel 469 us in round 4; an LDS ticket costs an LDS round trip.)  A wavefront holds two
     // tiles ahead of the one it works on (record asked / staging loads issued): the last, cheapest tiles wait for it.
-#ifndef GFM_GRAPH_STATIC_TILES
-    auto claim = [&]() -> int {
-        int j = 0;
-        if (lane == 0) j = atomicAdd(next_tile, 1);
-        j = __builtin_amdgcn_readfirstlane(j);
+    auto tile_at = [&](int j) -> int {
         const long long at = (long long)tile_begin + (long long)blockIdx.x + (long long)j * (long long)gridDim.x;
         return at < (long long)n_tiles ? (int)at : n_tiles;
     };
-    int ti = claim(), ti1 = n_tiles, ti2 = n_tiles;
-#else
-    const int stride = (int)gridDim.x * nw;
-    int ti = tile_begin + (int)blockIdx.x * nw + wave;
-#endif
+    auto claim = [&]() -> int {
+        int j = 0;
+        if (lane == 0) j = atomicAdd(next_tile, 1);
+        return tile_at(__builtin_amdgcn_readfirstlane(j));
+    };
     // The record of the tile after next travels as a VECTOR load, a dword per lane, and is put together from the lanes when
     // it is needed: as the scalar load the compiler makes of `tiles[uniform index]` it shares its counter with the LDS
     // reads, and the first LDS read of a tile waited for it (scalar loads return out of order: lgkmcnt(0)).
@@ -425,30 +413,32 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         return t;
     };
     Tile t_cur{}, t_nxt{};
-    unsigned nxt_dw = 0;
     TilePf pf{};
-#ifndef GFM_GRAPH_STATIC_TILES
+    // The kernel's start: every wavefront of the chip is at the same point, nobody covers anybody's latency -- so the first
+    // tile's record (wavefront w: the workgroup's w-th, no ticket needed) is asked for BEFORE the tables are filled and
+    // the histogram windows zeroed, and its staging loads are on their way before the barrier.
+    int ti = tile_at(wave), ti1 = n_tiles, ti2 = n_tiles;
+    unsigned nxt_dw = ti < n_tiles ? tile_ask(ti) : 0u;
+#pragma unroll
+    for (int m = 0; m < MM; ++m)
+        for (int i = tid; i < W8; i += n_thr) tab[m * W8 + i] = a.tab[m][i];
+    for (int i = tid; i < a.slab_stride; i += n_thr) h[i] = 0u;
+    if (tid == 0) *next_tile = nw;
     if (ti < n_tiles) {
-        t_cur = tiles[ti];
+        t_cur = tile_take(nxt_dw);
         pf = issue(t_cur);
+    }
+    __syncthreads();
+    if (ti < n_tiles) {
         ti1 = claim();
         if (ti1 < n_tiles) nxt_dw = tile_ask(ti1);
     }
     for (; ti < n_tiles; ti = ti1, ti1 = ti2) {
-#else
-    if (ti < n_tiles) {
-        t_cur = tiles[ti];
-        pf = issue(t_cur);
-        if (ti + stride < n_tiles) nxt_dw = tile_ask(ti + stride);
-    }
-    for (; ti < n_tiles; ti += stride) {
-#endif
         unsigned long long tk0 = GFM_DBG(a) ? wall_clock64() : 0ull, tk_tile = tk0;
         const Tile t = t_cur;
         commit(t, pf);
         const int my_pos = pf.r0.pos, my_alts = pf.r0.n_alts;      // lane s: the tile's site s (pure tiles read them by readlane)
         __builtin_amdgcn_wave_barrier();
-#ifndef GFM_GRAPH_STATIC_TILES
         ti2 = n_tiles;
         if (ti1 < n_tiles) {
             t_nxt = tile_take(nxt_dw);
@@ -457,14 +447,6 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
             ti2 = claim();
             if (ti2 < n_tiles) nxt_dw = tile_ask(ti2);
         }
-#else
-        if (ti + stride < n_tiles) {
-            t_nxt = tile_take(nxt_dw);
-            pf = issue(t_nxt);
-            t_cur = t_nxt;
-            if (ti + 2 * stride < n_tiles) nxt_dw = tile_ask(ti + 2 * stride);
-        }
-#endif
         const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);
         const int n_win = t.n_win & 0xff;
         lap(0, tk0);                   // 8: the staged data into LDS, the next tile's loads issued
