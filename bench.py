@@ -565,10 +565,11 @@ def product_paths_block(ctcf, dev, rank, world):
 
 
 def fused_issue_roofline(kernel_us):
-    """graph_score_kernel is integer / LDS work that moves ~40 MB per launch: its bound is instruction ISSUE, not HBM.  A
-    wave64 vector instruction occupies a SIMD for two cycles (MI355X_MICROARCH.md: SIMD-32 lanes), a CU has four SIMDs and ONE
-    scalar unit: floor = max(VALU x 2 / (4 x CUs), SALU / CUs) / clock, with the instruction counts of the committed
-    rocprofv3 --pmc passes (profiles/pmc_fused.json, valid while the kernel's sources hash as they did)."""
+    """graph_score_kernel is integer / LDS work that moves ~40 MB per launch: its bounds are the CU's own units, not HBM.  A
+    wave64 vector instruction occupies a SIMD for two cycles (MI355X_MICROARCH.md: SIMD-32 lanes), a CU has four SIMDs, ONE
+    scalar unit and ONE LDS array: floor = max(VALU x 2 / (4 x CUs), SALU / CUs, LDS-array cycles / CUs) / clock, with the
+    counts of the committed rocprofv3 --pmc passes (profiles/pmc_fused.json, valid while the kernel's sources hash as they
+    did; SQ_LDS_IDX_ACTIVE = all LDS-array cycles, bank conflicts included)."""
     import hashlib
     path = os.path.join(ROOT, "profiles", "pmc_fused.json")
     out = {"bound": "valu_issue", "kernel": "graph_score_kernel", "kernel_us": kernel_us, "clock_ghz": 2.4, "cus": 256}
@@ -576,11 +577,13 @@ def fused_issue_roofline(kernel_us):
         rec = json.load(open(path))
         src = b"".join(open(os.path.join(ROOT, f), "rb").read() for f in rec["kernel_source_files"])
         fresh = hashlib.sha256(src).hexdigest()[:16] == rec["kernel_source_sha16"]
-        valu_us = rec["insts_valu"] * 2.0 / (4 * 256) / 2.4e3
-        salu_us = rec["insts_salu"] / 256.0 / 2.4e3
-        out.update({"insts": {"valu": rec["insts_valu"], "salu": rec["insts_salu"], "lds": rec["insts_lds"]},
-                    "floor_us": max(valu_us, salu_us), "valu_floor_us": valu_us, "salu_floor_us": salu_us,
-                    "frac": max(valu_us, salu_us) / kernel_us if kernel_us > 0 else None,
+        floors = {"valu_issue": rec["insts_valu"] * 2.0 / (4 * 256) / 2.4e3, "salu_issue": rec["insts_salu"] / 256.0 / 2.4e3,
+                  "lds": (rec.get("lds_idx_active_cycles") or 0.0) / 256.0 / 2.4e3}
+        bound = max(floors, key=floors.get)
+        out.update({"bound": bound, "insts": {"valu": rec["insts_valu"], "salu": rec["insts_salu"], "lds": rec["insts_lds"]},
+                    "lds_array_cycles": rec.get("lds_idx_active_cycles"),
+                    "floor_us": floors[bound], "valu_floor_us": floors["valu_issue"], "salu_floor_us": floors["salu_issue"],
+                    "lds_floor_us": floors["lds"], "frac": floors[bound] / kernel_us if kernel_us > 0 else None,
                     "counters": rec["source"] if fresh else "profiles/pmc_fused.json is STALE: the fused kernels' sources changed "
                                                               "since its counters were taken (the floor is that of the older kernel)",
                     "counters_fresh": fresh})

@@ -102,6 +102,7 @@ struct FusedArgs {
     // LAB BUILDS ONLY (scripts/lab_build.sh -DGFM_LAB; never in libgrafimo_hip.so): per-phase timers and switches that turn
     // parts of graph_score_kernel off -- with a switch set the results are WRONG, only the kernel times count
     unsigned long long *dbg;      // GRAFIMO_FUSED_TIMERS=1: [k] sum, [16 + k] max of phase k's 10-ns ticks, [32 + k] count
+    unsigned long long *tile_log; // GRAFIMO_FUSED_TIMERS=2: per tile (ticks << 32) | (begin since the wavefront's loop began); no atomics
     int lab;                      // GRAFIMO_FUSED_LAB=bits: 1 no phase 2, 2 no base scores, 4 no window classification, 8 no booking
 #endif
 };
@@ -433,7 +434,13 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         ti1 = claim();
         if (ti1 < n_tiles) nxt_dw = tile_ask(ti1);
     }
+#ifdef GFM_LAB
+    const unsigned long long dbg_t0 = a.tile_log ? wall_clock64() : 0ull;
+#endif
     for (; ti < n_tiles; ti = ti1, ti1 = ti2) {
+#ifdef GFM_LAB
+        const unsigned long long tl_begin = a.tile_log ? wall_clock64() : 0ull;
+#endif
         unsigned long long tk0 = GFM_DBG(a) ? wall_clock64() : 0ull, tk_tile = tk0;
         const Tile t = t_cur;
         commit(t, pf);
@@ -739,6 +746,10 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         __builtin_amdgcn_wave_barrier();       // the tile's LDS is free again
         lap(4, tk0);                  // 12: phase 2
         lap(5, tk_tile);                       // 13: the whole tile
+#ifdef GFM_LAB
+        if (a.tile_log && lane == 0 && !a.listing)      // per tile: its ticks, and when it began (since the workgroup's loop began)
+            a.tile_log[ti] = ((wall_clock64() - tl_begin) << 32) | ((tl_begin - dbg_t0) & 0xffffffffull);
+#endif
         ++acc_n;
     }
     if (unsigned long long *dbg = GFM_DBG(a); dbg && lane == 0 && acc_n)

@@ -2209,11 +2209,15 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
     a.listing = listing ? 1 : 0;
     a.plan_overflow = P->f_flags.p + 4;
 #ifdef GFM_LAB      // lab builds only (scripts/lab_build.sh -DGFM_LAB): the product reads neither variable
-    static const bool timers = [] { const char *e = std::getenv("GRAFIMO_FUSED_TIMERS"); return e && *e == '1'; }();
-    if (timers) {
-        GX_TRY(g->f_dbg.reserve(48));
-        GX_TRY(hipMemsetAsync(g->f_dbg.p, 0, 48 * sizeof(unsigned long long), st));
-        a.dbg = g->f_dbg.p;
+    static const int timer_mode = [] { const char *e = std::getenv("GRAFIMO_FUSED_TIMERS"); return e ? atoi(e) : 0; }();
+    const bool timers = timer_mode == 1, tile_log = timer_mode == 2;
+    a.dbg = nullptr;
+    a.tile_log = nullptr;
+    if (timers || tile_log) {
+        GX_TRY(g->f_dbg.reserve(64 + (size_t)P->f_n_tiles));
+        GX_TRY(hipMemsetAsync(g->f_dbg.p, 0, (64 + (size_t)P->f_n_tiles) * sizeof(unsigned long long), st));
+        if (timers) a.dbg = g->f_dbg.p;
+        else a.tile_log = g->f_dbg.p + 64;
     }
     static const int lab = [] { const char *e = std::getenv("GRAFIMO_FUSED_LAB"); return e ? atoi(e) : 0; }();
     a.lab = lab;
@@ -2234,6 +2238,42 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
         std::fprintf(stderr, "[fused] listed windows %d, work items %d\n", fl[1], fl[3]);
         for (int k = 0; k < 16; ++k)
             if (h[32 + k]) std::fprintf(stderr, "[fused] phase %d: n %llu, mean %.2f us, max %.2f us\n", k, h[32 + k], 0.01 * (double)h[k] / (double)h[32 + k], 0.01 * (double)h[16 + k]);
+    }
+    if (tile_log) {
+        GX_TRY(hipStreamSynchronize(st));
+        if (!listing && P->f_n_tiles > 0) {       // per tile: duration and start (relative to its wavefront's first tile), with the tile's record
+            std::vector<unsigned long long> tt((size_t)P->f_n_tiles);
+            std::vector<Tile> tl((size_t)P->f_n_tiles);
+            GX_TRY(hipMemcpy(tt.data(), g->f_dbg.p + 64, tt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            GX_TRY(hipMemcpy(tl.data(), P->f_tiles.p, tl.size() * sizeof(Tile), hipMemcpyDeviceToHost));
+            std::vector<int> order(tt.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return (tt[(size_t)x] >> 32) > (tt[(size_t)y] >> 32); });
+            auto us = [&](int i) { return 0.01 * (double)(tt[(size_t)i] >> 32); };
+            std::fprintf(stderr, "[fused] tiles %zu: duration max %.2f, p99 %.2f, p90 %.2f, median %.2f, min %.2f us\n", order.size(), us(order[0]),
+                         us(order[order.size() / 100]), us(order[order.size() / 10]), us(order[order.size() / 2]), us(order.back()));
+            double last_end = 0;
+            for (size_t i = 0; i < tt.size(); ++i) last_end = std::max(last_end, 0.01 * (double)((tt[i] & 0xffffffffull) + (tt[i] >> 32)));
+            std::fprintf(stderr, "[fused] last tile ends %.2f us after its wavefront's loop began\n", last_end);
+            double sum_p = 0, sum_g = 0;
+            size_t n_p = 0, n_g = 0;
+            std::vector<double> ends(tt.size());
+            for (size_t i = 0; i < tt.size(); ++i) {
+                ends[i] = 0.01 * (double)((tt[i] & 0xffffffffull) + (tt[i] >> 32));
+                if (tl[i].n_win & kTilePure) { sum_p += us((int)i); ++n_p; } else { sum_g += us((int)i); ++n_g; }
+            }
+            std::sort(ends.begin(), ends.end());
+            std::fprintf(stderr, "[fused] pure tiles %zu: mean %.2f us; general tiles %zu: mean %.2f us; wave-time in tiles %.0f us\n", n_p,
+                         n_p ? sum_p / (double)n_p : 0.0, n_g, n_g ? sum_g / (double)n_g : 0.0, sum_p + sum_g);
+            std::fprintf(stderr, "[fused] tile END times: p10 %.1f, p50 %.1f, p90 %.1f, p99 %.1f, max %.1f us\n", ends[ends.size() / 10],
+                         ends[ends.size() / 2], ends[ends.size() * 9 / 10], ends[ends.size() * 99 / 100], ends.back());
+            for (int k = 0; k < 12 && k < (int)order.size(); ++k) {
+                const int i = order[(size_t)k];
+                const Tile &t = tl[(size_t)i];
+                std::fprintf(stderr, "[fused]   tile %d: %.2f us (began at %.2f), windows %d%s, sites %d (far %d)\n", i, us(i),
+                             0.01 * (double)(tt[(size_t)i] & 0xffffffffull), t.n_win & 0xff, (t.n_win & kTilePure) ? " pure" : "", t.i_hi - t.i_lo, t.i_far - t.i_lo);
+            }
+        }
     }
 #endif
     if (d_overflow) GX_TRY(hipMemcpyAsync(d_overflow, P->f_flags.p + 2, sizeof(int), hipMemcpyDeviceToDevice, st));

@@ -56,7 +56,9 @@ python scripts/ingest_probe.py > "$out/ingest_probe.txt" 2>&1
 bash "$root/scripts/pmc_fused_sq.sh" > /dev/null 2>&1
 cp "$root/gpurun_out/pmc_fused_sq/summary.txt" "$out/pmc_fused_sq.txt" 2>/dev/null
 # per-phase timers exist in lab builds only (scripts/lab_build.sh fusedlab -DGFM_LAB)
-[ -f "$root/lab/libgfm_fusedlab.so" ] && GRAFIMO_HIP_LIB="$root/lab/libgfm_fusedlab.so" GRAFIMO_FUSED_TIMERS=1 python scripts/fused_prof.py 2>&1 | grep "\[fused\]" | tail -16 > "$out/fused_timers.txt"
+# (GRAFIMO_FUSED_TIMERS=2: one store per tile, no atomics -- mode 1's per-phase sums go through atomics on a few words and
+# stretch the kernel tenfold)
+[ -f "$root/lab/libgfm_fusedlab.so" ] && GRAFIMO_HIP_LIB="$root/lab/libgfm_fusedlab.so" GRAFIMO_FUSED_TIMERS=2 python scripts/fused_prof.py 2>&1 | grep "\[fused\]" | tail -18 > "$out/fused_timers.txt"
 # the four fuzz drivers on fresh seeds (bounded: FUZZ_S seconds each), the round's last code
 {
   s0=$(( $(date +%s) % 100000 ))

@@ -17,10 +17,11 @@ for line in open(summary):
 files = ["grafimo_amd/csrc/gfm_graph_fused.hpp", "grafimo_amd/csrc/graph_extract.hip"]
 src = b"".join(open(os.path.join(root, f), "rb").read() for f in files)
 out = {
-    "kernel": "graph_score_kernel<1, false>", "workload": "bench.py extract block: 10 000 regions x 200 bp, 69 224 sites, W = 19, 6.04e6 rows",
+    "kernel": "graph_score_kernel<1, false, true>", "workload": "bench.py extract block: 10 000 regions x 200 bp, 69 224 sites, W = 19, 6.04e6 rows",
     "insts_valu": vals["SQ_INSTS_VALU"], "insts_salu": vals["SQ_INSTS_SALU"], "insts_lds": vals["SQ_INSTS_LDS"],
     "insts_branch": vals.get("SQ_INSTS_BRANCH"), "waves": vals.get("SQ_WAVES"), "wave_cycles": vals.get("SQ_WAVE_CYCLES"),
     "wait_any_cycles": vals.get("SQ_WAIT_ANY"), "active_inst_any": vals.get("SQ_ACTIVE_INST_ANY"),
+    "lds_idx_active_cycles": vals.get("SQ_LDS_IDX_ACTIVE"), "lds_bank_conflict_cycles": vals.get("SQ_LDS_BANK_CONFLICT"),
     "source": f"{os.path.relpath(summary, root)} ({note})",
     "kernel_source_sha16": hashlib.sha256(src).hexdigest()[:16], "kernel_source_files": files,
 }
