@@ -430,10 +430,12 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         pf = issue(t_cur);
     }
     __syncthreads();
+#ifndef GFM_GRAPH_HOLD1
     if (ti < n_tiles) {
         ti1 = claim();
         if (ti1 < n_tiles) nxt_dw = tile_ask(ti1);
     }
+#endif
 #ifdef GFM_LAB
     const unsigned long long dbg_t0 = a.tile_log ? wall_clock64() : 0ull;
 #endif
@@ -447,6 +449,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         const int my_pos = pf.r0.pos, my_alts = pf.r0.n_alts;      // lane s: the tile's site s (pure tiles read them by readlane)
         __builtin_amdgcn_wave_barrier();
         ti2 = n_tiles;
+#ifndef GFM_GRAPH_HOLD1
         if (ti1 < n_tiles) {
             t_nxt = tile_take(nxt_dw);
             pf = issue(t_nxt);
@@ -454,6 +457,10 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
             ti2 = claim();
             if (ti2 < n_tiles) nxt_dw = tile_ask(ti2);
         }
+#else   // lab variant: ONE tile held ahead -- its record asked for here, its staging loads issued between the tile's two phases
+        ti1 = claim();
+        if (ti1 < n_tiles) nxt_dw = tile_ask(ti1);
+#endif
         const int staged = min(t.i_far - t.i_lo + 1, kWaveSites);
         const int n_win = t.n_win & 0xff;
         lap(0, tk0);                   // 8: the staged data into LDS, the next tile's loads issued
@@ -650,6 +657,13 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         }
         __builtin_amdgcn_wave_barrier();
         lap(3, tk0);                  // 11: reference walks + listing + scan
+#ifdef GFM_GRAPH_HOLD1
+        if (ti1 < n_tiles) {
+            t_nxt = tile_take(nxt_dw);
+            pf = issue(t_nxt);
+            t_cur = t_nxt;
+        }
+#endif
         // ---- phase 2: lane per walk
         for (int base = 0; base < total; base += 64) {
             const int wt = base + lane;
