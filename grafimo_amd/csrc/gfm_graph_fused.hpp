@@ -102,7 +102,7 @@ struct FusedArgs {
     // LAB BUILDS ONLY (scripts/lab_build.sh -DGFM_LAB; never in libgrafimo_hip.so): per-phase timers and switches that turn
     // parts of graph_score_kernel off -- with a switch set the results are WRONG, only the kernel times count
     unsigned long long *dbg;      // GRAFIMO_FUSED_TIMERS=1: [k] sum, [16 + k] max of phase k's 10-ns ticks, [32 + k] count
-    unsigned long long *tile_log; // GRAFIMO_FUSED_TIMERS=2: per tile (ticks << 32) | (begin since the wavefront's loop began); no atomics
+    unsigned long long *tile_log; // GRAFIMO_FUSED_TIMERS=2: per tile ticks << 40 | begin since the wavefront's loop began << 16 | workgroup; no atomics
     int lab;                      // GRAFIMO_FUSED_LAB=bits: 1 no phase 2, 2 no base scores, 4 no window classification, 8 no booking
 #endif
 };
@@ -762,7 +762,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         lap(5, tk_tile);                       // 13: the whole tile
 #ifdef GFM_LAB
         if (a.tile_log && lane == 0 && !a.listing)      // per tile: its ticks, and when it began (since the workgroup's loop began)
-            a.tile_log[ti] = ((wall_clock64() - tl_begin) << 32) | ((tl_begin - dbg_t0) & 0xffffffffull);
+            a.tile_log[ti] = (((wall_clock64() - tl_begin) & 0xffffffull) << 40) | (((tl_begin - dbg_t0) & 0xffffffull) << 16) | (blockIdx.x & 0xffffu);
 #endif
         ++acc_n;
     }

@@ -2248,30 +2248,52 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
             GX_TRY(hipMemcpy(tl.data(), P->f_tiles.p, tl.size() * sizeof(Tile), hipMemcpyDeviceToHost));
             std::vector<int> order(tt.size());
             for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-            std::sort(order.begin(), order.end(), [&](int x, int y) { return (tt[(size_t)x] >> 32) > (tt[(size_t)y] >> 32); });
-            auto us = [&](int i) { return 0.01 * (double)(tt[(size_t)i] >> 32); };
-            std::fprintf(stderr, "[fused] tiles %zu: duration max %.2f, p99 %.2f, p90 %.2f, median %.2f, min %.2f us\n", order.size(), us(order[0]),
-                         us(order[order.size() / 100]), us(order[order.size() / 10]), us(order[order.size() / 2]), us(order.back()));
-            double last_end = 0;
-            for (size_t i = 0; i < tt.size(); ++i) last_end = std::max(last_end, 0.01 * (double)((tt[i] & 0xffffffffull) + (tt[i] >> 32)));
-            std::fprintf(stderr, "[fused] last tile ends %.2f us after its wavefront's loop began\n", last_end);
+            auto dur = [&](size_t i) { return 0.01 * (double)(tt[i] >> 40); };
+            auto beg = [&](size_t i) { return 0.01 * (double)((tt[i] >> 16) & 0xffffffull); };
+            auto wg = [&](size_t i) { return (size_t)(tt[i] & 0xffffull); };
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return (tt[(size_t)x] >> 40) > (tt[(size_t)y] >> 40); });
+            std::fprintf(stderr, "[fused] tiles %zu: duration max %.2f, p99 %.2f, p90 %.2f, median %.2f, min %.2f us\n", order.size(), dur((size_t)order[0]),
+                         dur((size_t)order[order.size() / 100]), dur((size_t)order[order.size() / 10]), dur((size_t)order[order.size() / 2]), dur((size_t)order.back()));
             double sum_p = 0, sum_g = 0;
-            size_t n_p = 0, n_g = 0;
+            size_t n_p = 0, n_g = 0, G = 0;
             std::vector<double> ends(tt.size());
             for (size_t i = 0; i < tt.size(); ++i) {
-                ends[i] = 0.01 * (double)((tt[i] & 0xffffffffull) + (tt[i] >> 32));
-                if (tl[i].n_win & kTilePure) { sum_p += us((int)i); ++n_p; } else { sum_g += us((int)i); ++n_g; }
+                ends[i] = beg(i) + dur(i);
+                G = std::max(G, wg(i) + 1);
+                if (tl[i].n_win & kTilePure) { sum_p += dur(i); ++n_p; } else { sum_g += dur(i); ++n_g; }
+            }
+            std::vector<double> wg_end(G, 0.0), wg_busy(G, 0.0);
+            std::vector<int> wg_tiles(G, 0);
+            for (size_t i = 0; i < tt.size(); ++i) {
+                wg_end[wg(i)] = std::max(wg_end[wg(i)], ends[i]);
+                wg_busy[wg(i)] += dur(i);
+                ++wg_tiles[wg(i)];
             }
             std::sort(ends.begin(), ends.end());
             std::fprintf(stderr, "[fused] pure tiles %zu: mean %.2f us; general tiles %zu: mean %.2f us; wave-time in tiles %.0f us\n", n_p,
                          n_p ? sum_p / (double)n_p : 0.0, n_g, n_g ? sum_g / (double)n_g : 0.0, sum_p + sum_g);
             std::fprintf(stderr, "[fused] tile END times: p10 %.1f, p50 %.1f, p90 %.1f, p99 %.1f, max %.1f us\n", ends[ends.size() / 10],
                          ends[ends.size() / 2], ends[ends.size() * 9 / 10], ends[ends.size() * 99 / 100], ends.back());
-            for (int k = 0; k < 12 && k < (int)order.size(); ++k) {
-                const int i = order[(size_t)k];
-                const Tile &t = tl[(size_t)i];
-                std::fprintf(stderr, "[fused]   tile %d: %.2f us (began at %.2f), windows %d%s, sites %d (far %d)\n", i, us(i),
-                             0.01 * (double)(tt[(size_t)i] & 0xffffffffull), t.n_win & 0xff, (t.n_win & kTilePure) ? " pure" : "", t.i_hi - t.i_lo, t.i_far - t.i_lo);
+            {
+                double e0 = 0, e1 = 0, b0 = 0, b1 = 0, t0 = 0, t1 = 0;
+                for (size_t b = 0; b < G; ++b) {
+                    (b < G / 2 ? e0 : e1) += wg_end[b];
+                    (b < G / 2 ? b0 : b1) += wg_busy[b];
+                    (b < G / 2 ? t0 : t1) += wg_tiles[b];
+                }
+                const double h = (double)(G / 2 ? G / 2 : 1);
+                std::fprintf(stderr, "[fused] workgroups %zu: lower half / upper half of the grid: done at %.1f / %.1f us, tiles %.1f / %.1f, wavefront-time %.0f / %.0f us\n",
+                             G, e0 / h, e1 / h, t0 / h, t1 / h, b0 / h, b1 / h);
+                std::vector<double> we = wg_end;
+                std::sort(we.begin(), we.end());
+                std::fprintf(stderr, "[fused] workgroups done at: min %.1f, p10 %.1f, median %.1f, p90 %.1f, max %.1f us\n", we.front(), we[G / 10], we[G / 2],
+                             we[G * 9 / 10], we.back());
+            }
+            for (int k = 0; k < 8 && k < (int)order.size(); ++k) {
+                const size_t i = (size_t)order[(size_t)k];
+                const Tile &t = tl[i];
+                std::fprintf(stderr, "[fused]   tile %zu: %.2f us (began at %.2f, workgroup %zu), windows %d%s, sites %d (far %d)\n", i, dur(i), beg(i), wg(i),
+                             t.n_win & 0xff, (t.n_win & kTilePure) ? " pure" : "", t.i_hi - t.i_lo, t.i_far - t.i_lo);
             }
         }
     }
