@@ -635,13 +635,8 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         // the walks left for phase 2: layout A's with an alternate allele somewhere, all of layout B's.  Inclusive scan.
         const int nA = walks_a > 0 ? walks_a - 1 : 0;
         const int v_w = nA + walks_b;
-        int incl = v_w;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        int total = __shfl(incl, 63);
+        const int incl = wave_prefix_sum(v_w);
+        int total = __builtin_amdgcn_readlane(incl, 63);
         if (GFM_LAB_BIT(a, 1)) total = 0;
         // the usual tile holds a few dozen such walks: every window writes its index over its walks' slots, and phase 2
         // reads a walk's window with ONE LDS access instead of a six-step search through incl[]
@@ -696,12 +691,12 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
 #pragma unroll
                     for (int m = 0; m < MM; ++m) sum[m] = wl->wsc[m][k];
                     bad = (int)(pw.y & 0x7fu);
-                    unsigned long long rest = (unsigned long long)q;
+                    unsigned rest = (unsigned)q;                                     // (<= kHeavyWalks: 32 bits and to spare)
                     const int pk = (int)(t.p0 + k);
                     for (int s = (int)((pw.x >> 16) & 0xffu) - 1; s >= 0 && rest; --s) {        // digits, last site first
                         const SiteRec r = sites.at(i0k + s);
                         const int nall = (r.del_len | r.ins_len) ? 1 : 1 + (r.n_alts & 3);     // (a one-deletion window's own record)
-                        const int al = take_digit(rest, nall);
+                        const int al = take_digit32(rest, nall);
                         if (al) {
                             const int j = r.pos - pk;
                             const unsigned cr = base_code(wl->ref[k + j]), ca = base_code((unsigned)r.n_alts >> (8 * al));
@@ -716,7 +711,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
                     for (int m = 0; m < MM; ++m) sum[m] = wl->score_b[m][k];
                     const unsigned si = wl->sinfo[k];
                     bad = (int)(si & 0xffu);
-                    unsigned long long rest = (unsigned long long)(qq - nA_k);
+                    unsigned rest = (unsigned)(qq - nA_k);
                     const long long pk = t.p0 + k;
                     const long long x = pk + (long long)((si >> 8) & 0xffu), len = (long long)(si >> 16);
                     for (int s = (int)(pw.x >> 24) - 1; s >= 0 && rest; --s) {
@@ -724,7 +719,7 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
                         if (r.del_len | r.ins_len) continue;      // (the deletion's own record)
                         if (r.pos > x && r.pos <= x + len) continue;
                         const int nall = 1 + (r.n_alts & 3);
-                        const int al = take_digit(rest, nall);
+                        const int al = take_digit32(rest, nall);
                         if (al) {
                             const int j = (int)(r.pos - pk) - (r.pos > x ? (int)len : 0);
                             const unsigned cr = base_code(ref_at(r.pos)), ca = base_code((unsigned)r.n_alts >> (8 * al));

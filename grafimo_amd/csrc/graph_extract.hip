@@ -141,6 +141,29 @@ __device__ inline int take_digit(unsigned long long &rest, int nall)
     return d;
 }
 
+// ... and where the walk number is known to fit 32 bits (graph_score_kernel's own walks: at most kHeavyWalks per window)
+__device__ inline int take_digit32(unsigned &rest, int nall)
+{
+    const unsigned r = rest;
+    const unsigned q3 = __umulhi(r, 0xAAAAAAABu) >> 1;
+    const unsigned q = nall == 1 ? r : (nall == 2 ? r >> 1 : (nall == 3 ? q3 : r >> 2));
+    rest = q;
+    return (int)(r - q * (unsigned)nall);
+}
+
+// Inclusive prefix sum over the wavefront's 64 lanes in the vector ALU alone (DPP: shifts inside the rows of 16 lanes, then the
+// last lane of a row broadcast into the rows behind it): __shfl_up goes through the LDS unit, six dependent round trips per tile.
+__device__ __forceinline__ int wave_prefix_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // A walk may start inside an insertion anchored at p - 1 (start coordinate p): `pre_site` = that site (or -1),
 // `pre_t` = offset of its first base inside the inserted string.  next_start() steps through the starts of
 // window p in enumeration order: the plain start, then per insertion anchored at p - 1 (site order) t = 0, 1, ...
