@@ -302,6 +302,7 @@ class XG:
         if len(self.path_names) != n_paths:
             raise VGFormatError(f"{path}: {len(self.path_names)} path names for {n_paths} paths")
         self.paths: Dict[str, np.ndarray] = {}
+        self._edge_key = None
         if n_paths:
             self._read_paths(p, r.o, n_paths)
 
@@ -312,7 +313,7 @@ class XG:
         size = r.u64()
         if size == 0 or size > 64 * len(self.ids) + 64 or (min_handle >> 1) > int(self.rec_off[-1]):
             raise VGFormatError("no path here")
-        zw, zwidth, _ = r.int_vector0()
+        zw, _, _ = r.int_vector0()
         zbits = len(zw) * 64
         samples = r.values0()
         if len(samples) != 2 * ((size + ENC_DENS - 1) // ENC_DENS + 1):
@@ -324,17 +325,13 @@ class XG:
         idx = np.searchsorted(self.rec_off, off)
         if (idx >= len(self.rec_off)).any() or not np.array_equal(self.rec_off[idx], off):
             raise VGFormatError("no path here")
-        have = set(zip(self.edge_from.tolist(), self.edge_to.tolist())) if len(idx) < 4096 else None
-        if have is not None:
-            if any((a, b) not in have for a, b in zip(idx[:-1].tolist(), idx[1:].tolist())):
-                raise VGFormatError("no path here")
-        else:
-            key = self.edge_from * len(self.ids) + self.edge_to
-            key.sort()
-            want = idx[:-1] * len(self.ids) + idx[1:]
-            at_ = np.searchsorted(key, want)
-            if (at_ >= len(key)).any() or not np.array_equal(key[np.minimum(at_, len(key) - 1)], want):
-                raise VGFormatError("no path here")
+        if self._edge_key is None:                                # (once: candidates that get this far are few, edges are many)
+            self._edge_key = np.sort(self.edge_from * len(self.ids) + self.edge_to)
+        want = idx[:-1] * len(self.ids) + idx[1:]
+        at_ = np.searchsorted(self._edge_key, want)
+        if len(want) and ((at_ >= len(self._edge_key)).any()
+                          or not np.array_equal(self._edge_key[np.minimum(at_, len(self._edge_key) - 1)], want)):
+            raise VGFormatError("no path here")                   # (two steps in a row that no edge joins)
         r.skip_rrr63()
         r.u8()                                                    # is_circular
         return idx, r.o
