@@ -179,6 +179,57 @@ __device__ __forceinline__ void push_hits(const FusedArgs &a, int m, bool hit, i
     }
 }
 
+// graph_score_kernel's arguments as they lie in the kernarg segment (in order, naturally aligned).  What the kernel needs once
+// in a while -- where hits go, the overflow flags, the lists the LISTING instantiation fills, what the epilogue writes -- is read
+// from there AT ITS USE, behind a pointer the compiler cannot see through: named as parameters these 24 scalar registers'
+// worth of pointers are loaded at the kernel's start and live across the tile loop, where 82 scalar registers are spilled into
+// vector lanes already.
+struct ScoreKernArgs {
+    GraphDev g;
+    FusedArgs a;
+    const Tile *tiles;
+    int tile_begin, n_tiles;
+    DelWin *del_wins;
+    int *del_count, *overflow;
+    HeavyWin *heavy_wins;
+    unsigned long long *heavy_ctl;
+    int *plan_overflow_w;
+};
+typedef const __attribute__((address_space(4))) ScoreKernArgs *ColdArgs;
+__device__ __forceinline__ ColdArgs cold_args()
+{
+    ColdArgs ka = (ColdArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return ka;
+}
+__device__ __forceinline__ void push_hits_cold(int m, bool hit, int tile, int k, long long q2, int score)
+{
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+    if (mask == 0ull) return;
+    ColdArgs ka = cold_args();
+    const int lane = threadIdx.x & 63;
+    const int leader = __builtin_ctzll(mask);
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(ka->a.hit_count[m], (unsigned long long)__popcll(mask));
+    base = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)(base & 0xffffffffull), leader);
+    if (hit) {
+        const unsigned long long at = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+        if (at < (unsigned long long)ka->a.hit_cap[m]) ka->a.hits[m][at] = GraphHit{tile, score, q2 | ((long long)k << kHitWinShift)};
+    }
+}
+__device__ __forceinline__ void book_score_cold(const FusedArgs &a, int m, unsigned *h, bool live, int s)      // (book_score, the spill target read at its use)
+{
+    const int d = s - a.hlo[m];
+    const bool inside = (unsigned)d < (unsigned)a.hnb[m];
+    const bool spill = live && !inside && s != a.min_val[m];
+    if (__builtin_amdgcn_ballot_w64(spill) != 0ull) {
+        if (spill) atomicAdd(&cold_args()->a.hist[m][s], 1ull);
+        live = live && !spill;
+    }
+    if (live) atomicAdd(&h[a.hoff[m] + (inside ? d : a.hnb[m])], 1u);
+}
+
 // h: the workgroup's LDS windows (all motifs); motif m's window starts at a.hoff[m], its min_val bin sits behind the window.
 // `live`: the lane holds a score.  Scores outside a partial window (rare: a window holds >= 90 % of the background mass) go to
 // the caller's histogram by global atomics -- decided for the whole wavefront first, so that the common case is one
@@ -488,14 +539,15 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
             if (!a.listing) return;
             const long long rounds = (n_walks + 63) >> 6;
             const unsigned n_chunks = (unsigned)min((long long)kHeavyMaxChunks, (rounds + kHeavyItemRounds - 1) / kHeavyItemRounds);
-            const unsigned long long got = atomicAdd(heavy_ctl, (1ull << 32) | (unsigned long long)n_chunks);
+            ColdArgs ka = cold_args();
+            const unsigned long long got = atomicAdd(ka->heavy_ctl, (1ull << 32) | (unsigned long long)n_chunks);
             const unsigned slot = (unsigned)(got >> 32), base = (unsigned)(got & 0xffffffffull);
             if (slot < (unsigned)kHeavyCap && (unsigned long long)base + n_chunks < 0xffffffffull) {
-                heavy_wins[slot] = HeavyWin{ti | (lane << kDelTileBits), i0, ns_, base, n_chunks,
+                ka->heavy_wins[slot] = HeavyWin{ti | (lane << kDelTileBits), i0, ns_, base, n_chunks,
                                             (unsigned)((rounds + n_chunks - 1) / n_chunks), n_walks, q_base, jx_, del_len_};
             } else {
-                atomicMax(overflow, 1);
-                atomicMax(plan_overflow_w, 1);
+                atomicMax(ka->overflow, 1);
+                atomicMax(ka->plan_overflow_w, 1);
             }
         };
         if constexpr (PURE) {
@@ -515,20 +567,20 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
                 i0 = t.i_lo + before;
                 ns = inside;
                 long long wlk = (p + W <= t.limit && p + W <= g.ref_len) ? (long long)prod : 0ll;
-                if (wlk > kFusedMaxWalks) { atomicMax(overflow, 1); wlk = 0; }       // refused: more than 2^40 walks
+                if (wlk > kFusedMaxWalks) { atomicMax(cold_args()->overflow, 1); wlk = 0; }       // refused: more than 2^40 walks
                 else if (wlk > kHeavyWalks) { to_heavy(wlk, 0, ns, 0, 0); wlk = 0; }  // (ns <= W <= 64: one substitution site per position)
                 walks_a = (int)wlk;
             }
         } else if (lane < n_win && !GFM_LAB_BIT(a, 4)) {
             WinInfo wi = classify_window(g, sites, p, W, t.limit, t.i_lo, t.i_hi);
-            if (wi.walks < 0) { atomicMax(overflow, 1); wi.walks = 0; }
+            if (wi.walks < 0) { atomicMax(cold_args()->overflow, 1); wi.walks = 0; }
             i0 = wi.i0;
             if (wi.simple && (wi.ns_b > 255 || wi.del_len > 0xffff)) {     // (what the window's LDS record cannot hold:
                 wi.simple = false;                                           //  the way of the other listed windows)
                 wi.walks = 0;
                 wi.walks_b = 0;
             }
-            if (wi.i0 - t.i_lo > 0xffff) { atomicMax(overflow, 1); wi.walks = 0; wi.walks_b = 0; wi.listed = wi.simple = false; }
+            if (wi.i0 - t.i_lo > 0xffff) { atomicMax(cold_args()->overflow, 1); wi.walks = 0; wi.walks_b = 0; wi.listed = wi.simple = false; }
             const bool many = wi.walks + wi.walks_b > kHeavyWalks;
             if (wi.simple && many) {
                 if (wi.ns <= 64 && wi.ns_b <= 64) {          // both layouts to graph_heavy_kernel (a lane per site record there)
@@ -607,11 +659,11 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
                     const int s_f = bad_a ? a.min_val[m] : (int)(sc_a[m] & 0xffffu);
                     const int s_r = bad_a ? a.min_val[m] : (int)(sc_a[m] >> 16);
                     if (a.hnb[m] > 0) {
-                        book_score(a, m, h, has_ref, s_f);
-                        if (!a.forward_only) book_score(a, m, h, has_ref, s_r);
+                        book_score_cold(a, m, h, has_ref, s_f);
+                        if (!a.forward_only) book_score_cold(a, m, h, has_ref, s_r);
                     }
-                    push_hits(a, m, has_ref && s_f >= a.cutoff[m], ti, lane, 0, s_f);
-                    if (!a.forward_only) push_hits(a, m, has_ref && s_r >= a.cutoff[m], ti, lane, 1, s_r);
+                    push_hits_cold(m, has_ref && s_f >= a.cutoff[m], ti, lane, 0, s_f);
+                    if (!a.forward_only) push_hits_cold(m, has_ref && s_r >= a.cutoff[m], ti, lane, 1, s_r);
                 }
             }
             rows_done += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(has_ref)) * (a.forward_only ? 1ull : 2ull);
@@ -624,10 +676,10 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
                 q_n += __popcll(lm);
                 if (q_n >= kWaveQueue - kTileWin) {
                     int base = 0;
-                    if (lane == 0) base = atomicAdd(del_count, q_n);
+                    if (lane == 0) base = atomicAdd(cold_args()->del_count, q_n);
                     base = __builtin_amdgcn_readfirstlane(base);
                     __builtin_amdgcn_wave_barrier();
-                    for (int i = lane; i < q_n; i += 64) del_wins[base + i] = wl->queue[i];
+                    { DelWin *dw = cold_args()->del_wins; for (int i = lane; i < q_n; i += 64) dw[base + i] = wl->queue[i]; }
                     q_n = 0;
                 }
             }
@@ -736,11 +788,11 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
                 const int s_f = bad ? a.min_val[m] : (int)(sum[m] & 0xffffu);
                 const int s_r = bad ? a.min_val[m] : (int)(sum[m] >> 16);
                 if (a.hnb[m] > 0) {
-                    book_score(a, m, h, live, s_f);
-                    if (!a.forward_only) book_score(a, m, h, live, s_r);
+                    book_score_cold(a, m, h, live, s_f);
+                    if (!a.forward_only) book_score_cold(a, m, h, live, s_r);
                 }
-                push_hits(a, m, live && s_f >= a.cutoff[m], ti, k, 2 * q, s_f);
-                if (!a.forward_only) push_hits(a, m, live && s_r >= a.cutoff[m], ti, k, 2 * q + 1, s_r);
+                push_hits_cold(m, live && s_f >= a.cutoff[m], ti, k, 2 * q, s_f);
+                if (!a.forward_only) push_hits_cold(m, live && s_r >= a.cutoff[m], ti, k, 2 * q + 1, s_r);
             }
         }
         rows_done += (unsigned long long)total * (a.forward_only ? 1ull : 2ull);
@@ -771,20 +823,20 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
     if (lane == 0) { blk_rows[wave] = rows_done; blk_q[wave] = q_n; }
     __syncthreads();
     if (tid == 0) {
-        if (!a.listing && blockIdx.x == 0 && *a.plan_overflow) atomicMax(overflow, 1);
+        if (!a.listing && blockIdx.x == 0 && *cold_args()->a.plan_overflow) atomicMax(cold_args()->overflow, 1);
         unsigned long long rows = 0;
         int left = 0;
         for (int k = 0; k < nw; ++k) { rows += blk_rows[k]; left += blk_q[k]; }
-        if (rows) atomicAdd(a.n_rows, rows);
-        blk_q[nw] = left ? atomicAdd(del_count, left) : 0;
+        if (rows) atomicAdd(cold_args()->a.n_rows, rows);
+        blk_q[nw] = left ? atomicAdd(cold_args()->del_count, left) : 0;
     }
     __syncthreads();
     if constexpr (LISTING && GENERAL) {
         int at = blk_q[nw];
         for (int k = 0; k < wave; ++k) at += blk_q[k];
-        for (int i = lane; i < q_n; i += 64) del_wins[at + i] = wl->queue[i];
+        { DelWin *dw = cold_args()->del_wins; for (int i = lane; i < q_n; i += 64) dw[at + i] = wl->queue[i]; }
     }
-    for (int i = tid; i < a.slab_stride; i += n_thr) a.slabs[(size_t)blockIdx.x * a.slab_stride + i] = h[i];
+    { unsigned *slabs = cold_args()->a.slabs; for (int i = tid; i < a.slab_stride; i += n_thr) slabs[(size_t)blockIdx.x * a.slab_stride + i] = h[i]; }
 }
 
 // visitor of simulate(): the bases of a walk into a k-mer slot (alternate / inserted bases at once, reference bases
