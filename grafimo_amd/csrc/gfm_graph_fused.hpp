@@ -525,8 +525,9 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         // ---- phase 1: lane per window
         auto ref_at = [&](long long x) -> unsigned {             // a reference base: from the staged bytes if it lies there
             const long long d = x - t.p0;
-            return (unsigned long long)d < (unsigned long long)kWaveRefBytes ? (unsigned)wl->ref[d]
-                                                                            : (x < g.ref_len ? (unsigned)g.ref[x] : (unsigned)'N');
+            if ((unsigned long long)d < (unsigned long long)kWaveRefBytes) return (unsigned)wl->ref[d];
+            ColdArgs ka = cold_args();                           // (a deletion longer than the staged bytes reach)
+            return x < ka->g.ref_len ? (unsigned)ka->g.ref[x] : (unsigned)'N';
         };
         const long long p = t.p0 + lane;
         bool listed = false;
@@ -802,7 +803,10 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         } else {
             if (t.n_win & kTilePure) work(LdsTileSites{wl->rec, wl->reach, t.p0, t.i_lo}, std::true_type{});
             else if (t.i_far - t.i_lo + 1 <= kWaveSites) work(LdsTileSites{wl->rec, wl->reach, t.p0, t.i_lo}, std::false_type{});
-            else work(TileSites{g, wl->rec, wl->reach, t.p0, t.i_lo, staged}, std::false_type{});
+            else {                        // (rare: more site records under the tile than are staged -- the graph's arrays, read at this use)
+                const GraphDev g_far = ((const ScoreKernArgs *)cold_args())->g;      // (as a flat pointer: the struct is copied whole)
+                work(TileSites{g_far, wl->rec, wl->reach, t.p0, t.i_lo, staged}, std::false_type{});
+            }
         }
         __builtin_amdgcn_wave_barrier();       // the tile's LDS is free again
         lap(4, tk0);                  // 12: phase 2
