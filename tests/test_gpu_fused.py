@@ -502,3 +502,30 @@ def test_a_motif_set_equals_the_oracle_on_heavy_and_one_deletion_windows(tmp_pat
             exp, _ = oracle_table(tmp_path / "oracle", "c", ref, v, regions, m, reuse_rows=True, **kw)
             assert_table_equals_oracle(got, exp, (i, kw))
     g.close()
+
+
+def test_more_region_sets_than_a_handle_keeps_plans_for(tmp_path):
+    """A graph handle keeps the plans of its 32 most recently used (regions, width) pairs; the 33rd evicts the least recently
+    used one -- whose buffers kernels of earlier calls may still be reading -- and a set that comes back is planned again:
+    forty region sets and three widths in turns, every table equal to the first answer for its (set, width), the first ones
+    again at the end."""
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
+    fasta, vcf = make_graph_files(str(tmp_path), chrom="7", length=6000, n_sites=500, n_samples=30, seed=41, rich=True)
+    idx = GraphIndex.from_fasta_vcf(fasta, vcf, "7")
+    g = DeviceGraph(idx)
+    motifs = {W: _motif_of_width(W, seed=3) for W in (12, 19, 24)}
+    sets = [np.array([[60 * k, 60 * k + 400], [3000 + 50 * k, 3000 + 50 * k + 300]], dtype=np.int64) for k in range(40)]
+    first = {}
+    order = [(k, W) for k in range(40) for W in (12, 19, 24)] + [(k, 19) for k in (0, 1, 2, 39, 0)]
+    for k, W in order:
+        df, _ = _fused(motifs[W], g, sets[k], threshold=0.01)
+        if (k, W) not in first:
+            first[(k, W)] = df
+            assert len(df) > 0
+        else:
+            _assert_same(df, first[(k, W)], f"set {k} width {W} planned again")
+    # ... and against the materialising path for a few of them
+    for k, W in ((0, 19), (17, 12), (39, 24)):
+        fused, rows = _both(motifs[W], g, sets[k], threshold=0.01)
+        _assert_same(fused, rows, f"set {k} width {W}")
+    g.close()
