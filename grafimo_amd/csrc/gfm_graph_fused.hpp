@@ -388,7 +388,18 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
     unsigned long long rows_done = 0;
     int q_n = 0;                                                   // listed windows in this wavefront's queue (uniform)
     unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0}, acc_n = 0;   // measurement aid: this wavefront's ticks per phase
+#ifdef GFM_LAB
+    unsigned ph_t[5] = {0, 0, 0, 0, 0};                             // GRAFIMO_FUSED_TIMERS=2: the current tile's ticks per phase
+#endif
     auto lap = [&](int slot, unsigned long long &t0) {
+#ifdef GFM_LAB
+        if (a.tile_log) {
+            const unsigned long long t1 = wall_clock64();
+            if (slot < 5) ph_t[slot] = (unsigned)(t1 - t0);
+            t0 = t1;
+            return;
+        }
+#endif
         if (!GFM_DBG(a)) return;
         const unsigned long long t1 = wall_clock64();
         acc_t[slot] += t1 - t0;
@@ -494,7 +505,11 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
 #ifdef GFM_LAB
         const unsigned long long tl_begin = a.tile_log ? wall_clock64() : 0ull;
 #endif
-        unsigned long long tk0 = GFM_DBG(a) ? wall_clock64() : 0ull, tk_tile = tk0;
+#ifdef GFM_LAB
+        unsigned long long tk0 = (GFM_DBG(a) || a.tile_log) ? wall_clock64() : 0ull, tk_tile = tk0;
+#else
+        unsigned long long tk0 = 0ull, tk_tile = 0ull;
+#endif
         const Tile t = t_cur;
         commit(t, pf);
         const int my_pos = pf.r0.pos, my_alts = pf.r0.n_alts;      // lane s: the tile's site s (pure tiles read them by readlane)
@@ -639,11 +654,38 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
 #pragma unroll
                 for (int m = 0; m < MM; ++m) sum[m] = 0u;
                 int bad = 0;
-                for (int j = 0; j < W; ++j) {
-                    const unsigned c = base_code(ref_at(p + j + (j > jx ? dlen : 0)));
+                if (lane + W + dlen <= kWaveRefBytes) {
+                    // the usual case -- the bases behind the deleted stretch are staged too: four bases a step, their reads in
+                    // flight together (one base a step through ref_at(), two LDS round trips each, was 4.0 of a general
+                    // tile's 10.8 us)
+                    const unsigned char *rb = wl->ref + lane;
+                    int j = 0;
+                    for (; j + 4 <= W; j += 4) {
+                        unsigned c[4];
 #pragma unroll
-                    for (int m = 0; m < MM; ++m) sum[m] += tab[m * W8 + j * 8 + c];
-                    bad += (int)(c >> 2);
+                        for (int u = 0; u < 4; ++u) c[u] = base_code(rb[j + u + (j + u > jx ? dlen : 0)]);
+#pragma unroll
+                        for (int m = 0; m < MM; ++m) {
+                            unsigned v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = tab[m * W8 + (j + u) * 8 + c[u]];
+                            sum[m] += (v[0] + v[1]) + (v[2] + v[3]);
+                        }
+                        bad += (int)((c[0] >> 2) + (c[1] >> 2) + (c[2] >> 2) + (c[3] >> 2));
+                    }
+                    for (; j < W; ++j) {
+                        const unsigned c = base_code(rb[j + (j > jx ? dlen : 0)]);
+#pragma unroll
+                        for (int m = 0; m < MM; ++m) sum[m] += tab[m * W8 + j * 8 + c];
+                        bad += (int)(c >> 2);
+                    }
+                } else {
+                    for (int j = 0; j < W; ++j) {
+                        const unsigned c = base_code(ref_at(p + j + (j > jx ? dlen : 0)));
+#pragma unroll
+                        for (int m = 0; m < MM; ++m) sum[m] += tab[m * W8 + j * 8 + c];
+                        bad += (int)(c >> 2);
+                    }
                 }
 #pragma unroll
                 for (int m = 0; m < MM; ++m) wl->score_b[m][lane] = sum[m];
@@ -812,8 +854,12 @@ graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int 
         lap(4, tk0);                  // 12: phase 2
         lap(5, tk_tile);                       // 13: the whole tile
 #ifdef GFM_LAB
-        if (a.tile_log && lane == 0 && !a.listing)      // per tile: its ticks, and when it began (since the workgroup's loop began)
+        if (a.tile_log && lane == 0 && !a.listing) {    // per tile: its ticks, and when it began (since the workgroup's loop began)
             a.tile_log[ti] = (((wall_clock64() - tl_begin) & 0xffffffull) << 40) | (((tl_begin - dbg_t0) & 0xffffffull) << 16) | (blockIdx.x & 0xffffu);
+            unsigned long long w = 0;                   // ... and its five phases, 12 bits each (10-ns ticks)
+            for (int k = 0; k < 5; ++k) w |= (unsigned long long)min(ph_t[k], 4095u) << (12 * k);
+            a.tile_log[n_tiles + ti] = w;
+        }
 #endif
         ++acc_n;
     }

@@ -2237,8 +2237,8 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
     a.dbg = nullptr;
     a.tile_log = nullptr;
     if (timers || tile_log) {
-        GX_TRY(g->f_dbg.reserve(64 + (size_t)P->f_n_tiles));
-        GX_TRY(hipMemsetAsync(g->f_dbg.p, 0, (64 + (size_t)P->f_n_tiles) * sizeof(unsigned long long), st));
+        GX_TRY(g->f_dbg.reserve(64 + 2 * (size_t)P->f_n_tiles));
+        GX_TRY(hipMemsetAsync(g->f_dbg.p, 0, (64 + 2 * (size_t)P->f_n_tiles) * sizeof(unsigned long long), st));
         if (timers) a.dbg = g->f_dbg.p;
         else a.tile_log = g->f_dbg.p + 64;
     }
@@ -2265,9 +2265,10 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
     if (tile_log) {
         GX_TRY(hipStreamSynchronize(st));
         if (!listing && P->f_n_tiles > 0) {       // per tile: duration and start (relative to its wavefront's first tile), with the tile's record
-            std::vector<unsigned long long> tt((size_t)P->f_n_tiles);
+            std::vector<unsigned long long> tt((size_t)P->f_n_tiles), tp((size_t)P->f_n_tiles);
             std::vector<Tile> tl((size_t)P->f_n_tiles);
             GX_TRY(hipMemcpy(tt.data(), g->f_dbg.p + 64, tt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            GX_TRY(hipMemcpy(tp.data(), g->f_dbg.p + 64 + tt.size(), tp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             GX_TRY(hipMemcpy(tl.data(), P->f_tiles.p, tl.size() * sizeof(Tile), hipMemcpyDeviceToHost));
             std::vector<int> order(tt.size());
             for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
@@ -2295,6 +2296,17 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
             std::sort(ends.begin(), ends.end());
             std::fprintf(stderr, "[fused] pure tiles %zu: mean %.2f us; general tiles %zu: mean %.2f us; wave-time in tiles %.0f us\n", n_p,
                          n_p ? sum_p / (double)n_p : 0.0, n_g, n_g ? sum_g / (double)n_g : 0.0, sum_p + sum_g);
+            {   // phases per kind of tile: staging -> LDS | classify | base scores | reference walks + scan | phase 2
+                double ps[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+                for (size_t i = 0; i < tp.size(); ++i)
+                    for (int k = 0; k < 5; ++k) ps[(tl[i].n_win & kTilePure) ? 0 : 1][k] += 0.01 * (double)((tp[i] >> (12 * k)) & 0xfffull);
+                for (int kind = 0; kind < 2; ++kind) {
+                    const double n = (double)(kind ? n_g : n_p);
+                    if (n > 0)
+                        std::fprintf(stderr, "[fused] %s tiles, mean us per phase: commit %.2f, classify %.2f, base scores %.2f, reference walks + scan %.2f, phase 2 %.2f\n",
+                                     kind ? "general" : "pure", ps[kind][0] / n, ps[kind][1] / n, ps[kind][2] / n, ps[kind][3] / n, ps[kind][4] / n);
+                }
+            }
             std::fprintf(stderr, "[fused] tile END times: p10 %.1f, p50 %.1f, p90 %.1f, p99 %.1f, max %.1f us\n", ends[ends.size() / 10],
                          ends[ends.size() / 2], ends[ends.size() * 9 / 10], ends[ends.size() * 99 / 100], ends.back());
             {
