@@ -17,6 +17,7 @@ complex alleles are taken apart into substitutions and one indel; records with a
 counted in `GraphIndex.skipped`, as `vg construct` without --handle-sv (constructVG.py:332) leaves them out.
 There is no CPU fallback: extraction needs libgrafimo_hip.so and a GPU.
 """
+import contextlib
 import ctypes
 import gzip
 import os
@@ -848,7 +849,9 @@ def graph_index_file(xg: str, chrom: str, whole_genome: bool, debug: bool = Fals
     for f in beside:
         if os.path.isfile(f):
             return f
-    gbwt = xg.replace("xg", "gbwt")                    # (the reference's own rule, extract_regions.py:174,219)
+    gbwt = xg.replace("xg", "gbwt")                    # (the reference's own rule, extract_regions.py:174,219: EVERY "xg" of the path)
+    if not os.path.isfile(gbwt) and xg.endswith(".xg") and os.path.isfile(xg[:-2] + "gbwt"):
+        gbwt = xg[:-2] + "gbwt"                        # (a directory called .../xg_graphs/: the file beside the XG is meant)
     for f in (xg, gbwt):
         if not os.path.isfile(f):
             exception_handler(VGError, f"Unable to locate {f}. Are your VGs named with \"chr\"? Consider using "
@@ -869,13 +872,14 @@ def graph_index_file(xg: str, chrom: str, whole_genome: bool, debug: bool = Fals
         print(f"Read {xg} + {os.path.basename(gbwt)}: {len(index.ref)} bases, {len(index.pos)} sites, "
               f"{index.n_haplotypes} haplotypes in %.2fs.\n" % (time.time() - t0))
     for target in (beside[0], cached):
+        tmp = target + f".{os.getpid()}.tmp" + INDEX_SUFFIX
         try:
-            tmp = target + f".{os.getpid()}.tmp" + INDEX_SUFFIX
             index.save(tmp)
             os.replace(tmp, target)
             return target
         except OSError:
-            continue
+            with contextlib.suppress(OSError):
+                os.remove(tmp)
     exception_handler(VGError, f"Unable to save the graph index of {xg} (tried {beside[0]} and {cached}).\n", debug)
 
 
