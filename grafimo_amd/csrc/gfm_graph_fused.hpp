@@ -367,6 +367,8 @@ __host__ __device__ constexpr int fused_tab_dwords(int MM, int W) { return (MM *
 // Two instantiations share the tiles of a call: GENERAL = false takes the PURE tiles (substitution sites only: four in five) with
 // none of the insertion / deletion machinery compiled in -- fewer registers, more wavefronts per SIMD -- and GENERAL = true the
 // rest; the host sorts the tile table into the two ranges [tile_begin, n_tiles).
+// (The parameter list and ScoreKernArgs above are ONE layout: a parameter added, removed or moved here is added, removed or moved
+// there -- the kernel reads its cold arguments through that struct; every one of them is exercised by tests/test_gpu_fused.py.)
 template <int MM, bool LISTING, bool GENERAL>
 __global__ void __launch_bounds__(kFusedMaxWaves * 64, LISTING ? 1 : GFM_GRAPH_SCORE_MIN_WAVES)
 graph_score_kernel(GraphDev g, FusedArgs a, const Tile *__restrict__ tiles, int tile_begin, int n_tiles,
