@@ -823,6 +823,8 @@ def read_bed_regions(bedfile: str, debug: bool = False) -> Dict[str, List[Tuple[
 
 
 def _index_path(xg: str) -> str:
+    if xg.endswith(INDEX_SUFFIX):          # (the saved index itself given where the reference takes an XG)
+        return xg
     return xg[:-3] + INDEX_SUFFIX if xg.endswith(".xg") else xg + INDEX_SUFFIX
 
 
