@@ -577,8 +577,9 @@ class DeviceGraph:
     # ---- extraction fused into scoring (gfm_graph_score[_multi] / gfm_graph_annotate)
     def fused_buffers(self, cap: int, slot: int = 0):
         """One int64 tensor per graph and SLOT (a slot per motif that shares a scoring pass), kept between calls:
-        [16 control words | cap entries of 2 words | cap records of 15 words].  Control: [0] hit count; in the first slot of a
-        call also [1] rows scored (per motif), [2] overflow flag (int32).  All slots have one capacity."""
+        [16 control words | cap records of 15 words | cap entries of 2 words] -- the records right behind the control words:
+        fused_results fetches both with ONE copy.  Control: [0] hit count; in the first slot of a call also [1] rows scored
+        (per motif), [2] overflow flag (int32).  All slots have one capacity."""
         torch = _torch()
         bufs = self.__dict__.setdefault("_fused_bufs", {})
         if getattr(self, "_fused_cap", 0) < cap:
@@ -609,7 +610,7 @@ class DeviceGraph:
         handles = (vp * M)(*[d.handle for d in dms])
         cuts = (ctypes.c_int32 * M)(*[int(c) for c in cutoffs])
         hist_p = (vp * M)(*[(h.data_ptr() if h is not None else None) for h in (hists if hists is not None else [None] * M)])
-        hits_p = (vp * M)(*[b_.data_ptr() + 128 for b_ in bufs])
+        hits_p = (vp * M)(*[b_.data_ptr() + 128 + 120 * cap for b_ in bufs])        # (entries: behind the records)
         caps = (ctypes.c_int64 * M)(*([cap] * M))
         cnt_p = (vp * M)(*[b_.data_ptr() for b_ in bufs])
         base0 = bufs[0].data_ptr()
@@ -631,20 +632,25 @@ class DeviceGraph:
         int32 [1] or None)."""
         buf, cap = self.fused_buffers(0, slot)
         base = buf.data_ptr()
-        nv.check(nv.lib().gfm_graph_annotate(self._h, base + 128, base, cap, cutoff.data_ptr() if cutoff is not None else None,
-                                             qtable.data_ptr() if qtable is not None else None, base + 128 + 16 * cap,
+        nv.check(nv.lib().gfm_graph_annotate(self._h, base + 128 + 120 * cap, base, cap, cutoff.data_ptr() if cutoff is not None else None,
+                                             qtable.data_ptr() if qtable is not None else None, base + 128,
                                              _stream_ptr(stream)))
 
     def fused_results(self, guess: int = 1024, slot: int = 0):
         """(hit count, rows scored, overflow flag, records as a numpy structured array) of the last score() + annotate() of
         `slot`; synchronises."""
         buf, cap = self.fused_buffers(0, slot)
-        ctl = buf[:16].cpu().numpy()
+        g_ = min(int(guess), cap)
+        head = buf[:16 + 15 * g_].cpu().numpy()          # the control words and the first `guess` records: one copy, one wait
+        ctl = head[:16]
         first = self.__dict__.get("_fused_ctl", {}).get(slot, slot)
         ctl0 = ctl if first == slot else self.fused_buffers(0, first)[0][:16].cpu().numpy()
         count, n_rows, over = int(ctl[0]), int(ctl0[1]), int(ctl0[2] & 0xffffffff)
         k = min(count, cap)
-        recs = buf[16 + 2 * cap:16 + 2 * cap + 15 * k].cpu().numpy().view(HIT_DTYPE) if k else np.empty(0, dtype=HIT_DTYPE)
+        if k <= g_:
+            recs = head[16:16 + 15 * k].view(HIT_DTYPE) if k else np.empty(0, dtype=HIT_DTYPE)
+        else:
+            recs = buf[16:16 + 15 * k].cpu().numpy().view(HIT_DTYPE)
         return count, n_rows, over, recs
 
     def extract(self, regions: Sequence[Tuple[int, int]], width: int, stream=None) -> ExtractedKmers:
