@@ -1251,6 +1251,7 @@ def _fused_tables(motifs, graph, regions, debug, args_obj, group, always_collect
         if works is not None and M > 1 and collective:
             hist_all = torch.zeros((M, L), dtype=torch.int64, device=dev)
         cap = max(getattr(g, "_fused_cap", 0) for g in graphs) or (1 << 14)
+        sp = _stream_ptr(None)                   # (torch's current stream, asked for once: 15 us a question)
         while True:
             hists = qtables = d_cuts = [None] * M
             if works is not None:
@@ -1266,19 +1267,19 @@ def _fused_tables(motifs, graph, regions, debug, args_obj, group, always_collect
                 sl = list(range(c0, min(M, c0 + FUSED_GROUP)))
                 for g, (s_, e_) in zip(graphs, spans):
                     g.score_many([dms[m] for m in sl], s_, e_, [cuts_p[m] for m in sl], [hists[m] for m in sl],
-                                 forward_only=no_reverse, cap=cap, slots=sl)
+                                 forward_only=no_reverse, cap=cap, slots=sl, stream=sp)
             if collective and works is not None:
                 # the one data-path exchange: BH ranks are global
                 dist.all_reduce(hist_all if hist_all is not None else hists[0], group=group)
             if works is not None:
                 if M == 1:
-                    dms[0].qvalue_table(hists[0], threshold, qval_t, qtables[0], d_cuts[0], None)
+                    dms[0].qvalue_table(hists[0], threshold, qval_t, qtables[0], d_cuts[0], None, stream=sp)
                 else:
                     from .device import qvalue_table_multi
-                    qvalue_table_multi(dms, hists, threshold, qval_t, qtables, d_cuts)
+                    qvalue_table_multi(dms, hists, threshold, qval_t, qtables, d_cuts, stream=sp)
             for g in graphs:
                 for m in range(M):
-                    g.annotate(cutoff=d_cuts[m] if qval_t else None, qtable=qtables[m], slot=m)
+                    g.annotate(cutoff=d_cuts[m] if qval_t else None, qtable=qtables[m], stream=sp, slot=m)
             got = [[g.fused_results(slot=m) for g in graphs] for m in range(M)]
             # a hit list that turned out too short is taken again at the size the counters ask for -- on EVERY rank or
             # on none: the scoring pass holds a collective (a rank-local retry would leave the ranks' all-reduce
