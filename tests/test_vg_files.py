@@ -461,3 +461,44 @@ def test_damaged_files_are_refused_or_read_never_anything_else(tmp_path):
     assert outcomes["refused"] > 100 and outcomes["same"] > 20, outcomes
     # (an "other index" is a flip inside the data itself -- a base, a haplotype's edge -- that leaves a well-formed file)
     assert outcomes["other index"] < outcomes["refused"], outcomes
+
+
+def test_scan_graph_on_a_whole_genome_xg(tmp_path, monkeypatch, capsys):
+    """`-g genome.xg` (extract_regions.py:184-226): one XG with a path per chromosome and ONE GBWT over all of them; scan_graph
+    makes one index per chromosome asked for (genome.<chrom>.gfmidx.npz: the path's component, its own haplotypes)"""
+    import vg_encode
+    from grafimo_amd import extract_regions as xr
+    from grafimo_amd.extract_regions import GraphIndex
+    from grafimo_amd.workflow import Findmotif
+    parts, nodes, edges, paths, walks_all, shift = {}, {}, [], {}, [], 0
+    for name, seed in (("1", 51), ("2", 52)):
+        fasta, vcf = make_consistent_graph_files(str(tmp_path), chrom=name, length=300, n_samples=6, seed=seed, kinds="sid")
+        idx = GraphIndex.from_fasta_vcf(fasta, vcf, name)
+        parts[name] = idx
+        ids, seqs, ef, et, steps, walks = graph_of_index(idx)
+        nodes.update({int(i) + shift: s for i, s in zip(ids.tolist(), seqs)})
+        edges += [(int(ids[a]) + shift, int(ids[b]) + shift) for a, b in zip(ef.tolist(), et.tolist())]
+        paths[name] = [int(i) + shift for i in ids[steps].tolist()]
+        walks_all += [[n + shift for n in w] for w in walks]
+        shift += int(ids.max())
+    (tmp_path / "genome.xg").write_bytes(vg_encode.xg_bytes(nodes, edges, paths, junk=bytes(300)))
+    (tmp_path / "genome.gbwt").write_bytes(vg_encode.gbwt_bytes(walks_all))
+    bed = tmp_path / "r.bed"
+    bed.write_text("chr1\t10\t120\nchr2\t0\t90\nchr2\t100\t250\n")
+    monkeypatch.setenv("GRAFIMO_SCAN_OUTPUT", "manifest")
+    monkeypatch.setenv("GRAFIMO_INDEX_CACHE", str(tmp_path / "cache"))
+    loc = xr.scan_graph({12}, Findmotif(graph_genome=str(tmp_path / "genome.xg"), bedfile=str(bed)), True)
+    man = json.load(open(os.path.join(loc, xr.MANIFEST_NAME)))
+    shutil.rmtree(loc)
+    assert [(os.path.basename(e["index"]), e["chrom"], e["regions"]) for e in man["entries"]] == \
+        [("genome.1.gfmidx.npz", "1", [[10, 120]]), ("genome.2.gfmidx.npz", "2", [[0, 90], [100, 250]])]
+    for e in man["entries"]:
+        got = GraphIndex.load(e["index"])
+        assert got.n_haplotypes == 12 and np.array_equal(got.ref, parts[e["chrom"]].ref) and _sites(got) == _sites(parts[e["chrom"]])
+    # one chromosome only, and a chromosome the genome does not hold
+    loc = xr.scan_graph({12}, Findmotif(graph_genome=str(tmp_path / "genome.xg"), bedfile=str(bed), chroms=["2"]), True)
+    assert [e["chrom"] for e in json.load(open(os.path.join(loc, xr.MANIFEST_NAME)))["entries"]] == ["2"]
+    shutil.rmtree(loc)
+    bed.write_text("chr1\t10\t120\nchr7\t0\t90\n")
+    with pytest.raises(Exception, match="no path named '7'"):
+        xr.scan_graph({12}, Findmotif(graph_genome=str(tmp_path / "genome.xg"), bedfile=str(bed)), True)
