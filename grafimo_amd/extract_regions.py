@@ -172,6 +172,14 @@ class GraphIndex:
         return cls(chrom, ref, pos, n_alts, alt_bases, bits, int(H.value), int(skipped.value), del_len=del_len,
                    ins_len=ins_len, ins_off=ins_off, ins_bases=ins_bases)
 
+    @classmethod
+    def from_vg(cls, xg: str, gbwt: Optional[str] = None, chrom: Optional[str] = None, path_name: Optional[str] = None) -> "GraphIndex":
+        """The same index from vg's own files: the XG (`vg index -x`) and the GBWT beside it (`vg index -G`) that the
+        reference hands to `vg find -x XG -H GBWT` (extract_regions.py:172-180) -- grafimo_amd/vg_files.py (XG version 15,
+        GBWT version 4: what the reference repository ships; pinned by its tutorial files)."""
+        from . import vg_files
+        return vg_files.index_from_vg(xg, gbwt, chrom=chrom, path_name=path_name)
+
     # ---- on disk (what a `buildvg` step leaves for scan_graph; numpy .npz, no pickles)
     def save(self, path: str) -> str:
         if not path.endswith(INDEX_SUFFIX):

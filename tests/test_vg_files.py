@@ -50,7 +50,7 @@ def vg_graphs():
 def test_index_from_vgs_files_equals_index_from_fasta_and_vcf(c, capfd):
     from grafimo_amd import vg_files
     from grafimo_amd.extract_regions import GraphIndex
-    got = vg_files.index_from_vg(os.path.join(MYGENOME, f"{c}.xg"), os.path.join(MYGENOME, f"{c}.gbwt"), c)
+    got = GraphIndex.from_vg(os.path.join(MYGENOME, f"{c}.xg"), os.path.join(MYGENOME, f"{c}.gbwt"), c)
     want = GraphIndex.from_fasta_vcf(os.path.join(REF_DATA, "xy.fa"), os.path.join(REF_DATA, "xy2.vcf.gz"), c)
     _same_index(got, want, c)
     assert got.chrom == c and got.skipped == 0 and len(got.pos) == 19 and got.n_haplotypes == 2
