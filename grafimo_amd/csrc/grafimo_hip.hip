@@ -220,14 +220,16 @@ int dispatch_quad(int W, int mm, gfm_motif *timer, const uint8_t *d_kmers, long 
 // line): 2e7 rows (80 MB of scores) nt 85.7-89.2 us, plain 84.4-86.6, sc1 82.4-83.4, sc0 sc1 82.1-83.1;
 // 1.25e8 rows (500 MB) nt 560 us, plain 575-619, sc1 600, sc0 sc1 600.  Write-through stores leave their lines
 // in the 256 MB Infinity Cache, which pays while a launch's scores fit it next to the k-mer stream and costs
-// once they do not.  GRAFIMO_STORE_POLICY=through|stream overrides the choice (measurement aid).
+// once they do not.  (Lab builds: GRAFIMO_STORE_POLICY=through|stream overrides the choice.)
 constexpr long long kStoreThroughMaxBytes = 96ll << 20;   // crossover between 76 and 114 MiB (scripts/size_sweep.py)
 int score_store_through(long long n, int mm)
 {
+#ifdef GFM_LAB      // lab builds only (scripts/lab_build.sh -DGFM_LAB): the product reads no timing knob
     if (const char *e = std::getenv("GRAFIMO_STORE_POLICY")) {
         if (!std::strcmp(e, "through")) return 1;
         if (!std::strcmp(e, "stream")) return 0;
     }
+#endif
     return n * 4ll * mm <= kStoreThroughMaxBytes ? 1 : 0;
 }
 
@@ -416,7 +418,11 @@ extern "C" __attribute__((visibility("hidden"))) int gfm_motif_view_(gfm_motif_t
     gfm_motif::Window w = best_window(m, std::max(1, std::min(max_bins, m->nb)));
     if (small_bins > 0 && small_bins < w.bins) {
         const gfm_motif::Window ws = best_window(m, small_bins);
-        static const double need = [] { const char *e = std::getenv("GRAFIMO_FUSED_SMALL_MASS"); return e ? atof(e) : 0.9; }();   // (measurement aid)
+#ifdef GFM_LAB
+        static const double need = [] { const char *e = std::getenv("GRAFIMO_FUSED_SMALL_MASS"); return e ? atof(e) : 0.9; }();
+#else
+        constexpr double need = 0.9;
+#endif
         if (ws.mass >= need) w = ws;
     }
     *sm = m->sm.data();
@@ -707,13 +713,15 @@ GFM_API int gfm_motif_create(const int64_t *sm, int W, const double *bg, int min
             m->q_waves = kWavesPerWG / 2;
             m->hnb = (int)std::min<long long>(m->nb, room8);
         }
-        if (const char *e = std::getenv("GRAFIMO_SCORE_WAVES")) {   // measurement aid: force 8 or 16 waves
+#ifdef GFM_LAB
+        if (const char *e = std::getenv("GRAFIMO_SCORE_WAVES")) {   // force 8 or 16 waves
             const int wv = atoi(e);
             if (wv == 8 || (wv == 16 && room16 >= 256)) {
                 m->q_waves = wv;
                 m->hnb = (int)std::min<long long>(m->nb, wv == 8 ? room8 : room16);
             }
         }
+#endif
         m->hlo = best_window(m, m->hnb).lo;   // partial when the range does not fit: the rest spills
         m->lds_bytes = quad_fixed_lds(W, m->q_waves) + sizeof(unsigned) * (size_t)(m->hnb + 1);
     }
@@ -830,10 +838,12 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
             const long long cap = (nchunks + per_turn - 1) / per_turn * per_turn;
             if (best_cap < 0 || cap < best_cap) { best_cap = cap; nslabs = g; }
         }
-        if (const char *e = std::getenv("GRAFIMO_SCORE_GRID")) {   // measurement aid: force the grid size
+#ifdef GFM_LAB
+        if (const char *e = std::getenv("GRAFIMO_SCORE_GRID")) {   // force the grid size
             const int g = atoi(e);
             if (g >= 1 && g <= m->max_slabs) nslabs = g;
         }
+#endif
     }
 
     const unsigned k = m->call_no++;

@@ -1666,7 +1666,11 @@ GFM_API int gfm_graph_emit(gfm_graph_t g, uint8_t *d_kmers, int64_t *d_start, in
                           ((reinterpret_cast<uintptr_t>(d_strand) | reinterpret_cast<uintptr_t>(d_is_ref)) & 1u) == 0;
     // measurement aid: GRAFIMO_EXTRACT_SERIAL=1 runs the two emit kernels one after the other on the caller's stream,
     // so that a kernel trace shows what each takes alone
+#ifdef GFM_LAB
     static const bool serial = [] { const char *e = std::getenv("GRAFIMO_EXTRACT_SERIAL"); return e && *e == '1'; }();
+#else
+    constexpr bool serial = false;
+#endif
     const CountJobs jobs = g->jobs;
     if (jobs.counters) GX_TRY(hipMemsetAsync(jobs.counters, 0, 4 * sizeof(int), st));
     // The deletion walks' chain -- kernel, its count jobs, the scatter of its staged rows -- stays on the caller's stream;
@@ -1866,7 +1870,11 @@ Shape pick_shape(int vgprs, size_t lds_fixed, size_t lds_per_wave)
     const int by_regs = std::max(1, std::min(8, 512 / std::max(8, alloc))) * 4;      // wavefronts per CU the registers allow
     Shape best{};
     int best_waves = 0;
-    static const int force = [] { const char *e = std::getenv("GRAFIMO_FUSED_WAVES"); return e ? atoi(e) : 0; }();   // measurement aid
+#ifdef GFM_LAB
+    static const int force = [] { const char *e = std::getenv("GRAFIMO_FUSED_WAVES"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int force = 0;
+#endif
     for (int per_cu = 2; per_cu >= 1; --per_cu)
         for (int waves = kFusedMaxWaves; waves >= 4; waves -= 4) {     // whole rounds of the four SIMDs: a workgroup of ten wavefronts
                                                                         // loads them 3, 3, 2, 2 and two such do not fit where 2 x 10 / 4 would (82.9 against 60.8 us)
@@ -1909,7 +1917,11 @@ template <int MM> int launch_fused(FusedLaunch &L)
     // ---- graph_score_kernel, twice: over the tiles that may hold insertions / deletions, then -- its lean instantiation -- over
     // the pure ones (the host sorted the table into the two ranges)
     struct Part { int begin, end, grid; Shape sh; size_t lds; } part[2];
+#ifdef GFM_LAB
     static const int split = [] { const char *e = std::getenv("GRAFIMO_FUSED_SPLIT"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int split = 0;
+#endif
     for (int general = 1; general >= 0; --general) {
         KernelInfo &ks = FK::score[L.listing ? 1 : 0][general];
         const void *fn = L.listing ? (general ? reinterpret_cast<const void *>(graph_score_kernel<MM, true, true>)
@@ -1962,7 +1974,11 @@ template <int MM> int launch_fused(FusedLaunch &L)
                            pitch);
         return GFM_OK;
     };
-    static const bool serial = [] { const char *e = std::getenv("GRAFIMO_FUSED_BESIDE"); return !(e && *e == '1'); }();   // measurement aid: '1' = beside
+#ifdef GFM_LAB
+    static const bool serial = [] { const char *e = std::getenv("GRAFIMO_FUSED_BESIDE"); return !(e && *e == '1'); }();   // '1' = beside
+#else
+    constexpr bool serial = true;
+#endif
     if (!P->items_known && P->items_asked) {
         if (hipEventQuery(P->ev_items) == hipSuccess) P->items_known = true;
         else (void)hipGetLastError();          // ("not ready" is no error of this call)

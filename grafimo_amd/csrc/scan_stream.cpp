@@ -50,6 +50,19 @@
 using gfm_tsv_detail::FileCols;
 
 namespace {
+// Phase times to stderr: lab builds only (scripts/lab_build.sh -DGFM_LAB); the product reads no timing knob.
+inline bool scan_trace_on()
+{
+#ifdef GFM_LAB
+    static const bool on = std::getenv("GRAFIMO_SCAN_TRACE") != nullptr;
+    return on;
+#else
+    return false;
+#endif
+}
+}   // namespace
+
+namespace {
 
 int sfail(int code, const std::string &msg)
 {
@@ -423,7 +436,7 @@ int fetch_hit_columns(gfm_scan *sc)
         }
     }
     if (jobs.empty()) return GFM_OK;
-    const bool trace = std::getenv("GRAFIMO_SCAN_TRACE") != nullptr;
+    const bool trace = scan_trace_on();
     const double t_jobs = trace ? now_s() : 0.0;
     std::atomic<int64_t> cpu_offsets{0}, cpu_lines{0};
     auto tcpu = []() -> int64_t {
@@ -641,7 +654,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
     sc->kept.assign((size_t)n_paths, gfm_scan::Kept());
     const double t_begin = now_s();
     sc->t_begin = t_begin;
-    const bool trace = std::getenv("GRAFIMO_SCAN_TRACE") != nullptr;   // development aid: phase times to stderr
+    const bool trace = scan_trace_on();   // development aid: phase times to stderr
     auto stamp = [&](const char *what) {
         if (trace) std::fprintf(stderr, "[scan] %8.3f ms  %s\n", (now_s() - t_begin) * 1e3, what);
     };
@@ -1148,7 +1161,7 @@ GFM_API int gfm_scan_tsv_finish(gfm_scan_t sc, int64_t *n_hits)
     const size_t M = sc->motifs.size();
     const int L = sc->L;
     const double t0 = now_s();
-    const bool trace = std::getenv("GRAFIMO_SCAN_TRACE") != nullptr;
+    const bool trace = scan_trace_on();
     auto proc_cpu = []() {
         timespec ts{};
         clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);

@@ -277,9 +277,11 @@ int gfm_tsv_detail::pick_threads(const char *const *paths, int n_paths, int requ
     bytes = bytes / (unsigned long long)sampled * (unsigned long long)n_paths;
     const unsigned long long by_size = bytes >> 20;
     if ((unsigned long long)nt > by_size) nt = (int)(by_size < 1 ? 1 : by_size);
-    if (const char *e = std::getenv("GRAFIMO_PARSE_THREADS_EXACT")) {   // measurement aid: no caps at all
+#ifdef GFM_LAB
+    if (const char *e = std::getenv("GRAFIMO_PARSE_THREADS_EXACT")) {   // no caps at all
         if (*e == '1') return nt;
     }
+#endif
     if (nt > kMaxParseThreads) nt = kMaxParseThreads;
     // Big inputs under a CPU quota.  On the GPU boxes (256 hardware threads, quota 16 = 1.6 CPU-seconds per 100 ms) a
     // scan whose CPU time exceeds one period's allowance is frozen as a whole until the period ends, the sooner the more

@@ -430,7 +430,9 @@ def test_lab_switches_are_not_in_the_product(tmp_path, monkeypatch):
     import sys
     from grafimo_amd import _native as nv
     blob = open(nv.LIB_PATH, "rb").read()
-    assert b"GRAFIMO_FUSED_LAB" not in blob and b"GRAFIMO_FUSED_TIMERS" not in blob
+    from test_host_logic import LAB_ONLY_KNOBS
+    for name in LAB_ONLY_KNOBS:
+        assert name not in blob, name
     code = (
         "import sys, contextlib, io; sys.path[:0] = [%r, %r]\n"
         "from test_gpu_fused import _ctcf, _fused\n"

@@ -34,12 +34,28 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert nv.device_count() >= 0
 
 
+# timing-only switches: compiled with -DGFM_LAB alone
+LAB_ONLY_KNOBS = (b"GRAFIMO_FUSED_LAB", b"GRAFIMO_FUSED_TIMERS", b"GRAFIMO_FUSED_SPLIT", b"GRAFIMO_FUSED_BESIDE",
+                  b"GRAFIMO_FUSED_SMALL_MASS", b"GRAFIMO_FUSED_WAVES", b"GRAFIMO_SCORE_GRID", b"GRAFIMO_SCORE_WAVES",
+                  b"GRAFIMO_STORE_POLICY", b"GRAFIMO_EXTRACT_SERIAL", b"GRAFIMO_PARSE_THREADS_EXACT", b"GRAFIMO_SCAN_TRACE")
+# what libgrafimo_hip.so reads: product settings, then test aids (they pick a code path, never a result)
+PRODUCT_KNOBS = ("GRAFIMO_RESERVE_CUS", "GRAFIMO_SCAN_KEEP_BYTES",
+                 "GRAFIMO_PLAN_MAX_WALKS", "GRAFIMO_EXTRACT_DEL_POOL", "GRAFIMO_SCAN_TEXT_BYTES", "GRAFIMO_SCAN_NO_AVX512")
+
+
 def test_product_library_holds_no_lab_switch():
     """the switches that turn parts of graph_score_kernel off (results wrong) and the kernels' phase timers
     exist in lab builds only (scripts/lab_build.sh -DGFM_LAB): the product library does not even contain their names."""
     blob = open(nv.LIB_PATH, "rb").read()
-    for name in (b"GRAFIMO_FUSED_LAB", b"GRAFIMO_FUSED_TIMERS"):
+    for name in LAB_ONLY_KNOBS:
         assert name not in blob, name
+    # ... and every variable the product library does read is one INTEGRATION.md lists (settings and test aids)
+    import re
+    read = set(re.findall(rb"GRAFIMO_[A-Z0-9_]+", blob))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert read == {k.encode() for k in PRODUCT_KNOBS}, sorted(read ^ {k.encode() for k in PRODUCT_KNOBS})
+    for k in PRODUCT_KNOBS:
+        assert k in doc, k + " is read by the library and not documented in INTEGRATION.md"
     src = open(os.path.join(ROOT, "grafimo_amd", "csrc", "graph_extract.hip")).read()
     at = src.index('getenv("GRAFIMO_FUSED_LAB")')
     assert "#ifdef GFM_LAB" in src[max(0, at - 1200):at] and "#endif" in src[at:at + 400]
