@@ -206,14 +206,21 @@ def main(argv=None):
         # and every motif is scored where its walks are enumerated
         from .extract_regions import scan_graph
         sequences_loc = scan_graph({int(m.width) for m in motifs}, wf, a.debug)
-    shared = None if from_graph or from_vg or len(motifs) < 2 else compute_results_many(motifs, a.sequences, a.debug, wf)
+    # a motif set is scored in ONE call: per width one ingest / one enumeration of the walks, up to three motifs per pass
+    shared = None
+    if len(motifs) >= 2:
+        if from_graph:
+            from .extract_regions import compute_results_from_graph_many
+            shared = compute_results_from_graph_many(motifs, graphs, region_lists, a.debug, wf)
+        else:
+            shared = compute_results_many(motifs, sequences_loc if from_vg else a.sequences, a.debug, wf)
     for k, motif in enumerate(motifs):
-        if from_vg:
+        if shared is not None:
+            res = shared[k]
+        elif from_vg:
             res = compute_results(motif, sequences_loc, a.debug, wf)
         elif from_graph:
             res = compute_results_from_graph(motif, graphs, region_lists, a.debug, wf)
-        elif shared is not None:
-            res = shared[k]              # one ingest / upload per width, batched launches
         else:
             res = compute_results(motif, a.sequences, a.debug, wf)
         if a.text_only:

@@ -29,7 +29,9 @@ GFM_MAX_WIDTH = 64
 GFM_BEST_ROW_BITS = 44
 GFM_GRAPH_FORWARD_ONLY = 1
 GFM_TSV_NO_NODEPATH = 1
-ABI_VERSION = 10
+GFM_HITS_DROP_ZERO_FREQ = 1
+GFM_HITS_FIRST_PER_REGION = 2
+ABI_VERSION = 11
 RANGE = 1000
 
 c_int = ctypes.c_int
@@ -115,6 +117,9 @@ PROTOTYPES = {
     "gfm_graph_profile_enable": (c_int, [c_void_p, c_int]),
     "gfm_graph_profile_read": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
     "gfm_graph_annotate": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gfm_graph_hit_columns": (c_int, [c_void_p, c_i32, c_i32, ctypes.c_double, c_i32, c_i32, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, ctypes.c_uint32, P(c_i64)] + [c_void_p] * 10),
+    "gfm_region_labels": (c_i64, [ctypes.c_char_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64]),
     "gfm_vcf_open": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_int, c_int, P(c_void_p), P(c_i64), P(c_i32),
                              P(c_i64)]),
     "gfm_vcf_read": (c_int, [c_void_p] * 6),

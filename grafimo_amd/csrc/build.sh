@@ -25,8 +25,9 @@ cc -c "$here/vcf_ingest.cpp" -o "$here/vcf_ingest.o"
 cc -c "$here/scan_stream.cpp" -o "$here/scan_stream.o"
 cc -c "$here/gfm_workers.cpp" -o "$here/gfm_workers.o"
 cc -c "$here/graph_tsv_writer.cpp" -o "$here/graph_tsv_writer.o"
+cc -c "$here/hit_table.cpp" -o "$here/hit_table.o"
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$here/libgrafimo_hip.so" \
     "$here/grafimo_hip.o" "${quad[@]}" "$here/graph_extract.o" "$here/stream_calib.o" "$here/region_reduce.o" "$here/tsv_ingest.o" \
-    "$here/vcf_ingest.o" "$here/scan_stream.o" "$here/gfm_workers.o" "$here/graph_tsv_writer.o" -lpthread -lz
+    "$here/vcf_ingest.o" "$here/scan_stream.o" "$here/gfm_workers.o" "$here/graph_tsv_writer.o" "$here/hit_table.o" -lpthread -lz
 echo "built $here/libgrafimo_hip.so"

@@ -125,6 +125,13 @@ class DeviceMotif:
         nv.check(nv.lib().gfm_motif_tables(self._h, nv.ptr(pmf), nv.ptr(pt)))
         return pmf, pt
 
+    def ptable_host(self) -> np.ndarray:
+        """p_table f64 [L] on the host (read once per handle): p-value of a scaled score = one lookup."""
+        pt = getattr(self, "_ptable_host", None)
+        if pt is None:
+            pt = self._ptable_host = self.tables()[1]
+        return pt
+
     def pvalue_cutoff(self, threshold: float) -> int:
         c = ctypes.c_int32()
         nv.check(nv.lib().gfm_motif_pvalue_cutoff(self._h, float(threshold), ctypes.byref(c)))

@@ -475,6 +475,11 @@ def compute_results_sharded(motif: Motif, sequence_loc: str, debug: bool, args_o
     no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
     if qval_t and no_qvalue:
         raise ValueError("q-value threshold without q-values")
+    if backend is None:        # scan_graph's manifest instead of rows: regions AND graph shard over the ranks
+        from .extract_regions import compute_results_from_manifest, read_manifest
+        manifest = read_manifest(sequence_loc)
+        if manifest is not None:
+            return compute_results_from_manifest(motif, manifest, debug, args_obj, group=group)
     if rank == 0:
         print_scoring_msg(motif, bool(args_obj.noreverse), debug)
     width = motif.width
@@ -499,6 +504,11 @@ def compute_results_many_sharded(motifs: Sequence[Motif], sequence_loc: str, deb
     no_qvalue = bool(args_obj.noqvalue)
     if bool(args_obj.qvalueT) and no_qvalue:
         raise ValueError("q-value threshold without q-values")
+    if backend is None:        # scan_graph's manifest instead of rows
+        from .extract_regions import compute_results_many_from_manifest, read_manifest
+        manifest = read_manifest(sequence_loc)
+        if manifest is not None:
+            return compute_results_many_from_manifest(list(motifs), manifest, debug, args_obj, group=group)
     out = [None] * len(motifs)
     by_width = {}
     for i, m in enumerate(motifs):

@@ -341,6 +341,15 @@ def compute_results_many(motifs: List[Motif], sequence_loc: str, debug: bool, ar
         if not is_motif_like(m):
             exception_handler(TypeError, f"Expected Motif, got {type(m).__name__}.\n", debug)
         by_width.setdefault(m.width, []).append(i)
+    # scan_graph's manifest instead of rows (extract_regions.scan_graph): the set goes through the graph, the motifs of a
+    # width sharing the enumeration of the walks
+    from .extract_regions import compute_results_many_from_manifest, read_manifest
+    manifest = read_manifest(sequence_loc)
+    if manifest is not None:
+        try:
+            return compute_results_many_from_manifest(motifs, manifest, debug, args_obj)
+        except nv.NativeError as e:
+            exception_handler(RuntimeError, e.msg + "\n", debug)
     for width, idxs in by_width.items():
         files = sorted(glob.glob(os.path.join(sequence_loc, f"width_{width}", "*.tsv")))
         no_rows = "No result retrieved. Unable to proceed.\n"

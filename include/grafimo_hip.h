@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFM_ABI_VERSION 10
+#define GFM_ABI_VERSION 11
 
 #define GFM_OK 0
 #define GFM_ERR_INVALID (-1)  /* bad argument (NULL, width out of range, ...)            */
@@ -482,6 +482,36 @@ int gfm_graph_profile_enable(gfm_graph_t g, int on);
 int gfm_graph_profile_read(gfm_graph_t g, float *h_ms_out, int capacity, int *n_out);
 int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t *d_hit_count, int64_t hit_capacity,
                        const int32_t *d_cutoff, const double *d_qtable, void *d_records, void *stream);
+
+/* ------------------------------------------------------------------ the report's rows from the hit records (host)
+ * replaces what ResultTmp.to_df does with the rows that passed the threshold (resultsTmp.py:303-314): the --recomb filter
+ * (:309-310: rows with haplotype_frequency == 0 are dropped unless --recomb), the ascending sort by p-value (:312; rows
+ * of equal p-value stay in the order of the TSV rows -- chromosome entry, window, walk, strand -- as a stable sort over
+ * the files' rows leaves them) and the columns of resultsTmp.py:270-301 as plain arrays.  No device is touched.
+ *   h_ptable [table_len]: the motif's tail table (gfm_motif_tables), p-value of a row = h_ptable[score]
+ *     (score_sequences.py:390-391); scale, offset, width: score = scaled / scale + width * offset (:393);
+ *   h_recs[p] / n_recs[p]: the records gfm_graph_annotate wrote for one graph handle of the call, copied to the host;
+ *   h_entry_of[p] (optional): int64 per region of that handle's region list -> the rank of its chromosome entry in the
+ *     caller's order (rows are ordered by it first); region_base[p] (optional): added to a record's `region` in o_region;
+ *   flags: GFM_HITS_DROP_ZERO_FREQ (no --recomb), GFM_HITS_FIRST_PER_REGION (only the first row of every region in
+ *     report order: what --top-graphs walks, res_writer.py:153-157);
+ *   outputs (caller-allocated for sum(n_recs) rows, any may be NULL): start, stop, haplotype_frequency, region,
+ *     score = log-odds (score_sequences.py:393), p-value, q-value, strand (0 '+', 1 '-'), reference (1 = "ref": vg's
+ *     flag AND |stop - start| == width, score_sequences.py:305-307), o_kmers [rows][width + 1] the k-mer and a '\n'
+ *     (one decode + split makes the matched_sequence strings).  *n_out = rows written. */
+#define GFM_HITS_DROP_ZERO_FREQ 1u
+#define GFM_HITS_FIRST_PER_REGION 2u
+int gfm_graph_hit_columns(const double *h_ptable, int32_t table_len, int32_t scale, double offset, int32_t width,
+                          int32_t n_parts, const gfm_graph_hit_t *const *h_recs,
+                          const int64_t *n_recs, const int64_t *const *h_entry_of, const int64_t *region_base,
+                          uint32_t flags, int64_t *n_out, int64_t *o_start, int64_t *o_stop, int64_t *o_freq,
+                          int64_t *o_region, double *o_score, double *o_pvalue, double *o_qvalue, uint8_t *o_strand,
+                          uint8_t *o_ref, uint8_t *o_kmers);
+/* The sequence_name strings of regions, "CHROM:START-STOP" (extract_regions.py:165-170: the query string of `vg find -p`,
+ * which score_seqs copies from column 1 of the rows), '\n'-terminated, one after the other in h_out.  Returns the bytes
+ * written; with capacity too small (0 to ask) nothing is written and the room to come back with is returned. */
+int64_t gfm_region_labels(const char *chrom, const int64_t *h_starts, const int64_t *h_stops, int64_t n, char *h_out,
+                          int64_t capacity);
 
 /* Phased VCF (plain or gzip/bgzip) -> the site arrays of gfm_graph_create for one chromosome; host
  * threads parse the lines.  The reference hands the VCF to `vg construct` / `vg index -G`

