@@ -1176,12 +1176,18 @@ struct FusedPlan {
     Buf<Tile> f_tiles;
     Buf<DelWin> f_del_wins;
     Buf<HeavyWin> f_heavy;                 // the plan's heavy windows (graph_heavy_kernel); f_flags[8..9]: their count << 32 | items
-    unsigned long long *h_heavy_ctl = nullptr;   // pinned [2]: that word, copied back once per plan (no heavy window: no launch); [1]: the
-                                                 // number of work items of graph_del_score_kernel (its grid, once the host knows it)
+    unsigned long long *h_heavy_ctl = nullptr;   // pinned [3]: that word, copied back once per plan (no heavy window: no launch); [1]: the
+                                                 // number of work items of graph_del_score_kernel (its grid, once the host knows it);
+                                                 // [2]: some item holds more than one round of walks (f_flags[6])
     hipEvent_t ev_heavy = nullptr, ev_items = nullptr;
     bool heavy_known = false, heavy_asked = false, items_known = false, items_asked = false;
     Buf<DelBatchRec> f_del_recs;         // per listed window: what graph_del_count_kernel found
     Buf<DelItem> f_del_items;            // work items of graph_del_score_kernel
+    // the listed windows' walks themselves (LwMeta, gfm_graph_fused.hpp): filled by graph_del_score_kernel on the first call that
+    // knows the number of work items, read by graph_score_kernel's wavefronts from then on
+    Buf<unsigned char> f_lw_kmers;
+    Buf<LwMeta> f_lw_meta;
+    int lw_state = 0, lw_pitch = 0, lw_items = 0;      // 0: not decided, 1: filled (stream order), -1: this plan does without
     // [0] unused, [1] listed windows, [2] overflow of the call, [3] work items of the deletion kernels, [4] overflow among the
     // listed windows.  [1], [3], [4] belong to the PLAN -- the list of windows that touch an indel, their layouts and the
     // work items cut from them depend on the graph, the regions and the width, not on the motif
@@ -1194,8 +1200,8 @@ struct FusedPlan {
         hipError_t e = hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_heavy, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_items, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h_heavy_ctl), 2 * sizeof(unsigned long long), hipHostMallocDefault);
-        if (e == hipSuccess) h_heavy_ctl[0] = h_heavy_ctl[1] = 0ull;
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&h_heavy_ctl), 3 * sizeof(unsigned long long), hipHostMallocDefault);
+        if (e == hipSuccess) h_heavy_ctl[0] = h_heavy_ctl[1] = h_heavy_ctl[2] = 0ull;
         return e;
     }
     ~FusedPlan()
@@ -1205,6 +1211,7 @@ struct FusedPlan {
         if (ev_items) (void)hipEventDestroy(ev_items);
         if (h_heavy_ctl) (void)hipHostFree(h_heavy_ctl);
         f_tiles.release(); f_del_wins.release(); f_heavy.release(); f_del_recs.release(); f_del_items.release(); f_flags.release();
+        f_lw_kmers.release(); f_lw_meta.release();
     }
 };
 
@@ -1902,6 +1909,7 @@ struct FusedLaunch {
     int n_cu, n_motifs;
     bool listing, indels, with_hist;
     unsigned long long *heavy_ctl;
+    int *overflow;                // the call's overflow word: the caller's d_overflow (zeroed by the caller with its counters), or f_flags[2]
 };
 
 // the launches of one gfm_graph_score[_multi] call for MM motifs
@@ -1941,7 +1949,7 @@ template <int MM> int launch_fused(FusedLaunch &L)
         pt.sh = pick_shape(ks.vgprs, tab_bytes + hist_bytes + 16, wave_bytes + sizeof(long long) + sizeof(int));
         const int n_t = pt.end - pt.begin;
         pt.grid = n_t > 0 ? std::max(1, std::min((n_t + pt.sh.waves - 1) / pt.sh.waves, pt.sh.per_cu * n_cu)) : 0;
-        pt.lds = tab_bytes + (size_t)pt.sh.waves * wave_bytes + sizeof(long long) * (size_t)pt.sh.waves + sizeof(int) * (size_t)(pt.sh.waves + 2) + hist_bytes;
+        pt.lds = tab_bytes + (size_t)pt.sh.waves * wave_bytes + sizeof(long long) * (size_t)pt.sh.waves + sizeof(int) * (size_t)(pt.sh.waves + 4) + hist_bytes;
     }
     const int g1 = part[0].grid + part[1].grid;          // slab rows of the two launches: the general one's first
     // ---- graph_heavy_kernel: a grid that fills the chip whatever the number of tiles
@@ -1959,7 +1967,7 @@ template <int MM> int launch_fused(FusedLaunch &L)
     // behind the score kernel) 0.106 against 0.089 ms -- graph_score_kernel stretches by more than graph_del_score_kernel
     // takes alone (its share of the tiles per wavefront is fixed before it starts: whatever delays some of its wavefronts
     // delays its end).  One after the other it is; the item count still sizes the grid.
-    auto launch_del_score = [&](hipStream_t on, int grid_cap) -> int {
+    auto launch_del_score = [&](hipStream_t on, int grid_cap, bool fill_cache) -> int {
         if (const int rc = kernel_prepare(FK::del_score, reinterpret_cast<const void *>(graph_del_score_kernel<MM>))) return rc;
         int pitch = ((W + 3) / 4) * 4;
         if ((pitch / 4) % 2 == 0) pitch += 4;         // an odd dword pitch: the lanes' slots fall on all LDS banks
@@ -1971,7 +1979,7 @@ template <int MM> int launch_fused(FusedLaunch &L)
         const int grid = grid_cap > 0 ? std::min(grid_cap, per_cu * n_cu) : per_cu * n_cu;
         hipLaunchKernelGGL((graph_del_score_kernel<MM>), dim3((unsigned)grid), dim3(kFusedDelThreads), lds_b, on, g->dev, a,
                            P->f_tiles.p, P->f_del_wins.p, P->f_flags.p + 1, P->f_del_recs.p, P->f_del_items.p, P->f_flags.p + 3,
-                           pitch);
+                           pitch, fill_cache ? P->f_lw_kmers.p : nullptr, fill_cache ? P->f_lw_meta.p : nullptr, P->lw_pitch);
         return GFM_OK;
     };
 #ifdef GFM_LAB
@@ -1983,10 +1991,38 @@ template <int MM> int launch_fused(FusedLaunch &L)
         if (hipEventQuery(P->ev_items) == hipSuccess) P->items_known = true;
         else (void)hipGetLastError();          // ("not ready" is no error of this call)
     }
-    const int n_items = P->items_known ? (int)P->h_heavy_ctl[1] : -1;
+    const int n_items = P->items_known ? (int)(P->h_heavy_ctl[1] & 0xffffffffull) : -1;
+    // The plan's cache of the listed windows' walks (LwMeta): decided once the item count is back.  This call FILLS it -- the
+    // deletion kernel replays the walks as on every earlier call and stores them beside scoring them; the calls that follow
+    // (stream order, or the handle's call event) hand the cache to graph_score_kernel and launch no deletion kernel at all.
+    // A plan whose items hold several rounds of walks (a listed window of > 4 096 walks with the pool used up) or whose walks
+    // would take more than kLwCacheBytes does without.
+    bool lw_fill = false;
+    if (!L.listing && L.indels && P->lw_state == 0 && P->items_known) {
+        constexpr size_t kLwCacheBytes = 256u << 20;
+        const int pitch16 = ((W + 15) / 16) * 16;
+        const size_t rows = (size_t)std::max(n_items, 0) * kFusedDelThreads;
+        if (n_items > 0 && (int)(P->h_heavy_ctl[2] & 0xffffffffull) == 0 && rows * ((size_t)pitch16 + sizeof(LwMeta)) <= kLwCacheBytes) {
+            GX_TRY(P->f_lw_kmers.reserve(rows * (size_t)pitch16 + 16));
+            GX_TRY(P->f_lw_meta.reserve(rows + 1));
+            GX_TRY(hipMemsetAsync(P->f_lw_meta.p, 0xff, rows * sizeof(LwMeta), st));        // tile_k = -1: no walk in the lane
+            P->lw_pitch = pitch16;
+            P->lw_items = n_items;
+            lw_fill = true;
+        } else {
+            P->lw_state = -1;
+        }
+    }
+    const bool lw_cached = !L.listing && P->lw_state == 1;
+    if (lw_cached) {
+        a.lw_kmers = reinterpret_cast<const uint4 *>(P->f_lw_kmers.p);
+        a.lw_meta = P->f_lw_meta.p;
+        a.lw_items = P->lw_items;
+        a.lw_pitch = P->lw_pitch;
+    }
     const bool beside = split == 2 && part[0].grid > 0 && part[1].grid > 0;
     const bool del_beside = !L.listing && L.indels && !serial && n_items > 0;
-    const bool del_none = !L.listing && n_items == 0;          // the plan lists no window: nothing to launch
+    const bool del_none = !L.listing && (n_items == 0 || lw_cached);   // the plan lists no window, or graph_score_kernel scores their walks: nothing to launch
     if (L.indels) {
         const size_t n_batches = ((size_t)P->f_general_windows + kFusedDelThreads - 1) / kFusedDelThreads;      // (listed windows live in the general tiles)
         GX_TRY(P->f_del_recs.reserve(n_batches * kFusedDelThreads + 1));
@@ -2008,17 +2044,18 @@ template <int MM> int launch_fused(FusedLaunch &L)
         hipStream_t st = (beside && general) ? g->side : L.st;      // (shadows: the general tiles' launch goes to the side stream)
         FusedArgs ap = a;
         ap.slabs = a.slabs + (general ? (size_t)0 : (size_t)part[1].grid * (size_t)a.slab_stride);
+        if (!general && part[1].grid > 0) ap.lw_items = 0;       // (two launches -- a lab split: the cached walks are the general one's)
         const dim3 grid((unsigned)pt.grid), block((unsigned)pt.sh.waves * 64);
 #define GFM_LAUNCH_SCORE(LST, GEN)                                                                                              \
         do {                                                                                                                    \
             if (timed_on_dispatch)                                                                                              \
                 hipExtLaunchKernelGGL((graph_score_kernel<MM, LST, GEN>), grid, block, pt.lds, st, g->prof_ev[2 * g->prof_n],   \
                                       g->prof_ev[2 * g->prof_n + 1], 0, g->dev, ap, P->f_tiles.p, pt.begin, pt.end,             \
-                                      P->f_del_wins.p, P->f_flags.p + 1, P->f_flags.p + 2, P->f_heavy.p, L.heavy_ctl,           \
+                                      P->f_del_wins.p, P->f_flags.p + 1, L.overflow, P->f_heavy.p, L.heavy_ctl,                 \
                                       P->f_flags.p + 4);                                                                        \
             else                                                                                                                \
                 hipLaunchKernelGGL((graph_score_kernel<MM, LST, GEN>), grid, block, pt.lds, st, g->dev, ap, P->f_tiles.p,       \
-                                   pt.begin, pt.end, P->f_del_wins.p, P->f_flags.p + 1, P->f_flags.p + 2, P->f_heavy.p,         \
+                                   pt.begin, pt.end, P->f_del_wins.p, P->f_flags.p + 1, L.overflow, P->f_heavy.p,               \
                                    L.heavy_ctl, P->f_flags.p + 4);                                                              \
         } while (0)
         if (L.listing) { if (general) GFM_LAUNCH_SCORE(true, true); else GFM_LAUNCH_SCORE(true, false); }
@@ -2030,8 +2067,8 @@ template <int MM> int launch_fused(FusedLaunch &L)
         if (!timed_on_dispatch) GX_TRY(hipEventRecord(g->prof_ev[2 * g->prof_n + 1], st));
         ++g->prof_n;
     }
-    if (del_beside)                 // behind the score kernel's launch: its workgroups have the CUs' LDS first
-        if (const int rc = launch_del_score(g->side, std::min(n_items, n_cu))) return rc;
+    if (del_beside && !lw_cached)   // behind the score kernel's launch: its workgroups have the CUs' LDS first
+        if (const int rc = launch_del_score(g->side, std::min(n_items, n_cu), false)) return rc;
     int n_slabs = g1;
     {
         // the heavy windows: launched until the plan's count has come back and says there is none
@@ -2060,18 +2097,21 @@ template <int MM> int launch_fused(FusedLaunch &L)
         // score kernel that lists them
         const size_t lds_a = sizeof(SiteRec) * kSiteCache * kFusedDelThreads;
         hipLaunchKernelGGL(graph_del_count_kernel, dim3((unsigned)(12 * n_cu)), dim3(kFusedDelThreads), lds_a, st, g->dev, W,
-                           P->f_tiles.p, P->f_del_wins.p, P->f_flags.p + 1, P->f_flags.p + 2, P->f_flags.p + 4, P->f_del_recs.p,
-                           P->f_del_items.p, P->f_flags.p + 3, P->f_flags.p + 5);
+                           P->f_tiles.p, P->f_del_wins.p, P->f_flags.p + 1, L.overflow, P->f_flags.p + 4, P->f_del_recs.p,
+                           P->f_del_items.p, P->f_flags.p + 3, P->f_flags.p + 5, P->f_flags.p + 6);
         P->f_plan_ready = true;       // (stream order: the calls that follow on this stream find the plan complete)
         P->f_plan_stream = st;
         GX_TRY(hipEventRecord(P->ev_plan, st));
         // how many work items the plan holds: the grid of graph_del_score_kernel on the calls that follow
         GX_TRY(hipMemcpyAsync(&P->h_heavy_ctl[1], P->f_flags.p + 3, sizeof(int), hipMemcpyDeviceToHost, st));
+        GX_TRY(hipMemcpyAsync(&P->h_heavy_ctl[2], P->f_flags.p + 6, sizeof(int), hipMemcpyDeviceToHost, st));
         GX_TRY(hipEventRecord(P->ev_items, st));
         P->items_asked = true;
     }
-    if (L.indels && !del_beside && !del_none)
-        if (const int rc = launch_del_score(st, n_items)) return rc;
+    if (L.indels && !del_beside && !del_none) {
+        if (const int rc = launch_del_score(st, n_items, lw_fill)) return rc;
+        if (lw_fill) P->lw_state = 1;
+    }
     if (beside || del_beside) {       // join: the histogram reduction and everything the caller enqueues next see the side stream's work
         GX_TRY(hipEventRecord(g->ev_join, g->side));
         GX_TRY(hipStreamWaitEvent(st, g->ev_join, 0));
@@ -2255,9 +2295,14 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
         GX_TRY(hipMemsetAsync(P->f_flags.p, 0, 16 * sizeof(int), st));
         P->heavy_known = P->heavy_asked = false;
         P->items_known = P->items_asked = false;
-    } else {
+        P->lw_state = 0;
+    } else if (!d_overflow) {
         GX_TRY(hipMemsetAsync(P->f_flags.p + 2, 0, sizeof(int), st));
     }
+    // The call's overflow word: the caller's own when it gives one -- zeroed by the caller together with its counters (one
+    // fill for all of them) and written by the kernels directly.  (Round 5 kept a word of the plan's: a 4-byte memset in front
+    // of the score kernel and a 4-byte copy behind the reduction, ~5 us each of a 60 us call.)
+    int *const overflow_word = d_overflow ? d_overflow : P->f_flags.p + 2;
     a.W = W;
     a.n_motifs = n_motifs;
     a.forward_only = (flags & GFM_GRAPH_FORWARD_ONLY) ? 1 : 0;
@@ -2278,7 +2323,7 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
     static const int lab = [] { const char *e = std::getenv("GRAFIMO_FUSED_LAB"); return e ? atoi(e) : 0; }();
     a.lab = lab;
 #endif
-    FusedLaunch L{g, P, a, st, n_cu, n_motifs, listing, indels, with_hist, reinterpret_cast<unsigned long long *>(P->f_flags.p + 8)};
+    FusedLaunch L{g, P, a, st, n_cu, n_motifs, listing, indels, with_hist, reinterpret_cast<unsigned long long *>(P->f_flags.p + 8), overflow_word};
     int rc = GFM_OK;
     if (n_motifs == 1) rc = launch_fused<1>(L);
     else if (n_motifs == 2) rc = launch_fused<2>(L);
@@ -2366,7 +2411,6 @@ GFM_API int gfm_graph_score_multi(gfm_graph_t g, const gfm_motif_t *motifs, int3
         }
     }
 #endif
-    if (d_overflow) GX_TRY(hipMemcpyAsync(d_overflow, P->f_flags.p + 2, sizeof(int), hipMemcpyDeviceToDevice, st));
     return g->called(st);
 }
 

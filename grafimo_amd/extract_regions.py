@@ -657,33 +657,43 @@ class DeviceGraph:
 
     # ---- extraction fused into scoring (gfm_graph_score[_multi] / gfm_graph_annotate)
     def fused_buffers(self, cap: int, slot: int = 0):
-        """One int64 tensor per graph and SLOT (a slot per motif that shares a scoring pass), kept between calls:
+        """One int64 row per SLOT (a slot per motif that shares a scoring pass) of ONE tensor per graph, kept between calls:
         [16 control words | cap records of 15 words | cap entries of 2 words] -- the records right behind the control words:
-        fused_results fetches both with ONE copy.  Control: [0] hit count; in the first slot of a call also [1] rows scored
-        (per motif), [2] overflow flag (int32).  All slots have one capacity."""
+        one copy fetches both; all slots in one tensor: ONE fill zeroes the control words of all of them (fused_zero).
+        Control: [0] hit count; in the first slot of a call also [1] rows scored (per motif), [2] overflow flag (int32).
+        All slots have one capacity; a larger capacity or slot number than before makes a new tensor (before a call's first
+        pass: _fused_tables reserves what the call needs)."""
         torch = _torch()
-        bufs = self.__dict__.setdefault("_fused_bufs", {})
-        if getattr(self, "_fused_cap", 0) < cap:
-            self._fused_cap = int(cap)
-            bufs.clear()
-        buf = bufs.get(slot)
-        if buf is None:
-            buf = bufs[slot] = torch.empty(16 + 17 * self._fused_cap, dtype=torch.int64, device=self.device)
-        return buf, self._fused_cap
+        all_ = self.__dict__.get("_fused_all")
+        n_slots = 0 if all_ is None else int(all_.shape[0])
+        if getattr(self, "_fused_cap", 0) < cap or slot >= n_slots:
+            self._fused_cap = max(int(cap), getattr(self, "_fused_cap", 0))
+            n_slots = max(n_slots, slot + 1, 3)
+            all_ = self._fused_all = torch.empty((n_slots, 16 + 17 * self._fused_cap), dtype=torch.int64, device=self.device)
+        return all_[slot], self._fused_cap
+
+    def fused_zero(self, n_slots: int):
+        """zero the control words of slots [0, n_slots): one fill"""
+        self.fused_buffers(0, n_slots - 1)
+        self._fused_all[:n_slots, :16].zero_()
 
     def score_many(self, dms, starts: np.ndarray, stops: np.ndarray, cutoffs, hists=None, forward_only: bool = False,
-                   cap: int = 1 << 14, slots=None, stream=None):
+                   cap: int = 1 << 14, slots=None, stream=None, zero_ctl: bool = True):
         """gfm_graph_score_multi over the regions: every walk of every window scored on both strands against up to THREE
         motifs of one width in ONE enumeration; per motif the rows' score histogram added to hists[m] (torch int64 [L] or
         None) and the rows with score >= cutoffs[m] left as entries in this graph's buffer of slot slots[m].  Enqueue only.
-        -> number of windows."""
+        `zero_ctl=False`: the caller has zeroed the slots' control words (fused_zero).  -> number of windows."""
         M = len(dms)
         slots = list(range(M)) if slots is None else list(slots)
-        bufs = [self.fused_buffers(cap, s_)[0] for s_ in slots]
+        self.fused_buffers(cap, max(slots))                             # (a capacity / slot count that grew: one new tensor)
         cap = self._fused_cap
-        bufs = [self.fused_buffers(cap, s_)[0] for s_ in slots]         # (a capacity that grew replaced the earlier slots)
-        for b_ in bufs:
-            b_[:16].zero_()
+        bufs = [self.fused_buffers(cap, s_)[0] for s_ in slots]
+        if zero_ctl:
+            if slots == list(range(slots[0], slots[0] + M)):
+                self._fused_all[slots[0]:slots[0] + M, :16].zero_()
+            else:
+                for b_ in bufs:
+                    b_[:16].zero_()
         ctl = self.__dict__.setdefault("_fused_ctl", {})
         for s_ in slots:
             ctl[s_] = slots[0]
@@ -1612,9 +1622,10 @@ def _fused_tables(motifs, prep: _FusedPrep, debug, args_obj, top_graphs):
         # per motif [L hist | L q-table | cutoff, nrows]: kept per handle; the histograms of several motifs cross the ranks
         # as ONE [M, L] tensor
         works = [dm.fused_workspace(dev) for dm in dms] if not no_qvalue else None
+        # (M > 1: the histograms as the rows of ONE tensor -- one fill zeroes them, one all-reduce carries them)
         hist_all = None
-        if works is not None and M > 1 and collective:
-            hist_all = torch.zeros((M, L), dtype=torch.int64, device=dev)
+        if works is not None and M > 1:
+            hist_all = torch.empty((M, L), dtype=torch.int64, device=dev)
         cap = max(getattr(g, "_fused_cap", 0) for g in graphs) or (1 << 14)
         sp = _stream_ptr(None)                   # (torch's current stream, asked for once: 15 us a question)
         while True:
@@ -1628,11 +1639,14 @@ def _fused_tables(motifs, prep: _FusedPrep, debug, args_obj, top_graphs):
                 else:
                     for h_ in hists:
                         h_.zero_()
+            for g in graphs:                     # the slots of all M motifs in one tensor per graph: one fill for their counters
+                g.fused_buffers(cap, M - 1)
+                g.fused_zero(M)
             for c0 in range(0, M, FUSED_GROUP):
                 sl = list(range(c0, min(M, c0 + FUSED_GROUP)))
                 for g, (s_, e_) in zip(graphs, spans):
                     g.score_many([dms[m] for m in sl], s_, e_, [cuts_p[m] for m in sl], [hists[m] for m in sl],
-                                 forward_only=no_reverse, cap=cap, slots=sl, stream=sp)
+                                 forward_only=no_reverse, cap=cap, slots=sl, stream=sp, zero_ctl=False)
             if collective and works is not None:
                 # the one data-path exchange: BH ranks are global
                 dist.all_reduce(hist_all if hist_all is not None else hists[0], group=group)

@@ -433,7 +433,8 @@ int gfm_graph_write_tsvs(gfm_graph_t g, const uint8_t *d_kmers, const int64_t *d
  *   flags: GFM_GRAPH_FORWARD_ONLY = skip the '-' rows before they are scored or counted (--no-reverse, :281-282).
  *   d_hist uint64 [L] in/out or NULL (+= rows per score); select_cutoff as gfm_score_kmers (GFM_NO_SELECT: no hits);
  *   d_hits gfm_graph_entry_t [hit_capacity], appended from *d_hit_count on (entries beyond the capacity are counted,
- *   not stored; the caller zeroes the counter); *d_n_rows += rows scored; *d_overflow (optional) = 1 if a window holds
+ *   not stored; the caller zeroes the counter); *d_n_rows += rows scored; *d_overflow (optional; the caller zeroes it
+ *   with its counters, the kernels write it directly) = 1 if a window holds
  *   more than 2^40 walks, or the regions hold more than 2^20 windows of more than 64 walks each (those windows' rows are
  *   left out: score fewer regions at a time); *n_windows (host, optional) = windows of the call.  Entry order is
  *   arbitrary; the records of gfm_graph_annotate sorted by (w, q2) are in the row order of gfm_graph_emit.  Enqueue only (the first call for a

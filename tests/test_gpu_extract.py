@@ -282,11 +282,13 @@ def test_several_graphs_share_one_scoring_pass_and_cli_mode(tmp_path, capsys):
         main(["-m", "x.meme", "-l", fasta])            # incomplete graph inputs
 
 
-def test_scan_graph_adapter_feeds_compute_results(tmp_path, capsys):
+def test_scan_graph_adapter_feeds_compute_results(tmp_path, capsys, monkeypatch):
     """scan_graph(widths, args_obj, debug) -> tmpdir with width_W/CHR_S-E.tsv, called the way
     grafimo.findmotif does (grafimo.py:174-179), then compute_results on that directory == the direct
-    compute_results_from_graph table.  The graph comes from the index saved next to the XG name."""
+    compute_results_from_graph table.  The graph comes from the index saved next to the XG name.  (The FILES are what is
+    tested here: this function holds grafimo_amd's compute_results, which alone would get it the manifest.)"""
     import shutil
+    monkeypatch.setenv("GRAFIMO_SCAN_OUTPUT", "tsv")
     from grafimo_amd.extract_regions import (DeviceGraph, GraphIndex, compute_results_from_graph, scan_graph)
     from grafimo_amd.motif_ops import build_motif_meme_host
     from grafimo_amd.score_sequences import compute_results

@@ -235,7 +235,7 @@ def test_config2_scale_graph_and_repeated_calls():
     a3, b3 = _both(motif, g, sub, threshold=1e-2)                   # other regions: new tiles
     _assert_same(a3, b3)
     assert len(a3) < len(a)
-    g._fused_bufs, g._fused_cap = {}, 0
+    g._fused_all, g._fused_cap = None, 0
     g.fused_buffers(64)                                             # 64 entries: far too few -> counted, grown, redone
     a4, _ = _both(motif, g, regions, threshold=1e-2, qval_t=False)
     _assert_same(a4, a)
