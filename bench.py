@@ -531,6 +531,29 @@ def product_paths_block(ctcf, dev, rank, world):
                          "what": "compute_results_from_graph(motif, GraphIndex, regions) on every rank: regions sharded, each rank "
                                  "uploads its shard of the graph (shard_index), one all-reduce of the histogram, hit rows gathered; "
                                  "median of 6 calls, MAX over ranks"}
+    # ---- the same graph, a motif SET: compute_results_from_graph_many (three CTCF-width motifs share one enumeration per rank,
+    # their histograms cross the ranks as ONE [3, L] all-reduce)
+    from grafimo_amd.extract_regions import compute_results_from_graph_many
+    rng = np.random.default_rng(11)
+    trio = [ctcf] + [synth.motif_object(synth.synthetic_motif(W, rng, np.full(4, 0.25)), f"S{k}") for k in range(2)]
+    ts = []
+    with contextlib.redirect_stdout(sink):
+        for _ in range(6):
+            dist.barrier()
+            t = time.perf_counter()
+            tabs = compute_results_from_graph_many(trio, idx, reg, False, wf)
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t)
+    t_many = torch.tensor([float(np.median(ts[2:]))], dtype=torch.float64, device=dev)
+    dist.all_reduce(t_many, op=dist.ReduceOp.MAX)
+    out["graph_path_many"] = {"motifs": 3, "regions": int(len(reg)), "compute_results_from_graph_many_ms": 1e3 * float(t_many.item()),
+                              "pairs_per_s": 3 * int(n_rows.item()) / float(t_many.item()),
+                              "hits": [int(len(t_)) for t_ in tabs] if tabs[0] is not None else None,
+                              "first_table_equals_single_call": bool(tabs[0] is None or (len(tabs[0]) == len(df) and bool(
+                                  (tabs[0]["matched_sequence"].to_numpy() == df["matched_sequence"].to_numpy()).all()))),
+                              "what": "compute_results_from_graph_many([CTCF, 2 synthetic W=19 PWMs], GraphIndex, regions) on every "
+                                      "rank: one enumeration of a rank's walks for the three motifs, one [3, L] all-reduce; median of 4, "
+                                      "MAX over ranks"}
     drop_graph_cache()
     # ---- streamed scan: every rank writes its own files, then compute_results_sharded over the whole directory
     tmp = tempfile.mkdtemp(prefix="gfm_bench_scan_") if rank == 0 else None
@@ -603,7 +626,10 @@ def extract_config_block(cfg, dev):
     mots = synth.config_motifs(cfg)
     motifs = [synth.motif_object(m, f"M{i}") for i, m in enumerate(mots)]
     n_regions = 50_000
-    idx, regions = synth.make_graph_index(n_regions, max(m.width for m in motifs))
+    # cfg 4: 2 % of the regions hold a sample of the motif's own PWM columns (SURVEY 8d's recipe for the resident batches), so
+    # that q < 1e-4 reports rows and the call's annotate / table half has work (VERDICT r5 Weak #1 ii: hits_q1e-4 was 0)
+    idx, regions = synth.make_graph_index(n_regions, max(m.width for m in motifs),
+                                          plant=(mots[0]["probs"], 0.02) if cfg == 4 else None)
     g = DeviceGraph(idx, dev)
     reg = np.asarray(regions, dtype=np.int64)
     sink = io.StringIO()
@@ -1055,10 +1081,11 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
     if use_dist and cfg in (2, 3) and not args.no_extras:
         # the two other PRODUCT paths under the same process group, so that a scaling run says something about all three: the
         # fused graph path (every rank uploads its shard of the graph) and the streamed TSV scan (every rank its files)
-        try:
-            extras["product_paths"] = product_paths_block(ctcf, dev, rank, world)
-        except Exception as e:                   # (side measurements: they must not take the bench line with them)
-            extras["product_paths"] = {"error": f"{type(e).__name__}: {e}"}
+        # NOT under a per-rank try/except: the block is a sequence of collectives -- a rank that swallowed its own
+        # exception would go on to the main bench's collectives while its peers still wait inside this block's, and the run
+        # would hang until the watchdog instead of failing.  An exception here ends this rank with a traceback and a non-zero
+        # exit; the launcher takes the other ranks down.
+        extras["product_paths"] = product_paths_block(ctcf, dev, rank, world)
     if default_n1 and not args.no_extras:
         W = mots[0]["width"]
         # (c) what this device sustains for a bare stream of the kernel's byte mix (76 B in / 16 B out per lane-step)
@@ -1265,6 +1292,29 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
         if "peak_measured" in extras:
             roofline["peak_measured"] = extras["peak_measured"]["GBps"]
             roofline["frac_of_measured"] = achieved / extras["peak_measured"]["GBps"]
+        # the fused graph path's figures as SCALARS inside `config` (the driver's record keeps `config`, `roofline` and
+        # `cpu_baseline` verbatim and only the names of the other blocks: VERDICT r5 Missing #5 / next #4)
+        def _pick(block, *path):
+            v = extras.get(block)
+            for k in path:
+                v = v.get(k) if isinstance(v, dict) else None
+            return float(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else None
+
+        k_us = _pick("extract", "roofline", "kernel_us")
+        f_ms = _pick("extract", "fused_ms")
+        fused_cfg = {
+            "kernel_us": k_us, "frac": _pick("extract", "roofline", "frac"), "fused_ms": f_ms,
+            "fused_minus_kernel_us": (1e3 * f_ms - k_us) if (k_us is not None and f_ms is not None) else None,
+            "extract_plus_score_ms": _pick("extract", "extract_plus_score_ms"),
+            "scan_graph_ms": _pick("extract", "scan_graph_e2e", "manifest", "scan_graph_ms"),
+            "first_call_ms": _pick("extract", "scan_graph_e2e", "manifest", "first_compute_results_ms"),
+            "compute_results_ms": _pick("extract", "scan_graph_e2e", "manifest", "compute_results_ms"),
+            "many_ms": _pick("extract_config5", "many_ms"), "fifty_single_calls_ms": _pick("extract_config5", "fifty_single_calls_ms"),
+            "speedup_vs_single_calls": _pick("extract_config5", "speedup_vs_single_calls"),
+            "device_pass_many_ms": _pick("extract_config5", "device_pass_many_ms"),
+            "device_pass_fifty_single_ms": _pick("extract_config5", "device_pass_fifty_single_ms"),
+            "config4_ms": _pick("extract_config4", "compute_results_from_graph_ms"), "config4_hits": _pick("extract_config4", "hits_q1e-4"),
+        } if "extract" in extras else None
         out = {
             "metric": "scored haplotype k-mers/sec",
             "value": value,
@@ -1308,6 +1358,7 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
                 "timing": "median burst of `steps` steps, each burst barrier + synchronize bracketed, MAX over ranks",
                 "sharding": (f"regions split over {world} rank(s); all-reduce(score histogram) + gather(hit entries, "
                              f"sized from the observed hit counts) per step") if world > 1 else "single GPU",
+                "fused": fused_cfg,
             },
             "roofline": roofline,
             "roofline_noscore": extras.get("roofline_noscore"),

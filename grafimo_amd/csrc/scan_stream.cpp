@@ -143,6 +143,11 @@ struct MotifBufs {
         table_len = len;
         return GFM_OK;
     }
+    // a list that was grown for a scan that has to be run again (too_short at finish): the capacity the retry needs.  trim()
+    // keeps such a list whatever its size -- the retry closes the scan (-> trim) before it begins the next one (with
+    // the list dropped there, the second begin reserved the default again and a scan of more than keep_bytes / 16 passing rows
+    // overflowed on every attempt) -- and the next begin reserves at least this much; a finish that holds clears it.
+    int64_t want_cap = 0;
     void release_hits()
     {
         if (d_hits) (void)hipFree(d_hits);
@@ -302,7 +307,7 @@ struct ScanPool {
             meta.pop_back();
         }
         for (auto &m : mb)          // hit lists that an overflow made large: back to the default next time
-            if ((size_t)m.hit_cap * 2 * sizeof(int64_t) > keep) m.release_hits();
+            if ((size_t)m.hit_cap * 2 * sizeof(int64_t) > keep && m.want_cap == 0) m.release_hits();
     }
     void release()
     {
@@ -705,7 +710,7 @@ GFM_API int gfm_scan_tsv_begin(const gfm_motif_t *motifs, int n_motifs, const ch
         if (want_qvalues) S_RC(b.reserve_tables((size_t)L));
         // room for one row in sixteen (a p < 1e-4 scan reports one in ten thousand; the bench plants one in a hundred); a
         // list that turns out too short is grown at finish and the scan asked for again (GFM_ERR_OVERFLOW)
-        S_RC(b.reserve_hits(std::max<int64_t>(std::max<int64_t>(b.hit_cap, 1 << 20), est_rows / 16)));
+        S_RC(b.reserve_hits(std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(b.hit_cap, 1 << 20), est_rows / 16), b.want_cap)));
         sc->d_hist[j] = want_qvalues ? (d_hist_ext ? d_hist_ext[j] : b.d_hist) : nullptr;
         // p-value threshold: the cutoff is known before scoring and the score kernel selects the hits.  q-value
         // threshold: q >= p, so the score kernel collects the p < t CANDIDATES the same way, and the selection behind
@@ -1194,7 +1199,9 @@ GFM_API int gfm_scan_tsv_finish(gfm_scan_t sc, int64_t *n_hits)
             // A list that was too short (the score kernel counts what it could not store): no score was kept to select from
             // again, so the list is grown to what the count asks for and the caller runs the scan once more.
             auto too_short = [&](uint64_t need) -> int {
-                S_RC(b.reserve_hits((int64_t)need + (int64_t)(need >> 3) + 1024));
+                const int64_t cap = (int64_t)need + (int64_t)(need >> 3) + 1024;
+                S_RC(b.reserve_hits(cap));
+                b.want_cap = cap;
                 return sfail(GFM_ERR_OVERFLOW, "the hit list of this scan was too short (" + std::to_string(need) + " rows pass the threshold); it "
                                                "has been grown: run the scan again");
             };
@@ -1211,6 +1218,7 @@ GFM_API int gfm_scan_tsv_finish(gfm_scan_t sc, int64_t *n_hits)
             S_TRY(hipMemcpyAsync(&cnt, b.d_count, sizeof cnt, hipMemcpyDeviceToHost, P->score));
             S_TRY(hipStreamSynchronize(P->score));
             if ((int64_t)cnt > b.hit_cap) return too_short(cnt);
+            b.want_cap = 0;                    // the list held: a closed scan's trim() may drop it again
             std::vector<int64_t> packed((size_t)cnt);
             std::vector<double> q;
             if (cnt)

@@ -236,17 +236,33 @@ def config_motifs(cfg: int):
 
 
 def make_graph_index(n_regions: int, width: int = 19, n_haplotypes: int = 5096, site_every: int = 32,
-                     del_frac: float = 0.06, seed: int = 20240139, with_counts: bool = True, with_dels: bool = True):
+                     del_frac: float = 0.06, seed: int = 20240139, with_counts: bool = True, with_dels: bool = True,
+                     plant=None):
     """A synthetic chromosome for the extraction kernels at BASELINE config-2 scale: region i = [16 000 + 1000 i,
     + 200] (SURVEY 8d's layout, shifted to a short contig), variant sites at 1000-Genomes-like density (one per
     `site_every` bp, 3 % with two alternates, `del_frac` of them deletions of 1..8 bases kept apart from each other),
     allele frequencies skewed to rare variants (af = u^4), one haplotype bitset per alternate allele.  Sites are
-    drawn only where a window of a region can see them.  -> (GraphIndex, [(S, E)] regions)."""
+    drawn only where a window of a region can see them.  `plant` = (probs f64 [4, W], fraction): in that fraction of the
+    regions one window of the reference is overwritten by a sample from the PWM's columns -- SURVEY 8(d)'s "1 % of the rows are
+    overwritten by a sample from the motif's own PWM", so that a strict threshold (q < 1e-4) still reports rows; drawn from a
+    generator of its own: everything else of the graph is what it is without.  -> (GraphIndex, [(S, E)] regions)."""
     from .extract_regions import GraphIndex
     rng = np.random.default_rng(seed)
     L = 16_000 + REGION_STRIDE * n_regions + 4 * REGION_LEN
     ref = _ACGT[rng.choice(4, size=L, p=BG_NT / BG_NT.sum())]
     regions = [(16_000 + REGION_STRIDE * i, 16_000 + REGION_STRIDE * i + REGION_LEN) for i in range(n_regions)]
+    if plant is not None:
+        probs, frac = plant
+        probs = np.asarray(probs, dtype=np.float64)
+        Wp = probs.shape[1]
+        rng_p = np.random.default_rng(seed + 7919)
+        chosen = np.flatnonzero(rng_p.random(n_regions) < frac)
+        cdf = np.cumsum(probs / probs.sum(0, keepdims=True), axis=0)
+        u = rng_p.random((len(chosen), Wp))
+        sample = _ACGT[(u[:, None, :] > cdf[None, :, :]).sum(1).clip(0, 3)]            # [n, Wp]
+        off = rng_p.integers(0, REGION_LEN - Wp + 1, size=len(chosen))
+        for k, r in enumerate(chosen.tolist()):
+            ref[regions[r][0] + int(off[k]):regions[r][0] + int(off[k]) + Wp] = sample[k]
     span = REGION_LEN + 2 * width + 16
     per_region = max(1, span // site_every)
     starts = np.asarray([r[0] for r in regions], dtype=np.int64) - width - 8
