@@ -731,17 +731,22 @@ def scan_graph_block(ctcf, idx, regions, rows, g):
         # (a) manifest: scan_graph does not touch the GPU; the first compute_results loads and uploads the graph
         os.environ["GRAFIMO_SCAN_OUTPUT"] = "manifest"
         with contextlib.redirect_stdout(sink):
-            t = time.perf_counter()
-            loc = xr.scan_graph({W}, wf, False)
-            t_scan = time.perf_counter() - t
+            t_scans = []
+            for _ in range(3):                               # (the first call of a process also imports the XG / GBWT reader)
+                t = time.perf_counter()
+                loc = xr.scan_graph({W}, wf, False)
+                t_scans.append(time.perf_counter() - t)
+                if len(t_scans) < 3:
+                    shutil.rmtree(loc)
+            t_scan = float(np.median(t_scans))
             calls = []
-            for _ in range(8):                               # "motif after motif" over one scan_graph result
+            for _ in range(24):                              # "motif after motif" over one scan_graph result
                 t = time.perf_counter()
                 df = compute_results(ctcf, loc, False, wf)
                 calls.append(time.perf_counter() - t)
         shutil.rmtree(loc)
         xr.drop_graph_cache()
-        out["manifest"] = {"scan_graph_ms": 1e3 * t_scan, "first_compute_results_ms": 1e3 * calls[0],
+        out["manifest"] = {"scan_graph_ms": 1e3 * t_scan, "scan_graph_first_ms": 1e3 * t_scans[0], "first_compute_results_ms": 1e3 * calls[0],
                            "compute_results_ms": 1e3 * float(np.median(calls[2:])), "hits": int(len(df)), "rows_written": 0,
                            "what": "scan_graph leaves a manifest (graph index, regions, widths); compute_results runs "
                                    "compute_results_from_graph; first call = + GraphIndex.load + upload of the graph"}

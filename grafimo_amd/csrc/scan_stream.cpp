@@ -1192,6 +1192,27 @@ GFM_API int gfm_scan_tsv_finish(gfm_scan_t sc, int64_t *n_hits)
                 S_RC(gfm_qvalue_table_multi(sc->motifs.data(), (int)M, sc->d_hist.data(), sc->threshold, sc->on_qvalue,
                                             v_q.data(), v_cut.data(), nullptr, 0, P->score));
         }
+        // ---- were the lists long enough?  Asked for ALL motifs before any is selected from: every list that was short is grown
+        // in this one go, so that the one retry the callers make (StreamScan.finish, _scan_width_sharded) serves a motif set too
+        {
+            std::vector<uint64_t> counted(M, 0);
+            for (size_t j = 0; j < M; ++j)
+                S_TRY(hipMemcpyAsync(&counted[j], sc->on_qvalue ? P->mb[j].d_cand_count : P->mb[j].d_count, sizeof(uint64_t),
+                                     hipMemcpyDeviceToHost, P->score));
+            S_TRY(hipStreamSynchronize(P->score));
+            uint64_t worst = 0;
+            for (size_t j = 0; j < M; ++j) {
+                MotifBufs &b = P->mb[j];
+                if ((int64_t)counted[j] <= b.hit_cap) continue;
+                const int64_t cap = (int64_t)counted[j] + (int64_t)(counted[j] >> 3) + 1024;
+                S_RC(b.reserve_hits(cap));
+                b.want_cap = cap;
+                worst = std::max(worst, counted[j]);
+            }
+            if (worst)
+                return sfail(GFM_ERR_OVERFLOW, "the hit list of this scan was too short (" + std::to_string(worst) + " rows pass the threshold); it "
+                                               "has been grown: run the scan again");
+        }
         // ---- selection, hits back: motif by motif
         for (size_t j = 0; j < M; ++j) {
             MotifBufs &b = P->mb[j];

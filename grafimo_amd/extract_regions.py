@@ -573,19 +573,21 @@ def shard_index(index: GraphIndex, starts, stops, max_width: int = nv.GFM_MAX_WI
     np.add.at(mark, lo, 1)
     np.add.at(mark, hi, -1)
     keep = np.cumsum(mark)[:n] > 0
+    # the kept insertions' bases, re-based into the shard's own pool -- without a Python step per insertion (the mask
+    # was applied to the whole offset array inside the loop, O(sites x insertions): minutes per rank on a 1000-Genomes chromosome)
     ins_len = index.ins_len[keep]
-    ins_off = np.zeros(int(keep.sum()), dtype=np.int32)
-    pieces = []
-    at = 0
-    for k in np.flatnonzero(ins_len > 0).tolist():
-        o = int(index.ins_off[keep][k])
-        pieces.append(index.ins_bases[o:o + int(ins_len[k])])
-        ins_off[k] = at
-        at += int(ins_len[k])
+    old_off = index.ins_off[keep].astype(np.int64)
+    has = ins_len > 0
+    lens = ins_len[has].astype(np.int64)
+    new_off = np.cumsum(lens) - lens                                         # where each kept insertion starts in the new pool
+    ins_off = np.zeros(len(ins_len), dtype=np.int32)
+    ins_off[has] = new_off.astype(np.int32)
+    total = int(lens.sum())
+    src = np.repeat(old_off[has] - new_off, lens) + np.arange(total, dtype=np.int64) if total else np.zeros(0, dtype=np.int64)
     sub = GraphIndex(index.chrom, index.ref, index.pos[keep], index.n_alts[keep], index.alt_bases[keep],
                      index.alt_bits[keep] if index.alt_bits is not None else None, index.n_haplotypes, index.skipped,
                      del_len=index.del_len[keep], ins_len=ins_len, ins_off=ins_off,
-                     ins_bases=np.concatenate(pieces) if pieces else np.zeros(0, dtype=np.uint8))
+                     ins_bases=np.ascontiguousarray(index.ins_bases[src]) if total else np.zeros(0, dtype=np.uint8))
     sub.shard_of = (n, int(keep.sum()))
     return sub
 
@@ -858,7 +860,7 @@ def write_region_tsvs(index: GraphIndex, rows: ExtractedKmers, out_dir: str, lab
             rows.stop.data_ptr() if n else None, rows.strand.data_ptr() if n else None, rows.freq.data_ptr() if n else None,
             rows.is_ref.data_ptr() if n else None, rows.region.data_ptr() if n else None,
             rows.walk.data_ptr() if n else None, n, W, n_reg, nv.ptr(stops), c_labels, c_files, cname.encode(),
-            0 if node_paths else nv.GFM_TSV_NO_NODEPATH, int(threads), nv.ptr(seen), None, ctypes.byref(st)))
+            0 if node_paths else nv.GFM_TSV_NO_NODEPATH, int(threads), nv.ptr(seen), _stream_ptr(None), ctypes.byref(st)))
     del keep1, keep2
     rows.write_stats = st
     if own_seen:

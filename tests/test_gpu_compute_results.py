@@ -256,6 +256,45 @@ print('ROWS', 3000000, 'HITS', len(df), 'TEXT', text_bytes, 'RSS_DELTA', rss1 - 
     assert val["HBM_DELTA"] < 64 << 20, val            # (3e6 int32 scores would be 12 MB per motif -- and are not there)
 
 
+def test_a_grown_hit_list_survives_the_retry(tmp_path):
+    """a hit list that turns out too short is grown at finish and the scan run again -- the retry CLOSES the scan
+    first, and the closed scan's trim() dropped every list above GRAFIMO_SCAN_KEEP_BYTES: the second begin reserved the default
+    again and overflowed again ('run the scan again' on every attempt) once more than keep / 16 rows passed.  Here keep =
+    1 MiB (65 536 entries) and 1.6e6 rows of 3e6... pass p < 0.6: compute_results returns them all."""
+    import subprocess
+    import sys
+    from conftest import REF_DATA, ROOT
+    code = """
+import contextlib, io, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from grafimo_amd import synth
+from grafimo_amd.motif_ops import build_motif_meme_host
+from grafimo_amd.score_sequences import compute_results, compute_results_many
+from grafimo_amd.workflow import Findmotif
+from oracle import oracle as orc
+motif = build_motif_meme_host(os.path.join(%r, 'MA0139.1.meme'), 'unfrm_dst', 0.1, False)[0]
+d = sys.argv[1]
+batch = synth.make_batch(1100, 2000, 19, np.asarray(motif.count_matrix, dtype=np.float64), synth.seed_for(2))
+synth.write_tsv_dir(batch, d, regions_per_file=10)
+sm, bg = motif.dense_score_matrix(), motif.dense_bg()
+pmf = orc.comp_pval_mat(sm, bg)
+_, _, pv = orc.score_kmers(batch.kmers, sm, pmf, motif.min_val, motif.scale, float(motif.offset), sum_mode=1)
+for t in (0.6, 0.9):
+    wf = Findmotif(cores=8, threshold=t, recomb=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        df = compute_results(motif, d, False, wf)
+        many = compute_results_many([motif, motif], d, False, wf)
+    want = int((pv < t).sum())
+    print('T', t, 'HITS', len(df), 'WANT', want, 'MANY', len(many[0]), len(many[1]))
+    assert len(df) == want and len(many[0]) == want and len(many[1]) == want and want > 1200000
+"""
+    r = subprocess.run([sys.executable, "-c", code % (ROOT, REF_DATA), str(tmp_path)], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, GRAFIMO_SCAN_KEEP_BYTES=str(1 << 20)))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert r.stdout.count("HITS") == 2
+
+
 def test_sharded_entry_point_on_one_gpu(golden_json):
     """compute_results_sharded with the HIP backend and no process group == compute_results."""
     from grafimo_amd.distributed import compute_results_sharded
