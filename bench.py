@@ -886,6 +886,8 @@ def main():
     ap.add_argument("--no-config45", action="store_true", help="skip the roofline_config4 / roofline_config5 blocks of the default line")
     ap.add_argument("--slots", type=int, default=3,
                     help="buffer slots of the scan pipeline (2: the device waits for slot reuse; >= 3: the host does)")
+    ap.add_argument("--score-buffers", type=int, default=None,
+                    help="score arrays of the scan pipeline (default: one per slot); fewer than --slots: a shorter ring")
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostic: initialise torch.distributed and issue the collectives even with "
                          "one rank (exercises the N > 1 code path on a 1-GPU box)")
@@ -1004,7 +1006,7 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
         hit_cap = max(4096, n // 64)
         scanner = KmerScanner(dms[0], n, hit_capacity=hit_cap, device=dev, group=None, side_stream=side,
                               n_slots=args.slots, always_collective=args.force_dist,
-                              candidates=not args.no_candidates)
+                              candidates=not args.no_candidates, score_buffers=args.score_buffers)
         scanner.profile_tail = side
         units_per_step = n
         alg_bytes = n * (W + 4)

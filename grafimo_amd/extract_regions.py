@@ -1326,10 +1326,31 @@ def compute_results_from_graph_many(motifs: Sequence[Motif], graph, regions, deb
     for i, m in enumerate(motifs):
         by_width.setdefault(int(m.width), []).append(i)
     prep = _prep if _prep is not None else _prepare_entries(graph, regions, chrom_names, group, always_collective)
-    for _, idxs in by_width.items():
-        tabs = _fused_tables([motifs[i] for i in idxs], prep, debug, args_obj, None)
-        for i, t_ in zip(idxs, tabs):
-            out[i] = t_
+    # The widths out of step: once a width's records are on the host (fetch) the NEXT width's passes are enqueued -- the device
+    # enumerates width w + 1 while the host builds the tables of width w (a table is ~0.5 ms of host work per 9 000 hit rows,
+    # a width's passes ~0.5 ms of device work).  Every rank runs the same sequence: the collectives stay in step.
+    widths = list(by_width.values())
+    live: List[_FusedPass] = []
+    try:
+        cur = _FusedPass([motifs[i] for i in widths[0]], prep, debug, args_obj, None) if widths else None
+        if cur is not None:
+            live.append(cur)
+            cur.enqueue()
+        for k, idxs in enumerate(widths):
+            cur.fetch()
+            nxt = None
+            if k + 1 < len(widths):
+                nxt = _FusedPass([motifs[i] for i in widths[k + 1]], prep, debug, args_obj, None)
+                live.append(nxt)
+                nxt.enqueue()
+            for i, t_ in zip(idxs, cur.tables()):
+                out[i] = t_
+            cur.close()
+            live.remove(cur)
+            cur = nxt
+    finally:
+        for p_ in live:
+            p_.close()
     return out
 
 
@@ -1597,105 +1618,134 @@ def _frame_of_columns(motif, c, seqnames, no_qvalue: bool) -> pd.DataFrame:
     return pd.DataFrame(data, copy=False)
 
 
-def _fused_tables(motifs, prep: _FusedPrep, debug, args_obj, top_graphs):
-    """The fused pass for motifs of ONE width -> their tables (see compute_results_from_graph[_many])."""
-    from .resultsTmp import build_frame_sorted
-    from .score_sequences import print_scoring_msg
-    torch = _torch()
-    M = len(motifs)
-    dist = torch.distributed
-    group, world, rank, collective = prep.group, prep.world, prep.rank, prep.collective
-    graphs, spans = prep.graphs, prep.spans
-    threshold = float(args_obj.threshold)
-    no_qvalue, qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
-    no_reverse, recomb = bool(args_obj.noreverse), bool(args_obj.recomb)
-    W = int(motifs[0].width)
-    dev = graphs[0].device
-    dms = []
-    for m in motifs:                 # kept handles when these motifs were scored before (device.py); the same numbers twice in
-        dm = DeviceMotif.lease(m)    # one set: a handle of its own (a handle's workspace holds ONE histogram)
-        if any(dm is d for d in dms):
+class _FusedPass:
+    """The fused pass for motifs of ONE width in three steps, so that a motif set can run them out of step (see
+    compute_results_from_graph_many): enqueue() -- the scoring passes, the exchange of the histograms, q-tables, the hit rows'
+    columns, all on the device; fetch() -- counters and records to the host (the one synchronisation), a hit list that turned
+    out too short taken again; tables() -- the report tables from the records, host work only (and, under a process group, the
+    gather of the rows).  close() gives the motif handles back."""
+
+    def __init__(self, motifs, prep: _FusedPrep, debug, args_obj, top_graphs):
+        torch = _torch()
+        self.motifs, self.prep, self.debug, self.top_graphs = list(motifs), prep, debug, top_graphs
+        self.threshold = float(args_obj.threshold)
+        self.no_qvalue, self.qval_t = bool(args_obj.noqvalue), bool(args_obj.qvalueT)
+        self.no_reverse, self.recomb = bool(args_obj.noreverse), bool(args_obj.recomb)
+        self.W = int(motifs[0].width)
+        self.dev = prep.graphs[0].device
+        self.got = None
+        self.dms = []
+        for m in motifs:                 # kept handles when these motifs were scored before (device.py); the same numbers twice in
+            dm = DeviceMotif.lease(m)    # one set: a handle of its own (a handle's workspace holds ONE histogram)
+            if any(dm is d for d in self.dms):
+                dm.release()
+                dm = DeviceMotif.from_motif(m)
+            self.dms.append(dm)
+        try:
+            M = len(self.dms)
+            self.L = self.dms[0].L
+            self.cuts_p = [dm.pvalue_cutoff(self.threshold) for dm in self.dms]
+            # per motif [L hist | L q-table | cutoff, nrows]: kept per handle
+            self.works = [dm.fused_workspace(self.dev) for dm in self.dms] if not self.no_qvalue else None
+            # (M > 1: the histograms as the rows of ONE tensor -- one fill zeroes them, one all-reduce carries them)
+            self.hist_all = torch.empty((M, self.L), dtype=torch.int64, device=self.dev) if (self.works is not None and M > 1) else None
+            self.cap = max(getattr(g, "_fused_cap", 0) for g in prep.graphs) or (1 << 14)
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        for dm in self.dms:
             dm.release()
-            dm = DeviceMotif.from_motif(m)
-        dms.append(dm)
-    try:
-        L = dms[0].L
-        cuts_p = [dm.pvalue_cutoff(threshold) for dm in dms]
-        # per motif [L hist | L q-table | cutoff, nrows]: kept per handle; the histograms of several motifs cross the ranks
-        # as ONE [M, L] tensor
-        works = [dm.fused_workspace(dev) for dm in dms] if not no_qvalue else None
-        # (M > 1: the histograms as the rows of ONE tensor -- one fill zeroes them, one all-reduce carries them)
-        hist_all = None
-        if works is not None and M > 1:
-            hist_all = torch.empty((M, L), dtype=torch.int64, device=dev)
-        cap = max(getattr(g, "_fused_cap", 0) for g in graphs) or (1 << 14)
+        self.dms = []
+
+    def enqueue(self):
+        torch = _torch()
+        dist = torch.distributed
+        prep, M, L, dms = self.prep, len(self.dms), self.L, self.dms
         sp = _stream_ptr(None)                   # (torch's current stream, asked for once: 15 us a question)
+        hists = qtables = d_cuts = [None] * M
+        if self.works is not None:
+            hists = [self.hist_all[m] for m in range(M)] if self.hist_all is not None else [w_[:L] for w_ in self.works]
+            qtables = [w_[L:2 * L].view(torch.float64) for w_ in self.works]
+            d_cuts = [w_[2 * L:2 * L + 1].view(torch.int32)[:1] for w_ in self.works]
+            if self.hist_all is not None:
+                self.hist_all.zero_()
+            else:
+                for h_ in hists:
+                    h_.zero_()
+        for g in prep.graphs:                    # the slots of all M motifs in one tensor per graph: one fill for their counters
+            g.fused_buffers(self.cap, M - 1)
+            g.fused_zero(M)
+        for c0 in range(0, M, FUSED_GROUP):
+            sl = list(range(c0, min(M, c0 + FUSED_GROUP)))
+            for g, (s_, e_) in zip(prep.graphs, prep.spans):
+                g.score_many([dms[m] for m in sl], s_, e_, [self.cuts_p[m] for m in sl], [hists[m] for m in sl],
+                             forward_only=self.no_reverse, cap=self.cap, slots=sl, stream=sp, zero_ctl=False)
+        if prep.collective and self.works is not None:
+            # the one data-path exchange: BH ranks are global
+            dist.all_reduce(self.hist_all if self.hist_all is not None else hists[0], group=prep.group)
+        if self.works is not None:
+            if M == 1:
+                dms[0].qvalue_table(hists[0], self.threshold, self.qval_t, qtables[0], d_cuts[0], None, stream=sp)
+            else:
+                from .device import qvalue_table_multi
+                qvalue_table_multi(dms, hists, self.threshold, self.qval_t, qtables, d_cuts, stream=sp)
+        for g in prep.graphs:
+            for m in range(M):
+                g.annotate(cutoff=d_cuts[m] if self.qval_t else None, qtable=qtables[m], stream=sp, slot=m)
+
+    def fetch(self):
+        torch = _torch()
+        dist = torch.distributed
+        prep = self.prep
         while True:
-            hists = qtables = d_cuts = [None] * M
-            if works is not None:
-                hists = [hist_all[m] for m in range(M)] if hist_all is not None else [w_[:L] for w_ in works]
-                qtables = [w_[L:2 * L].view(torch.float64) for w_ in works]
-                d_cuts = [w_[2 * L:2 * L + 1].view(torch.int32)[:1] for w_ in works]
-                if hist_all is not None:
-                    hist_all.zero_()
-                else:
-                    for h_ in hists:
-                        h_.zero_()
-            for g in graphs:                     # the slots of all M motifs in one tensor per graph: one fill for their counters
-                g.fused_buffers(cap, M - 1)
-                g.fused_zero(M)
-            for c0 in range(0, M, FUSED_GROUP):
-                sl = list(range(c0, min(M, c0 + FUSED_GROUP)))
-                for g, (s_, e_) in zip(graphs, spans):
-                    g.score_many([dms[m] for m in sl], s_, e_, [cuts_p[m] for m in sl], [hists[m] for m in sl],
-                                 forward_only=no_reverse, cap=cap, slots=sl, stream=sp, zero_ctl=False)
-            if collective and works is not None:
-                # the one data-path exchange: BH ranks are global
-                dist.all_reduce(hist_all if hist_all is not None else hists[0], group=group)
-            if works is not None:
-                if M == 1:
-                    dms[0].qvalue_table(hists[0], threshold, qval_t, qtables[0], d_cuts[0], None, stream=sp)
-                else:
-                    from .device import qvalue_table_multi
-                    qvalue_table_multi(dms, hists, threshold, qval_t, qtables, d_cuts, stream=sp)
-            for g in graphs:
-                for m in range(M):
-                    g.annotate(cutoff=d_cuts[m] if qval_t else None, qtable=qtables[m], stream=sp, slot=m)
-            got = _fetch_fused(graphs, M)
+            got = _fetch_fused(prep.graphs, len(self.dms))
             # a hit list that turned out too short is taken again at the size the counters ask for -- on EVERY rank or
             # on none: the scoring pass holds a collective (ADVICE r3: a rank-local retry would leave the ranks' all-reduce
             # sequences out of step)
             need = max([c for per in got for c, _, _, _ in per] + [0])
-            if collective:
-                t_need = torch.tensor([need], dtype=torch.int64, device=dev)
-                dist.all_reduce(t_need, op=dist.ReduceOp.MAX, group=group)
+            if prep.collective:
+                t_need = torch.tensor([need], dtype=torch.int64, device=self.dev)
+                dist.all_reduce(t_need, op=dist.ReduceOp.MAX, group=prep.group)
                 need = int(t_need.item())
-            if need <= cap:
+            if need <= self.cap:
                 break
             if need > MAX_HITS:
                 # every hit becomes a 120-byte record on the host and a row of the report: refuse before the host's memory
                 # does (a threshold near 1 over windows with many variant sites reports every allele combination)
                 raise nv.NativeError(nv.GFM_ERR_OVERFLOW,
-                                     f"{need} rows pass the threshold {threshold}: more than GRAFIMO_MAX_HITS = {MAX_HITS}; "
+                                     f"{need} rows pass the threshold {self.threshold}: more than GRAFIMO_MAX_HITS = {MAX_HITS}; "
                                      f"use a stricter threshold or raise the limit")
-            cap = need + need // 4 + 1024
+            self.cap = need + need // 4 + 1024
+            self.enqueue()
         if any(o for per in got for _, _, o, _ in per):
-            raise nv.NativeError(nv.GFM_ERR_OVERFLOW, f"a window of width {W} holds more than 2^40 walks through its variant sites, or the "
+            raise nv.NativeError(nv.GFM_ERR_OVERFLOW, f"a window of width {self.W} holds more than 2^40 walks through its variant sites, or the "
                                                       f"regions hold more than 2^20 windows of more than 64 walks each (scan fewer regions at a time)")
+        self.got = got
+
+    def tables(self):
+        from .resultsTmp import build_frame_sorted
+        from .score_sequences import print_scoring_msg
+        torch = _torch()
+        dist = torch.distributed
+        prep, got, W, dev = self.prep, self.got, self.W, self.dev
+        group, world, rank = prep.group, prep.world, prep.rank
+        no_qvalue, top_graphs = self.no_qvalue, self.top_graphs
         n_rows = sum(n for _, n, _, _ in got[0])
         n_global = n_rows
-        if collective:
+        if prep.collective:
             tot = torch.tensor([n_rows], dtype=torch.int64, device=dev)
             dist.all_reduce(tot, group=group)
             n_global = int(tot.item())
         tables = []
-        for mi, motif in enumerate(motifs):
+        for mi, motif in enumerate(self.motifs):
             if rank == 0:
-                print_scoring_msg(motif, no_reverse, debug)
+                print_scoring_msg(motif, self.no_reverse, self.debug)
             if n_global == 0:
                 errmsg = "No result retrieved. Unable to proceed.\n"
                 errmsg += "\nAre you using the correct VGs and searching on the right chromosomes?\n"
-                exception_handler(ValueError, errmsg, debug)
+                exception_handler(ValueError, errmsg, self.debug)
             if not no_qvalue and rank == 0:
                 print("\nComputing q-values...\n")
             if rank == 0:
@@ -1704,8 +1754,9 @@ def _fused_tables(motifs, prep: _FusedPrep, debug, args_obj, top_graphs):
             # ---- the hit rows: filtered (--recomb), in report order (p-value, then the TSV rows' order: entry, window, walk,
             # strand), as columns -- one native call; with top_graphs one row per region leaves this rank (the top-hit-only
             # gather)
-            c = _hit_columns(dms[mi].ptable_host(), dms[mi].scale, dms[mi].offset, W, prep.entry_of, prep.region_base,
-                             [recs for _, _, _, recs in got[mi]], recomb, top_graphs is not None)
+            dm = self.dms[mi]
+            c = _hit_columns(dm.ptable_host(), dm.scale, dm.offset, W, prep.entry_of, prep.region_base,
+                             [recs for _, _, _, recs in got[mi]], self.recomb, top_graphs is not None)
             seqnames = prep.labels.take(c["region"])
             if world > 1:      # packed columns to rank 0 (one tensor gather), the hit rows' region labels beside them
                 from .distributed import gather_columns, gather_names
@@ -1717,11 +1768,10 @@ def _fused_tables(motifs, prep: _FusedPrep, debug, args_obj, top_graphs):
                     continue
                 # every rank's rows are sorted; their concatenation in rank order is sorted again (stable: equal p-values
                 # stay in rank = region order)
-                k = got_c["kmers"]
                 df = build_frame_sorted(
                     motif, seqnames=np.array([x for lst in label_lists for x in lst], dtype=object), starts=got_c["start"],
                     stops=got_c["stop"], strands=_STRAND_OBJ[got_c["strand"]], scores=got_c["logodds"], pvalues=got_c["pvalue"],
-                    qvalues=None if no_qvalue else got_c["qvalue"], seqs=_split_lines(k), frequencies=got_c["freq"],
+                    qvalues=None if no_qvalue else got_c["qvalue"], seqs=_split_lines(got_c["kmers"]), frequencies=got_c["freq"],
                     references=_REF_OBJ[got_c["ref"]], recomb=True)
             else:
                 df = _frame_of_columns(motif, c, seqnames, no_qvalue)
@@ -1730,9 +1780,17 @@ def _fused_tables(motifs, prep: _FusedPrep, debug, args_obj, top_graphs):
                 df = top_regions_table(df, top_graphs)
             tables.append(df)
         return tables
+
+
+def _fused_tables(motifs, prep: _FusedPrep, debug, args_obj, top_graphs):
+    """The fused pass for motifs of ONE width -> their tables (see compute_results_from_graph[_many])."""
+    p = _FusedPass(motifs, prep, debug, args_obj, top_graphs)
+    try:
+        p.enqueue()
+        p.fetch()
+        return p.tables()
     finally:
-        for dm in dms:
-            dm.release()
+        p.close()
 
 
 def dm_annotate_host(motif, dm, scaled):

@@ -20,11 +20,11 @@ HIT_SCORE_BITS = 20  # GFM_HIT_SCORE_BITS: hit entry = (row << 20) | scaled scor
 class ScanSlot:
     """One set of device buffers for a batch of up to n_rows k-mers."""
 
-    def __init__(self, dm: DeviceMotif, n_rows: int, hit_capacity: int, device):
+    def __init__(self, dm: DeviceMotif, n_rows: int, hit_capacity: int, device, scores=None):
         torch = _torch()
         self.n_rows = int(n_rows)
         self.hit_capacity = int(hit_capacity)
-        self.scores = torch.empty(self.n_rows, dtype=torch.int32, device=device)
+        self.scores = scores if scores is not None else torch.empty(self.n_rows, dtype=torch.int32, device=device)
         self.hist = torch.zeros(dm.L, dtype=torch.int64, device=device)
         self.qtable = torch.empty(dm.L, dtype=torch.float64, device=device)
         self.cutoff = torch.zeros(1, dtype=torch.int32, device=device)
@@ -67,7 +67,7 @@ class KmerScanner:
     def __init__(self, dm: DeviceMotif, n_rows: int, hit_capacity: Optional[int] = None,
                  device=None, group=None, n_slots: int = 3, side_stream: bool = True,
                  always_collective: bool = False, gather_group=None, host_paced: Optional[bool] = None,
-                 candidates: bool = True):
+                 candidates: bool = True, score_buffers: Optional[int] = None):
         torch = _torch()
         self.dm = dm
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -95,7 +95,15 @@ class KmerScanner:
         if self.collective and side_stream:
             self._gather_stream = torch.cuda.Stream(device=self.device, priority=-1)
         cap = int(hit_capacity) if hit_capacity is not None else int(n_rows)
-        self.slots = [ScanSlot(dm, n_rows, cap, self.device) for _ in range(n_slots)]
+        # `score_buffers` < n_slots: the int32 [n_rows] score arrays form a shorter ring than the slots (slot k writes array
+        # k % score_buffers): a batch's `slot.scores` then stays valid for score_buffers - 1 further enqueues only, while its
+        # histogram, q-table and hit list stay valid for n_slots - 1.  What it is for: a fourth slot gives the host a third step of
+        # slack against a tail that runs long, but a fourth 80 MB score array pushes the write-through stores' working set
+        # (3 x 80 MB fits the 256 MB Infinity Cache, 4 x 80 MB does not: the score kernel 83 -> 87 us, profiles/r06_step_gap.txt).
+        nb = n_slots if score_buffers is None else max(1, min(int(score_buffers), n_slots))
+        ring = [torch.empty(int(n_rows), dtype=torch.int32, device=self.device) for _ in range(nb)]
+        self.slots = [ScanSlot(dm, n_rows, cap, self.device, scores=ring[k % nb]) for k in range(n_slots)]
+        self._score_ring = nb
         # high priority: tail kernels are tiny and sit on the critical path of slot reuse
         self.side = torch.cuda.Stream(device=self.device, priority=-1) if side_stream else None
         self._side_p = self.side.cuda_stream if self.side is not None else None
@@ -189,6 +197,12 @@ class KmerScanner:
             else:
                 main.wait_event(slot.done)
         slot.used = True
+        if self._score_ring < len(self.slots) and (on_qvalue or self._regions is not None):
+            # a shorter score ring, and this batch's tail READS the scores (selection on q, per-region best hit): the batch that
+            # wrote this score array last must be through its tail before the score kernel overwrites it
+            prev = self.slots[(self._turn - 1 - self._score_ring) % len(self.slots)]
+            if prev.used and self._turn > self._score_ring:
+                prev.done.synchronize()
         # no zeroing on the critical path: the q-value kernel hands the histogram back cleared
         # (GFM_FLAG_CLEAR_HIST) and the hit list restarts through GFM_FLAG_RESET_HITS
         n = int(d_kmers.shape[0])

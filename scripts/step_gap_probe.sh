@@ -15,11 +15,8 @@ print('%-34s value %.4g  step %.2f us  kernel %.2f us  gap %.2f us  tail avg %.1
 }
 {
 run "slots 3, reserve 4 (default)" ""
+run "slots 4, score ring 3" "" --slots 4 --score-buffers 3
+run "slots 4, score ring 2" "" --slots 4 --score-buffers 2
+run "slots 3, score ring 2" "" --slots 3 --score-buffers 2
 run "slots 4, reserve 4" "" --slots 4
-run "slots 3, reserve 8" "GRAFIMO_RESERVE_CUS=8"
-run "slots 4, reserve 8" "GRAFIMO_RESERVE_CUS=8" --slots 4
-run "slots 3, reserve 12" "GRAFIMO_RESERVE_CUS=12"
-run "slots 3, reserve 16" "GRAFIMO_RESERVE_CUS=16"
-run "slots 3, reserve 0" "GRAFIMO_RESERVE_CUS=0"
-run "overlap off" "" --overlap off
 } | tee "$out"

@@ -182,12 +182,27 @@ def manifest_dir(tmp_path, monkeypatch):
     def fake_prep(manifest, group=None):
         return ("prep", tuple(e["chrom"] for e in manifest["entries"]), group)
 
-    def fake_tables(motifs, prep, debug, args_obj, top_graphs):
-        calls.append(([m.motif_id for m in motifs], prep, top_graphs))
-        return [pd.DataFrame({"motif_id": [m.motif_id], "width": [m.width]}) for m in motifs]
+    class FakePass:                       # xr._FusedPass: enqueue -> fetch -> tables -> close
+        def __init__(self, motifs, prep, debug, args_obj, top_graphs):
+            self.motifs, self.state = motifs, []
+            calls.append(([m.motif_id for m in motifs], prep, top_graphs))
+
+        def enqueue(self):
+            self.state.append("enqueue")
+
+        def fetch(self):
+            assert self.state == ["enqueue"]
+            self.state.append("fetch")
+
+        def tables(self):
+            assert self.state == ["enqueue", "fetch"]
+            return [pd.DataFrame({"motif_id": [m.motif_id], "width": [m.width]}) for m in self.motifs]
+
+        def close(self):
+            self.state.append("close")
 
     monkeypatch.setattr(xr, "_manifest_prep", fake_prep)
-    monkeypatch.setattr(xr, "_fused_tables", fake_tables)
+    monkeypatch.setattr(xr, "_FusedPass", FakePass)
     yield loc, wf, calls
     import shutil
     shutil.rmtree(loc, ignore_errors=True)
