@@ -802,7 +802,7 @@ def extra_config_block(cfg, dev, rank, args, side, steps=12):
     if cfg == 4:
         W = mots[0]["width"]
         d = synth.make_device_kmers(n, W, mots[0]["probs"], synth.seed_for(4, rank), dev)
-        sc = KmerScanner(dms[0], n, hit_capacity=n // 64, device=dev, side_stream=side, n_slots=args.slots)
+        sc = KmerScanner(dms[0], n, hit_capacity=n // 64, device=dev, side_stream=side, n_slots=args.slots, score_buffers=args.score_buffers or None)
         step = lambda: sc.enqueue(d, args.threshold, on_qvalue=True, want_qvalues=True)      # noqa: E731
         units, alg = n, n * (W + 4)
         kname = f"score_quad_kernel<{W}, 1>"
@@ -884,10 +884,13 @@ def main():
                     help="skip roofline_config3, sustained, peak_measured and extract (N=1 default config only)")
     ap.add_argument("--sustained-s", type=float, default=5.0, help="length of the sustained leg in seconds")
     ap.add_argument("--no-config45", action="store_true", help="skip the roofline_config4 / roofline_config5 blocks of the default line")
-    ap.add_argument("--slots", type=int, default=3,
-                    help="buffer slots of the scan pipeline (2: the device waits for slot reuse; >= 3: the host does)")
-    ap.add_argument("--score-buffers", type=int, default=None,
-                    help="score arrays of the scan pipeline (default: one per slot); fewer than --slots: a shorter ring")
+    ap.add_argument("--slots", type=int, default=4,
+                    help="buffer slots of the scan pipeline (2: the device waits for slot reuse; >= 3: the host does); default 4 "
+                         "with --score-buffers 2 (profiles/r06_step_gap2.txt: the host a third step ahead, the score arrays' "
+                         "160 MB inside the Infinity Cache)")
+    ap.add_argument("--score-buffers", type=int, default=2,
+                    help="score arrays of the scan pipeline; fewer than --slots: a shorter ring (a batch's scores stay valid for "
+                         "score_buffers - 1 further steps; 0 = one per slot)")
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostic: initialise torch.distributed and issue the collectives even with "
                          "one rank (exercises the N > 1 code path on a 1-GPU box)")
@@ -1006,7 +1009,7 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
         hit_cap = max(4096, n // 64)
         scanner = KmerScanner(dms[0], n, hit_capacity=hit_cap, device=dev, group=None, side_stream=side,
                               n_slots=args.slots, always_collective=args.force_dist,
-                              candidates=not args.no_candidates, score_buffers=args.score_buffers)
+                              candidates=not args.no_candidates, score_buffers=args.score_buffers or None)
         scanner.profile_tail = side
         units_per_step = n
         alg_bytes = n * (W + 4)
@@ -1157,7 +1160,7 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
         # (a) the config-3 shard: scores beyond any cache (477 MiB per launch, nt stores); the 1-GPU point of the curve
         n3 = 125_000_000
         d3 = synth.make_device_kmers(n3, W, mots[0]["probs"], synth.seed_for(3, rank), dev)
-        sc3 = KmerScanner(dms[0], n3, hit_capacity=n3 // 64, device=dev, side_stream=side, n_slots=args.slots)
+        sc3 = KmerScanner(dms[0], n3, hit_capacity=n3 // 64, device=dev, side_stream=side, n_slots=args.slots, score_buffers=args.score_buffers or None)
         for _ in range(3):
             sc3.enqueue(d3, args.threshold, want_qvalues=True)
         fence()

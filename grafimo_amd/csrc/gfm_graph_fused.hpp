@@ -77,7 +77,10 @@ struct HitRec {               // what graph_annotate_kernel writes per hit (120 
 constexpr long long kFusedMaxWalks = 1ll << 40;      // per window; beyond it the product of allele counts is refused
 constexpr int kTileWin = 64;                         // windows per tile = lanes of the wavefront that works on it
 constexpr int kFusedMaxWaves = 16;                   // wavefronts per workgroup of graph_score_kernel / graph_heavy_kernel (they share the histogram windows)
-constexpr int kWaveSites = 48;                       // site records staged per tile (more: read from global memory)
+#ifndef GFM_GRAPH_WAVE_SITES          // (lab builds vary it)
+#define GFM_GRAPH_WAVE_SITES 48
+#endif
+constexpr int kWaveSites = GFM_GRAPH_WAVE_SITES;     // site records staged per tile (more: read from global memory)
 constexpr int kWaveRefBytes = 144;                   // kTileWin + GFM_MAX_WIDTH - 1 reference bytes, in 8-byte loads
 constexpr int kFusedDelThreads = 64;
 constexpr int kFusedLayouts = 8;

@@ -418,10 +418,13 @@ extern "C" __attribute__((visibility("hidden"))) int gfm_motif_view_(gfm_motif_t
     gfm_motif::Window w = best_window(m, std::max(1, std::min(max_bins, m->nb)));
     if (small_bins > 0 && small_bins < w.bins) {
         const gfm_motif::Window ws = best_window(m, small_bins);
+#ifndef GFM_GRAPH_SMALL_MASS          // (lab builds vary it: scripts/lab_build.sh <tag> -DGFM_GRAPH_SMALL_MASS=0.99)
+#define GFM_GRAPH_SMALL_MASS 0.9
+#endif
 #ifdef GFM_LAB
-        static const double need = [] { const char *e = std::getenv("GRAFIMO_FUSED_SMALL_MASS"); return e ? atof(e) : 0.9; }();
+        static const double need = [] { const char *e = std::getenv("GRAFIMO_FUSED_SMALL_MASS"); return e ? atof(e) : GFM_GRAPH_SMALL_MASS; }();
 #else
-        constexpr double need = 0.9;
+        constexpr double need = GFM_GRAPH_SMALL_MASS;
 #endif
         if (ws.mass >= need) w = ws;
     }

@@ -1839,7 +1839,10 @@ namespace {
 // workgroup per CU, 0.105 / 0.18 / 0.25 / 0.44 ms with the small one, round 4).  Two and three motifs: windows that leave
 // the workgroup its wavefronts.
 constexpr int kFusedMaxBins[kMaxMM] = {16384, 8000, 5400};
-constexpr int kFusedSmallBins[kMaxMM] = {8000, 6000, 5000};
+#ifndef GFM_GRAPH_SMALL_BINS1         // (lab builds vary it)
+#define GFM_GRAPH_SMALL_BINS1 8000
+#endif
+constexpr int kFusedSmallBins[kMaxMM] = {GFM_GRAPH_SMALL_BINS1, 6000, 5000};
 constexpr size_t kCuLdsBytes = 160 * 1024;
 
 // first site at or behind `target`, searched from a hint (tiles come in ascending order: a step or two)

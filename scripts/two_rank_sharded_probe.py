@@ -77,6 +77,50 @@ def worker(rank, world, port, seqdir, out):
                     bad.append((kw, name))
         else:
             assert one is None and all(x is None for x in many)
+    # ---- the same through scan_graph's MANIFEST and the sharded entry points (the unchanged call sequence of grafimo.findmotif
+    # under a process group): rank 0 leaves the manifest, every rank reads it, cuts its shard of the graph and of the regions,
+    # the motif set goes through compute_results_many_sharded -> compute_results_from_graph_many
+    from grafimo_amd import extract_regions as xr
+    from grafimo_amd.distributed import compute_results_many_sharded as many_sharded, compute_results_sharded as one_sharded
+    xr.drop_graph_cache()                           # (the shards of the sections above)
+    box = [None]
+    if rank == 0:
+        gdir = os.path.join(seqdir, "graphs")
+        os.makedirs(gdir, exist_ok=True)
+        idx.save(os.path.join(gdir, "chr22"))
+        bed = os.path.join(seqdir, "regions.bed")
+        with open(bed, "w") as fh:
+            fh.write("".join(f"chr22\t{s_}\t{e_}\n" for s_, e_ in regions))
+        os.environ["GRAFIMO_SCAN_OUTPUT"] = "manifest"
+        with contextlib.redirect_stdout(io.StringIO()):
+            box[0] = xr.scan_graph({19}, Findmotif(graph_genome_dir=gdir, bedfile=bed, chroms_prefix="chr"), True)
+    dist.broadcast_object_list(box, src=0)
+    loc = box[0]
+    wf = Findmotif(cores=2, threshold=1e-3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        many = many_sharded([ctcf, ctcf2, syn], loc, True, wf)
+        one = one_sharded(syn, loc, True, wf)
+    mine = [g for g in xr._SHARD_GRAPHS.values() if g._h is not None]
+    assert len(mine) == 1 and 0 < len(mine[0].index.pos) < len(idx.pos), "this rank holds a shard of the manifest's graph"
+    if rank == 0:
+        full = DeviceGraph(idx)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref = [compute_results_from_graph(m, full, reg, True, wf, group=solo) for m in (ctcf, ctcf2, syn)]
+        full.close()
+        for got, exp, name in ((many[0], ref[0], "manifest many[0]"), (many[1], ref[1], "manifest many[1]"), (many[2], ref[2], "manifest many[2]"),
+                               (one, ref[2], "manifest one")):
+            a, b = table_key(got), table_key(exp)
+            same = len(a) == len(b) and len(a) > 0 and all((a[c].astype(str) == b[c].astype(str)).all() for c in b.columns if b[c].dtype.kind != "f") and \
+                all(np.allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-12, atol=0) for c in b.columns if b[c].dtype.kind == "f")
+            print(f"{name}: {len(a)} rows, the manifest under two ranks == one process with the whole graph: {same}", flush=True)
+            if not same:
+                bad.append(("manifest", name))
+    else:
+        assert one is None and all(x is None for x in many)
+    dist.barrier()
+    if rank == 0:
+        import shutil
+        shutil.rmtree(loc, ignore_errors=True)
     if rank == 0 and bad:
         open(out, "w").write(str(bad))
     dist.barrier()

@@ -662,6 +662,9 @@ def test_two_ranks_on_one_gpu_through_the_sharded_entry_points():
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     assert r.stdout.count("two ranks == one process: True") == 9
     assert r.stdout.count("ranks holding shards of the graph == one process with all of it: True") == 8
+    # ... and scan_graph's manifest through compute_results[_many]_sharded: disjoint graph shards per rank, the motif set in
+    # one enumeration per rank
+    assert r.stdout.count("the manifest under two ranks == one process with the whole graph: True") == 4
 
 
 def test_hit_columns_from_the_kept_text_and_from_the_files_agree(tmp_path, monkeypatch):
