@@ -78,7 +78,7 @@ struct gfm_motif {
     bool sel_valid = false;
     HitCtl *d_ctl = nullptr;
     unsigned call_no = 0;           // score calls: HitCtl slot call_no % kCtlSlots, workspace call_no % kWorkspaces
-    // GFM_FLAG_CALLER_ORDERS_REUSE is a promise about the call four back ON THIS HANDLE, which a pipelined caller can
+    // GFM_FLAG_CALLER_ORDERS_REUSE is a promise about the call kWorkspaces back ON THIS HANDLE, which a pipelined caller can
     // only keep for its own calls: the flag is honoured when the kWorkspaces calls before this one came from the
     // same (stream, tail stream) pair, and ignored (the library waits on its own event) when another user of the
     // handle was in between.
@@ -853,7 +853,7 @@ GFM_API int gfm_score_kmers(gfm_motif_t m, const uint8_t *d_kmers, int64_t n, in
     const int ws = (int)(k % (unsigned)kWorkspaces), slot = (int)(k % (unsigned)kCtlSlots);
     const int ws_prev = (int)((k + kWorkspaces - 1) % (unsigned)kWorkspaces);
     const bool reset = (flags & GFM_FLAG_RESET_HITS) != 0;
-    // workspace `ws` was last used by call k-4: its post kernel must be done.  Appending to a
+    // workspace `ws` was last used by call k - kWorkspaces: its post kernel must be done.  Appending to a
     // hit list additionally needs the count published by call k-1.
     const bool same_owner = st == m->last_st && tail == m->last_tail;
     const bool caller_orders = (flags & GFM_FLAG_CALLER_ORDERS_REUSE) && same_owner && m->same_pair_run >= (unsigned)kWorkspaces;

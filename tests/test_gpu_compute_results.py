@@ -456,11 +456,12 @@ def test_two_ranks_on_one_gpu_through_the_scanner():
     assert r.stdout.count("two ranks == one process: True") == 2
 
 
-@pytest.mark.parametrize("n_slots", [2, 3, 4])
-def test_scanner_slot_rings_under_pipelining(golden_motifs, n_slots):
+@pytest.mark.parametrize("n_slots,ring", [(2, None), (3, None), (4, 2), (6, 2), (8, 3), (9, None)])
+def test_scanner_slot_rings_under_pipelining(golden_motifs, n_slots, ring):
     """Batches enqueued back to back without a host synchronisation in between (two slots: the device orders
-    slot reuse; three or four: the host paces it and the main stream carries score kernels only).  Thirteen
-    batches walk the library's workspace ring (4) and hit-counter ring (8) more than once; thresholds
+    slot reuse; three to eight: the host paces it and the main stream carries score kernels only; nine: more than the
+    library's workspace ring, which then orders the reuse itself; `ring`: the score arrays as a shorter ring than the
+    slots).  Forty-one batches walk the library's workspace ring (8) and hit-counter ring (16) more than twice; thresholds
     alternate between one that makes every wave flush its hit queue mid-run and selective ones, with and
     without a q-value threshold.  Every batch must equal the oracle's scores / histogram-derived q-table."""
     from grafimo_amd.device import DeviceMotif
@@ -474,14 +475,15 @@ def test_scanner_slot_rings_under_pipelining(golden_motifs, n_slots):
     rng = np.random.default_rng(5)
     n = 60_000
     batches = []
-    for b in range(13):
+    for b in range(41):
         km = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(n - 7 * b, 19))
         km[rng.integers(0, len(km), 40), rng.integers(0, 19, 40)] = ord("N")
         batches.append(km)
     d_batches = [torch.from_numpy(k).to(dev) for k in batches]
     plan = [(1.0, False), (1e-2, False), (0.3, True), (1e-3, False), (1.0, False), (0.5, True), (1e-2, False)]
-    sc = KmerScanner(dm, n, device=dev, n_slots=n_slots)
+    sc = KmerScanner(dm, n, device=dev, n_slots=n_slots, score_buffers=ring)
     assert sc.host_paced == (n_slots >= 3)
+    assert len({s_.scores.data_ptr() for s_ in sc.slots}) == (ring or n_slots)
     b = 0
     while b < len(batches):
         group = list(range(b, min(b + n_slots, len(batches))))
