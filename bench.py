@@ -884,13 +884,12 @@ def main():
                     help="skip roofline_config3, sustained, peak_measured and extract (N=1 default config only)")
     ap.add_argument("--sustained-s", type=float, default=5.0, help="length of the sustained leg in seconds")
     ap.add_argument("--no-config45", action="store_true", help="skip the roofline_config4 / roofline_config5 blocks of the default line")
-    ap.add_argument("--slots", type=int, default=4,
-                    help="buffer slots of the scan pipeline (2: the device waits for slot reuse; >= 3: the host does); default 4 "
-                         "with --score-buffers 2 (profiles/r06_step_gap2.txt: the host a third step ahead, the score arrays' "
-                         "160 MB inside the Infinity Cache)")
-    ap.add_argument("--score-buffers", type=int, default=2,
-                    help="score arrays of the scan pipeline; fewer than --slots: a shorter ring (a batch's scores stay valid for "
-                         "score_buffers - 1 further steps; 0 = one per slot)")
+    ap.add_argument("--slots", type=int, default=3,
+                    help="buffer slots of the scan pipeline (2: the device waits for slot reuse; >= 3: the host does)")
+    ap.add_argument("--score-buffers", type=int, default=0,
+                    help="score arrays of the scan pipeline (0 = one per slot); fewer than --slots: a shorter ring (a batch's "
+                         "scores stay valid for score_buffers - 1 further steps).  Measured and not the default: "
+                         "profiles/r06_step_gap*.txt")
     ap.add_argument("--force-dist", action="store_true",
                     help="diagnostic: initialise torch.distributed and issue the collectives even with "
                          "one rank (exercises the N > 1 code path on a 1-GPU box)")

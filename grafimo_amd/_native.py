@@ -29,7 +29,7 @@ GFM_MAX_WIDTH = 64
 GFM_BEST_ROW_BITS = 44
 GFM_GRAPH_FORWARD_ONLY = 1
 GFM_TSV_NO_NODEPATH = 1
-GFM_WORKSPACE_RING = 8
+GFM_WORKSPACE_RING = 4
 GFM_HITS_DROP_ZERO_FREQ = 1
 GFM_HITS_FIRST_PER_REGION = 2
 ABI_VERSION = 11

@@ -70,7 +70,11 @@ class DeviceMotif:
     # (compute_results, compute_results_from_graph): creating the handle -- one device allocation, the pair tables, the
     # DP or the upload of its result, the tail table -- and destroying it again was 0.65 ms of a 3 ms call
     _kept = OrderedDict()          # key -> [DeviceMotif, leases]
-    _KEEP = 8
+    # handles nobody holds that are kept for the next call, least recently used out first.  64: a motif set is scored motif after
+    # motif and again (grafimo.findmotif per chromosome set; BASELINE configs[4] has 50 PWMs) -- with 8, every call of a 50-motif
+    # set created and destroyed 50 handles, 0.5 ms each, a quarter of the call.  A handle holds ~80 MB of scoring workspace;
+    # GRAFIMO_MOTIF_CACHE sets another number, DeviceMotif.drop_kept() frees them.
+    _KEEP = max(1, int(__import__("os").environ.get("GRAFIMO_MOTIF_CACHE", 64)))
 
     @classmethod
     def lease(cls, motif, use_motif_pmf=True) -> "DeviceMotif":

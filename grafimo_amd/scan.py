@@ -117,9 +117,9 @@ class KmerScanner:
         self.host_paced = (n_slots >= 3) if host_paced is None else bool(host_paced)
         if self.host_paced and n_slots < 2:
             raise ValueError("host-paced slot reuse needs at least two slots")
-        # either way batch k - 8 is done when batch k is enqueued (n_slots <= 8): the library's workspace
-        # ring of eight is free again without its own event wait.  (The rings belong to the DeviceMotif, not to this
-        # scanner: the library honours the flag only while the eight calls before this one on the handle came from
+        # either way batch k - GFM_WORKSPACE_RING is done when batch k is enqueued (n_slots <= the ring, 4): the library's
+        # workspace ring is free again without its own event wait.  (The rings belong to the DeviceMotif, not to this
+        # scanner: the library honours the flag only while the ring's worth of calls before this one on the handle came from
         # the same stream pair, and orders the reuse itself when another scanner or a batched call was in between.)
         self._reuse_flag = _nv.GFM_FLAG_CALLER_ORDERS_REUSE if n_slots <= _nv.GFM_WORKSPACE_RING else 0
         # q-value threshold: select from the p < t candidates the score kernel collects (enqueue) instead of

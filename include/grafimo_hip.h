@@ -45,14 +45,14 @@ extern "C" {
 #define GFM_FLAG_RESET_HITS 1u /* start the hit list at 0 instead of appending at *d_hit_count */
 #define GFM_FLAG_CLEAR_HIST 2u /* gfm_qvalue_table: zero the histogram after reading it        */
 /* gfm_score_kmers with a tail stream: the caller guarantees (by its own stream order, or because the
- * host has seen it complete) that the tail work of the call GFM_WORKSPACE_RING (eight) before this one on the same handle
+ * host has seen it complete) that the tail work of the call GFM_WORKSPACE_RING (four) before this one on the same handle
  * has finished -- the handle's scoring workspace is a ring of that many -- so the library need not make the main
  * stream wait for it (an event wait is a barrier packet in front of the score kernel: several
- * microseconds of an idle GPU per step).  The library honours the flag only while the eight calls before this one
+ * microseconds of an idle GPU per step).  The library honours the flag only while the GFM_WORKSPACE_RING calls before this one
  * on the handle were made with the same (stream, tail_stream) pair -- a second user of the handle in between (another
  * scanner, a batched call) makes it fall back to its own event wait. */
 #define GFM_FLAG_CALLER_ORDERS_REUSE 4u
-#define GFM_WORKSPACE_RING 8
+#define GFM_WORKSPACE_RING 4
 /* a hit-list entry packs the global row id and the row's scaled score:
  * entry = (row << GFM_HIT_SCORE_BITS) | score   (score <= 1000*64 < 2^20) */
 #define GFM_HIT_SCORE_BITS 20

@@ -459,9 +459,9 @@ def test_two_ranks_on_one_gpu_through_the_scanner():
 @pytest.mark.parametrize("n_slots,ring", [(2, None), (3, None), (4, 2), (6, 2), (8, 3), (9, None)])
 def test_scanner_slot_rings_under_pipelining(golden_motifs, n_slots, ring):
     """Batches enqueued back to back without a host synchronisation in between (two slots: the device orders
-    slot reuse; three to eight: the host paces it and the main stream carries score kernels only; nine: more than the
+    slot reuse; three and more: the host paces it and the main stream carries score kernels only; more than four: more than the
     library's workspace ring, which then orders the reuse itself; `ring`: the score arrays as a shorter ring than the
-    slots).  Forty-one batches walk the library's workspace ring (8) and hit-counter ring (16) more than twice; thresholds
+    slots).  Forty-one batches walk the library's workspace ring (4) and hit-counter ring (8) many times; thresholds
     alternate between one that makes every wave flush its hit queue mid-run and selective ones, with and
     without a q-value threshold.  Every batch must equal the oracle's scores / histogram-derived q-table."""
     from grafimo_amd.device import DeviceMotif
