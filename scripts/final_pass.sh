@@ -3,7 +3,7 @@
 # fused extraction -> scoring kernels), PMC passes (score kernel; FETCH / WRITE of the fused kernels), the ingest probe.
 #   scripts/final_pass.sh <tag>      (outputs under gpurun_out/final_<tag>/)
 set -u
-tag="${1:-r05}"
+tag="${1:-r06}"
 root="$GRAFT_REPO_ROOT"
 out="$root/gpurun_out/final_$tag"
 mkdir -p "$out"

@@ -31,6 +31,14 @@ class SynMotif:
 def check_fused(g, S, E, W, got, seed):
     """every row of `got` (already checked against the brute force) comes out of the fused path with its coordinates,
     haplotype count, ref flag and the score of its k-mer"""
+    # THREE motifs over the same (graph, region, width): a plan's first call lists the windows that touch an insertion / deletion,
+    # its second -- the item count is back -- also stores their walks, from the third on graph_score_kernel scores them from that
+    # cache and no deletion kernel runs (gfm_graph_fused.hpp: LwMeta): every stage against the same brute-force rows
+    for k in range(3):
+        _check_fused_once(g, S, E, W, got, seed + 7919 * k)
+
+
+def _check_fused_once(g, S, E, W, got, seed):
     from grafimo_amd.extract_regions import compute_results_from_graph
     from grafimo_amd.workflow import Findmotif
     m = SynMotif(W, seed)
