@@ -1599,18 +1599,6 @@ def _hit_columns(ptable: np.ndarray, scale: int, offset: float, W: int, entry_of
     return {k: v[:n] for k, v in c.items()}
 
 
-_COLUMN_POOL = None
-
-
-def _column_pool():
-    """one helper thread for gfm_graph_hit_columns (see _FusedPass.tables)"""
-    global _COLUMN_POOL
-    if _COLUMN_POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _COLUMN_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="gfm-columns")
-    return _COLUMN_POOL
-
-
 def _frame_of_columns(motif, c, seqnames, no_qvalue: bool) -> pd.DataFrame:
     """The report table (column names and order of resultsTmp.py:270-301) from columns that are final -- filtered, in
     report order -- without a per-row Python step: the strings of a column are gathered from the few distinct ones, the
@@ -1751,14 +1739,6 @@ class _FusedPass:
             dist.all_reduce(tot, group=group)
             n_global = int(tot.item())
         tables = []
-        # the native half of every motif's table (filter, order, columns: the GIL is released inside the call) runs on a helper
-        # thread one motif AHEAD of the Python half (strings, DataFrame) on this one
-        def columns_of(mi):
-            dm = self.dms[mi]
-            return _hit_columns(dm.ptable_host(), dm.scale, dm.offset, W, prep.entry_of, prep.region_base,
-                                [recs for _, _, _, recs in got[mi]], self.recomb, top_graphs is not None)
-
-        ahead = _column_pool().submit(columns_of, 0) if (n_global and self.motifs) else None
         for mi, motif in enumerate(self.motifs):
             if rank == 0:
                 print_scoring_msg(motif, self.no_reverse, self.debug)
@@ -1774,8 +1754,9 @@ class _FusedPass:
             # ---- the hit rows: filtered (--recomb), in report order (p-value, then the TSV rows' order: entry, window, walk,
             # strand), as columns -- one native call; with top_graphs one row per region leaves this rank (the top-hit-only
             # gather)
-            c = ahead.result()
-            ahead = _column_pool().submit(columns_of, mi + 1) if mi + 1 < len(self.motifs) else None
+            dm = self.dms[mi]
+            c = _hit_columns(dm.ptable_host(), dm.scale, dm.offset, W, prep.entry_of, prep.region_base,
+                             [recs for _, _, _, recs in got[mi]], self.recomb, top_graphs is not None)
             seqnames = prep.labels.take(c["region"])
             if world > 1:      # packed columns to rank 0 (one tensor gather), the hit rows' region labels beside them
                 from .distributed import gather_columns, gather_names
