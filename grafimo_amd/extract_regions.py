@@ -253,10 +253,20 @@ class GraphIndex:
                       n_alts=self.n_alts, alt_bases=self.alt_bases, n_haplotypes=np.int64(self.n_haplotypes),
                       skipped=np.int64(self.skipped), ins_len=self.ins_len, ins_off=self.ins_off, ins_bases=self.ins_bases,
                       alt_bits=self.alt_bits if self.alt_bits is not None else np.empty(0, np.uint64))
-        if compressed:
-            np.savez_compressed(path, **arrays)
-        else:
-            _save_npz_aligned(path, arrays)
+        # written beside its place and moved there: a file that is being read through a mapping (load() of this very path, in this
+        # process or another) must not be truncated under the reader -- the rename leaves the old pages to those who mapped them
+        tmp = f"{path}.{os.getpid()}.tmp"
+        try:
+            if compressed:
+                with open(tmp, "wb") as fh:
+                    np.savez_compressed(fh, **arrays)
+            else:
+                _save_npz_aligned(tmp, arrays)
+            os.replace(tmp, path)
+        except BaseException:
+            with contextlib.suppress(OSError):
+                os.remove(tmp)
+            raise
         return path
 
     @classmethod

@@ -124,3 +124,37 @@ def test_the_tutorial_command_line(tmp_path, mygenome):
     for c in ("score", "p-value", "q-value"):
         np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-9)
     assert sorted(os.listdir(out)) == ["grafimo_out.gff", "grafimo_out.html", "grafimo_out.tsv"]
+
+
+def test_the_command_line_with_a_motif_set(tmp_path, mygenome):
+    """`python -m grafimo_amd -d DIR -b BED -m A.meme B.meme C.meme -t 0.05 -o OUT`: the motif set is scored in ONE
+    compute_results_many call over the manifest its scan_graph left (the CLI held the whole list and still called
+    compute_results per motif -- the shared enumeration was unreachable from any command line).  Every motif's report == the
+    report of a run with that motif alone == the oracle's rows."""
+    from grafimo_amd.motif_ops import get_motif_pwm
+    from grafimo_amd.workflow import Findmotif
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    files = [os.path.join(REF_DATA, f) for f in ("example.meme", "MA0605.2.meme", "MA0035.4.meme")]      # widths 15, 12, 11
+    out = tmp_path / "set"
+    cmd = [sys.executable, "-m", "grafimo_amd", "-d", mygenome + "/", "-b", BED, "-t", "0.05", "-o", str(out), "-j", "2", "-m"] + files
+    done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    assert done.stdout.count("Scanned sequences:") == 3
+    motifs = [get_motif_pwm(f, Findmotif(threshold=0.05), 1, True, pvalue_matrix=False)[0] for f in files]
+    names = sorted(os.listdir(out))
+    assert names == sorted(f"grafimo_out_{m.motif_id}.{ext}" for m in motifs for ext in ("tsv", "html", "gff")), names
+    key = ["sequence_name", "start", "stop", "strand", "matched_sequence"]
+    for f, m in zip(files, motifs):
+        report = pd.read_csv(out / f"grafimo_out_{m.motif_id}.tsv", sep="\t", index_col=0)
+        alone = tmp_path / ("alone_" + m.motif_id)
+        one = subprocess.run([sys.executable, "-m", "grafimo_amd", "-d", mygenome + "/", "-b", BED, "-t", "0.05", "-o", str(alone),
+                              "-j", "2", "-m", f], env=env, capture_output=True, text=True, timeout=600)
+        assert one.returncode == 0, one.stderr[-2000:]
+        assert (alone / "grafimo_out.tsv").read_bytes() == (out / f"grafimo_out_{m.motif_id}.tsv").read_bytes(), m.motif_id
+        exp = _oracle_tables(tmp_path / "oracle", m, ["x", "y"], threshold=0.05)
+        assert len(report) == len(exp) > 10, (m.motif_id, len(report), len(exp))
+        a, b = report.sort_values(key).reset_index(drop=True), exp.sort_values(key).reset_index(drop=True)
+        for c in key + ["haplotype_frequency", "reference"]:
+            assert (a[c].astype(str) == b[c].astype(str)).all(), (m.motif_id, c)
+        for c in ("score", "p-value", "q-value"):
+            np.testing.assert_allclose(a[c].to_numpy(float), b[c].to_numpy(float), rtol=1e-9)

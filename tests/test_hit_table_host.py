@@ -152,6 +152,10 @@ def test_index_file_is_mapped_not_read(tmp_path):
     assert os.path.getsize(pc) < os.path.getsize(p)
     k = xr.GraphIndex.load(pc)
     assert np.array_equal(k.alt_bits, idx.alt_bits) and np.array_equal(k.ref, idx.ref) and k._mapping is None
+    # saving over a file that is mapped (the index loaded from this very path) must not pull the pages from under the reader
+    again = xr.GraphIndex.load(p)
+    assert again.save(p) == p and np.array_equal(again.alt_bits, idx.alt_bits) and np.array_equal(j.ref, idx.ref)
+    assert np.array_equal(xr.GraphIndex.load(p).alt_bits, idx.alt_bits) and not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
     no_bits = xr.GraphIndex("1", idx.ref, idx.pos, idx.n_alts, idx.alt_bases, None, 0)
     assert xr.GraphIndex.load(no_bits.save(str(tmp_path / "nb"))).alt_bits is None
 
