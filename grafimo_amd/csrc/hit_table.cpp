@@ -73,6 +73,19 @@ GFM_API int gfm_graph_hit_columns(const double *h_ptable, int32_t table_len, int
         static thread_local std::vector<Key> keys, sorted;
         static thread_local std::vector<int32_t> canon;
         static thread_local std::vector<int64_t> at, put;
+        // ... but a call of millions of rows (GRAFIMO_MAX_HITS: 2^23) does not leave half a gigabyte behind: what is larger than
+        // ~32 MB is given back when the call returns
+        struct Trim {
+            ~Trim()
+            {
+                constexpr size_t kKeepKeys = (size_t)1 << 20;
+                if (keys.capacity() > kKeepKeys) std::vector<Key>().swap(keys);
+                if (sorted.capacity() > kKeepKeys) std::vector<Key>().swap(sorted);
+                if (canon.capacity() > 8 * kKeepKeys) std::vector<int32_t>().swap(canon);
+                if (at.capacity() > 4 * kKeepKeys) std::vector<int64_t>().swap(at);
+                if (put.capacity() > 4 * kKeepKeys) std::vector<int64_t>().swap(put);
+            }
+        } trim;
         keys.clear();
         keys.reserve((size_t)total);
         int32_t lo_s = INT32_MAX, hi_s = -1;

@@ -1046,7 +1046,10 @@ def _scan_output_mode(frame) -> str:
                 for key, v in list(space.items()):
                     if deep and isinstance(v, types.ModuleType):
                         for name in MANIFEST_CONSUMERS:
-                            k = _is_consumer(name, getattr(v, name, None))
+                            try:                     # (a module whose attribute lookup has side effects or fails: not a consumer)
+                                k = _is_consumer(name, v.__dict__.get(name))
+                            except Exception:
+                                k = None
                             if k:
                                 verdicts.add(k)
                     elif not deep:
