@@ -1679,9 +1679,10 @@ class _FusedPass:
         sp = _stream_ptr(None)                   # (torch's current stream, asked for once: 15 us a question)
         hists = qtables = d_cuts = [None] * M
         if self.works is not None:
-            hists = [self.hist_all[m] for m in range(M)] if self.hist_all is not None else [w_[:L] for w_ in self.works]
-            qtables = [w_[L:2 * L].view(torch.float64) for w_ in self.works]
-            d_cuts = [w_[2 * L:2 * L + 1].view(torch.int32)[:1] for w_ in self.works]
+            views = [dm.fused_views(self.dev) for dm in dms]
+            hists = [self.hist_all[m] for m in range(M)] if self.hist_all is not None else [v_[0] for v_ in views]
+            qtables = [v_[1] for v_ in views]
+            d_cuts = [v_[2] for v_ in views]
             if self.hist_all is not None:
                 self.hist_all.zero_()
             else:
