@@ -409,3 +409,81 @@ def write_region_tsvs_reference(index, rows, out_dir, labels=None, chrom=None):
             fh.writelines(lines)
         paths.append(path)
     return paths
+
+
+def snp_graph_score_histogram(idx, regions, W, sm, L, min_val, forward_only=False):
+    """TEST INFRASTRUCTURE (no HIP, no per-row Python): the score histogram of ALL rows `vg find -K W -E` would print for the
+    regions of a graph of substitution sites only -- every window start p with p + W inside the region and the reference, every
+    combination of the alleles of the sites in [p, p + W), both strands -- counted with numpy: the reference window's score by a
+    sliding window over the region's bases, the walks by adding per-site score differences combination by combination
+    (score_sequences.py:372-396: score = sum over j of sm[code(kmer[j]), j]; the reverse strand holds comp(base j) at W-1-j;
+    an invalid base makes the whole k-mer score min_val).  Pinned against the walk enumerator + the C oracle on small graphs
+    (tests/test_extract_host.py); used at BASELINE configs[1] scale where the enumerator cannot go (tests/test_gpu_fused.py).
+    -> (hist int64 [L], rows)"""
+    import itertools
+    assert not (np.asarray(idx.del_len) > 0).any() and not (np.asarray(idx.ins_len) > 0).any()
+    sm = np.asarray(sm, dtype=np.int64).reshape(4, W)
+    code_of = np.full(256, -1, dtype=np.int64)
+    for i, c in enumerate(b"ACGT"):
+        code_of[c] = i
+    ref = code_of[np.asarray(idx.ref, dtype=np.uint8)]
+    pos = np.asarray(idx.pos, dtype=np.int64)
+    n_alts = np.asarray(idx.n_alts, dtype=np.int64)
+    alt = code_of[np.asarray(idx.alt_bases, dtype=np.uint8)]          # [V, 3]
+    hist = np.zeros(L, dtype=np.int64)
+    rows = 0
+    ar = np.arange(W)
+    # every window start of every region, in chunks: all regions at once (a Python step per REGION was 30 ms of numpy calls)
+    lo = np.maximum(np.asarray([r[0] for r in regions], dtype=np.int64), 0)
+    hi = np.minimum(np.asarray([r[1] for r in regions], dtype=np.int64), len(ref))
+    n_win = np.maximum(hi - W - lo + 1, 0)
+    starts = np.repeat(lo, n_win) + (np.arange(int(n_win.sum())) - np.repeat(np.cumsum(n_win) - n_win, n_win))
+    for c0 in range(0, len(starts), 1 << 18):
+        p = starts[c0:c0 + (1 << 18)]
+        win = ref[p[:, None] + ar[None, :]]                                         # [n, W] codes
+        bad0 = (win < 0).sum(1)
+        safe = np.where(win < 0, 0, win)
+        base_f = sm[safe, ar].sum(1)
+        base_r = sm[3 - safe, W - 1 - ar].sum(1)
+        i0 = np.searchsorted(pos, p, side="left")
+        i1 = np.searchsorted(pos, p + W, side="left")
+        k_of = i1 - i0
+        for k in np.unique(k_of).tolist():
+            w = np.flatnonzero(k_of == k)
+            if k == 0:
+                f, r, bad = base_f[w], base_r[w], bad0[w]
+                s_f = np.where(bad > 0, min_val, f)
+                s_r = np.where(bad > 0, min_val, r)
+                hist += np.bincount(s_f, minlength=L)
+                rows += len(w)
+                if not forward_only:
+                    hist += np.bincount(s_r, minlength=L)
+                    rows += len(w)
+                continue
+            site = i0[w][:, None] + np.arange(k)[None, :]                           # [n, k] site indices
+            j = pos[site] - p[w][:, None]                                           # position in the window
+            cr = ref[pos[site]]
+            na = n_alts[site]
+            for combo in itertools.product(range(4), repeat=k):
+                c = np.asarray(combo)
+                ok = (c[None, :] <= na).all(1)
+                if not ok.any():
+                    continue
+                f, r, bad = base_f[w][ok].copy(), base_r[w][ok].copy(), bad0[w][ok].copy()
+                for t in range(k):
+                    if c[t] == 0:
+                        continue
+                    ca = alt[site[ok, t], c[t] - 1]
+                    jj, c0_ = j[ok, t], cr[ok, t]
+                    c0s, cas = np.where(c0_ < 0, 0, c0_), np.where(ca < 0, 0, ca)
+                    f += sm[cas, jj] - sm[c0s, jj]
+                    r += sm[3 - cas, W - 1 - jj] - sm[3 - c0s, W - 1 - jj]
+                    bad += (ca < 0).astype(np.int64) - (c0_ < 0).astype(np.int64)
+                s_f = np.where(bad > 0, min_val, f)
+                s_r = np.where(bad > 0, min_val, r)
+                hist += np.bincount(s_f, minlength=L)
+                rows += len(s_f)
+                if not forward_only:
+                    hist += np.bincount(s_r, minlength=L)
+                    rows += len(s_r)
+    return hist, rows

@@ -565,3 +565,38 @@ def test_scan_graph_manifest_mode_needs_no_gpu(tmp_path, monkeypatch, capsys):
     assert "Unable to locate" in str(e.value)
     out = capsys.readouterr().out
     assert "Extracting regions defined in" in out
+
+
+def test_the_numpy_row_counter_equals_the_walk_enumerator():
+    """tests/extract_helpers.snp_graph_score_histogram -- the CPU side of the full-size fused-path test (tests/test_gpu_fused.py)
+    -- against the walk enumerator's rows scored one by one (score_sequences.py:372-396 restated inline): a dense SNP graph (up to
+    five sites in a window, three alleles at some), an 'N' in the reference and an 'N' under a site, three widths, one strand
+    and both."""
+    from extract_helpers import snp_graph_score_histogram, variants_from_index
+    from grafimo_amd import synth
+    from grafimo_amd.extract_regions import GraphIndex
+    from oracle import extract_oracle as xo
+    idx, regions = synth.make_graph_index(12, 19, with_counts=False, with_dels=False, site_every=9)
+    ref = idx.ref.copy()
+    ref[regions[3][0] + 50] = ord("N")
+    ref[int(idx.pos[10])] = ord("N")
+    idx = GraphIndex(idx.chrom, ref, idx.pos, idx.n_alts, idx.alt_bases, None, 0)
+    v = variants_from_index(idx)
+    code = np.full(256, -1)
+    for i, c in enumerate(b"ACGT"):
+        code[c] = i
+    for W in (8, 19, 30):
+        rec = synth.synthetic_motif(W, np.random.default_rng(W), np.full(4, 0.25))
+        sm, L = np.asarray(rec["sm"], dtype=np.int64), 1000 * W + 1
+        for fwd_only in (False, True):
+            hist, rows = snp_graph_score_histogram(idx, regions, W, sm, L, rec["min_val"], forward_only=fwd_only)
+            want, n = np.zeros(L, np.int64), 0
+            for S, E in regions:
+                for r in xo.enumerate_region_variants(idx.chrom, idx.ref.tobytes(), v, S, E, W):
+                    if fwd_only and r[2] > r[3]:           # '-' rows carry start > stop
+                        continue
+                    c = code[np.frombuffer(r[1].encode(), dtype=np.uint8)]
+                    want[rec["min_val"] if (c < 0).any() else int(sm[c, np.arange(W)].sum())] += 1
+                    n += 1
+            assert rows == n > 4_000 and np.array_equal(hist, want), (W, fwd_only, rows, n)
+            assert hist[rec["min_val"]] > 0                # the 'N' rows are there
