@@ -580,3 +580,65 @@ def test_fused_histogram_at_config2_scale_equals_a_cpu_count(W, n_regions):
     for d in dms:
         d.close()
     g.close()
+
+
+def test_fused_histogram_with_deletions_equals_enumerator_plus_count():
+    """... and with deletions (the bench graph's recipe: 6 % of the sites), 1 500 regions, ~9e5 rows: the regions under which a
+    deletion lies go through the walk enumerator (oracle/extract_oracle.py; their k-mers scored in bulk with numpy), the others
+    through the numpy counter -- no HIP kernel on the expected side -- and the fused kernels' histogram and row count equal the
+    sum on a plan's first, second, third and fourth call (listing; the walks stored; scored from the cache inside
+    graph_score_kernel), for one motif and for three over one enumeration."""
+    from extract_helpers import snp_graph_score_histogram
+    from grafimo_amd import synth
+    from grafimo_amd.device import DeviceMotif
+    from grafimo_amd.extract_regions import DeviceGraph, GraphIndex
+    from oracle import extract_oracle as xo
+    W, L = 19, 19001
+    idx, regions = synth.make_graph_index(1500, W, with_counts=False)
+    assert int((idx.del_len > 0).sum()) > 300
+    v = variants_from_index(idx)
+    reach = int(idx.del_len.max()) + W + 2
+    del_pos = idx.pos[idx.del_len > 0].astype(np.int64)
+    touched = [bool(((del_pos >= s - reach) & (del_pos < e + reach)).any()) for s, e in regions]
+    plain = [r for r, t in zip(regions, touched) if not t]
+    assert 200 < len(plain) < 1300
+    # a graph without the deletion records gives the plain regions' rows (no deletion within reach of them)
+    keep = idx.del_len == 0
+    snp_only = GraphIndex(idx.chrom, idx.ref, idx.pos[keep], idx.n_alts[keep], idx.alt_bases[keep], None, 0)
+    recs = [synth.synthetic_motif(W, np.random.default_rng(40 + k), np.full(4, 0.25)) for k in range(3)]
+    code = np.full(256, -1, dtype=np.int64)
+    for i, c in enumerate(b"ACGT"):
+        code[c] = i
+    kmers = []
+    for (s, e), t in zip(regions, touched):
+        if t:
+            kmers += [r[1] for r in xo.enumerate_region_variants(idx.chrom, idx.ref.tobytes(), v, s, e, W)]
+    km = code[np.frombuffer("".join(kmers).encode(), dtype=np.uint8).reshape(-1, W)]
+    want = []
+    for rec in recs:
+        sm = np.asarray(rec["sm"], dtype=np.int64)
+        h, n = snp_graph_score_histogram(snp_only, plain, W, sm, L, rec["min_val"])
+        sc = np.where((km < 0).any(1), rec["min_val"], sm[np.where(km < 0, 0, km), np.arange(W)].sum(1))
+        want.append((h + np.bincount(sc, minlength=L), n + len(km)))
+    assert len(km) > 100_000 and want[0][1] > 800_000
+    g = DeviceGraph(idx)
+    reg = np.asarray(regions, dtype=np.int64)
+    starts, stops = np.ascontiguousarray(reg[:, 0]), np.ascontiguousarray(reg[:, 1])
+    dms = [DeviceMotif(r["sm"], r["bg"], r["min_val"], r["scale"], r["offset"]) for r in recs]
+    cuts = [d.pvalue_cutoff(1e-3) for d in dms]
+    for call in range(4):
+        hist = torch.zeros(L, dtype=torch.int64, device="cuda")
+        g.score(dms[0], starts, stops, cuts[0], hist=hist)
+        count, n_rows, over, _ = g.fused_results()
+        assert not over and n_rows == want[0][1], (call, n_rows, want[0][1])
+        assert np.array_equal(hist.cpu().numpy(), want[0][0]), call
+        assert count == int(want[0][0][cuts[0]:].sum()), (call, count)
+    hists = [torch.zeros(L, dtype=torch.int64, device="cuda") for _ in dms]
+    g.score_many(dms, starts, stops, cuts, hists)
+    for m in range(3):
+        count, n_rows, _, _ = g.fused_results(slot=m)
+        assert n_rows == want[m][1] and np.array_equal(hists[m].cpu().numpy(), want[m][0]), m
+        assert count == int(want[m][0][cuts[m]:].sum()), m
+    for d in dms:
+        d.close()
+    g.close()
