@@ -642,3 +642,70 @@ def test_fused_histogram_with_deletions_equals_enumerator_plus_count():
     for d in dms:
         d.close()
     g.close()
+
+
+def test_hit_rows_at_config2_scale_are_what_the_graph_says():
+    """The REPORT at BASELINE configs[1] scale (10 000 regions, 69 000 substitution sites, 5 096 haplotypes, 6.06e6 rows, p < 1e-3:
+    thousands of rows), every reported row checked from first principles on the CPU, no HIP and no enumerator: its k-mer is the
+    reference window with, at every site under it, the reference base or one of the site's alternates (reverse-complemented on
+    '-'); its score is the k-mer's (score_sequences.py:372-393), its p-value the table's; its haplotype_frequency the number of
+    haplotypes that carry exactly those alleles (AND of the bitsets); `reference` says whether any alternate is in it; the number
+    of rows is the histogram's tail (counted by tests/extract_helpers.snp_graph_score_histogram)."""
+    from extract_helpers import snp_graph_score_histogram
+    from grafimo_amd import synth
+    from grafimo_amd.extract_regions import DeviceGraph, compute_results_from_graph
+    from grafimo_amd.workflow import Findmotif
+    from oracle import oracle as orc
+    W, L = 19, 19001
+    idx, regions = synth.make_graph_index(10_000, W, with_dels=False)
+    motif = _ctcf()
+    sm = motif.dense_score_matrix()
+    g = DeviceGraph(idx)
+    with contextlib.redirect_stdout(io.StringIO()):
+        df = compute_results_from_graph(motif, g, np.asarray(regions, dtype=np.int64), True, Findmotif(threshold=1e-3, recomb=True))
+    g.close()
+    hist, rows = snp_graph_score_histogram(idx, regions, W, sm, L, motif.min_val)
+    pmf = orc.comp_pval_mat(sm, motif.dense_bg())
+    ptab = orc.p_table(pmf)
+    cut = int(np.flatnonzero(ptab < 1e-3)[0])
+    assert len(df) == int(hist[cut:].sum()) > 3000, (len(df), int(hist[cut:].sum()))
+    comp = {ord("A"): ord("T"), ord("C"): ord("G"), ord("G"): ord("C"), ord("T"): ord("A"), ord("N"): ord("N")}
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3}
+    H, hw = idx.n_haplotypes, idx.alt_bits.shape[2]
+    full = np.full(hw, np.uint64(0xFFFFFFFFFFFFFFFF))
+    if H % 64:
+        full[-1] = np.uint64((1 << (H % 64)) - 1)
+    region_of = {f"{idx.chrom}:{s}-{e}": (s, e) for s, e in regions}
+    pos = idx.pos.astype(np.int64)
+    seen = set()
+    for row in df.itertuples(index=False):
+        s_, e_ = region_of[row.sequence_name]
+        minus = row.strand == "-"
+        lo, hi = (row.stop, row.start) if minus else (row.start, row.stop)
+        assert hi - lo == W and s_ <= lo and hi <= e_, row
+        km = np.frombuffer(row.matched_sequence.encode(), dtype=np.uint8)
+        fwd = np.array([comp[int(c)] for c in km[::-1]], dtype=np.uint8) if minus else km
+        acc, any_alt = full.copy(), False
+        want = idx.ref[lo:hi].copy()
+        for i in range(int(np.searchsorted(pos, lo)), int(np.searchsorted(pos, hi))):
+            j = int(pos[i]) - lo
+            alts = [int(a) for a in idx.alt_bases[i, :int(idx.n_alts[i])]]
+            if int(fwd[j]) == int(idx.ref[pos[i]]):
+                for k in range(len(alts)):                                 # the reference allele: no alternate's carriers
+                    acc &= ~idx.alt_bits[i, k]
+            else:
+                assert int(fwd[j]) in alts, (row, j)
+                acc &= idx.alt_bits[i, alts.index(int(fwd[j]))]
+                want[j] = fwd[j]
+                any_alt = True
+        assert np.array_equal(fwd, want), row                               # off the sites it IS the reference
+        sc = int(sum(sm[code[int(c)], j] for j, c in enumerate(km)))
+        assert row.score == sc / motif.scale + W * float(motif.offset), row
+        assert int(row.haplotype_frequency) == int(sum(bin(int(x)).count("1") for x in acc)), row
+        assert row.reference == ("non.ref" if any_alt else "ref"), row
+        key = (row.sequence_name, row.start, row.stop, row.strand, row.matched_sequence)
+        assert key not in seen, row                                        # no row twice
+        seen.add(key)
+    sc_all = np.array([sum(sm[code[ord(c)], j] for j, c in enumerate(k)) for k in df["matched_sequence"]], dtype=np.int64)
+    assert np.allclose(df["p-value"].to_numpy(), ptab[sc_all], rtol=1e-12, atol=0) and (sc_all >= cut).all()
+    assert (np.diff(df["p-value"].to_numpy()) >= 0).all()                  # report order (resultsTmp.py:312)
