@@ -466,6 +466,7 @@ def extract_block(ctcf, dev, n_regions=10_000):
     }
 
 
+PRODUCT_PATHS_TIMEOUT_S = 300      # process-group timeout of the bench's ranks
 GRAPH_REGIONS_PER_RANK = 4000      # product_paths: regions of the synthetic chromosome per rank (weak scaling)
 SCAN_REGIONS_PER_RANK = 400        # ... and TSV files (2 000 rows each) per rank
 
@@ -492,75 +493,88 @@ def shard_plan(world, cores_flag=0):
 
 
 def product_paths_block(ctcf, dev, rank, world):
-    """N > 1: the fused graph path and the streamed scan under the run's process group (weak scaling: every rank brings
-    GRAPH_REGIONS_PER_RANK regions / SCAN_REGIONS_PER_RANK files).  Rank 0 reports; every rank takes part."""
+    """N > 1: the fused graph path (one motif, a motif set) and the streamed scan under the run's process group (weak scaling:
+    every rank brings GRAPH_REGIONS_PER_RANK regions / SCAN_REGIONS_PER_RANK files).  Rank 0 reports; every rank takes part.
+    Three STAGES, each a sequence of collectives.  A stage that raises on this rank is caught here, and the decision to go on is
+    COLLECTIVE: after every stage the ranks all-reduce(MAX) a failure flag -- a failure anywhere ends the block on
+    every rank together, with the stage's error in the line, and the main bench's collectives stay in step.  (A rank that fails
+    while its peers are still inside the stage's own collectives cannot be helped from here: the process group's timeout,
+    PRODUCT_PATHS_TIMEOUT_S, ends the run instead of a hang.)"""
     import shutil
     import tempfile
     import torch
     import torch.distributed as dist
     from grafimo_amd import synth
     from grafimo_amd.distributed import compute_results_sharded
-    from grafimo_amd.extract_regions import _SHARD_GRAPHS, compute_results_from_graph, drop_graph_cache
+    from grafimo_amd.extract_regions import (_SHARD_GRAPHS, compute_results_from_graph, compute_results_from_graph_many,
+                                             drop_graph_cache)
     from grafimo_amd.workflow import Findmotif
     W = ctcf.width
     out = {}
     sink = io.StringIO()
-    # ---- graph path: the HOST index is handed over; a rank uploads the part of the graph its regions can meet
-    idx, regions = synth.make_graph_index(GRAPH_REGIONS_PER_RANK * world, W)
-    reg = np.asarray(regions, dtype=np.int64)
-    wf = Findmotif(cores=1, threshold=1e-4)
-    ts = []
-    with contextlib.redirect_stdout(sink):
-        for _ in range(8):
-            dist.barrier()
-            t = time.perf_counter()
-            df = compute_results_from_graph(ctcf, idx, reg, False, wf)
-            torch.cuda.synchronize(dev)
-            ts.append(time.perf_counter() - t)
-    mine = [g for g in _SHARD_GRAPHS.values() if g._source is idx]
-    n_rows = torch.tensor([int(mine[0].fused_results()[1]) if mine else 0], dtype=torch.int64, device=dev)
-    sites = torch.tensor([len(mine[0].index.pos) if mine else 0], dtype=torch.int64, device=dev)
-    t_max = torch.tensor([float(np.median(ts[2:]))], dtype=torch.float64, device=dev)
-    dist.all_reduce(n_rows)
-    dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    per_rank_sites = [torch.zeros_like(sites) for _ in range(world)]
-    dist.all_gather(per_rank_sites, sites)
-    out["graph_path"] = {"regions": int(len(reg)), "rows": int(n_rows.item()), "compute_results_from_graph_ms": 1e3 * float(t_max.item()),
-                         "rows_per_s": int(n_rows.item()) / float(t_max.item()), "hits": int(len(df)) if df is not None else None,
-                         "sites_total": int(len(idx.pos)), "sites_per_rank": [int(x.item()) for x in per_rank_sites],
-                         "what": "compute_results_from_graph(motif, GraphIndex, regions) on every rank: regions sharded, each rank "
-                                 "uploads its shard of the graph (shard_index), one all-reduce of the histogram, hit rows gathered; "
-                                 "median of 6 calls, MAX over ranks"}
-    # ---- the same graph, a motif SET: compute_results_from_graph_many (three CTCF-width motifs share one enumeration per rank,
-    # their histograms cross the ranks as ONE [3, L] all-reduce)
-    from grafimo_amd.extract_regions import compute_results_from_graph_many
-    rng = np.random.default_rng(11)
-    trio = [ctcf] + [synth.motif_object(synth.synthetic_motif(W, rng, np.full(4, 0.25)), f"S{k}") for k in range(2)]
-    ts = []
-    with contextlib.redirect_stdout(sink):
-        for _ in range(6):
-            dist.barrier()
-            t = time.perf_counter()
-            tabs = compute_results_from_graph_many(trio, idx, reg, False, wf)
-            torch.cuda.synchronize(dev)
-            ts.append(time.perf_counter() - t)
-    t_many = torch.tensor([float(np.median(ts[2:]))], dtype=torch.float64, device=dev)
-    dist.all_reduce(t_many, op=dist.ReduceOp.MAX)
-    out["graph_path_many"] = {"motifs": 3, "regions": int(len(reg)), "compute_results_from_graph_many_ms": 1e3 * float(t_many.item()),
-                              "pairs_per_s": 3 * int(n_rows.item()) / float(t_many.item()),
-                              "hits": [int(len(t_)) for t_ in tabs] if tabs[0] is not None else None,
-                              "first_table_equals_single_call": bool(tabs[0] is None or (len(tabs[0]) == len(df) and bool(
-                                  (tabs[0]["matched_sequence"].to_numpy() == df["matched_sequence"].to_numpy()).all()))),
-                              "what": "compute_results_from_graph_many([CTCF, 2 synthetic W=19 PWMs], GraphIndex, regions) on every "
-                                      "rank: one enumeration of a rank's walks for the three motifs, one [3, L] all-reduce; median of 4, "
-                                      "MAX over ranks"}
-    drop_graph_cache()
-    # ---- streamed scan: every rank writes its own files, then compute_results_sharded over the whole directory
-    tmp = tempfile.mkdtemp(prefix="gfm_bench_scan_") if rank == 0 else None
-    box = [tmp]
-    dist.broadcast_object_list(box, src=0)
-    tmp = box[0]
-    try:
+    state = {}
+
+    def stage_graph():
+        # the HOST index is handed over; a rank uploads the part of the graph its regions can meet
+        idx, regions = synth.make_graph_index(GRAPH_REGIONS_PER_RANK * world, W)
+        reg = np.asarray(regions, dtype=np.int64)
+        wf = Findmotif(cores=1, threshold=1e-4)
+        state.update(idx=idx, reg=reg, wf=wf)
+        ts = []
+        with contextlib.redirect_stdout(sink):
+            for _ in range(8):
+                dist.barrier()
+                t = time.perf_counter()
+                df = compute_results_from_graph(ctcf, idx, reg, False, wf)
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t)
+        mine = [g for g in _SHARD_GRAPHS.values() if g._source is idx]
+        n_rows = torch.tensor([int(mine[0].fused_results()[1]) if mine else 0], dtype=torch.int64, device=dev)
+        sites = torch.tensor([len(mine[0].index.pos) if mine else 0], dtype=torch.int64, device=dev)
+        t_max = torch.tensor([float(np.median(ts[2:]))], dtype=torch.float64, device=dev)
+        dist.all_reduce(n_rows)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        per_rank_sites = [torch.zeros_like(sites) for _ in range(world)]
+        dist.all_gather(per_rank_sites, sites)
+        state.update(df=df, n_rows=int(n_rows.item()))
+        return {"regions": int(len(reg)), "rows": int(n_rows.item()), "compute_results_from_graph_ms": 1e3 * float(t_max.item()),
+                "rows_per_s": int(n_rows.item()) / float(t_max.item()), "hits": int(len(df)) if df is not None else None,
+                "sites_total": int(len(idx.pos)), "sites_per_rank": [int(x.item()) for x in per_rank_sites],
+                "what": "compute_results_from_graph(motif, GraphIndex, regions) on every rank: regions sharded, each rank "
+                        "uploads its shard of the graph (shard_index), one all-reduce of the histogram, hit rows gathered; "
+                        "median of 6 calls, MAX over ranks"}
+
+    def stage_graph_many():
+        # the same graph, a motif SET: three CTCF-width motifs share one enumeration per rank, their histograms cross the
+        # ranks as ONE [3, L] all-reduce
+        idx, reg, wf, df = state["idx"], state["reg"], state["wf"], state["df"]
+        rng = np.random.default_rng(11)
+        trio = [ctcf] + [synth.motif_object(synth.synthetic_motif(W, rng, np.full(4, 0.25)), f"S{k}") for k in range(2)]
+        ts = []
+        with contextlib.redirect_stdout(sink):
+            for _ in range(6):
+                dist.barrier()
+                t = time.perf_counter()
+                tabs = compute_results_from_graph_many(trio, idx, reg, False, wf)
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t)
+        t_many = torch.tensor([float(np.median(ts[2:]))], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_many, op=dist.ReduceOp.MAX)
+        return {"motifs": 3, "regions": int(len(reg)), "compute_results_from_graph_many_ms": 1e3 * float(t_many.item()),
+                "pairs_per_s": 3 * state["n_rows"] / float(t_many.item()),
+                "hits": [int(len(t_)) for t_ in tabs] if tabs[0] is not None else None,
+                "first_table_equals_single_call": bool(tabs[0] is None or (len(tabs[0]) == len(df) and bool(
+                    (tabs[0]["matched_sequence"].to_numpy() == df["matched_sequence"].to_numpy()).all()))),
+                "what": "compute_results_from_graph_many([CTCF, 2 synthetic W=19 PWMs], GraphIndex, regions) on every "
+                        "rank: one enumeration of a rank's walks for the three motifs, one [3, L] all-reduce; median of 4, "
+                        "MAX over ranks"}
+
+    def stage_scan():
+        # every rank writes its own files, then compute_results_sharded over the whole directory
+        tmp = tempfile.mkdtemp(prefix="gfm_bench_scan_") if rank == 0 else None
+        box = [tmp]
+        dist.broadcast_object_list(box, src=0)
+        tmp = state["tmp"] = box[0]
         batch = synth.make_batch(SCAN_REGIONS_PER_RANK, 2000, W, np.asarray(ctcf.count_matrix, dtype=np.float64), synth.seed_for(2, rank),
                                  region_base=rank * SCAN_REGIONS_PER_RANK)       # (file names are made from the region numbers)
         synth.write_tsv_dir(batch, tmp)
@@ -576,14 +590,30 @@ def product_paths_block(ctcf, dev, rank, world):
         t_max = torch.tensor([float(np.median(ts[1:]))], dtype=torch.float64, device=dev)
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         n = SCAN_REGIONS_PER_RANK * 2000 * world
-        out["streamed_scan"] = {"files": SCAN_REGIONS_PER_RANK * world, "rows": n, "compute_results_sharded_ms": 1e3 * float(t_max.item()),
-                                "rows_per_s": n / float(t_max.item()), "hits": int(len(df)) if df is not None else None,
-                                "what": "compute_results_sharded over one directory: files split over the ranks, gfm_scan_tsv_begin per "
-                                        "rank, all-reduce of the histogram, gfm_scan_tsv_finish, hit rows gathered; median of 4, MAX over ranks"}
+        return {"files": SCAN_REGIONS_PER_RANK * world, "rows": n, "compute_results_sharded_ms": 1e3 * float(t_max.item()),
+                "rows_per_s": n / float(t_max.item()), "hits": int(len(df)) if df is not None else None,
+                "what": "compute_results_sharded over one directory: files split over the ranks, gfm_scan_tsv_begin per "
+                        "rank, all-reduce of the histogram, gfm_scan_tsv_finish, hit rows gathered; median of 4, MAX over ranks"}
+
+    try:
+        for name, fn in (("graph_path", stage_graph), ("graph_path_many", stage_graph_many), ("streamed_scan", stage_scan)):
+            err = None
+            try:
+                out[name] = fn()
+            except Exception as e:               # (decided together, below)
+                err = f"{type(e).__name__}: {e}"
+            flag = torch.tensor([1 if err else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                out[name] = {"error": err or "another rank failed in this stage"}
+                out["stopped_after"] = name
+                break
+            if name == "graph_path_many":
+                drop_graph_cache()
     finally:
-        dist.barrier()
-        if rank == 0:
-            shutil.rmtree(tmp, ignore_errors=True)
+        drop_graph_cache()
+        if rank == 0 and state.get("tmp"):
+            shutil.rmtree(state["tmp"], ignore_errors=True)
     return out
 
 
@@ -969,7 +999,10 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        import datetime
+        # (a collective nobody answers ends the run after PRODUCT_PATHS_TIMEOUT_S instead of the default ten minutes)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(seconds=PRODUCT_PATHS_TIMEOUT_S))
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
         # RCCL's kernels need CUs of their own next to the persistent score grid: leave 16 free
         # (the score kernel is HBM-bound; 240 CUs move the same bytes, measured -1 %)
@@ -1090,10 +1123,7 @@ def run_rank(args, cfg, rank, local_rank, world, mots, ctcf, n, host_batch, on_q
     if use_dist and cfg in (2, 3) and not args.no_extras:
         # the two other PRODUCT paths under the same process group, so that a scaling run says something about all three: the
         # fused graph path (every rank uploads its shard of the graph) and the streamed TSV scan (every rank its files)
-        # NOT under a per-rank try/except: the block is a sequence of collectives -- a rank that swallowed its own
-        # exception would go on to the main bench's collectives while its peers still wait inside this block's, and the run
-        # would hang until the watchdog instead of failing.  An exception here ends this rank with a traceback and a non-zero
-        # exit; the launcher takes the other ranks down.
+        #  the block decides about failures COLLECTIVELY, stage by stage: see product_paths_block
         extras["product_paths"] = product_paths_block(ctcf, dev, rank, world)
     if default_n1 and not args.no_extras:
         W = mots[0]["width"]
