@@ -2002,7 +2002,11 @@ template <int MM> int launch_fused(FusedLaunch &L)
     // would take more than kLwCacheBytes does without.
     bool lw_fill = false;
     if (!L.listing && L.indels && P->lw_state == 0 && P->items_known) {
-        constexpr size_t kLwCacheBytes = 256u << 20;
+        // (GRAFIMO_FUSED_WALK_CACHE_BYTES: test aid -- 0 makes every plan do without the cache, as a plan too large for it does)
+        static const size_t kLwCacheBytes = [] {
+            const char *e = std::getenv("GRAFIMO_FUSED_WALK_CACHE_BYTES");
+            return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)256 << 20;
+        }();
         const int pitch16 = ((W + 15) / 16) * 16;
         const size_t rows = (size_t)std::max(n_items, 0) * kFusedDelThreads;
         if (n_items > 0 && (int)(P->h_heavy_ctl[2] & 0xffffffffull) == 0 && rows * ((size_t)pitch16 + sizeof(LwMeta)) <= kLwCacheBytes) {

@@ -709,3 +709,54 @@ def test_hit_rows_at_config2_scale_are_what_the_graph_says():
     sc_all = np.array([sum(sm[code[ord(c)], j] for j, c in enumerate(k)) for k in df["matched_sequence"]], dtype=np.int64)
     assert np.allclose(df["p-value"].to_numpy(), ptab[sc_all], rtol=1e-12, atol=0) and (sc_all >= cut).all()
     assert (np.diff(df["p-value"].to_numpy()) >= 0).all()                  # report order (resultsTmp.py:312)
+
+
+def test_a_plan_without_the_walk_cache_gives_the_same_tables(tmp_path):
+    """A plan whose listed windows' walks do not fit the cache (GRAFIMO_FUSED_WALK_CACHE_BYTES = 0 here: none fits) keeps
+    graph_del_score_kernel on EVERY call -- round 5's path; with the cache the calls from the third on score those walks inside
+    graph_score_kernel.  Same graph (insertions, deletions, multi-allelic sites), same regions, five calls each: every call's
+    histogram, row count and table equal the first call's, and the two processes agree."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, contextlib, io; sys.path[:0] = [%r, %r]\n"
+        "import numpy as np, torch\n"
+        "from test_gpu_fused import _ctcf, _fused\n"
+        "from extract_helpers import make_graph_files\n"
+        "from grafimo_amd.device import DeviceMotif\n"
+        "from grafimo_amd.extract_regions import DeviceGraph, GraphIndex\n"
+        "fasta, vcf = make_graph_files(sys.argv[1], chrom='7', length=6000, n_sites=700, n_samples=40, seed=77, rich=True)\n"
+        "idx = GraphIndex.from_fasta_vcf(fasta, vcf, '7')\n"
+        "g = DeviceGraph(idx)\n"
+        "regions = [(0, 1500), (1400, 3000), (3200, 5990)]\n"
+        "motif = _ctcf()\n"
+        "dm = DeviceMotif.from_motif(motif)\n"
+        "reg = np.asarray(regions, dtype=np.int64)\n"
+        "s, e = np.ascontiguousarray(reg[:, 0]), np.ascontiguousarray(reg[:, 1])\n"
+        "out = {}\n"
+        "for call in range(5):\n"
+        "    hist = torch.zeros(dm.L, dtype=torch.int64, device='cuda')\n"
+        "    g.score(dm, s, e, dm.pvalue_cutoff(0.05), hist=hist)\n"
+        "    count, n_rows, over, _ = g.fused_results()\n"
+        "    out[f'hist{call}'] = hist.cpu().numpy(); out[f'meta{call}'] = np.array([count, n_rows, over])\n"
+        "    df, _ = _fused(motif, g, regions, threshold=0.05, recomb=True)\n"
+        "    out[f'table{call}'] = np.frombuffer(df.to_csv(sep='\\t').encode(), dtype=np.uint8)\n"
+        "np.savez(sys.argv[2], **out)\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                            os.path.dirname(os.path.abspath(__file__))))
+    got = {}
+    for mode, env_val in (("cache", None), ("no_cache", "0")):
+        env = dict(os.environ)
+        env.pop("GRAFIMO_FUSED_WALK_CACHE_BYTES", None)
+        if env_val is not None:
+            env["GRAFIMO_FUSED_WALK_CACHE_BYTES"] = env_val
+        d = tmp_path / mode
+        d.mkdir()
+        r = subprocess.run([sys.executable, "-c", code, str(d), str(d / "out.npz")], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (mode, r.stderr[-3000:])
+        got[mode] = dict(np.load(d / "out.npz"))
+    a, b = got["cache"], got["no_cache"]
+    assert int(a["meta0"][1]) > 50_000 and int(a["meta0"][0]) > 500 and int(a["meta0"][2]) == 0
+    for call in range(5):
+        for z in (a, b):
+            assert np.array_equal(z[f"hist{call}"], a["hist0"]) and np.array_equal(z[f"meta{call}"], a["meta0"]), call
+            assert z[f"table{call}"].tobytes() == a["table0"].tobytes(), call

@@ -40,7 +40,8 @@ LAB_ONLY_KNOBS = (b"GRAFIMO_FUSED_LAB", b"GRAFIMO_FUSED_TIMERS", b"GRAFIMO_FUSED
                   b"GRAFIMO_STORE_POLICY", b"GRAFIMO_EXTRACT_SERIAL", b"GRAFIMO_PARSE_THREADS_EXACT", b"GRAFIMO_SCAN_TRACE")
 # what libgrafimo_hip.so reads: product settings, then test aids (they pick a code path, never a result)
 PRODUCT_KNOBS = ("GRAFIMO_RESERVE_CUS", "GRAFIMO_SCAN_KEEP_BYTES",
-                 "GRAFIMO_PLAN_MAX_WALKS", "GRAFIMO_EXTRACT_DEL_POOL", "GRAFIMO_SCAN_TEXT_BYTES", "GRAFIMO_SCAN_NO_AVX512")
+                 "GRAFIMO_PLAN_MAX_WALKS", "GRAFIMO_EXTRACT_DEL_POOL", "GRAFIMO_SCAN_TEXT_BYTES", "GRAFIMO_SCAN_NO_AVX512",
+                 "GRAFIMO_FUSED_WALK_CACHE_BYTES")
 
 
 def test_product_library_holds_no_lab_switch():
