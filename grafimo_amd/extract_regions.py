@@ -46,6 +46,11 @@ MAX_ALTS = 3
 _NPZ_ALIGN = 64
 
 
+def struct_error():
+    import struct
+    return struct.error
+
+
 def _save_npz_aligned(path: str, arrays: Dict[str, np.ndarray]) -> None:
     """np.savez's container -- a zip of .npy members -- with the members stored and padded (a zip "extra" record in the
     local header, as Android's zipalign does) so that every .npy starts at a multiple of 64 bytes: the .npy header is
@@ -271,10 +276,20 @@ class GraphIndex:
 
     @classmethod
     def load(cls, path: str) -> "GraphIndex":
-        z = _load_npz_mapped(path)
-        if z is None:                                   # deflated members (an index of rounds 1-5, or compressed=True)
-            with np.load(path, allow_pickle=False) as f:
-                z = {k: f[k] for k in f.files}
+        import zipfile
+        try:
+            z = _load_npz_mapped(path)
+            if z is None:                               # deflated members (an index of rounds 1-5, or compressed=True)
+                with np.load(path, allow_pickle=False) as f:
+                    z = {k: f[k] for k in f.files}
+            missing = [k for k in ("chrom", "ref", "pos", "n_alts", "alt_bases", "alt_bits", "n_haplotypes", "skipped", "del_len",
+                                   "ins_len", "ins_off", "ins_bases") if k not in z]
+            if missing:
+                raise KeyError(", ".join(missing))
+        except (zipfile.BadZipFile, KeyError, ValueError, EOFError, SyntaxError, struct_error()) as e:
+            raise VGError(f"\n\nERROR: {path} is not a graph index of this package ({type(e).__name__}: {e}); make it again "
+                          f"(GraphIndex.from_fasta_vcf(...).save(...), `python -m grafimo_amd buildvg`, or delete it beside the "
+                          f"XG + GBWT it was made from).\n") from e
         bits = z["alt_bits"] if z["alt_bits"].size else None
         idx = cls(str(z["chrom"]), z["ref"], z["pos"], z["n_alts"], z["alt_bases"], bits, int(z["n_haplotypes"]),
                   int(z["skipped"]), del_len=z["del_len"], ins_len=z["ins_len"], ins_off=z["ins_off"],

@@ -156,6 +156,17 @@ def test_index_file_is_mapped_not_read(tmp_path):
     again = xr.GraphIndex.load(p)
     assert again.save(p) == p and np.array_equal(again.alt_bits, idx.alt_bits) and np.array_equal(j.ref, idx.ref)
     assert np.array_equal(xr.GraphIndex.load(p).alt_bits, idx.alt_bits) and not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+    # a file that is no index (truncated, another .npz, not a zip at all): the package's own error, named
+    from grafimo_amd.grafimo_errors import VGError
+    raw = open(p, "rb").read()
+    for name, blob in (("cut", raw[:len(raw) // 2]), ("junk", b"not a zip" * 100), ("empty", b"")):
+        bad = tmp_path / f"{name}.gfmidx.npz"
+        bad.write_bytes(blob)
+        with pytest.raises(VGError, match="is not a graph index"):
+            xr.GraphIndex.load(str(bad))
+    np.savez(str(tmp_path / "other.gfmidx.npz"), a=np.arange(3))
+    with pytest.raises(VGError, match="is not a graph index"):
+        xr.GraphIndex.load(str(tmp_path / "other.gfmidx.npz"))
     no_bits = xr.GraphIndex("1", idx.ref, idx.pos, idx.n_alts, idx.alt_bases, None, 0)
     assert xr.GraphIndex.load(no_bits.save(str(tmp_path / "nb"))).alt_bits is None
 
