@@ -1701,8 +1701,12 @@ class _FusedPass:
             if self.hist_all is not None:
                 self.hist_all.zero_()
             else:
-                for h_ in hists:
-                    h_.zero_()
+                # (one motif: its handle's own histogram, handed back ZEROED by the q-table kernel of the call before --
+                #  GFM_FLAG_CLEAR_HIST -- so that a call after the first needs no fill for it)
+                for dm, h_ in zip(dms, hists):
+                    if getattr(dm, "_fused_hist_clean", None) is not h_:
+                        h_.zero_()
+                    dm._fused_hist_clean = None
         for g in prep.graphs:                    # the slots of all M motifs in one tensor per graph: one fill for their counters
             g.fused_buffers(self.cap, M - 1)
             g.fused_zero(M)
@@ -1716,7 +1720,10 @@ class _FusedPass:
             dist.all_reduce(self.hist_all if self.hist_all is not None else hists[0], group=prep.group)
         if self.works is not None:
             if M == 1:
-                dms[0].qvalue_table(hists[0], self.threshold, self.qval_t, qtables[0], d_cuts[0], None, stream=sp)
+                # nothing runs beside this chain of kernels: the q-table in ONE launch (GFM_FLAG_ALONE)
+                dms[0].qvalue_table(hists[0], self.threshold, self.qval_t, qtables[0], d_cuts[0], None, stream=sp,
+                                    clear_hist=True, alone=True)
+                dms[0]._fused_hist_clean = hists[0]
             else:
                 from .device import qvalue_table_multi
                 qvalue_table_multi(dms, hists, self.threshold, self.qval_t, qtables, d_cuts, stream=sp)
