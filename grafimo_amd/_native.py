@@ -25,7 +25,6 @@ GFM_NO_SELECT = 2**31 - 1
 GFM_FLAG_RESET_HITS = 1
 GFM_FLAG_CLEAR_HIST = 2
 GFM_FLAG_CALLER_ORDERS_REUSE = 4
-GFM_FLAG_ALONE = 8
 GFM_MAX_WIDTH = 64
 GFM_BEST_ROW_BITS = 44
 GFM_GRAPH_FORWARD_ONLY = 1

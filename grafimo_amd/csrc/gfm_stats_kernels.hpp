@@ -328,113 +328,4 @@ __global__ void __launch_bounds__(kQThreads) q_final_kernel(const QJobs jobs)
                  q.cutoff, q.nrows, q.clear, q.nblk);
 }
 
-// The same q-table by ONE workgroup of 1024 threads, for a caller whose stream has nothing running beside it (the fused
-// graph path: score -> slab reduction -> q-table -> annotate, one after the other): one launch instead of three -- in stream
-// order each of these latency-bound launches costs ~5 us.  (Beside the persistent score grid of the resident pipeline a
-// 1024-thread workgroup finds no empty CU and waits for the score kernel to end: that caller keeps the three small kernels
-// above.)  Every value equals the three-pass form's: C(s) and n are integer sums, raw(s) is the same expression, the running
-// minimum is a minimum.  Thread t owns the contiguous bins [lo + t * per, lo + (t + 1) * per).
-constexpr int kQOneThreads = 1024;
-__global__ void __launch_bounds__(kQOneThreads) q_one_kernel(const QJobs jobs)
-{
-    const QJob &q = jobs.j[0];
-    const unsigned long long *hist = q.hist;
-    const double *__restrict__ ptable = q.ptable;
-    double *qtable = q.qtable;
-    const int L = q.L, lo = q.lo, hi = q.hi, min_val = q.min_val;
-    __shared__ unsigned long long cnt[kQOneThreads];
-    __shared__ double mn[kQOneThreads];
-    __shared__ unsigned long long n_sh;
-    __shared__ double all_sh;
-    __shared__ int first_s;
-    const int tid = threadIdx.x;
-    const int nb = hi - lo + 1;
-    const int per = (nb + kQOneThreads - 1) / kQOneThreads;
-    const int a = lo + min(tid * per, nb), b = lo + min(tid * per + per, nb);
-    const bool n_outside = min_val < lo || min_val > hi;
-    unsigned long long mine = 0;
-    for (int j = a; j < b; ++j) mine += hist[j];
-    cnt[tid] = mine;
-    if (tid == 0) first_s = L;
-    __syncthreads();
-    if (tid < 64) {          // one wavefront turns the 1024 totals into "rows in the chunks ABOVE chunk t" (and n)
-        unsigned long long part[kQOneThreads / 64], run = 0;
-        for (int k = kQOneThreads / 64 - 1; k >= 0; --k) { part[k] = cnt[tid * (kQOneThreads / 64) + k]; }
-        unsigned long long own = 0;
-        for (int k = 0; k < kQOneThreads / 64; ++k) own += part[k];
-        // inclusive suffix over the 64 lanes' sums
-        unsigned long long suf = own;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned long long v = __shfl_down(suf, d);
-            if (tid + d < 64) suf += v;
-        }
-        run = suf - own;                                  // rows in the lanes above this one
-        for (int k = kQOneThreads / 64 - 1; k >= 0; --k) {
-            cnt[tid * (kQOneThreads / 64) + k] = run;     // rows above chunk (tid, k)
-            run += part[k];
-        }
-        if (tid == 0) n_sh = suf + (n_outside ? hist[min_val] : 0ull);
-    }
-    __syncthreads();
-    const unsigned long long n_rows_N = n_outside ? hist[min_val] : 0ull;
-    const unsigned long long n = n_sh;
-    const double nd = (double)n;
-    {   // raw(s), top-down inside the chunk; the chunk's minimum
-        unsigned long long c_ge = cnt[tid];
-        double m = INFINITY;
-        for (int j = b - 1; j >= a; --j) {
-            const unsigned long long h = hist[j];
-            c_ge += h;
-            const double raw = h ? ptable[j] / ((double)c_ge / nd) : INFINITY;
-            qtable[j] = raw;
-            m = fmin(m, raw);
-        }
-        mn[tid] = m;
-    }
-    __syncthreads();
-    if (tid < 64) {          // exclusive prefix minimum over the chunks (bottom-up), and the minimum of all
-        double part[kQOneThreads / 64], own = INFINITY;
-        for (int k = 0; k < kQOneThreads / 64; ++k) { part[k] = mn[tid * (kQOneThreads / 64) + k]; own = fmin(own, part[k]); }
-        double pre = own;                                 // inclusive prefix minimum over the lanes
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double v = __shfl_up(pre, d);
-            if (tid >= d) pre = fmin(pre, v);
-        }
-        double below = __shfl_up(pre, 1);
-        if (tid == 0) below = INFINITY;
-        for (int k = 0; k < kQOneThreads / 64; ++k) {
-            mn[tid * (kQOneThreads / 64) + k] = below;    // minimum of everything below chunk (tid, k)
-            below = fmin(below, part[k]);
-        }
-        if (tid == 63) all_sh = pre;
-    }
-    __syncthreads();
-    // rows holding an N sit below every other score: rank n, p = p_table[min_val] (= 1)
-    const double base = n_rows_N ? ptable[min_val] / (nd / nd) : INFINITY;
-    {
-        double run = mn[tid];
-        int first = L;
-        for (int j = a; j < b; ++j) {
-            run = fmin(run, qtable[j]);
-            const double qv = fmin(fmin(run, base), 1.0);
-            qtable[j] = qv;
-            const double val = jobs.on_qvalue ? qv : ptable[j];
-            if (val < jobs.threshold && first == L) first = j;
-            if (q.clear) q.clear[j] = 0ull;
-        }
-        if (first < L) atomicMin(&first_s, first);
-    }
-    const double q_above = fmin(fmin(base, all_sh), 1.0);
-    for (int jj = tid; jj < lo; jj += kQOneThreads) qtable[jj] = fmin(base, 1.0);
-    for (int jj = hi + 1 + tid; jj < L; jj += kQOneThreads) qtable[jj] = q_above;
-    __syncthreads();
-    if (tid == 0) {
-        if (q.cutoff) *q.cutoff = first_s;
-        if (q.nrows) *q.nrows = n;
-        if (q.clear && n_outside) q.clear[min_val] = 0ull;
-    }
-}
-
 }  // namespace

@@ -1136,11 +1136,6 @@ int launch_qtables(const gfm_motif_t *motifs, int count, uint64_t *const *d_hist
         q.nblk = (m->nb + kQThreads - 1) / kQThreads;   // <= 251 for W <= 64
         max_blk = std::max(max_blk, q.nblk);
     }
-    if (count == 1 && (flags & GFM_FLAG_ALONE)) {
-        hipLaunchKernelGGL(q_one_kernel, dim3(1), dim3(kQOneThreads), 0, st, jobs);
-        HIP_TRY(hipGetLastError());
-        return GFM_OK;
-    }
     const dim3 grid((unsigned)max_blk, (unsigned)count);
     hipLaunchKernelGGL(q_count_kernel, grid, dim3(kQThreads), 0, st, jobs);
     hipLaunchKernelGGL(q_raw_kernel, grid, dim3(kQThreads), 0, st, jobs);

@@ -186,14 +186,13 @@ class DeviceMotif:
             _stream_ptr(tail_stream) if tail_stream is not None else None))
 
     def qvalue_table(self, hist, threshold, on_qvalue, qtable=None, cutoff=None, nrows=None,
-                     stream=None, clear_hist=False, alone=False):
-        """gfm_qvalue_table.  `alone`: nothing runs beside this call on the device -- one launch instead of three."""
+                     stream=None, clear_hist=False):
         nv.check(nv.lib().gfm_qvalue_table(
             self._h, hist.data_ptr(), float(threshold), int(bool(on_qvalue)),
             qtable.data_ptr() if qtable is not None else None,
             cutoff.data_ptr() if cutoff is not None else None,
             nrows.data_ptr() if nrows is not None else None,
-            (nv.GFM_FLAG_CLEAR_HIST if clear_hist else 0) | (nv.GFM_FLAG_ALONE if alone else 0), _stream_ptr(stream)))
+            nv.GFM_FLAG_CLEAR_HIST if clear_hist else 0, _stream_ptr(stream)))
 
     def select_hits(self, scores, cutoff, hit_rows, hit_count, row_base=0, stream=None,
                     reset_hits=False):

@@ -1720,9 +1720,10 @@ class _FusedPass:
             dist.all_reduce(self.hist_all if self.hist_all is not None else hists[0], group=prep.group)
         if self.works is not None:
             if M == 1:
-                # nothing runs beside this chain of kernels: the q-table in ONE launch (GFM_FLAG_ALONE)
+                # (the q-table as ONE 1024-thread workgroup in one launch instead of the three small multi-block kernels was
+                #  measured here -- nothing runs beside this chain -- and is 12-18 us SLOWER per call: scripts/call_ab.py)
                 dms[0].qvalue_table(hists[0], self.threshold, self.qval_t, qtables[0], d_cuts[0], None, stream=sp,
-                                    clear_hist=True, alone=True)
+                                    clear_hist=True)
                 dms[0]._fused_hist_clean = hists[0]
             else:
                 from .device import qvalue_table_multi

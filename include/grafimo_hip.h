@@ -52,10 +52,6 @@ extern "C" {
  * on the handle were made with the same (stream, tail_stream) pair -- a second user of the handle in between (another
  * scanner, a batched call) makes it fall back to its own event wait. */
 #define GFM_FLAG_CALLER_ORDERS_REUSE 4u
-/* gfm_qvalue_table: nothing runs beside this call on the device (the fused graph path's chain of kernels): the table is made
- * by ONE workgroup in one launch instead of three small multi-block kernels (which exist to slot in beside the persistent
- * score grid of the resident pipeline).  Same values either way. */
-#define GFM_FLAG_ALONE 8u
 #define GFM_WORKSPACE_RING 4
 /* a hit-list entry packs the global row id and the row's scaled score:
  * entry = (row << GFM_HIT_SCORE_BITS) | score   (score <= 1000*64 < 2^20) */

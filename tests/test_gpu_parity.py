@@ -210,51 +210,6 @@ def test_qvalue_table_vs_sorted_bh(dev, golden_motifs):
         dm.close()
 
 
-def test_qvalue_table_in_one_launch_equals_the_three_passes(dev, golden_motifs):
-    """GFM_FLAG_ALONE (round 6: the fused graph path's q-table, ONE workgroup, one launch) against the three small multi-block
-    kernels of the resident pipeline: the whole table byte for byte, the cutoff, the row count, the histogram handed back zeroed
-    or untouched -- histograms of real scores and adversarial ones (a single bin, every bin of the window, rows with an N
-    inside / outside the window, no row at all), widths 8 ... 64, thresholds on p and on q."""
-    from grafimo_amd import synth
-    from grafimo_amd.device import DeviceMotif
-    rng = np.random.default_rng(60)
-    cases = 0
-    for W in (8, 11, 19, 30, 64):
-        rec = synth.synthetic_motif(W, np.random.default_rng(W), np.array([0.3, 0.2, 0.2, 0.3]))
-        dm = DeviceMotif(rec["sm"], rec["bg"], rec["min_val"], rec["scale"], rec["offset"])
-        lo, hi, L = dm.score_lo, dm.score_hi, dm.L
-        hists = []
-        h = np.zeros(L, dtype=np.int64)
-        km = random_kmers(rng, 40_000, W, n_frac=0.01)
-        d_h = torch.zeros(L, dtype=torch.int64, device=dev)
-        dm.score(torch.from_numpy(km).to(dev), None, hist=d_h)
-        hists.append(d_h.cpu().numpy())                                            # real scores (+ N rows at min_val)
-        h1 = h.copy(); h1[(lo + hi) // 2] = 12345; hists.append(h1)                 # one bin
-        h2 = h.copy(); h2[lo:hi + 1] = rng.integers(0, 5, hi - lo + 1); h2[hi] = 1; h2[lo] = 7; hists.append(h2)     # dense, both ends
-        h3 = h2.copy(); h3[rec["min_val"]] += 999; hists.append(h3)                 # + rows with an N
-        hists.append(h.copy())                                                      # no row at all
-        h5 = h.copy(); h5[hi] = 3; hists.append(h5)                                 # only the best score
-        for hist in hists:
-            for on_q, thr in ((False, 1e-3), (True, 0.2), (True, 1.0), (False, 1.0)):
-                out = []
-                for alone in (False, True):
-                    for clear in (False, True):
-                        d_hist = torch.from_numpy(hist.copy()).to(dev)
-                        q = torch.full((L,), -1.0, dtype=torch.float64, device=dev)
-                        cut = torch.full((1,), -7, dtype=torch.int32, device=dev)
-                        nrows = torch.full((1,), -7, dtype=torch.int64, device=dev)
-                        dm.qvalue_table(d_hist, thr, on_q, q, cut, nrows, clear_hist=clear, alone=alone)
-                        torch.cuda.synchronize()
-                        left = d_hist.cpu().numpy()
-                        assert np.array_equal(left, np.zeros_like(left) if clear else hist), (W, alone, clear)
-                        out.append((q.cpu().numpy().tobytes(), int(cut.item()), int(nrows.item())))
-                assert all(o == out[0] for o in out[1:]), (W, on_q, thr, [o[1:] for o in out])
-                assert out[0][2] == int(hist.sum())
-                cases += 1
-        dm.close()
-    assert cases == 5 * 6 * 4
-
-
 def test_selection_from_candidates_equals_selection_from_scores(dev, golden_motifs):
     """gfm_select_hits_from: with a q-value threshold the score kernel collects the rows with p < t (q >= p) and
     the selection filters that list instead of reading every score.  Same hit list as gfm_select_hits for a
