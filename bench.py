@@ -560,6 +560,7 @@ def product_paths_block(ctcf, dev, rank, world):
                 ts.append(time.perf_counter() - t)
         t_many = torch.tensor([float(np.median(ts[2:]))], dtype=torch.float64, device=dev)
         dist.all_reduce(t_many, op=dist.ReduceOp.MAX)
+        drop_graph_cache()
         return {"motifs": 3, "regions": int(len(reg)), "compute_results_from_graph_many_ms": 1e3 * float(t_many.item()),
                 "pairs_per_s": 3 * state["n_rows"] / float(t_many.item()),
                 "hits": [int(len(t_)) for t_ in tabs] if tabs[0] is not None else None,
@@ -596,24 +597,34 @@ def product_paths_block(ctcf, dev, rank, world):
                         "rank, all-reduce of the histogram, gfm_scan_tsv_finish, hit rows gathered; median of 4, MAX over ranks"}
 
     try:
-        for name, fn in (("graph_path", stage_graph), ("graph_path_many", stage_graph_many), ("streamed_scan", stage_scan)):
-            err = None
-            try:
-                out[name] = fn()
-            except Exception as e:               # (decided together, below)
-                err = f"{type(e).__name__}: {e}"
-            flag = torch.tensor([1 if err else 0], dtype=torch.int64, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if int(flag.item()):
-                out[name] = {"error": err or "another rank failed in this stage"}
-                out["stopped_after"] = name
-                break
-            if name == "graph_path_many":
-                drop_graph_cache()
+        out = run_stages_together((("graph_path", stage_graph), ("graph_path_many", stage_graph_many), ("streamed_scan", stage_scan)), dev)
     finally:
         drop_graph_cache()
         if rank == 0 and state.get("tmp"):
             shutil.rmtree(state["tmp"], ignore_errors=True)
+    return out
+
+
+def run_stages_together(stages, device):
+    """Runs (name, function) stages on every rank of the default process group; a stage's exception is caught on the rank that
+    raised it, and after EVERY stage the ranks all-reduce(MAX) a failure flag: a failure anywhere stops the sequence on every rank
+    together (its stage reads {"error": ...}, "stopped_after" names it), so that whatever follows the block stays in step.
+    -> {name: result}  (tests/test_bench_launcher.py drives it with two gloo ranks and a stage that fails on one of them)"""
+    import torch
+    import torch.distributed as dist
+    out = {}
+    for name, fn in stages:
+        err = None
+        try:
+            out[name] = fn()
+        except Exception as e:                   # (decided together, below)
+            err = f"{type(e).__name__}: {e}"
+        flag = torch.tensor([1 if err else 0], dtype=torch.int64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            out[name] = {"error": err or "another rank failed in this stage"}
+            out["stopped_after"] = name
+            break
     return out
 
 

@@ -54,3 +54,56 @@ def test_eight_ranks_as_the_driver_launches_them():
     p = _run(["--dry-run-fail-rank", "5"], gpus=8)
     assert p.returncode != 0
     assert not any(ln.lstrip().startswith("{") and '"metric"' in ln for ln in p.stdout.splitlines())
+
+
+def _stage_worker(rank, world, port, out_dir):
+    import json as _json
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def ok(name):
+        def fn():
+            calls.append(name)
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)                       # a stage is a sequence of collectives
+            return {"sum": int(t.item())}
+        return fn
+
+    def fails_on_rank_1_before_its_collective():
+        calls.append("b")
+        if rank == 1:
+            raise RuntimeError("rank 1 cannot")
+        return {"fine": True}
+
+    res = bench.run_stages_together((("a", ok("a")), ("b", fails_on_rank_1_before_its_collective), ("c", ok("c"))), torch.device("cpu"))
+    after = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(after)                           # whatever follows the block is still in step on every rank
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
+        _json.dump({"res": res, "calls": calls, "after": int(after.item())}, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_stage_that_fails_on_one_rank_stops_every_rank_together(tmp_path):
+    """bench.py's product_paths block is a sequence of collectives inside a per-rank try/except -- a rank that
+    swallowed its own exception went on to the main bench's collectives while its peers still waited inside the block's.  Now
+    the decision is collective (run_stages_together): two gloo ranks, a stage that raises on rank 1 only -- both ranks skip the
+    stage after it, both report where the block stopped, and the collective that FOLLOWS the block matches on both."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    mp.spawn(_stage_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    for r, g in enumerate(got):
+        assert g["calls"] == ["a", "b"], (r, g["calls"])                     # stage c was skipped on BOTH ranks
+        assert g["res"]["a"] == {"sum": 2} and g["res"]["stopped_after"] == "b" and "c" not in g["res"]
+        assert g["after"] == 3                                               # 1 + 2: the next collective is in step
+    assert got[1]["res"]["b"] == {"error": "RuntimeError: rank 1 cannot"}
+    assert got[0]["res"]["b"] == {"error": "another rank failed in this stage"}
