@@ -1584,7 +1584,10 @@ def _fetch_fused(graphs, M: int, guess: int = 1024):
         for m, gi, buf, k, off in long_:
             pin[off:off + 15 * k].copy_(buf[16:16 + 15 * k], non_blocking=True)
         st.synchronize()
-        host = pin[:need].numpy().copy()             # (the page-locked buffer is the next call's: the records move out)
+        # (views of the page-locked buffer, NOT copies -- 53 MB of records per BASELINE configs[4] call: they are consumed by
+        #  this pass's tables() before the next fetch's copies land in the buffer; a buffer that grows meanwhile leaves the old one
+        #  to these views)
+        host = pin[:need].numpy()
         for m, gi, buf, k, off in long_:
             big[(m, gi)] = host[off:off + 15 * k].view(HIT_DTYPE)
     got = [[None] * len(graphs) for _ in range(M)]
