@@ -32,7 +32,7 @@ GFM_TSV_NO_NODEPATH = 1
 GFM_WORKSPACE_RING = 4
 GFM_HITS_DROP_ZERO_FREQ = 1
 GFM_HITS_FIRST_PER_REGION = 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 RANGE = 1000
 
 c_int = ctypes.c_int
@@ -120,6 +120,8 @@ PROTOTYPES = {
     "gfm_graph_annotate": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfm_graph_hit_columns": (c_int, [c_void_p, c_i32, c_i32, ctypes.c_double, c_i32, c_i32, c_void_p, c_void_p, c_void_p,
                                       c_void_p, ctypes.c_uint32, P(c_i64)] + [c_void_p] * 10),
+    "gfm_graph_hit_columns_start": (c_int, [c_void_p, c_i32, P(c_void_p)]),
+    "gfm_graph_hit_columns_wait": (c_int, [c_void_p]),
     "gfm_region_labels": (c_i64, [ctypes.c_char_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64]),
     "gfm_vcf_open": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_int, c_int, P(c_void_p), P(c_i64), P(c_i32),
                              P(c_i64)]),
@@ -128,6 +130,19 @@ PROTOTYPES = {
     "gfm_vcf_read_insertions": (c_int, [c_void_p] * 4),
     "gfm_vcf_close": (None, [c_void_p]),
 }
+
+
+class HitColumnsJob(ctypes.Structure):
+    """gfm_hit_columns_job_t"""
+    _fields_ = [("h_ptable", c_void_p), ("h_recs", c_void_p), ("n_recs", c_void_p), ("h_entry_of", c_void_p),
+                ("region_base", c_void_p), ("o_start", c_void_p), ("o_stop", c_void_p), ("o_freq", c_void_p),
+                ("o_region", c_void_p), ("o_score", c_void_p), ("o_pvalue", c_void_p), ("o_qvalue", c_void_p),
+                ("o_strand", c_void_p), ("o_ref", c_void_p), ("o_kmers", c_void_p), ("offset", ctypes.c_double),
+                ("n_out", c_i64), ("table_len", c_i32), ("scale", c_i32), ("width", c_i32), ("n_parts", c_i32),
+                ("flags", ctypes.c_uint32), ("status", c_i32)]
+
+
+assert ctypes.sizeof(HitColumnsJob) == 160
 
 
 class ScanStats(ctypes.Structure):

@@ -9,14 +9,18 @@
 // hit row, 412 ms for the 440 000 hit rows of BASELINE configs[4] against 8.6 ms of GPU work (VERDICT r5 Weak #4).
 // Reference lines cited as file:line are relative to /root/reference/src/grafimo/.
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <climits>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include "gfm_workers.hpp"
 #include "grafimo_hip.h"
 
 #define GFM_API extern "C" __attribute__((visibility("default")))
@@ -46,14 +50,12 @@ inline bool key_less(const Key &a, const Key &b)      // inside one score: the o
     return a.part < b.part;
 }
 
-}   // namespace
-
-GFM_API int gfm_graph_hit_columns(const double *h_ptable, int32_t table_len, int32_t scale, double offset, int32_t width,
-                                  int32_t n_parts, const gfm_graph_hit_t *const *h_recs,
-                                  const int64_t *n_recs, const int64_t *const *h_entry_of, const int64_t *region_base,
-                                  uint32_t flags, int64_t *n_out, int64_t *o_start, int64_t *o_stop, int64_t *o_freq,
-                                  int64_t *o_region, double *o_score, double *o_pvalue, double *o_qvalue, uint8_t *o_strand,
-                                  uint8_t *o_ref, uint8_t *o_kmers)
+int hit_columns(const double *h_ptable, int32_t table_len, int32_t scale, double offset, int32_t width,
+                int32_t n_parts, const gfm_graph_hit_t *const *h_recs,
+                const int64_t *n_recs, const int64_t *const *h_entry_of, const int64_t *region_base,
+                uint32_t flags, int64_t *n_out, int64_t *o_start, int64_t *o_stop, int64_t *o_freq,
+                int64_t *o_region, double *o_score, double *o_pvalue, double *o_qvalue, uint8_t *o_strand,
+                uint8_t *o_ref, uint8_t *o_kmers)
 {
     if (!h_ptable || table_len < 1 || scale == 0 || !n_out || n_parts < 0 || (n_parts && (!h_recs || !n_recs)) || width < 1 || width > GFM_MAX_WIDTH)
         return hfail(GFM_ERR_INVALID, "gfm_graph_hit_columns: bad argument");
@@ -74,11 +76,11 @@ GFM_API int gfm_graph_hit_columns(const double *h_ptable, int32_t table_len, int
         static thread_local std::vector<int32_t> canon;
         static thread_local std::vector<int64_t> at, put;
         // ... but a call of millions of rows (GRAFIMO_MAX_HITS: 2^23) does not leave half a gigabyte behind: what is larger than
-        // ~32 MB is given back when the call returns
+        // ~10 MB is given back when the call returns (the scratch is per THREAD: the jobs of a motif set run on several)
         struct Trim {
             ~Trim()
             {
-                constexpr size_t kKeepKeys = (size_t)1 << 20;
+                constexpr size_t kKeepKeys = (size_t)1 << 18;
                 if (keys.capacity() > kKeepKeys) std::vector<Key>().swap(keys);
                 if (sorted.capacity() > kKeepKeys) std::vector<Key>().swap(sorted);
                 if (canon.capacity() > 8 * kKeepKeys) std::vector<int32_t>().swap(canon);
@@ -165,6 +167,80 @@ GFM_API int gfm_graph_hit_columns(const double *h_ptable, int32_t table_len, int
     } catch (const std::bad_alloc &) {
         return hfail(GFM_ERR_NOMEM, "gfm_graph_hit_columns: out of host memory");
     }
+}
+
+}   // namespace
+
+GFM_API int gfm_graph_hit_columns(const double *h_ptable, int32_t table_len, int32_t scale, double offset, int32_t width,
+                                  int32_t n_parts, const gfm_graph_hit_t *const *h_recs,
+                                  const int64_t *n_recs, const int64_t *const *h_entry_of, const int64_t *region_base,
+                                  uint32_t flags, int64_t *n_out, int64_t *o_start, int64_t *o_stop, int64_t *o_freq,
+                                  int64_t *o_region, double *o_score, double *o_pvalue, double *o_qvalue, uint8_t *o_strand,
+                                  uint8_t *o_ref, uint8_t *o_kmers)
+{
+    return hit_columns(h_ptable, table_len, scale, offset, width, n_parts, h_recs, n_recs, h_entry_of, region_base, flags, n_out,
+                       o_start, o_stop, o_freq, o_region, o_score, o_pvalue, o_qvalue, o_strand, o_ref, o_kmers);
+}
+
+// The tables of a motif SET: one job per motif, taken by the library's kept host threads while the caller goes on -- in
+// Python: builds the strings and the DataFrames of the width before, which hold the GIL (a Python helper thread around the
+// synchronous call bought nothing: a thread that wants the GIL back waits out the interpreter's 5 ms switch interval).
+static_assert(sizeof(gfm_hit_columns_job_t) == 160, "job layout of the C ABI (grafimo_amd/_native.py HitColumnsJob)");
+
+struct gfm_hit_columns_run {
+    gfm_workers::Run crew;
+    gfm_hit_columns_job_t *jobs = nullptr;
+    int n = 0;
+    std::atomic<int> next{0};
+    std::mutex mu;
+    int rc = GFM_OK;
+    std::string err;
+};
+
+GFM_API int gfm_graph_hit_columns_start(gfm_hit_columns_job_t *jobs, int32_t n_jobs, gfm_hit_columns_run_t *out)
+{
+    if (!out || n_jobs < 0 || (n_jobs && !jobs)) return hfail(GFM_ERR_INVALID, "gfm_graph_hit_columns_start: bad argument");
+    *out = nullptr;
+    gfm_hit_columns_run *r = new (std::nothrow) gfm_hit_columns_run;
+    if (!r) return hfail(GFM_ERR_NOMEM, "gfm_graph_hit_columns_start: out of host memory");
+    r->jobs = jobs;
+    r->n = n_jobs;
+    for (int i = 0; i < n_jobs; ++i) {
+        jobs[i].status = GFM_ERR_INVALID;      // (until its thread says otherwise)
+        jobs[i].n_out = 0;
+    }
+    const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+    const int threads = (int)std::min<unsigned>({(unsigned)n_jobs, hw / 2, 16u});
+    if (threads > 0)
+        r->crew.start(threads, [r] {
+            for (;;) {
+                const int i = r->next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= r->n) break;
+                gfm_hit_columns_job_t &j = r->jobs[i];
+                j.status = hit_columns(j.h_ptable, j.table_len, j.scale, j.offset, j.width, j.n_parts, j.h_recs, j.n_recs, j.h_entry_of,
+                                       j.region_base, j.flags, &j.n_out, j.o_start, j.o_stop, j.o_freq, j.o_region, j.o_score,
+                                       j.o_pvalue, j.o_qvalue, j.o_strand, j.o_ref, j.o_kmers);
+                if (j.status != GFM_OK) {      // the message sits in THIS thread's slot: carry it to the one that waits
+                    std::lock_guard<std::mutex> lk(r->mu);
+                    if (r->rc == GFM_OK) {
+                        r->rc = j.status;
+                        r->err = gfm_last_error();
+                    }
+                }
+            }
+        });
+    *out = r;
+    return GFM_OK;
+}
+
+GFM_API int gfm_graph_hit_columns_wait(gfm_hit_columns_run_t run)
+{
+    if (!run) return hfail(GFM_ERR_INVALID, "gfm_graph_hit_columns_wait: no run");
+    run->crew.wait();
+    const int rc = run->rc;
+    if (rc != GFM_OK) gfm_set_error_(run->err.c_str());
+    delete run;
+    return rc;
 }
 
 GFM_API int64_t gfm_region_labels(const char *chrom, const int64_t *h_starts, const int64_t *h_stops, int64_t n, char *h_out,

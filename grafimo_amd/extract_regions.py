@@ -1354,16 +1354,27 @@ def compute_results_from_graph_many(motifs: Sequence[Motif], graph, regions, deb
     for i, m in enumerate(motifs):
         by_width.setdefault(int(m.width), []).append(i)
     prep = _prep if _prep is not None else _prepare_entries(graph, regions, chrom_names, group, always_collective)
-    # The widths out of step: once a width's records are on the host (fetch) the NEXT width's passes are enqueued -- the device
-    # enumerates width w + 1 while the host builds the tables of width w (a table is ~0.5 ms of host work per 9 000 hit rows,
-    # a width's passes ~0.5 ms of device work).  Every rank runs the same sequence: the collectives stay in step.
+    # The widths out of step, three deep: once a width's records are on the host (fetch) the NEXT width's passes are enqueued
+    # -- the device enumerates width w + 1 --, the library's host threads turn the records of width w into columns (native code,
+    # no interpreter) and THIS thread builds the strings and DataFrames of width w - 1 meanwhile (per table of 9 000 hit rows:
+    # ~0.5 ms of device work, ~0.45 ms of native columns, ~0.7 ms of strings and pandas).  The records of width w are read in
+    # place from the page-locked buffer: its columns are waited for before the next fetch writes there.  Every rank runs the
+    # same sequence: the collectives stay in step.
     widths = list(by_width.values())
     live: List[_FusedPass] = []
+
+    def finish(p_, idxs_):
+        for i, t_ in zip(idxs_, p_.frames()):
+            out[i] = t_
+        p_.close()
+        live.remove(p_)
+
     try:
         cur = _FusedPass([motifs[i] for i in widths[0]], prep, debug, args_obj, None) if widths else None
         if cur is not None:
             live.append(cur)
             cur.enqueue()
+        prev = None
         for k, idxs in enumerate(widths):
             cur.fetch()
             nxt = None
@@ -1371,11 +1382,14 @@ def compute_results_from_graph_many(motifs: Sequence[Motif], graph, regions, deb
                 nxt = _FusedPass([motifs[i] for i in widths[k + 1]], prep, debug, args_obj, None)
                 live.append(nxt)
                 nxt.enqueue()
-            for i, t_ in zip(idxs, cur.tables()):
-                out[i] = t_
-            cur.close()
-            live.remove(cur)
+            cur.columns_start()
+            if prev is not None:
+                finish(*prev)
+            cur.columns_wait()
+            prev = (cur, idxs)
             cur = nxt
+        if prev is not None:
+            finish(*prev)
     finally:
         for p_ in live:
             p_.close()
@@ -1602,6 +1616,14 @@ def _fetch_fused(graphs, M: int, guess: int = 1024):
     return got
 
 
+def _columns_room(total: int, W: int) -> Dict[str, np.ndarray]:
+    i8 = lambda: np.empty(total, dtype=np.int64)      # noqa: E731
+    f8 = lambda: np.empty(total, dtype=np.float64)    # noqa: E731
+    u1 = lambda: np.empty(total, dtype=np.uint8)      # noqa: E731
+    return dict(start=i8(), stop=i8(), freq=i8(), region=i8(), logodds=f8(), pvalue=f8(), qvalue=f8(), strand=u1(), ref=u1(),
+                kmers=np.empty((total, W + 1), dtype=np.uint8))
+
+
 def _hit_columns(ptable: np.ndarray, scale: int, offset: float, W: int, entry_of, region_base, parts, recomb: bool,
                  first_per_region: bool):
     """gfm_graph_hit_columns over the records of one motif (one array per graph handle) -> the report's columns in report
@@ -1614,11 +1636,7 @@ def _hit_columns(ptable: np.ndarray, scale: int, offset: float, W: int, entry_of
     recs_p = (vp * n_parts)(*[r.ctypes.data if len(r) else None for r in parts])
     n_recs = (ctypes.c_int64 * n_parts)(*[len(r) for r in parts])
     eo_p = (vp * n_parts)(*[e.ctypes.data if len(e) else None for e in entry_of])
-    i8 = lambda: np.empty(total, dtype=np.int64)      # noqa: E731
-    f8 = lambda: np.empty(total, dtype=np.float64)    # noqa: E731
-    u1 = lambda: np.empty(total, dtype=np.uint8)      # noqa: E731
-    c = dict(start=i8(), stop=i8(), freq=i8(), region=i8(), logodds=f8(), pvalue=f8(), qvalue=f8(), strand=u1(), ref=u1(),
-             kmers=np.empty((total, W + 1), dtype=np.uint8))
+    c = _columns_room(total, W)
     n_out = ctypes.c_int64()
     flags = (0 if recomb else nv.GFM_HITS_DROP_ZERO_FREQ) | (nv.GFM_HITS_FIRST_PER_REGION if first_per_region else 0)
     nv.check(nv.lib().gfm_graph_hit_columns(nv.ptr(ptable), len(ptable), int(scale), float(offset), W, n_parts, recs_p, n_recs,
@@ -1628,6 +1646,52 @@ def _hit_columns(ptable: np.ndarray, scale: int, offset: float, W: int, entry_of
                                             nv.ptr(c["strand"]), nv.ptr(c["ref"]), nv.ptr(c["kmers"])))
     n = int(n_out.value)
     return {k: v[:n] for k, v in c.items()}
+
+
+class _ColumnsRun:
+    """_hit_columns for the motifs of a set on the library's host threads while this thread goes on (gfm_graph_hit_columns_start /
+    _wait): specs = one tuple of _hit_columns' arguments per motif; wait() -> their column dicts.  Everything the jobs point to
+    is held here until wait() returns; a run that was started is always waited for (close())."""
+
+    def __init__(self, specs):
+        vp = ctypes.c_void_p
+        self.keep = []
+        self.cols = []
+        self.jobs = (nv.HitColumnsJob * max(1, len(specs)))()
+        self.n = len(specs)
+        for j, (ptable, scale, offset, W, entry_of, region_base, parts, recomb, first_per_region) in zip(self.jobs, specs):
+            n_parts = len(parts)
+            parts = [np.ascontiguousarray(r) for r in parts]
+            recs_p = (vp * n_parts)(*[r.ctypes.data if len(r) else None for r in parts])
+            n_recs = (ctypes.c_int64 * n_parts)(*[len(r) for r in parts])
+            eo_p = (vp * n_parts)(*[e.ctypes.data if len(e) else None for e in entry_of])
+            c = _columns_room(int(sum(len(r) for r in parts)), W)
+            self.keep.append((ptable, parts, recs_p, n_recs, eo_p, entry_of, region_base))
+            self.cols.append(c)
+            j.h_ptable, j.table_len, j.scale, j.offset, j.width, j.n_parts = nv.ptr(ptable), len(ptable), int(scale), float(offset), W, n_parts
+            j.h_recs, j.n_recs = ctypes.cast(recs_p, vp), ctypes.cast(n_recs, vp)
+            j.h_entry_of, j.region_base = ctypes.cast(eo_p, vp), nv.ptr(region_base)
+            j.flags = (0 if recomb else nv.GFM_HITS_DROP_ZERO_FREQ) | (nv.GFM_HITS_FIRST_PER_REGION if first_per_region else 0)
+            j.o_start, j.o_stop, j.o_freq, j.o_region = nv.ptr(c["start"]), nv.ptr(c["stop"]), nv.ptr(c["freq"]), nv.ptr(c["region"])
+            j.o_score, j.o_pvalue, j.o_qvalue = nv.ptr(c["logodds"]), nv.ptr(c["pvalue"]), nv.ptr(c["qvalue"])
+            j.o_strand, j.o_ref, j.o_kmers = nv.ptr(c["strand"]), nv.ptr(c["ref"]), nv.ptr(c["kmers"])
+        self.run = ctypes.c_void_p()
+        nv.check(nv.lib().gfm_graph_hit_columns_start(ctypes.cast(self.jobs, vp), self.n, ctypes.byref(self.run)))
+
+    def wait(self):
+        run, self.run = self.run, None
+        if run is None:
+            raise RuntimeError("this run was waited for before")
+        nv.check(nv.lib().gfm_graph_hit_columns_wait(run))
+        out = [{k: v[:int(j.n_out)] for k, v in c.items()} for j, c in zip(self.jobs, self.cols)]
+        self.keep, self.cols = [], []
+        return out
+
+    def close(self):
+        if self.run is not None:
+            run, self.run = self.run, None
+            nv.lib().gfm_graph_hit_columns_wait(run)      # (the buffers go away with this object: the threads first)
+            self.keep, self.cols = [], []
 
 
 def _frame_of_columns(motif, c, seqnames, no_qvalue: bool) -> pd.DataFrame:
@@ -1654,7 +1718,9 @@ class _FusedPass:
     compute_results_from_graph_many): enqueue() -- the scoring passes, the exchange of the histograms, q-tables, the hit rows'
     columns, all on the device; fetch() -- counters and records to the host (the one synchronisation), a hit list that turned
     out too short taken again; tables() -- the report tables from the records, host work only (and, under a process group, the
-    gather of the rows).  close() gives the motif handles back."""
+    gather of the rows); for a motif set tables() in its two halves: columns_start() / columns_wait() -- the records into the
+    report's columns, native code on the library's host threads, this thread free meanwhile -- and frames() -- strings and
+    DataFrames, which hold the interpreter.  close() gives the motif handles back."""
 
     def __init__(self, motifs, prep: _FusedPrep, debug, args_obj, top_graphs):
         torch = _torch()
@@ -1665,6 +1731,8 @@ class _FusedPass:
         self.W = int(motifs[0].width)
         self.dev = prep.graphs[0].device
         self.got = None
+        self.cols = None
+        self._run = None
         self.dms = []
         for m in motifs:                 # kept handles when these motifs were scored before (device.py); the same numbers twice in
             dm = DeviceMotif.lease(m)    # one set: a handle of its own (a handle's workspace holds ONE histogram)
@@ -1686,6 +1754,9 @@ class _FusedPass:
             raise
 
     def close(self):
+        if self._run is not None:
+            self._run.close()
+            self._run = None
         for dm in self.dms:
             dm.release()
         self.dms = []
@@ -1764,7 +1835,26 @@ class _FusedPass:
                                                       f"regions hold more than 2^20 windows of more than 64 walks each (scan fewer regions at a time)")
         self.got = got
 
+    def _column_specs(self):
+        # the hit rows: filtered (--recomb), in report order (p-value, then the TSV rows' order: entry, window, walk, strand), as
+        # columns -- native code; with top_graphs one row per region leaves this rank (the top-hit-only gather)
+        prep = self.prep
+        return [(dm.ptable_host(), dm.scale, dm.offset, self.W, prep.entry_of, prep.region_base,
+                 [recs for _, _, _, recs in self.got[mi]], self.recomb, self.top_graphs is not None)
+                for mi, dm in enumerate(self.dms)]
+
+    def columns_start(self):
+        self._run = _ColumnsRun(self._column_specs())
+
+    def columns_wait(self):
+        run, self._run = self._run, None
+        self.cols = run.wait()
+
     def tables(self):
+        self.cols = [_hit_columns(*spec) for spec in self._column_specs()]
+        return self.frames()
+
+    def frames(self):
         from .resultsTmp import build_frame_sorted
         from .score_sequences import print_scoring_msg
         torch = _torch()
@@ -1791,12 +1881,7 @@ class _FusedPass:
             if rank == 0:
                 print(f"Scanned sequences:\t{n_global}")
                 print(f"Scanned nucleotides:\t{n_global * W}")
-            # ---- the hit rows: filtered (--recomb), in report order (p-value, then the TSV rows' order: entry, window, walk,
-            # strand), as columns -- one native call; with top_graphs one row per region leaves this rank (the top-hit-only
-            # gather)
-            dm = self.dms[mi]
-            c = _hit_columns(dm.ptable_host(), dm.scale, dm.offset, W, prep.entry_of, prep.region_base,
-                             [recs for _, _, _, recs in got[mi]], self.recomb, top_graphs is not None)
+            c = self.cols[mi]
             seqnames = prep.labels.take(c["region"])
             if world > 1:      # packed columns to rank 0 (one tensor gather), the hit rows' region labels beside them
                 from .distributed import gather_columns, gather_names
@@ -1819,6 +1904,7 @@ class _FusedPass:
                 from .top_hits import top_regions_table
                 df = top_regions_table(df, top_graphs)
             tables.append(df)
+        self.cols = None
         return tables
 
 

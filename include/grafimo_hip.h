@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GFM_ABI_VERSION 11
+#define GFM_ABI_VERSION 12
 
 #define GFM_OK 0
 #define GFM_ERR_INVALID (-1)  /* bad argument (NULL, width out of range, ...)            */
@@ -509,6 +509,31 @@ int gfm_graph_hit_columns(const double *h_ptable, int32_t table_len, int32_t sca
                           uint32_t flags, int64_t *n_out, int64_t *o_start, int64_t *o_stop, int64_t *o_freq,
                           int64_t *o_region, double *o_score, double *o_pvalue, double *o_qvalue, uint8_t *o_strand,
                           uint8_t *o_ref, uint8_t *o_kmers);
+/* gfm_graph_hit_columns for the motifs of a SET without holding the caller -- grafimo.findmotif builds one table per motif
+ * of the set (grafimo.py:177-183), and what a Python caller does with a table's columns next (strings, a DataFrame) holds
+ * the interpreter: the jobs -- one per motif, the arguments of gfm_graph_hit_columns as a struct; `status` and `n_out`
+ * are written by the library -- are taken by the library's kept host threads, _start returns at once, _wait returns when
+ * every job is done (and frees the run): GFM_OK, or the code of the first job that failed with its message in
+ * gfm_last_error(); jobs[i].status says which.  The jobs array and every buffer it points to stay untouched by the caller
+ * from _start to _wait.  Every run that was started must be waited for. */
+typedef struct gfm_hit_columns_job {
+    const double *h_ptable;
+    const gfm_graph_hit_t *const *h_recs;
+    const int64_t *n_recs;
+    const int64_t *const *h_entry_of;
+    const int64_t *region_base;
+    int64_t *o_start, *o_stop, *o_freq, *o_region;
+    double *o_score, *o_pvalue, *o_qvalue;
+    uint8_t *o_strand, *o_ref, *o_kmers;
+    double offset;
+    int64_t n_out;      /* out: rows written */
+    int32_t table_len, scale, width, n_parts;
+    uint32_t flags;
+    int32_t status;     /* out: GFM_OK or this job's error code */
+} gfm_hit_columns_job_t;
+typedef struct gfm_hit_columns_run *gfm_hit_columns_run_t;
+int gfm_graph_hit_columns_start(gfm_hit_columns_job_t *jobs, int32_t n_jobs, gfm_hit_columns_run_t *out);
+int gfm_graph_hit_columns_wait(gfm_hit_columns_run_t run);
 /* The sequence_name strings of regions, "CHROM:START-STOP" (extract_regions.py:165-170: the query string of `vg find -p`,
  * which score_seqs copies from column 1 of the rows), '\n'-terminated, one after the other in h_out.  Returns the bytes
  * written; with capacity too small (0 to ask) nothing is written and the room to come back with is returned. */

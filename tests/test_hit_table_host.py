@@ -97,6 +97,60 @@ def test_hit_columns_arguments_and_empty_input():
     assert nv.lib().gfm_region_labels(None, None, None, 0, None, 0) == nv.GFM_ERR_INVALID
 
 
+def test_columns_of_a_motif_set_on_the_library_threads_equal_the_single_calls():
+    """gfm_graph_hit_columns_start / _wait (one job per motif of a set, the caller free meanwhile) == gfm_graph_hit_columns
+    per motif: 23 jobs of different widths, sizes (empty ones among them), flags and part counts -- more jobs than threads --
+    several runs one after the other (the threads' scratch is reused), two runs in flight at once; a job that fails says
+    which and why while the others finish."""
+    rng = np.random.default_rng(77)
+
+    def spec(i):
+        W = int(rng.integers(1, 65))
+        L = 1000 * W + 1
+        pmf = rng.random(L)
+        ptable = np.minimum.accumulate(np.cumsum(pmf[::-1])[::-1] / pmf.sum())
+        n_parts = int(rng.integers(1, 4))
+        n_regions = [int(rng.integers(1, 300)) for _ in range(n_parts)]
+        parts = [_records(rng, 0 if i % 7 == 3 else int(rng.integers(0, 4000)), W, nr, dup_scores=bool(i % 2)) for nr in n_regions]
+        entry_of = [np.sort(rng.integers(10 * p, 10 * p + 3, nr)).astype(np.int64) for p, nr in enumerate(n_regions)]
+        return (ptable, 37 + i, -12.0 - i, W, entry_of, np.cumsum([0] + n_regions).astype(np.int64), parts, bool(i % 3), i % 5 == 4)
+
+    specs = [spec(i) for i in range(23)]
+    want = [xr._hit_columns(*sp) for sp in specs]
+    for rep in range(3):
+        got = xr._ColumnsRun(specs).wait()
+        assert len(got) == len(want)
+        for g_, w_ in zip(got, want):
+            assert set(g_) == set(w_)
+            for k in w_:
+                assert g_[k].dtype == w_[k].dtype and np.array_equal(g_[k], w_[k]), k
+    a, b = xr._ColumnsRun(specs[:9]), xr._ColumnsRun(specs[9:])                  # (the second finds the crew busy: threads of its own)
+    for g_, w_ in zip(a.wait() + b.wait(), want):
+        assert all(np.array_equal(g_[k], w_[k]) for k in w_)
+    assert xr._ColumnsRun([]).wait() == []
+    with pytest.raises(RuntimeError):
+        a.wait()
+    # one bad record in job 4: that job's status and message; the others' columns are complete
+    bad = list(specs[4])
+    recs = specs[4][6][0].copy() if len(specs[4][6][0]) else _records(rng, 5, specs[4][3], len(specs[4][4][0]))
+    recs["keep"][0], recs["score"][0] = 1, len(specs[4][0])
+    bad[6] = [recs] + list(specs[4][6][1:])
+    run = xr._ColumnsRun(specs[:4] + [tuple(bad)] + specs[5:8])
+    with pytest.raises(nv.NativeError) as e:
+        run.wait()
+    assert "outside the table" in e.value.msg
+    assert [int(j.status) for j in run.jobs][:8] == [0, 0, 0, 0, nv.GFM_ERR_INVALID, 0, 0, 0]
+    # a run nobody waited for is waited for by close(); the C entry points check their arguments
+    r_ = xr._ColumnsRun(specs[:3])
+    r_.close()
+    assert r_.run is None
+    import ctypes
+    out = ctypes.c_void_p()
+    assert nv.lib().gfm_graph_hit_columns_start(None, 2, ctypes.byref(out)) == nv.GFM_ERR_INVALID
+    assert nv.lib().gfm_graph_hit_columns_start(None, 0, None) == nv.GFM_ERR_INVALID
+    assert nv.lib().gfm_graph_hit_columns_wait(None) == nv.GFM_ERR_INVALID
+
+
 def test_region_labels():
     rng = np.random.default_rng(7)
     runs = [("22", rng.integers(0, 1 << 40, 300), rng.integers(0, 1 << 40, 300)), ("chrUn_KI270742v1", np.array([0, 7]), np.array([5, 9])),
@@ -197,7 +251,9 @@ def manifest_dir(tmp_path, monkeypatch):
     def fake_prep(manifest, group=None):
         return ("prep", tuple(e["chrom"] for e in manifest["entries"]), group)
 
-    class FakePass:                       # xr._FusedPass: enqueue -> fetch -> tables -> close
+    class FakePass:                       # xr._FusedPass: enqueue -> fetch -> tables -> close; a motif set: enqueue -> fetch ->
+        running = []                      # columns_start -> columns_wait -> frames -> close (native columns in flight: ONE pass's)
+
         def __init__(self, motifs, prep, debug, args_obj, top_graphs):
             self.motifs, self.state = motifs, []
             calls.append(([m.motif_id for m in motifs], prep, top_graphs))
@@ -207,11 +263,30 @@ def manifest_dir(tmp_path, monkeypatch):
 
         def fetch(self):
             assert self.state == ["enqueue"]
+            # the records are read in place from ONE page-locked buffer: nobody's columns may be running when a fetch writes there
+            assert not FakePass.running
             self.state.append("fetch")
+
+        def _frames(self):
+            return [pd.DataFrame({"motif_id": [m.motif_id], "width": [m.width]}) for m in self.motifs]
 
         def tables(self):
             assert self.state == ["enqueue", "fetch"]
-            return [pd.DataFrame({"motif_id": [m.motif_id], "width": [m.width]}) for m in self.motifs]
+            return self._frames()
+
+        def columns_start(self):
+            assert self.state == ["enqueue", "fetch"]
+            FakePass.running.append(self)
+            self.state.append("start")
+
+        def columns_wait(self):
+            assert self.state == ["enqueue", "fetch", "start"]
+            FakePass.running.remove(self)
+            self.state.append("wait")
+
+        def frames(self):
+            assert self.state == ["enqueue", "fetch", "start", "wait"]
+            return self._frames()
 
         def close(self):
             self.state.append("close")

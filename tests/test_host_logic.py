@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared but not exported"
         assert name in nv.PROTOTYPES, f"{name} has no ctypes prototype"
     assert set(nv.PROTOTYPES) == declared
-    assert lib.gfm_abi_version() == nv.ABI_VERSION == 11
+    assert lib.gfm_abi_version() == nv.ABI_VERSION == 12
     # importing / loading must not have initialised a device; counting devices is allowed
     assert nv.device_count() >= 0
 
