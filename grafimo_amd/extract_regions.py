@@ -1694,6 +1694,38 @@ class _ColumnsRun:
             self.keep, self.cols = [], []
 
 
+_FAST_FRAME = None      # None: not tried yet; True / False: pandas' block-manager constructor checked against the public one
+
+
+def _frame_from_final_columns(data: Dict[str, np.ndarray]) -> pd.DataFrame:
+    """pd.DataFrame(data, copy=False) for columns that are FINAL -- 1-D numpy arrays of one length, already of the dtype the
+    table holds.  The public constructor spends 90 of a 330 us compute_results call looking at twelve such columns again
+    (sanitize_array, datetime inference on the object columns, index extraction); pandas' own column-arrays -> block manager
+    step (what read_csv and the constructor end in) takes a third of that.  It is an internal of pandas, so: the first table
+    of a process is built both ways and compared -- any exception or difference, now or later, and the public constructor is
+    used from then on."""
+    global _FAST_FRAME
+    arrays = list(data.values())
+    n = len(arrays[0]) if arrays and type(arrays[0]) is np.ndarray else 0
+    final = bool(arrays) and all(type(a) is np.ndarray and a.ndim == 1 and len(a) == n for a in arrays)
+    if final and _FAST_FRAME is not False:
+        try:
+            from pandas.core.internals.managers import create_block_manager_from_column_arrays
+            mgr = create_block_manager_from_column_arrays(arrays, [pd.Index(list(data)), pd.RangeIndex(n)], consolidate=False,
+                                                          refs=[None] * len(arrays))
+            df = pd.DataFrame._from_mgr(mgr, axes=mgr.axes)
+            if _FAST_FRAME is None:
+                ref = pd.DataFrame(data, copy=False)
+                _FAST_FRAME = bool(type(df) is pd.DataFrame and df.equals(ref) and list(df.dtypes) == list(ref.dtypes)
+                                   and df.columns.equals(ref.columns) and df.index.equals(ref.index))
+                if not _FAST_FRAME:
+                    return ref
+            return df
+        except Exception:      # noqa: BLE001 -- whatever a future pandas does there: the public way
+            _FAST_FRAME = False
+    return pd.DataFrame(data, copy=False)
+
+
 def _frame_of_columns(motif, c, seqnames, no_qvalue: bool) -> pd.DataFrame:
     """The report table (column names and order of resultsTmp.py:270-301) from columns that are final -- filtered, in
     report order -- without a per-row Python step: the strings of a column are gathered from the few distinct ones, the
@@ -1710,7 +1742,7 @@ def _frame_of_columns(motif, c, seqnames, no_qvalue: bool) -> pd.DataFrame:
     data["matched_sequence"] = _split_lines(c["kmers"])
     data["haplotype_frequency"] = c["freq"]
     data["reference"] = _REF_OBJ[c["ref"]]
-    return pd.DataFrame(data, copy=False)
+    return _frame_from_final_columns(data)
 
 
 class _FusedPass:

@@ -188,6 +188,45 @@ def test_frame_of_columns_is_the_table_build_frame_makes():
         assert df["matched_sequence"].map(type).eq(str).all() and df["sequence_name"].map(type).eq(str).all()
 
 
+def test_frame_from_final_columns_is_the_public_constructors_frame(monkeypatch):
+    """_frame_from_final_columns goes through pandas' column-arrays -> block-manager step (an internal): the frame must be the
+    public constructor's -- values, dtypes, labels -- and behave like one (a new column, a cell written, sorted, written out,
+    empty); anything else than final columns, or a pandas whose internal differs, falls back to the public constructor."""
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 253):
+        obj = np.empty(n, dtype=object)
+        obj[:] = [f"s{i}" for i in range(n)]
+        data = {"motif_id": obj, "start": rng.integers(0, 1 << 40, n), "score": rng.random(n), "strand": xr._STRAND_OBJ[rng.integers(0, 2, n)],
+                "p-value": rng.random(n), "haplotype_frequency": rng.integers(0, 5000, n)}
+        monkeypatch.setattr(xr, "_FAST_FRAME", None)
+        first = xr._frame_from_final_columns(data)              # (the first table of a process: built both ways and compared)
+        assert xr._FAST_FRAME is True
+        df = xr._frame_from_final_columns(data)
+        ref = pd.DataFrame(data, copy=False)
+        for got in (first, df):
+            pd.testing.assert_frame_equal(got, ref)
+            assert type(got) is pd.DataFrame and list(got.dtypes) == list(ref.dtypes)
+        if n:
+            df["extra"] = 1
+            df.loc[0, "start"] = 7
+            assert df.loc[0, "start"] == 7 and df.shape == (n, 7)
+            assert df.sort_values("p-value").iloc[0]["p-value"] == data["p-value"].min()
+            assert df.drop(columns="extra").to_csv(sep="\t") == ref.assign(start=df["start"]).to_csv(sep="\t")
+            assert df[df["strand"] == "+"]["motif_id"].tolist() == [x for x, s_ in zip(obj, data["strand"]) if s_ == "+"]
+    # not final columns (a list, a 2-D array, ragged lengths): the public constructor, as it would behave
+    for odd in ({"a": [1, 2, 3], "b": np.arange(3)}, {"a": np.arange(3), "b": np.arange(3).astype(object).reshape(3, 1)[:, 0][::-1]}):
+        pd.testing.assert_frame_equal(xr._frame_from_final_columns(odd), pd.DataFrame(odd))
+    with pytest.raises(ValueError):
+        xr._frame_from_final_columns({"a": np.arange(3), "b": np.arange(4)})
+    assert xr._FAST_FRAME is True
+    # a pandas without that internal: the same
+    import pandas.core.internals.managers as mgrs
+    monkeypatch.setattr(xr, "_FAST_FRAME", None)
+    monkeypatch.delattr(mgrs, "create_block_manager_from_column_arrays")
+    pd.testing.assert_frame_equal(xr._frame_from_final_columns(data), pd.DataFrame(data))
+    assert xr._FAST_FRAME is False
+
+
 def test_index_file_is_mapped_not_read(tmp_path):
     """GraphIndex.save writes a .npz numpy can read whose members are stored and 64-byte aligned; load() maps it."""
     from grafimo_amd import synth
