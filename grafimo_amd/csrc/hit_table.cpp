@@ -211,24 +211,31 @@ GFM_API int gfm_graph_hit_columns_start(gfm_hit_columns_job_t *jobs, int32_t n_j
     }
     const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
     const int threads = (int)std::min<unsigned>({(unsigned)n_jobs, hw / 2, 16u});
-    if (threads > 0)
-        r->crew.start(threads, [r] {
-            for (;;) {
-                const int i = r->next.fetch_add(1, std::memory_order_relaxed);
-                if (i >= r->n) break;
-                gfm_hit_columns_job_t &j = r->jobs[i];
-                j.status = hit_columns(j.h_ptable, j.table_len, j.scale, j.offset, j.width, j.n_parts, j.h_recs, j.n_recs, j.h_entry_of,
-                                       j.region_base, j.flags, &j.n_out, j.o_start, j.o_stop, j.o_freq, j.o_region, j.o_score,
-                                       j.o_pvalue, j.o_qvalue, j.o_strand, j.o_ref, j.o_kmers);
-                if (j.status != GFM_OK) {      // the message sits in THIS thread's slot: carry it to the one that waits
-                    std::lock_guard<std::mutex> lk(r->mu);
-                    if (r->rc == GFM_OK) {
-                        r->rc = j.status;
-                        r->err = gfm_last_error();
-                    }
+    auto work = [r] {
+        for (;;) {
+            const int i = r->next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= r->n) break;
+            gfm_hit_columns_job_t &j = r->jobs[i];
+            j.status = hit_columns(j.h_ptable, j.table_len, j.scale, j.offset, j.width, j.n_parts, j.h_recs, j.n_recs, j.h_entry_of,
+                                   j.region_base, j.flags, &j.n_out, j.o_start, j.o_stop, j.o_freq, j.o_region, j.o_score,
+                                   j.o_pvalue, j.o_qvalue, j.o_strand, j.o_ref, j.o_kmers);
+            if (j.status != GFM_OK) {      // the message sits in THIS thread's slot: carry it to the one that waits
+                std::lock_guard<std::mutex> lk(r->mu);
+                if (r->rc == GFM_OK) {
+                    r->rc = j.status;
+                    r->err = gfm_last_error();
                 }
             }
-        });
+        }
+    };
+    if (threads > 0) {
+        try {
+            r->crew.start(threads, work);
+        } catch (...) {                    // no thread to be had: the jobs on this one, before _start returns
+            r->crew.wait();
+            work();
+        }
+    }
     *out = r;
     return GFM_OK;
 }
