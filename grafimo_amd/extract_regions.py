@@ -1547,21 +1547,26 @@ def _prepare_entries(graph, regions, chrom_names, group, always_collective) -> _
     return P
 
 
-_PINNED: Dict[int, "object"] = {}
+import threading as _threading
+
+_PINNED = _threading.local()
 
 
 def _pinned_words(n: int):
-    """int64 [>= n] of page-locked host memory, kept per device and grown geometrically: where a call's hit records land."""
+    """int64 [>= n] of page-locked host memory, kept per device and calling thread (the records are read from it in place: two
+    threads scoring over two graphs must not share it; it goes away with its thread) and grown geometrically: where a call's
+    hit records land."""
     torch = _torch()
     key = torch.cuda.current_device()
-    buf = _PINNED.get(key)
+    bufs = _PINNED.__dict__.setdefault("bufs", {})
+    buf = bufs.get(key)
     if buf is None or buf.numel() < n:
         size = max(int(n), 1 << 16, 0 if buf is None else 2 * buf.numel())
         try:
             buf = torch.empty(size, dtype=torch.int64, pin_memory=True)
         except RuntimeError:                         # (no page-locked memory to be had: pageable works, only slower)
             buf = torch.empty(size, dtype=torch.int64)
-        _PINNED[key] = buf
+        bufs[key] = buf
     return buf
 
 

@@ -13,7 +13,8 @@
  *  - every function returns GFM_OK (0) or a negative GFM_ERR_* code and never throws;
  *    gfm_last_error() returns a thread-local message for the last failure;
  *  - pointers named h_* are host memory, d_* are device memory of the current HIP device
- *    (e.g. torch tensors' data_ptr()); the library never keeps a caller pointer after return;
+ *    (e.g. torch tensors' data_ptr()); the library never keeps a caller pointer after return
+ *    (one exception, by its purpose: gfm_graph_hit_columns_start, until its _wait has returned);
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Functions that take
  *    a stream only enqueue work (no allocation, no synchronisation: graph-capturable);
  *  - HIP is initialised lazily by the first call that needs a device, never at load time,
