@@ -506,6 +506,57 @@ def test_a_motif_set_equals_the_oracle_on_heavy_and_one_deletion_windows(tmp_pat
     g.close()
 
 
+def test_two_host_threads_over_two_graphs(tmp_path):
+    """Two Python threads, each with a graph handle and motifs of its own, call compute_results_from_graph and
+    compute_results_from_graph_many at the same time (the waits and the native calls release the interpreter, so the calls do
+    overlap): every table equals the one the same call gave alone.  What the threads share is the library's host threads (the
+    second motif set finds them busy and starts its own), the kept motif handles' table and the stream; what they must NOT
+    share is the page-locked buffer the hit records are read from in place -- it is per thread.  (Two threads scoring the SAME
+    motif would share its handle's workspace: not supported, as in the reference, which forks processes.)"""
+    import threading
+    from grafimo_amd.extract_regions import (DeviceGraph, GraphIndex, compute_results_from_graph, compute_results_from_graph_many)
+    from grafimo_amd.workflow import Findmotif
+    work = []
+    for t, seed in enumerate((11, 12)):
+        d_ = tmp_path / f"g{t}"
+        d_.mkdir()
+        fasta, vcf = make_graph_files(str(d_), chrom="7", length=4000, n_sites=420, n_samples=30, seed=seed, rich=True)
+        g = DeviceGraph(GraphIndex.from_fasta_vcf(fasta, vcf, "7"))
+        regions = [(0, 900), (1000, 2400), (2500, 3990)]
+        motifs = [_motif_of_width(W, seed=40 + 10 * t + i) for i, W in enumerate((12, 19, 12, 8, 12, 12, 19))]
+        work.append((g, regions, motifs))
+    wf = Findmotif(threshold=0.2, recomb=True)          # thousands of rows per table: lists beyond the first 1 024 records
+    with contextlib.redirect_stdout(io.StringIO()):
+        alone = [([compute_results_from_graph(m, g, r, True, wf) for m in ms], compute_results_from_graph_many(ms, g, r, True, wf))
+                 for g, r, ms in work]
+        assert all(len(t_) > 1024 for singles, _ in alone for t_ in singles[:3])
+        got, errors = [[], []], []
+
+        def run(t):
+            try:
+                g, r, ms = work[t]
+                for rep in range(6):
+                    got[t].append(([compute_results_from_graph(m, g, r, True, wf) for m in ms],
+                                   compute_results_from_graph_many(ms, g, r, True, wf)))
+            except Exception as e:      # noqa: BLE001 -- reported by the main thread
+                errors.append((t, repr(e)))
+
+        threads = [threading.Thread(target=run, args=(t,)) for t in (0, 1)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    assert not errors, errors
+    for t in (0, 1):
+        assert len(got[t]) == 6
+        for rep, (singles, many) in enumerate(got[t]):
+            for i, (a, b, c) in enumerate(zip(singles, many, alone[t][0])):
+                _assert_same(a, c, f"thread {t} rep {rep} motif {i} single")
+                _assert_same(b, c, f"thread {t} rep {rep} motif {i} in the set")
+    for g, _, _ in work:
+        g.close()
+
+
 def test_more_region_sets_than_a_handle_keeps_plans_for(tmp_path):
     """A graph handle keeps the plans of its 32 most recently used (regions, width) pairs; the 33rd evicts the least recently
     used one -- whose buffers kernels of earlier calls may still be reading -- and a set that comes back is planned again:
