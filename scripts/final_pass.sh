@@ -59,11 +59,11 @@ cp "$root/gpurun_out/pmc_fused_sq/summary.txt" "$out/pmc_fused_sq.txt" 2>/dev/nu
 # (GRAFIMO_FUSED_TIMERS=2: one store per tile, no atomics -- mode 1's per-phase sums go through atomics on a few words and
 # stretch the kernel tenfold)
 [ -f "$root/lab/libgfm_fusedlab.so" ] && GRAFIMO_HIP_LIB="$root/lab/libgfm_fusedlab.so" GRAFIMO_FUSED_TIMERS=2 python scripts/fused_prof.py 2>&1 | grep "\[fused\]" | tail -18 > "$out/fused_timers.txt"
-# the four fuzz drivers on fresh seeds (bounded: FUZZ_S seconds each), the round's last code
+# the five fuzz drivers on fresh seeds (bounded: FUZZ_S seconds each), the round's last code
 {
   s0=$(( $(date +%s) % 100000 ))
-  for f in score_fuzz scan_fuzz results_fuzz extract_fuzz; do
+  for f in score_fuzz scan_fuzz results_fuzz extract_fuzz tables_fuzz; do
     echo "== scripts/$f.py ${FUZZ_S:-100} $s0"
-    timeout $(( ${FUZZ_S:-100} + 200 )) python scripts/$f.py ${FUZZ_S:-100} $s0 2>&1 | grep -v "amdgpu.ids" | tail -4
+    timeout $(( ${FUZZ_S:-100} + 200 )) python scripts/$f.py ${FUZZ_S:-100} $s0 2>&1 | grep -v -E "amdgpu.ids|^NOTE|^WARNING" | tail -4
   done
 } > "$out/fuzz_final.txt" 2>&1

@@ -422,6 +422,17 @@ def test_fuzz_seeds_fused_and_materialised_equal_enumerator_and_brute_force(tmp_
     assert stats["graphs"] == len(KINDS) and stats["fused"] >= 3 * len(KINDS) and stats["rows"] > 100_000, stats
 
 
+def test_fuzz_seeds_report_tables_equal_the_oracle(tmp_path):
+    """A bounded seed set of scripts/tables_fuzz.py inside the suite: random rich graphs, regions, motif sets (widths 1..40,
+    several motifs of a width, the same motif twice) and flags; compute_results_from_graph_many (widths out of step, native
+    columns on the library's threads) == compute_results_from_graph per motif == the CPU oracle's table, every column."""
+    from tables_fuzz_core import fuzz_seed
+    stats = dict(graphs=0, tables=0, rows_scanned=0, rows_reported=0)
+    for seed in range(1, 9):
+        fuzz_seed(seed, str(tmp_path), stats)
+    assert stats["graphs"] == 8 and stats["tables"] >= 16 and stats["rows_reported"] > 1000, stats
+
+
 def test_lab_switches_are_not_in_the_product(tmp_path, monkeypatch):
     """GRAFIMO_FUSED_LAB turned parts of graph_score_kernel off at run time (results wrong).  It now exists only
     in lab builds (scripts/lab_build.sh -DGFM_LAB): the product library does not contain the variable's name, and setting
