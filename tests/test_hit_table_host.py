@@ -166,6 +166,30 @@ def test_region_labels():
     assert list(xr.RegionLabels([]).take(np.zeros(0, np.int64))) == []
 
 
+def test_label_tables_are_shared_by_calls_over_the_same_regions(monkeypatch):
+    """RegionLabels.shared: GRAFIMO's loop makes one call per motif over one set of regions; the calls share ONE label table
+    (compared by content, not by identity), a different region set gets its own, four are kept, a caller that changes its
+    arrays afterwards does not change a kept table."""
+    monkeypatch.setattr(xr.RegionLabels, "_kept", [])
+    s_, e_ = np.arange(1000, dtype=np.int64) * 300, np.arange(1000, dtype=np.int64) * 300 + 200
+    a = xr.RegionLabels.shared([("chr1", s_, e_)])
+    b = xr.RegionLabels.shared([("chr1", s_.copy(), e_.copy())])
+    assert a is b
+    ids = np.array([5, 999, 5, 0])
+    assert list(a.take(ids)) == ["chr1:1500-1700", "chr1:299700-299900", "chr1:1500-1700", "chr1:0-200"]
+    assert xr.RegionLabels.shared([("chr2", s_, e_)]) is not a                      # another name
+    assert xr.RegionLabels.shared([("chr1", s_, e_ + 1)]) is not a                  # other coordinates
+    assert xr.RegionLabels.shared([("chr1", s_[:-1], e_[:-1])]) is not a            # fewer regions
+    assert xr.RegionLabels.shared([("chr1", s_, e_)]) is a and xr.RegionLabels._kept[0] is a
+    s_[5] = 7                                                                       # the caller's array, not the table's
+    assert a.take(np.array([5]))[0] == "chr1:1500-1700"
+    assert xr.RegionLabels.shared([("chr1", s_, e_)]) is not a
+    assert len(xr.RegionLabels._kept) == 4 and a in xr.RegionLabels._kept
+    for k in range(4):
+        xr.RegionLabels.shared([(f"x{k}", s_, e_)])
+    assert a not in xr.RegionLabels._kept and len(xr.RegionLabels._kept) == 4
+
+
 def test_frame_of_columns_is_the_table_build_frame_makes():
     from grafimo_amd.resultsTmp import build_frame
     from grafimo_amd.motif import Motif
