@@ -322,3 +322,25 @@ def test_paths_are_handed_over_as_one_blob():
         assert arr[i] == paths[i].encode()
     arr0, keep0 = nv.c_paths([])
     assert keep0 is None and not arr0
+
+
+def test_lease_key_fingerprint_of_a_score_distribution():
+    """DeviceMotif.lease keys a kept handle by the motif's numbers; the score distribution (152 KB) goes in as a fingerprint
+    that sees any changed entry and entries that trade places, and costs a fraction of hashing the bytes."""
+    from grafimo_amd.device import _fingerprint
+    rng = np.random.default_rng(8)
+    a = rng.random(19001)
+    f = _fingerprint(a)
+    assert f == _fingerprint(a.copy()) == _fingerprint(list(a)) and f[0] == 19001
+    seen = {f}
+    for i in rng.integers(0, len(a), 200):
+        b = a.copy()
+        b[i] = np.nextafter(b[i], 2.0)                      # one ulp in one entry
+        seen.add(_fingerprint(b))
+        j = int(rng.integers(0, len(a)))
+        if a[i] != a[j]:
+            c = a.copy()
+            c[[i, j]] = c[[j, i]]                           # two entries trade places
+            assert _fingerprint(c) != f
+    assert len(seen) == 201
+    assert _fingerprint(np.zeros(0)) == (0, 0, 0) and _fingerprint(a[:1000]) != _fingerprint(a[:1001])
