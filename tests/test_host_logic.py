@@ -333,7 +333,7 @@ def test_lease_key_fingerprint_of_a_score_distribution():
     f = _fingerprint(a)
     assert f == _fingerprint(a.copy()) == _fingerprint(list(a)) and f[0] == 19001
     seen = {f}
-    for i in rng.integers(0, len(a), 200):
+    for i in rng.choice(len(a), size=200, replace=False):
         b = a.copy()
         b[i] = np.nextafter(b[i], 2.0)                      # one ulp in one entry
         seen.add(_fingerprint(b))
