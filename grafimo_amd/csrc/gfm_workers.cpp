@@ -92,8 +92,13 @@ struct Run::Impl {
 
 void Run::start(int n, std::function<void()> fn)
 {
+    start_(n, std::move(fn), false);
+}
+
+bool Run::start_(int n, std::function<void()> fn, bool only_crew)
+{
     wait();
-    if (n < 1) return;
+    if (n < 1) return true;
     impl_ = new Impl();
     Crew *c = n <= kMaxCrew ? crew() : nullptr;
     if (c) {
@@ -117,11 +122,17 @@ void Run::start(int n, std::function<void()> fn)
                 impl_->crew = c;
                 lk.unlock();
                 c->cv_job.notify_all();
-                return;
+                return true;
             }
         }
     }
+    if (only_crew) {
+        delete impl_;
+        impl_ = nullptr;
+        return false;
+    }
     for (int k = 0; k < n; ++k) impl_->own.emplace_back(fn);
+    return true;
 }
 
 void Run::wait()
@@ -138,6 +149,15 @@ void Run::wait()
         if (th.joinable()) th.join();
     delete impl_;
     impl_ = nullptr;
+}
+
+bool run_if_idle(int n, const std::function<void()> &fn)
+{
+    if (n < 1) return false;
+    Run r;
+    if (!r.start_(n, fn, true)) return false;
+    r.wait();
+    return true;
 }
 
 void run(int n, const std::function<void()> &fn)

@@ -18,6 +18,7 @@ public:
     Run &operator=(const Run &) = delete;
     ~Run() { wait(); }
     void start(int n, std::function<void()> fn);
+    bool start_(int n, std::function<void()> fn, bool only_crew);   // start(); only_crew: false, nothing started, when the crew cannot take it
     void wait();
 
 private:
@@ -27,5 +28,9 @@ private:
 
 // start + wait; n <= 1 runs fn on the calling thread
 void run(int n, const std::function<void()> &fn);
+
+// run() for help that is only worth having when it is free: with the kept crew or not at all -- false, fn not called, when the
+// crew is busy with another Run or cannot grow to n (plain threads started for a 100 us job would cost more than they save)
+bool run_if_idle(int n, const std::function<void()> &fn);
 
 }  // namespace gfm_workers

@@ -43,6 +43,8 @@ struct Key {
     const gfm_graph_hit_t *rec;
 };
 
+constexpr int64_t kThreadedRows = 4096;     // a single table of fewer rows is not worth waking threads for (~20 us)
+
 inline bool key_less(const Key &a, const Key &b)      // inside one score: the order of the TSV rows
 {
     if (a.ew != b.ew) return a.ew < b.ew;
@@ -55,7 +57,7 @@ int hit_columns(const double *h_ptable, int32_t table_len, int32_t scale, double
                 const int64_t *n_recs, const int64_t *const *h_entry_of, const int64_t *region_base,
                 uint32_t flags, int64_t *n_out, int64_t *o_start, int64_t *o_stop, int64_t *o_freq,
                 int64_t *o_region, double *o_score, double *o_pvalue, double *o_qvalue, uint8_t *o_strand,
-                uint8_t *o_ref, uint8_t *o_kmers)
+                uint8_t *o_ref, uint8_t *o_kmers, int threads)
 {
     if (!h_ptable || table_len < 1 || scale == 0 || !n_out || n_parts < 0 || (n_parts && (!h_recs || !n_recs)) || width < 1 || width > GFM_MAX_WIDTH)
         return hfail(GFM_ERR_INVALID, "gfm_graph_hit_columns: bad argument");
@@ -121,9 +123,29 @@ int hit_columns(const double *h_ptable, int32_t table_len, int32_t scale, double
             sorted.resize((size_t)n);
             put.assign(at.begin(), at.end() - 1);
             for (const Key &k : keys) sorted[(size_t)put[(size_t)(hi_s - k.cs)]++] = k;
-            for (int32_t b = 0; b < span; ++b)
-                if (at[(size_t)b + 1] - at[(size_t)b] > 1)
-                    std::sort(sorted.begin() + at[(size_t)b], sorted.begin() + at[(size_t)b + 1], key_less);
+            Key *const sp = sorted.data();
+            const int64_t *const atp = at.data();
+            auto sort_buckets = [sp, atp](int32_t b0, int32_t b1) {
+                for (int32_t b = b0; b < b1; ++b)
+                    if (atp[b + 1] - atp[b] > 1) std::sort(sp + atp[b], sp + atp[b + 1], key_less);
+            };
+            if (threads > 1 && n >= kThreadedRows) {
+                // (one table for ONE motif -- GRAFIMO's loop makes a call per motif, grafimo.py:177-183 --: the buckets and, below,
+                //  the rows of the output dealt to a few of the library's host threads; the caller's thread local vectors are
+                //  read through plain pointers there)
+                std::atomic<int32_t> next{0};
+                const int32_t step = std::max<int32_t>(16, span / (8 * threads));
+                const bool helped = gfm_workers::run_if_idle(threads, [&] {
+                    for (;;) {
+                        const int32_t b0 = next.fetch_add(step, std::memory_order_relaxed);
+                        if (b0 >= span) break;
+                        sort_buckets(b0, std::min(span, b0 + step));
+                    }
+                });
+                if (!helped) sort_buckets(0, span);        // (the threads are busy with somebody else's work: alone, then)
+            } else {
+                sort_buckets(0, span);
+            }
             keys.swap(sorted);
         }
         int64_t out = 0;
@@ -135,32 +157,53 @@ int hit_columns(const double *h_ptable, int32_t table_len, int32_t scale, double
                 top = std::max<int64_t>(top, (region_base ? region_base[keys[(size_t)i].part] : 0) + keys[(size_t)i].rec->region + 1);
             seen.assign((size_t)top, 0);
         }
-        for (int64_t j = 0; j < n; ++j) {
-            const Key &k = keys[(size_t)j];
-            const gfm_graph_hit_t &r = *k.rec;
-            const int64_t region = (region_base ? region_base[k.part] : 0) + r.region;
-            if (first_only) {
-                if (seen[(size_t)region]) continue;
-                seen[(size_t)region] = 1;
+        const Key *const kp = keys.data();
+        uint8_t *const seen_p = seen.data();
+        // rows [j0, j1) of the report order; without GFM_HITS_FIRST_PER_REGION row j is output row j
+        auto emit = [=](int64_t j0, int64_t j1, int64_t out) -> int64_t {
+            for (int64_t j = j0; j < j1; ++j) {
+                const Key &k = kp[j];
+                const gfm_graph_hit_t &r = *k.rec;
+                const int64_t region = (region_base ? region_base[k.part] : 0) + r.region;
+                if (first_only) {
+                    if (seen_p[region]) continue;
+                    seen_p[region] = 1;
+                }
+                if (o_start) o_start[out] = r.start;
+                if (o_stop) o_stop[out] = r.stop;
+                if (o_freq) o_freq[out] = r.freq;
+                if (o_region) o_region[out] = region;
+                // score_sequences.py:393 (the same expression as gfm_motif_annotate)
+                if (o_score) o_score[out] = ((double)r.score / (double)scale) + ((double)width * offset);
+                if (o_pvalue) o_pvalue[out] = h_ptable[r.score];
+                if (o_qvalue) o_qvalue[out] = r.qvalue;
+                if (o_strand) o_strand[out] = r.strand == '-' ? 1 : 0;
+                // vg flags a walk over a deletion `ref`; GRAFIMO repairs that on ingest (score_sequences.py:305-307)
+                const int64_t span = r.stop > r.start ? r.stop - r.start : r.start - r.stop;
+                if (o_ref) o_ref[out] = (r.is_ref != 0 && span == width) ? 1 : 0;
+                if (o_kmers) {
+                    uint8_t *d = o_kmers + out * (int64_t)(width + 1);
+                    std::memcpy(d, r.kmer, (size_t)width);
+                    d[width] = '\n';
+                }
+                ++out;
             }
-            if (o_start) o_start[out] = r.start;
-            if (o_stop) o_stop[out] = r.stop;
-            if (o_freq) o_freq[out] = r.freq;
-            if (o_region) o_region[out] = region;
-            // score_sequences.py:393 (the same expression as gfm_motif_annotate)
-            if (o_score) o_score[out] = ((double)r.score / (double)scale) + ((double)width * offset);
-            if (o_pvalue) o_pvalue[out] = h_ptable[r.score];
-            if (o_qvalue) o_qvalue[out] = r.qvalue;
-            if (o_strand) o_strand[out] = r.strand == '-' ? 1 : 0;
-            // vg flags a walk over a deletion `ref`; GRAFIMO repairs that on ingest (score_sequences.py:305-307)
-            const int64_t span = r.stop > r.start ? r.stop - r.start : r.start - r.stop;
-            if (o_ref) o_ref[out] = (r.is_ref != 0 && span == width) ? 1 : 0;
-            if (o_kmers) {
-                uint8_t *d = o_kmers + out * (int64_t)(width + 1);
-                std::memcpy(d, r.kmer, (size_t)width);
-                d[width] = '\n';
-            }
-            ++out;
+            return out;
+        };
+        if (threads > 1 && n >= kThreadedRows && !first_only) {
+            std::atomic<int64_t> next{0};
+            const int64_t step = std::max<int64_t>(512, n / (4 * threads));
+            const bool helped = gfm_workers::run_if_idle(threads, [&] {
+                for (;;) {
+                    const int64_t j0 = next.fetch_add(step, std::memory_order_relaxed);
+                    if (j0 >= n) break;
+                    emit(j0, std::min(n, j0 + step), j0);
+                }
+            });
+            if (!helped) emit(0, n, 0);
+            out = n;
+        } else {
+            out = emit(0, n, 0);
         }
         *n_out = out;
         return GFM_OK;
@@ -178,8 +221,11 @@ GFM_API int gfm_graph_hit_columns(const double *h_ptable, int32_t table_len, int
                                   int64_t *o_region, double *o_score, double *o_pvalue, double *o_qvalue, uint8_t *o_strand,
                                   uint8_t *o_ref, uint8_t *o_kmers)
 {
+    // (this thread's caller waits for the table: a few of the library's host threads help with a large one; the jobs of
+    //  gfm_graph_hit_columns_start run on those threads themselves, one table each)
+    const int threads = (int)std::min(4u, std::max(2u, std::thread::hardware_concurrency()) / 2);
     return hit_columns(h_ptable, table_len, scale, offset, width, n_parts, h_recs, n_recs, h_entry_of, region_base, flags, n_out,
-                       o_start, o_stop, o_freq, o_region, o_score, o_pvalue, o_qvalue, o_strand, o_ref, o_kmers);
+                       o_start, o_stop, o_freq, o_region, o_score, o_pvalue, o_qvalue, o_strand, o_ref, o_kmers, threads);
 }
 
 // The tables of a motif SET: one job per motif, taken by the library's kept host threads while the caller goes on -- in
@@ -218,7 +264,7 @@ GFM_API int gfm_graph_hit_columns_start(gfm_hit_columns_job_t *jobs, int32_t n_j
             gfm_hit_columns_job_t &j = r->jobs[i];
             j.status = hit_columns(j.h_ptable, j.table_len, j.scale, j.offset, j.width, j.n_parts, j.h_recs, j.n_recs, j.h_entry_of,
                                    j.region_base, j.flags, &j.n_out, j.o_start, j.o_stop, j.o_freq, j.o_region, j.o_score,
-                                   j.o_pvalue, j.o_qvalue, j.o_strand, j.o_ref, j.o_kmers);
+                                   j.o_pvalue, j.o_qvalue, j.o_strand, j.o_ref, j.o_kmers, 1);
             if (j.status != GFM_OK) {      // the message sits in THIS thread's slot: carry it to the one that waits
                 std::lock_guard<std::mutex> lk(r->mu);
                 if (r->rc == GFM_OK) {

@@ -74,7 +74,7 @@ int main(int argc, char **argv)
             c.region_base.push_back(0);
             for (int q = 0; q < c.n_parts; ++q) {
                 const int n_regions = 1 + (int)below(300);
-                const int n = below(5) ? (int)below(3000) : 0;
+                const int n = below(5) ? (int)below(round % 3 == 2 ? 12000 : 3000) : 0;      // (>= 4 096 rows: the synchronous call uses threads)
                 std::vector<gfm_graph_hit_t> v((size_t)n);
                 for (gfm_graph_hit_t &r : v) {
                     std::memset(&r, 0, sizeof r);
@@ -139,6 +139,18 @@ int main(int argc, char **argv)
         for (int i = 0; i < 500; ++i) { s[(size_t)i] = below(1ull << 40); e[(size_t)i] = s[(size_t)i] + 200; }
         std::vector<char> buf((size_t)gfm_region_labels("chr22", s.data(), e.data(), 500, nullptr, 0));
         if (gfm_region_labels("chr22", s.data(), e.data(), 500, buf.data(), (int64_t)buf.size()) <= 0) return 1;
+        // ... and a table of its own, synchronously, while the library's threads are busy with the jobs: large ones find no
+        // help (gfm_workers::run_if_idle) and are built by this thread alone -- the same table
+        for (int i = 0; i < n_jobs && i < 3; ++i) {
+            Case &c = cases[(size_t)i];
+            Cols again;
+            again.room(c.total, c.W);
+            const int rc2 = gfm_graph_hit_columns(c.ptable.data(), c.L, 37, -12.0, c.W, c.n_parts, c.rec_p.data(), c.n_recs.data(), c.eo_p.data(),
+                                                  c.region_base.data(), c.flags, &again.n, again.start.data(), again.stop.data(), again.freq.data(),
+                                                  again.region.data(), again.score.data(), again.pvalue.data(), again.qvalue.data(),
+                                                  again.strand.data(), again.ref.data(), again.kmers.data());
+            if (rc2 != want_rc[(size_t)i] || (rc2 == GFM_OK && !again.same(want[(size_t)i], c.W))) { std::printf("MISMATCH: synchronous table %d beside the run\n", i); return 1; }
+        }
         const int rc = gfm_graph_hit_columns_wait(run);
         int first_bad = GFM_OK;
         for (int i = 0; i < n_jobs; ++i) {

@@ -83,6 +83,31 @@ def test_hit_columns_equal_the_numpy_steps(W, n_parts, dup, recomb, first):
         assert len(np.unique(got["region"])) == len(got["region"])
 
 
+@pytest.mark.parametrize("recomb,first", [(True, False), (False, False), (False, True)])
+def test_a_large_table_is_built_by_several_threads_and_is_the_same_table(recomb, first):
+    """A single table of >= 4 096 rows: gfm_graph_hit_columns deals its bucket sorts and its output rows to a few of the
+    library's host threads (not with GFM_HITS_FIRST_PER_REGION, whose rows depend on the rows before them) -- the numpy steps'
+    table, row for row; 30 000 and 4 096 + a few records, scores with ties and without."""
+    rng = np.random.default_rng(17 + 2 * recomb + first)
+    for n, dup in ((30_000, True), (4_300, False), (30_000, False)):
+        W = 19
+        L = 1000 * W + 1
+        pmf = rng.random(L)
+        ptable = np.minimum.accumulate(np.cumsum(pmf[::-1])[::-1] / pmf.sum())
+        ptable[L // 2 + 10:L // 2 + 20] = ptable[L // 2 + 10]
+        n_regions = [700, 900]
+        parts = [_records(rng, n, W, n_regions[0], n_win=40_000, dup_scores=dup), _records(rng, n // 3, W, n_regions[1], n_win=40_000, dup_scores=dup)]
+        parts[0]["keep"] = 1                                                  # (>= 4 096 rows stay whatever the filters drop)
+        parts[0]["freq"] = np.maximum(parts[0]["freq"], 1)
+        entry_of = [np.sort(rng.integers(10 * p, 10 * p + 3, nr)).astype(np.int64) for p, nr in enumerate(n_regions)]
+        region_base = np.cumsum([0] + n_regions).astype(np.int64)
+        got = xr._hit_columns(ptable, 37, -12.0, W, entry_of, region_base, parts, recomb, first)
+        want = _reference_columns(ptable, 37, -12.0, W, parts, entry_of, region_base, recomb, first)
+        assert first or len(got["start"]) >= 4096
+        for k in want:
+            assert got[k].dtype == want[k].dtype and np.array_equal(got[k], want[k]), (k, n, dup)
+
+
 def test_hit_columns_arguments_and_empty_input():
     pt = np.ones(19001)
     c = xr._hit_columns(pt, 62, -14.0, 19, [np.zeros(0, np.int64)], np.zeros(2, np.int64), [np.empty(0, xr.HIT_DTYPE)], True, False)
