@@ -501,7 +501,8 @@ int gfm_graph_annotate(gfm_graph_t g, const void *d_hits, const uint64_t *d_hit_
  *   outputs (caller-allocated for sum(n_recs) rows, any may be NULL): start, stop, haplotype_frequency, region,
  *     score = log-odds (score_sequences.py:393), p-value, q-value, strand (0 '+', 1 '-'), reference (1 = "ref": vg's
  *     flag AND |stop - start| == width, score_sequences.py:305-307), o_kmers [rows][width + 1] the k-mer and a '\n'
- *     (one decode + split makes the matched_sequence strings).  *n_out = rows written. */
+ *     (one decode + split makes the matched_sequence strings).  *n_out = rows written.
+ *   A table of 4 096 rows or more is built with the help of up to four of the library's kept host threads when they are idle. */
 #define GFM_HITS_DROP_ZERO_FREQ 1u
 #define GFM_HITS_FIRST_PER_REGION 2u
 int gfm_graph_hit_columns(const double *h_ptable, int32_t table_len, int32_t scale, double offset, int32_t width,
