@@ -8,6 +8,8 @@
 
 namespace gfm_workers {
 
+bool run_if_idle(int n, const std::function<void()> &fn);
+
 // One use of the crew: start() hands fn to n workers and returns; wait() (also run by the destructor) returns when
 // all n calls of fn have returned.  fn must not throw.  If the crew is busy with another Run (a concurrent call from
 // another host thread) or cannot grow, plain threads are started for this Run instead.
@@ -18,10 +20,11 @@ public:
     Run &operator=(const Run &) = delete;
     ~Run() { wait(); }
     void start(int n, std::function<void()> fn);
-    bool start_(int n, std::function<void()> fn, bool only_crew);   // start(); only_crew: false, nothing started, when the crew cannot take it
     void wait();
 
 private:
+    friend bool run_if_idle(int n, const std::function<void()> &fn);
+    bool start_(int n, std::function<void()> fn, bool only_crew);   // start(); only_crew: false, nothing started, when the crew cannot take it
     struct Impl;
     Impl *impl_ = nullptr;
 };
