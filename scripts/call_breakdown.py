@@ -37,6 +37,11 @@ timed(xr.DeviceGraph, "fused_zero", "DeviceGraph.fused_zero")
 timed(xr.DeviceMotif, "qvalue_table", "DeviceMotif.qvalue_table")
 
 ctcf = bench.load_ctcf()
+if "--full-motif" in sys.argv:        # a Motif that carries its score distribution (pval_matrix), as GRAFIMO's own always does
+    from grafimo_amd.motif_ops import build_motif_meme
+    with contextlib.redirect_stdout(io.StringIO()):
+        ctcf = build_motif_meme(os.path.join(bench.ROOT, "tests", "golden", "ref_data", "MA0139.1.meme"), "unfrm_dst", 0.1, False, 1, False, True)[0]
+    assert getattr(ctcf, "pval_matrix", None) is not None
 idx, regions = synth.make_graph_index(10_000, 19)
 tmp = tempfile.mkdtemp(prefix="gfm_brk_")
 idx.save(os.path.join(tmp, "chr22"))
