@@ -1733,7 +1733,7 @@ def _frame_from_final_columns(data: Dict[str, np.ndarray]) -> pd.DataFrame:
     arrays = list(data.values())
     n = len(arrays[0]) if arrays and type(arrays[0]) is np.ndarray else 0
     final = bool(arrays) and all(type(a) is np.ndarray and a.ndim == 1 and len(a) == n for a in arrays)
-    if final and _FAST_FRAME is not False:
+    if final and (_FAST_FRAME is True or (_FAST_FRAME is None and n > 0)):      # (the comparison wants a table with rows in it)
         try:
             from pandas.core.internals.managers import create_block_manager_from_column_arrays
             mgr = create_block_manager_from_column_arrays(arrays, [pd.Index(list(data)), pd.RangeIndex(n)], consolidate=False,
